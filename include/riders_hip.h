@@ -1,0 +1,156 @@
+/*
+ * riders_hip.h -- C ABI of libriders_hip.so, the MI355X (gfx950) kernel library behind the RIDERS
+ * RC-Net / Scale-Map-Learner training hot path.
+ *
+ * The reference (MMOCKING/RIDERS) has no FFI layer: its seam is torch.nn.Module and every device op is
+ * a stock ATen/cuDNN/torchvision call.  Each entry below replaces the ATen dispatch at the cited
+ * reference call site (paths relative to the reference root).  INTEGRATION.md shows the ctypes binding
+ * a reference maintainer would add.
+ *
+ * Conventions
+ *   - all pointers are DEVICE pointers owned by the caller (PyTorch allocates every tensor, saved-for-
+ *     backward buffer and workspace); the library keeps no device memory between calls;
+ *   - every entry is an asynchronous enqueue on `stream` (a hipStream_t passed as void*);
+ *   - activations are NHWC ("channels_last"), dtype RD_F32 or RD_BF16; parameters, gradients of
+ *     parameters, statistics and losses are always fp32 in the reference's layouts (OIHW, [out,in]);
+ *   - return value: 0 = ok, negative = argument error (message via rd_last_error_string()),
+ *     positive = hipError_t from the launch.  No C++ exception crosses the boundary.
+ */
+#ifndef RIDERS_HIP_H
+#define RIDERS_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RD_F32 0
+#define RD_BF16 1
+
+#define RD_ACT_NONE 0
+#define RD_ACT_RELU 1
+#define RD_ACT_LRELU 2 /* utils/net_utils.py:15  LeakyReLU(0.20) */
+#define RD_ACT_RELU6 3
+
+int rd_version(void);
+const char* rd_last_error_string(void);
+
+/* ---- convolution family -------------------------------------------------------------------------
+ * One descriptor serves forward, data-gradient and weight-gradient.  The logical conv input is the
+ * channel concatenation [src1 (C1 ch) | src2 (C2 ch)] of spatial size Hin x Win; with `upsample` set
+ * src1/src2 are physically H1 x W1 and read through F.interpolate(mode='nearest') index arithmetic.
+ * replaces: utils/net_utils.py:84-91 (Conv2d), :195-198 (UpConv2d), :564-569 (DecoderBlock concat),
+ *           RCNet/linear_attention.py:121-131 (nn.Linear as 1x1), modules/midas/blocks.py:28-39,83-88,147,185-191 */
+typedef struct rd_conv_desc {
+  int32_t dtype;               /* RD_F32 / RD_BF16 activations                                        */
+  int32_t N, Hin, Win;         /* logical input size                                                  */
+  int32_t C1, C2;              /* channels of src1 / src2 (C2 = 0: single source)                     */
+  int32_t upsample, H1, W1;    /* nearest-upsample the sources from H1 x W1 to Hin x Win              */
+  int32_t Cout, KH, KW, stride, pad;
+  int32_t in_dilate;           /* 1 for forward; s for the data-gradient of a stride-s convolution    */
+  int32_t OH, OW;              /* output spatial size                                                 */
+  int32_t act; float slope;    /* epilogue activation for convs without BatchNorm                     */
+  int32_t D1;                  /* output channels [0,D1) -> dst1, [D1,Cout) -> dst2 (D1 = Cout: one)  */
+} rd_conv_desc;
+
+/* elements (of the activation dtype) in a packed weight buffer for `rows` x (KH*KW*C) */
+int64_t rd_conv_packed_elems(int32_t rows, int32_t K, int32_t dtype);
+/* OIHW fp32 -> packed; mode 0: forward operand, mode 1: data-gradient operand (transposed + flipped) */
+int rd_conv_pack_weights(const float* w_oihw, void* packed, int32_t Cout, int32_t Cin, int32_t KH, int32_t KW,
+                         int32_t mode, int32_t dtype, void* stream);
+/* rows of the per-block BatchNorm statistics buffer stats[rows][Cout][2] written by rd_conv_fwd */
+int32_t rd_conv_stats_rows(const rd_conv_desc* d);
+int rd_conv_fwd(const rd_conv_desc* d, const void* src1, const void* src2, const void* w_packed, const float* bias,
+                void* dst1, void* dst2, float* stats, void* stream);
+/* fp32 workspace bytes needed by rd_conv_wgrad */
+int64_t rd_conv_wgrad_workspace_bytes(const rd_conv_desc* d);
+/* dw (OIHW fp32) = or += dY^T * gather(X); deterministic two-stage reduction */
+int rd_conv_wgrad(const rd_conv_desc* d, const void* src1, const void* src2, const void* dy, float* workspace,
+                  float* dw_oihw, int32_t accumulate, void* stream);
+
+/* ---- BatchNorm2d (+ activation, + residual) -- utils/net_utils.py:86-91, :309-323 ----------------- */
+int rd_bn_finalize(const float* stats, int32_t rows, int32_t C, double count, const float* gamma, const float* beta,
+                   float eps, float momentum, int32_t training, float* running_mean, float* running_var,
+                   float* save_mean, float* save_rstd, float* scale, float* shift, void* stream);
+/* out = act(scale[c]*y + shift[c] + residual); scale/shift/residual may be NULL */
+int rd_affine_act(const void* y, const float* scale, const float* shift, const void* residual, void* out, int64_t pixels,
+                  int32_t C, int32_t act, float slope, int32_t dtype, void* stream);
+int32_t rd_bn_bwd_rows(int64_t pixels, int32_t C);
+/* full BN(+act) backward: dy = dBN(dz * act'(z)); dres (optional) = dz * act'(z); dgamma/dbeta fp32 */
+int rd_bn_act_bwd(const void* dz, const void* z, const void* y, const float* save_mean, const float* save_rstd,
+                  const float* scale, float* partial /* [rows][C][2] */, float* coef /* [2][C] */, float* dgamma,
+                  float* dbeta, int32_t accumulate, void* dy, void* dres, int64_t pixels, int32_t C, int32_t act,
+                  float slope, int32_t dtype, void* stream);
+int rd_act_bwd(const void* dz, const void* z, void* dx, int64_t n, int32_t act, float slope, int32_t dtype, void* stream);
+/* bias gradient: out[c] (+)= sum over rows of x[rows][C] */
+int32_t rd_colsum_rows(int64_t rows, int32_t C);
+int rd_colsum(const void* x, float* partial, float* out, int32_t accumulate, int64_t rows, int32_t C, int32_t dtype,
+              void* stream);
+
+/* ---- LayerNorm -- RCNet/linear_attention.py:106-107,125,131-133 (norm1/norm2, x + message) -------- */
+int rd_layernorm_fwd(const void* x, const float* gamma, const float* beta, const void* residual, void* out,
+                     float* save_mean, float* save_rstd, int64_t rows, int32_t C, float eps, int32_t dtype, void* stream);
+int32_t rd_layernorm_bwd_rows(int64_t rows);
+int rd_layernorm_bwd(const void* dout, const void* x, const float* gamma, const float* save_mean, const float* save_rstd,
+                     void* dx, float* partial, float* dgamma, float* dbeta, int32_t accumulate, int64_t rows, int32_t C,
+                     int32_t dtype, void* stream);
+
+/* ---- linear attention -- RCNet/linear_attention.py:18-45 ------------------------------------------
+ * q [N*L][ldq], k/v [N*S][ldk/ldv], out [N*L][ldo]; head h uses columns h*16 .. h*16+15 (D = 16), L,S <= 32 */
+int rd_linear_attention_fwd(const void* q, const void* k, const void* v, void* out, int32_t N, int32_t L, int32_t S,
+                            int32_t H, int32_t ldq, int32_t ldk, int32_t ldv, int32_t ldo, float eps, int32_t dtype,
+                            void* stream);
+int rd_linear_attention_bwd(const void* q, const void* k, const void* v, const void* dout, void* dq, void* dk, void* dv,
+                            int32_t N, int32_t L, int32_t S, int32_t H, int32_t ldq, int32_t ldk, int32_t ldv,
+                            int32_t ldo, float eps, int32_t dtype, void* stream);
+
+/* ---- pooling -- RCNet/networks.py:73-76 (MaxPool2d) and :418-433 (torchvision.ops.roi_pool) -------- */
+int rd_maxpool_fwd(const void* x, void* out, uint8_t* argmax, int32_t N, int32_t H, int32_t W, int32_t C, int32_t OH,
+                   int32_t OW, int32_t k, int32_t s, int32_t p, int32_t dtype, void* stream);
+int rd_maxpool_bwd(const void* dout, const uint8_t* argmax, void* dx, int32_t N, int32_t H, int32_t W, int32_t C,
+                   int32_t OH, int32_t OW, int32_t k, int32_t s, int32_t p, int32_t dtype, void* stream);
+/* rois [R][5] fp32 = (batch index, x1, y1, x2, y2); out [R][PH][PW][C]; argmax int32 = h*W + w or -1 */
+int rd_roi_pool_fwd(const void* x, const float* rois, void* out, int32_t* argmax, int32_t R, int32_t N, int32_t H,
+                    int32_t W, int32_t C, int32_t PH, int32_t PW, float spatial_scale, int32_t dtype, void* stream);
+/* dx_f32 [N][H][W][C] fp32 is zeroed then scatter-added */
+int rd_roi_pool_bwd(const void* dout, const float* rois, const int32_t* argmax, float* dx_f32, int32_t R, int32_t N,
+                    int32_t H, int32_t W, int32_t C, int32_t PH, int32_t PW, int32_t dtype, void* stream);
+
+/* ---- layout / resampling helpers ------------------------------------------------------------------------- */
+int rd_cast(const void* src, void* dst, int64_t n, int32_t src_dtype, int32_t dst_dtype, float scale, void* stream);
+int rd_add(const void* a, const void* b, void* out, int64_t n, int32_t dtype, void* stream);
+int rd_nchw_to_nhwc(const void* src, void* dst, int32_t N, int32_t C, int32_t H, int32_t W, int32_t src_dtype,
+                    int32_t dst_dtype, float scale, void* stream);
+int rd_nhwc_to_nchw(const void* src, void* dst, int32_t N, int32_t C, int32_t H, int32_t W, int32_t src_dtype,
+                    int32_t dst_dtype, void* stream);
+int rd_transpose_last2(const void* src, void* dst, int64_t B, int32_t R, int32_t Ccols, int32_t dtype, void* stream);
+int rd_concat2(const void* a, const void* b, void* out, int64_t rows, int32_t Ca, int32_t Cb, int32_t dtype, void* stream);
+int rd_split2(const void* in, void* a, void* b, int64_t rows, int32_t Ca, int32_t Cb, int32_t dtype, void* stream);
+/* utils/net_utils.py:196 F.interpolate(nearest): standalone forward and its backward (sum over replicas) */
+int rd_upsample_nearest_fwd(const void* x, void* y, int32_t N, int32_t Hs, int32_t Ws, int32_t Hv, int32_t Wv, int32_t C,
+                            int32_t dtype, void* stream);
+int rd_upsample_nearest_bwd(const void* dy, void* dx, int32_t N, int32_t Hs, int32_t Ws, int32_t Hv, int32_t Wv, int32_t C,
+                            int32_t dtype, void* stream);
+
+/* ---- RC-Net labels / loss / inference scatter ---------------------------------------------------------- */
+/* RCNet/rcnet_main.py:308-332 */
+int rd_rcnet_labels(const float* gt, const float* points /* [R][3] */, float* label, float* valid, int32_t R, int32_t HW,
+                    float max_distance, int32_t all_valid, void* stream);
+/* RCNet/rcnet_model.py:152-160; sums[2] = (sum valid*bce, sum valid) is saved for the backward */
+int32_t rd_bce_rows(int64_t n);
+int rd_bce_masked_fwd(const void* logits, const float* label, const float* valid, float pos_weight, float* partial,
+                      float* loss, float* sums, int64_t n, int32_t dtype, void* stream);
+int rd_bce_masked_bwd(const void* logits, const float* label, const float* valid, float pos_weight, const float* sums,
+                      const float* dloss, void* dlogits, int64_t n, int32_t dtype, void* stream);
+int rd_sigmoid(const void* x, void* y, int64_t n, int32_t dtype, void* stream);
+/* RCNet/rcnet_main.py:460-485 (forward_output) */
+int rd_scatter_crops(const void* crops, const float* points, float* depth, float* response, int32_t Ncrop, int32_t PH,
+                     int32_t PW, int32_t H, int32_t W, float response_thr, int32_t dtype, void* stream);
+
+/* ---- optimizer -- RCNet/rcnet_main.py:233-238,357-359; train_zju.py:205-211,390-392 ------------------------ */
+int rd_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
+                 float beta2, float eps, float weight_decay, int64_t step, float grad_scale, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RIDERS_HIP_H */

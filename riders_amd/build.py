@@ -1,0 +1,71 @@
+"""Build recipe for libriders_hip.so (hipcc, gfx950 only).
+
+`python -m riders_amd.build` compiles every translation unit under riders_amd/csrc for gfx950 and links
+riders_amd/libriders_hip.so in-tree (the .so travels to the GPU box with the repo snapshot).  hipcc
+cross-compiles without a GPU, so this also is the "does it build" check run by __graft_entry__.build().
+"""
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(HERE, "_obj")
+LIB = os.path.join(HERE, "libriders_hip.so")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wno-unused-result"]
+
+
+def sources():
+    return sorted(f for f in os.listdir(CSRC) if f.endswith(".hip") or f.endswith(".cpp"))
+
+
+def _newer(a, b):
+    return (not os.path.exists(b)) or os.path.getmtime(a) > os.path.getmtime(b)
+
+
+def _headers_mtime():
+    hs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
+    hs.append(os.path.join(HERE, "..", "include", "riders_hip.h"))
+    return max(os.path.getmtime(h) for h in hs)
+
+
+def build(force=False, verbose=True):
+    os.makedirs(OBJ, exist_ok=True)
+    hm = _headers_mtime()
+    jobs = []
+    for f in sources():
+        src = os.path.join(CSRC, f)
+        obj = os.path.join(OBJ, f + ".o")
+        if force or _newer(src, obj) or hm > os.path.getmtime(obj):
+            jobs.append((src, obj))
+
+    def cc(job):
+        src, obj = job
+        cmd = [HIPCC, "-x", "hip"] + FLAGS + ["-c", src, "-o", obj]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        return job, r
+
+    if jobs:
+        with ThreadPoolExecutor(max_workers=min(6, len(jobs))) as ex:
+            for (src, obj), r in ex.map(cc, jobs):
+                if verbose:
+                    print("[hipcc] %s" % os.path.basename(src), flush=True)
+                if r.returncode != 0:
+                    sys.stderr.write(r.stdout + r.stderr)
+                    raise RuntimeError("hipcc failed on %s" % src)
+    objs = [os.path.join(OBJ, f + ".o") for f in sources()]
+    if jobs or not os.path.exists(LIB):
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            sys.stderr.write(r.stdout + r.stderr)
+            raise RuntimeError("link failed")
+        if verbose:
+            print("[link] %s" % LIB, flush=True)
+    return LIB
+
+
+if __name__ == "__main__":
+    build(force="--force" in sys.argv)

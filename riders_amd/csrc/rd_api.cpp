@@ -1,0 +1,296 @@
+// extern "C" surface of libriders_hip.so (see include/riders_hip.h).  Argument validation + launch only.
+#include "../../include/riders_hip.h"
+#include "rd_kernels.h"
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+namespace {
+thread_local char g_err[512] = "";
+int fail(const char* fmt, ...) {
+  va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof(g_err), fmt, ap); va_end(ap);
+  return -1;
+}
+int done(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e)); return (int)e; }
+  return 0;
+}
+inline hipStream_t S(void* s) { return (hipStream_t)s; }
+inline bool dt_ok(int d) { return d == RD_F32 || d == RD_BF16; }
+
+int check_desc(const rd_conv_desc* d) {
+  if (!d) return fail("conv: null descriptor");
+  if (!dt_ok(d->dtype)) return fail("conv: bad dtype %d", d->dtype);
+  if (d->N <= 0 || d->Hin <= 0 || d->Win <= 0 || d->C1 <= 0 || d->C2 < 0 || d->Cout <= 0) return fail("conv: bad sizes");
+  if (d->KH <= 0 || d->KW <= 0 || d->stride <= 0 || d->pad < 0 || d->in_dilate <= 0) return fail("conv: bad kernel geometry");
+  if (d->OH <= 0 || d->OW <= 0) return fail("conv: bad output size");
+  if (d->upsample && (d->H1 <= 0 || d->W1 <= 0)) return fail("conv: upsample needs H1/W1");
+  if (d->D1 <= 0 || d->D1 > d->Cout) return fail("conv: bad D1");
+  if ((int64_t)d->N * d->OH * d->OW >= (int64_t)1 << 31) return fail("conv: too many output pixels");
+  return 0;
+}
+void fill_args(const rd_conv_desc* d, rd::ConvArgs& a) {
+  memset(&a, 0, sizeof(a));
+  a.N = d->N; a.Hin = d->Hin; a.Win = d->Win; a.C1 = d->C1; a.C2 = d->C2;
+  a.ups = d->upsample ? 1 : 0;
+  a.H1 = a.ups ? d->H1 : d->Hin; a.W1 = a.ups ? d->W1 : d->Win;
+  a.Cout = d->Cout; a.KH = d->KH; a.KW = d->KW; a.stride = d->stride; a.pad = d->pad; a.dil = d->in_dilate;
+  a.OH = d->OH; a.OW = d->OW; a.act = d->act; a.slope = d->slope; a.D1 = d->D1;
+  // ATen nearest: scale = (float)in / out
+  a.scale_h = (float)a.H1 / (float)d->Hin; a.scale_w = (float)a.W1 / (float)d->Win;
+  a.M = d->N * d->OH * d->OW;
+  a.K = d->KH * d->KW * (d->C1 + d->C2);
+  a.Kpad = rd::conv_kpad(a.K, d->dtype);
+}
+}  // namespace
+
+extern "C" {
+
+int rd_version(void) { return 100; }
+const char* rd_last_error_string(void) { return g_err; }
+
+int64_t rd_conv_packed_elems(int32_t rows, int32_t K, int32_t dtype) {
+  return (int64_t)rd::conv_rows_pad(rows) * rd::conv_kpad(K, dtype);
+}
+int rd_conv_pack_weights(const float* w, void* packed, int32_t Cout, int32_t Cin, int32_t KH, int32_t KW, int32_t mode,
+                         int32_t dtype, void* stream) {
+  if (!w || !packed) return fail("pack_weights: null pointer");
+  if (!dt_ok(dtype) || (mode != 0 && mode != 1)) return fail("pack_weights: bad dtype/mode");
+  rd::launch_pack_weights(w, packed, Cout, Cin, KH, KW, mode, dtype, S(stream));
+  return done("rd_conv_pack_weights");
+}
+int32_t rd_conv_stats_rows(const rd_conv_desc* d) { return (int32_t)(((int64_t)d->N * d->OH * d->OW + 127) / 128); }
+
+int rd_conv_fwd(const rd_conv_desc* d, const void* src1, const void* src2, const void* w_packed, const float* bias, void* dst1,
+                void* dst2, float* stats, void* stream) {
+  if (int e = check_desc(d)) return e;
+  if (!src1 || !w_packed || !dst1) return fail("conv_fwd: null pointer");
+  if (d->C2 > 0 && !src2) return fail("conv_fwd: C2 > 0 but src2 is null");
+  if (d->D1 < d->Cout && !dst2) return fail("conv_fwd: D1 < Cout but dst2 is null");
+  rd::ConvArgs a; fill_args(d, a);
+  a.src1 = src1; a.src2 = src2; a.w = w_packed; a.bias = bias; a.dst1 = dst1; a.dst2 = dst2; a.stats = stats;
+  rd::launch_conv(a, d->dtype, S(stream));
+  return done("rd_conv_fwd");
+}
+int64_t rd_conv_wgrad_workspace_bytes(const rd_conv_desc* d) {
+  int M = d->N * d->OH * d->OW, K = d->KH * d->KW * (d->C1 + d->C2);
+  int ns = rd::wgrad_nsplit(M, K, d->Cout);
+  return (int64_t)(ns + 1) * d->Cout * K * (int64_t)sizeof(float);
+}
+int rd_conv_wgrad(const rd_conv_desc* d, const void* src1, const void* src2, const void* dy, float* workspace, float* dw,
+                  int32_t accumulate, void* stream) {
+  if (int e = check_desc(d)) return e;
+  if (!src1 || !dy || !workspace || !dw) return fail("conv_wgrad: null pointer");
+  if (d->in_dilate != 1) return fail("conv_wgrad: in_dilate must be 1");
+  rd::WgradArgs a; memset(&a, 0, sizeof(a));
+  a.src1 = src1; a.src2 = src2; a.dy = dy; a.slab = workspace;
+  a.N = d->N; a.Hin = d->Hin; a.Win = d->Win; a.C1 = d->C1; a.C2 = d->C2;
+  a.ups = d->upsample ? 1 : 0; a.H1 = a.ups ? d->H1 : d->Hin; a.W1 = a.ups ? d->W1 : d->Win;
+  a.Cout = d->Cout; a.KH = d->KH; a.KW = d->KW; a.stride = d->stride; a.pad = d->pad; a.OH = d->OH; a.OW = d->OW;
+  a.scale_h = (float)a.H1 / (float)d->Hin; a.scale_w = (float)a.W1 / (float)d->Win;
+  a.M = d->N * d->OH * d->OW; a.K = d->KH * d->KW * (d->C1 + d->C2);
+  rd::launch_wgrad(a, d->dtype, dw, accumulate, S(stream));
+  return done("rd_conv_wgrad");
+}
+
+int rd_bn_finalize(const float* stats, int32_t rows, int32_t C, double count, const float* gamma, const float* beta, float eps,
+                   float momentum, int32_t training, float* running_mean, float* running_var, float* save_mean,
+                   float* save_rstd, float* scale, float* shift, void* stream) {
+  if (!scale || !shift) return fail("bn_finalize: null scale/shift");
+  if (training && !stats) return fail("bn_finalize: training needs stats");
+  if (!training && (!running_mean || !running_var)) return fail("bn_finalize: eval needs running stats");
+  rd::launch_bn_finalize(stats, rows, C, count, gamma, beta, eps, momentum, training, running_mean, running_var, save_mean,
+                         save_rstd, scale, shift, S(stream));
+  return done("rd_bn_finalize");
+}
+int rd_affine_act(const void* y, const float* scale, const float* shift, const void* residual, void* out, int64_t pixels,
+                  int32_t C, int32_t act, float slope, int32_t dtype, void* stream) {
+  if (!y || !out || !dt_ok(dtype)) return fail("affine_act: bad args");
+  if (pixels * C == 0) return 0;
+  rd::launch_affine_act(y, scale, shift, residual, out, pixels, C, act, slope, dtype, S(stream));
+  return done("rd_affine_act");
+}
+int32_t rd_bn_bwd_rows(int64_t pixels, int32_t C) { return rd::bn_bwd_rows(pixels, C); }
+int rd_bn_act_bwd(const void* dz, const void* z, const void* y, const float* mean, const float* rstd, const float* scale,
+                  float* partial, float* coef, float* dgamma, float* dbeta, int32_t accumulate, void* dy, void* dres,
+                  int64_t pixels, int32_t C, int32_t act, float slope, int32_t dtype, void* stream) {
+  if (!dz || !y || !mean || !rstd || !scale || !partial || !coef || !dy || !dt_ok(dtype)) return fail("bn_act_bwd: bad args");
+  if (act != RD_ACT_NONE && !z) return fail("bn_act_bwd: activation backward needs z");
+  int rows = rd::bn_bwd_rows(pixels, C);
+  rd::launch_bn_bwd_reduce(dz, z, y, mean, rstd, partial, pixels, C, act, slope, dtype, S(stream));
+  rd::launch_bn_bwd_finalize(partial, rows, C, (double)pixels, dgamma, dbeta, accumulate, coef, coef + C, S(stream));
+  rd::launch_bn_bwd_apply(dz, z, y, mean, rstd, scale, coef, coef + C, dy, dres, pixels, C, act, slope, dtype, S(stream));
+  return done("rd_bn_act_bwd");
+}
+int rd_act_bwd(const void* dz, const void* z, void* dx, int64_t n, int32_t act, float slope, int32_t dtype, void* stream) {
+  if (!dz || !z || !dx || !dt_ok(dtype)) return fail("act_bwd: bad args");
+  if (n == 0) return 0;
+  rd::launch_act_bwd(dz, z, dx, n, act, slope, dtype, S(stream));
+  return done("rd_act_bwd");
+}
+int32_t rd_colsum_rows(int64_t rows, int32_t C) { return rd::colsum_rows(rows, C); }
+int rd_colsum(const void* x, float* partial, float* out, int32_t accumulate, int64_t rows, int32_t C, int32_t dtype, void* stream) {
+  if (!x || !partial || !out || !dt_ok(dtype)) return fail("colsum: bad args");
+  rd::launch_colsum(x, partial, out, accumulate, rows, C, dtype, S(stream));
+  return done("rd_colsum");
+}
+
+int rd_layernorm_fwd(const void* x, const float* gamma, const float* beta, const void* residual, void* out, float* mean,
+                     float* rstd, int64_t rows, int32_t C, float eps, int32_t dtype, void* stream) {
+  if (!x || !gamma || !beta || !out || !mean || !rstd || !dt_ok(dtype)) return fail("layernorm_fwd: bad args");
+  if (C % 64 || C > 512) return fail("layernorm: C must be a multiple of 64 and <= 512 (got %d)", C);
+  if (rows == 0) return 0;
+  rd::launch_layernorm_fwd(x, gamma, beta, residual, out, mean, rstd, rows, C, eps, dtype, S(stream));
+  return done("rd_layernorm_fwd");
+}
+int32_t rd_layernorm_bwd_rows(int64_t rows) { return rd::layernorm_bwd_rows(rows); }
+int rd_layernorm_bwd(const void* dout, const void* x, const float* gamma, const float* mean, const float* rstd, void* dx,
+                     float* partial, float* dgamma, float* dbeta, int32_t accumulate, int64_t rows, int32_t C, int32_t dtype,
+                     void* stream) {
+  if (!dout || !x || !gamma || !mean || !rstd || !dx || !partial || !dt_ok(dtype)) return fail("layernorm_bwd: bad args");
+  if (C % 64 || C > 512) return fail("layernorm: C must be a multiple of 64 and <= 512 (got %d)", C);
+  rd::launch_layernorm_bwd(dout, x, gamma, mean, rstd, dx, partial, dgamma, dbeta, accumulate, rows, C, dtype, S(stream));
+  return done("rd_layernorm_bwd");
+}
+
+int rd_linear_attention_fwd(const void* q, const void* k, const void* v, void* out, int32_t N, int32_t L, int32_t Sx, int32_t H,
+                            int32_t ldq, int32_t ldk, int32_t ldv, int32_t ldo, float eps, int32_t dtype, void* stream) {
+  if (!q || !k || !v || !out || !dt_ok(dtype)) return fail("linear_attention_fwd: bad args");
+  if (L <= 0 || Sx <= 0 || L > 32 || Sx > 32) return fail("linear_attention: L,S must be in 1..32 (got %d,%d)", L, Sx);
+  rd::launch_linear_attention_fwd(q, k, v, out, N, L, Sx, H, ldq, ldk, ldv, ldo, eps, dtype, S(stream));
+  return done("rd_linear_attention_fwd");
+}
+int rd_linear_attention_bwd(const void* q, const void* k, const void* v, const void* dout, void* dq, void* dk, void* dv,
+                            int32_t N, int32_t L, int32_t Sx, int32_t H, int32_t ldq, int32_t ldk, int32_t ldv, int32_t ldo,
+                            float eps, int32_t dtype, void* stream) {
+  if (!q || !k || !v || !dout || !dq || !dk || !dv || !dt_ok(dtype)) return fail("linear_attention_bwd: bad args");
+  if (L <= 0 || Sx <= 0 || L > 32 || Sx > 32) return fail("linear_attention: L,S must be in 1..32 (got %d,%d)", L, Sx);
+  rd::launch_linear_attention_bwd(q, k, v, dout, dq, dk, dv, N, L, Sx, H, ldq, ldk, ldv, ldo, eps, dtype, S(stream));
+  return done("rd_linear_attention_bwd");
+}
+
+int rd_maxpool_fwd(const void* x, void* out, uint8_t* arg, int32_t N, int32_t H, int32_t W, int32_t C, int32_t OH, int32_t OW,
+                   int32_t k, int32_t s, int32_t p, int32_t dtype, void* stream) {
+  if (!x || !out || !arg || !dt_ok(dtype) || k * k > 255) return fail("maxpool_fwd: bad args");
+  rd::launch_maxpool_fwd(x, out, arg, N, H, W, C, OH, OW, k, s, p, dtype, S(stream));
+  return done("rd_maxpool_fwd");
+}
+int rd_maxpool_bwd(const void* dout, const uint8_t* arg, void* dx, int32_t N, int32_t H, int32_t W, int32_t C, int32_t OH,
+                   int32_t OW, int32_t k, int32_t s, int32_t p, int32_t dtype, void* stream) {
+  if (!dout || !dx || !arg || !dt_ok(dtype)) return fail("maxpool_bwd: bad args");
+  rd::launch_maxpool_bwd(dout, arg, dx, N, H, W, C, OH, OW, k, s, p, dtype, S(stream));
+  return done("rd_maxpool_bwd");
+}
+int rd_roi_pool_fwd(const void* x, const float* rois, void* out, int32_t* argmax, int32_t R, int32_t N, int32_t H, int32_t W,
+                    int32_t C, int32_t PH, int32_t PW, float scale, int32_t dtype, void* stream) {
+  if (R == 0) return 0;
+  if (!x || !rois || !out || !argmax || !dt_ok(dtype)) return fail("roi_pool_fwd: bad args");
+  rd::launch_roi_pool_fwd(x, rois, out, argmax, R, N, H, W, C, PH, PW, scale, dtype, S(stream));
+  return done("rd_roi_pool_fwd");
+}
+int rd_roi_pool_bwd(const void* dout, const float* rois, const int32_t* argmax, float* dx, int32_t R, int32_t N, int32_t H,
+                    int32_t W, int32_t C, int32_t PH, int32_t PW, int32_t dtype, void* stream) {
+  if (!dx || !dt_ok(dtype)) return fail("roi_pool_bwd: bad args");
+  if (R > 0 && (!dout || !rois || !argmax)) return fail("roi_pool_bwd: null pointer");
+  rd::launch_roi_pool_bwd(dout, rois, argmax, dx, R, N, H, W, C, PH, PW, dtype, S(stream));
+  return done("rd_roi_pool_bwd");
+}
+
+int rd_cast(const void* src, void* dst, int64_t n, int32_t sd, int32_t dd, float scale, void* stream) {
+  if (!src || !dst || !dt_ok(sd) || !dt_ok(dd)) return fail("cast: bad args");
+  if (n == 0) return 0;
+  rd::launch_cast(src, dst, n, sd, dd, scale, S(stream));
+  return done("rd_cast");
+}
+int rd_add(const void* a, const void* b, void* out, int64_t n, int32_t dtype, void* stream) {
+  if (!a || !b || !out || !dt_ok(dtype)) return fail("add: bad args");
+  if (n == 0) return 0;
+  rd::launch_add(a, b, out, n, dtype, S(stream));
+  return done("rd_add");
+}
+int rd_nchw_to_nhwc(const void* src, void* dst, int32_t N, int32_t C, int32_t H, int32_t W, int32_t sd, int32_t dd, float scale,
+                    void* stream) {
+  if (!src || !dst || !dt_ok(sd) || !dt_ok(dd)) return fail("nchw_to_nhwc: bad args");
+  rd::launch_nchw_to_nhwc(src, dst, N, C, H, W, sd, dd, scale, S(stream));
+  return done("rd_nchw_to_nhwc");
+}
+int rd_nhwc_to_nchw(const void* src, void* dst, int32_t N, int32_t C, int32_t H, int32_t W, int32_t sd, int32_t dd, void* stream) {
+  if (!src || !dst || !dt_ok(sd) || !dt_ok(dd)) return fail("nhwc_to_nchw: bad args");
+  rd::launch_nhwc_to_nchw(src, dst, N, C, H, W, sd, dd, S(stream));
+  return done("rd_nhwc_to_nchw");
+}
+int rd_transpose_last2(const void* src, void* dst, int64_t B, int32_t R, int32_t Cc, int32_t dtype, void* stream) {
+  if (!src || !dst || !dt_ok(dtype)) return fail("transpose_last2: bad args");
+  rd::launch_transpose_last2(src, dst, B, R, Cc, dtype, S(stream));
+  return done("rd_transpose_last2");
+}
+int rd_concat2(const void* a, const void* b, void* out, int64_t rows, int32_t Ca, int32_t Cb, int32_t dtype, void* stream) {
+  if (!a || !b || !out || !dt_ok(dtype)) return fail("concat2: bad args");
+  rd::launch_concat2(a, b, out, rows, Ca, Cb, dtype, S(stream));
+  return done("rd_concat2");
+}
+int rd_split2(const void* in, void* a, void* b, int64_t rows, int32_t Ca, int32_t Cb, int32_t dtype, void* stream) {
+  if (!a || !b || !in || !dt_ok(dtype)) return fail("split2: bad args");
+  rd::launch_split2(in, a, b, rows, Ca, Cb, dtype, S(stream));
+  return done("rd_split2");
+}
+int rd_upsample_nearest_fwd(const void* x, void* y, int32_t N, int32_t Hs, int32_t Ws, int32_t Hv, int32_t Wv, int32_t C,
+                            int32_t dtype, void* stream) {
+  if (!x || !y || !dt_ok(dtype)) return fail("upsample_nearest_fwd: bad args");
+  rd::launch_upsample_nearest_fwd(x, y, N, Hs, Ws, Hv, Wv, C, dtype, S(stream));
+  return done("rd_upsample_nearest_fwd");
+}
+int rd_upsample_nearest_bwd(const void* dy, void* dx, int32_t N, int32_t Hs, int32_t Ws, int32_t Hv, int32_t Wv, int32_t C,
+                            int32_t dtype, void* stream) {
+  if (!dy || !dx || !dt_ok(dtype)) return fail("upsample_nearest_bwd: bad args");
+  rd::launch_upsample_nearest_bwd(dy, dx, N, Hs, Ws, Hv, Wv, C, dtype, S(stream));
+  return done("rd_upsample_nearest_bwd");
+}
+
+int rd_rcnet_labels(const float* gt, const float* points, float* label, float* valid, int32_t R, int32_t HW, float thr,
+                    int32_t all_valid, void* stream) {
+  if (!gt || !points || !label || !valid) return fail("rcnet_labels: null pointer");
+  rd::launch_rcnet_labels(gt, points, label, valid, R, HW, thr, all_valid, S(stream));
+  return done("rd_rcnet_labels");
+}
+int32_t rd_bce_rows(int64_t n) { return rd::bce_rows(n); }
+int rd_bce_masked_fwd(const void* logits, const float* label, const float* valid, float pw, float* partial, float* loss,
+                      float* sums, int64_t n, int32_t dtype, void* stream) {
+  if (!logits || !label || !valid || !partial || !loss || !sums || !dt_ok(dtype)) return fail("bce_fwd: bad args");
+  rd::launch_bce_fwd(logits, label, valid, pw, partial, loss, sums, n, dtype, S(stream));
+  return done("rd_bce_masked_fwd");
+}
+int rd_bce_masked_bwd(const void* logits, const float* label, const float* valid, float pw, const float* sums, const float* dloss,
+                      void* dlogits, int64_t n, int32_t dtype, void* stream) {
+  if (!logits || !label || !valid || !sums || !dloss || !dlogits || !dt_ok(dtype)) return fail("bce_bwd: bad args");
+  rd::launch_bce_bwd(logits, label, valid, pw, sums, dloss, dlogits, n, dtype, S(stream));
+  return done("rd_bce_masked_bwd");
+}
+int rd_sigmoid(const void* x, void* y, int64_t n, int32_t dtype, void* stream) {
+  if (!x || !y || !dt_ok(dtype)) return fail("sigmoid: bad args");
+  if (n == 0) return 0;
+  rd::launch_sigmoid(x, y, n, dtype, S(stream));
+  return done("rd_sigmoid");
+}
+int rd_scatter_crops(const void* crops, const float* points, float* depth, float* response, int32_t Ncrop, int32_t PH, int32_t PW,
+                     int32_t H, int32_t W, float thr, int32_t dtype, void* stream) {
+  if (!depth || !response || !dt_ok(dtype)) return fail("scatter_crops: bad args");
+  if (Ncrop > 0 && (!crops || !points)) return fail("scatter_crops: null pointer");
+  if ((PH & 1) || (PW & 1)) return fail("scatter_crops: patch size must be even (reference uses patch//2 on both sides)");
+  rd::launch_scatter_crops(crops, points, depth, response, Ncrop, PH, PW, H, W, thr, dtype, S(stream));
+  return done("rd_scatter_crops");
+}
+
+int rd_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2, float eps, float wd,
+                 int64_t step, float gscale, void* stream) {
+  if (!p || !g || !m || !v) return fail("adam: null pointer");
+  if (step < 1) return fail("adam: step must be >= 1");
+  if (n == 0) return 0;
+  double bc1 = 1.0 - pow((double)b1, (double)step), bc2 = 1.0 - pow((double)b2, (double)step);
+  rd::launch_adam(p, g, m, v, n, lr, b1, b2, eps, wd, (float)bc1, (float)sqrt(bc2), gscale, S(stream));
+  return done("rd_adam_step");
+}
+
+}  // extern "C"

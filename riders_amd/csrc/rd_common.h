@@ -1,0 +1,115 @@
+// Shared device-side helpers for the riders_amd HIP kernels (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace rd {
+
+// ---- element types -------------------------------------------------------------------------
+// Activations are stored either as fp32 or as bf16 (raw uint16 bit patterns); every kernel
+// computes in fp32.  dtype codes match RD_F32 / RD_BF16 in include/riders_hip.h.
+struct bf16_t { unsigned short v; };
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ float bf16_to_f32(unsigned short h) {
+  return __uint_as_float(((unsigned)h) << 16);
+}
+// round-to-nearest-even, NaN preserved
+__device__ __forceinline__ unsigned short f32_to_bf16(float f) {
+  unsigned u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (unsigned short)(u >> 16);
+}
+
+template <typename T> struct Elem;
+template <> struct Elem<float> {
+  static constexpr int VE = 4;  // elements per 16-byte vector
+  static __device__ __forceinline__ float ld(const float* p) { return *p; }
+  static __device__ __forceinline__ void st(float* p, float v) { *p = v; }
+  static __device__ __forceinline__ float rnd(float v) { return v; }
+};
+template <> struct Elem<bf16_t> {
+  static constexpr int VE = 8;
+  static __device__ __forceinline__ float ld(const bf16_t* p) { return bf16_to_f32(p->v); }
+  static __device__ __forceinline__ void st(bf16_t* p, float v) { p->v = f32_to_bf16(v); }
+  static __device__ __forceinline__ float rnd(float v) { return bf16_to_f32(f32_to_bf16(v)); }
+};
+
+// 4 consecutive elements <-> 4 floats (16 B for f32, 8 B for bf16)
+__device__ __forceinline__ void ld4(const float* p, float (&o)[4]) {
+  float4 v = *reinterpret_cast<const float4*>(p);
+  o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+}
+__device__ __forceinline__ void ld4(const bf16_t* p, float (&o)[4]) {
+  uint2 v = *reinterpret_cast<const uint2*>(p);
+  o[0] = __uint_as_float(v.x << 16); o[1] = __uint_as_float(v.x & 0xffff0000u);
+  o[2] = __uint_as_float(v.y << 16); o[3] = __uint_as_float(v.y & 0xffff0000u);
+}
+__device__ __forceinline__ void st4(float* p, const float (&o)[4]) {
+  *reinterpret_cast<float4*>(p) = make_float4(o[0], o[1], o[2], o[3]);
+}
+__device__ __forceinline__ void st4(bf16_t* p, const float (&o)[4]) {
+  uint2 v;
+  v.x = (unsigned)f32_to_bf16(o[0]) | ((unsigned)f32_to_bf16(o[1]) << 16);
+  v.y = (unsigned)f32_to_bf16(o[2]) | ((unsigned)f32_to_bf16(o[3]) << 16);
+  *reinterpret_cast<uint2*>(p) = v;
+}
+
+// ---- MFMA ------------------------------------------------------------------------------------
+// D = A*B + C on one 64-lane wave; lane l supplies A[i=l&15][k-group l>>4] and B[k-group l>>4][j=l&15],
+// and holds D[row=(l>>4)*4+r][col=l&15] in register r (cdna_hip_programming.md section 3).
+__device__ __forceinline__ f32x4 mfma_16x16x4_f32(float a, float b, f32x4 c) {
+#ifdef RD_EMU
+  return emu_mfma_f32_16x16x4f32(a, b, c);
+#else
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+#endif
+}
+__device__ __forceinline__ f32x4 mfma_16x16x32_bf16(s16x8 a, s16x8 b, f32x4 c) {
+#ifdef RD_EMU
+  return emu_mfma_f32_16x16x32_bf16(a, b, c);
+#else
+  return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+#endif
+}
+
+// ---- wave / block reductions ---------------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+__device__ __forceinline__ float wave_min(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o));
+  return v;
+}
+
+// activation codes (RD_ACT_* in include/riders_hip.h)
+enum { ACT_NONE = 0, ACT_RELU = 1, ACT_LRELU = 2, ACT_RELU6 = 3 };
+
+__device__ __forceinline__ float act_fwd(float x, int act, float slope) {
+  if (act == ACT_RELU) return x > 0.f ? x : 0.f;
+  if (act == ACT_LRELU) return x > 0.f ? x : x * slope;
+  if (act == ACT_RELU6) return fminf(fmaxf(x, 0.f), 6.f);
+  return x;
+}
+// derivative expressed through the activation OUTPUT z (valid for slope > 0 / relu / relu6)
+__device__ __forceinline__ float act_grad_from_out(float z, int act, float slope) {
+  if (act == ACT_RELU) return z > 0.f ? 1.f : 0.f;
+  if (act == ACT_LRELU) return z > 0.f ? 1.f : slope;
+  if (act == ACT_RELU6) return (z > 0.f && z < 6.f) ? 1.f : 0.f;
+  return 1.f;
+}
+
+__host__ __device__ __forceinline__ int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+}  // namespace rd

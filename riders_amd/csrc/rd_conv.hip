@@ -1,0 +1,482 @@
+// Implicit-GEMM convolution family for gfx950 (MFMA 16x16 tiles, LDS-staged, NHWC activations).
+//
+// Replaces the cuDNN/ATen convolutions dispatched by the reference at
+//   utils/net_utils.py:84-91   (Conv2d.forward: conv -> BN -> act)
+//   utils/net_utils.py:195-198 (UpConv2d: nearest interpolate -> conv; the upsample is folded
+//                               into this kernel's gather, never materialised)
+//   utils/net_utils.py:564-569 (DecoderBlock: cat([deconv, skip]) -> conv; the concat is folded
+//                               into the gather as a second source tensor)
+//   RCNet/linear_attention.py:121-131 (nn.Linear projections = 1x1 convolutions over tokens)
+//   modules/midas/blocks.py (all dense convs of the Scale Map Learner)
+//
+// One kernel serves forward and data-gradient:
+//   forward : out[m, co] = sum_{kh,kw,ci} X[n, oh*s-p+kh, ow*s-p+kw, ci] * W[co, kh, kw, ci]
+//   dgrad   : the same gather over dY with stride 1, pad' = K-1-p, the input viewed as zero-dilated
+//             by s (in_dilate) and the weights packed flipped/transposed by rd_conv_pack_weights.
+// The weight-gradient kernel reduces over pixels into per-split slabs that a second kernel sums in
+// a fixed order (deterministic), writing the reference's OIHW fp32 layout directly.
+//
+// GEMM view: rows = output pixels (block tile 128), cols = output channels (block tile BN),
+// K = KH*KW*Cin walked in 128-byte stages (32 fp32 / 64 bf16 per row).  MFMA operand roles are
+// swapped (A = weights, B = pixels) so each lane ends up holding 4 consecutive output channels of
+// one pixel -> one 16-byte (fp32) / 8-byte (bf16) NHWC store per lane per tile.
+#include "rd_common.h"
+#include "rd_kernels.h"
+
+namespace rd {
+
+static constexpr int BM = 128;          // pixels per block tile
+static constexpr int STAGE_BYTES = 128; // K bytes per row per stage
+
+// LDS byte offset of 16-byte slot `slot` (0..7) of tile row `row`; XOR swizzle keeps the
+// ds_read_b128 fragment reads (16 rows x 4 k-groups per wave) bank-conflict free.
+__device__ __forceinline__ int lds_slot(int row, int slot) { return row * 8 + (slot ^ ((row >> 1) & 7)); }
+
+template <typename T>
+__device__ __forceinline__ bool conv_src_ptr(const ConvArgs& a, int n, int ih, int iw, int ci, const T*& p) {
+  if (a.dil > 1) {
+    if (ih < 0 || iw < 0) return false;
+    if ((ih % a.dil) | (iw % a.dil)) return false;
+    ih /= a.dil; iw /= a.dil;
+  }
+  if ((unsigned)ih >= (unsigned)a.Hin || (unsigned)iw >= (unsigned)a.Win) return false;
+  int hs = ih, ws = iw, Hp = a.Hin, Wp = a.Win;
+  if (a.ups) {  // F.interpolate(mode='nearest') source index, ATen float formula
+    hs = min((int)floorf((float)ih * a.scale_h), a.H1 - 1);
+    ws = min((int)floorf((float)iw * a.scale_w), a.W1 - 1);
+    Hp = a.H1; Wp = a.W1;
+  }
+  if (ci < a.C1) p = (const T*)a.src1 + ((((int64_t)n * Hp + hs) * Wp + ws) * a.C1 + ci);
+  else p = (const T*)a.src2 + ((((int64_t)n * Hp + hs) * Wp + ws) * a.C2 + (ci - a.C1));
+  return true;
+}
+
+template <typename T, int BN, bool VEC>
+__global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs a) {
+  constexpr int VE = Elem<T>::VE;
+  constexpr int BKE = STAGE_BYTES / (int)sizeof(T);  // K elements per stage
+  constexpr int CT = BN / 16;                        // cout tiles per wave
+  constexpr int BITER = (BN * 8 + 255) / 256;        // weight-tile vec loads per thread
+  __shared__ uint4 sA[2][BM * 8];
+  __shared__ uint4 sB[2][BN * 8];
+
+  const int t = threadIdx.x;
+  const int lane = t & 63, wv = t >> 6;
+  const int m0 = blockIdx.x * BM;
+  const int n0 = blockIdx.y * BN;
+  const int Cin = a.C1 + a.C2;
+
+  // ---- per-thread staging state: slot s of rows r0+32*i --------------------------------------
+  const int s = t & 7, r0 = t >> 3;
+  int rn[4], rih[4], riw[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    int m = m0 + r0 + 32 * i;
+    if (m < a.M) {
+      int ow = m % a.OW; int q = m / a.OW; int oh = q % a.OH; rn[i] = q / a.OH;
+      rih[i] = oh * a.stride - a.pad; riw[i] = ow * a.stride - a.pad;
+    } else { rn[i] = -1; rih[i] = 0; riw[i] = 0; }
+  }
+  // k-state of this thread's vector (VEC path): k = kt*BKE + s*VE
+  int kci = 0, kkw = 0, kkh = 0;
+  if (VEC) {
+    int k = s * VE; int tap = k / Cin; kci = k - tap * Cin; kkh = tap / a.KW; kkw = tap - kkh * a.KW;
+  }
+
+  uint4 ra[4]; uint4 rb[BITER];
+
+  auto load_tile = [&](int kt) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (rn[i] >= 0) {
+        if (VEC) {
+          const T* p;
+          if (kkh < a.KH && conv_src_ptr<T>(a, rn[i], rih[i] + kkh, riw[i] + kkw, kci, p))
+            v = *reinterpret_cast<const uint4*>(p);
+        } else {
+          T tmp[VE];
+#pragma unroll
+          for (int e = 0; e < VE; e++) {
+            int k = kt * BKE + s * VE + e;
+            float f = 0.f;
+            if (k < a.K) {
+              int tap = k / Cin; int ci = k - tap * Cin; int kh = tap / a.KW; int kw = tap - kh * a.KW;
+              const T* p;
+              if (conv_src_ptr<T>(a, rn[i], rih[i] + kh, riw[i] + kw, ci, p)) f = Elem<T>::ld(p);
+            }
+            Elem<T>::st(&tmp[e], f);
+          }
+          v = *reinterpret_cast<uint4*>(tmp);
+        }
+      }
+      ra[i] = v;
+    }
+    const uint4* wp = reinterpret_cast<const uint4*>(a.w);
+    const int kslots = a.Kpad / VE;  // 16-byte slots per packed weight row
+#pragma unroll
+    for (int i = 0; i < BITER; i++) {
+      int idx = t + 256 * i;
+      if (idx < BN * 8) {
+        int row = idx >> 3, sl = idx & 7;
+        rb[i] = wp[(int64_t)(n0 + row) * kslots + kt * 8 + sl];
+      }
+    }
+    if (VEC) {  // advance this thread's k-state by one stage
+      kci += BKE;
+      while (kci >= Cin) { kci -= Cin; if (++kkw == a.KW) { kkw = 0; ++kkh; } }
+    }
+  };
+  auto store_tile = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) sA[buf][lds_slot(r0 + 32 * i, s)] = ra[i];
+#pragma unroll
+    for (int i = 0; i < BITER; i++) {
+      int idx = t + 256 * i;
+      if (idx < BN * 8) sB[buf][lds_slot(idx >> 3, idx & 7)] = rb[i];
+    }
+  };
+
+  f32x4 acc[CT][2];
+#pragma unroll
+  for (int c = 0; c < CT; c++) { acc[c][0] = f32x4{0, 0, 0, 0}; acc[c][1] = f32x4{0, 0, 0, 0}; }
+
+  const int nk = a.Kpad / BKE;
+  load_tile(0);
+  store_tile(0);
+  __syncthreads();
+  const int fr = lane & 15, fg = lane >> 4;
+  for (int kt = 0; kt < nk; kt++) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) load_tile(kt + 1);
+#pragma unroll
+    for (int ch = 0; ch < 2; ch++) {  // two 64-byte chunks per stage
+      uint4 pf[2];
+#pragma unroll
+      for (int pt = 0; pt < 2; pt++) pf[pt] = sA[buf][lds_slot(wv * 32 + pt * 16 + fr, ch * 4 + fg)];
+#pragma unroll
+      for (int c = 0; c < CT; c++) {
+        uint4 wf = sB[buf][lds_slot(c * 16 + fr, ch * 4 + fg)];
+#pragma unroll
+        for (int pt = 0; pt < 2; pt++) {
+          if (sizeof(T) == 4) {
+            acc[c][pt] = mfma_16x16x4_f32(__uint_as_float(wf.x), __uint_as_float(pf[pt].x), acc[c][pt]);
+            acc[c][pt] = mfma_16x16x4_f32(__uint_as_float(wf.y), __uint_as_float(pf[pt].y), acc[c][pt]);
+            acc[c][pt] = mfma_16x16x4_f32(__uint_as_float(wf.z), __uint_as_float(pf[pt].z), acc[c][pt]);
+            acc[c][pt] = mfma_16x16x4_f32(__uint_as_float(wf.w), __uint_as_float(pf[pt].w), acc[c][pt]);
+          } else {
+            s16x8 wa, pb;
+            __builtin_memcpy(&wa, &wf, 16);
+            __builtin_memcpy(&pb, &pf[pt], 16);
+            acc[c][pt] = mfma_16x16x32_bf16(wa, pb, acc[c][pt]);
+          }
+        }
+      }
+    }
+    if (kt + 1 < nk) store_tile(buf ^ 1);
+    __syncthreads();
+  }
+
+  // ---- epilogue: bias, activation, NHWC store (dual destination), BN statistics ----------------
+  const int D2 = a.Cout - a.D1;
+  const bool vec_ok = ((a.D1 & 3) == 0) && ((D2 & 3) == 0);
+  float ssum[CT][4], ssq[CT][4];
+#pragma unroll
+  for (int c = 0; c < CT; c++)
+#pragma unroll
+    for (int r = 0; r < 4; r++) { ssum[c][r] = 0.f; ssq[c][r] = 0.f; }
+
+#pragma unroll
+  for (int pt = 0; pt < 2; pt++) {
+    const int m = m0 + wv * 32 + pt * 16 + fr;
+    const bool mv = m < a.M;
+#pragma unroll
+    for (int c = 0; c < CT; c++) {
+      const int co = n0 + c * 16 + fg * 4;
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        float x = acc[c][pt][r];
+        if (a.bias && co + r < a.Cout) x += a.bias[co + r];
+        x = act_fwd(x, a.act, a.slope);
+        x = Elem<T>::rnd(x);
+        v[r] = x;
+        if (mv) { ssum[c][r] += x; ssq[c][r] += x * x; }
+      }
+      if (mv && co < a.Cout) {
+        if (vec_ok && co + 3 < a.Cout) {
+          T* d = (co < a.D1) ? ((T*)a.dst1 + (int64_t)m * a.D1 + co) : ((T*)a.dst2 + (int64_t)m * D2 + (co - a.D1));
+          st4(d, v);
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; r++) {
+            int cc = co + r;
+            if (cc < a.Cout) {
+              T* d = (cc < a.D1) ? ((T*)a.dst1 + (int64_t)m * a.D1 + cc) : ((T*)a.dst2 + (int64_t)m * D2 + (cc - a.D1));
+              Elem<T>::st(d, v[r]);
+            }
+          }
+        }
+      }
+    }
+  }
+  if (a.stats) {  // per-block partial sum / sum-of-squares per output channel (deterministic order)
+    float* red = reinterpret_cast<float*>(&sA[0][0]);  // [4 waves][BN][2]
+#pragma unroll
+    for (int c = 0; c < CT; c++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        float s1 = ssum[c][r], s2 = ssq[c][r];
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+        if (fr == 0) {
+          int col = c * 16 + fg * 4 + r;
+          red[(wv * BN + col) * 2 + 0] = s1;
+          red[(wv * BN + col) * 2 + 1] = s2;
+        }
+      }
+    __syncthreads();
+    for (int col = t; col < BN; col += 256) {
+      int co = n0 + col;
+      if (co < a.Cout) {
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; w++) { s1 += red[(w * BN + col) * 2]; s2 += red[(w * BN + col) * 2 + 1]; }
+        a.stats[((int64_t)blockIdx.x * a.Cout + co) * 2 + 0] = s1;
+        a.stats[((int64_t)blockIdx.x * a.Cout + co) * 2 + 1] = s2;
+      }
+    }
+  }
+}
+
+// ---- weight packing -------------------------------------------------------------------------------
+// OIHW fp32 (the reference's parameter layout) -> [rows_pad][Kpad] of T with k = (kh*KW+kw)*C + c.
+// mode 0 (forward): rows = Cout, C = Cin.   mode 1 (dgrad): rows = Cin, C = Cout, taps flipped.
+template <typename T>
+__global__ void pack_weights_kernel(const float* __restrict__ w, T* __restrict__ out, int Cout, int Cin, int KH,
+                                    int KW, int mode, int rows_pad, int Kpad) {
+  int64_t total = (int64_t)rows_pad * Kpad;
+  int rows = mode ? Cin : Cout, C = mode ? Cout : Cin;
+  int K = KH * KW * C;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int row = (int)(i / Kpad), k = (int)(i - (int64_t)row * Kpad);
+    float v = 0.f;
+    if (row < rows && k < K) {
+      int tap = k / C, c = k - tap * C, kh = tap / KW, kw = tap - kh * KW;
+      if (mode == 0) v = w[(((int64_t)row * Cin + c) * KH + kh) * KW + kw];
+      else v = w[(((int64_t)c * Cin + row) * KH + (KH - 1 - kh)) * KW + (KW - 1 - kw)];
+    }
+    Elem<T>::st(&out[i], v);
+  }
+}
+
+// ---- weight gradient ----------------------------------------------------------------------------------
+// dW[co, k] = sum_m dY[m, co] * Xg[m, k]   (Xg = the same gathered/virtual input as the forward).
+// Block = (k-tile of 128, cout-tile of 128, pixel split).  Reduction runs over pixels in stages of 32;
+// both operands are converted to fp32 in LDS and fed to the exact-fp32 MFMA (v_mfma_f32_16x16x4_f32),
+// for which each lane supplies one scalar -> the pixel-major tiles need no transpose.
+__device__ __forceinline__ int wg_idx(int p, int col) { return p * 128 + (col ^ ((p & 1) << 4)); }
+
+template <typename T, bool VEC>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
+  constexpr int PK = 32;  // pixels per stage
+  __shared__ float sX[2][PK * 128];
+  __shared__ float sY[2][PK * 128];
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  const int kt0 = blockIdx.x * 128, c0 = blockIdx.y * 128;
+  const int Cin = a.C1 + a.C2;
+  const int mbeg = blockIdx.z * a.rows_per_split;
+  const int mend = min(a.M, mbeg + a.rows_per_split);
+
+  // staging role: column group cg (4 consecutive columns), pixel rows pr + 8*i (i<4)
+  const int cg = t & 31, pr = t >> 5;
+  // X columns = k indices kt0 + cg*4 .. +3 (fixed per thread for the whole pixel loop)
+  int xkh[4], xkw[4], xci[4]; bool xv[4];
+#pragma unroll
+  for (int e = 0; e < 4; e++) {
+    int k = kt0 + cg * 4 + e;
+    xv[e] = k < a.K;
+    int kk = xv[e] ? k : 0;
+    int tap = kk / Cin; xci[e] = kk - tap * Cin; xkh[e] = tap / a.KW; xkw[e] = tap - xkh[e] * a.KW;
+  }
+  ConvArgs g;  // reuse the forward gather
+  g.src1 = a.src1; g.src2 = a.src2; g.Hin = a.Hin; g.Win = a.Win; g.C1 = a.C1; g.C2 = a.C2; g.H1 = a.H1; g.W1 = a.W1;
+  g.dil = 1; g.ups = a.ups; g.scale_h = a.scale_h; g.scale_w = a.scale_w;
+
+  float rx[4][4], ry[4][4];
+  auto load_stage = [&](int mb) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      int m = mb + pr + 8 * i;
+#pragma unroll
+      for (int e = 0; e < 4; e++) { rx[i][e] = 0.f; ry[i][e] = 0.f; }
+      if (m < mend) {
+        int ow = m % a.OW; int q = m / a.OW; int oh = q % a.OH; int n = q / a.OH;
+        int ihb = oh * a.stride - a.pad, iwb = ow * a.stride - a.pad;
+        if (VEC) {
+          if (xv[0]) {
+            const T* p;
+            if (conv_src_ptr<T>(g, n, ihb + xkh[0], iwb + xkw[0], xci[0], p)) ld4(p, rx[i]);
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; e++) {
+            const T* p;
+            if (xv[e] && conv_src_ptr<T>(g, n, ihb + xkh[e], iwb + xkw[e], xci[e], p)) rx[i][e] = Elem<T>::ld(p);
+          }
+        }
+        int co = c0 + cg * 4;
+        const T* yp = (const T*)a.dy + (int64_t)m * a.Cout + co;
+        if ((a.Cout & 3) == 0 && co + 3 < a.Cout) ld4(yp, ry[i]);
+        else {
+#pragma unroll
+          for (int e = 0; e < 4; e++) if (co + e < a.Cout) ry[i][e] = Elem<T>::ld(yp + e);
+        }
+      }
+    }
+  };
+  auto store_stage = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      int p = pr + 8 * i;
+      *reinterpret_cast<float4*>(&sX[buf][wg_idx(p, cg * 4)]) = make_float4(rx[i][0], rx[i][1], rx[i][2], rx[i][3]);
+      *reinterpret_cast<float4*>(&sY[buf][wg_idx(p, cg * 4)]) = make_float4(ry[i][0], ry[i][1], ry[i][2], ry[i][3]);
+    }
+  };
+
+  // wave tile: cout rows (wv>>1)*64 .. +63, k cols (wv&1)*64 .. +63  -> 4x4 MFMA tiles
+  const int wr = (wv >> 1) * 64, wc = (wv & 1) * 64;
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+#pragma unroll
+    for (int j = 0; j < 4; j++) acc[i][j] = f32x4{0, 0, 0, 0};
+  const int fr = lane & 15, fg = lane >> 4;
+
+  int nst = (mend > mbeg) ? (mend - mbeg + PK - 1) / PK : 0;
+  if (nst > 0) {
+    load_stage(mbeg);
+    store_stage(0);
+  }
+  __syncthreads();
+  for (int st = 0; st < nst; st++) {
+    int buf = st & 1;
+    if (st + 1 < nst) load_stage(mbeg + (st + 1) * PK);
+#pragma unroll
+    for (int p4 = 0; p4 < PK / 4; p4++) {
+      int p = p4 * 4 + fg;
+      float ya[4], xb[4];
+#pragma unroll
+      for (int i = 0; i < 4; i++) ya[i] = sY[buf][wg_idx(p, wr + i * 16 + fr)];
+#pragma unroll
+      for (int j = 0; j < 4; j++) xb[j] = sX[buf][wg_idx(p, wc + j * 16 + fr)];
+#pragma unroll
+      for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[i][j] = mfma_16x16x4_f32(ya[i], xb[j], acc[i][j]);
+    }
+    if (st + 1 < nst) store_stage(buf ^ 1);
+    __syncthreads();
+  }
+  // slab[split][co][k]: lane holds rows (cout) fg*4+r, col (k) fr
+  float* slab = a.slab + (int64_t)blockIdx.z * a.Cout * a.K;
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      int k = kt0 + wc + j * 16 + fr;
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        int co = c0 + wr + i * 16 + fg * 4 + r;
+        if (co < a.Cout && k < a.K) slab[(int64_t)co * a.K + k] = acc[i][j][r];
+      }
+    }
+}
+
+// sum slabs in split order and write / accumulate the OIHW fp32 gradient
+__global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int Cout, int Cin, int KH,
+                                    int KW, int nsplit, int accumulate) {
+  int K = KH * KW * Cin;
+  int64_t total = (int64_t)Cout * K;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    float s = 0.f;
+    for (int sp = 0; sp < nsplit; sp++) s += slab[(int64_t)sp * total + i];
+    int co = (int)(i / K), k = (int)(i - (int64_t)co * K);
+    int tap = k / Cin, ci = k - tap * Cin, kh = tap / KW, kw = tap - kh * KW;
+    int64_t o = (((int64_t)co * Cin + ci) * KH + kh) * KW + kw;
+    dw[o] = accumulate ? dw[o] + s : s;
+  }
+}
+
+// ---- host-side launchers ------------------------------------------------------------------------------------
+static int pick_bn(int cout) {
+  if (cout <= 16) return 16;
+  if (cout <= 32) return 32;
+  if (cout <= 64) return 64;
+  return 128;
+}
+int conv_rows_pad(int rows) { int bn = pick_bn(rows); return (int)cdiv(rows, bn) * bn; }
+int conv_kpad(int K, int dtype) { int bke = dtype == 0 ? 32 : 64; return (int)cdiv(K, bke) * bke; }
+
+template <typename T>
+static void launch_conv_t(const ConvArgs& a, hipStream_t st) {
+  constexpr int VE = Elem<T>::VE;
+  const int Cin = a.C1 + a.C2;
+  const bool vec = (Cin % VE == 0) && (a.C1 % VE == 0);
+  const int bn = pick_bn(a.Cout);
+  dim3 grid((unsigned)cdiv(a.M, BM), (unsigned)cdiv(a.Cout, bn));
+#define RD_CONV_CASE(BNV)                                                                                  \
+  if (bn == BNV) {                                                                                         \
+    if (vec) hipLaunchKernelGGL((conv_gemm_kernel<T, BNV, true>), grid, dim3(256), 0, st, a);              \
+    else hipLaunchKernelGGL((conv_gemm_kernel<T, BNV, false>), grid, dim3(256), 0, st, a);                 \
+  }
+  RD_CONV_CASE(16) RD_CONV_CASE(32) RD_CONV_CASE(64) RD_CONV_CASE(128)
+#undef RD_CONV_CASE
+}
+
+void launch_conv(const ConvArgs& a, int dtype, hipStream_t st) {
+  if (dtype == 0) launch_conv_t<float>(a, st);
+  else launch_conv_t<bf16_t>(a, st);
+}
+
+void launch_pack_weights(const float* w, void* out, int Cout, int Cin, int KH, int KW, int mode, int dtype,
+                         hipStream_t st) {
+  int rows = mode ? Cin : Cout, C = mode ? Cout : Cin;
+  int rows_pad = conv_rows_pad(rows), Kpad = conv_kpad(KH * KW * C, dtype);
+  int64_t total = (int64_t)rows_pad * Kpad;
+  unsigned grid = (unsigned)std::min<int64_t>(cdiv(total, 256), 4096);
+  if (dtype == 0)
+    hipLaunchKernelGGL((pack_weights_kernel<float>), dim3(grid), dim3(256), 0, st, w, (float*)out, Cout, Cin, KH, KW, mode, rows_pad, Kpad);
+  else
+    hipLaunchKernelGGL((pack_weights_kernel<bf16_t>), dim3(grid), dim3(256), 0, st, w, (bf16_t*)out, Cout, Cin, KH, KW, mode, rows_pad, Kpad);
+}
+
+// split the pixel reduction so the launch has a few blocks per CU, stage-aligned
+int wgrad_nsplit(int M, int K, int Cout) {
+  int64_t tiles = cdiv(K, 128) * cdiv(Cout, 128);
+  int64_t want = cdiv(1024, tiles);
+  int64_t maxs = cdiv(M, 256);  // at least 256 pixels per split
+  int64_t s = std::max<int64_t>(1, std::min(want, maxs));
+  return (int)s;
+}
+
+void launch_wgrad(WgradArgs a, int dtype, float* dw, int accumulate, hipStream_t st) {
+  const int Cin = a.C1 + a.C2;
+  a.nsplit = wgrad_nsplit(a.M, a.K, a.Cout);
+  a.rows_per_split = (int)(cdiv(cdiv(a.M, a.nsplit), 32) * 32);
+  a.nsplit = (int)cdiv(a.M, a.rows_per_split);
+  dim3 grid((unsigned)cdiv(a.K, 128), (unsigned)cdiv(a.Cout, 128), (unsigned)a.nsplit);
+  bool vec = (Cin % 4 == 0) && (a.C1 % 4 == 0);
+  if (dtype == 0) {
+    if (vec) hipLaunchKernelGGL((conv_wgrad_kernel<float, true>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((conv_wgrad_kernel<float, false>), grid, dim3(256), 0, st, a);
+  } else {
+    if (vec) hipLaunchKernelGGL((conv_wgrad_kernel<bf16_t, true>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((conv_wgrad_kernel<bf16_t, false>), grid, dim3(256), 0, st, a);
+  }
+  int64_t total = (int64_t)a.Cout * a.K;
+  unsigned rg = (unsigned)std::min<int64_t>(cdiv(total, 256), 2048);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rg), dim3(256), 0, st, a.slab, dw, a.Cout, Cin, a.KH, a.KW, a.nsplit, accumulate);
+}
+
+}  // namespace rd

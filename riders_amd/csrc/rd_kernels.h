@@ -1,0 +1,100 @@
+// Internal launcher declarations shared by the kernel translation units and rd_api.cpp.
+// Nothing here is part of the public C ABI (that is include/riders_hip.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <algorithm>
+
+namespace rd {
+
+struct ConvArgs {
+  const void* src1; const void* src2; const void* w; const float* bias;
+  void* dst1; void* dst2; float* stats;
+  int N, Hin, Win, C1, C2, H1, W1, Cout, KH, KW, stride, pad, dil, OH, OW, act, D1;
+  float slope, scale_h, scale_w;
+  int M, K, Kpad, ups;
+};
+struct WgradArgs {
+  const void* src1; const void* src2; const void* dy; float* slab;
+  int N, Hin, Win, C1, C2, H1, W1, Cout, KH, KW, stride, pad, OH, OW;
+  float scale_h, scale_w;
+  int M, K, ups, nsplit, rows_per_split;
+};
+
+// rd_conv.hip
+int conv_rows_pad(int rows);
+int conv_kpad(int K, int dtype);
+int wgrad_nsplit(int M, int K, int Cout);
+void launch_conv(const ConvArgs& a, int dtype, hipStream_t st);
+void launch_pack_weights(const float* w, void* out, int Cout, int Cin, int KH, int KW, int mode, int dtype, hipStream_t st);
+void launch_wgrad(WgradArgs a, int dtype, float* dw, int accumulate, hipStream_t st);
+
+// rd_norm.hip
+void launch_bn_finalize(const float* partial, int rows, int C, double count, const float* gamma, const float* beta,
+                        float eps, float momentum, int training, float* running_mean, float* running_var,
+                        float* mean, float* rstd, float* scale, float* shift, hipStream_t st);
+void launch_affine_act(const void* y, const float* scale, const float* shift, const void* res, void* out, int64_t pixels,
+                       int C, int act, float slope, int dtype, hipStream_t st);
+int bn_bwd_rows(int64_t pixels, int C);
+void launch_bn_bwd_reduce(const void* dz, const void* z, const void* y, const float* mean, const float* rstd,
+                          float* partial, int64_t pixels, int C, int act, float slope, int dtype, hipStream_t st);
+void launch_bn_bwd_finalize(const float* partial, int rows, int C, double count, float* dgamma, float* dbeta,
+                            int accumulate, float* c1, float* c2, hipStream_t st);
+void launch_bn_bwd_apply(const void* dz, const void* z, const void* y, const float* mean, const float* rstd,
+                         const float* scale, const float* c1, const float* c2, void* dy, void* dres, int64_t pixels,
+                         int C, int act, float slope, int dtype, hipStream_t st);
+void launch_act_bwd(const void* dz, const void* z, void* dx, int64_t n, int act, float slope, int dtype, hipStream_t st);
+void launch_colsum(const void* x, float* partial, float* out, int accumulate, int64_t rows, int C, int dtype, hipStream_t st);
+int colsum_rows(int64_t rows, int C);
+void launch_layernorm_fwd(const void* x, const float* gamma, const float* beta, const void* res, void* out, float* mean,
+                          float* rstd, int64_t rows, int C, float eps, int dtype, hipStream_t st);
+int layernorm_bwd_rows(int64_t rows);
+void launch_layernorm_bwd(const void* dout, const void* x, const float* gamma, const float* mean, const float* rstd,
+                          void* dx, float* partial, float* dgamma, float* dbeta, int accumulate, int64_t rows, int C,
+                          int dtype, hipStream_t st);
+
+// rd_pool.hip
+void launch_maxpool_fwd(const void* x, void* out, unsigned char* arg, int N, int H, int W, int C, int OH, int OW, int k,
+                        int s, int p, int dtype, hipStream_t st);
+void launch_maxpool_bwd(const void* dout, const unsigned char* arg, void* dx, int N, int H, int W, int C, int OH, int OW,
+                        int k, int s, int p, int dtype, hipStream_t st);
+void launch_roi_pool_fwd(const void* x, const float* rois, void* out, int* argmax, int R, int N, int H, int W, int C,
+                         int PH, int PW, float scale, int dtype, hipStream_t st);
+void launch_roi_pool_bwd(const void* dout, const float* rois, const int* argmax, float* dx_f32, int R, int N, int H, int W,
+                         int C, int PH, int PW, int dtype, hipStream_t st);
+
+// rd_elementwise.hip
+void launch_cast(const void* src, void* dst, int64_t n, int src_dtype, int dst_dtype, float scale, hipStream_t st);
+void launch_add(const void* a, const void* b, void* out, int64_t n, int dtype, hipStream_t st);
+void launch_nchw_to_nhwc(const void* src, void* dst, int N, int C, int H, int W, int src_dtype, int dst_dtype, float scale, hipStream_t st);
+void launch_nhwc_to_nchw(const void* src, void* dst, int N, int C, int H, int W, int src_dtype, int dst_dtype, hipStream_t st);
+void launch_transpose_last2(const void* src, void* dst, int64_t B, int R, int Ccols, int dtype, hipStream_t st);
+void launch_concat2(const void* a, const void* b, void* out, int64_t rows, int Ca, int Cb, int dtype, hipStream_t st);
+void launch_split2(const void* in, void* a, void* b, int64_t rows, int Ca, int Cb, int dtype, hipStream_t st);
+void launch_upsample_nearest_bwd(const void* dy, void* dx, int N, int Hs, int Ws, int Hv, int Wv, int C, int dtype, hipStream_t st);
+void launch_upsample_nearest_fwd(const void* x, void* y, int N, int Hs, int Ws, int Hv, int Wv, int C, int dtype, hipStream_t st);
+
+// rd_attention.hip
+void launch_linear_attention_fwd(const void* q, const void* k, const void* v, void* out, int N, int L, int S, int H,
+                                 int ldq, int ldk, int ldv, int ldo, float eps, int dtype, hipStream_t st);
+void launch_linear_attention_bwd(const void* q, const void* k, const void* v, const void* dout, void* dq, void* dk,
+                                 void* dv, int N, int L, int S, int H, int ldq, int ldk, int ldv, int ldo, float eps,
+                                 int dtype, hipStream_t st);
+
+// rd_loss.hip
+void launch_rcnet_labels(const float* gt, const float* points, float* label, float* valid, int R, int HW, float thr,
+                         int all_valid, hipStream_t st);
+int bce_rows(int64_t n);
+void launch_bce_fwd(const void* logits, const float* label, const float* valid, float pos_weight, float* partial,
+                    float* loss, float* sums, int64_t n, int dtype, hipStream_t st);
+void launch_bce_bwd(const void* logits, const float* label, const float* valid, float pos_weight, const float* sums,
+                    const float* dloss, void* dlogits, int64_t n, int dtype, hipStream_t st);
+void launch_sigmoid(const void* x, void* y, int64_t n, int dtype, hipStream_t st);
+void launch_scatter_crops(const void* crops, const float* points, float* depth, float* response, int Ncrop, int PH, int PW,
+                          int H, int W, float thr, int dtype, hipStream_t st);
+
+// rd_optim.hip
+void launch_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2, float eps,
+                 float wd, float bc1, float bc2, float gscale, hipStream_t st);
+
+}  // namespace rd

@@ -1,0 +1,138 @@
+// RC-Net label build, masked weighted BCE, sigmoid and the inference crop scatter.
+//
+// Reference:
+//   RCNet/rcnet_main.py:308-332  label = (|gt - z| < thr) & (gt > 0); validity = gt > 0
+//   RCNet/rcnet_model.py:152-160 binary_cross_entropy_with_logits(pos_weight) * validity, sum / sum(validity)
+//   RCNet/rcnet_main.py:460-485  forward_output: threshold, paste each crop at integer offsets, confidence-
+//                                weighted mean depth, 0 where no crop responds (gather-by-pixel here, so the
+//                                non-zero index set is exact and no N full-size canvases are allocated)
+#include "rd_common.h"
+#include "rd_kernels.h"
+
+namespace rd {
+
+static unsigned ew_grid(int64_t n, int cap = 2048) { return (unsigned)std::max<int64_t>(1, std::min<int64_t>(cdiv(n, 256), cap)); }
+
+__global__ __launch_bounds__(256) void rcnet_labels_kernel(const float* __restrict__ gt, const float* __restrict__ points,
+                                                           float* __restrict__ label, float* __restrict__ valid, int R, int HW,
+                                                           float thr, int all_valid) {
+  const int64_t total = (int64_t)R * HW;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int r = (int)(i / HW);
+    float z = points[(int64_t)r * 3 + 2];
+    float g = gt[i];
+    float lab = (fabsf(g - z) < thr) ? 1.f : 0.f;
+    label[i] = (g > 0.f) ? lab : 0.f;
+    valid[i] = all_valid ? 1.f : ((g <= 0.f) ? 0.f : 1.f);
+  }
+}
+
+__device__ __forceinline__ float bce_logits(float x, float y, float pw) {
+  // (1-y)*x + (1+(pw-1)*y) * (log1p(exp(-|x|)) + max(-x,0))
+  float sp = log1pf(__expf(-fabsf(x))) + fmaxf(-x, 0.f);
+  return (1.f - y) * x + (1.f + (pw - 1.f) * y) * sp;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bce_fwd_kernel(const T* __restrict__ logits, const float* __restrict__ label,
+                                                      const float* __restrict__ valid, float pw, float* __restrict__ partial,
+                                                      int64_t n) {
+  __shared__ float red[2][4];
+  float a = 0.f, b = 0.f;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    float vm = valid[i];
+    a += vm * bce_logits(Elem<T>::ld(logits + i), label[i], pw);
+    b += vm;
+  }
+  a = wave_sum(a); b = wave_sum(b);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (lane == 0) { red[0][wv] = a; red[1][wv] = b; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    partial[blockIdx.x * 2] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+    partial[blockIdx.x * 2 + 1] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+  }
+}
+
+__global__ void bce_finalize_kernel(const float* __restrict__ partial, int rows, float* loss, float* sums) {
+  if (threadIdx.x || blockIdx.x) return;
+  double a = 0.0, b = 0.0;
+  for (int r = 0; r < rows; r++) { a += partial[r * 2]; b += partial[r * 2 + 1]; }
+  sums[0] = (float)a; sums[1] = (float)b;
+  loss[0] = (float)(a / b);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bce_bwd_kernel(const T* __restrict__ logits, const float* __restrict__ label,
+                                                      const float* __restrict__ valid, float pw, const float* __restrict__ sums,
+                                                      const float* __restrict__ dloss, T* __restrict__ dlogits, int64_t n) {
+  const float gs = dloss[0] / sums[1];
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    float x = Elem<T>::ld(logits + i), y = label[i];
+    float sg = 1.f / (1.f + __expf(-x));
+    float d = (1.f - y) - (1.f + (pw - 1.f) * y) * (1.f - sg);
+    Elem<T>::st(dlogits + i, valid[i] * d * gs);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void sigmoid_kernel(const T* __restrict__ x, T* __restrict__ y, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    Elem<T>::st(y + i, 1.f / (1.f + __expf(-Elem<T>::ld(x + i))));
+}
+
+// crops [Ncrop][PH][PW] (responses), points [Ncrop][3] = (x, y, z) in PADDED image coordinates,
+// outputs are the un-padded H x W depth and response maps.
+template <typename T>
+__global__ __launch_bounds__(256) void scatter_crops_kernel(const T* __restrict__ crops, const float* __restrict__ points,
+                                                            float* __restrict__ depth, float* __restrict__ response, int Ncrop,
+                                                            int PH, int PW, int H, int W, float thr) {
+  const int pad_y = PH / 2, pad_x = PW / 2;
+  const int total = H * W;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+    int u = i / W, v = i - u * W;
+    int pr = u + pad_y, pc = v + pad_x;  // padded coordinates of this pixel
+    float wsum = 0.f, zsum = 0.f, wmax = 0.f;
+    for (int c = 0; c < Ncrop; c++) {
+      int y0 = (int)points[c * 3 + 1] - pad_y, x0 = (int)points[c * 3 + 0] - pad_x;
+      int cr = pr - y0, cc = pc - x0;
+      if ((unsigned)cr >= (unsigned)(2 * pad_y) || (unsigned)cc >= (unsigned)(2 * pad_x)) continue;
+      float w = Elem<T>::ld(crops + ((int64_t)c * PH + cr) * PW + cc);
+      if (w < thr) w = 0.f;
+      wsum += w; zsum += w * points[c * 3 + 2];
+      wmax = fmaxf(wmax, w);
+    }
+    response[i] = wmax;
+    depth[i] = (wmax == 0.f) ? 0.f : zsum / wsum;
+  }
+}
+
+void launch_rcnet_labels(const float* gt, const float* points, float* label, float* valid, int R, int HW, float thr,
+                         int all_valid, hipStream_t st) {
+  hipLaunchKernelGGL(rcnet_labels_kernel, dim3(ew_grid((int64_t)R * HW)), dim3(256), 0, st, gt, points, label, valid, R, HW, thr, all_valid);
+}
+int bce_rows(int64_t n) { return (int)ew_grid(n, 1024); }
+void launch_bce_fwd(const void* logits, const float* label, const float* valid, float pw, float* partial, float* loss,
+                    float* sums, int64_t n, int dtype, hipStream_t st) {
+  int rows = bce_rows(n);
+  if (dtype == 0) hipLaunchKernelGGL((bce_fwd_kernel<float>), dim3(rows), dim3(256), 0, st, (const float*)logits, label, valid, pw, partial, n);
+  else hipLaunchKernelGGL((bce_fwd_kernel<bf16_t>), dim3(rows), dim3(256), 0, st, (const bf16_t*)logits, label, valid, pw, partial, n);
+  hipLaunchKernelGGL(bce_finalize_kernel, dim3(1), dim3(64), 0, st, partial, rows, loss, sums);
+}
+void launch_bce_bwd(const void* logits, const float* label, const float* valid, float pw, const float* sums, const float* dloss,
+                    void* dlogits, int64_t n, int dtype, hipStream_t st) {
+  if (dtype == 0) hipLaunchKernelGGL((bce_bwd_kernel<float>), dim3(ew_grid(n)), dim3(256), 0, st, (const float*)logits, label, valid, pw, sums, dloss, (float*)dlogits, n);
+  else hipLaunchKernelGGL((bce_bwd_kernel<bf16_t>), dim3(ew_grid(n)), dim3(256), 0, st, (const bf16_t*)logits, label, valid, pw, sums, dloss, (bf16_t*)dlogits, n);
+}
+void launch_sigmoid(const void* x, void* y, int64_t n, int dtype, hipStream_t st) {
+  if (dtype == 0) hipLaunchKernelGGL((sigmoid_kernel<float>), dim3(ew_grid(n)), dim3(256), 0, st, (const float*)x, (float*)y, n);
+  else hipLaunchKernelGGL((sigmoid_kernel<bf16_t>), dim3(ew_grid(n)), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, n);
+}
+void launch_scatter_crops(const void* crops, const float* points, float* depth, float* response, int Ncrop, int PH, int PW, int H,
+                          int W, float thr, int dtype, hipStream_t st) {
+  unsigned g = ew_grid((int64_t)H * W);
+  if (dtype == 0) hipLaunchKernelGGL((scatter_crops_kernel<float>), dim3(g), dim3(256), 0, st, (const float*)crops, points, depth, response, Ncrop, PH, PW, H, W, thr);
+  else hipLaunchKernelGGL((scatter_crops_kernel<bf16_t>), dim3(g), dim3(256), 0, st, (const bf16_t*)crops, points, depth, response, Ncrop, PH, PW, H, W, thr);
+}
+
+}  // namespace rd

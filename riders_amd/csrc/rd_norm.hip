@@ -1,0 +1,364 @@
+// BatchNorm (training/eval), activation, LayerNorm and bias-gradient kernels.  HBM-bound, NHWC.
+//
+// Reference semantics:
+//   utils/net_utils.py:84-91    conv -> torch.nn.BatchNorm2d (train: biased batch var for the
+//                               normalisation, unbiased var into running_var, momentum 0.1) -> act
+//   utils/net_utils.py:15       LeakyReLU(negative_slope=0.20)
+//   utils/net_utils.py:309-323  ResNetBlock: act(conv2 + X)  (residual folded into rd_affine_act)
+//   RCNet/linear_attention.py:106-107,125,131  nn.LayerNorm(d_model), eps 1e-5, biased var
+//
+// BN statistics come from the convolution epilogue as per-block partial (sum, sum^2) rows; they are
+// combined here in a fixed order in double precision (deterministic).
+#include "rd_common.h"
+#include "rd_kernels.h"
+
+namespace rd {
+
+// ---- BN finalize: partial[rows][C][2] -> mean/rstd + fused scale/shift, running-stat update ----
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ partial, int rows, int C, double count,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          float eps, float momentum, int training, float* running_mean,
+                                                          float* running_var, float* mean_out, float* rstd_out,
+                                                          float* scale, float* shift) {
+  __shared__ double s1[256], s2[256];
+  const int c = blockIdx.x, t = threadIdx.x;
+  float mean, var;
+  if (training) {
+    double a = 0.0, b = 0.0;
+    for (int r = t; r < rows; r += 256) {
+      a += (double)partial[((int64_t)r * C + c) * 2];
+      b += (double)partial[((int64_t)r * C + c) * 2 + 1];
+    }
+    s1[t] = a; s2[t] = b;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+      if (t < o) { s1[t] += s1[t + o]; s2[t] += s2[t + o]; }
+      __syncthreads();
+    }
+    double m = s1[0] / count;
+    double v = s2[0] / count - m * m;
+    if (v < 0.0) v = 0.0;
+    mean = (float)m; var = (float)v;
+    if (t == 0 && running_mean) {
+      double unb = count > 1.0 ? v * count / (count - 1.0) : v;
+      running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+      running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unb;
+    }
+  } else {
+    mean = running_mean[c]; var = running_var[c];
+  }
+  if (t == 0) {
+    float rstd = 1.0f / sqrtf(var + eps);
+    float g = gamma ? gamma[c] : 1.f, b = beta ? beta[c] : 0.f;
+    if (mean_out) mean_out[c] = mean;
+    if (rstd_out) rstd_out[c] = rstd;
+    scale[c] = g * rstd;
+    shift[c] = b - mean * g * rstd;
+  }
+}
+
+// ---- z = act(scale[c]*y + shift[c] + res) ---------------------------------------------------------
+template <typename T, bool V4>
+__global__ __launch_bounds__(256) void affine_act_kernel(const T* __restrict__ y, const float* __restrict__ scale,
+                                                         const float* __restrict__ shift, const T* __restrict__ res,
+                                                         T* __restrict__ out, int64_t total, int C, int act, float slope) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  if (V4) {
+    int64_t nv = total >> 2;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += stride) {
+      int c = (int)((i << 2) % C);
+      float v[4], r[4] = {0.f, 0.f, 0.f, 0.f};
+      ld4(y + (i << 2), v);
+      if (res) ld4(res + (i << 2), r);
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        float s = scale ? scale[c + e] : 1.f, b = shift ? shift[c + e] : 0.f;
+        v[e] = act_fwd(v[e] * s + b + r[e], act, slope);
+      }
+      st4(out + (i << 2), v);
+    }
+  } else {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+      int c = (int)(i % C);
+      float s = scale ? scale[c] : 1.f, b = shift ? shift[c] : 0.f;
+      float x = Elem<T>::ld(y + i) * s + b + (res ? Elem<T>::ld(res + i) : 0.f);
+      Elem<T>::st(out + i, act_fwd(x, act, slope));
+    }
+  }
+}
+
+// ---- per-channel column reductions over an NHWC [pixels][C] tensor --------------------------------
+// thread = (pixel lane pl, channel cl); a block covers BC = min(C,256)-rounded channels x a pixel range
+struct RedGeom { int CB, PL, nchunk; };
+static RedGeom red_geom(int C) {
+  RedGeom g;
+  int cb = 1; while (cb < C && cb < 256) cb <<= 1;
+  g.CB = cb; g.PL = 256 / cb; g.nchunk = (int)cdiv(C, cb);
+  return g;
+}
+static int red_rows(int64_t pixels, int C) {
+  RedGeom g = red_geom(C);
+  int64_t per_block = (int64_t)g.PL * 64;  // >= 64 pixels per thread-row
+  int64_t r = cdiv(pixels, per_block);
+  return (int)std::max<int64_t>(1, std::min<int64_t>(r, 1024));
+}
+
+// MODE 0: (sum dpre, sum dpre*xhat) for BN backward; MODE 1: column sum of x (bias gradient)
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void col_reduce_kernel(const T* __restrict__ dz, const T* __restrict__ z,
+                                                         const T* __restrict__ y, const float* __restrict__ mean,
+                                                         const float* __restrict__ rstd, float* __restrict__ partial,
+                                                         int64_t pixels, int C, int CB, int PL, int act, float slope) {
+  __shared__ float red[2][256];
+  const int t = threadIdx.x;
+  const int cl = t % CB, pl = t / CB;
+  const int c = blockIdx.y * CB + cl;
+  const int nrow = gridDim.x;
+  const int64_t per = cdiv(pixels, nrow);
+  const int64_t pbeg = (int64_t)blockIdx.x * per, pend = pbeg + per < pixels ? pbeg + per : pixels;
+  float a = 0.f, b = 0.f;
+  if (c < C) {
+    float mu = 0.f, rs = 1.f;
+    if (MODE == 0) { mu = mean[c]; rs = rstd[c]; }
+    for (int64_t p = pbeg + pl; p < pend; p += PL) {
+      int64_t i = p * C + c;
+      if (MODE == 0) {
+        float g = Elem<T>::ld(dz + i);
+        if (act) g *= act_grad_from_out(Elem<T>::ld(z + i), act, slope);
+        float xh = (Elem<T>::ld(y + i) - mu) * rs;
+        a += g; b += g * xh;
+      } else {
+        a += Elem<T>::ld(dz + i);
+      }
+    }
+  }
+  red[0][t] = a; red[1][t] = b;
+  __syncthreads();
+  if (pl == 0 && c < C) {
+    float sa = 0.f, sb = 0.f;
+    for (int q = 0; q < PL; q++) { sa += red[0][q * CB + cl]; sb += red[1][q * CB + cl]; }
+    partial[((int64_t)blockIdx.x * C + c) * 2] = sa;
+    partial[((int64_t)blockIdx.x * C + c) * 2 + 1] = sb;
+  }
+}
+
+__global__ void bn_bwd_finalize_kernel(const float* __restrict__ partial, int rows, int C, double count, float* dgamma,
+                                       float* dbeta, int accumulate, float* c1, float* c2) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double a = 0.0, b = 0.0;
+  for (int r = 0; r < rows; r++) { a += partial[((int64_t)r * C + c) * 2]; b += partial[((int64_t)r * C + c) * 2 + 1]; }
+  if (dbeta) dbeta[c] = accumulate ? dbeta[c] + (float)a : (float)a;
+  if (dgamma) dgamma[c] = accumulate ? dgamma[c] + (float)b : (float)b;
+  if (c1) c1[c] = (float)(a / count);
+  if (c2) c2[c] = (float)(b / count);
+}
+
+__global__ void colsum_finalize_kernel(const float* __restrict__ partial, int rows, int C, float* out, int accumulate) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double a = 0.0;
+  for (int r = 0; r < rows; r++) a += partial[((int64_t)r * C + c) * 2];
+  out[c] = accumulate ? out[c] + (float)a : (float)a;
+}
+
+// dy = scale[c] * (dpre - c1[c] - xhat*c2[c]);  dres = dpre
+template <typename T, bool V4>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__ dz, const T* __restrict__ z,
+                                                           const T* __restrict__ y, const float* __restrict__ mean,
+                                                           const float* __restrict__ rstd, const float* __restrict__ scale,
+                                                           const float* __restrict__ c1, const float* __restrict__ c2,
+                                                           T* __restrict__ dy, T* __restrict__ dres, int64_t total, int C,
+                                                           int act, float slope) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  if (V4) {
+    int64_t nv = total >> 2;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += stride) {
+      int c = (int)((i << 2) % C);
+      float g[4], zz[4], yy[4], o[4];
+      ld4(dz + (i << 2), g);
+      if (act) { ld4(z + (i << 2), zz); }
+      ld4(y + (i << 2), yy);
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        if (act) g[e] *= act_grad_from_out(zz[e], act, slope);
+        float xh = (yy[e] - mean[c + e]) * rstd[c + e];
+        o[e] = scale[c + e] * (g[e] - c1[c + e] - xh * c2[c + e]);
+      }
+      st4(dy + (i << 2), o);
+      if (dres) st4(dres + (i << 2), g);
+    }
+  } else {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
+      int c = (int)(i % C);
+      float g = Elem<T>::ld(dz + i);
+      if (act) g *= act_grad_from_out(Elem<T>::ld(z + i), act, slope);
+      float xh = (Elem<T>::ld(y + i) - mean[c]) * rstd[c];
+      Elem<T>::st(dy + i, scale[c] * (g - c1[c] - xh * c2[c]));
+      if (dres) Elem<T>::st(dres + i, g);
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void act_bwd_kernel(const T* __restrict__ dz, const T* __restrict__ z, T* __restrict__ dx,
+                                                      int64_t n, int act, float slope) {
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride)
+    Elem<T>::st(dx + i, Elem<T>::ld(dz + i) * act_grad_from_out(Elem<T>::ld(z + i), act, slope));
+}
+
+// ---- LayerNorm over the last dim (C multiple of 64, <= 512): one wave per row -------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void layernorm_fwd_kernel(const T* __restrict__ x, const float* __restrict__ gamma,
+                                                            const float* __restrict__ beta, const T* __restrict__ res,
+                                                            T* __restrict__ out, float* __restrict__ mean,
+                                                            float* __restrict__ rstd, int64_t rows, int C, float eps) {
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int epl = C >> 6;  // elements per lane
+  for (int64_t r = (int64_t)blockIdx.x * 4 + wv; r < rows; r += (int64_t)gridDim.x * 4) {
+    float v[8];
+    float s = 0.f;
+    for (int e = 0; e < epl; e++) { v[e] = Elem<T>::ld(x + r * C + e * 64 + lane); s += v[e]; }
+    float mu = wave_sum(s) / (float)C;
+    float q = 0.f;
+    for (int e = 0; e < epl; e++) { float d = v[e] - mu; q += d * d; }
+    float var = wave_sum(q) / (float)C;
+    float rs = 1.0f / sqrtf(var + eps);
+    for (int e = 0; e < epl; e++) {
+      int c = e * 64 + lane;
+      float o = (v[e] - mu) * rs * gamma[c] + beta[c];
+      if (res) o += Elem<T>::ld(res + r * C + c);
+      Elem<T>::st(out + r * C + c, o);
+    }
+    if (lane == 0) { mean[r] = mu; rstd[r] = rs; }
+  }
+}
+
+// dx = rstd*(g - mean(g) - xhat*mean(g*xhat)), g = dout*gamma; partial[block][C][2] = (sum dout, sum dout*xhat)
+template <typename T>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict__ dout, const T* __restrict__ x,
+                                                            const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                            const float* __restrict__ rstd, T* __restrict__ dx,
+                                                            float* __restrict__ partial, int64_t rows, int C) {
+  __shared__ float red[4][2][512];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int epl = C >> 6;
+  float ag[8], ab[8];
+  for (int e = 0; e < 8; e++) { ag[e] = 0.f; ab[e] = 0.f; }
+  for (int64_t r = (int64_t)blockIdx.x * 4 + wv; r < rows; r += (int64_t)gridDim.x * 4) {
+    float mu = mean[r], rs = rstd[r];
+    float g[8], xh[8];
+    float s1 = 0.f, s2 = 0.f;
+    for (int e = 0; e < epl; e++) {
+      int c = e * 64 + lane;
+      float d = Elem<T>::ld(dout + r * C + c);
+      xh[e] = (Elem<T>::ld(x + r * C + c) - mu) * rs;
+      g[e] = d * gamma[c];
+      s1 += g[e]; s2 += g[e] * xh[e];
+      ag[e] += d * xh[e]; ab[e] += d;
+    }
+    s1 = wave_sum(s1) / (float)C; s2 = wave_sum(s2) / (float)C;
+    for (int e = 0; e < epl; e++)
+      Elem<T>::st(dx + r * C + e * 64 + lane, rs * (g[e] - s1 - xh[e] * s2));
+  }
+  for (int e = 0; e < epl; e++) { red[wv][0][e * 64 + lane] = ag[e]; red[wv][1][e * 64 + lane] = ab[e]; }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float a = 0.f, b = 0.f;
+    for (int w = 0; w < 4; w++) { a += red[w][0][c]; b += red[w][1][c]; }
+    partial[((int64_t)blockIdx.x * C + c) * 2] = b;      // dbeta terms
+    partial[((int64_t)blockIdx.x * C + c) * 2 + 1] = a;  // dgamma terms
+  }
+}
+
+// ---- launchers ---------------------------------------------------------------------------------------------
+static unsigned ew_grid(int64_t n) { return (unsigned)std::max<int64_t>(1, std::min<int64_t>(cdiv(n, 256), 2048)); }
+
+void launch_bn_finalize(const float* partial, int rows, int C, double count, const float* gamma, const float* beta,
+                        float eps, float momentum, int training, float* running_mean, float* running_var, float* mean,
+                        float* rstd, float* scale, float* shift, hipStream_t st) {
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3(C), dim3(256), 0, st, partial, rows, C, count, gamma, beta, eps, momentum,
+                     training, running_mean, running_var, mean, rstd, scale, shift);
+}
+
+void launch_affine_act(const void* y, const float* scale, const float* shift, const void* res, void* out, int64_t pixels,
+                       int C, int act, float slope, int dtype, hipStream_t st) {
+  int64_t total = pixels * C;
+  bool v4 = (C % 4 == 0);
+  unsigned g = ew_grid(v4 ? total / 4 : total);
+#define RD_AA(T, V) hipLaunchKernelGGL((affine_act_kernel<T, V>), dim3(g), dim3(256), 0, st, (const T*)y, scale, shift, (const T*)res, (T*)out, total, C, act, slope)
+  if (dtype == 0) { if (v4) RD_AA(float, true); else RD_AA(float, false); }
+  else { if (v4) RD_AA(bf16_t, true); else RD_AA(bf16_t, false); }
+#undef RD_AA
+}
+
+int bn_bwd_rows(int64_t pixels, int C) { return red_rows(pixels, C); }
+int colsum_rows(int64_t rows, int C) { return red_rows(rows, C); }
+
+void launch_bn_bwd_reduce(const void* dz, const void* z, const void* y, const float* mean, const float* rstd,
+                          float* partial, int64_t pixels, int C, int act, float slope, int dtype, hipStream_t st) {
+  RedGeom g = red_geom(C);
+  dim3 grid(red_rows(pixels, C), g.nchunk);
+  if (dtype == 0)
+    hipLaunchKernelGGL((col_reduce_kernel<float, 0>), grid, dim3(256), 0, st, (const float*)dz, (const float*)z, (const float*)y, mean, rstd, partial, pixels, C, g.CB, g.PL, act, slope);
+  else
+    hipLaunchKernelGGL((col_reduce_kernel<bf16_t, 0>), grid, dim3(256), 0, st, (const bf16_t*)dz, (const bf16_t*)z, (const bf16_t*)y, mean, rstd, partial, pixels, C, g.CB, g.PL, act, slope);
+}
+
+void launch_bn_bwd_finalize(const float* partial, int rows, int C, double count, float* dgamma, float* dbeta,
+                            int accumulate, float* c1, float* c2, hipStream_t st) {
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)cdiv(C, 64)), dim3(64), 0, st, partial, rows, C, count, dgamma, dbeta, accumulate, c1, c2);
+}
+
+void launch_bn_bwd_apply(const void* dz, const void* z, const void* y, const float* mean, const float* rstd,
+                         const float* scale, const float* c1, const float* c2, void* dy, void* dres, int64_t pixels, int C,
+                         int act, float slope, int dtype, hipStream_t st) {
+  int64_t total = pixels * C;
+  bool v4 = (C % 4 == 0);
+  unsigned g = ew_grid(v4 ? total / 4 : total);
+#define RD_BA(T, V) hipLaunchKernelGGL((bn_bwd_apply_kernel<T, V>), dim3(g), dim3(256), 0, st, (const T*)dz, (const T*)z, (const T*)y, mean, rstd, scale, c1, c2, (T*)dy, (T*)dres, total, C, act, slope)
+  if (dtype == 0) { if (v4) RD_BA(float, true); else RD_BA(float, false); }
+  else { if (v4) RD_BA(bf16_t, true); else RD_BA(bf16_t, false); }
+#undef RD_BA
+}
+
+void launch_act_bwd(const void* dz, const void* z, void* dx, int64_t n, int act, float slope, int dtype, hipStream_t st) {
+  if (dtype == 0) hipLaunchKernelGGL((act_bwd_kernel<float>), dim3(ew_grid(n)), dim3(256), 0, st, (const float*)dz, (const float*)z, (float*)dx, n, act, slope);
+  else hipLaunchKernelGGL((act_bwd_kernel<bf16_t>), dim3(ew_grid(n)), dim3(256), 0, st, (const bf16_t*)dz, (const bf16_t*)z, (bf16_t*)dx, n, act, slope);
+}
+
+void launch_colsum(const void* x, float* partial, float* out, int accumulate, int64_t rows, int C, int dtype, hipStream_t st) {
+  RedGeom g = red_geom(C);
+  int nr = red_rows(rows, C);
+  dim3 grid(nr, g.nchunk);
+  if (dtype == 0)
+    hipLaunchKernelGGL((col_reduce_kernel<float, 1>), grid, dim3(256), 0, st, (const float*)x, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, partial, rows, C, g.CB, g.PL, 0, 0.f);
+  else
+    hipLaunchKernelGGL((col_reduce_kernel<bf16_t, 1>), grid, dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)nullptr, (const bf16_t*)nullptr, (const float*)nullptr, (const float*)nullptr, partial, rows, C, g.CB, g.PL, 0, 0.f);
+  hipLaunchKernelGGL(colsum_finalize_kernel, dim3((unsigned)cdiv(C, 64)), dim3(64), 0, st, partial, nr, C, out, accumulate);
+}
+
+void launch_layernorm_fwd(const void* x, const float* gamma, const float* beta, const void* res, void* out, float* mean,
+                          float* rstd, int64_t rows, int C, float eps, int dtype, hipStream_t st) {
+  unsigned g = (unsigned)std::max<int64_t>(1, std::min<int64_t>(cdiv(rows, 4), 2048));
+  if (dtype == 0)
+    hipLaunchKernelGGL((layernorm_fwd_kernel<float>), dim3(g), dim3(256), 0, st, (const float*)x, gamma, beta, (const float*)res, (float*)out, mean, rstd, rows, C, eps);
+  else
+    hipLaunchKernelGGL((layernorm_fwd_kernel<bf16_t>), dim3(g), dim3(256), 0, st, (const bf16_t*)x, gamma, beta, (const bf16_t*)res, (bf16_t*)out, mean, rstd, rows, C, eps);
+}
+
+int layernorm_bwd_rows(int64_t rows) { return (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(rows, 16), 512)); }
+
+void launch_layernorm_bwd(const void* dout, const void* x, const float* gamma, const float* mean, const float* rstd, void* dx,
+                          float* partial, float* dgamma, float* dbeta, int accumulate, int64_t rows, int C, int dtype,
+                          hipStream_t st) {
+  int nb = layernorm_bwd_rows(rows);
+  if (dtype == 0)
+    hipLaunchKernelGGL((layernorm_bwd_kernel<float>), dim3(nb), dim3(256), 0, st, (const float*)dout, (const float*)x, gamma, mean, rstd, (float*)dx, partial, rows, C);
+  else
+    hipLaunchKernelGGL((layernorm_bwd_kernel<bf16_t>), dim3(nb), dim3(256), 0, st, (const bf16_t*)dout, (const bf16_t*)x, gamma, mean, rstd, (bf16_t*)dx, partial, rows, C);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)cdiv(C, 64)), dim3(64), 0, st, partial, nb, C, 1.0, dgamma, dbeta, accumulate, (float*)nullptr, (float*)nullptr);
+}
+
+}  // namespace rd
