@@ -1,0 +1,736 @@
+"""Execution engine: a small explicit tape over the HIP kernels (no tracing compiler, no torch compute ops).
+
+PyTorch provides device memory, streams and the outer autograd edge; everything between a region's inputs
+and outputs is a hand-scheduled sequence of libriders_hip.so launches recorded on a `Tape`, whose backward is
+replayed in reverse.  Activations are NHWC tensors of shape (N, H, W, C) (or (rows, C) for token matrices) in
+the engine's activation dtype (fp32 or bf16); parameters and their gradients stay fp32 in the reference's
+layouts so `state_dict`s are exchangeable with the reference.
+
+A module's forward runs either inside an already-active tape (it is part of a larger fused region) or opens
+its own region, which appears to torch.autograd as ONE node (`_Region`).
+"""
+import contextlib
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import ACT_LRELU, ACT_NONE, ACT_RELU, ACT_RELU6, RD_BF16, RD_F32, ConvDesc
+
+_TORCH_DT = {RD_F32: torch.float32, RD_BF16: torch.bfloat16}
+_RD_DT = {torch.float32: RD_F32, torch.bfloat16: RD_BF16}
+
+_state = {"dtype": RD_F32, "tape": None}
+
+
+def set_compute_dtype(dt):
+    """Activation storage dtype of subsequently executed regions: 'fp32' or 'bf16' (accumulation is always fp32)."""
+    _state["dtype"] = {"fp32": RD_F32, "bf16": RD_BF16, RD_F32: RD_F32, RD_BF16: RD_BF16}[dt]
+
+
+def compute_dtype():
+    return _state["dtype"]
+
+
+def act_dtype():
+    return _TORCH_DT[_state["dtype"]]
+
+
+def _stream(t):
+    if t.is_cuda:
+        return ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+    if not _lib.ALLOW_HOST_POINTERS:
+        raise RuntimeError("riders_amd kernels need ROCm device tensors (got %s); there is no CPU path" % t.device)
+    return ctypes.c_void_p(0)
+
+
+def _p(t):
+    return None if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _chk(rc, what):
+    if rc != 0:
+        _lib.check(rc, what)
+
+
+def L():
+    return _lib.load()
+
+
+def rd_of(t):
+    return _RD_DT[t.dtype]
+
+
+# ------------------------------------------------------------------------------------------------- tape
+class Tape:
+    def __init__(self):
+        self.nodes = []
+        self.grads = {}    # id(tensor) -> gradient tensor (same shape/dtype as the tensor)
+        self.keep = {}     # id -> tensor, keeps ids unique while grads are pending
+        self.req = set()   # ids of tensors that need a gradient
+        self.pgrads = {}   # id(param) -> fp32 gradient tensor
+        self.params = {}   # id(param) -> param
+        self.grad_alloc = None  # optional callable(param) -> preallocated fp32 grad view (flat arena)
+
+    def requires(self, *ts):
+        return any(t is not None and id(t) in self.req for t in ts)
+
+    def mark(self, t):
+        self.req.add(id(t))
+        self.keep[id(t)] = t
+
+    def record(self, fn):
+        self.nodes.append(fn)
+
+    def add_grad(self, t, g):
+        if t is None or g is None or id(t) not in self.req:
+            return
+        cur = self.grads.get(id(t))
+        if cur is None:
+            self.grads[id(t)] = g
+        else:  # never in place: gradient tensors may be shared with other consumers
+            s = torch.empty_like(cur)
+            _chk(L().rd_add(_p(cur), _p(g), _p(s), cur.numel(), rd_of(cur), _stream(cur)), "rd_add")
+            self.grads[id(t)] = s
+
+    def pop_grad(self, t):
+        return self.grads.pop(id(t), None)
+
+    def param_grad(self, p):
+        """-> (fp32 grad tensor, accumulate flag).  First touch in this tape overwrites, later touches add."""
+        g = self.pgrads.get(id(p))
+        if g is not None:
+            return g, 1
+        g = self.grad_alloc(p) if self.grad_alloc is not None else None
+        if g is None:
+            g = torch.empty_like(p, dtype=torch.float32, memory_format=torch.contiguous_format)
+        self.pgrads[id(p)] = g
+        self.params[id(p)] = p
+        return g, 0
+
+    def backward(self):
+        for fn in reversed(self.nodes):
+            fn()
+        self.nodes = []
+        self.keep = {}
+
+
+def tape():
+    return _state["tape"]
+
+
+@contextlib.contextmanager
+def _active(t):
+    prev = _state["tape"]
+    _state["tape"] = t
+    try:
+        yield t
+    finally:
+        _state["tape"] = prev
+
+
+_grad_alloc_hook = {"fn": None}
+
+
+def set_param_grad_allocator(fn):
+    """fn(param) -> preallocated fp32 gradient tensor or None (used by the flat-arena optimizer / DDP)."""
+    _grad_alloc_hook["fn"] = fn
+
+
+class _Region(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, runner, n_in, *tensors):
+        inputs, params = tensors[:n_in], tensors[n_in:]
+        t = Tape()
+        t.grad_alloc = _grad_alloc_hook["fn"]
+        for i, x in enumerate(inputs):
+            if x is not None and ctx.needs_input_grad[2 + i]:
+                t.mark(x)
+        with _active(t):
+            outs = runner(*inputs)
+        single = not isinstance(outs, (tuple, list))
+        outs = (outs,) if single else tuple(outs)
+        ctx.tape, ctx.inputs, ctx.params, ctx.outs = t, inputs, params, outs
+        ctx.set_materialize_grads(False)
+        return outs[0] if single else outs
+
+    @staticmethod
+    def backward(ctx, *gouts):
+        t = ctx.tape
+        for o, g in zip(ctx.outs, gouts):
+            if g is None or id(o) not in t.req:
+                continue
+            if g.dtype != o.dtype or g.stride() != o.stride():
+                g = _match_layout(g, o)
+            t.grads[id(o)] = g
+        with _active(t):
+            t.backward()
+        gin = tuple(t.grads.get(id(x)) if x is not None else None for x in ctx.inputs)
+        gp = tuple(t.pgrads.get(id(p)) for p in ctx.params)
+        ctx.tape = None
+        return (None, None) + gin + gp
+
+
+def _match_layout(g, like):
+    """Bring an incoming gradient to the dtype / strides of the tensor it belongs to (boundary only)."""
+    out = torch.empty_strided(like.shape, like.stride(), dtype=like.dtype, device=like.device)
+    if g.is_contiguous() and like.dim() == 4 and like.permute(0, 2, 3, 1).is_contiguous():
+        n, c, h, w = like.shape
+        _chk(L().rd_nchw_to_nhwc(_p(g), _p(out), n, c, h, w, rd_of(g), rd_of(out), 1.0, _stream(g)), "rd_nchw_to_nhwc")
+    elif g.stride() == like.stride() or (g.is_contiguous() and like.is_contiguous()):
+        _chk(L().rd_cast(_p(g), _p(out), g.numel(), rd_of(g), rd_of(out), 1.0, _stream(g)), "rd_cast")
+    else:
+        out.copy_(g)  # arbitrary user layout: torch copy, off the hot path
+    return out
+
+
+def run_region(runner, inputs, params):
+    """Run `runner(*inputs)` as one autograd node, or inline when a tape is already active / grad is off."""
+    if _state["tape"] is not None:
+        return runner(*inputs)
+    if not torch.is_grad_enabled():
+        with _active(None):
+            return runner(*inputs)
+    params = [p for p in params if p.requires_grad]
+    return _Region.apply(runner, len(inputs), *inputs, *params)
+
+
+# --------------------------------------------------------------------------------------- small helpers
+def empty(shape, like, dtype=None):
+    return torch.empty(shape, dtype=dtype or like.dtype, device=like.device)
+
+
+def to_act(x, scale=1.0):
+    """Any fp32/bf16 contiguous tensor -> engine activation dtype (same shape), optionally scaled."""
+    dt = act_dtype()
+    if x.dtype == dt and scale == 1.0:
+        return x
+    out = torch.empty(x.shape, dtype=dt, device=x.device)
+    _chk(L().rd_cast(_p(x), _p(out), x.numel(), rd_of(x), rd_of(out), float(scale), _stream(x)), "rd_cast")
+    return out
+
+
+def cast(x, dtype, scale=1.0):
+    if x.dtype == dtype and scale == 1.0:
+        return x
+    out = torch.empty(x.shape, dtype=dtype, device=x.device)
+    _chk(L().rd_cast(_p(x), _p(out), x.numel(), rd_of(x), rd_of(out), float(scale), _stream(x)), "rd_cast")
+    return out
+
+
+def nchw_to_nhwc(x, scale=1.0, dtype=None):
+    """Logical NCHW tensor (any of: contiguous, channels_last) -> engine (N,H,W,C) activation tensor."""
+    n, c, h, w = x.shape
+    dt = dtype or act_dtype()
+    xp = x.permute(0, 2, 3, 1)
+    if xp.is_contiguous():
+        return cast(xp, dt, scale) if (x.dtype != dt or scale != 1.0) else xp
+    if not x.is_contiguous():
+        x = x.contiguous()
+    out = torch.empty((n, h, w, c), dtype=dt, device=x.device)
+    _chk(L().rd_nchw_to_nhwc(_p(x), _p(out), n, c, h, w, rd_of(x), rd_of(out), float(scale), _stream(x)), "rd_nchw_to_nhwc")
+    return out
+
+
+def as_nchw(x):
+    """(N,H,W,C) engine tensor -> logical NCHW view (channels_last strides, zero copy)."""
+    return x.permute(0, 3, 1, 2)
+
+
+# packed-weight cache: (id(param), version, mode, dtype) -> tensor
+_pack_cache = {}
+
+
+def packed_weight(w, mode, dt):
+    key = (id(w), w._version, mode, dt, w.data_ptr())
+    hit = _pack_cache.get(id(w), {}).get((mode, dt))
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    cout, cin, kh, kw = w.shape if w.dim() == 4 else (w.shape[0], w.shape[1], 1, 1)
+    rows, c = (cin, cout) if mode else (cout, cin)
+    n = L().rd_conv_packed_elems(rows, kh * kw * c, dt)
+    buf = torch.empty(n, dtype=_TORCH_DT[dt], device=w.device)
+    _chk(L().rd_conv_pack_weights(_p(w.detach()), _p(buf), cout, cin, kh, kw, mode, dt, _stream(w)), "rd_conv_pack_weights")
+    _pack_cache.setdefault(id(w), {})[(mode, dt)] = (key, buf)
+    return buf
+
+
+def clear_caches():
+    _pack_cache.clear()
+
+
+# ------------------------------------------------------------------------------------------ conv block
+def _desc(dt, N, Hin, Win, C1, C2, up, H1, W1, Cout, KH, KW, stride, pad, dil, OH, OW, act, slope, D1):
+    d = ConvDesc()
+    d.dtype, d.N, d.Hin, d.Win, d.C1, d.C2 = dt, N, Hin, Win, C1, C2
+    d.upsample, d.H1, d.W1 = (1 if up else 0), H1, W1
+    d.Cout, d.KH, d.KW, d.stride, d.pad, d.in_dilate = Cout, KH, KW, stride, pad, dil
+    d.OH, d.OW, d.act, d.slope, d.D1 = OH, OW, act, slope, D1
+    return d
+
+
+def conv_block(x, weight, *, x2=None, bias=None, stride=1, pad=None, up=None, bn=None, act=ACT_NONE, slope=0.2,
+               residual=None, training=True):
+    """act(BN(conv([up(x) | up(x2)], weight) + bias) + residual) on NHWC tensors; records its own backward.
+
+    x: (N,H,W,C1) [, x2: (N,H,W,C2)]; weight OIHW fp32 (nn.Linear [out,in] is treated as 1x1);
+    up: (Hv, Wv) nearest-upsample target applied to the sources inside the gather;
+    bn: a torch.nn.BatchNorm2d used as a parameter container (train: batch stats + running update).
+    """
+    lib = L()
+    t = tape()
+    dt = rd_of(x)
+    st = _stream(x)
+    N, H1, W1, C1 = x.shape
+    C2 = 0 if x2 is None else x2.shape[3]
+    if weight.dim() == 4:
+        Cout, Cin, KH, KW = weight.shape
+    else:
+        (Cout, Cin), KH, KW = weight.shape, 1, 1
+    assert Cin == C1 + C2, "conv_block: weight expects %d input channels, got %d" % (Cin, C1 + C2)
+    if pad is None:
+        pad = KH // 2
+    Hin, Win = (int(up[0]), int(up[1])) if up is not None else (H1, W1)
+    is_up = up is not None and (Hin, Win) != (H1, W1)
+    OH = (Hin + 2 * pad - KH) // stride + 1
+    OW = (Win + 2 * pad - KW) // stride + 1
+    use_bn = bn is not None
+    conv_act = ACT_NONE if (use_bn or residual is not None) else act
+    d = _desc(dt, N, Hin, Win, C1, C2, is_up, H1, W1, Cout, KH, KW, stride, pad, 1, OH, OW, conv_act, slope, Cout)
+    wp = packed_weight(weight, 0, dt)
+    y = torch.empty((N, OH, OW, Cout), dtype=x.dtype, device=x.device)
+    stats = None
+    bn_train = use_bn and (training or not bn.track_running_stats)
+    if bn_train:
+        rows = lib.rd_conv_stats_rows(ctypes.byref(d))
+        stats = torch.empty((rows, Cout, 2), dtype=torch.float32, device=x.device)
+    _chk(lib.rd_conv_fwd(ctypes.byref(d), _p(x), _p(x2), _p(wp), _p(bias.detach() if bias is not None else None), _p(y), None,
+                         _p(stats), st), "rd_conv_fwd")
+    pixels = N * OH * OW
+    scale = shift = mean = rstd = None
+    if use_bn:
+        coef = torch.empty((4, Cout), dtype=torch.float32, device=x.device)
+        scale, shift, mean, rstd = coef[0], coef[1], coef[2], coef[3]
+        _chk(lib.rd_bn_finalize(_p(stats), 0 if stats is None else stats.shape[0], Cout, float(pixels),
+                                _p(bn.weight.detach() if bn.weight is not None else None),
+                                _p(bn.bias.detach() if bn.bias is not None else None), float(bn.eps),
+                                float(bn.momentum if bn.momentum is not None else 0.1), 1 if bn_train else 0,
+                                _p(bn.running_mean), _p(bn.running_var), _p(mean), _p(rstd), _p(scale), _p(shift), st),
+             "rd_bn_finalize")
+    if use_bn or residual is not None:
+        z = torch.empty_like(y)
+        _chk(lib.rd_affine_act(_p(y), _p(scale), _p(shift), _p(residual), _p(z), pixels, Cout, act, slope, dt, st), "rd_affine_act")
+    else:
+        z = y
+    if t is None:
+        return z
+
+    need_in = t.requires(x, x2)
+    need_res = t.requires(residual)
+    w_req = weight.requires_grad
+    if not (need_in or need_res or w_req or (use_bn and bn.weight is not None and bn.weight.requires_grad)):
+        return z
+    t.mark(z)
+
+    def backward():
+        dz = t.pop_grad(z)
+        if dz is None:
+            return
+        dres = None
+        if use_bn:
+            if not bn_train:
+                raise NotImplementedError("backward through eval-mode BatchNorm is not supported")
+            rows = lib.rd_bn_bwd_rows(pixels, Cout)
+            partial = torch.empty((rows, Cout, 2), dtype=torch.float32, device=x.device)
+            coef2 = torch.empty((2, Cout), dtype=torch.float32, device=x.device)
+            dgam, acc = t.param_grad(bn.weight)
+            dbet, acc2 = t.param_grad(bn.bias)
+            assert acc == acc2
+            dy = torch.empty_like(y)
+            dres = torch.empty_like(y) if need_res else None
+            _chk(lib.rd_bn_act_bwd(_p(dz), _p(z), _p(y), _p(mean), _p(rstd), _p(scale), _p(partial), _p(coef2), _p(dgam),
+                                   _p(dbet), acc, _p(dy), _p(dres), pixels, Cout, act, slope, dt, st), "rd_bn_act_bwd")
+        else:
+            eff_act = act
+            if eff_act != ACT_NONE:
+                dy = torch.empty_like(y)
+                _chk(lib.rd_act_bwd(_p(dz), _p(z), _p(dy), dz.numel(), eff_act, slope, dt, st), "rd_act_bwd")
+            else:
+                dy = dz
+            dres = dy
+        if need_res:
+            t.add_grad(residual, dres)
+        if bias is not None and bias.requires_grad:
+            db, acc = t.param_grad(bias)
+            rows = lib.rd_colsum_rows(pixels, Cout)
+            part = torch.empty((rows, Cout, 2), dtype=torch.float32, device=x.device)
+            _chk(lib.rd_colsum(_p(dy), _p(part), _p(db), acc, pixels, Cout, dt, st), "rd_colsum")
+        if w_req:
+            dw, acc = t.param_grad(weight)
+            ws = torch.empty(lib.rd_conv_wgrad_workspace_bytes(ctypes.byref(d)) // 4, dtype=torch.float32, device=x.device)
+            _chk(lib.rd_conv_wgrad(ctypes.byref(d), _p(x), _p(x2), _p(dy), _p(ws), _p(dw), acc, st), "rd_conv_wgrad")
+        if need_in:
+            wpd = packed_weight(weight, 1, dt)
+            dd = _desc(dt, N, OH, OW, Cout, 0, False, OH, OW, Cin, KH, KW, 1, KH - 1 - pad, stride, Hin, Win, ACT_NONE, 0.0, C1)
+            dxv1 = torch.empty((N, Hin, Win, C1), dtype=x.dtype, device=x.device)
+            dxv2 = torch.empty((N, Hin, Win, C2), dtype=x.dtype, device=x.device) if C2 else None
+            _chk(lib.rd_conv_fwd(ctypes.byref(dd), _p(dy), None, _p(wpd), None, _p(dxv1), _p(dxv2), None, st), "rd_conv_fwd(dgrad)")
+            if is_up:
+                g1 = torch.empty_like(x)
+                _chk(lib.rd_upsample_nearest_bwd(_p(dxv1), _p(g1), N, H1, W1, Hin, Win, C1, dt, st), "rd_upsample_nearest_bwd")
+                g2 = None
+                if C2:
+                    g2 = torch.empty_like(x2)
+                    _chk(lib.rd_upsample_nearest_bwd(_p(dxv2), _p(g2), N, H1, W1, Hin, Win, C2, dt, st), "rd_upsample_nearest_bwd")
+            else:
+                g1, g2 = dxv1, dxv2
+            t.add_grad(x, g1)
+            t.add_grad(x2, g2)
+
+    t.record(backward)
+    return z
+
+
+def linear(x, weight, *, x2=None, bias=None, act=ACT_NONE, slope=0.2):
+    """Token/feature matrix (rows, C) -> (rows, Cout): nn.Linear as a 1x1 convolution over rows."""
+    rows = x.shape[0]
+    x4 = x.view(rows, 1, 1, x.shape[1])
+    x24 = None if x2 is None else x2.view(rows, 1, 1, x2.shape[1])
+    z = conv_block(x4, weight, x2=x24, bias=bias, stride=1, pad=0, act=act, slope=slope)
+    return _view2d(z, x4, x24)
+
+
+def _view2d(z4, x4, x24):
+    """(rows,1,1,C) -> (rows,C) keeping tape identity: register an alias node."""
+    t = tape()
+    z = z4.view(z4.shape[0], z4.shape[3])
+    if t is not None and id(z4) in t.req:
+        t.mark(z)
+
+        def backward():
+            g = t.pop_grad(z)
+            if g is not None:
+                t.add_grad(z4, g.view(z4.shape))
+        t.record(backward)
+    return z
+
+
+def alias(src, view):
+    """Register `view` (a reshaped view of `src`, same memory) on the tape so gradients flow back to `src`."""
+    t = tape()
+    if t is not None and id(src) in t.req:
+        t.mark(view)
+
+        def backward():
+            g = t.pop_grad(view)
+            if g is not None:
+                t.add_grad(src, g.reshape(src.shape))
+        t.record(backward)
+    return view
+
+
+# ------------------------------------------------------------------------------------------- pooling
+def maxpool(x, k=3, s=2, p=1):
+    lib, t, dt, st = L(), tape(), rd_of(x), _stream(x)
+    N, H, W, C = x.shape
+    OH, OW = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+    out = torch.empty((N, OH, OW, C), dtype=x.dtype, device=x.device)
+    arg = torch.empty((N, OH, OW, C), dtype=torch.uint8, device=x.device)
+    _chk(lib.rd_maxpool_fwd(_p(x), _p(out), _p(arg), N, H, W, C, OH, OW, k, s, p, dt, st), "rd_maxpool_fwd")
+    if t is not None and t.requires(x):
+        t.mark(out)
+
+        def backward():
+            g = t.pop_grad(out)
+            if g is None:
+                return
+            dx = torch.empty_like(x)
+            _chk(lib.rd_maxpool_bwd(_p(g), _p(arg), _p(dx), N, H, W, C, OH, OW, k, s, p, dt, st), "rd_maxpool_bwd")
+            t.add_grad(x, dx)
+        t.record(backward)
+    return out
+
+
+def roi_pool(x, rois, output_size, spatial_scale):
+    """x (N,H,W,C); rois (R,5) fp32 = (batch idx, x1, y1, x2, y2) -> (R,PH,PW,C) + int32 argmax."""
+    lib, t, dt, st = L(), tape(), rd_of(x), _stream(x)
+    N, H, W, C = x.shape
+    R = rois.shape[0]
+    PH, PW = int(output_size[0]), int(output_size[1])
+    out = torch.empty((R, PH, PW, C), dtype=x.dtype, device=x.device)
+    arg = torch.empty((R, PH, PW, C), dtype=torch.int32, device=x.device)
+    _chk(lib.rd_roi_pool_fwd(_p(x), _p(rois), _p(out), _p(arg), R, N, H, W, C, PH, PW, float(spatial_scale), dt, st), "rd_roi_pool_fwd")
+    out._rd_argmax = arg
+    if t is not None and t.requires(x):
+        t.mark(out)
+
+        def backward():
+            g = t.pop_grad(out)
+            if g is None:
+                return
+            dx32 = torch.empty((N, H, W, C), dtype=torch.float32, device=x.device)
+            _chk(lib.rd_roi_pool_bwd(_p(g), _p(rois), _p(arg), _p(dx32), R, N, H, W, C, PH, PW, dt, st), "rd_roi_pool_bwd")
+            t.add_grad(x, cast(dx32, x.dtype))
+        t.record(backward)
+    return out
+
+
+# ------------------------------------------------------------------------------------- token-level ops
+def layernorm(x, ln, residual=None):
+    """(rows, C) -> residual + LayerNorm(x) with ln.weight / ln.bias (torch.nn.LayerNorm as container)."""
+    lib, t, dt, st = L(), tape(), rd_of(x), _stream(x)
+    rows, C = x.shape
+    out = torch.empty_like(x)
+    stat = torch.empty((2, rows), dtype=torch.float32, device=x.device)
+    _chk(lib.rd_layernorm_fwd(_p(x), _p(ln.weight.detach()), _p(ln.bias.detach()), _p(residual), _p(out), _p(stat[0]), _p(stat[1]),
+                              rows, C, float(ln.eps), dt, st), "rd_layernorm_fwd")
+    if t is not None and (t.requires(x, residual) or ln.weight.requires_grad):
+        t.mark(out)
+
+        def backward():
+            g = t.pop_grad(out)
+            if g is None:
+                return
+            dx = torch.empty_like(x)
+            nb = lib.rd_layernorm_bwd_rows(rows)
+            part = torch.empty((nb, C, 2), dtype=torch.float32, device=x.device)
+            dg, acc = t.param_grad(ln.weight)
+            db, acc2 = t.param_grad(ln.bias)
+            _chk(lib.rd_layernorm_bwd(_p(g), _p(x), _p(ln.weight.detach()), _p(stat[0]), _p(stat[1]), _p(dx), _p(part), _p(dg), _p(db),
+                                      acc, rows, C, dt, st), "rd_layernorm_bwd")
+            t.add_grad(x, dx)
+            t.add_grad(residual, g)
+        t.record(backward)
+    return out
+
+
+def linear_attention(q, k, v, N, Lq, S, H, eps=1e-6):
+    """q (N*L, H*16), k/v (N*S, H*16) token matrices -> (N*L, H*16)."""
+    lib, t, dt, st = L(), tape(), rd_of(q), _stream(q)
+    C = q.shape[1]
+    assert C == H * 16, "linear_attention kernel is specialised for head dim 16"
+    out = torch.empty_like(q)
+    _chk(lib.rd_linear_attention_fwd(_p(q), _p(k), _p(v), _p(out), N, Lq, S, H, C, C, C, C, eps, dt, st), "rd_linear_attention_fwd")
+    if t is not None and t.requires(q, k, v):
+        t.mark(out)
+
+        def backward():
+            g = t.pop_grad(out)
+            if g is None:
+                return
+            dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+            _chk(lib.rd_linear_attention_bwd(_p(q), _p(k), _p(v), _p(g), _p(dq), _p(dk), _p(dv), N, Lq, S, H, C, C, C, C, eps, dt, st),
+                 "rd_linear_attention_bwd")
+            t.add_grad(q, dq)
+            t.add_grad(k, dk)
+            t.add_grad(v, dv)
+        t.record(backward)
+    return out
+
+
+def transpose_last2(x, B, R, Cc):
+    """contiguous [B][R][Cc] -> [B][Cc][R] (any leading shape; returns a flat (B, Cc, R) tensor)."""
+    lib, t, dt, st = L(), tape(), rd_of(x), _stream(x)
+    out = torch.empty((B, Cc, R), dtype=x.dtype, device=x.device)
+    _chk(lib.rd_transpose_last2(_p(x), _p(out), B, R, Cc, dt, st), "rd_transpose_last2")
+    if t is not None and t.requires(x):
+        t.mark(out)
+
+        def backward():
+            g = t.pop_grad(out)
+            if g is None:
+                return
+            dx = torch.empty_like(x)
+            _chk(lib.rd_transpose_last2(_p(g), _p(dx), B, Cc, R, dt, st), "rd_transpose_last2")
+            t.add_grad(x, dx)
+        t.record(backward)
+    return out
+
+
+def concat_channels(a, b):
+    """(..., Ca), (..., Cb) -> (..., Ca+Cb) on the innermost (channel) axis."""
+    lib, t, dt, st = L(), tape(), rd_of(a), _stream(a)
+    Ca, Cb = a.shape[-1], b.shape[-1]
+    rows = a.numel() // Ca
+    out = torch.empty(a.shape[:-1] + (Ca + Cb,), dtype=a.dtype, device=a.device)
+    _chk(lib.rd_concat2(_p(a), _p(b), _p(out), rows, Ca, Cb, dt, st), "rd_concat2")
+    if t is not None and t.requires(a, b):
+        t.mark(out)
+
+        def backward():
+            g = t.pop_grad(out)
+            if g is None:
+                return
+            ga, gb = torch.empty_like(a), torch.empty_like(b)
+            _chk(lib.rd_split2(_p(g), _p(ga), _p(gb), rows, Ca, Cb, dt, st), "rd_split2")
+            t.add_grad(a, ga)
+            t.add_grad(b, gb)
+        t.record(backward)
+    return out
+
+
+def input_cast(x, scale=1.0):
+    """Region input (fp32) -> activation dtype; gradient flows back as fp32."""
+    t = tape()
+    out = to_act(x, scale)
+    if out is x:
+        return x
+    if t is not None and t.requires(x):
+        t.mark(out)
+
+        def backward():
+            g = t.pop_grad(out)
+            if g is not None:
+                t.add_grad(x, cast(g, x.dtype, scale))
+        t.record(backward)
+    return out
+
+
+def output_cast(x, dtype):
+    t = tape()
+    out = cast(x, dtype)
+    if out is x:
+        return x
+    if t is not None and t.requires(x):
+        t.mark(out)
+
+        def backward():
+            g = t.pop_grad(out)
+            if g is not None:
+                t.add_grad(x, cast(g, x.dtype))
+        t.record(backward)
+    return out
+
+
+def add_act(a, b, act=ACT_NONE, slope=0.2):
+    """act(a + b) on same-shape NHWC tensors (ResNet block tail, utils/net_utils.py:323)."""
+    lib, t, dt, st = L(), tape(), rd_of(a), _stream(a)
+    C = a.shape[-1]
+    out = torch.empty_like(a)
+    _chk(lib.rd_affine_act(_p(a), None, None, _p(b), _p(out), a.numel() // C, C, act, slope, dt, st), "rd_affine_act")
+    if t is not None and t.requires(a, b):
+        t.mark(out)
+
+        def backward():
+            g = t.pop_grad(out)
+            if g is None:
+                return
+            if act != ACT_NONE:
+                d = torch.empty_like(g)
+                _chk(lib.rd_act_bwd(_p(g), _p(out), _p(d), g.numel(), act, slope, dt, st), "rd_act_bwd")
+            else:
+                d = g
+            t.add_grad(a, d)
+            t.add_grad(b, d)
+        t.record(backward)
+    return out
+
+
+def from_nchw(x, scale=1.0, dtype=None):
+    """Region input, logical NCHW (contiguous or channels_last, fp32 or act dtype) -> (N,H,W,C) engine tensor."""
+    t = tape()
+    out = nchw_to_nhwc(x, scale, dtype)
+    if t is not None and t.requires(x):
+        t.mark(out)
+
+        def backward():
+            g = t.pop_grad(out)
+            if g is None:
+                return
+            gi = torch.empty_strided(x.shape, x.stride(), dtype=x.dtype, device=x.device)
+            n, c, h, w = x.shape
+            if x.permute(0, 2, 3, 1).is_contiguous():
+                _chk(L().rd_cast(_p(g), _p(gi), g.numel(), rd_of(g), rd_of(gi), float(scale), _stream(g)), "rd_cast")
+            else:
+                assert scale == 1.0
+                _chk(L().rd_nhwc_to_nchw(_p(g), _p(gi), n, c, h, w, rd_of(g), rd_of(gi), _stream(g)), "rd_nhwc_to_nchw")
+            t.add_grad(x, gi)
+        t.record(backward)
+    return out
+
+
+def to_nchw_out(z, dtype=None):
+    """(N,H,W,C) engine tensor -> logical NCHW region output (channels_last view, optionally cast)."""
+    t = tape()
+    zc = z if dtype is None else cast(z, dtype)
+    out = zc.permute(0, 3, 1, 2)
+    if t is not None and t.requires(z):
+        t.mark(out)
+
+        def backward():
+            g = t.pop_grad(out)
+            if g is not None:
+                t.add_grad(z, cast(g.permute(0, 2, 3, 1), z.dtype))
+        t.record(backward)
+    return out
+
+
+def tokens_in(x, C):
+    """Region input [..., C-ish] (any leading shape) -> contiguous (rows, C) token matrix in the activation dtype."""
+    xc = x if x.is_contiguous() else x.contiguous()
+    v = alias(x, xc.view(-1, C))
+    return input_cast(v)
+
+
+def alias_cast_view(o, dtype, shape):
+    """(rows, C) engine tensor -> region output of `dtype` viewed as `shape` (same element order)."""
+    t = tape()
+    out = cast(o, dtype).view(shape)
+    if t is not None and t.requires(o):
+        t.mark(out)
+
+        def backward():
+            g = t.pop_grad(out)
+            if g is not None:
+                gc = g if g.is_contiguous() else g.contiguous()
+                t.add_grad(o, cast(gc.view(o.shape), o.dtype))
+        t.record(backward)
+    return out
+
+
+def sigmoid(x):
+    out = torch.empty_like(x)
+    _chk(L().rd_sigmoid(_p(x), _p(out), x.numel(), rd_of(x), _stream(x)), "rd_sigmoid")
+    return out
+
+
+# ----------------------------------------------------------------------------------------- RC-Net loss
+def rcnet_labels(ground_truth_depth, radar_points, max_distance, all_valid=False):
+    """RCNet/rcnet_main.py:308-332: gt (R,1,H,W) fp32, points (R,3) -> (label, validity) fp32 tensors."""
+    R = ground_truth_depth.shape[0]
+    hw = ground_truth_depth.numel() // max(R, 1)
+    gt = ground_truth_depth if ground_truth_depth.is_contiguous() else ground_truth_depth.contiguous()
+    pts = radar_points if radar_points.is_contiguous() else radar_points.contiguous()
+    label, valid = torch.empty_like(gt), torch.empty_like(gt)
+    _chk(L().rd_rcnet_labels(_p(gt), _p(pts), _p(label), _p(valid), R, hw, float(max_distance), 1 if all_valid else 0,
+                             _stream(gt)), "rd_rcnet_labels")
+    return label, valid
+
+
+def bce_masked(logits, label, valid, pos_weight):
+    """sum(valid * BCEWithLogits(logits, label, pos_weight)) / sum(valid) as a 0-dim fp32 tensor."""
+    lib, t, st = L(), tape(), _stream(logits)
+    lg = logits if logits.is_contiguous() else logits.contiguous()  # (R,1,H,W): C == 1, NCHW == NHWC
+    lg = alias(logits, lg) if lg is not logits else lg
+    n = lg.numel()
+    rows = lib.rd_bce_rows(n)
+    partial = torch.empty((rows, 2), dtype=torch.float32, device=lg.device)
+    out = torch.empty(3, dtype=torch.float32, device=lg.device)  # [loss, sum valid*bce, sum valid]
+    loss, sums = out[0:1], out[1:3]
+    _chk(lib.rd_bce_masked_fwd(_p(lg), _p(label), _p(valid), float(pos_weight), _p(partial), _p(loss), _p(sums), n, rd_of(lg), st),
+         "rd_bce_masked_fwd")
+    res = out[0]
+    if t is not None and t.requires(lg):
+        t.mark(res)
+
+        def backward():
+            g = t.pop_grad(res)
+            if g is None:
+                return
+            g32 = g if g.dtype == torch.float32 else cast(g.reshape(1), torch.float32)
+            d = torch.empty_like(lg)
+            _chk(lib.rd_bce_masked_bwd(_p(lg), _p(label), _p(valid), float(pos_weight), _p(sums), _p(g32), _p(d), n, rd_of(lg), st),
+                 "rd_bce_masked_bwd")
+            t.add_grad(lg, d)
+        t.record(backward)
+    return res

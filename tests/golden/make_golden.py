@@ -1,0 +1,196 @@
+"""Generate golden vectors by IMPORTING THE REFERENCE (/root/reference) in the build container.
+
+Run here only:  python tests/golden/make_golden.py
+The reference cannot travel to the GPU box; what is committed is data: seeds, shapes, outputs, gradient summaries.
+Weights and inputs are regenerated from names+seeds by `tests/golden/fill.py` on both sides, so fixtures stay
+small.  torchvision / cv2 / tensorboard are absent here: tests/golden/stubs provides import stubs (torchvision's
+roi_pool is the oracle's restatement -- third-party arithmetic that the reference itself cannot pin).
+"""
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.abspath(os.path.join(HERE, "..", ".."))
+sys.path[:0] = [ROOT, os.path.join(HERE, "stubs"), "/root/reference", "/root/reference/RCNet"]
+tb = types.ModuleType("torch.utils.tensorboard")
+tb.SummaryWriter = object
+sys.modules["torch.utils.tensorboard"] = tb
+
+from tests.golden.fill import fill_state_dict, rand_array  # noqa: E402
+
+torch.manual_seed(0)
+torch.set_num_threads(8)
+
+
+def t(a):
+    return torch.from_numpy(np.ascontiguousarray(a))
+
+
+def grad_summary(named):
+    out = {}
+    for k, p in named:
+        if p.grad is None:
+            out[k + "|none"] = np.zeros(1, np.float32)
+        else:
+            g = p.grad.detach().float().reshape(-1)
+            out[k + "|norm"] = np.array([g.norm().item()], np.float32)
+            out[k + "|head"] = g[:16].numpy().copy()
+    return out
+
+
+def save(name, **arrs):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **arrs)
+    print("%-28s %7.1f KB" % (name, os.path.getsize(path) / 1024))
+
+
+# ---------------------------------------------------------------------------------------------- G1 / G2
+def g_attention():
+    import linear_attention as la
+    N, L, S, H, D = 4, 21, 21, 8, 16
+    q, k, v = [t(rand_array("g1." + n, (N, L if n == "q" else S, H, D), 1.0)).requires_grad_() for n in "qkv"]
+    out = la.LinearAttention()(q, k, v)
+    w = t(rand_array("g1.w", out.shape, 1.0))
+    (out * w).sum().backward()
+    save("g1_linear_attention", out=out.detach().numpy(), dq=q.grad.numpy(), dk=k.grad.numpy(), dv=v.grad.numpy())
+
+    layer = la.LoFTREncoderLayer(128, 8)
+    fill_state_dict(layer, "g2.layer")
+    x = t(rand_array("g2.x", (3, 21, 128), 1.0)).requires_grad_()
+    s = t(rand_array("g2.s", (3, 21, 128), 1.0)).requires_grad_()
+    o = layer(x, s)
+    (o * t(rand_array("g2.w", o.shape, 1.0))).sum().backward()
+    save("g2_loftr_layer", out=o.detach().numpy(), dx=x.grad.numpy(), ds=s.grad.numpy(),
+         **grad_summary(layer.named_parameters()))
+
+    tf = la.LocalFeatureTransformer(['self', 'cross'], n_layers=4, d_model=128)
+    fill_state_dict(tf, "g2.tf")
+    a = t(rand_array("g2.a", (2, 21, 128), 1.0)).requires_grad_()
+    b = t(rand_array("g2.b", (2, 21, 128), 1.0)).requires_grad_()
+    o0, o1 = tf(a, b)
+    ((o0 * t(rand_array("g2.w0", o0.shape, 1.0))).sum() + (o1 * t(rand_array("g2.w1", o1.shape, 1.0))).sum()).backward()
+    save("g2_transformer", out0=o0.detach().numpy(), out1=o1.detach().numpy(), da=a.grad.numpy(), db=b.grad.numpy(),
+         **grad_summary(tf.named_parameters()))
+
+
+# --------------------------------------------------------------------------------------------------- G3
+def g_resnet_encoder():
+    import networks
+    enc = networks.ResNetEncoder(n_layer=18, input_channels=3, n_filters=[32, 64, 128, 128, 128],
+                                 weight_initializer='kaiming_uniform', activation_func='leaky_relu', use_batch_norm=True)
+    fill_state_dict(enc, "g3.enc")
+    x = t(rand_array("g3.x", (2, 3, 96, 128), 1.0, lo=0.0))
+    enc.train()
+    latent, skips = enc(x)
+    loss = (latent * t(rand_array("g3.wl", latent.shape, 1.0))).sum()
+    for i, s in enumerate(skips):
+        loss = loss + (s * t(rand_array("g3.ws%d" % i, s.shape, 1.0))).sum() * 0.1
+    loss.backward()
+    sd = enc.state_dict()
+    arrs = dict(latent=latent.detach().numpy(), skip3=skips[3].detach().numpy(),
+                skip0_sub=skips[0].detach().numpy()[:, ::4, ::4, ::4].copy(),
+                rm=sd['blocks3.0.conv1.batch_norm.running_mean'].numpy(), rv=sd['blocks3.0.conv1.batch_norm.running_var'].numpy(),
+                rm1=sd['conv1.batch_norm.running_mean'].numpy(), rv1=sd['conv1.batch_norm.running_var'].numpy())
+    arrs.update(grad_summary(enc.named_parameters()))
+    enc.eval()
+    with torch.no_grad():
+        le, _ = enc(x)
+    arrs["latent_eval"] = le.numpy()
+    save("g3_resnet_encoder", **arrs)
+
+
+# --------------------------------------------------------------------------------------------------- G5
+def g_decoder():
+    import networks
+    for tag, patch, R in (("small", (64, 32), 2), ("zju", (240, 100), 1)):
+        dec = networks.MultiScaleDecoder(input_channels=256, output_channels=1, n_resolution=1,
+                                         n_filters=[256, 128, 64, 32, 16], n_skips=[128, 128, 64, 32, 0],
+                                         weight_initializer='kaiming_uniform', activation_func='leaky_relu',
+                                         output_func='linear', use_batch_norm=True, deconv_type='up')
+        fill_state_dict(dec, "g5.dec")
+        lh, lw = patch[0] // 32, patch[1] // 32
+        sizes = [(int(patch[0] * s), int(patch[1] * s)) for s in (1 / 2., 1 / 4., 1 / 8., 1 / 16.)]
+        chans = [32, 64, 128, 128]
+        x = t(rand_array("g5.%s.x" % tag, (R, 256, lh, lw), 1.0)).requires_grad_()
+        skips = [t(rand_array("g5.%s.s%d" % (tag, i), (R, chans[i]) + sizes[i], 1.0)).requires_grad_() for i in range(4)]
+        dec.train()
+        out = dec(x, skips, shape=patch)[-1]
+        (out * t(rand_array("g5.%s.w" % tag, out.shape, 1.0))).sum().backward()
+        arrs = dict(out=out.detach().numpy(), dx=x.grad.numpy(), ds3=skips[3].grad.numpy(),
+                    ds0_sub=skips[0].grad.numpy()[:, ::4, ::4, ::4].copy())
+        arrs.update(grad_summary(dec.named_parameters()))
+        save("g5_decoder_" + tag, **arrs)
+
+
+# ------------------------------------------------------------------------------------------------- G6 / G10
+def g_rcnet_e2e():
+    import rcnet_model
+    import rcnet_main
+    patch = [64, 32]
+    model = rcnet_model.RCNetModel(3, 3, patch, ['rcnet', 'batch_norm'], [32, 64, 128, 128, 128], [32, 64, 128, 128, 128],
+                                   ['multiscale', 'batch_norm'], [256, 128, 64, 32, 16], device=torch.device('cpu'))
+    fill_state_dict(model.encoder, "g6.enc")
+    fill_state_dict(model.decoder, "g6.dec")
+    B, K, H, W = 2, 3, 64, 96
+    pad_y, pad_x = patch[0] // 2, patch[1] // 2
+    img = t(rand_array("g6.img", (B, 3, H, W), 1.0, lo=0.0))
+    img = torch.nn.functional.pad(img, (pad_x, pad_x, pad_y, pad_y), mode='replicate')
+    rs = np.random.RandomState(606)
+    pts = np.stack([rs.randint(0, W, (B, K)) + pad_x, rs.randint(0, H, (B, K)) + pad_y, rs.uniform(1.5, 30.0, (B, K))], -1).astype(np.float32)
+    boxes = np.stack([pts[..., 0] - pad_x, pts[..., 1] - pad_y, pts[..., 0] + pad_x, pts[..., 1] + pad_y], -1).astype(np.float32)
+    gt = rand_array("g6.gt", (B * K, 1, patch[0], patch[1]), 1.0, lo=0.0) * 30.0
+    gt[rand_array("g6.gtm", gt.shape, 1.0, lo=0.0) < 0.5] = 0.0
+    z = pts[..., 2].reshape(-1)
+    for r in range(B * K):  # make some positives
+        gt[r, 0, ::3, ::2] = np.where(gt[r, 0, ::3, ::2] > 0, z[r] + 0.2, 0.0)
+    gt_t, pts_t = t(gt), t(pts).view(B * K, 3)
+
+    # label build exactly as rcnet_main.train :308-332 (copied call pattern, executed on the reference's ops)
+    radar_depth = pts_t[..., 2].view(pts_t.shape[0], 1, 1, 1)
+    dist = torch.abs(gt_t - radar_depth * torch.ones_like(gt_t))
+    label = torch.where(dist < 0.5, torch.ones_like(gt_t), torch.zeros_like(gt_t))
+    label = torch.where(gt_t > 0, label, torch.zeros_like(label))
+    valid = torch.where(gt_t <= 0, torch.zeros_like(gt_t), torch.ones_like(gt_t))
+
+    model.train()
+    blist = [t(boxes[i]) for i in range(B)]
+    logits = model.forward(img, pts_t, blist, return_logits=True)
+    loss, _ = model.compute_loss(logits=logits, ground_truth=label.float(), validity_map=valid, w_positive_class=2.5)
+    loss.backward()
+    arrs = dict(pts=pts, boxes=boxes, logits=logits.detach().numpy(), loss=np.array([loss.item()], np.float32),
+                label=label.numpy().astype(np.uint8), valid=valid.numpy().astype(np.uint8))
+    arrs.update({"enc." + k: v for k, v in grad_summary(model.encoder.named_parameters()).items()})
+    arrs.update({"dec." + k: v for k, v in grad_summary(model.decoder.named_parameters()).items()})
+    save("g6_rcnet_e2e", **arrs)
+
+    # G10: the reference's own forward_output (rcnet_main.py:435-487) in eval mode on one unpadded image
+    model.eval()
+    with torch.no_grad():
+        img1 = t(rand_array("g10.img", (1, 3, H, W), 1.0, lo=0.0))
+        N = 7
+        rs = np.random.RandomState(1010)
+        p1 = np.stack([rs.randint(0, W, N) + pad_x, rs.randint(0, H, N) + pad_y, rs.uniform(1.5, 30.0, N)], -1).astype(np.float32)
+        b1 = np.stack([p1[:, 0] - pad_x, p1[:, 1] - pad_y, p1[:, 0] + pad_x, p1[:, 1] + pad_y], -1).astype(np.float32)
+        depth, resp = rcnet_main.forward_output(model, img1, t(p1), [t(b1)], response_thr=0.5, device=torch.device('cpu'))
+        img1p = torch.nn.functional.pad(img1, (pad_x, pad_x, pad_y, pad_y), mode='replicate')
+        crops = model.forward(img1p, t(p1), [t(b1)], return_logits=False)
+        thr = float(np.median(crops.numpy()))  # a threshold that splits the responses
+        depth2, resp2 = rcnet_main.forward_output(model, img1, t(p1), [t(b1)], response_thr=thr, device=torch.device('cpu'))
+    save("g10_forward_output", pts=p1, boxes=b1, crops=crops.numpy(), depth=depth.numpy(), resp=resp.numpy(),
+         thr2=np.array([thr], np.float32), depth2=depth2.numpy(), resp2=resp2.numpy())
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["attention", "resnet", "decoder", "e2e"]
+    if "attention" in which:
+        g_attention()
+    if "resnet" in which:
+        g_resnet_encoder()
+    if "decoder" in which:
+        g_decoder()
+    if "e2e" in which:
+        g_rcnet_e2e()

@@ -1,0 +1,9 @@
+import torch.nn.functional as F
+
+
+def pad(img, padding, fill=0, padding_mode='constant'):
+    l, t, r, b = padding
+    mode = {'edge': 'replicate', 'constant': 'constant', 'reflect': 'reflect'}[padding_mode]
+    x = img if img.dim() == 4 else img.unsqueeze(0)
+    y = F.pad(x, (l, r, t, b), mode=mode) if mode != 'constant' else F.pad(x, (l, r, t, b), value=fill)
+    return y if img.dim() == 4 else y.squeeze(0)
