@@ -394,25 +394,10 @@ def conv_block(x, weight, *, x2=None, bias=None, stride=1, pad=None, up=None, bn
 def linear(x, weight, *, x2=None, bias=None, act=ACT_NONE, slope=0.2):
     """Token/feature matrix (rows, C) -> (rows, Cout): nn.Linear as a 1x1 convolution over rows."""
     rows = x.shape[0]
-    x4 = x.view(rows, 1, 1, x.shape[1])
-    x24 = None if x2 is None else x2.view(rows, 1, 1, x2.shape[1])
+    x4 = alias(x, x.view(rows, 1, 1, x.shape[1]))
+    x24 = None if x2 is None else alias(x2, x2.view(rows, 1, 1, x2.shape[1]))
     z = conv_block(x4, weight, x2=x24, bias=bias, stride=1, pad=0, act=act, slope=slope)
-    return _view2d(z, x4, x24)
-
-
-def _view2d(z4, x4, x24):
-    """(rows,1,1,C) -> (rows,C) keeping tape identity: register an alias node."""
-    t = tape()
-    z = z4.view(z4.shape[0], z4.shape[3])
-    if t is not None and id(z4) in t.req:
-        t.mark(z)
-
-        def backward():
-            g = t.pop_grad(z)
-            if g is not None:
-                t.add_grad(z4, g.view(z4.shape))
-        t.record(backward)
-    return z
+    return alias(z, z.view(rows, z.shape[3]))
 
 
 def alias(src, view):

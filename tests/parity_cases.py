@@ -1,0 +1,377 @@
+"""Device-agnostic parity cases: riders_amd (HIP kernels through the C ABI) vs the oracle on identical inputs.
+
+The same functions run (a) on the GPU box against libriders_hip.so (`-m gpu`, the parity tests proper) and
+(b) in the GPU-less build container against the fiber-emulator build of the same kernel sources (tests/emu),
+which only checks kernel/host logic.  Tolerance: 1e-3 relative to max|ref| for fp32 (north_star), bit-exact
+for index outputs (roi_pool argmax, crop-scatter support set, labels).
+"""
+import os
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from oracle import rcnet as O
+from tests.golden.fill import fill_state_dict, rand_array
+
+G = os.path.join(os.path.dirname(__file__), "golden")
+TOL = 1e-3
+
+
+def t(a, dev=None):
+    x = torch.from_numpy(np.ascontiguousarray(a))
+    return x if dev is None else x.to(dev)
+
+
+def load(name):
+    return dict(np.load(os.path.join(G, name + ".npz")))
+
+
+def close(a, b, tol=TOL, what=""):
+    a = a.detach().float().cpu().numpy().astype(np.float64) if torch.is_tensor(a) else np.asarray(a, np.float64)
+    b = b.detach().float().cpu().numpy().astype(np.float64) if torch.is_tensor(b) else np.asarray(b, np.float64)
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    assert np.isfinite(a).all(), what + ": non-finite values"
+    err = np.abs(a - b).max() / max(np.abs(b).max(), 1e-6)
+    assert err < tol, "%s: max err / max|ref| = %.3e (tol %.1e)" % (what, err, tol)
+
+
+def leaves(sd):
+    return {k: v.detach().cpu().clone().requires_grad_(v.is_floating_point() and "running" not in k) for k, v in sd.items()}
+
+
+def compare_param_grads(module, sd_oracle, tol=TOL, prefix=""):
+    n = 0
+    for k, p in module.named_parameters():
+        ref = sd_oracle[prefix + k].grad
+        if ref is None:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, "unexpected grad for " + k
+            continue
+        assert p.grad is not None, "missing grad for " + k
+        close(p.grad, ref, tol, "grad " + k)
+        n += 1
+    return n
+
+
+# ------------------------------------------------------------------------------------------------ conv family
+CONV_CASES = [
+    # Cin, Cout, k, stride, H, W, N, bn, act
+    dict(cin=16, cout=16, k=3, s=1, H=9, W=7, N=2, bn=True),
+    dict(cin=32, cout=64, k=3, s=2, H=10, W=13, N=2, bn=True),
+    dict(cin=3, cout=32, k=7, s=2, H=20, W=18, N=1, bn=True),
+    dict(cin=64, cout=128, k=1, s=2, H=9, W=8, N=2, bn=False, act=None),
+    dict(cin=16, cout=1, k=3, s=1, H=12, W=10, N=2, bn=False, act=None),
+    dict(cin=128, cout=256, k=3, s=1, H=5, W=6, N=1, bn=True),
+]
+
+
+def conv_case(dev, c, tol=TOL):
+    from riders_amd import net_utils
+    act = net_utils.activation_func('leaky_relu') if c.get("act", "lrelu") else None
+    m = net_utils.Conv2d(c["cin"], c["cout"], c["k"], c["s"], 'kaiming_uniform', act, c["bn"]).to(dev)
+    tag = "conv.%d.%d.%d" % (c["cin"], c["cout"], c["k"])
+    sd = leaves(fill_state_dict(m, tag))
+    x = t(rand_array(tag + ".x", (c["N"], c["cin"], c["H"], c["W"]), 1.0))
+    xr = x.clone().requires_grad_()
+    ref = O.conv_bn_act(xr, sd, "", c["s"], use_bn=c["bn"], act=act is not None, training=True)
+    w = t(rand_array(tag + ".w", ref.shape, 1.0))
+    (ref * w).sum().backward()
+    xd = x.to(dev).requires_grad_()
+    m.train()
+    out = m(xd)
+    assert out.shape == ref.shape
+    close(out, ref, tol, tag + " fwd")
+    (out * w.to(dev)).sum().backward()
+    close(xd.grad, xr.grad, tol, tag + " dx")
+    compare_param_grads(m, sd, tol)
+    if c["bn"]:
+        close(m.batch_norm.running_mean, sd["batch_norm.running_mean"], tol, "running_mean")
+        close(m.batch_norm.running_var, sd["batch_norm.running_var"], tol, "running_var")
+        assert int(m.state_dict()["batch_norm.num_batches_tracked"]) == 1
+
+
+def decoder_block_case(dev, cin=32, cskip=16, cout=16, hs=(4, 3), hv=(9, 6), N=2, tol=TOL):
+    """nearest up (non-integer ratio) + concat folded into the conv gather, both backward paths."""
+    from riders_amd import net_utils
+    act = net_utils.activation_func('leaky_relu')
+    m = net_utils.DecoderBlock(cin, cskip, cout, 'kaiming_uniform', act, True, 'up').to(dev)
+    sd = leaves(fill_state_dict(m, "decblk"))
+    x = t(rand_array("decblk.x", (N, cin) + hs, 1.0))
+    s = t(rand_array("decblk.s", (N, cskip) + hv, 1.0))
+    xr, sr = x.clone().requires_grad_(), s.clone().requires_grad_()
+    ref = O.decoder_block(xr, sr if cskip else None, hv, sd, "")
+    w = t(rand_array("decblk.w", ref.shape, 1.0))
+    (ref * w).sum().backward()
+    xd, sdv = x.to(dev).requires_grad_(), s.to(dev).requires_grad_()
+    m.train()
+    out = m(xd, sdv) if cskip else m(xd, shape=hv)
+    close(out, ref, tol, "decoder block fwd")
+    (out * w.to(dev)).sum().backward()
+    close(xd.grad, xr.grad, tol, "decoder block dx")
+    if cskip:
+        close(sdv.grad, sr.grad, tol, "decoder block dskip")
+    compare_param_grads(m, sd, tol)
+
+
+def resnet_block_case(dev, cin=16, cout=32, stride=2, tol=TOL):
+    from riders_amd import net_utils
+    act = net_utils.activation_func('leaky_relu')
+    m = net_utils.ResNetBlock(cin, cout, stride, 'kaiming_uniform', act, True).to(dev)
+    sd = leaves(fill_state_dict(m, "resblk"))
+    x = t(rand_array("resblk.x", (2, cin, 9, 11), 1.0))
+    xr = x.clone().requires_grad_()
+    ref = O.resnet_block(xr, sd, "", stride)
+    w = t(rand_array("resblk.w", ref.shape, 1.0))
+    (ref * w).sum().backward()
+    xd = x.to(dev).requires_grad_()
+    m.train()
+    out = m(xd)
+    close(out, ref, tol, "resnet block fwd")
+    (out * w.to(dev)).sum().backward()
+    close(xd.grad, xr.grad, tol, "resnet block dx")
+    compare_param_grads(m, sd, tol)
+
+
+# -------------------------------------------------------------------------------------------- attention / LoFTR
+def linear_attention_case(dev, N=3, L=21, S=21, tol=TOL):
+    from riders_amd.linear_attention import LinearAttention
+    H, D = 8, 16
+    q = t(rand_array("la.q", (N, L, H, D), 1.5)); k = t(rand_array("la.k", (N, S, H, D), 1.5)); v = t(rand_array("la.v", (N, S, H, D), 1.0))
+    qr, kr, vr = [a.clone().requires_grad_() for a in (q, k, v)]
+    ref = O.linear_attention(qr, kr, vr)
+    w = t(rand_array("la.w", ref.shape, 1.0))
+    (ref * w).sum().backward()
+    qd, kd, vd = [a.to(dev).requires_grad_() for a in (q, k, v)]
+    out = LinearAttention()(qd, kd, vd)
+    close(out, ref, tol, "linear attention fwd")
+    (out * w.to(dev)).sum().backward()
+    close(qd.grad, qr.grad, tol, "dq"); close(kd.grad, kr.grad, tol, "dk"); close(vd.grad, vr.grad, tol, "dv")
+
+
+def golden_attention_case(dev, tol=TOL):
+    """HIP path vs the REFERENCE's own outputs (fixture g1, g2)."""
+    from riders_amd.linear_attention import LinearAttention, LoFTREncoderLayer
+    g = load("g1_linear_attention")
+    q, k, v = [t(rand_array("g1." + n, (4, 21, 8, 16), 1.0), dev).requires_grad_() for n in "qkv"]
+    out = LinearAttention()(q, k, v)
+    close(out, g["out"], tol, "g1 out")
+    (out * t(rand_array("g1.w", out.shape, 1.0), dev)).sum().backward()
+    close(q.grad, g["dq"], tol, "g1 dq"); close(k.grad, g["dk"], tol, "g1 dk"); close(v.grad, g["dv"], tol, "g1 dv")
+    g = load("g2_loftr_layer")
+    layer = LoFTREncoderLayer(128, 8).to(dev)
+    fill_state_dict(layer, "g2.layer")
+    x = t(rand_array("g2.x", (3, 21, 128), 1.0), dev).requires_grad_()
+    s = t(rand_array("g2.s", (3, 21, 128), 1.0), dev).requires_grad_()
+    o = layer(x, s)
+    close(o, g["out"], tol, "g2 out")
+    (o * t(rand_array("g2.w", o.shape, 1.0), dev)).sum().backward()
+    close(x.grad, g["dx"], tol, "g2 dx"); close(s.grad, g["ds"], tol, "g2 ds")
+    for kname, p in layer.named_parameters():
+        gg = p.grad.reshape(-1)
+        close(gg[:16], g[kname + "|head"], 2 * tol, "g2 grad " + kname)
+
+
+def transformer_case(dev, N=2, n_layers=1, tol=TOL):
+    from riders_amd.linear_attention import LocalFeatureTransformer
+    m = LocalFeatureTransformer(['self', 'cross'], n_layers=n_layers, d_model=128).to(dev)
+    sd = leaves(fill_state_dict(m, "tf%d" % n_layers))
+    a = t(rand_array("tf.a", (N, 21, 128), 1.0)); b = t(rand_array("tf.b", (N, 21, 128), 1.0))
+    ar, br = a.clone().requires_grad_(), b.clone().requires_grad_()
+    r0, r1 = O.local_feature_transformer(ar, br, sd, "", ('self', 'cross') * n_layers)
+    w0, w1 = t(rand_array("tf.w0", r0.shape, 1.0)), t(rand_array("tf.w1", r1.shape, 1.0))
+    ((r0 * w0).sum() + (r1 * w1).sum()).backward()
+    ad, bd = a.to(dev).requires_grad_(), b.to(dev).requires_grad_()
+    o0, o1 = m(ad, bd)
+    close(o0, r0, tol, "tf out0"); close(o1, r1, tol, "tf out1")
+    ((o0 * w0.to(dev)).sum() + (o1 * w1.to(dev)).sum()).backward()
+    close(ad.grad, ar.grad, tol, "tf da"); close(bd.grad, br.grad, tol, "tf db")
+    compare_param_grads(m, sd, tol)
+
+
+# ---------------------------------------------------------------------------------------------- pooling etc.
+def roi_pool_case(dev):
+    """argmax indices bit-exact against the oracle; KATs from tests/golden/roi_pool_kat.json are checked in test_abi."""
+    from riders_amd import engine
+    rs = np.random.RandomState(11)
+    N, C, H, W = 2, 8, 15, 19
+    x = t(rs.randn(N, C, H, W).astype(np.float32))
+    rois = np.array([[0, 0, 0, 18, 14], [1, 2.5, 3.5, 9.4, 8.6], [0, 7, 5, 7, 5], [1, -3, -2, 4, 30], [0, 18.5, 14.5, 22, 16],
+                     [1, 4, 4, 13, 12], [0, 1, 1, 17, 13]], np.float32)
+    for scale, (PH, PW) in ((1.0, (3, 2)), (0.5, (4, 3)), (1.0, (7, 9))):
+        xr = x.clone().requires_grad_()
+        ref, arg = O.roi_pool(xr, t(rois), scale, (PH, PW), return_argmax=True)
+        w = t(rs.randn(*ref.shape).astype(np.float32))
+        (ref * w).sum().backward()
+        xd = x.to(dev).permute(0, 2, 3, 1).contiguous()          # NHWC engine tensor
+        tape = engine.Tape(); tape.mark(xd)
+        with engine._active(tape):
+            out = engine.roi_pool(xd, t(rois, dev), (PH, PW), scale)
+            tape.grads[id(out)] = w.to(dev).permute(0, 2, 3, 1).contiguous()
+            tape.backward()
+        assert torch.equal(out._rd_argmax.permute(0, 3, 1, 2).cpu(), arg), "roi_pool argmax differs"
+        assert torch.equal(out.permute(0, 3, 1, 2).cpu(), ref.detach()), "roi_pool values differ"
+        close(tape.grads[id(xd)].permute(0, 3, 1, 2), xr.grad, 1e-5, "roi_pool bwd")
+
+
+def maxpool_case(dev):
+    from riders_amd import engine
+    x = t(rand_array("mp.x", (2, 8, 13, 10), 1.0))
+    xr = x.clone().requires_grad_()
+    ref = F.max_pool2d(xr, 3, 2, 1)
+    w = t(rand_array("mp.w", ref.shape, 1.0))
+    (ref * w).sum().backward()
+    xd = x.to(dev).permute(0, 2, 3, 1).contiguous()
+    tape = engine.Tape(); tape.mark(xd)
+    with engine._active(tape):
+        out = engine.maxpool(xd, 3, 2, 1)
+        tape.grads[id(out)] = w.to(dev).permute(0, 2, 3, 1).contiguous()
+        tape.backward()
+    assert torch.equal(out.permute(0, 3, 1, 2).cpu(), ref.detach())
+    close(tape.grads[id(xd)].permute(0, 3, 1, 2), xr.grad, 1e-6, "maxpool bwd")
+
+
+def labels_loss_case(dev, tol=1e-4):
+    from riders_amd import engine
+    from riders_amd.rcnet_model import RCNetModel
+    R, H, W = 5, 12, 9
+    gt = rand_array("ll.gt", (R, 1, H, W), 30.0, lo=0.0)
+    gt[rand_array("ll.m", gt.shape, 1.0, lo=0.0) < 0.4] = 0.0
+    pts = np.stack([rand_array("ll.px", (R,), 50.0, lo=0.0), rand_array("ll.py", (R,), 50.0, lo=0.0), rand_array("ll.pz", (R,), 30.0, lo=0.0)], -1)
+    gt[:, 0, ::2, ::2] = np.where(gt[:, 0, ::2, ::2] > 0, pts[:, 2][:, None, None] + 0.3, 0)
+    lr, vr = O.rcnet_labels(t(gt), t(pts), 0.5)
+    ld, vd = engine.rcnet_labels(t(gt, dev), t(pts, dev), 0.5)
+    assert torch.equal(ld.cpu(), lr) and torch.equal(vd.cpu(), vr), "labels / validity differ"
+    assert float(lr.sum()) > 0
+    logits = t(rand_array("ll.lg", (R, 1, H, W), 3.0))
+    xr = logits.clone().requires_grad_()
+    ref = O.rcnet_loss(xr, lr, vr, 2.5)
+    (ref * 1.7).backward()
+    xd = logits.to(dev).requires_grad_()
+    model = RCNetModel.__new__(RCNetModel)
+    loss, info = RCNetModel.compute_loss(model, xd, ld, vd, 2.5)
+    assert abs(float(loss) - float(ref)) < tol * abs(float(ref))
+    (loss * 1.7).backward()
+    close(xd.grad, xr.grad, tol, "bce grad")
+
+
+def scatter_crops_case(dev):
+    """HIP scatter vs the REFERENCE's own forward_output results (fixture g10): exact support set."""
+    import ctypes
+    from riders_amd import engine
+    g = load("g10_forward_output")
+    patch, H, W = (64, 32), 64, 96
+    crops, pts = t(g["crops"], dev), t(g["pts"], dev)
+    for thr, dk, rk in ((0.5, "depth", "resp"), (float(g["thr2"][0]), "depth2", "resp2")):
+        depth = torch.empty((1, H, W), dtype=torch.float32, device=dev)
+        resp = torch.empty((1, H, W), dtype=torch.float32, device=dev)
+        rc = engine.L().rd_scatter_crops(engine._p(crops), engine._p(pts), engine._p(depth), engine._p(resp), crops.shape[0], patch[0],
+                                         patch[1], H, W, ctypes.c_float(thr), 0, engine._stream(crops))
+        assert rc == 0
+        assert np.array_equal(depth.cpu().numpy() != 0, g[dk] != 0), "support set differs"
+        close(depth, g[dk], 1e-5, "scatter depth"); close(resp, g[rk], 1e-6, "scatter response")
+
+
+def adam_case(dev):
+    from riders_amd.optim import FlatAdam
+    ps = [torch.nn.Parameter(t(rand_array("ad.p%d" % i, s, 1.0), dev)) for i, s in enumerate([(7, 5), (33,), (4, 3, 3, 3)])]
+    ref = [p.detach().cpu().clone() for p in ps]
+    ms = [torch.zeros_like(r) for r in ref]; vs = [torch.zeros_like(r) for r in ref]
+    opt = FlatAdam(ps, lr=2e-3)
+    for step in range(1, 4):
+        for i, p in enumerate(ps):
+            g = t(rand_array("ad.g%d.%d" % (i, step), tuple(p.shape), 1.0))
+            p.grad = g.to(dev)
+            ref[i], ms[i], vs[i] = O.adam_step(ref[i], g, ms[i], vs[i], step, 2e-3)
+        opt.step()
+    for p, r in zip(ps, ref):
+        close(p, r, 1e-5, "adam")
+
+
+# ------------------------------------------------------------------------------------------------ networks
+def resnet_encoder_case(dev, golden=True, tol=TOL):
+    from riders_amd.networks import ResNetEncoder
+    g = load("g3_resnet_encoder")
+    m = ResNetEncoder(18, 3, [32, 64, 128, 128, 128], 'kaiming_uniform', 'leaky_relu', True).to(dev)
+    fill_state_dict(m, "g3.enc")
+    x = t(rand_array("g3.x", (2, 3, 96, 128), 1.0, lo=0.0), dev)
+    m.train()
+    latent, skips = m(x)
+    close(latent, g["latent"], tol, "g3 latent")
+    close(skips[3], g["skip3"], tol, "g3 skip3")
+    close(skips[0][:, ::4, ::4, ::4], g["skip0_sub"], tol, "g3 skip0")
+    loss = (latent * t(rand_array("g3.wl", latent.shape, 1.0), dev)).sum()
+    for i, s in enumerate(skips):
+        loss = loss + (s * t(rand_array("g3.ws%d" % i, s.shape, 1.0), dev)).sum() * 0.1
+    loss.backward()
+    sd = m.state_dict()
+    close(sd['blocks3.0.conv1.batch_norm.running_mean'], g["rm"], tol, "running mean")
+    close(sd['blocks3.0.conv1.batch_norm.running_var'], g["rv"], tol, "running var")
+    for k, p in m.named_parameters():
+        if (k + "|none") in g:
+            assert p.grad is None
+            continue
+        close(p.grad.reshape(-1)[:16], g[k + "|head"], 4 * tol, "g3 grad " + k)
+        rn = float(g[k + "|norm"][0])
+        assert abs(float(p.grad.norm()) - rn) < 4 * tol * max(rn, 1e-3), k
+    m.eval()
+    with torch.no_grad():
+        le, _ = m(x)
+    close(le, g["latent_eval"], tol, "g3 eval latent")
+
+
+def decoder_case(dev, tag="small", tol=TOL):
+    from riders_amd.networks import MultiScaleDecoder
+    patch, R = {"small": ((64, 32), 2), "zju": ((240, 100), 1)}[tag]
+    g = load("g5_decoder_" + tag)
+    m = MultiScaleDecoder(256, 1, 1, [256, 128, 64, 32, 16], [128, 128, 64, 32, 0], 'kaiming_uniform', 'leaky_relu', 'linear', True, 'up').to(dev)
+    fill_state_dict(m, "g5.dec")
+    lh, lw = patch[0] // 32, patch[1] // 32
+    sizes = [(int(patch[0] * s), int(patch[1] * s)) for s in (1 / 2., 1 / 4., 1 / 8., 1 / 16.)]
+    chans = [32, 64, 128, 128]
+    x = t(rand_array("g5.%s.x" % tag, (R, 256, lh, lw), 1.0), dev).requires_grad_()
+    skips = [t(rand_array("g5.%s.s%d" % (tag, i), (R, chans[i]) + sizes[i], 1.0), dev).requires_grad_() for i in range(4)]
+    m.train()
+    out = m(x, skips, shape=patch)[-1]
+    close(out, g["out"], tol, "g5 out")
+    (out * t(rand_array("g5.%s.w" % tag, out.shape, 1.0), dev)).sum().backward()
+    close(x.grad, g["dx"], 2 * tol, "g5 dx"); close(skips[3].grad, g["ds3"], 2 * tol, "g5 ds3")
+    close(skips[0].grad[:, ::4, ::4, ::4], g["ds0_sub"], 2 * tol, "g5 ds0")
+    for k, p in m.named_parameters():
+        close(p.grad.reshape(-1)[:16], g[k + "|head"], 4 * tol, "g5 grad " + k)
+
+
+def rcnet_e2e_case(dev, tol=TOL):
+    """Full RCNetModel step vs the REFERENCE's own logits / loss / gradients (fixture g6)."""
+    from riders_amd import engine
+    from riders_amd.rcnet_model import RCNetModel
+    g = load("g6_rcnet_e2e")
+    patch = [64, 32]
+    m = RCNetModel(3, 3, patch, ['rcnet', 'batch_norm'], [32, 64, 128, 128, 128], [32, 64, 128, 128, 128],
+                   ['multiscale', 'batch_norm'], [256, 128, 64, 32, 16], device=dev)
+    fill_state_dict(m.encoder, "g6.enc"); fill_state_dict(m.decoder, "g6.dec")
+    B, K, H, W = 2, 3, 64, 96
+    pad_y, pad_x = patch[0] // 2, patch[1] // 2
+    img = F.pad(t(rand_array("g6.img", (B, 3, H, W), 1.0, lo=0.0)), (pad_x, pad_x, pad_y, pad_y), mode='replicate').to(dev)
+    pts = t(g["pts"], dev).view(B * K, 3)
+    boxes = [t(b, dev) for b in g["boxes"]]
+    gt = rand_array("g6.gt", (B * K, 1, patch[0], patch[1]), 1.0, lo=0.0) * 30.0
+    gt[rand_array("g6.gtm", gt.shape, 1.0, lo=0.0) < 0.5] = 0.0
+    z = g["pts"][..., 2].reshape(-1)
+    for r in range(B * K):
+        gt[r, 0, ::3, ::2] = np.where(gt[r, 0, ::3, ::2] > 0, z[r] + 0.2, 0.0)
+    label, valid = engine.rcnet_labels(t(gt, dev), pts, 0.5)
+    assert np.array_equal(label.cpu().numpy().astype(np.uint8), g["label"])
+    assert np.array_equal(valid.cpu().numpy().astype(np.uint8), g["valid"])
+    m.train()
+    logits = m.forward(img, pts, boxes, return_logits=True)
+    close(logits, g["logits"], tol, "g6 logits")
+    loss, _ = m.compute_loss(logits, label, valid, 2.5)
+    assert abs(float(loss) - float(g["loss"][0])) < tol * abs(float(g["loss"][0])), (float(loss), float(g["loss"][0]))
+    loss.backward()
+    for pref, mod in (("enc.", m.encoder), ("dec.", m.decoder)):
+        for k, p in mod.named_parameters():
+            if (pref + k + "|none") in g:
+                assert p.grad is None, k
+                continue
+            rn = float(g[pref + k + "|norm"][0])
+            assert abs(float(p.grad.norm()) - rn) < 5 * tol * max(rn, 1e-4), (k, float(p.grad.norm()), rn)

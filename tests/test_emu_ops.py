@@ -1,0 +1,55 @@
+"""Kernel/host LOGIC checks on the GPU-less build container: the riders_amd Python layer driving a host build of
+the same kernel sources under the fiber emulator (tests/emu), compared with the oracle.  These do not count as
+parity evidence (that is tests/test_gpu_parity.py on a real MI355X); they keep index math, LDS layouts, the tape
+and the module wiring honest between GPU runs."""
+import pytest
+
+from tests import parity_cases as P
+
+
+@pytest.mark.parametrize("case", range(len(P.CONV_CASES)))
+def test_conv(emu, case):
+    P.conv_case(emu, P.CONV_CASES[case])
+
+
+def test_decoder_block(emu):
+    P.decoder_block_case(emu)
+    P.decoder_block_case(emu, cin=16, cskip=0, cout=16, hs=(5, 4), hv=(10, 8))
+
+
+def test_resnet_block(emu):
+    P.resnet_block_case(emu)
+    P.resnet_block_case(emu, cin=16, cout=16, stride=1)
+
+
+def test_linear_attention(emu):
+    P.linear_attention_case(emu)
+    P.linear_attention_case(emu, N=1, L=7, S=30)
+
+
+def test_golden_attention(emu):
+    P.golden_attention_case(emu)
+
+
+def test_transformer(emu):
+    P.transformer_case(emu)
+
+
+def test_roi_pool(emu):
+    P.roi_pool_case(emu)
+
+
+def test_maxpool(emu):
+    P.maxpool_case(emu)
+
+
+def test_labels_loss(emu):
+    P.labels_loss_case(emu)
+
+
+def test_scatter_crops(emu):
+    P.scatter_crops_case(emu)
+
+
+def test_adam(emu):
+    P.adam_case(emu)
