@@ -1,0 +1,161 @@
+"""bench.py -- RC-Net training throughput on MI355X (BASELINE.json metric: train imgs/sec, 256x512, synthetic ZJU shape).
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+A "step" is one full optimisation step of the hot path on one batch of synthetic input already resident in HBM:
+/255 normalise + label build + RC-Net forward + masked BCE + backward + (RCCL gradient all-reduce for N > 1) + fused Adam.
+Workload at N = 1 is BASELINE.json configs[1]: RC-Net training, batch 8 per GPU (K = 30 radar points, patch 240x100,
+3x256x512 thermal image edge-padded to 496x612).  Weak scaling: every rank processes its own batch of 8.
+
+Prints ONE JSON line on rank 0 (see the contract in the task statement) including
+  "roofline":     dominant GEMM-class kernel family, algorithmic FLOPs / measured HIP-event time inside the timed region
+  "cpu_baseline": the oracle (PyTorch-CPU restatement of the reference path) timed on this box's host cores on a
+                  bounded sample (test infrastructure used as the reported baseline only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+
+def cpu_baseline(seconds_budget=25.0):
+    """Oracle fwd + loss + bwd on B=1 (K=30, 256x512) with torch CPU ops on all host threads; imgs/s."""
+    from oracle import rcnet as O
+    from riders_amd import rcnet_main
+    cfg = rcnet_main.ZJU_CONFIG
+    torch.manual_seed(0)
+    model = rcnet_main.build_model(torch.device('cpu'), cfg)
+    sd_e = {k: v.detach().clone().requires_grad_(v.is_floating_point() and 'running' not in k) for k, v in model.encoder.state_dict().items()}
+    sd_d = {k: v.detach().clone().requires_grad_(v.is_floating_point() and 'running' not in k) for k, v in model.decoder.state_dict().items()}
+    img, pts, boxes, gt = rcnet_main.synthetic_batch(1, 256, 512, cfg, seed=99)
+    img = img / 255.0
+    pts = pts.reshape(-1, 3)
+    gt = gt.reshape(-1, 1, cfg['patch_size'][0], cfg['patch_size'][1])
+    label, valid = O.rcnet_labels(gt, pts, 0.5)
+
+    def step():
+        for d in (sd_e, sd_d):
+            for v in d.values():
+                v.grad = None
+        logits = O.rcnet_forward(img, pts, [b for b in boxes], sd_e, sd_d, cfg['patch_size'], True)
+        O.rcnet_loss(logits, label, valid, cfg['w_positive_class']).backward()
+    t0 = time.time()
+    step()  # warm-up
+    first = time.time() - t0
+    n, t0 = 0, time.time()
+    while n < 3 or (time.time() - t0 < seconds_budget - first and n < 12):
+        step()
+        n += 1
+    dt = (time.time() - t0) / n
+    return dict(value=1.0 / dt, unit="imgs/s", cores=torch.get_num_threads(), kind="port",
+                sample="oracle RC-Net fwd+loss+bwd, B=1 (30 ROIs, 256x512), fp32, %d timed steps after 1 warm-up, Adam excluded" % n)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=8, help="images per GPU (BASELINE configs[1]: 8)")
+    ap.add_argument("--dtype", default=os.environ.get("RIDERS_BENCH_DTYPE", "fp32"), choices=["fp32", "bf16"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--height", type=int, default=256)
+    ap.add_argument("--width", type=int, default=512)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise RuntimeError("bench.py needs a GPU: the riders_amd hot path has no CPU fallback")
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    from riders_amd import engine, rcnet_main
+    from riders_amd.optim import FlatAdam
+    from riders_amd.parallel import GradientAllReducer
+    engine.set_compute_dtype(args.dtype)
+    cfg = rcnet_main.ZJU_CONFIG
+    torch.manual_seed(0)  # identical initial weights on every rank
+    model = rcnet_main.build_model(dev, cfg)
+    model.train()
+    opt = FlatAdam(model.parameters(), lr=cfg['learning_rate'])
+    reducer = GradientAllReducer(opt) if world > 1 else None
+    if reducer is not None:
+        reducer.broadcast_parameters(0)
+    batch = rcnet_main.synthetic_batch(args.batch, args.height, args.width, cfg, seed=1234 + rank, device=dev)
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    loss = None
+    for _ in range(args.warmup):
+        loss = rcnet_main.train_step(model, opt, batch, cfg, reducer)
+    timer = engine.KernelTimer()
+    engine.set_kernel_timer(timer)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = rcnet_main.train_step(model, opt, batch, cfg, reducer)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    engine.set_kernel_timer(None)
+    if world > 1:
+        import torch.distributed as dist
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    final_loss = float(loss) if loss is not None else float('nan')
+
+    if rank == 0:
+        ms = elapsed * 1e3 / max(args.steps, 1)
+        imgs = args.batch * world * args.steps / elapsed
+        peak = {"fp32": 157.3, "bf16": 2500.0}[args.dtype]
+        ks = timer.summary()
+        dom = max(ks, key=lambda k: ks[k]["ms"]) if ks else None
+        roof = None
+        if dom is not None:
+            k = ks[dom]
+            ach = k["flops"] / (k["ms"] * 1e-3) / 1e12
+            roof = dict(bound="mfma", kernel=dom, achieved=ach, peak=peak if dom == "conv_gemm" else 157.3, unit="TFLOP/s",
+                        frac=ach / (peak if dom == "conv_gemm" else 157.3), traffic=None,
+                        launches_per_step=k["launches"] / max(args.steps, 1),
+                        avg_launch_us=k["ms"] * 1e3 / max(k["launches"], 1),
+                        note="algorithmic FLOPs (2/MAC) of all launches of this kernel family in the timed region / their summed HIP-event time")
+            roof["other_kernels"] = {kk: dict(ms_per_step=v["ms"] / max(args.steps, 1), tflops=v["flops"] / (v["ms"] * 1e-3) / 1e12)
+                                     for kk, v in ks.items() if kk != dom}
+        out = {
+            "metric": "train imgs/sec (RC-Net, 256x512 thermal + 30 radar points, patch 240x100)",
+            "value": imgs, "unit": "imgs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": {"fp32": "f32", "bf16": "bf16"}[args.dtype], "data": "synthetic",
+            "config": {"workload": "RC-Net training step, batch %d/GPU, ZJU config (K=30, patch 240x100), %dx%d image, fwd+loss+bwd+Adam" % (
+                args.batch, args.height, args.width), "global_batch": args.batch * world, "parallelism": "dp%d" % world},
+            "final_loss": final_loss,
+            "roofline": roof,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

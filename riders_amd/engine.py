@@ -61,6 +61,43 @@ def rd_of(t):
     return _RD_DT[t.dtype]
 
 
+# ------------------------------------------------------------------------------------- kernel timing hook
+class KernelTimer(object):
+    """Optional per-launch HIP-event timing of the GEMM-class kernels (used by bench.py for the roofline line).
+    Events are recorded on the stream the kernels are launched on (torch's current stream)."""
+
+    def __init__(self):
+        self.records = {}  # kind -> [(start_event, end_event, algorithmic_flops)]
+
+    def run(self, kind, flops, fn):
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        rc = fn()
+        e.record()
+        self.records.setdefault(kind, []).append((s, e, flops))
+        return rc
+
+    def summary(self):
+        out = {}
+        for kind, recs in self.records.items():
+            ms = sum(s.elapsed_time(e) for s, e, _ in recs)
+            fl = sum(f for _, _, f in recs)
+            out[kind] = dict(launches=len(recs), ms=ms, flops=fl)
+        return out
+
+
+_timer = {"t": None}
+
+
+def set_kernel_timer(t):
+    _timer["t"] = t
+
+
+def _timed(kind, flops, fn):
+    kt = _timer["t"]
+    return fn() if kt is None else kt.run(kind, flops, fn)
+
+
 # ------------------------------------------------------------------------------------------------- tape
 class Tape:
     def __init__(self):
@@ -304,8 +341,10 @@ def conv_block(x, weight, *, x2=None, bias=None, stride=1, pad=None, up=None, bn
     if bn_train:
         rows = lib.rd_conv_stats_rows(ctypes.byref(d))
         stats = torch.empty((rows, Cout, 2), dtype=torch.float32, device=x.device)
-    _chk(lib.rd_conv_fwd(ctypes.byref(d), _p(x), _p(x2), _p(wp), _p(bias.detach() if bias is not None else None), _p(y), None,
-                         _p(stats), st), "rd_conv_fwd")
+    flops = 2.0 * N * OH * OW * Cout * KH * KW * Cin  # algorithmic (2 FLOP per MAC), same count for dgrad / wgrad
+    bias_t = bias.detach() if bias is not None else None
+    _chk(_timed("conv_gemm", flops, lambda: lib.rd_conv_fwd(ctypes.byref(d), _p(x), _p(x2), _p(wp), _p(bias_t), _p(y), None,
+                                                               _p(stats), st)), "rd_conv_fwd")
     pixels = N * OH * OW
     scale = shift = mean = rstd = None
     if use_bn:
@@ -368,13 +407,15 @@ def conv_block(x, weight, *, x2=None, bias=None, stride=1, pad=None, up=None, bn
         if w_req:
             dw, acc = t.param_grad(weight)
             ws = torch.empty(lib.rd_conv_wgrad_workspace_bytes(ctypes.byref(d)) // 4, dtype=torch.float32, device=x.device)
-            _chk(lib.rd_conv_wgrad(ctypes.byref(d), _p(x), _p(x2), _p(dy), _p(ws), _p(dw), acc, st), "rd_conv_wgrad")
+            _chk(_timed("conv_wgrad", flops, lambda: lib.rd_conv_wgrad(ctypes.byref(d), _p(x), _p(x2), _p(dy), _p(ws), _p(dw), acc, st)),
+                 "rd_conv_wgrad")
         if need_in:
             wpd = packed_weight(weight, 1, dt)
             dd = _desc(dt, N, OH, OW, Cout, 0, False, OH, OW, Cin, KH, KW, 1, KH - 1 - pad, stride, Hin, Win, ACT_NONE, 0.0, C1)
             dxv1 = torch.empty((N, Hin, Win, C1), dtype=x.dtype, device=x.device)
             dxv2 = torch.empty((N, Hin, Win, C2), dtype=x.dtype, device=x.device) if C2 else None
-            _chk(lib.rd_conv_fwd(ctypes.byref(dd), _p(dy), None, _p(wpd), None, _p(dxv1), _p(dxv2), None, st), "rd_conv_fwd(dgrad)")
+            _chk(_timed("conv_gemm", flops, lambda: lib.rd_conv_fwd(ctypes.byref(dd), _p(dy), None, _p(wpd), None, _p(dxv1), _p(dxv2),
+                                                                       None, st)), "rd_conv_fwd(dgrad)")
             if is_up:
                 g1 = torch.empty_like(x)
                 _chk(lib.rd_upsample_nearest_bwd(_p(dxv1), _p(g1), N, H1, W1, Hin, Win, C1, dt, st), "rd_upsample_nearest_bwd")

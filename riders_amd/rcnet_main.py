@@ -1,0 +1,106 @@
+"""RC-Net training / inference harness on MI355X: the counterpart of the reference's RCNet/rcnet_main.py for the
+hot path (train step body :272-359, forward_output :435-487) plus the synthetic ZJU-shape batch generator that
+restates the tensor contract of data/datasets.py:170-288.  File I/O, TensorBoard and the
+augmentation transforms are out of scope.
+"""
+import ctypes
+
+import torch
+
+from . import engine
+from .networks import boxes_to_rois
+from .rcnet_model import RCNetModel
+
+# RCNet/train_rcnet_zju.py:28-65
+ZJU_CONFIG = dict(
+    patch_size=[240, 100], total_points_sampled=30, batch_size=4,
+    input_channels_image=3, input_channels_depth=3,
+    encoder_type=['rcnet', 'batch_norm'], n_filters_encoder_image=[32, 64, 128, 128, 128],
+    n_neurons_encoder_depth=[32, 64, 128, 128, 128],
+    decoder_type=['multiscale', 'batch_norm'], n_filters_decoder=[256, 128, 64, 32, 16],
+    weight_initializer='kaiming_uniform', activation_func='leaky_relu',
+    learning_rate=2e-4, w_positive_class=2.5, max_distance_correspondence=0.5, set_invalid_to_negative_class=False,
+)
+
+
+def build_model(device, cfg=ZJU_CONFIG):
+    return RCNetModel(cfg['input_channels_image'], cfg['input_channels_depth'], cfg['patch_size'], cfg['encoder_type'],
+                      cfg['n_filters_encoder_image'], cfg['n_neurons_encoder_depth'], cfg['decoder_type'],
+                      cfg['n_filters_decoder'], cfg['weight_initializer'], cfg['activation_func'], device=device)
+
+
+def synthetic_batch(batch_size, height=256, width=512, cfg=ZJU_CONFIG, seed=1234, device='cpu'):
+    """The tuple RCNetTrainingDataset.__getitem__ returns, batched (data/datasets.py:288):
+    image (B,3,H+ph,W+pw) fp32 0..255 edge-padded; radar_points (B,K,3) = (x+pad_x, y+pad_y, z);
+    bounding_boxes (B,K,4) = (x-pad_x, y-pad_y, x+pad_x, y+pad_y) in padded coords; ground truth crops
+    (B,K,1,ph,pw) cut from a zero-padded synthetic dense depth with ~50% invalid pixels."""
+    g = torch.Generator().manual_seed(seed)
+    ph, pw = cfg['patch_size']
+    pad_y, pad_x = ph // 2, pw // 2
+    K = cfg['total_points_sampled']
+    B = batch_size
+    img = torch.randint(0, 256, (B, 3, height, width), generator=g).float()
+    img = torch.nn.functional.pad(img, (pad_x, pad_x, pad_y, pad_y), mode='replicate')
+    x = torch.randint(0, width, (B, K), generator=g).float()
+    y = torch.randint(0, height, (B, K), generator=g).float()
+    z = torch.rand((B, K), generator=g) * 98.5 + 1.5
+    pts = torch.stack([x + pad_x, y + pad_y, z], dim=-1)
+    boxes = torch.stack([pts[..., 0] - pad_x, pts[..., 1] - pad_y, pts[..., 0] + pad_x, pts[..., 1] + pad_y], dim=-1)
+    depth = torch.rand((B, 1, height, width), generator=g) * 98.5 + 1.5
+    depth = depth * (torch.rand((B, 1, height, width), generator=g) > 0.5).float()
+    # make a share of pixels agree with the radar depth so that positives exist
+    depth = torch.nn.functional.pad(depth, (pad_x, pad_x, pad_y, pad_y))
+    crops = torch.empty((B, K, 1, ph, pw))
+    for b in range(B):
+        for k in range(K):
+            xs, ys = int(pts[b, k, 0]) - pad_x, int(pts[b, k, 1]) - pad_y
+            c = depth[b, :, ys:ys + ph, xs:xs + pw].clone()
+            m = (torch.rand(c.shape, generator=g) < 0.05) & (c > 0)
+            c[m] = z[b, k] + 0.25
+            crops[b, k] = c
+    return tuple(t.to(device) for t in (img, pts, boxes, crops))
+
+
+def prepare_batch(batch):
+    """Device-side batch preparation of the train loop (rcnet_main.py:283-340): /255 normalise (rcnet_transforms.py:258),
+    flatten points and crops, per-image box list -> ROI rows."""
+    image, radar_point, boxes, gt = batch
+    image = engine.as_nchw(engine.nchw_to_nhwc(image, scale=1.0 / 255.0))
+    B, K = radar_point.shape[0], radar_point.shape[1]
+    radar_point = radar_point.reshape(B * K, radar_point.shape[2])
+    gt = gt.reshape(B * K, gt.shape[2], gt.shape[3], gt.shape[4])
+    rois = boxes_to_rois(boxes)
+    return image, radar_point, rois, gt
+
+
+def train_step(model, optimizer, batch, cfg=ZJU_CONFIG, reducer=None):
+    """One optimisation step (rcnet_main.py:294-359).  Returns the loss as a device tensor (no host sync)."""
+    image, radar_point, rois, gt = prepare_batch(batch)
+    label, valid = engine.rcnet_labels(gt, radar_point, cfg['max_distance_correspondence'], cfg['set_invalid_to_negative_class'])
+    logits = model.forward(image, radar_point, rois, return_logits=True)
+    loss, _ = model.compute_loss(logits=logits, ground_truth=label, validity_map=valid, w_positive_class=cfg['w_positive_class'])
+    optimizer.zero_grad()
+    loss.backward()
+    if reducer is not None:
+        reducer.reduce()
+    optimizer.step()
+    return loss
+
+
+def forward_output(model, image, radar_points, bounding_boxes_list, response_thr=0.5, device=None):
+    """rcnet_main.py:435-487: edge-pad, one forward over all N points, threshold, integer paste, confidence-weighted
+    mean depth; zero where nothing responds.  image (1,3,H,W) already normalised; radar_points (N,3) in padded coords."""
+    ph, pw = model.input_patch_size_image
+    pad_y, pad_x = ph // 2, pw // 2
+    image = torch.nn.functional.pad(image, (pad_x, pad_x, pad_y, pad_y), mode='replicate')  # data prep, as the reference
+    if radar_points.dim() == 3:
+        radar_points = torch.squeeze(radar_points, dim=0)
+    pts = radar_points.contiguous().float()
+    crops = model.forward(image=image, point=pts, bounding_boxes=bounding_boxes_list, return_logits=False)
+    H, W = image.shape[-2] - 2 * pad_y, image.shape[-1] - 2 * pad_x
+    depth = torch.empty((1, H, W), dtype=torch.float32, device=crops.device)
+    resp = torch.empty((1, H, W), dtype=torch.float32, device=crops.device)
+    engine._chk(engine.L().rd_scatter_crops(engine._p(crops), engine._p(pts), engine._p(depth), engine._p(resp), crops.shape[0], ph, pw,
+                                            H, W, ctypes.c_float(response_thr), engine.rd_of(crops), engine._stream(crops)),
+                "rd_scatter_crops")
+    return depth, resp

@@ -306,13 +306,30 @@ def resnet_encoder_case(dev, golden=True, tol=TOL):
     sd = m.state_dict()
     close(sd['blocks3.0.conv1.batch_norm.running_mean'], g["rm"], tol, "running mean")
     close(sd['blocks3.0.conv1.batch_norm.running_var'], g["rv"], tol, "running var")
+    # This fixture (batch 2, 3x4 latent => 24 samples per BN channel at the deepest stage) is ill-conditioned in fp32:
+    # the reference's own fp32 gradients sit ~1e-2 from the fp64 truth for the early layers.  So gradients are
+    # judged against an fp64 run of the oracle, each with tolerance max(4e-3, 3 x the fp32 oracle's own error).
+    def oracle_grads(dt):
+        sdo = {k: (v.detach().cpu().to(dt) if v.is_floating_point() else v.detach().cpu()).clone() for k, v in fill_state_dict(
+            ResNetEncoder(18, 3, [32, 64, 128, 128, 128], 'kaiming_uniform', 'leaky_relu', True), "g3.enc").items()}
+        for k, v in sdo.items():
+            if v.is_floating_point() and "running" not in k:
+                v.requires_grad_()
+        lat, sk = O.resnet_encoder(t(rand_array("g3.x", (2, 3, 96, 128), 1.0, lo=0.0)).to(dt), sdo, "", training=True)
+        ls = (lat * t(rand_array("g3.wl", lat.shape, 1.0)).to(dt)).sum()
+        for i, s_ in enumerate(sk):
+            ls = ls + (s_ * t(rand_array("g3.ws%d" % i, s_.shape, 1.0)).to(dt)).sum() * 0.1
+        ls.backward()
+        return {k: v.grad for k, v in sdo.items() if v.requires_grad}
+    g64, g32 = oracle_grads(torch.float64), oracle_grads(torch.float32)
     for k, p in m.named_parameters():
         if (k + "|none") in g:
             assert p.grad is None
             continue
-        close(p.grad.reshape(-1)[:16], g[k + "|head"], 4 * tol, "g3 grad " + k)
-        rn = float(g[k + "|norm"][0])
-        assert abs(float(p.grad.norm()) - rn) < 4 * tol * max(rn, 1e-3), k
+        ref = g64[k]
+        cond = float((g32[k].double() - ref).abs().max() / ref.abs().max())
+        close(p.grad, ref, max(4 * tol, 3 * cond), "g3 grad " + k)
+        close(g32[k].reshape(-1)[:16], g[k + "|head"], max(4 * tol, 3 * cond), "oracle vs reference fixture " + k)
     m.eval()
     with torch.no_grad():
         le, _ = m(x)
