@@ -69,6 +69,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--height", type=int, default=256)
     ap.add_argument("--width", type=int, default=512)
+    ap.add_argument("--detail", default=None, help="write a per-launch-shape timing table to this file")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -149,6 +150,12 @@ def main():
             "final_loss": final_loss,
             "roofline": roof,
         }
+        if args.detail:
+            rows = sorted(timer.detail().items(), key=lambda kv: -kv[1][1])
+            with open(args.detail, "w") as f:
+                for (kind, desc), (n, tms, fl) in rows:
+                    f.write("%-11s %-48s launches/step %5.1f  ms/step %8.3f  TFLOP/s %7.2f\n" % (
+                        kind, desc, n / args.steps, tms / args.steps, fl / (tms * 1e-3) / 1e12))
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

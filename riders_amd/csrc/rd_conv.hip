@@ -276,21 +276,28 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, T* __restrict__
 // both operands are converted to fp32 in LDS and fed to the exact-fp32 MFMA (v_mfma_f32_16x16x4_f32),
 // for which each lane supplies one scalar -> the pixel-major tiles need no transpose.
 __device__ __forceinline__ int wg_idx(int p, int col) { return p * 128 + (col ^ ((p & 1) << 4)); }
+// dY tile [32 pixels][COT]: the XOR keeps the two pixel rows a ds_read_b32 half-wave touches on different banks
+// (COT = 16 rows are 16 words apart, which already does that)
+template <int COT>
+__device__ __forceinline__ int wgy_idx(int p, int col) { return p * COT + (COT >= 32 ? (col ^ ((p & 1) << 4)) : col); }
 
-template <typename T, bool VEC>
+template <typename T, bool VEC, int COT>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
   constexpr int PK = 32;  // pixels per stage
+  constexpr int WROWS = COT == 128 ? 2 : 1, WCOLS = 4 / WROWS;
+  constexpr int TI = COT / (16 * WROWS), TJ = 128 / (16 * WCOLS);
+  constexpr int YV = PK * COT / 4;              // float4 vectors in the dY tile
+  constexpr int YIT = (YV + 255) / 256;
   __shared__ float sX[2][PK * 128];
-  __shared__ float sY[2][PK * 128];
+  __shared__ float sY[2][PK * COT];
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-  const int kt0 = blockIdx.x * 128, c0 = blockIdx.y * 128;
+  const int kt0 = blockIdx.x * 128, c0 = blockIdx.y * COT;
   const int Cin = a.C1 + a.C2;
   const int mbeg = blockIdx.z * a.rows_per_split;
   const int mend = min(a.M, mbeg + a.rows_per_split);
 
-  // staging role: column group cg (4 consecutive columns), pixel rows pr + 8*i (i<4)
+  // X staging role: column group cg (4 consecutive k columns, fixed for the whole pixel loop), pixel rows pr + 8*i
   const int cg = t & 31, pr = t >> 5;
-  // X columns = k indices kt0 + cg*4 .. +3 (fixed per thread for the whole pixel loop)
   int xkh[4], xkw[4], xci[4]; bool xv[4];
 #pragma unroll
   for (int e = 0; e < 4; e++) {
@@ -303,13 +310,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
   g.src1 = a.src1; g.src2 = a.src2; g.Hin = a.Hin; g.Win = a.Win; g.C1 = a.C1; g.C2 = a.C2; g.H1 = a.H1; g.W1 = a.W1;
   g.dil = 1; g.ups = a.ups; g.scale_h = a.scale_h; g.scale_w = a.scale_w;
 
-  float rx[4][4], ry[4][4];
+  float rx[4][4], ry[YIT][4];
   auto load_stage = [&](int mb) {
 #pragma unroll
     for (int i = 0; i < 4; i++) {
       int m = mb + pr + 8 * i;
 #pragma unroll
-      for (int e = 0; e < 4; e++) { rx[i][e] = 0.f; ry[i][e] = 0.f; }
+      for (int e = 0; e < 4; e++) rx[i][e] = 0.f;
       if (m < mend) {
         int ow = m % a.OW; int q = m / a.OW; int oh = q % a.OH; int n = q / a.OH;
         int ihb = oh * a.stride - a.pad, iwb = ow * a.stride - a.pad;
@@ -325,7 +332,16 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
             if (xv[e] && conv_src_ptr<T>(g, n, ihb + xkh[e], iwb + xkw[e], xci[e], p)) rx[i][e] = Elem<T>::ld(p);
           }
         }
-        int co = c0 + cg * 4;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < YIT; i++) {
+      int idx = t + 256 * i;
+      int py = idx / (COT / 4), cy = (idx % (COT / 4)) * 4;
+      int m = mb + py, co = c0 + cy;
+#pragma unroll
+      for (int e = 0; e < 4; e++) ry[i][e] = 0.f;
+      if (idx < YV && m < mend) {
         const T* yp = (const T*)a.dy + (int64_t)m * a.Cout + co;
         if ((a.Cout & 3) == 0 && co + 3 < a.Cout) ld4(yp, ry[i]);
         else {
@@ -340,18 +356,28 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
     for (int i = 0; i < 4; i++) {
       int p = pr + 8 * i;
       *reinterpret_cast<float4*>(&sX[buf][wg_idx(p, cg * 4)]) = make_float4(rx[i][0], rx[i][1], rx[i][2], rx[i][3]);
-      *reinterpret_cast<float4*>(&sY[buf][wg_idx(p, cg * 4)]) = make_float4(ry[i][0], ry[i][1], ry[i][2], ry[i][3]);
+    }
+#pragma unroll
+    for (int i = 0; i < YIT; i++) {
+      int idx = t + 256 * i;
+      if (idx < YV) {
+        int py = idx / (COT / 4), cy = (idx % (COT / 4)) * 4;
+        *reinterpret_cast<float4*>(&sY[buf][wgy_idx<COT>(py, cy)]) = make_float4(ry[i][0], ry[i][1], ry[i][2], ry[i][3]);
+      }
     }
   };
 
-  // wave tile: cout rows (wv>>1)*64 .. +63, k cols (wv&1)*64 .. +63  -> 4x4 MFMA tiles
-  const int wr = (wv >> 1) * 64, wc = (wv & 1) * 64;
-  f32x4 acc[4][4];
+  // wave tile: cout rows wr .. wr+16*TI, k cols wc .. wc+16*TJ
+  const int wr = (wv / WCOLS) * TI * 16, wc = (wv % WCOLS) * TJ * 16;
+  f32x4 acc[TI][TJ];
 #pragma unroll
-  for (int i = 0; i < 4; i++)
+  for (int i = 0; i < TI; i++)
 #pragma unroll
-    for (int j = 0; j < 4; j++) acc[i][j] = f32x4{0, 0, 0, 0};
+    for (int j = 0; j < TJ; j++) acc[i][j] = f32x4{0, 0, 0, 0};
   const int fr = lane & 15, fg = lane >> 4;
+  bool jv[TJ];
+#pragma unroll
+  for (int j = 0; j < TJ; j++) jv[j] = kt0 + wc + j * 16 < a.K;  // wave-uniform: skip all-padding column tiles
 
   int nst = (mend > mbeg) ? (mend - mbeg + PK - 1) / PK : 0;
   if (nst > 0) {
@@ -365,15 +391,17 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
 #pragma unroll
     for (int p4 = 0; p4 < PK / 4; p4++) {
       int p = p4 * 4 + fg;
-      float ya[4], xb[4];
+      float ya[TI], xb[TJ];
 #pragma unroll
-      for (int i = 0; i < 4; i++) ya[i] = sY[buf][wg_idx(p, wr + i * 16 + fr)];
+      for (int i = 0; i < TI; i++) ya[i] = sY[buf][wgy_idx<COT>(p, wr + i * 16 + fr)];
 #pragma unroll
-      for (int j = 0; j < 4; j++) xb[j] = sX[buf][wg_idx(p, wc + j * 16 + fr)];
+      for (int j = 0; j < TJ; j++) xb[j] = sX[buf][wg_idx(p, wc + j * 16 + fr)];
 #pragma unroll
-      for (int i = 0; i < 4; i++)
+      for (int j = 0; j < TJ; j++)
+        if (jv[j]) {
 #pragma unroll
-        for (int j = 0; j < 4; j++) acc[i][j] = mfma_16x16x4_f32(ya[i], xb[j], acc[i][j]);
+          for (int i = 0; i < TI; i++) acc[i][j] = mfma_16x16x4_f32(ya[i], xb[j], acc[i][j]);
+        }
     }
     if (st + 1 < nst) store_stage(buf ^ 1);
     __syncthreads();
@@ -381,9 +409,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
   // slab[split][co][k]: lane holds rows (cout) fg*4+r, col (k) fr
   float* slab = a.slab + (int64_t)blockIdx.z * a.Cout * a.K;
 #pragma unroll
-  for (int i = 0; i < 4; i++)
+  for (int i = 0; i < TI; i++)
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
+    for (int j = 0; j < TJ; j++) {
       int k = kt0 + wc + j * 16 + fr;
 #pragma unroll
       for (int r = 0; r < 4; r++) {
@@ -453,11 +481,25 @@ void launch_pack_weights(const float* w, void* out, int Cout, int Cin, int KH, i
 
 // split the pixel reduction so the launch has a few blocks per CU, stage-aligned
 int wgrad_nsplit(int M, int K, int Cout) {
-  int64_t tiles = cdiv(K, 128) * cdiv(Cout, 128);
+  int cot = pick_bn(Cout);
+  int64_t tiles = cdiv(K, 128) * cdiv(Cout, cot);
   int64_t want = cdiv(1024, tiles);
   int64_t maxs = cdiv(M, 256);  // at least 256 pixels per split
   int64_t s = std::max<int64_t>(1, std::min(want, maxs));
   return (int)s;
+}
+
+template <typename T>
+static void launch_wgrad_t(const WgradArgs& a, bool vec, hipStream_t st) {
+  int cot = pick_bn(a.Cout);
+  dim3 grid((unsigned)cdiv(a.K, 128), (unsigned)cdiv(a.Cout, cot), (unsigned)a.nsplit);
+#define RD_WG_CASE(C)                                                                              \
+  if (cot == C) {                                                                                  \
+    if (vec) hipLaunchKernelGGL((conv_wgrad_kernel<T, true, C>), grid, dim3(256), 0, st, a);        \
+    else hipLaunchKernelGGL((conv_wgrad_kernel<T, false, C>), grid, dim3(256), 0, st, a);           \
+  }
+  RD_WG_CASE(16) RD_WG_CASE(32) RD_WG_CASE(64) RD_WG_CASE(128)
+#undef RD_WG_CASE
 }
 
 void launch_wgrad(WgradArgs a, int dtype, float* dw, int accumulate, hipStream_t st) {
@@ -465,15 +507,9 @@ void launch_wgrad(WgradArgs a, int dtype, float* dw, int accumulate, hipStream_t
   a.nsplit = wgrad_nsplit(a.M, a.K, a.Cout);
   a.rows_per_split = (int)(cdiv(cdiv(a.M, a.nsplit), 32) * 32);
   a.nsplit = (int)cdiv(a.M, a.rows_per_split);
-  dim3 grid((unsigned)cdiv(a.K, 128), (unsigned)cdiv(a.Cout, 128), (unsigned)a.nsplit);
   bool vec = (Cin % 4 == 0) && (a.C1 % 4 == 0);
-  if (dtype == 0) {
-    if (vec) hipLaunchKernelGGL((conv_wgrad_kernel<float, true>), grid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((conv_wgrad_kernel<float, false>), grid, dim3(256), 0, st, a);
-  } else {
-    if (vec) hipLaunchKernelGGL((conv_wgrad_kernel<bf16_t, true>), grid, dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((conv_wgrad_kernel<bf16_t, false>), grid, dim3(256), 0, st, a);
-  }
+  if (dtype == 0) launch_wgrad_t<float>(a, vec, st);
+  else launch_wgrad_t<bf16_t>(a, vec, st);
   int64_t total = (int64_t)a.Cout * a.K;
   unsigned rg = (unsigned)std::min<int64_t>(cdiv(total, 256), 2048);
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rg), dim3(256), 0, st, a.slab, dw, a.Cout, Cin, a.KH, a.KW, a.nsplit, accumulate);

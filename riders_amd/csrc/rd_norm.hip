@@ -142,24 +142,30 @@ __global__ __launch_bounds__(256) void col_reduce_kernel(const T* __restrict__ d
   }
 }
 
-__global__ void bn_bwd_finalize_kernel(const float* __restrict__ partial, int rows, int C, double count, float* dgamma,
-                                       float* dbeta, int accumulate, float* c1, float* c2) {
-  int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+// one wave per channel: lanes stride over the partial rows, double-precision wave reduction (fixed order)
+__global__ __launch_bounds__(64) void bn_bwd_finalize_kernel(const float* __restrict__ partial, int rows, int C, double count,
+                                                             float* dgamma, float* dbeta, int accumulate, float* c1, float* c2) {
+  const int c = blockIdx.x, lane = threadIdx.x;
   double a = 0.0, b = 0.0;
-  for (int r = 0; r < rows; r++) { a += partial[((int64_t)r * C + c) * 2]; b += partial[((int64_t)r * C + c) * 2 + 1]; }
-  if (dbeta) dbeta[c] = accumulate ? dbeta[c] + (float)a : (float)a;
-  if (dgamma) dgamma[c] = accumulate ? dgamma[c] + (float)b : (float)b;
-  if (c1) c1[c] = (float)(a / count);
-  if (c2) c2[c] = (float)(b / count);
+  for (int r = lane; r < rows; r += 64) { a += partial[((int64_t)r * C + c) * 2]; b += partial[((int64_t)r * C + c) * 2 + 1]; }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
+  if (lane == 0) {
+    if (dbeta) dbeta[c] = accumulate ? dbeta[c] + (float)a : (float)a;
+    if (dgamma) dgamma[c] = accumulate ? dgamma[c] + (float)b : (float)b;
+    if (c1) c1[c] = (float)(a / count);
+    if (c2) c2[c] = (float)(b / count);
+  }
 }
 
-__global__ void colsum_finalize_kernel(const float* __restrict__ partial, int rows, int C, float* out, int accumulate) {
-  int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+__global__ __launch_bounds__(64) void colsum_finalize_kernel(const float* __restrict__ partial, int rows, int C, float* out,
+                                                             int accumulate) {
+  const int c = blockIdx.x, lane = threadIdx.x;
   double a = 0.0;
-  for (int r = 0; r < rows; r++) a += partial[((int64_t)r * C + c) * 2];
-  out[c] = accumulate ? out[c] + (float)a : (float)a;
+  for (int r = lane; r < rows; r += 64) a += partial[((int64_t)r * C + c) * 2];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o);
+  if (lane == 0) out[c] = accumulate ? out[c] + (float)a : (float)a;
 }
 
 // dy = scale[c] * (dpre - c1[c] - xhat*c2[c]);  dres = dpre
@@ -308,7 +314,7 @@ void launch_bn_bwd_reduce(const void* dz, const void* z, const void* y, const fl
 
 void launch_bn_bwd_finalize(const float* partial, int rows, int C, double count, float* dgamma, float* dbeta,
                             int accumulate, float* c1, float* c2, hipStream_t st) {
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)cdiv(C, 64)), dim3(64), 0, st, partial, rows, C, count, dgamma, dbeta, accumulate, c1, c2);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)C), dim3(64), 0, st, partial, rows, C, count, dgamma, dbeta, accumulate, c1, c2);
 }
 
 void launch_bn_bwd_apply(const void* dz, const void* z, const void* y, const float* mean, const float* rstd,
@@ -336,7 +342,7 @@ void launch_colsum(const void* x, float* partial, float* out, int accumulate, in
     hipLaunchKernelGGL((col_reduce_kernel<float, 1>), grid, dim3(256), 0, st, (const float*)x, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, partial, rows, C, g.CB, g.PL, 0, 0.f);
   else
     hipLaunchKernelGGL((col_reduce_kernel<bf16_t, 1>), grid, dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)nullptr, (const bf16_t*)nullptr, (const float*)nullptr, (const float*)nullptr, partial, rows, C, g.CB, g.PL, 0, 0.f);
-  hipLaunchKernelGGL(colsum_finalize_kernel, dim3((unsigned)cdiv(C, 64)), dim3(64), 0, st, partial, nr, C, out, accumulate);
+  hipLaunchKernelGGL(colsum_finalize_kernel, dim3((unsigned)C), dim3(64), 0, st, partial, nr, C, out, accumulate);
 }
 
 void launch_layernorm_fwd(const void* x, const float* gamma, const float* beta, const void* res, void* out, float* mean,
@@ -358,7 +364,7 @@ void launch_layernorm_bwd(const void* dout, const void* x, const float* gamma, c
     hipLaunchKernelGGL((layernorm_bwd_kernel<float>), dim3(nb), dim3(256), 0, st, (const float*)dout, (const float*)x, gamma, mean, rstd, (float*)dx, partial, rows, C);
   else
     hipLaunchKernelGGL((layernorm_bwd_kernel<bf16_t>), dim3(nb), dim3(256), 0, st, (const bf16_t*)dout, (const bf16_t*)x, gamma, mean, rstd, (bf16_t*)dx, partial, rows, C);
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)cdiv(C, 64)), dim3(64), 0, st, partial, nb, C, 1.0, dgamma, dbeta, accumulate, (float*)nullptr, (float*)nullptr);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)C), dim3(64), 0, st, partial, nb, C, 1.0, dgamma, dbeta, accumulate, (float*)nullptr, (float*)nullptr);
 }
 
 }  // namespace rd

@@ -69,19 +69,29 @@ class KernelTimer(object):
     def __init__(self):
         self.records = {}  # kind -> [(start_event, end_event, algorithmic_flops)]
 
-    def run(self, kind, flops, fn):
+    def run(self, kind, flops, fn, desc=None):
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s.record()
         rc = fn()
         e.record()
-        self.records.setdefault(kind, []).append((s, e, flops))
+        self.records.setdefault(kind, []).append((s, e, flops, desc))
         return rc
+
+    def detail(self):
+        """-> {(kind, desc): (launches, total ms, total flops)} aggregated over identical launch shapes."""
+        out = {}
+        for kind, recs in self.records.items():
+            for s, e, f, d in recs:
+                k = (kind, d)
+                n, ms, fl = out.get(k, (0, 0.0, 0.0))
+                out[k] = (n + 1, ms + s.elapsed_time(e), fl + f)
+        return out
 
     def summary(self):
         out = {}
         for kind, recs in self.records.items():
-            ms = sum(s.elapsed_time(e) for s, e, _ in recs)
-            fl = sum(f for _, _, f in recs)
+            ms = sum(r[0].elapsed_time(r[1]) for r in recs)
+            fl = sum(r[2] for r in recs)
             out[kind] = dict(launches=len(recs), ms=ms, flops=fl)
         return out
 
@@ -93,9 +103,9 @@ def set_kernel_timer(t):
     _timer["t"] = t
 
 
-def _timed(kind, flops, fn):
+def _timed(kind, flops, fn, desc=None):
     kt = _timer["t"]
-    return fn() if kt is None else kt.run(kind, flops, fn)
+    return fn() if kt is None else kt.run(kind, flops, fn, desc)
 
 
 # ------------------------------------------------------------------------------------------------- tape
@@ -139,11 +149,14 @@ class Tape:
         if g is not None:
             return g, 1
         g = self.grad_alloc(p) if self.grad_alloc is not None else None
+        acc = 0
         if g is None:
             g = torch.empty_like(p, dtype=torch.float32, memory_format=torch.contiguous_format)
+        elif p.grad is not None and p.grad.data_ptr() == g.data_ptr():
+            acc = 1  # another region already wrote this step's gradient into the arena slot
         self.pgrads[id(p)] = g
         self.params[id(p)] = p
-        return g, 0
+        return g, acc
 
     def backward(self):
         for fn in reversed(self.nodes):
@@ -203,9 +216,20 @@ class _Region(torch.autograd.Function):
         with _active(t):
             t.backward()
         gin = tuple(t.grads.get(id(x)) if x is not None else None for x in ctx.inputs)
-        gp = tuple(t.pgrads.get(id(p)) for p in ctx.params)
+        # Parameter gradients are deposited on .grad directly (returning them would make autograd's AccumulateGrad
+        # clone every arena view: one copy kernel per parameter per step).
+        for p in ctx.params:
+            g = t.pgrads.get(id(p))
+            if g is None:
+                continue
+            if p.grad is None or p.grad.data_ptr() == g.data_ptr():
+                p.grad = g
+            else:
+                acc = torch.empty_like(g)
+                _chk(L().rd_add(_p(p.grad), _p(g), _p(acc), g.numel(), RD_F32, _stream(g)), "rd_add")
+                p.grad = acc
         ctx.tape = None
-        return (None, None) + gin + gp
+        return (None, None) + gin + (None,) * len(ctx.params)
 
 
 def _match_layout(g, like):
@@ -342,9 +366,10 @@ def conv_block(x, weight, *, x2=None, bias=None, stride=1, pad=None, up=None, bn
         rows = lib.rd_conv_stats_rows(ctypes.byref(d))
         stats = torch.empty((rows, Cout, 2), dtype=torch.float32, device=x.device)
     flops = 2.0 * N * OH * OW * Cout * KH * KW * Cin  # algorithmic (2 FLOP per MAC), same count for dgrad / wgrad
+    shp = "M=%d Cin=%d Cout=%d k=%d s=%d%s" % (N * OH * OW, Cin, Cout, KH, stride, " up" if is_up else "")
     bias_t = bias.detach() if bias is not None else None
     _chk(_timed("conv_gemm", flops, lambda: lib.rd_conv_fwd(ctypes.byref(d), _p(x), _p(x2), _p(wp), _p(bias_t), _p(y), None,
-                                                               _p(stats), st)), "rd_conv_fwd")
+                                                               _p(stats), st), "fwd " + shp), "rd_conv_fwd")
     pixels = N * OH * OW
     scale = shift = mean = rstd = None
     if use_bn:
@@ -407,15 +432,15 @@ def conv_block(x, weight, *, x2=None, bias=None, stride=1, pad=None, up=None, bn
         if w_req:
             dw, acc = t.param_grad(weight)
             ws = torch.empty(lib.rd_conv_wgrad_workspace_bytes(ctypes.byref(d)) // 4, dtype=torch.float32, device=x.device)
-            _chk(_timed("conv_wgrad", flops, lambda: lib.rd_conv_wgrad(ctypes.byref(d), _p(x), _p(x2), _p(dy), _p(ws), _p(dw), acc, st)),
-                 "rd_conv_wgrad")
+            _chk(_timed("conv_wgrad", flops, lambda: lib.rd_conv_wgrad(ctypes.byref(d), _p(x), _p(x2), _p(dy), _p(ws), _p(dw), acc, st),
+                        "wgrad " + shp), "rd_conv_wgrad")
         if need_in:
             wpd = packed_weight(weight, 1, dt)
             dd = _desc(dt, N, OH, OW, Cout, 0, False, OH, OW, Cin, KH, KW, 1, KH - 1 - pad, stride, Hin, Win, ACT_NONE, 0.0, C1)
             dxv1 = torch.empty((N, Hin, Win, C1), dtype=x.dtype, device=x.device)
             dxv2 = torch.empty((N, Hin, Win, C2), dtype=x.dtype, device=x.device) if C2 else None
             _chk(_timed("conv_gemm", flops, lambda: lib.rd_conv_fwd(ctypes.byref(dd), _p(dy), None, _p(wpd), None, _p(dxv1), _p(dxv2),
-                                                                       None, st)), "rd_conv_fwd(dgrad)")
+                                                                       None, st), "dgrad " + shp), "rd_conv_fwd(dgrad)")
             if is_up:
                 g1 = torch.empty_like(x)
                 _chk(lib.rd_upsample_nearest_bwd(_p(dxv1), _p(g1), N, H1, W1, Hin, Win, C1, dt, st), "rd_upsample_nearest_bwd")

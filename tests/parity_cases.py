@@ -351,10 +351,32 @@ def decoder_case(dev, tag="small", tol=TOL):
     out = m(x, skips, shape=patch)[-1]
     close(out, g["out"], tol, "g5 out")
     (out * t(rand_array("g5.%s.w" % tag, out.shape, 1.0), dev)).sum().backward()
-    close(x.grad, g["dx"], 2 * tol, "g5 dx"); close(skips[3].grad, g["ds3"], 2 * tol, "g5 ds3")
-    close(skips[0].grad[:, ::4, ::4, ::4], g["ds0_sub"], 2 * tol, "g5 ds0")
+    # Gradients: the R=1 ZJU-size fixture is ill-conditioned in fp32 (the reference's own fp32 input gradients sit up to
+    # 2e-2 from an fp64 evaluation), so they are judged against an fp64 run of the oracle with tolerance
+    # max(2e-3, 3 x the fp32 oracle's own error); the fp32 oracle is also re-checked against the reference fixture.
+    def oracle_grads(dt):
+        sdo = {k: (v.detach().cpu().to(dt) if v.is_floating_point() else v.detach().cpu()).clone() for k, v in fill_state_dict(
+            MultiScaleDecoder(256, 1, 1, [256, 128, 64, 32, 16], [128, 128, 64, 32, 0], 'kaiming_uniform', 'leaky_relu', 'linear', True,
+                              'up'), "g5.dec").items()}
+        for k, v in sdo.items():
+            if v.is_floating_point() and "running" not in k:
+                v.requires_grad_()
+        xo = t(rand_array("g5.%s.x" % tag, (R, 256, lh, lw), 1.0)).to(dt).requires_grad_()
+        so = [t(rand_array("g5.%s.s%d" % (tag, i), (R, chans[i]) + sizes[i], 1.0)).to(dt).requires_grad_() for i in range(4)]
+        oo = O.multiscale_decoder(xo, so, patch, sdo, True)[-1]
+        (oo * t(rand_array("g5.%s.w" % tag, oo.shape, 1.0)).to(dt)).sum().backward()
+        return dict(x=xo.grad, s0=so[0].grad, s3=so[3].grad, **{k: v.grad for k, v in sdo.items() if v.grad is not None})
+    g64, g32 = oracle_grads(torch.float64), oracle_grads(torch.float32)
+
+    def cond(k):
+        return float((g32[k].double() - g64[k]).abs().max() / g64[k].abs().max())
+    close(x.grad, g64["x"], max(2 * tol, 3 * cond("x")), "g5 dx")
+    close(skips[3].grad, g64["s3"], max(2 * tol, 3 * cond("s3")), "g5 ds3")
+    close(skips[0].grad, g64["s0"], max(2 * tol, 3 * cond("s0")), "g5 ds0")
+    close(g32["x"], g["dx"], max(2 * tol, 3 * cond("x")), "oracle vs reference dx")
+    close(g32["s0"][:, ::4, ::4, ::4], g["ds0_sub"], max(2 * tol, 3 * cond("s0")), "oracle vs reference ds0")
     for k, p in m.named_parameters():
-        close(p.grad.reshape(-1)[:16], g[k + "|head"], 4 * tol, "g5 grad " + k)
+        close(p.grad, g64[k], max(4 * tol, 3 * cond(k)), "g5 grad " + k)
 
 
 def rcnet_e2e_case(dev, tol=TOL):
