@@ -112,6 +112,14 @@ __global__ __launch_bounds__(256) void roi_pool_bwd_kernel(const T* __restrict__
   }
 }
 
+// explicit zero-fill kernel (kept as a kernel node so hipGraph replays order it like every other launch)
+__global__ __launch_bounds__(256) void zero_f32_kernel(float* __restrict__ p, int64_t n) {
+  const int64_t n4 = n >> 2;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x)
+    reinterpret_cast<float4*>(p)[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int64_t i = (n4 << 2) + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = 0.f;
+}
+
 static unsigned ew_grid(int64_t n) { return (unsigned)std::max<int64_t>(1, std::min<int64_t>(cdiv(n, 256), 4096)); }
 
 void launch_maxpool_fwd(const void* x, void* out, unsigned char* arg, int N, int H, int W, int C, int OH, int OW, int k, int s,
@@ -135,7 +143,8 @@ void launch_roi_pool_fwd(const void* x, const float* rois, void* out, int* argma
 }
 void launch_roi_pool_bwd(const void* dout, const float* rois, const int* argmax, float* dx_f32, int R, int N, int H, int W, int C,
                          int PH, int PW, int dtype, hipStream_t st) {
-  hipMemsetAsync(dx_f32, 0, (size_t)N * H * W * C * sizeof(float), st);
+  int64_t nz = (int64_t)N * H * W * C;
+  hipLaunchKernelGGL(zero_f32_kernel, dim3(ew_grid(nz / 4 + 1)), dim3(256), 0, st, dx_f32, nz);
   int64_t n = (int64_t)R * PH * PW * C;
   if (n == 0) return;
   if (dtype == 0) hipLaunchKernelGGL((roi_pool_bwd_kernel<float>), dim3(ew_grid(n)), dim3(256), 0, st, (const float*)dout, rois, argmax, dx_f32, R, N, H, W, C, PH, PW);

@@ -104,3 +104,49 @@ def forward_output(model, image, radar_points, bounding_boxes_list, response_thr
                                             H, W, ctypes.c_float(response_thr), engine.rd_of(crops), engine._stream(crops)),
                 "rd_scatter_crops")
     return depth, resp
+
+
+def compute_gradients(model, optimizer, batch, cfg=ZJU_CONFIG):
+    """Forward + loss + backward of one step (everything of rcnet_main.py:294-358 except the optimizer)."""
+    image, radar_point, rois, gt = prepare_batch(batch)
+    label, valid = engine.rcnet_labels(gt, radar_point, cfg['max_distance_correspondence'], cfg['set_invalid_to_negative_class'])
+    logits = model.forward(image, radar_point, rois, return_logits=True)
+    loss, _ = model.compute_loss(logits=logits, ground_truth=label, validity_map=valid, w_positive_class=cfg['w_positive_class'])
+    optimizer.zero_grad()
+    loss.backward()
+    return loss
+
+
+class GraphedTrainStep(object):
+    """The launch-bound part of the step (~1100 small kernel launches for forward + backward) captured once into a
+    hipGraph and replayed per step; the RCCL gradient all-reduce and the fused Adam launch stay eager on the same
+    stream.  Inputs are the static device tensors of `batch` (refill them in place for new data)."""
+
+    def __init__(self, model, optimizer, batch, cfg=ZJU_CONFIG, reducer=None, warmup=2):
+        self.model, self.opt, self.reducer = model, optimizer, reducer
+        assert engine._timer["t"] is None, "kernel timing and graph capture are exclusive"
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                train_step(model, optimizer, batch, cfg, reducer)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self._bn = [m for net in (model.encoder, model.decoder) for m in net.modules()
+                    if getattr(m, 'use_batch_norm', False) and hasattr(m, '_nbt_pending')]
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.loss = compute_gradients(model, optimizer, batch, cfg)
+        # the capture pass itself did not execute; keep host-side counters consistent
+        for m in self._bn:
+            m._nbt_pending -= 1
+
+    def __call__(self):
+        self.graph.replay()
+        for m in self._bn:
+            if m.training:
+                m._nbt_pending += 1
+        if self.reducer is not None:
+            self.reducer.reduce()
+        self.opt.step()
+        return self.loss

@@ -414,3 +414,38 @@ def rcnet_e2e_case(dev, tol=TOL):
                 continue
             rn = float(g[pref + k + "|norm"][0])
             assert abs(float(p.grad.norm()) - rn) < 5 * tol * max(rn, 1e-4), (k, float(p.grad.norm()), rn)
+
+
+def bf16_exact_conv_case(dev, cin=16, cout=16, k=3, s=1, H=9, W=7, N=2, up=None, cin2=0):
+    """bf16 data path check that does not depend on rounding: with inputs / weights / upstream gradients in {-1,0,1}
+    every product and partial sum is exactly representable, so the bf16 kernels must reproduce the fp32 oracle
+    bit for bit (forward, data gradient, weight gradient), including the concat / upsample gather variants."""
+    from riders_amd import engine
+    rs = np.random.RandomState(cin * 131 + cout * 17 + k)
+    w = torch.nn.Parameter(t(rs.randint(-1, 2, (cout, cin + cin2, k, k)).astype(np.float32), dev))
+    hs, ws_ = (H, W) if up is None else up[0]
+    x1 = t(rs.randint(-1, 2, (N, cin, hs, ws_)).astype(np.float32))
+    x2 = t(rs.randint(-1, 2, (N, cin2, hs, ws_)).astype(np.float32)) if cin2 else None
+    x1r = x1.clone().requires_grad_()
+    x2r = x2.clone().requires_grad_() if cin2 else None
+    xin = x1r if not cin2 else torch.cat([x1r, x2r], 1)
+    if up is not None:
+        xin = F.interpolate(xin, size=up[1])
+    wr = w.detach().cpu().clone().requires_grad_()
+    ref = F.conv2d(xin, wr, None, stride=s, padding=k // 2)
+    gy = t(rs.randint(-1, 2, tuple(ref.shape)).astype(np.float32))
+    (ref * gy).sum().backward()
+    a = x1.to(dev).permute(0, 2, 3, 1).contiguous().to(torch.bfloat16)
+    b = x2.to(dev).permute(0, 2, 3, 1).contiguous().to(torch.bfloat16) if cin2 else None
+    tape = engine.Tape(); tape.mark(a)
+    if cin2:
+        tape.mark(b)
+    with engine._active(tape):
+        out = engine.conv_block(a, w, x2=b, stride=s, pad=k // 2, up=None if up is None else up[1])
+        tape.grads[id(out)] = gy.to(dev).permute(0, 2, 3, 1).contiguous().to(torch.bfloat16)
+        tape.backward()
+    assert torch.equal(out.float().permute(0, 3, 1, 2).cpu(), ref.detach()), "bf16 forward differs"
+    assert torch.equal(tape.grads[id(a)].float().permute(0, 3, 1, 2).cpu(), x1r.grad), "bf16 dgrad (src1) differs"
+    if cin2:
+        assert torch.equal(tape.grads[id(b)].float().permute(0, 3, 1, 2).cpu(), x2r.grad), "bf16 dgrad (src2) differs"
+    assert torch.equal(tape.pgrads[id(w)].cpu(), wr.grad), "bf16 wgrad differs"

@@ -80,3 +80,47 @@ def test_native_library_loaded(gpu):
     assert not _lib.ALLOW_HOST_POINTERS
     maps = open("/proc/self/maps").read()
     assert os.path.join("riders_amd", "libriders_hip.so") in maps
+
+
+def test_bf16_throughput_mode(gpu):
+    """bf16 activations (fp32 accumulate / parameters / statistics) are a throughput mode with their own, looser
+    tolerance vs the fp32 oracle: 3e-2 of max|ref| per op, 5e-2 on end-to-end logits (bf16 has 8 mantissa bits)."""
+    from riders_amd import engine
+    engine.set_compute_dtype("bf16")
+    try:
+        for c in (P.CONV_CASES[0], P.CONV_CASES[1], P.CONV_CASES[2], P.CONV_CASES[5]):
+            P.conv_case(gpu, c, tol=3e-2)
+        P.decoder_block_case(gpu, tol=3e-2)
+        P.linear_attention_case(gpu, tol=3e-2)
+        P.transformer_case(gpu, tol=5e-2)
+        P.rcnet_e2e_case(gpu, tol=5e-2)
+    finally:
+        engine.set_compute_dtype("fp32")
+
+
+def test_graphed_step_matches_eager(gpu):
+    """hipGraph-captured forward+backward reproduces the eager step (same kernels, same order; the only run-to-run
+    freedom is the fp32 atomic order of the ROI-pool scatter-add)."""
+    import torch
+    from riders_amd import rcnet_main
+    from riders_amd.optim import FlatAdam
+    cfg = dict(rcnet_main.ZJU_CONFIG, patch_size=[64, 32], total_points_sampled=4)
+    batch = rcnet_main.synthetic_batch(2, 64, 96, cfg, seed=5, device=gpu)
+    losses = {}
+    for mode in ("eager", "graph"):
+        torch.manual_seed(0)
+        model = rcnet_main.build_model(gpu, cfg)
+        model.train()
+        opt = FlatAdam(model.parameters(), lr=1e-3)
+        if mode == "eager":
+            step = lambda: rcnet_main.train_step(model, opt, batch, cfg)  # noqa: E731
+            for _ in range(2):
+                step()
+        else:
+            step = rcnet_main.GraphedTrainStep(model, opt, batch, cfg, warmup=2)
+        losses[mode] = [float(step()) for _ in range(3)]
+        if mode == "graph":
+            nbt = int(model.encoder.state_dict()["encoder_image.conv1.batch_norm.num_batches_tracked"])
+            assert nbt == 5, nbt
+    for a, b in zip(losses["eager"], losses["graph"]):
+        assert abs(a - b) <= 1e-5 * abs(a), losses
