@@ -1,0 +1,39 @@
+"""CPU-only checks of the C-ABI boundary: libriders_hip.so (hipcc, gfx950) exists, loads, and exports every symbol
+include/riders_hip.h declares; no compute call is made (there is no GPU here)."""
+import ctypes
+import os
+
+import pytest
+
+from riders_amd import _lib
+
+
+def test_header_parses_and_lists_entries():
+    protos = _lib.parse_header()
+    assert len(protos) >= 40
+    for must in ("rd_conv_fwd", "rd_conv_wgrad", "rd_linear_attention_fwd", "rd_roi_pool_fwd", "rd_scatter_crops", "rd_adam_step"):
+        assert must in protos
+
+
+def test_library_exports_every_declared_symbol():
+    if not os.path.exists(_lib.LIB_PATH):
+        from riders_amd import build
+        build.build(verbose=False)
+    h = ctypes.CDLL(_lib.LIB_PATH)
+    missing = [n for n in _lib.parse_header() if not hasattr(h, n)]
+    assert not missing, missing
+    h.rd_version.restype = ctypes.c_int
+    assert h.rd_version() >= 100
+
+
+def test_conv_desc_matches_c_layout():
+    # 20 x 4-byte fields, no padding
+    assert ctypes.sizeof(_lib.ConvDesc) == 80
+
+
+def test_product_refuses_host_tensors():
+    import torch
+    from riders_amd import engine
+    _lib._uninstall_for_tests()
+    with pytest.raises(RuntimeError):
+        engine._stream(torch.zeros(1))
