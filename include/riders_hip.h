@@ -150,6 +150,53 @@ int rd_scatter_crops(const void* crops, const float* points, float* depth, float
 int rd_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
                  float beta2, float eps, float weight_decay, int64_t step, float grad_scale, void* stream);
 
+/* ==== Scale Map Learner (MiDaS-small) ================================================================================ */
+/* depthwise convolution of the tf_efficientnet_lite3 backbone (modules/midas/blocks.py:44-64; torch.hub, third-party):
+ * w = OIHW fp32 with I = 1; p = TF-"SAME" leading pad; partial [rd_dw_rows][C][k*k] */
+int32_t rd_dw_rows(int64_t pixels, int32_t C);
+int rd_dwconv_fwd(const void* x, const float* w, void* y, int32_t N, int32_t H, int32_t W, int32_t C, int32_t OH, int32_t OW, int32_t k,
+                  int32_t s, int32_t p, int32_t dtype, void* stream);
+int rd_dwconv_dgrad(const void* dy, const float* w, void* dx, int32_t N, int32_t H, int32_t W, int32_t C, int32_t OH, int32_t OW, int32_t k,
+                    int32_t s, int32_t p, int32_t dtype, void* stream);
+int rd_dwconv_wgrad(const void* x, const void* dy, float* partial, float* dw, int32_t accumulate, int32_t N, int32_t H, int32_t W,
+                    int32_t C, int32_t OH, int32_t OW, int32_t k, int32_t s, int32_t p, int32_t dtype, void* stream);
+/* BatchNorm (sum, sum^2) partials [rd_dw_rows][C][2] for producers without a fused statistics epilogue */
+int rd_bn_stats(const void* y, float* partial, int64_t pixels, int32_t C, int32_t dtype, void* stream);
+/* modules/midas/blocks.py:168-170 (align_corners=1) and :187 nn.Upsample (align_corners=0) */
+int rd_bilinear_fwd(const void* x, void* y, int32_t N, int32_t H, int32_t W, int32_t C, int32_t OH, int32_t OW, int32_t align_corners,
+                    int32_t dtype, void* stream);
+int rd_bilinear_bwd(const void* dy, void* dx, int32_t N, int32_t H, int32_t W, int32_t C, int32_t OH, int32_t OW, int32_t align_corners,
+                    int32_t dtype, void* stream);
+/* modules/midas/midas_net_custom.py:121-133: pred = d*relu(1+out), clamps (hi = 1/min_pred, lo = 1/max_pred, <= 0 disables) */
+int rd_sml_head_fwd(const void* out, const float* d, float* pred, int64_t n, float hi, float lo, int32_t dtype, void* stream);
+int rd_sml_head_bwd(const void* out, const float* d, const float* dpred, void* dout, int64_t n, float hi, float lo, int32_t dtype,
+                    void* stream);
+/* train_zju.py:355-356: out = 1/x (dy == NULL) or dx = -dy/x^2 */
+int rd_reciprocal(const float* x, const float* dy, float* out, int64_t n, void* stream);
+/* train_zju.py:246-343 + modules/estimator.py:146-176: per-sample bounded L1 scale fit of mono inverse depth to radar */
+int rd_sml_scale_align(const float* mono, const float* sparse_depth, int32_t B, int32_t HW, float min_depth, float max_depth, float lo,
+                       float hi, float* scale, int32_t* nvalid, void* stream);
+/* int_depth / int_scales / min-max normalise / nearest resize / mean-std normalise / gray -> x (B,h,w,3), d (B,h,w); mm [B][3] scratch */
+int rd_sml_build_inputs(const float* image_nchw, const float* mono, const float* sparse_depth, const float* rcnet_depth, const float* scale,
+                        float* mm, int32_t B, int32_t H, int32_t W, int32_t h, int32_t w, float min_depth, float max_depth, float clamp_hi,
+                        float clamp_lo, int32_t use_rcnet, float mean_depth, float std_depth, float mean_scales, float std_scales, float* x,
+                        float* d, void* stream);
+/* utils/net_utils.py:591-638 */
+int32_t rd_outlier_parts(int64_t n);
+int rd_outlier_removal(const float* depth, float* partial, float* out, int32_t N, int32_t H, int32_t W, int32_t kernel_size, float threshold,
+                       void* stream);
+/* utils/loss.py:5-135,187-274 ('l1'); info[7] = loss, supervised, lidar, smoothness, edge, n_interp, n_lidar; partial = doubles [rows][8] */
+int32_t rd_sml_loss_rows(int64_t n);
+int rd_sml_loss_fwd(const float* pred, const float* image, const float* gt_interp, const float* gt_sparse, const float* weights, int32_t N,
+                    int32_t H, int32_t W, int32_t filter_size, float w_lidar, float w_smooth, float w_edge, float* gfx, float* gfy,
+                    double* partial, float* info, void* stream);
+int rd_sml_loss_bwd(const float* pred, const float* gt_interp, const float* gt_sparse, const float* gfx, const float* gfy, const float* info,
+                    const float* dloss, int32_t N, int32_t H, int32_t W, int32_t filter_size, float w_lidar, float w_smooth, float* dpred,
+                    void* stream);
+/* val_zju.py:200-206 bicubic (A=-0.75, align_corners=False); :212-231 + utils/eval_utils.py metric sums, res = doubles [N][8] */
+int rd_bicubic_resize(const float* x, float* y, int32_t N, int32_t H, int32_t W, int32_t OH, int32_t OW, void* stream);
+int rd_depth_metrics(const float* out, const float* gt, int32_t N, int32_t HW, float min_depth, float max_depth, double* res, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -293,4 +293,103 @@ int rd_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float 
   return done("rd_adam_step");
 }
 
+
+// ---- Scale Map Learner ------------------------------------------------------------------------------------------------
+int32_t rd_dw_rows(int64_t pixels, int32_t C) { return rd::dw_rows(pixels, C); }
+int rd_dwconv_fwd(const void* x, const float* w, void* y, int32_t N, int32_t H, int32_t W, int32_t C, int32_t OH, int32_t OW, int32_t k,
+                  int32_t s, int32_t p, int32_t dtype, void* stream) {
+  if (!x || !w || !y || !dt_ok(dtype) || k > 5 || k < 1) return fail("dwconv_fwd: bad args");
+  rd::launch_dwconv_fwd(x, w, y, N, H, W, C, OH, OW, k, s, p, dtype, S(stream));
+  return done("rd_dwconv_fwd");
+}
+int rd_dwconv_dgrad(const void* dy, const float* w, void* dx, int32_t N, int32_t H, int32_t W, int32_t C, int32_t OH, int32_t OW, int32_t k,
+                    int32_t s, int32_t p, int32_t dtype, void* stream) {
+  if (!dy || !w || !dx || !dt_ok(dtype) || k > 5 || k < 1) return fail("dwconv_dgrad: bad args");
+  rd::launch_dwconv_dgrad(dy, w, dx, N, H, W, C, OH, OW, k, s, p, dtype, S(stream));
+  return done("rd_dwconv_dgrad");
+}
+int rd_dwconv_wgrad(const void* x, const void* dy, float* partial, float* dw, int32_t accumulate, int32_t N, int32_t H, int32_t W, int32_t C,
+                    int32_t OH, int32_t OW, int32_t k, int32_t s, int32_t p, int32_t dtype, void* stream) {
+  if (!x || !dy || !partial || !dw || !dt_ok(dtype) || k > 5 || k < 1) return fail("dwconv_wgrad: bad args");
+  rd::launch_dwconv_wgrad(x, dy, partial, dw, accumulate, N, H, W, C, OH, OW, k, s, p, dtype, S(stream));
+  return done("rd_dwconv_wgrad");
+}
+int rd_bn_stats(const void* y, float* partial, int64_t pixels, int32_t C, int32_t dtype, void* stream) {
+  if (!y || !partial || !dt_ok(dtype)) return fail("bn_stats: bad args");
+  rd::launch_bn_stats(y, partial, pixels, C, dtype, S(stream));
+  return done("rd_bn_stats");
+}
+int rd_bilinear_fwd(const void* x, void* y, int32_t N, int32_t H, int32_t W, int32_t C, int32_t OH, int32_t OW, int32_t align, int32_t dtype,
+                    void* stream) {
+  if (!x || !y || !dt_ok(dtype)) return fail("bilinear_fwd: bad args");
+  rd::launch_bilinear(x, y, N, H, W, C, OH, OW, align, 0, dtype, S(stream));
+  return done("rd_bilinear_fwd");
+}
+int rd_bilinear_bwd(const void* dy, void* dx, int32_t N, int32_t H, int32_t W, int32_t C, int32_t OH, int32_t OW, int32_t align, int32_t dtype,
+                    void* stream) {
+  if (!dy || !dx || !dt_ok(dtype)) return fail("bilinear_bwd: bad args");
+  rd::launch_bilinear(dy, dx, N, H, W, C, OH, OW, align, 1, dtype, S(stream));
+  return done("rd_bilinear_bwd");
+}
+int rd_sml_head_fwd(const void* out, const float* d, float* pred, int64_t n, float hi, float lo, int32_t dtype, void* stream) {
+  if (!out || !d || !pred || !dt_ok(dtype)) return fail("sml_head_fwd: bad args");
+  rd::launch_sml_head_fwd(out, d, pred, n, hi, lo, dtype, S(stream));
+  return done("rd_sml_head_fwd");
+}
+int rd_sml_head_bwd(const void* out, const float* d, const float* dpred, void* dout, int64_t n, float hi, float lo, int32_t dtype, void* stream) {
+  if (!out || !d || !dpred || !dout || !dt_ok(dtype)) return fail("sml_head_bwd: bad args");
+  rd::launch_sml_head_bwd(out, d, dpred, dout, n, hi, lo, dtype, S(stream));
+  return done("rd_sml_head_bwd");
+}
+int rd_reciprocal(const float* x, const float* dy, float* out, int64_t n, void* stream) {
+  if (!x || !out) return fail("reciprocal: null pointer");
+  if (n == 0) return 0;
+  rd::launch_reciprocal(x, dy, out, n, S(stream));
+  return done("rd_reciprocal");
+}
+int rd_sml_scale_align(const float* mono, const float* sparse, int32_t B, int32_t HW, float dmin, float dmax, float lo, float hi, float* scale,
+                       int32_t* nvalid, void* stream) {
+  if (!mono || !sparse || !scale || !nvalid) return fail("sml_scale_align: null pointer");
+  rd::launch_sml_scale_align(mono, sparse, B, HW, dmin, dmax, lo, hi, scale, nvalid, S(stream));
+  return done("rd_sml_scale_align");
+}
+int rd_sml_build_inputs(const float* image, const float* mono, const float* sparse, const float* rcnet, const float* scale, float* mm, int32_t B,
+                        int32_t H, int32_t W, int32_t h, int32_t w, float dmin, float dmax, float hi, float lo, int32_t use_rcnet, float m0,
+                        float s0, float m1, float s1, float* x, float* d, void* stream) {
+  if (!image || !mono || !sparse || !scale || !mm || !x || !d) return fail("sml_build_inputs: null pointer");
+  if (use_rcnet && !rcnet) return fail("sml_build_inputs: use_rcnet without rcnet depth");
+  rd::launch_sml_build_inputs(image, mono, sparse, rcnet, scale, mm, B, H, W, h, w, dmin, dmax, hi, lo, use_rcnet, m0, s0, m1, s1, x, d, S(stream));
+  return done("rd_sml_build_inputs");
+}
+int32_t rd_outlier_parts(int64_t n) { return rd::outlier_parts(n); }
+int rd_outlier_removal(const float* depth, float* partial, float* out, int32_t N, int32_t H, int32_t W, int32_t k, float thr, void* stream) {
+  if (!depth || !partial || !out) return fail("outlier_removal: null pointer");
+  rd::launch_outlier_removal(depth, partial, out, N, H, W, k, thr, S(stream));
+  return done("rd_outlier_removal");
+}
+int32_t rd_sml_loss_rows(int64_t n) { return rd::sml_loss_rows(n); }
+int rd_sml_loss_fwd(const float* pred, const float* image, const float* gi, const float* gs, const float* weights, int32_t N, int32_t H, int32_t W,
+                    int32_t fs, float w_lidar, float w_smooth, float w_edge, float* gfx, float* gfy, double* partial, float* info, void* stream) {
+  if (!pred || !image || !gi || !gs || !gfx || !gfy || !partial || !info) return fail("sml_loss_fwd: null pointer");
+  if (fs < 3 || fs > 9 || !(fs & 1)) return fail("sml_loss: filter size must be odd in 3..9");
+  rd::launch_sml_loss_fwd(pred, image, gi, gs, weights, N, H, W, fs, w_lidar > 0.f ? 1 : 0, w_lidar, w_smooth, w_edge, gfx, gfy, partial, info, S(stream));
+  return done("rd_sml_loss_fwd");
+}
+int rd_sml_loss_bwd(const float* pred, const float* gi, const float* gs, const float* gfx, const float* gfy, const float* info, const float* dloss,
+                    int32_t N, int32_t H, int32_t W, int32_t fs, float w_lidar, float w_smooth, float* dpred, void* stream) {
+  if (!pred || !gi || !gs || !gfx || !gfy || !info || !dloss || !dpred) return fail("sml_loss_bwd: null pointer");
+  rd::launch_sml_loss_bwd(pred, gi, gs, gfx, gfy, info, dloss, N, H, W, fs, w_lidar > 0.f ? 1 : 0, w_lidar, w_smooth, dpred, S(stream));
+  return done("rd_sml_loss_bwd");
+}
+int rd_bicubic_resize(const float* x, float* y, int32_t N, int32_t H, int32_t W, int32_t OH, int32_t OW, void* stream) {
+  if (!x || !y) return fail("bicubic_resize: null pointer");
+  rd::launch_bicubic(x, y, N, H, W, OH, OW, S(stream));
+  return done("rd_bicubic_resize");
+}
+int rd_depth_metrics(const float* out, const float* gt, int32_t N, int32_t HW, float dmin, float dmax, double* res, void* stream) {
+  if (!out || !gt || !res) return fail("depth_metrics: null pointer");
+  rd::launch_depth_metrics(out, gt, N, HW, dmin, dmax, res, S(stream));
+  return done("rd_depth_metrics");
+}
+
 }  // extern "C"

@@ -1,0 +1,286 @@
+// Depthwise convolution, bilinear x2 resampling, the SML prediction head and small elementwise helpers.
+// All HBM-bound (depthwise: 2*k*k FLOP per 4-byte element), NHWC, coalesced over channels.
+//
+// Reference call sites:
+//   modules/midas/blocks.py:44-64  tf_efficientnet_lite3 (torch.hub, third-party: geffnet DepthwiseSeparableConv /
+//                                  InvertedResidual: conv_dw k3/k5 stride 1/2, TF-"SAME" padding, BN eps 1e-3, ReLU6)
+//   modules/midas/blocks.py:168-170 F.interpolate(scale_factor=2, bilinear, align_corners=True)
+//   modules/midas/blocks.py:187     nn.Upsample(scale_factor=2, mode="bilinear")  (align_corners=False)
+//   modules/midas/midas_net_custom.py:121-133  scales = relu(1 + out); pred = d * scales; in-place clamps
+//   train_zju.py:355-356            d = 1/d; sml_pred = 1/sml_pred
+#include "rd_common.h"
+#include "rd_kernels.h"
+
+namespace rd {
+
+static unsigned ew_grid(int64_t n) { return (unsigned)std::max<int64_t>(1, std::min<int64_t>(cdiv(n, 256), 4096)); }
+
+// weights: OIHW with I = 1 -> w[c*k*k + kh*k + kw]
+template <typename T>
+__global__ __launch_bounds__(256) void dwconv_fwd_kernel(const T* __restrict__ x, const float* __restrict__ w, T* __restrict__ y,
+                                                         int N, int H, int W, int C, int OH, int OW, int k, int s, int p) {
+  const int64_t total = (int64_t)N * OH * OW * C;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int c = (int)(i % C); int64_t q = i / C;
+    int ow = (int)(q % OW); q /= OW; int oh = (int)(q % OH); int n = (int)(q / OH);
+    float acc = 0.f;
+    for (int kh = 0; kh < k; kh++) {
+      int ih = oh * s - p + kh;
+      if ((unsigned)ih >= (unsigned)H) continue;
+      for (int kw = 0; kw < k; kw++) {
+        int iw = ow * s - p + kw;
+        if ((unsigned)iw >= (unsigned)W) continue;
+        acc += Elem<T>::ld(x + (((int64_t)n * H + ih) * W + iw) * C + c) * w[(c * k + kh) * k + kw];
+      }
+    }
+    Elem<T>::st(y + i, acc);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void dwconv_dgrad_kernel(const T* __restrict__ dy, const float* __restrict__ w, T* __restrict__ dx,
+                                                           int N, int H, int W, int C, int OH, int OW, int k, int s, int p) {
+  const int64_t total = (int64_t)N * H * W * C;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int c = (int)(i % C); int64_t q = i / C;
+    int iw = (int)(q % W); q /= W; int ih = (int)(q % H); int n = (int)(q / H);
+    float acc = 0.f;
+    for (int kh = 0; kh < k; kh++) {
+      int t = ih + p - kh;
+      if (t < 0 || (t % s)) continue;
+      int oh = t / s;
+      if (oh >= OH) continue;
+      for (int kw = 0; kw < k; kw++) {
+        int u = iw + p - kw;
+        if (u < 0 || (u % s)) continue;
+        int ow = u / s;
+        if (ow >= OW) continue;
+        acc += Elem<T>::ld(dy + (((int64_t)n * OH + oh) * OW + ow) * C + c) * w[(c * k + kh) * k + kw];
+      }
+    }
+    Elem<T>::st(dx + i, acc);
+  }
+}
+
+// partial[row][c][k*k]: thread (channel cl, pixel lane pl) accumulates all taps of its channel over its pixels
+template <typename T, int KK>
+__global__ __launch_bounds__(256) void dwconv_wgrad_kernel(const T* __restrict__ x, const T* __restrict__ dy, float* __restrict__ partial,
+                                                           int N, int H, int W, int C, int OH, int OW, int k, int s, int p, int CB,
+                                                           int PL) {
+  __shared__ float red[256];
+  const int t = threadIdx.x, cl = t % CB, pl = t / CB;
+  const int c = blockIdx.y * CB + cl;
+  const int64_t pixels = (int64_t)N * OH * OW;
+  const int64_t per = cdiv(pixels, gridDim.x);
+  const int64_t pbeg = (int64_t)blockIdx.x * per, pend = pbeg + per < pixels ? pbeg + per : pixels;
+  float acc[KK];
+#pragma unroll
+  for (int j = 0; j < KK; j++) acc[j] = 0.f;
+  if (c < C) {
+    for (int64_t m = pbeg + pl; m < pend; m += PL) {
+      int ow = (int)(m % OW); int64_t q = m / OW; int oh = (int)(q % OH); int n = (int)(q / OH);
+      float g = Elem<T>::ld(dy + m * C + c);
+#pragma unroll
+      for (int j = 0; j < KK; j++) {
+        int kh = j / k, kw = j - kh * k;
+        int ih = oh * s - p + kh, iw = ow * s - p + kw;
+        if (j < k * k && (unsigned)ih < (unsigned)H && (unsigned)iw < (unsigned)W)
+          acc[j] += g * Elem<T>::ld(x + (((int64_t)n * H + ih) * W + iw) * C + c);
+      }
+    }
+  }
+  for (int j = 0; j < k * k; j++) {
+    float v = 0.f;
+#pragma unroll
+    for (int jj = 0; jj < KK; jj++) if (jj == j) v = acc[jj];
+    red[t] = v;
+    __syncthreads();
+    if (pl == 0 && c < C) {
+      float sacc = 0.f;
+      for (int q = 0; q < PL; q++) sacc += red[q * CB + cl];
+      partial[((int64_t)blockIdx.x * C + c) * (k * k) + j] = sacc;
+    }
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(64) void dwconv_wgrad_finalize_kernel(const float* __restrict__ partial, int rows, int CK, float* dw,
+                                                                   int accumulate) {
+  const int i = blockIdx.x, lane = threadIdx.x;
+  double a = 0.0;
+  for (int r = lane; r < rows; r += 64) a += partial[(int64_t)r * CK + i];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o);
+  if (lane == 0) dw[i] = accumulate ? dw[i] + (float)a : (float)a;
+}
+
+// per-channel (sum, sum^2) partials of an NHWC tensor: BatchNorm statistics for layers whose producer has no fused epilogue
+template <typename T>
+__global__ __launch_bounds__(256) void bn_stats_kernel(const T* __restrict__ y, float* __restrict__ partial, int64_t pixels, int C,
+                                                       int CB, int PL) {
+  __shared__ float red[2][256];
+  const int t = threadIdx.x, cl = t % CB, pl = t / CB;
+  const int c = blockIdx.y * CB + cl;
+  const int64_t per = cdiv(pixels, gridDim.x);
+  const int64_t pbeg = (int64_t)blockIdx.x * per, pend = pbeg + per < pixels ? pbeg + per : pixels;
+  float a = 0.f, b = 0.f;
+  if (c < C)
+    for (int64_t m = pbeg + pl; m < pend; m += PL) { float v = Elem<T>::ld(y + m * C + c); a += v; b += v * v; }
+  red[0][t] = a; red[1][t] = b;
+  __syncthreads();
+  if (pl == 0 && c < C) {
+    float sa = 0.f, sb = 0.f;
+    for (int q = 0; q < PL; q++) { sa += red[0][q * CB + cl]; sb += red[1][q * CB + cl]; }
+    partial[((int64_t)blockIdx.x * C + c) * 2] = sa;
+    partial[((int64_t)blockIdx.x * C + c) * 2 + 1] = sb;
+  }
+}
+
+// ---- bilinear x2 (ATen upsample_bilinear2d index arithmetic) ------------------------------------------------------
+__device__ __forceinline__ void bil_src(int d, int in, int out, int align, int& i0, int& i1, float& l1) {
+  float src;
+  if (align) src = (out > 1) ? (float)d * ((float)(in - 1) / (float)(out - 1)) : 0.f;
+  else { src = ((float)d + 0.5f) * ((float)in / (float)out) - 0.5f; if (src < 0.f) src = 0.f; }
+  i0 = (int)src; if (i0 > in - 1) i0 = in - 1;
+  i1 = i0 < in - 1 ? i0 + 1 : i0;
+  l1 = src - (float)i0;
+}
+template <typename T>
+__global__ __launch_bounds__(256) void bilinear_fwd_kernel(const T* __restrict__ x, T* __restrict__ y, int N, int H, int W, int C, int OH,
+                                                           int OW, int align) {
+  const int64_t total = (int64_t)N * OH * OW * C;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int c = (int)(i % C); int64_t q = i / C;
+    int ow = (int)(q % OW); q /= OW; int oh = (int)(q % OH); int n = (int)(q / OH);
+    int h0, h1, w0, w1; float lh, lw;
+    bil_src(oh, H, OH, align, h0, h1, lh);
+    bil_src(ow, W, OW, align, w0, w1, lw);
+    const T* b = x + (int64_t)n * H * W * C + c;
+    float v00 = Elem<T>::ld(b + ((int64_t)h0 * W + w0) * C), v01 = Elem<T>::ld(b + ((int64_t)h0 * W + w1) * C);
+    float v10 = Elem<T>::ld(b + ((int64_t)h1 * W + w0) * C), v11 = Elem<T>::ld(b + ((int64_t)h1 * W + w1) * C);
+    Elem<T>::st(y + i, (1.f - lh) * ((1.f - lw) * v00 + lw * v01) + lh * ((1.f - lw) * v10 + lw * v11));
+  }
+}
+// deterministic gather: every source pixel collects the weights with which destination pixels read it
+template <typename T>
+__global__ __launch_bounds__(256) void bilinear_bwd_kernel(const T* __restrict__ dy, T* __restrict__ dx, int N, int H, int W, int C, int OH,
+                                                           int OW, int align) {
+  const int64_t total = (int64_t)N * H * W * C;
+  const int rh = (OH + H - 1) / H + 2, rw = (OW + W - 1) / W + 2;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int c = (int)(i % C); int64_t q = i / C;
+    int w = (int)(q % W); q /= W; int h = (int)(q % H); int n = (int)(q / H);
+    int ohc = (int)(((int64_t)h * OH) / H), owc = (int)(((int64_t)w * OW) / W);
+    float g = 0.f;
+    for (int oh = max(ohc - rh, 0); oh <= min(ohc + rh, OH - 1); oh++) {
+      int h0, h1; float lh; int dum0, dum1; (void)dum0; (void)dum1;
+      bil_src(oh, H, OH, align, h0, h1, lh);
+      float wh = (h0 == h ? 1.f - lh : 0.f) + (h1 == h ? lh : 0.f);
+      if (wh == 0.f) continue;
+      for (int ow = max(owc - rw, 0); ow <= min(owc + rw, OW - 1); ow++) {
+        int w0, w1; float lw;
+        bil_src(ow, W, OW, align, w0, w1, lw);
+        float ww = (w0 == w ? 1.f - lw : 0.f) + (w1 == w ? lw : 0.f);
+        if (ww == 0.f) continue;
+        g += wh * ww * Elem<T>::ld(dy + (((int64_t)n * OH + oh) * OW + ow) * C + c);
+      }
+    }
+    Elem<T>::st(dx + i, g);
+  }
+}
+
+// ---- SML head ---------------------------------------------------------------------------------------------------------
+// pred = d * relu(1 + out); pred > hi -> hi; pred < lo -> lo   (hi = 1/min_pred, lo = 1/max_pred; <0 disables)
+template <typename T>
+__global__ __launch_bounds__(256) void sml_head_fwd_kernel(const T* __restrict__ out, const float* __restrict__ d, float* __restrict__ pred,
+                                                           int64_t n, float hi, float lo) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    float sc = 1.f + Elem<T>::ld(out + i); sc = sc > 0.f ? sc : 0.f;
+    float p = d[i] * sc;
+    if (hi > 0.f && p > hi) p = hi;
+    if (lo > 0.f && p < lo) p = lo;
+    pred[i] = p;
+  }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void sml_head_bwd_kernel(const T* __restrict__ out, const float* __restrict__ d, const float* __restrict__ dpred,
+                                                           T* __restrict__ dout, int64_t n, float hi, float lo) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    float sc = 1.f + Elem<T>::ld(out + i);
+    float p = d[i] * (sc > 0.f ? sc : 0.f);
+    bool clamped = (hi > 0.f && p > hi);
+    if (!clamped && lo > 0.f && p < lo) clamped = true;
+    Elem<T>::st(dout + i, (sc > 0.f && !clamped) ? dpred[i] * d[i] : 0.f);
+  }
+}
+// y = 1/x ; dx = -dy / x^2   (fp32)
+__global__ __launch_bounds__(256) void reciprocal_kernel(const float* __restrict__ x, const float* __restrict__ dy, float* __restrict__ out,
+                                                         int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    float v = x[i];
+    out[i] = dy ? -dy[i] / (v * v) : 1.f / v;
+  }
+}
+
+// ---- launchers -----------------------------------------------------------------------------------------------------------
+struct RG { int CB, PL, nchunk; };
+static RG rgeom(int C) { RG g; int cb = 1; while (cb < C && cb < 256) cb <<= 1; g.CB = cb; g.PL = 256 / cb; g.nchunk = (int)cdiv(C, cb); return g; }
+int dw_rows(int64_t pixels, int C) {
+  RG g = rgeom(C);
+  return (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(pixels, (int64_t)g.PL * 64), 512));
+}
+
+void launch_dwconv_fwd(const void* x, const float* w, void* y, int N, int H, int W, int C, int OH, int OW, int k, int s, int p, int dtype,
+                       hipStream_t st) {
+  int64_t n = (int64_t)N * OH * OW * C;
+  if (dtype == 0) hipLaunchKernelGGL((dwconv_fwd_kernel<float>), dim3(ew_grid(n)), dim3(256), 0, st, (const float*)x, w, (float*)y, N, H, W, C, OH, OW, k, s, p);
+  else hipLaunchKernelGGL((dwconv_fwd_kernel<bf16_t>), dim3(ew_grid(n)), dim3(256), 0, st, (const bf16_t*)x, w, (bf16_t*)y, N, H, W, C, OH, OW, k, s, p);
+}
+void launch_dwconv_dgrad(const void* dy, const float* w, void* dx, int N, int H, int W, int C, int OH, int OW, int k, int s, int p,
+                         int dtype, hipStream_t st) {
+  int64_t n = (int64_t)N * H * W * C;
+  if (dtype == 0) hipLaunchKernelGGL((dwconv_dgrad_kernel<float>), dim3(ew_grid(n)), dim3(256), 0, st, (const float*)dy, w, (float*)dx, N, H, W, C, OH, OW, k, s, p);
+  else hipLaunchKernelGGL((dwconv_dgrad_kernel<bf16_t>), dim3(ew_grid(n)), dim3(256), 0, st, (const bf16_t*)dy, w, (bf16_t*)dx, N, H, W, C, OH, OW, k, s, p);
+}
+void launch_dwconv_wgrad(const void* x, const void* dy, float* partial, float* dw, int accumulate, int N, int H, int W, int C, int OH,
+                         int OW, int k, int s, int p, int dtype, hipStream_t st) {
+  RG g = rgeom(C);
+  int rows = dw_rows((int64_t)N * OH * OW, C);
+  dim3 grid(rows, g.nchunk);
+#define RD_DW(T, KK) hipLaunchKernelGGL((dwconv_wgrad_kernel<T, KK>), grid, dim3(256), 0, st, (const T*)x, (const T*)dy, partial, N, H, W, C, OH, OW, k, s, p, g.CB, g.PL)
+  if (dtype == 0) { if (k <= 3) RD_DW(float, 9); else RD_DW(float, 25); }
+  else { if (k <= 3) RD_DW(bf16_t, 9); else RD_DW(bf16_t, 25); }
+#undef RD_DW
+  hipLaunchKernelGGL(dwconv_wgrad_finalize_kernel, dim3(C * k * k), dim3(64), 0, st, partial, rows, C * k * k, dw, accumulate);
+}
+void launch_bn_stats(const void* y, float* partial, int64_t pixels, int C, int dtype, hipStream_t st) {
+  RG g = rgeom(C);
+  dim3 grid(dw_rows(pixels, C), g.nchunk);
+  if (dtype == 0) hipLaunchKernelGGL((bn_stats_kernel<float>), grid, dim3(256), 0, st, (const float*)y, partial, pixels, C, g.CB, g.PL);
+  else hipLaunchKernelGGL((bn_stats_kernel<bf16_t>), grid, dim3(256), 0, st, (const bf16_t*)y, partial, pixels, C, g.CB, g.PL);
+}
+void launch_bilinear(const void* x, void* y, int N, int H, int W, int C, int OH, int OW, int align, int backward, int dtype, hipStream_t st) {
+  if (!backward) {
+    unsigned g = ew_grid((int64_t)N * OH * OW * C);
+    if (dtype == 0) hipLaunchKernelGGL((bilinear_fwd_kernel<float>), dim3(g), dim3(256), 0, st, (const float*)x, (float*)y, N, H, W, C, OH, OW, align);
+    else hipLaunchKernelGGL((bilinear_fwd_kernel<bf16_t>), dim3(g), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, N, H, W, C, OH, OW, align);
+  } else {  // x = dy (N,OH,OW,C), y = dx (N,H,W,C)
+    unsigned g = ew_grid((int64_t)N * H * W * C);
+    if (dtype == 0) hipLaunchKernelGGL((bilinear_bwd_kernel<float>), dim3(g), dim3(256), 0, st, (const float*)x, (float*)y, N, H, W, C, OH, OW, align);
+    else hipLaunchKernelGGL((bilinear_bwd_kernel<bf16_t>), dim3(g), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, N, H, W, C, OH, OW, align);
+  }
+}
+void launch_sml_head_fwd(const void* out, const float* d, float* pred, int64_t n, float hi, float lo, int dtype, hipStream_t st) {
+  if (dtype == 0) hipLaunchKernelGGL((sml_head_fwd_kernel<float>), dim3(ew_grid(n)), dim3(256), 0, st, (const float*)out, d, pred, n, hi, lo);
+  else hipLaunchKernelGGL((sml_head_fwd_kernel<bf16_t>), dim3(ew_grid(n)), dim3(256), 0, st, (const bf16_t*)out, d, pred, n, hi, lo);
+}
+void launch_sml_head_bwd(const void* out, const float* d, const float* dpred, void* dout, int64_t n, float hi, float lo, int dtype,
+                         hipStream_t st) {
+  if (dtype == 0) hipLaunchKernelGGL((sml_head_bwd_kernel<float>), dim3(ew_grid(n)), dim3(256), 0, st, (const float*)out, d, dpred, (float*)dout, n, hi, lo);
+  else hipLaunchKernelGGL((sml_head_bwd_kernel<bf16_t>), dim3(ew_grid(n)), dim3(256), 0, st, (const bf16_t*)out, d, dpred, (bf16_t*)dout, n, hi, lo);
+}
+void launch_reciprocal(const float* x, const float* dy, float* out, int64_t n, hipStream_t st) {
+  hipLaunchKernelGGL(reciprocal_kernel, dim3(ew_grid(n)), dim3(256), 0, st, x, dy, out, n);
+}
+
+}  // namespace rd

@@ -97,4 +97,27 @@ void launch_scatter_crops(const void* crops, const float* points, float* depth, 
 void launch_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2, float eps,
                  float wd, float bc1, float bc2, float gscale, hipStream_t st);
 
+
+// rd_dwconv.hip
+int dw_rows(int64_t pixels, int C);
+void launch_dwconv_fwd(const void* x, const float* w, void* y, int N, int H, int W, int C, int OH, int OW, int k, int s, int p, int dtype, hipStream_t st);
+void launch_dwconv_dgrad(const void* dy, const float* w, void* dx, int N, int H, int W, int C, int OH, int OW, int k, int s, int p, int dtype, hipStream_t st);
+void launch_dwconv_wgrad(const void* x, const void* dy, float* partial, float* dw, int accumulate, int N, int H, int W, int C, int OH, int OW, int k, int s, int p, int dtype, hipStream_t st);
+void launch_bn_stats(const void* y, float* partial, int64_t pixels, int C, int dtype, hipStream_t st);
+void launch_bilinear(const void* x, void* y, int N, int H, int W, int C, int OH, int OW, int align, int backward, int dtype, hipStream_t st);
+void launch_sml_head_fwd(const void* out, const float* d, float* pred, int64_t n, float hi, float lo, int dtype, hipStream_t st);
+void launch_sml_head_bwd(const void* out, const float* d, const float* dpred, void* dout, int64_t n, float hi, float lo, int dtype, hipStream_t st);
+void launch_reciprocal(const float* x, const float* dy, float* out, int64_t n, hipStream_t st);
+
+// rd_sml.hip
+void launch_sml_scale_align(const float* mono, const float* sparse, int B, int HW, float dmin, float dmax, float lo, float hi, float* scale, int* nvalid, hipStream_t st);
+void launch_sml_build_inputs(const float* image, const float* mono, const float* sparse, const float* rcnet, const float* scale, float* mm, int B, int H, int W, int h, int w, float dmin, float dmax, float hi, float lo, int use_rcnet, float m0, float s0, float m1, float s1, float* x, float* d, hipStream_t st);
+int outlier_parts(int64_t n);
+void launch_outlier_removal(const float* depth, float* partial, float* out, int N, int H, int W, int k, float thr, hipStream_t st);
+int sml_loss_rows(int64_t n);
+void launch_sml_loss_fwd(const float* pred, const float* image, const float* gi, const float* gs, const float* weights, int N, int H, int W, int fs, int mask_interp, float w_lidar, float w_smooth, float w_edge, float* gfx, float* gfy, double* partial, float* info, hipStream_t st);
+void launch_sml_loss_bwd(const float* pred, const float* gi, const float* gs, const float* gfx, const float* gfy, const float* info, const float* dloss, int N, int H, int W, int fs, int mask_interp, float w_lidar, float w_smooth, float* dpred, hipStream_t st);
+void launch_bicubic(const float* x, float* y, int N, int H, int W, int OH, int OW, hipStream_t st);
+void launch_depth_metrics(const float* out, const float* gt, int N, int HW, float dmin, float dmax, double* res, hipStream_t st);
+
 }  // namespace rd

@@ -1,0 +1,382 @@
+// Scale-Map-Learner pre-step, loss, outlier removal and validation kernels (all HBM-bound; reductions by wave shuffles +
+// per-block partials combined in a fixed order).
+//
+// Reference:
+//   train_zju.py:246-343        per-sample CPU pre-step (valid masks, 1/depth, Optimizer.optimize_scale, int_scales,
+//                               min-max normalise, cv2 nearest resize, fixed mean/std normalise, gray image)
+//   modules/estimator.py:129-176 objective sum(mask*|s*p - t|), bounded minimisation, clamps
+//   utils/net_utils.py:591-638  OutlierRemoval.remove_outliers
+//   utils/loss.py:5-135,187-274 compute_loss ('l1'), sobel_smoothness_loss_func, sobel_filter
+//   val_zju.py:198-231, utils/eval_utils.py  bicubic resize (A=-0.75, align_corners=False) and the metric set
+#include "rd_common.h"
+#include "rd_kernels.h"
+
+namespace rd {
+
+static unsigned ew_grid(int64_t n, int cap = 2048) { return (unsigned)std::max<int64_t>(1, std::min<int64_t>(cdiv(n, 256), cap)); }
+
+__device__ __forceinline__ double block_sum_d(double v, double* sh) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) sh[wv] = v;
+  __syncthreads();
+  double r = 0.0;
+  for (int w = 0; w < (int)(blockDim.x >> 6); w++) r += sh[w];
+  return r;
+}
+
+// ---- S1: global scale alignment --------------------------------------------------------------------------------------
+// s* = argmin_{s in [lo,hi]} sum_valid |s*p - t|, t = 1/depth on valid radar pixels.  The objective is convex piecewise
+// linear, so s* is where its slope g(s) = sum p*sign(s*p - t) changes sign: 50 bisection steps, one block per sample.
+// (scipy's bounded Brent stops within xatol = 1e-5 of the same point; with no valid pixel it returns 0.299996..., kept.)
+__global__ __launch_bounds__(256) void sml_scale_align_kernel(const float* __restrict__ mono, const float* __restrict__ sparse, int HW,
+                                                              float dmin, float dmax, float lo, float hi, float* __restrict__ scale,
+                                                              int* __restrict__ nvalid) {
+  __shared__ double sh[4];
+  const int b = blockIdx.x;
+  const float* p = mono + (int64_t)b * HW;
+  const float* z = sparse + (int64_t)b * HW;
+  double cnt = 0.0;
+  for (int i = threadIdx.x; i < HW; i += 256) cnt += (z[i] < dmax && z[i] > dmin) ? 1.0 : 0.0;
+  cnt = block_sum_d(cnt, sh);
+  auto slope = [&](float s) {
+    double g = 0.0;
+    for (int i = threadIdx.x; i < HW; i += 256) {
+      float zi = z[i];
+      if (zi < dmax && zi > dmin) {
+        float r = s * p[i] - 1.0f / zi;
+        g += r > 0.f ? (double)p[i] : (r < 0.f ? -(double)p[i] : 0.0);
+      }
+    }
+    return block_sum_d(g, sh);
+  };
+  float a = lo, c = hi, res;
+  if (cnt == 0.0) res = 0.29999601510536417f * (hi / 0.3f);
+  else if (slope(a) >= 0.0) res = a;
+  else if (slope(c) <= 0.0) res = c;
+  else {
+    for (int it = 0; it < 50; it++) {
+      float m = 0.5f * (a + c);
+      if (slope(m) < 0.0) a = m; else c = m;
+    }
+    res = c;
+  }
+  if (threadIdx.x == 0) { scale[b] = res; nvalid[b] = (int)cnt; }
+}
+
+// int_depth = clamp(s*mono), int_scales (1 / rcnet / radar override) -> per-sample min & max of int_scales
+__device__ __forceinline__ float int_depth_of(float s, float mono, float hi, float lo) {
+  float v = s * mono;
+  if (hi > 0.f && v > hi) v = hi;
+  if (lo > 0.f && v < lo) v = lo;
+  return v;
+}
+__device__ __forceinline__ float int_scale_of(float idp, float radar, float rc, float dmin, float dmax, int use_rcnet) {
+  float sc = 1.f;
+  if (use_rcnet && rc < dmax && rc > dmin) sc = (1.f / rc) / idp;
+  if (radar < dmax && radar > dmin) sc = (1.f / radar) / idp;
+  return sc;
+}
+__global__ __launch_bounds__(256) void sml_scales_minmax_kernel(const float* __restrict__ mono, const float* __restrict__ sparse,
+                                                                const float* __restrict__ rcnet, const float* __restrict__ scale, int HW,
+                                                                float dmin, float dmax, float hi, float lo, int use_rcnet,
+                                                                float* __restrict__ mm /* [B][3] = min, max, nvalid(radar+rcnet) */) {
+  __shared__ float smin[4], smax[4], scnt[4];
+  const int b = blockIdx.x;
+  const float s = scale[b];
+  float mn = INFINITY, mx = -INFINITY, cn = 0.f;
+  for (int i = threadIdx.x; i < HW; i += 256) {
+    int64_t j = (int64_t)b * HW + i;
+    float rc = use_rcnet ? rcnet[j] : 0.f;
+    float v = int_scale_of(int_depth_of(s, mono[j], hi, lo), sparse[j], rc, dmin, dmax, use_rcnet);
+    mn = fminf(mn, v); mx = fmaxf(mx, v);
+    cn += (sparse[j] < dmax && sparse[j] > dmin) ? 1.f : 0.f;
+    cn += (use_rcnet && rc < dmax && rc > dmin) ? 1.f : 0.f;
+  }
+  mn = wave_min(mn); mx = wave_max(mx); cn = wave_sum(cn);
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (lane == 0) { smin[wv] = mn; smax[wv] = mx; scnt[wv] = cn; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    mm[b * 3 + 0] = fminf(fminf(smin[0], smin[1]), fminf(smin[2], smin[3]));
+    mm[b * 3 + 1] = fmaxf(fmaxf(smax[0], smax[1]), fmaxf(smax[2], smax[3]));
+    mm[b * 3 + 2] = scnt[0] + scnt[1] + scnt[2] + scnt[3];
+  }
+}
+// network input x (B,h,w,3) NHWC = [(int_depth-m0)/s0, (int_scales_n-m1)/s1, gray]; d (B,h,w) = int_depth;
+// cv2.INTER_NEAREST source index = min(floor(dst * src/dst_size), src-1)
+__global__ __launch_bounds__(256) void sml_build_inputs_kernel(const float* __restrict__ image /* B,3,H,W */, const float* __restrict__ mono,
+                                                               const float* __restrict__ sparse, const float* __restrict__ rcnet,
+                                                               const float* __restrict__ scale, const float* __restrict__ mm, int B, int H,
+                                                               int W, int h, int w, float dmin, float dmax, float hi, float lo,
+                                                               int use_rcnet, float m0, float s0, float m1, float s1,
+                                                               float* __restrict__ x, float* __restrict__ d) {
+  const int64_t total = (int64_t)B * h * w;
+  const double fy = (double)H / (double)h, fx = (double)W / (double)w;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int xx = (int)(i % w); int64_t q = i / w; int yy = (int)(q % h); int b = (int)(q / h);
+    int sy = min((int)floor((double)yy * fy), H - 1), sx = min((int)floor((double)xx * fx), W - 1);
+    int64_t j = ((int64_t)b * H + sy) * W + sx;
+    float idp = int_depth_of(scale[b], mono[j], hi, lo);
+    float rc = use_rcnet ? rcnet[j] : 0.f;
+    float sc = int_scale_of(idp, sparse[j], rc, dmin, dmax, use_rcnet);
+    float mn = mm[b * 3], mx = mm[b * 3 + 1];
+    if (mm[b * 3 + 2] > 1.f && (mx - mn) > 2.220446049250313e-16f) sc = (sc - mn) / (mx - mn);
+    const float* im = image + (int64_t)b * 3 * H * W + (int64_t)sy * W + sx;
+    float gray = im[0] * 0.299f + im[(int64_t)H * W] * 0.587f + im[(int64_t)2 * H * W] * 0.114f;
+    x[i * 3 + 0] = (idp - m0) / s0;
+    x[i * 3 + 1] = (sc - m1) / s1;
+    x[i * 3 + 2] = gray;
+    d[i] = idp;
+  }
+}
+
+// ---- S9: outlier removal -------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void max_partial_kernel(const float* __restrict__ x, int64_t n, float* __restrict__ partial) {
+  __shared__ float sm[4];
+  float m = -INFINITY;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) m = fmaxf(m, x[i]);
+  m = wave_max(m);
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[blockIdx.x] = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
+}
+__global__ __launch_bounds__(256) void outlier_removal_kernel(const float* __restrict__ depth, const float* __restrict__ partial, int nparts,
+                                                              float* __restrict__ out, int N, int H, int W, int k, float thr) {
+  float mx = -INFINITY;
+  for (int i = 0; i < nparts; i++) mx = fmaxf(mx, partial[i]);
+  const float fill = 10.f * mx;
+  const int r = k / 2;
+  const int64_t total = (int64_t)N * H * W;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int w = (int)(i % W); int64_t q = i / W; int h = (int)(q % H); int n = (int)(q / H);
+    float mn = INFINITY;
+    for (int dy = -r; dy <= r; dy++)
+      for (int dx = -r; dx <= r; dx++) {
+        int hh = h + dy, ww = w + dx;
+        float v = fill;
+        if ((unsigned)hh < (unsigned)H && (unsigned)ww < (unsigned)W) {
+          float dd = depth[((int64_t)n * H + hh) * W + ww];
+          v = dd > 0.f ? dd : fill;  // validity_map <= 0 -> filled
+        }
+        mn = fminf(mn, v);
+      }
+    float dv = depth[i];
+    out[i] = (mn < dv - thr) ? 0.f : dv;
+  }
+}
+
+// ---- S10/S11: loss ----------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float sobel_gx(int u, int v, int fs) {
+  int c = fs / 2;
+  if (v == c) return 0.f;
+  float m = (u == c && (v == c - 1 || v == c + 1)) ? 2.f : 1.f;
+  return v < c ? m : -m;
+}
+__device__ __forceinline__ float sobel_gy(int u, int v, int fs) {
+  int c = fs / 2;
+  if (u == c) return 0.f;
+  float m = (v == c && (u == c - 1 || u == c + 1)) ? 2.f : 1.f;
+  return u < c ? m : -m;
+}
+__device__ __forceinline__ float sgn(float x) { return x > 0.f ? 1.f : (x < 0.f ? -1.f : 0.f); }
+
+// per pixel: masked L1 terms and Sobel terms; block partials[blk][8]; gfx/gfy = weights * w_{x,y} * sign(pred_{dx,dy})
+__global__ __launch_bounds__(256) void sml_loss_fwd_kernel(const float* __restrict__ pred, const float* __restrict__ image,
+                                                           const float* __restrict__ gt_interp, const float* __restrict__ gt_sparse,
+                                                           const float* __restrict__ weights, int N, int H, int W, int fs, int mask_interp,
+                                                           float* __restrict__ gfx, float* __restrict__ gfy, double* __restrict__ partial) {
+  __shared__ double sh[4];
+  const int64_t total = (int64_t)N * H * W;
+  const int r = fs / 2;
+  double acc[8];
+  for (int j = 0; j < 8; j++) acc[j] = 0.0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int w = (int)(i % W); int64_t q = i / W; int h = (int)(q % H); int n = (int)(q / H);
+    const float* P = pred + (int64_t)n * H * W; const float* I = image + (int64_t)n * H * W;
+    float o = P[(int64_t)h * W + w];
+    float gs = gt_sparse[i], gi = gt_interp[i];
+    if (mask_interp && gs > 0.f) gi = 0.f;
+    if (gi > 0.f) { acc[0] += fabsf(o - gi); acc[1] += 1.0; }
+    if (gs > 0.f) { acc[2] += fabsf(o - gs); acc[3] += 1.0; }
+    float pdx = 0.f, pdy = 0.f, idx = 0.f, idy = 0.f;
+    for (int u = 0; u < fs; u++) {
+      int hh = min(max(h + u - r, 0), H - 1);
+      for (int v = 0; v < fs; v++) {
+        int ww = min(max(w + v - r, 0), W - 1);
+        float gx = sobel_gx(u, v, fs), gy = sobel_gy(u, v, fs);
+        float pv = P[(int64_t)hh * W + ww], iv = I[(int64_t)hh * W + ww];
+        pdx += pv * gx; pdy += pv * gy; idx += iv * gx; idy += iv * gy;
+      }
+    }
+    float sdx = 0.f, sdy = 0.f;
+    for (int u = 0; u < 3; u++) {
+      int hh = min(max(h + u - 1, 0), H - 1);
+      for (int v = 0; v < 3; v++) {
+        int ww = min(max(w + v - 1, 0), W - 1);
+        float iv = I[(int64_t)hh * W + ww];
+        sdx += iv * sobel_gx(u, v, 3); sdy += iv * sobel_gy(u, v, 3);
+      }
+    }
+    float wt = weights ? weights[i] : 1.f;
+    float wx = wt * __expf(-fabsf(sdy)), wy = wt * __expf(-fabsf(sdx));  // x-term weighted by the image's y-gradient (loss.py:235-239)
+    acc[4] += wx * fabsf(pdx); acc[5] += wy * fabsf(pdy);
+    acc[6] += wt * fabsf(fabsf(pdx) - fabsf(idx)); acc[7] += wt * fabsf(fabsf(pdy) - fabsf(idy));
+    gfx[i] = wx * sgn(pdx); gfy[i] = wy * sgn(pdy);
+  }
+  for (int j = 0; j < 8; j++) {
+    double s = block_sum_d(acc[j], sh);
+    if (threadIdx.x == 0) partial[(int64_t)blockIdx.x * 8 + j] = s;
+  }
+}
+// info = [loss, supervised, lidar, smoothness, edge, n_interp, n_lidar]
+__global__ void sml_loss_finalize_kernel(const double* __restrict__ partial, int rows, double npix, int fs, float w_lidar, float w_smooth,
+                                         float w_edge, float* __restrict__ info) {
+  if (threadIdx.x || blockIdx.x) return;
+  double a[8];
+  for (int j = 0; j < 8; j++) { a[j] = 0.0; for (int r = 0; r < rows; r++) a[j] += partial[(int64_t)r * 8 + j]; }
+  double sup = a[0] / a[1], lid = w_lidar > 0.f ? a[2] / a[3] : 0.0;
+  double sm = (a[4] / npix + a[5] / npix) / (double)(fs * fs), ed = (a[6] / npix + a[7] / npix) / (double)(fs * fs);
+  if (!(w_smooth > 0.f || w_edge > 0.f)) { sm = 0.0; ed = 0.0; }
+  info[0] = (float)(sup + w_lidar * lid + w_smooth * sm + w_edge * ed);
+  info[1] = (float)sup; info[2] = (float)lid; info[3] = (float)sm; info[4] = (float)ed; info[5] = (float)a[1]; info[6] = (float)a[3];
+}
+// d loss / d pred: L1 signs + transposed Sobel through the replicate padding (gather over padded positions clamping to p)
+__global__ __launch_bounds__(256) void sml_loss_bwd_kernel(const float* __restrict__ pred, const float* __restrict__ gt_interp,
+                                                           const float* __restrict__ gt_sparse, const float* __restrict__ gfx,
+                                                           const float* __restrict__ gfy, const float* __restrict__ info,
+                                                           const float* __restrict__ dloss, int N, int H, int W, int fs, int mask_interp,
+                                                           float w_lidar, float w_smooth, float* __restrict__ dpred) {
+  const int64_t total = (int64_t)N * H * W;
+  const int r = fs / 2;
+  const float gl = dloss[0];
+  const float c_sup = 1.f / info[5], c_lid = w_lidar > 0.f ? w_lidar / info[6] : 0.f;
+  const float c_sm = w_smooth / ((float)total * (float)(fs * fs));
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int w = (int)(i % W); int64_t q = i / W; int h = (int)(q % H); int n = (int)(q / H);
+    float o = pred[i], gs = gt_sparse[i], gi = gt_interp[i];
+    if (mask_interp && gs > 0.f) gi = 0.f;
+    float g = 0.f;
+    if (gi > 0.f) g += c_sup * sgn(o - gi);
+    if (gs > 0.f) g += c_lid * sgn(o - gs);
+    if (w_smooth > 0.f) {
+      // padded rows that clamp onto h: h itself, plus -r..-1 when h == 0, plus H..H+r-1 when h == H-1 (same for columns)
+      int ph0 = h == 0 ? -r : h, ph1 = h == H - 1 ? H - 1 + r : h;
+      int pw0 = w == 0 ? -r : w, pw1 = w == W - 1 ? W - 1 + r : w;
+      const float* FX = gfx + (int64_t)n * H * W; const float* FY = gfy + (int64_t)n * H * W;
+      float s = 0.f;
+      for (int ph = ph0; ph <= ph1; ph++)
+        for (int pw = pw0; pw <= pw1; pw++)
+          for (int u = 0; u < fs; u++) {
+            int a = ph - u + r;  // output row whose tap u reads padded row ph
+            if ((unsigned)a >= (unsigned)H) continue;
+            for (int v = 0; v < fs; v++) {
+              int b = pw - v + r;
+              if ((unsigned)b >= (unsigned)W) continue;
+              s += FX[(int64_t)a * W + b] * sobel_gx(u, v, fs) + FY[(int64_t)a * W + b] * sobel_gy(u, v, fs);
+            }
+          }
+      g += c_sm * s;
+    }
+    dpred[i] = gl * g;
+  }
+}
+
+// ---- S12: validation ---------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void cubic_w(float t, float (&w)[4]) {
+  const float A = -0.75f;
+  float x = t + 1.f; w[0] = ((A * x - 5.f * A) * x + 8.f * A) * x - 4.f * A;
+  x = t; w[1] = ((A + 2.f) * x - (A + 3.f)) * x * x + 1.f;
+  x = 1.f - t; w[2] = ((A + 2.f) * x - (A + 3.f)) * x * x + 1.f;
+  x = 2.f - t; w[3] = ((A * x - 5.f * A) * x + 8.f * A) * x - 4.f * A;
+}
+__global__ __launch_bounds__(256) void bicubic_kernel(const float* __restrict__ x, float* __restrict__ y, int N, int H, int W, int OH,
+                                                      int OW) {
+  const int64_t total = (int64_t)N * OH * OW;
+  const float sh = (float)H / (float)OH, sw = (float)W / (float)OW;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int ow = (int)(i % OW); int64_t q = i / OW; int oh = (int)(q % OH); int n = (int)(q / OH);
+    float fy = sh * ((float)oh + 0.5f) - 0.5f, fx = sw * ((float)ow + 0.5f) - 0.5f;
+    int iy = (int)floorf(fy), ix = (int)floorf(fx);
+    float wy[4], wx[4];
+    cubic_w(fy - (float)iy, wy); cubic_w(fx - (float)ix, wx);
+    const float* b = x + (int64_t)n * H * W;
+    float acc = 0.f;
+    for (int u = 0; u < 4; u++) {
+      int yy = min(max(iy - 1 + u, 0), H - 1);
+      float row = 0.f;
+      for (int v = 0; v < 4; v++) row += wx[v] * b[(int64_t)yy * W + min(max(ix - 1 + v, 0), W - 1)];
+      acc += wy[u] * row;
+    }
+    y[i] = acc;
+  }
+}
+// per image n: sums over the mask (gt > 0 & dmin < gt < dmax) of the eval_utils terms; out[n][8] =
+// [count, sum|1000(o-g)|, sum(1000(o-g))^2, sum|1/(.001g) - 1/(.001o)|, sum(.)^2, sum|o-g|/g, sum 1000(o-g)^2/g, count(max(o/g,g/o)<1.25)]
+__global__ __launch_bounds__(256) void depth_metrics_kernel(const float* __restrict__ out, const float* __restrict__ gt, int HW, float dmin,
+                                                            float dmax, double* __restrict__ res) {
+  __shared__ double sh[4];
+  const int n = blockIdx.x;
+  double a[8];
+  for (int j = 0; j < 8; j++) a[j] = 0.0;
+  for (int i = threadIdx.x; i < HW; i += 256) {
+    float g = gt[(int64_t)n * HW + i], o = out[(int64_t)n * HW + i];
+    if (g > 0.f && g > dmin && g < dmax) {
+      double e = 1000.0 * (double)o - 1000.0 * (double)g;
+      double ie = 1.0 / (0.001 * (double)g) - 1.0 / (0.001 * (double)o);
+      a[0] += 1.0; a[1] += fabs(e); a[2] += e * e; a[3] += fabs(ie); a[4] += ie * ie;
+      a[5] += fabs(e) / (1000.0 * (double)g); a[6] += e * e / (1000.0 * (double)g);
+      double rr = (double)o / (double)g, r2 = (double)g / (double)o;
+      a[7] += (rr > r2 ? rr : r2) < 1.25 ? 1.0 : 0.0;
+    }
+  }
+  for (int j = 0; j < 8; j++) {
+    double s = block_sum_d(a[j], sh);
+    if (threadIdx.x == 0) res[n * 8 + j] = s;
+  }
+}
+
+// ---- launchers ---------------------------------------------------------------------------------------------------------------
+void launch_sml_scale_align(const float* mono, const float* sparse, int B, int HW, float dmin, float dmax, float lo, float hi, float* scale,
+                            int* nvalid, hipStream_t st) {
+  hipLaunchKernelGGL(sml_scale_align_kernel, dim3(B), dim3(256), 0, st, mono, sparse, HW, dmin, dmax, lo, hi, scale, nvalid);
+}
+void launch_sml_build_inputs(const float* image, const float* mono, const float* sparse, const float* rcnet, const float* scale, float* mm,
+                             int B, int H, int W, int h, int w, float dmin, float dmax, float hi, float lo, int use_rcnet, float m0, float s0,
+                             float m1, float s1, float* x, float* d, hipStream_t st) {
+  hipLaunchKernelGGL(sml_scales_minmax_kernel, dim3(B), dim3(256), 0, st, mono, sparse, rcnet, scale, H * W, dmin, dmax, hi, lo, use_rcnet, mm);
+  hipLaunchKernelGGL(sml_build_inputs_kernel, dim3(ew_grid((int64_t)B * h * w)), dim3(256), 0, st, image, mono, sparse, rcnet, scale, mm, B, H, W,
+                     h, w, dmin, dmax, hi, lo, use_rcnet, m0, s0, m1, s1, x, d);
+}
+int outlier_parts(int64_t n) { return (int)ew_grid(n, 256); }
+void launch_outlier_removal(const float* depth, float* partial, float* out, int N, int H, int W, int k, float thr, hipStream_t st) {
+  int64_t n = (int64_t)N * H * W;
+  int parts = outlier_parts(n);
+  hipLaunchKernelGGL(max_partial_kernel, dim3(parts), dim3(256), 0, st, depth, n, partial);
+  hipLaunchKernelGGL(outlier_removal_kernel, dim3(ew_grid(n)), dim3(256), 0, st, depth, partial, parts, out, N, H, W, k, thr);
+}
+int sml_loss_rows(int64_t n) { return (int)ew_grid(n, 512); }
+void launch_sml_loss_fwd(const float* pred, const float* image, const float* gi, const float* gs, const float* weights, int N, int H, int W,
+                         int fs, int mask_interp, float w_lidar, float w_smooth, float w_edge, float* gfx, float* gfy, double* partial,
+                         float* info, hipStream_t st) {
+  int64_t n = (int64_t)N * H * W;
+  int rows = sml_loss_rows(n);
+  hipLaunchKernelGGL(sml_loss_fwd_kernel, dim3(rows), dim3(256), 0, st, pred, image, gi, gs, weights, N, H, W, fs, mask_interp, gfx, gfy, partial);
+  hipLaunchKernelGGL(sml_loss_finalize_kernel, dim3(1), dim3(64), 0, st, partial, rows, (double)n, fs, w_lidar, w_smooth, w_edge, info);
+}
+void launch_sml_loss_bwd(const float* pred, const float* gi, const float* gs, const float* gfx, const float* gfy, const float* info,
+                         const float* dloss, int N, int H, int W, int fs, int mask_interp, float w_lidar, float w_smooth, float* dpred,
+                         hipStream_t st) {
+  hipLaunchKernelGGL(sml_loss_bwd_kernel, dim3(ew_grid((int64_t)N * H * W)), dim3(256), 0, st, pred, gi, gs, gfx, gfy, info, dloss, N, H, W, fs,
+                     mask_interp, w_lidar, w_smooth, dpred);
+}
+void launch_bicubic(const float* x, float* y, int N, int H, int W, int OH, int OW, hipStream_t st) {
+  hipLaunchKernelGGL(bicubic_kernel, dim3(ew_grid((int64_t)N * OH * OW)), dim3(256), 0, st, x, y, N, H, W, OH, OW);
+}
+void launch_depth_metrics(const float* out, const float* gt, int N, int HW, float dmin, float dmax, double* res, hipStream_t st) {
+  hipLaunchKernelGGL(depth_metrics_kernel, dim3(N), dim3(256), 0, st, out, gt, HW, dmin, dmax, res);
+}
+
+}  // namespace rd
