@@ -331,7 +331,7 @@ def _desc(dt, N, Hin, Win, C1, C2, up, H1, W1, Cout, KH, KW, stride, pad, dil, O
 
 
 def conv_block(x, weight, *, x2=None, bias=None, stride=1, pad=None, up=None, bn=None, act=ACT_NONE, slope=0.2,
-               residual=None, training=True):
+               residual=None, training=True, out_hw=None):
     """act(BN(conv([up(x) | up(x2)], weight) + bias) + residual) on NHWC tensors; records its own backward.
 
     x: (N,H,W,C1) [, x2: (N,H,W,C2)]; weight OIHW fp32 (nn.Linear [out,in] is treated as 1x1);
@@ -355,6 +355,8 @@ def conv_block(x, weight, *, x2=None, bias=None, stride=1, pad=None, up=None, bn
     is_up = up is not None and (Hin, Win) != (H1, W1)
     OH = (Hin + 2 * pad - KH) // stride + 1
     OW = (Win + 2 * pad - KW) // stride + 1
+    if out_hw is not None:  # asymmetric (TF-"SAME") padding: `pad` is the leading pad, the output size is given
+        OH, OW = int(out_hw[0]), int(out_hw[1])
     use_bn = bn is not None
     conv_act = ACT_NONE if (use_bn or residual is not None) else act
     d = _desc(dt, N, Hin, Win, C1, C2, is_up, H1, W1, Cout, KH, KW, stride, pad, 1, OH, OW, conv_act, slope, Cout)
@@ -785,3 +787,198 @@ def bce_masked(logits, label, valid, pos_weight):
             t.add_grad(lg, d)
         t.record(backward)
     return res
+
+
+# =================================================================================== Scale Map Learner ops
+def _bn_forward(y, bn, act, slope, residual, training, stats=None):
+    """BatchNorm (+residual, +activation) on an NHWC tensor whose producer has no fused statistics epilogue."""
+    lib, dt, st = L(), rd_of(y), _stream(y)
+    C = y.shape[-1]
+    pixels = y.numel() // C
+    bn_train = training or not bn.track_running_stats
+    if bn_train and stats is None:
+        rows = lib.rd_dw_rows(pixels, C)
+        stats = torch.empty((rows, C, 2), dtype=torch.float32, device=y.device)
+        _chk(lib.rd_bn_stats(_p(y), _p(stats), pixels, C, dt, st), "rd_bn_stats")
+    coef = torch.empty((4, C), dtype=torch.float32, device=y.device)
+    _chk(lib.rd_bn_finalize(_p(stats), 0 if stats is None else stats.shape[0], C, float(pixels), _p(bn.weight.detach()), _p(bn.bias.detach()),
+                            float(bn.eps), float(bn.momentum if bn.momentum is not None else 0.1), 1 if bn_train else 0,
+                            _p(bn.running_mean), _p(bn.running_var), _p(coef[2]), _p(coef[3]), _p(coef[0]), _p(coef[1]), st), "rd_bn_finalize")
+    z = torch.empty_like(y)
+    _chk(lib.rd_affine_act(_p(y), _p(coef[0]), _p(coef[1]), _p(residual), _p(z), pixels, C, act, slope, dt, st), "rd_affine_act")
+    return z, coef, bn_train
+
+
+def _bn_backward(t, dz, z, y, coef, bn, act, slope, want_res):
+    lib, dt, st = L(), rd_of(y), _stream(y)
+    C = y.shape[-1]
+    pixels = y.numel() // C
+    rows = lib.rd_bn_bwd_rows(pixels, C)
+    partial = torch.empty((rows, C, 2), dtype=torch.float32, device=y.device)
+    coef2 = torch.empty((2, C), dtype=torch.float32, device=y.device)
+    dgam, acc = t.param_grad(bn.weight)
+    dbet, _ = t.param_grad(bn.bias)
+    dy = torch.empty_like(y)
+    dres = torch.empty_like(y) if want_res else None
+    _chk(lib.rd_bn_act_bwd(_p(dz), _p(z), _p(y), _p(coef[2]), _p(coef[3]), _p(coef[0]), _p(partial), _p(coef2), _p(dgam), _p(dbet), acc,
+                           _p(dy), _p(dres), pixels, C, act, slope, dt, st), "rd_bn_act_bwd")
+    return dy, dres
+
+
+def dwconv_block(x, weight, *, stride=1, pad=0, out_hw=None, bn=None, act=ACT_NONE, slope=0.0, training=True):
+    """act(BN(depthwise_conv(x))) for the EfficientNet-Lite blocks; weight (C,1,k,k) fp32."""
+    lib, t, dt, st = L(), tape(), rd_of(x), _stream(x)
+    N, H, W, C = x.shape
+    k = weight.shape[-1]
+    OH, OW = (int(out_hw[0]), int(out_hw[1])) if out_hw is not None else ((H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1)
+    y = torch.empty((N, OH, OW, C), dtype=x.dtype, device=x.device)
+    _chk(lib.rd_dwconv_fwd(_p(x), _p(weight.detach()), _p(y), N, H, W, C, OH, OW, k, stride, pad, dt, st), "rd_dwconv_fwd")
+    if bn is not None:
+        z, coef, bn_train = _bn_forward(y, bn, act, slope, None, training)
+    else:
+        z, coef, bn_train = y, None, False
+        assert act == ACT_NONE
+    if t is None or not (t.requires(x) or weight.requires_grad):
+        return z
+    t.mark(z)
+
+    def backward():
+        dz = t.pop_grad(z)
+        if dz is None:
+            return
+        if bn is not None:
+            if not bn_train:
+                raise NotImplementedError("backward through eval-mode BatchNorm is not supported")
+            dy, _ = _bn_backward(t, dz, z, y, coef, bn, act, slope, False)
+        else:
+            dy = dz
+        if weight.requires_grad:
+            dw, acc = t.param_grad(weight)
+            rows = lib.rd_dw_rows(N * OH * OW, C)
+            part = torch.empty((rows, C, k * k), dtype=torch.float32, device=x.device)
+            _chk(lib.rd_dwconv_wgrad(_p(x), _p(dy), _p(part), _p(dw), acc, N, H, W, C, OH, OW, k, stride, pad, dt, st), "rd_dwconv_wgrad")
+        if t.requires(x):
+            dx = torch.empty_like(x)
+            _chk(lib.rd_dwconv_dgrad(_p(dy), _p(weight.detach()), _p(dx), N, H, W, C, OH, OW, k, stride, pad, dt, st), "rd_dwconv_dgrad")
+            t.add_grad(x, dx)
+    t.record(backward)
+    return z
+
+
+def activation(x, act, slope=0.0):
+    """Stand-alone activation (pre-activation ReLU of the residual conv units, modules/midas/blocks.py:107)."""
+    lib, t, dt, st = L(), tape(), rd_of(x), _stream(x)
+    C = x.shape[-1]
+    out = torch.empty_like(x)
+    _chk(lib.rd_affine_act(_p(x), None, None, None, _p(out), x.numel() // C, C, act, slope, dt, st), "rd_affine_act")
+    if t is not None and t.requires(x):
+        t.mark(out)
+
+        def backward():
+            g = t.pop_grad(out)
+            if g is None:
+                return
+            d = torch.empty_like(g)
+            _chk(lib.rd_act_bwd(_p(g), _p(out), _p(d), g.numel(), act, slope, dt, st), "rd_act_bwd")
+            t.add_grad(x, d)
+        t.record(backward)
+    return out
+
+
+def bilinear2x(x, align_corners):
+    """F.interpolate(scale_factor=2, mode='bilinear') on NHWC (modules/midas/blocks.py:168-170, :187)."""
+    lib, t, dt, st = L(), tape(), rd_of(x), _stream(x)
+    N, H, W, C = x.shape
+    OH, OW, al = 2 * H, 2 * W, 1 if align_corners else 0
+    out = torch.empty((N, OH, OW, C), dtype=x.dtype, device=x.device)
+    _chk(lib.rd_bilinear_fwd(_p(x), _p(out), N, H, W, C, OH, OW, al, dt, st), "rd_bilinear_fwd")
+    if t is not None and t.requires(x):
+        t.mark(out)
+
+        def backward():
+            g = t.pop_grad(out)
+            if g is None:
+                return
+            dx = torch.empty_like(x)
+            _chk(lib.rd_bilinear_bwd(_p(g), _p(dx), N, H, W, C, OH, OW, al, dt, st), "rd_bilinear_bwd")
+            t.add_grad(x, dx)
+        t.record(backward)
+    return out
+
+
+def sml_head(out, d, min_pred, max_pred):
+    """pred = d * relu(1 + out) with the in-place clamps of midas_net_custom.py:121-133; out (N,H,W,1), d fp32 same size."""
+    lib, t, dt, st = L(), tape(), rd_of(out), _stream(out)
+    hi = 1.0 / min_pred if min_pred is not None else -1.0
+    lo = 1.0 / max_pred if max_pred is not None else -1.0
+    pred = torch.empty(out.shape, dtype=torch.float32, device=out.device)
+    n = out.numel()
+    _chk(lib.rd_sml_head_fwd(_p(out), _p(d), _p(pred), n, hi, lo, dt, st), "rd_sml_head_fwd")
+    if t is not None and t.requires(out):
+        t.mark(pred)
+
+        def backward():
+            g = t.pop_grad(pred)
+            if g is None:
+                return
+            do = torch.empty_like(out)
+            _chk(lib.rd_sml_head_bwd(_p(out), _p(d), _p(g), _p(do), n, hi, lo, dt, st), "rd_sml_head_bwd")
+            t.add_grad(out, do)
+        t.record(backward)
+    return pred
+
+
+def reciprocal(x):
+    lib, t, st = L(), tape(), _stream(x)
+    out = torch.empty_like(x)
+    _chk(lib.rd_reciprocal(_p(x), None, _p(out), x.numel(), st), "rd_reciprocal")
+    if t is not None and t.requires(x):
+        t.mark(out)
+
+        def backward():
+            g = t.pop_grad(out)
+            if g is None:
+                return
+            dx = torch.empty_like(x)
+            _chk(lib.rd_reciprocal(_p(x), _p(g), _p(dx), x.numel(), st), "rd_reciprocal")
+            t.add_grad(x, dx)
+        t.record(backward)
+    return out
+
+
+def sml_loss(pred, image, gt_interp, gt_sparse, weights, w_lidar, w_smooth, w_edge, filter_size):
+    """utils/loss.py compute_loss ('l1') on (N,1,H,W) fp32 contiguous tensors -> (info[7] tensor)."""
+    lib, t, st = L(), tape(), _stream(pred)
+    N, _, H, W = pred.shape
+    n = pred.numel()
+    rows = lib.rd_sml_loss_rows(n)
+    partial = torch.empty((rows, 8), dtype=torch.float64, device=pred.device)
+    gfx, gfy = torch.empty_like(pred), torch.empty_like(pred)
+    info = torch.empty(7, dtype=torch.float32, device=pred.device)
+    _chk(lib.rd_sml_loss_fwd(_p(pred), _p(image), _p(gt_interp), _p(gt_sparse), _p(weights), N, H, W, filter_size, w_lidar, w_smooth, w_edge,
+                             _p(gfx), _p(gfy), _p(partial), _p(info), st), "rd_sml_loss_fwd")
+    loss = info[0]
+    if t is not None and t.requires(pred):
+        if w_edge > 0:
+            raise NotImplementedError("w_edge > 0 has no backward kernel (train_zju.py:466 uses w_edge = 0)")
+        t.mark(loss)
+
+        def backward():
+            g = t.pop_grad(loss)
+            if g is None:
+                return
+            dp = torch.empty_like(pred)
+            _chk(lib.rd_sml_loss_bwd(_p(pred), _p(gt_interp), _p(gt_sparse), _p(gfx), _p(gfy), _p(info), _p(g), N, H, W, filter_size, w_lidar,
+                                     w_smooth, _p(dp), st), "rd_sml_loss_bwd")
+            t.add_grad(pred, dp)
+        t.record(backward)
+    return loss, info
+
+
+def outlier_removal(depth, kernel_size, threshold):
+    lib, st = L(), _stream(depth)
+    N, _, H, W = depth.shape
+    part = torch.empty(lib.rd_outlier_parts(depth.numel()), dtype=torch.float32, device=depth.device)
+    out = torch.empty_like(depth)
+    _chk(lib.rd_outlier_removal(_p(depth), _p(part), _p(out), N, H, W, int(kernel_size), float(threshold), st), "rd_outlier_removal")
+    return out

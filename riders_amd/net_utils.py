@@ -204,3 +204,15 @@ class DecoderBlock(torch.nn.Module):
             s = None if skip is None else engine.from_nchw(skip)
             return engine.to_nchw_out(self._fwd(engine.from_nchw(x), s, shape), x.dtype)
         return engine.run_region(run, ins, list(self.parameters()))
+
+
+class OutlierRemoval(object):
+    """Min-filter based outlier removal of sparse depth.  Reference: utils/net_utils.py:575-638."""
+
+    def __init__(self, kernel_size=7, threshold=1.5):
+        self.kernel_size = kernel_size
+        self.threshold = threshold
+
+    def remove_outliers(self, depth):
+        d = depth if depth.is_contiguous() else depth.contiguous()
+        return engine.outlier_removal(d.float(), self.kernel_size, self.threshold)

@@ -1,0 +1,196 @@
+"""Scale-Map-Learner parity cases (see tests/parity_cases.py for how these are used by the emulator and GPU suites)."""
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from oracle import sml as OS
+from oracle import effnet_lite3_torch as OE
+from tests.golden.fill import fill_state_dict, rand_array
+from tests.parity_cases import TOL, close, load, t
+
+
+def _nhwc(x, dev, dtype=torch.float32):
+    return x.to(dev).permute(0, 2, 3, 1).contiguous().to(dtype)
+
+
+def _run_tape(dev, inputs, fn, gout):
+    """Run fn(*nhwc inputs) under a fresh tape, seed grad gout (NCHW cpu) and return (out NCHW, grads NCHW)."""
+    from riders_amd import engine
+    xs = [_nhwc(x, dev) for x in inputs]
+    tape = engine.Tape()
+    for x in xs:
+        tape.mark(x)
+    with engine._active(tape):
+        out = fn(*xs)
+        tape.grads[id(out)] = _nhwc(gout, dev)
+        tape.backward()
+    return out.permute(0, 3, 1, 2), [tape.grads[id(x)].permute(0, 3, 1, 2) for x in xs], tape
+
+
+def effnet_block_case(dev, kind="ir", cin=24, cout=32, k=3, s=2, H=12, W=16, tol=TOL):
+    from riders_amd.midas import efficientnet_lite3 as E
+    mine = (E.InvertedResidual if kind == "ir" else E.DepthwiseSeparableConv)(cin, cout, k, s).to(dev)
+    ref = (OE.InvertedResidual if kind == "ir" else OE.DepthwiseSeparableConv)(cin, cout, k, s)
+    tag = "eff.%s.%d.%d.%d.%d" % (kind, cin, cout, k, s)
+    ref.load_state_dict({kk: v.cpu() for kk, v in fill_state_dict(mine, tag).items()})
+    x = t(rand_array(tag + ".x", (2, cin, H, W), 1.0))
+    xr = x.clone().requires_grad_()
+    ref.train(); mine.train()
+    yr = ref(xr)
+    w = t(rand_array(tag + ".w", yr.shape, 1.0))
+    (yr * w).sum().backward()
+    out, (dx,), tape = _run_tape(dev, [x], lambda a: mine._fwd(a), w)
+    close(out, yr, tol, tag + " fwd")
+    close(dx, xr.grad, tol, tag + " dx")
+    for (kk, p), (_, pr) in zip(mine.named_parameters(), ref.named_parameters()):
+        close(tape.pgrads[id(p)], pr.grad, 2 * tol, tag + " grad " + kk)
+    for kk in ("bn1.running_mean", "bn2.running_var"):
+        close(mine.state_dict()[kk], ref.state_dict()[kk], tol, kk)
+
+
+def bilinear_case(dev, tol=1e-5):
+    from riders_amd import engine
+    x = t(rand_array("bil.x", (2, 8, 5, 7), 1.0))
+    for align in (True, False):
+        xr = x.clone().requires_grad_()
+        yr = F.interpolate(xr, scale_factor=2, mode="bilinear", align_corners=align)
+        w = t(rand_array("bil.w", yr.shape, 1.0))
+        (yr * w).sum().backward()
+        out, (dx,), _ = _run_tape(dev, [x], lambda a: engine.bilinear2x(a, align), w)
+        close(out, yr, tol, "bilinear fwd align=%s" % align)
+        close(dx, xr.grad, tol, "bilinear bwd align=%s" % align)
+
+
+def fusion_block_case(dev, f=32, tol=TOL):
+    from riders_amd.midas.blocks import FeatureFusionBlock_custom
+    mine = FeatureFusionBlock_custom(f, torch.nn.ReLU(False), deconv=False, bn=False, expand=True, align_corners=True).to(dev)
+    ref = OS.FFB(f, True)
+    ref.load_state_dict({k: v.cpu() for k, v in fill_state_dict(mine, "ffb").items()})
+    a, b = t(rand_array("ffb.a", (2, f, 6, 5), 1.0)), t(rand_array("ffb.b", (2, f, 6, 5), 1.0))
+    ar, br = a.clone().requires_grad_(), b.clone().requires_grad_()
+    yr = ref(ar, br)
+    w = t(rand_array("ffb.w", yr.shape, 1.0))
+    (yr * w).sum().backward()
+    out, (da, db), tape = _run_tape(dev, [a, b], lambda p, q: mine._fwd(p, q), w)
+    close(out, yr, tol, "ffb fwd"); close(da, ar.grad, tol, "ffb da"); close(db, br.grad, tol, "ffb db")
+    for (kk, p), (_, pr) in zip(mine.named_parameters(), ref.named_parameters()):
+        close(tape.pgrads[id(p)], pr.grad, 2 * tol, "ffb grad " + kk)
+
+
+def loss_case(dev, tol=1e-4):
+    """HIP loss vs the REFERENCE's own loss values / gradient (fixture g7) and outlier removal."""
+    from riders_amd.loss import compute_loss
+    from riders_amd.net_utils import OutlierRemoval
+    N, H, W = 2, 24, 32
+    image = t(rand_array("g7.img", (N, 1, H, W), 20.0, lo=0.05), dev)
+    gi = rand_array("g7.gi", (N, 1, H, W), 30.0, lo=0.0); gi[rand_array("g7.gim", gi.shape, 1.0, lo=0.0) < 0.3] = 0
+    gs = rand_array("g7.gs", (N, 1, H, W), 30.0, lo=0.0); gs[rand_array("g7.gsm", gs.shape, 1.0, lo=0.0) < 0.9] = 0
+    for fs, wl in ((7, 1.5), (3, 0.0)):
+        g = load("g7_loss_fs%d" % fs)
+        pred = t(rand_array("g7.pred", (N, 1, H, W), 20.0, lo=0.05), dev).requires_grad_()
+        loss, info = compute_loss(image=image, output_depth=pred, gt_interp=t(gi, dev), gt_sparse=t(gs, dev), loss_func='l1', w_smoothness=0.2,
+                                  sobel_filter_size=fs, validity_map_loss_smoothness=torch.ones_like(image), w_lidar_loss=wl, w_edge=0.0,
+                                  invalid_map_gt=None, w_unsupervised=0.0)
+        got = [float(info[k]) for k in ('loss', 'loss_supervised', 'loss_lidar', 'loss_smoothness', 'loss_edge')]
+        for a, b, nm in zip(got, g["loss"], ('loss', 'sup', 'lidar', 'smooth', 'edge')):
+            assert abs(a - float(b)) <= tol * max(abs(float(b)), 1e-3), (fs, nm, a, float(b))
+        loss.backward()
+        close(pred.grad, g["dpred"], 10 * tol, "sml loss dpred fs=%d" % fs)
+    g = load("g7_outlier")
+    gt = rand_array("g7.or", (N, 1, H, W), 40.0, lo=0.0); gt[rand_array("g7.orm", gt.shape, 1.0, lo=0.0) < 0.5] = 0
+    assert np.array_equal(OutlierRemoval(3, 1.5).remove_outliers(t(gt, dev)).cpu().numpy(), g["out"])
+    assert np.array_equal(OutlierRemoval(7, 1.5).remove_outliers(t(gt, dev)).cpu().numpy(), g["out7"])
+
+
+def prestep_case(dev):
+    """Device pre-step vs the REFERENCE's scipy scales (fixture g8, |ds| <= 2e-5 = 2 x scipy's xatol) and vs the oracle's per-sample
+    restatement of train_zju.py:246-343 for the assembled network inputs."""
+    from riders_amd import sml_main
+    g = load("g8_scale")
+    H, W = 48, 64
+    monos, sparses = [], []
+    for i, dens in enumerate((0.02, 0.2, 0.0, 0.0005)):
+        mono = rand_array("g8.mono%d" % i, (H, W), 3.0, lo=0.15)
+        true_s = 0.02 + 0.05 * i
+        depth = 1.0 / (true_s * mono * (1 + 0.1 * rand_array("g8.n%d" % i, (H, W), 1.0)))
+        m = rand_array("g8.m%d" % i, (H, W), 1.0, lo=0.0) < dens
+        monos.append(mono); sparses.append(np.where(m, depth, 0).astype(np.float32))
+    B = len(monos)
+    mono = t(np.stack(monos)[:, None], dev).contiguous(); sparse = t(np.stack(sparses)[:, None], dev).contiguous()
+    image = t(rand_array("g8.img", (B, 3, H, W), 1.0, lo=0.0), dev)
+    rc = rand_array("g8.rc", (B, 1, H, W), 50.0, lo=0.02); rc[rand_array("g8.rcm", rc.shape, 1.0, lo=0.0) < 0.9] = 0
+    hw = (32, 32)
+    x, d, scale = sml_main.prepare_inputs(image, mono, sparse, t(rc, dev), hw)
+    sc = scale.cpu().numpy()
+    for i in range(B):
+        assert abs(float(sc[i]) - float(g["s%d" % i][0])) <= 2e-5, (i, float(sc[i]), float(g["s%d" % i][0]))
+        xo, do, _ = OS.prestep_sample(image[i].cpu().numpy(), monos[i], sparses[i], rc[i, 0], hw, scale=float(sc[i]))
+        close(d[i], do, 1e-5, "prestep d[%d]" % i)
+        close(x[i], xo, 1e-4, "prestep x[%d]" % i)
+        close((monos[i] * np.float32(sc[i])).clip(1 / 255.0, 10.0)[::4, ::4], g["out%d" % i], 5e-4, "int_depth vs reference")
+
+
+def metrics_case(dev):
+    import ctypes
+    from riders_amd import engine
+    g = load("g11_metrics")
+    inv = rand_array("g11.inv", (1, 1, 36, 48), 0.3, lo=0.03) + np.float32(0.01)
+    gt = rand_array("g11.gt", (60, 80), 60.0, lo=0.0); gt[rand_array("g11.m", gt.shape, 1.0, lo=0.0) < 0.9] = 0
+    lib, p = engine.L(), engine._p
+    depth = (1.0 / t(inv)).to(dev).contiguous()
+    up = torch.empty((1, 1, 60, 80), dtype=torch.float32, device=dev)
+    assert lib.rd_bicubic_resize(p(depth), p(up), 1, 36, 48, 60, 80, engine._stream(depth)) == 0
+    close(up[0, 0], g["pred"], 1e-5, "bicubic")
+    res = torch.empty((1, 8), dtype=torch.float64, device=dev)
+    gtd = t(gt, dev).contiguous()
+    assert lib.rd_depth_metrics(p(up), p(gtd), 1, 60 * 80, ctypes.c_float(0.0), ctypes.c_float(50.0), p(res), engine._stream(up)) == 0
+    r = res.cpu().numpy()[0]
+    got = [r[1] / r[0], np.sqrt(r[2] / r[0]), r[3] / r[0], np.sqrt(r[4] / r[0]), r[5] / r[0], r[6] / r[0], r[7] / r[0]]
+    for a, b, nm in zip(got, g["vals"], ("mae", "rmse", "imae", "irmse", "abs_rel", "sq_rel", "delta1")):
+        assert abs(a - b) <= 1e-3 * max(abs(b), 1e-6), (nm, a, b)   # abs-rel within 1e-3 (north_star)
+
+
+def sml_net_case(dev, tol=TOL):
+    """Full MidasNet_small_videpth forward/backward vs the REFERENCE's own outputs (fixture g9; hub backbone = the restated one)."""
+    from riders_amd.midas.midas_net_custom import MidasNet_small_videpth
+    g = load("g9_sml")
+    m = MidasNet_small_videpth(device=dev, min_pred=0.1, max_pred=255.0, in_channels=3)
+    fill_state_dict(m, "g9.sml")
+    B, H, W = 2, 64, 96
+    x = t(rand_array("g9.x", (B, 3, H, W), 1.0), dev).requires_grad_()
+    d = t(rand_array("g9.d", (B, 1, H, W), 0.3, lo=0.05) + np.float32(0.02), dev)
+    m.train()
+    pred = m.forward(x, d)
+    close(pred, g["pred"], tol, "g9 pred")
+    (pred * t(rand_array("g9.w", pred.shape, 1.0), dev)).sum().backward()
+    sd = m.state_dict()
+    close(sd["first.1.running_mean"], g["rm_first"], tol, "first BN running mean")
+    close(sd["pretrained.layer1.1.running_var"], g["rv_stem"], tol, "stem BN running var")
+    # conditioning-aware gradient check against an fp64 run of the oracle (see tests/parity_cases.py)
+    def oracle_grads(dt):
+        o = OS.SMLOracle().to(dt)
+        o.load_state_dict({k: (v.to(dt) if v.is_floating_point() else v) for k, v in fill_state_dict(MidasNet_small_videpth(
+            device='cpu', min_pred=0.1, max_pred=255.0, in_channels=3), "g9.sml").items()})
+        o.train()
+        xo = t(rand_array("g9.x", (B, 3, H, W), 1.0)).to(dt).requires_grad_()
+        po = o(xo, (t(rand_array("g9.d", (B, 1, H, W), 0.3, lo=0.05) + np.float32(0.02))).to(dt))
+        (po * t(rand_array("g9.w", po.shape, 1.0)).to(dt)).sum().backward()
+        gr = {k: p.grad for k, p in o.named_parameters()}
+        gr["x"] = xo.grad
+        return gr
+    g64, g32 = oracle_grads(torch.float64), oracle_grads(torch.float32)
+
+    def cond(k):
+        return float((g32[k].double() - g64[k]).abs().max() / max(float(g64[k].abs().max()), 1e-30))
+    close(x.grad, g64["x"], max(4 * tol, 3 * cond("x")), "g9 dx")
+    close(g32["x"], g["dx"], max(4 * tol, 3 * cond("x")), "oracle vs reference dx")
+    for k, p in m.named_parameters():
+        if (k + "|none") in g:
+            assert p.grad is None, k
+            continue
+        if float(g64[k].abs().max()) < 1e-12:
+            continue
+        close(p.grad, g64[k], max(4 * tol, 8 * cond(k)), "g9 grad " + k)  # 12-sample BN at layer4: one fp32 run is a noisy estimate of the conditioning
+    m.eval()
+    with torch.no_grad():
+        close(m.forward(x.detach(), d), g["pred_eval"], tol, "g9 eval pred")
