@@ -69,6 +69,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--height", type=int, default=256)
     ap.add_argument("--width", type=int, default=512)
+    ap.add_argument("--workload", default="rcnet", choices=["rcnet", "sml"],
+                    help="rcnet = BASELINE configs[1] (headline); sml = configs[2] Scale Map Learner, batch 16, 288x384")
     ap.add_argument("--eager", action="store_true", help="do not capture forward+backward into a hipGraph")
     ap.add_argument("--detail", default=None, help="write a per-launch-shape timing table to this file")
     args = ap.parse_args()
@@ -85,19 +87,30 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", device_id=dev)
 
-    from riders_amd import engine, rcnet_main
+    from riders_amd import engine, rcnet_main, sml_main
     from riders_amd.optim import FlatAdam
     from riders_amd.parallel import GradientAllReducer
     engine.set_compute_dtype(args.dtype)
-    cfg = rcnet_main.ZJU_CONFIG
     torch.manual_seed(0)  # identical initial weights on every rank
-    model = rcnet_main.build_model(dev, cfg)
+    if args.workload == "sml":
+        if args.batch == 8 and "--batch" not in sys.argv:
+            args.batch = 16
+        if args.height == 256 and "--height" not in sys.argv:
+            args.height, args.width = 288, 384
+        cfg = sml_main.ZJU_SML_CONFIG
+        model = sml_main.build_model(dev, cfg)
+        main_mod, extra = sml_main, dict(outlier=sml_main.make_outlier_removal(cfg))
+        batch = sml_main.synthetic_batch(args.batch, args.height, args.width, seed=1234 + rank, device=dev)
+    else:
+        cfg = rcnet_main.ZJU_CONFIG
+        model = rcnet_main.build_model(dev, cfg)
+        main_mod, extra = rcnet_main, {}
+        batch = rcnet_main.synthetic_batch(args.batch, args.height, args.width, cfg, seed=1234 + rank, device=dev)
     model.train()
     opt = FlatAdam(model.parameters(), lr=cfg['learning_rate'])
     reducer = GradientAllReducer(opt) if world > 1 else None
     if reducer is not None:
         reducer.broadcast_parameters(0)
-    batch = rcnet_main.synthetic_batch(args.batch, args.height, args.width, cfg, seed=1234 + rank, device=dev)
 
     def barrier():
         if world > 1:
@@ -108,9 +121,9 @@ def main():
     loss = None
     if args.eager:
         def step():
-            return rcnet_main.train_step(model, opt, batch, cfg, reducer)
+            return main_mod.train_step(model, opt, batch, cfg, reducer, **extra)
     else:
-        step = rcnet_main.GraphedTrainStep(model, opt, batch, cfg, reducer)
+        step = main_mod.GraphedTrainStep(model, opt, batch, cfg, reducer, **extra)
     for _ in range(args.warmup):
         loss = step()
     timer = engine.KernelTimer()
@@ -129,7 +142,7 @@ def main():
         # same shapes, same stream) for a few instrumented iterations right after the timed region
         engine.set_kernel_timer(timer)
         for _ in range(min(3, max(1, args.steps))):
-            rcnet_main.train_step(model, opt, batch, cfg, reducer)
+            main_mod.train_step(model, opt, batch, cfg, reducer, **extra)
         torch.cuda.synchronize()
         engine.set_kernel_timer(None)
     timed_steps = args.steps if args.eager else min(3, max(1, args.steps))
@@ -156,11 +169,14 @@ def main():
             roof["other_kernels"] = {kk: dict(ms_per_step=v["ms"] / timed_steps, tflops=v["flops"] / (v["ms"] * 1e-3) / 1e12)
                                      for kk, v in ks.items() if kk != dom}
         out = {
-            "metric": "train imgs/sec (RC-Net, 256x512 thermal + 30 radar points, patch 240x100)",
+            "metric": "train imgs/sec (RC-Net, 256x512 thermal + 30 radar points, patch 240x100)" if args.workload == "rcnet" else
+                      "train imgs/sec (Scale Map Learner, MiDaS-small / EfficientNet-Lite3)",
             "value": imgs, "unit": "imgs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": {"fp32": "f32", "bf16": "bf16"}[args.dtype], "data": "synthetic",
-            "config": {"workload": "RC-Net training step, batch %d/GPU, ZJU config (K=30, patch 240x100), %dx%d image, fwd+loss+bwd+Adam" % (
+            "config": {"workload": ("RC-Net training step, batch %d/GPU, ZJU config (K=30, patch 240x100), %dx%d image, fwd+loss+bwd+Adam" if
+                                    args.workload == "rcnet" else
+                                    "SML training step, batch %d/GPU, %dx%d frames, device pre-step+fwd+loss+bwd+Adam") % (
                 args.batch, args.height, args.width), "global_batch": args.batch * world, "parallelism": "dp%d" % world},
             "final_loss": final_loss, "launch_mode": "eager" if args.eager else "hipGraph(fwd+bwd) + eager allreduce/Adam",
             "roofline": roof,
@@ -171,7 +187,7 @@ def main():
                 for (kind, desc), (n, tms, fl) in rows:
                     f.write("%-11s %-48s launches/step %5.1f  ms/step %8.3f  TFLOP/s %7.2f\n" % (
                         kind, desc, n / timed_steps, tms / timed_steps, fl / (tms * 1e-3) / 1e12))
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.workload == "rcnet":
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
     if world > 1:

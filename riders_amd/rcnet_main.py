@@ -117,36 +117,54 @@ def compute_gradients(model, optimizer, batch, cfg=ZJU_CONFIG):
     return loss
 
 
-class GraphedTrainStep(object):
-    """The launch-bound part of the step (~1100 small kernel launches for forward + backward) captured once into a
-    hipGraph and replayed per step; the RCCL gradient all-reduce and the fused Adam launch stay eager on the same
-    stream.  Inputs are the static device tensors of `batch` (refill them in place for new data)."""
+class GraphedStep(object):
+    """The launch-bound part of a step (forward + loss + backward: ~1100 small kernel launches for RC-Net) captured once into a
+    hipGraph and replayed per step; the RCCL gradient all-reduce and the fused Adam launch stay eager on the same stream.
+    `compute()` must run forward+backward on static device tensors and return the loss tensor; `on_replay()` keeps host-side
+    bookkeeping (BatchNorm num_batches_tracked counters) in step with replays."""
 
-    def __init__(self, model, optimizer, batch, cfg=ZJU_CONFIG, reducer=None, warmup=2):
-        self.model, self.opt, self.reducer = model, optimizer, reducer
+    def __init__(self, compute, optimizer, reducer=None, warmup=2, on_replay=None):
+        self.opt, self.reducer, self.on_replay = optimizer, reducer, on_replay
         assert engine._timer["t"] is None, "kernel timing and graph capture are exclusive"
+
+        def eager():
+            loss = compute()
+            if reducer is not None:
+                reducer.reduce()
+            optimizer.step()
+            return loss
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(warmup):
-                train_step(model, optimizer, batch, cfg, reducer)
+                eager()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
-        self._bn = [m for net in (model.encoder, model.decoder) for m in net.modules()
-                    if getattr(m, 'use_batch_norm', False) and hasattr(m, '_nbt_pending')]
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
-            self.loss = compute_gradients(model, optimizer, batch, cfg)
-        # the capture pass itself did not execute; keep host-side counters consistent
-        for m in self._bn:
-            m._nbt_pending -= 1
+            self.loss = compute()
+        if on_replay is not None:
+            on_replay(-1)  # the capture pass itself did not execute
 
     def __call__(self):
         self.graph.replay()
-        for m in self._bn:
-            if m.training:
-                m._nbt_pending += 1
+        if self.on_replay is not None:
+            self.on_replay(+1)
         if self.reducer is not None:
             self.reducer.reduce()
         self.opt.step()
         return self.loss
+
+
+class GraphedTrainStep(GraphedStep):
+    """RC-Net training step with forward+backward replayed from a hipGraph (inputs: the static tensors of `batch`)."""
+
+    def __init__(self, model, optimizer, batch, cfg=ZJU_CONFIG, reducer=None, warmup=2):
+        bn = [m for net in (model.encoder, model.decoder) for m in net.modules()
+              if getattr(m, 'use_batch_norm', False) and hasattr(m, '_nbt_pending')]
+
+        def bump(delta):
+            for m in bn:
+                if m.training:
+                    m._nbt_pending += delta
+        super().__init__(lambda: compute_gradients(model, optimizer, batch, cfg), optimizer, reducer, warmup, bump)

@@ -139,3 +139,20 @@ def validate_batch(model, batch, cfg=ZJU_SML_CONFIG, min_depth_val=0.0, max_dept
     n = np.maximum(r[:, 0], 1.0)
     return dict(count=r[:, 0], mae=r[:, 1] / n, rmse=np.sqrt(r[:, 2] / n), imae=r[:, 3] / n, irmse=np.sqrt(r[:, 4] / n), abs_rel=r[:, 5] / n,
                 sq_rel=r[:, 6] / n, delta1=r[:, 7] / n, depth=up)
+
+
+class GraphedTrainStep(object):
+    """SML training step with pre-step + forward + loss + backward replayed from a hipGraph."""
+
+    def __new__(cls, model, optimizer, batch, cfg=ZJU_SML_CONFIG, reducer=None, outlier=None, warmup=2):
+        from .rcnet_main import GraphedStep
+        from .midas.efficientnet_lite3 import _Counted
+        counted = [m for m in model.modules() if isinstance(m, _Counted)]
+
+        def bump(delta):
+            if model.training:
+                for m in counted:
+                    m._pending += delta
+                model._first_pending += delta
+                model.pretrained.layer1._stem_pending = getattr(model.pretrained.layer1, "_stem_pending", 0) + delta
+        return GraphedStep(lambda: compute_gradients(model, optimizer, batch, cfg, outlier), optimizer, reducer, warmup, bump)
