@@ -61,7 +61,10 @@ int rd_conv_pack_weights(const float* w, void* packed, int32_t Cout, int32_t Cin
   rd::launch_pack_weights(w, packed, Cout, Cin, KH, KW, mode, dtype, S(stream));
   return done("rd_conv_pack_weights");
 }
-int32_t rd_conv_stats_rows(const rd_conv_desc* d) { return (int32_t)(((int64_t)d->N * d->OH * d->OW + 127) / 128); }
+int32_t rd_conv_stats_rows(const rd_conv_desc* d) {
+  int M = d->N * d->OH * d->OW, bp = rd::conv_block_pixels(M, d->Cout);
+  return (int32_t)((M + bp - 1) / bp);
+}
 
 int rd_conv_fwd(const rd_conv_desc* d, const void* src1, const void* src2, const void* w_packed, const float* bias, void* dst1,
                 void* dst2, float* stats, void* stream) {

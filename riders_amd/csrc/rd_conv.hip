@@ -51,26 +51,31 @@ __device__ __forceinline__ bool conv_src_ptr(const ConvArgs& a, int n, int ih, i
   return true;
 }
 
-template <typename T, int BN, bool VEC>
+// WM = waves along the pixel axis (block tile = 32*WM pixels x BN channels; the other 4/WM wave factor splits the channels).
+// WM = 2 halves the tile for small-M launches (LoFTR projections, deep encoder stages) so they spread over more CUs.
+template <typename T, int BN, bool VEC, int WM>
 __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs a) {
   constexpr int VE = Elem<T>::VE;
   constexpr int BKE = STAGE_BYTES / (int)sizeof(T);  // K elements per stage
-  constexpr int CT = BN / 16;                        // cout tiles per wave
+  constexpr int WN = 4 / WM;
+  constexpr int BMV = 32 * WM;                       // pixels per block tile
+  constexpr int CT = BN / 16 / WN;                   // cout tiles per wave
   constexpr int BITER = (BN * 8 + 255) / 256;        // weight-tile vec loads per thread
-  __shared__ uint4 sA[2][BM * 8];
+  __shared__ uint4 sA[2][BMV * 8];
   __shared__ uint4 sB[2][BN * 8];
 
   const int t = threadIdx.x;
   const int lane = t & 63, wv = t >> 6;
-  const int m0 = blockIdx.x * BM;
+  const int m0 = blockIdx.x * BMV;
+  const int wm = wv % WM, wn = wv / WM;
   const int n0 = blockIdx.y * BN;
   const int Cin = a.C1 + a.C2;
 
   // ---- per-thread staging state: slot s of rows r0+32*i --------------------------------------
   const int s = t & 7, r0 = t >> 3;
-  int rn[4], rih[4], riw[4];
+  int rn[WM], rih[WM], riw[WM];
 #pragma unroll
-  for (int i = 0; i < 4; i++) {
+  for (int i = 0; i < WM; i++) {
     int m = m0 + r0 + 32 * i;
     if (m < a.M) {
       int ow = m % a.OW; int q = m / a.OW; int oh = q % a.OH; rn[i] = q / a.OH;
@@ -83,11 +88,11 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs a) {
     int k = s * VE; int tap = k / Cin; kci = k - tap * Cin; kkh = tap / a.KW; kkw = tap - kkh * a.KW;
   }
 
-  uint4 ra[4]; uint4 rb[BITER];
+  uint4 ra[WM]; uint4 rb[BITER];
 
   auto load_tile = [&](int kt) {
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
+    for (int i = 0; i < WM; i++) {
       uint4 v = make_uint4(0, 0, 0, 0);
       if (rn[i] >= 0) {
         if (VEC) {
@@ -129,7 +134,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs a) {
   };
   auto store_tile = [&](int buf) {
 #pragma unroll
-    for (int i = 0; i < 4; i++) sA[buf][lds_slot(r0 + 32 * i, s)] = ra[i];
+    for (int i = 0; i < WM; i++) sA[buf][lds_slot(r0 + 32 * i, s)] = ra[i];
 #pragma unroll
     for (int i = 0; i < BITER; i++) {
       int idx = t + 256 * i;
@@ -153,10 +158,10 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs a) {
     for (int ch = 0; ch < 2; ch++) {  // two 64-byte chunks per stage
       uint4 pf[2];
 #pragma unroll
-      for (int pt = 0; pt < 2; pt++) pf[pt] = sA[buf][lds_slot(wv * 32 + pt * 16 + fr, ch * 4 + fg)];
+      for (int pt = 0; pt < 2; pt++) pf[pt] = sA[buf][lds_slot(wm * 32 + pt * 16 + fr, ch * 4 + fg)];
 #pragma unroll
       for (int c = 0; c < CT; c++) {
-        uint4 wf = sB[buf][lds_slot(c * 16 + fr, ch * 4 + fg)];
+        uint4 wf = sB[buf][lds_slot((wn * CT + c) * 16 + fr, ch * 4 + fg)];
 #pragma unroll
         for (int pt = 0; pt < 2; pt++) {
           if (sizeof(T) == 4) {
@@ -188,11 +193,11 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs a) {
 
 #pragma unroll
   for (int pt = 0; pt < 2; pt++) {
-    const int m = m0 + wv * 32 + pt * 16 + fr;
+    const int m = m0 + wm * 32 + pt * 16 + fr;
     const bool mv = m < a.M;
 #pragma unroll
     for (int c = 0; c < CT; c++) {
-      const int co = n0 + c * 16 + fg * 4;
+      const int co = n0 + (wn * CT + c) * 16 + fg * 4;
       float v[4];
 #pragma unroll
       for (int r = 0; r < 4; r++) {
@@ -221,7 +226,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs a) {
     }
   }
   if (a.stats) {  // per-block partial sum / sum-of-squares per output channel (deterministic order)
-    float* red = reinterpret_cast<float*>(&sA[0][0]);  // [4 waves][BN][2]
+    float* red = reinterpret_cast<float*>(&sA[0][0]);  // [WM][BN][2]
 #pragma unroll
     for (int c = 0; c < CT; c++)
 #pragma unroll
@@ -230,9 +235,9 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs a) {
 #pragma unroll
         for (int o = 1; o < 16; o <<= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
         if (fr == 0) {
-          int col = c * 16 + fg * 4 + r;
-          red[(wv * BN + col) * 2 + 0] = s1;
-          red[(wv * BN + col) * 2 + 1] = s2;
+          int col = (wn * CT + c) * 16 + fg * 4 + r;
+          red[(wm * BN + col) * 2 + 0] = s1;
+          red[(wm * BN + col) * 2 + 1] = s2;
         }
       }
     __syncthreads();
@@ -241,7 +246,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs a) {
       if (co < a.Cout) {
         float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-        for (int w = 0; w < 4; w++) { s1 += red[(w * BN + col) * 2]; s2 += red[(w * BN + col) * 2 + 1]; }
+        for (int w = 0; w < WM; w++) { s1 += red[(w * BN + col) * 2]; s2 += red[(w * BN + col) * 2 + 1]; }
         a.stats[((int64_t)blockIdx.x * a.Cout + co) * 2 + 0] = s1;
         a.stats[((int64_t)blockIdx.x * a.Cout + co) * 2 + 1] = s2;
       }
@@ -446,19 +451,32 @@ static int pick_bn(int cout) {
 int conv_rows_pad(int rows) { int bn = pick_bn(rows); return (int)cdiv(rows, bn) * bn; }
 int conv_kpad(int K, int dtype) { int bke = dtype == 0 ? 32 : 64; return (int)cdiv(K, bke) * bke; }
 
+// tile choice: small-M launches (fewer than ~1.5 blocks per CU with 128-pixel tiles) halve the pixel tile, then the channel tile
+static void conv_tiles(int M, int Cout, int& bn, int& wm) {
+  bn = pick_bn(Cout);
+  wm = 4;
+  if (bn >= 32 && cdiv(M, BM) * cdiv(Cout, bn) < 384) {
+    wm = 2;
+    if (bn == 128 && cdiv(M, 64) * cdiv(Cout, bn) < 384) bn = 64;
+  }
+}
+int conv_block_pixels(int M, int Cout) { int bn, wm; conv_tiles(M, Cout, bn, wm); return 32 * wm; }
+
 template <typename T>
 static void launch_conv_t(const ConvArgs& a, hipStream_t st) {
   constexpr int VE = Elem<T>::VE;
   const int Cin = a.C1 + a.C2;
   const bool vec = (Cin % VE == 0) && (a.C1 % VE == 0);
-  const int bn = pick_bn(a.Cout);
-  dim3 grid((unsigned)cdiv(a.M, BM), (unsigned)cdiv(a.Cout, bn));
-#define RD_CONV_CASE(BNV)                                                                                  \
-  if (bn == BNV) {                                                                                         \
-    if (vec) hipLaunchKernelGGL((conv_gemm_kernel<T, BNV, true>), grid, dim3(256), 0, st, a);              \
-    else hipLaunchKernelGGL((conv_gemm_kernel<T, BNV, false>), grid, dim3(256), 0, st, a);                 \
+  int bn, wm;
+  conv_tiles(a.M, a.Cout, bn, wm);
+  dim3 grid((unsigned)cdiv(a.M, 32 * wm), (unsigned)cdiv(a.Cout, bn));
+#define RD_CONV_CASE(BNV, WMV)                                                                                  \
+  if (bn == BNV && wm == WMV) {                                                                                  \
+    if (vec) hipLaunchKernelGGL((conv_gemm_kernel<T, BNV, true, WMV>), grid, dim3(256), 0, st, a);              \
+    else hipLaunchKernelGGL((conv_gemm_kernel<T, BNV, false, WMV>), grid, dim3(256), 0, st, a);                 \
   }
-  RD_CONV_CASE(16) RD_CONV_CASE(32) RD_CONV_CASE(64) RD_CONV_CASE(128)
+  RD_CONV_CASE(16, 4) RD_CONV_CASE(32, 4) RD_CONV_CASE(64, 4) RD_CONV_CASE(128, 4)
+  RD_CONV_CASE(32, 2) RD_CONV_CASE(64, 2) RD_CONV_CASE(128, 2)
 #undef RD_CONV_CASE
 }
 
@@ -484,7 +502,7 @@ int wgrad_nsplit(int M, int K, int Cout) {
   int cot = pick_bn(Cout);
   int64_t tiles = cdiv(K, 128) * cdiv(Cout, cot);
   int64_t want = cdiv(1024, tiles);
-  int64_t maxs = cdiv(M, 256);  // at least 256 pixels per split
+  int64_t maxs = cdiv(M, 64);  // at least two 32-pixel stages per split (small-M GEMMs such as the LoFTR projections need the blocks)
   int64_t s = std::max<int64_t>(1, std::min(want, maxs));
   return (int)s;
 }

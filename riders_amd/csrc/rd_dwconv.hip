@@ -104,6 +104,100 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_kernel(const T* __restrict__
   }
 }
 
+
+// ---- channel-vectorised depthwise kernels (C % 4 == 0): thread = (4 channels, pixel lane); the k*k x 4 weights of the
+// thread's channels live in registers, every tap is one 16-byte (fp32) / 8-byte (bf16) load ------------------------------------
+template <typename T, int K, int MODE>  // MODE 0: forward, 1: data gradient
+__global__ __launch_bounds__(256) void dwconv_vec_kernel(const T* __restrict__ src, const float* __restrict__ w, T* __restrict__ dst, int N,
+                                                         int H, int W, int C, int OH, int OW, int s, int p, int C4B, int PL, int PPB) {
+  const int t = threadIdx.x, cl = t % C4B, pl = t / C4B;
+  const int c = (blockIdx.y * C4B + cl) * 4;
+  if (c >= C) return;
+  float wr[K * K][4];
+#pragma unroll
+  for (int j = 0; j < K * K; j++)
+#pragma unroll
+    for (int e = 0; e < 4; e++) wr[j][e] = w[(c + e) * K * K + j];
+  const int DH = MODE ? H : OH, DW = MODE ? W : OW;           // destination spatial size
+  const int64_t M = (int64_t)N * DH * DW;
+  const int64_t mbeg = (int64_t)blockIdx.x * PPB, mend = mbeg + PPB < M ? mbeg + PPB : M;
+  for (int64_t m = mbeg + pl; m < mend; m += PL) {
+    int dw_ = (int)(m % DW); int64_t q = m / DW; int dh = (int)(q % DH); int n = (int)(q / DH);
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kh = 0; kh < K; kh++) {
+      int sh;
+      if (MODE == 0) { sh = dh * s - p + kh; if ((unsigned)sh >= (unsigned)H) continue; }
+      else { int u = dh + p - kh; if (u < 0 || (u % s)) continue; sh = u / s; if (sh >= OH) continue; }
+#pragma unroll
+      for (int kw = 0; kw < K; kw++) {
+        int sw;
+        if (MODE == 0) { sw = dw_ * s - p + kw; if ((unsigned)sw >= (unsigned)W) continue; }
+        else { int u = dw_ + p - kw; if (u < 0 || (u % s)) continue; sw = u / s; if (sw >= OW) continue; }
+        const int SH = MODE ? OH : H, SW = MODE ? OW : W;
+        float v[4];
+        ld4(src + (((int64_t)n * SH + sh) * SW + sw) * C + c, v);
+#pragma unroll
+        for (int e = 0; e < 4; e++) acc[e] += v[e] * wr[kh * K + kw][e];
+      }
+    }
+    st4(dst + m * C + c, acc);
+  }
+}
+
+template <typename T, int K>
+__global__ __launch_bounds__(256) void dwconv_wgrad_vec_kernel(const T* __restrict__ x, const T* __restrict__ dy, float* __restrict__ partial,
+                                                               int N, int H, int W, int C, int OH, int OW, int s, int p, int C4B, int PL) {
+  __shared__ float red[256][4];
+  const int t = threadIdx.x, cl = t % C4B, pl = t / C4B;
+  const int c = (blockIdx.y * C4B + cl) * 4;
+  const bool cv = c < C;
+  const int64_t pixels = (int64_t)N * OH * OW;
+  const int64_t per = cdiv(pixels, gridDim.x);
+  const int64_t pbeg = (int64_t)blockIdx.x * per, pend = pbeg + per < pixels ? pbeg + per : pixels;
+  float acc[K * K][4];
+#pragma unroll
+  for (int j = 0; j < K * K; j++)
+#pragma unroll
+    for (int e = 0; e < 4; e++) acc[j][e] = 0.f;
+  if (cv) {
+    for (int64_t m = pbeg + pl; m < pend; m += PL) {
+      int ow = (int)(m % OW); int64_t q = m / OW; int oh = (int)(q % OH); int n = (int)(q / OH);
+      float g[4];
+      ld4(dy + m * C + c, g);
+#pragma unroll
+      for (int kh = 0; kh < K; kh++) {
+        int ih = oh * s - p + kh;
+        if ((unsigned)ih >= (unsigned)H) continue;
+#pragma unroll
+        for (int kw = 0; kw < K; kw++) {
+          int iw = ow * s - p + kw;
+          if ((unsigned)iw >= (unsigned)W) continue;
+          float v[4];
+          ld4(x + (((int64_t)n * H + ih) * W + iw) * C + c, v);
+#pragma unroll
+          for (int e = 0; e < 4; e++) acc[kh * K + kw][e] += g[e] * v[e];
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < K * K; j++) {
+#pragma unroll
+    for (int e = 0; e < 4; e++) red[t][e] = acc[j][e];
+    __syncthreads();
+    if (pl == 0 && cv) {
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        float sacc = 0.f;
+        for (int q = 0; q < PL; q++) sacc += red[q * C4B + cl][e];
+        partial[((int64_t)blockIdx.x * C + c + e) * (K * K) + j] = sacc;
+      }
+    }
+    __syncthreads();
+  }
+}
+
 __global__ __launch_bounds__(64) void dwconv_wgrad_finalize_kernel(const float* __restrict__ partial, int rows, int CK, float* dw,
                                                                    int accumulate) {
   const int i = blockIdx.x, lane = threadIdx.x;
@@ -230,22 +324,57 @@ int dw_rows(int64_t pixels, int C) {
   return (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(pixels, (int64_t)g.PL * 64), 512));
 }
 
+struct VG { int C4B, PL, PPB, nchunk; };
+static VG vgeom(int C) {
+  VG g; int c4 = C / 4; int cb = 1; while (cb < c4 && cb < 64) cb <<= 1;
+  g.C4B = cb; g.PL = 256 / cb; g.PPB = g.PL * 16; g.nchunk = (int)cdiv(c4, cb);
+  return g;
+}
+template <typename T, int MODE>
+static void launch_dw_vec(const void* src, const float* w, void* dst, int N, int H, int W, int C, int OH, int OW, int k, int s, int p, hipStream_t st) {
+  VG g = vgeom(C);
+  int64_t M = (int64_t)N * (MODE ? (int64_t)H * W : (int64_t)OH * OW);
+  dim3 grid((unsigned)cdiv(M, g.PPB), g.nchunk);
+  if (k == 3) hipLaunchKernelGGL((dwconv_vec_kernel<T, 3, MODE>), grid, dim3(256), 0, st, (const T*)src, w, (T*)dst, N, H, W, C, OH, OW, s, p, g.C4B, g.PL, g.PPB);
+  else hipLaunchKernelGGL((dwconv_vec_kernel<T, 5, MODE>), grid, dim3(256), 0, st, (const T*)src, w, (T*)dst, N, H, W, C, OH, OW, s, p, g.C4B, g.PL, g.PPB);
+}
+
 void launch_dwconv_fwd(const void* x, const float* w, void* y, int N, int H, int W, int C, int OH, int OW, int k, int s, int p, int dtype,
                        hipStream_t st) {
+  if (C % 4 == 0 && (k == 3 || k == 5)) {
+    if (dtype == 0) launch_dw_vec<float, 0>(x, w, y, N, H, W, C, OH, OW, k, s, p, st);
+    else launch_dw_vec<bf16_t, 0>(x, w, y, N, H, W, C, OH, OW, k, s, p, st);
+    return;
+  }
   int64_t n = (int64_t)N * OH * OW * C;
   if (dtype == 0) hipLaunchKernelGGL((dwconv_fwd_kernel<float>), dim3(ew_grid(n)), dim3(256), 0, st, (const float*)x, w, (float*)y, N, H, W, C, OH, OW, k, s, p);
   else hipLaunchKernelGGL((dwconv_fwd_kernel<bf16_t>), dim3(ew_grid(n)), dim3(256), 0, st, (const bf16_t*)x, w, (bf16_t*)y, N, H, W, C, OH, OW, k, s, p);
 }
 void launch_dwconv_dgrad(const void* dy, const float* w, void* dx, int N, int H, int W, int C, int OH, int OW, int k, int s, int p,
                          int dtype, hipStream_t st) {
+  if (C % 4 == 0 && (k == 3 || k == 5)) {
+    if (dtype == 0) launch_dw_vec<float, 1>(dy, w, dx, N, H, W, C, OH, OW, k, s, p, st);
+    else launch_dw_vec<bf16_t, 1>(dy, w, dx, N, H, W, C, OH, OW, k, s, p, st);
+    return;
+  }
   int64_t n = (int64_t)N * H * W * C;
   if (dtype == 0) hipLaunchKernelGGL((dwconv_dgrad_kernel<float>), dim3(ew_grid(n)), dim3(256), 0, st, (const float*)dy, w, (float*)dx, N, H, W, C, OH, OW, k, s, p);
   else hipLaunchKernelGGL((dwconv_dgrad_kernel<bf16_t>), dim3(ew_grid(n)), dim3(256), 0, st, (const bf16_t*)dy, w, (bf16_t*)dx, N, H, W, C, OH, OW, k, s, p);
 }
 void launch_dwconv_wgrad(const void* x, const void* dy, float* partial, float* dw, int accumulate, int N, int H, int W, int C, int OH,
                          int OW, int k, int s, int p, int dtype, hipStream_t st) {
-  RG g = rgeom(C);
   int rows = dw_rows((int64_t)N * OH * OW, C);
+  if (C % 4 == 0 && (k == 3 || k == 5)) {
+    VG v = vgeom(C);
+    dim3 vgrid(rows, v.nchunk);
+#define RD_DWV(T, K) hipLaunchKernelGGL((dwconv_wgrad_vec_kernel<T, K>), vgrid, dim3(256), 0, st, (const T*)x, (const T*)dy, partial, N, H, W, C, OH, OW, s, p, v.C4B, v.PL)
+    if (dtype == 0) { if (k == 3) RD_DWV(float, 3); else RD_DWV(float, 5); }
+    else { if (k == 3) RD_DWV(bf16_t, 3); else RD_DWV(bf16_t, 5); }
+#undef RD_DWV
+    hipLaunchKernelGGL(dwconv_wgrad_finalize_kernel, dim3(C * k * k), dim3(64), 0, st, partial, rows, C * k * k, dw, accumulate);
+    return;
+  }
+  RG g = rgeom(C);
   dim3 grid(rows, g.nchunk);
 #define RD_DW(T, KK) hipLaunchKernelGGL((dwconv_wgrad_kernel<T, KK>), grid, dim3(256), 0, st, (const T*)x, (const T*)dy, partial, N, H, W, C, OH, OW, k, s, p, g.CB, g.PL)
   if (dtype == 0) { if (k <= 3) RD_DW(float, 9); else RD_DW(float, 25); }

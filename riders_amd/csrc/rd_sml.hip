@@ -34,26 +34,45 @@ __device__ __forceinline__ double block_sum_d(double v, double* sh) {
 __global__ __launch_bounds__(256) void sml_scale_align_kernel(const float* __restrict__ mono, const float* __restrict__ sparse, int HW,
                                                               float dmin, float dmax, float lo, float hi, float* __restrict__ scale,
                                                               int* __restrict__ nvalid) {
+  constexpr int CAP = 4096;  // valid radar pixels kept in LDS (sparse radar: a few hundred per frame); more -> rescan global memory
   __shared__ double sh[4];
+  __shared__ float sp[CAP], st[CAP];
+  __shared__ int scount;
   const int b = blockIdx.x;
   const float* p = mono + (int64_t)b * HW;
   const float* z = sparse + (int64_t)b * HW;
-  double cnt = 0.0;
-  for (int i = threadIdx.x; i < HW; i += 256) cnt += (z[i] < dmax && z[i] > dmin) ? 1.0 : 0.0;
-  cnt = block_sum_d(cnt, sh);
-  auto slope = [&](float s) {
+  if (threadIdx.x == 0) scount = 0;
+  __syncthreads();
+  for (int i = threadIdx.x; i < HW; i += 256) {
+    float zi = z[i];
+    if (zi < dmax && zi > dmin) {
+      int k = atomicAdd(&scount, 1);
+      if (k < CAP) { sp[k] = p[i]; st[k] = 1.0f / zi; }
+    }
+  }
+  __syncthreads();
+  const int cnt = scount;
+  const bool in_lds = cnt <= CAP;
+  auto slope = [&](float s) {  // the sum is order-independent up to double rounding: compaction order does not matter
     double g = 0.0;
-    for (int i = threadIdx.x; i < HW; i += 256) {
-      float zi = z[i];
-      if (zi < dmax && zi > dmin) {
-        float r = s * p[i] - 1.0f / zi;
-        g += r > 0.f ? (double)p[i] : (r < 0.f ? -(double)p[i] : 0.0);
+    if (in_lds) {
+      for (int i = threadIdx.x; i < cnt; i += 256) {
+        float r = s * sp[i] - st[i];
+        g += r > 0.f ? (double)sp[i] : (r < 0.f ? -(double)sp[i] : 0.0);
+      }
+    } else {
+      for (int i = threadIdx.x; i < HW; i += 256) {
+        float zi = z[i];
+        if (zi < dmax && zi > dmin) {
+          float r = s * p[i] - 1.0f / zi;
+          g += r > 0.f ? (double)p[i] : (r < 0.f ? -(double)p[i] : 0.0);
+        }
       }
     }
     return block_sum_d(g, sh);
   };
   float a = lo, c = hi, res;
-  if (cnt == 0.0) res = 0.29999601510536417f * (hi / 0.3f);
+  if (cnt == 0) res = 0.29999601510536417f * (hi / 0.3f);
   else if (slope(a) >= 0.0) res = a;
   else if (slope(c) <= 0.0) res = c;
   else {
@@ -63,7 +82,7 @@ __global__ __launch_bounds__(256) void sml_scale_align_kernel(const float* __res
     }
     res = c;
   }
-  if (threadIdx.x == 0) { scale[b] = res; nvalid[b] = (int)cnt; }
+  if (threadIdx.x == 0) { scale[b] = res; nvalid[b] = cnt; }
 }
 
 // int_depth = clamp(s*mono), int_scales (1 / rcnet / radar override) -> per-sample min & max of int_scales

@@ -62,6 +62,7 @@ CONV_CASES = [
     dict(cin=64, cout=128, k=1, s=2, H=9, W=8, N=2, bn=False, act=None),
     dict(cin=16, cout=1, k=3, s=1, H=12, W=10, N=2, bn=False, act=None),
     dict(cin=128, cout=256, k=3, s=1, H=5, W=6, N=1, bn=True),
+    dict(cin=384, cout=512, k=3, s=1, H=2, W=3, N=2, bn=False, act=None),   # SML layer4_rn: 12 output pixels, K = 3456
 ]
 
 

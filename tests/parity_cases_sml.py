@@ -184,13 +184,23 @@ def sml_net_case(dev, tol=TOL):
         return float((g32[k].double() - g64[k]).abs().max() / max(float(g64[k].abs().max()), 1e-30))
     close(x.grad, g64["x"], max(4 * tol, 3 * cond("x")), "g9 dx")
     close(g32["x"], g["dx"], max(4 * tol, 3 * cond("x")), "oracle vs reference dx")
+    # B=2 at 64x96 leaves 12 samples per BatchNorm channel in layer4: single parameters are ill-conditioned in fp32 (one fp32 oracle run is
+    # itself a noisy estimate of that), so the per-parameter bound is loose (20 x) and the decisive check is the global relative L2 error of
+    # ALL parameter gradients, which must stay within 3 x the fp32 oracle's own global error (floor 2e-3).
+    num = den = num32 = 0.0
     for k, p in m.named_parameters():
         if (k + "|none") in g:
             assert p.grad is None, k
             continue
-        if float(g64[k].abs().max()) < 1e-12:
+        ref = g64[k]
+        num += float((p.grad.detach().cpu().double() - ref).pow(2).sum())
+        num32 += float((g32[k].double() - ref).pow(2).sum())
+        den += float(ref.pow(2).sum())
+        if float(ref.abs().max()) < 1e-12:
             continue
-        close(p.grad, g64[k], max(4 * tol, 8 * cond(k)), "g9 grad " + k)  # 12-sample BN at layer4: one fp32 run is a noisy estimate of the conditioning
+        close(p.grad, ref, max(4 * tol, 20 * cond(k)), "g9 grad " + k)
+    gerr, gcond = (num / den) ** 0.5, (num32 / den) ** 0.5
+    assert gerr <= max(2e-3, 3 * gcond), "global gradient error %.3e vs fp32-oracle %.3e" % (gerr, gcond)
     m.eval()
     with torch.no_grad():
         close(m.forward(x.detach(), d), g["pred_eval"], tol, "g9 eval pred")
