@@ -13,7 +13,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, outdir):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -29,20 +29,23 @@ def _worker(rank, world, port, q):
         opt._grad_view(p).copy_(torch.full_like(p, float(rank + 1)))
     red.reduce()
     ok = all(bool(torch.all(opt._grad_view(p) == 3.0)) for p in params)  # 1 + 2
-    q.put((rank, ok, opt.grad_scale, ref0, len(red.buckets)))
+    dist.barrier()
     dist.destroy_process_group()
+    torch.save((rank, ok, opt.grad_scale, ref0, len(red.buckets)), os.path.join(outdir, "r%d.pt" % rank))
 
 
 def test_arena_allreduce_world2():
+    import tempfile
     ctx = mp.get_context("spawn")
-    q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
-    for p in procs:
-        p.start()
-    res = sorted([q.get(timeout=120) for _ in range(2)], key=lambda r: r[0])
-    for p in procs:
-        p.join(timeout=60)
+    with tempfile.TemporaryDirectory() as outdir:
+        procs = [ctx.Process(target=_worker, args=(r, 2, port, outdir)) for r in range(2)]
+        for p in procs:
+            p.start()
+        for p in procs:
+            p.join(timeout=180)
+            assert p.exitcode == 0, "worker exit code %s" % p.exitcode
+        res = [torch.load(os.path.join(outdir, "r%d.pt" % r)) for r in range(2)]
     assert res[0][1] and res[1][1], "gradient sum wrong"
     assert res[0][2] == 0.5 and res[1][2] == 0.5
     assert torch.equal(res[0][3], res[1][3]), "parameters not broadcast from rank 0"
