@@ -79,7 +79,7 @@ int rd_conv_fwd(const rd_conv_desc* d, const void* src1, const void* src2, const
 }
 int64_t rd_conv_wgrad_workspace_bytes(const rd_conv_desc* d) {
   int M = d->N * d->OH * d->OW, K = d->KH * d->KW * (d->C1 + d->C2);
-  int ns = rd::wgrad_nsplit(M, K, d->Cout);
+  int ns = rd::wgrad_slabs(M, K, d->Cout);
   return (int64_t)(ns + 1) * d->Cout * K * (int64_t)sizeof(float);
 }
 int rd_conv_wgrad(const rd_conv_desc* d, const void* src1, const void* src2, const void* dy, float* workspace, float* dw,

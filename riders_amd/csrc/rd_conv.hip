@@ -22,6 +22,7 @@
 // one pixel -> one 16-byte (fp32) / 8-byte (bf16) NHWC store per lane per tile.
 #include "rd_common.h"
 #include "rd_kernels.h"
+#include <type_traits>
 
 namespace rd {
 
@@ -384,6 +385,27 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
 #pragma unroll
   for (int j = 0; j < TJ; j++) jv[j] = kt0 + wc + j * 16 < a.K;  // wave-uniform: skip all-padding column tiles
 
+  // wave-uniform count of column tiles that are not all padding (a prefix): selects a fully unrolled MFMA body without per-MFMA branches
+  int nj = 0;
+#pragma unroll
+  for (int j = 0; j < TJ; j++) nj += jv[j] ? 1 : 0;
+  auto mma_stage = [&](int buf, auto njc) {
+    constexpr int NJ = decltype(njc)::value;
+#pragma unroll
+    for (int p4 = 0; p4 < PK / 4; p4++) {
+      int p = p4 * 4 + fg;
+      float ya[TI], xb[NJ];
+#pragma unroll
+      for (int i = 0; i < TI; i++) ya[i] = sY[buf][wgy_idx<COT>(p, wr + i * 16 + fr)];
+#pragma unroll
+      for (int j = 0; j < NJ; j++) xb[j] = sX[buf][wg_idx(p, wc + j * 16 + fr)];
+#pragma unroll
+      for (int j = 0; j < NJ; j++)
+#pragma unroll
+        for (int i = 0; i < TI; i++) acc[i][j] = mfma_16x16x4_f32(ya[i], xb[j], acc[i][j]);
+    }
+  };
+
   int nst = (mend > mbeg) ? (mend - mbeg + PK - 1) / PK : 0;
   if (nst > 0) {
     load_stage(mbeg);
@@ -393,21 +415,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
   for (int st = 0; st < nst; st++) {
     int buf = st & 1;
     if (st + 1 < nst) load_stage(mbeg + (st + 1) * PK);
-#pragma unroll
-    for (int p4 = 0; p4 < PK / 4; p4++) {
-      int p = p4 * 4 + fg;
-      float ya[TI], xb[TJ];
-#pragma unroll
-      for (int i = 0; i < TI; i++) ya[i] = sY[buf][wgy_idx<COT>(p, wr + i * 16 + fr)];
-#pragma unroll
-      for (int j = 0; j < TJ; j++) xb[j] = sX[buf][wg_idx(p, wc + j * 16 + fr)];
-#pragma unroll
-      for (int j = 0; j < TJ; j++)
-        if (jv[j]) {
-#pragma unroll
-          for (int i = 0; i < TI; i++) acc[i][j] = mfma_16x16x4_f32(ya[i], xb[j], acc[i][j]);
-        }
-    }
+    if (nj == TJ) mma_stage(buf, std::integral_constant<int, TJ>{});
+    else if (TJ > 1 && nj == TJ - 1) mma_stage(buf, std::integral_constant<int, (TJ > 1 ? TJ - 1 : 1)>{});
+    else if (TJ > 2 && nj == TJ - 2) mma_stage(buf, std::integral_constant<int, (TJ > 2 ? TJ - 2 : 1)>{});
+    else if (TJ > 3 && nj == TJ - 3) mma_stage(buf, std::integral_constant<int, (TJ > 3 ? TJ - 3 : 1)>{});
     if (st + 1 < nst) store_stage(buf ^ 1);
     __syncthreads();
   }
@@ -426,19 +437,210 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
     }
 }
 
-// sum slabs in split order and write / accumulate the OIHW fp32 gradient
-__global__ void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int Cout, int Cin, int KH,
-                                    int KW, int nsplit, int accumulate) {
-  int K = KH * KW * Cin;
-  int64_t total = (int64_t)Cout * K;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    float s = 0.f;
-    for (int sp = 0; sp < nsplit; sp++) s += slab[(int64_t)sp * total + i];
-    int co = (int)(i / K), k = (int)(i - (int64_t)co * K);
-    int tap = k / Cin, ci = k - tap * Cin, kh = tap / KW, kw = tap - kh * KW;
-    int64_t o = (((int64_t)co * Cin + ci) * KH + kh) * KW + kw;
-    dw[o] = accumulate ? dw[o] + s : s;
+
+// ---- halo-tile weight gradient for 3x3 / stride-1 layers with few channels (decoder tail: Cin <= 64, Cout <= 32) -----------
+// The generic wgrad re-gathers every input pixel once per tap (9x through L1/L2), which bounds these layers far below both the
+// MFMA and the HBM roofline.  Here a block stages an (TH+2) x (TW+2) x Cin input patch (upsample / concat folded in) and the
+// TH x TW x Cout output-gradient tile in LDS ONCE, converts to fp32, and runs all 9 taps from LDS on v_mfma_f32_16x16x4_f32:
+// D[cout][(tap, cin)] += dY[pixel][cout] * X[pixel + tap][cin], k = 4 consecutive pixels of a row.  Blocks are persistent over
+// tiles and write one slab each, summed in order by wgrad_reduce_kernel (deterministic).
+__device__ __forceinline__ int hswz(int C, int c, int parity) { return C >= 32 ? (c ^ (parity << 4)) : c; }
+
+// tile geometry (compile time): the (TH, TW) with TW in {16, 32} that fits 60 KiB and has the best useful / staged pixel ratio
+constexpr int halo_th(int cti, int rt) { return (cti == 4 && rt == 2) ? 4 : 8; }
+constexpr int halo_tw(int cti, int rt) { return (cti == 4 || (cti == 2 && rt == 2)) ? 16 : 32; }
+
+template <typename T, int CTI, int RT>  // CTI = Cin/16, RT = ceil(Cout/16)
+__global__ __launch_bounds__(256) void conv_wgrad_halo_kernel(WgradArgs a, int tilesH, int tilesW) {
+  constexpr int CIN = CTI * 16, COP = RT * 16;
+  constexpr int TH = halo_th(CTI, RT), TW = halo_tw(CTI, RT), HT = TH + 2, WT = TW + 2;
+  constexpr int NCW = (9 * CTI + 3) / 4;  // (tap, cin-tile) column tiles per wave
+  constexpr int VX = CIN / 4, PLX = 256 / VX, NX = (HT * WT + PLX - 1) / PLX;  // staged input vectors per thread
+  constexpr int VY = COP / 4, PLY = 256 / VY, NY = (TH * TW + PLY - 1) / PLY;
+  static_assert(HT * WT * CIN + TH * TW * COP <= 15360, "halo tile exceeds 60 KiB of LDS");
+  __shared__ float smem[HT * WT * CIN + TH * TW * COP];
+  float* sX = smem;                       // [HT][WT][CIN]   (channel index XOR-swizzled by column parity)
+  float* sY = smem + HT * WT * CIN;       // [TH*TW][COP]
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  const int fr = lane & 15, fg = lane >> 4;
+  ConvArgs g;
+  g.src1 = a.src1; g.src2 = a.src2; g.Hin = a.Hin; g.Win = a.Win; g.C1 = a.C1; g.C2 = a.C2; g.H1 = a.H1; g.W1 = a.W1;
+  g.dil = 1; g.ups = a.ups; g.scale_h = a.scale_h; g.scale_w = a.scale_w;
+
+  f32x4 acc[RT][NCW];
+#pragma unroll
+  for (int i = 0; i < RT; i++)
+#pragma unroll
+    for (int j = 0; j < NCW; j++) acc[i][j] = f32x4{0, 0, 0, 0};
+  int jtap[NCW], jct[NCW]; bool jv[NCW];
+#pragma unroll
+  for (int j = 0; j < NCW; j++) {
+    int idx = wv + 4 * j;
+    jv[j] = idx < 9 * CTI;
+    int id2 = jv[j] ? idx : 0;
+    jtap[j] = id2 / CTI; jct[j] = id2 - jtap[j] * CTI;
   }
+  // per-lane LDS offsets: px0 and 4*qd are even, so the swizzle parity of a lane's pixel is (fg + kw) & 1 and every LDS address of the
+  // MFMA loop is  row base + per-lane constant + compile-time offset (the first version spent 41 VALU instructions per MFMA here)
+  int offx[NCW], offy[RT];
+#pragma unroll
+  for (int j = 0; j < NCW; j++) {
+    int kh = jtap[j] / 3, kw = jtap[j] - kh * 3;
+    offx[j] = (kh * WT + fg + kw) * CIN + hswz(CIN, jct[j] * 16 + fr, (fg + kw) & 1);
+  }
+#pragma unroll
+  for (int i = 0; i < RT; i++) offy[i] = fg * COP + hswz(COP, i * 16 + fr, fg & 1);
+
+  // staging roles: thread = (fixed 4-channel vector, pixel lane); the next tile is fetched into registers while the current one is
+  // being multiplied, so global-memory latency is off the critical path (2 blocks per CU would otherwise idle through it)
+  const int xc = (t % VX) * 4, xp0 = t / VX;
+  const int yc = (t % VY) * 4, yp0 = t / VY;
+  float fx[NX][4], fy[NY][4];
+  const int ntiles = a.N * tilesH * tilesW;
+  auto fetch = [&](int tile) {
+    int tw_ = tile % tilesW; int q = tile / tilesW; int th_ = q % tilesH; int n = q / tilesH;
+    const int oh0 = th_ * TH, ow0 = tw_ * TW;
+#pragma unroll
+    for (int it = 0; it < NX; it++) {
+      int pq = xp0 + it * PLX;
+      int py = pq / WT, px = pq - py * WT;
+#pragma unroll
+      for (int e = 0; e < 4; e++) fx[it][e] = 0.f;
+      const T* p;
+      if (pq < HT * WT && conv_src_ptr<T>(g, n, oh0 - 1 + py, ow0 - 1 + px, xc, p)) ld4(p, fx[it]);
+    }
+#pragma unroll
+    for (int it = 0; it < NY; it++) {
+      int pq = yp0 + it * PLY;
+      int py = pq / TW, px = pq - py * TW;
+      int oh = oh0 + py, ow = ow0 + px;
+#pragma unroll
+      for (int e = 0; e < 4; e++) fy[it][e] = 0.f;
+      if (pq < TH * TW && oh < a.OH && ow < a.OW) {
+        const T* yp = (const T*)a.dy + (((int64_t)n * a.OH + oh) * a.OW + ow) * a.Cout + yc;
+        if ((a.Cout & 3) == 0 && yc + 3 < a.Cout) ld4(yp, fy[it]);
+        else {
+#pragma unroll
+          for (int e = 0; e < 4; e++) if (yc + e < a.Cout) fy[it][e] = Elem<T>::ld(yp + e);
+        }
+      }
+    }
+  };
+  auto stash = [&]() {
+#pragma unroll
+    for (int it = 0; it < NX; it++) {
+      int pq = xp0 + it * PLX;
+      int px = pq % WT;
+      if (pq < HT * WT)
+        *reinterpret_cast<float4*>(&sX[pq * CIN + hswz(CIN, xc, px & 1)]) = make_float4(fx[it][0], fx[it][1], fx[it][2], fx[it][3]);
+    }
+#pragma unroll
+    for (int it = 0; it < NY; it++) {
+      int pq = yp0 + it * PLY;
+      int px = pq % TW;
+      if (pq < TH * TW)
+        *reinterpret_cast<float4*>(&sY[pq * COP + hswz(COP, yc, px & 1)]) = make_float4(fy[it][0], fy[it][1], fy[it][2], fy[it][3]);
+    }
+  };
+
+  auto compute = [&](auto njc) {
+    constexpr int NJ = decltype(njc)::value;
+    constexpr int QD = CTI == 4 ? 2 : 4;  // pixel quads whose LDS reads are batched ahead of their MFMAs (register budget)
+#pragma unroll
+    for (int py = 0; py < TH; py++)
+#pragma unroll
+      for (int px0 = 0; px0 < TW; px0 += 4 * QD) {
+        const float* xrow = sX + (py * WT + px0) * CIN;
+        const float* yrow = sY + (py * TW + px0) * COP;
+        float ya[QD][RT], xb[QD][NJ > 0 ? NJ : 1];
+#pragma unroll
+        for (int qd = 0; qd < QD; qd++) {
+#pragma unroll
+          for (int i = 0; i < RT; i++) ya[qd][i] = yrow[offy[i] + qd * 4 * COP];
+#pragma unroll
+          for (int j = 0; j < NJ; j++) xb[qd][j] = xrow[offx[j] + qd * 4 * CIN];
+        }
+#pragma unroll
+        for (int qd = 0; qd < QD; qd++)
+#pragma unroll
+          for (int j = 0; j < NJ; j++)
+#pragma unroll
+            for (int i = 0; i < RT; i++) acc[i][j] = mfma_16x16x4_f32(ya[qd][i], xb[qd][j], acc[i][j]);
+      }
+  };
+
+  int tile = blockIdx.x;
+  if (tile < ntiles) fetch(tile);
+  for (; tile < ntiles; tile += gridDim.x) {
+    __syncthreads();  // previous tile fully consumed
+    stash();
+    __syncthreads();
+    if (tile + (int)gridDim.x < ntiles) fetch(tile + gridDim.x);
+    // the number of column tiles a wave owns (NCW or NCW-1) selects one of two fully unrolled bodies: a per-MFMA `if` made the
+    // compiler shuttle the accumulators between register files around every MFMA (33 VALU instructions per MFMA, measured)
+    if (jv[NCW - 1]) compute(std::integral_constant<int, NCW>{});
+    else compute(std::integral_constant<int, NCW - 1>{});
+  }
+  float* slab = a.slab + (int64_t)blockIdx.x * a.Cout * a.K;
+#pragma unroll
+  for (int i = 0; i < RT; i++)
+#pragma unroll
+    for (int j = 0; j < NCW; j++)
+      if (jv[j]) {
+        int k = jtap[j] * CIN + jct[j] * 16 + fr;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          int co = i * 16 + fg * 4 + r;
+          if (co < a.Cout) slab[(int64_t)co * a.K + k] = acc[i][j][r];
+        }
+      }
+}
+
+static bool wgrad_halo_ok(const WgradArgs& a) {
+  const int Cin = a.C1 + a.C2;
+  return a.KH == 3 && a.KW == 3 && a.stride == 1 && a.pad == 1 && (Cin == 16 || Cin == 32 || Cin == 64) && a.Cout <= 32 &&
+         (a.C1 % 8 == 0) && a.OH == a.Hin && a.OW == a.Win;
+}
+static void halo_geom(int Cin, int Cout, int& TH, int& TW) {
+  const int cti = Cin / 16, rt = Cout <= 16 ? 1 : 2;
+  TH = halo_th(cti, rt); TW = halo_tw(cti, rt);
+}
+static const int HALO_BLOCKS = 1024;
+
+// sum slabs and write / accumulate the OIHW fp32 gradient.  thread = (output o, split lane sl): lane sl adds splits sl, sl+SL, ...
+// in order, the SL lane sums are then added in lane order -> a fixed summation tree (deterministic) with SL-fold memory parallelism
+// (the halo-tile path produces up to 1024 slabs for a few thousand outputs).
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slab, float* __restrict__ dw, int Cout, int Cin, int KH,
+                                                           int KW, int nsplit, int accumulate, int SL) {
+  __shared__ float red[256];
+  const int K = KH * KW * Cin;
+  const int64_t total = (int64_t)Cout * K;
+  const int OB = 256 / SL;
+  const int t = threadIdx.x, ol = t % OB, sl = t / OB;
+  for (int64_t base = (int64_t)blockIdx.x * OB; base < total; base += (int64_t)gridDim.x * OB) {
+    const int64_t i = base + ol;
+    float s = 0.f;
+    if (i < total)
+      for (int sp = sl; sp < nsplit; sp += SL) s += slab[(int64_t)sp * total + i];
+    red[t] = s;
+    __syncthreads();
+    if (sl == 0 && i < total) {
+      float acc = 0.f;
+      for (int q = 0; q < SL; q++) acc += red[q * OB + ol];
+      int co = (int)(i / K), k = (int)(i - (int64_t)co * K);
+      int tap = k / Cin, ci = k - tap * Cin, kh = tap / KW, kw = tap - kh * KW;
+      int64_t o = (((int64_t)co * Cin + ci) * KH + kh) * KW + kw;
+      dw[o] = accumulate ? dw[o] + acc : acc;
+    }
+    __syncthreads();
+  }
+}
+
+static void launch_wgrad_reduce(const float* slab, float* dw, int Cout, int Cin, int KH, int KW, int nsplit, int accumulate, hipStream_t st) {
+  int SL = 1; while (SL < nsplit && SL < 16) SL <<= 1;
+  int64_t total = (int64_t)Cout * KH * KW * Cin;
+  unsigned rg = (unsigned)std::min<int64_t>(cdiv(total, 256 / SL), 4096);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rg), dim3(256), 0, st, slab, dw, Cout, Cin, KH, KW, nsplit, accumulate, SL);
 }
 
 // ---- host-side launchers ------------------------------------------------------------------------------------
@@ -498,6 +700,11 @@ void launch_pack_weights(const float* w, void* out, int Cout, int Cin, int KH, i
 }
 
 // split the pixel reduction so the launch has a few blocks per CU, stage-aligned
+int wgrad_nsplit(int M, int K, int Cout);
+int wgrad_slabs(int M, int K, int Cout) {
+  int ns = wgrad_nsplit(M, K, Cout);
+  return (Cout <= 32 && K <= 9 * 64) ? std::max(ns, HALO_BLOCKS) : ns;  // the halo-tile path writes one slab per persistent block
+}
 int wgrad_nsplit(int M, int K, int Cout) {
   int cot = pick_bn(Cout);
   int64_t tiles = cdiv(K, 128) * cdiv(Cout, cot);
@@ -520,17 +727,38 @@ static void launch_wgrad_t(const WgradArgs& a, bool vec, hipStream_t st) {
 #undef RD_WG_CASE
 }
 
+template <typename T>
+static void launch_wgrad_halo_t(const WgradArgs& a, int nblk, hipStream_t st) {
+  const int Cin = a.C1 + a.C2, rt = a.Cout <= 16 ? 1 : 2;
+  int TH, TW;
+  halo_geom(Cin, a.Cout, TH, TW);
+  int tilesH = (int)cdiv(a.OH, TH), tilesW = (int)cdiv(a.OW, TW);
+#define RD_HALO(CTI, RT) hipLaunchKernelGGL((conv_wgrad_halo_kernel<T, CTI, RT>), dim3(nblk), dim3(256), 0, st, a, tilesH, tilesW)
+  if (Cin == 16) { if (rt == 1) RD_HALO(1, 1); else RD_HALO(1, 2); }
+  else if (Cin == 32) { if (rt == 1) RD_HALO(2, 1); else RD_HALO(2, 2); }
+  else { if (rt == 1) RD_HALO(4, 1); else RD_HALO(4, 2); }
+#undef RD_HALO
+}
+
 void launch_wgrad(WgradArgs a, int dtype, float* dw, int accumulate, hipStream_t st) {
   const int Cin = a.C1 + a.C2;
+  if (wgrad_halo_ok(a)) {
+    int TH, TW;
+    halo_geom(Cin, a.Cout, TH, TW);
+    int64_t ntiles = (int64_t)a.N * cdiv(a.OH, TH) * cdiv(a.OW, TW);
+    int nblk = (int)std::min<int64_t>(ntiles, HALO_BLOCKS);
+    if (dtype == 0) launch_wgrad_halo_t<float>(a, nblk, st);
+    else launch_wgrad_halo_t<bf16_t>(a, nblk, st);
+    launch_wgrad_reduce(a.slab, dw, a.Cout, Cin, a.KH, a.KW, nblk, accumulate, st);
+    return;
+  }
   a.nsplit = wgrad_nsplit(a.M, a.K, a.Cout);
   a.rows_per_split = (int)(cdiv(cdiv(a.M, a.nsplit), 32) * 32);
   a.nsplit = (int)cdiv(a.M, a.rows_per_split);
   bool vec = (Cin % 4 == 0) && (a.C1 % 4 == 0);
   if (dtype == 0) launch_wgrad_t<float>(a, vec, st);
   else launch_wgrad_t<bf16_t>(a, vec, st);
-  int64_t total = (int64_t)a.Cout * a.K;
-  unsigned rg = (unsigned)std::min<int64_t>(cdiv(total, 256), 2048);
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rg), dim3(256), 0, st, a.slab, dw, a.Cout, Cin, a.KH, a.KW, a.nsplit, accumulate);
+  launch_wgrad_reduce(a.slab, dw, a.Cout, Cin, a.KH, a.KW, a.nsplit, accumulate, st);
 }
 
 }  // namespace rd

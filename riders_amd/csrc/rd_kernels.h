@@ -26,6 +26,7 @@ int conv_rows_pad(int rows);
 int conv_kpad(int K, int dtype);
 int conv_block_pixels(int M, int Cout);
 int wgrad_nsplit(int M, int K, int Cout);
+int wgrad_slabs(int M, int K, int Cout);
 void launch_conv(const ConvArgs& a, int dtype, hipStream_t st);
 void launch_pack_weights(const float* w, void* out, int Cout, int Cin, int KH, int KW, int mode, int dtype, hipStream_t st);
 void launch_wgrad(WgradArgs a, int dtype, float* dw, int accumulate, hipStream_t st);
