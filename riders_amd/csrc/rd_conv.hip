@@ -438,6 +438,131 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
 }
 
 
+// ---- bf16 weight gradient on the bf16 MFMA (16x16x32): both operands need 8 CONSECUTIVE PIXELS per lane, i.e. the pixel-major
+// NHWC tiles transposed.  The transpose happens on the way into LDS: a thread loads the same 8 channels of two neighbouring pixels
+// (two 16-byte loads), packs the pairs and writes eight 32-bit words into channel-major rows [col][64 pixels]; fragments are then
+// single ds_read_b128 (16-byte slots XOR-swizzled as in the forward kernel).  64 pixels per stage = two MFMA k-steps. ------------
+template <int COT>
+__global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(WgradArgs a) {
+  typedef bf16_t T;
+  constexpr int PK = 64;
+  constexpr int WROWS = COT == 128 ? 2 : 1, WCOLS = 4 / WROWS;
+  constexpr int TI = COT / (16 * WROWS), TJ = 128 / (16 * WCOLS);
+  constexpr int YG = COT / 8;                          // 8-channel groups of the dY tile
+  constexpr int YIT = (YG * 32 + 255) / 256;           // (group, pixel pair) items per thread
+  __shared__ uint4 sX[2][128 * 8];                     // [k col][64 px] bf16 = 8 slots of 16 B per row
+  __shared__ uint4 sY[2][COT * 8];
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  const int kt0 = blockIdx.x * 128, c0 = blockIdx.y * COT;
+  const int Cin = a.C1 + a.C2;
+  const int mbeg = blockIdx.z * a.rows_per_split;
+  const int mend = min(a.M, mbeg + a.rows_per_split);
+  ConvArgs g;
+  g.src1 = a.src1; g.src2 = a.src2; g.Hin = a.Hin; g.Win = a.Win; g.C1 = a.C1; g.C2 = a.C2; g.H1 = a.H1; g.W1 = a.W1;
+  g.dil = 1; g.ups = a.ups; g.scale_h = a.scale_h; g.scale_w = a.scale_w;
+
+  // X role: pixel pair pp = t % 16 (+16 for the second item), 8-column group cg = t / 16 (fixed k columns for the whole loop)
+  const int xpp = t & 15, xcg = t >> 4;
+  const int kx = kt0 + xcg * 8;
+  const bool xv = kx < a.K;
+  int xkh, xkw, xci;
+  { int kk = xv ? kx : 0; int tap = kk / Cin; xci = kk - tap * Cin; xkh = tap / a.KW; xkw = tap - xkh * a.KW; }
+
+  uint4 rx[2][2], ry[YIT][2];
+  auto load_px = [&](int m, uint4& v) {
+    v = make_uint4(0, 0, 0, 0);
+    if (xv && m < mend) {
+      int ow = m % a.OW; int q = m / a.OW; int oh = q % a.OH; int n = q / a.OH;
+      const T* p;
+      if (conv_src_ptr<T>(g, n, oh * a.stride - a.pad + xkh, ow * a.stride - a.pad + xkw, xci, p)) v = *reinterpret_cast<const uint4*>(p);
+    }
+  };
+  auto load_stage = [&](int mb) {
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      int m = mb + (xpp + 16 * i) * 2;
+      load_px(m, rx[i][0]);
+      load_px(m + 1, rx[i][1]);
+    }
+#pragma unroll
+    for (int i = 0; i < YIT; i++) {
+      int idx = t + 256 * i;
+      int pp = idx & 31, yg = idx >> 5;
+      int co = c0 + yg * 8;
+#pragma unroll
+      for (int h = 0; h < 2; h++) {
+        int m = mb + pp * 2 + h;
+        ry[i][h] = make_uint4(0, 0, 0, 0);
+        if (yg < YG && m < mend && co < a.Cout) ry[i][h] = *reinterpret_cast<const uint4*>((const T*)a.dy + (int64_t)m * a.Cout + co);
+      }
+    }
+  };
+  // word w (two bf16: pixel 2pp in the low half, 2pp+1 in the high half) of channel e of a pixel-pair
+  auto put = [&](uint4* tile, int row0, int pp, const uint4& lo, const uint4& hi) {
+    const unsigned l[4] = {lo.x, lo.y, lo.z, lo.w}, h[4] = {hi.x, hi.y, hi.z, hi.w};
+    unsigned* words = reinterpret_cast<unsigned*>(tile);
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+      unsigned a16 = (e & 1) ? (l[e >> 1] >> 16) : (l[e >> 1] & 0xffffu);
+      unsigned b16 = (e & 1) ? (h[e >> 1] & 0xffff0000u) : (h[e >> 1] << 16);
+      int row = row0 + e;
+      words[lds_slot(row, pp >> 2) * 4 + (pp & 3)] = a16 | b16;
+    }
+  };
+  auto store_stage = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 2; i++) put(sX[buf], xcg * 8, xpp + 16 * i, rx[i][0], rx[i][1]);
+#pragma unroll
+    for (int i = 0; i < YIT; i++) {
+      int idx = t + 256 * i;
+      int pp = idx & 31, yg = idx >> 5;
+      if (yg < YG) put(sY[buf], yg * 8, pp, ry[i][0], ry[i][1]);
+    }
+  };
+
+  const int wr = (wv / WCOLS) * TI * 16, wc = (wv % WCOLS) * TJ * 16;
+  f32x4 acc[TI][TJ];
+#pragma unroll
+  for (int i = 0; i < TI; i++)
+#pragma unroll
+    for (int j = 0; j < TJ; j++) acc[i][j] = f32x4{0, 0, 0, 0};
+  const int fr = lane & 15, fg = lane >> 4;
+
+  int nst = (mend > mbeg) ? (mend - mbeg + PK - 1) / PK : 0;
+  if (nst > 0) { load_stage(mbeg); store_stage(0); }
+  __syncthreads();
+  for (int st = 0; st < nst; st++) {
+    int buf = st & 1;
+    if (st + 1 < nst) load_stage(mbeg + (st + 1) * PK);
+#pragma unroll
+    for (int ks = 0; ks < 2; ks++) {  // 32 pixels per MFMA k-step: lane group fg supplies pixels ks*32 + fg*8 .. +7 (one 16-byte slot)
+      s16x8 ya[TI], xb[TJ];
+#pragma unroll
+      for (int i = 0; i < TI; i++) { uint4 v = sY[buf][lds_slot(wr + i * 16 + fr, ks * 4 + fg)]; __builtin_memcpy(&ya[i], &v, 16); }
+#pragma unroll
+      for (int j = 0; j < TJ; j++) { uint4 v = sX[buf][lds_slot(wc + j * 16 + fr, ks * 4 + fg)]; __builtin_memcpy(&xb[j], &v, 16); }
+#pragma unroll
+      for (int i = 0; i < TI; i++)
+#pragma unroll
+        for (int j = 0; j < TJ; j++) acc[i][j] = mfma_16x16x32_bf16(ya[i], xb[j], acc[i][j]);
+    }
+    if (st + 1 < nst) store_stage(buf ^ 1);
+    __syncthreads();
+  }
+  float* slab = a.slab + (int64_t)blockIdx.z * a.Cout * a.K;
+#pragma unroll
+  for (int i = 0; i < TI; i++)
+#pragma unroll
+    for (int j = 0; j < TJ; j++) {
+      int k = kt0 + wc + j * 16 + fr;
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        int co = c0 + wr + i * 16 + fg * 4 + r;
+        if (co < a.Cout && k < a.K) slab[(int64_t)co * a.K + k] = acc[i][j][r];
+      }
+    }
+}
+
 // ---- halo-tile weight gradient for 3x3 / stride-1 layers with few channels (decoder tail: Cin <= 64, Cout <= 32) -----------
 // The generic wgrad re-gathers every input pixel once per tap (9x through L1/L2), which bounds these layers far below both the
 // MFMA and the HBM roofline.  Here a block stages an (TH+2) x (TW+2) x Cin input patch (upsample / concat folded in) and the
@@ -756,6 +881,19 @@ void launch_wgrad(WgradArgs a, int dtype, float* dw, int accumulate, hipStream_t
   a.rows_per_split = (int)(cdiv(cdiv(a.M, a.nsplit), 32) * 32);
   a.nsplit = (int)cdiv(a.M, a.rows_per_split);
   bool vec = (Cin % 4 == 0) && (a.C1 % 4 == 0);
+  if (dtype == 1 && (Cin % 8 == 0) && (a.C1 % 8 == 0) && (a.Cout % 8 == 0)) {
+    // bf16 MFMA path: 64-pixel stages
+    a.rows_per_split = (int)(cdiv(cdiv(a.M, wgrad_nsplit(a.M, a.K, a.Cout)), 64) * 64);
+    a.nsplit = (int)cdiv(a.M, a.rows_per_split);
+    int cot = pick_bn(a.Cout);
+    dim3 grid((unsigned)cdiv(a.K, 128), (unsigned)cdiv(a.Cout, cot), (unsigned)a.nsplit);
+    if (cot == 16) hipLaunchKernelGGL((conv_wgrad_bf16_kernel<16>), grid, dim3(256), 0, st, a);
+    else if (cot == 32) hipLaunchKernelGGL((conv_wgrad_bf16_kernel<32>), grid, dim3(256), 0, st, a);
+    else if (cot == 64) hipLaunchKernelGGL((conv_wgrad_bf16_kernel<64>), grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((conv_wgrad_bf16_kernel<128>), grid, dim3(256), 0, st, a);
+    launch_wgrad_reduce(a.slab, dw, a.Cout, Cin, a.KH, a.KW, a.nsplit, accumulate, st);
+    return;
+  }
   if (dtype == 0) launch_wgrad_t<float>(a, vec, st);
   else launch_wgrad_t<bf16_t>(a, vec, st);
   launch_wgrad_reduce(a.slab, dw, a.Cout, Cin, a.KH, a.KW, a.nsplit, accumulate, st);
