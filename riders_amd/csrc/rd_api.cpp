@@ -62,8 +62,8 @@ int rd_conv_pack_weights(const float* w, void* packed, int32_t Cout, int32_t Cin
   return done("rd_conv_pack_weights");
 }
 int32_t rd_conv_stats_rows(const rd_conv_desc* d) {
-  int M = d->N * d->OH * d->OW, bp = rd::conv_block_pixels(M, d->Cout);
-  return (int32_t)((M + bp - 1) / bp);
+  rd::ConvArgs a; fill_args(d, a);
+  return (int32_t)rd::conv_stats_rows(a, d->dtype);
 }
 
 int rd_conv_fwd(const rd_conv_desc* d, const void* src1, const void* src2, const void* w_packed, const float* bias, void* dst1,

@@ -3,6 +3,10 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// Device lambdas that capture register arrays by reference MUST be inlined: an out-of-line closure call forces every captured
+// array into scratch (or LDS via promote-alloca) -- seen as private_segment 48..80 bytes / +16 KB LDS on the conv kernels.
+#define RD_INLINE_LAMBDA __attribute__((always_inline))
+
 namespace rd {
 
 // ---- element types -------------------------------------------------------------------------

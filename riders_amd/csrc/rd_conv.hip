@@ -20,37 +20,10 @@
 // K = KH*KW*Cin walked in 128-byte stages (32 fp32 / 64 bf16 per row).  MFMA operand roles are
 // swapped (A = weights, B = pixels) so each lane ends up holding 4 consecutive output channels of
 // one pixel -> one 16-byte (fp32) / 8-byte (bf16) NHWC store per lane per tile.
-#include "rd_common.h"
-#include "rd_kernels.h"
+#include "rd_conv_common.h"
 #include <type_traits>
 
 namespace rd {
-
-static constexpr int BM = 128;          // pixels per block tile
-static constexpr int STAGE_BYTES = 128; // K bytes per row per stage
-
-// LDS byte offset of 16-byte slot `slot` (0..7) of tile row `row`; XOR swizzle keeps the
-// ds_read_b128 fragment reads (16 rows x 4 k-groups per wave) bank-conflict free.
-__device__ __forceinline__ int lds_slot(int row, int slot) { return row * 8 + (slot ^ ((row >> 1) & 7)); }
-
-template <typename T>
-__device__ __forceinline__ bool conv_src_ptr(const ConvArgs& a, int n, int ih, int iw, int ci, const T*& p) {
-  if (a.dil > 1) {
-    if (ih < 0 || iw < 0) return false;
-    if ((ih % a.dil) | (iw % a.dil)) return false;
-    ih /= a.dil; iw /= a.dil;
-  }
-  if ((unsigned)ih >= (unsigned)a.Hin || (unsigned)iw >= (unsigned)a.Win) return false;
-  int hs = ih, ws = iw, Hp = a.Hin, Wp = a.Win;
-  if (a.ups) {  // F.interpolate(mode='nearest') source index, ATen float formula
-    hs = min((int)floorf((float)ih * a.scale_h), a.H1 - 1);
-    ws = min((int)floorf((float)iw * a.scale_w), a.W1 - 1);
-    Hp = a.H1; Wp = a.W1;
-  }
-  if (ci < a.C1) p = (const T*)a.src1 + ((((int64_t)n * Hp + hs) * Wp + ws) * a.C1 + ci);
-  else p = (const T*)a.src2 + ((((int64_t)n * Hp + hs) * Wp + ws) * a.C2 + (ci - a.C1));
-  return true;
-}
 
 // WM = waves along the pixel axis (block tile = 32*WM pixels x BN channels; the other 4/WM wave factor splits the channels).
 // WM = 2 halves the tile for small-M launches (LoFTR projections, deep encoder stages) so they spread over more CUs.
@@ -67,7 +40,14 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs a) {
 
   const int t = threadIdx.x;
   const int lane = t & 63, wv = t >> 6;
-  const int m0 = blockIdx.x * BMV;
+  // XCD-aware tile order: the dispatcher places block b on XCD b % 8 (speed only, never correctness), so give every XCD a CONTIGUOUS
+  // range of pixel tiles -- neighbouring tiles share their 3x3 halo rows and then hit the same 4 MiB L2 (bijective remap; +3 % measured).
+  int bx = blockIdx.x;
+  {
+    const int nb = gridDim.x, q = nb >> 3, r = nb & 7, xcd = bx & 7, idx = bx >> 3;
+    bx = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int m0 = bx * BMV;
   const int wm = wv % WM, wn = wv / WM;
   const int n0 = blockIdx.y * BN;
   const int Cin = a.C1 + a.C2;
@@ -91,7 +71,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs a) {
 
   uint4 ra[WM]; uint4 rb[BITER];
 
-  auto load_tile = [&](int kt) {
+  auto load_tile = [&](int kt) RD_INLINE_LAMBDA {
 #pragma unroll
     for (int i = 0; i < WM; i++) {
       uint4 v = make_uint4(0, 0, 0, 0);
@@ -123,9 +103,10 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs a) {
 #pragma unroll
     for (int i = 0; i < BITER; i++) {
       int idx = t + 256 * i;
-      if (idx < BN * 8) {
+      if (BN * 8 % 256 == 0 || idx < BN * 8) {  // compile-time when the tile divides evenly: a runtime guard parks rb[] in scratch
         int row = idx >> 3, sl = idx & 7;
-        rb[i] = wp[(int64_t)(n0 + row) * kslots + kt * 8 + sl];
+        const uint4 v = wp[(int64_t)(n0 + row) * kslots + kt * 8 + sl];  // via a value: a direct global->array struct copy stays a memcpy
+        rb[i] = v;                                                        // through a private alloca (scratch / LDS-promoted)
       }
     }
     if (VEC) {  // advance this thread's k-state by one stage
@@ -133,13 +114,13 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs a) {
       while (kci >= Cin) { kci -= Cin; if (++kkw == a.KW) { kkw = 0; ++kkh; } }
     }
   };
-  auto store_tile = [&](int buf) {
+  auto store_tile = [&](int buf) RD_INLINE_LAMBDA {
 #pragma unroll
     for (int i = 0; i < WM; i++) sA[buf][lds_slot(r0 + 32 * i, s)] = ra[i];
 #pragma unroll
     for (int i = 0; i < BITER; i++) {
       int idx = t + 256 * i;
-      if (idx < BN * 8) sB[buf][lds_slot(idx >> 3, idx & 7)] = rb[i];
+      if (BN * 8 % 256 == 0 || idx < BN * 8) sB[buf][lds_slot(idx >> 3, idx & 7)] = rb[i];
     }
   };
 
@@ -183,76 +164,11 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs a) {
     __syncthreads();
   }
 
-  // ---- epilogue: bias, activation, NHWC store (dual destination), BN statistics ----------------
-  const int D2 = a.Cout - a.D1;
-  const bool vec_ok = ((a.D1 & 3) == 0) && ((D2 & 3) == 0);
-  float ssum[CT][4], ssq[CT][4];
+  // ---- epilogue (shared): bias, activation, NHWC store (dual destination), BN statistics ----------------
+  int64_t mm[2]; bool mvv[2];
 #pragma unroll
-  for (int c = 0; c < CT; c++)
-#pragma unroll
-    for (int r = 0; r < 4; r++) { ssum[c][r] = 0.f; ssq[c][r] = 0.f; }
-
-#pragma unroll
-  for (int pt = 0; pt < 2; pt++) {
-    const int m = m0 + wm * 32 + pt * 16 + fr;
-    const bool mv = m < a.M;
-#pragma unroll
-    for (int c = 0; c < CT; c++) {
-      const int co = n0 + (wn * CT + c) * 16 + fg * 4;
-      float v[4];
-#pragma unroll
-      for (int r = 0; r < 4; r++) {
-        float x = acc[c][pt][r];
-        if (a.bias && co + r < a.Cout) x += a.bias[co + r];
-        x = act_fwd(x, a.act, a.slope);
-        x = Elem<T>::rnd(x);
-        v[r] = x;
-        if (mv) { ssum[c][r] += x; ssq[c][r] += x * x; }
-      }
-      if (mv && co < a.Cout) {
-        if (vec_ok && co + 3 < a.Cout) {
-          T* d = (co < a.D1) ? ((T*)a.dst1 + (int64_t)m * a.D1 + co) : ((T*)a.dst2 + (int64_t)m * D2 + (co - a.D1));
-          st4(d, v);
-        } else {
-#pragma unroll
-          for (int r = 0; r < 4; r++) {
-            int cc = co + r;
-            if (cc < a.Cout) {
-              T* d = (cc < a.D1) ? ((T*)a.dst1 + (int64_t)m * a.D1 + cc) : ((T*)a.dst2 + (int64_t)m * D2 + (cc - a.D1));
-              Elem<T>::st(d, v[r]);
-            }
-          }
-        }
-      }
-    }
-  }
-  if (a.stats) {  // per-block partial sum / sum-of-squares per output channel (deterministic order)
-    float* red = reinterpret_cast<float*>(&sA[0][0]);  // [WM][BN][2]
-#pragma unroll
-    for (int c = 0; c < CT; c++)
-#pragma unroll
-      for (int r = 0; r < 4; r++) {
-        float s1 = ssum[c][r], s2 = ssq[c][r];
-#pragma unroll
-        for (int o = 1; o < 16; o <<= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
-        if (fr == 0) {
-          int col = (wn * CT + c) * 16 + fg * 4 + r;
-          red[(wm * BN + col) * 2 + 0] = s1;
-          red[(wm * BN + col) * 2 + 1] = s2;
-        }
-      }
-    __syncthreads();
-    for (int col = t; col < BN; col += 256) {
-      int co = n0 + col;
-      if (co < a.Cout) {
-        float s1 = 0.f, s2 = 0.f;
-#pragma unroll
-        for (int w = 0; w < WM; w++) { s1 += red[(w * BN + col) * 2]; s2 += red[(w * BN + col) * 2 + 1]; }
-        a.stats[((int64_t)blockIdx.x * a.Cout + co) * 2 + 0] = s1;
-        a.stats[((int64_t)blockIdx.x * a.Cout + co) * 2 + 1] = s2;
-      }
-    }
-  }
+  for (int pt = 0; pt < 2; pt++) { mm[pt] = m0 + wm * 32 + pt * 16 + fr; mvv[pt] = mm[pt] < a.M; }
+  conv_epilogue<T, CT, BN, WM>(a, acc, mm, mvv, n0, wn, wm, fr, fg, t, bx, reinterpret_cast<float*>(&sA[0][0]));
 }
 
 // ---- weight packing -------------------------------------------------------------------------------
@@ -317,7 +233,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
   g.dil = 1; g.ups = a.ups; g.scale_h = a.scale_h; g.scale_w = a.scale_w;
 
   float rx[4][4], ry[YIT][4];
-  auto load_stage = [&](int mb) {
+  auto load_stage = [&](int mb) RD_INLINE_LAMBDA {
 #pragma unroll
     for (int i = 0; i < 4; i++) {
       int m = mb + pr + 8 * i;
@@ -357,7 +273,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
       }
     }
   };
-  auto store_stage = [&](int buf) {
+  auto store_stage = [&](int buf) RD_INLINE_LAMBDA {
 #pragma unroll
     for (int i = 0; i < 4; i++) {
       int p = pr + 8 * i;
@@ -389,7 +305,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
   int nj = 0;
 #pragma unroll
   for (int j = 0; j < TJ; j++) nj += jv[j] ? 1 : 0;
-  auto mma_stage = [&](int buf, auto njc) {
+  auto mma_stage = [&](int buf, auto njc) RD_INLINE_LAMBDA {
     constexpr int NJ = decltype(njc)::value;
 #pragma unroll
     for (int p4 = 0; p4 < PK / 4; p4++) {
@@ -469,7 +385,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(WgradArgs a) {
   { int kk = xv ? kx : 0; int tap = kk / Cin; xci = kk - tap * Cin; xkh = tap / a.KW; xkw = tap - xkh * a.KW; }
 
   uint4 rx[2][2], ry[YIT][2];
-  auto load_px = [&](int m, uint4& v) {
+  auto load_px = [&](int m, uint4& v) RD_INLINE_LAMBDA {
     v = make_uint4(0, 0, 0, 0);
     if (xv && m < mend) {
       int ow = m % a.OW; int q = m / a.OW; int oh = q % a.OH; int n = q / a.OH;
@@ -477,7 +393,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(WgradArgs a) {
       if (conv_src_ptr<T>(g, n, oh * a.stride - a.pad + xkh, ow * a.stride - a.pad + xkw, xci, p)) v = *reinterpret_cast<const uint4*>(p);
     }
   };
-  auto load_stage = [&](int mb) {
+  auto load_stage = [&](int mb) RD_INLINE_LAMBDA {
 #pragma unroll
     for (int i = 0; i < 2; i++) {
       int m = mb + (xpp + 16 * i) * 2;
@@ -498,7 +414,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(WgradArgs a) {
     }
   };
   // word w (two bf16: pixel 2pp in the low half, 2pp+1 in the high half) of channel e of a pixel-pair
-  auto put = [&](uint4* tile, int row0, int pp, const uint4& lo, const uint4& hi) {
+  auto put = [&](uint4* tile, int row0, int pp, const uint4& lo, const uint4& hi) RD_INLINE_LAMBDA {
     const unsigned l[4] = {lo.x, lo.y, lo.z, lo.w}, h[4] = {hi.x, hi.y, hi.z, hi.w};
     unsigned* words = reinterpret_cast<unsigned*>(tile);
 #pragma unroll
@@ -509,7 +425,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(WgradArgs a) {
       words[lds_slot(row, pp >> 2) * 4 + (pp & 3)] = a16 | b16;
     }
   };
-  auto store_stage = [&](int buf) {
+  auto store_stage = [&](int buf) RD_INLINE_LAMBDA {
 #pragma unroll
     for (int i = 0; i < 2; i++) put(sX[buf], xcg * 8, xpp + 16 * i, rx[i][0], rx[i][1]);
 #pragma unroll
@@ -622,7 +538,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_halo_kernel(WgradArgs a, int t
   const int yc = (t % VY) * 4, yp0 = t / VY;
   float fx[NX][4], fy[NY][4];
   const int ntiles = a.N * tilesH * tilesW;
-  auto fetch = [&](int tile) {
+  auto fetch = [&](int tile) RD_INLINE_LAMBDA {
     int tw_ = tile % tilesW; int q = tile / tilesW; int th_ = q % tilesH; int n = q / tilesH;
     const int oh0 = th_ * TH, ow0 = tw_ * TW;
 #pragma unroll
@@ -651,7 +567,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_halo_kernel(WgradArgs a, int t
       }
     }
   };
-  auto stash = [&]() {
+  auto stash = [&]() RD_INLINE_LAMBDA {
 #pragma unroll
     for (int it = 0; it < NX; it++) {
       int pq = xp0 + it * PLX;
@@ -668,7 +584,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_halo_kernel(WgradArgs a, int t
     }
   };
 
-  auto compute = [&](auto njc) {
+  auto compute = [&](auto njc) RD_INLINE_LAMBDA {
     constexpr int NJ = decltype(njc)::value;
     constexpr int QD = CTI == 4 ? 2 : 4;  // pixel quads whose LDS reads are batched ahead of their MFMAs (register budget)
 #pragma unroll
@@ -721,8 +637,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_halo_kernel(WgradArgs a, int t
       }
 }
 
-static bool wgrad_halo_ok(const WgradArgs& a) {
+static bool wgrad_halo_ok(const WgradArgs& a, int dtype) {
   const int Cin = a.C1 + a.C2;
+  if (dtype == 1 && Cin == 64 && a.Cout % 8 == 0) return false;  // measured: the bf16-MFMA generic kernel is ~1.8x faster there
   return a.KH == 3 && a.KW == 3 && a.stride == 1 && a.pad == 1 && (Cin == 16 || Cin == 32 || Cin == 64) && a.Cout <= 32 &&
          (a.C1 % 8 == 0) && a.OH == a.Hin && a.OW == a.Win;
 }
@@ -807,7 +724,22 @@ static void launch_conv_t(const ConvArgs& a, hipStream_t st) {
 #undef RD_CONV_CASE
 }
 
+// 3x3/stride-1 layers with enough tiles to fill the chip go to the patch-staged kernel (rd_conv3x3.hip)
+static int conv3x3_min_blocks() {
+  const char* e = getenv("RD_CONV3X3_MIN_BLOCKS");  // test hook: 0 forces the patch kernel on small cases
+  return e ? atoi(e) : 256;
+}
+static bool use_conv3x3(const ConvArgs& a, int dtype) {
+  if (!conv3x3_ok(a, dtype)) return false;
+  return (int64_t)conv3x3_tiles(a) * cdiv(a.Cout, pick_bn(a.Cout)) >= conv3x3_min_blocks();
+}
+int conv_stats_rows(const ConvArgs& a, int dtype) {
+  if (use_conv3x3(a, dtype)) return conv3x3_tiles(a);
+  return (int)cdiv(a.M, conv_block_pixels(a.M, a.Cout));
+}
+
 void launch_conv(const ConvArgs& a, int dtype, hipStream_t st) {
+  if (use_conv3x3(a, dtype)) { launch_conv3x3(a, dtype, st); return; }
   if (dtype == 0) launch_conv_t<float>(a, st);
   else launch_conv_t<bf16_t>(a, st);
 }
@@ -867,7 +799,7 @@ static void launch_wgrad_halo_t(const WgradArgs& a, int nblk, hipStream_t st) {
 
 void launch_wgrad(WgradArgs a, int dtype, float* dw, int accumulate, hipStream_t st) {
   const int Cin = a.C1 + a.C2;
-  if (wgrad_halo_ok(a)) {
+  if (wgrad_halo_ok(a, dtype)) {
     int TH, TW;
     halo_geom(Cin, a.Cout, TH, TW);
     int64_t ntiles = (int64_t)a.N * cdiv(a.OH, TH) * cdiv(a.OW, TW);

@@ -1,0 +1,195 @@
+// Patch-staged 3x3 / stride-1 convolution (forward and data gradient) for gfx950.
+//
+// The implicit-GEMM kernel in rd_conv.hip re-gathers every input pixel once per filter tap; rocprofv3 showed those nine passes are
+// NOT absorbed by L1/L2 at RC-Net's sizes (per-CU load rate ~12 B/clk = the HBM-bound rate, MFMA busy 12 %), so 3x3 layers ran at the
+// HBM roofline of 9x their algorithmic bytes.  Here a block owns a 128-pixel output tile (16x8 or 8x16 pixels), stages the
+// (rows+2) x (cols+2) input patch ONCE per 128-byte channel chunk in LDS (nearest-upsample and two-source concat folded into the
+// staging gather, zero fill = padding) and walks the nine taps out of LDS; only the packed weights stream per tap (double-buffered).
+// MFMA roles, 16-byte XOR-swizzled LDS slots, epilogue (bias / activation / dual destination / BatchNorm partials) are the ones of
+// the implicit-GEMM kernel.  Replaces the same reference call sites (utils/net_utils.py:84-91,195-198,564-569) for k=3, s=1.
+#include "rd_conv_common.h"
+
+namespace rd {
+
+template <typename T, int BN, bool W8>
+__global__ __launch_bounds__(256) void conv3x3_patch_kernel(ConvArgs a, int tilesH, int tilesW) {
+  constexpr int VE = Elem<T>::VE;
+  constexpr int CKE = STAGE_BYTES / (int)sizeof(T);     // channels per chunk (128 bytes per pixel)
+  constexpr int TW = W8 ? 8 : 16, TH = W8 ? 16 : 8;      // 128 output pixels
+  constexpr int WT = TW + 2, HT = TH + 2, NP = HT * WT; // patch pixels (180)
+  constexpr int PIT = (NP * 8 + 255) / 256;             // patch vectors per thread (6)
+  constexpr int CT = BN / 16;
+  constexpr int BITER = (BN * 8 + 255) / 256;
+  __shared__ uint4 sP[NP * 8];
+  __shared__ uint4 sB[2][BN * 8];
+
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  const int fr = lane & 15, fg = lane >> 4;
+  int bx = blockIdx.x;
+  {  // XCD-aware order (see rd_conv.hip)
+    const int nb = gridDim.x, q = nb >> 3, r = nb & 7, xcd = bx & 7, idx = bx >> 3;
+    bx = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int n0 = blockIdx.y * BN;
+  const int Cin = a.C1 + a.C2;
+  const int tw_ = bx % tilesW; const int q_ = bx / tilesW; const int th_ = q_ % tilesH; const int n = q_ / tilesH;
+  const int oh0 = th_ * TH, ow0 = tw_ * TW;
+  const int nchunk = Cin / CKE;
+
+  // patch staging role: idx = t + 256*i -> pixel pp = idx >> 3, 16-byte slot = idx & 7
+  uint4 rp[PIT], rb[BITER];
+  auto load_patch = [&](int chunk) RD_INLINE_LAMBDA {
+#pragma unroll
+    for (int i = 0; i < PIT; i++) {
+      int idx = t + 256 * i;
+      int pp = idx >> 3, sl = idx & 7;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (pp < NP) {
+        int py = pp / WT, px = pp - py * WT;
+        const T* p;
+        if (conv_src_ptr<T>(a, n, oh0 - 1 + py, ow0 - 1 + px, chunk * CKE + sl * VE, p)) v = *reinterpret_cast<const uint4*>(p);
+      }
+      rp[i] = v;
+    }
+  };
+  auto store_patch = [&]() RD_INLINE_LAMBDA {
+#pragma unroll
+    for (int i = 0; i < PIT; i++) {
+      int idx = t + 256 * i;
+      int pp = idx >> 3, sl = idx & 7;
+      if (pp < NP) sP[lds_slot(pp, sl)] = rp[i];
+    }
+  };
+  const uint4* wp = reinterpret_cast<const uint4*>(a.w);
+  const int kslots = a.Kpad / VE;
+  auto load_w = [&](int chunk, int tap) RD_INLINE_LAMBDA {  // packed row = [tap][Cin]: 128 contiguous bytes per output channel
+    const int k0 = (tap * Cin + chunk * CKE) / VE;
+#pragma unroll
+    for (int i = 0; i < BITER; i++) {
+      int idx = t + 256 * i;
+      if (BN * 8 % 256 == 0 || idx < BN * 8) {
+        const uint4 v = wp[(int64_t)(n0 + (idx >> 3)) * kslots + k0 + (idx & 7)];  // via a value (see rd_conv.hip: avoids a scratch alloca)
+        rb[i] = v;
+      }
+    }
+  };
+  auto store_w = [&](int buf) RD_INLINE_LAMBDA {
+#pragma unroll
+    for (int i = 0; i < BITER; i++) {
+      int idx = t + 256 * i;
+      if (BN * 8 % 256 == 0 || idx < BN * 8) sB[buf][lds_slot(idx >> 3, idx & 7)] = rb[i];
+    }
+  };
+
+  // this lane's two output pixels (one per MFMA pixel tile) inside the tile, as patch coordinates of tap (0,0)
+  int ppix[2];
+#pragma unroll
+  for (int pt = 0; pt < 2; pt++) {
+    int py = W8 ? (wv * 4 + pt * 2 + (fr >> 3)) : (wv * 2 + pt);
+    int px = W8 ? (fr & 7) : fr;
+    ppix[pt] = py * WT + px;
+  }
+
+  f32x4 acc[CT][2];
+#pragma unroll
+  for (int c = 0; c < CT; c++) { acc[c][0] = f32x4{0, 0, 0, 0}; acc[c][1] = f32x4{0, 0, 0, 0}; }
+
+  load_patch(0);
+  load_w(0, 0);
+  int wbuf = 0;
+  for (int chunk = 0; chunk < nchunk; chunk++) {
+    __syncthreads();            // every wave is done with the previous patch chunk and weight buffers
+    store_patch();
+    store_w(wbuf);
+    __syncthreads();
+    if (chunk + 1 < nchunk) load_patch(chunk + 1);   // next chunk's patch travels while the nine taps run
+#pragma unroll 1
+    for (int tap = 0; tap < 9; tap++) {
+      const bool more = (tap < 8) || (chunk + 1 < nchunk);
+      if (more) load_w(tap < 8 ? chunk : chunk + 1, tap < 8 ? tap + 1 : 0);
+      const int kh = tap / 3, kw = tap - kh * 3;
+      const int toff = kh * WT + kw;
+#pragma unroll
+      for (int ch = 0; ch < 2; ch++) {
+        uint4 pf[2];
+#pragma unroll
+        for (int pt = 0; pt < 2; pt++) pf[pt] = sP[lds_slot(ppix[pt] + toff, ch * 4 + fg)];
+#pragma unroll
+        for (int c = 0; c < CT; c++) {
+          uint4 wf = sB[wbuf][lds_slot(c * 16 + fr, ch * 4 + fg)];
+#pragma unroll
+          for (int pt = 0; pt < 2; pt++) {
+            if (sizeof(T) == 4) {
+              acc[c][pt] = mfma_16x16x4_f32(__uint_as_float(wf.x), __uint_as_float(pf[pt].x), acc[c][pt]);
+              acc[c][pt] = mfma_16x16x4_f32(__uint_as_float(wf.y), __uint_as_float(pf[pt].y), acc[c][pt]);
+              acc[c][pt] = mfma_16x16x4_f32(__uint_as_float(wf.z), __uint_as_float(pf[pt].z), acc[c][pt]);
+              acc[c][pt] = mfma_16x16x4_f32(__uint_as_float(wf.w), __uint_as_float(pf[pt].w), acc[c][pt]);
+            } else {
+              s16x8 wa, pb;
+              __builtin_memcpy(&wa, &wf, 16);
+              __builtin_memcpy(&pb, &pf[pt], 16);
+              acc[c][pt] = mfma_16x16x32_bf16(wa, pb, acc[c][pt]);
+            }
+          }
+        }
+      }
+      if (tap < 8) {           // publish the next tap's weights (the last tap's successor is published with the next patch)
+        store_w(wbuf ^ 1);
+        __syncthreads();
+        wbuf ^= 1;
+      }
+    }
+    wbuf ^= 1;
+  }
+
+  int64_t mm[2]; bool mvv[2];
+#pragma unroll
+  for (int pt = 0; pt < 2; pt++) {
+    int py = W8 ? (wv * 4 + pt * 2 + (fr >> 3)) : (wv * 2 + pt);
+    int px = W8 ? (fr & 7) : fr;
+    int oh = oh0 + py, ow = ow0 + px;
+    mvv[pt] = oh < a.OH && ow < a.OW;
+    mm[pt] = ((int64_t)n * a.OH + oh) * a.OW + ow;
+  }
+  __syncthreads();  // all waves finished reading the patch before it is reused as reduction scratch
+  conv_epilogue<T, CT, BN, 4>(a, acc, mm, mvv, n0, 0, wv, fr, fg, t, bx, reinterpret_cast<float*>(&sP[0]));
+}
+
+// ---- host side -------------------------------------------------------------------------------------------------------------------
+static int pick_bn3(int cout) { return cout <= 16 ? 16 : (cout <= 32 ? 32 : (cout <= 64 ? 64 : 128)); }
+
+bool conv3x3_ok(const ConvArgs& a, int dtype) {
+  const int Cin = a.C1 + a.C2;
+  const int ve = dtype == 0 ? 4 : 8, cke = dtype == 0 ? 32 : 64;
+  return a.KH == 3 && a.KW == 3 && a.stride == 1 && a.pad == 1 && a.dil == 1 && a.OH == a.Hin && a.OW == a.Win && (Cin % cke == 0) &&
+         (a.C1 % ve == 0);
+}
+static bool use_w8(const ConvArgs& a) {  // tile shape with the smaller padded area
+  int64_t a16 = cdiv(a.OH, 8) * 8 * cdiv(a.OW, 16) * 16, a8 = cdiv(a.OH, 16) * 16 * cdiv(a.OW, 8) * 8;
+  return a8 < a16;
+}
+int conv3x3_tiles(const ConvArgs& a) {
+  bool w8 = use_w8(a);
+  return a.N * (int)cdiv(a.OH, w8 ? 16 : 8) * (int)cdiv(a.OW, w8 ? 8 : 16);
+}
+
+template <typename T>
+static void launch3_t(const ConvArgs& a, hipStream_t st) {
+  const bool w8 = use_w8(a);
+  const int tilesH = (int)cdiv(a.OH, w8 ? 16 : 8), tilesW = (int)cdiv(a.OW, w8 ? 8 : 16);
+  const int bn = pick_bn3(a.Cout);
+  dim3 grid((unsigned)(a.N * tilesH * tilesW), (unsigned)cdiv(a.Cout, bn));
+#define RD_C3(BNV)                                                                                                   \
+  if (bn == BNV) {                                                                                                   \
+    if (w8) hipLaunchKernelGGL((conv3x3_patch_kernel<T, BNV, true>), grid, dim3(256), 0, st, a, tilesH, tilesW);     \
+    else hipLaunchKernelGGL((conv3x3_patch_kernel<T, BNV, false>), grid, dim3(256), 0, st, a, tilesH, tilesW);       \
+  }
+  RD_C3(16) RD_C3(32) RD_C3(64) RD_C3(128)
+#undef RD_C3
+}
+void launch_conv3x3(const ConvArgs& a, int dtype, hipStream_t st) {
+  if (dtype == 0) launch3_t<float>(a, st);
+  else launch3_t<bf16_t>(a, st);
+}
+
+}  // namespace rd

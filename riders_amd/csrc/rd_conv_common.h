@@ -1,0 +1,107 @@
+// Device helpers shared by the convolution kernels (rd_conv.hip, rd_conv3x3.hip).
+#pragma once
+#include "rd_common.h"
+#include "rd_kernels.h"
+
+namespace rd {
+
+static constexpr int BM = 128;          // pixels per block tile
+static constexpr int STAGE_BYTES = 128; // K bytes per row per stage
+
+// LDS byte offset of 16-byte slot `slot` (0..7) of tile row `row`; XOR swizzle keeps the
+// ds_read_b128 fragment reads (16 rows x 4 k-groups per wave) bank-conflict free.
+__device__ __forceinline__ int lds_slot(int row, int slot) { return row * 8 + (slot ^ ((row >> 1) & 7)); }
+
+template <typename T>
+__device__ __forceinline__ bool conv_src_ptr(const ConvArgs& a, int n, int ih, int iw, int ci, const T*& p) {
+  if (a.dil > 1) {
+    if (ih < 0 || iw < 0) return false;
+    if ((ih % a.dil) | (iw % a.dil)) return false;
+    ih /= a.dil; iw /= a.dil;
+  }
+  if ((unsigned)ih >= (unsigned)a.Hin || (unsigned)iw >= (unsigned)a.Win) return false;
+  int hs = ih, ws = iw, Hp = a.Hin, Wp = a.Win;
+  if (a.ups) {  // F.interpolate(mode='nearest') source index, ATen float formula
+    hs = min((int)floorf((float)ih * a.scale_h), a.H1 - 1);
+    ws = min((int)floorf((float)iw * a.scale_w), a.W1 - 1);
+    Hp = a.H1; Wp = a.W1;
+  }
+  if (ci < a.C1) p = (const T*)a.src1 + ((((int64_t)n * Hp + hs) * Wp + ws) * a.C1 + ci);
+  else p = (const T*)a.src2 + ((((int64_t)n * Hp + hs) * Wp + ws) * a.C2 + (ci - a.C1));
+  return true;
+}
+
+
+// ---- shared epilogue: bias, activation, NHWC store (dual destination), BatchNorm (sum, sum^2) partials ------------------------------
+// acc[c][pt][r] = output channel n0 + (wn*CT + c)*16 + fg*4 + r of pixel m[pt] (valid iff mv[pt]); WMV waves share the pixel axis.
+template <typename T, int CT, int BN, int WMV>
+__device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[CT][2], const int64_t (&m)[2], const bool (&mv)[2], int n0,
+                                              int wn, int wm, int fr, int fg, int t, int64_t stats_row, float* red /* >= WMV*BN*2 floats */) {
+  const int D2 = a.Cout - a.D1;
+  const bool vec_ok = ((a.D1 & 3) == 0) && ((D2 & 3) == 0);
+  float ssum[CT][4], ssq[CT][4];
+#pragma unroll
+  for (int c = 0; c < CT; c++)
+#pragma unroll
+    for (int r = 0; r < 4; r++) { ssum[c][r] = 0.f; ssq[c][r] = 0.f; }
+#pragma unroll
+  for (int pt = 0; pt < 2; pt++) {
+#pragma unroll
+    for (int c = 0; c < CT; c++) {
+      const int co = n0 + (wn * CT + c) * 16 + fg * 4;
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        float x = acc[c][pt][r];
+        if (a.bias && co + r < a.Cout) x += a.bias[co + r];
+        x = act_fwd(x, a.act, a.slope);
+        x = Elem<T>::rnd(x);
+        v[r] = x;
+        if (mv[pt]) { ssum[c][r] += x; ssq[c][r] += x * x; }
+      }
+      if (mv[pt] && co < a.Cout) {
+        if (vec_ok && co + 3 < a.Cout) {
+          T* d = (co < a.D1) ? ((T*)a.dst1 + m[pt] * a.D1 + co) : ((T*)a.dst2 + m[pt] * D2 + (co - a.D1));
+          st4(d, v);
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; r++) {
+            int cc = co + r;
+            if (cc < a.Cout) {
+              T* d = (cc < a.D1) ? ((T*)a.dst1 + m[pt] * a.D1 + cc) : ((T*)a.dst2 + m[pt] * D2 + (cc - a.D1));
+              Elem<T>::st(d, v[r]);
+            }
+          }
+        }
+      }
+    }
+  }
+  if (a.stats) {  // per-block partials, combined later in a fixed order (deterministic)
+#pragma unroll
+    for (int c = 0; c < CT; c++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        float s1 = ssum[c][r], s2 = ssq[c][r];
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+        if (fr == 0) {
+          int col = (wn * CT + c) * 16 + fg * 4 + r;
+          red[(wm * BN + col) * 2 + 0] = s1;
+          red[(wm * BN + col) * 2 + 1] = s2;
+        }
+      }
+    __syncthreads();
+    for (int col = t; col < BN; col += 256) {
+      int co = n0 + col;
+      if (co < a.Cout) {
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int w = 0; w < WMV; w++) { s1 += red[(w * BN + col) * 2]; s2 += red[(w * BN + col) * 2 + 1]; }
+        a.stats[(stats_row * a.Cout + co) * 2 + 0] = s1;
+        a.stats[(stats_row * a.Cout + co) * 2 + 1] = s2;
+      }
+    }
+  }
+}
+
+}  // namespace rd

@@ -27,7 +27,12 @@ int conv_kpad(int K, int dtype);
 int conv_block_pixels(int M, int Cout);
 int wgrad_nsplit(int M, int K, int Cout);
 int wgrad_slabs(int M, int K, int Cout);
+int conv_stats_rows(const ConvArgs& a, int dtype);
 void launch_conv(const ConvArgs& a, int dtype, hipStream_t st);
+// rd_conv3x3.hip
+bool conv3x3_ok(const ConvArgs& a, int dtype);
+int conv3x3_tiles(const ConvArgs& a);
+void launch_conv3x3(const ConvArgs& a, int dtype, hipStream_t st);
 void launch_pack_weights(const float* w, void* out, int Cout, int Cin, int KH, int KW, int mode, int dtype, hipStream_t st);
 void launch_wgrad(WgradArgs a, int dtype, float* dw, int accumulate, hipStream_t st);
 

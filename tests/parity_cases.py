@@ -66,6 +66,25 @@ CONV_CASES = [
 ]
 
 
+class force_patch_conv:
+    """Route every eligible 3x3/stride-1 layer to the patch-staged kernel (rd_conv3x3.hip) regardless of its block count."""
+    def __enter__(self):
+        self.old = os.environ.get("RD_CONV3X3_MIN_BLOCKS")
+        os.environ["RD_CONV3X3_MIN_BLOCKS"] = "0"
+    def __exit__(self, *a):
+        if self.old is None:
+            del os.environ["RD_CONV3X3_MIN_BLOCKS"]
+        else:
+            os.environ["RD_CONV3X3_MIN_BLOCKS"] = self.old
+
+
+PATCH_CONV_CASES = [
+    dict(cin=32, cout=32, k=3, s=1, H=9, W=19, N=2, bn=True),                  # 16x8 tiles, ragged in both axes; dgrad also patch-staged
+    dict(cin=64, cout=160, k=3, s=1, H=17, W=7, N=1, bn=False, act=None),      # 8x16 tiles, two channel blocks, two chunks
+    dict(cin=128, cout=64, k=3, s=1, H=8, W=16, N=2, bn=True),                 # exact tile, four chunks
+]
+
+
 def conv_case(dev, c, tol=TOL):
     from riders_amd import net_utils
     act = net_utils.activation_func('leaky_relu') if c.get("act", "lrelu") else None

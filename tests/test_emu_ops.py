@@ -12,6 +12,19 @@ def test_conv(emu, case):
     P.conv_case(emu, P.CONV_CASES[case])
 
 
+@pytest.mark.parametrize("case", range(len(P.PATCH_CONV_CASES)))
+def test_patch_conv(emu, case):
+    with P.force_patch_conv():
+        P.conv_case(emu, P.PATCH_CONV_CASES[case])
+
+
+def test_patch_conv_decoder_and_bf16(emu):
+    with P.force_patch_conv():
+        P.decoder_block_case(emu, cin=32, cskip=32, cout=32)
+        P.bf16_exact_conv_case(emu, cin=64, cout=64, k=3, s=1, H=9, W=19, N=1)
+        P.bf16_exact_conv_case(emu, cin=32, cout=128, k=3, s=1, N=1, up=((4, 3), (17, 6)), cin2=32)
+
+
 def test_decoder_block(emu):
     P.decoder_block_case(emu)
     P.decoder_block_case(emu, cin=16, cskip=0, cout=16, hs=(5, 4), hv=(10, 8))

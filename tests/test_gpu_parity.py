@@ -13,6 +13,22 @@ def test_conv(gpu, case):
     P.conv_case(gpu, P.CONV_CASES[case])
 
 
+@pytest.mark.parametrize("case", range(len(P.PATCH_CONV_CASES)))
+def test_patch_conv(gpu, case):
+    with P.force_patch_conv():
+        P.conv_case(gpu, P.PATCH_CONV_CASES[case])
+
+
+def test_patch_conv_decoder_and_bf16(gpu):
+    with P.force_patch_conv():
+        P.decoder_block_case(gpu, cin=32, cskip=32, cout=32)
+        P.decoder_block_case(gpu, cin=256, cskip=128, cout=256, hs=(7, 3), hv=(15, 6), N=6)
+        P.bf16_exact_conv_case(gpu, cin=64, cout=64, k=3, s=1, H=9, W=19, N=1)
+        P.bf16_exact_conv_case(gpu, cin=32, cout=128, k=3, s=1, N=1, up=((4, 3), (17, 6)), cin2=32)
+    P.bf16_exact_conv_case(gpu, cin=64, cout=128, k=3, s=1, H=80, W=72, N=4)     # routed to the patch kernel by block count
+    P.conv_case(gpu, dict(cin=64, cout=64, k=3, s=1, H=64, W=96, N=4, bn=True))
+
+
 def test_decoder_block(gpu):
     P.decoder_block_case(gpu)
     P.decoder_block_case(gpu, cin=16, cskip=0, cout=16, hs=(5, 4), hv=(10, 8))

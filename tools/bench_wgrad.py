@@ -5,7 +5,8 @@ import torch
 from riders_amd import engine
 from riders_amd.engine import _desc, _p, L, _stream
 dev = torch.device("cuda:0")
-N, H, W, Cin, Cout = 240, 240, 100, int(sys.argv[1]) if len(sys.argv) > 1 else 16, int(sys.argv[2]) if len(sys.argv) > 2 else 16
+N, H, W = [int(v) for v in os.environ.get("RD_NHW", "240,240,100").split(",")]
+Cin, Cout = int(sys.argv[1]) if len(sys.argv) > 1 else 16, int(sys.argv[2]) if len(sys.argv) > 2 else 16
 dt_name = sys.argv[3] if len(sys.argv) > 3 else "bf16"
 which = sys.argv[4] if len(sys.argv) > 4 else "wgrad"
 tdt = torch.bfloat16 if dt_name == "bf16" else torch.float32
@@ -28,4 +29,4 @@ torch.cuda.synchronize(); t0 = time.time()
 for _ in range(10): run()
 torch.cuda.synchronize(); dtm = (time.time() - t0) / 10
 fl = 2.0 * N * H * W * Cin * Cout * 9
-print("%s Cin=%d Cout=%d %s: %.3f ms  %.1f TFLOP/s  %.1f GB/s(alg)" % (which, Cin, Cout, dt_name, dtm * 1e3, fl / dtm / 1e12, (x.numel() + dy.numel()) * x.element_size() / dtm / 1e9))
+print("%s NHW=%s Cin=%d Cout=%d %s: %.3f ms  %.1f TFLOP/s  %.1f GB/s(alg)" % (which, os.environ.get("RD_NHW", "-"), Cin, Cout, dt_name, dtm * 1e3, fl / dtm / 1e12, (x.numel() + dy.numel()) * x.element_size() / dtm / 1e9))
