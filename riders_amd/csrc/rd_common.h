@@ -62,6 +62,25 @@ __device__ __forceinline__ void st4(bf16_t* p, const float (&o)[4]) {
   *reinterpret_cast<uint2*>(p) = v;
 }
 
+// VE consecutive elements (one 16-byte access) <-> VE floats
+__device__ __forceinline__ void ldv(const float* p, float (&o)[4]) { ld4(p, o); }
+__device__ __forceinline__ void stv(float* p, const float (&o)[4]) { st4(p, o); }
+__device__ __forceinline__ void ldv(const bf16_t* p, float (&o)[8]) {
+  uint4 v = *reinterpret_cast<const uint4*>(p);
+  o[0] = __uint_as_float(v.x << 16); o[1] = __uint_as_float(v.x & 0xffff0000u);
+  o[2] = __uint_as_float(v.y << 16); o[3] = __uint_as_float(v.y & 0xffff0000u);
+  o[4] = __uint_as_float(v.z << 16); o[5] = __uint_as_float(v.z & 0xffff0000u);
+  o[6] = __uint_as_float(v.w << 16); o[7] = __uint_as_float(v.w & 0xffff0000u);
+}
+__device__ __forceinline__ void stv(bf16_t* p, const float (&o)[8]) {
+  uint4 v;
+  v.x = (unsigned)f32_to_bf16(o[0]) | ((unsigned)f32_to_bf16(o[1]) << 16);
+  v.y = (unsigned)f32_to_bf16(o[2]) | ((unsigned)f32_to_bf16(o[3]) << 16);
+  v.z = (unsigned)f32_to_bf16(o[4]) | ((unsigned)f32_to_bf16(o[5]) << 16);
+  v.w = (unsigned)f32_to_bf16(o[6]) | ((unsigned)f32_to_bf16(o[7]) << 16);
+  *reinterpret_cast<uint4*>(p) = v;
+}
+
 // ---- MFMA ------------------------------------------------------------------------------------
 // D = A*B + C on one 64-lane wave; lane l supplies A[i=l&15][k-group l>>4] and B[k-group l>>4][j=l&15],
 // and holds D[row=(l>>4)*4+r][col=l&15] in register r (cdna_hip_programming.md section 3).

@@ -733,12 +733,17 @@ static bool use_conv3x3(const ConvArgs& a, int dtype) {
   if (!conv3x3_ok(a, dtype)) return false;
   return (int64_t)conv3x3_tiles(a) * cdiv(a.Cout, pick_bn(a.Cout)) >= conv3x3_min_blocks();
 }
+static bool use_conv3x3_small(const ConvArgs& a, int dtype) {
+  return conv3x3_small_ok(a, dtype) && conv3x3_tiles(a) >= conv3x3_min_blocks();
+}
 int conv_stats_rows(const ConvArgs& a, int dtype) {
-  if (use_conv3x3(a, dtype)) return conv3x3_tiles(a);
+  if (use_conv3x3_small(a, dtype) || use_conv3x3(a, dtype)) return conv3x3_tiles(a);
   return (int)cdiv(a.M, conv_block_pixels(a.M, a.Cout));
 }
 
 void launch_conv(const ConvArgs& a, int dtype, hipStream_t st) {
+  if (conv3x3_c1_ok(a)) { launch_conv3x3_c1(a, dtype, st); return; }
+  if (use_conv3x3_small(a, dtype)) { launch_conv3x3_small(a, dtype, st); return; }
   if (use_conv3x3(a, dtype)) { launch_conv3x3(a, dtype, st); return; }
   if (dtype == 0) launch_conv_t<float>(a, st);
   else launch_conv_t<bf16_t>(a, st);

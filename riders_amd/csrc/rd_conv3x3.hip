@@ -155,6 +155,181 @@ __global__ __launch_bounds__(256) void conv3x3_patch_kernel(ConvArgs a, int tile
   conv_epilogue<T, CT, BN, 4>(a, acc, mm, mvv, n0, 0, wv, fr, fg, t, bx, reinterpret_cast<float*>(&sP[0]));
 }
 
+// ---- narrow layers (Cin * sizeof(T) = 32 / 64 / 128 bytes, Cout <= 32): persistent blocks, weights in registers ---------------------
+// RC-Net's decoder tail runs at ROI resolution (5.76 M output pixels for the ZJU config) with 16..32 channels: the layers are HBM-bound
+// (algorithmic bytes / 8 TB/s = 50..70 us) and the implicit-GEMM kernel spent 0.3..0.5 ms on them (9x re-gather).  Here the whole K axis
+// (9 taps x Cin) of a 128-pixel tile is one LDS patch; a lane keeps its weight fragments for all taps in registers, blocks are
+// persistent (tile loop, next patch prefetched into registers, double-buffered LDS, one barrier per tile) and every XCD walks a
+// contiguous range of tiles so that halo pixels shared by neighbouring tiles are L2 hits.
+template <int SPP>
+__device__ __forceinline__ int patch_slot(int p, int j) { return p * SPP + (j ^ ((p / (16 / SPP)) % SPP)); }
+
+template <typename T, int SPP, int BN, bool W8>
+__global__ __launch_bounds__(256) void conv3x3_small_kernel(ConvArgs a, int tilesH, int tilesW) {
+  constexpr int VE = Elem<T>::VE;
+  constexpr int TW = W8 ? 8 : 16, TH = W8 ? 16 : 8;
+  constexpr int WT = TW + 2, HT = TH + 2, NP = HT * WT;
+  constexpr int NSLOT = NP * SPP;
+  constexpr int PIT = (NSLOT + 255) / 256;
+  constexpr int CT = BN / 16;
+  constexpr int STEPS = (9 * SPP + 3) / 4;  // one step = 4 x 16 bytes of K (one bf16 MFMA / four fp32 MFMAs)
+  __shared__ uint4 sP[2][NSLOT];
+  __shared__ float red[4 * BN * 2];
+
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  const int fr = lane & 15, fg = lane >> 4;
+  const int ntiles = a.N * tilesH * tilesW;
+  // XCD x (blocks with blockIdx % 8 == x) owns tiles [x*T8, (x+1)*T8)
+  const int T8 = (ntiles + 7) >> 3, G8 = gridDim.x >> 3;
+  const int xcd = blockIdx.x & 7;
+  const int tend = min(ntiles, (xcd + 1) * T8);
+  int tile = xcd * T8 + (blockIdx.x >> 3);
+
+  // weight fragments: row = cout (c*16 + fr), 16-byte K slot = s*4 + fg
+  uint4 wr[CT][STEPS];
+  {
+    const uint4* wp = reinterpret_cast<const uint4*>(a.w);
+    const int kslots = a.Kpad / VE;
+#pragma unroll
+    for (int c = 0; c < CT; c++)
+#pragma unroll
+      for (int s = 0; s < STEPS; s++) {
+        const uint4 v = wp[(int64_t)(c * 16 + fr) * kslots + s * 4 + fg];
+        wr[c][s] = v;
+      }
+  }
+  uint4 rp[PIT];
+  auto load_patch = [&](int tl) RD_INLINE_LAMBDA {
+    const int tw_ = tl % tilesW; const int q_ = tl / tilesW; const int th_ = q_ % tilesH; const int n = q_ / tilesH;
+    const int oh0 = th_ * TH, ow0 = tw_ * TW;
+#pragma unroll
+    for (int i = 0; i < PIT; i++) {
+      int idx = t + 256 * i;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (idx < NSLOT) {
+        int pp = idx / SPP, sl = idx - pp * SPP;
+        int py = pp / WT, px = pp - py * WT;
+        const T* p;
+        if (conv_src_ptr<T>(a, n, oh0 - 1 + py, ow0 - 1 + px, sl * VE, p)) v = *reinterpret_cast<const uint4*>(p);
+      }
+      rp[i] = v;
+    }
+  };
+  auto store_patch = [&](int buf) RD_INLINE_LAMBDA {
+#pragma unroll
+    for (int i = 0; i < PIT; i++) {
+      int idx = t + 256 * i;
+      if (idx < NSLOT) { int pp = idx / SPP; sP[buf][patch_slot<SPP>(pp, idx - pp * SPP)] = rp[i]; }
+    }
+  };
+  int ppix[2], lpy[2], lpx[2];
+#pragma unroll
+  for (int pt = 0; pt < 2; pt++) {
+    lpy[pt] = W8 ? (wv * 4 + pt * 2 + (fr >> 3)) : (wv * 2 + pt);
+    lpx[pt] = W8 ? (fr & 7) : fr;
+    ppix[pt] = lpy[pt] * WT + lpx[pt];
+  }
+
+  if (tile < tend) load_patch(tile);
+  int buf = 0;
+  while (tile < tend) {
+    store_patch(buf);
+    __syncthreads();
+    const int next = tile + G8;
+    if (next < tend) load_patch(next);
+
+    f32x4 acc[CT][2];
+#pragma unroll
+    for (int c = 0; c < CT; c++) { acc[c][0] = f32x4{0, 0, 0, 0}; acc[c][1] = f32x4{0, 0, 0, 0}; }
+#pragma unroll
+    for (int s = 0; s < STEPS; s++) {
+      // K slot g = s*4 + fg  ->  tap g / SPP (clamped: the packed weights are zero past tap 8), slot-in-pixel g % SPP
+      int tap, j;
+      if (SPP >= 4) { tap = (s * 4) / SPP; j = (s * 4) % SPP + fg; }
+      else { tap = min(s * 2 + (fg >> 1), 8); j = fg & 1; }
+      const int toff = (tap / 3) * WT + (tap % 3);
+      uint4 pf[2];
+#pragma unroll
+      for (int pt = 0; pt < 2; pt++) pf[pt] = sP[buf][patch_slot<SPP>(ppix[pt] + toff, j)];
+#pragma unroll
+      for (int c = 0; c < CT; c++) {
+        const uint4 wf = wr[c][s];
+#pragma unroll
+        for (int pt = 0; pt < 2; pt++) {
+          if (sizeof(T) == 4) {
+            acc[c][pt] = mfma_16x16x4_f32(__uint_as_float(wf.x), __uint_as_float(pf[pt].x), acc[c][pt]);
+            acc[c][pt] = mfma_16x16x4_f32(__uint_as_float(wf.y), __uint_as_float(pf[pt].y), acc[c][pt]);
+            acc[c][pt] = mfma_16x16x4_f32(__uint_as_float(wf.z), __uint_as_float(pf[pt].z), acc[c][pt]);
+            acc[c][pt] = mfma_16x16x4_f32(__uint_as_float(wf.w), __uint_as_float(pf[pt].w), acc[c][pt]);
+          } else {
+            s16x8 wa, pb;
+            __builtin_memcpy(&wa, &wf, 16);
+            __builtin_memcpy(&pb, &pf[pt], 16);
+            acc[c][pt] = mfma_16x16x32_bf16(wa, pb, acc[c][pt]);
+          }
+        }
+      }
+    }
+    {
+      const int tw_ = tile % tilesW; const int q_ = tile / tilesW; const int th_ = q_ % tilesH; const int n = q_ / tilesH;
+      int64_t mm[2]; bool mvv[2];
+#pragma unroll
+      for (int pt = 0; pt < 2; pt++) {
+        int oh = th_ * TH + lpy[pt], ow = tw_ * TW + lpx[pt];
+        mvv[pt] = oh < a.OH && ow < a.OW;
+        mm[pt] = ((int64_t)n * a.OH + oh) * a.OW + ow;
+      }
+      conv_epilogue<T, CT, BN, 4>(a, acc, mm, mvv, 0, 0, wv, fr, fg, t, tile, red);
+    }
+    tile = next;
+    buf ^= 1;
+  }
+}
+
+// ---- single input channel (data gradient of a Cout = 1 head): direct form, one pixel per thread ---------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void conv3x3_c1_kernel(ConvArgs a) {
+  constexpr int VE = Elem<T>::VE;
+  __shared__ float sw[9 * 32];  // [tap][cout]
+  for (int i = threadIdx.x; i < 9 * a.Cout; i += 256) {
+    int tap = i / a.Cout, co = i - tap * a.Cout;
+    sw[i] = Elem<T>::ld((const T*)a.w + (int64_t)co * a.Kpad + tap);
+  }
+  __syncthreads();
+  const T* x = (const T*)a.src1;
+  const bool vec = (a.Cout % VE) == 0;
+  for (int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x; m < a.M; m += (int64_t)gridDim.x * 256) {
+    int ow = (int)(m % a.OW); int64_t q = m / a.OW; int oh = (int)(q % a.OH); int n = (int)(q / a.OH);
+    float xv[9];
+#pragma unroll
+    for (int kh = 0; kh < 3; kh++)
+#pragma unroll
+      for (int kw = 0; kw < 3; kw++) {
+        int ih = oh - 1 + kh, iw = ow - 1 + kw;
+        bool ok = (unsigned)ih < (unsigned)a.Hin && (unsigned)iw < (unsigned)a.Win;
+        xv[kh * 3 + kw] = ok ? Elem<T>::ld(x + ((int64_t)n * a.Hin + ih) * a.Win + iw) : 0.f;
+      }
+    T* d = (T*)a.dst1 + m * a.Cout;
+    for (int c0 = 0; c0 < a.Cout; c0 += 4) {
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        int co = c0 + r;
+        float s = 0.f;
+        if (co < a.Cout) {
+#pragma unroll
+          for (int tp = 0; tp < 9; tp++) s += sw[tp * a.Cout + co] * xv[tp];   // ascending-k order, as the MFMA path's oracle
+          if (a.bias) s += a.bias[co];
+          s = act_fwd(s, a.act, a.slope);
+        }
+        v[r] = s;
+      }
+      if (vec || c0 + 3 < a.Cout) { if ((a.Cout & 3) == 0) st4(d + c0, v); else { for (int r = 0; r < 4; r++) Elem<T>::st(d + c0 + r, v[r]); } }
+      else for (int r = 0; r < 4 && c0 + r < a.Cout; r++) Elem<T>::st(d + c0 + r, v[r]);
+    }
+  }
+}
+
 // ---- host side -------------------------------------------------------------------------------------------------------------------
 static int pick_bn3(int cout) { return cout <= 16 ? 16 : (cout <= 32 ? 32 : (cout <= 64 ? 64 : 128)); }
 
@@ -190,6 +365,48 @@ static void launch3_t(const ConvArgs& a, hipStream_t st) {
 void launch_conv3x3(const ConvArgs& a, int dtype, hipStream_t st) {
   if (dtype == 0) launch3_t<float>(a, st);
   else launch3_t<bf16_t>(a, st);
+}
+
+static bool geom3x3(const ConvArgs& a) {
+  return a.KH == 3 && a.KW == 3 && a.stride == 1 && a.pad == 1 && a.dil == 1 && a.OH == a.Hin && a.OW == a.Win;
+}
+// narrow layers: Cin bytes per pixel in {32, 64, 128}, Cout <= 32, register budget CT * STEPS <= 20
+bool conv3x3_small_ok(const ConvArgs& a, int dtype) {
+  const int Cin = a.C1 + a.C2, es = dtype == 0 ? 4 : 2, ve = 16 / es;
+  const int cb = Cin * es;
+  if (!geom3x3(a) || a.Cout > 32 || (cb != 32 && cb != 64 && cb != 128) || (a.C1 % ve) != 0) return false;
+  const int spp = cb / 16, steps = (9 * spp + 3) / 4, ct = pick_bn3(a.Cout) / 16;
+  return ct * steps <= 20;
+}
+template <typename T>
+static void launch_small_t(const ConvArgs& a, hipStream_t st) {
+  const bool w8 = use_w8(a);
+  const int tilesH = (int)cdiv(a.OH, w8 ? 16 : 8), tilesW = (int)cdiv(a.OW, w8 ? 8 : 16);
+  const int ntiles = a.N * tilesH * tilesW;
+  const int spp = (a.C1 + a.C2) * (int)sizeof(T) / 16, bn = pick_bn3(a.Cout);
+  const char* e = getenv("RD_CONV3X3_G8");  // test hook: few persistent blocks -> several tiles per block on small cases
+  const int g8 = (int)std::min<int64_t>(cdiv(ntiles, 8), e ? atoi(e) : 128);  // 8 XCDs x up to 128 persistent blocks (4 per CU)
+  dim3 grid((unsigned)(8 * g8));
+#define RD_S3(SPPV, BNV)                                                                                                  \
+  if (spp == SPPV && bn == BNV) {                                                                                         \
+    if (w8) hipLaunchKernelGGL((conv3x3_small_kernel<T, SPPV, BNV, true>), grid, dim3(256), 0, st, a, tilesH, tilesW);    \
+    else hipLaunchKernelGGL((conv3x3_small_kernel<T, SPPV, BNV, false>), grid, dim3(256), 0, st, a, tilesH, tilesW);      \
+  }
+  RD_S3(2, 16) RD_S3(4, 16) RD_S3(8, 16) RD_S3(2, 32) RD_S3(4, 32)
+#undef RD_S3
+}
+void launch_conv3x3_small(const ConvArgs& a, int dtype, hipStream_t st) {
+  if (dtype == 0) launch_small_t<float>(a, st);
+  else launch_small_t<bf16_t>(a, st);
+}
+
+bool conv3x3_c1_ok(const ConvArgs& a) {
+  return geom3x3(a) && a.C1 == 1 && a.C2 == 0 && !a.ups && !a.stats && a.D1 == a.Cout && a.Cout <= 32;
+}
+void launch_conv3x3_c1(const ConvArgs& a, int dtype, hipStream_t st) {
+  unsigned grid = (unsigned)std::min<int64_t>(cdiv(a.M, 256), 256 * 32);
+  if (dtype == 0) hipLaunchKernelGGL((conv3x3_c1_kernel<float>), dim3(grid), dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((conv3x3_c1_kernel<bf16_t>), dim3(grid), dim3(256), 0, st, a);
 }
 
 }  // namespace rd

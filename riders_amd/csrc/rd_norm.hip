@@ -206,6 +206,122 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
   }
 }
 
+
+// ---- 16-byte-vector forms (C % VE == 0 and C/VE divides 256): a thread keeps the same VE channels for the whole grid-stride loop, so
+// the per-channel parameters live in registers and every memory instruction moves 16 bytes per lane.  The scalar forms above issued
+// 2-byte loads plus five parameter loads per element and ran 5-17x off the HBM roofline (rocprofv3: col_reduce 116 us/launch). ------------
+template <typename T>
+__global__ __launch_bounds__(256) void affine_act_vec_kernel(const T* __restrict__ y, const float* __restrict__ scale,
+                                                             const float* __restrict__ shift, const T* __restrict__ res,
+                                                             T* __restrict__ out, int64_t nvec, int C, int act, float slope) {
+  constexpr int VE = Elem<T>::VE;
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int c0 = (int)((i * VE) % C);
+  float sc[VE], sh[VE];
+#pragma unroll
+  for (int e = 0; e < VE; e++) { sc[e] = scale ? scale[c0 + e] : 1.f; sh[e] = shift ? shift[c0 + e] : 0.f; }
+  for (; i < nvec; i += stride) {
+    float v[VE], r[VE];
+    ldv(y + i * VE, v);
+    if (res) ldv(res + i * VE, r);
+#pragma unroll
+    for (int e = 0; e < VE; e++) v[e] = act_fwd(v[e] * sc[e] + sh[e] + (res ? r[e] : 0.f), act, slope);
+    stv(out + i * VE, v);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_apply_vec_kernel(const T* __restrict__ dz, const T* __restrict__ z,
+                                                               const T* __restrict__ y, const float* __restrict__ mean,
+                                                               const float* __restrict__ rstd, const float* __restrict__ scale,
+                                                               const float* __restrict__ c1, const float* __restrict__ c2,
+                                                               T* __restrict__ dy, T* __restrict__ dres, int64_t nvec, int C,
+                                                               int act, float slope) {
+  constexpr int VE = Elem<T>::VE;
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int c0 = (int)((i * VE) % C);
+  float mu[VE], rs[VE], sc[VE], k1[VE], k2[VE];
+#pragma unroll
+  for (int e = 0; e < VE; e++) { mu[e] = mean[c0 + e]; rs[e] = rstd[c0 + e]; sc[e] = scale[c0 + e]; k1[e] = c1[c0 + e]; k2[e] = c2[c0 + e]; }
+  for (; i < nvec; i += stride) {
+    float g[VE], zz[VE], yy[VE], o[VE];
+    ldv(dz + i * VE, g);
+    if (act) ldv(z + i * VE, zz);
+    ldv(y + i * VE, yy);
+#pragma unroll
+    for (int e = 0; e < VE; e++) {
+      if (act) g[e] *= act_grad_from_out(zz[e], act, slope);
+      float xh = (yy[e] - mu[e]) * rs[e];
+      o[e] = sc[e] * (g[e] - k1[e] - xh * k2[e]);
+    }
+    stv(dy + i * VE, o);
+    if (dres) stv(dres + i * VE, g);
+  }
+}
+
+// MODE 0: (sum dpre, sum dpre*xhat); MODE 1: column sum.  Block b reduces pixels [b*per, (b+1)*per); thread t owns channel group t % VP.
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void col_reduce_vec_kernel(const T* __restrict__ dz, const T* __restrict__ z,
+                                                             const T* __restrict__ y, const float* __restrict__ mean,
+                                                             const float* __restrict__ rstd, float* __restrict__ partial,
+                                                             int64_t pixels, int C, int act, float slope) {
+  constexpr int VE = Elem<T>::VE;
+  __shared__ float red[256 * VE * 2];
+  const int t = threadIdx.x, lane = t & 63;
+  const int VP = C / VE;
+  const int64_t per = cdiv(pixels, (int64_t)gridDim.x);
+  const int64_t pbeg = (int64_t)blockIdx.x * per, pend = pbeg + per < pixels ? pbeg + per : pixels;
+  const int c0 = (t % VP) * VE;
+  float mu[VE], rs[VE], a[VE], b[VE];
+#pragma unroll
+  for (int e = 0; e < VE; e++) {
+    a[e] = 0.f; b[e] = 0.f;
+    mu[e] = MODE == 0 ? mean[c0 + e] : 0.f; rs[e] = MODE == 0 ? rstd[c0 + e] : 1.f;
+  }
+  const int64_t vend = pend * VP;
+  for (int64_t i = pbeg * VP + t; i < vend; i += 256) {
+    float g[VE];
+    ldv(dz + i * VE, g);
+    if (MODE == 0) {
+      float zz[VE], yy[VE];
+      if (act) ldv(z + i * VE, zz);
+      ldv(y + i * VE, yy);
+#pragma unroll
+      for (int e = 0; e < VE; e++) {
+        if (act) g[e] *= act_grad_from_out(zz[e], act, slope);
+        a[e] += g[e]; b[e] += g[e] * ((yy[e] - mu[e]) * rs[e]);
+      }
+    } else {
+#pragma unroll
+      for (int e = 0; e < VE; e++) a[e] += g[e];
+    }
+  }
+  // lanes of a wave that share a channel group (lane % VP), fixed xor tree
+  for (int o = 32; o >= VP; o >>= 1) {
+#pragma unroll
+    for (int e = 0; e < VE; e++) { a[e] += __shfl_xor(a[e], o); if (MODE == 0) b[e] += __shfl_xor(b[e], o); }
+  }
+#pragma unroll
+  for (int e = 0; e < VE; e++) { red[(t * VE + e) * 2] = a[e]; red[(t * VE + e) * 2 + 1] = b[e]; }
+  __syncthreads();
+  for (int c = t; c < C; c += 256) {
+    const int g = c / VE, e = c - g * VE;
+    float sa = 0.f, sb = 0.f;
+    for (int tt = g; tt < 256; tt += VP)
+      if ((tt & 63) < VP) { sa += red[(tt * VE + e) * 2]; sb += red[(tt * VE + e) * 2 + 1]; }
+    partial[((int64_t)blockIdx.x * C + c) * 2] = sa;
+    partial[((int64_t)blockIdx.x * C + c) * 2 + 1] = sb;
+  }
+}
+static bool vec_ok(int C, int dtype) {
+  const int ve = dtype == 0 ? 4 : 8;
+  if (C % ve) return false;
+  const int vp = C / ve;
+  return vp <= 256 && (256 % vp) == 0;
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void act_bwd_kernel(const T* __restrict__ dz, const T* __restrict__ z, T* __restrict__ dx,
                                                       int64_t n, int act, float slope) {
@@ -291,6 +407,13 @@ void launch_bn_finalize(const float* partial, int rows, int C, double count, con
 void launch_affine_act(const void* y, const float* scale, const float* shift, const void* res, void* out, int64_t pixels,
                        int C, int act, float slope, int dtype, hipStream_t st) {
   int64_t total = pixels * C;
+  if (vec_ok(C, dtype)) {
+    const int64_t nvec = total / (dtype == 0 ? 4 : 8);
+    unsigned gv = ew_grid(nvec);
+    if (dtype == 0) hipLaunchKernelGGL((affine_act_vec_kernel<float>), dim3(gv), dim3(256), 0, st, (const float*)y, scale, shift, (const float*)res, (float*)out, nvec, C, act, slope);
+    else hipLaunchKernelGGL((affine_act_vec_kernel<bf16_t>), dim3(gv), dim3(256), 0, st, (const bf16_t*)y, scale, shift, (const bf16_t*)res, (bf16_t*)out, nvec, C, act, slope);
+    return;
+  }
   bool v4 = (C % 4 == 0);
   unsigned g = ew_grid(v4 ? total / 4 : total);
 #define RD_AA(T, V) hipLaunchKernelGGL((affine_act_kernel<T, V>), dim3(g), dim3(256), 0, st, (const T*)y, scale, shift, (const T*)res, (T*)out, total, C, act, slope)
@@ -306,6 +429,11 @@ void launch_bn_bwd_reduce(const void* dz, const void* z, const void* y, const fl
                           float* partial, int64_t pixels, int C, int act, float slope, int dtype, hipStream_t st) {
   RedGeom g = red_geom(C);
   dim3 grid(red_rows(pixels, C), g.nchunk);
+  if (vec_ok(C, dtype)) {
+    if (dtype == 0) hipLaunchKernelGGL((col_reduce_vec_kernel<float, 0>), dim3(grid.x), dim3(256), 0, st, (const float*)dz, (const float*)z, (const float*)y, mean, rstd, partial, pixels, C, act, slope);
+    else hipLaunchKernelGGL((col_reduce_vec_kernel<bf16_t, 0>), dim3(grid.x), dim3(256), 0, st, (const bf16_t*)dz, (const bf16_t*)z, (const bf16_t*)y, mean, rstd, partial, pixels, C, act, slope);
+    return;
+  }
   if (dtype == 0)
     hipLaunchKernelGGL((col_reduce_kernel<float, 0>), grid, dim3(256), 0, st, (const float*)dz, (const float*)z, (const float*)y, mean, rstd, partial, pixels, C, g.CB, g.PL, act, slope);
   else
@@ -321,6 +449,13 @@ void launch_bn_bwd_apply(const void* dz, const void* z, const void* y, const flo
                          const float* scale, const float* c1, const float* c2, void* dy, void* dres, int64_t pixels, int C,
                          int act, float slope, int dtype, hipStream_t st) {
   int64_t total = pixels * C;
+  if (vec_ok(C, dtype)) {
+    const int64_t nvec = total / (dtype == 0 ? 4 : 8);
+    unsigned gv = ew_grid(nvec);
+    if (dtype == 0) hipLaunchKernelGGL((bn_bwd_apply_vec_kernel<float>), dim3(gv), dim3(256), 0, st, (const float*)dz, (const float*)z, (const float*)y, mean, rstd, scale, c1, c2, (float*)dy, (float*)dres, nvec, C, act, slope);
+    else hipLaunchKernelGGL((bn_bwd_apply_vec_kernel<bf16_t>), dim3(gv), dim3(256), 0, st, (const bf16_t*)dz, (const bf16_t*)z, (const bf16_t*)y, mean, rstd, scale, c1, c2, (bf16_t*)dy, (bf16_t*)dres, nvec, C, act, slope);
+    return;
+  }
   bool v4 = (C % 4 == 0);
   unsigned g = ew_grid(v4 ? total / 4 : total);
 #define RD_BA(T, V) hipLaunchKernelGGL((bn_bwd_apply_kernel<T, V>), dim3(g), dim3(256), 0, st, (const T*)dz, (const T*)z, (const T*)y, mean, rstd, scale, c1, c2, (T*)dy, (T*)dres, total, C, act, slope)
@@ -338,7 +473,10 @@ void launch_colsum(const void* x, float* partial, float* out, int accumulate, in
   RedGeom g = red_geom(C);
   int nr = red_rows(rows, C);
   dim3 grid(nr, g.nchunk);
-  if (dtype == 0)
+  if (vec_ok(C, dtype)) {
+    if (dtype == 0) hipLaunchKernelGGL((col_reduce_vec_kernel<float, 1>), dim3(nr), dim3(256), 0, st, (const float*)x, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, partial, rows, C, 0, 0.f);
+    else hipLaunchKernelGGL((col_reduce_vec_kernel<bf16_t, 1>), dim3(nr), dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)nullptr, (const bf16_t*)nullptr, (const float*)nullptr, (const float*)nullptr, partial, rows, C, 0, 0.f);
+  } else if (dtype == 0)
     hipLaunchKernelGGL((col_reduce_kernel<float, 1>), grid, dim3(256), 0, st, (const float*)x, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, partial, rows, C, g.CB, g.PL, 0, 0.f);
   else
     hipLaunchKernelGGL((col_reduce_kernel<bf16_t, 1>), grid, dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)nullptr, (const bf16_t*)nullptr, (const float*)nullptr, (const float*)nullptr, partial, rows, C, g.CB, g.PL, 0, 0.f);

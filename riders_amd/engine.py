@@ -11,6 +11,7 @@ its own region, which appears to torch.autograd as ONE node (`_Region`).
 """
 import contextlib
 import ctypes
+import weakref
 
 import torch
 
@@ -303,8 +304,18 @@ _pack_cache = {}
 
 
 def packed_weight(w, mode, dt):
-    key = (id(w), w._version, mode, dt, w.data_ptr())
-    hit = _pack_cache.get(id(w), {}).get((mode, dt))
+    """MFMA-layout copy of a weight tensor, re-packed whenever the tensor was written (version counter) or re-allocated.
+    Entries die with their tensor (weakref callback): CPython recycles id()s and the caching allocator recycles addresses, so an
+    (id, data_ptr, version) key alone can match a DIFFERENT later tensor -- seen as stale weights / out-of-bounds reads in stress runs."""
+    key = (w._version, mode, dt, w.data_ptr(), tuple(w.shape))
+    ent = _pack_cache.get(id(w))
+    if ent is not None and ent["ref"]() is not w:
+        ent = None
+    if ent is None:
+        wid = id(w)
+        ent = {"ref": weakref.ref(w, lambda _r, wid=wid: _pack_cache.pop(wid, None))}
+        _pack_cache[wid] = ent
+    hit = ent.get((mode, dt))
     if hit is not None and hit[0] == key:
         return hit[1]
     cout, cin, kh, kw = w.shape if w.dim() == 4 else (w.shape[0], w.shape[1], 1, 1)
@@ -312,7 +323,7 @@ def packed_weight(w, mode, dt):
     n = L().rd_conv_packed_elems(rows, kh * kw * c, dt)
     buf = torch.empty(n, dtype=_TORCH_DT[dt], device=w.device)
     _chk(L().rd_conv_pack_weights(_p(w.detach()), _p(buf), cout, cin, kh, kw, mode, dt, _stream(w)), "rd_conv_pack_weights")
-    _pack_cache.setdefault(id(w), {})[(mode, dt)] = (key, buf)
+    ent[(mode, dt)] = (key, buf)
     return buf
 
 

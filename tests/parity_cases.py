@@ -68,20 +68,31 @@ CONV_CASES = [
 
 class force_patch_conv:
     """Route every eligible 3x3/stride-1 layer to the patch-staged kernel (rd_conv3x3.hip) regardless of its block count."""
+    def __init__(self, g8=None):
+        self.env = {"RD_CONV3X3_MIN_BLOCKS": "0"}
+        if g8 is not None:
+            self.env["RD_CONV3X3_G8"] = str(g8)     # persistent blocks per XCD of the narrow-layer kernel
+
     def __enter__(self):
-        self.old = os.environ.get("RD_CONV3X3_MIN_BLOCKS")
-        os.environ["RD_CONV3X3_MIN_BLOCKS"] = "0"
+        self.old = {k: os.environ.get(k) for k in self.env}
+        os.environ.update(self.env)
+
     def __exit__(self, *a):
-        if self.old is None:
-            del os.environ["RD_CONV3X3_MIN_BLOCKS"]
-        else:
-            os.environ["RD_CONV3X3_MIN_BLOCKS"] = self.old
+        for k, v in self.old.items():
+            if v is None:
+                del os.environ[k]
+            else:
+                os.environ[k] = v
 
 
 PATCH_CONV_CASES = [
     dict(cin=32, cout=32, k=3, s=1, H=9, W=19, N=2, bn=True),                  # 16x8 tiles, ragged in both axes; dgrad also patch-staged
     dict(cin=64, cout=160, k=3, s=1, H=17, W=7, N=1, bn=False, act=None),      # 8x16 tiles, two channel blocks, two chunks
     dict(cin=128, cout=64, k=3, s=1, H=8, W=16, N=2, bn=True),                 # exact tile, four chunks
+    # narrow-layer persistent kernel (Cin bytes 32/64/128, Cout <= 32); several tiles per persistent block come from the GPU-size cases
+    dict(cin=16, cout=16, k=3, s=1, H=19, W=9, N=2, bn=True),                  # fp32: 4 slots per pixel
+    dict(cin=8, cout=32, k=3, s=1, H=9, W=21, N=1, bn=True),                   # fp32: 2 slots per pixel (tap pairs, clamped 10th tap)
+    dict(cin=32, cout=1, k=3, s=1, H=10, W=17, N=2, bn=False, act=None),       # fp32: 8 slots per pixel, Cout = 1 head
 ]
 
 
@@ -436,7 +447,7 @@ def rcnet_e2e_case(dev, tol=TOL):
             assert abs(float(p.grad.norm()) - rn) < 5 * tol * max(rn, 1e-4), (k, float(p.grad.norm()), rn)
 
 
-def bf16_exact_conv_case(dev, cin=16, cout=16, k=3, s=1, H=9, W=7, N=2, up=None, cin2=0):
+def bf16_exact_conv_case(dev, cin=16, cout=16, k=3, s=1, H=9, W=7, N=2, up=None, cin2=0, report=False):
     """bf16 data path check that does not depend on rounding: with inputs / weights / upstream gradients in {-1,0,1}
     every product and partial sum is exactly representable, so the bf16 kernels must reproduce the fp32 oracle
     bit for bit (forward, data gradient, weight gradient), including the concat / upsample gather variants."""
@@ -464,6 +475,10 @@ def bf16_exact_conv_case(dev, cin=16, cout=16, k=3, s=1, H=9, W=7, N=2, up=None,
         out = engine.conv_block(a, w, x2=b, stride=s, pad=k // 2, up=None if up is None else up[1])
         tape.grads[id(out)] = gy.to(dev).permute(0, 2, 3, 1).contiguous().to(torch.bfloat16)
         tape.backward()
+    if report:      # stress tooling: which of (forward, dgrad, wgrad) matched
+        return (torch.equal(out.float().permute(0, 3, 1, 2).cpu(), ref.detach()),
+                torch.equal(tape.grads[id(a)].float().permute(0, 3, 1, 2).cpu(), x1r.grad),
+                torch.equal(tape.pgrads[id(w)].cpu(), wr.grad))
     assert torch.equal(out.float().permute(0, 3, 1, 2).cpu(), ref.detach()), "bf16 forward differs"
     assert torch.equal(tape.grads[id(a)].float().permute(0, 3, 1, 2).cpu(), x1r.grad), "bf16 dgrad (src1) differs"
     if cin2:

@@ -23,6 +23,13 @@ def test_patch_conv_decoder_and_bf16(emu):
         P.decoder_block_case(emu, cin=32, cskip=32, cout=32)
         P.bf16_exact_conv_case(emu, cin=64, cout=64, k=3, s=1, H=9, W=19, N=1)
         P.bf16_exact_conv_case(emu, cin=32, cout=128, k=3, s=1, N=1, up=((4, 3), (17, 6)), cin2=32)
+        # narrow-layer kernel, bf16: 2 / 4 / 8 slots per pixel, dual-destination dgrad, upsample + concat gather
+        P.bf16_exact_conv_case(emu, cin=16, cout=16, k=3, s=1, H=17, W=9, N=1)
+        P.bf16_exact_conv_case(emu, cin=16, cout=16, k=3, s=1, N=1, up=((4, 3), (9, 17)), cin2=16)
+        P.bf16_exact_conv_case(emu, cin=64, cout=8, k=3, s=1, H=8, W=5, N=2)
+    with P.force_patch_conv(g8=1):   # 8 persistent blocks: tile loop, LDS double buffer, register prefetch
+        P.bf16_exact_conv_case(emu, cin=32, cout=16, k=3, s=1, H=33, W=25, N=3)
+        P.conv_case(emu, dict(cin=16, cout=16, k=3, s=1, H=30, W=20, N=3, bn=True))
 
 
 def test_decoder_block(emu):

@@ -25,6 +25,13 @@ def test_patch_conv_decoder_and_bf16(gpu):
         P.decoder_block_case(gpu, cin=256, cskip=128, cout=256, hs=(7, 3), hv=(15, 6), N=6)
         P.bf16_exact_conv_case(gpu, cin=64, cout=64, k=3, s=1, H=9, W=19, N=1)
         P.bf16_exact_conv_case(gpu, cin=32, cout=128, k=3, s=1, N=1, up=((4, 3), (17, 6)), cin2=32)
+        P.bf16_exact_conv_case(gpu, cin=16, cout=16, k=3, s=1, H=17, W=9, N=1)
+        P.bf16_exact_conv_case(gpu, cin=16, cout=16, k=3, s=1, N=1, up=((4, 3), (9, 17)), cin2=16)
+        P.bf16_exact_conv_case(gpu, cin=64, cout=8, k=3, s=1, H=8, W=5, N=2)
+    # persistent narrow-layer kernel with many tiles per block (1024 blocks): 3300+ tiles, ragged edges, upsample + concat
+    P.bf16_exact_conv_case(gpu, cin=16, cout=16, k=3, s=1, N=12, up=((60, 25), (121, 50)), cin2=16)
+    P.bf16_exact_conv_case(gpu, cin=16, cout=1, k=3, s=1, H=130, W=100, N=24)
+    P.conv_case(gpu, dict(cin=16, cout=16, k=3, s=1, H=120, W=100, N=24, bn=True))
     P.bf16_exact_conv_case(gpu, cin=64, cout=128, k=3, s=1, H=80, W=72, N=4)     # routed to the patch kernel by block count
     P.conv_case(gpu, dict(cin=64, cout=64, k=3, s=1, H=64, W=96, N=4, bn=True))
 
