@@ -57,6 +57,13 @@ int64_t rd_conv_packed_elems(int32_t rows, int32_t K, int32_t dtype);
 /* OIHW fp32 -> packed; mode 0: forward operand, mode 1: data-gradient operand (transposed + flipped) */
 int rd_conv_pack_weights(const float* w_oihw, void* packed, int32_t Cout, int32_t Cin, int32_t KH, int32_t KW,
                          int32_t mode, int32_t dtype, void* stream);
+/* The same re-layout for MANY weights in one launch (after an optimizer step every cached operand of every conv / linear
+   layer is stale: RC-Net has 159 of them, 4.4 us each as separate launches).  `items` is a DEVICE array of n descriptors. */
+typedef struct rd_pack_item {
+  const float* w_oihw; void* packed;
+  int32_t Cout, Cin, KH, KW, mode, dtype;
+} rd_pack_item;
+int rd_conv_pack_weights_batch(const rd_pack_item* items, int32_t n, void* stream);
 /* rows of the per-block BatchNorm statistics buffer stats[rows][Cout][2] written by rd_conv_fwd */
 int32_t rd_conv_stats_rows(const rd_conv_desc* d);
 int rd_conv_fwd(const rd_conv_desc* d, const void* src1, const void* src2, const void* w_packed, const float* bias,

@@ -34,6 +34,11 @@ class ConvDesc(ctypes.Structure):
     ]
 
 
+class PackItem(ctypes.Structure):
+    _fields_ = [("w", ctypes.c_void_p), ("packed", ctypes.c_void_p), ("Cout", ctypes.c_int32), ("Cin", ctypes.c_int32),
+                ("KH", ctypes.c_int32), ("KW", ctypes.c_int32), ("mode", ctypes.c_int32), ("dtype", ctypes.c_int32)]
+
+
 _SCALARS = {
     "int": ctypes.c_int, "int32_t": ctypes.c_int32, "int64_t": ctypes.c_int64,
     "float": ctypes.c_float, "double": ctypes.c_double,

@@ -61,6 +61,13 @@ int rd_conv_pack_weights(const float* w, void* packed, int32_t Cout, int32_t Cin
   rd::launch_pack_weights(w, packed, Cout, Cin, KH, KW, mode, dtype, S(stream));
   return done("rd_conv_pack_weights");
 }
+int rd_conv_pack_weights_batch(const rd_pack_item* items, int32_t n, void* stream) {
+  if (n <= 0) return 0;
+  if (!items) return fail("pack_weights_batch: null table");
+  if (n > 65535) return fail("pack_weights_batch: too many items (%d)", n);
+  rd::launch_pack_weights_batch(items, n, S(stream));
+  return done("rd_conv_pack_weights_batch");
+}
 int32_t rd_conv_stats_rows(const rd_conv_desc* d) {
   rd::ConvArgs a; fill_args(d, a);
   return (int32_t)rd::conv_stats_rows(a, d->dtype);

@@ -192,6 +192,35 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, T* __restrict__
   }
 }
 
+// batch form: blockIdx.y = item (device descriptor table), blockIdx.x strides over the item's packed elements
+struct PackItem { const float* w; void* out; int Cout, Cin, KH, KW, mode, dtype; };
+template <typename T>
+__device__ __forceinline__ void pack_one(const PackItem& it, int bx, int nbx) {
+  const int rows = it.mode ? it.Cin : it.Cout, C = it.mode ? it.Cout : it.Cin;
+  const int K = it.KH * it.KW * C;
+  const int bn = rows <= 16 ? 16 : (rows <= 32 ? 32 : (rows <= 64 ? 64 : 128));
+  const int rows_pad = (rows + bn - 1) / bn * bn;
+  const int bke = sizeof(T) == 4 ? 32 : 64;
+  const int Kpad = (K + bke - 1) / bke * bke;
+  const int64_t total = (int64_t)rows_pad * Kpad;
+  T* out = (T*)it.out;
+  for (int64_t i = (int64_t)bx * 256 + threadIdx.x; i < total; i += (int64_t)nbx * 256) {
+    int row = (int)(i / Kpad), k = (int)(i - (int64_t)row * Kpad);
+    float v = 0.f;
+    if (row < rows && k < K) {
+      int tap = k / C, c = k - tap * C, kh = tap / it.KW, kw = tap - kh * it.KW;
+      if (it.mode == 0) v = it.w[(((int64_t)row * it.Cin + c) * it.KH + kh) * it.KW + kw];
+      else v = it.w[(((int64_t)c * it.Cin + row) * it.KH + (it.KH - 1 - kh)) * it.KW + (it.KW - 1 - kw)];
+    }
+    Elem<T>::st(&out[i], v);
+  }
+}
+__global__ __launch_bounds__(256) void pack_weights_batch_kernel(const PackItem* __restrict__ items) {
+  const PackItem it = items[blockIdx.y];
+  if (it.dtype == 0) pack_one<float>(it, blockIdx.x, gridDim.x);
+  else pack_one<bf16_t>(it, blockIdx.x, gridDim.x);
+}
+
 // ---- weight gradient ----------------------------------------------------------------------------------
 // dW[co, k] = sum_m dY[m, co] * Xg[m, k]   (Xg = the same gathered/virtual input as the forward).
 // Block = (k-tile of 128, cout-tile of 128, pixel split).  Reduction runs over pixels in stages of 32;
@@ -759,6 +788,11 @@ void launch_pack_weights(const float* w, void* out, int Cout, int Cin, int KH, i
     hipLaunchKernelGGL((pack_weights_kernel<float>), dim3(grid), dim3(256), 0, st, w, (float*)out, Cout, Cin, KH, KW, mode, rows_pad, Kpad);
   else
     hipLaunchKernelGGL((pack_weights_kernel<bf16_t>), dim3(grid), dim3(256), 0, st, w, (bf16_t*)out, Cout, Cin, KH, KW, mode, rows_pad, Kpad);
+}
+
+void launch_pack_weights_batch(const void* items, int n, hipStream_t st) {
+  static_assert(sizeof(PackItem) == 40, "PackItem mirrors rd_pack_item");
+  hipLaunchKernelGGL(pack_weights_batch_kernel, dim3(16, (unsigned)n), dim3(256), 0, st, (const PackItem*)items);
 }
 
 // split the pixel reduction so the launch has a few blocks per CU, stage-aligned

@@ -23,6 +23,20 @@ __global__ __launch_bounds__(256) void add_kernel(const T* __restrict__ a, const
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
     Elem<T>::st(out + i, Elem<T>::ld(a + i) + Elem<T>::ld(b + i));
 }
+// 16-byte vectors for the aligned body, scalars for the tail
+template <typename T>
+__global__ __launch_bounds__(256) void add_vec_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ out, int64_t n) {
+  constexpr int VE = Elem<T>::VE;
+  const int64_t nv = n / VE, stride = (int64_t)gridDim.x * blockDim.x, i0 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  for (int64_t i = i0; i < nv; i += stride) {
+    float x[VE], y[VE];
+    ldv(a + i * VE, x); ldv(b + i * VE, y);
+#pragma unroll
+    for (int e = 0; e < VE; e++) x[e] += y[e];
+    stv(out + i * VE, x);
+  }
+  for (int64_t i = nv * VE + i0; i < n; i += stride) Elem<T>::st(out + i, Elem<T>::ld(a + i) + Elem<T>::ld(b + i));
+}
 
 // [N][C][H][W] -> [N][H][W][C] (and back); small C on the hot path (3-channel thermal image), so a plain
 // gather with coalesced writes is enough.
@@ -111,6 +125,36 @@ __global__ __launch_bounds__(256) void upsample_nearest_bwd_kernel(const T* __re
   }
 }
 
+// 16-byte-vector form (C % VE == 0): one thread sums VE channels of a source pixel
+template <typename T>
+__global__ __launch_bounds__(256) void upsample_nearest_bwd_vec_kernel(const T* __restrict__ dy, T* __restrict__ dx, int N, int Hs, int Ws,
+                                                                       int Hv, int Wv, int C, float sh, float sw) {
+  constexpr int VE = Elem<T>::VE;
+  const int CV = C / VE;
+  const int64_t total = (int64_t)N * Hs * Ws * CV;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int cv = (int)(i % CV); int64_t q = i / CV;
+    int w = (int)(q % Ws); q /= Ws; int h = (int)(q % Hs); int n = (int)(q / Hs);
+    int h0 = (int)(((int64_t)h * Hv) / Hs) - 1, h1 = (int)(((int64_t)(h + 1) * Hv + Hs - 1) / Hs) + 1;
+    int w0 = (int)(((int64_t)w * Wv) / Ws) - 1, w1 = (int)(((int64_t)(w + 1) * Wv + Ws - 1) / Ws) + 1;
+    h0 = max(h0, 0); w0 = max(w0, 0); h1 = min(h1, Hv - 1); w1 = min(w1, Wv - 1);
+    float g[VE];
+#pragma unroll
+    for (int e = 0; e < VE; e++) g[e] = 0.f;
+    for (int hv = h0; hv <= h1; hv++) {
+      if (nearest_src(hv, sh, Hs) != h) continue;
+      for (int wv = w0; wv <= w1; wv++) {
+        if (nearest_src(wv, sw, Ws) != w) continue;
+        float v[VE];
+        ldv(dy + ((((int64_t)n * Hv + hv) * Wv + wv) * CV + cv) * VE, v);
+#pragma unroll
+        for (int e = 0; e < VE; e++) g[e] += v[e];
+      }
+    }
+    stv(dx + i * VE, g);
+  }
+}
+
 void launch_cast(const void* src, void* dst, int64_t n, int sd, int dd, float scale, hipStream_t st) {
   unsigned g = ew_grid(n);
   if (sd == 0 && dd == 0) hipLaunchKernelGGL((cast_kernel<float, float>), dim3(g), dim3(256), 0, st, (const float*)src, (float*)dst, n, scale);
@@ -119,6 +163,12 @@ void launch_cast(const void* src, void* dst, int64_t n, int sd, int dd, float sc
   else hipLaunchKernelGGL((cast_kernel<bf16_t, bf16_t>), dim3(g), dim3(256), 0, st, (const bf16_t*)src, (bf16_t*)dst, n, scale);
 }
 void launch_add(const void* a, const void* b, void* out, int64_t n, int dtype, hipStream_t st) {
+  if ((((uintptr_t)a | (uintptr_t)b | (uintptr_t)out) & 15) == 0) {
+    unsigned g = ew_grid(n / (dtype == 0 ? 4 : 8) + 1);
+    if (dtype == 0) hipLaunchKernelGGL((add_vec_kernel<float>), dim3(g), dim3(256), 0, st, (const float*)a, (const float*)b, (float*)out, n);
+    else hipLaunchKernelGGL((add_vec_kernel<bf16_t>), dim3(g), dim3(256), 0, st, (const bf16_t*)a, (const bf16_t*)b, (bf16_t*)out, n);
+    return;
+  }
   if (dtype == 0) hipLaunchKernelGGL((add_kernel<float>), dim3(ew_grid(n)), dim3(256), 0, st, (const float*)a, (const float*)b, (float*)out, n);
   else hipLaunchKernelGGL((add_kernel<bf16_t>), dim3(ew_grid(n)), dim3(256), 0, st, (const bf16_t*)a, (const bf16_t*)b, (bf16_t*)out, n);
 }
@@ -159,6 +209,13 @@ void launch_upsample_nearest_fwd(const void* x, void* y, int N, int Hs, int Ws, 
 }
 void launch_upsample_nearest_bwd(const void* dy, void* dx, int N, int Hs, int Ws, int Hv, int Wv, int C, int dtype, hipStream_t st) {
   float sh = (float)Hs / (float)Hv, sw = (float)Ws / (float)Wv;
+  const int ve = dtype == 0 ? 4 : 8;
+  if (C % ve == 0) {
+    unsigned gv = ew_grid((int64_t)N * Hs * Ws * (C / ve));
+    if (dtype == 0) hipLaunchKernelGGL((upsample_nearest_bwd_vec_kernel<float>), dim3(gv), dim3(256), 0, st, (const float*)dy, (float*)dx, N, Hs, Ws, Hv, Wv, C, sh, sw);
+    else hipLaunchKernelGGL((upsample_nearest_bwd_vec_kernel<bf16_t>), dim3(gv), dim3(256), 0, st, (const bf16_t*)dy, (bf16_t*)dx, N, Hs, Ws, Hv, Wv, C, sh, sw);
+    return;
+  }
   unsigned g = ew_grid((int64_t)N * Hs * Ws * C);
   if (dtype == 0) hipLaunchKernelGGL((upsample_nearest_bwd_kernel<float>), dim3(g), dim3(256), 0, st, (const float*)dy, (float*)dx, N, Hs, Ws, Hv, Wv, C, sh, sw);
   else hipLaunchKernelGGL((upsample_nearest_bwd_kernel<bf16_t>), dim3(g), dim3(256), 0, st, (const bf16_t*)dy, (bf16_t*)dx, N, Hs, Ws, Hv, Wv, C, sh, sw);

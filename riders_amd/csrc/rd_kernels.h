@@ -38,6 +38,7 @@ void launch_conv3x3_small(const ConvArgs& a, int dtype, hipStream_t st);
 bool conv3x3_c1_ok(const ConvArgs& a);
 void launch_conv3x3_c1(const ConvArgs& a, int dtype, hipStream_t st);
 void launch_pack_weights(const float* w, void* out, int Cout, int Cin, int KH, int KW, int mode, int dtype, hipStream_t st);
+void launch_pack_weights_batch(const void* items, int n, hipStream_t st);
 void launch_wgrad(WgradArgs a, int dtype, float* dw, int accumulate, hipStream_t st);
 
 // rd_norm.hip

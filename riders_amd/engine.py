@@ -329,6 +329,45 @@ def packed_weight(w, mode, dt):
 
 def clear_caches():
     _pack_cache.clear()
+    _pack_table.clear()
+
+
+_pack_table = {}
+
+
+def refresh_packed():
+    """Re-pack EVERY cached operand in one launch (rd_conv_pack_weights_batch).  Called by the optimizer right after it rewrote the
+    parameters in place: the cached buffers keep their addresses (hipGraph replays keep reading them) and the next forward finds
+    every operand fresh instead of issuing one pack launch per layer and direction."""
+    live = []
+    for wid, ent in list(_pack_cache.items()):
+        w = ent["ref"]()
+        if w is None:
+            continue
+        for k, hit in ent.items():
+            if k == "ref":
+                continue
+            mode, dt = k
+            key, buf = hit
+            if key != (w._version, mode, dt, w.data_ptr(), tuple(w.shape)):
+                ent.pop(k)          # written through torch since it was packed: falls back to an individual re-pack
+                continue
+            live.append((w, buf, mode, dt))
+    if not live:
+        return
+    sig = tuple((w.data_ptr(), buf.data_ptr(), mode, dt) for w, buf, mode, dt in live)
+    if _pack_table.get("sig") != sig:
+        items = (_lib.PackItem * len(live))()
+        for it, (w, buf, mode, dt) in zip(items, live):
+            cout, cin, kh, kw = w.shape if w.dim() == 4 else (w.shape[0], w.shape[1], 1, 1)
+            it.w, it.packed, it.Cout, it.Cin, it.KH, it.KW, it.mode, it.dtype = w.data_ptr(), buf.data_ptr(), cout, cin, kh, kw, mode, dt
+        host = torch.frombuffer(bytearray(bytes(items)), dtype=torch.uint8)
+        _pack_table["dev"] = host.to(live[0][0].device)
+        _pack_table["sig"] = sig
+        _pack_table["n"] = len(live)
+        _pack_table["keep"] = [b for _, b, _, _ in live]
+    w0 = live[0][0]
+    _chk(L().rd_conv_pack_weights_batch(_p(_pack_table["dev"]), _pack_table["n"], _stream(w0)), "rd_conv_pack_weights_batch")
 
 
 # ------------------------------------------------------------------------------------------ conv block

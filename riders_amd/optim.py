@@ -76,9 +76,7 @@ class FlatAdam(object):
                                      ctypes.c_float(g['betas'][1]), ctypes.c_float(g['eps']), ctypes.c_float(g['weight_decay']),
                                      self.step_count, ctypes.c_float(self.grad_scale), engine._stream(fp))
         engine._chk(rc, "rd_adam_step")
-        for p in self.params:  # packed weights are keyed on the parameter version
-            p._version_bump = None
-        engine.clear_caches()
+        engine.refresh_packed()   # one launch re-packs every cached MFMA operand of the rewritten parameters
 
     def state_dict(self):
         return dict(step=self.step_count, exp_avg=self.exp_avg, exp_avg_sq=self.exp_avg_sq, param_groups=[

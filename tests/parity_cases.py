@@ -484,3 +484,29 @@ def bf16_exact_conv_case(dev, cin=16, cout=16, k=3, s=1, H=9, W=7, N=2, up=None,
     if cin2:
         assert torch.equal(tape.grads[id(b)].float().permute(0, 3, 1, 2).cpu(), x2r.grad), "bf16 dgrad (src2) differs"
     assert torch.equal(tape.pgrads[id(w)].cpu(), wr.grad), "bf16 wgrad differs"
+
+
+def pack_batch_case(dev):
+    """rd_conv_pack_weights_batch (one launch for every cached operand) must reproduce the per-weight packing bit for bit."""
+    from riders_amd import engine
+    engine.clear_caches()
+    rs = np.random.RandomState(7)
+    ws = [torch.nn.Parameter(t(rs.randn(*shp).astype(np.float32), dev))
+          for shp in [(16, 16, 3, 3), (1, 16, 3, 3), (32, 3, 7, 7), (128, 64, 1, 1), (40, 24, 3, 3), (256, 128)]]
+    bufs = []
+    for dt in (engine.RD_F32, engine.RD_BF16):
+        for w in ws:
+            for mode in (0, 1):
+                bufs.append(engine.packed_weight(w, mode, dt))
+    want = [b.clone() for b in bufs]
+    for b in bufs:
+        b.zero_()
+    engine.refresh_packed()
+    for b, wnt in zip(bufs, want):
+        assert torch.equal(b.cpu().view(torch.uint8), wnt.cpu().view(torch.uint8))
+    # a parameter rewritten in place keeps its cache entry and picks up the new values on refresh
+    with torch.no_grad():
+        ws[0].data.mul_(2.0)
+    engine.refresh_packed()
+    assert torch.equal(engine.packed_weight(ws[0], 0, engine.RD_F32).cpu(), (want[0].cpu() * 2.0))
+    engine.clear_caches()

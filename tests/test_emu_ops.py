@@ -82,3 +82,7 @@ def test_bf16_exact_conv(emu):
     P.bf16_exact_conv_case(emu, cin=16, cout=16, k=3, s=1, N=1, up=((4, 3), (9, 6)), cin2=8)
     P.bf16_exact_conv_case(emu, cin=3, cout=32, k=7, s=2, H=14, W=12, N=1)
     P.bf16_exact_conv_case(emu, cin=128, cout=128, k=1, s=1, H=5, W=1, N=2)
+
+
+def test_pack_batch(emu):
+    P.pack_batch_case(emu)

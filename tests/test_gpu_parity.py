@@ -153,3 +153,7 @@ def test_graphed_step_matches_eager(gpu):
             assert nbt == 5, nbt
     for a, b in zip(losses["eager"], losses["graph"]):
         assert abs(a - b) <= 1e-3 * abs(a), losses  # atomics-order noise amplified by Adam's normalised first steps
+
+
+def test_pack_batch(gpu):
+    P.pack_batch_case(gpu)
