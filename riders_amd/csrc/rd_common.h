@@ -99,6 +99,24 @@ __device__ __forceinline__ f32x4 mfma_16x16x32_bf16(s16x8 a, s16x8 b, f32x4 c) {
 #endif
 }
 
+// LDS transpose read (ds_read_b64_tr_b16): every lane passes an 8-byte aligned LDS address of 4 consecutive 16-bit elements; within a
+// 16-lane group lane i receives out[j] = lds16[A_{4j + (i>>2)} + (i&3)], A_m = lane m's address.  The ISA text the programming guide
+// cites for this instruction is not in the build image; the mapping was measured on an MI355X (tools/probes/tr_b16_probe.hip ->
+// profiles/r01_tr_b16_probe.txt) and the host emulator models exactly that table.  Use: an NHWC (pixel-major) LDS image feeds MFMA
+// operands whose k axis is PIXELS (weight gradient) without a transposing store pass.
+__device__ __forceinline__ uint2 lds_read_tr16_b64(const void* p) {
+#ifdef RD_EMU
+  emu_u16x4 r = emu_ds_read_tr16_b64(p);
+  uint2 o; o.x = (unsigned)r.v[0] | ((unsigned)r.v[1] << 16); o.y = (unsigned)r.v[2] | ((unsigned)r.v[3] << 16);
+  return o;
+#else
+  typedef __bf16 rd_bf16x4 __attribute__((ext_vector_type(4)));
+  rd_bf16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((rd_bf16x4 __attribute__((address_space(3)))*)p);
+  uint2 o; __builtin_memcpy(&o, &v, 8);
+  return o;
+#endif
+}
+
 // ---- wave / block reductions ---------------------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -838,6 +838,11 @@ static void launch_wgrad_halo_t(const WgradArgs& a, int nblk, hipStream_t st) {
 
 void launch_wgrad(WgradArgs a, int dtype, float* dw, int accumulate, hipStream_t st) {
   const int Cin = a.C1 + a.C2;
+  if (wgrad3x3_tr_ok(a, dtype)) {  // bf16 narrow layers: transpose-read kernel, one slab per persistent block (<= HALO_BLOCKS)
+    launch_wgrad3x3_tr(a, st);
+    launch_wgrad_reduce(a.slab, dw, a.Cout, Cin, a.KH, a.KW, wgrad3x3_tr_blocks(a), accumulate, st);
+    return;
+  }
   if (wgrad_halo_ok(a, dtype)) {
     int TH, TW;
     halo_geom(Cin, a.Cout, TH, TW);

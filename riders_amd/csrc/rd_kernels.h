@@ -41,6 +41,11 @@ void launch_pack_weights(const float* w, void* out, int Cout, int Cin, int KH, i
 void launch_pack_weights_batch(const void* items, int n, hipStream_t st);
 void launch_wgrad(WgradArgs a, int dtype, float* dw, int accumulate, hipStream_t st);
 
+// rd_wgrad3x3.hip
+bool wgrad3x3_tr_ok(const WgradArgs& a, int dtype);
+int wgrad3x3_tr_blocks(const WgradArgs& a);
+void launch_wgrad3x3_tr(const WgradArgs& a, hipStream_t st);
+
 // rd_norm.hip
 void launch_bn_finalize(const float* partial, int rows, int C, double count, const float* gamma, const float* beta,
                         float eps, float momentum, int training, float* running_mean, float* running_var,

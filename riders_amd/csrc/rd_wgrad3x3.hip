@@ -1,0 +1,198 @@
+// bf16 weight gradient of narrow 3x3 / stride-1 layers (Cin in {16, 32, 64}, Cout <= 32) on the bf16 MFMA, fed by the gfx950 LDS
+// transpose read.
+//
+//   dW[co][tap][ci] = sum over pixels p of dY[p][co] * X[p + tap][ci]          (reference: autograd of utils/net_utils.py:84-91,195-198)
+//
+// The contraction axis is PIXELS, but activations are NHWC: a lane of v_mfma_f32_16x16x32_bf16 must hold 8 consecutive pixels of ONE
+// channel.  The earlier kernels either converted to fp32 and used the 16x16x4 fp32 MFMA (157 TF peak: the halo kernel, 0.56-0.93 ms on
+// RC-Net's ROI-resolution layers) or re-packed pixel pairs into 32-bit words with shifts/masks on the way into LDS.  Here the input
+// patch (rows+2) x (cols+2) x Cin and the dY tile are copied into LDS as they are (16-byte vectors, upsample / concat folded into the
+// gather) and ds_read_b64_tr_b16 delivers the transposed fragments: within a 16-lane group, lane m supplies the address of pixel
+// (m >> 2), channels 4*(m & 3)..+3, and lane i receives channel i of pixels 0..3 (mapping measured on the GPU, see rd_common.h).
+// Blocks are persistent over 8 x TW pixel tiles (next tile prefetched into registers, double-buffered LDS, one barrier per tile), keep
+// the fp32 accumulators of all nine taps in registers, and write ONE slab each; wgrad_reduce_kernel sums the slabs in a fixed order.
+#include "rd_conv_common.h"
+#include <type_traits>
+
+namespace rd {
+
+template <int CTI, int RT, int TW>
+__global__ __launch_bounds__(256) void conv3x3_wgrad_tr_kernel(WgradArgs a, int tilesH, int tilesW) {
+  typedef bf16_t T;
+  constexpr int CIN = CTI * 16, COP = RT * 16;
+  constexpr int TH = 8, WT = TW + 2, HT = TH + 2, NPX = HT * WT, NPY = TH * TW;
+  constexpr int XS = CIN / 8, YS = COP / 8;           // 16-byte slots per pixel
+  constexpr int NXS = NPX * XS, NYS = NPY * YS;
+  constexpr int XIT = (NXS + 255) / 256, YIT = (NYS + 255) / 256;
+  constexpr int KSTEPS = NPY / 32;                     // 32 pixels per MFMA k-step
+  constexpr int NCT = 9 * CTI, NCW = (NCT + 3) / 4;    // (tap, cin-tile) column tiles, per wave
+  constexpr int ASTEP = 32 * COP;                      // elements between k-steps in the dY tile (32 consecutive pixels)
+  constexpr int BSTEP = (TW == 16 ? 2 : 1) * WT * CIN; // ... in the patch (two rows of 16 or one row of 32)
+  __shared__ uint4 sX[2][NXS];
+  __shared__ uint4 sY[2][NYS];
+
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  const int fr = lane & 15, fg = lane >> 4;
+  ConvArgs g;
+  g.src1 = a.src1; g.src2 = a.src2; g.Hin = a.Hin; g.Win = a.Win; g.C1 = a.C1; g.C2 = a.C2; g.H1 = a.H1; g.W1 = a.W1;
+  g.dil = 1; g.ups = a.ups; g.scale_h = a.scale_h; g.scale_w = a.scale_w;
+
+  // persistent tile walk: XCD x owns a contiguous range of tiles (halo pixels shared by neighbouring tiles stay in its L2)
+  const int ntiles = a.N * tilesH * tilesW;
+  const int T8 = (ntiles + 7) >> 3, G8 = gridDim.x >> 3;
+  const int xcd = blockIdx.x & 7;
+  const int tend = min(ntiles, (xcd + 1) * T8);
+  int tile = xcd * T8 + (blockIdx.x >> 3);
+
+  // transpose-read roles.  k-step s, lane group fg: pixels (y, x0 .. x0+7) of the tile; this lane supplies pixel x0 + (fr >> 2) (+4
+  // for the second read) and channels 4*(fr & 3)..+3 of whichever 16-channel tile is being read.
+  const int yl = TW == 16 ? (fg >> 1) : 0, x0 = TW == 16 ? (fg & 1) * 8 : fg * 8;
+  const int aoff = ((yl * TW) + x0 + (fr >> 2)) * COP + (fr & 3) * 4;
+  const int boff = ((yl * WT) + x0 + (fr >> 2)) * CIN + (fr & 3) * 4;
+  int coloff[NCW]; bool jv[NCW]; int jk[NCW];
+#pragma unroll
+  for (int j = 0; j < NCW; j++) {
+    int idx = wv + 4 * j;
+    jv[j] = idx < NCT;
+    if (!jv[j]) idx = 0;
+    const int tap = idx / CTI, ct = idx - tap * CTI;
+    coloff[j] = ((tap / 3) * WT + (tap % 3)) * CIN + ct * 16;
+    jk[j] = tap * CIN + ct * 16;
+  }
+
+  f32x4 acc[RT][NCW];
+#pragma unroll
+  for (int i = 0; i < RT; i++)
+#pragma unroll
+    for (int j = 0; j < NCW; j++) acc[i][j] = f32x4{0, 0, 0, 0};
+
+  uint4 rx[XIT], ry[YIT];
+  const bool yvec = (a.Cout & 7) == 0;
+  auto fetch = [&](int tl) RD_INLINE_LAMBDA {
+    const int tw_ = tl % tilesW; const int q_ = tl / tilesW; const int th_ = q_ % tilesH; const int n = q_ / tilesH;
+    const int oh0 = th_ * TH, ow0 = tw_ * TW;
+#pragma unroll
+    for (int i = 0; i < XIT; i++) {
+      const int idx = t + 256 * i;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (idx < NXS) {
+        const int pp = idx / XS, sl = idx - pp * XS;
+        const int py = pp / WT, px = pp - py * WT;
+        const T* p;
+        if (conv_src_ptr<T>(g, n, oh0 - 1 + py, ow0 - 1 + px, sl * 8, p)) v = *reinterpret_cast<const uint4*>(p);
+      }
+      rx[i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < YIT; i++) {
+      const int idx = t + 256 * i;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (idx < NYS) {
+        const int pp = idx / YS, sl = idx - pp * YS;
+        const int py = pp / TW, px = pp - py * TW;
+        const int oh = oh0 + py, ow = ow0 + px;
+        if (oh < a.OH && ow < a.OW && sl * 8 < a.Cout) {
+          const T* p = (const T*)a.dy + (((int64_t)n * a.OH + oh) * a.OW + ow) * a.Cout + sl * 8;
+          if (yvec) v = *reinterpret_cast<const uint4*>(p);
+          else {  // Cout not a multiple of 8 (the 1-channel head): element-wise, zero padded
+            unsigned short e[8];
+#pragma unroll
+            for (int q = 0; q < 8; q++) e[q] = (sl * 8 + q < a.Cout) ? p[q].v : (unsigned short)0;
+            v.x = e[0] | ((unsigned)e[1] << 16); v.y = e[2] | ((unsigned)e[3] << 16);
+            v.z = e[4] | ((unsigned)e[5] << 16); v.w = e[6] | ((unsigned)e[7] << 16);
+          }
+        }
+      }
+      ry[i] = v;
+    }
+  };
+  auto stash = [&](int buf) RD_INLINE_LAMBDA {
+#pragma unroll
+    for (int i = 0; i < XIT; i++) { const int idx = t + 256 * i; if (idx < NXS) sX[buf][idx] = rx[i]; }
+#pragma unroll
+    for (int i = 0; i < YIT; i++) { const int idx = t + 256 * i; if (idx < NYS) sY[buf][idx] = ry[i]; }
+  };
+  auto compute = [&](int buf, auto njc) RD_INLINE_LAMBDA {
+    constexpr int NJ = decltype(njc)::value;
+    const unsigned short* bx = reinterpret_cast<const unsigned short*>(&sX[buf][0]) + boff;
+    const unsigned short* by = reinterpret_cast<const unsigned short*>(&sY[buf][0]) + aoff;
+#pragma unroll
+    for (int s = 0; s < KSTEPS; s++) {
+      s16x8 ya[RT];
+#pragma unroll
+      for (int i = 0; i < RT; i++) {
+        uint2 lo = lds_read_tr16_b64(by + s * ASTEP + i * 16), hi = lds_read_tr16_b64(by + s * ASTEP + i * 16 + 4 * COP);
+        uint4 v = make_uint4(lo.x, lo.y, hi.x, hi.y);
+        __builtin_memcpy(&ya[i], &v, 16);
+      }
+#pragma unroll
+      for (int j = 0; j < NJ; j++) {
+        uint2 lo = lds_read_tr16_b64(bx + s * BSTEP + coloff[j]), hi = lds_read_tr16_b64(bx + s * BSTEP + coloff[j] + 4 * CIN);
+        uint4 v = make_uint4(lo.x, lo.y, hi.x, hi.y);
+        s16x8 xb;
+        __builtin_memcpy(&xb, &v, 16);
+#pragma unroll
+        for (int i = 0; i < RT; i++) acc[i][j] = mfma_16x16x32_bf16(ya[i], xb, acc[i][j]);
+      }
+    }
+  };
+
+  if (tile < tend) fetch(tile);
+  int buf = 0;
+  while (tile < tend) {
+    stash(buf);
+    __syncthreads();
+    const int next = tile + G8;
+    if (next < tend) fetch(next);
+    // two fully unrolled bodies (a wave owns NCW or NCW-1 column tiles): a per-MFMA branch makes the compiler shuttle accumulators
+    if (jv[NCW - 1]) compute(buf, std::integral_constant<int, NCW>{});
+    else compute(buf, std::integral_constant<int, NCW - 1>{});
+    tile = next;
+    buf ^= 1;
+  }
+
+  float* slab = a.slab + (int64_t)blockIdx.x * a.Cout * a.K;
+#pragma unroll
+  for (int i = 0; i < RT; i++)
+#pragma unroll
+    for (int j = 0; j < NCW; j++)
+      if (jv[j]) {
+        const int k = jk[j] + fr;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const int co = i * 16 + fg * 4 + r;
+          if (co < a.Cout) slab[(int64_t)co * a.K + k] = acc[i][j][r];
+        }
+      }
+}
+
+// ---- host side -------------------------------------------------------------------------------------------------------------------
+bool wgrad3x3_tr_ok(const WgradArgs& a, int dtype) {
+  const int Cin = a.C1 + a.C2;
+  return dtype == 1 && a.KH == 3 && a.KW == 3 && a.stride == 1 && a.pad == 1 && (Cin == 16 || Cin == 32 || Cin == 64) && a.Cout <= 32 &&
+         (a.C1 % 8 == 0) && a.OH == a.Hin && a.OW == a.Win;
+}
+static int tr_tw(const WgradArgs& a) {
+  const int Cin = a.C1 + a.C2;
+  if (Cin == 64) return 16;  // LDS budget
+  return (cdiv(a.OW, 32) * 32 <= cdiv(a.OW, 16) * 16) ? 32 : 16;
+}
+int wgrad3x3_tr_blocks(const WgradArgs& a) {
+  const int tw = tr_tw(a);
+  const int64_t ntiles = (int64_t)a.N * cdiv(a.OH, 8) * cdiv(a.OW, tw);
+  const char* e = getenv("RD_CONV3X3_G8");  // test hook shared with the forward kernel
+  return 8 * (int)std::min<int64_t>(cdiv(ntiles, 8), e ? atoi(e) : 128);
+}
+void launch_wgrad3x3_tr(const WgradArgs& a, hipStream_t st) {
+  const int Cin = a.C1 + a.C2, cti = Cin / 16, rt = a.Cout <= 16 ? 1 : 2, tw = tr_tw(a);
+  const int tilesH = (int)cdiv(a.OH, 8), tilesW = (int)cdiv(a.OW, tw);
+  const int nblk = wgrad3x3_tr_blocks(a);
+#define RD_TR(CTIV, RTV, TWV) \
+  if (cti == CTIV && rt == RTV && tw == TWV) hipLaunchKernelGGL((conv3x3_wgrad_tr_kernel<CTIV, RTV, TWV>), dim3(nblk), dim3(256), 0, st, a, tilesH, tilesW);
+  RD_TR(1, 1, 16) RD_TR(1, 1, 32) RD_TR(1, 2, 16) RD_TR(1, 2, 32)
+  RD_TR(2, 1, 16) RD_TR(2, 1, 32) RD_TR(2, 2, 16) RD_TR(2, 2, 32)
+  RD_TR(4, 1, 16) RD_TR(4, 2, 16)
+#undef RD_TR
+}
+
+}  // namespace rd

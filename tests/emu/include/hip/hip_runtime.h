@@ -267,6 +267,25 @@ static inline emu_f32x4 emu_mfma_f32_16x16x4f32(float a, float b, emu_f32x4 c) {
   emu::wave_sync();
   return c;
 }
+// gfx950 ds_read_b64_tr_b16, modelled on the mapping MEASURED on an MI355X (tools/probes/tr_b16_probe.hip, output committed as
+// profiles/r01_tr_b16_probe.txt): within each 16-lane group, lane i receives out[j] = mem16[A_{4j + (i>>2)} + (i&3)], j = 0..3,
+// where A_m is the (8-byte aligned) address lane m of the group supplied.
+struct emu_u16x4 { unsigned short v[4]; };
+static inline emu_u16x4 emu_ds_read_tr16_b64(const void* addr) {
+  emu::Wave& w = emu::my_wave();
+  int l = emu::lane_id();
+  memcpy(w.buf[0][l], &addr, sizeof(addr));
+  emu::wave_sync();
+  emu_u16x4 o;
+  int base = l & ~15, i = l & 15;
+  for (int j = 0; j < 4; j++) {
+    const unsigned short* a;
+    memcpy(&a, w.buf[0][base + 4 * j + (i >> 2)], sizeof(a));
+    o.v[j] = a[i & 3];
+  }
+  emu::wave_sync();
+  return o;
+}
 // bf16: lane l supplies 8 consecutive k (k = 8*(l>>4)+e) of A row i=l&15 / B column j=l&15.
 static inline emu_f32x4 emu_mfma_f32_16x16x32_bf16(emu_s16x8 a, emu_s16x8 b, emu_f32x4 c) {
   emu::Wave& w = emu::my_wave();

@@ -84,5 +84,17 @@ def test_bf16_exact_conv(emu):
     P.bf16_exact_conv_case(emu, cin=128, cout=128, k=1, s=1, H=5, W=1, N=2)
 
 
+def test_bf16_wgrad_transpose_read(emu):
+    """bf16 weight gradient of narrow 3x3 layers through the LDS transpose read (rd_wgrad3x3.hip): every (Cin tile, Cout tile, tile
+    width) variant, the element-wise dY staging of the 1-channel head, ragged tiles and several tiles per persistent block."""
+    P.bf16_exact_conv_case(emu, cin=16, cout=1, k=3, s=1, H=9, W=20, N=1)
+    P.bf16_exact_conv_case(emu, cin=16, cout=32, k=3, s=1, H=8, W=33, N=1)
+    P.bf16_exact_conv_case(emu, cin=32, cout=24, k=3, s=1, H=11, W=16, N=2)
+    P.bf16_exact_conv_case(emu, cin=64, cout=32, k=3, s=1, H=9, W=17, N=1)
+    with P.force_patch_conv(g8=1):
+        P.bf16_exact_conv_case(emu, cin=16, cout=16, k=3, s=1, H=40, W=50, N=2)
+        P.bf16_exact_conv_case(emu, cin=16, cout=16, k=3, s=1, N=2, up=((13, 9), (27, 64)), cin2=16)
+
+
 def test_pack_batch(emu):
     P.pack_batch_case(emu)

@@ -155,5 +155,20 @@ def test_graphed_step_matches_eager(gpu):
         assert abs(a - b) <= 1e-3 * abs(a), losses  # atomics-order noise amplified by Adam's normalised first steps
 
 
+def test_bf16_wgrad_transpose_read(gpu):
+    """bf16 weight gradient of narrow 3x3 layers through the LDS transpose read (rd_wgrad3x3.hip), bit-exact on integer data."""
+    P.bf16_exact_conv_case(gpu, cin=16, cout=1, k=3, s=1, H=9, W=20, N=1)
+    P.bf16_exact_conv_case(gpu, cin=16, cout=32, k=3, s=1, H=8, W=33, N=1)
+    P.bf16_exact_conv_case(gpu, cin=32, cout=24, k=3, s=1, H=11, W=16, N=2)
+    P.bf16_exact_conv_case(gpu, cin=64, cout=32, k=3, s=1, H=9, W=17, N=1)
+    with P.force_patch_conv(g8=1):
+        P.bf16_exact_conv_case(gpu, cin=16, cout=16, k=3, s=1, H=40, W=50, N=2)
+        P.bf16_exact_conv_case(gpu, cin=16, cout=16, k=3, s=1, N=2, up=((13, 9), (27, 64)), cin2=16)
+    # full persistent grid (1024 blocks, several tiles each) at a slice of the ROI-resolution shapes
+    P.bf16_exact_conv_case(gpu, cin=16, cout=16, k=3, s=1, H=240, W=100, N=12)
+    P.bf16_exact_conv_case(gpu, cin=16, cout=16, k=3, s=1, N=12, up=((120, 50), (240, 100)), cin2=16)
+    P.bf16_exact_conv_case(gpu, cin=64, cout=32, k=3, s=1, H=120, W=50, N=12)
+
+
 def test_pack_batch(gpu):
     P.pack_batch_case(gpu)
