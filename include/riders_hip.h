@@ -64,6 +64,19 @@ typedef struct rd_pack_item {
   int32_t Cout, Cin, KH, KW, mode, dtype;
 } rd_pack_item;
 int rd_conv_pack_weights_batch(const rd_pack_item* items, int32_t n, void* stream);
+/* Weight gradients of MANY 1x1 / linear layers in one launch + one ordered reduction (reference: autograd of the nn.Linear layers of
+   RCNet/linear_attention.py:84-135; 96 products per RC-Net step).  gemm p: slab_p[split][Cout][C1+C2] = partial dY_p^T [X1_p | X2_p]
+   over tokens [split*rows_per_split, ...); C1, C2, Cout multiples of 64 (C2 = 0: x2 unused).  reduce q: dw_q[elems] (+)= sum of nsplit
+   consecutive slabs (several gemms that share a weight write consecutive slabs of one reduce item).  Both arrays are HOST memory. */
+typedef struct rd_lwg_gemm {
+  const void* x1; const void* x2; const void* dy; float* slab;
+  int32_t M, C1, C2, Cout, nsplit, rows_per_split;
+} rd_lwg_gemm;
+typedef struct rd_lwg_reduce {
+  const float* slab; float* dw; int64_t elems; int32_t nsplit, accumulate;
+} rd_lwg_reduce;
+int rd_linear_wgrad_batch(const rd_lwg_gemm* gemms, int32_t n_gemm, const rd_lwg_reduce* reduces, int32_t n_reduce, int32_t dtype,
+                          void* stream);
 /* rows of the per-block BatchNorm statistics buffer stats[rows][Cout][2] written by rd_conv_fwd */
 int32_t rd_conv_stats_rows(const rd_conv_desc* d);
 int rd_conv_fwd(const rd_conv_desc* d, const void* src1, const void* src2, const void* w_packed, const float* bias,

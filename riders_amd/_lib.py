@@ -39,6 +39,17 @@ class PackItem(ctypes.Structure):
                 ("KH", ctypes.c_int32), ("KW", ctypes.c_int32), ("mode", ctypes.c_int32), ("dtype", ctypes.c_int32)]
 
 
+class LwgGemm(ctypes.Structure):
+    _fields_ = [("x1", ctypes.c_void_p), ("x2", ctypes.c_void_p), ("dy", ctypes.c_void_p), ("slab", ctypes.c_void_p),
+                ("M", ctypes.c_int32), ("C1", ctypes.c_int32), ("C2", ctypes.c_int32), ("Cout", ctypes.c_int32),
+                ("nsplit", ctypes.c_int32), ("rows_per_split", ctypes.c_int32)]
+
+
+class LwgReduce(ctypes.Structure):
+    _fields_ = [("slab", ctypes.c_void_p), ("dw", ctypes.c_void_p), ("elems", ctypes.c_int64), ("nsplit", ctypes.c_int32),
+                ("accumulate", ctypes.c_int32)]
+
+
 _SCALARS = {
     "int": ctypes.c_int, "int32_t": ctypes.c_int32, "int64_t": ctypes.c_int64,
     "float": ctypes.c_float, "double": ctypes.c_double,

@@ -68,6 +68,23 @@ int rd_conv_pack_weights_batch(const rd_pack_item* items, int32_t n, void* strea
   rd::launch_pack_weights_batch(items, n, S(stream));
   return done("rd_conv_pack_weights_batch");
 }
+int rd_linear_wgrad_batch(const rd_lwg_gemm* gemms, int32_t n_gemm, const rd_lwg_reduce* reduces, int32_t n_reduce, int32_t dtype,
+                          void* stream) {
+  static_assert(sizeof(rd_lwg_gemm) == sizeof(rd::LwgGemm) && sizeof(rd_lwg_reduce) == sizeof(rd::LwgReduce), "ABI mirrors");
+  if (n_gemm <= 0) return 0;
+  if (!gemms || !reduces || n_reduce <= 0) return fail("linear_wgrad_batch: null table");
+  if (!dt_ok(dtype)) return fail("linear_wgrad_batch: bad dtype %d", dtype);
+  for (int i = 0; i < n_gemm; i++) {
+    const rd_lwg_gemm& g = gemms[i];
+    if (!g.x1 || !g.dy || !g.slab || (g.C2 > 0 && !g.x2)) return fail("linear_wgrad_batch: item %d has a null pointer", i);
+    if (g.M <= 0 || g.C1 <= 0 || (g.C1 & 63) || (g.C2 & 63) || (g.Cout & 63) || g.Cout <= 0) return fail("linear_wgrad_batch: item %d: channels must be multiples of 64", i);
+    if (g.nsplit <= 0 || g.rows_per_split <= 0 || (int64_t)g.nsplit * g.rows_per_split < g.M) return fail("linear_wgrad_batch: item %d: splits do not cover M", i);
+  }
+  for (int i = 0; i < n_reduce; i++)
+    if (!reduces[i].slab || !reduces[i].dw || reduces[i].elems <= 0 || reduces[i].nsplit <= 0) return fail("linear_wgrad_batch: bad reduce item %d", i);
+  rd::launch_linear_wgrad_batch(reinterpret_cast<const rd::LwgGemm*>(gemms), n_gemm, reinterpret_cast<const rd::LwgReduce*>(reduces), n_reduce, dtype, S(stream));
+  return done("rd_linear_wgrad_batch");
+}
 int32_t rd_conv_stats_rows(const rd_conv_desc* d) {
   rd::ConvArgs a; fill_args(d, a);
   return (int32_t)rd::conv_stats_rows(a, d->dtype);

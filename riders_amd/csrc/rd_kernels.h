@@ -46,6 +46,12 @@ bool wgrad3x3_tr_ok(const WgradArgs& a, int dtype);
 int wgrad3x3_tr_blocks(const WgradArgs& a);
 void launch_wgrad3x3_tr(const WgradArgs& a, hipStream_t st);
 
+// rd_linear_wgrad.hip (descriptors mirror rd_lwg_gemm / rd_lwg_reduce of the C ABI; passed BY VALUE in kernel arguments)
+struct LwgGemm { const void* x1; const void* x2; const void* dy; float* slab; int M, C1, C2, Cout, nsplit, rows_per_split; };
+struct LwgReduce { const float* slab; float* dw; int64_t elems; int nsplit, accumulate; };
+static const int LWG_MAX_ITEMS = 64, LWG_MAX_REDS = 96;   // 64 x 56 B and 96 x 32 B: both under the 4 KiB kernel-argument limit
+void launch_linear_wgrad_batch(const LwgGemm* gemms, int n_gemm, const LwgReduce* reds, int n_red, int dtype, hipStream_t st);
+
 // rd_norm.hip
 void launch_bn_finalize(const float* partial, int rows, int C, double count, const float* gamma, const float* beta,
                         float eps, float momentum, int training, float* running_mean, float* running_var,

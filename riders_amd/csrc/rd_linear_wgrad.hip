@@ -1,0 +1,174 @@
+// Grouped weight gradient of 1x1 / linear layers:  dW_p[Cout][Cin] = dY_p^T [Cout x M] . [X1_p | X2_p] [M x Cin]  for MANY layers p at once.
+//
+// RC-Net's LoFTR transformer (reference RCNet/linear_attention.py:84-135: q/k/v/merge projections and the two MLP linears of 16 layer
+// applications) has 96 such products per step with M = R*L = 5040 tokens and 128..256 channels: 26 GFLOP in total, but as 96 separate
+// weight-gradient + slab-reduce launches they cost 2.9 ms (15.7 + 8 us each, latency bound).  Here the engine defers them to the end
+// of the backward sweep and issues ONE launch over (layer, 64x64 output tile, token split) blocks plus ONE ordered reduction.
+// Descriptors travel by value in the kernel arguments (no device table, nothing to keep alive under hipGraph capture).
+// bf16: token-major tiles are copied to LDS as they are and the pixel(k)-major MFMA fragments come from ds_read_b64_tr_b16 (see
+// rd_common.h); fp32: v_mfma_f32_16x16x4_f32 takes one k per lane, so plain ds_read_b32 of the same image suffices.
+#include "rd_common.h"
+#include "rd_kernels.h"
+
+namespace rd {
+
+struct LwgBatch { LwgGemm it[LWG_MAX_ITEMS]; };
+struct LwgRedBatch { LwgReduce it[LWG_MAX_REDS]; };
+
+template <typename T>
+__global__ __launch_bounds__(256) void linear_wgrad_kernel(LwgBatch b) {
+  constexpr bool BF = sizeof(T) == 2;
+  constexpr int ST = BF ? 64 : 32;             // tokens per stage (a 64-channel row is 128 / 256 bytes)
+  constexpr int RS = BF ? 8 : 17;              // 16-byte slots per LDS row (fp32 rows padded by one slot: 4 k-groups on 4 bank sets)
+  constexpr int SPR = BF ? 8 : 16;             // data slots per row
+  constexpr int VE = Elem<T>::VE;
+  __shared__ uint4 sX[2][ST * RS];
+  __shared__ uint4 sY[2][ST * RS];
+  const LwgGemm& g = b.it[blockIdx.y];
+  const int Cin = g.C1 + g.C2;
+  const int tci = Cin >> 6, tco = g.Cout >> 6;
+  const int per = tci * tco;
+  if ((int)blockIdx.x >= per * g.nsplit) return;
+  const int sp = blockIdx.x / per, rem = blockIdx.x - sp * per;
+  const int co0 = (rem / tci) * 64, ci0 = (rem % tci) * 64;
+  const int mbeg = sp * g.rows_per_split, mend = min(g.M, mbeg + g.rows_per_split);
+  const T* xs; int xld, xc0;
+  if (ci0 < g.C1) { xs = (const T*)g.x1; xld = g.C1; xc0 = ci0; } else { xs = (const T*)g.x2; xld = g.C2; xc0 = ci0 - g.C1; }
+  const T* ys = (const T*)g.dy;
+
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  const int fr = lane & 15, fg = lane >> 4;
+  const int wr = wv >> 1, wc = wv & 1;        // wave tile: couts wr*32..+31, cins wc*32..+31
+
+  uint4 rx[2], ry[2];
+  auto fetch = [&](int m0) RD_INLINE_LAMBDA {
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      const int idx = t + 256 * i;             // ST * SPR = 512 slots per tile
+      const int row = idx / SPR, sl = idx - row * SPR;
+      const int m = m0 + row;
+      uint4 vx = make_uint4(0, 0, 0, 0), vy = vx;
+      if (m < mend) {
+        vx = *reinterpret_cast<const uint4*>(xs + (int64_t)m * xld + xc0 + sl * VE);
+        vy = *reinterpret_cast<const uint4*>(ys + (int64_t)m * g.Cout + co0 + sl * VE);
+      }
+      rx[i] = vx; ry[i] = vy;
+    }
+  };
+  auto stash = [&](int buf) RD_INLINE_LAMBDA {
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      const int idx = t + 256 * i;
+      const int row = idx / SPR, sl = idx - row * SPR;
+      sX[buf][row * RS + sl] = rx[i];
+      sY[buf][row * RS + sl] = ry[i];
+    }
+  };
+
+  f32x4 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++) acc[i][j] = f32x4{0, 0, 0, 0};
+
+  const int nst = mend > mbeg ? (mend - mbeg + ST - 1) / ST : 0;
+  if (nst > 0) fetch(mbeg);
+  for (int s = 0; s < nst; s++) {
+    const int buf = s & 1;
+    stash(buf);
+    __syncthreads();
+    if (s + 1 < nst) fetch(mbeg + (s + 1) * ST);
+    if (BF) {
+      // transpose-read roles: this lane supplies token (fg*8 + (fr>>2)) (+4), channels 4*(fr&3)..+3 of the 16-channel tile being read
+      const unsigned short* bx = reinterpret_cast<const unsigned short*>(&sX[buf][0]) + (fg * 8 + (fr >> 2)) * 64 + (fr & 3) * 4;
+      const unsigned short* by = reinterpret_cast<const unsigned short*>(&sY[buf][0]) + (fg * 8 + (fr >> 2)) * 64 + (fr & 3) * 4;
+#pragma unroll
+      for (int ks = 0; ks < 2; ks++) {
+        s16x8 ya[2], xb[2];
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+          const int o = ks * 32 * 64 + (wr * 2 + i) * 16;
+          uint2 lo = lds_read_tr16_b64(by + o), hi = lds_read_tr16_b64(by + o + 4 * 64);
+          uint4 v = make_uint4(lo.x, lo.y, hi.x, hi.y);
+          __builtin_memcpy(&ya[i], &v, 16);
+        }
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+          const int o = ks * 32 * 64 + (wc * 2 + j) * 16;
+          uint2 lo = lds_read_tr16_b64(bx + o), hi = lds_read_tr16_b64(bx + o + 4 * 64);
+          uint4 v = make_uint4(lo.x, lo.y, hi.x, hi.y);
+          __builtin_memcpy(&xb[j], &v, 16);
+        }
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+          for (int j = 0; j < 2; j++) acc[i][j] = mfma_16x16x32_bf16(ya[i], xb[j], acc[i][j]);
+      }
+    } else {
+      const float* fx = reinterpret_cast<const float*>(&sX[buf][0]);
+      const float* fy = reinterpret_cast<const float*>(&sY[buf][0]);
+#pragma unroll
+      for (int ks = 0; ks < ST / 4; ks++) {
+        const int row = (ks * 4 + fg) * RS * 4;
+        float ya[2], xb[2];
+#pragma unroll
+        for (int i = 0; i < 2; i++) ya[i] = fy[row + (wr * 2 + i) * 16 + fr];
+#pragma unroll
+        for (int j = 0; j < 2; j++) xb[j] = fx[row + (wc * 2 + j) * 16 + fr];
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+          for (int j = 0; j < 2; j++) acc[i][j] = mfma_16x16x4_f32(ya[i], xb[j], acc[i][j]);
+      }
+    }
+  }
+  float* slab = g.slab + (int64_t)sp * g.Cout * Cin;
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+      const int ci = ci0 + (wc * 2 + j) * 16 + fr;
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int co = co0 + (wr * 2 + i) * 16 + fg * 4 + r;
+        slab[(int64_t)co * Cin + ci] = acc[i][j][r];
+      }
+    }
+}
+
+// dw[e] (+)= slab[0][e] + slab[1][e] + ... in split order (deterministic)
+__global__ __launch_bounds__(256) void linear_wgrad_reduce_kernel(LwgRedBatch b) {
+  const LwgReduce& r = b.it[blockIdx.y];
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < r.elems; e += (int64_t)gridDim.x * 256) {
+    float s = 0.f;
+    for (int sp = 0; sp < r.nsplit; sp++) s += r.slab[(int64_t)sp * r.elems + e];
+    r.dw[e] = r.accumulate ? r.dw[e] + s : s;
+  }
+}
+
+void launch_linear_wgrad_batch(const LwgGemm* gemms, int n_gemm, const LwgReduce* reds, int n_red, int dtype, hipStream_t st) {
+  for (int base = 0; base < n_gemm; base += LWG_MAX_ITEMS) {
+    const int n = std::min(LWG_MAX_ITEMS, n_gemm - base);
+    LwgBatch b;
+    int maxb = 1;
+    for (int i = 0; i < n; i++) {
+      b.it[i] = gemms[base + i];
+      const LwgGemm& g = b.it[i];
+      maxb = std::max(maxb, ((g.C1 + g.C2) >> 6) * (g.Cout >> 6) * g.nsplit);
+    }
+    for (int i = n; i < LWG_MAX_ITEMS; i++) b.it[i] = b.it[0];
+    if (dtype == 0) hipLaunchKernelGGL((linear_wgrad_kernel<float>), dim3((unsigned)maxb, (unsigned)n), dim3(256), 0, st, b);
+    else hipLaunchKernelGGL((linear_wgrad_kernel<bf16_t>), dim3((unsigned)maxb, (unsigned)n), dim3(256), 0, st, b);
+  }
+  for (int base = 0; base < n_red; base += LWG_MAX_REDS) {
+    const int n = std::min(LWG_MAX_REDS, n_red - base);
+    LwgRedBatch b;
+    int64_t maxe = 1;
+    for (int i = 0; i < n; i++) { b.it[i] = reds[base + i]; maxe = std::max(maxe, b.it[i].elems); }
+    for (int i = n; i < LWG_MAX_REDS; i++) b.it[i] = b.it[0];
+    unsigned gx = (unsigned)std::min<int64_t>(cdiv(maxe, 256), 64);
+    hipLaunchKernelGGL(linear_wgrad_reduce_kernel, dim3(gx, (unsigned)n), dim3(256), 0, st, b);
+  }
+}
+
+}  // namespace rd

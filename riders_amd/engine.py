@@ -21,7 +21,13 @@ from ._lib import ACT_LRELU, ACT_NONE, ACT_RELU, ACT_RELU6, RD_BF16, RD_F32, Con
 _TORCH_DT = {RD_F32: torch.float32, RD_BF16: torch.bfloat16}
 _RD_DT = {torch.float32: RD_F32, torch.bfloat16: RD_BF16}
 
-_state = {"dtype": RD_F32, "tape": None}
+_state = {"dtype": RD_F32, "tape": None, "defer_wgrad": True}
+
+
+def set_defer_wgrad(flag):
+    """Group the weight gradients of 1x1 / linear layers into one launch at the end of each tape's backward (default on)."""
+    _state["defer_wgrad"] = bool(flag)
+
 
 
 def set_compute_dtype(dt):
@@ -119,6 +125,7 @@ class Tape:
         self.pgrads = {}   # id(param) -> fp32 gradient tensor
         self.params = {}   # id(param) -> param
         self.grad_alloc = None  # optional callable(param) -> preallocated fp32 grad view (flat arena)
+        self.deferred = []      # weight gradients of 1x1 / linear layers, issued as ONE grouped launch at the end of backward()
 
     def requires(self, *ts):
         return any(t is not None and id(t) in self.req for t in ts)
@@ -162,8 +169,58 @@ class Tape:
     def backward(self):
         for fn in reversed(self.nodes):
             fn()
+        self.flush_deferred()
         self.nodes = []
         self.keep = {}
+
+    def flush_deferred(self):
+        """rd_linear_wgrad_batch over every deferred (x, dy, weight): one launch + one ordered reduction instead of two small
+        latency-bound launches per layer (RC-Net's LoFTR transformer alone has 96 of them per step)."""
+        pending, self.deferred = self.deferred, []
+        by_dt = {}
+        for it in pending:                    # a tape may mix fp32 regions (RC-Net's point MLP) with bf16 ones: one batch per dtype
+            by_dt.setdefault(it["x"].dtype, []).append(it)
+        for items in by_dt.values():
+            self._flush_items(items)
+
+    def _flush_items(self, items):
+        lib = L()
+        groups = {}
+        for it in items:                      # several uses of one weight share a reduction (fixed order: first use first)
+            groups.setdefault(id(it["weight"]), []).append(it)
+        total = 0
+        for it in items:
+            M = it["M"]
+            it["rps"] = rps = 640 if M >= 2560 else max(64, (M + 3) // 4 + 63 & ~63)
+            it["nsplit"] = (M + rps - 1) // rps
+            it["off"] = total
+            total += it["nsplit"] * it["Cout"] * it["Cin"]
+        x0 = items[0]["x"]
+        ws = torch.empty(total, dtype=torch.float32, device=x0.device)
+        gem = (_lib.LwgGemm * len(items))()
+        red = (_lib.LwgReduce * len(groups))()
+        order, gi = [], 0
+        for grp in groups.values():           # slabs of one group must be consecutive: lay the items out group by group
+            order.extend(grp)
+        off = 0
+        for it in order:
+            it["off"] = off
+            off += it["nsplit"] * it["Cout"] * it["Cin"]
+        for k, it in enumerate(order):
+            g = gem[k]
+            g.x1, g.x2, g.dy = it["x"].data_ptr(), (0 if it["x2"] is None else it["x2"].data_ptr()), it["dy"].data_ptr()
+            g.slab = ws.data_ptr() + 4 * it["off"]
+            g.M, g.C1, g.C2, g.Cout, g.nsplit, g.rows_per_split = it["M"], it["C1"], it["C2"], it["Cout"], it["nsplit"], it["rps"]
+        for k, grp in enumerate(groups.values()):
+            w = grp[0]["weight"]
+            dw, acc = self.param_grad(w)
+            r = red[k]
+            r.slab, r.dw, r.elems = ws.data_ptr() + 4 * grp[0]["off"], dw.data_ptr(), grp[0]["Cout"] * grp[0]["Cin"]
+            r.nsplit, r.accumulate = sum(i["nsplit"] for i in grp), acc
+        flops = sum(i["flops"] for i in items)
+        dt, st = rd_of(x0), _stream(x0)
+        _chk(_timed("conv_wgrad", flops, lambda: lib.rd_linear_wgrad_batch(gem, len(items), red, len(groups), dt, st),
+                    "wgrad grouped linear n=%d" % len(items)), "rd_linear_wgrad_batch")
 
 
 def tape():
@@ -481,7 +538,10 @@ def conv_block(x, weight, *, x2=None, bias=None, stride=1, pad=None, up=None, bn
             rows = lib.rd_colsum_rows(pixels, Cout)
             part = torch.empty((rows, Cout, 2), dtype=torch.float32, device=x.device)
             _chk(lib.rd_colsum(_p(dy), _p(part), _p(db), acc, pixels, Cout, dt, st), "rd_colsum")
-        if w_req:
+        if w_req and KH == 1 and KW == 1 and stride == 1 and not is_up and C1 % 64 == 0 and C2 % 64 == 0 and Cout % 64 == 0 \
+                and _state["defer_wgrad"]:
+            t.deferred.append(dict(x=x, x2=x2, dy=dy, weight=weight, M=pixels, C1=C1, C2=C2, Cin=Cin, Cout=Cout, flops=flops))
+        elif w_req:
             dw, acc = t.param_grad(weight)
             ws = torch.empty(lib.rd_conv_wgrad_workspace_bytes(ctypes.byref(d)) // 4, dtype=torch.float32, device=x.device)
             _chk(_timed("conv_wgrad", flops, lambda: lib.rd_conv_wgrad(ctypes.byref(d), _p(x), _p(x2), _p(dy), _p(ws), _p(dw), acc, st),

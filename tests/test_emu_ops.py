@@ -96,5 +96,14 @@ def test_bf16_wgrad_transpose_read(emu):
         P.bf16_exact_conv_case(emu, cin=16, cout=16, k=3, s=1, N=2, up=((13, 9), (27, 64)), cin2=16)
 
 
+def test_grouped_linear_wgrad(emu):
+    """rd_linear_wgrad_batch (deferred, grouped weight gradients of 1x1 / linear layers): bf16 transpose-read and fp32 paths, two-source
+    concat, several token splits, ragged last stage."""
+    P.bf16_exact_conv_case(emu, cin=64, cout=192, k=1, s=1, H=9, W=7, N=3, cin2=64)
+    P.bf16_exact_conv_case(emu, cin=128, cout=64, k=1, s=1, H=41, W=17, N=1)
+    P.conv_case(emu, dict(cin=128, cout=64, k=1, s=1, H=13, W=11, N=2, bn=False, act=None))
+    P.conv_case(emu, dict(cin=64, cout=128, k=1, s=1, H=30, W=23, N=1, bn=True))
+
+
 def test_pack_batch(emu):
     P.pack_batch_case(emu)

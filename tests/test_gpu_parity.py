@@ -170,5 +170,15 @@ def test_bf16_wgrad_transpose_read(gpu):
     P.bf16_exact_conv_case(gpu, cin=64, cout=32, k=3, s=1, H=120, W=50, N=12)
 
 
+def test_grouped_linear_wgrad(gpu):
+    """rd_linear_wgrad_batch: bit-exact bf16 (transpose-read MFMA operands) and 1e-3 fp32 against the oracle, LoFTR-sized token counts."""
+    P.bf16_exact_conv_case(gpu, cin=64, cout=192, k=1, s=1, H=9, W=7, N=3, cin2=64)
+    P.bf16_exact_conv_case(gpu, cin=128, cout=64, k=1, s=1, H=41, W=17, N=1)
+    P.bf16_exact_conv_case(gpu, cin=128, cout=256, k=1, s=1, H=240, W=21, N=1, cin2=128)
+    P.conv_case(gpu, dict(cin=128, cout=64, k=1, s=1, H=13, W=11, N=2, bn=False, act=None))
+    P.conv_case(gpu, dict(cin=64, cout=128, k=1, s=1, H=30, W=23, N=1, bn=True))
+    P.conv_case(gpu, dict(cin=128, cout=128, k=1, s=1, H=240, W=21, N=1, bn=False, act=None))
+
+
 def test_pack_batch(gpu):
     P.pack_batch_case(gpu)
