@@ -77,6 +77,32 @@ typedef struct rd_lwg_reduce {
 } rd_lwg_reduce;
 int rd_linear_wgrad_batch(const rd_lwg_gemm* gemms, int32_t n_gemm, const rd_lwg_reduce* reduces, int32_t n_reduce, int32_t dtype,
                           void* stream);
+/* ---- fused LoFTR encoder layer (reference RCNet/linear_attention.py:84-135, LoFTREncoderLayer.forward; d_model = 128, nhead = 8,
+   attention = 'linear', at most 32 tokens per sequence): x [N][L][128], src [N][S][128] (src == x: self attention), one workgroup per
+   sequence.  Weights are rd_conv_pack_weights operands of the six nn.Linear layers (mode 0 for the forward, mode 1 for the backward);
+   g1/b1/g2/b2 are norm1 / norm2 weight and bias (fp32).  The forward fills `saved` (activation dtype; stats fp32 [N*L][4] = mean1,
+   rstd1, mean2, rstd2); the backward consumes it and writes dx [, dsrc], the LayerNorm parameter gradients, and the output gradients of
+   the six linears (dq, dk, dv, dmpre, dhid, dm2pre) whose weight gradients are then one rd_linear_wgrad_batch call:
+     Wq: (x, dq)  Wk: (src, dk)  Wv: (src, dv)  Wm: (att, dmpre)  W0: ([x | msg], dhid)  W2: (hid, dm2pre).
+   lnp1 / lnp2 are [N][128][2] fp32 scratch. */
+typedef struct rd_loftr_weights {
+  const void *wq, *wk, *wv, *wm, *w0, *w2;
+  const float *g1, *b1, *g2, *b2;
+} rd_loftr_weights;
+typedef struct rd_loftr_saved {
+  void *q, *k, *v, *att, *mpre, *msg, *hid, *m2pre;
+  float* stats;
+} rd_loftr_saved;
+typedef struct rd_loftr_grads {
+  const void* dout;
+  void *dm2pre, *dhid, *dmpre, *datt, *dq, *dk, *dv, *dx, *dsrc;
+  float *lnp1, *lnp2, *dg1, *db1, *dg2, *db2;
+  int32_t accumulate, reserved;
+} rd_loftr_grads;
+int rd_loftr_layer_fwd(const void* x, const void* src, const rd_loftr_weights* w, void* out, const rd_loftr_saved* saved, int32_t N,
+                       int32_t L, int32_t S, float eps_attn, float eps_ln, int32_t dtype, void* stream);
+int rd_loftr_layer_bwd(const void* x, const void* src, const rd_loftr_weights* w_t, const rd_loftr_saved* saved,
+                       const rd_loftr_grads* grads, int32_t N, int32_t L, int32_t S, float eps_attn, int32_t dtype, void* stream);
 /* rows of the per-block BatchNorm statistics buffer stats[rows][Cout][2] written by rd_conv_fwd */
 int32_t rd_conv_stats_rows(const rd_conv_desc* d);
 int rd_conv_fwd(const rd_conv_desc* d, const void* src1, const void* src2, const void* w_packed, const float* bias,

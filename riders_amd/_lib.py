@@ -50,6 +50,23 @@ class LwgReduce(ctypes.Structure):
                 ("accumulate", ctypes.c_int32)]
 
 
+def _ptr_struct(names):
+    return [(n, ctypes.c_void_p) for n in names]
+
+
+class LoftrWeights(ctypes.Structure):
+    _fields_ = _ptr_struct(["wq", "wk", "wv", "wm", "w0", "w2", "g1", "b1", "g2", "b2"])
+
+
+class LoftrSaved(ctypes.Structure):
+    _fields_ = _ptr_struct(["q", "k", "v", "att", "mpre", "msg", "hid", "m2pre", "stats"])
+
+
+class LoftrGrads(ctypes.Structure):
+    _fields_ = _ptr_struct(["dout", "dm2pre", "dhid", "dmpre", "datt", "dq", "dk", "dv", "dx", "dsrc", "lnp1", "lnp2", "dg1", "db1",
+                            "dg2", "db2"]) + [("accumulate", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+
+
 _SCALARS = {
     "int": ctypes.c_int, "int32_t": ctypes.c_int32, "int64_t": ctypes.c_int64,
     "float": ctypes.c_float, "double": ctypes.c_double,

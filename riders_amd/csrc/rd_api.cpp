@@ -85,6 +85,31 @@ int rd_linear_wgrad_batch(const rd_lwg_gemm* gemms, int32_t n_gemm, const rd_lwg
   rd::launch_linear_wgrad_batch(reinterpret_cast<const rd::LwgGemm*>(gemms), n_gemm, reinterpret_cast<const rd::LwgReduce*>(reduces), n_reduce, dtype, S(stream));
   return done("rd_linear_wgrad_batch");
 }
+int rd_loftr_layer_fwd(const void* x, const void* src, const rd_loftr_weights* w, void* out, const rd_loftr_saved* sv, int32_t N,
+                       int32_t L, int32_t S, float eps_attn, float eps_ln, int32_t dtype, void* stream) {
+  static_assert(sizeof(rd_loftr_weights) == sizeof(rd::LoftrW) && sizeof(rd_loftr_saved) == sizeof(rd::LoftrSaved) &&
+                sizeof(rd_loftr_grads) == sizeof(rd::LoftrGrads), "ABI mirrors");
+  if (!x || !src || !w || !out || !sv) return fail("loftr_layer_fwd: null pointer");
+  if (!dt_ok(dtype)) return fail("loftr_layer_fwd: bad dtype %d", dtype);
+  if (N < 0 || L <= 0 || S <= 0 || L > 32 || S > 32) return fail("loftr_layer_fwd: needs 1..32 tokens per sequence (L=%d S=%d)", L, S);
+  if (!w->wq || !w->wk || !w->wv || !w->wm || !w->w0 || !w->w2 || !w->g1 || !w->b1 || !w->g2 || !w->b2) return fail("loftr_layer_fwd: null weight");
+  if (!sv->q || !sv->k || !sv->v || !sv->att || !sv->mpre || !sv->msg || !sv->hid || !sv->m2pre || !sv->stats) return fail("loftr_layer_fwd: null saved buffer");
+  rd::launch_loftr_layer_fwd(x, src, *reinterpret_cast<const rd::LoftrW*>(w), out, *reinterpret_cast<const rd::LoftrSaved*>(sv), N, L, S,
+                             eps_attn, eps_ln, dtype, (hipStream_t)stream);
+  return done("rd_loftr_layer_fwd");
+}
+int rd_loftr_layer_bwd(const void* x, const void* src, const rd_loftr_weights* w, const rd_loftr_saved* sv, const rd_loftr_grads* g,
+                       int32_t N, int32_t L, int32_t S, float eps_attn, int32_t dtype, void* stream) {
+  if (!x || !src || !w || !sv || !g) return fail("loftr_layer_bwd: null pointer");
+  if (!dt_ok(dtype)) return fail("loftr_layer_bwd: bad dtype %d", dtype);
+  if (N < 0 || L <= 0 || S <= 0 || L > 32 || S > 32) return fail("loftr_layer_bwd: needs 1..32 tokens per sequence (L=%d S=%d)", L, S);
+  if (!g->dout || !g->dm2pre || !g->dhid || !g->dmpre || !g->datt || !g->dq || !g->dk || !g->dv || !g->dx || (src != x && !g->dsrc))
+    return fail("loftr_layer_bwd: null gradient buffer");
+  if (!g->lnp1 || !g->lnp2 || !g->dg1 || !g->db1 || !g->dg2 || !g->db2) return fail("loftr_layer_bwd: null LayerNorm gradient buffer");
+  rd::launch_loftr_layer_bwd(x, src, *reinterpret_cast<const rd::LoftrW*>(w), *reinterpret_cast<const rd::LoftrSaved*>(sv),
+                             *reinterpret_cast<const rd::LoftrGrads*>(g), N, L, S, eps_attn, dtype, (hipStream_t)stream);
+  return done("rd_loftr_layer_bwd");
+}
 int32_t rd_conv_stats_rows(const rd_conv_desc* d) {
   rd::ConvArgs a; fill_args(d, a);
   return (int32_t)rd::conv_stats_rows(a, d->dtype);

@@ -8,43 +8,9 @@
 // One wave owns one (n, h) pair: the three 21x16 head slices are staged in LDS (rows padded to 32 with zeros),
 // the two contractions K^T V (16x16x32) and Q KV (32x16x16) run on v_mfma_f32_16x16x4_f32 (exact fp32),
 // the normaliser on the VALU.  The backward recomputes KV / P from q,k,v (nothing but q,k,v is saved).
-#include "rd_common.h"
-#include "rd_kernels.h"
+#include "rd_attention_head.h"
 
 namespace rd {
-
-static constexpr int LD = 17;    // padded row pitch (floats) of the [rows][16] LDS tiles
-static constexpr int MAXR = 32;  // max tokens per sequence handled by this kernel
-
-// acc(16x16) += A(16xK) * B(Kx16); A(i,k) = a[i*ai + k*ak], B(k,j) = b[k*bk + j*bj]; K % 4 == 0.
-// lane (r = lane&15, g = lane>>4) ends with D[row = g*4 + reg][col = r].
-__device__ __forceinline__ f32x4 wave_mm(const float* a, int ai, int ak, const float* b, int bk, int bj, int K, f32x4 acc) {
-  const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
-  for (int k0 = 0; k0 < K; k0 += 4) acc = mfma_16x16x4_f32(a[r * ai + (k0 + g) * ak], b[(k0 + g) * bk + r * bj], acc);
-  return acc;
-}
-
-struct AttnSmem {
-  float q[MAXR * LD], k[MAXR * LD], v[MAXR * LD], d[MAXR * LD];
-  float kv[16 * LD], dkv[16 * LD];
-  float ksum[16], dksum[16], dden[MAXR];
-};
-
-template <typename T>
-__device__ __forceinline__ void stage_head(const T* __restrict__ src, int64_t row0, int ld, int col0, int rows, float* dst,
-                                            int mode, float scale, bool active) {
-  // mode 0: raw*scale, mode 1: elu(x)+1
-  const int lane = threadIdx.x & 63;
-  for (int idx = lane; idx < MAXR * 16; idx += 64) {
-    int r = idx >> 4, c = idx & 15;
-    float x = 0.f;
-    if (active && r < rows) {
-      x = Elem<T>::ld(src + (row0 + r) * ld + col0 + c);
-      x = mode ? (x > 0.f ? x + 1.f : __expf(x)) : x * scale;
-    }
-    dst[r * LD + c] = x;
-  }
-}
 
 template <typename T, bool BWD>
 __global__ __launch_bounds__(256) void linear_attention_kernel(const T* __restrict__ q, const T* __restrict__ k,
@@ -53,125 +19,11 @@ __global__ __launch_bounds__(256) void linear_attention_kernel(const T* __restri
                                                                T* __restrict__ dv, int N, int L, int S, int H, int ldq,
                                                                int ldk, int ldv, int ldo, float eps) {
   __shared__ AttnSmem sm[4];
-  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-  const int r = lane & 15, g = lane >> 4;
-  AttnSmem& s = sm[wv];
+  const int wv = threadIdx.x >> 6;
   const int pair = blockIdx.x * 4 + wv;
   const bool active = pair < N * H;
   const int n = active ? pair / H : 0, h = active ? pair % H : 0;
-  const int col0 = h * 16;
-  const float fS = (float)S;
-  const int Lp = (L + 3) & ~3, Sp = (S + 3) & ~3;
-  const int lt = (L + 15) >> 4, stl = (S + 15) >> 4;  // 16-row tiles
-
-  stage_head<T>(q, (int64_t)n * L, ldq, col0, L, s.q, 1, 1.f, active);
-  stage_head<T>(k, (int64_t)n * S, ldk, col0, S, s.k, 1, 1.f, active);
-  stage_head<T>(v, (int64_t)n * S, ldv, col0, S, s.v, 0, 1.f / fS, active);
-  if (BWD) stage_head<T>(dout, (int64_t)n * L, ldo, col0, L, s.d, 0, 1.f, active);
-  __syncthreads();
-
-  // KV = K^T V  (16 x 16), Ksum
-  {
-    f32x4 acc = f32x4{0, 0, 0, 0};
-    acc = wave_mm(s.k, 1, LD, s.v, LD, 1, Sp, acc);
-#pragma unroll
-    for (int e = 0; e < 4; e++) s.kv[(g * 4 + e) * LD + r] = acc[e];
-    if (lane < 16) {
-      float t = 0.f;
-      for (int ss = 0; ss < S; ss++) t += s.k[ss * LD + lane];
-      s.ksum[lane] = t;
-    }
-  }
-  __syncthreads();
-
-  // P = Q KV, normaliser
-  f32x4 P[2]; float Z[2][4];
-#pragma unroll
-  for (int tI = 0; tI < 2; tI++) {
-    P[tI] = f32x4{0, 0, 0, 0};
-    if (tI < lt) P[tI] = wave_mm(s.q + tI * 16 * LD, LD, 1, s.kv, LD, 1, 16, P[tI]);
-#pragma unroll
-    for (int e = 0; e < 4; e++) {
-      int l = tI * 16 + g * 4 + e;
-      float den = eps;
-      for (int dd = 0; dd < 16; dd++) den += s.q[l * LD + dd] * s.ksum[dd];
-      Z[tI][e] = 1.f / den;
-    }
-  }
-
-  if (!BWD) {
-#pragma unroll
-    for (int tI = 0; tI < 2; tI++)
-#pragma unroll
-      for (int e = 0; e < 4; e++) {
-        int l = tI * 16 + g * 4 + e;
-        if (active && l < L) Elem<T>::st(out + ((int64_t)n * L + l) * ldo + col0 + r, P[tI][e] * Z[tI][e] * fS);
-      }
-    return;
-  }
-
-  // ---- backward ------------------------------------------------------------------------------------------
-  // dP = S*Z*dO (in place over s.d), dden = -Z^2 * S * sum_e P*dO
-#pragma unroll
-  for (int tI = 0; tI < 2; tI++)
-#pragma unroll
-    for (int e = 0; e < 4; e++) {
-      int l = tI * 16 + g * 4 + e;
-      float dO = s.d[l * LD + r];
-      float dz = P[tI][e] * dO;
-#pragma unroll
-      for (int o = 1; o < 16; o <<= 1) dz += __shfl_xor(dz, o);
-      s.d[l * LD + r] = fS * Z[tI][e] * dO;
-      if (r == 0) s.dden[l] = -Z[tI][e] * Z[tI][e] * fS * dz;
-    }
-  __syncthreads();
-
-  // dQ = dP KV^T + dden * Ksum ; dq = dQ * phi'(q)
-#pragma unroll
-  for (int tI = 0; tI < 2; tI++) {
-    if (tI < lt) {
-      f32x4 a = f32x4{0, 0, 0, 0};
-      a = wave_mm(s.d + tI * 16 * LD, LD, 1, s.kv, 1, LD, 16, a);
-#pragma unroll
-      for (int e = 0; e < 4; e++) {
-        int l = tI * 16 + g * 4 + e;
-        float Q = s.q[l * LD + r];
-        float gq = (a[e] + s.dden[l] * s.ksum[r]) * (Q > 1.f ? 1.f : Q);
-        if (active && l < L) Elem<T>::st(dq + ((int64_t)n * L + l) * ldq + col0 + r, gq);
-      }
-    }
-  }
-  // dKV = Q^T dP (16 x 16), dKsum = sum_l dden[l] Q[l,:]
-  {
-    f32x4 a = f32x4{0, 0, 0, 0};
-    a = wave_mm(s.q, 1, LD, s.d, LD, 1, Lp, a);
-#pragma unroll
-    for (int e = 0; e < 4; e++) s.dkv[(g * 4 + e) * LD + r] = a[e];
-    if (lane < 16) {
-      float t = 0.f;
-      for (int l = 0; l < L; l++) t += s.dden[l] * s.q[l * LD + lane];
-      s.dksum[lane] = t;
-    }
-  }
-  __syncthreads();
-  // dK = V' dKV^T + dKsum ; dV' = K dKV
-#pragma unroll
-  for (int tI = 0; tI < 2; tI++) {
-    if (tI < stl) {
-      f32x4 a = f32x4{0, 0, 0, 0}, b = f32x4{0, 0, 0, 0};
-      a = wave_mm(s.v + tI * 16 * LD, LD, 1, s.dkv, 1, LD, 16, a);
-      b = wave_mm(s.k + tI * 16 * LD, LD, 1, s.dkv, LD, 1, 16, b);
-#pragma unroll
-      for (int e = 0; e < 4; e++) {
-        int ss = tI * 16 + g * 4 + e;
-        float K = s.k[ss * LD + r];
-        if (active && ss < S) {
-          Elem<T>::st(dk + ((int64_t)n * S + ss) * ldk + col0 + r, (a[e] + s.dksum[r]) * (K > 1.f ? 1.f : K));
-          Elem<T>::st(dv + ((int64_t)n * S + ss) * ldv + col0 + r, b[e] / fS);
-        }
-      }
-    }
-  }
+  attn_head<T, BWD>(sm[wv], q, k, v, dout, out, dq, dk, dv, n, h, active, L, S, ldq, ldk, ldv, ldo, eps);
 }
 
 void launch_linear_attention_fwd(const void* q, const void* k, const void* v, void* out, int N, int L, int S, int H, int ldq,

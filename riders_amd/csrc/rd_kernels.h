@@ -52,6 +52,18 @@ struct LwgReduce { const float* slab; float* dw; int64_t elems; int nsplit, accu
 static const int LWG_MAX_ITEMS = 64, LWG_MAX_REDS = 96;   // 64 x 56 B and 96 x 32 B: both under the 4 KiB kernel-argument limit
 void launch_linear_wgrad_batch(const LwgGemm* gemms, int n_gemm, const LwgReduce* reds, int n_red, int dtype, hipStream_t st);
 
+// rd_loftr.hip (structs mirror rd_loftr_weights / rd_loftr_saved / rd_loftr_grads of the C ABI)
+struct LoftrW { const void *wq, *wk, *wv, *wm, *w0, *w2; const float *g1, *b1, *g2, *b2; };
+struct LoftrSaved { void *q, *k, *v, *att, *mpre, *msg, *hid, *m2pre; float* stats; };
+struct LoftrGrads {
+  const void* dout; void *dm2pre, *dhid, *dmpre, *datt, *dq, *dk, *dv, *dx, *dsrc;
+  float *lnp1, *lnp2, *dg1, *db1, *dg2, *db2; int accumulate, pad_;
+};
+void launch_loftr_layer_fwd(const void* x, const void* src, const LoftrW& w, void* out, const LoftrSaved& sv, int N, int L, int S,
+                            float eps_attn, float eps_ln, int dtype, hipStream_t st);
+void launch_loftr_layer_bwd(const void* x, const void* src, const LoftrW& w, const LoftrSaved& sv, const LoftrGrads& gr, int N, int L,
+                            int S, float eps_attn, int dtype, hipStream_t st);
+
 // rd_norm.hip
 void launch_bn_finalize(const float* partial, int rows, int C, double count, const float* gamma, const float* beta,
                         float eps, float momentum, int training, float* running_mean, float* running_var,

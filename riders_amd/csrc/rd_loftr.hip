@@ -1,0 +1,389 @@
+// Fused LoFTR encoder layer (forward and backward), one workgroup per ROI.
+//
+// Reference: RCNet/linear_attention.py:84-135 (LoFTREncoderLayer.forward):
+//   q = Wq x, k = Wk src, v = Wv src;  message = LinearAttention(q, k, v);  message = norm1(Wm message);
+//   message = norm2(W2 relu(W0 [x | message]));  return x + message
+// RC-Net applies it 16 times per step to R = 240 ROIs x L = 21 tokens x C = 128 channels.  As separate launches that is ~600 small
+// latency-bound kernels (3.5 ms of a 17 ms step, 26 GFLOP).  Every ROI is independent through the whole layer, so here a workgroup
+// keeps one ROI's token tile (21 rows padded to 32) in LDS and walks the layer: six token GEMMs on the MFMA (weights streamed from
+// L2 in fragment layout, tokens are the B operand so padded rows never contaminate real ones), the per-head linear attention of
+// rd_attention_head.h, LayerNorm on the VALU.  Intermediates the backward / the weight gradients need are written once to HBM
+// (q, k, v, attention output, pre-norm activations, hidden) -- 21 x 1.3 K elements per ROI.  The backward kernel mirrors the walk with the
+// transposed (mode 1) packed weights and leaves (input, output-gradient) pairs for the grouped weight gradient (rd_linear_wgrad.hip);
+// LayerNorm parameter gradients leave per-ROI partials that bn_bwd_finalize sums in a fixed order.
+#include "rd_attention_head.h"
+
+namespace rd {
+
+static constexpr int LC = 128, LC2 = 256, LTOK = 32, LF = 132;   // channels, hidden, padded tokens, float row pitch
+static constexpr int LNW = 8, LNT = LNW * 64;                     // waves / threads per workgroup: one attention head per wave, two waves
+                                                                  // per SIMD (the layer is a chain of short latency-bound phases)
+
+template <typename T> struct LoftrGeom {
+  static constexpr int PADE = 16 / (int)sizeof(T);        // one 16-byte slot of padding per row: 16 token rows land on 16 bank groups
+  static constexpr int LDA = LC + PADE, LDH = LC2 + PADE;
+};
+
+template <typename T>
+struct LoftrSmemFwd {
+  T bX[LTOK * LoftrGeom<T>::LDA], bS[LTOK * LoftrGeom<T>::LDA], bM[LTOK * LoftrGeom<T>::LDA];
+  union U {
+    AttnSmem at[LNW];
+    struct FH { float f[LTOK * LF]; T h[LTOK * LoftrGeom<T>::LDH]; } fh;
+  } u;
+};
+template <typename T>
+struct LoftrSmemBwd {
+  T bD[LTOK * LoftrGeom<T>::LDA];
+  float acc[LTOK * LF];
+  float red[LNW][2][LC];
+  union U {
+    AttnSmem at[LNW];
+    struct FH { float f[LTOK * LF]; T h[LTOK * LoftrGeom<T>::LDH]; } fh;
+  } u;
+};
+
+// rows x 128 channels of a token matrix -> LDS tile (rows >= `rows` zero filled)
+template <typename T>
+__device__ __forceinline__ void load_rows(const T* __restrict__ g, int rows, T* lds, int ld) {
+  constexpr int VE = Elem<T>::VE, SPR = LC / VE;
+  for (int idx = threadIdx.x; idx < LTOK * SPR; idx += LNT) {
+    const int r = idx / SPR, sl = idx - r * SPR;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (r < rows) v = *reinterpret_cast<const uint4*>(g + (int64_t)r * LC + sl * VE);
+    *reinterpret_cast<uint4*>(lds + r * ld + sl * VE) = v;
+  }
+}
+
+// tile[32 tokens][NO] = A[32][K] . W^T with A in LDS (columns [0,K0) from a0, [K0,K) from a1, row pitch lda) and W packed [NO][K].
+// epi(ct, acc): this lane holds acc[tt][r] = (token tt*16 + (lane&15), channel ct*16 + (lane>>4)*4 + r).
+template <typename T, int K, int NO, typename Epi>
+__device__ __forceinline__ void tok_gemm(const T* a0, const T* a1, int K0, int lda, const void* wpacked, Epi epi) {
+  constexpr int VE = Elem<T>::VE, SE = 4 * VE, NS = K / SE, KSL = K / VE;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, fr = lane & 15, fg = lane >> 4;
+  const uint4* wp = reinterpret_cast<const uint4*>(wpacked);
+  constexpr int NCT = NO / 16 / LNW;               // channel tiles per wave (1 or 2)
+  constexpr bool HOIST = NCT * NS <= 16;           // all weight fragments of the GEMM in flight at once when they fit in 64 VGPRs
+  uint4 wf[NCT][NS];
+  if (HOIST) {
+#pragma unroll
+    for (int ci = 0; ci < NCT; ci++)
+#pragma unroll
+      for (int ks = 0; ks < NS; ks++) { const uint4 v = wp[(int64_t)((wv + ci * LNW) * 16 + fr) * KSL + ks * 4 + fg]; wf[ci][ks] = v; }
+  }
+#pragma unroll
+  for (int ci = 0; ci < NCT; ci++) {
+    const int ct = wv + ci * LNW;
+    if (!HOIST) {
+#pragma unroll
+      for (int ks = 0; ks < NS; ks++) { const uint4 v = wp[(int64_t)(ct * 16 + fr) * KSL + ks * 4 + fg]; wf[ci][ks] = v; }
+    }
+    f32x4 acc[2] = {f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}};
+#pragma unroll
+    for (int ks = 0; ks < NS; ks++) {
+      const T* ap = (ks * SE < K0) ? a0 + ks * SE : a1 + (ks * SE - K0);
+#pragma unroll
+      for (int tt = 0; tt < 2; tt++) {
+        const uint4 pf = *reinterpret_cast<const uint4*>(ap + (tt * 16 + fr) * lda + fg * VE);
+        if (sizeof(T) == 4) {
+          acc[tt] = mfma_16x16x4_f32(__uint_as_float(wf[ci][ks].x), __uint_as_float(pf.x), acc[tt]);
+          acc[tt] = mfma_16x16x4_f32(__uint_as_float(wf[ci][ks].y), __uint_as_float(pf.y), acc[tt]);
+          acc[tt] = mfma_16x16x4_f32(__uint_as_float(wf[ci][ks].z), __uint_as_float(pf.z), acc[tt]);
+          acc[tt] = mfma_16x16x4_f32(__uint_as_float(wf[ci][ks].w), __uint_as_float(pf.w), acc[tt]);
+        } else {
+          s16x8 wa, pb;
+          __builtin_memcpy(&wa, &wf[ci][ks], 16);
+          __builtin_memcpy(&pb, &pf, 16);
+          acc[tt] = mfma_16x16x32_bf16(wa, pb, acc[tt]);
+        }
+      }
+    }
+    epi(ct, acc);
+  }
+}
+
+// ---- forward ----------------------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(LNT) void loftr_layer_fwd_kernel(const T* __restrict__ x, const T* __restrict__ src, LoftrW w,
+                                                              T* __restrict__ out, LoftrSaved sv, int L, int S, float eps_attn,
+                                                              float eps_ln) {
+  constexpr int LDA = LoftrGeom<T>::LDA, LDH = LoftrGeom<T>::LDH;
+  __shared__ LoftrSmemFwd<T> sm;
+  const int n = blockIdx.x;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, fr = lane & 15, fg = lane >> 4;
+  const bool self = (src == x);
+  const int64_t xo = (int64_t)n * L * LC, so = (int64_t)n * S * LC;
+
+  load_rows<T>(x + xo, L, sm.bX, LDA);
+  if (!self) load_rows<T>(src + so, S, sm.bS, LDA);
+  __syncthreads();
+  const T* sp = self ? sm.bX : sm.bS;
+
+  auto to_global = [&](T* base, int64_t off, int rows, int ldg) RD_INLINE_LAMBDA {
+    return [=](int ct, f32x4 (&acc)[2]) RD_INLINE_LAMBDA {
+#pragma unroll
+      for (int tt = 0; tt < 2; tt++) {
+        const int tok = tt * 16 + fr;
+        if (tok < rows) {
+          float v[4] = {acc[tt][0], acc[tt][1], acc[tt][2], acc[tt][3]};
+          st4(base + off + (int64_t)tok * ldg + ct * 16 + fg * 4, v);
+        }
+      }
+    };
+  };
+  tok_gemm<T, LC, LC>(sm.bX, sm.bX, LC, LDA, w.wq, to_global((T*)sv.q, xo, L, LC));
+  tok_gemm<T, LC, LC>(sp, sp, LC, LDA, w.wk, to_global((T*)sv.k, so, S, LC));
+  tok_gemm<T, LC, LC>(sp, sp, LC, LDA, w.wv, to_global((T*)sv.v, so, S, LC));
+  __syncthreads();
+
+  // linear attention: wave wv owns head wv (q, k, v come back from L2; the head routine stages them per head)
+  attn_head<T, false>(sm.u.at[wv], (const T*)sv.q, (const T*)sv.k, (const T*)sv.v, (const T*)nullptr, (T*)sv.att, (T*)nullptr,
+                      (T*)nullptr, (T*)nullptr, n, wv, true, L, S, LC, LC, LC, LC, eps_attn);
+  __syncthreads();
+  load_rows<T>((const T*)sv.att + xo, L, sm.bS, LDA);
+  __syncthreads();
+
+  // merge projection -> fp32 scratch (values as the unfused path stores them) + saved pre-norm activation
+  auto to_f = [&](T* gbase, int rows) RD_INLINE_LAMBDA {
+    return [=](int ct, f32x4 (&acc)[2]) RD_INLINE_LAMBDA {
+#pragma unroll
+      for (int tt = 0; tt < 2; tt++) {
+        const int tok = tt * 16 + fr;
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) { v[r] = Elem<T>::rnd(acc[tt][r]); sm.u.fh.f[tok * LF + ct * 16 + fg * 4 + r] = v[r]; }
+        if (tok < rows) st4(gbase + xo + (int64_t)tok * LC + ct * 16 + fg * 4, v);
+      }
+    };
+  };
+  tok_gemm<T, LC, LC>(sm.bS, sm.bS, LC, LDA, w.wm, to_f((T*)sv.mpre, L));
+  __syncthreads();
+
+  // LayerNorm (one wave per row, two channels per lane); which = 0: norm1 -> bM + saved message, 1: norm2 + residual -> out
+  auto ln_rows = [&](const float* gamma, const float* beta, int which) RD_INLINE_LAMBDA {
+    for (int r = wv; r < LTOK; r += LNW) {
+      if (r >= L) {
+        if (which == 0) { Elem<T>::st(&sm.bM[r * LDA + lane], 0.f); Elem<T>::st(&sm.bM[r * LDA + 64 + lane], 0.f); }
+        continue;
+      }
+      const float v0 = sm.u.fh.f[r * LF + lane], v1 = sm.u.fh.f[r * LF + 64 + lane];
+      const float mu = wave_sum(v0 + v1) / (float)LC;
+      const float d0 = v0 - mu, d1 = v1 - mu;
+      const float var = wave_sum(d0 * d0 + d1 * d1) / (float)LC;
+      const float rs = 1.0f / sqrtf(var + eps_ln);
+      float o0 = d0 * rs * gamma[lane] + beta[lane], o1 = d1 * rs * gamma[64 + lane] + beta[64 + lane];
+      const int64_t go = xo + (int64_t)r * LC;
+      if (which == 0) {
+        Elem<T>::st(&sm.bM[r * LDA + lane], o0); Elem<T>::st(&sm.bM[r * LDA + 64 + lane], o1);
+        Elem<T>::st((T*)sv.msg + go + lane, o0); Elem<T>::st((T*)sv.msg + go + 64 + lane, o1);
+      } else {
+        o0 += Elem<T>::ld(&sm.bX[r * LDA + lane]); o1 += Elem<T>::ld(&sm.bX[r * LDA + 64 + lane]);
+        Elem<T>::st(out + go + lane, o0); Elem<T>::st(out + go + 64 + lane, o1);
+      }
+      if (lane == 0) { sv.stats[((int64_t)n * L + r) * 4 + which * 2] = mu; sv.stats[((int64_t)n * L + r) * 4 + which * 2 + 1] = rs; }
+    }
+  };
+  ln_rows(w.g1, w.b1, 0);
+  __syncthreads();
+
+  // hidden = relu(W0 [x | message])
+  tok_gemm<T, LC2, LC2>(sm.bX, sm.bM, LC, LDA, w.w0, [&](int ct, f32x4 (&acc)[2]) RD_INLINE_LAMBDA {
+#pragma unroll
+    for (int tt = 0; tt < 2; tt++) {
+      const int tok = tt * 16 + fr;
+      float v[4];
+#pragma unroll
+      for (int r = 0; r < 4; r++) v[r] = fmaxf(acc[tt][r], 0.f);
+      st4(&sm.u.fh.h[tok * LDH + ct * 16 + fg * 4], v);
+      if (tok < L) st4((T*)sv.hid + ((int64_t)n * L + tok) * LC2 + ct * 16 + fg * 4, v);
+    }
+  });
+  __syncthreads();
+  tok_gemm<T, LC2, LC>(sm.u.fh.h, sm.u.fh.h, LC2, LDH, w.w2, to_f((T*)sv.m2pre, L));
+  __syncthreads();
+  ln_rows(w.g2, w.b2, 1);
+}
+
+// ---- backward ---------------------------------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(LNT) void loftr_layer_bwd_kernel(const T* __restrict__ x, const T* __restrict__ src, LoftrW w,
+                                                              LoftrSaved sv, LoftrGrads gr, int L, int S, float eps_attn) {
+  constexpr int LDA = LoftrGeom<T>::LDA, LDH = LoftrGeom<T>::LDH;
+  __shared__ LoftrSmemBwd<T> sm;
+  const int n = blockIdx.x;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, fr = lane & 15, fg = lane >> 4;
+  const bool self = (src == x);
+  const int64_t xo = (int64_t)n * L * LC, so = (int64_t)n * S * LC;
+
+  // LayerNorm backward over the rows of this ROI.  d(row, c) supplies the upstream gradient, pre = saved pre-norm activation,
+  // which selects the statistics; result -> bD (T) + saved copy for the weight gradient; per-ROI (sum d, sum d*xhat) -> lnp[n][c][2].
+  auto ln_bwd = [&](auto dfn, const T* pre, const float* gamma, int which, T* gout, float* lnp, bool seed_acc) RD_INLINE_LAMBDA {
+    float ag[2] = {0.f, 0.f}, ab[2] = {0.f, 0.f};
+    for (int r = wv; r < LTOK; r += LNW) {
+      if (r >= L) {
+        Elem<T>::st(&sm.bD[r * LDA + lane], 0.f); Elem<T>::st(&sm.bD[r * LDA + 64 + lane], 0.f);
+        if (seed_acc) { sm.acc[r * LF + lane] = 0.f; sm.acc[r * LF + 64 + lane] = 0.f; }
+        continue;
+      }
+      const int64_t go = xo + (int64_t)r * LC;
+      const float mu = sv.stats[((int64_t)n * L + r) * 4 + which * 2], rs = sv.stats[((int64_t)n * L + r) * 4 + which * 2 + 1];
+      float d[2], xh[2], g[2];
+#pragma unroll
+      for (int e = 0; e < 2; e++) {
+        const int c = e * 64 + lane;
+        d[e] = dfn(r, c);
+        xh[e] = (Elem<T>::ld(pre + go + c) - mu) * rs;
+        g[e] = d[e] * gamma[c];
+        ag[e] += d[e] * xh[e]; ab[e] += d[e];
+        if (seed_acc) sm.acc[r * LF + c] = d[e];   // residual path: dx starts as the upstream gradient
+      }
+      const float s1 = wave_sum(g[0] + g[1]) / (float)LC, s2 = wave_sum(g[0] * xh[0] + g[1] * xh[1]) / (float)LC;
+#pragma unroll
+      for (int e = 0; e < 2; e++) {
+        const int c = e * 64 + lane;
+        const float o = rs * (g[e] - s1 - xh[e] * s2);
+        Elem<T>::st(&sm.bD[r * LDA + c], o);
+        Elem<T>::st(gout + go + c, o);
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 2; e++) { sm.red[wv][0][e * 64 + lane] = ab[e]; sm.red[wv][1][e * 64 + lane] = ag[e]; }
+    __syncthreads();
+    if (threadIdx.x < LC) {
+      const int c = threadIdx.x;
+      float a = 0.f, b = 0.f;
+      for (int q = 0; q < LNW; q++) { b += sm.red[q][0][c]; a += sm.red[q][1][c]; }
+      lnp[((int64_t)n * LC + c) * 2] = b;       // dbeta terms
+      lnp[((int64_t)n * LC + c) * 2 + 1] = a;   // dgamma terms
+    }
+  };
+
+  // 1. out = x + norm2(m2pre)
+  const T* dout = (const T*)gr.dout;
+  ln_bwd([&](int r, int c) RD_INLINE_LAMBDA { return Elem<T>::ld(dout + xo + (int64_t)r * LC + c); }, (const T*)sv.m2pre, w.g2, 1, (T*)gr.dm2pre, gr.lnp2, true);
+  __syncthreads();
+
+  // 2. dhid = (dm2pre W2) * relu'(hid)
+  tok_gemm<T, LC, LC2>(sm.bD, sm.bD, LC, LDA, w.w2, [&](int ct, f32x4 (&acc)[2]) RD_INLINE_LAMBDA {
+#pragma unroll
+    for (int tt = 0; tt < 2; tt++) {
+      const int tok = tt * 16 + fr;
+      float v[4] = {0.f, 0.f, 0.f, 0.f};
+      if (tok < L) {
+        float h[4];
+        ld4((const T*)sv.hid + ((int64_t)n * L + tok) * LC2 + ct * 16 + fg * 4, h);
+#pragma unroll
+        for (int r = 0; r < 4; r++) v[r] = h[r] > 0.f ? acc[tt][r] : 0.f;
+        st4((T*)gr.dhid + ((int64_t)n * L + tok) * LC2 + ct * 16 + fg * 4, v);
+      }
+      st4(&sm.u.fh.h[tok * LDH + ct * 16 + fg * 4], v);
+    }
+  });
+  __syncthreads();
+
+  // 3. dcat = dhid W0: channels [0,128) add into dx, [128,256) are the gradient of the normalised message
+  tok_gemm<T, LC2, LC2>(sm.u.fh.h, sm.u.fh.h, LC2, LDH, w.w0, [&](int ct, f32x4 (&acc)[2]) RD_INLINE_LAMBDA {
+#pragma unroll
+    for (int tt = 0; tt < 2; tt++) {
+      const int tok = tt * 16 + fr;
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int c = ct * 16 + fg * 4 + r;
+        const float v = Elem<T>::rnd(acc[tt][r]);
+        if (c < LC) sm.acc[tok * LF + c] += v; else sm.u.fh.f[tok * LF + c - LC] = v;
+      }
+    }
+  });
+  __syncthreads();
+
+  // 4. message = norm1(mpre)
+  ln_bwd([&](int r, int c) RD_INLINE_LAMBDA { return sm.u.fh.f[r * LF + c]; }, (const T*)sv.mpre, w.g1, 0, (T*)gr.dmpre, gr.lnp1, false);
+  __syncthreads();
+
+  // 5. datt = dmpre Wm
+  auto to_global = [&](T* base, int64_t off, int rows) RD_INLINE_LAMBDA {
+    return [=](int ct, f32x4 (&acc)[2]) RD_INLINE_LAMBDA {
+#pragma unroll
+      for (int tt = 0; tt < 2; tt++) {
+        const int tok = tt * 16 + fr;
+        if (tok < rows) {
+          float v[4] = {acc[tt][0], acc[tt][1], acc[tt][2], acc[tt][3]};
+          st4(base + off + (int64_t)tok * LC + ct * 16 + fg * 4, v);
+        }
+      }
+    };
+  };
+  tok_gemm<T, LC, LC>(sm.bD, sm.bD, LC, LDA, w.wm, to_global((T*)gr.datt, xo, L));
+  __syncthreads();
+
+  // 6. attention backward (recomputes KV / P from the saved q, k, v)
+  attn_head<T, true>(sm.u.at[wv], (const T*)sv.q, (const T*)sv.k, (const T*)sv.v, (const T*)gr.datt, (T*)nullptr, (T*)gr.dq,
+                     (T*)gr.dk, (T*)gr.dv, n, wv, true, L, S, LC, LC, LC, LC, eps_attn);
+  __syncthreads();
+
+  // 7. dx += dq Wq;  dsrc = dk Wk + dv Wv  (self-attention: dsrc adds into dx)
+  load_rows<T>((const T*)gr.dq + xo, L, sm.bD, LDA);
+  __syncthreads();
+  tok_gemm<T, LC, LC>(sm.bD, sm.bD, LC, LDA, w.wq, [&](int ct, f32x4 (&acc)[2]) RD_INLINE_LAMBDA {
+#pragma unroll
+    for (int tt = 0; tt < 2; tt++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) sm.acc[(tt * 16 + fr) * LF + ct * 16 + fg * 4 + r] += Elem<T>::rnd(acc[tt][r]);
+  });
+  __syncthreads();
+  float* sacc = self ? sm.acc : sm.u.fh.f;
+  load_rows<T>((const T*)gr.dk + so, S, sm.bD, LDA);
+  __syncthreads();
+  tok_gemm<T, LC, LC>(sm.bD, sm.bD, LC, LDA, w.wk, [&](int ct, f32x4 (&acc)[2]) RD_INLINE_LAMBDA {
+#pragma unroll
+    for (int tt = 0; tt < 2; tt++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        float* p = &sacc[(tt * 16 + fr) * LF + ct * 16 + fg * 4 + r];
+        const float v = Elem<T>::rnd(acc[tt][r]);
+        *p = self ? *p + v : v;
+      }
+  });
+  __syncthreads();
+  load_rows<T>((const T*)gr.dv + so, S, sm.bD, LDA);
+  __syncthreads();
+  tok_gemm<T, LC, LC>(sm.bD, sm.bD, LC, LDA, w.wv, [&](int ct, f32x4 (&acc)[2]) RD_INLINE_LAMBDA {
+#pragma unroll
+    for (int tt = 0; tt < 2; tt++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) sacc[(tt * 16 + fr) * LF + ct * 16 + fg * 4 + r] += Elem<T>::rnd(acc[tt][r]);
+  });
+  __syncthreads();
+
+  // 8. results
+  for (int idx = threadIdx.x; idx < L * (LC / 4); idx += LNT) {
+    const int r = idx / (LC / 4), c4 = (idx - r * (LC / 4)) * 4;
+    float v[4] = {sm.acc[r * LF + c4], sm.acc[r * LF + c4 + 1], sm.acc[r * LF + c4 + 2], sm.acc[r * LF + c4 + 3]};
+    st4((T*)gr.dx + xo + (int64_t)r * LC + c4, v);
+  }
+  if (!self)
+    for (int idx = threadIdx.x; idx < S * (LC / 4); idx += LNT) {
+      const int r = idx / (LC / 4), c4 = (idx - r * (LC / 4)) * 4;
+      float v[4] = {sm.u.fh.f[r * LF + c4], sm.u.fh.f[r * LF + c4 + 1], sm.u.fh.f[r * LF + c4 + 2], sm.u.fh.f[r * LF + c4 + 3]};
+      st4((T*)gr.dsrc + so + (int64_t)r * LC + c4, v);
+    }
+}
+
+// ---- launchers ----------------------------------------------------------------------------------------------------------------------
+void launch_loftr_layer_fwd(const void* x, const void* src, const LoftrW& w, void* out, const LoftrSaved& sv, int N, int L, int S,
+                            float eps_attn, float eps_ln, int dtype, hipStream_t st) {
+  if (N <= 0) return;
+  if (dtype == 0) hipLaunchKernelGGL((loftr_layer_fwd_kernel<float>), dim3((unsigned)N), dim3(LNT), 0, st, (const float*)x, (const float*)src, w, (float*)out, sv, L, S, eps_attn, eps_ln);
+  else hipLaunchKernelGGL((loftr_layer_fwd_kernel<bf16_t>), dim3((unsigned)N), dim3(LNT), 0, st, (const bf16_t*)x, (const bf16_t*)src, w, (bf16_t*)out, sv, L, S, eps_attn, eps_ln);
+}
+void launch_loftr_layer_bwd(const void* x, const void* src, const LoftrW& w, const LoftrSaved& sv, const LoftrGrads& gr, int N, int L,
+                            int S, float eps_attn, int dtype, hipStream_t st) {
+  if (N <= 0) return;
+  if (dtype == 0) hipLaunchKernelGGL((loftr_layer_bwd_kernel<float>), dim3((unsigned)N), dim3(LNT), 0, st, (const float*)x, (const float*)src, w, sv, gr, L, S, eps_attn);
+  else hipLaunchKernelGGL((loftr_layer_bwd_kernel<bf16_t>), dim3((unsigned)N), dim3(LNT), 0, st, (const bf16_t*)x, (const bf16_t*)src, w, sv, gr, L, S, eps_attn);
+  // LayerNorm parameter gradients: ordered sum of the per-ROI partials
+  launch_bn_bwd_finalize(gr.lnp1, N, LC, 1.0, gr.dg1, gr.db1, gr.accumulate, nullptr, nullptr, st);
+  launch_bn_bwd_finalize(gr.lnp2, N, LC, 1.0, gr.dg2, gr.db2, gr.accumulate, nullptr, nullptr, st);
+}
+
+}  // namespace rd

@@ -21,7 +21,17 @@ from ._lib import ACT_LRELU, ACT_NONE, ACT_RELU, ACT_RELU6, RD_BF16, RD_F32, Con
 _TORCH_DT = {RD_F32: torch.float32, RD_BF16: torch.bfloat16}
 _RD_DT = {torch.float32: RD_F32, torch.bfloat16: RD_BF16}
 
-_state = {"dtype": RD_F32, "tape": None, "defer_wgrad": True}
+_state = {"dtype": RD_F32, "tape": None, "defer_wgrad": True, "fused_loftr": True}
+
+
+def set_fused_loftr(flag):
+    """Run eligible LoFTR encoder layers (d_model 128, 8 heads, <= 32 tokens) through the fused per-ROI kernels (default on)."""
+    _state["fused_loftr"] = bool(flag)
+
+
+def fused_loftr():
+    return _state["fused_loftr"]
+
 
 
 def set_defer_wgrad(flag):
@@ -62,6 +72,9 @@ def _chk(rc, what):
 
 def L():
     return _lib.load()
+
+
+L_ = L   # alias for functions whose signature uses L as a token count
 
 
 def rd_of(t):
@@ -688,6 +701,78 @@ def linear_attention(q, k, v, N, Lq, S, H, eps=1e-6):
             t.add_grad(k, dk)
             t.add_grad(v, dv)
         t.record(backward)
+    return out
+
+
+def loftr_layer(x, source, layer, N, L, S):
+    """Fused LoFTREncoderLayer (rd_loftr_layer_fwd / _bwd): x (N*L, 128), source (N*S, 128) token matrices -> (N*L, 128).
+    `layer` is the nn.Module holding q_proj / k_proj / v_proj / merge / mlp / norm1 / norm2 (reference linear_attention.py:84-135).
+    The weight gradients of the six linears join the tape's grouped weight-gradient launch."""
+    lib, t, dt, st = L_(), tape(), rd_of(x), _stream(x)
+    C = x.shape[1]
+    same = source is x
+    ws = [layer.q_proj.weight, layer.k_proj.weight, layer.v_proj.weight, layer.merge.weight, layer.mlp[0].weight, layer.mlp[2].weight]
+    lns = [layer.norm1.weight, layer.norm1.bias, layer.norm2.weight, layer.norm2.bias]
+
+    def wstruct(mode):
+        w = _lib.LoftrWeights()
+        packs = [packed_weight(p, mode, dt) for p in ws]
+        w.wq, w.wk, w.wv, w.wm, w.w0, w.w2 = [b.data_ptr() for b in packs]
+        w.g1, w.b1, w.g2, w.b2 = [p.detach().data_ptr() for p in lns]
+        return w, packs
+    ML, MS = N * L, N * S
+    dev, T = x.device, x.dtype
+    q = torch.empty((ML, C), dtype=T, device=dev)
+    k, v = torch.empty((MS, C), dtype=T, device=dev), torch.empty((MS, C), dtype=T, device=dev)
+    att, mpre, msg, m2pre = (torch.empty((ML, C), dtype=T, device=dev) for _ in range(4))
+    hid = torch.empty((ML, 2 * C), dtype=T, device=dev)
+    stats = torch.empty((ML, 4), dtype=torch.float32, device=dev)
+    out = torch.empty_like(x)
+    sv = _lib.LoftrSaved()
+    sv.q, sv.k, sv.v, sv.att, sv.mpre, sv.msg, sv.hid, sv.m2pre, sv.stats = [b.data_ptr() for b in (q, k, v, att, mpre, msg, hid, m2pre, stats)]
+    wf, keep = wstruct(0)
+    eps_a, eps_l = float(layer.attention.eps), float(layer.norm1.eps)
+    flops = 2.0 * (ML * C * C * 2 + MS * C * C * 2 + ML * 2 * C * 2 * C + ML * 2 * C * C)   # the six token GEMMs
+    _chk(_timed("loftr_layer", flops, lambda: lib.rd_loftr_layer_fwd(_p(x), _p(source), ctypes.byref(wf), _p(out), ctypes.byref(sv), N, L, S,
+                                                                       eps_a, eps_l, dt, st), "fwd N=%d L=%d" % (N, L)), "rd_loftr_layer_fwd")
+    if t is None or not (t.requires(x, source) or any(p.requires_grad for p in ws + lns)):
+        return out
+    t.mark(out)
+    saved_keep = (q, k, v, att, mpre, msg, hid, m2pre, stats)   # `sv` holds raw pointers: the tensors must outlive the backward
+
+    def backward():
+        g = t.pop_grad(out)
+        if g is None:
+            return
+        assert len(saved_keep) == 9
+        if not g.is_contiguous():
+            g = g.contiguous()
+        dm2pre, dmpre, datt, dq, dx = (torch.empty((ML, C), dtype=T, device=dev) for _ in range(5))
+        dk, dv = torch.empty((MS, C), dtype=T, device=dev), torch.empty((MS, C), dtype=T, device=dev)
+        dhid = torch.empty((ML, 2 * C), dtype=T, device=dev)
+        dsrc = None if same else torch.empty((MS, C), dtype=T, device=dev)
+        lnp = torch.empty((2, N, C, 2), dtype=torch.float32, device=dev)
+        (dg1, a1), (db1, a2), (dg2, a3), (db2, a4) = [t.param_grad(p) for p in lns]
+        assert a1 == a2 == a3 == a4
+        gr = _lib.LoftrGrads()
+        gr.dout, gr.dm2pre, gr.dhid, gr.dmpre, gr.datt, gr.dq, gr.dk, gr.dv, gr.dx = [b.data_ptr() for b in (g, dm2pre, dhid, dmpre, datt, dq, dk, dv, dx)]
+        gr.dsrc = 0 if dsrc is None else dsrc.data_ptr()
+        gr.lnp1, gr.lnp2 = lnp[0].data_ptr(), lnp[1].data_ptr()
+        gr.dg1, gr.db1, gr.dg2, gr.db2, gr.accumulate = dg1.data_ptr(), db1.data_ptr(), dg2.data_ptr(), db2.data_ptr(), a1
+        wb, keepb = wstruct(1)
+        _chk(_timed("loftr_layer", 2.0 * flops, lambda: lib.rd_loftr_layer_bwd(_p(x), _p(source), ctypes.byref(wb), ctypes.byref(sv), ctypes.byref(gr),
+                                                                                 N, L, S, eps_a, dt, st), "bwd N=%d L=%d" % (N, L)), "rd_loftr_layer_bwd")
+        for w_, x1, x2, dy, M in ((ws[0], x, None, dq, ML), (ws[1], source, None, dk, MS), (ws[2], source, None, dv, MS),
+                                  (ws[3], att, None, dmpre, ML), (ws[4], x, msg, dhid, ML), (ws[5], hid, None, dm2pre, ML)):
+            if w_.requires_grad:
+                c1 = x1.shape[1]
+                c2 = 0 if x2 is None else x2.shape[1]
+                t.deferred.append(dict(x=x1, x2=x2, dy=dy, weight=w_, M=M, C1=c1, C2=c2, Cin=c1 + c2, Cout=dy.shape[1],
+                                       flops=2.0 * M * (c1 + c2) * dy.shape[1]))
+        t.add_grad(x, dx)
+        if not same:
+            t.add_grad(source, dsrc)
+    t.record(backward)
     return out
 
 

@@ -61,6 +61,8 @@ class LoFTREncoderLayer(nn.Module):
 
     def _fwd(self, x, source, N, L, S):
         """x (N*L, C), source (N*S, C) token matrices -> (N*L, C)."""
+        if engine.fused_loftr() and x.shape[1] == 128 and self.nhead == 8 and L <= 32 and S <= 32:
+            return engine.loftr_layer(x, source, self, N, L, S)      # one workgroup per sequence walks the whole layer
         q = engine.linear(x, self.q_proj.weight)
         k = engine.linear(source, self.k_proj.weight)
         v = engine.linear(source, self.v_proj.weight)

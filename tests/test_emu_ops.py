@@ -107,3 +107,14 @@ def test_grouped_linear_wgrad(emu):
 
 def test_pack_batch(emu):
     P.pack_batch_case(emu)
+
+
+def test_loftr_unfused_path(emu):
+    """The per-op LoFTR path (separate projection / attention / LayerNorm launches) stays covered now that eligible layers run fused."""
+    from riders_amd import engine
+    engine.set_fused_loftr(False)
+    try:
+        P.golden_attention_case(emu)
+        P.transformer_case(emu)
+    finally:
+        engine.set_fused_loftr(True)

@@ -182,3 +182,14 @@ def test_grouped_linear_wgrad(gpu):
 
 def test_pack_batch(gpu):
     P.pack_batch_case(gpu)
+
+
+def test_loftr_unfused_path(gpu):
+    """The per-op LoFTR path (separate projection / attention / LayerNorm launches) stays covered now that eligible layers run fused."""
+    from riders_amd import engine
+    engine.set_fused_loftr(False)
+    try:
+        P.golden_attention_case(gpu)
+        P.transformer_case(gpu)
+    finally:
+        engine.set_fused_loftr(True)
