@@ -126,10 +126,20 @@ int rd_conv_fwd(const rd_conv_desc* d, const void* src1, const void* src2, const
   rd::launch_conv(a, d->dtype, S(stream));
   return done("rd_conv_fwd");
 }
+static void fill_wgrad_args(const rd_conv_desc* d, rd::WgradArgs& a) {
+  memset(&a, 0, sizeof(a));
+  a.N = d->N; a.Hin = d->Hin; a.Win = d->Win; a.C1 = d->C1; a.C2 = d->C2;
+  a.ups = d->upsample ? 1 : 0; a.H1 = a.ups ? d->H1 : d->Hin; a.W1 = a.ups ? d->W1 : d->Win;
+  a.Cout = d->Cout; a.KH = d->KH; a.KW = d->KW; a.stride = d->stride; a.pad = d->pad; a.OH = d->OH; a.OW = d->OW;
+  a.scale_h = (float)a.H1 / (float)d->Hin; a.scale_w = (float)a.W1 / (float)d->Win;
+  a.M = d->N * d->OH * d->OW;
+  a.K = d->KH * d->KW * (d->C1 + d->C2);
+}
 int64_t rd_conv_wgrad_workspace_bytes(const rd_conv_desc* d) {
-  int M = d->N * d->OH * d->OW, K = d->KH * d->KW * (d->C1 + d->C2);
-  int ns = rd::wgrad_slabs(M, K, d->Cout);
-  return (int64_t)(ns + 1) * d->Cout * K * (int64_t)sizeof(float);
+  rd::WgradArgs a; fill_wgrad_args(d, a);
+  int ns = rd::wgrad_slabs(a.M, a.K, d->Cout);
+  if (rd::wgrad3x3_tr_ok(a, d->dtype)) ns = std::max(ns, rd::wgrad3x3_tr_blocks(a));
+  return (int64_t)(ns + 1) * d->Cout * a.K * (int64_t)sizeof(float);
 }
 int rd_conv_wgrad(const rd_conv_desc* d, const void* src1, const void* src2, const void* dy, float* workspace, float* dw,
                   int32_t accumulate, void* stream) {

@@ -1,5 +1,5 @@
-// bf16 weight gradient of narrow 3x3 / stride-1 layers (Cin in {16, 32, 64}, Cout <= 32) on the bf16 MFMA, fed by the gfx950 LDS
-// transpose read.
+// bf16 weight gradient of 3x3 / stride-1 layers on the bf16 MFMA, fed by the gfx950 LDS transpose read: narrow layers (Cin in {16, 32,
+// 64}, Cout <= 32) as one slice, wide layers (Cin % 64 == 0) as (64 input channels) x (32 output channels) slices on blockIdx.y.
 //
 //   dW[co][tap][ci] = sum over pixels p of dY[p][co] * X[p + tap][ci]          (reference: autograd of utils/net_utils.py:84-91,195-198)
 //
@@ -16,8 +16,13 @@
 
 namespace rd {
 
+// LDS layout note (measured, profiles/r01_wgrad_tr_lds_swizzle.txt): with the plain [pixel][channel] images the 32-lane transpose reads
+// of the 64-channel slices hit 2..4 bank groups (SQ_LDS_BANK_CONFLICT = 66 % of SQ_LDS_IDX_ACTIVE).  An XOR swizzle of the 16-channel tile
+// position with pixel bits 1 and 3 removed every conflict (counter = 0, LDS cycles / 3) and made the kernel SLOWER (0.210 -> 0.224 ms
+// wide, 0.102 -> 0.140 ms narrow): the per-read address arithmetic replaces immediate offsets and the kernel is issue / latency bound
+// with one wave per SIMD, not LDS bound.  The affine layout stays.
 template <int CTI, int RT, int TW>
-__global__ __launch_bounds__(256) void conv3x3_wgrad_tr_kernel(WgradArgs a, int tilesH, int tilesW) {
+__global__ __launch_bounds__(256) void conv3x3_wgrad_tr_kernel(WgradArgs a, int tilesH, int tilesW, int nci) {
   typedef bf16_t T;
   constexpr int CIN = CTI * 16, COP = RT * 16;
   constexpr int TH = 8, WT = TW + 2, HT = TH + 2, NPX = HT * WT, NPY = TH * TW;
@@ -33,6 +38,9 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_tr_kernel(WgradArgs a, int 
 
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
   const int fr = lane & 15, fg = lane >> 4;
+  // wide layers: blockIdx.y picks a (CIN input channels) x (COP output channels) slice of the gradient; every slice walks all tiles
+  const int ci0 = ((int)blockIdx.y % nci) * CIN, co0 = ((int)blockIdx.y / nci) * COP;
+  const int CinT = a.C1 + a.C2;
   ConvArgs g;
   g.src1 = a.src1; g.src2 = a.src2; g.Hin = a.Hin; g.Win = a.Win; g.C1 = a.C1; g.C2 = a.C2; g.H1 = a.H1; g.W1 = a.W1;
   g.dil = 1; g.ups = a.ups; g.scale_h = a.scale_h; g.scale_w = a.scale_w;
@@ -57,7 +65,7 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_tr_kernel(WgradArgs a, int 
     if (!jv[j]) idx = 0;
     const int tap = idx / CTI, ct = idx - tap * CTI;
     coloff[j] = ((tap / 3) * WT + (tap % 3)) * CIN + ct * 16;
-    jk[j] = tap * CIN + ct * 16;
+    jk[j] = tap * CinT + ci0 + ct * 16;
   }
 
   f32x4 acc[RT][NCW];
@@ -79,7 +87,7 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_tr_kernel(WgradArgs a, int 
         const int pp = idx / XS, sl = idx - pp * XS;
         const int py = pp / WT, px = pp - py * WT;
         const T* p;
-        if (conv_src_ptr<T>(g, n, oh0 - 1 + py, ow0 - 1 + px, sl * 8, p)) v = *reinterpret_cast<const uint4*>(p);
+        if (conv_src_ptr<T>(g, n, oh0 - 1 + py, ow0 - 1 + px, ci0 + sl * 8, p)) v = *reinterpret_cast<const uint4*>(p);
       }
       rx[i] = v;
     }
@@ -91,13 +99,13 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_tr_kernel(WgradArgs a, int 
         const int pp = idx / YS, sl = idx - pp * YS;
         const int py = pp / TW, px = pp - py * TW;
         const int oh = oh0 + py, ow = ow0 + px;
-        if (oh < a.OH && ow < a.OW && sl * 8 < a.Cout) {
-          const T* p = (const T*)a.dy + (((int64_t)n * a.OH + oh) * a.OW + ow) * a.Cout + sl * 8;
+        if (oh < a.OH && ow < a.OW && co0 + sl * 8 < a.Cout) {
+          const T* p = (const T*)a.dy + (((int64_t)n * a.OH + oh) * a.OW + ow) * a.Cout + co0 + sl * 8;
           if (yvec) v = *reinterpret_cast<const uint4*>(p);
           else {  // Cout not a multiple of 8 (the 1-channel head): element-wise, zero padded
             unsigned short e[8];
 #pragma unroll
-            for (int q = 0; q < 8; q++) e[q] = (sl * 8 + q < a.Cout) ? p[q].v : (unsigned short)0;
+            for (int q = 0; q < 8; q++) e[q] = (co0 + sl * 8 + q < a.Cout) ? p[q].v : (unsigned short)0;
             v.x = e[0] | ((unsigned)e[1] << 16); v.y = e[2] | ((unsigned)e[3] << 16);
             v.z = e[4] | ((unsigned)e[5] << 16); v.w = e[6] | ((unsigned)e[7] << 16);
           }
@@ -160,35 +168,58 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_tr_kernel(WgradArgs a, int 
         const int k = jk[j] + fr;
 #pragma unroll
         for (int r = 0; r < 4; r++) {
-          const int co = i * 16 + fg * 4 + r;
+          const int co = co0 + i * 16 + fg * 4 + r;
           if (co < a.Cout) slab[(int64_t)co * a.K + k] = acc[i][j][r];
         }
       }
 }
 
 // ---- host side -------------------------------------------------------------------------------------------------------------------
+// narrow layers (Cin in {16, 32, 64}, Cout <= 32): one slice.  Wide layers (Cin % 64 == 0): (Cin/64) x ceil(Cout/32) slices, used when the
+// 8 x 16 tiles cover the feature map well enough (the MFMA work is spent on whole tiles).
+static bool tr_geom(const WgradArgs& a) {
+  return a.KH == 3 && a.KW == 3 && a.stride == 1 && a.pad == 1 && (a.C1 % 8 == 0) && a.OH == a.Hin && a.OW == a.Win;
+}
+static bool tr_narrow(const WgradArgs& a) { const int Cin = a.C1 + a.C2; return (Cin == 16 || Cin == 32 || Cin == 64) && a.Cout <= 32; }
 bool wgrad3x3_tr_ok(const WgradArgs& a, int dtype) {
+  if (dtype != 1 || !tr_geom(a)) return false;
+  if (tr_narrow(a)) return true;
   const int Cin = a.C1 + a.C2;
-  return dtype == 1 && a.KH == 3 && a.KW == 3 && a.stride == 1 && a.pad == 1 && (Cin == 16 || Cin == 32 || Cin == 64) && a.Cout <= 32 &&
-         (a.C1 % 8 == 0) && a.OH == a.Hin && a.OW == a.Win;
+  if (Cin % 64 != 0 || a.Cout % 8 != 0) return false;
+  const double eff = (double)a.OH * a.OW / (double)(cdiv(a.OH, 8) * 8 * cdiv(a.OW, 16) * 16);
+  return eff >= 0.6;
 }
 static int tr_tw(const WgradArgs& a) {
   const int Cin = a.C1 + a.C2;
-  if (Cin == 64) return 16;  // LDS budget
+  if (Cin >= 64) return 16;  // LDS budget
   return (cdiv(a.OW, 32) * 32 <= cdiv(a.OW, 16) * 16) ? 32 : 16;
 }
-int wgrad3x3_tr_blocks(const WgradArgs& a) {
+static void tr_slices(const WgradArgs& a, int& cti, int& rt, int& nci, int& nco) {
+  const int Cin = a.C1 + a.C2;
+  cti = Cin >= 64 ? 4 : Cin / 16;
+  rt = a.Cout <= 16 ? 1 : 2;
+  nci = Cin >= 64 ? Cin / 64 : 1;
+  nco = (int)cdiv(a.Cout, rt * 16);
+}
+int wgrad3x3_tr_blocks(const WgradArgs& a) {   // persistent blocks per slice = slabs to reduce
+  int cti, rt, nci, nco;
+  tr_slices(a, cti, rt, nci, nco);
   const int tw = tr_tw(a);
   const int64_t ntiles = (int64_t)a.N * cdiv(a.OH, 8) * cdiv(a.OW, tw);
   const char* e = getenv("RD_CONV3X3_G8");  // test hook shared with the forward kernel
-  return 8 * (int)std::min<int64_t>(cdiv(ntiles, 8), e ? atoi(e) : 128);
+  int cap = e ? atoi(e) : std::max(1, 128 / (nci * nco));
+  // every block writes (and the reduction re-reads) a Cout x K slab slice: wide layers with few tiles keep >= 4 tiles per block
+  if (!e && nci * nco > 1) cap = (int)std::max<int64_t>(1, std::min<int64_t>(cap, ntiles / 32));
+  return 8 * (int)std::min<int64_t>(cdiv(ntiles, 8), cap);
 }
 void launch_wgrad3x3_tr(const WgradArgs& a, hipStream_t st) {
-  const int Cin = a.C1 + a.C2, cti = Cin / 16, rt = a.Cout <= 16 ? 1 : 2, tw = tr_tw(a);
+  int cti, rt, nci, nco;
+  tr_slices(a, cti, rt, nci, nco);
+  const int tw = tr_tw(a);
   const int tilesH = (int)cdiv(a.OH, 8), tilesW = (int)cdiv(a.OW, tw);
-  const int nblk = wgrad3x3_tr_blocks(a);
+  const dim3 grid((unsigned)wgrad3x3_tr_blocks(a), (unsigned)(nci * nco));
 #define RD_TR(CTIV, RTV, TWV) \
-  if (cti == CTIV && rt == RTV && tw == TWV) hipLaunchKernelGGL((conv3x3_wgrad_tr_kernel<CTIV, RTV, TWV>), dim3(nblk), dim3(256), 0, st, a, tilesH, tilesW);
+  if (cti == CTIV && rt == RTV && tw == TWV) hipLaunchKernelGGL((conv3x3_wgrad_tr_kernel<CTIV, RTV, TWV>), grid, dim3(256), 0, st, a, tilesH, tilesW, nci);
   RD_TR(1, 1, 16) RD_TR(1, 1, 32) RD_TR(1, 2, 16) RD_TR(1, 2, 32)
   RD_TR(2, 1, 16) RD_TR(2, 1, 32) RD_TR(2, 2, 16) RD_TR(2, 2, 32)
   RD_TR(4, 1, 16) RD_TR(4, 2, 16)

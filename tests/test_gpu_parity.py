@@ -161,6 +161,10 @@ def test_bf16_wgrad_transpose_read(gpu):
     P.bf16_exact_conv_case(gpu, cin=16, cout=32, k=3, s=1, H=8, W=33, N=1)
     P.bf16_exact_conv_case(gpu, cin=32, cout=24, k=3, s=1, H=11, W=16, N=2)
     P.bf16_exact_conv_case(gpu, cin=64, cout=32, k=3, s=1, H=9, W=17, N=1)
+    # wide layers: (64-channel input slice) x (32-channel output slice) blocks, concat boundary inside a slice, partial last output slice
+    P.bf16_exact_conv_case(gpu, cin=128, cout=64, k=3, s=1, H=17, W=16, N=1)
+    P.bf16_exact_conv_case(gpu, cin=96, cout=40, k=3, s=1, N=1, up=((5, 7), (15, 14)), cin2=32)
+    P.bf16_exact_conv_case(gpu, cin=192, cout=16, k=3, s=1, H=8, W=14, N=2)
     with P.force_patch_conv(g8=1):
         P.bf16_exact_conv_case(gpu, cin=16, cout=16, k=3, s=1, H=40, W=50, N=2)
         P.bf16_exact_conv_case(gpu, cin=16, cout=16, k=3, s=1, N=2, up=((13, 9), (27, 64)), cin2=16)
