@@ -89,22 +89,22 @@ class KernelTimer(object):
     def __init__(self):
         self.records = {}  # kind -> [(start_event, end_event, algorithmic_flops)]
 
-    def run(self, kind, flops, fn, desc=None):
+    def run(self, kind, flops, fn, desc=None, nbytes=0.0):
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s.record()
         rc = fn()
         e.record()
-        self.records.setdefault(kind, []).append((s, e, flops, desc))
+        self.records.setdefault(kind, []).append((s, e, flops, desc, nbytes))
         return rc
 
     def detail(self):
-        """-> {(kind, desc): (launches, total ms, total flops)} aggregated over identical launch shapes."""
+        """-> {(kind, desc): (launches, total ms, total flops, total algorithmic bytes)} aggregated over identical launch shapes."""
         out = {}
         for kind, recs in self.records.items():
-            for s, e, f, d in recs:
+            for s, e, f, d, b in recs:
                 k = (kind, d)
-                n, ms, fl = out.get(k, (0, 0.0, 0.0))
-                out[k] = (n + 1, ms + s.elapsed_time(e), fl + f)
+                n, ms, fl, by = out.get(k, (0, 0.0, 0.0, 0.0))
+                out[k] = (n + 1, ms + s.elapsed_time(e), fl + f, by + b)
         return out
 
     def summary(self):
@@ -123,9 +123,9 @@ def set_kernel_timer(t):
     _timer["t"] = t
 
 
-def _timed(kind, flops, fn, desc=None):
+def _timed(kind, flops, fn, desc=None, nbytes=0.0):
     kt = _timer["t"]
-    return fn() if kt is None else kt.run(kind, flops, fn, desc)
+    return fn() if kt is None else kt.run(kind, flops, fn, desc, nbytes)
 
 
 # ------------------------------------------------------------------------------------------------- tape
@@ -490,8 +490,11 @@ def conv_block(x, weight, *, x2=None, bias=None, stride=1, pad=None, up=None, bn
     flops = 2.0 * N * OH * OW * Cout * KH * KW * Cin  # algorithmic (2 FLOP per MAC), same count for dgrad / wgrad
     shp = "M=%d Cin=%d Cout=%d k=%d s=%d%s" % (N * OH * OW, Cin, Cout, KH, stride, " up" if is_up else "")
     bias_t = bias.detach() if bias is not None else None
+    es = x.element_size()   # algorithmic HBM bytes of the three convolution launches (every operand moved exactly once)
+    b_in = (x.numel() + (0 if x2 is None else x2.numel())) * es
+    b_w, b_out = weight.numel() * es, N * OH * OW * Cout * es
     _chk(_timed("conv_gemm", flops, lambda: lib.rd_conv_fwd(ctypes.byref(d), _p(x), _p(x2), _p(wp), _p(bias_t), _p(y), None,
-                                                               _p(stats), st), "fwd " + shp), "rd_conv_fwd")
+                                                               _p(stats), st), "fwd " + shp, b_in + b_w + b_out), "rd_conv_fwd")
     pixels = N * OH * OW
     scale = shift = mean = rstd = None
     if use_bn:
@@ -558,14 +561,14 @@ def conv_block(x, weight, *, x2=None, bias=None, stride=1, pad=None, up=None, bn
             dw, acc = t.param_grad(weight)
             ws = torch.empty(lib.rd_conv_wgrad_workspace_bytes(ctypes.byref(d)) // 4, dtype=torch.float32, device=x.device)
             _chk(_timed("conv_wgrad", flops, lambda: lib.rd_conv_wgrad(ctypes.byref(d), _p(x), _p(x2), _p(dy), _p(ws), _p(dw), acc, st),
-                        "wgrad " + shp), "rd_conv_wgrad")
+                        "wgrad " + shp, b_in + b_out + weight.numel() * 4), "rd_conv_wgrad")
         if need_in:
             wpd = packed_weight(weight, 1, dt)
             dd = _desc(dt, N, OH, OW, Cout, 0, False, OH, OW, Cin, KH, KW, 1, KH - 1 - pad, stride, Hin, Win, ACT_NONE, 0.0, C1)
             dxv1 = torch.empty((N, Hin, Win, C1), dtype=x.dtype, device=x.device)
             dxv2 = torch.empty((N, Hin, Win, C2), dtype=x.dtype, device=x.device) if C2 else None
             _chk(_timed("conv_gemm", flops, lambda: lib.rd_conv_fwd(ctypes.byref(dd), _p(dy), None, _p(wpd), None, _p(dxv1), _p(dxv2),
-                                                                       None, st), "dgrad " + shp), "rd_conv_fwd(dgrad)")
+                                                                       None, st), "dgrad " + shp, b_out + b_w + N * Hin * Win * Cin * es), "rd_conv_fwd(dgrad)")
             if is_up:
                 g1 = torch.empty_like(x)
                 _chk(lib.rd_upsample_nearest_bwd(_p(dxv1), _p(g1), N, H1, W1, Hin, Win, C1, dt, st), "rd_upsample_nearest_bwd")
