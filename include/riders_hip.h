@@ -66,7 +66,7 @@ typedef struct rd_pack_item {
 int rd_conv_pack_weights_batch(const rd_pack_item* items, int32_t n, void* stream);
 /* Weight gradients of MANY 1x1 / linear layers in one launch + one ordered reduction (reference: autograd of the nn.Linear layers of
    RCNet/linear_attention.py:84-135; 96 products per RC-Net step).  gemm p: slab_p[split][Cout][C1+C2] = partial dY_p^T [X1_p | X2_p]
-   over tokens [split*rows_per_split, ...); C1, C2, Cout multiples of 64 (C2 = 0: x2 unused).  reduce q: dw_q[elems] (+)= sum of nsplit
+   over tokens [split*rows_per_split, ...); C1, C2, Cout multiples of the 16-byte vector (4 fp32 / 8 bf16), C1 % 64 == 0 when C2 > 0.  reduce q: dw_q[elems] (+)= sum of nsplit
    consecutive slabs (several gemms that share a weight write consecutive slabs of one reduce item).  Both arrays are HOST memory. */
 typedef struct rd_lwg_gemm {
   const void* x1; const void* x2; const void* dy; float* slab;

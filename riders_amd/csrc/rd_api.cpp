@@ -77,7 +77,9 @@ int rd_linear_wgrad_batch(const rd_lwg_gemm* gemms, int32_t n_gemm, const rd_lwg
   for (int i = 0; i < n_gemm; i++) {
     const rd_lwg_gemm& g = gemms[i];
     if (!g.x1 || !g.dy || !g.slab || (g.C2 > 0 && !g.x2)) return fail("linear_wgrad_batch: item %d has a null pointer", i);
-    if (g.M <= 0 || g.C1 <= 0 || (g.C1 & 63) || (g.C2 & 63) || (g.Cout & 63) || g.Cout <= 0) return fail("linear_wgrad_batch: item %d: channels must be multiples of 64", i);
+    const int ve = dtype == RD_F32 ? 4 : 8;
+    if (g.M <= 0 || g.C1 <= 0 || g.Cout <= 0 || g.C2 < 0 || (g.C1 % ve) || (g.C2 % ve) || (g.Cout % ve) || (g.C2 > 0 && (g.C1 & 63)))
+      return fail("linear_wgrad_batch: item %d: channels must be multiples of %d (and C1 of 64 when C2 > 0)", i, ve);
     if (g.nsplit <= 0 || g.rows_per_split <= 0 || (int64_t)g.nsplit * g.rows_per_split < g.M) return fail("linear_wgrad_batch: item %d: splits do not cover M", i);
   }
   for (int i = 0; i < n_reduce; i++)

@@ -198,8 +198,7 @@ __global__ __launch_bounds__(256) void conv3x3_small_kernel(ConvArgs a, int tile
         wr[c][s] = v;
       }
   }
-  uint4 rp[PIT];
-  auto load_patch = [&](int tl) RD_INLINE_LAMBDA {
+  auto load_patch = [&](int tl, uint4 (&rp)[PIT]) RD_INLINE_LAMBDA {
     const int tw_ = tl % tilesW; const int q_ = tl / tilesW; const int th_ = q_ % tilesH; const int n = q_ / tilesH;
     const int oh0 = th_ * TH, ow0 = tw_ * TW;
 #pragma unroll
@@ -215,7 +214,7 @@ __global__ __launch_bounds__(256) void conv3x3_small_kernel(ConvArgs a, int tile
       rp[i] = v;
     }
   };
-  auto store_patch = [&](int buf) RD_INLINE_LAMBDA {
+  auto store_patch = [&](int buf, const uint4 (&rp)[PIT]) RD_INLINE_LAMBDA {
 #pragma unroll
     for (int i = 0; i < PIT; i++) {
       int idx = t + 256 * i;
@@ -230,14 +229,8 @@ __global__ __launch_bounds__(256) void conv3x3_small_kernel(ConvArgs a, int tile
     ppix[pt] = lpy[pt] * WT + lpx[pt];
   }
 
-  if (tile < tend) load_patch(tile);
-  int buf = 0;
-  while (tile < tend) {
-    store_patch(buf);
-    __syncthreads();
-    const int next = tile + G8;
-    if (next < tend) load_patch(next);
-
+  // one tile: MFMA over the LDS patch in `buf`, then the shared epilogue
+  auto tile_body = [&](int tile, int buf) RD_INLINE_LAMBDA {
     f32x4 acc[CT][2];
 #pragma unroll
     for (int c = 0; c < CT; c++) { acc[c][0] = f32x4{0, 0, 0, 0}; acc[c][1] = f32x4{0, 0, 0, 0}; }
@@ -281,8 +274,24 @@ __global__ __launch_bounds__(256) void conv3x3_small_kernel(ConvArgs a, int tile
       }
       conv_epilogue<T, CT, BN, 4>(a, acc, mm, mvv, 0, 0, wv, fr, fg, t, tile, red);
     }
-    tile = next;
-    buf ^= 1;
+  };
+
+  // prefetch distance TWO tiles (two register sets, loop unrolled by two so no set is ever copied): a tile's MFMA + epilogue is far
+  // shorter than the HBM latency, with distance one every block stalled on its next patch (ROI-resolution layers ran at 17-30 % of
+  // the HBM roof with four blocks per CU)
+  uint4 ra[PIT], rb[PIT];
+  int t0 = tile, t1 = tile + G8;
+  if (t0 < tend) load_patch(t0, ra);
+  if (t1 < tend) load_patch(t1, rb);
+  int buf = 0;
+  while (t0 < tend) {
+    store_patch(buf, ra);
+    __syncthreads();
+    { const int t2 = t1 + G8; if (t2 < tend) load_patch(t2, ra); tile_body(t0, buf); t0 = t1; t1 = t2; buf ^= 1; }
+    if (t0 >= tend) break;
+    store_patch(buf, rb);
+    __syncthreads();
+    { const int t2 = t1 + G8; if (t2 < tend) load_patch(t2, rb); tile_body(t0, buf); t0 = t1; t1 = t2; buf ^= 1; }
   }
 }
 
@@ -340,6 +349,7 @@ bool conv3x3_ok(const ConvArgs& a, int dtype) {
          (a.C1 % ve == 0);
 }
 static bool use_w8(const ConvArgs& a) {  // tile shape with the smaller padded area
+  if (const char* e = getenv("RD_CONV3X3_W8")) return atoi(e) != 0;   // experiment hook
   int64_t a16 = cdiv(a.OH, 8) * 8 * cdiv(a.OW, 16) * 16, a8 = cdiv(a.OH, 16) * 16 * cdiv(a.OW, 8) * 8;
   return a8 < a16;
 }

@@ -26,13 +26,13 @@ __global__ __launch_bounds__(256) void linear_wgrad_kernel(LwgBatch b) {
   __shared__ uint4 sY[2][ST * RS];
   const LwgGemm& g = b.it[blockIdx.y];
   const int Cin = g.C1 + g.C2;
-  const int tci = Cin >> 6, tco = g.Cout >> 6;
+  const int tci = (Cin + 63) >> 6, tco = (g.Cout + 63) >> 6;   // partial edge tiles: channel counts need only be multiples of VE
   const int per = tci * tco;
   if ((int)blockIdx.x >= per * g.nsplit) return;
   const int sp = blockIdx.x / per, rem = blockIdx.x - sp * per;
   const int co0 = (rem / tci) * 64, ci0 = (rem % tci) * 64;
   const int mbeg = sp * g.rows_per_split, mend = min(g.M, mbeg + g.rows_per_split);
-  const T* xs; int xld, xc0;
+  const T* xs; int xld, xc0;   // a 64-channel tile lies in ONE source (C1 % 64 == 0 whenever C2 > 0)
   if (ci0 < g.C1) { xs = (const T*)g.x1; xld = g.C1; xc0 = ci0; } else { xs = (const T*)g.x2; xld = g.C2; xc0 = ci0 - g.C1; }
   const T* ys = (const T*)g.dy;
 
@@ -49,8 +49,8 @@ __global__ __launch_bounds__(256) void linear_wgrad_kernel(LwgBatch b) {
       const int m = m0 + row;
       uint4 vx = make_uint4(0, 0, 0, 0), vy = vx;
       if (m < mend) {
-        vx = *reinterpret_cast<const uint4*>(xs + (int64_t)m * xld + xc0 + sl * VE);
-        vy = *reinterpret_cast<const uint4*>(ys + (int64_t)m * g.Cout + co0 + sl * VE);
+        if (xc0 + sl * VE < xld) vx = *reinterpret_cast<const uint4*>(xs + (int64_t)m * xld + xc0 + sl * VE);
+        if (co0 + sl * VE < g.Cout) vy = *reinterpret_cast<const uint4*>(ys + (int64_t)m * g.Cout + co0 + sl * VE);
       }
       rx[i] = vx; ry[i] = vy;
     }
@@ -131,7 +131,7 @@ __global__ __launch_bounds__(256) void linear_wgrad_kernel(LwgBatch b) {
 #pragma unroll
       for (int r = 0; r < 4; r++) {
         const int co = co0 + (wr * 2 + i) * 16 + fg * 4 + r;
-        slab[(int64_t)co * Cin + ci] = acc[i][j][r];
+        if (co < g.Cout && ci < Cin) slab[(int64_t)co * Cin + ci] = acc[i][j][r];
       }
     }
 }
@@ -154,7 +154,7 @@ void launch_linear_wgrad_batch(const LwgGemm* gemms, int n_gemm, const LwgReduce
     for (int i = 0; i < n; i++) {
       b.it[i] = gemms[base + i];
       const LwgGemm& g = b.it[i];
-      maxb = std::max(maxb, ((g.C1 + g.C2) >> 6) * (g.Cout >> 6) * g.nsplit);
+      maxb = std::max(maxb, ((g.C1 + g.C2 + 63) >> 6) * ((g.Cout + 63) >> 6) * g.nsplit);
     }
     for (int i = n; i < LWG_MAX_ITEMS; i++) b.it[i] = b.it[0];
     if (dtype == 0) hipLaunchKernelGGL((linear_wgrad_kernel<float>), dim3((unsigned)maxb, (unsigned)n), dim3(256), 0, st, b);

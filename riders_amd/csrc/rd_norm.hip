@@ -315,6 +315,118 @@ __global__ __launch_bounds__(256) void col_reduce_vec_kernel(const T* __restrict
     partial[((int64_t)blockIdx.x * C + c) * 2 + 1] = sb;
   }
 }
+
+// ---- 16-byte-vector forms for ANY channel count with C % VE == 0 and C/VE <= 256 (EfficientNet-Lite3's 24..1392-channel maps):
+// thread t owns channel group t % VP of pixel slot t / VP; a block covers PPB = 256 / VP consecutive pixels per iteration, so the
+// accesses of a block stay one contiguous span and the per-channel parameters still live in registers. ------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void affine_act_gen_kernel(const T* __restrict__ y, const float* __restrict__ scale,
+                                                             const float* __restrict__ shift, const T* __restrict__ res,
+                                                             T* __restrict__ out, int64_t pixels, int C, int act, float slope) {
+  constexpr int VE = Elem<T>::VE;
+  const int VP = C / VE, PPB = 256 / VP;
+  const int g = threadIdx.x % VP, pl = threadIdx.x / VP;
+  if (pl >= PPB) return;
+  float sc[VE], sh[VE];
+#pragma unroll
+  for (int e = 0; e < VE; e++) { sc[e] = scale ? scale[g * VE + e] : 1.f; sh[e] = shift ? shift[g * VE + e] : 0.f; }
+  for (int64_t p = (int64_t)blockIdx.x * PPB + pl; p < pixels; p += (int64_t)gridDim.x * PPB) {
+    const int64_t o = p * C + g * VE;
+    float v[VE], r[VE];
+    ldv(y + o, v);
+    if (res) ldv(res + o, r);
+#pragma unroll
+    for (int e = 0; e < VE; e++) v[e] = act_fwd(v[e] * sc[e] + sh[e] + (res ? r[e] : 0.f), act, slope);
+    stv(out + o, v);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_apply_gen_kernel(const T* __restrict__ dz, const T* __restrict__ z,
+                                                               const T* __restrict__ y, const float* __restrict__ mean,
+                                                               const float* __restrict__ rstd, const float* __restrict__ scale,
+                                                               const float* __restrict__ c1, const float* __restrict__ c2,
+                                                               T* __restrict__ dy, T* __restrict__ dres, int64_t pixels, int C,
+                                                               int act, float slope) {
+  constexpr int VE = Elem<T>::VE;
+  const int VP = C / VE, PPB = 256 / VP;
+  const int g = threadIdx.x % VP, pl = threadIdx.x / VP;
+  if (pl >= PPB) return;
+  float mu[VE], rs[VE], sc[VE], k1[VE], k2[VE];
+#pragma unroll
+  for (int e = 0; e < VE; e++) {
+    const int c = g * VE + e;
+    mu[e] = mean[c]; rs[e] = rstd[c]; sc[e] = scale[c]; k1[e] = c1[c]; k2[e] = c2[c];
+  }
+  for (int64_t p = (int64_t)blockIdx.x * PPB + pl; p < pixels; p += (int64_t)gridDim.x * PPB) {
+    const int64_t o = p * C + g * VE;
+    float gg[VE], zz[VE], yy[VE], ov[VE];
+    ldv(dz + o, gg);
+    if (act) ldv(z + o, zz);
+    ldv(y + o, yy);
+#pragma unroll
+    for (int e = 0; e < VE; e++) {
+      if (act) gg[e] *= act_grad_from_out(zz[e], act, slope);
+      const float xh = (yy[e] - mu[e]) * rs[e];
+      ov[e] = sc[e] * (gg[e] - k1[e] - xh * k2[e]);
+    }
+    stv(dy + o, ov);
+    if (dres) stv(dres + o, gg);
+  }
+}
+
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void col_reduce_gen_kernel(const T* __restrict__ dz, const T* __restrict__ z,
+                                                             const T* __restrict__ y, const float* __restrict__ mean,
+                                                             const float* __restrict__ rstd, float* __restrict__ partial,
+                                                             int64_t pixels, int C, int act, float slope) {
+  constexpr int VE = Elem<T>::VE;
+  __shared__ float red[256 * VE * 2];
+  const int t = threadIdx.x;
+  const int VP = C / VE, PPB = 256 / VP;
+  const int g = t % VP, pl = t / VP;
+  const int64_t per = cdiv(pixels, (int64_t)gridDim.x);
+  const int64_t pbeg = (int64_t)blockIdx.x * per, pend = pbeg + per < pixels ? pbeg + per : pixels;
+  float mu[VE], rs[VE], a[VE], b[VE];
+#pragma unroll
+  for (int e = 0; e < VE; e++) {
+    a[e] = 0.f; b[e] = 0.f;
+    mu[e] = MODE == 0 ? mean[g * VE + e] : 0.f; rs[e] = MODE == 0 ? rstd[g * VE + e] : 1.f;
+  }
+  if (pl < PPB)
+    for (int64_t p = pbeg + pl; p < pend; p += PPB) {
+      const int64_t o = p * C + g * VE;
+      float gg[VE];
+      ldv(dz + o, gg);
+      if (MODE == 0) {
+        float zz[VE], yy[VE];
+        if (act) ldv(z + o, zz);
+        ldv(y + o, yy);
+#pragma unroll
+        for (int e = 0; e < VE; e++) {
+          if (act) gg[e] *= act_grad_from_out(zz[e], act, slope);
+          a[e] += gg[e]; b[e] += gg[e] * ((yy[e] - mu[e]) * rs[e]);
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < VE; e++) a[e] += gg[e];
+      }
+    }
+#pragma unroll
+  for (int e = 0; e < VE; e++) { red[(t * VE + e) * 2] = a[e]; red[(t * VE + e) * 2 + 1] = b[e]; }
+  __syncthreads();
+  for (int c = t; c < C; c += 256) {
+    const int gg = c / VE, e = c - gg * VE;
+    float sa = 0.f, sb = 0.f;
+    for (int q = 0; q < PPB; q++) { sa += red[((q * VP + gg) * VE + e) * 2]; sb += red[((q * VP + gg) * VE + e) * 2 + 1]; }
+    partial[((int64_t)blockIdx.x * C + c) * 2] = sa;
+    partial[((int64_t)blockIdx.x * C + c) * 2 + 1] = sb;
+  }
+}
+static bool gen_ok(int C, int dtype) {
+  const int ve = dtype == 0 ? 4 : 8;
+  return (C % ve) == 0 && C / ve <= 256;
+}
 static bool vec_ok(int C, int dtype) {
   const int ve = dtype == 0 ? 4 : 8;
   if (C % ve) return false;
@@ -414,6 +526,13 @@ void launch_affine_act(const void* y, const float* scale, const float* shift, co
     else hipLaunchKernelGGL((affine_act_vec_kernel<bf16_t>), dim3(gv), dim3(256), 0, st, (const bf16_t*)y, scale, shift, (const bf16_t*)res, (bf16_t*)out, nvec, C, act, slope);
     return;
   }
+  if (gen_ok(C, dtype)) {
+    const int ppb = 256 / (C / (dtype == 0 ? 4 : 8));
+    unsigned gg = (unsigned)std::max<int64_t>(1, std::min<int64_t>(cdiv(pixels, ppb), 2048));
+    if (dtype == 0) hipLaunchKernelGGL((affine_act_gen_kernel<float>), dim3(gg), dim3(256), 0, st, (const float*)y, scale, shift, (const float*)res, (float*)out, pixels, C, act, slope);
+    else hipLaunchKernelGGL((affine_act_gen_kernel<bf16_t>), dim3(gg), dim3(256), 0, st, (const bf16_t*)y, scale, shift, (const bf16_t*)res, (bf16_t*)out, pixels, C, act, slope);
+    return;
+  }
   bool v4 = (C % 4 == 0);
   unsigned g = ew_grid(v4 ? total / 4 : total);
 #define RD_AA(T, V) hipLaunchKernelGGL((affine_act_kernel<T, V>), dim3(g), dim3(256), 0, st, (const T*)y, scale, shift, (const T*)res, (T*)out, total, C, act, slope)
@@ -432,6 +551,11 @@ void launch_bn_bwd_reduce(const void* dz, const void* z, const void* y, const fl
   if (vec_ok(C, dtype)) {
     if (dtype == 0) hipLaunchKernelGGL((col_reduce_vec_kernel<float, 0>), dim3(grid.x), dim3(256), 0, st, (const float*)dz, (const float*)z, (const float*)y, mean, rstd, partial, pixels, C, act, slope);
     else hipLaunchKernelGGL((col_reduce_vec_kernel<bf16_t, 0>), dim3(grid.x), dim3(256), 0, st, (const bf16_t*)dz, (const bf16_t*)z, (const bf16_t*)y, mean, rstd, partial, pixels, C, act, slope);
+    return;
+  }
+  if (gen_ok(C, dtype)) {
+    if (dtype == 0) hipLaunchKernelGGL((col_reduce_gen_kernel<float, 0>), dim3(grid.x), dim3(256), 0, st, (const float*)dz, (const float*)z, (const float*)y, mean, rstd, partial, pixels, C, act, slope);
+    else hipLaunchKernelGGL((col_reduce_gen_kernel<bf16_t, 0>), dim3(grid.x), dim3(256), 0, st, (const bf16_t*)dz, (const bf16_t*)z, (const bf16_t*)y, mean, rstd, partial, pixels, C, act, slope);
     return;
   }
   if (dtype == 0)
@@ -456,6 +580,13 @@ void launch_bn_bwd_apply(const void* dz, const void* z, const void* y, const flo
     else hipLaunchKernelGGL((bn_bwd_apply_vec_kernel<bf16_t>), dim3(gv), dim3(256), 0, st, (const bf16_t*)dz, (const bf16_t*)z, (const bf16_t*)y, mean, rstd, scale, c1, c2, (bf16_t*)dy, (bf16_t*)dres, nvec, C, act, slope);
     return;
   }
+  if (gen_ok(C, dtype)) {
+    const int ppb = 256 / (C / (dtype == 0 ? 4 : 8));
+    unsigned gg = (unsigned)std::max<int64_t>(1, std::min<int64_t>(cdiv(pixels, ppb), 2048));
+    if (dtype == 0) hipLaunchKernelGGL((bn_bwd_apply_gen_kernel<float>), dim3(gg), dim3(256), 0, st, (const float*)dz, (const float*)z, (const float*)y, mean, rstd, scale, c1, c2, (float*)dy, (float*)dres, pixels, C, act, slope);
+    else hipLaunchKernelGGL((bn_bwd_apply_gen_kernel<bf16_t>), dim3(gg), dim3(256), 0, st, (const bf16_t*)dz, (const bf16_t*)z, (const bf16_t*)y, mean, rstd, scale, c1, c2, (bf16_t*)dy, (bf16_t*)dres, pixels, C, act, slope);
+    return;
+  }
   bool v4 = (C % 4 == 0);
   unsigned g = ew_grid(v4 ? total / 4 : total);
 #define RD_BA(T, V) hipLaunchKernelGGL((bn_bwd_apply_kernel<T, V>), dim3(g), dim3(256), 0, st, (const T*)dz, (const T*)z, (const T*)y, mean, rstd, scale, c1, c2, (T*)dy, (T*)dres, total, C, act, slope)
@@ -476,6 +607,9 @@ void launch_colsum(const void* x, float* partial, float* out, int accumulate, in
   if (vec_ok(C, dtype)) {
     if (dtype == 0) hipLaunchKernelGGL((col_reduce_vec_kernel<float, 1>), dim3(nr), dim3(256), 0, st, (const float*)x, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, partial, rows, C, 0, 0.f);
     else hipLaunchKernelGGL((col_reduce_vec_kernel<bf16_t, 1>), dim3(nr), dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)nullptr, (const bf16_t*)nullptr, (const float*)nullptr, (const float*)nullptr, partial, rows, C, 0, 0.f);
+  } else if (gen_ok(C, dtype)) {
+    if (dtype == 0) hipLaunchKernelGGL((col_reduce_gen_kernel<float, 1>), dim3(nr), dim3(256), 0, st, (const float*)x, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, partial, rows, C, 0, 0.f);
+    else hipLaunchKernelGGL((col_reduce_gen_kernel<bf16_t, 1>), dim3(nr), dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)nullptr, (const bf16_t*)nullptr, (const float*)nullptr, (const float*)nullptr, partial, rows, C, 0, 0.f);
   } else if (dtype == 0)
     hipLaunchKernelGGL((col_reduce_kernel<float, 1>), grid, dim3(256), 0, st, (const float*)x, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, partial, rows, C, g.CB, g.PL, 0, 0.f);
   else

@@ -74,9 +74,8 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_tr_kernel(WgradArgs a, int 
 #pragma unroll
     for (int j = 0; j < NCW; j++) acc[i][j] = f32x4{0, 0, 0, 0};
 
-  uint4 rx[XIT], ry[YIT];
   const bool yvec = (a.Cout & 7) == 0;
-  auto fetch = [&](int tl) RD_INLINE_LAMBDA {
+  auto fetch = [&](int tl, uint4 (&rx)[XIT], uint4 (&ry)[YIT]) RD_INLINE_LAMBDA {
     const int tw_ = tl % tilesW; const int q_ = tl / tilesW; const int th_ = q_ % tilesH; const int n = q_ / tilesH;
     const int oh0 = th_ * TH, ow0 = tw_ * TW;
 #pragma unroll
@@ -114,7 +113,7 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_tr_kernel(WgradArgs a, int 
       ry[i] = v;
     }
   };
-  auto stash = [&](int buf) RD_INLINE_LAMBDA {
+  auto stash = [&](int buf, const uint4 (&rx)[XIT], const uint4 (&ry)[YIT]) RD_INLINE_LAMBDA {
 #pragma unroll
     for (int i = 0; i < XIT; i++) { const int idx = t + 256 * i; if (idx < NXS) sX[buf][idx] = rx[i]; }
 #pragma unroll
@@ -145,18 +144,39 @@ __global__ __launch_bounds__(256) void conv3x3_wgrad_tr_kernel(WgradArgs a, int 
     }
   };
 
-  if (tile < tend) fetch(tile);
-  int buf = 0;
-  while (tile < tend) {
-    stash(buf);
-    __syncthreads();
-    const int next = tile + G8;
-    if (next < tend) fetch(next);
-    // two fully unrolled bodies (a wave owns NCW or NCW-1 column tiles): a per-MFMA branch makes the compiler shuttle accumulators
+  // two fully unrolled bodies (a wave owns NCW or NCW-1 column tiles): a per-MFMA branch makes the compiler shuttle accumulators
+  auto tile_body = [&](int buf) RD_INLINE_LAMBDA {
     if (jv[NCW - 1]) compute(buf, std::integral_constant<int, NCW>{});
     else compute(buf, std::integral_constant<int, NCW - 1>{});
-    tile = next;
-    buf ^= 1;
+  };
+  // prefetch distance two tiles where the register budget allows (narrow slices), one otherwise
+  constexpr bool DEEP = (XIT + YIT) <= 5;
+  uint4 xa[XIT], ya_[YIT], xb_[DEEP ? XIT : 1], yb_[DEEP ? YIT : 1];
+  int buf = 0;
+  if (DEEP) {
+    int t0 = tile, t1 = tile + G8;
+    if (t0 < tend) fetch(t0, xa, ya_);
+    if (t1 < tend) fetch(t1, reinterpret_cast<uint4 (&)[XIT]>(xb_), reinterpret_cast<uint4 (&)[YIT]>(yb_));
+    while (t0 < tend) {
+      stash(buf, xa, ya_);
+      __syncthreads();
+      { const int t2 = t1 + G8; if (t2 < tend) fetch(t2, xa, ya_); tile_body(buf); t0 = t1; t1 = t2; buf ^= 1; }
+      if (t0 >= tend) break;
+      stash(buf, reinterpret_cast<const uint4 (&)[XIT]>(xb_), reinterpret_cast<const uint4 (&)[YIT]>(yb_));
+      __syncthreads();
+      { const int t2 = t1 + G8; if (t2 < tend) fetch(t2, reinterpret_cast<uint4 (&)[XIT]>(xb_), reinterpret_cast<uint4 (&)[YIT]>(yb_)); tile_body(buf); t0 = t1; t1 = t2; buf ^= 1; }
+    }
+  } else {
+    if (tile < tend) fetch(tile, xa, ya_);
+    while (tile < tend) {
+      stash(buf, xa, ya_);
+      __syncthreads();
+      const int next = tile + G8;
+      if (next < tend) fetch(next, xa, ya_);
+      tile_body(buf);
+      tile = next;
+      buf ^= 1;
+    }
   }
 
   float* slab = a.slab + (int64_t)blockIdx.x * a.Cout * a.K;

@@ -554,8 +554,9 @@ def conv_block(x, weight, *, x2=None, bias=None, stride=1, pad=None, up=None, bn
             rows = lib.rd_colsum_rows(pixels, Cout)
             part = torch.empty((rows, Cout, 2), dtype=torch.float32, device=x.device)
             _chk(lib.rd_colsum(_p(dy), _p(part), _p(db), acc, pixels, Cout, dt, st), "rd_colsum")
-        if w_req and KH == 1 and KW == 1 and stride == 1 and not is_up and C1 % 64 == 0 and C2 % 64 == 0 and Cout % 64 == 0 \
-                and _state["defer_wgrad"]:
+        ve = 16 // es
+        if w_req and KH == 1 and KW == 1 and stride == 1 and not is_up and _state["defer_wgrad"] and C1 % ve == 0 and Cout % ve == 0 \
+                and (C2 == 0 or (C1 % 64 == 0 and C2 % ve == 0)):
             t.deferred.append(dict(x=x, x2=x2, dy=dy, weight=weight, M=pixels, C1=C1, C2=C2, Cin=Cin, Cout=Cout, flops=flops))
         elif w_req:
             dw, acc = t.param_grad(weight)

@@ -181,6 +181,10 @@ def test_grouped_linear_wgrad(gpu):
     P.bf16_exact_conv_case(gpu, cin=128, cout=256, k=1, s=1, H=240, W=21, N=1, cin2=128)
     P.conv_case(gpu, dict(cin=128, cout=64, k=1, s=1, H=13, W=11, N=2, bn=False, act=None))
     P.conv_case(gpu, dict(cin=64, cout=128, k=1, s=1, H=30, W=23, N=1, bn=True))
+    # ragged edge tiles: channel counts that are multiples of the 16-byte vector only
+    P.bf16_exact_conv_case(gpu, cin=24, cout=144, k=1, s=1, H=9, W=7, N=2)
+    P.bf16_exact_conv_case(gpu, cin=64, cout=40, k=1, s=1, H=11, W=5, N=1, cin2=24)
+    P.conv_case(gpu, dict(cin=36, cout=100, k=1, s=1, H=13, W=11, N=2, bn=True))
     P.conv_case(gpu, dict(cin=128, cout=128, k=1, s=1, H=240, W=21, N=1, bn=False, act=None))
 
 
@@ -197,3 +201,10 @@ def test_loftr_unfused_path(gpu):
         P.transformer_case(gpu)
     finally:
         engine.set_fused_loftr(True)
+
+
+def test_bn_generic_channel_counts(gpu):
+    """BatchNorm / activation passes for channel counts whose 16-byte vector count does not divide 256 (EfficientNet-Lite3 widths)."""
+    P.conv_case(gpu, dict(cin=24, cout=40, k=1, s=1, H=13, W=11, N=2, bn=True))
+    P.conv_case(gpu, dict(cin=16, cout=144, k=1, s=1, H=9, W=10, N=2, bn=True))
+    P.conv_case(gpu, dict(cin=8, cout=232, k=3, s=1, H=6, W=7, N=1, bn=True))
