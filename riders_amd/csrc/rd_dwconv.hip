@@ -198,6 +198,124 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_vec_kernel(const T* __restri
   }
 }
 
+
+// ---- stride-1 forms with a sliding register window: a thread produces DWR = 4 consecutive outputs of a row, so a filter row costs
+// DWR + K - 1 loads instead of DWR * K (5x5: 10 loads per output instead of 25; the per-tap form above is bound by L1 load issue). ----
+static constexpr int DWR = 4;
+template <typename T, int K, int MODE>  // MODE 0: forward, 1: data gradient (stride 1)
+__global__ __launch_bounds__(256) void dwconv_run_kernel(const T* __restrict__ src, const float* __restrict__ w, T* __restrict__ dst, int N,
+                                                         int H, int W, int C, int OH, int OW, int p, int C4B, int PL, int PPB) {
+  const int t = threadIdx.x, cl = t % C4B, pl = t / C4B;
+  const int c = (blockIdx.y * C4B + cl) * 4;
+  if (c >= C) return;
+  float wr[K * K][4];
+#pragma unroll
+  for (int j = 0; j < K * K; j++)
+#pragma unroll
+    for (int e = 0; e < 4; e++) wr[j][e] = w[(c + e) * K * K + j];
+  const int DH = MODE ? H : OH, DW = MODE ? W : OW;           // destination size
+  const int SH = MODE ? OH : H, SW = MODE ? OW : W;           // source size
+  const int runs = (DW + DWR - 1) / DWR;
+  const int64_t M = (int64_t)N * DH * runs;
+  const int64_t mbeg = (int64_t)blockIdx.x * PPB, mend = mbeg + PPB < M ? mbeg + PPB : M;
+  for (int64_t m = mbeg + pl; m < mend; m += PL) {
+    const int rw = (int)(m % runs); int64_t q = m / runs; const int dh = (int)(q % DH); const int n = (int)(q / DH);
+    const int dw0 = rw * DWR;
+    const int cbase = MODE ? dw0 + p - (K - 1) : dw0 - p;     // source column of window slot 0
+    float acc[DWR][4];
+#pragma unroll
+    for (int r = 0; r < DWR; r++)
+#pragma unroll
+      for (int e = 0; e < 4; e++) acc[r][e] = 0.f;
+#pragma unroll
+    for (int kh = 0; kh < K; kh++) {
+      const int sh = MODE ? dh + p - kh : dh - p + kh;
+      if ((unsigned)sh >= (unsigned)SH) continue;
+      const T* row = src + (((int64_t)n * SH + sh) * SW) * C + c;
+      float v[DWR + K - 1][4];
+#pragma unroll
+      for (int j = 0; j < DWR + K - 1; j++) {
+        const int sw = cbase + j;
+        if ((unsigned)sw < (unsigned)SW) ld4(row + (int64_t)sw * C, v[j]);
+        else { v[j][0] = 0.f; v[j][1] = 0.f; v[j][2] = 0.f; v[j][3] = 0.f; }
+      }
+#pragma unroll
+      for (int kw = 0; kw < K; kw++)
+#pragma unroll
+        for (int r = 0; r < DWR; r++)
+#pragma unroll
+          for (int e = 0; e < 4; e++) acc[r][e] += v[MODE ? r + K - 1 - kw : r + kw][e] * wr[kh * K + kw][e];
+    }
+#pragma unroll
+    for (int r = 0; r < DWR; r++)
+      if (dw0 + r < DW) st4(dst + (((int64_t)n * DH + dh) * DW + dw0 + r) * C + c, acc[r]);
+  }
+}
+
+template <typename T, int K>
+__global__ __launch_bounds__(256) void dwconv_wgrad_run_kernel(const T* __restrict__ x, const T* __restrict__ dy, float* __restrict__ partial,
+                                                               int N, int H, int W, int C, int OH, int OW, int p, int C4B, int PL) {
+  __shared__ float red[256][4];
+  const int t = threadIdx.x, cl = t % C4B, pl = t / C4B;
+  const int c = (blockIdx.y * C4B + cl) * 4;
+  const bool cv = c < C;
+  const int runs = (OW + DWR - 1) / DWR;
+  const int64_t units = (int64_t)N * OH * runs;
+  const int64_t per = cdiv(units, gridDim.x);
+  const int64_t ubeg = (int64_t)blockIdx.x * per, uend = ubeg + per < units ? ubeg + per : units;
+  float acc[K * K][4];
+#pragma unroll
+  for (int j = 0; j < K * K; j++)
+#pragma unroll
+    for (int e = 0; e < 4; e++) acc[j][e] = 0.f;
+  if (cv) {
+    for (int64_t m = ubeg + pl; m < uend; m += PL) {
+      const int rw = (int)(m % runs); int64_t q = m / runs; const int oh = (int)(q % OH); const int n = (int)(q / OH);
+      const int ow0 = rw * DWR;
+      float g[DWR][4];
+#pragma unroll
+      for (int r = 0; r < DWR; r++) {
+        if (ow0 + r < OW) ld4(dy + (((int64_t)n * OH + oh) * OW + ow0 + r) * C + c, g[r]);
+        else { g[r][0] = 0.f; g[r][1] = 0.f; g[r][2] = 0.f; g[r][3] = 0.f; }
+      }
+#pragma unroll
+      for (int kh = 0; kh < K; kh++) {
+        const int ih = oh - p + kh;
+        if ((unsigned)ih >= (unsigned)H) continue;
+        const T* row = x + (((int64_t)n * H + ih) * W) * C + c;
+        float v[DWR + K - 1][4];
+#pragma unroll
+        for (int j = 0; j < DWR + K - 1; j++) {
+          const int iw = ow0 - p + j;
+          if ((unsigned)iw < (unsigned)W) ld4(row + (int64_t)iw * C, v[j]);
+          else { v[j][0] = 0.f; v[j][1] = 0.f; v[j][2] = 0.f; v[j][3] = 0.f; }
+        }
+#pragma unroll
+        for (int kw = 0; kw < K; kw++)
+#pragma unroll
+          for (int r = 0; r < DWR; r++)
+#pragma unroll
+            for (int e = 0; e < 4; e++) acc[kh * K + kw][e] += g[r][e] * v[r + kw][e];
+      }
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < K * K; j++) {
+#pragma unroll
+    for (int e = 0; e < 4; e++) red[t][e] = acc[j][e];
+    __syncthreads();
+    if (pl == 0 && cv) {
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        float sacc = 0.f;
+        for (int q = 0; q < PL; q++) sacc += red[q * C4B + cl][e];
+        partial[((int64_t)blockIdx.x * C + c + e) * (K * K) + j] = sacc;
+      }
+    }
+    __syncthreads();
+  }
+}
+
 __global__ __launch_bounds__(64) void dwconv_wgrad_finalize_kernel(const float* __restrict__ partial, int rows, int CK, float* dw,
                                                                    int accumulate) {
   const int i = blockIdx.x, lane = threadIdx.x;
@@ -333,6 +451,15 @@ static VG vgeom(int C) {
 template <typename T, int MODE>
 static void launch_dw_vec(const void* src, const float* w, void* dst, int N, int H, int W, int C, int OH, int OW, int k, int s, int p, hipStream_t st) {
   VG g = vgeom(C);
+  if (s == 1) {  // sliding-window form: units of DWR outputs
+    const int DH = MODE ? H : OH, DW = MODE ? W : OW;
+    int64_t units = (int64_t)N * DH * cdiv(DW, DWR);
+    const int ppb = g.PL * 4;
+    dim3 rgrid((unsigned)cdiv(units, ppb), g.nchunk);
+    if (k == 3) hipLaunchKernelGGL((dwconv_run_kernel<T, 3, MODE>), rgrid, dim3(256), 0, st, (const T*)src, w, (T*)dst, N, H, W, C, OH, OW, p, g.C4B, g.PL, ppb);
+    else hipLaunchKernelGGL((dwconv_run_kernel<T, 5, MODE>), rgrid, dim3(256), 0, st, (const T*)src, w, (T*)dst, N, H, W, C, OH, OW, p, g.C4B, g.PL, ppb);
+    return;
+  }
   int64_t M = (int64_t)N * (MODE ? (int64_t)H * W : (int64_t)OH * OW);
   dim3 grid((unsigned)cdiv(M, g.PPB), g.nchunk);
   if (k == 3) hipLaunchKernelGGL((dwconv_vec_kernel<T, 3, MODE>), grid, dim3(256), 0, st, (const T*)src, w, (T*)dst, N, H, W, C, OH, OW, s, p, g.C4B, g.PL, g.PPB);
@@ -367,6 +494,14 @@ void launch_dwconv_wgrad(const void* x, const void* dy, float* partial, float* d
   if (C % 4 == 0 && (k == 3 || k == 5)) {
     VG v = vgeom(C);
     dim3 vgrid(rows, v.nchunk);
+    if (s == 1) {
+#define RD_DWR(T, K) hipLaunchKernelGGL((dwconv_wgrad_run_kernel<T, K>), vgrid, dim3(256), 0, st, (const T*)x, (const T*)dy, partial, N, H, W, C, OH, OW, p, v.C4B, v.PL)
+      if (dtype == 0) { if (k == 3) RD_DWR(float, 3); else RD_DWR(float, 5); }
+      else { if (k == 3) RD_DWR(bf16_t, 3); else RD_DWR(bf16_t, 5); }
+#undef RD_DWR
+      hipLaunchKernelGGL(dwconv_wgrad_finalize_kernel, dim3(C * k * k), dim3(64), 0, st, partial, rows, C * k * k, dw, accumulate);
+      return;
+    }
 #define RD_DWV(T, K) hipLaunchKernelGGL((dwconv_wgrad_vec_kernel<T, K>), vgrid, dim3(256), 0, st, (const T*)x, (const T*)dy, partial, N, H, W, C, OH, OW, s, p, v.C4B, v.PL)
     if (dtype == 0) { if (k == 3) RD_DWV(float, 3); else RD_DWV(float, 5); }
     else { if (k == 3) RD_DWV(bf16_t, 3); else RD_DWV(bf16_t, 5); }

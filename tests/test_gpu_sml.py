@@ -11,6 +11,8 @@ def test_effnet_blocks(gpu):
     S.effnet_block_case(gpu, "ir", 16, 16, 5, 1, H=7, W=9)
     S.effnet_block_case(gpu, "ds", 32, 24, 3, 1, H=8, W=8)
     S.effnet_block_case(gpu, "ir", 136, 232, 5, 2, H=18, W=24)
+    S.effnet_block_case(gpu, "ir", 48, 48, 5, 1, H=19, W=30)      # sliding-window depthwise kernels, ragged last run
+    S.effnet_block_case(gpu, "ir", 24, 24, 3, 1, H=10, W=13)
 
 
 def test_bilinear(gpu):
