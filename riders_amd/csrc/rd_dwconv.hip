@@ -523,7 +523,75 @@ void launch_bn_stats(const void* y, float* partial, int64_t pixels, int C, int d
   if (dtype == 0) hipLaunchKernelGGL((bn_stats_kernel<float>), grid, dim3(256), 0, st, (const float*)y, partial, pixels, C, g.CB, g.PL);
   else hipLaunchKernelGGL((bn_stats_kernel<bf16_t>), grid, dim3(256), 0, st, (const bf16_t*)y, partial, pixels, C, g.CB, g.PL);
 }
+// 16-byte-vector forms (C % VE == 0): one thread interpolates / gathers VE channels
+template <typename T>
+__global__ __launch_bounds__(256) void bilinear_fwd_vec_kernel(const T* __restrict__ x, T* __restrict__ y, int N, int H, int W, int C, int OH,
+                                                               int OW, int align) {
+  constexpr int VE = Elem<T>::VE;
+  const int CV = C / VE;
+  const int64_t total = (int64_t)N * OH * OW * CV;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int cv = (int)(i % CV); int64_t q = i / CV;
+    int ow = (int)(q % OW); q /= OW; int oh = (int)(q % OH); int n = (int)(q / OH);
+    int h0, h1, w0, w1; float lh, lw;
+    bil_src(oh, H, OH, align, h0, h1, lh);
+    bil_src(ow, W, OW, align, w0, w1, lw);
+    const T* b = x + (int64_t)n * H * W * C + cv * VE;
+    float v00[VE], v01[VE], v10[VE], v11[VE], o[VE];
+    ldv(b + ((int64_t)h0 * W + w0) * C, v00); ldv(b + ((int64_t)h0 * W + w1) * C, v01);
+    ldv(b + ((int64_t)h1 * W + w0) * C, v10); ldv(b + ((int64_t)h1 * W + w1) * C, v11);
+#pragma unroll
+    for (int e = 0; e < VE; e++) o[e] = (1.f - lh) * ((1.f - lw) * v00[e] + lw * v01[e]) + lh * ((1.f - lw) * v10[e] + lw * v11[e]);
+    stv(y + i * VE, o);
+  }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void bilinear_bwd_vec_kernel(const T* __restrict__ dy, T* __restrict__ dx, int N, int H, int W, int C, int OH,
+                                                               int OW, int align) {
+  constexpr int VE = Elem<T>::VE;
+  const int CV = C / VE;
+  const int64_t total = (int64_t)N * H * W * CV;
+  const int rh = (OH + H - 1) / H + 2, rw = (OW + W - 1) / W + 2;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int cv = (int)(i % CV); int64_t q = i / CV;
+    int w = (int)(q % W); q /= W; int h = (int)(q % H); int n = (int)(q / H);
+    int ohc = (int)(((int64_t)h * OH) / H), owc = (int)(((int64_t)w * OW) / W);
+    float g[VE];
+#pragma unroll
+    for (int e = 0; e < VE; e++) g[e] = 0.f;
+    for (int oh = max(ohc - rh, 0); oh <= min(ohc + rh, OH - 1); oh++) {
+      int h0, h1; float lh;
+      bil_src(oh, H, OH, align, h0, h1, lh);
+      float wh = (h0 == h ? 1.f - lh : 0.f) + (h1 == h ? lh : 0.f);
+      if (wh == 0.f) continue;
+      for (int ow = max(owc - rw, 0); ow <= min(owc + rw, OW - 1); ow++) {
+        int w0, w1; float lw;
+        bil_src(ow, W, OW, align, w0, w1, lw);
+        float ww = (w0 == w ? 1.f - lw : 0.f) + (w1 == w ? lw : 0.f);
+        if (ww == 0.f) continue;
+        float v[VE];
+        ldv(dy + (((int64_t)n * OH + oh) * OW + ow) * C + cv * VE, v);
+#pragma unroll
+        for (int e = 0; e < VE; e++) g[e] += wh * ww * v[e];
+      }
+    }
+    stv(dx + i * VE, g);
+  }
+}
 void launch_bilinear(const void* x, void* y, int N, int H, int W, int C, int OH, int OW, int align, int backward, int dtype, hipStream_t st) {
+  const int ve = dtype == 0 ? 4 : 8;
+  if (C % ve == 0) {
+    if (!backward) {
+      unsigned g = ew_grid((int64_t)N * OH * OW * (C / ve));
+      if (dtype == 0) hipLaunchKernelGGL((bilinear_fwd_vec_kernel<float>), dim3(g), dim3(256), 0, st, (const float*)x, (float*)y, N, H, W, C, OH, OW, align);
+      else hipLaunchKernelGGL((bilinear_fwd_vec_kernel<bf16_t>), dim3(g), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, N, H, W, C, OH, OW, align);
+    } else {
+      unsigned g = ew_grid((int64_t)N * H * W * (C / ve));
+      if (dtype == 0) hipLaunchKernelGGL((bilinear_bwd_vec_kernel<float>), dim3(g), dim3(256), 0, st, (const float*)x, (float*)y, N, H, W, C, OH, OW, align);
+      else hipLaunchKernelGGL((bilinear_bwd_vec_kernel<bf16_t>), dim3(g), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y, N, H, W, C, OH, OW, align);
+    }
+    return;
+  }
   if (!backward) {
     unsigned g = ew_grid((int64_t)N * OH * OW * C);
     if (dtype == 0) hipLaunchKernelGGL((bilinear_fwd_kernel<float>), dim3(g), dim3(256), 0, st, (const float*)x, (float*)y, N, H, W, C, OH, OW, align);

@@ -100,7 +100,7 @@ static int red_rows(int64_t pixels, int C) {
   RedGeom g = red_geom(C);
   int64_t per_block = (int64_t)g.PL * 64;  // >= 64 pixels per thread-row
   int64_t r = cdiv(pixels, per_block);
-  return (int)std::max<int64_t>(1, std::min<int64_t>(r, 1024));
+  return (int)std::max<int64_t>(1, std::min<int64_t>(r, 4096));   // short per-block loops: the reduce kernels are load-latency bound
 }
 
 // MODE 0: (sum dpre, sum dpre*xhat) for BN backward; MODE 1: column sum of x (bias gradient)
@@ -281,22 +281,31 @@ __global__ __launch_bounds__(256) void col_reduce_vec_kernel(const T* __restrict
     mu[e] = MODE == 0 ? mean[c0 + e] : 0.f; rs[e] = MODE == 0 ? rstd[c0 + e] : 1.f;
   }
   const int64_t vend = pend * VP;
-  for (int64_t i = pbeg * VP + t; i < vend; i += 256) {
-    float g[VE];
-    ldv(dz + i * VE, g);
-    if (MODE == 0) {
-      float zz[VE], yy[VE];
-      if (act) ldv(z + i * VE, zz);
-      ldv(y + i * VE, yy);
+  auto accum = [&](const float (&g0)[VE], const float (&zz)[VE], const float (&yy)[VE]) RD_INLINE_LAMBDA {
 #pragma unroll
-      for (int e = 0; e < VE; e++) {
-        if (act) g[e] *= act_grad_from_out(zz[e], act, slope);
-        a[e] += g[e]; b[e] += g[e] * ((yy[e] - mu[e]) * rs[e]);
-      }
-    } else {
-#pragma unroll
-      for (int e = 0; e < VE; e++) a[e] += g[e];
+    for (int e = 0; e < VE; e++) {
+      float gg = g0[e];
+      if (MODE == 0) {
+        if (act) gg *= act_grad_from_out(zz[e], act, slope);
+        a[e] += gg; b[e] += gg * ((yy[e] - mu[e]) * rs[e]);
+      } else a[e] += gg;
     }
+  };
+  int64_t i = pbeg * VP + t;
+  for (; i + 256 < vend; i += 512) {   // two independent load sets in flight per iteration
+    float g0[VE], z0[VE], y0[VE], g1[VE], z1[VE], y1[VE];
+    ldv(dz + i * VE, g0); ldv(dz + (i + 256) * VE, g1);
+    if (MODE == 0) {
+      if (act) { ldv(z + i * VE, z0); ldv(z + (i + 256) * VE, z1); }
+      ldv(y + i * VE, y0); ldv(y + (i + 256) * VE, y1);
+    }
+    accum(g0, z0, y0); accum(g1, z1, y1);
+  }
+  for (; i < vend; i += 256) {
+    float g0[VE], z0[VE], y0[VE];
+    ldv(dz + i * VE, g0);
+    if (MODE == 0) { if (act) ldv(z + i * VE, z0); ldv(y + i * VE, y0); }
+    accum(g0, z0, y0);
   }
   // lanes of a wave that share a channel group (lane % VP), fixed xor tree
   for (int o = 32; o >= VP; o >>= 1) {
@@ -393,25 +402,36 @@ __global__ __launch_bounds__(256) void col_reduce_gen_kernel(const T* __restrict
     a[e] = 0.f; b[e] = 0.f;
     mu[e] = MODE == 0 ? mean[g * VE + e] : 0.f; rs[e] = MODE == 0 ? rstd[g * VE + e] : 1.f;
   }
-  if (pl < PPB)
-    for (int64_t p = pbeg + pl; p < pend; p += PPB) {
-      const int64_t o = p * C + g * VE;
-      float gg[VE];
-      ldv(dz + o, gg);
+  auto accum = [&](const float (&g0)[VE], const float (&zz)[VE], const float (&yy)[VE]) RD_INLINE_LAMBDA {
+#pragma unroll
+    for (int e = 0; e < VE; e++) {
+      float gv = g0[e];
       if (MODE == 0) {
-        float zz[VE], yy[VE];
-        if (act) ldv(z + o, zz);
-        ldv(y + o, yy);
-#pragma unroll
-        for (int e = 0; e < VE; e++) {
-          if (act) gg[e] *= act_grad_from_out(zz[e], act, slope);
-          a[e] += gg[e]; b[e] += gg[e] * ((yy[e] - mu[e]) * rs[e]);
-        }
-      } else {
-#pragma unroll
-        for (int e = 0; e < VE; e++) a[e] += gg[e];
-      }
+        if (act) gv *= act_grad_from_out(zz[e], act, slope);
+        a[e] += gv; b[e] += gv * ((yy[e] - mu[e]) * rs[e]);
+      } else a[e] += gv;
     }
+  };
+  if (pl < PPB) {
+    int64_t p = pbeg + pl;
+    for (; p + PPB < pend; p += 2 * PPB) {   // two independent load sets in flight per iteration
+      const int64_t o0 = p * C + g * VE, o1 = (p + PPB) * C + g * VE;
+      float g0[VE], z0[VE], y0[VE], g1[VE], z1[VE], y1[VE];
+      ldv(dz + o0, g0); ldv(dz + o1, g1);
+      if (MODE == 0) {
+        if (act) { ldv(z + o0, z0); ldv(z + o1, z1); }
+        ldv(y + o0, y0); ldv(y + o1, y1);
+      }
+      accum(g0, z0, y0); accum(g1, z1, y1);
+    }
+    for (; p < pend; p += PPB) {
+      const int64_t o0 = p * C + g * VE;
+      float g0[VE], z0[VE], y0[VE];
+      ldv(dz + o0, g0);
+      if (MODE == 0) { if (act) ldv(z + o0, z0); ldv(y + o0, y0); }
+      accum(g0, z0, y0);
+    }
+  }
 #pragma unroll
   for (int e = 0; e < VE; e++) { red[(t * VE + e) * 2] = a[e]; red[(t * VE + e) * 2 + 1] = b[e]; }
   __syncthreads();

@@ -204,7 +204,11 @@ class Tape:
         total = 0
         for it in items:
             M = it["M"]
-            it["rps"] = rps = 640 if M >= 2560 else max(64, (M + 3) // 4 + 63 & ~63)
+            if M > 40960:       # at most 64 token splits per item: every split writes (and the reduction re-reads) a Cout x Cin slab
+                rps = ((M + 63) // 64 + 63) & ~63
+            else:
+                rps = 640 if M >= 2560 else max(64, (M + 3) // 4 + 63 & ~63)
+            it["rps"] = rps
             it["nsplit"] = (M + rps - 1) // rps
             it["off"] = total
             total += it["nsplit"] * it["Cout"] * it["Cin"]
