@@ -62,7 +62,16 @@ int rd_conv_pack_weights(const float* w_oihw, void* packed, int32_t Cout, int32_
 typedef struct rd_pack_item {
   const float* w_oihw; void* packed;
   int32_t Cout, Cin, KH, KW, mode, dtype;
+  int32_t Cin_src;             /* 0 or the real input-channel count of w_oihw when the packed layout is zero-padded to Cin (mode 0) */
+  int32_t reserved;
 } rd_pack_item;
+/* forward operand with the input channels zero-padded from Cin_src to Cin (the 3-channel stems of utils/net_utils.py's encoders run
+   on the 16-byte-vector kernels: pad the image with rd_pad_channels, un-pad the weight gradient with rd_unpad_weight_grad) */
+int rd_conv_pack_weights_padded(const float* w_oihw, void* packed, int32_t Cout, int32_t Cin_src, int32_t Cin, int32_t KH, int32_t KW,
+                                int32_t dtype, void* stream);
+int rd_pad_channels(const void* src, void* dst, int64_t rows, int32_t C, int32_t Cpad, int32_t dtype, void* stream);
+int rd_unpad_weight_grad(const float* dw_padded, float* dw, int32_t Cout, int32_t Cin, int32_t Cin_pad, int32_t taps, int32_t accumulate,
+                         void* stream);
 int rd_conv_pack_weights_batch(const rd_pack_item* items, int32_t n, void* stream);
 /* Weight gradients of MANY 1x1 / linear layers in one launch + one ordered reduction (reference: autograd of the nn.Linear layers of
    RCNet/linear_attention.py:84-135; 96 products per RC-Net step).  gemm p: slab_p[split][Cout][C1+C2] = partial dY_p^T [X1_p | X2_p]

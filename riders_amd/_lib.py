@@ -36,7 +36,8 @@ class ConvDesc(ctypes.Structure):
 
 class PackItem(ctypes.Structure):
     _fields_ = [("w", ctypes.c_void_p), ("packed", ctypes.c_void_p), ("Cout", ctypes.c_int32), ("Cin", ctypes.c_int32),
-                ("KH", ctypes.c_int32), ("KW", ctypes.c_int32), ("mode", ctypes.c_int32), ("dtype", ctypes.c_int32)]
+                ("KH", ctypes.c_int32), ("KW", ctypes.c_int32), ("mode", ctypes.c_int32), ("dtype", ctypes.c_int32),
+                ("Cin_src", ctypes.c_int32), ("reserved", ctypes.c_int32)]
 
 
 class LwgGemm(ctypes.Structure):

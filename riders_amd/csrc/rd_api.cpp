@@ -61,6 +61,27 @@ int rd_conv_pack_weights(const float* w, void* packed, int32_t Cout, int32_t Cin
   rd::launch_pack_weights(w, packed, Cout, Cin, KH, KW, mode, dtype, S(stream));
   return done("rd_conv_pack_weights");
 }
+int rd_conv_pack_weights_padded(const float* w, void* packed, int32_t Cout, int32_t Cin_src, int32_t Cin, int32_t KH, int32_t KW,
+                                int32_t dtype, void* stream) {
+  if (!w || !packed) return fail("pack_weights_padded: null pointer");
+  if (!dt_ok(dtype) || Cin_src <= 0 || Cin < Cin_src) return fail("pack_weights_padded: bad dtype / channel counts");
+  rd::launch_pack_weights(w, packed, Cout, Cin, KH, KW, 0, dtype, S(stream), Cin_src);
+  return done("rd_conv_pack_weights_padded");
+}
+int rd_pad_channels(const void* src, void* dst, int64_t rows, int32_t C, int32_t Cpad, int32_t dtype, void* stream) {
+  if (!src || !dst) return fail("pad_channels: null pointer");
+  if (!dt_ok(dtype) || C <= 0 || Cpad < C || rows < 0) return fail("pad_channels: bad arguments");
+  if (rows == 0) return 0;
+  rd::launch_pad_channels(src, dst, rows, C, Cpad, dtype, S(stream));
+  return done("rd_pad_channels");
+}
+int rd_unpad_weight_grad(const float* dwp, float* dw, int32_t Cout, int32_t Cin, int32_t Cin_pad, int32_t taps, int32_t accumulate,
+                         void* stream) {
+  if (!dwp || !dw) return fail("unpad_weight_grad: null pointer");
+  if (Cout <= 0 || Cin <= 0 || Cin_pad < Cin || taps <= 0) return fail("unpad_weight_grad: bad arguments");
+  rd::launch_unpad_weight_grad(dwp, dw, Cout, Cin, Cin_pad, taps, accumulate, S(stream));
+  return done("rd_unpad_weight_grad");
+}
 int rd_conv_pack_weights_batch(const rd_pack_item* items, int32_t n, void* stream) {
   if (n <= 0) return 0;
   if (!items) return fail("pack_weights_batch: null table");

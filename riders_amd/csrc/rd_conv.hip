@@ -176,7 +176,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs a) {
 // mode 0 (forward): rows = Cout, C = Cin.   mode 1 (dgrad): rows = Cin, C = Cout, taps flipped.
 template <typename T>
 __global__ void pack_weights_kernel(const float* __restrict__ w, T* __restrict__ out, int Cout, int Cin, int KH,
-                                    int KW, int mode, int rows_pad, int Kpad) {
+                                    int KW, int mode, int rows_pad, int Kpad, int CinSrc) {
   int64_t total = (int64_t)rows_pad * Kpad;
   int rows = mode ? Cin : Cout, C = mode ? Cout : Cin;
   int K = KH * KW * C;
@@ -185,7 +185,8 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, T* __restrict__
     float v = 0.f;
     if (row < rows && k < K) {
       int tap = k / C, c = k - tap * C, kh = tap / KW, kw = tap - kh * KW;
-      if (mode == 0) v = w[(((int64_t)row * Cin + c) * KH + kh) * KW + kw];
+      // CinSrc < Cin: the packed layout carries zero-padded input channels (3-channel stems run on the 16-byte-vector paths)
+      if (mode == 0) v = c < CinSrc ? w[(((int64_t)row * CinSrc + c) * KH + kh) * KW + kw] : 0.f;
       else v = w[(((int64_t)c * Cin + row) * KH + (KH - 1 - kh)) * KW + (KW - 1 - kw)];
     }
     Elem<T>::st(&out[i], v);
@@ -193,7 +194,7 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, T* __restrict__
 }
 
 // batch form: blockIdx.y = item (device descriptor table), blockIdx.x strides over the item's packed elements
-struct PackItem { const float* w; void* out; int Cout, Cin, KH, KW, mode, dtype; };
+struct PackItem { const float* w; void* out; int Cout, Cin, KH, KW, mode, dtype, CinSrc, pad_; };
 template <typename T>
 __device__ __forceinline__ void pack_one(const PackItem& it, int bx, int nbx) {
   const int rows = it.mode ? it.Cin : it.Cout, C = it.mode ? it.Cout : it.Cin;
@@ -209,7 +210,8 @@ __device__ __forceinline__ void pack_one(const PackItem& it, int bx, int nbx) {
     float v = 0.f;
     if (row < rows && k < K) {
       int tap = k / C, c = k - tap * C, kh = tap / it.KW, kw = tap - kh * it.KW;
-      if (it.mode == 0) v = it.w[(((int64_t)row * it.Cin + c) * it.KH + kh) * it.KW + kw];
+      const int cs = it.CinSrc > 0 ? it.CinSrc : it.Cin;
+      if (it.mode == 0) v = c < cs ? it.w[(((int64_t)row * cs + c) * it.KH + kh) * it.KW + kw] : 0.f;
       else v = it.w[(((int64_t)c * it.Cin + row) * it.KH + (it.KH - 1 - kh)) * it.KW + (it.KW - 1 - kw)];
     }
     Elem<T>::st(&out[i], v);
@@ -779,19 +781,20 @@ void launch_conv(const ConvArgs& a, int dtype, hipStream_t st) {
 }
 
 void launch_pack_weights(const float* w, void* out, int Cout, int Cin, int KH, int KW, int mode, int dtype,
-                         hipStream_t st) {
+                         hipStream_t st, int CinSrc) {
+  if (CinSrc <= 0) CinSrc = Cin;
   int rows = mode ? Cin : Cout, C = mode ? Cout : Cin;
   int rows_pad = conv_rows_pad(rows), Kpad = conv_kpad(KH * KW * C, dtype);
   int64_t total = (int64_t)rows_pad * Kpad;
   unsigned grid = (unsigned)std::min<int64_t>(cdiv(total, 256), 4096);
   if (dtype == 0)
-    hipLaunchKernelGGL((pack_weights_kernel<float>), dim3(grid), dim3(256), 0, st, w, (float*)out, Cout, Cin, KH, KW, mode, rows_pad, Kpad);
+    hipLaunchKernelGGL((pack_weights_kernel<float>), dim3(grid), dim3(256), 0, st, w, (float*)out, Cout, Cin, KH, KW, mode, rows_pad, Kpad, CinSrc);
   else
-    hipLaunchKernelGGL((pack_weights_kernel<bf16_t>), dim3(grid), dim3(256), 0, st, w, (bf16_t*)out, Cout, Cin, KH, KW, mode, rows_pad, Kpad);
+    hipLaunchKernelGGL((pack_weights_kernel<bf16_t>), dim3(grid), dim3(256), 0, st, w, (bf16_t*)out, Cout, Cin, KH, KW, mode, rows_pad, Kpad, CinSrc);
 }
 
 void launch_pack_weights_batch(const void* items, int n, hipStream_t st) {
-  static_assert(sizeof(PackItem) == 40, "PackItem mirrors rd_pack_item");
+  static_assert(sizeof(PackItem) == 48, "PackItem mirrors rd_pack_item");
   hipLaunchKernelGGL(pack_weights_batch_kernel, dim3(16, (unsigned)n), dim3(256), 0, st, (const PackItem*)items);
 }
 

@@ -155,6 +155,34 @@ __global__ __launch_bounds__(256) void upsample_nearest_bwd_vec_kernel(const T* 
   }
 }
 
+// [rows][C] -> [rows][Cpad] with zero fill (3-channel images onto the 16-byte-vector convolution paths)
+template <typename T>
+__global__ __launch_bounds__(256) void pad_channels_kernel(const T* __restrict__ src, T* __restrict__ dst, int64_t rows, int C, int Cpad) {
+  const int64_t total = rows * Cpad;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % Cpad); const int64_t r = i / Cpad;
+    if (c < C) dst[i] = src[r * C + c]; else Elem<T>::st(dst + i, 0.f);
+  }
+}
+// dw[co][ci][tap] (+)= dwp[co][ci][tap] for ci < Cin (dwp has CinPad input channels)
+__global__ __launch_bounds__(256) void unpad_weight_grad_kernel(const float* __restrict__ dwp, float* __restrict__ dw, int Cout, int Cin,
+                                                                int CinPad, int taps, int accumulate) {
+  const int total = Cout * Cin * taps;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+    const int tp = i % taps, ci = (i / taps) % Cin, co = i / (taps * Cin);
+    const float v = dwp[((int64_t)co * CinPad + ci) * taps + tp];
+    dw[i] = accumulate ? dw[i] + v : v;
+  }
+}
+void launch_pad_channels(const void* src, void* dst, int64_t rows, int C, int Cpad, int dtype, hipStream_t st) {
+  unsigned g = ew_grid(rows * Cpad);
+  if (dtype == 0) hipLaunchKernelGGL((pad_channels_kernel<float>), dim3(g), dim3(256), 0, st, (const float*)src, (float*)dst, rows, C, Cpad);
+  else hipLaunchKernelGGL((pad_channels_kernel<bf16_t>), dim3(g), dim3(256), 0, st, (const bf16_t*)src, (bf16_t*)dst, rows, C, Cpad);
+}
+void launch_unpad_weight_grad(const float* dwp, float* dw, int Cout, int Cin, int CinPad, int taps, int accumulate, hipStream_t st) {
+  hipLaunchKernelGGL(unpad_weight_grad_kernel, dim3((unsigned)cdiv(Cout * Cin * taps, 256)), dim3(256), 0, st, dwp, dw, Cout, Cin, CinPad, taps, accumulate);
+}
+
 void launch_cast(const void* src, void* dst, int64_t n, int sd, int dd, float scale, hipStream_t st) {
   unsigned g = ew_grid(n);
   if (sd == 0 && dd == 0) hipLaunchKernelGGL((cast_kernel<float, float>), dim3(g), dim3(256), 0, st, (const float*)src, (float*)dst, n, scale);

@@ -37,7 +37,7 @@ bool conv3x3_small_ok(const ConvArgs& a, int dtype);
 void launch_conv3x3_small(const ConvArgs& a, int dtype, hipStream_t st);
 bool conv3x3_c1_ok(const ConvArgs& a);
 void launch_conv3x3_c1(const ConvArgs& a, int dtype, hipStream_t st);
-void launch_pack_weights(const float* w, void* out, int Cout, int Cin, int KH, int KW, int mode, int dtype, hipStream_t st);
+void launch_pack_weights(const float* w, void* out, int Cout, int Cin, int KH, int KW, int mode, int dtype, hipStream_t st, int CinSrc = 0);
 void launch_pack_weights_batch(const void* items, int n, hipStream_t st);
 void launch_wgrad(WgradArgs a, int dtype, float* dw, int accumulate, hipStream_t st);
 
@@ -99,6 +99,8 @@ void launch_roi_pool_bwd(const void* dout, const float* rois, const int* argmax,
                          int C, int PH, int PW, int dtype, hipStream_t st);
 
 // rd_elementwise.hip
+void launch_pad_channels(const void* src, void* dst, int64_t rows, int C, int Cpad, int dtype, hipStream_t st);
+void launch_unpad_weight_grad(const float* dwp, float* dw, int Cout, int Cin, int CinPad, int taps, int accumulate, hipStream_t st);
 void launch_cast(const void* src, void* dst, int64_t n, int src_dtype, int dst_dtype, float scale, hipStream_t st);
 void launch_add(const void* a, const void* b, void* out, int64_t n, int dtype, hipStream_t st);
 void launch_nchw_to_nhwc(const void* src, void* dst, int N, int C, int H, int W, int src_dtype, int dst_dtype, float scale, hipStream_t st);

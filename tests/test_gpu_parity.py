@@ -208,3 +208,11 @@ def test_bn_generic_channel_counts(gpu):
     P.conv_case(gpu, dict(cin=24, cout=40, k=1, s=1, H=13, W=11, N=2, bn=True))
     P.conv_case(gpu, dict(cin=16, cout=144, k=1, s=1, H=9, W=10, N=2, bn=True))
     P.conv_case(gpu, dict(cin=8, cout=232, k=3, s=1, H=6, W=7, N=1, bn=True))
+
+
+def test_stem_padded_channels(gpu):
+    """3-channel stems without an input gradient run zero-padded to one 16-byte vector (rd_pad_channels / rd_conv_pack_weights_padded /
+    rd_unpad_weight_grad): forward, BatchNorm and the weight gradient must match the oracle on the original 3-channel weights."""
+    P.conv_case(gpu, dict(cin=3, cout=32, k=7, s=2, H=20, W=18, N=2, bn=True, no_input_grad=True))
+    P.conv_case(gpu, dict(cin=3, cout=32, k=3, s=2, H=15, W=14, N=1, bn=True, no_input_grad=True))
+    P.conv_case(gpu, dict(cin=5, cout=16, k=3, s=1, H=9, W=11, N=2, bn=False, act=None, no_input_grad=True))
