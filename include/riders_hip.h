@@ -170,6 +170,11 @@ int rd_roi_pool_fwd(const void* x, const float* rois, void* out, int32_t* argmax
 int rd_roi_pool_bwd(const void* dout, const float* rois, const int32_t* argmax, float* dx_f32, int32_t R, int32_t N,
                     int32_t H, int32_t W, int32_t C, int32_t PH, int32_t PW, int32_t dtype, void* stream);
 
+/* gather form: dx [N][H][W][C] in the activation dtype, every element written once (no atomics, fixed summation order: ascending roi,
+   then bin); needs C % (16 / sizeof(element)) == 0 and the forward's spatial_scale */
+int rd_roi_pool_bwd_gather(const void* dout, const float* rois, const int32_t* argmax, void* dx, int32_t R, int32_t N, int32_t H,
+                           int32_t W, int32_t C, int32_t PH, int32_t PW, float spatial_scale, int32_t dtype, void* stream);
+
 /* ---- layout / resampling helpers ------------------------------------------------------------------------- */
 int rd_cast(const void* src, void* dst, int64_t n, int32_t src_dtype, int32_t dst_dtype, float scale, void* stream);
 int rd_add(const void* a, const void* b, void* out, int64_t n, int32_t dtype, void* stream);

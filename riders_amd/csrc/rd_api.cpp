@@ -283,6 +283,15 @@ int rd_roi_pool_bwd(const void* dout, const float* rois, const int32_t* argmax, 
   return done("rd_roi_pool_bwd");
 }
 
+int rd_roi_pool_bwd_gather(const void* dout, const float* rois, const int32_t* argmax, void* dx, int32_t R, int32_t N, int32_t H,
+                           int32_t W, int32_t C, int32_t PH, int32_t PW, float scale, int32_t dtype, void* stream) {
+  if (!dx || !dt_ok(dtype)) return fail("roi_pool_bwd_gather: bad args");
+  if (R > 0 && (!dout || !rois || !argmax)) return fail("roi_pool_bwd_gather: null pointer");
+  if (C % (dtype == RD_F32 ? 4 : 8)) return fail("roi_pool_bwd_gather: C must be a multiple of the 16-byte vector");
+  if (N <= 0 || H <= 0 || W <= 0 || PH <= 0 || PW <= 0) return fail("roi_pool_bwd_gather: bad sizes");
+  rd::launch_roi_pool_bwd_gather(dout, rois, argmax, dx, R, N, H, W, C, PH, PW, scale, dtype, S(stream));
+  return done("rd_roi_pool_bwd_gather");
+}
 int rd_cast(const void* src, void* dst, int64_t n, int32_t sd, int32_t dd, float scale, void* stream) {
   if (!src || !dst || !dt_ok(sd) || !dt_ok(dd)) return fail("cast: bad args");
   if (n == 0) return 0;

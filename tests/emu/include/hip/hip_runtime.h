@@ -38,6 +38,7 @@ struct alignas(8) uint2 { unsigned x, y; };
 struct alignas(16) int4 { int x, y, z, w; };
 static inline float4 make_float4(float a, float b, float c, float d) { return float4{a, b, c, d}; }
 static inline uint4 make_uint4(unsigned a, unsigned b, unsigned c, unsigned d) { return uint4{a, b, c, d}; }
+static inline int4 make_int4(int a, int b, int c, int d) { return int4{a, b, c, d}; }
 static inline uint2 make_uint2(unsigned a, unsigned b) { return uint2{a, b}; }
 static inline float2 make_float2(float a, float b) { return float2{a, b}; }
 
@@ -220,6 +221,19 @@ template <typename T> static inline T __shfl_up(T v, unsigned d, int width = 64)
   if (src < 0 || (src & ~(width - 1)) != (l & ~(width - 1))) src = l;
   return emu::shfl_generic(v, src);
 }
+
+// wave vote: bit l of the result = predicate of lane l (wave-collective)
+static inline unsigned long long __ballot(int pred) {
+  emu::Wave& w = emu::my_wave();
+  int l = emu::lane_id();
+  w.buf[0][l][0] = pred ? 1 : 0;
+  emu::wave_sync();
+  unsigned long long m = 0;
+  for (int i = 0; i < 64; i++) if (i < w.alive && w.buf[0][i][0]) m |= 1ull << i;
+  emu::wave_sync();
+  return m;
+}
+static inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
 
 static inline float atomicAdd(float* p, float v) { float o = *p; *p = o + v; return o; }
 static inline int atomicAdd(int* p, int v) { int o = *p; *p = o + v; return o; }

@@ -247,6 +247,41 @@ def roi_pool_case(dev):
         close(tape.grads[id(xd)].permute(0, 3, 1, 2), xr.grad, 1e-5, "roi_pool bwd")
 
 
+def roi_pool_stress_case(dev, R=300, C=64, H=20, W=24):
+    """gather backward with more RoIs than one listing pass (256), more than one LDS list chunk (64) meeting a tile, several item
+    passes per thread (C = 64 fp32 -> 16 channel groups), bins smaller and larger than a pixel, boxes leaving the map."""
+    from riders_amd import engine
+    engine.set_deterministic_roi_pool(True)
+    try:
+        _roi_pool_stress(dev, R, C, H, W)
+    finally:
+        engine.set_deterministic_roi_pool(False)
+
+
+def _roi_pool_stress(dev, R, C, H, W):
+    from riders_amd import engine
+    rs = np.random.RandomState(5)
+    N = 2
+    x = t(rs.randn(N, C, H, W).astype(np.float32))
+    b = rs.randint(0, N, R).astype(np.float32)
+    x1 = rs.uniform(-4, W * 2 - 6, R); y1 = rs.uniform(-4, H * 2 - 6, R)
+    ww = rs.uniform(1, 30, R); hh = rs.uniform(1, 26, R)
+    rois = np.stack([b, x1, y1, x1 + ww, y1 + hh], 1).astype(np.float32)
+    for scale, (PH, PW) in ((0.5, (6, 5)), (0.5, (3, 9))):
+        xr = x.clone().requires_grad_()
+        ref, arg = O.roi_pool(xr, t(rois), scale, (PH, PW), return_argmax=True)
+        w = t(rs.randn(*ref.shape).astype(np.float32))
+        (ref * w).sum().backward()
+        xd = x.to(dev).permute(0, 2, 3, 1).contiguous()
+        tape = engine.Tape(); tape.mark(xd)
+        with engine._active(tape):
+            out = engine.roi_pool(xd, t(rois, dev), (PH, PW), scale)
+            tape.grads[id(out)] = w.to(dev).permute(0, 2, 3, 1).contiguous()
+            tape.backward()
+        assert torch.equal(out._rd_argmax.permute(0, 3, 1, 2).cpu(), arg), "roi_pool argmax differs"
+        close(tape.grads[id(xd)].permute(0, 3, 1, 2), xr.grad, 1e-5, "roi_pool gather bwd (stress)")
+
+
 def maxpool_case(dev):
     from riders_amd import engine
     x = t(rand_array("mp.x", (2, 8, 13, 10), 1.0))

@@ -216,3 +216,7 @@ def test_stem_padded_channels(gpu):
     P.conv_case(gpu, dict(cin=3, cout=32, k=7, s=2, H=20, W=18, N=2, bn=True, no_input_grad=True))
     P.conv_case(gpu, dict(cin=3, cout=32, k=3, s=2, H=15, W=14, N=1, bn=True, no_input_grad=True))
     P.conv_case(gpu, dict(cin=5, cout=16, k=3, s=1, H=9, W=11, N=2, bn=False, act=None, no_input_grad=True))
+
+
+def test_roi_pool_gather_backward(gpu):
+    P.roi_pool_stress_case(gpu)
