@@ -175,6 +175,15 @@ def main():
                         share_of_step=(tms / timed_steps) / ms,
                         note="dominant timed launch shape; algorithmic bytes = each operand once; HIP events on the launch stream over "
                              "%d instrumented eager steps of the same workload" % timed_steps)
+            # HBM bytes of that launch from PMC counters, measured in a separate rocprofv3 pass of the same kernel / shape (PMC passes
+            # cannot run inside the timed region); absent for shapes that have not been profiled
+            try:
+                tr = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json"))).get(roof["kernel"])
+                if tr is not None:
+                    roof["traffic"] = tr["fetch_bytes"] + tr["write_bytes"]
+                    roof["traffic_source"] = tr["note"]
+            except (OSError, ValueError):
+                pass
             ks = timer.summary()
             roof["families"] = {kk: dict(ms_per_step=v["ms"] / timed_steps, tflops=v["flops"] / (v["ms"] * 1e-3) / 1e12,
                                          launches_per_step=v["launches"] / timed_steps) for kk, v in ks.items()}

@@ -20,7 +20,13 @@ ws = torch.empty(lib.rd_conv_wgrad_workspace_bytes(ctypes.byref(d)) // 4, dtype=
 dw = torch.empty_like(w)
 wp = engine.packed_weight(w, 0, dt)
 y = torch.empty((N, H, W, Cout), dtype=tdt, device=dev)
+if which == "dgrad":   # data gradient of a (Cin -> Cout) layer whose input is a 2-way concat: dy (Cout ch) -> dx1 | dx2 (Cin/2 each)
+    dd = _desc(dt, N, H, W, Cout, 0, False, H, W, Cin, 3, 3, 1, 1, 1, H, W, 0, 0.0, Cin // 2)
+    wpd = engine.packed_weight(w, 1, dt)
+    dx1 = torch.empty((N, H, W, Cin // 2), dtype=tdt, device=dev); dx2 = torch.empty_like(dx1)
 def run():
+    if which == "dgrad":
+        return lib.rd_conv_fwd(ctypes.byref(dd), _p(dy), None, _p(wpd), None, _p(dx1), _p(dx2), None, st)
     if which == "wgrad":
         return lib.rd_conv_wgrad(ctypes.byref(d), _p(x), None, _p(dy), _p(ws), _p(dw), 0, st)
     return lib.rd_conv_fwd(ctypes.byref(d), _p(x), None, _p(wp), None, _p(y), None, None, st)
