@@ -123,6 +123,11 @@ def load():
             raise RuntimeError(
                 "riders_amd: %s not found. Build it with `python -m riders_amd.build` (hipcc, gfx950). "
                 "There is no CPU fallback." % LIB_PATH)
+        # torch's HIP runtime must be the one that initialises the device: loading this library first (its code objects register with
+        # the runtime at dlopen) left the process with "no ROCm-capable device" once torch initialised afterwards
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.init()
         _lib = _bind(ctypes.CDLL(LIB_PATH))
     return _lib
 

@@ -432,7 +432,7 @@ def refresh_packed():
         w = ent["ref"]()
         if w is None:
             continue
-        for k, hit in ent.items():
+        for k, hit in list(ent.items()):
             if k == "ref":
                 continue
             mode, dt = k[0], k[1]
