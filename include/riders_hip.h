@@ -135,6 +135,12 @@ int rd_bn_act_bwd(const void* dz, const void* z, const void* y, const float* sav
                   const float* scale, float* partial /* [rows][C][2] */, float* coef /* [2][C] */, float* dgamma,
                   float* dbeta, int32_t accumulate, void* dy, void* dres, int64_t pixels, int32_t C, int32_t act,
                   float slope, int32_t dtype, void* stream);
+/* same, for z = act(scale*y + shift) WITHOUT a residual: the activation's argument is recomputed from y (bit-identical to the forward's
+   expression), so z is not read (one tensor less in both passes); z is only consulted when C is not a multiple of the 16-byte vector */
+int rd_bn_act_bwd_recompute(const void* dz, const void* z, const void* y, const float* save_mean, const float* save_rstd,
+                            const float* scale, const float* shift, float* partial, float* coef, float* dgamma, float* dbeta,
+                            int32_t accumulate, void* dy, void* dres, int64_t pixels, int32_t C, int32_t act, float slope,
+                            int32_t dtype, void* stream);
 int rd_act_bwd(const void* dz, const void* z, void* dx, int64_t n, int32_t act, float slope, int32_t dtype, void* stream);
 /* bias gradient: out[c] (+)= sum over rows of x[rows][C] */
 int32_t rd_colsum_rows(int64_t rows, int32_t C);

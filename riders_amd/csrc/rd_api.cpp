@@ -209,6 +209,17 @@ int rd_bn_act_bwd(const void* dz, const void* z, const void* y, const float* mea
   rd::launch_bn_bwd_apply(dz, z, y, mean, rstd, scale, coef, coef + C, dy, dres, pixels, C, act, slope, dtype, S(stream));
   return done("rd_bn_act_bwd");
 }
+int rd_bn_act_bwd_recompute(const void* dz, const void* z, const void* y, const float* mean, const float* rstd, const float* scale,
+                            const float* shift, float* partial, float* coef, float* dgamma, float* dbeta, int32_t accumulate, void* dy,
+                            void* dres, int64_t pixels, int32_t C, int32_t act, float slope, int32_t dtype, void* stream) {
+  if (!dz || !y || !mean || !rstd || !scale || !shift || !partial || !coef || !dy || !dt_ok(dtype)) return fail("bn_act_bwd_recompute: bad args");
+  if (act != RD_ACT_NONE && !z && (C % (dtype == RD_F32 ? 4 : 8))) return fail("bn_act_bwd_recompute: this channel count needs z");
+  int rows = rd::bn_bwd_rows(pixels, C);
+  rd::launch_bn_bwd_reduce(dz, z, y, mean, rstd, partial, pixels, C, act, slope, dtype, S(stream), scale, shift);
+  rd::launch_bn_bwd_finalize(partial, rows, C, (double)pixels, dgamma, dbeta, accumulate, coef, coef + C, S(stream));
+  rd::launch_bn_bwd_apply(dz, z, y, mean, rstd, scale, coef, coef + C, dy, dres, pixels, C, act, slope, dtype, S(stream), shift);
+  return done("rd_bn_act_bwd_recompute");
+}
 int rd_act_bwd(const void* dz, const void* z, void* dx, int64_t n, int32_t act, float slope, int32_t dtype, void* stream) {
   if (!dz || !z || !dx || !dt_ok(dtype)) return fail("act_bwd: bad args");
   if (n == 0) return 0;

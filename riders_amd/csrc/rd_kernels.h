@@ -72,12 +72,13 @@ void launch_affine_act(const void* y, const float* scale, const float* shift, co
                        int C, int act, float slope, int dtype, hipStream_t st);
 int bn_bwd_rows(int64_t pixels, int C);
 void launch_bn_bwd_reduce(const void* dz, const void* z, const void* y, const float* mean, const float* rstd,
-                          float* partial, int64_t pixels, int C, int act, float slope, int dtype, hipStream_t st);
+                          float* partial, int64_t pixels, int C, int act, float slope, int dtype, hipStream_t st,
+                          const float* scale = nullptr, const float* shift = nullptr);
 void launch_bn_bwd_finalize(const float* partial, int rows, int C, double count, float* dgamma, float* dbeta,
                             int accumulate, float* c1, float* c2, hipStream_t st);
 void launch_bn_bwd_apply(const void* dz, const void* z, const void* y, const float* mean, const float* rstd,
                          const float* scale, const float* c1, const float* c2, void* dy, void* dres, int64_t pixels,
-                         int C, int act, float slope, int dtype, hipStream_t st);
+                         int C, int act, float slope, int dtype, hipStream_t st, const float* shift = nullptr);
 void launch_act_bwd(const void* dz, const void* z, void* dx, int64_t n, int act, float slope, int dtype, hipStream_t st);
 void launch_colsum(const void* x, float* partial, float* out, int accumulate, int64_t rows, int C, int dtype, hipStream_t st);
 int colsum_rows(int64_t rows, int C);

@@ -10,6 +10,7 @@ A module's forward runs either inside an already-active tape (it is part of a la
 its own region, which appears to torch.autograd as ONE node (`_Region`).
 """
 import contextlib
+import os
 import ctypes
 import weakref
 
@@ -382,6 +383,7 @@ def as_nchw(x):
 
 # packed-weight cache: (id(param), version, mode, dtype) -> tensor
 _pack_cache = {}
+_BN_RECOMPUTE = os.environ.get("RIDERS_BN_RECOMPUTE", "1") != "0"   # A/B switch for the BatchNorm backward that does not read z
 
 
 def packed_weight(w, mode, dt, cin_pad=0):
@@ -566,8 +568,13 @@ def conv_block(x, weight, *, x2=None, bias=None, stride=1, pad=None, up=None, bn
             assert acc == acc2
             dy = torch.empty_like(y)
             dres = torch.empty_like(y) if need_res else None
-            _chk(lib.rd_bn_act_bwd(_p(dz), _p(z), _p(y), _p(mean), _p(rstd), _p(scale), _p(partial), _p(coef2), _p(dgam),
-                                   _p(dbet), acc, _p(dy), _p(dres), pixels, Cout, act, slope, dt, st), "rd_bn_act_bwd")
+            if residual is None and _BN_RECOMPUTE:   # z = act(scale*y + shift): the backward recomputes the activation argument from y, z is not read
+                _chk(lib.rd_bn_act_bwd_recompute(_p(dz), _p(z), _p(y), _p(mean), _p(rstd), _p(scale), _p(shift), _p(partial), _p(coef2),
+                                                 _p(dgam), _p(dbet), acc, _p(dy), _p(dres), pixels, Cout, act, slope, dt, st),
+                     "rd_bn_act_bwd_recompute")
+            else:
+                _chk(lib.rd_bn_act_bwd(_p(dz), _p(z), _p(y), _p(mean), _p(rstd), _p(scale), _p(partial), _p(coef2), _p(dgam),
+                                       _p(dbet), acc, _p(dy), _p(dres), pixels, Cout, act, slope, dt, st), "rd_bn_act_bwd")
         else:
             eff_act = act
             if eff_act != ACT_NONE:
@@ -1060,8 +1067,13 @@ def _bn_backward(t, dz, z, y, coef, bn, act, slope, want_res):
     dbet, _ = t.param_grad(bn.bias)
     dy = torch.empty_like(y)
     dres = torch.empty_like(y) if want_res else None
-    _chk(lib.rd_bn_act_bwd(_p(dz), _p(z), _p(y), _p(coef[2]), _p(coef[3]), _p(coef[0]), _p(partial), _p(coef2), _p(dgam), _p(dbet), acc,
-                           _p(dy), _p(dres), pixels, C, act, slope, dt, st), "rd_bn_act_bwd")
+    if not _BN_RECOMPUTE:
+        _chk(lib.rd_bn_act_bwd(_p(dz), _p(z), _p(y), _p(coef[2]), _p(coef[3]), _p(coef[0]), _p(partial), _p(coef2), _p(dgam), _p(dbet), acc,
+                               _p(dy), _p(dres), pixels, C, act, slope, dt, st), "rd_bn_act_bwd")
+        return dy, dres
+    # no residual on this path: the activation argument is recomputed from y (coef[0] = scale, coef[1] = shift), z is not read
+    _chk(lib.rd_bn_act_bwd_recompute(_p(dz), _p(z), _p(y), _p(coef[2]), _p(coef[3]), _p(coef[0]), _p(coef[1]), _p(partial), _p(coef2), _p(dgam),
+                                     _p(dbet), acc, _p(dy), _p(dres), pixels, C, act, slope, dt, st), "rd_bn_act_bwd_recompute")
     return dy, dres
 
 
