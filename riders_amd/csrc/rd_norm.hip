@@ -231,7 +231,7 @@ __global__ __launch_bounds__(256) void affine_act_vec_kernel(const T* __restrict
   }
 }
 
-template <typename T>
+template <typename T, bool RC>
 __global__ __launch_bounds__(256) void bn_bwd_apply_vec_kernel(const T* __restrict__ dz, const T* __restrict__ z,
                                                                const T* __restrict__ y, const float* __restrict__ mean,
                                                                const float* __restrict__ rstd, const float* __restrict__ scale,
@@ -246,17 +246,17 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_vec_kernel(const T* __restri
 #pragma unroll
   for (int e = 0; e < VE; e++) {
     mu[e] = mean[c0 + e]; rs[e] = rstd[c0 + e]; sc[e] = scale[c0 + e]; k1[e] = c1[c0 + e]; k2[e] = c2[c0 + e];
-    sh[e] = shift ? shift[c0 + e] : 0.f;
+    sh[e] = RC ? shift[c0 + e] : 0.f;
   }
   for (; i < nvec; i += stride) {
     float g[VE], zz[VE], yy[VE], o[VE];
     ldv(dz + i * VE, g);
-    if (act && !shift) ldv(z + i * VE, zz);
+    if (act && !RC) ldv(z + i * VE, zz);
     ldv(y + i * VE, yy);
 #pragma unroll
     for (int e = 0; e < VE; e++) {
       // shift given: the activation's argument is recomputed from y exactly as the forward computed it (no read of z)
-      if (act) g[e] *= act_grad_from_out(shift ? yy[e] * sc[e] + sh[e] : zz[e], act, slope);
+      if (act) g[e] *= act_grad_from_out(RC ? yy[e] * sc[e] + sh[e] : zz[e], act, slope);
       float xh = (yy[e] - mu[e]) * rs[e];
       o[e] = sc[e] * (g[e] - k1[e] - xh * k2[e]);
     }
@@ -266,7 +266,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_vec_kernel(const T* __restri
 }
 
 // MODE 0: (sum dpre, sum dpre*xhat); MODE 1: column sum.  Block b reduces pixels [b*per, (b+1)*per); thread t owns channel group t % VP.
-template <typename T, int MODE>
+template <typename T, int MODE, bool RC>
 __global__ __launch_bounds__(256) void col_reduce_vec_kernel(const T* __restrict__ dz, const T* __restrict__ z,
                                                              const T* __restrict__ y, const float* __restrict__ mean,
                                                              const float* __restrict__ rstd, float* __restrict__ partial,
@@ -284,7 +284,7 @@ __global__ __launch_bounds__(256) void col_reduce_vec_kernel(const T* __restrict
   for (int e = 0; e < VE; e++) {
     a[e] = 0.f; b[e] = 0.f;
     mu[e] = MODE == 0 ? mean[c0 + e] : 0.f; rs[e] = MODE == 0 ? rstd[c0 + e] : 1.f;
-    sq[e] = shift ? scale[c0 + e] : 0.f; hq[e] = shift ? shift[c0 + e] : 0.f;
+    sq[e] = RC ? scale[c0 + e] : 0.f; hq[e] = RC ? shift[c0 + e] : 0.f;
   }
   const int64_t vend = pend * VP;
   auto accum = [&](const float (&g0)[VE], const float (&zz)[VE], const float (&yy)[VE]) RD_INLINE_LAMBDA {
@@ -292,7 +292,7 @@ __global__ __launch_bounds__(256) void col_reduce_vec_kernel(const T* __restrict
     for (int e = 0; e < VE; e++) {
       float gg = g0[e];
       if (MODE == 0) {
-        if (act) gg *= act_grad_from_out(shift ? yy[e] * sq[e] + hq[e] : zz[e], act, slope);
+        if (act) gg *= act_grad_from_out(RC ? yy[e] * sq[e] + hq[e] : zz[e], act, slope);
         a[e] += gg; b[e] += gg * ((yy[e] - mu[e]) * rs[e]);
       } else a[e] += gg;
     }
@@ -302,7 +302,7 @@ __global__ __launch_bounds__(256) void col_reduce_vec_kernel(const T* __restrict
     float g0[VE], z0[VE], y0[VE], g1[VE], z1[VE], y1[VE];
     ldv(dz + i * VE, g0); ldv(dz + (i + 256) * VE, g1);
     if (MODE == 0) {
-      if (act && !shift) { ldv(z + i * VE, z0); ldv(z + (i + 256) * VE, z1); }
+      if (act && !RC) { ldv(z + i * VE, z0); ldv(z + (i + 256) * VE, z1); }
       ldv(y + i * VE, y0); ldv(y + (i + 256) * VE, y1);
     }
     accum(g0, z0, y0); accum(g1, z1, y1);
@@ -310,7 +310,7 @@ __global__ __launch_bounds__(256) void col_reduce_vec_kernel(const T* __restrict
   for (; i < vend; i += 256) {
     float g0[VE], z0[VE], y0[VE];
     ldv(dz + i * VE, g0);
-    if (MODE == 0) { if (act && !shift) ldv(z + i * VE, z0); ldv(y + i * VE, y0); }
+    if (MODE == 0) { if (act && !RC) ldv(z + i * VE, z0); ldv(y + i * VE, y0); }
     accum(g0, z0, y0);
   }
   // lanes of a wave that share a channel group (lane % VP), fixed xor tree
@@ -356,7 +356,7 @@ __global__ __launch_bounds__(256) void affine_act_gen_kernel(const T* __restrict
   }
 }
 
-template <typename T>
+template <typename T, bool RC>
 __global__ __launch_bounds__(256) void bn_bwd_apply_gen_kernel(const T* __restrict__ dz, const T* __restrict__ z,
                                                                const T* __restrict__ y, const float* __restrict__ mean,
                                                                const float* __restrict__ rstd, const float* __restrict__ scale,
@@ -371,17 +371,17 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_gen_kernel(const T* __restri
 #pragma unroll
   for (int e = 0; e < VE; e++) {
     const int c = g * VE + e;
-    mu[e] = mean[c]; rs[e] = rstd[c]; sc[e] = scale[c]; k1[e] = c1[c]; k2[e] = c2[c]; sh[e] = shift ? shift[c] : 0.f;
+    mu[e] = mean[c]; rs[e] = rstd[c]; sc[e] = scale[c]; k1[e] = c1[c]; k2[e] = c2[c]; sh[e] = RC ? shift[c] : 0.f;
   }
   for (int64_t p = (int64_t)blockIdx.x * PPB + pl; p < pixels; p += (int64_t)gridDim.x * PPB) {
     const int64_t o = p * C + g * VE;
     float gg[VE], zz[VE], yy[VE], ov[VE];
     ldv(dz + o, gg);
-    if (act && !shift) ldv(z + o, zz);
+    if (act && !RC) ldv(z + o, zz);
     ldv(y + o, yy);
 #pragma unroll
     for (int e = 0; e < VE; e++) {
-      if (act) gg[e] *= act_grad_from_out(shift ? yy[e] * sc[e] + sh[e] : zz[e], act, slope);
+      if (act) gg[e] *= act_grad_from_out(RC ? yy[e] * sc[e] + sh[e] : zz[e], act, slope);
       const float xh = (yy[e] - mu[e]) * rs[e];
       ov[e] = sc[e] * (gg[e] - k1[e] - xh * k2[e]);
     }
@@ -390,7 +390,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_gen_kernel(const T* __restri
   }
 }
 
-template <typename T, int MODE>
+template <typename T, int MODE, bool RC>
 __global__ __launch_bounds__(256) void col_reduce_gen_kernel(const T* __restrict__ dz, const T* __restrict__ z,
                                                              const T* __restrict__ y, const float* __restrict__ mean,
                                                              const float* __restrict__ rstd, float* __restrict__ partial,
@@ -408,14 +408,14 @@ __global__ __launch_bounds__(256) void col_reduce_gen_kernel(const T* __restrict
   for (int e = 0; e < VE; e++) {
     a[e] = 0.f; b[e] = 0.f;
     mu[e] = MODE == 0 ? mean[g * VE + e] : 0.f; rs[e] = MODE == 0 ? rstd[g * VE + e] : 1.f;
-    sq[e] = shift ? scale[g * VE + e] : 0.f; hq[e] = shift ? shift[g * VE + e] : 0.f;
+    sq[e] = RC ? scale[g * VE + e] : 0.f; hq[e] = RC ? shift[g * VE + e] : 0.f;
   }
   auto accum = [&](const float (&g0)[VE], const float (&zz)[VE], const float (&yy)[VE]) RD_INLINE_LAMBDA {
 #pragma unroll
     for (int e = 0; e < VE; e++) {
       float gv = g0[e];
       if (MODE == 0) {
-        if (act) gv *= act_grad_from_out(shift ? yy[e] * sq[e] + hq[e] : zz[e], act, slope);
+        if (act) gv *= act_grad_from_out(RC ? yy[e] * sq[e] + hq[e] : zz[e], act, slope);
         a[e] += gv; b[e] += gv * ((yy[e] - mu[e]) * rs[e]);
       } else a[e] += gv;
     }
@@ -427,7 +427,7 @@ __global__ __launch_bounds__(256) void col_reduce_gen_kernel(const T* __restrict
       float g0[VE], z0[VE], y0[VE], g1[VE], z1[VE], y1[VE];
       ldv(dz + o0, g0); ldv(dz + o1, g1);
       if (MODE == 0) {
-        if (act && !shift) { ldv(z + o0, z0); ldv(z + o1, z1); }
+        if (act && !RC) { ldv(z + o0, z0); ldv(z + o1, z1); }
         ldv(y + o0, y0); ldv(y + o1, y1);
       }
       accum(g0, z0, y0); accum(g1, z1, y1);
@@ -436,7 +436,7 @@ __global__ __launch_bounds__(256) void col_reduce_gen_kernel(const T* __restrict
       const int64_t o0 = p * C + g * VE;
       float g0[VE], z0[VE], y0[VE];
       ldv(dz + o0, g0);
-      if (MODE == 0) { if (act && !shift) ldv(z + o0, z0); ldv(y + o0, y0); }
+      if (MODE == 0) { if (act && !RC) ldv(z + o0, z0); ldv(y + o0, y0); }
       accum(g0, z0, y0);
     }
   }
@@ -579,13 +579,13 @@ void launch_bn_bwd_reduce(const void* dz, const void* z, const void* y, const fl
   RedGeom g = red_geom(C);
   dim3 grid(red_rows(pixels, C), g.nchunk);
   if (vec_ok(C, dtype)) {
-    if (dtype == 0) hipLaunchKernelGGL((col_reduce_vec_kernel<float, 0>), dim3(grid.x), dim3(256), 0, st, (const float*)dz, (const float*)z, (const float*)y, mean, rstd, partial, pixels, C, act, slope, scale, shift);
-    else hipLaunchKernelGGL((col_reduce_vec_kernel<bf16_t, 0>), dim3(grid.x), dim3(256), 0, st, (const bf16_t*)dz, (const bf16_t*)z, (const bf16_t*)y, mean, rstd, partial, pixels, C, act, slope, scale, shift);
+    if (dtype == 0) { if (shift) hipLaunchKernelGGL((col_reduce_vec_kernel<float, 0, true>), dim3(grid.x), dim3(256), 0, st, (const float*)dz, (const float*)z, (const float*)y, mean, rstd, partial, pixels, C, act, slope, scale, shift); else hipLaunchKernelGGL((col_reduce_vec_kernel<float, 0, false>), dim3(grid.x), dim3(256), 0, st, (const float*)dz, (const float*)z, (const float*)y, mean, rstd, partial, pixels, C, act, slope, scale, shift); }
+    else { if (shift) hipLaunchKernelGGL((col_reduce_vec_kernel<bf16_t, 0, true>), dim3(grid.x), dim3(256), 0, st, (const bf16_t*)dz, (const bf16_t*)z, (const bf16_t*)y, mean, rstd, partial, pixels, C, act, slope, scale, shift); else hipLaunchKernelGGL((col_reduce_vec_kernel<bf16_t, 0, false>), dim3(grid.x), dim3(256), 0, st, (const bf16_t*)dz, (const bf16_t*)z, (const bf16_t*)y, mean, rstd, partial, pixels, C, act, slope, scale, shift); }
     return;
   }
   if (gen_ok(C, dtype)) {
-    if (dtype == 0) hipLaunchKernelGGL((col_reduce_gen_kernel<float, 0>), dim3(grid.x), dim3(256), 0, st, (const float*)dz, (const float*)z, (const float*)y, mean, rstd, partial, pixels, C, act, slope, scale, shift);
-    else hipLaunchKernelGGL((col_reduce_gen_kernel<bf16_t, 0>), dim3(grid.x), dim3(256), 0, st, (const bf16_t*)dz, (const bf16_t*)z, (const bf16_t*)y, mean, rstd, partial, pixels, C, act, slope, scale, shift);
+    if (dtype == 0) { if (shift) hipLaunchKernelGGL((col_reduce_gen_kernel<float, 0, true>), dim3(grid.x), dim3(256), 0, st, (const float*)dz, (const float*)z, (const float*)y, mean, rstd, partial, pixels, C, act, slope, scale, shift); else hipLaunchKernelGGL((col_reduce_gen_kernel<float, 0, false>), dim3(grid.x), dim3(256), 0, st, (const float*)dz, (const float*)z, (const float*)y, mean, rstd, partial, pixels, C, act, slope, scale, shift); }
+    else { if (shift) hipLaunchKernelGGL((col_reduce_gen_kernel<bf16_t, 0, true>), dim3(grid.x), dim3(256), 0, st, (const bf16_t*)dz, (const bf16_t*)z, (const bf16_t*)y, mean, rstd, partial, pixels, C, act, slope, scale, shift); else hipLaunchKernelGGL((col_reduce_gen_kernel<bf16_t, 0, false>), dim3(grid.x), dim3(256), 0, st, (const bf16_t*)dz, (const bf16_t*)z, (const bf16_t*)y, mean, rstd, partial, pixels, C, act, slope, scale, shift); }
     return;
   }
   if (dtype == 0)
@@ -607,15 +607,15 @@ void launch_bn_bwd_apply(const void* dz, const void* z, const void* y, const flo
   if (vec_ok(C, dtype)) {
     const int64_t nvec = total / (dtype == 0 ? 4 : 8);
     unsigned gv = ew_grid(nvec);
-    if (dtype == 0) hipLaunchKernelGGL((bn_bwd_apply_vec_kernel<float>), dim3(gv), dim3(256), 0, st, (const float*)dz, (const float*)z, (const float*)y, mean, rstd, scale, c1, c2, shift, (float*)dy, (float*)dres, nvec, C, act, slope);
-    else hipLaunchKernelGGL((bn_bwd_apply_vec_kernel<bf16_t>), dim3(gv), dim3(256), 0, st, (const bf16_t*)dz, (const bf16_t*)z, (const bf16_t*)y, mean, rstd, scale, c1, c2, shift, (bf16_t*)dy, (bf16_t*)dres, nvec, C, act, slope);
+    if (dtype == 0) { if (shift) hipLaunchKernelGGL((bn_bwd_apply_vec_kernel<float, true>), dim3(gv), dim3(256), 0, st, (const float*)dz, (const float*)z, (const float*)y, mean, rstd, scale, c1, c2, shift, (float*)dy, (float*)dres, nvec, C, act, slope); else hipLaunchKernelGGL((bn_bwd_apply_vec_kernel<float, false>), dim3(gv), dim3(256), 0, st, (const float*)dz, (const float*)z, (const float*)y, mean, rstd, scale, c1, c2, shift, (float*)dy, (float*)dres, nvec, C, act, slope); }
+    else { if (shift) hipLaunchKernelGGL((bn_bwd_apply_vec_kernel<bf16_t, true>), dim3(gv), dim3(256), 0, st, (const bf16_t*)dz, (const bf16_t*)z, (const bf16_t*)y, mean, rstd, scale, c1, c2, shift, (bf16_t*)dy, (bf16_t*)dres, nvec, C, act, slope); else hipLaunchKernelGGL((bn_bwd_apply_vec_kernel<bf16_t, false>), dim3(gv), dim3(256), 0, st, (const bf16_t*)dz, (const bf16_t*)z, (const bf16_t*)y, mean, rstd, scale, c1, c2, shift, (bf16_t*)dy, (bf16_t*)dres, nvec, C, act, slope); }
     return;
   }
   if (gen_ok(C, dtype)) {
     const int ppb = 256 / (C / (dtype == 0 ? 4 : 8));
     unsigned gg = (unsigned)std::max<int64_t>(1, std::min<int64_t>(cdiv(pixels, ppb), 2048));
-    if (dtype == 0) hipLaunchKernelGGL((bn_bwd_apply_gen_kernel<float>), dim3(gg), dim3(256), 0, st, (const float*)dz, (const float*)z, (const float*)y, mean, rstd, scale, c1, c2, shift, (float*)dy, (float*)dres, pixels, C, act, slope);
-    else hipLaunchKernelGGL((bn_bwd_apply_gen_kernel<bf16_t>), dim3(gg), dim3(256), 0, st, (const bf16_t*)dz, (const bf16_t*)z, (const bf16_t*)y, mean, rstd, scale, c1, c2, shift, (bf16_t*)dy, (bf16_t*)dres, pixels, C, act, slope);
+    if (dtype == 0) { if (shift) hipLaunchKernelGGL((bn_bwd_apply_gen_kernel<float, true>), dim3(gg), dim3(256), 0, st, (const float*)dz, (const float*)z, (const float*)y, mean, rstd, scale, c1, c2, shift, (float*)dy, (float*)dres, pixels, C, act, slope); else hipLaunchKernelGGL((bn_bwd_apply_gen_kernel<float, false>), dim3(gg), dim3(256), 0, st, (const float*)dz, (const float*)z, (const float*)y, mean, rstd, scale, c1, c2, shift, (float*)dy, (float*)dres, pixels, C, act, slope); }
+    else { if (shift) hipLaunchKernelGGL((bn_bwd_apply_gen_kernel<bf16_t, true>), dim3(gg), dim3(256), 0, st, (const bf16_t*)dz, (const bf16_t*)z, (const bf16_t*)y, mean, rstd, scale, c1, c2, shift, (bf16_t*)dy, (bf16_t*)dres, pixels, C, act, slope); else hipLaunchKernelGGL((bn_bwd_apply_gen_kernel<bf16_t, false>), dim3(gg), dim3(256), 0, st, (const bf16_t*)dz, (const bf16_t*)z, (const bf16_t*)y, mean, rstd, scale, c1, c2, shift, (bf16_t*)dy, (bf16_t*)dres, pixels, C, act, slope); }
     return;
   }
   bool v4 = (C % 4 == 0);
@@ -636,11 +636,11 @@ void launch_colsum(const void* x, float* partial, float* out, int accumulate, in
   int nr = red_rows(rows, C);
   dim3 grid(nr, g.nchunk);
   if (vec_ok(C, dtype)) {
-    if (dtype == 0) hipLaunchKernelGGL((col_reduce_vec_kernel<float, 1>), dim3(nr), dim3(256), 0, st, (const float*)x, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, partial, rows, C, 0, 0.f, (const float*)nullptr, (const float*)nullptr);
-    else hipLaunchKernelGGL((col_reduce_vec_kernel<bf16_t, 1>), dim3(nr), dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)nullptr, (const bf16_t*)nullptr, (const float*)nullptr, (const float*)nullptr, partial, rows, C, 0, 0.f, (const float*)nullptr, (const float*)nullptr);
+    if (dtype == 0) hipLaunchKernelGGL((col_reduce_vec_kernel<float, 1, false>), dim3(nr), dim3(256), 0, st, (const float*)x, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, partial, rows, C, 0, 0.f, (const float*)nullptr, (const float*)nullptr);
+    else hipLaunchKernelGGL((col_reduce_vec_kernel<bf16_t, 1, false>), dim3(nr), dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)nullptr, (const bf16_t*)nullptr, (const float*)nullptr, (const float*)nullptr, partial, rows, C, 0, 0.f, (const float*)nullptr, (const float*)nullptr);
   } else if (gen_ok(C, dtype)) {
-    if (dtype == 0) hipLaunchKernelGGL((col_reduce_gen_kernel<float, 1>), dim3(nr), dim3(256), 0, st, (const float*)x, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, partial, rows, C, 0, 0.f, (const float*)nullptr, (const float*)nullptr);
-    else hipLaunchKernelGGL((col_reduce_gen_kernel<bf16_t, 1>), dim3(nr), dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)nullptr, (const bf16_t*)nullptr, (const float*)nullptr, (const float*)nullptr, partial, rows, C, 0, 0.f, (const float*)nullptr, (const float*)nullptr);
+    if (dtype == 0) hipLaunchKernelGGL((col_reduce_gen_kernel<float, 1, false>), dim3(nr), dim3(256), 0, st, (const float*)x, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, partial, rows, C, 0, 0.f, (const float*)nullptr, (const float*)nullptr);
+    else hipLaunchKernelGGL((col_reduce_gen_kernel<bf16_t, 1, false>), dim3(nr), dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)nullptr, (const bf16_t*)nullptr, (const float*)nullptr, (const float*)nullptr, partial, rows, C, 0, 0.f, (const float*)nullptr, (const float*)nullptr);
   } else if (dtype == 0)
     hipLaunchKernelGGL((col_reduce_kernel<float, 1>), grid, dim3(256), 0, st, (const float*)x, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, partial, rows, C, g.CB, g.PL, 0, 0.f);
   else
