@@ -11,6 +11,7 @@
 // combined here in a fixed order in double precision (deterministic).
 #include "rd_common.h"
 #include "rd_kernels.h"
+#include <type_traits>
 
 namespace rd {
 
@@ -210,11 +211,12 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* __restrict__
 // ---- 16-byte-vector forms (C % VE == 0 and C/VE divides 256): a thread keeps the same VE channels for the whole grid-stride loop, so
 // the per-channel parameters live in registers and every memory instruction moves 16 bytes per lane.  The scalar forms above issued
 // 2-byte loads plus five parameter loads per element and ran 5-17x off the HBM roofline (rocprofv3: col_reduce 116 us/launch). ------------
-template <typename T>
+template <typename T, int ACT, bool HAS_RES>
 __global__ __launch_bounds__(256) void affine_act_vec_kernel(const T* __restrict__ y, const float* __restrict__ scale,
                                                              const float* __restrict__ shift, const T* __restrict__ res,
                                                              T* __restrict__ out, int64_t nvec, int C, int act, float slope) {
   constexpr int VE = Elem<T>::VE;
+  const int actv = ACT >= 0 ? ACT : act;   // compile-time activation where the launcher knows it
   const int64_t stride = (int64_t)gridDim.x * 256;
   int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int c0 = (int)((i * VE) % C);
@@ -224,14 +226,14 @@ __global__ __launch_bounds__(256) void affine_act_vec_kernel(const T* __restrict
   for (; i < nvec; i += stride) {
     float v[VE], r[VE];
     ldv(y + i * VE, v);
-    if (res) ldv(res + i * VE, r);
+    if (HAS_RES) ldv(res + i * VE, r);
 #pragma unroll
-    for (int e = 0; e < VE; e++) v[e] = act_fwd(v[e] * sc[e] + sh[e] + (res ? r[e] : 0.f), act, slope);
+    for (int e = 0; e < VE; e++) v[e] = act_fwd(v[e] * sc[e] + sh[e] + (HAS_RES ? r[e] : 0.f), actv, slope);
     stv(out + i * VE, v);
   }
 }
 
-template <typename T, bool RC>
+template <typename T, bool RC, int ACT>
 __global__ __launch_bounds__(256) void bn_bwd_apply_vec_kernel(const T* __restrict__ dz, const T* __restrict__ z,
                                                                const T* __restrict__ y, const float* __restrict__ mean,
                                                                const float* __restrict__ rstd, const float* __restrict__ scale,
@@ -239,6 +241,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_vec_kernel(const T* __restri
                                                                T* __restrict__ dy, T* __restrict__ dres, int64_t nvec, int C,
                                                                int act, float slope) {
   constexpr int VE = Elem<T>::VE;
+  const int actv = ACT >= 0 ? ACT : act;   // compile-time activation where the launcher knows it
   const int64_t stride = (int64_t)gridDim.x * 256;
   int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int c0 = (int)((i * VE) % C);
@@ -251,12 +254,12 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_vec_kernel(const T* __restri
   for (; i < nvec; i += stride) {
     float g[VE], zz[VE], yy[VE], o[VE];
     ldv(dz + i * VE, g);
-    if (act && !RC) ldv(z + i * VE, zz);
+    if (actv && !RC) ldv(z + i * VE, zz);
     ldv(y + i * VE, yy);
 #pragma unroll
     for (int e = 0; e < VE; e++) {
       // shift given: the activation's argument is recomputed from y exactly as the forward computed it (no read of z)
-      if (act) g[e] *= act_grad_from_out(RC ? yy[e] * sc[e] + sh[e] : zz[e], act, slope);
+      if (actv) g[e] *= act_grad_from_out(RC ? yy[e] * sc[e] + sh[e] : zz[e], actv, slope);
       float xh = (yy[e] - mu[e]) * rs[e];
       o[e] = sc[e] * (g[e] - k1[e] - xh * k2[e]);
     }
@@ -266,13 +269,14 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_vec_kernel(const T* __restri
 }
 
 // MODE 0: (sum dpre, sum dpre*xhat); MODE 1: column sum.  Block b reduces pixels [b*per, (b+1)*per); thread t owns channel group t % VP.
-template <typename T, int MODE, bool RC>
+template <typename T, int MODE, bool RC, int ACT>
 __global__ __launch_bounds__(256) void col_reduce_vec_kernel(const T* __restrict__ dz, const T* __restrict__ z,
                                                              const T* __restrict__ y, const float* __restrict__ mean,
                                                              const float* __restrict__ rstd, float* __restrict__ partial,
                                                              int64_t pixels, int C, int act, float slope, const float* __restrict__ scale,
                                                              const float* __restrict__ shift) {
   constexpr int VE = Elem<T>::VE;
+  const int actv = ACT >= 0 ? ACT : act;   // compile-time activation where the launcher knows it
   __shared__ float red[256 * VE * 2];
   const int t = threadIdx.x, lane = t & 63;
   const int VP = C / VE;
@@ -292,7 +296,7 @@ __global__ __launch_bounds__(256) void col_reduce_vec_kernel(const T* __restrict
     for (int e = 0; e < VE; e++) {
       float gg = g0[e];
       if (MODE == 0) {
-        if (act) gg *= act_grad_from_out(RC ? yy[e] * sq[e] + hq[e] : zz[e], act, slope);
+        if (actv) gg *= act_grad_from_out(RC ? yy[e] * sq[e] + hq[e] : zz[e], actv, slope);
         a[e] += gg; b[e] += gg * ((yy[e] - mu[e]) * rs[e]);
       } else a[e] += gg;
     }
@@ -302,7 +306,7 @@ __global__ __launch_bounds__(256) void col_reduce_vec_kernel(const T* __restrict
     float g0[VE], z0[VE], y0[VE], g1[VE], z1[VE], y1[VE];
     ldv(dz + i * VE, g0); ldv(dz + (i + 256) * VE, g1);
     if (MODE == 0) {
-      if (act && !RC) { ldv(z + i * VE, z0); ldv(z + (i + 256) * VE, z1); }
+      if (actv && !RC) { ldv(z + i * VE, z0); ldv(z + (i + 256) * VE, z1); }
       ldv(y + i * VE, y0); ldv(y + (i + 256) * VE, y1);
     }
     accum(g0, z0, y0); accum(g1, z1, y1);
@@ -310,7 +314,7 @@ __global__ __launch_bounds__(256) void col_reduce_vec_kernel(const T* __restrict
   for (; i < vend; i += 256) {
     float g0[VE], z0[VE], y0[VE];
     ldv(dz + i * VE, g0);
-    if (MODE == 0) { if (act && !RC) ldv(z + i * VE, z0); ldv(y + i * VE, y0); }
+    if (MODE == 0) { if (actv && !RC) ldv(z + i * VE, z0); ldv(y + i * VE, y0); }
     accum(g0, z0, y0);
   }
   // lanes of a wave that share a channel group (lane % VP), fixed xor tree
@@ -334,11 +338,12 @@ __global__ __launch_bounds__(256) void col_reduce_vec_kernel(const T* __restrict
 // ---- 16-byte-vector forms for ANY channel count with C % VE == 0 and C/VE <= 256 (EfficientNet-Lite3's 24..1392-channel maps):
 // thread t owns channel group t % VP of pixel slot t / VP; a block covers PPB = 256 / VP consecutive pixels per iteration, so the
 // accesses of a block stay one contiguous span and the per-channel parameters still live in registers. ------------------------------
-template <typename T>
+template <typename T, int ACT, bool HAS_RES>
 __global__ __launch_bounds__(256) void affine_act_gen_kernel(const T* __restrict__ y, const float* __restrict__ scale,
                                                              const float* __restrict__ shift, const T* __restrict__ res,
                                                              T* __restrict__ out, int64_t pixels, int C, int act, float slope) {
   constexpr int VE = Elem<T>::VE;
+  const int actv = ACT >= 0 ? ACT : act;   // compile-time activation where the launcher knows it
   const int VP = C / VE, PPB = 256 / VP;
   const int g = threadIdx.x % VP, pl = threadIdx.x / VP;
   if (pl >= PPB) return;
@@ -349,14 +354,14 @@ __global__ __launch_bounds__(256) void affine_act_gen_kernel(const T* __restrict
     const int64_t o = p * C + g * VE;
     float v[VE], r[VE];
     ldv(y + o, v);
-    if (res) ldv(res + o, r);
+    if (HAS_RES) ldv(res + o, r);
 #pragma unroll
-    for (int e = 0; e < VE; e++) v[e] = act_fwd(v[e] * sc[e] + sh[e] + (res ? r[e] : 0.f), act, slope);
+    for (int e = 0; e < VE; e++) v[e] = act_fwd(v[e] * sc[e] + sh[e] + (HAS_RES ? r[e] : 0.f), actv, slope);
     stv(out + o, v);
   }
 }
 
-template <typename T, bool RC>
+template <typename T, bool RC, int ACT>
 __global__ __launch_bounds__(256) void bn_bwd_apply_gen_kernel(const T* __restrict__ dz, const T* __restrict__ z,
                                                                const T* __restrict__ y, const float* __restrict__ mean,
                                                                const float* __restrict__ rstd, const float* __restrict__ scale,
@@ -364,6 +369,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_gen_kernel(const T* __restri
                                                                T* __restrict__ dy, T* __restrict__ dres, int64_t pixels, int C,
                                                                int act, float slope) {
   constexpr int VE = Elem<T>::VE;
+  const int actv = ACT >= 0 ? ACT : act;   // compile-time activation where the launcher knows it
   const int VP = C / VE, PPB = 256 / VP;
   const int g = threadIdx.x % VP, pl = threadIdx.x / VP;
   if (pl >= PPB) return;
@@ -377,11 +383,11 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_gen_kernel(const T* __restri
     const int64_t o = p * C + g * VE;
     float gg[VE], zz[VE], yy[VE], ov[VE];
     ldv(dz + o, gg);
-    if (act && !RC) ldv(z + o, zz);
+    if (actv && !RC) ldv(z + o, zz);
     ldv(y + o, yy);
 #pragma unroll
     for (int e = 0; e < VE; e++) {
-      if (act) gg[e] *= act_grad_from_out(RC ? yy[e] * sc[e] + sh[e] : zz[e], act, slope);
+      if (actv) gg[e] *= act_grad_from_out(RC ? yy[e] * sc[e] + sh[e] : zz[e], actv, slope);
       const float xh = (yy[e] - mu[e]) * rs[e];
       ov[e] = sc[e] * (gg[e] - k1[e] - xh * k2[e]);
     }
@@ -390,13 +396,14 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_gen_kernel(const T* __restri
   }
 }
 
-template <typename T, int MODE, bool RC>
+template <typename T, int MODE, bool RC, int ACT>
 __global__ __launch_bounds__(256) void col_reduce_gen_kernel(const T* __restrict__ dz, const T* __restrict__ z,
                                                              const T* __restrict__ y, const float* __restrict__ mean,
                                                              const float* __restrict__ rstd, float* __restrict__ partial,
                                                              int64_t pixels, int C, int act, float slope, const float* __restrict__ scale,
                                                              const float* __restrict__ shift) {
   constexpr int VE = Elem<T>::VE;
+  const int actv = ACT >= 0 ? ACT : act;   // compile-time activation where the launcher knows it
   __shared__ float red[256 * VE * 2];
   const int t = threadIdx.x;
   const int VP = C / VE, PPB = 256 / VP;
@@ -415,7 +422,7 @@ __global__ __launch_bounds__(256) void col_reduce_gen_kernel(const T* __restrict
     for (int e = 0; e < VE; e++) {
       float gv = g0[e];
       if (MODE == 0) {
-        if (act) gv *= act_grad_from_out(RC ? yy[e] * sq[e] + hq[e] : zz[e], act, slope);
+        if (actv) gv *= act_grad_from_out(RC ? yy[e] * sq[e] + hq[e] : zz[e], actv, slope);
         a[e] += gv; b[e] += gv * ((yy[e] - mu[e]) * rs[e]);
       } else a[e] += gv;
     }
@@ -427,7 +434,7 @@ __global__ __launch_bounds__(256) void col_reduce_gen_kernel(const T* __restrict
       float g0[VE], z0[VE], y0[VE], g1[VE], z1[VE], y1[VE];
       ldv(dz + o0, g0); ldv(dz + o1, g1);
       if (MODE == 0) {
-        if (act && !RC) { ldv(z + o0, z0); ldv(z + o1, z1); }
+        if (actv && !RC) { ldv(z + o0, z0); ldv(z + o1, z1); }
         ldv(y + o0, y0); ldv(y + o1, y1);
       }
       accum(g0, z0, y0); accum(g1, z1, y1);
@@ -436,7 +443,7 @@ __global__ __launch_bounds__(256) void col_reduce_gen_kernel(const T* __restrict
       const int64_t o0 = p * C + g * VE;
       float g0[VE], z0[VE], y0[VE];
       ldv(dz + o0, g0);
-      if (MODE == 0) { if (act && !RC) ldv(z + o0, z0); ldv(y + o0, y0); }
+      if (MODE == 0) { if (actv && !RC) ldv(z + o0, z0); ldv(y + o0, y0); }
       accum(g0, z0, y0);
     }
   }
@@ -454,6 +461,16 @@ __global__ __launch_bounds__(256) void col_reduce_gen_kernel(const T* __restrict
 static bool gen_ok(int C, int dtype) {
   const int ve = dtype == 0 ? 4 : 8;
   return (C % ve) == 0 && C / ve <= 256;
+}
+template <typename F>
+static void act_dispatch(int act, F&& f) {   // compile-time activation variants for the streaming kernels
+  switch (act) {
+    case 0: f(std::integral_constant<int, 0>{}); break;
+    case 1: f(std::integral_constant<int, 1>{}); break;
+    case 2: f(std::integral_constant<int, 2>{}); break;
+    case 3: f(std::integral_constant<int, 3>{}); break;
+    default: f(std::integral_constant<int, -1>{}); break;
+  }
 }
 static bool vec_ok(int C, int dtype) {
   const int ve = dtype == 0 ? 4 : 8;
@@ -550,15 +567,25 @@ void launch_affine_act(const void* y, const float* scale, const float* shift, co
   if (vec_ok(C, dtype)) {
     const int64_t nvec = total / (dtype == 0 ? 4 : 8);
     unsigned gv = ew_grid(nvec);
-    if (dtype == 0) hipLaunchKernelGGL((affine_act_vec_kernel<float>), dim3(gv), dim3(256), 0, st, (const float*)y, scale, shift, (const float*)res, (float*)out, nvec, C, act, slope);
-    else hipLaunchKernelGGL((affine_act_vec_kernel<bf16_t>), dim3(gv), dim3(256), 0, st, (const bf16_t*)y, scale, shift, (const bf16_t*)res, (bf16_t*)out, nvec, C, act, slope);
+    act_dispatch(act, [&](auto ac) {
+      constexpr int A = decltype(ac)::value;
+      if (dtype == 0) { if (res) hipLaunchKernelGGL((affine_act_vec_kernel<float, A, true>), dim3(gv), dim3(256), 0, st, (const float*)y, scale, shift, (const float*)res, (float*)out, nvec, C, act, slope);
+                        else hipLaunchKernelGGL((affine_act_vec_kernel<float, A, false>), dim3(gv), dim3(256), 0, st, (const float*)y, scale, shift, (const float*)res, (float*)out, nvec, C, act, slope); }
+      else { if (res) hipLaunchKernelGGL((affine_act_vec_kernel<bf16_t, A, true>), dim3(gv), dim3(256), 0, st, (const bf16_t*)y, scale, shift, (const bf16_t*)res, (bf16_t*)out, nvec, C, act, slope);
+             else hipLaunchKernelGGL((affine_act_vec_kernel<bf16_t, A, false>), dim3(gv), dim3(256), 0, st, (const bf16_t*)y, scale, shift, (const bf16_t*)res, (bf16_t*)out, nvec, C, act, slope); }
+    });
     return;
   }
   if (gen_ok(C, dtype)) {
     const int ppb = 256 / (C / (dtype == 0 ? 4 : 8));
     unsigned gg = (unsigned)std::max<int64_t>(1, std::min<int64_t>(cdiv(pixels, ppb), 2048));
-    if (dtype == 0) hipLaunchKernelGGL((affine_act_gen_kernel<float>), dim3(gg), dim3(256), 0, st, (const float*)y, scale, shift, (const float*)res, (float*)out, pixels, C, act, slope);
-    else hipLaunchKernelGGL((affine_act_gen_kernel<bf16_t>), dim3(gg), dim3(256), 0, st, (const bf16_t*)y, scale, shift, (const bf16_t*)res, (bf16_t*)out, pixels, C, act, slope);
+    act_dispatch(act, [&](auto ac) {
+      constexpr int A = decltype(ac)::value;
+      if (dtype == 0) { if (res) hipLaunchKernelGGL((affine_act_gen_kernel<float, A, true>), dim3(gg), dim3(256), 0, st, (const float*)y, scale, shift, (const float*)res, (float*)out, pixels, C, act, slope);
+                        else hipLaunchKernelGGL((affine_act_gen_kernel<float, A, false>), dim3(gg), dim3(256), 0, st, (const float*)y, scale, shift, (const float*)res, (float*)out, pixels, C, act, slope); }
+      else { if (res) hipLaunchKernelGGL((affine_act_gen_kernel<bf16_t, A, true>), dim3(gg), dim3(256), 0, st, (const bf16_t*)y, scale, shift, (const bf16_t*)res, (bf16_t*)out, pixels, C, act, slope);
+             else hipLaunchKernelGGL((affine_act_gen_kernel<bf16_t, A, false>), dim3(gg), dim3(256), 0, st, (const bf16_t*)y, scale, shift, (const bf16_t*)res, (bf16_t*)out, pixels, C, act, slope); }
+    });
     return;
   }
   bool v4 = (C % 4 == 0);
@@ -579,13 +606,19 @@ void launch_bn_bwd_reduce(const void* dz, const void* z, const void* y, const fl
   RedGeom g = red_geom(C);
   dim3 grid(red_rows(pixels, C), g.nchunk);
   if (vec_ok(C, dtype)) {
-    if (dtype == 0) { if (shift) hipLaunchKernelGGL((col_reduce_vec_kernel<float, 0, true>), dim3(grid.x), dim3(256), 0, st, (const float*)dz, (const float*)z, (const float*)y, mean, rstd, partial, pixels, C, act, slope, scale, shift); else hipLaunchKernelGGL((col_reduce_vec_kernel<float, 0, false>), dim3(grid.x), dim3(256), 0, st, (const float*)dz, (const float*)z, (const float*)y, mean, rstd, partial, pixels, C, act, slope, scale, shift); }
-    else { if (shift) hipLaunchKernelGGL((col_reduce_vec_kernel<bf16_t, 0, true>), dim3(grid.x), dim3(256), 0, st, (const bf16_t*)dz, (const bf16_t*)z, (const bf16_t*)y, mean, rstd, partial, pixels, C, act, slope, scale, shift); else hipLaunchKernelGGL((col_reduce_vec_kernel<bf16_t, 0, false>), dim3(grid.x), dim3(256), 0, st, (const bf16_t*)dz, (const bf16_t*)z, (const bf16_t*)y, mean, rstd, partial, pixels, C, act, slope, scale, shift); }
+    act_dispatch(act, [&](auto ac) {
+      constexpr int A = decltype(ac)::value; (void)A;
+      if (dtype == 0) { if (shift) hipLaunchKernelGGL((col_reduce_vec_kernel<float, 0, true, A>), dim3(grid.x), dim3(256), 0, st, (const float*)dz, (const float*)z, (const float*)y, mean, rstd, partial, pixels, C, act, slope, scale, shift); else hipLaunchKernelGGL((col_reduce_vec_kernel<float, 0, false, -1>), dim3(grid.x), dim3(256), 0, st, (const float*)dz, (const float*)z, (const float*)y, mean, rstd, partial, pixels, C, act, slope, scale, shift); }
+      else { if (shift) hipLaunchKernelGGL((col_reduce_vec_kernel<bf16_t, 0, true, A>), dim3(grid.x), dim3(256), 0, st, (const bf16_t*)dz, (const bf16_t*)z, (const bf16_t*)y, mean, rstd, partial, pixels, C, act, slope, scale, shift); else hipLaunchKernelGGL((col_reduce_vec_kernel<bf16_t, 0, false, -1>), dim3(grid.x), dim3(256), 0, st, (const bf16_t*)dz, (const bf16_t*)z, (const bf16_t*)y, mean, rstd, partial, pixels, C, act, slope, scale, shift); }
+    });
     return;
   }
   if (gen_ok(C, dtype)) {
-    if (dtype == 0) { if (shift) hipLaunchKernelGGL((col_reduce_gen_kernel<float, 0, true>), dim3(grid.x), dim3(256), 0, st, (const float*)dz, (const float*)z, (const float*)y, mean, rstd, partial, pixels, C, act, slope, scale, shift); else hipLaunchKernelGGL((col_reduce_gen_kernel<float, 0, false>), dim3(grid.x), dim3(256), 0, st, (const float*)dz, (const float*)z, (const float*)y, mean, rstd, partial, pixels, C, act, slope, scale, shift); }
-    else { if (shift) hipLaunchKernelGGL((col_reduce_gen_kernel<bf16_t, 0, true>), dim3(grid.x), dim3(256), 0, st, (const bf16_t*)dz, (const bf16_t*)z, (const bf16_t*)y, mean, rstd, partial, pixels, C, act, slope, scale, shift); else hipLaunchKernelGGL((col_reduce_gen_kernel<bf16_t, 0, false>), dim3(grid.x), dim3(256), 0, st, (const bf16_t*)dz, (const bf16_t*)z, (const bf16_t*)y, mean, rstd, partial, pixels, C, act, slope, scale, shift); }
+    act_dispatch(act, [&](auto ac) {
+      constexpr int A = decltype(ac)::value; (void)A;
+      if (dtype == 0) { if (shift) hipLaunchKernelGGL((col_reduce_gen_kernel<float, 0, true, A>), dim3(grid.x), dim3(256), 0, st, (const float*)dz, (const float*)z, (const float*)y, mean, rstd, partial, pixels, C, act, slope, scale, shift); else hipLaunchKernelGGL((col_reduce_gen_kernel<float, 0, false, -1>), dim3(grid.x), dim3(256), 0, st, (const float*)dz, (const float*)z, (const float*)y, mean, rstd, partial, pixels, C, act, slope, scale, shift); }
+      else { if (shift) hipLaunchKernelGGL((col_reduce_gen_kernel<bf16_t, 0, true, A>), dim3(grid.x), dim3(256), 0, st, (const bf16_t*)dz, (const bf16_t*)z, (const bf16_t*)y, mean, rstd, partial, pixels, C, act, slope, scale, shift); else hipLaunchKernelGGL((col_reduce_gen_kernel<bf16_t, 0, false, -1>), dim3(grid.x), dim3(256), 0, st, (const bf16_t*)dz, (const bf16_t*)z, (const bf16_t*)y, mean, rstd, partial, pixels, C, act, slope, scale, shift); }
+    });
     return;
   }
   if (dtype == 0)
@@ -607,15 +640,21 @@ void launch_bn_bwd_apply(const void* dz, const void* z, const void* y, const flo
   if (vec_ok(C, dtype)) {
     const int64_t nvec = total / (dtype == 0 ? 4 : 8);
     unsigned gv = ew_grid(nvec);
-    if (dtype == 0) { if (shift) hipLaunchKernelGGL((bn_bwd_apply_vec_kernel<float, true>), dim3(gv), dim3(256), 0, st, (const float*)dz, (const float*)z, (const float*)y, mean, rstd, scale, c1, c2, shift, (float*)dy, (float*)dres, nvec, C, act, slope); else hipLaunchKernelGGL((bn_bwd_apply_vec_kernel<float, false>), dim3(gv), dim3(256), 0, st, (const float*)dz, (const float*)z, (const float*)y, mean, rstd, scale, c1, c2, shift, (float*)dy, (float*)dres, nvec, C, act, slope); }
-    else { if (shift) hipLaunchKernelGGL((bn_bwd_apply_vec_kernel<bf16_t, true>), dim3(gv), dim3(256), 0, st, (const bf16_t*)dz, (const bf16_t*)z, (const bf16_t*)y, mean, rstd, scale, c1, c2, shift, (bf16_t*)dy, (bf16_t*)dres, nvec, C, act, slope); else hipLaunchKernelGGL((bn_bwd_apply_vec_kernel<bf16_t, false>), dim3(gv), dim3(256), 0, st, (const bf16_t*)dz, (const bf16_t*)z, (const bf16_t*)y, mean, rstd, scale, c1, c2, shift, (bf16_t*)dy, (bf16_t*)dres, nvec, C, act, slope); }
+    act_dispatch(act, [&](auto ac) {
+      constexpr int A = decltype(ac)::value; (void)A;
+      if (dtype == 0) { if (shift) hipLaunchKernelGGL((bn_bwd_apply_vec_kernel<float, true, A>), dim3(gv), dim3(256), 0, st, (const float*)dz, (const float*)z, (const float*)y, mean, rstd, scale, c1, c2, shift, (float*)dy, (float*)dres, nvec, C, act, slope); else hipLaunchKernelGGL((bn_bwd_apply_vec_kernel<float, false, -1>), dim3(gv), dim3(256), 0, st, (const float*)dz, (const float*)z, (const float*)y, mean, rstd, scale, c1, c2, shift, (float*)dy, (float*)dres, nvec, C, act, slope); }
+      else { if (shift) hipLaunchKernelGGL((bn_bwd_apply_vec_kernel<bf16_t, true, A>), dim3(gv), dim3(256), 0, st, (const bf16_t*)dz, (const bf16_t*)z, (const bf16_t*)y, mean, rstd, scale, c1, c2, shift, (bf16_t*)dy, (bf16_t*)dres, nvec, C, act, slope); else hipLaunchKernelGGL((bn_bwd_apply_vec_kernel<bf16_t, false, -1>), dim3(gv), dim3(256), 0, st, (const bf16_t*)dz, (const bf16_t*)z, (const bf16_t*)y, mean, rstd, scale, c1, c2, shift, (bf16_t*)dy, (bf16_t*)dres, nvec, C, act, slope); }
+    });
     return;
   }
   if (gen_ok(C, dtype)) {
     const int ppb = 256 / (C / (dtype == 0 ? 4 : 8));
     unsigned gg = (unsigned)std::max<int64_t>(1, std::min<int64_t>(cdiv(pixels, ppb), 2048));
-    if (dtype == 0) { if (shift) hipLaunchKernelGGL((bn_bwd_apply_gen_kernel<float, true>), dim3(gg), dim3(256), 0, st, (const float*)dz, (const float*)z, (const float*)y, mean, rstd, scale, c1, c2, shift, (float*)dy, (float*)dres, pixels, C, act, slope); else hipLaunchKernelGGL((bn_bwd_apply_gen_kernel<float, false>), dim3(gg), dim3(256), 0, st, (const float*)dz, (const float*)z, (const float*)y, mean, rstd, scale, c1, c2, shift, (float*)dy, (float*)dres, pixels, C, act, slope); }
-    else { if (shift) hipLaunchKernelGGL((bn_bwd_apply_gen_kernel<bf16_t, true>), dim3(gg), dim3(256), 0, st, (const bf16_t*)dz, (const bf16_t*)z, (const bf16_t*)y, mean, rstd, scale, c1, c2, shift, (bf16_t*)dy, (bf16_t*)dres, pixels, C, act, slope); else hipLaunchKernelGGL((bn_bwd_apply_gen_kernel<bf16_t, false>), dim3(gg), dim3(256), 0, st, (const bf16_t*)dz, (const bf16_t*)z, (const bf16_t*)y, mean, rstd, scale, c1, c2, shift, (bf16_t*)dy, (bf16_t*)dres, pixels, C, act, slope); }
+    act_dispatch(act, [&](auto ac) {
+      constexpr int A = decltype(ac)::value; (void)A;
+      if (dtype == 0) { if (shift) hipLaunchKernelGGL((bn_bwd_apply_gen_kernel<float, true, A>), dim3(gg), dim3(256), 0, st, (const float*)dz, (const float*)z, (const float*)y, mean, rstd, scale, c1, c2, shift, (float*)dy, (float*)dres, pixels, C, act, slope); else hipLaunchKernelGGL((bn_bwd_apply_gen_kernel<float, false, -1>), dim3(gg), dim3(256), 0, st, (const float*)dz, (const float*)z, (const float*)y, mean, rstd, scale, c1, c2, shift, (float*)dy, (float*)dres, pixels, C, act, slope); }
+      else { if (shift) hipLaunchKernelGGL((bn_bwd_apply_gen_kernel<bf16_t, true, A>), dim3(gg), dim3(256), 0, st, (const bf16_t*)dz, (const bf16_t*)z, (const bf16_t*)y, mean, rstd, scale, c1, c2, shift, (bf16_t*)dy, (bf16_t*)dres, pixels, C, act, slope); else hipLaunchKernelGGL((bn_bwd_apply_gen_kernel<bf16_t, false, -1>), dim3(gg), dim3(256), 0, st, (const bf16_t*)dz, (const bf16_t*)z, (const bf16_t*)y, mean, rstd, scale, c1, c2, shift, (bf16_t*)dy, (bf16_t*)dres, pixels, C, act, slope); }
+    });
     return;
   }
   bool v4 = (C % 4 == 0);
@@ -636,11 +675,11 @@ void launch_colsum(const void* x, float* partial, float* out, int accumulate, in
   int nr = red_rows(rows, C);
   dim3 grid(nr, g.nchunk);
   if (vec_ok(C, dtype)) {
-    if (dtype == 0) hipLaunchKernelGGL((col_reduce_vec_kernel<float, 1, false>), dim3(nr), dim3(256), 0, st, (const float*)x, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, partial, rows, C, 0, 0.f, (const float*)nullptr, (const float*)nullptr);
-    else hipLaunchKernelGGL((col_reduce_vec_kernel<bf16_t, 1, false>), dim3(nr), dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)nullptr, (const bf16_t*)nullptr, (const float*)nullptr, (const float*)nullptr, partial, rows, C, 0, 0.f, (const float*)nullptr, (const float*)nullptr);
+    if (dtype == 0) hipLaunchKernelGGL((col_reduce_vec_kernel<float, 1, false, -1>), dim3(nr), dim3(256), 0, st, (const float*)x, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, partial, rows, C, 0, 0.f, (const float*)nullptr, (const float*)nullptr);
+    else hipLaunchKernelGGL((col_reduce_vec_kernel<bf16_t, 1, false, -1>), dim3(nr), dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)nullptr, (const bf16_t*)nullptr, (const float*)nullptr, (const float*)nullptr, partial, rows, C, 0, 0.f, (const float*)nullptr, (const float*)nullptr);
   } else if (gen_ok(C, dtype)) {
-    if (dtype == 0) hipLaunchKernelGGL((col_reduce_gen_kernel<float, 1, false>), dim3(nr), dim3(256), 0, st, (const float*)x, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, partial, rows, C, 0, 0.f, (const float*)nullptr, (const float*)nullptr);
-    else hipLaunchKernelGGL((col_reduce_gen_kernel<bf16_t, 1, false>), dim3(nr), dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)nullptr, (const bf16_t*)nullptr, (const float*)nullptr, (const float*)nullptr, partial, rows, C, 0, 0.f, (const float*)nullptr, (const float*)nullptr);
+    if (dtype == 0) hipLaunchKernelGGL((col_reduce_gen_kernel<float, 1, false, -1>), dim3(nr), dim3(256), 0, st, (const float*)x, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, partial, rows, C, 0, 0.f, (const float*)nullptr, (const float*)nullptr);
+    else hipLaunchKernelGGL((col_reduce_gen_kernel<bf16_t, 1, false, -1>), dim3(nr), dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)nullptr, (const bf16_t*)nullptr, (const float*)nullptr, (const float*)nullptr, partial, rows, C, 0, 0.f, (const float*)nullptr, (const float*)nullptr);
   } else if (dtype == 0)
     hipLaunchKernelGGL((col_reduce_kernel<float, 1>), grid, dim3(256), 0, st, (const float*)x, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, partial, rows, C, g.CB, g.PL, 0, 0.f);
   else
