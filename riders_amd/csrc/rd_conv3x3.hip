@@ -165,7 +165,7 @@ template <int SPP>
 __device__ __forceinline__ int patch_slot(int p, int j) { return p * SPP + (j ^ ((p / (16 / SPP)) % SPP)); }
 
 template <typename T, int SPP, int BN, bool W8>
-__global__ __launch_bounds__(256) void conv3x3_small_kernel(ConvArgs a, int tilesH, int tilesW) {
+__global__ __launch_bounds__(256, (SPP * BN <= 64) ? 4 : 1) void conv3x3_small_kernel(ConvArgs a, int tilesH, int tilesW) {
   constexpr int VE = Elem<T>::VE;
   constexpr int TW = W8 ? 8 : 16, TH = W8 ? 16 : 8;
   constexpr int WT = TW + 2, HT = TH + 2, NP = HT * WT;
@@ -185,8 +185,12 @@ __global__ __launch_bounds__(256) void conv3x3_small_kernel(ConvArgs a, int tile
   const int tend = min(ntiles, (xcd + 1) * T8);
   int tile = xcd * T8 + (blockIdx.x >> 3);
 
-  // weight fragments: row = cout (c*16 + fr), 16-byte K slot = s*4 + fg
-  uint4 wr[CT][STEPS];
+  // weight fragments: row = cout (c*16 + fr), 16-byte K slot = s*4 + fg.  Kept in registers, except for the variants where those 36-40
+  // VGPRs cost a wave of occupancy (these kernels are latency bound: 2 -> 3 -> 4 waves per SIMD each measured faster): there every
+  // wave reads its fragments from a lane-major LDS copy ([c][s][lane], conflict free).
+  constexpr bool WLDS = (SPP * BN == 64);
+  __shared__ uint4 sW[WLDS ? CT * STEPS * 64 : 1];
+  uint4 wr[WLDS ? 1 : CT][WLDS ? 1 : STEPS];
   {
     const uint4* wp = reinterpret_cast<const uint4*>(a.w);
     const int kslots = a.Kpad / VE;
@@ -195,12 +199,25 @@ __global__ __launch_bounds__(256) void conv3x3_small_kernel(ConvArgs a, int tile
 #pragma unroll
       for (int s = 0; s < STEPS; s++) {
         const uint4 v = wp[(int64_t)(c * 16 + fr) * kslots + s * 4 + fg];
-        wr[c][s] = v;
+        if (WLDS) { if (wv == 0) sW[(c * STEPS + s) * 64 + lane] = v; }
+        else wr[WLDS ? 0 : c][WLDS ? 0 : s] = v;
       }
   }
-  auto load_patch = [&](int tl, uint4 (&rp)[PIT]) RD_INLINE_LAMBDA {
-    const int tw_ = tl % tilesW; const int q_ = tl / tilesW; const int th_ = q_ % tilesH; const int n = q_ / tilesH;
-    const int oh0 = th_ * TH, ow0 = tw_ * TW;
+  // tile coordinates (image, tile row, tile column) advance by G8 tiles with carries: the runtime divisions of a per-tile decode were
+  // ~200 of the ~215 scalar instructions per tile (SQ_INSTS_SALU = SQ_INSTS_VALU in the PMC pass)
+  struct TC { int n, th, tw; };
+  const TC step = {(G8 / tilesW) / tilesH, (G8 / tilesW) % tilesH, G8 % tilesW};
+  auto decode = [&](int tl) RD_INLINE_LAMBDA { TC c; c.tw = tl % tilesW; const int q_ = tl / tilesW; c.th = q_ % tilesH; c.n = q_ / tilesH; return c; };
+  auto advance = [&](TC c) RD_INLINE_LAMBDA {
+    c.tw += step.tw; if (c.tw >= tilesW) { c.tw -= tilesW; c.th++; }
+    c.th += step.th; if (c.th >= tilesH) { c.th -= tilesH; c.n++; }
+    if (c.th >= tilesH) { c.th -= tilesH; c.n++; }
+    c.n += step.n;
+    return c;
+  };
+  auto load_patch = [&](TC tc, uint4 (&rp)[PIT]) RD_INLINE_LAMBDA {
+    const int n = tc.n;
+    const int oh0 = tc.th * TH, ow0 = tc.tw * TW;
 #pragma unroll
     for (int i = 0; i < PIT; i++) {
       int idx = t + 256 * i;
@@ -230,7 +247,7 @@ __global__ __launch_bounds__(256) void conv3x3_small_kernel(ConvArgs a, int tile
   }
 
   // one tile: MFMA over the LDS patch in `buf`, then the shared epilogue
-  auto tile_body = [&](int tile, int buf) RD_INLINE_LAMBDA {
+  auto tile_body = [&](int tile, TC tc, int buf) RD_INLINE_LAMBDA {
     f32x4 acc[CT][2];
 #pragma unroll
     for (int c = 0; c < CT; c++) { acc[c][0] = f32x4{0, 0, 0, 0}; acc[c][1] = f32x4{0, 0, 0, 0}; }
@@ -246,7 +263,7 @@ __global__ __launch_bounds__(256) void conv3x3_small_kernel(ConvArgs a, int tile
       for (int pt = 0; pt < 2; pt++) pf[pt] = sP[buf][patch_slot<SPP>(ppix[pt] + toff, j)];
 #pragma unroll
       for (int c = 0; c < CT; c++) {
-        const uint4 wf = wr[c][s];
+        const uint4 wf = WLDS ? sW[(c * STEPS + s) * 64 + lane] : wr[WLDS ? 0 : c][WLDS ? 0 : s];
 #pragma unroll
         for (int pt = 0; pt < 2; pt++) {
           if (sizeof(T) == 4) {
@@ -264,13 +281,12 @@ __global__ __launch_bounds__(256) void conv3x3_small_kernel(ConvArgs a, int tile
       }
     }
     {
-      const int tw_ = tile % tilesW; const int q_ = tile / tilesW; const int th_ = q_ % tilesH; const int n = q_ / tilesH;
       int64_t mm[2]; bool mvv[2];
 #pragma unroll
       for (int pt = 0; pt < 2; pt++) {
-        int oh = th_ * TH + lpy[pt], ow = tw_ * TW + lpx[pt];
+        int oh = tc.th * TH + lpy[pt], ow = tc.tw * TW + lpx[pt];
         mvv[pt] = oh < a.OH && ow < a.OW;
-        mm[pt] = ((int64_t)n * a.OH + oh) * a.OW + ow;
+        mm[pt] = ((int64_t)tc.n * a.OH + oh) * a.OW + ow;
       }
       conv_epilogue<T, CT, BN, 4>(a, acc, mm, mvv, 0, 0, wv, fr, fg, t, tile, red);
     }
@@ -281,17 +297,18 @@ __global__ __launch_bounds__(256) void conv3x3_small_kernel(ConvArgs a, int tile
   // the HBM roof with four blocks per CU)
   uint4 ra[PIT], rb[PIT];
   int t0 = tile, t1 = tile + G8;
-  if (t0 < tend) load_patch(t0, ra);
-  if (t1 < tend) load_patch(t1, rb);
+  TC c0 = decode(t0), c1 = advance(c0);
+  if (t0 < tend) load_patch(c0, ra);
+  if (t1 < tend) load_patch(c1, rb);
   int buf = 0;
   while (t0 < tend) {
     store_patch(buf, ra);
     __syncthreads();
-    { const int t2 = t1 + G8; if (t2 < tend) load_patch(t2, ra); tile_body(t0, buf); t0 = t1; t1 = t2; buf ^= 1; }
+    { const int t2 = t1 + G8; const TC c2 = advance(c1); if (t2 < tend) load_patch(c2, ra); tile_body(t0, c0, buf); t0 = t1; t1 = t2; c0 = c1; c1 = c2; buf ^= 1; }
     if (t0 >= tend) break;
     store_patch(buf, rb);
     __syncthreads();
-    { const int t2 = t1 + G8; if (t2 < tend) load_patch(t2, rb); tile_body(t0, buf); t0 = t1; t1 = t2; buf ^= 1; }
+    { const int t2 = t1 + G8; const TC c2 = advance(c1); if (t2 < tend) load_patch(c2, rb); tile_body(t0, c0, buf); t0 = t1; t1 = t2; c0 = c1; c1 = c2; buf ^= 1; }
   }
 }
 

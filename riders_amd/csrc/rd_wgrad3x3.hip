@@ -75,9 +75,19 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_tr_kernel(WgradArgs a, i
     for (int j = 0; j < NCW; j++) acc[i][j] = f32x4{0, 0, 0, 0};
 
   const bool yvec = (a.Cout & 7) == 0;
-  auto fetch = [&](int tl, uint4 (&rx)[XIT], uint4 (&ry)[YIT]) RD_INLINE_LAMBDA {
-    const int tw_ = tl % tilesW; const int q_ = tl / tilesW; const int th_ = q_ % tilesH; const int n = q_ / tilesH;
-    const int oh0 = th_ * TH, ow0 = tw_ * TW;
+  // tile coordinates advance by G8 tiles with carries (no per-tile runtime divisions, see rd_conv3x3.hip)
+  struct TC { int n, th, tw; };
+  const TC tstep = {(G8 / tilesW) / tilesH, (G8 / tilesW) % tilesH, G8 % tilesW};
+  auto decode = [&](int tl) RD_INLINE_LAMBDA { TC c; c.tw = tl % tilesW; const int q_ = tl / tilesW; c.th = q_ % tilesH; c.n = q_ / tilesH; return c; };
+  auto advance = [&](TC c) RD_INLINE_LAMBDA {
+    c.tw += tstep.tw; if (c.tw >= tilesW) { c.tw -= tilesW; c.th++; }
+    c.th += tstep.th; if (c.th >= tilesH) { c.th -= tilesH; c.n++; }
+    c.n += tstep.n;
+    return c;
+  };
+  auto fetch = [&](TC tc, uint4 (&rx)[XIT], uint4 (&ry)[YIT]) RD_INLINE_LAMBDA {
+    const int n = tc.n;
+    const int oh0 = tc.th * TH, ow0 = tc.tw * TW;
 #pragma unroll
     for (int i = 0; i < XIT; i++) {
       const int idx = t + 256 * i;
@@ -155,24 +165,27 @@ __global__ __launch_bounds__(256, 2) void conv3x3_wgrad_tr_kernel(WgradArgs a, i
   int buf = 0;
   if (DEEP) {
     int t0 = tile, t1 = tile + G8;
-    if (t0 < tend) fetch(t0, xa, ya_);
-    if (t1 < tend) fetch(t1, reinterpret_cast<uint4 (&)[XIT]>(xb_), reinterpret_cast<uint4 (&)[YIT]>(yb_));
+    TC c1 = advance(decode(t0));
+    if (t0 < tend) fetch(decode(t0), xa, ya_);
+    if (t1 < tend) fetch(c1, reinterpret_cast<uint4 (&)[XIT]>(xb_), reinterpret_cast<uint4 (&)[YIT]>(yb_));
     while (t0 < tend) {
       stash(buf, xa, ya_);
       __syncthreads();
-      { const int t2 = t1 + G8; if (t2 < tend) fetch(t2, xa, ya_); tile_body(buf); t0 = t1; t1 = t2; buf ^= 1; }
+      { const int t2 = t1 + G8; c1 = advance(c1); if (t2 < tend) fetch(c1, xa, ya_); tile_body(buf); t0 = t1; t1 = t2; buf ^= 1; }
       if (t0 >= tend) break;
       stash(buf, reinterpret_cast<const uint4 (&)[XIT]>(xb_), reinterpret_cast<const uint4 (&)[YIT]>(yb_));
       __syncthreads();
-      { const int t2 = t1 + G8; if (t2 < tend) fetch(t2, reinterpret_cast<uint4 (&)[XIT]>(xb_), reinterpret_cast<uint4 (&)[YIT]>(yb_)); tile_body(buf); t0 = t1; t1 = t2; buf ^= 1; }
+      { const int t2 = t1 + G8; c1 = advance(c1); if (t2 < tend) fetch(c1, reinterpret_cast<uint4 (&)[XIT]>(xb_), reinterpret_cast<uint4 (&)[YIT]>(yb_)); tile_body(buf); t0 = t1; t1 = t2; buf ^= 1; }
     }
   } else {
-    if (tile < tend) fetch(tile, xa, ya_);
+    TC c0 = decode(tile);
+    if (tile < tend) fetch(c0, xa, ya_);
     while (tile < tend) {
       stash(buf, xa, ya_);
       __syncthreads();
       const int next = tile + G8;
-      if (next < tend) fetch(next, xa, ya_);
+      c0 = advance(c0);
+      if (next < tend) fetch(c0, xa, ya_);
       tile_body(buf);
       tile = next;
       buf ^= 1;
