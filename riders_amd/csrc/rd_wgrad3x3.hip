@@ -22,7 +22,7 @@ namespace rd {
 // wide, 0.102 -> 0.140 ms narrow): the per-read address arithmetic replaces immediate offsets and the kernel is issue / latency bound
 // with one wave per SIMD, not LDS bound.  The affine layout stays.
 template <int CTI, int RT, int TW>
-__global__ __launch_bounds__(256, 2) void conv3x3_wgrad_tr_kernel(WgradArgs a, int tilesH, int tilesW, int nci) {
+__global__ __launch_bounds__(256, (CTI * RT <= 2) ? 4 : 2) void conv3x3_wgrad_tr_kernel(WgradArgs a, int tilesH, int tilesW, int nci) {
   typedef bf16_t T;
   constexpr int CIN = CTI * 16, COP = RT * 16;
   constexpr int TH = 8, WT = TW + 2, HT = TH + 2, NPX = HT * WT, NPY = TH * TW;
