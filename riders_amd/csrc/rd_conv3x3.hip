@@ -161,11 +161,17 @@ __global__ __launch_bounds__(256) void conv3x3_patch_kernel(ConvArgs a, int tile
 // (9 taps x Cin) of a 128-pixel tile is one LDS patch; a lane keeps its weight fragments for all taps in registers, blocks are
 // persistent (tile loop, next patch prefetched into registers, double-buffered LDS, one barrier per tile) and every XCD walks a
 // contiguous range of tiles so that halo pixels shared by neighbouring tiles are L2 hits.
+// occupancy target of a variant: four waves per SIMD while four blocks fit the LDS (patch double buffer + LDS-resident weights), else two
+constexpr int small_min_waves(int spp, int bn) {
+  const int steps = (9 * spp + 3) / 4, ct = bn / 16;
+  const int lds = 2 * 180 * spp * 16 + (ct * steps > 5 ? ct * steps * 1024 : 0) + 4 * bn * 8;
+  return (bn < 64 && lds * 4 <= 160 * 1024) ? 4 : 2;   // 64-channel tiles keep 64 accumulator + epilogue registers: two waves
+}
 template <int SPP>
 __device__ __forceinline__ int patch_slot(int p, int j) { return p * SPP + (j ^ ((p / (16 / SPP)) % SPP)); }
 
 template <typename T, int SPP, int BN, bool W8>
-__global__ __launch_bounds__(256, (SPP * BN <= 64) ? 4 : 1) void conv3x3_small_kernel(ConvArgs a, int tilesH, int tilesW) {
+__global__ __launch_bounds__(256, small_min_waves(SPP, BN)) void conv3x3_small_kernel(ConvArgs a, int tilesH, int tilesW) {
   constexpr int VE = Elem<T>::VE;
   constexpr int TW = W8 ? 8 : 16, TH = W8 ? 16 : 8;
   constexpr int WT = TW + 2, HT = TH + 2, NP = HT * WT;
@@ -188,7 +194,7 @@ __global__ __launch_bounds__(256, (SPP * BN <= 64) ? 4 : 1) void conv3x3_small_k
   // weight fragments: row = cout (c*16 + fr), 16-byte K slot = s*4 + fg.  Kept in registers, except for the variants where those 36-40
   // VGPRs cost a wave of occupancy (these kernels are latency bound: 2 -> 3 -> 4 waves per SIMD each measured faster): there every
   // wave reads its fragments from a lane-major LDS copy ([c][s][lane], conflict free).
-  constexpr bool WLDS = (SPP * BN == 64);
+  constexpr bool WLDS = (CT * STEPS > 5);
   __shared__ uint4 sW[WLDS ? CT * STEPS * 64 : 1];
   uint4 wr[WLDS ? 1 : CT][WLDS ? 1 : STEPS];
   {
@@ -397,13 +403,12 @@ void launch_conv3x3(const ConvArgs& a, int dtype, hipStream_t st) {
 static bool geom3x3(const ConvArgs& a) {
   return a.KH == 3 && a.KW == 3 && a.stride == 1 && a.pad == 1 && a.dil == 1 && a.OH == a.Hin && a.OW == a.Win;
 }
-// narrow layers: Cin bytes per pixel in {32, 64, 128}, Cout <= 32, register budget CT * STEPS <= 20
+// narrow layers: Cin bytes per pixel in {32, 64} with Cout <= 64, or 128 bytes with Cout <= 16
 bool conv3x3_small_ok(const ConvArgs& a, int dtype) {
   const int Cin = a.C1 + a.C2, es = dtype == 0 ? 4 : 2, ve = 16 / es;
   const int cb = Cin * es;
-  if (!geom3x3(a) || a.Cout > 32 || (cb != 32 && cb != 64 && cb != 128) || (a.C1 % ve) != 0) return false;
-  const int spp = cb / 16, steps = (9 * spp + 3) / 4, ct = pick_bn3(a.Cout) / 16;
-  return ct * steps <= 20;
+  if (!geom3x3(a) || (cb != 32 && cb != 64 && cb != 128) || (a.C1 % ve) != 0) return false;
+  return cb == 128 ? a.Cout <= 16 : a.Cout <= 64;
 }
 template <typename T>
 static void launch_small_t(const ConvArgs& a, hipStream_t st) {
@@ -419,7 +424,7 @@ static void launch_small_t(const ConvArgs& a, hipStream_t st) {
     if (w8) hipLaunchKernelGGL((conv3x3_small_kernel<T, SPPV, BNV, true>), grid, dim3(256), 0, st, a, tilesH, tilesW);    \
     else hipLaunchKernelGGL((conv3x3_small_kernel<T, SPPV, BNV, false>), grid, dim3(256), 0, st, a, tilesH, tilesW);      \
   }
-  RD_S3(2, 16) RD_S3(4, 16) RD_S3(8, 16) RD_S3(2, 32) RD_S3(4, 32)
+  RD_S3(2, 16) RD_S3(4, 16) RD_S3(8, 16) RD_S3(2, 32) RD_S3(4, 32) RD_S3(2, 64) RD_S3(4, 64)
 #undef RD_S3
 }
 void launch_conv3x3_small(const ConvArgs& a, int dtype, hipStream_t st) {

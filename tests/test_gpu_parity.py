@@ -28,6 +28,8 @@ def test_patch_conv_decoder_and_bf16(gpu):
         P.bf16_exact_conv_case(gpu, cin=16, cout=16, k=3, s=1, H=17, W=9, N=1)
         P.bf16_exact_conv_case(gpu, cin=16, cout=16, k=3, s=1, N=1, up=((4, 3), (9, 17)), cin2=16)
         P.bf16_exact_conv_case(gpu, cin=64, cout=8, k=3, s=1, H=8, W=5, N=2)
+        P.bf16_exact_conv_case(gpu, cin=32, cout=64, k=3, s=1, H=12, W=17, N=1)     # 64 output channels: weights in LDS
+        P.bf16_exact_conv_case(gpu, cin=16, cout=48, k=3, s=1, H=9, W=10, N=2)
     # persistent narrow-layer kernel with many tiles per block (1024 blocks): 3300+ tiles, ragged edges, upsample + concat
     P.bf16_exact_conv_case(gpu, cin=16, cout=16, k=3, s=1, N=12, up=((60, 25), (121, 50)), cin2=16)
     P.bf16_exact_conv_case(gpu, cin=16, cout=1, k=3, s=1, H=130, W=100, N=24)
