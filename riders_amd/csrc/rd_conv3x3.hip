@@ -253,6 +253,12 @@ __global__ __launch_bounds__(256, small_min_waves(SPP, BN)) void conv3x3_small_k
   }
 
   // one tile: MFMA over the LDS patch in `buf`, then the shared epilogue
+  // BatchNorm partial sums of ALL tiles of this block stay in registers; one statistics row per block at the end
+  float ssum[CT][4], ssq[CT][4];
+#pragma unroll
+  for (int c = 0; c < CT; c++)
+#pragma unroll
+    for (int r = 0; r < 4; r++) { ssum[c][r] = 0.f; ssq[c][r] = 0.f; }
   auto tile_body = [&](int tile, TC tc, int buf) RD_INLINE_LAMBDA {
     f32x4 acc[CT][2];
 #pragma unroll
@@ -294,7 +300,7 @@ __global__ __launch_bounds__(256, small_min_waves(SPP, BN)) void conv3x3_small_k
         mvv[pt] = oh < a.OH && ow < a.OW;
         mm[pt] = ((int64_t)tc.n * a.OH + oh) * a.OW + ow;
       }
-      conv_epilogue<T, CT, BN, 4>(a, acc, mm, mvv, 0, 0, wv, fr, fg, t, tile, red);
+      conv_epilogue_store<T, CT>(a, acc, mm, mvv, 0, 0, fr, fg, ssum, ssq);
     }
   };
 
@@ -316,6 +322,7 @@ __global__ __launch_bounds__(256, small_min_waves(SPP, BN)) void conv3x3_small_k
     __syncthreads();
     { const int t2 = t1 + G8; const TC c2 = advance(c1); if (t2 < tend) load_patch(c2, rb); tile_body(t0, c0, buf); t0 = t1; t1 = t2; c0 = c1; c1 = c2; buf ^= 1; }
   }
+  conv_epilogue_stats<CT, BN, 4>(a, ssum, ssq, 0, 0, wv, fr, fg, t, blockIdx.x, red);   // every block writes its row (zeros if it had no tile)
 }
 
 // ---- single input channel (data gradient of a Cout = 1 head): direct form, one pixel per thread ---------------------------------------
@@ -410,15 +417,19 @@ bool conv3x3_small_ok(const ConvArgs& a, int dtype) {
   if (!geom3x3(a) || (cb != 32 && cb != 64 && cb != 128) || (a.C1 % ve) != 0) return false;
   return cb == 128 ? a.Cout <= 16 : a.Cout <= 64;
 }
+int conv3x3_small_blocks(const ConvArgs& a) {   // persistent blocks = BatchNorm statistics rows of this path
+  const bool w8 = use_w8(a);
+  const int64_t ntiles = (int64_t)a.N * cdiv(a.OH, w8 ? 16 : 8) * cdiv(a.OW, w8 ? 8 : 16);
+  const char* e = getenv("RD_CONV3X3_G8");  // test hook: few persistent blocks -> several tiles per block on small cases
+  return 8 * (int)std::min<int64_t>(cdiv(ntiles, 8), e ? atoi(e) : 128);  // 8 XCDs x up to 128 persistent blocks (4 per CU)
+}
 template <typename T>
 static void launch_small_t(const ConvArgs& a, hipStream_t st) {
   const bool w8 = use_w8(a);
   const int tilesH = (int)cdiv(a.OH, w8 ? 16 : 8), tilesW = (int)cdiv(a.OW, w8 ? 8 : 16);
   const int ntiles = a.N * tilesH * tilesW;
   const int spp = (a.C1 + a.C2) * (int)sizeof(T) / 16, bn = pick_bn3(a.Cout);
-  const char* e = getenv("RD_CONV3X3_G8");  // test hook: few persistent blocks -> several tiles per block on small cases
-  const int g8 = (int)std::min<int64_t>(cdiv(ntiles, 8), e ? atoi(e) : 128);  // 8 XCDs x up to 128 persistent blocks (4 per CU)
-  dim3 grid((unsigned)(8 * g8));
+  dim3 grid((unsigned)conv3x3_small_blocks(a));
 #define RD_S3(SPPV, BNV)                                                                                                  \
   if (spp == SPPV && bn == BNV) {                                                                                         \
     if (w8) hipLaunchKernelGGL((conv3x3_small_kernel<T, SPPV, BNV, true>), grid, dim3(256), 0, st, a, tilesH, tilesW);    \
