@@ -178,6 +178,10 @@ int rd_roi_pool_bwd(const void* dout, const float* rois, const int32_t* argmax, 
 
 /* gather form: dx [N][H][W][C] in the activation dtype, every element written once (no atomics, fixed summation order: ascending roi,
    then bin); needs C % (16 / sizeof(element)) == 0 and the forward's spatial_scale */
+/* tile-accumulate form (default when C % 32 == 0): fp32 LDS accumulators per 16 x 16 pixel x 32 channel tile, every gradient element
+   written once in the activation dtype; no global atomics */
+int rd_roi_pool_bwd_tile(const void* dout, const float* rois, const int32_t* argmax, void* dx, int32_t R, int32_t N, int32_t H,
+                         int32_t W, int32_t C, int32_t PH, int32_t PW, float spatial_scale, int32_t dtype, void* stream);
 int rd_roi_pool_bwd_gather(const void* dout, const float* rois, const int32_t* argmax, void* dx, int32_t R, int32_t N, int32_t H,
                            int32_t W, int32_t C, int32_t PH, int32_t PW, float spatial_scale, int32_t dtype, void* stream);
 

@@ -294,6 +294,15 @@ int rd_roi_pool_bwd(const void* dout, const float* rois, const int32_t* argmax, 
   return done("rd_roi_pool_bwd");
 }
 
+int rd_roi_pool_bwd_tile(const void* dout, const float* rois, const int32_t* argmax, void* dx, int32_t R, int32_t N, int32_t H,
+                         int32_t W, int32_t C, int32_t PH, int32_t PW, float scale, int32_t dtype, void* stream) {
+  if (!dx || !dt_ok(dtype)) return fail("roi_pool_bwd_tile: bad args");
+  if (R > 0 && (!dout || !rois || !argmax)) return fail("roi_pool_bwd_tile: null pointer");
+  if (C % 32) return fail("roi_pool_bwd_tile: C must be a multiple of 32");
+  if (N <= 0 || H <= 0 || W <= 0 || PH <= 0 || PW <= 0 || (int64_t)H * W >= (1 << 24)) return fail("roi_pool_bwd_tile: bad sizes");
+  rd::launch_roi_pool_bwd_tile(dout, rois, argmax, dx, R, N, H, W, C, PH, PW, scale, dtype, S(stream));
+  return done("rd_roi_pool_bwd_tile");
+}
 int rd_roi_pool_bwd_gather(const void* dout, const float* rois, const int32_t* argmax, void* dx, int32_t R, int32_t N, int32_t H,
                            int32_t W, int32_t C, int32_t PH, int32_t PW, float scale, int32_t dtype, void* stream) {
   if (!dx || !dt_ok(dtype)) return fail("roi_pool_bwd_gather: bad args");

@@ -100,6 +100,8 @@ void launch_roi_pool_fwd(const void* x, const float* rois, void* out, int* argma
 void launch_roi_pool_bwd(const void* dout, const float* rois, const int* argmax, float* dx_f32, int R, int N, int H, int W,
                          int C, int PH, int PW, int dtype, hipStream_t st);
 
+void launch_roi_pool_bwd_tile(const void* dout, const float* rois, const int* argmax, void* dx, int R, int N, int H, int W, int C,
+                              int PH, int PW, float scale, int dtype, hipStream_t st);
 void launch_roi_pool_bwd_gather(const void* dout, const float* rois, const int* argmax, void* dx, int R, int N, int H, int W, int C,
                                 int PH, int PW, float scale, int dtype, hipStream_t st);
 

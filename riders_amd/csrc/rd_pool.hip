@@ -277,6 +277,96 @@ __global__ __launch_bounds__(256) void roi_pool_bwd_gather_kernel(const T* __res
   }
 }
 
+// ---- tile-accumulate form of the RoI-pool backward ---------------------------------------------------------------------------------
+// A block owns a 16 x 16 pixel tile x 32 channels of one image as fp32 accumulators in LDS.  It lists the RoIs of the image that can
+// reach the tile (as the gather kernel), and for each of them walks the sub-rectangle of bins whose windows can touch the tile:
+// (bin, VE-channel) items read arg-max and dout with 16-byte vectors and add into the LDS tile where the arg-max falls inside it
+// (ds_add_f32); bins on tile borders are scanned by both neighbours, each adds only its own pixels.  The tile is written once, in the
+// activation dtype: no global atomics (83.6 M per RC-Net step before), no zero fill, no fp32 -> bf16 cast pass.
+static constexpr int RPT_CC = 32;
+template <typename T>
+__global__ __launch_bounds__(256) void roi_pool_bwd_tile_kernel(const T* __restrict__ dout, const float* __restrict__ rois,
+                                                                const int* __restrict__ argmax, T* __restrict__ dx, int R, int H,
+                                                                int W, int C, int PH, int PW, float scale, int tilesW) {
+  constexpr int VE = Elem<T>::VE, GC = RPT_CC / VE;
+  __shared__ float tacc[RPB_T * RPB_T * RPT_CC];
+  __shared__ RoiGeo list[RPB_MAXL];
+  __shared__ int wcount[4];
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  const int b = blockIdx.y, c0 = blockIdx.z * RPT_CC;
+  const int h0 = ((int)blockIdx.x / tilesW) * RPB_T, w0 = ((int)blockIdx.x % tilesW) * RPB_T;
+  const float invW = 1.0f / (float)W;
+  for (int i = t; i < RPB_T * RPB_T * RPT_CC; i += 256) tacc[i] = 0.f;
+
+  for (int rbase = 0; rbase < R; rbase += 256) {
+    const int r = rbase + t;
+    bool hit = false; RoiGeo gme;
+    if (r < R) {
+      const float* roi = rois + (int64_t)r * 5;
+      const int sw = (int)roundf(roi[1] * scale), sh = (int)roundf(roi[2] * scale);
+      const int ew = (int)roundf(roi[3] * scale), eh = (int)roundf(roi[4] * scale);
+      const int rw = max(ew - sw + 1, 1), rh = max(eh - sh + 1, 1);
+      gme.r = r; gme.sh = sh; gme.sw = sw; gme.eh = sh + rh + 1; gme.ew = sw + rw + 1;
+      gme.bh = (float)rh / (float)PH; gme.bw = (float)rw / (float)PW;
+      hit = ((int)roi[0] == b) && (sh <= h0 + RPB_T - 1) && (sh + rh + 1 >= h0) && (sw <= w0 + RPB_T - 1) && (sw + rw + 1 >= w0);
+    }
+    const unsigned long long m = __ballot(hit);
+    const int before = __popcll(m & ((1ull << lane) - 1ull));
+    if (lane == 0) wcount[wv] = __popcll(m);
+    __syncthreads();
+    int woff = 0;
+    for (int q = 0; q < wv; q++) woff += wcount[q];
+    const int total = wcount[0] + wcount[1] + wcount[2] + wcount[3];
+    const int mypos = woff + before;
+    for (int cbase = 0; cbase < total; cbase += RPB_MAXL) {
+      __syncthreads();
+      if (hit && mypos >= cbase && mypos < cbase + RPB_MAXL) list[mypos - cbase] = gme;
+      __syncthreads();
+      const int nl = min(total - cbase, RPB_MAXL);
+      for (int li = 0; li < nl; li++) {
+        const RoiGeo q = list[li];
+        // bins whose window [floor(p*bin), ceil((p+1)*bin)) + start can touch rows h0..h0+15 / columns w0..w0+15 (conservative)
+        const int ph_lo = max((int)floorf((float)(h0 - q.sh - 1) / q.bh) - 1, 0), ph_hi = min((int)ceilf((float)(h0 + RPB_T - q.sh) / q.bh), PH - 1);
+        const int pw_lo = max((int)floorf((float)(w0 - q.sw - 1) / q.bw) - 1, 0), pw_hi = min((int)ceilf((float)(w0 + RPB_T - q.sw) / q.bw), PW - 1);
+        const int nph = ph_hi - ph_lo + 1, npw = pw_hi - pw_lo + 1;
+        if (nph <= 0 || npw <= 0) continue;
+        const int items = nph * npw * GC;
+        for (int it = t; it < items; it += 256) {
+          const int g = it % GC; const int bq = it / GC;
+          const int pw = pw_lo + bq % npw, ph = ph_lo + bq / npw;
+          const int64_t o = (((int64_t)q.r * PH + ph) * PW + pw) * C + c0 + g * VE;
+          int am[VE];
+#pragma unroll
+          for (int e4 = 0; e4 < VE / 4; e4++) {
+            const int4 a4 = *reinterpret_cast<const int4*>(argmax + o + e4 * 4);
+            am[e4 * 4] = a4.x; am[e4 * 4 + 1] = a4.y; am[e4 * 4 + 2] = a4.z; am[e4 * 4 + 3] = a4.w;
+          }
+          float dv[VE];
+          ldv(dout + o, dv);
+#pragma unroll
+          for (int e = 0; e < VE; e++) {
+            const int a = am[e];
+            if (a < 0) continue;
+            const int ah = (int)(((float)a + 0.5f) * invW);   // exact: a < 2^24 and (a + 0.5) / W is >= 0.5 / W away from an integer
+            const int lh = ah - h0, lw = a - ah * W - w0;
+            if ((unsigned)lh < (unsigned)RPB_T && (unsigned)lw < (unsigned)RPB_T) atomicAdd(&tacc[(lh * RPB_T + lw) * RPT_CC + g * VE + e], dv[e]);
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+  __syncthreads();
+  for (int i = t; i < RPB_T * RPB_T * (RPT_CC / 4); i += 256) {
+    const int c4 = (i % (RPT_CC / 4)) * 4, pix = i / (RPT_CC / 4);
+    const int h = h0 + pix / RPB_T, w = w0 + pix % RPB_T;
+    if (h < H && w < W) {
+      float v[4] = {tacc[pix * RPT_CC + c4], tacc[pix * RPT_CC + c4 + 1], tacc[pix * RPT_CC + c4 + 2], tacc[pix * RPT_CC + c4 + 3]};
+      st4(dx + (((int64_t)b * H + h) * W + w) * C + c0 + c4, v);
+    }
+  }
+}
+
 // explicit zero-fill kernel (kept as a kernel node so hipGraph replays order it like every other launch)
 __global__ __launch_bounds__(256) void zero_f32_kernel(float* __restrict__ p, int64_t n) {
   const int64_t n4 = n >> 2;
@@ -323,6 +413,13 @@ void launch_roi_pool_bwd(const void* dout, const float* rois, const int* argmax,
   else hipLaunchKernelGGL((roi_pool_bwd_kernel<bf16_t>), dim3(ew_grid(n)), dim3(256), 0, st, (const bf16_t*)dout, rois, argmax, dx_f32, R, N, H, W, C, PH, PW);
 }
 
+void launch_roi_pool_bwd_tile(const void* dout, const float* rois, const int* argmax, void* dx, int R, int N, int H, int W, int C,
+                              int PH, int PW, float scale, int dtype, hipStream_t st) {
+  const int tilesH = (int)cdiv(H, RPB_T), tilesW = (int)cdiv(W, RPB_T);
+  dim3 grid((unsigned)(tilesH * tilesW), (unsigned)N, (unsigned)(C / RPT_CC));
+  if (dtype == 0) hipLaunchKernelGGL((roi_pool_bwd_tile_kernel<float>), grid, dim3(256), 0, st, (const float*)dout, rois, argmax, (float*)dx, R, H, W, C, PH, PW, scale, tilesW);
+  else hipLaunchKernelGGL((roi_pool_bwd_tile_kernel<bf16_t>), grid, dim3(256), 0, st, (const bf16_t*)dout, rois, argmax, (bf16_t*)dx, R, H, W, C, PH, PW, scale, tilesW);
+}
 void launch_roi_pool_bwd_gather(const void* dout, const float* rois, const int* argmax, void* dx, int R, int N, int H, int W, int C,
                                 int PH, int PW, float scale, int dtype, hipStream_t st) {
   const int tilesH = (int)cdiv(H, RPB_T), tilesW = (int)cdiv(W, RPB_T);

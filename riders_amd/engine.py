@@ -383,6 +383,7 @@ def as_nchw(x):
 
 # packed-weight cache: (id(param), version, mode, dtype) -> tensor
 _pack_cache = {}
+_ROI_TILE = os.environ.get("RIDERS_ROI_TILE", "1") != "0"           # A/B switch: LDS-tile RoI-pool backward vs global atomics
 _BN_RECOMPUTE = os.environ.get("RIDERS_BN_RECOMPUTE", "1") != "0"   # A/B switch for the BatchNorm backward that does not read z
 
 
@@ -694,6 +695,12 @@ def roi_pool(x, rois, output_size, spatial_scale):
                 dx = torch.empty_like(x)
                 _chk(lib.rd_roi_pool_bwd_gather(_p(g), _p(rois), _p(arg), _p(dx), R, N, H, W, C, PH, PW, float(spatial_scale), dt, st),
                      "rd_roi_pool_bwd_gather")
+                t.add_grad(x, dx)
+                return
+            if C % 32 == 0 and H * W < (1 << 24) and _ROI_TILE:   # LDS tile accumulators, no global atomics
+                dx = torch.empty_like(x)
+                _chk(lib.rd_roi_pool_bwd_tile(_p(g), _p(rois), _p(arg), _p(dx), R, N, H, W, C, PH, PW, float(spatial_scale), dt, st),
+                     "rd_roi_pool_bwd_tile")
                 t.add_grad(x, dx)
                 return
             dx32 = torch.empty((N, H, W, C), dtype=torch.float32, device=x.device)

@@ -251,11 +251,12 @@ def roi_pool_stress_case(dev, R=300, C=64, H=20, W=24):
     """gather backward with more RoIs than one listing pass (256), more than one LDS list chunk (64) meeting a tile, several item
     passes per thread (C = 64 fp32 -> 16 channel groups), bins smaller and larger than a pixel, boxes leaving the map."""
     from riders_amd import engine
-    engine.set_deterministic_roi_pool(True)
+    engine.set_deterministic_roi_pool(True)      # gather kernel
     try:
         _roi_pool_stress(dev, R, C, H, W)
     finally:
         engine.set_deterministic_roi_pool(False)
+    _roi_pool_stress(dev, R, C, H, W)            # default: LDS tile-accumulate kernel (C % 32 == 0)
 
 
 def _roi_pool_stress(dev, R, C, H, W):
