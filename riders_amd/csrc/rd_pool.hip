@@ -343,13 +343,20 @@ __global__ __launch_bounds__(256) void roi_pool_bwd_tile_kernel(const T* __restr
           }
           float dv[VE];
           ldv(dout + o, dv);
+          // bins are about one pixel: the VE channels usually share their arg-max, decode a pixel index only when it changes
+          int pa = -2, pslot = -1;
 #pragma unroll
           for (int e = 0; e < VE; e++) {
             const int a = am[e];
-            if (a < 0) continue;
-            const int ah = (int)(((float)a + 0.5f) * invW);   // exact: a < 2^24 and (a + 0.5) / W is >= 0.5 / W away from an integer
-            const int lh = ah - h0, lw = a - ah * W - w0;
-            if ((unsigned)lh < (unsigned)RPB_T && (unsigned)lw < (unsigned)RPB_T) atomicAdd(&tacc[(lh * RPB_T + lw) * RPT_CC + g * VE + e], dv[e]);
+            if (a != pa) {
+              pa = a; pslot = -1;
+              if (a >= 0) {
+                const int ah = (int)(((float)a + 0.5f) * invW);   // exact: a < 2^24 and (a + 0.5) / W is >= 0.5 / W away from an integer
+                const int lh = ah - h0, lw = a - ah * W - w0;
+                if ((unsigned)lh < (unsigned)RPB_T && (unsigned)lw < (unsigned)RPB_T) pslot = (lh * RPB_T + lw) * RPT_CC + g * VE;
+              }
+            }
+            if (pslot >= 0) atomicAdd(&tacc[pslot + e], dv[e]);
           }
         }
       }

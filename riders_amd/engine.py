@@ -22,7 +22,13 @@ from ._lib import ACT_LRELU, ACT_NONE, ACT_RELU, ACT_RELU6, RD_BF16, RD_F32, Con
 _TORCH_DT = {RD_F32: torch.float32, RD_BF16: torch.bfloat16}
 _RD_DT = {torch.float32: RD_F32, torch.bfloat16: RD_BF16}
 
-_state = {"dtype": RD_F32, "tape": None, "defer_wgrad": True, "fused_loftr": True, "deterministic_roi_pool": False}
+_state = {"dtype": RD_F32, "tape": None, "defer_wgrad": True, "fused_loftr": True, "deterministic_roi_pool": False, "roi_tile_min_blocks": 256}
+
+
+def set_roi_tile_min_blocks(n):
+    """Smallest launch (in workgroups) for which the RoI-pool backward uses the LDS-tile kernel; smaller maps use global atomics."""
+    _state["roi_tile_min_blocks"] = int(n)
+
 
 
 def set_deterministic_roi_pool(flag):
@@ -697,7 +703,8 @@ def roi_pool(x, rois, output_size, spatial_scale):
                      "rd_roi_pool_bwd_gather")
                 t.add_grad(x, dx)
                 return
-            if C % 32 == 0 and H * W < (1 << 24) and _ROI_TILE:   # LDS tile accumulators, no global atomics
+            nblk = ((H + 15) // 16) * ((W + 15) // 16) * N * (C // 32)
+            if C % 32 == 0 and H * W < (1 << 24) and _ROI_TILE and nblk >= _state["roi_tile_min_blocks"]:   # LDS tile accumulators (small maps: too few tiles)
                 dx = torch.empty_like(x)
                 _chk(lib.rd_roi_pool_bwd_tile(_p(g), _p(rois), _p(arg), _p(dx), R, N, H, W, C, PH, PW, float(spatial_scale), dt, st),
                      "rd_roi_pool_bwd_tile")

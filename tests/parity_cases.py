@@ -256,7 +256,12 @@ def roi_pool_stress_case(dev, R=300, C=64, H=20, W=24):
         _roi_pool_stress(dev, R, C, H, W)
     finally:
         engine.set_deterministic_roi_pool(False)
-    _roi_pool_stress(dev, R, C, H, W)            # default: LDS tile-accumulate kernel (C % 32 == 0)
+    engine.set_roi_tile_min_blocks(0)            # LDS tile-accumulate kernel (C % 32 == 0) regardless of the map size
+    try:
+        _roi_pool_stress(dev, R, C, H, W)
+    finally:
+        engine.set_roi_tile_min_blocks(256)
+    _roi_pool_stress(dev, R, C, H, W)            # small map: global-atomic scatter
 
 
 def _roi_pool_stress(dev, R, C, H, W):
