@@ -81,18 +81,26 @@ __global__ __launch_bounds__(256) void conv3x3_patch_kernel(ConvArgs a, int tile
     }
   };
 
-  // this lane's two output pixels (one per MFMA pixel tile) inside the tile, as patch coordinates of tap (0,0)
-  int ppix[2];
+  // wave tiling: 4 waves x (32 pixels x BN channels), or for BN = 128 a square 2 x 2 arrangement of (64 pixels x 64 channels) per wave:
+  // 4 + 4 instead of 2 + 8 fragment reads per 16 MFMAs (the kernel is LDS-read bound: measured ~10 ds_read_b128 per MFMA pair)
+  constexpr bool SQ = (BN == 128);
+  constexpr int NPT = SQ ? 4 : 2, CTW = SQ ? CT / 2 : CT;
+  const int wpx = SQ ? (wv & 1) : wv, wc = SQ ? (wv >> 1) : 0;
+  // this lane's output pixels (one per MFMA pixel tile) inside the tile, as patch coordinates of tap (0,0)
+  int ppix[NPT];
 #pragma unroll
-  for (int pt = 0; pt < 2; pt++) {
-    int py = W8 ? (wv * 4 + pt * 2 + (fr >> 3)) : (wv * 2 + pt);
+  for (int pt = 0; pt < NPT; pt++) {
+    const int ptile = SQ ? wpx * 4 + pt : wv * 2 + pt;
+    int py = W8 ? (ptile * 2 + (fr >> 3)) : ptile;
     int px = W8 ? (fr & 7) : fr;
     ppix[pt] = py * WT + px;
   }
 
-  f32x4 acc[CT][2];
+  f32x4 acc[CTW][NPT];
 #pragma unroll
-  for (int c = 0; c < CT; c++) { acc[c][0] = f32x4{0, 0, 0, 0}; acc[c][1] = f32x4{0, 0, 0, 0}; }
+  for (int c = 0; c < CTW; c++)
+#pragma unroll
+    for (int pt = 0; pt < NPT; pt++) acc[c][pt] = f32x4{0, 0, 0, 0};
 
   load_patch(0);
   load_w(0, 0);
@@ -111,14 +119,14 @@ __global__ __launch_bounds__(256) void conv3x3_patch_kernel(ConvArgs a, int tile
       const int toff = kh * WT + kw;
 #pragma unroll
       for (int ch = 0; ch < 2; ch++) {
-        uint4 pf[2];
+        uint4 pf[NPT];
 #pragma unroll
-        for (int pt = 0; pt < 2; pt++) pf[pt] = sP[lds_slot(ppix[pt] + toff, ch * 4 + fg)];
+        for (int pt = 0; pt < NPT; pt++) pf[pt] = sP[lds_slot(ppix[pt] + toff, ch * 4 + fg)];
 #pragma unroll
-        for (int c = 0; c < CT; c++) {
-          uint4 wf = sB[wbuf][lds_slot(c * 16 + fr, ch * 4 + fg)];
+        for (int c = 0; c < CTW; c++) {
+          uint4 wf = sB[wbuf][lds_slot((wc * CTW + c) * 16 + fr, ch * 4 + fg)];
 #pragma unroll
-          for (int pt = 0; pt < 2; pt++) {
+          for (int pt = 0; pt < NPT; pt++) {
             if (sizeof(T) == 4) {
               acc[c][pt] = mfma_16x16x4_f32(__uint_as_float(wf.x), __uint_as_float(pf[pt].x), acc[c][pt]);
               acc[c][pt] = mfma_16x16x4_f32(__uint_as_float(wf.y), __uint_as_float(pf[pt].y), acc[c][pt]);
@@ -142,17 +150,30 @@ __global__ __launch_bounds__(256) void conv3x3_patch_kernel(ConvArgs a, int tile
     wbuf ^= 1;
   }
 
-  int64_t mm[2]; bool mvv[2];
-#pragma unroll
-  for (int pt = 0; pt < 2; pt++) {
-    int py = W8 ? (wv * 4 + pt * 2 + (fr >> 3)) : (wv * 2 + pt);
-    int px = W8 ? (fr & 7) : fr;
-    int oh = oh0 + py, ow = ow0 + px;
-    mvv[pt] = oh < a.OH && ow < a.OW;
-    mm[pt] = ((int64_t)n * a.OH + oh) * a.OW + ow;
-  }
   __syncthreads();  // all waves finished reading the patch before it is reused as reduction scratch
-  conv_epilogue<T, CT, BN, 4>(a, acc, mm, mvv, n0, 0, wv, fr, fg, t, bx, reinterpret_cast<float*>(&sP[0]));
+  float ssum[CTW][4], ssq[CTW][4];
+#pragma unroll
+  for (int c = 0; c < CTW; c++)
+#pragma unroll
+    for (int r = 0; r < 4; r++) { ssum[c][r] = 0.f; ssq[c][r] = 0.f; }
+#pragma unroll
+  for (int pp = 0; pp < NPT / 2; pp++) {   // the store routine takes two pixel tiles at a time
+    int64_t mm[2]; bool mvv[2]; f32x4 a2[CTW][2];
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      const int pt = pp * 2 + h;
+      const int ptile = SQ ? wpx * 4 + pt : wv * 2 + pt;
+      int py = W8 ? (ptile * 2 + (fr >> 3)) : ptile;
+      int px = W8 ? (fr & 7) : fr;
+      int oh = oh0 + py, ow = ow0 + px;
+      mvv[h] = oh < a.OH && ow < a.OW;
+      mm[h] = ((int64_t)n * a.OH + oh) * a.OW + ow;
+#pragma unroll
+      for (int c = 0; c < CTW; c++) a2[c][h] = acc[c][pt];
+    }
+    conv_epilogue_store<T, CTW>(a, a2, mm, mvv, n0, wc, fr, fg, ssum, ssq);
+  }
+  conv_epilogue_stats<CTW, BN, SQ ? 2 : 4>(a, ssum, ssq, n0, wc, wpx, fr, fg, t, bx, reinterpret_cast<float*>(&sP[0]));
 }
 
 // ---- narrow layers (Cin * sizeof(T) = 32 / 64 / 128 bytes, Cout <= 32): persistent blocks, weights in registers ---------------------

@@ -54,12 +54,17 @@ __global__ __launch_bounds__(256) void bce_fwd_kernel(const T* __restrict__ logi
   }
 }
 
+// one wave: lanes stride over the partial rows, double-precision xor tree (fixed order -> deterministic)
 __global__ void bce_finalize_kernel(const float* __restrict__ partial, int rows, float* loss, float* sums) {
-  if (threadIdx.x || blockIdx.x) return;
+  const int lane = threadIdx.x;
   double a = 0.0, b = 0.0;
-  for (int r = 0; r < rows; r++) { a += partial[r * 2]; b += partial[r * 2 + 1]; }
-  sums[0] = (float)a; sums[1] = (float)b;
-  loss[0] = (float)(a / b);
+  for (int r = lane; r < rows; r += 64) { a += partial[r * 2]; b += partial[r * 2 + 1]; }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
+  if (lane == 0) {
+    sums[0] = (float)a; sums[1] = (float)b;
+    loss[0] = (float)(a / b);
+  }
 }
 
 template <typename T>

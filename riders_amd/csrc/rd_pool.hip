@@ -62,6 +62,39 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ 
   }
 }
 
+// 16-byte-vector form (C % VE == 0)
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_bwd_vec_kernel(const T* __restrict__ dout, const unsigned char* __restrict__ arg,
+                                                              T* __restrict__ dx, int N, int H, int W, int C, int OH, int OW,
+                                                              int k, int s, int p) {
+  constexpr int VE = Elem<T>::VE;
+  const int G = C / VE;
+  const int64_t total = (int64_t)N * H * W * G;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    int g = (int)(i % G); int64_t q = i / G;
+    int w = (int)(q % W); q /= W; int h = (int)(q % H); int n = (int)(q / H);
+    float acc[VE];
+#pragma unroll
+    for (int e = 0; e < VE; e++) acc[e] = 0.f;
+    int oh_lo = (h + p - k + 1 + s - 1); oh_lo = oh_lo < 0 ? 0 : oh_lo / s;
+    int oh_hi = (h + p) / s; if (oh_hi > OH - 1) oh_hi = OH - 1;
+    int ow_lo = (w + p - k + 1 + s - 1); ow_lo = ow_lo < 0 ? 0 : ow_lo / s;
+    int ow_hi = (w + p) / s; if (ow_hi > OW - 1) ow_hi = OW - 1;
+    for (int oh = oh_lo; oh <= oh_hi; oh++)
+      for (int ow = ow_lo; ow <= ow_hi; ow++) {
+        const int64_t o = (((int64_t)n * OH + oh) * OW + ow) * C + g * VE;
+        // the window tap that maps this output back to (h, w); an output contributes where its saved arg-max equals it
+        const int want = (h - (oh * s - p)) * k + (w - (ow * s - p));
+        float dv[VE];
+        ldv(dout + o, dv);
+        const unsigned char* ap = arg + o;
+#pragma unroll
+        for (int e = 0; e < VE; e++) if ((int)ap[e] == want) acc[e] += dv[e];
+      }
+    stv(dx + i * VE, acc);
+  }
+}
+
 // rois: [R][5] = (batch index, x1, y1, x2, y2) in input-image pixels
 template <typename T>
 __global__ __launch_bounds__(256) void roi_pool_fwd_kernel(const T* __restrict__ x, const float* __restrict__ rois,
@@ -393,6 +426,13 @@ void launch_maxpool_fwd(const void* x, void* out, unsigned char* arg, int N, int
 void launch_maxpool_bwd(const void* dout, const unsigned char* arg, void* dx, int N, int H, int W, int C, int OH, int OW, int k,
                         int s, int p, int dtype, hipStream_t st) {
   int64_t n = (int64_t)N * H * W * C;
+  const int ve = dtype == 0 ? 4 : 8;
+  if (C % ve == 0) {
+    unsigned gv = ew_grid(n / ve);
+    if (dtype == 0) hipLaunchKernelGGL((maxpool_bwd_vec_kernel<float>), dim3(gv), dim3(256), 0, st, (const float*)dout, arg, (float*)dx, N, H, W, C, OH, OW, k, s, p);
+    else hipLaunchKernelGGL((maxpool_bwd_vec_kernel<bf16_t>), dim3(gv), dim3(256), 0, st, (const bf16_t*)dout, arg, (bf16_t*)dx, N, H, W, C, OH, OW, k, s, p);
+    return;
+  }
   if (dtype == 0) hipLaunchKernelGGL((maxpool_bwd_kernel<float>), dim3(ew_grid(n)), dim3(256), 0, st, (const float*)dout, arg, (float*)dx, N, H, W, C, OH, OW, k, s, p);
   else hipLaunchKernelGGL((maxpool_bwd_kernel<bf16_t>), dim3(ew_grid(n)), dim3(256), 0, st, (const bf16_t*)dout, arg, (bf16_t*)dx, N, H, W, C, OH, OW, k, s, p);
 }
