@@ -796,7 +796,7 @@ void launch_pack_weights(const float* w, void* out, int Cout, int Cin, int KH, i
 
 void launch_pack_weights_batch(const void* items, int n, hipStream_t st) {
   static_assert(sizeof(PackItem) == 48, "PackItem mirrors rd_pack_item");
-  hipLaunchKernelGGL(pack_weights_batch_kernel, dim3(64, (unsigned)n), dim3(256), 0, st, (const PackItem*)items);
+  hipLaunchKernelGGL(pack_weights_batch_kernel, dim3(256, (unsigned)n), dim3(256), 0, st, (const PackItem*)items);  // small items: most blocks exit at once
 }
 
 // split the pixel reduction so the launch has a few blocks per CU, stage-aligned

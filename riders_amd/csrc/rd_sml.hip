@@ -253,9 +253,17 @@ __global__ __launch_bounds__(256) void sml_loss_fwd_kernel(const float* __restri
 // info = [loss, supervised, lidar, smoothness, edge, n_interp, n_lidar]
 __global__ void sml_loss_finalize_kernel(const double* __restrict__ partial, int rows, double npix, int fs, float w_lidar, float w_smooth,
                                          float w_edge, float* __restrict__ info) {
-  if (threadIdx.x || blockIdx.x) return;
+  // one wave: lanes stride over the rows, double-precision xor tree (fixed order)
+  const int lane = threadIdx.x;
   double a[8];
-  for (int j = 0; j < 8; j++) { a[j] = 0.0; for (int r = 0; r < rows; r++) a[j] += partial[(int64_t)r * 8 + j]; }
+  for (int j = 0; j < 8; j++) {
+    double v = 0.0;
+    for (int r = lane; r < rows; r += 64) v += partial[(int64_t)r * 8 + j];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    a[j] = v;
+  }
+  if (lane) return;
   double sup = a[0] / a[1], lid = w_lidar > 0.f ? a[2] / a[3] : 0.0;
   double sm = (a[4] / npix + a[5] / npix) / (double)(fs * fs), ed = (a[6] / npix + a[7] / npix) / (double)(fs * fs);
   if (!(w_smooth > 0.f || w_edge > 0.f)) { sm = 0.0; ed = 0.0; }

@@ -218,8 +218,12 @@ class Tape:
         total = 0
         for it in items:
             M = it["M"]
-            if M > 40960:       # at most 64 token splits per item: every split writes (and the reduction re-reads) a Cout x Cin slab
-                rps = ((M + 63) // 64 + 63) & ~63
+            if M > 40960:
+                # enough (tile, split) blocks to fill the GPU, bounded by the slab traffic: every split writes (and the reduction
+                # re-reads) a Cout x Cin slab -- at most 512 splits and 32 MB of slabs per item
+                tiles = ((it["Cin"] + 63) // 64) * ((it["Cout"] + 63) // 64)
+                want = max(64, min(512, (1024 + tiles - 1) // tiles, (32 << 20) // (4 * it["Cin"] * it["Cout"])))
+                rps = max(128, ((M + want - 1) // want + 63) & ~63)
             else:
                 rps = 640 if M >= 2560 else max(64, (M + 3) // 4 + 63 & ~63)
             it["rps"] = rps
