@@ -27,7 +27,9 @@ namespace rd {
 
 // WM = waves along the pixel axis (block tile = 32*WM pixels x BN channels; the other 4/WM wave factor splits the channels).
 // WM = 2 halves the tile for small-M launches (LoFTR projections, deep encoder stages) so they spread over more CUs.
-template <typename T, int BN, bool VEC, int WM>
+// DEEP = two register sets, global loads issued two stages ahead: small-M launches with a long K axis (SML's 1x1 convolutions on
+// 1.7-7 K pixels with up to 1392 channels) are a chain of stages each waiting one L2 round trip (~1.3 us per stage measured).
+template <typename T, int BN, bool VEC, int WM, bool DEEP = false>
 __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs a) {
   constexpr int VE = Elem<T>::VE;
   constexpr int BKE = STAGE_BYTES / (int)sizeof(T);  // K elements per stage
@@ -70,8 +72,9 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs a) {
   }
 
   uint4 ra[WM]; uint4 rb[BITER];
+  uint4 ra2[DEEP ? WM : 1]; uint4 rb2[DEEP ? BITER : 1];
 
-  auto load_tile = [&](int kt) RD_INLINE_LAMBDA {
+  auto load_tile = [&](int kt, uint4 (&ra)[WM], uint4 (&rb)[BITER]) RD_INLINE_LAMBDA {
 #pragma unroll
     for (int i = 0; i < WM; i++) {
       uint4 v = make_uint4(0, 0, 0, 0);
@@ -114,7 +117,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs a) {
       while (kci >= Cin) { kci -= Cin; if (++kkw == a.KW) { kkw = 0; ++kkh; } }
     }
   };
-  auto store_tile = [&](int buf) RD_INLINE_LAMBDA {
+  auto store_tile = [&](int buf, const uint4 (&ra)[WM], const uint4 (&rb)[BITER]) RD_INLINE_LAMBDA {
 #pragma unroll
     for (int i = 0; i < WM; i++) sA[buf][lds_slot(r0 + 32 * i, s)] = ra[i];
 #pragma unroll
@@ -129,13 +132,8 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs a) {
   for (int c = 0; c < CT; c++) { acc[c][0] = f32x4{0, 0, 0, 0}; acc[c][1] = f32x4{0, 0, 0, 0}; }
 
   const int nk = a.Kpad / BKE;
-  load_tile(0);
-  store_tile(0);
-  __syncthreads();
   const int fr = lane & 15, fg = lane >> 4;
-  for (int kt = 0; kt < nk; kt++) {
-    const int buf = kt & 1;
-    if (kt + 1 < nk) load_tile(kt + 1);
+  auto compute = [&](int buf) RD_INLINE_LAMBDA {
 #pragma unroll
     for (int ch = 0; ch < 2; ch++) {  // two 64-byte chunks per stage
       uint4 pf[2];
@@ -160,8 +158,36 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs a) {
         }
       }
     }
-    if (kt + 1 < nk) store_tile(buf ^ 1);
+  };
+  if (!DEEP) {
+    load_tile(0, ra, rb);
+    store_tile(0, ra, rb);
     __syncthreads();
+    for (int kt = 0; kt < nk; kt++) {
+      const int buf = kt & 1;
+      if (kt + 1 < nk) load_tile(kt + 1, ra, rb);
+      compute(buf);
+      if (kt + 1 < nk) store_tile(buf ^ 1, ra, rb);
+      __syncthreads();
+    }
+  } else {
+    auto& xa = reinterpret_cast<uint4 (&)[WM]>(ra2); auto& xb = reinterpret_cast<uint4 (&)[BITER]>(rb2);
+    load_tile(0, ra, rb);
+    store_tile(0, ra, rb);
+    if (nk > 1) load_tile(1, ra, rb);      // set A: stage 1
+    if (nk > 2) load_tile(2, xa, xb);      // set B: stage 2
+    __syncthreads();
+    for (int kt = 0; kt < nk; kt += 2) {   // stage kt sits in LDS buffer 0
+      compute(0);
+      if (kt + 1 < nk) store_tile(1, ra, rb);
+      __syncthreads();
+      if (kt + 3 < nk) load_tile(kt + 3, ra, rb);
+      if (kt + 1 >= nk) break;
+      compute(1);
+      if (kt + 2 < nk) store_tile(0, xa, xb);
+      __syncthreads();
+      if (kt + 4 < nk) load_tile(kt + 4, xa, xb);
+    }
   }
 
   // ---- epilogue (shared): bias, activation, NHWC store (dual destination), BN statistics ----------------
@@ -745,11 +771,16 @@ static void launch_conv_t(const ConvArgs& a, hipStream_t st) {
   int bn, wm;
   conv_tiles(a.M, a.Cout, bn, wm);
   dim3 grid((unsigned)cdiv(a.M, 32 * wm), (unsigned)cdiv(a.Cout, bn));
+  // few blocks and a long K axis: latency-bound stage chain -> two-stage-ahead loads
+  const bool deep = vec && wm == 2 && (int64_t)grid.x * grid.y <= 512 && a.Kpad / (STAGE_BYTES / (int)sizeof(T)) >= 6;
 #define RD_CONV_CASE(BNV, WMV)                                                                                  \
   if (bn == BNV && wm == WMV) {                                                                                  \
-    if (vec) hipLaunchKernelGGL((conv_gemm_kernel<T, BNV, true, WMV>), grid, dim3(256), 0, st, a);              \
+    if (vec) hipLaunchKernelGGL((conv_gemm_kernel<T, BNV, true, WMV>), grid, dim3(256), 0, st, a);         \
     else hipLaunchKernelGGL((conv_gemm_kernel<T, BNV, false, WMV>), grid, dim3(256), 0, st, a);                 \
   }
+#define RD_CONV_DEEP(BNV) if (bn == BNV) { hipLaunchKernelGGL((conv_gemm_kernel<T, BNV, true, 2, true>), grid, dim3(256), 0, st, a); return; }
+  if (deep) { RD_CONV_DEEP(32) RD_CONV_DEEP(64) RD_CONV_DEEP(128) }
+#undef RD_CONV_DEEP
   RD_CONV_CASE(16, 4) RD_CONV_CASE(32, 4) RD_CONV_CASE(64, 4) RD_CONV_CASE(128, 4)
   RD_CONV_CASE(32, 2) RD_CONV_CASE(64, 2) RD_CONV_CASE(128, 2)
 #undef RD_CONV_CASE
