@@ -799,7 +799,7 @@ static bool use_conv3x3_small(const ConvArgs& a, int dtype) {
   return conv3x3_small_ok(a, dtype) && conv3x3_tiles(a) >= conv3x3_min_blocks();
 }
 int conv_stats_rows(const ConvArgs& a, int dtype) {
-  if (use_conv3x3_small(a, dtype)) return conv3x3_small_blocks(a);   // persistent blocks: one statistics row each
+  if (use_conv3x3_small(a, dtype)) return conv3x3_small_blocks(a, dtype);   // persistent blocks: one statistics row each
   if (use_conv3x3(a, dtype)) return conv3x3_tiles(a);
   return (int)cdiv(a.M, conv_block_pixels(a.M, a.Cout));
 }

@@ -438,11 +438,14 @@ bool conv3x3_small_ok(const ConvArgs& a, int dtype) {
   if (!geom3x3(a) || (cb != 32 && cb != 64 && cb != 128) || (a.C1 % ve) != 0) return false;
   return cb == 128 ? a.Cout <= 16 : a.Cout <= 64;
 }
-int conv3x3_small_blocks(const ConvArgs& a) {   // persistent blocks = BatchNorm statistics rows of this path
+int conv3x3_small_blocks(const ConvArgs& a, int dtype) {   // persistent blocks = BatchNorm statistics rows of this path
   const bool w8 = use_w8(a);
   const int64_t ntiles = (int64_t)a.N * cdiv(a.OH, w8 ? 16 : 8) * cdiv(a.OW, w8 ? 8 : 16);
   const char* e = getenv("RD_CONV3X3_G8");  // test hook: few persistent blocks -> several tiles per block on small cases
-  return 8 * (int)std::min<int64_t>(cdiv(ntiles, 8), e ? atoi(e) : 128);  // 8 XCDs x up to 128 persistent blocks (4 per CU)
+  // persistent grid = resident capacity: 8 XCDs x 32 CUs x (4 or 2 blocks per CU, see small_min_waves)
+  const int cb_slots = ((a.C1 + a.C2) * (dtype == 0 ? 4 : 2)) / 16;
+  const int per_cu = small_min_waves(cb_slots, pick_bn3(a.Cout));
+  return 8 * (int)std::min<int64_t>(cdiv(ntiles, 8), e ? atoi(e) : 32 * per_cu);
 }
 template <typename T>
 static void launch_small_t(const ConvArgs& a, hipStream_t st) {
@@ -450,7 +453,7 @@ static void launch_small_t(const ConvArgs& a, hipStream_t st) {
   const int tilesH = (int)cdiv(a.OH, w8 ? 16 : 8), tilesW = (int)cdiv(a.OW, w8 ? 8 : 16);
   const int ntiles = a.N * tilesH * tilesW;
   const int spp = (a.C1 + a.C2) * (int)sizeof(T) / 16, bn = pick_bn3(a.Cout);
-  dim3 grid((unsigned)conv3x3_small_blocks(a));
+  dim3 grid((unsigned)conv3x3_small_blocks(a, (int)sizeof(T) == 4 ? 0 : 1));
 #define RD_S3(SPPV, BNV)                                                                                                  \
   if (spp == SPPV && bn == BNV) {                                                                                         \
     if (w8) hipLaunchKernelGGL((conv3x3_small_kernel<T, SPPV, BNV, true>), grid, dim3(256), 0, st, a, tilesH, tilesW);    \

@@ -240,7 +240,13 @@ int wgrad3x3_tr_blocks(const WgradArgs& a) {   // persistent blocks per slice = 
   const int tw = tr_tw(a);
   const int64_t ntiles = (int64_t)a.N * cdiv(a.OH, 8) * cdiv(a.OW, tw);
   const char* e = getenv("RD_CONV3X3_G8");  // test hook shared with the forward kernel
-  int cap = e ? atoi(e) : std::max(1, 128 / (nci * nco));
+  // persistent grid = resident capacity: 4 blocks per CU for the light variants, 2 where registers (launch bounds) or LDS allow only two
+  // (measured: 512 instead of 1024 blocks is 8-13 % faster on the 64-channel slices and halves the slab traffic)
+  const int Cin = a.C1 + a.C2;
+  const int lds = 2 * 16 * ((8 + 2) * (tw + 2) * (cti * 16 / 8) + 8 * tw * (rt * 16 / 8));
+  const int per_cu = (cti * rt <= 2 && lds * 4 <= 160 * 1024) ? 4 : 2;
+  (void)Cin;
+  int cap = e ? atoi(e) : std::max(1, 32 * per_cu / (nci * nco));
   // every block writes (and the reduction re-reads) a Cout x K slab slice: wide layers with few tiles keep >= 4 tiles per block
   if (!e && nci * nco > 1) cap = (int)std::max<int64_t>(1, std::min<int64_t>(cap, ntiles / 32));
   return 8 * (int)std::min<int64_t>(cdiv(ntiles, 8), cap);
