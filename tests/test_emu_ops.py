@@ -30,6 +30,9 @@ def test_patch_conv_decoder_and_bf16(emu):
         P.bf16_exact_conv_case(emu, cin=32, cout=64, k=3, s=1, H=12, W=17, N=1)     # 64 output channels: weights in LDS
         P.bf16_exact_conv_case(emu, cin=16, cout=48, k=3, s=1, H=9, W=10, N=2)
     with P.force_patch_conv(g8=1):   # 8 persistent blocks: tile loop, LDS double buffer, register prefetch
+        # patch-staged kernel, several tiles per persistent block: cross-tile patch / weight prefetch, per-tile statistics rows
+        P.conv_case(emu, dict(cin=32, cout=32, k=3, s=1, H=20, W=40, N=3, bn=True))
+        P.bf16_exact_conv_case(emu, cin=128, cout=160, k=3, s=1, H=17, W=33, N=2)
         P.bf16_exact_conv_case(emu, cin=32, cout=16, k=3, s=1, H=33, W=25, N=3)
         P.conv_case(emu, dict(cin=16, cout=16, k=3, s=1, H=30, W=20, N=3, bn=True))
 
