@@ -66,6 +66,19 @@ CONV_CASES = [
 ]
 
 
+class force_direct_1x1:
+    """Route every eligible 1x1 layer to the direct pointwise kernel regardless of its pixel count."""
+    def __enter__(self):
+        self.old = os.environ.get("RD_CONV1X1_MIN_M")
+        os.environ["RD_CONV1X1_MIN_M"] = "0"
+
+    def __exit__(self, *a):
+        if self.old is None:
+            del os.environ["RD_CONV1X1_MIN_M"]
+        else:
+            os.environ["RD_CONV1X1_MIN_M"] = self.old
+
+
 class force_patch_conv:
     """Route every eligible 3x3/stride-1 layer to the patch-staged kernel (rd_conv3x3.hip) regardless of its block count."""
     def __init__(self, g8=None):

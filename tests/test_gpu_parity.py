@@ -222,3 +222,14 @@ def test_stem_padded_channels(gpu):
 
 def test_roi_pool_gather_backward(gpu):
     P.roi_pool_stress_case(gpu)
+
+
+def test_direct_pointwise_conv(gpu):
+    """1x1 layers with a short K axis through conv1x1_direct_kernel (pixel fragments straight from memory, weights in registers)."""
+    with P.force_direct_1x1():
+        P.conv_case(gpu, dict(cin=24, cout=144, k=1, s=1, H=13, W=11, N=2, bn=True))             # fp32: two k-steps, two channel blocks
+        P.conv_case(gpu, dict(cin=16, cout=40, k=1, s=1, H=9, W=15, N=1, bn=False, act=None))    # fp32: one k-step
+        P.bf16_exact_conv_case(gpu, cin=24, cout=144, k=1, s=1, H=13, W=11, N=2)                  # bf16: one k-step
+        P.bf16_exact_conv_case(gpu, cin=48, cout=288, k=1, s=1, H=7, W=19, N=1)                   # bf16: two k-steps, three channel blocks
+        P.bf16_exact_conv_case(gpu, cin=64, cout=8, k=1, s=1, H=10, W=13, N=1)
+    P.bf16_exact_conv_case(gpu, cin=32, cout=192, k=1, s=1, H=144, W=192, N=2)   # routed by pixel count (55 K pixels)
