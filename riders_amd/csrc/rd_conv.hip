@@ -735,9 +735,61 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
   }
 }
 
+// float4 version (Cout*K a multiple of 4): thread = (float4 column ol, slab lane sl); each slab lane sums every SL-th slab with
+// 16-byte loads (a quarter of the load instructions of the scalar kernel, whose per-thread loop was the whole latency of this launch),
+// then a fixed-order LDS tree over the slab lanes.  Deterministic.
+__global__ __launch_bounds__(256) void wgrad_reduce_vec_kernel(const float* __restrict__ slab, float* __restrict__ dw, int Cout, int Cin,
+                                                                int KH, int KW, int nsplit, int accumulate, int SL) {
+  __shared__ float4 red[256];
+  const int K = KH * KW * Cin;
+  const int64_t total = (int64_t)Cout * K, total4 = total >> 2;
+  const int OB = 256 / SL;
+  const int t = threadIdx.x, ol = t % OB, sl = t / OB;
+  const float4* s4 = reinterpret_cast<const float4*>(slab);
+  for (int64_t base = (int64_t)blockIdx.x * OB; base < total4; base += (int64_t)gridDim.x * OB) {
+    const int64_t i4 = base + ol;
+    float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (i4 < total4) {
+      int sp = sl;
+      for (; sp + 3 * SL < nsplit; sp += 4 * SL) {   // four independent loads in flight
+        const float4 v0 = s4[(int64_t)sp * total4 + i4], v1 = s4[(int64_t)(sp + SL) * total4 + i4];
+        const float4 v2 = s4[(int64_t)(sp + 2 * SL) * total4 + i4], v3 = s4[(int64_t)(sp + 3 * SL) * total4 + i4];
+        s.x += (v0.x + v1.x) + (v2.x + v3.x); s.y += (v0.y + v1.y) + (v2.y + v3.y);
+        s.z += (v0.z + v1.z) + (v2.z + v3.z); s.w += (v0.w + v1.w) + (v2.w + v3.w);
+      }
+      for (; sp < nsplit; sp += SL) { const float4 v = s4[(int64_t)sp * total4 + i4]; s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; }
+    }
+    red[t] = s;
+    __syncthreads();
+    for (int h = SL >> 1; h > 0; h >>= 1) {
+      if (sl < h) { const float4 o = red[t + h * OB]; float4 m = red[t]; m.x += o.x; m.y += o.y; m.z += o.z; m.w += o.w; red[t] = m; }
+      __syncthreads();
+    }
+    if (sl == 0 && i4 < total4) {
+      const float4 m = red[t];
+      const float acc[4] = {m.x, m.y, m.z, m.w};
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        const int64_t i = i4 * 4 + e;
+        int co = (int)(i / K), k = (int)(i - (int64_t)co * K);
+        int tap = k / Cin, ci = k - tap * Cin, kh = tap / KW, kw = tap - kh * KW;
+        int64_t o = (((int64_t)co * Cin + ci) * KH + kh) * KW + kw;
+        dw[o] = accumulate ? dw[o] + acc[e] : acc[e];
+      }
+    }
+    __syncthreads();
+  }
+}
+
 static void launch_wgrad_reduce(const float* slab, float* dw, int Cout, int Cin, int KH, int KW, int nsplit, int accumulate, hipStream_t st) {
-  int SL = 1; while (SL < nsplit && SL < 16) SL <<= 1;
   int64_t total = (int64_t)Cout * KH * KW * Cin;
+  if (total % 4 == 0) {
+    int SL = 1; while (SL * 8 < nsplit && SL < 64) SL <<= 1;   // about 8 slabs per slab lane
+    unsigned rg = (unsigned)std::min<int64_t>(cdiv(total / 4, 256 / SL), 4096);
+    hipLaunchKernelGGL(wgrad_reduce_vec_kernel, dim3(rg), dim3(256), 0, st, slab, dw, Cout, Cin, KH, KW, nsplit, accumulate, SL);
+    return;
+  }
+  int SL = 1; while (SL < nsplit && SL < 16) SL <<= 1;
   unsigned rg = (unsigned)std::min<int64_t>(cdiv(total, 256 / SL), 4096);
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(rg), dim3(256), 0, st, slab, dw, Cout, Cin, KH, KW, nsplit, accumulate, SL);
 }

@@ -15,6 +15,14 @@
 
 namespace rd {
 
+#ifdef RD_LOFTR_PROF   // phase timing probe (tools/loftr_prof.py builds a separate library with this define; never in the product build)
+__device__ unsigned long long g_loftr_prof[32];
+#define LPROF_INIT unsigned long long pt_ = wall_clock64();
+#define LPROF(i) if (threadIdx.x == 0) { const unsigned long long n_ = wall_clock64(); atomicAdd(&g_loftr_prof[i], n_ - pt_); pt_ = n_; }
+#else
+#define LPROF_INIT
+#define LPROF(i)
+#endif
 static constexpr int LC = 128, LC2 = 256, LTOK = 32, LF = 132;   // channels, hidden, padded tokens, float row pitch
 static constexpr int LNW = 8, LNT = LNW * 64;                     // waves / threads per workgroup: one attention head per wave, two waves
                                                                   // per SIMD (the layer is a chain of short latency-bound phases)
@@ -114,9 +122,11 @@ __global__ __launch_bounds__(LNT) void loftr_layer_fwd_kernel(const T* __restric
   const bool self = (src == x);
   const int64_t xo = (int64_t)n * L * LC, so = (int64_t)n * S * LC;
 
+  LPROF_INIT
   load_rows<T>(x + xo, L, sm.bX, LDA);
   if (!self) load_rows<T>(src + so, S, sm.bS, LDA);
   __syncthreads();
+  LPROF(0)
   const T* sp = self ? sm.bX : sm.bS;
 
   auto to_global = [&](T* base, int64_t off, int rows, int ldg) RD_INLINE_LAMBDA {
@@ -135,13 +145,16 @@ __global__ __launch_bounds__(LNT) void loftr_layer_fwd_kernel(const T* __restric
   tok_gemm<T, LC, LC>(sp, sp, LC, LDA, w.wk, to_global((T*)sv.k, so, S, LC));
   tok_gemm<T, LC, LC>(sp, sp, LC, LDA, w.wv, to_global((T*)sv.v, so, S, LC));
   __syncthreads();
+  LPROF(1)
 
   // linear attention: wave wv owns head wv (q, k, v come back from L2; the head routine stages them per head)
   attn_head<T, false>(sm.u.at[wv], (const T*)sv.q, (const T*)sv.k, (const T*)sv.v, (const T*)nullptr, (T*)sv.att, (T*)nullptr,
                       (T*)nullptr, (T*)nullptr, n, wv, true, L, S, LC, LC, LC, LC, eps_attn);
   __syncthreads();
+  LPROF(2)
   load_rows<T>((const T*)sv.att + xo, L, sm.bS, LDA);
   __syncthreads();
+  LPROF(3)
 
   // merge projection -> fp32 scratch (values as the unfused path stores them) + saved pre-norm activation
   auto to_f = [&](T* gbase, int rows) RD_INLINE_LAMBDA {
@@ -158,6 +171,7 @@ __global__ __launch_bounds__(LNT) void loftr_layer_fwd_kernel(const T* __restric
   };
   tok_gemm<T, LC, LC>(sm.bS, sm.bS, LC, LDA, w.wm, to_f((T*)sv.mpre, L));
   __syncthreads();
+  LPROF(4)
 
   // LayerNorm (one wave per row, two channels per lane); which = 0: norm1 -> bM + saved message, 1: norm2 + residual -> out
   auto ln_rows = [&](const float* gamma, const float* beta, int which) RD_INLINE_LAMBDA {
@@ -185,6 +199,7 @@ __global__ __launch_bounds__(LNT) void loftr_layer_fwd_kernel(const T* __restric
   };
   ln_rows(w.g1, w.b1, 0);
   __syncthreads();
+  LPROF(5)
 
   // hidden = relu(W0 [x | message])
   tok_gemm<T, LC2, LC2>(sm.bX, sm.bM, LC, LDA, w.w0, [&](int ct, f32x4 (&acc)[2]) RD_INLINE_LAMBDA {
@@ -199,9 +214,12 @@ __global__ __launch_bounds__(LNT) void loftr_layer_fwd_kernel(const T* __restric
     }
   });
   __syncthreads();
+  LPROF(6)
   tok_gemm<T, LC2, LC>(sm.u.fh.h, sm.u.fh.h, LC2, LDH, w.w2, to_f((T*)sv.m2pre, L));
   __syncthreads();
+  LPROF(7)
   ln_rows(w.g2, w.b2, 1);
+  LPROF(8)
 }
 
 // ---- backward ---------------------------------------------------------------------------------------------------------------------
@@ -258,10 +276,12 @@ __global__ __launch_bounds__(LNT) void loftr_layer_bwd_kernel(const T* __restric
     }
   };
 
+  LPROF_INIT
   // 1. out = x + norm2(m2pre)
   const T* dout = (const T*)gr.dout;
   ln_bwd([&](int r, int c) RD_INLINE_LAMBDA { return Elem<T>::ld(dout + xo + (int64_t)r * LC + c); }, (const T*)sv.m2pre, w.g2, 1, (T*)gr.dm2pre, gr.lnp2, true);
   __syncthreads();
+  LPROF(10)
 
   // 2. dhid = (dm2pre W2) * relu'(hid)
   tok_gemm<T, LC, LC2>(sm.bD, sm.bD, LC, LDA, w.w2, [&](int ct, f32x4 (&acc)[2]) RD_INLINE_LAMBDA {
@@ -280,6 +300,7 @@ __global__ __launch_bounds__(LNT) void loftr_layer_bwd_kernel(const T* __restric
     }
   });
   __syncthreads();
+  LPROF(11)
 
   // 3. dcat = dhid W0: channels [0,128) add into dx, [128,256) are the gradient of the normalised message
   tok_gemm<T, LC2, LC2>(sm.u.fh.h, sm.u.fh.h, LC2, LDH, w.w0, [&](int ct, f32x4 (&acc)[2]) RD_INLINE_LAMBDA {
@@ -295,10 +316,12 @@ __global__ __launch_bounds__(LNT) void loftr_layer_bwd_kernel(const T* __restric
     }
   });
   __syncthreads();
+  LPROF(12)
 
   // 4. message = norm1(mpre)
   ln_bwd([&](int r, int c) RD_INLINE_LAMBDA { return sm.u.fh.f[r * LF + c]; }, (const T*)sv.mpre, w.g1, 0, (T*)gr.dmpre, gr.lnp1, false);
   __syncthreads();
+  LPROF(13)
 
   // 5. datt = dmpre Wm
   auto to_global = [&](T* base, int64_t off, int rows) RD_INLINE_LAMBDA {
@@ -315,11 +338,13 @@ __global__ __launch_bounds__(LNT) void loftr_layer_bwd_kernel(const T* __restric
   };
   tok_gemm<T, LC, LC>(sm.bD, sm.bD, LC, LDA, w.wm, to_global((T*)gr.datt, xo, L));
   __syncthreads();
+  LPROF(14)
 
   // 6. attention backward (recomputes KV / P from the saved q, k, v)
   attn_head<T, true>(sm.u.at[wv], (const T*)sv.q, (const T*)sv.k, (const T*)sv.v, (const T*)gr.datt, (T*)nullptr, (T*)gr.dq,
                      (T*)gr.dk, (T*)gr.dv, n, wv, true, L, S, LC, LC, LC, LC, eps_attn);
   __syncthreads();
+  LPROF(15)
 
   // 7. dx += dq Wq;  dsrc = dk Wk + dv Wv  (self-attention: dsrc adds into dx)
   load_rows<T>((const T*)gr.dq + xo, L, sm.bD, LDA);
@@ -331,6 +356,7 @@ __global__ __launch_bounds__(LNT) void loftr_layer_bwd_kernel(const T* __restric
       for (int r = 0; r < 4; r++) sm.acc[(tt * 16 + fr) * LF + ct * 16 + fg * 4 + r] += Elem<T>::rnd(acc[tt][r]);
   });
   __syncthreads();
+  LPROF(16)
   float* sacc = self ? sm.acc : sm.u.fh.f;
   load_rows<T>((const T*)gr.dk + so, S, sm.bD, LDA);
   __syncthreads();
@@ -345,6 +371,7 @@ __global__ __launch_bounds__(LNT) void loftr_layer_bwd_kernel(const T* __restric
       }
   });
   __syncthreads();
+  LPROF(17)
   load_rows<T>((const T*)gr.dv + so, S, sm.bD, LDA);
   __syncthreads();
   tok_gemm<T, LC, LC>(sm.bD, sm.bD, LC, LDA, w.wv, [&](int ct, f32x4 (&acc)[2]) RD_INLINE_LAMBDA {
@@ -355,6 +382,7 @@ __global__ __launch_bounds__(LNT) void loftr_layer_bwd_kernel(const T* __restric
   });
   __syncthreads();
 
+  LPROF(18)
   // 8. results
   for (int idx = threadIdx.x; idx < L * (LC / 4); idx += LNT) {
     const int r = idx / (LC / 4), c4 = (idx - r * (LC / 4)) * 4;
@@ -367,6 +395,7 @@ __global__ __launch_bounds__(LNT) void loftr_layer_bwd_kernel(const T* __restric
       float v[4] = {sm.u.fh.f[r * LF + c4], sm.u.fh.f[r * LF + c4 + 1], sm.u.fh.f[r * LF + c4 + 2], sm.u.fh.f[r * LF + c4 + 3]};
       st4((T*)gr.dsrc + so + (int64_t)r * LC + c4, v);
     }
+  LPROF(19)
 }
 
 // ---- launchers ----------------------------------------------------------------------------------------------------------------------
@@ -387,3 +416,11 @@ void launch_loftr_layer_bwd(const void* x, const void* src, const LoftrW& w, con
 }
 
 }  // namespace rd
+
+#ifdef RD_LOFTR_PROF
+extern "C" int rd_debug_loftr_prof(unsigned long long* out, int reset) {
+  if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(rd::g_loftr_prof), sizeof(unsigned long long) * 32) != hipSuccess) return 1;
+  if (reset) { unsigned long long z[32] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(rd::g_loftr_prof), z, sizeof(z)) != hipSuccess) return 1; }
+  return 0;
+}
+#endif

@@ -21,23 +21,21 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
                                                           float eps, float momentum, int training, float* running_mean,
                                                           float* running_var, float* mean_out, float* rstd_out,
                                                           float* scale, float* shift) {
-  __shared__ double s1[256], s2[256];
+  __shared__ double s1[4], s2[4];
   const int c = blockIdx.x, t = threadIdx.x;
   float mean, var;
   if (training) {
+    // float2 loads, lanes stride over the partial rows; wave shuffle + 4-entry LDS combine (fixed order, double precision)
+    const float2* p2 = reinterpret_cast<const float2*>(partial);
     double a = 0.0, b = 0.0;
-    for (int r = t; r < rows; r += 256) {
-      a += (double)partial[((int64_t)r * C + c) * 2];
-      b += (double)partial[((int64_t)r * C + c) * 2 + 1];
-    }
-    s1[t] = a; s2[t] = b;
+    for (int r = t; r < rows; r += 256) { const float2 v = p2[(int64_t)r * C + c]; a += (double)v.x; b += (double)v.y; }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
+    if ((t & 63) == 0) { s1[t >> 6] = a; s2[t >> 6] = b; }
     __syncthreads();
-    for (int o = 128; o > 0; o >>= 1) {
-      if (t < o) { s1[t] += s1[t + o]; s2[t] += s2[t + o]; }
-      __syncthreads();
-    }
-    double m = s1[0] / count;
-    double v = s2[0] / count - m * m;
+    const double sa = (s1[0] + s1[1]) + (s1[2] + s1[3]), sb = (s2[0] + s2[1]) + (s2[2] + s2[3]);
+    double m = sa / count;
+    double v = sb / count - m * m;
     if (v < 0.0) v = 0.0;
     mean = (float)m; var = (float)v;
     if (t == 0 && running_mean) {
@@ -143,15 +141,21 @@ __global__ __launch_bounds__(256) void col_reduce_kernel(const T* __restrict__ d
   }
 }
 
-// one wave per channel: lanes stride over the partial rows, double-precision wave reduction (fixed order)
-__global__ __launch_bounds__(64) void bn_bwd_finalize_kernel(const float* __restrict__ partial, int rows, int C, double count,
-                                                             float* dgamma, float* dbeta, int accumulate, float* c1, float* c2) {
-  const int c = blockIdx.x, lane = threadIdx.x;
+// one workgroup per channel: threads stride over the partial rows (float2 loads), wave shuffle + 4-entry LDS combine in double
+// precision (fixed order).  Four waves keep 4x the loads in flight of the one-wave version: this kernel is pure load latency.
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ partial, int rows, int C, double count,
+                                                              float* dgamma, float* dbeta, int accumulate, float* c1, float* c2) {
+  __shared__ double s1[4], s2[4];
+  const int c = blockIdx.x, t = threadIdx.x;
+  const float2* p2 = reinterpret_cast<const float2*>(partial);
   double a = 0.0, b = 0.0;
-  for (int r = lane; r < rows; r += 64) { a += partial[((int64_t)r * C + c) * 2]; b += partial[((int64_t)r * C + c) * 2 + 1]; }
+  for (int r = t; r < rows; r += 256) { const float2 v = p2[(int64_t)r * C + c]; a += (double)v.x; b += (double)v.y; }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
-  if (lane == 0) {
+  if ((t & 63) == 0) { s1[t >> 6] = a; s2[t >> 6] = b; }
+  __syncthreads();
+  if (t == 0) {
+    a = (s1[0] + s1[1]) + (s1[2] + s1[3]); b = (s2[0] + s2[1]) + (s2[2] + s2[3]);
     if (dbeta) dbeta[c] = accumulate ? dbeta[c] + (float)a : (float)a;
     if (dgamma) dgamma[c] = accumulate ? dgamma[c] + (float)b : (float)b;
     if (c1) c1[c] = (float)(a / count);
@@ -629,7 +633,7 @@ void launch_bn_bwd_reduce(const void* dz, const void* z, const void* y, const fl
 
 void launch_bn_bwd_finalize(const float* partial, int rows, int C, double count, float* dgamma, float* dbeta,
                             int accumulate, float* c1, float* c2, hipStream_t st) {
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)C), dim3(64), 0, st, partial, rows, C, count, dgamma, dbeta, accumulate, c1, c2);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)C), dim3(256), 0, st, partial, rows, C, count, dgamma, dbeta, accumulate, c1, c2);
 }
 
 void launch_bn_bwd_apply(const void* dz, const void* z, const void* y, const float* mean, const float* rstd,
@@ -706,7 +710,7 @@ void launch_layernorm_bwd(const void* dout, const void* x, const float* gamma, c
     hipLaunchKernelGGL((layernorm_bwd_kernel<float>), dim3(nb), dim3(256), 0, st, (const float*)dout, (const float*)x, gamma, mean, rstd, (float*)dx, partial, rows, C);
   else
     hipLaunchKernelGGL((layernorm_bwd_kernel<bf16_t>), dim3(nb), dim3(256), 0, st, (const bf16_t*)dout, (const bf16_t*)x, gamma, mean, rstd, (bf16_t*)dx, partial, rows, C);
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)C), dim3(64), 0, st, partial, nb, C, 1.0, dgamma, dbeta, accumulate, (float*)nullptr, (float*)nullptr);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)C), dim3(256), 0, st, partial, nb, C, 1.0, dgamma, dbeta, accumulate, (float*)nullptr, (float*)nullptr);
 }
 
 }  // namespace rd
