@@ -53,10 +53,44 @@ __device__ __forceinline__ void attn_head(AttnSmem& s, const T* __restrict__ q, 
   const int lt = (L + 15) >> 4, stl = (S + 15) >> 4;  // 16-row tiles
 
   __syncthreads();  // a previous call's reads of this wave's scratch are complete before it is restaged (back-to-back calls)
-  stage_head<T>(q, (int64_t)n * L, ldq, col0, L, s.q, 1, 1.f, active);
-  stage_head<T>(k, (int64_t)n * S, ldk, col0, S, s.k, 1, 1.f, active);
-  stage_head<T>(v, (int64_t)n * S, ldv, col0, S, s.v, 0, 1.f / fS, active);
-  if (BWD) stage_head<T>(dout, (int64_t)n * L, ldo, col0, L, s.d, 0, 1.f, active);
+  constexpr int VE = Elem<T>::VE;
+  const bool vec = L > 0 && S > 0 && (ldq % VE == 0) && (ldk % VE == 0) && (ldv % VE == 0) && (!BWD || ldo % VE == 0) &&
+                   (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (BWD ? (uintptr_t)dout : (uintptr_t)0)) & 15) == 0;
+  if (vec) {
+    // 16-byte loads, all tensors' requests in flight together (the element-wise path below is one 2-byte round trip after another:
+    // it was the whole cost of the attention phase inside the fused LoFTR layer)
+    constexpr int SPR = 16 / VE, NIT = MAXR * SPR / 64;   // slots per row, slots per lane (1 for bf16, 2 for fp32)
+    float xq[NIT][VE], xk[NIT][VE], xv[NIT][VE], xd[BWD ? NIT : 1][VE];
+    const int64_t nn = active ? n : 0;     // inactive waves read sequence 0 / head 0 and discard: no branch around the loads
+    const int cc0 = active ? col0 : 0;     // (a load under a condition is waited for at the join, one round trip per tensor)
+#pragma unroll
+    for (int i = 0; i < NIT; i++) {
+      const int idx = lane + 64 * i, rr = idx / SPR, c = (idx - rr * SPR) * VE;
+      const int rl = min(rr, L - 1), rs = min(rr, S - 1);
+      rd::ldv(q + (nn * L + rl) * ldq + cc0 + c, xq[i]);
+      rd::ldv(k + (nn * S + rs) * ldk + cc0 + c, xk[i]);
+      rd::ldv(v + (nn * S + rs) * ldv + cc0 + c, xv[i]);
+      if (BWD) rd::ldv(dout + (nn * L + rl) * ldo + cc0 + c, xd[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < NIT; i++) {
+      const int idx = lane + 64 * i, rr = idx / SPR, c = (idx - rr * SPR) * VE;
+      const bool okq = active && rr < L, okk = active && rr < S;
+#pragma unroll
+      for (int e = 0; e < VE; e++) {
+        const float a = xq[i][e], b = xk[i][e];
+        s.q[rr * LD + c + e] = okq ? (a > 0.f ? a + 1.f : __expf(a)) : 0.f;
+        s.k[rr * LD + c + e] = okk ? (b > 0.f ? b + 1.f : __expf(b)) : 0.f;
+        s.v[rr * LD + c + e] = okk ? xv[i][e] * (1.f / fS) : 0.f;
+        if (BWD) s.d[rr * LD + c + e] = okq ? xd[i][e] * 1.f : 0.f;
+      }
+    }
+  } else {
+    stage_head<T>(q, (int64_t)n * L, ldq, col0, L, s.q, 1, 1.f, active);
+    stage_head<T>(k, (int64_t)n * S, ldk, col0, S, s.k, 1, 1.f, active);
+    stage_head<T>(v, (int64_t)n * S, ldv, col0, S, s.v, 0, 1.f / fS, active);
+    if (BWD) stage_head<T>(dout, (int64_t)n * L, ldo, col0, L, s.d, 0, 1.f, active);
+  }
   __syncthreads();
 
   // KV = K^T V  (16 x 16), Ksum

@@ -117,6 +117,13 @@ __device__ __forceinline__ uint2 lds_read_tr16_b64(const void* p) {
 #endif
 }
 
+// Scheduling fence: no instruction moves across it (used to keep a block of prefetch loads where it is written).
+__device__ __forceinline__ void sched_fence() {
+#ifndef RD_EMU
+  __builtin_amdgcn_sched_barrier(0);
+#endif
+}
+
 // ---- wave / block reductions ---------------------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -18,10 +18,12 @@ namespace rd {
 #ifdef RD_LOFTR_PROF   // phase timing probe (tools/loftr_prof.py builds a separate library with this define; never in the product build)
 __device__ unsigned long long g_loftr_prof[32];
 #define LPROF_INIT unsigned long long pt_ = wall_clock64();
-#define LPROF(i) if (threadIdx.x == 0) { const unsigned long long n_ = wall_clock64(); atomicAdd(&g_loftr_prof[i], n_ - pt_); pt_ = n_; }
+#define LPROF(i) { const unsigned long long n_ = wall_clock64(); if (threadIdx.x == 0) atomicAdd(&g_loftr_prof[i], n_ - pt_); pt_ = n_; }
+#define LPROFW(i) if ((threadIdx.x & 63) == 0) atomicAdd(&g_loftr_prof[i], wall_clock64() - pt_);   // per wave, time since the phase began (sum over 8 waves)
 #else
 #define LPROF_INIT
 #define LPROF(i)
+#define LPROFW(i)
 #endif
 static constexpr int LC = 128, LC2 = 256, LTOK = 32, LF = 132;   // channels, hidden, padded tokens, float row pitch
 static constexpr int LNW = 8, LNT = LNW * 64;                     // waves / threads per workgroup: one attention head per wave, two waves
@@ -51,41 +53,72 @@ struct LoftrSmemBwd {
   } u;
 };
 
-// rows x 128 channels of a token matrix -> LDS tile (rows >= `rows` zero filled)
+// rows x 128 channels of a token matrix -> LDS tile (rows >= `rows` zero filled).  RowsReg splits the copy into fetch (global loads
+// issued) and commit (LDS stores) so that other loads can be issued in between without being waited for (vmcnt counts in order).
+template <typename T> struct RowsReg { static constexpr int NIT = LTOK * (LC / Elem<T>::VE) / LNT; uint4 v[NIT]; };
+template <typename T>
+__device__ __forceinline__ void rows_fetch(const T* __restrict__ g, int rows, RowsReg<T>& rr) {
+  constexpr int VE = Elem<T>::VE, SPR = LC / VE;
+#pragma unroll
+  for (int i = 0; i < RowsReg<T>::NIT; i++) {
+    const int idx = threadIdx.x + i * LNT, r = idx / SPR, sl = idx - r * SPR;
+    const uint4 v = *reinterpret_cast<const uint4*>(g + (int64_t)min(r, rows - 1) * LC + sl * VE);   // clamped row: no branch around the load
+    rr.v[i] = v;
+  }
+}
+template <typename T>
+__device__ __forceinline__ void rows_commit(const RowsReg<T>& rr, int rows, T* lds, int ld) {
+  constexpr int VE = Elem<T>::VE, SPR = LC / VE;
+#pragma unroll
+  for (int i = 0; i < RowsReg<T>::NIT; i++) {
+    const int idx = threadIdx.x + i * LNT, r = idx / SPR, sl = idx - r * SPR;
+    *reinterpret_cast<uint4*>(lds + r * ld + sl * VE) = (r < rows) ? rr.v[i] : make_uint4(0, 0, 0, 0);
+  }
+}
 template <typename T>
 __device__ __forceinline__ void load_rows(const T* __restrict__ g, int rows, T* lds, int ld) {
-  constexpr int VE = Elem<T>::VE, SPR = LC / VE;
-  for (int idx = threadIdx.x; idx < LTOK * SPR; idx += LNT) {
-    const int r = idx / SPR, sl = idx - r * SPR;
-    uint4 v = make_uint4(0, 0, 0, 0);
-    if (r < rows) v = *reinterpret_cast<const uint4*>(g + (int64_t)r * LC + sl * VE);
-    *reinterpret_cast<uint4*>(lds + r * ld + sl * VE) = v;
-  }
+  RowsReg<T> rr;
+  rows_fetch<T>(g, rows, rr);
+  rows_commit<T>(rr, rows, lds, ld);
 }
 
 // tile[32 tokens][NO] = A[32][K] . W^T with A in LDS (columns [0,K0) from a0, [K0,K) from a1, row pitch lda) and W packed [NO][K].
 // epi(ct, acc): this lane holds acc[tt][r] = (token tt*16 + (lane&15), channel ct*16 + (lane>>4)*4 + r).
-template <typename T, int K, int NO, typename Epi>
-__device__ __forceinline__ void tok_gemm(const T* a0, const T* a1, int K0, int lda, const void* wpacked, Epi epi) {
-  constexpr int VE = Elem<T>::VE, SE = 4 * VE, NS = K / SE, KSL = K / VE;
+// The weight fragments of one GEMM live in a TokW: tok_load() issues every load of the GEMM at once (when they fit in 64 VGPRs) and
+// is called a phase EARLY -- before the barrier / attention / LayerNorm that precedes the GEMM -- so the L2 round trip of the weights
+// overlaps that phase instead of starting the GEMM (the layer is a chain of latency-bound phases; profiles/r01_loftr_phases.txt).
+template <typename T, int K, int NO> struct TokW {
+  static constexpr int VE = Elem<T>::VE, SE = 4 * VE, NS = K / SE, KSL = K / VE, NCT = NO / 16 / LNW;
+  static constexpr bool HOIST = NCT * NS <= 16;
+  uint4 f[HOIST ? NCT : 1][NS];
+  const uint4* wp;
+};
+template <typename T, int K, int NO>
+__device__ __forceinline__ void tok_load(const void* wpacked, TokW<T, K, NO>& w) {
+  using W = TokW<T, K, NO>;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, fr = lane & 15, fg = lane >> 4;
-  const uint4* wp = reinterpret_cast<const uint4*>(wpacked);
-  constexpr int NCT = NO / 16 / LNW;               // channel tiles per wave (1 or 2)
-  constexpr bool HOIST = NCT * NS <= 16;           // all weight fragments of the GEMM in flight at once when they fit in 64 VGPRs
-  uint4 wf[NCT][NS];
-  if (HOIST) {
+  w.wp = reinterpret_cast<const uint4*>(wpacked);
+  if (W::HOIST) {
 #pragma unroll
-    for (int ci = 0; ci < NCT; ci++)
+    for (int ci = 0; ci < W::NCT; ci++)
 #pragma unroll
-      for (int ks = 0; ks < NS; ks++) { const uint4 v = wp[(int64_t)((wv + ci * LNW) * 16 + fr) * KSL + ks * 4 + fg]; wf[ci][ks] = v; }
+      for (int ks = 0; ks < W::NS; ks++) { const uint4 v = w.wp[(int64_t)((wv + ci * LNW) * 16 + fr) * W::KSL + ks * 4 + fg]; w.f[ci][ks] = v; }
+    sched_fence();   // keep the loads here: the scheduler otherwise sinks them next to their MFMA, two at a time
   }
+}
+template <typename T, int K, int NO, typename Epi>
+__device__ __forceinline__ void tok_mma(const T* a0, const T* a1, int K0, int lda, TokW<T, K, NO>& w, Epi epi) {
+  using W = TokW<T, K, NO>;
+  constexpr int VE = W::VE, SE = W::SE, NS = W::NS;
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, fr = lane & 15, fg = lane >> 4;
 #pragma unroll
-  for (int ci = 0; ci < NCT; ci++) {
+  for (int ci = 0; ci < W::NCT; ci++) {
     const int ct = wv + ci * LNW;
-    if (!HOIST) {
+    if (!W::HOIST) {
 #pragma unroll
-      for (int ks = 0; ks < NS; ks++) { const uint4 v = wp[(int64_t)(ct * 16 + fr) * KSL + ks * 4 + fg]; wf[ci][ks] = v; }
+      for (int ks = 0; ks < NS; ks++) { const uint4 v = w.wp[(int64_t)(ct * 16 + fr) * W::KSL + ks * 4 + fg]; w.f[0][ks] = v; }
     }
+    const uint4 (&wf)[NS] = w.f[W::HOIST ? ci : 0];
     f32x4 acc[2] = {f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}};
 #pragma unroll
     for (int ks = 0; ks < NS; ks++) {
@@ -94,13 +127,13 @@ __device__ __forceinline__ void tok_gemm(const T* a0, const T* a1, int K0, int l
       for (int tt = 0; tt < 2; tt++) {
         const uint4 pf = *reinterpret_cast<const uint4*>(ap + (tt * 16 + fr) * lda + fg * VE);
         if (sizeof(T) == 4) {
-          acc[tt] = mfma_16x16x4_f32(__uint_as_float(wf[ci][ks].x), __uint_as_float(pf.x), acc[tt]);
-          acc[tt] = mfma_16x16x4_f32(__uint_as_float(wf[ci][ks].y), __uint_as_float(pf.y), acc[tt]);
-          acc[tt] = mfma_16x16x4_f32(__uint_as_float(wf[ci][ks].z), __uint_as_float(pf.z), acc[tt]);
-          acc[tt] = mfma_16x16x4_f32(__uint_as_float(wf[ci][ks].w), __uint_as_float(pf.w), acc[tt]);
+          acc[tt] = mfma_16x16x4_f32(__uint_as_float(wf[ks].x), __uint_as_float(pf.x), acc[tt]);
+          acc[tt] = mfma_16x16x4_f32(__uint_as_float(wf[ks].y), __uint_as_float(pf.y), acc[tt]);
+          acc[tt] = mfma_16x16x4_f32(__uint_as_float(wf[ks].z), __uint_as_float(pf.z), acc[tt]);
+          acc[tt] = mfma_16x16x4_f32(__uint_as_float(wf[ks].w), __uint_as_float(pf.w), acc[tt]);
         } else {
           s16x8 wa, pb;
-          __builtin_memcpy(&wa, &wf[ci][ks], 16);
+          __builtin_memcpy(&wa, &wf[ks], 16);
           __builtin_memcpy(&pb, &pf, 16);
           acc[tt] = mfma_16x16x32_bf16(wa, pb, acc[tt]);
         }
@@ -109,7 +142,6 @@ __device__ __forceinline__ void tok_gemm(const T* a0, const T* a1, int K0, int l
     epi(ct, acc);
   }
 }
-
 // ---- forward ----------------------------------------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(LNT) void loftr_layer_fwd_kernel(const T* __restrict__ x, const T* __restrict__ src, LoftrW w,
@@ -123,8 +155,20 @@ __global__ __launch_bounds__(LNT) void loftr_layer_fwd_kernel(const T* __restric
   const int64_t xo = (int64_t)n * L * LC, so = (int64_t)n * S * LC;
 
   LPROF_INIT
-  load_rows<T>(x + xo, L, sm.bX, LDA);
-  if (!self) load_rows<T>(src + so, S, sm.bS, LDA);
+  TokW<T, LC, LC> Wq, Wk, Wv, Wm;
+  TokW<T, LC2, LC2> W0;
+  TokW<T, LC2, LC> W2;
+  constexpr bool EARLY = sizeof(T) == 2;   // fp32 fragments are twice the registers: its weights are fetched right before each GEMM
+  {
+    RowsReg<T> rx, rs;
+    rows_fetch<T>(x + xo, L, rx);
+    if (!self) rows_fetch<T>(src + so, S, rs);
+    sched_fence();
+    tok_load<T, LC, LC>(w.wq, Wq);
+    if (EARLY) { tok_load<T, LC, LC>(w.wk, Wk); tok_load<T, LC, LC>(w.wv, Wv); }
+    rows_commit<T>(rx, L, sm.bX, LDA);
+    if (!self) rows_commit<T>(rs, S, sm.bS, LDA);
+  }
   __syncthreads();
   LPROF(0)
   const T* sp = self ? sm.bX : sm.bS;
@@ -141,9 +185,12 @@ __global__ __launch_bounds__(LNT) void loftr_layer_fwd_kernel(const T* __restric
       }
     };
   };
-  tok_gemm<T, LC, LC>(sm.bX, sm.bX, LC, LDA, w.wq, to_global((T*)sv.q, xo, L, LC));
-  tok_gemm<T, LC, LC>(sp, sp, LC, LDA, w.wk, to_global((T*)sv.k, so, S, LC));
-  tok_gemm<T, LC, LC>(sp, sp, LC, LDA, w.wv, to_global((T*)sv.v, so, S, LC));
+  tok_mma<T, LC, LC>(sm.bX, sm.bX, LC, LDA, Wq, to_global((T*)sv.q, xo, L, LC));
+  if (!EARLY) tok_load<T, LC, LC>(w.wk, Wk);
+  tok_mma<T, LC, LC>(sp, sp, LC, LDA, Wk, to_global((T*)sv.k, so, S, LC));
+  if (!EARLY) tok_load<T, LC, LC>(w.wv, Wv);
+  tok_mma<T, LC, LC>(sp, sp, LC, LDA, Wv, to_global((T*)sv.v, so, S, LC));
+  tok_load<T, LC, LC>(w.wm, Wm);        // in flight across the attention phase
   __syncthreads();
   LPROF(1)
 
@@ -169,7 +216,8 @@ __global__ __launch_bounds__(LNT) void loftr_layer_fwd_kernel(const T* __restric
       }
     };
   };
-  tok_gemm<T, LC, LC>(sm.bS, sm.bS, LC, LDA, w.wm, to_f((T*)sv.mpre, L));
+  tok_load<T, LC2, LC2>(w.w0, W0);     // in flight across the merge GEMM and norm1
+  tok_mma<T, LC, LC>(sm.bS, sm.bS, LC, LDA, Wm, to_f((T*)sv.mpre, L));
   __syncthreads();
   LPROF(4)
 
@@ -202,7 +250,10 @@ __global__ __launch_bounds__(LNT) void loftr_layer_fwd_kernel(const T* __restric
   LPROF(5)
 
   // hidden = relu(W0 [x | message])
-  tok_gemm<T, LC2, LC2>(sm.bX, sm.bM, LC, LDA, w.w0, [&](int ct, f32x4 (&acc)[2]) RD_INLINE_LAMBDA {
+  tok_load<T, LC2, LC>(w.w2, W2);
+  LPROFW(20)
+  tok_mma<T, LC2, LC2>(sm.bX, sm.bM, LC, LDA, W0, [&](int ct, f32x4 (&acc)[2]) RD_INLINE_LAMBDA {
+    if (ct < LNW) { LPROFW(21) } else { LPROFW(23) }
 #pragma unroll
     for (int tt = 0; tt < 2; tt++) {
       const int tok = tt * 16 + fr;
@@ -212,10 +263,12 @@ __global__ __launch_bounds__(LNT) void loftr_layer_fwd_kernel(const T* __restric
       st4(&sm.u.fh.h[tok * LDH + ct * 16 + fg * 4], v);
       if (tok < L) st4((T*)sv.hid + ((int64_t)n * L + tok) * LC2 + ct * 16 + fg * 4, v);
     }
+    if (ct < LNW) { LPROFW(22) } else { LPROFW(24) }
   });
+  LPROFW(25)
   __syncthreads();
   LPROF(6)
-  tok_gemm<T, LC2, LC>(sm.u.fh.h, sm.u.fh.h, LC2, LDH, w.w2, to_f((T*)sv.m2pre, L));
+  tok_mma<T, LC2, LC>(sm.u.fh.h, sm.u.fh.h, LC2, LDH, W2, to_f((T*)sv.m2pre, L));
   __syncthreads();
   LPROF(7)
   ln_rows(w.g2, w.b2, 1);
@@ -277,6 +330,12 @@ __global__ __launch_bounds__(LNT) void loftr_layer_bwd_kernel(const T* __restric
   };
 
   LPROF_INIT
+  TokW<T, LC, LC2> W2;
+  TokW<T, LC2, LC2> W0;
+  TokW<T, LC, LC> Wm, Wq, Wk, Wv;
+  constexpr bool EARLY = sizeof(T) == 2;   // fp32 fragments are twice the registers: fewer GEMMs' weights in flight at once
+  tok_load<T, LC, LC2>(w.w2, W2);                 // in flight across the norm2 backward
+  if (EARLY) tok_load<T, LC2, LC2>(w.w0, W0);
   // 1. out = x + norm2(m2pre)
   const T* dout = (const T*)gr.dout;
   ln_bwd([&](int r, int c) RD_INLINE_LAMBDA { return Elem<T>::ld(dout + xo + (int64_t)r * LC + c); }, (const T*)sv.m2pre, w.g2, 1, (T*)gr.dm2pre, gr.lnp2, true);
@@ -284,7 +343,7 @@ __global__ __launch_bounds__(LNT) void loftr_layer_bwd_kernel(const T* __restric
   LPROF(10)
 
   // 2. dhid = (dm2pre W2) * relu'(hid)
-  tok_gemm<T, LC, LC2>(sm.bD, sm.bD, LC, LDA, w.w2, [&](int ct, f32x4 (&acc)[2]) RD_INLINE_LAMBDA {
+  tok_mma<T, LC, LC2>(sm.bD, sm.bD, LC, LDA, W2, [&](int ct, f32x4 (&acc)[2]) RD_INLINE_LAMBDA {
 #pragma unroll
     for (int tt = 0; tt < 2; tt++) {
       const int tok = tt * 16 + fr;
@@ -303,7 +362,9 @@ __global__ __launch_bounds__(LNT) void loftr_layer_bwd_kernel(const T* __restric
   LPROF(11)
 
   // 3. dcat = dhid W0: channels [0,128) add into dx, [128,256) are the gradient of the normalised message
-  tok_gemm<T, LC2, LC2>(sm.u.fh.h, sm.u.fh.h, LC2, LDH, w.w0, [&](int ct, f32x4 (&acc)[2]) RD_INLINE_LAMBDA {
+  if (!EARLY) tok_load<T, LC2, LC2>(w.w0, W0);
+  tok_load<T, LC, LC>(w.wm, Wm);
+  tok_mma<T, LC2, LC2>(sm.u.fh.h, sm.u.fh.h, LC2, LDH, W0, [&](int ct, f32x4 (&acc)[2]) RD_INLINE_LAMBDA {
 #pragma unroll
     for (int tt = 0; tt < 2; tt++) {
       const int tok = tt * 16 + fr;
@@ -336,7 +397,9 @@ __global__ __launch_bounds__(LNT) void loftr_layer_bwd_kernel(const T* __restric
       }
     };
   };
-  tok_gemm<T, LC, LC>(sm.bD, sm.bD, LC, LDA, w.wm, to_global((T*)gr.datt, xo, L));
+  tok_mma<T, LC, LC>(sm.bD, sm.bD, LC, LDA, Wm, to_global((T*)gr.datt, xo, L));
+  tok_load<T, LC, LC>(w.wq, Wq);                  // in flight across the attention backward
+  if (EARLY) { tok_load<T, LC, LC>(w.wk, Wk); tok_load<T, LC, LC>(w.wv, Wv); }
   __syncthreads();
   LPROF(14)
 
@@ -347,9 +410,14 @@ __global__ __launch_bounds__(LNT) void loftr_layer_bwd_kernel(const T* __restric
   LPROF(15)
 
   // 7. dx += dq Wq;  dsrc = dk Wk + dv Wv  (self-attention: dsrc adds into dx)
-  load_rows<T>((const T*)gr.dq + xo, L, sm.bD, LDA);
+  RowsReg<T> rdq, rdk, rdv;     // all three token matrices requested now; dk / dv arrive while the dq GEMM runs
+  rows_fetch<T>((const T*)gr.dq + xo, L, rdq);
+  rows_fetch<T>((const T*)gr.dk + so, S, rdk);
+  rows_fetch<T>((const T*)gr.dv + so, S, rdv);
+  sched_fence();
+  rows_commit<T>(rdq, L, sm.bD, LDA);
   __syncthreads();
-  tok_gemm<T, LC, LC>(sm.bD, sm.bD, LC, LDA, w.wq, [&](int ct, f32x4 (&acc)[2]) RD_INLINE_LAMBDA {
+  tok_mma<T, LC, LC>(sm.bD, sm.bD, LC, LDA, Wq, [&](int ct, f32x4 (&acc)[2]) RD_INLINE_LAMBDA {
 #pragma unroll
     for (int tt = 0; tt < 2; tt++)
 #pragma unroll
@@ -358,9 +426,10 @@ __global__ __launch_bounds__(LNT) void loftr_layer_bwd_kernel(const T* __restric
   __syncthreads();
   LPROF(16)
   float* sacc = self ? sm.acc : sm.u.fh.f;
-  load_rows<T>((const T*)gr.dk + so, S, sm.bD, LDA);
+  rows_commit<T>(rdk, S, sm.bD, LDA);
   __syncthreads();
-  tok_gemm<T, LC, LC>(sm.bD, sm.bD, LC, LDA, w.wk, [&](int ct, f32x4 (&acc)[2]) RD_INLINE_LAMBDA {
+  if (!EARLY) tok_load<T, LC, LC>(w.wk, Wk);
+  tok_mma<T, LC, LC>(sm.bD, sm.bD, LC, LDA, Wk, [&](int ct, f32x4 (&acc)[2]) RD_INLINE_LAMBDA {
 #pragma unroll
     for (int tt = 0; tt < 2; tt++)
 #pragma unroll
@@ -372,9 +441,10 @@ __global__ __launch_bounds__(LNT) void loftr_layer_bwd_kernel(const T* __restric
   });
   __syncthreads();
   LPROF(17)
-  load_rows<T>((const T*)gr.dv + so, S, sm.bD, LDA);
+  rows_commit<T>(rdv, S, sm.bD, LDA);
   __syncthreads();
-  tok_gemm<T, LC, LC>(sm.bD, sm.bD, LC, LDA, w.wv, [&](int ct, f32x4 (&acc)[2]) RD_INLINE_LAMBDA {
+  if (!EARLY) tok_load<T, LC, LC>(w.wv, Wv);
+  tok_mma<T, LC, LC>(sm.bD, sm.bD, LC, LDA, Wv, [&](int ct, f32x4 (&acc)[2]) RD_INLINE_LAMBDA {
 #pragma unroll
     for (int tt = 0; tt < 2; tt++)
 #pragma unroll

@@ -19,7 +19,9 @@ if len(sys.argv) > 1 and sys.argv[1] == "build":
     print(PROF)
     sys.exit(0)
 
-os.environ["RIDERS_HIP_LIB"] = PROF
+PLAIN = os.environ.get("LOFTR_PLAIN") == "1"   # product library, no stamps (for rocprofv3 --pmc runs)
+if not PLAIN:
+    os.environ["RIDERS_HIP_LIB"] = PROF
 sys.path.insert(0, ROOT)
 import torch
 from riders_amd import engine, _lib
@@ -29,7 +31,7 @@ N = int(sys.argv[1]) if len(sys.argv) > 1 else 240
 L = int(sys.argv[2]) if len(sys.argv) > 2 else 21
 dev = torch.device("cuda:0")
 lib = _lib.load()
-raw = ctypes.CDLL(PROF)
+raw = None if PLAIN else ctypes.CDLL(PROF)
 layer = LoFTREncoderLayer(128, 8).to(dev)   # fp32 master parameters, bf16 activations
 names = {0: "load x/src", 1: "q,k,v GEMMs", 2: "attention", 3: "load att", 4: "merge GEMM", 5: "norm1", 6: "mlp0 GEMM", 7: "mlp2 GEMM", 8: "norm2+out",
          10: "norm2 bwd", 11: "dhid GEMM", 12: "dcat GEMM", 13: "norm1 bwd", 14: "datt GEMM", 15: "attention bwd", 16: "dq Wq", 17: "dk Wk", 18: "dv Wv",
@@ -40,13 +42,18 @@ for cross in (False, True):
     reps = 20
     for it in range(reps + 3):
         if it == 3:
-            torch.cuda.synchronize(); raw.rd_debug_loftr_prof(None, 1)
+            torch.cuda.synchronize()
+            if raw: raw.rd_debug_loftr_prof(None, 1)
         o = layer(x, s if cross else x)
         o.sum().backward()
     torch.cuda.synchronize()
+    if PLAIN:
+        continue
     buf = (ctypes.c_ulonglong * 32)()
     assert raw.rd_debug_loftr_prof(buf, 1) == 0
     print("cross" if cross else "self", "N=%d L=%d: mean per workgroup, us (100 MHz wall clock)" % (N, L))
     for i in sorted(names):
         print("  %-14s %7.2f" % (names[i], buf[i] / (reps * N) / 100.0))
+    print("  mlp0 per-wave, since phase start: after W2 issue %.2f | ct0 MFMAs done %.2f | ct0 stored %.2f | ct1 MFMAs done %.2f | ct1 stored %.2f | before barrier %.2f"
+          % tuple(buf[i] / (reps * N * 8) / 100.0 for i in (20, 21, 22, 23, 24, 25)))
     print("  fwd total %.2f   bwd total %.2f" % (sum(buf[i] for i in range(10)) / (reps * N) / 100.0, sum(buf[i] for i in range(10, 20)) / (reps * N) / 100.0))
