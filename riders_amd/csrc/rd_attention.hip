@@ -23,7 +23,7 @@ __global__ __launch_bounds__(256) void linear_attention_kernel(const T* __restri
   const int pair = blockIdx.x * 4 + wv;
   const bool active = pair < N * H;
   const int n = active ? pair / H : 0, h = active ? pair % H : 0;
-  attn_head<T, BWD>(sm[wv], q, k, v, dout, out, dq, dk, dv, n, h, active, L, S, ldq, ldk, ldv, ldo, eps);
+  attn_head<T, BWD>(sm[wv], q, k, v, dout, out, dq, dk, dv, n, h, active, L, S, ldq, ldk, ldv, ldo, eps, []() {});
 }
 
 void launch_linear_attention_fwd(const void* q, const void* k, const void* v, void* out, int N, int L, int S, int H, int ldq,

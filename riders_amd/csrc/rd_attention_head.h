@@ -19,7 +19,7 @@ __device__ __forceinline__ f32x4 wave_mm(const float* a, int ai, int ak, const f
 struct AttnSmem {
   float q[MAXR * LD], k[MAXR * LD], v[MAXR * LD], d[MAXR * LD];
   float kv[16 * LD], dkv[16 * LD];
-  float ksum[16], dksum[16], dden[MAXR];
+  float ksum[16], dksum[16], dden[MAXR], zinv[MAXR];
 };
 
 template <typename T>
@@ -38,13 +38,15 @@ __device__ __forceinline__ void stage_head(const T* __restrict__ src, int64_t ro
   }
 }
 
-// One wave, one (n, h) head.  `s` is this wave's LDS scratch; q/k/v/dout/out/dq/dk/dv are token matrices with leading dimensions
-// ldq/ldk/ldv/ldo (global memory).  Contains block-wide barriers: every wave of the block must call it the same number of times.
-template <typename T, bool BWD>
+// One wave, one (n, h) head.  `s` is this wave's PRIVATE LDS scratch; q/k/v/dout/out/dq/dk/dv are token matrices with leading
+// dimensions ldq/ldk/ldv/ldo (global memory).  Phases are ordered by wave_sync() (no block barrier on the GPU; a block barrier under
+// the host emulator): every wave of the block must call it the same number of times, and the caller owns any block-level ordering.
+// after_loads() runs right after the staging loads are issued (a caller's prefetch for its next phase goes behind them).
+template <typename T, bool BWD, typename Hook>
 __device__ __forceinline__ void attn_head(AttnSmem& s, const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v,
                                           const T* __restrict__ dout, T* __restrict__ out, T* __restrict__ dq, T* __restrict__ dk,
                                           T* __restrict__ dv, int n, int h, bool active, int L, int S, int ldq, int ldk, int ldv,
-                                          int ldo, float eps) {
+                                          int ldo, float eps, Hook after_loads) {
   const int lane = threadIdx.x & 63;
   const int r = lane & 15, g = lane >> 4;
   const int col0 = h * 16;
@@ -52,7 +54,7 @@ __device__ __forceinline__ void attn_head(AttnSmem& s, const T* __restrict__ q, 
   const int Lp = (L + 3) & ~3, Sp = (S + 3) & ~3;
   const int lt = (L + 15) >> 4, stl = (S + 15) >> 4;  // 16-row tiles
 
-  __syncthreads();  // a previous call's reads of this wave's scratch are complete before it is restaged (back-to-back calls)
+  wave_sync();  // a previous call's reads of this wave's scratch are complete before it is restaged (back-to-back calls)
   constexpr int VE = Elem<T>::VE;
   const bool vec = L > 0 && S > 0 && (ldq % VE == 0) && (ldk % VE == 0) && (ldv % VE == 0) && (!BWD || ldo % VE == 0) &&
                    (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (BWD ? (uintptr_t)dout : (uintptr_t)0)) & 15) == 0;
@@ -72,6 +74,8 @@ __device__ __forceinline__ void attn_head(AttnSmem& s, const T* __restrict__ q, 
       rd::ldv(v + (nn * S + rs) * ldv + cc0 + c, xv[i]);
       if (BWD) rd::ldv(dout + (nn * L + rl) * ldo + cc0 + c, xd[i]);
     }
+    sched_fence();
+    after_loads();
 #pragma unroll
     for (int i = 0; i < NIT; i++) {
       const int idx = lane + 64 * i, rr = idx / SPR, c = (idx - rr * SPR) * VE;
@@ -90,8 +94,9 @@ __device__ __forceinline__ void attn_head(AttnSmem& s, const T* __restrict__ q, 
     stage_head<T>(k, (int64_t)n * S, ldk, col0, S, s.k, 1, 1.f, active);
     stage_head<T>(v, (int64_t)n * S, ldv, col0, S, s.v, 0, 1.f / fS, active);
     if (BWD) stage_head<T>(dout, (int64_t)n * L, ldo, col0, L, s.d, 0, 1.f, active);
+    after_loads();
   }
-  __syncthreads();
+  wave_sync();
 
   // KV = K^T V  (16 x 16), Ksum
   {
@@ -105,21 +110,22 @@ __device__ __forceinline__ void attn_head(AttnSmem& s, const T* __restrict__ q, 
       s.ksum[lane] = t;
     }
   }
-  __syncthreads();
+  wave_sync();
 
-  // P = Q KV, normaliser
+  // normaliser, one token per lane (dd ascending from eps), then P = Q KV
+  if (lane < MAXR) {
+    float den = eps;
+    for (int dd = 0; dd < 16; dd++) den += s.q[lane * LD + dd] * s.ksum[dd];
+    s.zinv[lane] = 1.f / den;
+  }
+  wave_sync();
   f32x4 P[2]; float Z[2][4];
 #pragma unroll
   for (int tI = 0; tI < 2; tI++) {
     P[tI] = f32x4{0, 0, 0, 0};
     if (tI < lt) P[tI] = wave_mm(s.q + tI * 16 * LD, LD, 1, s.kv, LD, 1, 16, P[tI]);
 #pragma unroll
-    for (int e = 0; e < 4; e++) {
-      int l = tI * 16 + g * 4 + e;
-      float den = eps;
-      for (int dd = 0; dd < 16; dd++) den += s.q[l * LD + dd] * s.ksum[dd];
-      Z[tI][e] = 1.f / den;
-    }
+    for (int e = 0; e < 4; e++) Z[tI][e] = s.zinv[tI * 16 + g * 4 + e];
   }
 
   if (!BWD) {
@@ -147,7 +153,7 @@ __device__ __forceinline__ void attn_head(AttnSmem& s, const T* __restrict__ q, 
       s.d[l * LD + r] = fS * Z[tI][e] * dO;
       if (r == 0) s.dden[l] = -Z[tI][e] * Z[tI][e] * fS * dz;
     }
-  __syncthreads();
+  wave_sync();
 
   // dQ = dP KV^T + dden * Ksum ; dq = dQ * phi'(q)
 #pragma unroll
@@ -176,7 +182,7 @@ __device__ __forceinline__ void attn_head(AttnSmem& s, const T* __restrict__ q, 
       s.dksum[lane] = t;
     }
   }
-  __syncthreads();
+  wave_sync();
   // dK = V' dKV^T + dKsum ; dV' = K dKV
 #pragma unroll
   for (int tI = 0; tI < 2; tI++) {

@@ -124,6 +124,19 @@ __device__ __forceinline__ void sched_fence() {
 #endif
 }
 
+// Orders one wave's LDS traffic (lanes exchanging data through a wave-private LDS region): LDS operations of a wave execute in
+// order, so a wavefront-scope fence is enough and the other waves of the workgroup are not held up.  The host emulator runs lanes
+// as fibers, where only a block barrier orders them -- every wave of the block must therefore reach the same wave_sync() calls.
+__device__ __forceinline__ void wave_sync() {
+#ifdef RD_EMU
+  __syncthreads();
+#else
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#endif
+}
+
 // ---- wave / block reductions ---------------------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -159,6 +159,9 @@ __global__ __launch_bounds__(LNT) void loftr_layer_fwd_kernel(const T* __restric
   TokW<T, LC2, LC2> W0;
   TokW<T, LC2, LC> W2;
   constexpr bool EARLY = sizeof(T) == 2;   // fp32 fragments are twice the registers: its weights are fetched right before each GEMM
+  // LayerNorm parameters first: loads return in order, so requested behind a weight prefetch they would wait for all of it
+  const float lg1[2] = {w.g1[lane], w.g1[64 + lane]}, lb1[2] = {w.b1[lane], w.b1[64 + lane]};
+  const float lg2[2] = {w.g2[lane], w.g2[64 + lane]}, lb2[2] = {w.b2[lane], w.b2[64 + lane]};
   {
     RowsReg<T> rx, rs;
     rows_fetch<T>(x + xo, L, rx);
@@ -190,13 +193,13 @@ __global__ __launch_bounds__(LNT) void loftr_layer_fwd_kernel(const T* __restric
   tok_mma<T, LC, LC>(sp, sp, LC, LDA, Wk, to_global((T*)sv.k, so, S, LC));
   if (!EARLY) tok_load<T, LC, LC>(w.wv, Wv);
   tok_mma<T, LC, LC>(sp, sp, LC, LDA, Wv, to_global((T*)sv.v, so, S, LC));
-  tok_load<T, LC, LC>(w.wm, Wm);        // in flight across the attention phase
   __syncthreads();
   LPROF(1)
 
   // linear attention: wave wv owns head wv (q, k, v come back from L2; the head routine stages them per head)
   attn_head<T, false>(sm.u.at[wv], (const T*)sv.q, (const T*)sv.k, (const T*)sv.v, (const T*)nullptr, (T*)sv.att, (T*)nullptr,
-                      (T*)nullptr, (T*)nullptr, n, wv, true, L, S, LC, LC, LC, LC, eps_attn);
+                      (T*)nullptr, (T*)nullptr, n, wv, true, L, S, LC, LC, LC, LC, eps_attn,
+                      [&]() RD_INLINE_LAMBDA { tok_load<T, LC, LC>(w.wm, Wm); });   // merge weights: behind the staging loads, in flight across the phase
   __syncthreads();
   LPROF(2)
   load_rows<T>((const T*)sv.att + xo, L, sm.bS, LDA);
@@ -222,7 +225,7 @@ __global__ __launch_bounds__(LNT) void loftr_layer_fwd_kernel(const T* __restric
   LPROF(4)
 
   // LayerNorm (one wave per row, two channels per lane); which = 0: norm1 -> bM + saved message, 1: norm2 + residual -> out
-  auto ln_rows = [&](const float* gamma, const float* beta, int which) RD_INLINE_LAMBDA {
+  auto ln_rows = [&](const float (&gamma)[2], const float (&beta)[2], int which) RD_INLINE_LAMBDA {
     for (int r = wv; r < LTOK; r += LNW) {
       if (r >= L) {
         if (which == 0) { Elem<T>::st(&sm.bM[r * LDA + lane], 0.f); Elem<T>::st(&sm.bM[r * LDA + 64 + lane], 0.f); }
@@ -233,7 +236,7 @@ __global__ __launch_bounds__(LNT) void loftr_layer_fwd_kernel(const T* __restric
       const float d0 = v0 - mu, d1 = v1 - mu;
       const float var = wave_sum(d0 * d0 + d1 * d1) / (float)LC;
       const float rs = 1.0f / sqrtf(var + eps_ln);
-      float o0 = d0 * rs * gamma[lane] + beta[lane], o1 = d1 * rs * gamma[64 + lane] + beta[64 + lane];
+      float o0 = d0 * rs * gamma[0] + beta[0], o1 = d1 * rs * gamma[1] + beta[1];
       const int64_t go = xo + (int64_t)r * LC;
       if (which == 0) {
         Elem<T>::st(&sm.bM[r * LDA + lane], o0); Elem<T>::st(&sm.bM[r * LDA + 64 + lane], o1);
@@ -245,15 +248,13 @@ __global__ __launch_bounds__(LNT) void loftr_layer_fwd_kernel(const T* __restric
       if (lane == 0) { sv.stats[((int64_t)n * L + r) * 4 + which * 2] = mu; sv.stats[((int64_t)n * L + r) * 4 + which * 2 + 1] = rs; }
     }
   };
-  ln_rows(w.g1, w.b1, 0);
+  ln_rows(lg1, lb1, 0);
   __syncthreads();
   LPROF(5)
 
   // hidden = relu(W0 [x | message])
   tok_load<T, LC2, LC>(w.w2, W2);
-  LPROFW(20)
   tok_mma<T, LC2, LC2>(sm.bX, sm.bM, LC, LDA, W0, [&](int ct, f32x4 (&acc)[2]) RD_INLINE_LAMBDA {
-    if (ct < LNW) { LPROFW(21) } else { LPROFW(23) }
 #pragma unroll
     for (int tt = 0; tt < 2; tt++) {
       const int tok = tt * 16 + fr;
@@ -263,15 +264,13 @@ __global__ __launch_bounds__(LNT) void loftr_layer_fwd_kernel(const T* __restric
       st4(&sm.u.fh.h[tok * LDH + ct * 16 + fg * 4], v);
       if (tok < L) st4((T*)sv.hid + ((int64_t)n * L + tok) * LC2 + ct * 16 + fg * 4, v);
     }
-    if (ct < LNW) { LPROFW(22) } else { LPROFW(24) }
   });
-  LPROFW(25)
   __syncthreads();
   LPROF(6)
   tok_mma<T, LC2, LC>(sm.u.fh.h, sm.u.fh.h, LC2, LDH, W2, to_f((T*)sv.m2pre, L));
   __syncthreads();
   LPROF(7)
-  ln_rows(w.g2, w.b2, 1);
+  ln_rows(lg2, lb2, 1);
   LPROF(8)
 }
 
@@ -288,23 +287,39 @@ __global__ __launch_bounds__(LNT) void loftr_layer_bwd_kernel(const T* __restric
 
   // LayerNorm backward over the rows of this ROI.  d(row, c) supplies the upstream gradient, pre = saved pre-norm activation,
   // which selects the statistics; result -> bD (T) + saved copy for the weight gradient; per-ROI (sum d, sum d*xhat) -> lnp[n][c][2].
-  auto ln_bwd = [&](auto dfn, const T* pre, const float* gamma, int which, T* gout, float* lnp, bool seed_acc) RD_INLINE_LAMBDA {
+  auto ln_bwd = [&](auto dfn, const T* pre, const float (&gm)[2], int which, T* gout, float* lnp, bool seed_acc, auto after_loads) RD_INLINE_LAMBDA {
     float ag[2] = {0.f, 0.f}, ab[2] = {0.f, 0.f};
-    for (int r = wv; r < LTOK; r += LNW) {
+    constexpr int RPW = LTOK / LNW;   // rows per wave
+    // every global value of this wave's rows is requested before the first reduction (clamped row: no branch around the loads);
+    // row by row the loop was one round trip per row
+    float dv_[RPW][2], pv_[RPW][2], mu_[RPW], rs_[RPW];
+#pragma unroll
+    for (int j = 0; j < RPW; j++) {
+      const int rc = min(wv + j * LNW, L - 1);
+      const int64_t go = xo + (int64_t)rc * LC;
+      mu_[j] = sv.stats[((int64_t)n * L + rc) * 4 + which * 2]; rs_[j] = sv.stats[((int64_t)n * L + rc) * 4 + which * 2 + 1];
+#pragma unroll
+      for (int e = 0; e < 2; e++) { dv_[j][e] = dfn(rc, e * 64 + lane); pv_[j][e] = Elem<T>::ld(pre + go + e * 64 + lane); }
+    }
+    sched_fence();
+    after_loads();   // weight prefetch of the next GEMMs goes BEHIND this phase's own loads (loads return in order)
+#pragma unroll
+    for (int j = 0; j < RPW; j++) {
+      const int r = wv + j * LNW;
       if (r >= L) {
         Elem<T>::st(&sm.bD[r * LDA + lane], 0.f); Elem<T>::st(&sm.bD[r * LDA + 64 + lane], 0.f);
         if (seed_acc) { sm.acc[r * LF + lane] = 0.f; sm.acc[r * LF + 64 + lane] = 0.f; }
         continue;
       }
       const int64_t go = xo + (int64_t)r * LC;
-      const float mu = sv.stats[((int64_t)n * L + r) * 4 + which * 2], rs = sv.stats[((int64_t)n * L + r) * 4 + which * 2 + 1];
+      const float mu = mu_[j], rs = rs_[j];
       float d[2], xh[2], g[2];
 #pragma unroll
       for (int e = 0; e < 2; e++) {
         const int c = e * 64 + lane;
-        d[e] = dfn(r, c);
-        xh[e] = (Elem<T>::ld(pre + go + c) - mu) * rs;
-        g[e] = d[e] * gamma[c];
+        d[e] = dv_[j][e];
+        xh[e] = (pv_[j][e] - mu) * rs;
+        g[e] = d[e] * gm[e];
         ag[e] += d[e] * xh[e]; ab[e] += d[e];
         if (seed_acc) sm.acc[r * LF + c] = d[e];   // residual path: dx starts as the upstream gradient
       }
@@ -334,11 +349,11 @@ __global__ __launch_bounds__(LNT) void loftr_layer_bwd_kernel(const T* __restric
   TokW<T, LC2, LC2> W0;
   TokW<T, LC, LC> Wm, Wq, Wk, Wv;
   constexpr bool EARLY = sizeof(T) == 2;   // fp32 fragments are twice the registers: fewer GEMMs' weights in flight at once
-  tok_load<T, LC, LC2>(w.w2, W2);                 // in flight across the norm2 backward
-  if (EARLY) tok_load<T, LC2, LC2>(w.w0, W0);
+  const float lg1[2] = {w.g1[lane], w.g1[64 + lane]}, lg2[2] = {w.g2[lane], w.g2[64 + lane]};
   // 1. out = x + norm2(m2pre)
   const T* dout = (const T*)gr.dout;
-  ln_bwd([&](int r, int c) RD_INLINE_LAMBDA { return Elem<T>::ld(dout + xo + (int64_t)r * LC + c); }, (const T*)sv.m2pre, w.g2, 1, (T*)gr.dm2pre, gr.lnp2, true);
+  ln_bwd([&](int r, int c) RD_INLINE_LAMBDA { return Elem<T>::ld(dout + xo + (int64_t)r * LC + c); }, (const T*)sv.m2pre, lg2, 1, (T*)gr.dm2pre, gr.lnp2, true,
+         [&]() RD_INLINE_LAMBDA { tok_load<T, LC, LC2>(w.w2, W2); if (EARLY) tok_load<T, LC2, LC2>(w.w0, W0); });   // in flight across the norm2 backward
   __syncthreads();
   LPROF(10)
 
@@ -363,7 +378,6 @@ __global__ __launch_bounds__(LNT) void loftr_layer_bwd_kernel(const T* __restric
 
   // 3. dcat = dhid W0: channels [0,128) add into dx, [128,256) are the gradient of the normalised message
   if (!EARLY) tok_load<T, LC2, LC2>(w.w0, W0);
-  tok_load<T, LC, LC>(w.wm, Wm);
   tok_mma<T, LC2, LC2>(sm.u.fh.h, sm.u.fh.h, LC2, LDH, W0, [&](int ct, f32x4 (&acc)[2]) RD_INLINE_LAMBDA {
 #pragma unroll
     for (int tt = 0; tt < 2; tt++) {
@@ -380,7 +394,8 @@ __global__ __launch_bounds__(LNT) void loftr_layer_bwd_kernel(const T* __restric
   LPROF(12)
 
   // 4. message = norm1(mpre)
-  ln_bwd([&](int r, int c) RD_INLINE_LAMBDA { return sm.u.fh.f[r * LF + c]; }, (const T*)sv.mpre, w.g1, 0, (T*)gr.dmpre, gr.lnp1, false);
+  ln_bwd([&](int r, int c) RD_INLINE_LAMBDA { return sm.u.fh.f[r * LF + c]; }, (const T*)sv.mpre, lg1, 0, (T*)gr.dmpre, gr.lnp1, false,
+         [&]() RD_INLINE_LAMBDA { tok_load<T, LC, LC>(w.wm, Wm); });
   __syncthreads();
   LPROF(13)
 
@@ -398,14 +413,13 @@ __global__ __launch_bounds__(LNT) void loftr_layer_bwd_kernel(const T* __restric
     };
   };
   tok_mma<T, LC, LC>(sm.bD, sm.bD, LC, LDA, Wm, to_global((T*)gr.datt, xo, L));
-  tok_load<T, LC, LC>(w.wq, Wq);                  // in flight across the attention backward
-  if (EARLY) { tok_load<T, LC, LC>(w.wk, Wk); tok_load<T, LC, LC>(w.wv, Wv); }
   __syncthreads();
   LPROF(14)
 
   // 6. attention backward (recomputes KV / P from the saved q, k, v)
   attn_head<T, true>(sm.u.at[wv], (const T*)sv.q, (const T*)sv.k, (const T*)sv.v, (const T*)gr.datt, (T*)nullptr, (T*)gr.dq,
-                     (T*)gr.dk, (T*)gr.dv, n, wv, true, L, S, LC, LC, LC, LC, eps_attn);
+                     (T*)gr.dk, (T*)gr.dv, n, wv, true, L, S, LC, LC, LC, LC, eps_attn,
+                     [&]() RD_INLINE_LAMBDA { tok_load<T, LC, LC>(w.wq, Wq); if (EARLY) { tok_load<T, LC, LC>(w.wk, Wk); tok_load<T, LC, LC>(w.wv, Wv); } });
   __syncthreads();
   LPROF(15)
 

@@ -31,17 +31,20 @@ N = int(sys.argv[1]) if len(sys.argv) > 1 else 240
 L = int(sys.argv[2]) if len(sys.argv) > 2 else 21
 dev = torch.device("cuda:0")
 lib = _lib.load()
+DT = torch.float32 if os.environ.get("LOFTR_DTYPE") == "fp32" else torch.bfloat16
+engine.set_compute_dtype("fp32" if DT == torch.float32 else "bf16")
 raw = None if PLAIN else ctypes.CDLL(PROF)
 layer = LoFTREncoderLayer(128, 8).to(dev)   # fp32 master parameters, bf16 activations
 names = {0: "load x/src", 1: "q,k,v GEMMs", 2: "attention", 3: "load att", 4: "merge GEMM", 5: "norm1", 6: "mlp0 GEMM", 7: "mlp2 GEMM", 8: "norm2+out",
          10: "norm2 bwd", 11: "dhid GEMM", 12: "dcat GEMM", 13: "norm1 bwd", 14: "datt GEMM", 15: "attention bwd", 16: "dq Wq", 17: "dk Wk", 18: "dv Wv",
          19: "store"}
-for cross in (False, True):
-    x = torch.randn(N, L, 128, device=dev, dtype=torch.bfloat16).requires_grad_()
-    s = torch.randn(N, L, 128, device=dev, dtype=torch.bfloat16).requires_grad_()
-    reps = 20
-    for it in range(reps + 3):
-        if it == 3:
+for cross in ((False,) if PLAIN else (False, True)):
+    x = torch.randn(N, L, 128, device=dev, dtype=DT).requires_grad_()
+    s = torch.randn(N, L, 128, device=dev, dtype=DT).requires_grad_()
+    reps = int(os.environ.get("LOFTR_REPS", "20"))
+    warm = 3 if reps > 2 else 0
+    for it in range(reps + warm):
+        if it == warm:
             torch.cuda.synchronize()
             if raw: raw.rd_debug_loftr_prof(None, 1)
         o = layer(x, s if cross else x)
@@ -54,6 +57,4 @@ for cross in (False, True):
     print("cross" if cross else "self", "N=%d L=%d: mean per workgroup, us (100 MHz wall clock)" % (N, L))
     for i in sorted(names):
         print("  %-14s %7.2f" % (names[i], buf[i] / (reps * N) / 100.0))
-    print("  mlp0 per-wave, since phase start: after W2 issue %.2f | ct0 MFMAs done %.2f | ct0 stored %.2f | ct1 MFMAs done %.2f | ct1 stored %.2f | before barrier %.2f"
-          % tuple(buf[i] / (reps * N * 8) / 100.0 for i in (20, 21, 22, 23, 24, 25)))
     print("  fwd total %.2f   bwd total %.2f" % (sum(buf[i] for i in range(10)) / (reps * N) / 100.0, sum(buf[i] for i in range(10, 20)) / (reps * N) / 100.0))
