@@ -186,6 +186,7 @@ __global__ __launch_bounds__(256) void conv3x3_patch_kernel(ConvArgs a, int tile
 constexpr int small_min_waves(int spp, int bn) {
   const int steps = (9 * spp + 3) / 4, ct = bn / 16;
   const int lds = 2 * 180 * spp * 16 + (ct * steps > 5 ? ct * steps * 1024 : 0) + 4 * bn * 8;
+  if (spp == 2 && bn == 32) return 3;                  // 128 VGPRs spill (60 bytes of scratch inside the tile loop): three waves, 168 VGPRs
   return (bn < 64 && lds * 4 <= 160 * 1024) ? 4 : 2;   // 64-channel tiles keep 64 accumulator + epilogue registers: two waves
 }
 template <int SPP>
