@@ -20,12 +20,32 @@ typedef short s16x8 __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ float bf16_to_f32(unsigned short h) {
   return __uint_as_float(((unsigned)h) << 16);
 }
-// round-to-nearest-even, NaN preserved
+// round-to-nearest-even, NaN preserved.  gfx950 has the conversion in hardware (v_cvt_pk_bf16_f32, two values per instruction); the
+// integer sequence (7 VALU instructions per value) is what the host emulator runs and what the epilogues used to spend their time on.
 __device__ __forceinline__ unsigned short f32_to_bf16(float f) {
+#ifdef RD_EMU
   unsigned u = __float_as_uint(f);
   if ((u & 0x7fffffffu) > 0x7f800000u) return (unsigned short)((u >> 16) | 0x40);
   u += 0x7fffu + ((u >> 16) & 1u);
   return (unsigned short)(u >> 16);
+#else
+  const __bf16 b = (__bf16)f;
+  unsigned short h; __builtin_memcpy(&h, &b, 2);
+  return h;
+#endif
+}
+// two values -> one 32-bit word (lo in bits 0..15)
+__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
+#ifdef RD_EMU
+  return (unsigned)f32_to_bf16(lo) | ((unsigned)f32_to_bf16(hi) << 16);
+#else
+  typedef __bf16 rd_bf2 __attribute__((ext_vector_type(2)));
+  typedef float rd_f2 __attribute__((ext_vector_type(2)));
+  const rd_f2 v = {lo, hi};
+  const rd_bf2 b = __builtin_convertvector(v, rd_bf2);
+  unsigned u; __builtin_memcpy(&u, &b, 4);
+  return u;
+#endif
 }
 
 template <typename T> struct Elem;
@@ -57,8 +77,8 @@ __device__ __forceinline__ void st4(float* p, const float (&o)[4]) {
 }
 __device__ __forceinline__ void st4(bf16_t* p, const float (&o)[4]) {
   uint2 v;
-  v.x = (unsigned)f32_to_bf16(o[0]) | ((unsigned)f32_to_bf16(o[1]) << 16);
-  v.y = (unsigned)f32_to_bf16(o[2]) | ((unsigned)f32_to_bf16(o[3]) << 16);
+  v.x = pack_bf16x2(o[0], o[1]);
+  v.y = pack_bf16x2(o[2], o[3]);
   *reinterpret_cast<uint2*>(p) = v;
 }
 
@@ -74,10 +94,10 @@ __device__ __forceinline__ void ldv(const bf16_t* p, float (&o)[8]) {
 }
 __device__ __forceinline__ void stv(bf16_t* p, const float (&o)[8]) {
   uint4 v;
-  v.x = (unsigned)f32_to_bf16(o[0]) | ((unsigned)f32_to_bf16(o[1]) << 16);
-  v.y = (unsigned)f32_to_bf16(o[2]) | ((unsigned)f32_to_bf16(o[3]) << 16);
-  v.z = (unsigned)f32_to_bf16(o[4]) | ((unsigned)f32_to_bf16(o[5]) << 16);
-  v.w = (unsigned)f32_to_bf16(o[6]) | ((unsigned)f32_to_bf16(o[7]) << 16);
+  v.x = pack_bf16x2(o[0], o[1]);
+  v.y = pack_bf16x2(o[2], o[3]);
+  v.z = pack_bf16x2(o[4], o[5]);
+  v.w = pack_bf16x2(o[6], o[7]);
   *reinterpret_cast<uint4*>(p) = v;
 }
 
