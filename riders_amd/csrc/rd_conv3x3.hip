@@ -186,8 +186,10 @@ __global__ __launch_bounds__(256) void conv3x3_patch_kernel(ConvArgs a, int tile
 constexpr int small_min_waves(int spp, int bn) {
   const int steps = (9 * spp + 3) / 4, ct = bn / 16;
   const int lds = 2 * 180 * spp * 16 + (ct * steps > 5 ? ct * steps * 1024 : 0) + 4 * bn * 8;
-  if (spp == 2 && bn == 32) return 3;                  // 128 VGPRs spill (60 bytes of scratch inside the tile loop): three waves, 168 VGPRs
-  return (bn < 64 && lds * 4 <= 160 * 1024) ? 4 : 2;   // 64-channel tiles keep 64 accumulator + epilogue registers: two waves
+  // most blocks per CU whose LDS fits; 64-channel tiles keep 64 accumulator + epilogue registers, i.e. at most three waves (168 VGPRs)
+  for (int k = (bn >= 64 ? 3 : 4); k > 2; k--)
+    if (lds * k <= 160 * 1024) return k;
+  return 2;
 }
 template <int SPP>
 __device__ __forceinline__ int patch_slot(int p, int j) { return p * SPP + (j ^ ((p / (16 / SPP)) % SPP)); }
@@ -243,18 +245,35 @@ __global__ __launch_bounds__(256, small_min_waves(SPP, BN)) void conv3x3_small_k
     c.n += step.n;
     return c;
   };
+  // This thread's patch slots are the same for every tile: pixel (py, px) of the patch, source tensor and channel offset are decoded
+  // once; per tile only the bounds test and one 64-bit multiply-add remain (the general gather, conv_src_ptr, re-derived all of it per
+  // load -- ~75 VALU instructions each in a VALU-bound kernel).  dil == 1 here (geom3x3); pixel indices fit 32 bits (conv3x3_small_ok).
+  int spy[PIT], spx[PIT], sC[PIT]; const T* sbase[PIT]; bool sok[PIT];
+#pragma unroll
+  for (int i = 0; i < PIT; i++) {
+    const int idx = t + 256 * i;
+    sok[i] = idx < NSLOT;
+    const int pp = idx / SPP, sl = idx - pp * SPP;
+    spy[i] = pp / WT - 1; spx[i] = pp - (pp / WT) * WT - 1;
+    const int ci = sl * VE;
+    if (ci < a.C1) { sbase[i] = (const T*)a.src1 + ci; sC[i] = a.C1; }
+    else { sbase[i] = (const T*)a.src2 + (ci - a.C1); sC[i] = a.C2; }
+  }
+  const int Hp = a.ups ? a.H1 : a.Hin, Wp = a.ups ? a.W1 : a.Win;
   auto load_patch = [&](TC tc, uint4 (&rp)[PIT]) RD_INLINE_LAMBDA {
-    const int n = tc.n;
-    const int oh0 = tc.th * TH, ow0 = tc.tw * TW;
+    const int oh0 = tc.th * TH, ow0 = tc.tw * TW, nb = tc.n * Hp;
 #pragma unroll
     for (int i = 0; i < PIT; i++) {
-      int idx = t + 256 * i;
       uint4 v = make_uint4(0, 0, 0, 0);
-      if (idx < NSLOT) {
-        int pp = idx / SPP, sl = idx - pp * SPP;
-        int py = pp / WT, px = pp - py * WT;
-        const T* p;
-        if (conv_src_ptr<T>(a, n, oh0 - 1 + py, ow0 - 1 + px, sl * VE, p)) v = *reinterpret_cast<const uint4*>(p);
+      const int ih = oh0 + spy[i], iw = ow0 + spx[i];
+      if (sok[i] && (unsigned)ih < (unsigned)a.Hin && (unsigned)iw < (unsigned)a.Win) {
+        int hs = ih, ws = iw;
+        if (a.ups) {  // F.interpolate(mode='nearest') source index, ATen float formula (as conv_src_ptr)
+          hs = min((int)floorf((float)ih * a.scale_h), a.H1 - 1);
+          ws = min((int)floorf((float)iw * a.scale_w), a.W1 - 1);
+        }
+        const int pix = (nb + hs) * Wp + ws;
+        v = *reinterpret_cast<const uint4*>(sbase[i] + (int64_t)pix * sC[i]);
       }
       rp[i] = v;
     }
@@ -498,6 +517,7 @@ bool conv3x3_small_ok(const ConvArgs& a, int dtype) {
   const int Cin = a.C1 + a.C2, es = dtype == 0 ? 4 : 2, ve = 16 / es;
   const int cb = Cin * es;
   if (!geom3x3(a) || (cb != 32 && cb != 64 && cb != 128) || (a.C1 % ve) != 0) return false;
+  if ((int64_t)a.N * a.Hin * a.Win >= (int64_t)1 << 31) return false;   // the kernel keeps pixel indices in 32 bits
   return cb == 128 ? a.Cout <= 16 : a.Cout <= 64;
 }
 int conv3x3_small_blocks(const ConvArgs& a, int dtype) {   // persistent blocks = BatchNorm statistics rows of this path

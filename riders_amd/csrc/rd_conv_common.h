@@ -37,41 +37,60 @@ __device__ __forceinline__ bool conv_src_ptr(const ConvArgs& a, int n, int ih, i
 // Part 1 stores the tile and ADDS its values into the caller's per-lane statistics registers; part 2 reduces those registers over
 // the block and writes one statistics row.  One-tile-per-block kernels call both per tile; persistent kernels keep the registers across
 // their tiles and call part 2 once (one row per block instead of one per tile: 45 000 -> 1024 rows on RC-Net's ROI-resolution layers).
+// 4 consecutive channels: round to T once, hand back the rounded values (BatchNorm statistics are taken over what is stored)
+__device__ __forceinline__ void round_store4(float* d, const float (&x)[4], float (&xr)[4]) {
+  *reinterpret_cast<float4*>(d) = make_float4(x[0], x[1], x[2], x[3]);
+#pragma unroll
+  for (int r = 0; r < 4; r++) xr[r] = x[r];
+}
+__device__ __forceinline__ void round_store4(bf16_t* d, const float (&x)[4], float (&xr)[4]) {
+  uint2 u;
+  u.x = pack_bf16x2(x[0], x[1]); u.y = pack_bf16x2(x[2], x[3]);
+  xr[0] = __uint_as_float(u.x << 16); xr[1] = __uint_as_float(u.x & 0xffff0000u);
+  xr[2] = __uint_as_float(u.y << 16); xr[3] = __uint_as_float(u.y & 0xffff0000u);
+  *reinterpret_cast<uint2*>(d) = u;
+}
+
+// The narrow RC-Net layers are VALU-bound in this routine (rocprofv3: ~380 VALU instructions per wave and 128-pixel tile, 4 cycles
+// each), so everything uniform is decided once: no bias / no activation (every BatchNorm-ed convolution) skips both per element,
+// invalid pixels skip the whole channel loop, the destination row pointers are formed once per pixel, and a value is rounded once.
 template <typename T, int CT>
 __device__ __forceinline__ void conv_epilogue_store(const ConvArgs& a, f32x4 (&acc)[CT][2], const int64_t (&m)[2], const bool (&mv)[2], int n0,
                                                     int wn, int fr, int fg, float (&ssum)[CT][4], float (&ssq)[CT][4]) {
   const int D2 = a.Cout - a.D1;
   const bool vec_ok = ((a.D1 & 3) == 0) && ((D2 & 3) == 0);
+  const bool has_bias = a.bias != nullptr;
+  const bool plain = !has_bias && a.act == ACT_NONE;
 #pragma unroll
   for (int pt = 0; pt < 2; pt++) {
+    if (!mv[pt]) continue;
+    T* const p1 = (T*)a.dst1 + m[pt] * a.D1;
+    T* const p2 = (T*)a.dst2 + m[pt] * D2 - a.D1;     // indexed by the global channel (only dereferenced for co >= D1)
 #pragma unroll
     for (int c = 0; c < CT; c++) {
       const int co = n0 + (wn * CT + c) * 16 + fg * 4;
-      float v[4];
+      float x[4], xr[4];
 #pragma unroll
-      for (int r = 0; r < 4; r++) {
-        float x = acc[c][pt][r];
-        if (a.bias && co + r < a.Cout) x += a.bias[co + r];
-        x = act_fwd(x, a.act, a.slope);
-        x = Elem<T>::rnd(x);
-        v[r] = x;
-        if (mv[pt]) { ssum[c][r] += x; ssq[c][r] += x * x; }
-      }
-      if (mv[pt] && co < a.Cout) {
-        if (vec_ok && co + 3 < a.Cout) {
-          T* d = (co < a.D1) ? ((T*)a.dst1 + m[pt] * a.D1 + co) : ((T*)a.dst2 + m[pt] * D2 + (co - a.D1));
-          st4(d, v);
-        } else {
+      for (int r = 0; r < 4; r++) x[r] = acc[c][pt][r];
+      if (!plain) {
 #pragma unroll
-          for (int r = 0; r < 4; r++) {
-            int cc = co + r;
-            if (cc < a.Cout) {
-              T* d = (cc < a.D1) ? ((T*)a.dst1 + m[pt] * a.D1 + cc) : ((T*)a.dst2 + m[pt] * D2 + (cc - a.D1));
-              Elem<T>::st(d, v[r]);
-            }
-          }
+        for (int r = 0; r < 4; r++) {
+          if (has_bias && co + r < a.Cout) x[r] += a.bias[co + r];
+          x[r] = act_fwd(x[r], a.act, a.slope);
         }
       }
+      if (vec_ok && co + 3 < a.Cout) {
+        round_store4((co < a.D1 ? p1 : p2) + co, x, xr);
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          xr[r] = Elem<T>::rnd(x[r]);
+          const int cc = co + r;
+          if (cc < a.Cout) Elem<T>::st((cc < a.D1 ? p1 : p2) + cc, xr[r]);
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 4; r++) { ssum[c][r] += xr[r]; ssq[c][r] += xr[r] * xr[r]; }
     }
   }
 }
