@@ -36,19 +36,40 @@ __global__ __launch_bounds__(256) void conv3x3_patch_kernel(ConvArgs a, int tile
   const int oh0 = th_ * TH, ow0 = tw_ * TW;
   const int nchunk = Cin / CKE;
 
-  // patch staging role: idx = t + 256*i -> pixel pp = idx >> 3, 16-byte slot = idx & 7
+  // patch staging role: idx = t + 256*i -> pixel pp = idx >> 3, 16-byte slot = idx & 7 (= t & 7 for every i).  A block owns ONE tile, so
+  // the source pixel of each of this thread's slots is decoded once (bounds, nearest-upsample index; -1 = padding) and a chunk only
+  // picks the source tensor for its channel offset: one 64-bit multiply-add per load instead of the general gather (conv_src_ptr,
+  // ~45 VALU instructions per load -- a quarter of the issue cycles of this kernel next to its MFMAs).  dil == 1 (geom3x3); pixel
+  // indices fit 32 bits (conv3x3_ok).
   uint4 rp[PIT], rb[BITER];
-  auto load_patch = [&](int chunk) RD_INLINE_LAMBDA {
+  int spix[PIT];
+  {
+    const int Hp = a.ups ? a.H1 : a.Hin, Wp = a.ups ? a.W1 : a.Win;
 #pragma unroll
     for (int i = 0; i < PIT; i++) {
-      int idx = t + 256 * i;
-      int pp = idx >> 3, sl = idx & 7;
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (pp < NP) {
-        int py = pp / WT, px = pp - py * WT;
-        const T* p;
-        if (conv_src_ptr<T>(a, n, oh0 - 1 + py, ow0 - 1 + px, chunk * CKE + sl * VE, p)) v = *reinterpret_cast<const uint4*>(p);
+      const int pp = (t + 256 * i) >> 3;
+      const int py = pp / WT, px = pp - py * WT;
+      const int ih = oh0 - 1 + py, iw = ow0 - 1 + px;
+      int pix = -1;
+      if (pp < NP && (unsigned)ih < (unsigned)a.Hin && (unsigned)iw < (unsigned)a.Win) {
+        int hs = ih, ws = iw;
+        if (a.ups) {  // F.interpolate(mode='nearest') source index, ATen float formula (as conv_src_ptr)
+          hs = min((int)floorf((float)ih * a.scale_h), a.H1 - 1);
+          ws = min((int)floorf((float)iw * a.scale_w), a.W1 - 1);
+        }
+        pix = (n * Hp + hs) * Wp + ws;
       }
+      spix[i] = pix;
+    }
+  }
+  auto load_patch = [&](int chunk) RD_INLINE_LAMBDA {
+    const int ci = chunk * CKE + (t & 7) * VE;
+    const T* cb; int cs;
+    if (ci < a.C1) { cb = (const T*)a.src1 + ci; cs = a.C1; } else { cb = (const T*)a.src2 + (ci - a.C1); cs = a.C2; }
+#pragma unroll
+    for (int i = 0; i < PIT; i++) {
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (spix[i] >= 0) v = *reinterpret_cast<const uint4*>(cb + (int64_t)spix[i] * cs);
       rp[i] = v;
     }
   };
@@ -477,6 +498,7 @@ static int pick_bn3(int cout) { return cout <= 16 ? 16 : (cout <= 32 ? 32 : (cou
 bool conv3x3_ok(const ConvArgs& a, int dtype) {
   const int Cin = a.C1 + a.C2;
   const int ve = dtype == 0 ? 4 : 8, cke = dtype == 0 ? 32 : 64;
+  if ((int64_t)a.N * a.Hin * a.Win >= (int64_t)1 << 31) return false;   // the kernel keeps source pixel indices in 32 bits
   return a.KH == 3 && a.KW == 3 && a.stride == 1 && a.pad == 1 && a.dil == 1 && a.OH == a.Hin && a.OW == a.Win && (Cin % cke == 0) &&
          (a.C1 % ve == 0);
 }

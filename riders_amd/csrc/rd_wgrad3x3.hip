@@ -41,9 +41,6 @@ __global__ __launch_bounds__(256, (CTI * RT <= 2) ? 4 : 2) void conv3x3_wgrad_tr
   // wide layers: blockIdx.y picks a (CIN input channels) x (COP output channels) slice of the gradient; every slice walks all tiles
   const int ci0 = ((int)blockIdx.y % nci) * CIN, co0 = ((int)blockIdx.y / nci) * COP;
   const int CinT = a.C1 + a.C2;
-  ConvArgs g;
-  g.src1 = a.src1; g.src2 = a.src2; g.Hin = a.Hin; g.Win = a.Win; g.C1 = a.C1; g.C2 = a.C2; g.H1 = a.H1; g.W1 = a.W1;
-  g.dil = 1; g.ups = a.ups; g.scale_h = a.scale_h; g.scale_w = a.scale_w;
 
   // persistent tile walk: XCD x owns a contiguous range of tiles (halo pixels shared by neighbouring tiles stay in its L2)
   const int ntiles = a.N * tilesH * tilesW;
@@ -85,39 +82,63 @@ __global__ __launch_bounds__(256, (CTI * RT <= 2) ? 4 : 2) void conv3x3_wgrad_tr
     c.n += tstep.n;
     return c;
   };
+  // This thread's x / dy slots are the same for every tile: patch pixel, channel offset and source tensor are decoded once and packed
+  // into two registers per slot; per tile a slot costs a bounds test and one 64-bit multiply-add (the general gather re-derived all
+  // of it per load, ~45 VALU instructions, in a kernel that is issue bound).  Pixel indices fit 32 bits (wgrad3x3_tr_ok).
+  int xpk[XIT], xco[XIT];   // (py-1 + 1) << 8 | (px-1 + 1) | source-2 flag << 16 | valid << 17;  channel offset inside the source
+#pragma unroll
+  for (int i = 0; i < XIT; i++) {
+    const int idx = t + 256 * i;
+    const int pp = idx / XS, sl = idx - pp * XS;
+    const int py = pp / WT, px = pp - py * WT;
+    const int ci = ci0 + sl * 8;
+    const bool s2 = ci >= a.C1;
+    xpk[i] = (py << 8) | px | (s2 ? 1 << 16 : 0) | (idx < NXS ? 1 << 17 : 0);
+    xco[i] = s2 ? ci - a.C1 : ci;
+  }
+  int ypk[YIT];             // py << 8 | px | valid << 16 (valid = slot exists and its 8 channels start inside Cout)
+#pragma unroll
+  for (int i = 0; i < YIT; i++) {
+    const int idx = t + 256 * i;
+    const int pp = idx / YS, sl = idx - pp * YS;
+    const int py = pp / TW, px = pp - py * TW;
+    ypk[i] = (py << 8) | px | ((idx < NYS && co0 + sl * 8 < a.Cout) ? 1 << 16 : 0) | (sl << 20);
+  }
+  const int Hp = a.ups ? a.H1 : a.Hin, Wp = a.ups ? a.W1 : a.Win;
   auto fetch = [&](TC tc, uint4 (&rx)[XIT], uint4 (&ry)[YIT]) RD_INLINE_LAMBDA {
     const int n = tc.n;
     const int oh0 = tc.th * TH, ow0 = tc.tw * TW;
 #pragma unroll
     for (int i = 0; i < XIT; i++) {
-      const int idx = t + 256 * i;
       uint4 v = make_uint4(0, 0, 0, 0);
-      if (idx < NXS) {
-        const int pp = idx / XS, sl = idx - pp * XS;
-        const int py = pp / WT, px = pp - py * WT;
-        const T* p;
-        if (conv_src_ptr<T>(g, n, oh0 - 1 + py, ow0 - 1 + px, ci0 + sl * 8, p)) v = *reinterpret_cast<const uint4*>(p);
+      const int ih = oh0 - 1 + ((xpk[i] >> 8) & 0xff), iw = ow0 - 1 + (xpk[i] & 0xff);
+      if ((xpk[i] >> 17) && (unsigned)ih < (unsigned)a.Hin && (unsigned)iw < (unsigned)a.Win) {
+        int hs = ih, ws = iw;
+        if (a.ups) {  // F.interpolate(mode='nearest') source index, ATen float formula (as conv_src_ptr)
+          hs = min((int)floorf((float)ih * a.scale_h), a.H1 - 1);
+          ws = min((int)floorf((float)iw * a.scale_w), a.W1 - 1);
+        }
+        const int pix = (n * Hp + hs) * Wp + ws;
+        const bool s2 = (xpk[i] >> 16) & 1;
+        const T* sb = s2 ? (const T*)a.src2 : (const T*)a.src1;
+        v = *reinterpret_cast<const uint4*>(sb + (int64_t)pix * (s2 ? a.C2 : a.C1) + xco[i]);
       }
       rx[i] = v;
     }
 #pragma unroll
     for (int i = 0; i < YIT; i++) {
-      const int idx = t + 256 * i;
       uint4 v = make_uint4(0, 0, 0, 0);
-      if (idx < NYS) {
-        const int pp = idx / YS, sl = idx - pp * YS;
-        const int py = pp / TW, px = pp - py * TW;
-        const int oh = oh0 + py, ow = ow0 + px;
-        if (oh < a.OH && ow < a.OW && co0 + sl * 8 < a.Cout) {
-          const T* p = (const T*)a.dy + (((int64_t)n * a.OH + oh) * a.OW + ow) * a.Cout + co0 + sl * 8;
-          if (yvec) v = *reinterpret_cast<const uint4*>(p);
-          else {  // Cout not a multiple of 8 (the 1-channel head): element-wise, zero padded
-            unsigned short e[8];
+      const int oh = oh0 + ((ypk[i] >> 8) & 0xff), ow = ow0 + (ypk[i] & 0xff);
+      if (((ypk[i] >> 16) & 1) && oh < a.OH && ow < a.OW) {
+        const int sl = ypk[i] >> 20;
+        const T* p = (const T*)a.dy + (int64_t)((n * a.OH + oh) * a.OW + ow) * a.Cout + co0 + sl * 8;
+        if (yvec) v = *reinterpret_cast<const uint4*>(p);
+        else {  // Cout not a multiple of 8 (the 1-channel head): element-wise, zero padded
+          unsigned short e[8];
 #pragma unroll
-            for (int q = 0; q < 8; q++) e[q] = (co0 + sl * 8 + q < a.Cout) ? p[q].v : (unsigned short)0;
-            v.x = e[0] | ((unsigned)e[1] << 16); v.y = e[2] | ((unsigned)e[3] << 16);
-            v.z = e[4] | ((unsigned)e[5] << 16); v.w = e[6] | ((unsigned)e[7] << 16);
-          }
+          for (int q = 0; q < 8; q++) e[q] = (co0 + sl * 8 + q < a.Cout) ? p[q].v : (unsigned short)0;
+          v.x = e[0] | ((unsigned)e[1] << 16); v.y = e[2] | ((unsigned)e[3] << 16);
+          v.z = e[4] | ((unsigned)e[5] << 16); v.w = e[6] | ((unsigned)e[7] << 16);
         }
       }
       ry[i] = v;
@@ -216,6 +237,7 @@ static bool tr_geom(const WgradArgs& a) {
 static bool tr_narrow(const WgradArgs& a) { const int Cin = a.C1 + a.C2; return (Cin == 16 || Cin == 32 || Cin == 64) && a.Cout <= 32; }
 bool wgrad3x3_tr_ok(const WgradArgs& a, int dtype) {
   if (dtype != 1 || !tr_geom(a)) return false;
+  if ((int64_t)a.N * a.Hin * a.Win >= (int64_t)1 << 31) return false;   // the kernel keeps pixel indices in 32 bits
   if (tr_narrow(a)) return true;
   const int Cin = a.C1 + a.C2;
   if (Cin % 64 != 0 || a.Cout % 8 != 0) return false;
