@@ -363,10 +363,18 @@ __global__ __launch_bounds__(256) void roi_pool_bwd_tile_kernel(const T* __restr
         const int pw_lo = max((int)floorf((float)(w0 - q.sw - 1) / q.bw) - 1, 0), pw_hi = min((int)ceilf((float)(w0 + RPB_T - q.sw) / q.bw), PW - 1);
         const int nph = ph_hi - ph_lo + 1, npw = pw_hi - pw_lo + 1;
         if (nph <= 0 || npw <= 0) continue;
-        const int items = nph * npw * GC;
-        for (int it = t; it < items; it += 256) {
-          const int g = it % GC; const int bq = it / GC;
-          const int pw = pw_lo + bq % npw, ph = ph_lo + bq / npw;
+        // thread = (channel group g, bin lane tb); the bin index advances by NB per iteration and (ph, pw) follow by carries instead of
+        // two runtime divisions by npw per item (measured neutral on the step: the LDS atomics dominate this kernel)
+        constexpr int NB = 256 / GC;
+        static_assert(256 % GC == 0, "bin lanes");
+        const int g = t % GC, tb = t / GC;
+        const int nbins = nph * npw;
+        const int dph = NB / npw, dpw = NB - dph * npw;
+        int phi = tb / npw, pwi = tb - phi * npw;
+        for (int bq = tb; bq < nbins; bq += NB) {
+          const int pw = pw_lo + pwi, ph = ph_lo + phi;
+          pwi += dpw; phi += dph;
+          if (pwi >= npw) { pwi -= npw; phi++; }
           const int64_t o = (((int64_t)q.r * PH + ph) * PW + pw) * C + c0 + g * VE;
           int am[VE];
 #pragma unroll

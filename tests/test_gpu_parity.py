@@ -233,3 +233,26 @@ def test_direct_pointwise_conv(gpu):
         P.bf16_exact_conv_case(gpu, cin=48, cout=288, k=1, s=1, H=7, W=19, N=1)                   # bf16: two k-steps, three channel blocks
         P.bf16_exact_conv_case(gpu, cin=64, cout=8, k=1, s=1, H=10, W=13, N=1)
     P.bf16_exact_conv_case(gpu, cin=32, cout=192, k=1, s=1, H=144, W=192, N=2)   # routed by pixel count (55 K pixels)
+
+
+def test_bf16_hardware_rounding_is_rne(gpu):
+    """The kernels round fp32 -> bf16 with gfx950's v_cvt_pk_bf16_f32 (rd_common.h: f32_to_bf16 / pack_bf16x2); the emulator and the
+    oracle use the integer round-to-nearest-even sequence.  Bit-exact on ties, denormals, infinities and the largest finite values."""
+    import torch
+    from riders_amd import engine
+    g = torch.Generator().manual_seed(5)
+    bits = torch.randint(-2**31, 2**31 - 1, (1 << 16,), dtype=torch.int64, generator=g).to(torch.int32)
+    x = bits.view(torch.float32)
+    x = x[torch.isfinite(x)]
+    ties = (torch.arange(0x3f80, 0x3f80 + 512, dtype=torch.int32) << 16 | 0x8000).view(torch.float32)       # exactly half way
+    above = (torch.arange(0x3f80, 0x3f80 + 512, dtype=torch.int32) << 16 | 0x8001).view(torch.float32)
+    below = (torch.arange(0x3f80, 0x3f80 + 512, dtype=torch.int32) << 16 | 0x7fff).view(torch.float32)
+    edge = torch.tensor([0.0, -0.0, float("inf"), float("-inf"), 3.3895314e38, -3.3895314e38, 3.4028235e38, 1e-40, -1e-40, 1.1754944e-38,
+                         9.1835e-41, 65504.0, 1.0, -1.0], dtype=torch.float32)
+    x = torch.cat([x, ties, -ties, above, below, edge])
+    if x.numel() % 8:
+        x = x[: x.numel() - x.numel() % 8]
+    xd = x.to(gpu)
+    out = engine.cast(xd, torch.bfloat16)
+    ref = x.to(torch.bfloat16)
+    assert torch.equal(out.cpu().view(torch.int16), ref.view(torch.int16)), "fp32 -> bf16 rounding differs from round-to-nearest-even"
