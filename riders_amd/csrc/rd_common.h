@@ -137,6 +137,22 @@ __device__ __forceinline__ uint2 lds_read_tr16_b64(const void* p) {
 #endif
 }
 
+// 16-bit interleave of two words (one v_perm_b32 each): lo16(l) | lo16(h) << 16 and hi16(l) | hi16(h) << 16
+__device__ __forceinline__ unsigned pack_lo16(unsigned l, unsigned h) {
+#ifdef RD_EMU
+  return (l & 0xffffu) | (h << 16);
+#else
+  return __builtin_amdgcn_perm(h, l, 0x05040100u);
+#endif
+}
+__device__ __forceinline__ unsigned pack_hi16(unsigned l, unsigned h) {
+#ifdef RD_EMU
+  return (l >> 16) | (h & 0xffff0000u);
+#else
+  return __builtin_amdgcn_perm(h, l, 0x07060302u);
+#endif
+}
+
 // Scheduling fence: no instruction moves across it (used to keep a block of prefetch loads where it is written).
 __device__ __forceinline__ void sched_fence() {
 #ifndef RD_EMU

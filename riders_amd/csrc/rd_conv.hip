@@ -260,6 +260,21 @@ __device__ __forceinline__ int wg_idx(int p, int col) { return p * 128 + (col ^ 
 template <int COT>
 __device__ __forceinline__ int wgy_idx(int p, int col) { return p * COT + (COT >= 32 ? (col ^ ((p & 1) << 4)) : col); }
 
+// XCD-aware block order of the split-K weight-gradient kernels.  Consecutive workgroup ids go round-robin to the 8 XCDs, each with
+// its own L2; with (k-tile, cout-tile, split) = blockIdx.(x, y, z) every XCD touched every pixel of x and dY (PMC: 225 MB fetched for
+// 28 MB of operands on the 384->256 layer).  Here the grid is 1-D and XCD x owns the pixel splits s = x, x+8, ...: all (k-tile,
+// cout-tile) blocks of a split -- nine taps over the same pixels, every cout tile over the same x -- hit one L2.
+struct WgBlock { int kt, ct, split; };
+__device__ __forceinline__ bool wg_block(int K, int Cout, int cot, int nsplit, WgBlock& b) {
+  const int nkt = (K + 127) / 128, nct = (Cout + cot - 1) / cot, per = nkt * nct;
+  const int xcd = (int)blockIdx.x & 7, j = (int)blockIdx.x >> 3;
+  b.split = xcd + 8 * (j / per);
+  const int r = j % per;
+  b.kt = r % nkt; b.ct = r / nkt;
+  return b.split < nsplit;
+}
+static unsigned wg_grid(int K, int Cout, int cot, int nsplit) { return (unsigned)(8 * cdiv(K, 128) * cdiv(Cout, cot) * cdiv(nsplit, 8)); }
+
 template <typename T, bool VEC, int COT>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
   constexpr int PK = 32;  // pixels per stage
@@ -270,9 +285,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
   __shared__ float sX[2][PK * 128];
   __shared__ float sY[2][PK * COT];
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-  const int kt0 = blockIdx.x * 128, c0 = blockIdx.y * COT;
+  WgBlock wb;
+  if (!wg_block(a.K, a.Cout, COT, a.nsplit, wb)) return;
+  const int kt0 = wb.kt * 128, c0 = wb.ct * COT;
   const int Cin = a.C1 + a.C2;
-  const int mbeg = blockIdx.z * a.rows_per_split;
+  const int mbeg = wb.split * a.rows_per_split;
   const int mend = min(a.M, mbeg + a.rows_per_split);
 
   // X staging role: column group cg (4 consecutive k columns, fixed for the whole pixel loop), pixel rows pr + 8*i
@@ -396,7 +413,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
     __syncthreads();
   }
   // slab[split][co][k]: lane holds rows (cout) fg*4+r, col (k) fr
-  float* slab = a.slab + (int64_t)blockIdx.z * a.Cout * a.K;
+  float* slab = a.slab + (int64_t)wb.split * a.Cout * a.K;
 #pragma unroll
   for (int i = 0; i < TI; i++)
 #pragma unroll
@@ -426,9 +443,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(WgradArgs a) {
   __shared__ uint4 sX[2][128 * 8];                     // [k col][64 px] bf16 = 8 slots of 16 B per row
   __shared__ uint4 sY[2][COT * 8];
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-  const int kt0 = blockIdx.x * 128, c0 = blockIdx.y * COT;
+  WgBlock wb;
+  if (!wg_block(a.K, a.Cout, COT, a.nsplit, wb)) return;
+  const int kt0 = wb.kt * 128, c0 = wb.ct * COT;
   const int Cin = a.C1 + a.C2;
-  const int mbeg = blockIdx.z * a.rows_per_split;
+  const int mbeg = wb.split * a.rows_per_split;
   const int mend = min(a.M, mbeg + a.rows_per_split);
 
   // X role: pixel pair pp = t % 16 (+16 for the second item), 8-column group cg = t / 16 (fixed k columns for the whole loop)
@@ -491,26 +510,30 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(WgradArgs a) {
       }
     }
   };
-  // word w (two bf16: pixel 2pp in the low half, 2pp+1 in the high half) of channel e of a pixel-pair
-  auto put = [&](uint4* tile, int row0, int pp, const uint4& lo, const uint4& hi) RD_INLINE_LAMBDA {
+  // word w (two bf16: pixel 2pp in the low half, 2pp+1 in the high half) of channel e of a pixel-pair.  The eight LDS word offsets of
+  // a (row group, pixel pair) are the same in every stage: computed once; the halves are interleaved by one v_perm_b32 per word (the
+  // shift / mask / or form plus the per-word swizzle arithmetic were ~250 of the ~400 VALU instructions per wave and stage).
+  int xw[2][8], yw[YIT][8];
+#pragma unroll
+  for (int e = 0; e < 8; e++) {
+#pragma unroll
+    for (int i = 0; i < 2; i++) { const int pp = xpp + 16 * i; xw[i][e] = lds_slot(xcg * 8 + e, pp >> 2) * 4 + (pp & 3); }
+#pragma unroll
+    for (int i = 0; i < YIT; i++) { const int idx = t + 256 * i, pp = idx & 31, yg = idx >> 5; yw[i][e] = lds_slot(yg * 8 + e, pp >> 2) * 4 + (pp & 3); }
+  }
+  auto put = [&](uint4* tile, const int (&wo)[8], const uint4& lo, const uint4& hi) RD_INLINE_LAMBDA {
     const unsigned l[4] = {lo.x, lo.y, lo.z, lo.w}, h[4] = {hi.x, hi.y, hi.z, hi.w};
     unsigned* words = reinterpret_cast<unsigned*>(tile);
 #pragma unroll
-    for (int e = 0; e < 8; e++) {
-      unsigned a16 = (e & 1) ? (l[e >> 1] >> 16) : (l[e >> 1] & 0xffffu);
-      unsigned b16 = (e & 1) ? (h[e >> 1] & 0xffff0000u) : (h[e >> 1] << 16);
-      int row = row0 + e;
-      words[lds_slot(row, pp >> 2) * 4 + (pp & 3)] = a16 | b16;
-    }
+    for (int e = 0; e < 8; e++) words[wo[e]] = (e & 1) ? pack_hi16(l[e >> 1], h[e >> 1]) : pack_lo16(l[e >> 1], h[e >> 1]);
   };
   auto store_stage = [&](int buf) RD_INLINE_LAMBDA {
 #pragma unroll
-    for (int i = 0; i < 2; i++) put(sX[buf], xcg * 8, xpp + 16 * i, rx[i][0], rx[i][1]);
+    for (int i = 0; i < 2; i++) put(sX[buf], xw[i], rx[i][0], rx[i][1]);
 #pragma unroll
     for (int i = 0; i < YIT; i++) {
       int idx = t + 256 * i;
-      int pp = idx & 31, yg = idx >> 5;
-      if (yg < YG) put(sY[buf], yg * 8, pp, ry[i][0], ry[i][1]);
+      if ((idx >> 5) < YG) put(sY[buf], yw[i], ry[i][0], ry[i][1]);
     }
   };
 
@@ -543,7 +566,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(WgradArgs a) {
     if (st + 1 < nst) store_stage(buf ^ 1);
     __syncthreads();
   }
-  float* slab = a.slab + (int64_t)blockIdx.z * a.Cout * a.K;
+  float* slab = a.slab + (int64_t)wb.split * a.Cout * a.K;
 #pragma unroll
   for (int i = 0; i < TI; i++)
 #pragma unroll
@@ -917,13 +940,14 @@ int wgrad_nsplit(int M, int K, int Cout) {
   int64_t want = cdiv(1024, tiles);
   int64_t maxs = cdiv(M, 64);  // at least two 32-pixel stages per split (small-M GEMMs such as the LoFTR projections need the blocks)
   int64_t s = std::max<int64_t>(1, std::min(want, maxs));
+  if (s >= 8) s -= s % 8;   // XCD x owns the splits x, x+8, ...: a multiple of 8 keeps the XCDs balanced
   return (int)s;
 }
 
 template <typename T>
 static void launch_wgrad_t(const WgradArgs& a, bool vec, hipStream_t st) {
   int cot = pick_bn(a.Cout);
-  dim3 grid((unsigned)cdiv(a.K, 128), (unsigned)cdiv(a.Cout, cot), (unsigned)a.nsplit);
+  dim3 grid(wg_grid(a.K, a.Cout, cot, a.nsplit));
 #define RD_WG_CASE(C)                                                                              \
   if (cot == C) {                                                                                  \
     if (vec) hipLaunchKernelGGL((conv_wgrad_kernel<T, true, C>), grid, dim3(256), 0, st, a);        \
@@ -972,7 +996,7 @@ void launch_wgrad(WgradArgs a, int dtype, float* dw, int accumulate, hipStream_t
     a.rows_per_split = (int)(cdiv(cdiv(a.M, wgrad_nsplit(a.M, a.K, a.Cout)), 64) * 64);
     a.nsplit = (int)cdiv(a.M, a.rows_per_split);
     int cot = pick_bn(a.Cout);
-    dim3 grid((unsigned)cdiv(a.K, 128), (unsigned)cdiv(a.Cout, cot), (unsigned)a.nsplit);
+    dim3 grid(wg_grid(a.K, a.Cout, cot, a.nsplit));
     if (cot == 16) hipLaunchKernelGGL((conv_wgrad_bf16_kernel<16>), grid, dim3(256), 0, st, a);
     else if (cot == 32) hipLaunchKernelGGL((conv_wgrad_bf16_kernel<32>), grid, dim3(256), 0, st, a);
     else if (cot == 64) hipLaunchKernelGGL((conv_wgrad_bf16_kernel<64>), grid, dim3(256), 0, st, a);
