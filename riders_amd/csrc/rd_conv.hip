@@ -937,7 +937,8 @@ int wgrad_slabs(int M, int K, int Cout) {
 int wgrad_nsplit(int M, int K, int Cout) {
   int cot = pick_bn(Cout);
   int64_t tiles = cdiv(K, 128) * cdiv(Cout, cot);
-  int64_t want = cdiv(1024, tiles);
+  static const int target = getenv("RD_WGRAD_BLOCKS") ? atoi(getenv("RD_WGRAD_BLOCKS")) : 1024;   // experiment hook
+  int64_t want = cdiv(target, tiles);
   int64_t maxs = cdiv(M, 64);  // at least two 32-pixel stages per split (small-M GEMMs such as the LoFTR projections need the blocks)
   int64_t s = std::max<int64_t>(1, std::min(want, maxs));
   if (s >= 8) s -= s % 8;   // XCD x owns the splits x, x+8, ...: a multiple of 8 keeps the XCDs balanced

@@ -63,6 +63,8 @@ CONV_CASES = [
     dict(cin=16, cout=1, k=3, s=1, H=12, W=10, N=2, bn=False, act=None),
     dict(cin=128, cout=256, k=3, s=1, H=5, W=6, N=1, bn=True),
     dict(cin=384, cout=512, k=3, s=1, H=2, W=3, N=2, bn=False, act=None),   # SML layer4_rn: 12 output pixels, K = 3456
+    dict(cin=8, cout=16, k=3, s=2, H=46, W=90, N=1, bn=True),                # 1035 output pixels: 9 (bf16) / 11 (fp32) split-K slabs, i.e.
+                                                                              # the XCD-aware split mapping with idle blocks on some XCDs
 ]
 
 
