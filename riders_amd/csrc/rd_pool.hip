@@ -363,27 +363,20 @@ __global__ __launch_bounds__(256) void roi_pool_bwd_tile_kernel(const T* __restr
         const int pw_lo = max((int)floorf((float)(w0 - q.sw - 1) / q.bw) - 1, 0), pw_hi = min((int)ceilf((float)(w0 + RPB_T - q.sw) / q.bw), PW - 1);
         const int nph = ph_hi - ph_lo + 1, npw = pw_hi - pw_lo + 1;
         if (nph <= 0 || npw <= 0) continue;
-        // thread = (channel group g, bin lane tb); the bin index advances by NB per iteration and (ph, pw) follow by carries instead of
-        // two runtime divisions by npw per item (measured neutral on the step: the LDS atomics dominate this kernel)
         constexpr int NB = 256 / GC;
         static_assert(256 % GC == 0, "bin lanes");
         const int g = t % GC, tb = t / GC;
-        const int nbins = nph * npw;
-        const int dph = NB / npw, dpw = NB - dph * npw;
-        int phi = tb / npw, pwi = tb - phi * npw;
-        for (int bq = tb; bq < nbins; bq += NB) {
-          const int pw = pw_lo + pwi, ph = ph_lo + phi;
-          pwi += dpw; phi += dph;
-          if (pwi >= npw) { pwi -= npw; phi++; }
+        // one item = (bin, 8 channels): arg-max + gradient (two / one 16-byte loads), then `apply(tile slot, value)` per channel
+        auto fetch = [&](int ph, int pw, int (&am)[VE], float (&dv)[VE]) RD_INLINE_LAMBDA {
           const int64_t o = (((int64_t)q.r * PH + ph) * PW + pw) * C + c0 + g * VE;
-          int am[VE];
 #pragma unroll
           for (int e4 = 0; e4 < VE / 4; e4++) {
             const int4 a4 = *reinterpret_cast<const int4*>(argmax + o + e4 * 4);
             am[e4 * 4] = a4.x; am[e4 * 4 + 1] = a4.y; am[e4 * 4 + 2] = a4.z; am[e4 * 4 + 3] = a4.w;
           }
-          float dv[VE];
           ldv(dout + o, dv);
+        };
+        auto scatter = [&](const int (&am)[VE], const float (&dv)[VE], auto apply) RD_INLINE_LAMBDA {
           // bins are about one pixel: the VE channels usually share their arg-max, decode a pixel index only when it changes
           int pa = -2, pslot = -1;
 #pragma unroll
@@ -397,7 +390,56 @@ __global__ __launch_bounds__(256) void roi_pool_bwd_tile_kernel(const T* __restr
                 if ((unsigned)lh < (unsigned)RPB_T && (unsigned)lw < (unsigned)RPB_T) pslot = (lh * RPB_T + lw) * RPT_CC + g * VE;
               }
             }
-            if (pslot >= 0) atomicAdd(&tacc[pslot + e], dv[e]);
+            if (pslot >= 0) apply(pslot + e, dv[e]);
+          }
+        };
+        if (q.bh >= 1.001f && q.bw >= 1.001f) {
+          // Bins at least one pixel large (every RC-Net pooling: the RoI has the size of its output): the window of bin p ends before the
+          // window of bin p + 2 begins (ceil((p+1) b) <= floor((p+2) b) for b >= 1; the 0.001 margin covers the float products), so bins
+          // of one parity class (ph & 1, pw & 1) pick DIFFERENT pixels.  The four classes run one after the other with plain LDS
+          // read-add-write: no atomics -- fp32 LDS atomics retire about one lane per clock (PMC: 100 LDS-busy cycles per wave instruction,
+          // 60 % of this kernel) -- and the summation order is fixed (RoI order, then class order).  The first item of the NEXT class
+          // is requested before the barrier that ends the current one, so the barriers do not expose the load latency.
+          auto plain = [&](int slot, float v) RD_INLINE_LAMBDA { tacc[slot] += v; };
+          int cph0[4], cpw0[4], cnw[4], cnb[4];
+#pragma unroll
+          for (int cls = 0; cls < 4; cls++) {
+            cph0[cls] = ph_lo + (((cls >> 1) ^ ph_lo) & 1); cpw0[cls] = pw_lo + (((cls & 1) ^ pw_lo) & 1);
+            const int nh = cph0[cls] <= ph_hi ? (ph_hi - cph0[cls]) / 2 + 1 : 0;
+            cnw[cls] = cpw0[cls] <= pw_hi ? (pw_hi - cpw0[cls]) / 2 + 1 : 0;
+            cnb[cls] = nh * cnw[cls];
+          }
+          int amA[VE]; float dvA[VE];
+          auto fetch_cls = [&](int cls, int bq, int (&am)[VE], float (&dv)[VE]) RD_INLINE_LAMBDA {
+            const int i = bq / cnw[cls], j = bq - i * cnw[cls];
+            fetch(cph0[cls] + 2 * i, cpw0[cls] + 2 * j, am, dv);
+          };
+          if (tb < cnb[0]) fetch_cls(0, tb, amA, dvA);
+#pragma unroll
+          for (int cls = 0; cls < 4; cls++) {
+            __syncthreads();   // the previous class (or a previous RoI's atomics) is complete in every wave
+            if (tb < cnb[cls]) scatter(amA, dvA, plain);
+            for (int bq = tb + NB; bq < cnb[cls]; bq += NB) {
+              int am[VE]; float dv[VE];
+              fetch_cls(cls, bq, am, dv);
+              scatter(am, dv, plain);
+            }
+            if (cls < 3 && tb < cnb[cls + 1]) fetch_cls(cls + 1, tb, amA, dvA);
+          }
+          __syncthreads();     // before the next RoI touches the tile (it may use atomics)
+        } else {
+          // general bins (smaller than a pixel: many bins per pixel): LDS atomics; the bin index advances by NB per iteration and
+          // (ph, pw) follow by carries
+          const int nbins = nph * npw;
+          const int dph = NB / npw, dpw = NB - dph * npw;
+          int phi = tb / npw, pwi = tb - phi * npw;
+          for (int bq = tb; bq < nbins; bq += NB) {
+            const int pw = pw_lo + pwi, ph = ph_lo + phi;
+            pwi += dpw; phi += dph;
+            if (pwi >= npw) { pwi -= npw; phi++; }
+            int am[VE]; float dv[VE];
+            fetch(ph, pw, am, dv);
+            scatter(am, dv, [&](int slot, float v) RD_INLINE_LAMBDA { atomicAdd(&tacc[slot], v); });
           }
         }
       }

@@ -569,3 +569,35 @@ def pack_batch_case(dev):
     engine.refresh_packed()
     assert torch.equal(engine.packed_weight(ws[0], 0, engine.RD_F32).cpu(), (want[0].cpu() * 2.0))
     engine.clear_caches()
+
+
+def roi_pool_tile_deterministic_case(dev):
+    """RC-Net geometry (bins a little larger than a pixel, many overlapping RoIs): the LDS-tile backward takes its atomic-free
+    parity-class path -- same result as the oracle and bit-identical from run to run."""
+    from riders_amd import engine
+    rs = np.random.RandomState(9)
+    N, C, H, W, R = 2, 32, 40, 72, 48
+    PH, PW, scale = 24, 20, 0.5       # 18 x 18 candidate bins per 16 x 16 tile: enough for the parity-class path
+    x = t(rs.randn(N, C, H, W).astype(np.float32))
+    b = rs.randint(0, N, R).astype(np.float32)
+    x1 = rs.randint(0, 2 * W - 41, R).astype(np.float32); y1 = rs.randint(0, 2 * H - 49, R).astype(np.float32)
+    rois = np.stack([b, x1, y1, x1 + 40, y1 + 48], 1).astype(np.float32)
+    xr = x.clone().requires_grad_()
+    ref = O.roi_pool(xr, t(rois), scale, (PH, PW))
+    w = t(rs.randn(*ref.shape).astype(np.float32))
+    (ref * w).sum().backward()
+    engine.set_roi_tile_min_blocks(0)
+    try:
+        grads = []
+        for rep in range(3):
+            xd = x.to(dev).permute(0, 2, 3, 1).contiguous()
+            tape = engine.Tape(); tape.mark(xd)
+            with engine._active(tape):
+                out = engine.roi_pool(xd, t(rois, dev), (PH, PW), scale)
+                tape.grads[id(out)] = w.to(dev).permute(0, 2, 3, 1).contiguous()
+                tape.backward()
+            grads.append(tape.grads[id(xd)].clone())
+        close(grads[0].permute(0, 3, 1, 2), xr.grad, 1e-5, "roi_pool tile bwd (bins >= 1 px)")
+        assert torch.equal(grads[0], grads[1]) and torch.equal(grads[0], grads[2]), "parity-class roi_pool backward is not reproducible"
+    finally:
+        engine.set_roi_tile_min_blocks(256)

@@ -152,6 +152,10 @@ def test_roi_pool_gather_backward(emu):
     P.roi_pool_stress_case(emu)
 
 
+def test_roi_pool_tile_parity_classes(emu):
+    P.roi_pool_tile_deterministic_case(emu)
+
+
 def test_direct_pointwise_conv(emu):
     """1x1 layers with a short K axis through conv1x1_direct_kernel (pixel fragments straight from memory, weights in registers)."""
     with P.force_direct_1x1():

@@ -224,6 +224,10 @@ def test_roi_pool_gather_backward(gpu):
     P.roi_pool_stress_case(gpu)
 
 
+def test_roi_pool_tile_backward_is_reproducible(gpu):
+    P.roi_pool_tile_deterministic_case(gpu)
+
+
 def test_direct_pointwise_conv(gpu):
     """1x1 layers with a short K axis through conv1x1_direct_kernel (pixel fragments straight from memory, weights in registers)."""
     with P.force_direct_1x1():
