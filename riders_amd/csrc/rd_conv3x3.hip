@@ -116,6 +116,23 @@ __global__ __launch_bounds__(256) void conv3x3_patch_kernel(ConvArgs a, int tile
     int px = W8 ? (fr & 7) : fr;
     ppix[pt] = py * WT + px;
   }
+  // LDS fragment addresses without per-tap swizzle arithmetic (a PMC pass counted 787 VALU instructions per wave and tile next to 72
+  // MFMAs on the 64->32 layer; the XOR-swizzled slot of every fragment read was recomputed per tap): the weight-fragment slots do not
+  // depend on the tap and are formed once; a pixel's nine XOR terms ((row + tap offset) >> 1) & 7 are packed three bits each into one
+  // register, so a patch fragment address is a bit-field extract, an XOR and an add.
+  int wfa[2][CTW];
+#pragma unroll
+  for (int ch = 0; ch < 2; ch++)
+#pragma unroll
+    for (int c = 0; c < CTW; c++) wfa[ch][c] = lds_slot((wc * CTW + c) * 16 + fr, ch * 4 + fg);
+  unsigned pxor[NPT];
+#pragma unroll
+  for (int pt = 0; pt < NPT; pt++) {
+    unsigned pk = 0;
+#pragma unroll
+    for (int tp = 0; tp < 9; tp++) pk |= (unsigned)(((ppix[pt] + (tp / 3) * WT + (tp % 3)) >> 1) & 7) << (3 * tp);
+    pxor[pt] = pk;
+  }
 
   f32x4 acc[CTW][NPT];
 #pragma unroll
@@ -142,10 +159,10 @@ __global__ __launch_bounds__(256) void conv3x3_patch_kernel(ConvArgs a, int tile
       for (int ch = 0; ch < 2; ch++) {
         uint4 pf[NPT];
 #pragma unroll
-        for (int pt = 0; pt < NPT; pt++) pf[pt] = sP[lds_slot(ppix[pt] + toff, ch * 4 + fg)];
+        for (int pt = 0; pt < NPT; pt++) pf[pt] = sP[(ppix[pt] + toff) * 8 + ((ch * 4 + fg) ^ (int)((pxor[pt] >> (3 * tap)) & 7u))];   // = lds_slot(ppix + toff, ch*4 + fg)
 #pragma unroll
         for (int c = 0; c < CTW; c++) {
-          uint4 wf = sB[wbuf][lds_slot((wc * CTW + c) * 16 + fr, ch * 4 + fg)];
+          uint4 wf = sB[wbuf][wfa[ch][c]];
 #pragma unroll
           for (int pt = 0; pt < NPT; pt++) {
             if (sizeof(T) == 4) {
