@@ -7,7 +7,7 @@
  *   round() (C, half away from zero) of the scaled corners, +1 extents, floor/ceil bin edges, clamp to the
  *   map, empty bin -> 0 and argmax -1, strict '>' scan in row-major order (first maximum wins).
  * "parity unpinned" against upstream binaries: the reference holds no test for this op; the contract is the
- * hand-derived known-answer vectors in tests/golden/roi_pool_kat.json.
+ * hand-derived known-answer vectors in tests/golden/roi_pool_kat.json (tests/test_oracle_golden.py).
  *
  * Layout here is NCHW (as the reference sees it); rois are (R,5) = (batch, x1, y1, x2, y2).
  */

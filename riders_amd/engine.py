@@ -194,11 +194,22 @@ class Tape:
         return g, acc
 
     def backward(self):
-        for fn in reversed(self.nodes):
+        while self.backward_stage() is not None:
+            pass
+
+    def backward_stage(self):
+        """Run backward nodes (newest first) up to and including the next stage mark; -> the mark's tag, or None when the tape is
+        exhausted.  A driver that owns the calling thread (rcnet_main.GraphedStep) uses the boundaries to end one hipGraph capture and
+        begin the next, and to hand finished gradient buckets to the all-reducer while the remaining backward is still queued."""
+        while self.nodes:
+            fn = self.nodes.pop()
             fn()
+            tag = getattr(fn, "_stage", None)
+            if tag is not None:
+                return tag
         self.flush_deferred()
-        self.nodes = []
         self.keep = {}
+        return None
 
     def flush_deferred(self):
         """rd_linear_wgrad_batch over every deferred (x, dy, weight): one launch + one ordered reduction instead of two small
@@ -260,6 +271,68 @@ class Tape:
 
 def tape():
     return _state["tape"]
+
+
+# ------------------------------------------------------------------------------------------ stage marks
+_stage_hooks = []
+
+
+def add_stage_hook(fn):
+    """fn(tag) is called from the backward whenever a stage mark is passed (gradients of everything recorded after the mark are final)."""
+    _stage_hooks.append(fn)
+
+
+def remove_stage_hook(fn):
+    if fn in _stage_hooks:
+        _stage_hooks.remove(fn)
+
+
+def stage_mark(tag):
+    """Record a backward-order boundary on the active tape.  When the backward reaches it, every operation recorded AFTER this call has
+    run its backward, the grouped 1x1 / linear weight gradients collected so far are issued, and the stage hooks fire -- this is where
+    data parallelism starts the all-reduce of the finished gradient bucket while earlier layers are still back-propagating
+    (reference counterpart: torch.nn.DataParallel's gather of replica gradients, RCNet/rcnet_model.py:259-265)."""
+    t = tape()
+    if t is None:
+        return
+
+    def backward():
+        t.flush_deferred()
+        for fn in list(_stage_hooks):
+            fn(tag)
+    backward._stage = tag
+    t.record(backward)
+
+
+class StepTape(object):
+    """One whole training step on ONE tape driven from the calling thread, without torch.autograd: module forwards called inside
+    `forward()` run inline on this tape (engine.run_region), `seed()` sets dLoss, and `backward_stage()` walks the backward one stage
+    at a time so that the caller can split hipGraph captures / start bucket all-reduces at the stage marks.  Parameter gradients land
+    in the optimizer's arena views (or fresh fp32 tensors) and are deposited on `.grad` by `finish()`."""
+
+    def __init__(self):
+        self.tape = Tape()
+        self.tape.grad_alloc = _grad_alloc_hook["fn"]
+
+    def forward(self, fn):
+        with torch.no_grad(), _active(self.tape):
+            return fn()
+
+    def seed(self, loss, value=1.0):
+        t = self.tape
+        if id(loss) not in t.req:
+            raise RuntimeError("StepTape.seed: the loss does not depend on any trainable tensor of this tape")
+        t.grads[id(loss)] = torch.full((1,), float(value), dtype=torch.float32, device=loss.device)
+
+    def backward_stage(self):
+        with torch.no_grad(), _active(self.tape):
+            return self.tape.backward_stage()
+
+    def finish(self):
+        t = self.tape
+        for pid, g in t.pgrads.items():
+            t.params[pid].grad = g
+        t.pgrads, t.params, t.grads = {}, {}, {}
 
 
 @contextlib.contextmanager
@@ -400,7 +473,9 @@ _BN_RECOMPUTE = os.environ.get("RIDERS_BN_RECOMPUTE", "1") != "0"   # A/B switch
 def packed_weight(w, mode, dt, cin_pad=0):
     """MFMA-layout copy of a weight tensor, re-packed whenever the tensor was written (version counter) or re-allocated.
     Entries die with their tensor (weakref callback): CPython recycles id()s and the caching allocator recycles addresses, so an
-    (id, data_ptr, version) key alone can match a DIFFERENT later tensor -- seen as stale weights / out-of-bounds reads in stress runs."""
+    (id, data_ptr, version) key alone can match a DIFFERENT later tensor -- seen as stale weights / out-of-bounds reads in stress runs.
+    A stale entry is re-packed INTO ITS EXISTING BUFFER: captured hipGraphs keep reading that address, so a weight written through
+    torch (load_state_dict, broadcast) must never move its packed operand."""
     key = (w._version, mode, dt, w.data_ptr(), tuple(w.shape))
     slot = (mode, dt) if not cin_pad else (mode, dt, cin_pad)
     ent = _pack_cache.get(id(w))
@@ -417,12 +492,13 @@ def packed_weight(w, mode, dt, cin_pad=0):
     if cin_pad:     # forward operand with zero-padded input channels (3-channel stems on the vector kernels)
         assert mode == 0 and cin_pad >= cin
         n = L().rd_conv_packed_elems(cout, kh * kw * cin_pad, dt)
-        buf = torch.empty(n, dtype=_TORCH_DT[dt], device=w.device)
-        _chk(L().rd_conv_pack_weights_padded(_p(w.detach()), _p(buf), cout, cin, cin_pad, kh, kw, dt, _stream(w)), "rd_conv_pack_weights_padded")
     else:
         rows, c = (cin, cout) if mode else (cout, cin)
         n = L().rd_conv_packed_elems(rows, kh * kw * c, dt)
-        buf = torch.empty(n, dtype=_TORCH_DT[dt], device=w.device)
+    buf = hit[1] if (hit is not None and hit[1].numel() == n and hit[1].device == w.device) else torch.empty(n, dtype=_TORCH_DT[dt], device=w.device)
+    if cin_pad:
+        _chk(L().rd_conv_pack_weights_padded(_p(w.detach()), _p(buf), cout, cin, cin_pad, kh, kw, dt, _stream(w)), "rd_conv_pack_weights_padded")
+    else:
         _chk(L().rd_conv_pack_weights(_p(w.detach()), _p(buf), cout, cin, kh, kw, mode, dt, _stream(w)), "rd_conv_pack_weights")
     ent[slot] = (key, buf)
     return buf
@@ -451,9 +527,12 @@ def refresh_packed():
             mode, dt = k[0], k[1]
             cpad = k[2] if len(k) > 2 else 0
             key, buf = hit
-            if key != (w._version, mode, dt, w.data_ptr(), tuple(w.shape)):
-                ent.pop(k)          # written through torch since it was packed: falls back to an individual re-pack
-                continue
+            cur = (w._version, mode, dt, w.data_ptr(), tuple(w.shape))
+            if key != cur:
+                if key[4] != cur[4] or buf.device != w.device:
+                    ent.pop(k)      # re-shaped / moved to another device: the next forward packs a fresh operand
+                    continue
+                ent[k] = (cur, buf)  # written through torch (load_state_dict, broadcast) since it was packed: re-packed below IN PLACE
             live.append((w, buf, mode, dt, cpad))
     if not live:
         return

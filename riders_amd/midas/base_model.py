@@ -12,10 +12,12 @@ class BaseModel(torch.nn.Module):
             state_dict = parameters['state_dict']
             new_state_dict = {}
             for k, v in state_dict.items():
-                new_key = k[len("model."):] if k.startswith("model.") else k
-                new_state_dict[new_key] = v
+                if k.startswith("model."):      # modules/midas/base_model.py:17-21: keys WITHOUT the prefix are dropped, not kept
+                    new_state_dict[k[len("model."):]] = v
             parameters = new_state_dict
         self.load_state_dict(parameters)
+        from .. import engine
+        engine.refresh_packed()   # cached MFMA operands follow the loaded weights in place
 
     def save(self, path):
         torch.save(self.state_dict(), path)

@@ -74,7 +74,9 @@ class MidasNet_small_videpth(BaseModel):
         layer_1 = efficientnet_lite3.run_layer1(self.pretrained.layer1, layer_0, tr)
         layer_2 = efficientnet_lite3.run_stages(self.pretrained.layer2, layer_1)
         layer_3 = efficientnet_lite3.run_stages(self.pretrained.layer3, layer_2)
+        engine.stage_mark("layer4_done")      # backward-order boundaries for the bucketed gradient all-reduce (parallel.sml_stages)
         layer_4 = efficientnet_lite3.run_stages(self.pretrained.layer4, layer_3)
+        engine.stage_mark("scratch_done")
         s = self.scratch
         l1 = engine.conv_block(layer_1, s.layer1_rn.weight)
         l2 = engine.conv_block(layer_2, s.layer2_rn.weight)

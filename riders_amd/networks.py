@@ -148,6 +148,7 @@ class RCNetEncoder(torch.nn.Module):
         L = latent_height * latent_width
 
         latent_image, skips_image = self.encoder_image._fwd(image)
+        engine.stage_mark("attention_done")   # backward: RoI pooling, point MLP and transformer gradients are final here
         latent_image_pooled = engine.roi_pool(latent_image, rois, (latent_height, latent_width), 1 / 32.0)
         skips_image_pooled = [engine.roi_pool(skips_image[i], rois, skip_feature_sizes[i], skip_scales[i])
                               for i in range(len(skips_image))]

@@ -2,11 +2,21 @@
 
 The reference only has single-process torch.nn.DataParallel (RCNet/rcnet_model.py:259-265, val_zju.py:341) which
 cannot shard the per-image box list; here each rank runs the full step on its shard of the batch (per-rank
-BatchNorm statistics, as DataParallel has) and the only exchange is a sum-all-reduce of the flat gradient arena,
-issued in bucket order on a side stream as soon as a region's backward has produced its slice.
+BatchNorm statistics, as DataParallel has) and the only exchange is a sum-all-reduce of the flat gradient arena.
+
+Overlap with backward: the models place `engine.stage_mark(tag)` boundaries in their forward (RC-Net: decoder |
+transformer + point MLP | image encoder; SML: scratch decoder | backbone layer4 | rest).  When the backward passes a
+mark, the gradients of everything after it are final; `GradientAllReducer.on_stage(tag)` then starts the asynchronous
+all-reduce of that bucket (arena slices, in place) on torch.distributed's communication stream, which waits only for
+the work queued so far, so the exchange runs while the earlier layers are still back-propagating on the compute stream.
+`reduce()` starts whatever has not been started and waits for everything before the optimizer step.
+Buckets are whole stages (7-9 MB for RC-Net): xGMI is point-to-point, a ring collective is per-link bound, so few large
+messages beat many small ones.
 """
 import torch
 import torch.distributed as dist
+
+from . import engine
 
 
 class ModuleHolder(torch.nn.Module):
@@ -24,31 +34,88 @@ class ModuleHolder(torch.nn.Module):
 
 
 class GradientAllReducer(object):
-    """All-reduce the FlatAdam gradient arena across ranks (sum; the 1/world average is folded into Adam's
-    grad_scale).  `buckets` slices are reduced asynchronously on torch.distributed's communication stream, so the
-    reduction of early buckets overlaps the remaining backward work queued on the compute stream."""
+    """All-reduce the FlatAdam gradient arena across ranks (sum; the 1/world average is folded into Adam's grad_scale).
 
-    def __init__(self, optimizer, bucket_bytes=32 << 20, process_group=None):
+    stages: optional {tag: iterable of parameters whose gradients are final when the backward passes stage mark `tag`}.
+    Without stages (or for parameters in none) the arena is reduced by `reduce()` in `bucket_bytes` slices after backward."""
+
+    def __init__(self, optimizer, bucket_bytes=32 << 20, process_group=None, stages=None):
         self.opt = optimizer
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
-        n = optimizer.numel
-        per = max(1, bucket_bytes // 4)
-        self.buckets = [(s, min(n, s + per)) for s in range(0, n, per)]
+        self.per = max(4, (bucket_bytes // 4) & ~3)
+        self.stage_ranges = {}
+        covered = []
+        for tag, params in (stages or {}).items():
+            rs = optimizer.slot_range(list(params))
+            self.stage_ranges[tag] = rs
+            covered += rs
+        # the rest of the arena (stages never cover everything: the first layers finish last), front to back
+        covered.sort()
+        self.rest, pos = [], 0
+        for s, e in covered:
+            if s < pos:
+                raise ValueError("GradientAllReducer: stages overlap")
+            if s > pos:
+                self.rest.append((pos, s))
+            pos = e
+        if pos < optimizer.numel:
+            self.rest.append((pos, optimizer.numel))
+        self.buckets = [b for rs in list(self.stage_ranges.values()) + [self.rest] for b in self._split(rs)]
         optimizer.grad_scale = 1.0 / self.world
         self._handles = []
+        self._done = set()
+        self.log = []      # (tag, start, end) of every all-reduce issued since the last reduce(): test / debugging aid
+        if self.stage_ranges:
+            engine.add_stage_hook(self.on_stage)
+
+    def _split(self, ranges):
+        return [(s0, min(e, s0 + self.per)) for s, e in ranges for s0 in range(s, e, self.per)]
+
+    def close(self):
+        engine.remove_stage_hook(self.on_stage)
 
     def broadcast_parameters(self, src=0):
         if self.world > 1:
             dist.broadcast(self.opt.flat_param, src, group=self.group)
+        engine.refresh_packed()     # the packed MFMA operands cached by earlier forwards follow the new values (same buffers)
+
+    def _issue(self, tag, ranges):
+        for s, e in self._split(ranges):
+            self.log.append((tag, s, e))
+            if self.world > 1:
+                self._handles.append(dist.all_reduce(self.opt.flat_grad[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def on_stage(self, tag):
+        """Stage hook (called from the backward, or by a graph-replaying driver right after the stage's graph was enqueued)."""
+        rs = self.stage_ranges.get(tag)
+        if rs is None or tag in self._done:
+            return
+        self._done.add(tag)
+        self._issue(tag, rs)
 
     def reduce(self):
-        """Call after backward(); returns when every bucket's all-reduce has been enqueued and waited on."""
-        if self.world == 1:
-            return
-        # buckets hold decoder grads last in arena order; reduce back-to-front = reverse execution order
-        for s, e in reversed(self.buckets):
-            self._handles.append(dist.all_reduce(self.opt.flat_grad[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        """Call after backward(): starts every bucket not started by a stage mark, then waits for all of them (the compute stream is
+        made to wait for the communication stream; the host does not block)."""
+        for tag, rs in self.stage_ranges.items():
+            if tag not in self._done:
+                self._issue(tag, rs)
+        self._issue(None, self.rest)
         for h in self._handles:
             h.wait()
         self._handles = []
+        self._done = set()
+
+
+def rcnet_stages(model):
+    """Stage -> parameters for RCNetModel (marks are placed by RCNetModel.forward / RCNetEncoder._fwd)."""
+    enc = model.encoder.module if hasattr(model.encoder, "module") else model.encoder
+    dec = model.decoder.module if hasattr(model.decoder, "module") else model.decoder
+    return {"decoder_done": list(dec.parameters()),
+            "attention_done": list(enc.attention.parameters()) + list(enc.encoder_depth.parameters())}
+
+
+def sml_stages(model):
+    """Stage -> parameters for MidasNet_small_videpth (marks are placed by MidasNet_small_videpth._fwd)."""
+    return {"scratch_done": list(model.scratch.parameters()),
+            "layer4_done": list(model.pretrained.layer4.parameters())}

@@ -106,48 +106,102 @@ def forward_output(model, image, radar_points, bounding_boxes_list, response_thr
     return depth, resp
 
 
-def compute_gradients(model, optimizer, batch, cfg=ZJU_CONFIG):
-    """Forward + loss + backward of one step (everything of rcnet_main.py:294-358 except the optimizer)."""
+def forward_loss(model, batch, cfg=ZJU_CONFIG):
+    """Label build + forward + masked BCE of one step (rcnet_main.py:294-352) -> loss tensor."""
     image, radar_point, rois, gt = prepare_batch(batch)
     label, valid = engine.rcnet_labels(gt, radar_point, cfg['max_distance_correspondence'], cfg['set_invalid_to_negative_class'])
     logits = model.forward(image, radar_point, rois, return_logits=True)
     loss, _ = model.compute_loss(logits=logits, ground_truth=label, validity_map=valid, w_positive_class=cfg['w_positive_class'])
+    return loss
+
+
+def compute_gradients(model, optimizer, batch, cfg=ZJU_CONFIG):
+    """Forward + loss + backward of one step (everything of rcnet_main.py:294-358 except the optimizer) through torch.autograd,
+    as an unchanged training script would run it."""
+    loss = forward_loss(model, batch, cfg)
     optimizer.zero_grad()
     loss.backward()
     return loss
 
 
-class GraphedStep(object):
-    """The launch-bound part of a step (forward + loss + backward: ~1100 small kernel launches for RC-Net) captured once into a
-    hipGraph and replayed per step; the RCCL gradient all-reduce and the fused Adam launch stay eager on the same stream.
-    `compute()` must run forward+backward on static device tensors and return the loss tensor; `on_replay()` keeps host-side
-    bookkeeping (BatchNorm num_batches_tracked counters) in step with replays."""
+def staged_gradients(fwd_loss, optimizer, on_stage=None, loss_scale=1.0):
+    """The same step on ONE engine tape driven from this thread (engine.StepTape, no torch.autograd): the backward stops at every
+    stage mark and calls `on_stage(tag)`, which is where GraphedStep ends one hipGraph capture and begins the next.  The stage hooks
+    registered with the engine (the all-reducer's) fire at the same marks."""
+    optimizer.zero_grad()
+    st = engine.StepTape()
+    loss = st.forward(fwd_loss)
+    st.seed(loss, loss_scale)
+    while True:
+        tag = st.backward_stage()
+        if tag is None:
+            break
+        if on_stage is not None:
+            on_stage(tag)
+    st.finish()
+    return loss
 
-    def __init__(self, compute, optimizer, reducer=None, warmup=2, on_replay=None):
+
+class GraphedStep(object):
+    """The launch-bound part of a step (forward + loss + backward: ~1100 small kernel launches for RC-Net) captured once into
+    hipGraphs and replayed per step; the RCCL gradient all-reduce and the fused Adam launch stay eager.  The capture is SPLIT at the
+    model's stage marks: after the graph of a stage has been enqueued the all-reducer starts that stage's bucket on the communication
+    stream, so the exchange overlaps the replay of the remaining backward graphs.
+    `fwd_loss()` runs forward + loss on static device tensors and returns the loss tensor; `on_replay(n)` keeps host-side bookkeeping
+    (BatchNorm num_batches_tracked counters) in step with replays; `buffers` are tensors the forward updates in place (BatchNorm running
+    statistics): the warm-up passes needed before a capture are undone on them, so constructing a GraphedStep trains nothing."""
+
+    def __init__(self, fwd_loss, optimizer, reducer=None, warmup=2, on_replay=None, buffers=(), loss_scale=1.0):
         self.opt, self.reducer, self.on_replay = optimizer, reducer, on_replay
         assert engine._timer["t"] is None, "kernel timing and graph capture are exclusive"
+        buffers = list(buffers)
+        hooks, engine._stage_hooks[:] = list(engine._stage_hooks), []      # no collectives during warm-up / capture
+        try:
+            saved = [b.clone() for b in buffers]
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(warmup):
+                    staged_gradients(fwd_loss, optimizer, None, loss_scale)
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            with torch.no_grad():
+                for b, s_ in zip(buffers, saved):
+                    b.copy_(s_)
+            self.graphs, self.tags = [], []
+            pool = torch.cuda.graph_pool_handle()
+            state = {}
 
-        def eager():
-            loss = compute()
-            if reducer is not None:
-                reducer.reduce()
-            optimizer.step()
-            return loss
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            for _ in range(warmup):
-                eager()
-        torch.cuda.current_stream().wait_stream(side)
-        torch.cuda.synchronize()
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            self.loss = compute()
+            def begin():
+                state["g"] = torch.cuda.CUDAGraph()
+                state["ctx"] = torch.cuda.graph(state["g"], pool=pool)
+                state["ctx"].__enter__()
+
+            def end(tag):
+                state["ctx"].__exit__(None, None, None)
+                self.graphs.append(state["g"])
+                self.tags.append(tag)
+
+            def boundary(tag):
+                end(tag)
+                begin()
+            begin()
+            try:
+                self.loss = staged_gradients(fwd_loss, optimizer, boundary, loss_scale)
+            except BaseException:
+                state["ctx"].__exit__(None, None, None)
+                raise
+            end(None)
+        finally:
+            engine._stage_hooks[:] = hooks
         if on_replay is not None:
-            on_replay(-1)  # the capture pass itself did not execute
+            on_replay(-(warmup + 1))  # neither the warm-up passes (undone) nor the capture pass (not executed) were training steps
 
     def __call__(self):
-        self.graph.replay()
+        for g, tag in zip(self.graphs, self.tags):
+            g.replay()
+            if tag is not None and self.reducer is not None:
+                self.reducer.on_stage(tag)
         if self.on_replay is not None:
             self.on_replay(+1)
         if self.reducer is not None:
@@ -157,14 +211,15 @@ class GraphedStep(object):
 
 
 class GraphedTrainStep(GraphedStep):
-    """RC-Net training step with forward+backward replayed from a hipGraph (inputs: the static tensors of `batch`)."""
+    """RC-Net training step with forward+backward replayed from hipGraphs (inputs: the static tensors of `batch`)."""
 
-    def __init__(self, model, optimizer, batch, cfg=ZJU_CONFIG, reducer=None, warmup=2):
-        bn = [m for net in (model.encoder, model.decoder) for m in net.modules()
-              if getattr(m, 'use_batch_norm', False) and hasattr(m, '_nbt_pending')]
+    def __init__(self, model, optimizer, batch, cfg=ZJU_CONFIG, reducer=None, warmup=2, loss_scale=1.0):
+        nets = [RCNetModel._unwrap(model.encoder), RCNetModel._unwrap(model.decoder)]
+        bn = [m for net in nets for m in net.modules() if getattr(m, 'use_batch_norm', False) and hasattr(m, '_nbt_pending')]
 
         def bump(delta):
             for m in bn:
                 if m.training:
                     m._nbt_pending += delta
-        super().__init__(lambda: compute_gradients(model, optimizer, batch, cfg), optimizer, reducer, warmup, bump)
+        buffers = [b for net in nets for b in net.buffers() if b.is_floating_point()]
+        super().__init__(lambda: forward_loss(model, batch, cfg), optimizer, reducer, warmup, bump, buffers, loss_scale)

@@ -53,6 +53,7 @@ class RCNetModel(object):
         def run(image, point):
             pts = point if point.is_contiguous() else point.contiguous()
             latent, skips = enc._fwd(engine.from_nchw(image), pts, rois)
+            engine.stage_mark("decoder_done")     # backward: every decoder gradient is final here (parallel.GradientAllReducer)
             logits = dec._fwd(latent, skips, shape)[-1]
             return engine.to_nchw_out(logits, torch.float32)
         params = list(enc.parameters()) + list(dec.parameters())
@@ -106,6 +107,7 @@ class RCNetModel(object):
         self.decoder.load_state_dict(checkpoint['radarnet_decoder_state_dict'])
         if optimizer is not None:
             optimizer.load_state_dict(checkpoint['radarnet_optimizer_state_dict'])
+        engine.refresh_packed()   # cached MFMA operands follow the restored weights in place (captured hipGraphs keep their addresses)
         return checkpoint['train_step'], optimizer
 
     # -- reference: rcnet_model.py:259-265 -------------------------------------------------------------------

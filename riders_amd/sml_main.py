@@ -82,7 +82,8 @@ def nearest_resize(t, h, w):
     return t[:, :, ys][:, :, :, xs].contiguous()  # data preparation (index gather), off the timed path when sizes already match
 
 
-def compute_gradients(model, optimizer, batch, cfg=ZJU_SML_CONFIG, outlier=None):
+def forward_loss(model, batch, cfg=ZJU_SML_CONFIG, outlier=None):
+    """Pre-step + forward + loss of one SML step (train_zju.py:246-376) -> loss tensor."""
     image, mono, sparse_depth, gt, sparse_gt, rcnet = batch
     H, W = image.shape[-2:]
     hw = net_size(H, W)
@@ -99,6 +100,11 @@ def compute_gradients(model, optimizer, batch, cfg=ZJU_SML_CONFIG, outlier=None)
                               w_smoothness=cfg['w_smoothness'], sobel_filter_size=cfg['sobel_filter_size'],
                               validity_map_loss_smoothness=None, w_lidar_loss=cfg['w_lidar_loss'], w_edge=cfg['w_edge'],
                               invalid_map_gt=None, w_unsupervised=0.0)
+    return loss
+
+
+def compute_gradients(model, optimizer, batch, cfg=ZJU_SML_CONFIG, outlier=None):
+    loss = forward_loss(model, batch, cfg, outlier)
     optimizer.zero_grad()
     loss.backward()
     return loss
@@ -142,9 +148,9 @@ def validate_batch(model, batch, cfg=ZJU_SML_CONFIG, min_depth_val=0.0, max_dept
 
 
 class GraphedTrainStep(object):
-    """SML training step with pre-step + forward + loss + backward replayed from a hipGraph."""
+    """SML training step with pre-step + forward + loss + backward replayed from hipGraphs split at the stage marks."""
 
-    def __new__(cls, model, optimizer, batch, cfg=ZJU_SML_CONFIG, reducer=None, outlier=None, warmup=2):
+    def __new__(cls, model, optimizer, batch, cfg=ZJU_SML_CONFIG, reducer=None, outlier=None, warmup=2, loss_scale=1.0):
         from .rcnet_main import GraphedStep
         from .midas.efficientnet_lite3 import _Counted
         counted = [m for m in model.modules() if isinstance(m, _Counted)]
@@ -155,4 +161,5 @@ class GraphedTrainStep(object):
                     m._pending += delta
                 model._first_pending += delta
                 model.pretrained.layer1._stem_pending = getattr(model.pretrained.layer1, "_stem_pending", 0) + delta
-        return GraphedStep(lambda: compute_gradients(model, optimizer, batch, cfg, outlier), optimizer, reducer, warmup, bump)
+        buffers = [b for b in model.buffers() if b.is_floating_point()]
+        return GraphedStep(lambda: forward_loss(model, batch, cfg, outlier), optimizer, reducer, warmup, bump, buffers, loss_scale)

@@ -239,7 +239,7 @@ def transformer_case(dev, N=2, n_layers=1, tol=TOL):
 
 # ---------------------------------------------------------------------------------------------- pooling etc.
 def roi_pool_case(dev):
-    """argmax indices bit-exact against the oracle; KATs from tests/golden/roi_pool_kat.json are checked in test_abi."""
+    """argmax indices bit-exact against the oracle; the hand-derived KATs are checked by roi_pool_kat_case."""
     from riders_amd import engine
     rs = np.random.RandomState(11)
     N, C, H, W = 2, 8, 15, 19
@@ -260,6 +260,52 @@ def roi_pool_case(dev):
         assert torch.equal(out._rd_argmax.permute(0, 3, 1, 2).cpu(), arg), "roi_pool argmax differs"
         assert torch.equal(out.permute(0, 3, 1, 2).cpu(), ref.detach()), "roi_pool values differ"
         close(tape.grads[id(xd)].permute(0, 3, 1, 2), xr.grad, 1e-5, "roi_pool bwd")
+
+
+def load_roi_pool_kat():
+    import json
+    return json.load(open(os.path.join(G, "roi_pool_kat.json")))["cases"]
+
+
+def roi_pool_kat_case(dev):
+    """rd_roi_pool_fwd / every backward variant against the hand-derived known-answer vectors (tests/golden/roi_pool_kat.json:
+    integer boxes, x.5 rounding of both signs, empty bins, ties, boxes leaving the map, overlapping fractional bins, ZJU latent
+    geometry) -- values and argmax exact, scatter-add exact.  Call sites: RCNet/networks.py:418-433."""
+    from riders_amd import engine
+    for c in load_roi_pool_kat():
+        x = t(np.asarray(c["input"], np.float32))
+        N, C, H, W = x.shape
+        rois = t(np.asarray(c["rois"], np.float32), dev)
+        PH, PW = c["output_size"]
+        for dtype in (torch.float32, torch.bfloat16):       # every KAT value is an integer < 2048 or representable: exact in bf16 too
+            if dtype == torch.bfloat16 and float(x.abs().max()) > 256:
+                continue
+            xd = x.to(dev).permute(0, 2, 3, 1).contiguous().to(dtype)
+            modes = ["atomic", "gather", "tile"] if "grad_out" in c else ["atomic"]
+            for mode in modes:
+                if mode != "atomic" and C % (16 // xd.element_size()) != 0:
+                    continue     # vector kernels need whole 16-byte channel groups; covered by the stress cases
+                engine.set_deterministic_roi_pool(mode == "gather")
+                engine.set_roi_tile_min_blocks(0 if mode == "tile" else 256)
+                try:
+                    tape = engine.Tape(); tape.mark(xd)
+                    with engine._active(tape):
+                        out = engine.roi_pool(xd, rois, (PH, PW), c["scale"])
+                        if "grad_out" in c:
+                            tape.grads[id(out)] = t(np.asarray(c["grad_out"], np.float32), dev).permute(0, 2, 3, 1).contiguous().to(dtype)
+                            tape.backward()
+                finally:
+                    engine.set_deterministic_roi_pool(False)
+                    engine.set_roi_tile_min_blocks(256)
+                what = "%s [%s, %s]" % (c["name"], str(dtype).split(".")[-1], mode)
+                assert np.array_equal(out._rd_argmax.permute(0, 3, 1, 2).cpu().numpy(), np.asarray(c["argmax"], np.int32)), what + ": argmax"
+                assert np.array_equal(out.float().permute(0, 3, 1, 2).cpu().numpy(), np.asarray(c["out"], np.float32)), what + ": values"
+                if "grad_out" in c:
+                    want = np.zeros((N, C, H * W), np.float32)
+                    for n_, c_, k, v in c["grad_in_nonzero"]:
+                        want[n_, c_, k] = v
+                    got = tape.grads[id(xd)].float().permute(0, 3, 1, 2).reshape(N, C, H * W).cpu().numpy()
+                    assert np.array_equal(got, want), what + ": scatter-add"
 
 
 def roi_pool_stress_case(dev, R=300, C=64, H=20, W=24):

@@ -50,3 +50,84 @@ def test_arena_allreduce_world2():
     assert res[0][2] == 0.5 and res[1][2] == 0.5
     assert torch.equal(res[0][3], res[1][3]), "parameters not broadcast from rank 0"
     assert res[0][4] > 1
+
+
+def _ddp_worker(rank, world, port, outdir, emu_lib):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from riders_amd import _lib, engine, rcnet_main
+    from riders_amd.optim import FlatAdam
+    from riders_amd.parallel import GradientAllReducer
+    from tests.test_host_logic import _TwoStage, _toy_batch, _toy_loss
+    _lib._install_for_tests(emu_lib)      # TEST INFRA: host build of the kernel sources (no GPU in this container)
+    engine.set_compute_dtype("fp32")
+    torch.manual_seed(100 + rank)          # different initial weights per rank on purpose: broadcast must fix it
+    model = _TwoStage(); model.train()
+    opt = FlatAdam(list(model.parameters()), lr=1e-2)
+    red = GradientAllReducer(opt, stages={"head_done": list(model.head.parameters()) + list(model.out.parameters())})
+    red.broadcast_parameters(0)
+    init = opt.flat_param.clone()
+    grads, order = [], []
+    for step in range(2):
+        x, label, valid = _toy_batch(10 * step + rank)      # this rank's shard
+        rcnet_main.staged_gradients(lambda: _toy_loss(model, x, label, valid), opt)
+        order.append([t for t, _, _ in red.log])      # what was started from the stage marks, before reduce()
+        red.reduce()
+        red.log = []
+        grads.append(opt.flat_grad.clone() * opt.grad_scale)
+        opt.step()
+    dist.barrier()
+    dist.destroy_process_group()
+    torch.save(dict(rank=rank, init=init, grads=grads, final=opt.flat_param.clone(), order=order), os.path.join(outdir, "r%d.pt" % rank))
+
+
+def test_two_training_steps_world2_match_per_shard_mean(emu_lib_path):
+    """SURVEY 8(e) semantics: every rank runs the full step on its own shard (per-rank BatchNorm statistics, per-rank loss
+    normaliser), the stage-bucketed all-reduce averages the gradients, Adam applies the average.  Two steps on two ranks must equal a
+    single process that evaluates both shards on the same weights and applies the mean gradient; the head bucket is issued at its
+    stage mark, i.e. before the body's backward has run."""
+    import tempfile
+    ctx = mp.get_context("spawn")
+    port = _free_port()
+    with tempfile.TemporaryDirectory() as outdir:
+        procs = [ctx.Process(target=_ddp_worker, args=(r, 2, port, outdir, emu_lib_path)) for r in range(2)]
+        for p in procs:
+            p.start()
+        for p in procs:
+            p.join(timeout=600)
+            assert p.exitcode == 0, "worker exit code %s" % p.exitcode
+        res = [torch.load(os.path.join(outdir, "r%d.pt" % r)) for r in range(2)]
+    assert torch.equal(res[0]["init"], res[1]["init"]), "parameters not broadcast from rank 0"
+    assert torch.equal(res[0]["final"], res[1]["final"]), "ranks diverged"
+    assert res[0]["order"] == [["head_done"], ["head_done"]], res[0]["order"]     # bucket started from the stage mark, before reduce()
+    for s in range(2):
+        assert torch.equal(res[0]["grads"][s], res[1]["grads"][s])
+    # single-process reference: same initial weights, per-shard gradients on identical weights, mean, Adam
+    from riders_amd import _lib, engine, rcnet_main
+    from riders_amd.optim import FlatAdam
+    from tests.test_host_logic import _TwoStage, _toy_batch, _toy_loss
+    _lib._install_for_tests(emu_lib_path)
+    try:
+        engine.set_compute_dtype("fp32")
+        torch.manual_seed(100)
+        model = _TwoStage(); model.train()
+        opt = FlatAdam(list(model.parameters()), lr=1e-2)
+        assert torch.equal(opt.flat_param, res[0]["init"])
+        for step in range(2):
+            per = []
+            for rank in range(2):
+                x, label, valid = _toy_batch(10 * step + rank)
+                rcnet_main.staged_gradients(lambda: _toy_loss(model, x, label, valid), opt)
+                per.append(opt.flat_grad.clone())
+            mean = (per[0] + per[1]) * 0.5
+            err = float((mean - res[0]["grads"][step]).abs().max() / mean.abs().max())
+            assert err < 1e-6, "step %d: all-reduced gradient differs from the per-shard mean (%.2e)" % (step, err)
+            opt.flat_grad.copy_(mean)
+            opt.step()
+        err = float((opt.flat_param - res[0]["final"]).abs().max() / opt.flat_param.abs().max())
+        assert err < 1e-6, "parameters after two data-parallel steps differ from the single-process reference (%.2e)" % err
+    finally:
+        engine.clear_caches()
+        engine.set_param_grad_allocator(None)
+        _lib._uninstall_for_tests()

@@ -69,6 +69,10 @@ def test_roi_pool(gpu):
     P.roi_pool_case(gpu)
 
 
+def test_roi_pool_known_answers(gpu):
+    P.roi_pool_kat_case(gpu)
+
+
 def test_maxpool(gpu):
     P.maxpool_case(gpu)
 

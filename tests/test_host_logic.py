@@ -1,0 +1,216 @@
+"""Host-side logic on the GPU-less build container (kernels run through the tests/emu host build of the same sources):
+optimizer state interchange with torch.optim.Adam, skipped (gradient-less) parameters, in-place re-packing of cached MFMA
+operands, and the staged backward (engine.StepTape + stage marks) that the split hipGraph capture and the overlapped gradient
+all-reduce are built on."""
+import numpy as np
+import torch
+
+from tests.parity_cases import close
+
+
+def _toy_params(seed=0):
+    g = torch.Generator().manual_seed(seed)
+    return [torch.nn.Parameter(torch.randn(7, 5, generator=g)), torch.nn.Parameter(torch.randn(33, generator=g)),
+            torch.nn.Parameter(torch.randn(4, 3, 3, 3, generator=g))]
+
+
+def _grads(step, shapes, seed=11):
+    g = torch.Generator().manual_seed(seed + step)
+    return [torch.randn(s, generator=g) for s in shapes]
+
+
+def test_flat_adam_matches_torch_and_exchanges_state(emu):
+    """RCNet/rcnet_model.py:224-257: `radarnet_optimizer_state_dict` is torch.optim.Adam's state_dict.  FlatAdam must produce that
+    layout, accept it, and continue bit-compatibly (1e-6) in both directions."""
+    from riders_amd.optim import FlatAdam
+    ours, theirs = _toy_params(), _toy_params()
+    shapes = [p.shape for p in ours]
+    fa, ta = FlatAdam(ours, lr=2e-4), torch.optim.Adam(theirs, lr=2e-4)
+    for s in range(3):
+        gs = _grads(s, shapes)
+        fa.zero_grad()
+        for p, q, g in zip(ours, theirs, gs):
+            p.grad, q.grad = g.clone(), g.clone()
+        fa.step(); ta.step()
+    for p, q in zip(ours, theirs):
+        close(p, q, 1e-6, "param after 3 steps")
+    sd = fa.state_dict()
+    assert set(sd) == {"state", "param_groups"} and sd["param_groups"][0]["params"] == [0, 1, 2]
+    assert set(sd["state"][0]) == {"step", "exp_avg", "exp_avg_sq"} and float(sd["state"][0]["step"]) == 3.0
+    # ours -> torch
+    fresh = _toy_params(5)
+    with torch.no_grad():
+        for q, p in zip(fresh, ours):
+            q.copy_(p)
+    tb = torch.optim.Adam(fresh, lr=1e-3)
+    tb.load_state_dict(sd)
+    assert tb.param_groups[0]["lr"] == 2e-4
+    # torch -> ours
+    fresh2 = _toy_params(6)
+    with torch.no_grad():
+        for q, p in zip(fresh2, theirs):
+            q.copy_(p)
+    fb = FlatAdam(fresh2, lr=1e-3)
+    fb.load_state_dict(ta.state_dict())
+    assert fb.param_groups[0]["lr"] == 2e-4 and fb.steps == [3, 3, 3]
+    gs = _grads(9, shapes)
+    fb.zero_grad()
+    for p, q, r, g in zip(fresh2, fresh, theirs, gs):
+        p.grad, q.grad, r.grad = g.clone(), g.clone(), g.clone()
+    fb.step(); tb.step(); ta.step()
+    for p, q, r in zip(fresh2, fresh, theirs):
+        close(p, r, 1e-6, "torch state loaded into FlatAdam")
+        close(q, r, 1e-6, "FlatAdam state loaded into torch")
+    # round trip through torch.save
+    import io
+    buf = io.BytesIO()
+    torch.save(fb.state_dict(), buf); buf.seek(0)
+    fc = FlatAdam(_toy_params(7), lr=1.0)
+    fc.load_state_dict(torch.load(buf))
+    assert torch.equal(fc.exp_avg, fb.exp_avg) and torch.equal(fc.exp_avg_sq, fb.exp_avg_sq) and fc.steps == fb.steps
+
+
+def test_flat_adam_skips_parameters_without_gradient(emu):
+    """torch skips a parameter whose grad is None (no moment decay, no step increment); a parameter that is used only every other
+    step must follow torch exactly, and a never-used one (the reference's idle `projection` convolutions) has no optimizer state."""
+    from riders_amd.optim import FlatAdam
+    ours, theirs = _toy_params(), _toy_params()
+    shapes = [p.shape for p in ours]
+    fa, ta = FlatAdam(ours, lr=1e-2), torch.optim.Adam(theirs, lr=1e-2)
+    for s in range(4):
+        gs = _grads(s, shapes)
+        fa.zero_grad(); ta.zero_grad()
+        for i, (p, q, g) in enumerate(zip(ours, theirs, gs)):
+            if i == 2 or (i == 1 and s % 2 == 1):     # param 2 never trains, param 1 only on even steps
+                continue
+            view = fa._grad_view(p)                    # what a backward kernel does: write the arena slot
+            view.copy_(g)
+            p.grad, q.grad = view, g.clone()
+        fa.step(); ta.step()
+    for p, q in zip(ours, theirs):
+        close(p, q, 1e-6, "intermittently used parameter")
+    assert fa.steps == [4, 2, 0]
+    sd = fa.state_dict()
+    assert sorted(sd["state"]) == [0, 1] and sorted(ta.state_dict()["state"]) == [0, 1]
+
+
+def test_packed_operand_is_repacked_in_place(emu):
+    """A weight written through torch (load_state_dict / broadcast) keeps its packed MFMA operand at the same address (captured
+    hipGraphs read it) and the operand follows the new values."""
+    from riders_amd import engine, net_utils
+    m = net_utils.Conv2d(8, 8, 3, 1, 'kaiming_uniform', None, False)
+    x = torch.randn(1, 8, 6, 5)
+    with torch.no_grad():
+        y0 = m(x)
+    ent = engine._pack_cache[id(m.conv.weight)]
+    (slot, (key0, buf0)), = [(k, v) for k, v in ent.items() if k != "ref"]
+    addr = buf0.data_ptr()
+    new_w = torch.randn_like(m.conv.weight)
+    m.load_state_dict({"conv.weight": new_w})
+    engine.refresh_packed()
+    assert ent[slot][1].data_ptr() == addr and ent[slot][0] != key0
+    with torch.no_grad():
+        y1 = m(x)
+    assert ent[slot][1].data_ptr() == addr
+    ref = torch.nn.functional.conv2d(x, new_w, padding=1)
+    close(y1, ref, 1e-3, "forward after in-place re-pack")
+    assert float((y1 - y0).abs().max()) > 1e-3
+    # without the explicit refresh the next forward re-packs into the same buffer as well
+    with torch.no_grad():
+        m.conv.weight.copy_(torch.randn_like(new_w))
+        y2 = m(x)
+    assert ent[slot][1].data_ptr() == addr
+    close(y2, torch.nn.functional.conv2d(x, m.conv.weight.detach(), padding=1), 1e-3, "forward after torch write")
+
+
+class _TwoStage(torch.nn.Module):
+    """Decoder-style toy with one stage mark: body (Conv2d+BN+LReLU, 1x1 projection) | head (DecoderBlock + 1-channel output conv)."""
+
+    def __init__(self):
+        super().__init__()
+        from riders_amd import net_utils
+        act = net_utils.activation_func('leaky_relu')
+        self.body = net_utils.Conv2d(4, 8, 3, 1, 'kaiming_uniform', act, True)
+        self.proj = net_utils.Conv2d(8, 8, 1, 1, 'kaiming_uniform', None, False)
+        self.head = net_utils.DecoderBlock(8, 0, 8, 'kaiming_uniform', act, True)
+        self.out = net_utils.Conv2d(8, 1, 3, 1, 'kaiming_uniform', None, False)
+
+    def forward(self, x):
+        from riders_amd import engine
+
+        def run(x):
+            h = self.proj._fwd(self.body._fwd(engine.from_nchw(x)))
+            engine.stage_mark("head_done")
+            h = self.out._fwd(self.head._fwd(h, shape=(2 * x.shape[2], 2 * x.shape[3])))
+            return engine.to_nchw_out(h, torch.float32)
+        return engine.run_region(run, (x,), list(self.parameters()))
+
+
+def _toy_loss(model, x, label, valid):
+    from riders_amd import engine
+    logits = model(x)
+    return engine.run_region(lambda lg: engine.bce_masked(lg, label, valid, 2.5), (logits,), [])
+
+
+def _toy_batch(seed, n=2):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(n, 4, 6, 5, generator=g)
+    label = (torch.rand(n, 1, 12, 10, generator=g) > 0.5).float()
+    valid = (torch.rand(n, 1, 12, 10, generator=g) > 0.3).float()
+    return x, label, valid
+
+
+def test_staged_backward_equals_autograd(emu):
+    """engine.StepTape (one tape, driven stage by stage from the calling thread) produces the gradients torch.autograd produces
+    through the module's region, stops at every stage mark, and issues the grouped 1x1 weight gradients before the mark's hooks."""
+    from riders_amd import engine, rcnet_main
+    from riders_amd.optim import FlatAdam
+    from riders_amd.parallel import GradientAllReducer
+    torch.manual_seed(3)
+    model = _TwoStage(); model.train()
+    opt = FlatAdam(list(model.parameters()), lr=1e-3)
+    x, label, valid = _toy_batch(1)
+    loss = _toy_loss(model, x, label, valid)
+    opt.zero_grad(); loss.backward()
+    ref = opt.flat_grad.clone()
+    assert float(ref.abs().max()) > 0
+    opt.flat_grad.zero_()
+    red = GradientAllReducer(opt, stages={"head_done": list(model.head.parameters()) + list(model.out.parameters())})
+    try:
+        tags = []
+        loss2 = rcnet_main.staged_gradients(lambda: _toy_loss(model, x, label, valid), opt, tags.append)
+        assert tags == ["head_done"]
+        assert float(loss2) == float(loss)
+        assert torch.equal(opt.flat_grad, ref)
+        # the stage hook started the head bucket at the mark; reduce() adds the rest of the arena, front to back
+        assert [t for t, _, _ in red.log] == ["head_done"]
+        red.reduce()
+        issued = sorted((s, e) for _, s, e in red.log)
+        assert issued[0][0] == 0 and issued[-1][1] == opt.numel and all(a[1] == b[0] for a, b in zip(issued, issued[1:]))
+        head_lo = min(opt.offsets[opt._index[id(p)]] for p in list(model.head.parameters()) + list(model.out.parameters()))
+        assert red.log[0][1] == head_lo
+    finally:
+        red.close()
+    assert all(p.grad is not None for p in model.parameters())
+
+
+def test_stage_ranges_cover_rcnet_arena():
+    """parallel.rcnet_stages: decoder | transformer + point MLP | (rest = image encoder) are contiguous arena slices."""
+    from riders_amd import rcnet_main
+    from riders_amd.optim import FlatAdam
+    from riders_amd.parallel import GradientAllReducer, rcnet_stages
+    cfg = dict(rcnet_main.ZJU_CONFIG, patch_size=[32, 32], n_filters_encoder_image=[8, 8, 16, 16, 128],
+               n_neurons_encoder_depth=[8, 8, 8, 8, 128], n_filters_decoder=[16, 16, 8, 8, 8])
+    model = rcnet_main.build_model(torch.device('cpu'), cfg)
+    opt = FlatAdam(model.parameters(), lr=1e-3)
+    red = GradientAllReducer(opt, stages=rcnet_stages(model))
+    try:
+        assert len(red.stage_ranges["decoder_done"]) == 1 and len(red.stage_ranges["attention_done"]) == 1
+        n_img = sum((p.numel() + 3) // 4 * 4 for p in model.encoder.encoder_image.parameters())
+        assert red.rest == [(0, n_img)]
+        assert red.stage_ranges["attention_done"][0][0] == n_img
+        assert red.stage_ranges["decoder_done"][0] == (red.stage_ranges["attention_done"][0][1], opt.numel)
+    finally:
+        red.close()
+        from riders_amd import engine
+        engine.set_param_grad_allocator(None)

@@ -164,3 +164,27 @@ def test_roi_pool_c_matches_python_twin():
         o2, a2 = O.roi_pool_py(x, rois, PH, PW, scale)
         assert np.array_equal(a1.numpy(), a2)
         assert np.array_equal(o1.numpy(), o2)
+
+
+def test_roi_pool_oracle_matches_hand_derived_kats():
+    """Pins oracle/roi_pool.c AND its Python twin against tests/golden/roi_pool_kat.json (hand-derived from torchvision's published
+    semantics, generator with the derivations: tests/golden/make_roi_pool_kat.py): values, argmax and the backward scatter-add."""
+    from tests.parity_cases import load_roi_pool_kat
+    cases = load_roi_pool_kat()
+    assert len(cases) >= 11
+    for c in cases:
+        x = np.asarray(c["input"], np.float32)
+        rois = np.asarray(c["rois"], np.float32)
+        PH, PW = c["output_size"]
+        xr = t(x).requires_grad_()
+        o1, a1 = O.roi_pool(xr, t(rois), c["scale"], (PH, PW), return_argmax=True)
+        o2, a2 = O.roi_pool_py(x, rois, PH, PW, c["scale"])
+        for o, a, who in ((o1.detach().numpy(), a1.numpy(), "C"), (o2, a2, "python twin")):
+            assert np.array_equal(a, np.asarray(c["argmax"], np.int32)), (c["name"], who, "argmax")
+            assert np.array_equal(o, np.asarray(c["out"], np.float32)), (c["name"], who, "values")
+        if "grad_out" in c:
+            (o1 * t(np.asarray(c["grad_out"], np.float32))).sum().backward()
+            want = np.zeros(x.shape, np.float32).reshape(x.shape[0], x.shape[1], -1)
+            for n_, c_, k, v in c["grad_in_nonzero"]:
+                want[n_, c_, k] = v
+            assert np.array_equal(xr.grad.numpy().reshape(want.shape), want), (c["name"], "scatter-add")
