@@ -216,6 +216,17 @@ int rd_sigmoid(const void* x, void* y, int64_t n, int32_t dtype, void* stream);
 int rd_scatter_crops(const void* crops, const float* points, float* depth, float* response, int32_t Ncrop, int32_t PH,
                      int32_t PW, int32_t H, int32_t W, float response_thr, int32_t dtype, void* stream);
 
+/* RCNet/run_rcnet_zju.py:221-234: radar points (N,3) -> padded-image coordinates (+pad) and RoI rows (batch, x-pad_x, y-pad_y, x+pad_x, y+pad_y) */
+int rd_points_to_rois(const float* points_in, float* points_out, float* rois, int32_t N, float pad_x, float pad_y, int32_t batch_index,
+                      void* stream);
+/* torchvision convert_boxes_to_roi_format as used by roi_pool at RCNet/networks.py:418-433: boxes (B,K,4) -> rois (B*K,5), image-major;
+   first_image offsets the batch index (per-image box lists are converted one image at a time) */
+int rd_boxes_to_rois(const float* boxes, float* rois, int32_t B, int32_t K, int32_t first_image, void* stream);
+/* data/data_utils.py:128-143 save_depth: uint16 = clamp(trunc(z * multiplier), 0, 65535) (what PIL stores for np.uint32(z * multiplier)) */
+int rd_depth_quantize_u16(const float* z, uint16_t* out, int64_t n, float multiplier, void* stream);
+/* RCNet/run_rcnet_zju.py:253 np.sum(output_depth) == 0 test of the threshold-retry loop: double-precision sum of n floats */
+int rd_sum_f32(const float* x, int64_t n, double* out, void* stream);
+
 /* ---- optimizer -- RCNet/rcnet_main.py:233-238,357-359; train_zju.py:205-211,390-392 ------------------------ */
 int rd_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
                  float beta2, float eps, float weight_decay, int64_t step, float grad_scale, void* stream);
@@ -246,11 +257,15 @@ int rd_reciprocal(const float* x, const float* dy, float* out, int64_t n, void* 
 /* train_zju.py:246-343 + modules/estimator.py:146-176: per-sample bounded L1 scale fit of mono inverse depth to radar */
 int rd_sml_scale_align(const float* mono, const float* sparse_depth, int32_t B, int32_t HW, float min_depth, float max_depth, float lo,
                        float hi, float* scale, int32_t* nvalid, void* stream);
-/* int_depth / int_scales / min-max normalise / nearest resize / mean-std normalise / gray -> x (B,h,w,3), d (B,h,w); mm [B][3] scratch */
+/* train_zju.py:278-287 ('st') + modules/estimator.py:5-29,90-118: per-sample closed-form least-squares scale AND shift */
+int rd_sml_scale_shift_ls(const float* mono, const float* sparse_depth, int32_t B, int32_t HW, float min_depth, float max_depth, float* scale,
+                          float* shift, int32_t* nvalid, void* stream);
+/* int_depth = clamp(scale * mono + shift) (shift may be NULL: 's' alignment) / int_scales / min-max normalise / nearest resize /
+   mean-std normalise / gray -> x (B,h,w,3), d (B,h,w); mm [B][3] scratch.  train_zju.py:289-337 */
 int rd_sml_build_inputs(const float* image_nchw, const float* mono, const float* sparse_depth, const float* rcnet_depth, const float* scale,
-                        float* mm, int32_t B, int32_t H, int32_t W, int32_t h, int32_t w, float min_depth, float max_depth, float clamp_hi,
-                        float clamp_lo, int32_t use_rcnet, float mean_depth, float std_depth, float mean_scales, float std_scales, float* x,
-                        float* d, void* stream);
+                        const float* shift, float* mm, int32_t B, int32_t H, int32_t W, int32_t h, int32_t w, float min_depth,
+                        float max_depth, float clamp_hi, float clamp_lo, int32_t use_rcnet, float mean_depth, float std_depth,
+                        float mean_scales, float std_scales, float* x, float* d, void* stream);
 /* utils/net_utils.py:591-638 */
 int32_t rd_outlier_parts(int64_t n);
 int rd_outlier_removal(const float* depth, float* partial, float* out, int32_t N, int32_t H, int32_t W, int32_t kernel_size, float threshold,

@@ -397,6 +397,30 @@ int rd_scatter_crops(const void* crops, const float* points, float* depth, float
   return done("rd_scatter_crops");
 }
 
+int rd_points_to_rois(const float* points_in, float* points_out, float* rois, int32_t N, float pad_x, float pad_y, int32_t batch_index, void* stream) {
+  if (N < 0) return fail("points_to_rois: negative count");
+  if (N > 0 && (!points_in || !points_out || !rois)) return fail("points_to_rois: null pointer");
+  rd::launch_points_to_rois(points_in, points_out, rois, N, pad_x, pad_y, batch_index, S(stream));
+  return done("rd_points_to_rois");
+}
+int rd_boxes_to_rois(const float* boxes, float* rois, int32_t B, int32_t K, int32_t first_image, void* stream) {
+  if (B < 0 || K < 0) return fail("boxes_to_rois: negative count");
+  if ((int64_t)B * K > 0 && (!boxes || !rois)) return fail("boxes_to_rois: null pointer");
+  rd::launch_boxes_to_rois(boxes, rois, B, K, first_image, S(stream));
+  return done("rd_boxes_to_rois");
+}
+int rd_depth_quantize_u16(const float* z, uint16_t* out, int64_t n, float multiplier, void* stream) {
+  if (n < 0) return fail("depth_quantize_u16: negative count");
+  if (n > 0 && (!z || !out)) return fail("depth_quantize_u16: null pointer");
+  rd::launch_depth_quantize_u16(z, out, n, multiplier, S(stream));
+  return done("rd_depth_quantize_u16");
+}
+int rd_sum_f32(const float* x, int64_t n, double* out, void* stream) {
+  if (!out || (n > 0 && !x) || n < 0) return fail("sum_f32: bad args");
+  rd::launch_sum_f32(x, n, out, S(stream));
+  return done("rd_sum_f32");
+}
+
 int rd_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2, float eps, float wd,
                  int64_t step, float gscale, void* stream) {
   if (!p || !g || !m || !v) return fail("adam: null pointer");
@@ -467,12 +491,19 @@ int rd_sml_scale_align(const float* mono, const float* sparse, int32_t B, int32_
   rd::launch_sml_scale_align(mono, sparse, B, HW, dmin, dmax, lo, hi, scale, nvalid, S(stream));
   return done("rd_sml_scale_align");
 }
-int rd_sml_build_inputs(const float* image, const float* mono, const float* sparse, const float* rcnet, const float* scale, float* mm, int32_t B,
-                        int32_t H, int32_t W, int32_t h, int32_t w, float dmin, float dmax, float hi, float lo, int32_t use_rcnet, float m0,
-                        float s0, float m1, float s1, float* x, float* d, void* stream) {
+int rd_sml_scale_shift_ls(const float* mono, const float* sparse, int32_t B, int32_t HW, float dmin, float dmax, float* scale, float* shift,
+                          int32_t* nvalid, void* stream) {
+  if (!mono || !sparse || !scale || !shift || !nvalid) return fail("sml_scale_shift_ls: null pointer");
+  rd::launch_sml_scale_shift_ls(mono, sparse, B, HW, dmin, dmax, scale, shift, nvalid, S(stream));
+  return done("rd_sml_scale_shift_ls");
+}
+int rd_sml_build_inputs(const float* image, const float* mono, const float* sparse, const float* rcnet, const float* scale, const float* shift,
+                        float* mm, int32_t B, int32_t H, int32_t W, int32_t h, int32_t w, float dmin, float dmax, float hi, float lo,
+                        int32_t use_rcnet, float m0, float s0, float m1, float s1, float* x, float* d, void* stream) {
   if (!image || !mono || !sparse || !scale || !mm || !x || !d) return fail("sml_build_inputs: null pointer");
   if (use_rcnet && !rcnet) return fail("sml_build_inputs: use_rcnet without rcnet depth");
-  rd::launch_sml_build_inputs(image, mono, sparse, rcnet, scale, mm, B, H, W, h, w, dmin, dmax, hi, lo, use_rcnet, m0, s0, m1, s1, x, d, S(stream));
+  rd::launch_sml_build_inputs(image, mono, sparse, rcnet, scale, shift, mm, B, H, W, h, w, dmin, dmax, hi, lo, use_rcnet, m0, s0, m1, s1, x, d,
+                              S(stream));
   return done("rd_sml_build_inputs");
 }
 int32_t rd_outlier_parts(int64_t n) { return rd::outlier_parts(n); }

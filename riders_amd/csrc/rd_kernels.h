@@ -140,6 +140,11 @@ void launch_sigmoid(const void* x, void* y, int64_t n, int dtype, hipStream_t st
 void launch_scatter_crops(const void* crops, const float* points, float* depth, float* response, int Ncrop, int PH, int PW,
                           int H, int W, float thr, int dtype, hipStream_t st);
 
+void launch_points_to_rois(const float* pin, float* pout, float* rois, int N, float pad_x, float pad_y, int batch_index, hipStream_t st);
+void launch_boxes_to_rois(const float* boxes, float* rois, int B, int K, int first_image, hipStream_t st);
+void launch_depth_quantize_u16(const float* z, unsigned short* out, int64_t n, float multiplier, hipStream_t st);
+void launch_sum_f32(const float* x, int64_t n, double* out, hipStream_t st);
+
 // rd_optim.hip
 void launch_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2, float eps,
                  float wd, float bc1, float bc2, float gscale, hipStream_t st);
@@ -158,7 +163,8 @@ void launch_reciprocal(const float* x, const float* dy, float* out, int64_t n, h
 
 // rd_sml.hip
 void launch_sml_scale_align(const float* mono, const float* sparse, int B, int HW, float dmin, float dmax, float lo, float hi, float* scale, int* nvalid, hipStream_t st);
-void launch_sml_build_inputs(const float* image, const float* mono, const float* sparse, const float* rcnet, const float* scale, float* mm, int B, int H, int W, int h, int w, float dmin, float dmax, float hi, float lo, int use_rcnet, float m0, float s0, float m1, float s1, float* x, float* d, hipStream_t st);
+void launch_sml_scale_shift_ls(const float* mono, const float* sparse, int B, int HW, float dmin, float dmax, float* scale, float* shift, int* nvalid, hipStream_t st);
+void launch_sml_build_inputs(const float* image, const float* mono, const float* sparse, const float* rcnet, const float* scale, const float* shift, float* mm, int B, int H, int W, int h, int w, float dmin, float dmax, float hi, float lo, int use_rcnet, float m0, float s0, float m1, float s1, float* x, float* d, hipStream_t st);
 int outlier_parts(int64_t n);
 void launch_outlier_removal(const float* depth, float* partial, float* out, int N, int H, int W, int k, float thr, hipStream_t st);
 int sml_loss_rows(int64_t n);

@@ -112,6 +112,59 @@ __global__ __launch_bounds__(256) void scatter_crops_kernel(const T* __restrict_
   }
 }
 
+// ---- inference driver pieces (RCNet/run_rcnet_zju.py:204-271) ------------------------------------------------------------------------
+// :221-234: every radar point is moved to padded-image coordinates (+ half patch) and gets the box (x - px, y - py, x + px, y + py);
+// rows of `rois` are torchvision's (batch index, x1, y1, x2, y2) (convert_boxes_to_roi_format), so no concatenation is needed later.
+__global__ void points_to_rois_kernel(const float* __restrict__ pin, float* __restrict__ pout, float* __restrict__ rois, int N, float pad_x,
+                                      float pad_y, float batch_index) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N) return;
+  const float x = pin[i * 3] + pad_x, y = pin[i * 3 + 1] + pad_y;
+  pout[i * 3] = x; pout[i * 3 + 1] = y; pout[i * 3 + 2] = pin[i * 3 + 2];
+  float* r = rois + (int64_t)i * 5;
+  r[0] = batch_index; r[1] = x - pad_x; r[2] = y - pad_y; r[3] = x + pad_x; r[4] = y + pad_y;
+}
+// boxes (B, K, 4) -> rois (B*K, 5), image-major (the order torchvision.ops.roi_pool gives a list of per-image box tensors)
+__global__ void boxes_to_rois_kernel(const float* __restrict__ boxes, float* __restrict__ rois, int total, int K, int first_image) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const float* b = boxes + (int64_t)i * 4;
+  float* r = rois + (int64_t)i * 5;
+  r[0] = (float)(first_image + i / K); r[1] = b[0]; r[2] = b[1]; r[3] = b[2]; r[4] = b[3];
+}
+// data/data_utils.py:128-143 save_depth: np.uint32(z * multiplier) stored as a 16-bit PNG.  float32 product, truncation toward zero, and
+// the clamp to 0..65535 PIL applies when it packs mode 'I' into I;16 (negative -> 0, > 65535 -> 65535).
+__global__ void depth_quantize_u16_kernel(const float* __restrict__ z, unsigned short* __restrict__ out, int64_t n, float multiplier) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const float v = z[i] * multiplier;
+    out[i] = (unsigned short)(v >= 65536.f ? 65535.f : (v > 0.f ? truncf(v) : 0.f));
+  }
+}
+// :253 `np.sum(output_depth) == 0` (retry with a lower threshold): one block, double accumulation
+__global__ __launch_bounds__(256) void sum_f32_kernel(const float* __restrict__ x, int64_t n, double* __restrict__ out) {
+  __shared__ double sh[4];
+  double s = 0.0;
+  for (int64_t i = threadIdx.x; i < n; i += 256) s += (double)x[i];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) out[0] = sh[0] + sh[1] + sh[2] + sh[3];
+}
+void launch_points_to_rois(const float* pin, float* pout, float* rois, int N, float pad_x, float pad_y, int batch_index, hipStream_t st) {
+  if (N > 0) hipLaunchKernelGGL(points_to_rois_kernel, dim3((N + 255) / 256), dim3(256), 0, st, pin, pout, rois, N, pad_x, pad_y, (float)batch_index);
+}
+void launch_boxes_to_rois(const float* boxes, float* rois, int B, int K, int first_image, hipStream_t st) {
+  const int total = B * K;
+  if (total > 0) hipLaunchKernelGGL(boxes_to_rois_kernel, dim3((total + 255) / 256), dim3(256), 0, st, boxes, rois, total, K, first_image);
+}
+void launch_depth_quantize_u16(const float* z, unsigned short* out, int64_t n, float multiplier, hipStream_t st) {
+  if (n > 0) hipLaunchKernelGGL(depth_quantize_u16_kernel, dim3(ew_grid(n)), dim3(256), 0, st, z, out, n, multiplier);
+}
+void launch_sum_f32(const float* x, int64_t n, double* out, hipStream_t st) {
+  hipLaunchKernelGGL(sum_f32_kernel, dim3(1), dim3(256), 0, st, x, n, out);
+}
+
 void launch_rcnet_labels(const float* gt, const float* points, float* label, float* valid, int R, int HW, float thr,
                          int all_valid, hipStream_t st) {
   hipLaunchKernelGGL(rcnet_labels_kernel, dim3(ew_grid((int64_t)R * HW)), dim3(256), 0, st, gt, points, label, valid, R, HW, thr, all_valid);

@@ -385,8 +385,11 @@ __global__ __launch_bounds__(256) void roi_pool_bwd_tile_kernel(const T* __restr
             if (a != pa) {
               pa = a; pslot = -1;
               if (a >= 0) {
-                const int ah = (int)(((float)a + 0.5f) * invW);   // exact: a < 2^24 and (a + 0.5) / W is >= 0.5 / W away from an integer
-                const int lh = ah - h0, lw = a - ah * W - w0;
+                // float reciprocal estimate of a / W (error ~ ah * 2^-22: off by one row at most for a < 2^24) + one exact integer correction
+                int ah = (int)(((float)a + 0.5f) * invW);
+                int rem = a - ah * W;
+                if (rem < 0) { ah--; rem += W; } else if (rem >= W) { ah++; rem -= W; }
+                const int lh = ah - h0, lw = rem - w0;
                 if ((unsigned)lh < (unsigned)RPB_T && (unsigned)lw < (unsigned)RPB_T) pslot = (lh * RPB_T + lw) * RPT_CC + g * VE;
               }
             }

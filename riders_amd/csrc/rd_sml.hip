@@ -85,9 +85,37 @@ __global__ __launch_bounds__(256) void sml_scale_align_kernel(const float* __res
   if (threadIdx.x == 0) { scale[b] = res; nvalid[b] = cnt; }
 }
 
-// int_depth = clamp(s*mono), int_scales (1 / rcnet / radar override) -> per-sample min & max of int_scales
-__device__ __forceinline__ float int_depth_of(float s, float mono, float hi, float lo) {
-  float v = s * mono;
+// 'st' global alignment (modules/estimator.py:5-29 compute_scale_and_shift_ls, LeastSquaresEstimator :90-118): closed-form least squares
+// of scale * mono + shift against the inverse radar depth over the valid radar pixels; the 2x2 normal equations are accumulated in
+// double (the reference sums float32 arrays with numpy's pairwise fp32 sum: same quantities, ~1e-6 apart); singular -> (0, 0).
+__global__ __launch_bounds__(256) void sml_scale_shift_ls_kernel(const float* __restrict__ mono, const float* __restrict__ sparse, int HW,
+                                                                 float dmin, float dmax, float* __restrict__ scale,
+                                                                 float* __restrict__ shift, int* __restrict__ nvalid) {
+  __shared__ double sh[4];
+  const int b = blockIdx.x;
+  const float* p = mono + (int64_t)b * HW;
+  const float* z = sparse + (int64_t)b * HW;
+  double a00 = 0.0, a01 = 0.0, a11 = 0.0, b0 = 0.0, b1 = 0.0;
+  for (int i = threadIdx.x; i < HW; i += 256) {
+    const float zi = z[i];
+    if (zi < dmax && zi > dmin) {
+      const double pi = (double)p[i], ti = (double)(1.0f / zi);
+      a00 += pi * pi; a01 += pi; a11 += 1.0; b0 += pi * ti; b1 += ti;
+    }
+  }
+  a00 = block_sum_d(a00, sh); a01 = block_sum_d(a01, sh); a11 = block_sum_d(a11, sh);
+  b0 = block_sum_d(b0, sh); b1 = block_sum_d(b1, sh);
+  if (threadIdx.x == 0) {
+    const double det = a00 * a11 - a01 * a01;
+    double x0 = 0.0, x1 = 0.0;
+    if (det > 0.0) { x0 = (a11 * b0 - a01 * b1) / det; x1 = (-a01 * b0 + a00 * b1) / det; }
+    scale[b] = (float)x0; shift[b] = (float)x1; nvalid[b] = (int)a11;
+  }
+}
+
+// int_depth = clamp(s*mono + shift), int_scales (1 / rcnet / radar override) -> per-sample min & max of int_scales
+__device__ __forceinline__ float int_depth_of(float s, float mono, float hi, float lo, float sft = 0.f) {
+  float v = s * mono + sft;
   if (hi > 0.f && v > hi) v = hi;
   if (lo > 0.f && v < lo) v = lo;
   return v;
@@ -99,17 +127,18 @@ __device__ __forceinline__ float int_scale_of(float idp, float radar, float rc, 
   return sc;
 }
 __global__ __launch_bounds__(256) void sml_scales_minmax_kernel(const float* __restrict__ mono, const float* __restrict__ sparse,
-                                                                const float* __restrict__ rcnet, const float* __restrict__ scale, int HW,
+                                                                const float* __restrict__ rcnet, const float* __restrict__ scale,
+                                                                const float* __restrict__ shift, int HW,
                                                                 float dmin, float dmax, float hi, float lo, int use_rcnet,
                                                                 float* __restrict__ mm /* [B][3] = min, max, nvalid(radar+rcnet) */) {
   __shared__ float smin[4], smax[4], scnt[4];
   const int b = blockIdx.x;
-  const float s = scale[b];
+  const float s = scale[b], sft = shift ? shift[b] : 0.f;
   float mn = INFINITY, mx = -INFINITY, cn = 0.f;
   for (int i = threadIdx.x; i < HW; i += 256) {
     int64_t j = (int64_t)b * HW + i;
     float rc = use_rcnet ? rcnet[j] : 0.f;
-    float v = int_scale_of(int_depth_of(s, mono[j], hi, lo), sparse[j], rc, dmin, dmax, use_rcnet);
+    float v = int_scale_of(int_depth_of(s, mono[j], hi, lo, sft), sparse[j], rc, dmin, dmax, use_rcnet);
     mn = fminf(mn, v); mx = fmaxf(mx, v);
     cn += (sparse[j] < dmax && sparse[j] > dmin) ? 1.f : 0.f;
     cn += (use_rcnet && rc < dmax && rc > dmin) ? 1.f : 0.f;
@@ -128,8 +157,8 @@ __global__ __launch_bounds__(256) void sml_scales_minmax_kernel(const float* __r
 // cv2.INTER_NEAREST source index = min(floor(dst * src/dst_size), src-1)
 __global__ __launch_bounds__(256) void sml_build_inputs_kernel(const float* __restrict__ image /* B,3,H,W */, const float* __restrict__ mono,
                                                                const float* __restrict__ sparse, const float* __restrict__ rcnet,
-                                                               const float* __restrict__ scale, const float* __restrict__ mm, int B, int H,
-                                                               int W, int h, int w, float dmin, float dmax, float hi, float lo,
+                                                               const float* __restrict__ scale, const float* __restrict__ shift,
+                                                               const float* __restrict__ mm, int B, int H, int W, int h, int w, float dmin, float dmax, float hi, float lo,
                                                                int use_rcnet, float m0, float s0, float m1, float s1,
                                                                float* __restrict__ x, float* __restrict__ d) {
   const int64_t total = (int64_t)B * h * w;
@@ -138,7 +167,7 @@ __global__ __launch_bounds__(256) void sml_build_inputs_kernel(const float* __re
     int xx = (int)(i % w); int64_t q = i / w; int yy = (int)(q % h); int b = (int)(q / h);
     int sy = min((int)floor((double)yy * fy), H - 1), sx = min((int)floor((double)xx * fx), W - 1);
     int64_t j = ((int64_t)b * H + sy) * W + sx;
-    float idp = int_depth_of(scale[b], mono[j], hi, lo);
+    float idp = int_depth_of(scale[b], mono[j], hi, lo, shift ? shift[b] : 0.f);
     float rc = use_rcnet ? rcnet[j] : 0.f;
     float sc = int_scale_of(idp, sparse[j], rc, dmin, dmax, use_rcnet);
     float mn = mm[b * 3], mx = mm[b * 3 + 1];
@@ -370,12 +399,16 @@ void launch_sml_scale_align(const float* mono, const float* sparse, int B, int H
                             int* nvalid, hipStream_t st) {
   hipLaunchKernelGGL(sml_scale_align_kernel, dim3(B), dim3(256), 0, st, mono, sparse, HW, dmin, dmax, lo, hi, scale, nvalid);
 }
-void launch_sml_build_inputs(const float* image, const float* mono, const float* sparse, const float* rcnet, const float* scale, float* mm,
-                             int B, int H, int W, int h, int w, float dmin, float dmax, float hi, float lo, int use_rcnet, float m0, float s0,
-                             float m1, float s1, float* x, float* d, hipStream_t st) {
-  hipLaunchKernelGGL(sml_scales_minmax_kernel, dim3(B), dim3(256), 0, st, mono, sparse, rcnet, scale, H * W, dmin, dmax, hi, lo, use_rcnet, mm);
-  hipLaunchKernelGGL(sml_build_inputs_kernel, dim3(ew_grid((int64_t)B * h * w)), dim3(256), 0, st, image, mono, sparse, rcnet, scale, mm, B, H, W,
-                     h, w, dmin, dmax, hi, lo, use_rcnet, m0, s0, m1, s1, x, d);
+void launch_sml_scale_shift_ls(const float* mono, const float* sparse, int B, int HW, float dmin, float dmax, float* scale, float* shift,
+                               int* nvalid, hipStream_t st) {
+  hipLaunchKernelGGL(sml_scale_shift_ls_kernel, dim3(B), dim3(256), 0, st, mono, sparse, HW, dmin, dmax, scale, shift, nvalid);
+}
+void launch_sml_build_inputs(const float* image, const float* mono, const float* sparse, const float* rcnet, const float* scale,
+                             const float* shift, float* mm, int B, int H, int W, int h, int w, float dmin, float dmax, float hi, float lo,
+                             int use_rcnet, float m0, float s0, float m1, float s1, float* x, float* d, hipStream_t st) {
+  hipLaunchKernelGGL(sml_scales_minmax_kernel, dim3(B), dim3(256), 0, st, mono, sparse, rcnet, scale, shift, H * W, dmin, dmax, hi, lo, use_rcnet, mm);
+  hipLaunchKernelGGL(sml_build_inputs_kernel, dim3(ew_grid((int64_t)B * h * w)), dim3(256), 0, st, image, mono, sparse, rcnet, scale, shift, mm, B,
+                     H, W, h, w, dmin, dmax, hi, lo, use_rcnet, m0, s0, m1, s1, x, d);
 }
 int outlier_parts(int64_t n) { return (int)ew_grid(n, 256); }
 void launch_outlier_removal(const float* depth, float* partial, float* out, int N, int H, int W, int k, float thr, hipStream_t st) {

@@ -1,0 +1,120 @@
+"""Depth-map disk format of the RIDERS pipeline: 16-bit grayscale PNG holding uint16(depth * 256), the hand-off between RC-Net
+inference (RCNet/run_rcnet_zju.py:266) and the Scale Map Learner's dataset (data/UTV_dataset.py:14-17).
+
+Same signatures and arithmetic as the reference's data/data_utils.py load_depth :94-125 and save_depth :128-143
+(`np.uint32(z * multiplier)` -> PIL mode 'I' -> PNG, which PIL stores as 16-bit big-endian samples clamped to 0..65535).
+The quantisation runs on the device (rd_depth_quantize_u16) when `z` is a ROCm tensor, so only two bytes per pixel cross PCIe;
+the PNG container itself (zlib-compressed scanlines) is written and parsed here without PIL.
+"""
+import struct
+import zlib
+
+import numpy as np
+
+_SIG = b"\x89PNG\r\n\x1a\n"
+
+
+def quantize_depth(z, multiplier=256.0):
+    """-> numpy uint16 (H,W): clamp(trunc(z * multiplier), 0, 65535), float32 arithmetic as np.uint32(z * multiplier)."""
+    try:
+        import torch
+    except ImportError:  # pragma: no cover
+        torch = None
+    if torch is not None and torch.is_tensor(z):
+        from . import engine
+        zc = z.detach().float().contiguous()
+        out = torch.empty(zc.shape, dtype=torch.int16, device=zc.device)
+        engine._chk(engine.L().rd_depth_quantize_u16(engine._p(zc), engine._p(out), zc.numel(), float(multiplier), engine._stream(zc)),
+                    "rd_depth_quantize_u16")
+        return out.cpu().numpy().view(np.uint16)
+    v = np.asarray(z, dtype=np.float32) * np.float32(multiplier)
+    v = np.where(v >= 65536.0, 65535.0, np.where(v > 0, np.trunc(v), 0.0))
+    return v.astype(np.uint16)
+
+
+def _chunk(tag, data):
+    return struct.pack(">I", len(data)) + tag + data + struct.pack(">I", zlib.crc32(tag + data) & 0xffffffff)
+
+
+def encode_png16(q, level=6):
+    """uint16 (H,W) -> bytes of a 16-bit grayscale PNG (colour type 0, filter 0 on every scanline)."""
+    q = np.ascontiguousarray(q, dtype=np.uint16)
+    assert q.ndim == 2, "depth maps are H x W"
+    h, w = q.shape
+    rows = np.empty((h, 1 + 2 * w), dtype=np.uint8)
+    rows[:, 0] = 0
+    rows[:, 1:] = q.astype(">u2").view(np.uint8).reshape(h, 2 * w)
+    ihdr = struct.pack(">IIBBBBB", w, h, 16, 0, 0, 0, 0)
+    return _SIG + _chunk(b"IHDR", ihdr) + _chunk(b"IDAT", zlib.compress(rows.tobytes(), level)) + _chunk(b"IEND", b"")
+
+
+def decode_png16(data):
+    """bytes of an 8/16-bit grayscale, non-interlaced PNG (what PIL writes for modes 'I' / 'I;16' / 'L') -> integer (H,W) array."""
+    if data[:8] != _SIG:
+        raise ValueError("not a PNG file")
+    pos, idat, hdr = 8, [], None
+    while pos < len(data):
+        n, tag = struct.unpack(">I4s", data[pos:pos + 8])
+        body = data[pos + 8:pos + 8 + n]
+        pos += 12 + n
+        if tag == b"IHDR":
+            hdr = struct.unpack(">IIBBBBB", body)
+        elif tag == b"IDAT":
+            idat.append(body)
+        elif tag == b"IEND":
+            break
+    w, h, depth, ctype, _, _, interlace = hdr
+    if ctype != 0 or interlace != 0 or depth not in (8, 16):
+        raise ValueError("unsupported PNG layout (colour type %d, bit depth %d, interlace %d)" % (ctype, depth, interlace))
+    bpp = depth // 8
+    raw = np.frombuffer(zlib.decompress(b"".join(idat)), dtype=np.uint8).reshape(h, 1 + w * bpp)
+    out = np.zeros((h, w * bpp), dtype=np.uint8)
+    prev = np.zeros(w * bpp, dtype=np.int32)
+    for y in range(h):          # PNG scanline filters (PIL picks them adaptively)
+        ft, line = int(raw[y, 0]), raw[y, 1:].astype(np.int32)
+        if ft == 0:
+            cur = line
+        elif ft == 2:
+            cur = (line + prev) & 255
+        else:
+            cur = np.zeros_like(line)
+            for x in range(w * bpp):
+                a = cur[x - bpp] if x >= bpp else 0
+                b = prev[x]
+                c = prev[x - bpp] if x >= bpp else 0
+                if ft == 1:
+                    pred = a
+                elif ft == 3:
+                    pred = (a + b) >> 1
+                elif ft == 4:
+                    p = a + b - c
+                    pa, pb, pc = abs(p - a), abs(p - b), abs(p - c)
+                    pred = a if (pa <= pb and pa <= pc) else (b if pb <= pc else c)
+                else:
+                    raise ValueError("bad PNG filter type %d" % ft)
+                cur[x] = (line[x] + pred) & 255
+        out[y] = cur
+        prev = cur
+    return out.view(">u2").astype(np.uint16) if depth == 16 else out
+
+
+def load_depth(path, multiplier=256.0, data_format='HW'):
+    """data/data_utils.py:94-125."""
+    z = decode_png16(open(path, "rb").read()).astype(np.float32)
+    z = z / multiplier
+    z[z <= 0] = 0.0
+    if data_format == 'HW':
+        pass
+    elif data_format == 'CHW':
+        z = np.expand_dims(z, axis=0)
+    elif data_format == 'HWC':
+        z = np.expand_dims(z, axis=-1)
+    else:
+        raise ValueError('Unsupported data format: {}'.format(data_format))
+    return z
+
+
+def save_depth(z, path, multiplier=256.0):
+    """data/data_utils.py:128-143; `z` may be a numpy array or a (ROCm) tensor."""
+    with open(path, "wb") as f:
+        f.write(encode_png16(quantize_depth(z, multiplier)))

@@ -142,6 +142,12 @@ def _timed(kind, flops, fn, desc=None, nbytes=0.0):
     return fn() if kt is None else kt.run(kind, flops, fn, desc, nbytes)
 
 
+def _tb(kind, nbytes, fn, desc=None):
+    """HBM-bound launch: algorithmic bytes only (every operand moved once)."""
+    kt = _timer["t"]
+    return fn() if kt is None else kt.run(kind, 0.0, fn, desc, float(nbytes))
+
+
 # ------------------------------------------------------------------------------------------------- tape
 class Tape:
     def __init__(self):
@@ -172,7 +178,8 @@ class Tape:
             self.grads[id(t)] = g
         else:  # never in place: gradient tensors may be shared with other consumers
             s = torch.empty_like(cur)
-            _chk(L().rd_add(_p(cur), _p(g), _p(s), cur.numel(), rd_of(cur), _stream(cur)), "rd_add")
+            _chk(_tb("elementwise", 3 * cur.numel() * cur.element_size(),
+                     lambda: L().rd_add(_p(cur), _p(g), _p(s), cur.numel(), rd_of(cur), _stream(cur)), "grad add"), "rd_add")
             self.grads[id(t)] = s
 
     def pop_grad(self, t):
@@ -621,15 +628,18 @@ def conv_block(x, weight, *, x2=None, bias=None, stride=1, pad=None, up=None, bn
     if use_bn:
         coef = torch.empty((4, Cout), dtype=torch.float32, device=x.device)
         scale, shift, mean, rstd = coef[0], coef[1], coef[2], coef[3]
-        _chk(lib.rd_bn_finalize(_p(stats), 0 if stats is None else stats.shape[0], Cout, float(pixels),
-                                _p(bn.weight.detach() if bn.weight is not None else None),
-                                _p(bn.bias.detach() if bn.bias is not None else None), float(bn.eps),
-                                float(bn.momentum if bn.momentum is not None else 0.1), 1 if bn_train else 0,
-                                _p(bn.running_mean), _p(bn.running_var), _p(mean), _p(rstd), _p(scale), _p(shift), st),
-             "rd_bn_finalize")
+        _chk(_tb("bn_finalize", 0 if stats is None else stats.numel() * 4,
+                 lambda: lib.rd_bn_finalize(_p(stats), 0 if stats is None else stats.shape[0], Cout, float(pixels),
+                                            _p(bn.weight.detach() if bn.weight is not None else None),
+                                            _p(bn.bias.detach() if bn.bias is not None else None), float(bn.eps),
+                                            float(bn.momentum if bn.momentum is not None else 0.1), 1 if bn_train else 0,
+                                            _p(bn.running_mean), _p(bn.running_var), _p(mean), _p(rstd), _p(scale), _p(shift), st),
+                 "bn finalize C=%d" % Cout), "rd_bn_finalize")
     if use_bn or residual is not None:
         z = torch.empty_like(y)
-        _chk(lib.rd_affine_act(_p(y), _p(scale), _p(shift), _p(residual), _p(z), pixels, Cout, act, slope, dt, st), "rd_affine_act")
+        _chk(_tb("bn_apply", (2 + (residual is not None)) * b_out,
+                 lambda: lib.rd_affine_act(_p(y), _p(scale), _p(shift), _p(residual), _p(z), pixels, Cout, act, slope, dt, st),
+                 "bn apply+act M=%d C=%d" % (pixels, Cout)), "rd_affine_act")
     else:
         z = y
     if t is None:
@@ -659,17 +669,22 @@ def conv_block(x, weight, *, x2=None, bias=None, stride=1, pad=None, up=None, bn
             dy = torch.empty_like(y)
             dres = torch.empty_like(y) if need_res else None
             if residual is None and _BN_RECOMPUTE:   # z = act(scale*y + shift): the backward recomputes the activation argument from y, z is not read
-                _chk(lib.rd_bn_act_bwd_recompute(_p(dz), _p(z), _p(y), _p(mean), _p(rstd), _p(scale), _p(shift), _p(partial), _p(coef2),
-                                                 _p(dgam), _p(dbet), acc, _p(dy), _p(dres), pixels, Cout, act, slope, dt, st),
-                     "rd_bn_act_bwd_recompute")
+                # algorithmic bytes: dz and y read once, dy written once (the two-pass kernels read dz and y twice)
+                _chk(_tb("bn_backward", 3 * b_out,
+                         lambda: lib.rd_bn_act_bwd_recompute(_p(dz), _p(z), _p(y), _p(mean), _p(rstd), _p(scale), _p(shift), _p(partial), _p(coef2),
+                                                             _p(dgam), _p(dbet), acc, _p(dy), _p(dres), pixels, Cout, act, slope, dt, st),
+                         "bn backward M=%d C=%d" % (pixels, Cout)), "rd_bn_act_bwd_recompute")
             else:
-                _chk(lib.rd_bn_act_bwd(_p(dz), _p(z), _p(y), _p(mean), _p(rstd), _p(scale), _p(partial), _p(coef2), _p(dgam),
-                                       _p(dbet), acc, _p(dy), _p(dres), pixels, Cout, act, slope, dt, st), "rd_bn_act_bwd")
+                _chk(_tb("bn_backward", (4 + (dres is not None)) * b_out,
+                         lambda: lib.rd_bn_act_bwd(_p(dz), _p(z), _p(y), _p(mean), _p(rstd), _p(scale), _p(partial), _p(coef2), _p(dgam),
+                                                   _p(dbet), acc, _p(dy), _p(dres), pixels, Cout, act, slope, dt, st),
+                         "bn backward(res) M=%d C=%d" % (pixels, Cout)), "rd_bn_act_bwd")
         else:
             eff_act = act
             if eff_act != ACT_NONE:
                 dy = torch.empty_like(y)
-                _chk(lib.rd_act_bwd(_p(dz), _p(z), _p(dy), dz.numel(), eff_act, slope, dt, st), "rd_act_bwd")
+                _chk(_tb("elementwise", 3 * b_out, lambda: lib.rd_act_bwd(_p(dz), _p(z), _p(dy), dz.numel(), eff_act, slope, dt, st), "act bwd"),
+                     "rd_act_bwd")
             else:
                 dy = dz
             dres = dy
@@ -704,11 +719,15 @@ def conv_block(x, weight, *, x2=None, bias=None, stride=1, pad=None, up=None, bn
                                                                        None, st), "dgrad " + shp, b_out + b_w + N * Hin * Win * Cin * es), "rd_conv_fwd(dgrad)")
             if is_up:
                 g1 = torch.empty_like(x)
-                _chk(lib.rd_upsample_nearest_bwd(_p(dxv1), _p(g1), N, H1, W1, Hin, Win, C1, dt, st), "rd_upsample_nearest_bwd")
+                _chk(_tb("elementwise", (dxv1.numel() + g1.numel()) * es,
+                         lambda: lib.rd_upsample_nearest_bwd(_p(dxv1), _p(g1), N, H1, W1, Hin, Win, C1, dt, st), "upsample bwd"),
+                     "rd_upsample_nearest_bwd")
                 g2 = None
                 if C2:
                     g2 = torch.empty_like(x2)
-                    _chk(lib.rd_upsample_nearest_bwd(_p(dxv2), _p(g2), N, H1, W1, Hin, Win, C2, dt, st), "rd_upsample_nearest_bwd")
+                    _chk(_tb("elementwise", (dxv2.numel() + g2.numel()) * es,
+                             lambda: lib.rd_upsample_nearest_bwd(_p(dxv2), _p(g2), N, H1, W1, Hin, Win, C2, dt, st), "upsample bwd"),
+                         "rd_upsample_nearest_bwd")
             else:
                 g1, g2 = dxv1, dxv2
             t.add_grad(x, g1)
@@ -748,7 +767,8 @@ def maxpool(x, k=3, s=2, p=1):
     OH, OW = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
     out = torch.empty((N, OH, OW, C), dtype=x.dtype, device=x.device)
     arg = torch.empty((N, OH, OW, C), dtype=torch.uint8, device=x.device)
-    _chk(lib.rd_maxpool_fwd(_p(x), _p(out), _p(arg), N, H, W, C, OH, OW, k, s, p, dt, st), "rd_maxpool_fwd")
+    _chk(_tb("pooling", x.numel() * x.element_size() + out.numel() * (x.element_size() + 1),
+             lambda: lib.rd_maxpool_fwd(_p(x), _p(out), _p(arg), N, H, W, C, OH, OW, k, s, p, dt, st), "maxpool fwd"), "rd_maxpool_fwd")
     if t is not None and t.requires(x):
         t.mark(out)
 
@@ -757,7 +777,8 @@ def maxpool(x, k=3, s=2, p=1):
             if g is None:
                 return
             dx = torch.empty_like(x)
-            _chk(lib.rd_maxpool_bwd(_p(g), _p(arg), _p(dx), N, H, W, C, OH, OW, k, s, p, dt, st), "rd_maxpool_bwd")
+            _chk(_tb("pooling", x.numel() * x.element_size() + out.numel() * (x.element_size() + 1),
+                     lambda: lib.rd_maxpool_bwd(_p(g), _p(arg), _p(dx), N, H, W, C, OH, OW, k, s, p, dt, st), "maxpool bwd"), "rd_maxpool_bwd")
             t.add_grad(x, dx)
         t.record(backward)
     return out
@@ -771,7 +792,10 @@ def roi_pool(x, rois, output_size, spatial_scale):
     PH, PW = int(output_size[0]), int(output_size[1])
     out = torch.empty((R, PH, PW, C), dtype=x.dtype, device=x.device)
     arg = torch.empty((R, PH, PW, C), dtype=torch.int32, device=x.device)
-    _chk(lib.rd_roi_pool_fwd(_p(x), _p(rois), _p(out), _p(arg), R, N, H, W, C, PH, PW, float(spatial_scale), dt, st), "rd_roi_pool_fwd")
+    # algorithmic bytes: pooled values + int32 argmax written, the source map read once
+    roi_bytes = out.numel() * (x.element_size() + 4) + x.numel() * x.element_size()
+    _chk(_tb("roi_pool", roi_bytes, lambda: lib.rd_roi_pool_fwd(_p(x), _p(rois), _p(out), _p(arg), R, N, H, W, C, PH, PW, float(spatial_scale), dt, st),
+             "roi_pool fwd %dx%d C=%d" % (PH, PW, C)), "rd_roi_pool_fwd")
     out._rd_argmax = arg
     if t is not None and t.requires(x):
         t.mark(out)
@@ -789,12 +813,14 @@ def roi_pool(x, rois, output_size, spatial_scale):
             nblk = ((H + 15) // 16) * ((W + 15) // 16) * N * (C // 32)
             if C % 32 == 0 and H * W < (1 << 24) and _ROI_TILE and nblk >= _state["roi_tile_min_blocks"]:   # LDS tile accumulators (small maps: too few tiles)
                 dx = torch.empty_like(x)
-                _chk(lib.rd_roi_pool_bwd_tile(_p(g), _p(rois), _p(arg), _p(dx), R, N, H, W, C, PH, PW, float(spatial_scale), dt, st),
-                     "rd_roi_pool_bwd_tile")
+                _chk(_tb("roi_pool", roi_bytes, lambda: lib.rd_roi_pool_bwd_tile(_p(g), _p(rois), _p(arg), _p(dx), R, N, H, W, C, PH, PW,
+                                                                                    float(spatial_scale), dt, st),
+                         "roi_pool bwd(tile) %dx%d C=%d" % (PH, PW, C)), "rd_roi_pool_bwd_tile")
                 t.add_grad(x, dx)
                 return
             dx32 = torch.empty((N, H, W, C), dtype=torch.float32, device=x.device)
-            _chk(lib.rd_roi_pool_bwd(_p(g), _p(rois), _p(arg), _p(dx32), R, N, H, W, C, PH, PW, dt, st), "rd_roi_pool_bwd")
+            _chk(_tb("roi_pool", roi_bytes, lambda: lib.rd_roi_pool_bwd(_p(g), _p(rois), _p(arg), _p(dx32), R, N, H, W, C, PH, PW, dt, st),
+                     "roi_pool bwd(atomic) %dx%d C=%d" % (PH, PW, C)), "rd_roi_pool_bwd")
             t.add_grad(x, cast(dx32, x.dtype))
         t.record(backward)
     return out
@@ -1004,7 +1030,8 @@ def add_act(a, b, act=ACT_NONE, slope=0.2):
     lib, t, dt, st = L(), tape(), rd_of(a), _stream(a)
     C = a.shape[-1]
     out = torch.empty_like(a)
-    _chk(lib.rd_affine_act(_p(a), None, None, _p(b), _p(out), a.numel() // C, C, act, slope, dt, st), "rd_affine_act")
+    _chk(_tb("elementwise", 3 * a.numel() * a.element_size(),
+             lambda: lib.rd_affine_act(_p(a), None, None, _p(b), _p(out), a.numel() // C, C, act, slope, dt, st), "add+act"), "rd_affine_act")
     if t is not None and t.requires(a, b):
         t.mark(out)
 

@@ -12,19 +12,32 @@ from .linear_attention import LocalFeatureTransformer
 
 
 def boxes_to_rois(b_boxes, device=None):
-    """list of B tensors (K,4) (x1,y1,x2,y2) -> (R,5) fp32 rows (batch index, x1, y1, x2, y2), image-major.
-    Mirrors torchvision.ops._utils.convert_boxes_to_roi_format used by roi_pool (networks.py:418-433).
-    A ready (R,5) tensor is passed through."""
+    """list of B tensors (K,4) (x1,y1,x2,y2), or one (B,K,4) tensor -> (R,5) fp32 rows (batch index, x1, y1, x2, y2), image-major.
+    Mirrors torchvision.ops._utils.convert_boxes_to_roi_format used by roi_pool (networks.py:418-433); one rd_boxes_to_rois launch
+    (per image for a list) instead of a fill + concatenation per image.  A ready (R,5) tensor is passed through."""
     if torch.is_tensor(b_boxes):
         if b_boxes.dim() == 2 and b_boxes.shape[1] == 5:
             return b_boxes.to(torch.float32).contiguous()
-        if b_boxes.dim() == 3:  # (B, K, 4)
-            b_boxes = list(b_boxes)
-    rows = []
-    for i, b in enumerate(b_boxes):
-        idx = torch.full((b.shape[0], 1), float(i), dtype=torch.float32, device=b.device)
-        rows.append(torch.cat([idx, b.to(torch.float32)], dim=1))
-    return torch.cat(rows, dim=0).contiguous()
+        if b_boxes.dim() == 2 and b_boxes.shape[1] == 4:
+            b_boxes = b_boxes[None]
+        b_boxes = [b_boxes]
+        chunks = [(b_boxes[0], 0)]
+    else:
+        chunks, img = [], 0
+        for b in b_boxes:
+            chunks.append((b[None], img))
+            img += 1
+    total = sum(c.shape[0] * c.shape[1] for c, _ in chunks)
+    dev = chunks[0][0].device
+    rois = torch.empty((total, 5), dtype=torch.float32, device=dev)
+    lib, row = engine.L(), 0
+    for c, first in chunks:
+        c = c if (c.dtype == torch.float32 and c.is_contiguous()) else c.to(torch.float32).contiguous()
+        B, K = c.shape[0], c.shape[1]
+        if B * K:
+            engine._chk(lib.rd_boxes_to_rois(engine._p(c), engine._p(rois[row:]), B, K, first, engine._stream(c)), "rd_boxes_to_rois")
+        row += B * K
+    return rois
 
 
 class ResNetEncoder(torch.nn.Module):

@@ -105,10 +105,10 @@ class FlatAdam(object):
     def _launch(self, start, end, step):
         g = self.param_groups[0]
         sl = slice(start, end)
-        rc = engine.L().rd_adam_step(engine._p(self.flat_param[sl]), engine._p(self.flat_grad[sl]), engine._p(self.exp_avg[sl]),
-                                     engine._p(self.exp_avg_sq[sl]), end - start, ctypes.c_float(g['lr']), ctypes.c_float(g['betas'][0]),
-                                     ctypes.c_float(g['betas'][1]), ctypes.c_float(g['eps']), ctypes.c_float(g['weight_decay']),
-                                     step, ctypes.c_float(self.grad_scale), engine._stream(self.flat_param))
+        rc = engine._tb("optimizer", 28 * (end - start), lambda: engine.L().rd_adam_step(
+            engine._p(self.flat_param[sl]), engine._p(self.flat_grad[sl]), engine._p(self.exp_avg[sl]), engine._p(self.exp_avg_sq[sl]), end - start,
+            ctypes.c_float(g['lr']), ctypes.c_float(g['betas'][0]), ctypes.c_float(g['betas'][1]), ctypes.c_float(g['eps']),
+            ctypes.c_float(g['weight_decay']), step, ctypes.c_float(self.grad_scale), engine._stream(self.flat_param)), "adam")
         engine._chk(rc, "rd_adam_step")
 
     def step(self):

@@ -87,9 +87,17 @@ def train_step(model, optimizer, batch, cfg=ZJU_CONFIG, reducer=None):
     return loss
 
 
-def forward_output(model, image, radar_points, bounding_boxes_list, response_thr=0.5, device=None):
-    """rcnet_main.py:435-487: edge-pad, one forward over all N points, threshold, integer paste, confidence-weighted
-    mean depth; zero where nothing responds.  image (1,3,H,W) already normalised; radar_points (N,3) in padded coords."""
+def _scatter(crops, pts, ph, pw, H, W, response_thr):
+    depth = torch.empty((1, H, W), dtype=torch.float32, device=crops.device)
+    resp = torch.empty((1, H, W), dtype=torch.float32, device=crops.device)
+    engine._chk(engine.L().rd_scatter_crops(engine._p(crops), engine._p(pts), engine._p(depth), engine._p(resp), crops.shape[0], ph, pw,
+                                            H, W, ctypes.c_float(response_thr), engine.rd_of(crops), engine._stream(crops)),
+                "rd_scatter_crops")
+    return depth, resp
+
+
+def forward_crops(model, image, radar_points, bounding_boxes_list):
+    """First half of rcnet_main.py:435-487: edge-pad, one forward over all N points -> (crops (N,1,ph,pw) sigmoid responses, points)."""
     ph, pw = model.input_patch_size_image
     pad_y, pad_x = ph // 2, pw // 2
     image = torch.nn.functional.pad(image, (pad_x, pad_x, pad_y, pad_y), mode='replicate')  # data prep, as the reference
@@ -97,13 +105,56 @@ def forward_output(model, image, radar_points, bounding_boxes_list, response_thr
         radar_points = torch.squeeze(radar_points, dim=0)
     pts = radar_points.contiguous().float()
     crops = model.forward(image=image, point=pts, bounding_boxes=bounding_boxes_list, return_logits=False)
-    H, W = image.shape[-2] - 2 * pad_y, image.shape[-1] - 2 * pad_x
-    depth = torch.empty((1, H, W), dtype=torch.float32, device=crops.device)
-    resp = torch.empty((1, H, W), dtype=torch.float32, device=crops.device)
-    engine._chk(engine.L().rd_scatter_crops(engine._p(crops), engine._p(pts), engine._p(depth), engine._p(resp), crops.shape[0], ph, pw,
-                                            H, W, ctypes.c_float(response_thr), engine.rd_of(crops), engine._stream(crops)),
-                "rd_scatter_crops")
-    return depth, resp
+    return crops, pts, (image.shape[-2] - 2 * pad_y, image.shape[-1] - 2 * pad_x)
+
+
+def forward_output(model, image, radar_points, bounding_boxes_list, response_thr=0.5, device=None):
+    """rcnet_main.py:435-487: edge-pad, one forward over all N points, threshold, integer paste, confidence-weighted
+    mean depth; zero where nothing responds.  image (1,3,H,W) already normalised; radar_points (N,3) in padded coords."""
+    ph, pw = model.input_patch_size_image
+    crops, pts, (H, W) = forward_crops(model, image, radar_points, bounding_boxes_list)
+    return _scatter(crops, pts, ph, pw, H, W, response_thr)
+
+
+def points_to_boxes(radar_points, patch_size):
+    """run_rcnet_zju.py:221-234: (N,3) radar points in image coordinates -> (points shifted into the padded image, RoI rows
+    (0, x - pad_x, y - pad_y, x + pad_x, y + pad_y)); one launch instead of the reference's per-point Python loop."""
+    pad_x, pad_y = patch_size[1] // 2, patch_size[0] // 2
+    pts = radar_points.reshape(-1, radar_points.shape[-1]).contiguous().float()
+    N = pts.shape[0]
+    out = torch.empty_like(pts)
+    rois = torch.empty((N, 5), dtype=torch.float32, device=pts.device)
+    engine._chk(engine.L().rd_points_to_rois(engine._p(pts), engine._p(out), engine._p(rois), N, float(pad_x), float(pad_y), 0,
+                                             engine._stream(pts)), "rd_points_to_rois")
+    return out, rois
+
+
+def fuse_with_retry(crops, pts, ph, pw, H, W, response_thr=0.5, thr_step=0.05):
+    """run_rcnet_zju.py:250-264: fuse the crops (rcnet_main.py:460-485); while the fused depth sums to zero lower the threshold by 0.05."""
+    thr = response_thr
+    total = torch.empty(1, dtype=torch.float64, device=crops.device)
+    while True:
+        depth, resp = _scatter(crops, pts, ph, pw, H, W, thr)
+        engine._chk(engine.L().rd_sum_f32(engine._p(depth), depth.numel(), engine._p(total), engine._stream(depth)), "rd_sum_f32")
+        if float(total) != 0.0:
+            return depth, resp, thr
+        if thr < -1.0:
+            raise RuntimeError("fuse_with_retry: no radar point responds at any threshold (no points?)")
+        thr = thr - thr_step
+
+
+def run_frame(model, image, radar_points, response_thr=0.5, thr_step=0.05):
+    """One frame of run_rcnet_zju.py:204-266: box construction (:221-234), /255 normalisation (transforms, :236-240), forward_output
+    (:242-248) and the retry loop (:250-264) that lowers the response threshold by 0.05 while the fused depth map is all zeros.
+    The reference re-runs the whole network per retry; the crops do not depend on the threshold, so only the scatter is repeated here.
+    image (1,3,H,W) 0..255, radar_points (N,3) or (1,N,3) image coordinates.  Returns (depth (H,W) fp32, response (H,W), threshold)."""
+    ph, pw = model.input_patch_size_image
+    pts, rois = points_to_boxes(radar_points, (ph, pw))
+    img = engine.as_nchw(engine.nchw_to_nhwc(image.float(), scale=1.0 / 255.0, dtype=torch.float32))
+    with torch.no_grad():
+        crops, pts, (H, W) = forward_crops(model, img, pts, rois)
+        depth, resp, thr = fuse_with_retry(crops, pts, ph, pw, H, W, response_thr, thr_step)
+    return depth[0], resp[0], thr
 
 
 def forward_loss(model, batch, cfg=ZJU_CONFIG):

@@ -15,7 +15,7 @@ from .net_utils import OutlierRemoval
 # train_zju.py:429-487
 ZJU_SML_CONFIG = dict(min_pred=0.1, max_pred=255.0, min_depth=0.0, max_depth=100.0, learning_rate=1e-4, loss_func='l1', w_smoothness=0.2,
                       w_lidar_loss=1.5, w_edge=0.0, sobel_filter_size=7, outlier_removal_kernel_size=3, outlier_removal_threshold=1.5,
-                      scale_bounds=(0.01, 0.3), mean_std=dict(int_depth=(0.729, 0.210), int_scales=(0.404, 0.117)), interp='rcnet')
+                      scale_bounds=(0.01, 0.3), mean_std=dict(int_depth=(0.729, 0.210), int_scales=(0.404, 0.117)), interp='rcnet', global_alignment='s')
 
 
 def net_size(height, width, net_h=288, net_w=384, multiple=32):
@@ -49,8 +49,9 @@ def synthetic_batch(batch_size, height=288, width=384, seed=1234, device='cpu'):
 
 
 def prepare_inputs(image, mono_pred, sparse_depth, rcnet, net_hw, cfg=ZJU_SML_CONFIG):
-    """S1 on device: valid masks, inverse depth, bounded L1 scale fit, int_depth / int_scales, min-max normalise, nearest resize,
-    mean/std normalise, gray image.  Returns x (B,3,h,w) logical NCHW (channels_last, fp32), d (B,1,h,w), scale (B,)."""
+    """S1 on device: valid masks, inverse depth, global alignment ('s': bounded L1 scale fit, estimator.py:146-160; 'st': closed-form
+    least-squares scale + shift, estimator.py:5-29), int_depth / int_scales, min-max normalise, nearest resize, mean/std normalise, gray
+    image.  Returns x (B,3,h,w) logical NCHW (channels_last, fp32), d (B,1,h,w), scale (B,) -- or (scale, shift) for 'st'."""
     lib = engine.L()
     B, _, H, W = image.shape
     h, w = net_hw
@@ -58,18 +59,27 @@ def prepare_inputs(image, mono_pred, sparse_depth, rcnet, net_hw, cfg=ZJU_SML_CO
     p = engine._p
     scale = torch.empty(B, dtype=torch.float32, device=image.device)
     nvalid = torch.empty(B, dtype=torch.int32, device=image.device)
-    lo, hi = cfg['scale_bounds']
-    engine._chk(lib.rd_sml_scale_align(p(mono_pred), p(sparse_depth), B, H * W, cfg['min_depth'], cfg['max_depth'], lo, hi, p(scale), p(nvalid), st),
-                "rd_sml_scale_align")
+    shift = None
+    mode = cfg.get('global_alignment', 's')
+    if mode == 'st':
+        shift = torch.empty(B, dtype=torch.float32, device=image.device)
+        engine._chk(lib.rd_sml_scale_shift_ls(p(mono_pred), p(sparse_depth), B, H * W, cfg['min_depth'], cfg['max_depth'], p(scale), p(shift),
+                                              p(nvalid), st), "rd_sml_scale_shift_ls")
+    elif mode == 's':
+        lo, hi = cfg['scale_bounds']
+        engine._chk(lib.rd_sml_scale_align(p(mono_pred), p(sparse_depth), B, H * W, cfg['min_depth'], cfg['max_depth'], lo, hi, p(scale), p(nvalid),
+                                           st), "rd_sml_scale_align")
+    else:
+        raise NotImplementedError("global_alignment %r (train_zju.py:278-302 knows 's' and 'st')" % (mode,))
     mm = torch.empty((B, 3), dtype=torch.float32, device=image.device)
     x = torch.empty((B, h, w, 3), dtype=torch.float32, device=image.device)
     d = torch.empty((B, 1, h, w), dtype=torch.float32, device=image.device)
     use_rc = 1 if ('rcnet' in cfg['interp'] and rcnet is not None) else 0
     (m0, s0), (m1, s1) = cfg['mean_std']['int_depth'], cfg['mean_std']['int_scales']
-    engine._chk(lib.rd_sml_build_inputs(p(image), p(mono_pred), p(sparse_depth), p(rcnet), p(scale), p(mm), B, H, W, h, w, cfg['min_depth'],
-                                        cfg['max_depth'], 1.0 / cfg['min_pred'], 1.0 / cfg['max_pred'], use_rc, m0, s0, m1, s1, p(x), p(d), st),
-                "rd_sml_build_inputs")
-    return x.permute(0, 3, 1, 2), d, scale
+    engine._chk(lib.rd_sml_build_inputs(p(image), p(mono_pred), p(sparse_depth), p(rcnet), p(scale), p(shift), p(mm), B, H, W, h, w,
+                                        cfg['min_depth'], cfg['max_depth'], 1.0 / cfg['min_pred'], 1.0 / cfg['max_pred'], use_rc, m0, s0, m1, s1,
+                                        p(x), p(d), st), "rd_sml_build_inputs")
+    return x.permute(0, 3, 1, 2), d, (scale if shift is None else (scale, shift))
 
 
 def nearest_resize(t, h, w):

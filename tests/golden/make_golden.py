@@ -184,8 +184,31 @@ def g_rcnet_e2e():
          thr2=np.array([thr], np.float32), depth2=depth2.numpy(), resp2=resp2.numpy())
 
 
+# ---------------------------------------------------------------------------------------------- G12: depth PNG codec
+def g_depth_png():
+    """The reference's own save_depth / load_depth (data/data_utils.py:94-143) on a seeded depth map with the edge values of the uint16 * 256
+    encoding: the PNG file it writes (bytes), what it reads back, and the stored integers."""
+    import io
+    import tempfile
+    from data import data_utils
+    z = rand_array("g12.z", (37, 53), 90.0, lo=0.0).astype(np.float32)
+    z[rand_array("g12.m", z.shape, 1.0, lo=0.0) < 0.6] = 0.0
+    z[0, :8] = np.array([0.0, 0.001, 0.0039, 0.00390625, 1.5, 255.99, 255.998, 99.999], np.float32)
+    z[1, :4] = np.array([256.0, 300.0, 1e-9, 255.99609375], np.float32)      # >= 256 m saturates at 65535 in the reference's file
+    with tempfile.TemporaryDirectory() as d:
+        path = os.path.join(d, "z.png")
+        data_utils.save_depth(z, path)
+        raw = np.frombuffer(open(path, "rb").read(), dtype=np.uint8).copy()
+        back = data_utils.load_depth(path)
+        from PIL import Image
+        stored = np.array(Image.open(io.BytesIO(raw.tobytes()))).astype(np.uint16)
+    save("g12_depth_png", z=z, png=raw, loaded=back.astype(np.float32), stored=stored)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["attention", "resnet", "decoder", "e2e"]
+    which = sys.argv[1:] or ["attention", "resnet", "decoder", "e2e", "png"]
+    if "png" in which:
+        g_depth_png()
     if "attention" in which:
         g_attention()
     if "resnet" in which:

@@ -407,6 +407,44 @@ def scatter_crops_case(dev):
         close(depth, g[dk], 1e-5, "scatter depth"); close(resp, g[rk], 1e-6, "scatter response")
 
 
+def inference_driver_case(dev):
+    """H4 pieces of RCNet/run_rcnet_zju.py:204-271 on the device: box construction (:221-234) against the boxes the golden generator
+    built the reference way (fixture g10, exact), the threshold-retry loop (:250-264) against the oracle's forward_output run in the same
+    loop (exact support set; the first threshold that gives a non-empty map must be the same), and save_depth's quantisation
+    (data/data_utils.py:128-143) against the integers the REFERENCE stored (fixture g12, exact)."""
+    from riders_amd import data_utils, engine, rcnet_main
+    from riders_amd.networks import boxes_to_rois
+    g = load("g10_forward_output")
+    patch, H, W = (64, 32), 64, 96
+    pad_y, pad_x = patch[0] // 2, patch[1] // 2
+    raw = g["pts"].copy(); raw[:, 0] -= pad_x; raw[:, 1] -= pad_y           # image coordinates, as the dataset hands them over
+    pts, rois = rcnet_main.points_to_boxes(t(raw, dev)[None], patch)
+    assert np.array_equal(pts.cpu().numpy(), g["pts"]) and np.array_equal(rois[:, 1:].cpu().numpy(), g["boxes"])
+    assert float(rois[:, 0].abs().max()) == 0.0
+    # per-image box lists -> RoI rows (image-major, batch index column), list and stacked-tensor forms
+    b2 = np.stack([g["boxes"], g["boxes"] + 1.0])
+    want = np.concatenate([np.concatenate([np.full((b2.shape[1], 1), i, np.float32), b2[i]], 1) for i in range(2)])
+    assert np.array_equal(boxes_to_rois([t(b2[0], dev), t(b2[1], dev)]).cpu().numpy(), want)
+    assert np.array_equal(boxes_to_rois(t(b2, dev)).cpu().numpy(), want)
+    # retry loop: start above every response
+    crops = t(g["crops"], dev)
+    start = float(g["crops"].max()) + 0.12
+    depth, resp, thr = rcnet_main.fuse_with_retry(crops, t(g["pts"], dev), patch[0], patch[1], H, W, start)
+    rthr = start
+    while True:
+        rd_, rr_ = O.forward_output(t(g["crops"]), t(g["pts"]), patch, (H + 2 * pad_y, W + 2 * pad_x), rthr)
+        if float(rd_.sum()) != 0:
+            break
+        rthr -= 0.05
+    assert thr == rthr and thr < start, (thr, rthr, start)
+    assert np.array_equal(depth.cpu().numpy().reshape(H, W) != 0, rd_.numpy().reshape(H, W) != 0), "support set after retry differs"
+    close(depth.reshape(H, W), rd_.reshape(H, W), 1e-5, "depth after retry")
+    # save_depth quantisation on the device
+    g12 = load("g12_depth_png")
+    q = data_utils.quantize_depth(t(g12["z"], dev))
+    assert q.dtype == np.uint16 and np.array_equal(q, g12["stored"]), "uint16 * 256 encoding differs from what the reference stored"
+
+
 def adam_case(dev):
     from riders_amd.optim import FlatAdam
     ps = [torch.nn.Parameter(t(rand_array("ad.p%d" % i, s, 1.0), dev)) for i, s in enumerate([(7, 5), (33,), (4, 3, 3, 3)])]
@@ -550,6 +588,78 @@ def rcnet_e2e_case(dev, tol=TOL):
                 continue
             rn = float(g[pref + k + "|norm"][0])
             assert abs(float(p.grad.norm()) - rn) < 5 * tol * max(rn, 1e-4), (k, float(p.grad.norm()), rn)
+
+
+def _module_grads(model):
+    """{top-level module name: flat fp32 gradient vector} for the RC-Net encoder / decoder parts."""
+    enc, dec = model.encoder, model.decoder
+    groups = {"encoder_image": enc.encoder_image, "attention": enc.attention, "encoder_depth": enc.encoder_depth, "decoder": dec}
+    return {k: torch.cat([p.grad.detach().float().reshape(-1) for p in m.parameters() if p.grad is not None]).cpu() for k, m in groups.items()}
+
+
+def rcnet_fullsize_oracle_case(dev, tol=TOL):
+    """configs[1] geometry at full size on ONE image: 3x256x512 thermal edge-padded to 496x612, K = 30 radar points, patch 240x100
+    (R = 30 RoIs; every launch geometry of the B = 8 step except the batch factor) -- fp32 HIP path vs the oracle: logits and loss
+    within 1e-3, labels exact, per-module gradient vectors within 5e-3 relative L2."""
+    from riders_amd import engine, rcnet_main
+    cfg = rcnet_main.ZJU_CONFIG
+    torch.manual_seed(0)
+    model = rcnet_main.build_model(dev, cfg)
+    model.train()
+    sd_e = leaves(model.encoder.state_dict()); sd_d = leaves(model.decoder.state_dict())
+    batch = rcnet_main.synthetic_batch(1, 256, 512, cfg, seed=77)
+    image, pts, rois, gt = rcnet_main.prepare_batch(tuple(b.to(dev) for b in batch))
+    label, valid = engine.rcnet_labels(gt, pts, 0.5)
+    logits = model.forward(image, pts, rois)
+    loss, _ = model.compute_loss(logits, label, valid, 2.5)
+    loss.backward()
+    pts_c = batch[1].reshape(-1, 3); gt_c = batch[3].reshape(-1, 1, 240, 100)
+    lab_c, val_c = O.rcnet_labels(gt_c, pts_c, 0.5)
+    assert torch.equal(label.cpu(), lab_c) and torch.equal(valid.cpu(), val_c)
+    ref = O.rcnet_forward(batch[0] / 255.0, pts_c, [b for b in batch[2]], sd_e, sd_d, cfg['patch_size'], True)
+    ref_loss = O.rcnet_loss(ref, lab_c, val_c, 2.5)
+    ref_loss.backward()
+    close(logits, ref, tol, "full-size logits")
+    assert abs(float(loss) - float(ref_loss)) <= tol * abs(float(ref_loss)), (float(loss), float(ref_loss))
+    got = _module_grads(model)
+    for name, mod, sd, pref in (("encoder_image", model.encoder.encoder_image, sd_e, "encoder_image."), ("attention", model.encoder.attention, sd_e, "attention."),
+                                ("encoder_depth", model.encoder.encoder_depth, sd_e, "encoder_depth."), ("decoder", model.decoder, sd_d, "")):
+        r = torch.cat([sd[pref + k].grad.reshape(-1) for k, p in mod.named_parameters() if p.grad is not None])
+        err = float((got[name] - r).norm() / r.norm())
+        assert err <= 5 * tol, "full-size %s gradient: relative L2 error %.3e" % (name, err)
+
+
+def rcnet_fullsize_bf16_case(dev, tol_logits=3e-2, tol_grad=0.08):
+    """configs[1] exactly (B = 8, 496x612 padded, R = 240, patch 240x100): the bf16 throughput mode against the fp32 HIP path (itself
+    pinned to the oracle / reference at 1e-3) on identical weights and inputs.  Stated tolerances: logits of 24 sampled RoIs within
+    3e-2 of max|logit|, loss within 1e-2 relative, per-module gradient vectors within 8 % relative L2 and cosine > 0.995."""
+    from riders_amd import engine, rcnet_main
+    cfg = rcnet_main.ZJU_CONFIG
+    batch = rcnet_main.synthetic_batch(8, 256, 512, cfg, seed=1234, device=dev)
+    res = {}
+    for mode in ("fp32", "bf16"):
+        engine.set_compute_dtype(mode)
+        try:
+            torch.manual_seed(0)
+            model = rcnet_main.build_model(dev, cfg)
+            model.train()
+            image, pts, rois, gt = rcnet_main.prepare_batch(batch)
+            label, valid = engine.rcnet_labels(gt, pts, 0.5)
+            logits = model.forward(image, pts, rois)
+            loss, _ = model.compute_loss(logits, label, valid, 2.5)
+            loss.backward()
+            res[mode] = (logits.detach()[::10].float().cpu(), float(loss), _module_grads(model))
+        finally:
+            engine.set_compute_dtype("fp32")
+            engine.clear_caches()
+    (l32, loss32, g32), (l16, loss16, g16) = res["fp32"], res["bf16"]
+    assert l32.shape[0] == 24
+    close(l16, l32, tol_logits, "bf16 vs fp32 logits (24 sampled RoIs)")
+    assert abs(loss16 - loss32) <= 1e-2 * abs(loss32), (loss16, loss32)
+    for k in g32:
+        err = float((g16[k] - g32[k]).norm() / g32[k].norm())
+        cos = float(torch.dot(g16[k], g32[k]) / (g16[k].norm() * g32[k].norm()))
+        assert err <= tol_grad and cos >= 0.995, "bf16 %s gradient: relative L2 error %.3e, cosine %.5f" % (k, err, cos)
 
 
 def bf16_exact_conv_case(dev, cin=16, cout=16, k=3, s=1, H=9, W=7, N=2, up=None, cin2=0, report=False):

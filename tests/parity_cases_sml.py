@@ -14,17 +14,59 @@ def _nhwc(x, dev, dtype=torch.float32):
 
 
 def _run_tape(dev, inputs, fn, gout):
-    """Run fn(*nhwc inputs) under a fresh tape, seed grad gout (NCHW cpu) and return (out NCHW, grads NCHW)."""
+    """Run fn(*nhwc inputs) under a fresh tape (tensors in the engine's activation dtype), seed grad gout (NCHW cpu) and return
+    (out NCHW, grads NCHW)."""
     from riders_amd import engine
-    xs = [_nhwc(x, dev) for x in inputs]
+    dt = engine.act_dtype()
+    xs = [_nhwc(x, dev, dt) for x in inputs]
     tape = engine.Tape()
     for x in xs:
         tape.mark(x)
     with engine._active(tape):
         out = fn(*xs)
-        tape.grads[id(out)] = _nhwc(gout, dev)
+        tape.grads[id(out)] = _nhwc(gout, dev, out.dtype)
         tape.backward()
     return out.permute(0, 3, 1, 2), [tape.grads[id(x)].permute(0, 3, 1, 2) for x in xs], tape
+
+
+class bf16_mode:
+    def __enter__(self):
+        from riders_amd import engine
+        engine.set_compute_dtype("bf16")
+
+    def __exit__(self, *a):
+        from riders_amd import engine
+        engine.set_compute_dtype("fp32")
+
+
+def bf16_exact_dwconv_case(dev, C=48, k=5, s=1, H=11, W=14, N=2):
+    """bf16 depthwise path without rounding: inputs / weights / upstream gradients in {-1,0,1} make every product and partial sum exactly
+    representable, so the bf16 depthwise forward, data gradient and weight gradient must equal the fp32 torch result bit for bit
+    (EfficientNet-Lite3 blocks of the SML backbone, modules/midas/blocks.py:44-64; TF-SAME padding as the blocks use it)."""
+    from riders_amd import engine
+    from riders_amd.midas.efficientnet_lite3 import same_pad
+    rs = np.random.RandomState(C * 7 + k * 3 + s)
+    w = torch.nn.Parameter(t(rs.randint(-1, 2, (C, 1, k, k)).astype(np.float32), dev))
+    x = t(rs.randint(-1, 2, (N, C, H, W)).astype(np.float32))
+    ph, oh = same_pad(H, k, s); pw, ow = same_pad(W, k, s)
+    assert ph == pw
+    tot_h, tot_w = max((oh - 1) * s + k - H, 0), max((ow - 1) * s + k - W, 0)
+    xr = x.clone().requires_grad_()
+    wr = w.detach().cpu().clone().requires_grad_()
+    ref = F.conv2d(F.pad(xr, (pw, tot_w - pw, ph, tot_h - ph)), wr, None, stride=s, groups=C)
+    assert tuple(ref.shape[2:]) == (oh, ow)
+    gy = t(rs.randint(-1, 2, tuple(ref.shape)).astype(np.float32))
+    (ref * gy).sum().backward()
+    a = _nhwc(x, dev, torch.bfloat16)
+    tape = engine.Tape(); tape.mark(a)
+    with engine._active(tape):
+        out = engine.dwconv_block(a, w, stride=s, pad=ph, out_hw=(oh, ow))
+        tape.grads[id(out)] = _nhwc(gy, dev, torch.bfloat16)
+        tape.backward()
+    what = "bf16 dwconv C=%d k=%d s=%d" % (C, k, s)
+    assert torch.equal(out.float().permute(0, 3, 1, 2).cpu(), ref.detach()), what + ": forward"
+    assert torch.equal(tape.grads[id(a)].float().permute(0, 3, 1, 2).cpu(), xr.grad), what + ": data gradient"
+    assert torch.equal(tape.pgrads[id(w)].cpu(), wr.grad), what + ": weight gradient"
 
 
 def effnet_block_case(dev, kind="ir", cin=24, cout=32, k=3, s=2, H=12, W=16, tol=TOL):
@@ -130,6 +172,42 @@ def prestep_case(dev):
         close((monos[i] * np.float32(sc[i])).clip(1 / 255.0, 10.0)[::4, ::4], g["out%d" % i], 5e-4, "int_depth vs reference")
 
 
+def prestep_st_case(dev):
+    """'st' global alignment on device (rd_sml_scale_shift_ls, train_zju.py:278-287) vs the REFERENCE's LeastSquaresEstimator values
+    (fixture g8 `ls*`, 1e-3 relative as north_star; the singular sample gives exactly (0, 0)) and vs the oracle's per-sample
+    restatement for the assembled inputs."""
+    from riders_amd import sml_main
+    g = load("g8_scale")
+    H, W = 48, 64
+    monos, sparses = [], []
+    for i, dens in enumerate((0.02, 0.2, 0.0, 0.0005)):
+        mono = rand_array("g8.mono%d" % i, (H, W), 3.0, lo=0.15)
+        true_s = 0.02 + 0.05 * i
+        depth = 1.0 / (true_s * mono * (1 + 0.1 * rand_array("g8.n%d" % i, (H, W), 1.0)))
+        m = rand_array("g8.m%d" % i, (H, W), 1.0, lo=0.0) < dens
+        monos.append(mono); sparses.append(np.where(m, depth, 0).astype(np.float32))
+    B = len(monos)
+    mono = t(np.stack(monos)[:, None], dev).contiguous(); sparse = t(np.stack(sparses)[:, None], dev).contiguous()
+    image = t(rand_array("g8.img", (B, 3, H, W), 1.0, lo=0.0), dev)
+    rc = rand_array("g8.rc", (B, 1, H, W), 50.0, lo=0.02); rc[rand_array("g8.rcm", rc.shape, 1.0, lo=0.0) < 0.9] = 0
+    hw = (32, 32)
+    cfg = dict(sml_main.ZJU_SML_CONFIG, global_alignment='st')
+    x, d, (scale, shift) = sml_main.prepare_inputs(image, mono, sparse, t(rc, dev), hw, cfg)
+    sc, sf = scale.cpu().numpy(), shift.cpu().numpy()
+    for i in range(B):
+        rs, rt = float(g["ls%d" % i][0]), float(g["ls%d" % i][1])
+        if rs == 0.0 and rt == 0.0:
+            assert float(sc[i]) == 0.0 and float(sf[i]) == 0.0, (i, sc[i], sf[i])
+        else:
+            assert abs(float(sc[i]) - rs) <= 1e-3 * abs(rs), (i, float(sc[i]), rs)
+            # the shift is a small difference of large sums: bound it by what a 1e-3 scale error does to the fit at the data's mean
+            assert abs(float(sf[i]) - rt) <= 1e-3 * (abs(rt) + abs(rs) * float(monos[i].mean())), (i, float(sf[i]), rt)
+        xo, do, _ = OS.prestep_sample(image[i].cpu().numpy(), monos[i], sparses[i], rc[i, 0], hw, scale=float(sc[i]), shift=float(sf[i]),
+                                      global_alignment='st')
+        close(d[i], do, 1e-5, "prestep('st') d[%d]" % i)
+        close(x[i], xo, 1e-4, "prestep('st') x[%d]" % i)
+
+
 def metrics_case(dev):
     import ctypes
     from riders_amd import engine
@@ -148,6 +226,71 @@ def metrics_case(dev):
     got = [r[1] / r[0], np.sqrt(r[2] / r[0]), r[3] / r[0], np.sqrt(r[4] / r[0]), r[5] / r[0], r[6] / r[0], r[7] / r[0]]
     for a, b, nm in zip(got, g["vals"], ("mae", "rmse", "imae", "irmse", "abs_rel", "sq_rel", "delta1")):
         assert abs(a - b) <= 1e-3 * max(abs(b), 1e-6), (nm, a, b)   # abs-rel within 1e-3 (north_star)
+
+
+def sml_net_bf16_case(dev, tol_pred=4e-2, tol_grad=0.15):
+    """configs[2] runs the SML in bf16: the same network / fixture as sml_net_case with bf16 activations (fp32 accumulation, parameters
+    and statistics).  Stated tolerances: prediction within 4e-2 of max|ref| (train and eval mode), input gradient within 0.15 of
+    max|ref|, and the global relative L2 error over ALL parameter gradients (vs the fp64 oracle) below 0.15."""
+    from riders_amd.midas.midas_net_custom import MidasNet_small_videpth
+    g = load("g9_sml")
+    with bf16_mode():
+        m = MidasNet_small_videpth(device=dev, min_pred=0.1, max_pred=255.0, in_channels=3)
+        fill_state_dict(m, "g9.sml")
+        B, H, W = 2, 64, 96
+        x = t(rand_array("g9.x", (B, 3, H, W), 1.0), dev).requires_grad_()
+        d = t(rand_array("g9.d", (B, 1, H, W), 0.3, lo=0.05) + np.float32(0.02), dev)
+        m.train()
+        pred = m.forward(x, d)
+        close(pred, g["pred"], tol_pred, "g9 pred (bf16)")
+        (pred * t(rand_array("g9.w", pred.shape, 1.0), dev)).sum().backward()
+        close(x.grad, g["dx"], tol_grad, "g9 dx (bf16)")
+        o = OS.SMLOracle().double()
+        o.load_state_dict({k: (v.double() if v.is_floating_point() else v) for k, v in fill_state_dict(MidasNet_small_videpth(
+            device='cpu', min_pred=0.1, max_pred=255.0, in_channels=3), "g9.sml").items()})
+        o.train()
+        po = o(t(rand_array("g9.x", (B, 3, H, W), 1.0)).double(), (t(rand_array("g9.d", (B, 1, H, W), 0.3, lo=0.05) + np.float32(0.02))).double())
+        (po * t(rand_array("g9.w", po.shape, 1.0)).double()).sum().backward()
+        ref = {k: p.grad for k, p in o.named_parameters()}
+        num = den = 0.0
+        for k, p in m.named_parameters():
+            if (k + "|none") in g:
+                assert p.grad is None, k
+                continue
+            num += float((p.grad.detach().cpu().double() - ref[k]).pow(2).sum())
+            den += float(ref[k].pow(2).sum())
+        assert (num / den) ** 0.5 <= tol_grad, "bf16 global parameter-gradient error %.3e" % ((num / den) ** 0.5)
+        m.eval()
+        with torch.no_grad():
+            close(m.forward(x.detach(), d), g["pred_eval"], tol_pred, "g9 eval pred (bf16)")
+
+
+def validate_chain_case(dev, tol=1e-3):
+    """H3 (val_zju.py:124-254) end to end on identical weights (g9 fill) and inputs: device pre-step -> network (eval) -> 1/pred ->
+    bicubic to the frame size -> masked metrics, against the oracle chain prestep_sample -> SMLOracle -> val_metrics.
+    north_star: abs-rel within 1e-3 (absolute) of the CPU path; the other metrics within 1e-3 relative."""
+    from riders_amd import sml_main
+    from riders_amd.midas.midas_net_custom import MidasNet_small_videpth
+    m = MidasNet_small_videpth(device=dev, min_pred=0.1, max_pred=255.0, in_channels=3)
+    sd = fill_state_dict(m, "g9.sml")
+    m.eval()
+    B, H, W = 2, 60, 80                                   # frames are resized (nearest) to the 288 x 384 network input, as for ZJU
+    batch = sml_main.synthetic_batch(B, H, W, seed=21)
+    got = sml_main.validate_batch(m, tuple(b.to(dev) for b in batch))
+    o = OS.SMLOracle()
+    o.load_state_dict({k: v.cpu() for k, v in sd.items()})
+    o.eval()
+    image, mono, radar, gt, sparse_gt, rcnet = [b.numpy() for b in batch]
+    hw = sml_main.net_size(H, W)
+    for i in range(B):
+        xo, do, _ = OS.prestep_sample(image[i], mono[i, 0], radar[i, 0], rcnet[i, 0], hw)
+        with torch.no_grad():
+            po = o(t(xo)[None], t(do)[None])
+        ref = OS.val_metrics(po, sparse_gt[i, 0], (H, W))
+        assert abs(float(got["abs_rel"][i]) - float(ref["abs_rel"])) <= tol, ("abs_rel", i, got["abs_rel"][i], ref["abs_rel"])
+        for k in ("mae", "rmse", "imae", "irmse", "sq_rel", "delta1"):
+            assert abs(float(got[k][i]) - float(ref[k])) <= tol * max(abs(float(ref[k])), 1e-6), (k, i, got[k][i], ref[k])
+        close(got["depth"][i, 0], ref["pred"], tol, "validation depth map %d" % i)
 
 
 def sml_net_case(dev, tol=TOL):

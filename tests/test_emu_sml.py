@@ -24,5 +24,9 @@ def test_prestep(emu):
     S.prestep_case(emu)
 
 
+def test_prestep_scale_and_shift(emu):
+    S.prestep_st_case(emu)
+
+
 def test_metrics(emu):
     S.metrics_case(emu)

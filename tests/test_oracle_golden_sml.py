@@ -38,6 +38,10 @@ def test_g8_scale():
         valid = (sparse < 100.0) * (sparse > 0.0)
         tgt = sparse.copy(); tgt[~valid] = np.inf; tgt = 1.0 / tgt
         assert abs(OS.optimize_scale(mono, tgt, valid) - float(g["s%d" % i][0])) < 1e-9
+        # 'st' closed form (modules/estimator.py:5-29) against the reference's LeastSquaresEstimator output stored in the same fixture
+        s_ls, t_ls = OS.scale_and_shift_ls(mono, tgt, valid)
+        assert abs(s_ls - float(g["ls%d" % i][0])) <= 1e-6 * max(1.0, abs(float(g["ls%d" % i][0]))), (i, s_ls, g["ls%d" % i])
+        assert abs(t_ls - float(g["ls%d" % i][1])) <= 1e-6, (i, t_ls, g["ls%d" % i])
 
 
 def test_g9_sml_network():
