@@ -137,7 +137,9 @@ def run_workload(kind, args, dev, world, rank, steps, warmup):
     if kind == "sml":
         batch_n, h, w = args.sml_batch, args.sml_height, args.sml_width
         cfg = sml_main.ZJU_SML_CONFIG
-        model = sml_main.build_model(dev, cfg)
+        import contextlib
+        with contextlib.redirect_stdout(sys.stderr):      # the constructor prints like the reference's; stdout carries the ONE JSON line only
+            model = sml_main.build_model(dev, cfg)
         main_mod, extra, stages = sml_main, dict(outlier=sml_main.make_outlier_removal(cfg)), sml_stages(model)
         batch = sml_main.synthetic_batch(batch_n, h, w, seed=1234 + rank, device=dev)
     else:

@@ -12,6 +12,9 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 
+from .precision import Precision  # noqa: E402  (bf16-mode rounding points; identity by default)
+
+
 class Conv2dSame(nn.Conv2d):
     """TF-"SAME": pad_total = max((ceil(i/s)-1)*s + k - i, 0), leading pad = total // 2."""
 
@@ -21,7 +24,13 @@ class Conv2dSame(nn.Conv2d):
         ph = max((math.ceil(ih / s) - 1) * s + k - ih, 0)
         pw = max((math.ceil(iw / s) - 1) * s + k - iw, 0)
         x = F.pad(x, [pw // 2, pw - pw // 2, ph // 2, ph - ph // 2])
-        return F.conv2d(x, self.weight, self.bias, self.stride, 0, self.dilation, self.groups)
+        w = Precision.w(self.weight) if self.groups == 1 else self.weight      # depthwise weights stay fp32 on the HIP path
+        return Precision.r(F.conv2d(x, w, self.bias, self.stride, 0, self.dilation, self.groups))
+
+
+class ReLU6R(nn.ReLU6):
+    def forward(self, x):
+        return Precision.r(super().forward(x))
 
 
 def _bn(c):
@@ -33,14 +42,14 @@ class DepthwiseSeparableConv(nn.Module):
         super().__init__()
         self.conv_dw = Conv2dSame(cin, cin, k, s, groups=cin, bias=False)
         self.bn1 = _bn(cin)
-        self.act1 = nn.ReLU6()
+        self.act1 = ReLU6R()
         self.conv_pw = Conv2dSame(cin, cout, 1, bias=False)
         self.bn2 = _bn(cout)
         self.has_residual = s == 1 and cin == cout
 
     def forward(self, x):
         h = self.bn2(self.conv_pw(self.act1(self.bn1(self.conv_dw(x)))))
-        return h + x if self.has_residual else h
+        return Precision.r(h + x if self.has_residual else h)
 
 
 class InvertedResidual(nn.Module):
@@ -49,10 +58,10 @@ class InvertedResidual(nn.Module):
         mid = cin * exp
         self.conv_pw = Conv2dSame(cin, mid, 1, bias=False)
         self.bn1 = _bn(mid)
-        self.act1 = nn.ReLU6()
+        self.act1 = ReLU6R()
         self.conv_dw = Conv2dSame(mid, mid, k, s, groups=mid, bias=False)
         self.bn2 = _bn(mid)
-        self.act2 = nn.ReLU6()
+        self.act2 = ReLU6R()
         self.conv_pwl = Conv2dSame(mid, cout, 1, bias=False)
         self.bn3 = _bn(cout)
         self.has_residual = s == 1 and cin == cout
@@ -61,7 +70,7 @@ class InvertedResidual(nn.Module):
         h = self.act1(self.bn1(self.conv_pw(x)))
         h = self.act2(self.bn2(self.conv_dw(h)))
         h = self.bn3(self.conv_pwl(h))
-        return h + x if self.has_residual else h
+        return Precision.r(h + x if self.has_residual else h)
 
 
 def _round_channels(c, mult=1.2, div=8):
@@ -81,7 +90,7 @@ class EfficientNetLite3Features(nn.Module):
         super().__init__()
         self.conv_stem = Conv2dSame(3, 32, 3, 2, bias=False)
         self.bn1 = _bn(32)
-        self.act1 = nn.ReLU6()
+        self.act1 = ReLU6R()
         blocks, cin = [], 32
         for si, (typ, r, k, s, c) in enumerate(ARCH):
             cout = _round_channels(c)

@@ -49,19 +49,21 @@ def test_bf16_depthwise_exact(gpu):
     S.bf16_exact_dwconv_case(gpu)
     S.bf16_exact_dwconv_case(gpu, C=144, k=3, s=2, H=18, W=24)
     S.bf16_exact_dwconv_case(gpu, C=32, k=3, s=1, H=9, W=7, N=1)
-    S.bf16_exact_dwconv_case(gpu, C=232 * 6, k=5, s=2, H=9, W=12, N=2)
-    S.bf16_exact_dwconv_case(gpu, C=24 * 6, k=3, s=2, H=37, W=48, N=2)
+    S.bf16_exact_dwconv_case(gpu, C=232 * 6, k=5, s=2, H=18, W=24, N=2)
+    S.bf16_exact_dwconv_case(gpu, C=24 * 6, k=3, s=2, H=36, W=48, N=2)
 
 
 def test_sml_bf16_blocks(gpu):
     """configs[2] precision mode: EfficientNet-Lite3 blocks and a fusion block in bf16 (the `*_gen` BatchNorm passes, depthwise
-    kernels and 1x1 direct kernels the throughput numbers run on) within 3e-2 / 6e-2 of max|ref| of the fp32 oracle."""
+    kernels and 1x1 direct kernels the throughput numbers run on) against the oracle rounding at the same tensors
+    (oracle/precision.py).  Relative L2: forward / running statistics 2e-3, input and parameter gradients 6e-3 (measured 4e-5 .. 2.7e-3);
+    fusion block max-norm 1e-2 (= 2.5 bf16 ulp)."""
     with S.bf16_mode():
-        S.effnet_block_case(gpu, "ir", 24, 32, 3, 2, tol=3e-2)
-        S.effnet_block_case(gpu, "ds", 32, 24, 3, 1, H=8, W=8, tol=3e-2)
-        S.effnet_block_case(gpu, "ir", 136, 232, 5, 2, H=18, W=24, tol=3e-2)
-        S.effnet_block_case(gpu, "ir", 48, 48, 5, 1, H=19, W=30, tol=3e-2)
-        S.fusion_block_case(gpu, f=64, tol=3e-2)
+        S.effnet_block_case(gpu, "ir", 24, 32, 3, 2, H=24, W=32, N=4, tol=2e-3, l2=True)
+        S.effnet_block_case(gpu, "ds", 32, 24, 3, 1, H=16, W=16, N=4, tol=2e-3, l2=True)
+        S.effnet_block_case(gpu, "ir", 136, 232, 5, 2, H=18, W=24, N=4, tol=2e-3, l2=True)
+        S.effnet_block_case(gpu, "ir", 48, 48, 5, 1, H=19, W=30, N=4, tol=2e-3, l2=True)
+        S.fusion_block_case(gpu, f=64, tol=1e-2)
 
 
 def test_sml_network_bf16(gpu):
