@@ -7,6 +7,16 @@
 // array into scratch (or LDS via promote-alloca) -- seen as private_segment 48..80 bytes / +16 KB LDS on the conv kernels.
 #define RD_INLINE_LAMBDA __attribute__((always_inline))
 
+// Launch-time sized LDS (hipLaunchKernelGGL's shmem argument).  The host emulator runs blocks one after the other: a static arena of the
+// CU's full 160 KiB stands in.
+#ifdef RD_EMU
+#define RD_DYN_SMEM(name) static __attribute__((aligned(16))) unsigned char name[160 * 1024]
+#define RD_WAVE_UNIFORM(x) (x)
+#else
+#define RD_DYN_SMEM(name) extern __shared__ __attribute__((aligned(16))) unsigned char name[]
+#define RD_WAVE_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)
+#endif
+
 namespace rd {
 
 // ---- element types -------------------------------------------------------------------------
@@ -116,6 +126,56 @@ __device__ __forceinline__ f32x4 mfma_16x16x32_bf16(s16x8 a, s16x8 b, f32x4 c) {
   return emu_mfma_f32_16x16x32_bf16(a, b, c);
 #else
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+#endif
+}
+
+// 32x32x16 bf16 MFMA (measured on MI355X, tools/probes/dma_mfma32_probe.hip -> profiles/r02_dma_mfma32_probe.txt): lane l supplies
+// A[i = l & 31][k = 8 (l >> 5) + e] and B[k = 8 (l >> 5) + e][j = l & 31], e = 0..7, and holds D[(v & 3) + 8 (v >> 2) + 4 (l >> 5)][l & 31]
+// in register v = 0..15.  Twice the FLOPs of 16x16x32 per instruction at the same operand bytes per lane.
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+__device__ __forceinline__ f32x16 mfma_32x32x16_bf16(s16x8 a, s16x8 b, f32x16 c) {
+#ifdef RD_EMU
+  return emu_mfma_f32_32x32x16_bf16(a, b, c);
+#else
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+#endif
+}
+
+// LDS DMA (global_load_lds_dwordx4): 16 bytes per lane from global memory straight into LDS, no VGPR staging and no ds_write pass.
+// The destination is NOT per-lane: lane l's bytes land at `lds_wave_base + 16 l`, lds_wave_base wave-uniform (probe: as above; lanes
+// that are masked off leave their 16 bytes untouched).  Swizzled LDS images are therefore produced by permuting the per-lane SOURCE
+// addresses.  Completion is tracked by vmcnt: `dma_wait_all()` (or the vmcnt(0) hipcc puts in front of __syncthreads() while a DMA is
+// in flight) before any wave reads the bytes.
+// Issued through inline asm ON PURPOSE: hipcc treats the builtin (__builtin_amdgcn_global_load_lds) as an LDS write that may alias any
+// later ds_read / ds_write and puts `s_waitcnt vmcnt(0)` in front of the next LDS access -- a prefetch issued before a compute phase is then
+// waited for before that phase starts (seen in the ISA of the first version of rd_conv3x3_dma.hip: no overlap at all).  An asm statement
+// is invisible to that bookkeeping: the kernel counts its DMAs itself (dma_wait_le<N>, they complete in issue order) and orders them with
+// barriers.  M0 carries the destination base and is restored (cdna_hip_programming.md section 5.7).
+__device__ __forceinline__ void dma16_to_lds(const void* gsrc, void* lds_wave_base) {
+#ifdef RD_EMU
+  emu_global_load_lds16(gsrc, lds_wave_base);
+#else
+  // the caller derives lds_wave_base from wave-uniform values only (RD_WAVE_UNIFORM(wave index)): it is an SGPR already
+  const unsigned dst = (unsigned)(size_t)(__attribute__((address_space(3))) void*)lds_wave_base;
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
+#endif
+}
+// Same DMA with the source given as wave-uniform base (SGPR pair) + per-lane 32-bit byte offset: the per-lane part is a constant of the
+// thread in the convolution kernels, so a piece costs no vector address arithmetic.  M0 is written and not restored (hipcc keeps nothing
+// live in M0 across an asm statement; it reloads M0 for its own LDS-DMA / interp uses).
+__device__ __forceinline__ void dma16_to_lds_base(const void* gbase_uniform, unsigned lane_byte_offset, void* lds_wave_base) {
+#ifdef RD_EMU
+  emu_global_load_lds16((const char*)gbase_uniform + lane_byte_offset, lds_wave_base);
+#else
+  const unsigned dst = (unsigned)(size_t)(__attribute__((address_space(3))) void*)lds_wave_base;
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(lane_byte_offset), "s"(gbase_uniform), "s"(dst) : "memory");
+#endif
+}
+__device__ __forceinline__ void dma_wait_all() {
+#ifndef RD_EMU
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #endif
 }
 

@@ -894,9 +894,14 @@ static bool use_conv3x3(const ConvArgs& a, int dtype) {
 static bool use_conv3x3_small(const ConvArgs& a, int dtype) {
   return conv3x3_small_ok(a, dtype) && conv3x3_tiles(a) >= conv3x3_min_blocks();
 }
+static bool use_conv3x3_dma(const ConvArgs& a, int dtype) {   // wide bf16 layers: LDS-DMA staging + 32x32x16 MFMA (rd_conv3x3_dma.hip)
+  if (!conv3x3_dma_ok(a, dtype)) return false;
+  return (int64_t)conv3x3_dma_tiles(a) * cdiv(a.Cout, a.Cout <= 32 ? 32 : (a.Cout <= 64 ? 64 : 128)) >= conv3x3_min_blocks();
+}
 int conv_stats_rows(const ConvArgs& a, int dtype) {
   if (conv1x1_direct_ok(a, dtype)) return conv1x1_direct_rows(a);
   if (use_conv3x3_small(a, dtype)) return conv3x3_small_blocks(a, dtype);   // persistent blocks: one statistics row each
+  if (use_conv3x3_dma(a, dtype)) return conv3x3_dma_tiles(a);
   if (use_conv3x3(a, dtype)) return conv3x3_tiles(a);
   return (int)cdiv(a.M, conv_block_pixels(a.M, a.Cout));
 }
@@ -905,6 +910,7 @@ void launch_conv(const ConvArgs& a, int dtype, hipStream_t st) {
   if (conv1x1_direct_ok(a, dtype)) { launch_conv1x1_direct(a, dtype, st); return; }
   if (conv3x3_c1_ok(a)) { launch_conv3x3_c1(a, dtype, st); return; }
   if (use_conv3x3_small(a, dtype)) { launch_conv3x3_small(a, dtype, st); return; }
+  if (use_conv3x3_dma(a, dtype)) { launch_conv3x3_dma(a, st); return; }
   if (use_conv3x3(a, dtype)) { launch_conv3x3(a, dtype, st); return; }
   if (dtype == 0) launch_conv_t<float>(a, st);
   else launch_conv_t<bf16_t>(a, st);

@@ -49,6 +49,8 @@ static inline hipError_t hipGetLastError() { return 0; }
 static inline hipError_t hipPeekAtLastError() { return 0; }
 static inline const char* hipGetErrorString(hipError_t) { return "emu"; }
 static inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { memset(p, v, n); return 0; }
+enum hipFuncAttribute { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
+static inline hipError_t hipFuncSetAttribute(const void*, hipFuncAttribute, int) { return 0; }
 enum hipMemcpyKind { hipMemcpyDeviceToDevice = 3, hipMemcpyHostToDevice = 1, hipMemcpyDeviceToHost = 2 };
 static inline hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { memcpy(d, s, n); return 0; }
 
@@ -301,6 +303,34 @@ static inline emu_u16x4 emu_ds_read_tr16_b64(const void* addr) {
   return o;
 }
 // bf16: lane l supplies 8 consecutive k (k = 8*(l>>4)+e) of A row i=l&15 / B column j=l&15.
+typedef float emu_f32x16 __attribute__((ext_vector_type(16)));
+// v_mfma_f32_32x32x16_bf16: lane l supplies A[l & 31][8 (l >> 5) + e], B[8 (l >> 5) + e][l & 31]; D[(v & 3) + 8 (v >> 2) + 4 (l >> 5)][l & 31] in v
+static inline emu_f32x16 emu_mfma_f32_32x32x16_bf16(emu_s16x8 a, emu_s16x8 b, emu_f32x16 c) {
+  emu::Wave& w = emu::my_wave();
+  int l = emu::lane_id();
+  memcpy(w.buf[0][l], &a, 16);
+  memcpy(w.buf[1][l], &b, 16);
+  emu::wave_sync();
+  int j = l & 31;
+  for (int v = 0; v < 16; v++) {
+    int i = (v & 3) + 8 * (v >> 2) + 4 * (l >> 5);
+    float acc = c[v];
+    for (int g = 0; g < 2; g++) {
+      unsigned short av[8], bv[8];
+      memcpy(av, w.buf[0][i + 32 * g], 16);
+      memcpy(bv, w.buf[1][j + 32 * g], 16);
+      for (int e = 0; e < 8; e++) acc += emu_bf16_to_f32(av[e]) * emu_bf16_to_f32(bv[e]);
+    }
+    c[v] = acc;
+  }
+  emu::wave_sync();
+  return c;
+}
+// global_load_lds_dwordx4: lane l's 16 bytes land at (wave-uniform) base + 16 l; executed immediately (the model has no asynchrony)
+static inline void emu_global_load_lds16(const void* gsrc, void* lds_wave_base) {
+  memcpy((char*)lds_wave_base + 16 * emu::lane_id(), gsrc, 16);
+}
+
 static inline emu_f32x4 emu_mfma_f32_16x16x32_bf16(emu_s16x8 a, emu_s16x8 b, emu_f32x4 c) {
   emu::Wave& w = emu::my_wave();
   int l = emu::lane_id();

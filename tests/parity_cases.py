@@ -135,6 +135,29 @@ class force_patch_conv:
                 os.environ[k] = v
 
 
+class force_dma_conv(force_patch_conv):
+    """Route eligible wide bf16 3x3 layers to the experimental LDS-DMA / 32x32x16-MFMA kernel (rd_conv3x3_dma.hip), any block count;
+    `mode` selects the weight staging variant (RD_DMA_MODE)."""
+    def __init__(self, mode=0, pbufs=None):
+        super().__init__()
+        self.env.update({"RD_CONV3X3_DMA": "1", "RD_DMA_MODE": str(mode)})
+        if pbufs is not None:
+            self.env["RD_DMA_PBUFS"] = str(pbufs)
+
+
+def dma_conv_cases(dev):
+    """Bit-exact bf16 cases of the experimental kernel: every tile configuration (32 / 64 / 128 channels, 16- and 8-wide tiles), one to
+    three chunks, upsample + concat gather, dual destination (data gradient of a concat input), every staging mode."""
+    shapes = [dict(cin=64, cout=32, k=3, s=1, H=9, W=17, N=1), dict(cin=32, cout=64, k=3, s=1, H=12, W=17, N=1),
+              dict(cin=64, cout=64, k=3, s=1, H=9, W=19, N=1), dict(cin=128, cout=128, k=3, s=1, H=8, W=16, N=2),
+              dict(cin=64, cout=128, k=3, s=1, N=1, up=((4, 3), (17, 6)), cin2=64), dict(cin=192, cout=96, k=3, s=1, H=9, W=10, N=1),
+              dict(cin=32, cout=64, k=3, s=1, N=1, up=((5, 4), (11, 9)), cin2=32)]     # concat boundary inside a chunk (per-lane source)
+    for mode, pbufs in ((0, None), (1, None), (2, 2)):
+        with force_dma_conv(mode, pbufs):
+            for c in shapes:
+                bf16_exact_conv_case(dev, **c)
+
+
 PATCH_CONV_CASES = [
     dict(cin=32, cout=32, k=3, s=1, H=9, W=19, N=2, bn=True),                  # 16x8 tiles, ragged in both axes; dgrad also patch-staged
     dict(cin=64, cout=160, k=3, s=1, H=17, W=7, N=1, bn=False, act=None),      # 8x16 tiles, two channel blocks, two chunks

@@ -148,6 +148,10 @@ def test_stem_padded_channels(emu):
     P.conv_case(emu, dict(cin=5, cout=16, k=3, s=1, H=9, W=11, N=2, bn=False, act=None, no_input_grad=True))
 
 
+def test_experimental_dma_conv_exact(emu):
+    P.dma_conv_cases(emu)
+
+
 def test_inference_driver(emu):
     P.inference_driver_case(emu)
 

@@ -38,6 +38,10 @@ def test_patch_conv_decoder_and_bf16(gpu):
     P.conv_case(gpu, dict(cin=64, cout=64, k=3, s=1, H=64, W=96, N=4, bn=True))
 
 
+def test_experimental_dma_conv_exact(gpu):
+    P.dma_conv_cases(gpu)
+
+
 def test_decoder_block(gpu):
     P.decoder_block_case(gpu)
     P.decoder_block_case(gpu, cin=16, cskip=0, cout=16, hs=(5, 4), hv=(10, 8))
