@@ -32,7 +32,7 @@ __global__ __launch_bounds__(256, (CTI * RT <= 2) ? 4 : 2) void conv3x3_wgrad_tr
   constexpr int KSTEPS = NPY / 32;                     // 32 pixels per MFMA k-step
   constexpr int NCT = 9 * CTI, NCW = (NCT + 3) / 4;    // (tap, cin-tile) column tiles, per wave
   constexpr int ASTEP = 32 * COP;                      // elements between k-steps in the dY tile (32 consecutive pixels)
-  constexpr int BSTEP = (TW == 16 ? 2 : 1) * WT * CIN; // ... in the patch (two rows of 16 or one row of 32)
+  constexpr int BSTEP = (32 / TW) * WT * CIN;          // ... in the patch (four rows of 8, two rows of 16 or one row of 32)
   __shared__ uint4 sX[2][NXS];
   __shared__ uint4 sY[2][NYS];
 
@@ -51,7 +51,8 @@ __global__ __launch_bounds__(256, (CTI * RT <= 2) ? 4 : 2) void conv3x3_wgrad_tr
 
   // transpose-read roles.  k-step s, lane group fg: pixels (y, x0 .. x0+7) of the tile; this lane supplies pixel x0 + (fr >> 2) (+4
   // for the second read) and channels 4*(fr & 3)..+3 of whichever 16-channel tile is being read.
-  const int yl = TW == 16 ? (fg >> 1) : 0, x0 = TW == 16 ? (fg & 1) * 8 : fg * 8;
+  constexpr int GPR = TW / 8;                          // lane groups (8 pixels each) per tile row
+  const int yl = fg / GPR, x0 = (fg % GPR) * 8;
   const int aoff = ((yl * TW) + x0 + (fr >> 2)) * COP + (fr & 3) * 4;
   const int boff = ((yl * WT) + x0 + (fr >> 2)) * CIN + (fr & 3) * 4;
   int coloff[NCW]; bool jv[NCW]; int jk[NCW];
@@ -235,19 +236,24 @@ static bool tr_geom(const WgradArgs& a) {
   return a.KH == 3 && a.KW == 3 && a.stride == 1 && a.pad == 1 && (a.C1 % 8 == 0) && a.OH == a.Hin && a.OW == a.Win;
 }
 static bool tr_narrow(const WgradArgs& a) { const int Cin = a.C1 + a.C2; return (Cin == 16 || Cin == 32 || Cin == 64) && a.Cout <= 32; }
+static int tr_tw(const WgradArgs& a) {    // tile width with the smallest padded area (8 x TW tiles); 32 only where the LDS budget allows
+  const int Cin = a.C1 + a.C2;
+  int best = 16;
+  int64_t area = cdiv(a.OW, 16) * 16;
+  if (cdiv(a.OW, 8) * 8 < area) { best = 8; area = cdiv(a.OW, 8) * 8; }
+  if (Cin < 64 && cdiv(a.OW, 32) * 32 <= area) best = 32;
+  if (const char* e = getenv("RD_WGRAD_TR_TW")) { const int v = atoi(e); if (v == 8 || v == 16 || (v == 32 && Cin < 64)) best = v; }   // experiment hook
+  return best;
+}
 bool wgrad3x3_tr_ok(const WgradArgs& a, int dtype) {
   if (dtype != 1 || !tr_geom(a)) return false;
   if ((int64_t)a.N * a.Hin * a.Win >= (int64_t)1 << 31) return false;   // the kernel keeps pixel indices in 32 bits
   if (tr_narrow(a)) return true;
   const int Cin = a.C1 + a.C2;
   if (Cin % 64 != 0 || a.Cout % 8 != 0) return false;
-  const double eff = (double)a.OH * a.OW / (double)(cdiv(a.OH, 8) * 8 * cdiv(a.OW, 16) * 16);
+  const int tw = tr_tw(a);
+  const double eff = (double)a.OH * a.OW / (double)(cdiv(a.OH, 8) * 8 * cdiv(a.OW, tw) * tw);
   return eff >= 0.6;
-}
-static int tr_tw(const WgradArgs& a) {
-  const int Cin = a.C1 + a.C2;
-  if (Cin >= 64) return 16;  // LDS budget
-  return (cdiv(a.OW, 32) * 32 <= cdiv(a.OW, 16) * 16) ? 32 : 16;
 }
 static void tr_slices(const WgradArgs& a, int& cti, int& rt, int& nci, int& nco) {
   const int Cin = a.C1 + a.C2;
@@ -281,9 +287,9 @@ void launch_wgrad3x3_tr(const WgradArgs& a, hipStream_t st) {
   const dim3 grid((unsigned)wgrad3x3_tr_blocks(a), (unsigned)(nci * nco));
 #define RD_TR(CTIV, RTV, TWV) \
   if (cti == CTIV && rt == RTV && tw == TWV) hipLaunchKernelGGL((conv3x3_wgrad_tr_kernel<CTIV, RTV, TWV>), grid, dim3(256), 0, st, a, tilesH, tilesW, nci);
-  RD_TR(1, 1, 16) RD_TR(1, 1, 32) RD_TR(1, 2, 16) RD_TR(1, 2, 32)
-  RD_TR(2, 1, 16) RD_TR(2, 1, 32) RD_TR(2, 2, 16) RD_TR(2, 2, 32)
-  RD_TR(4, 1, 16) RD_TR(4, 2, 16)
+  RD_TR(1, 1, 8) RD_TR(1, 1, 16) RD_TR(1, 1, 32) RD_TR(1, 2, 8) RD_TR(1, 2, 16) RD_TR(1, 2, 32)
+  RD_TR(2, 1, 8) RD_TR(2, 1, 16) RD_TR(2, 1, 32) RD_TR(2, 2, 8) RD_TR(2, 2, 16) RD_TR(2, 2, 32)
+  RD_TR(4, 1, 8) RD_TR(4, 1, 16) RD_TR(4, 2, 8) RD_TR(4, 2, 16)
 #undef RD_TR
 }
 

@@ -879,8 +879,69 @@ def linear_attention(q, k, v, N, Lq, S, H, eps=1e-6):
     return out
 
 
-def loftr_layer(x, source, layer, N, L, S):
-    """Fused LoFTREncoderLayer (rd_loftr_layer_fwd / _bwd): x (N*L, 128), source (N*S, 128) token matrices -> (N*L, 128).
+def rows_cat(a, b):
+    """(Ra, C), (Rb, C) -> one (Ra + Rb, C) token matrix (copy).  The LoFTR transformer keeps both token streams in ONE buffer so that a
+    'self' layer -- the same weights on both streams, no interaction (RCNet/linear_attention.py:171-173) -- is one launch over all
+    2 N sequences instead of two launches of N workgroups each on a 256-CU chip."""
+    t = tape()
+    ra, rb = a.shape[0], b.shape[0]
+    out = torch.empty((ra + rb, a.shape[1]), dtype=a.dtype, device=a.device)
+    for src, dst in ((a, out[:ra]), (b, out[ra:])):
+        _chk(L_().rd_cast(_p(src), _p(dst), src.numel(), rd_of(src), rd_of(dst), 1.0, _stream(src)), "rd_cast")
+    if t is not None and t.requires(a, b):
+        t.mark(out)
+
+        def backward():
+            g = t.pop_grad(out)
+            if g is not None:
+                t.add_grad(a, g[:ra])
+                t.add_grad(b, g[ra:])
+        t.record(backward)
+    return out
+
+
+def rows_split(x, ra):
+    """(R, C) -> views (x[:ra], x[ra:]); the backward gathers the two gradients into one matrix (they come from different launches)."""
+    t = tape()
+    a, b = x[:ra], x[ra:]
+    if t is not None and t.requires(x):
+        t.mark(a); t.mark(b)
+
+        def backward():
+            ga, gb = t.pop_grad(a), t.pop_grad(b)
+            if ga is None and gb is None:
+                return
+            g = torch.empty_like(x)
+            for src, dst in ((ga, g[:ra]), (gb, g[ra:])):
+                if src is None:
+                    dst.zero_()
+                else:
+                    _chk(L_().rd_cast(_p(src), _p(dst), src.numel(), rd_of(src), rd_of(dst), 1.0, _stream(src)), "rd_cast")
+            t.add_grad(x, g)
+        t.record(backward)
+    return a, b
+
+
+def rows_join(a, b, whole):
+    """a and b are the two row ranges of `whole` (already written in place by their producers): returns `whole` as a tape tensor whose
+    gradient flows back to a and b as views (no copy)."""
+    t = tape()
+    if t is not None and t.requires(a, b):
+        t.mark(whole)
+        ra = a.shape[0]
+
+        def backward():
+            g = t.pop_grad(whole)
+            if g is not None:
+                t.add_grad(a, g[:ra])
+                t.add_grad(b, g[ra:])
+        t.record(backward)
+    return whole
+
+
+def loftr_layer(x, source, layer, N, L, S, out=None):
+    """Fused LoFTREncoderLayer (rd_loftr_layer_fwd / _bwd): x (N*L, 128), source (N*S, 128) token matrices -> (N*L, 128)
+    (written into `out` when given: a row range of a larger token matrix).
     `layer` is the nn.Module holding q_proj / k_proj / v_proj / merge / mlp / norm1 / norm2 (reference linear_attention.py:84-135).
     The weight gradients of the six linears join the tape's grouped weight-gradient launch."""
     lib, t, dt, st = L_(), tape(), rd_of(x), _stream(x)
@@ -902,7 +963,9 @@ def loftr_layer(x, source, layer, N, L, S):
     att, mpre, msg, m2pre = (torch.empty((ML, C), dtype=T, device=dev) for _ in range(4))
     hid = torch.empty((ML, 2 * C), dtype=T, device=dev)
     stats = torch.empty((ML, 4), dtype=torch.float32, device=dev)
-    out = torch.empty_like(x)
+    if out is None:
+        out = torch.empty_like(x)
+    assert out.shape == x.shape and out.dtype == x.dtype and out.is_contiguous()
     sv = _lib.LoftrSaved()
     sv.q, sv.k, sv.v, sv.att, sv.mpre, sv.msg, sv.hid, sv.m2pre, sv.stats = [b.data_ptr() for b in (q, k, v, att, mpre, msg, hid, m2pre, stats)]
     wf, keep = wstruct(0)

@@ -109,6 +109,9 @@ class LocalFeatureTransformer(nn.Module):
                 nn.init.xavier_uniform_(p)
 
     def _fwd(self, f0, f1, N, L, S):
+        fused = engine.fused_loftr() and f0.shape[1] == 128 and L == S and L <= 32 and all(l.nhead == 8 for l in self.layers)
+        if fused and engine._state.get("merge_self_layers", True):
+            return self._fwd_merged(f0, f1, N, L)
         for layer, name in zip(self.layers, self.layer_names):
             if name == 'self':
                 f0 = layer._fwd(f0, f0, N, L, L)
@@ -119,6 +122,26 @@ class LocalFeatureTransformer(nn.Module):
             else:
                 raise KeyError
         return f0, f1
+
+    def _fwd_merged(self, f0, f1, N, L):
+        """Both token streams live in one (2 N L, C) matrix.  A 'self' layer applies the same weights to each stream independently
+        (linear_attention.py:171-173), so it runs as ONE fused launch over 2 N sequences (480 workgroups at B = 8: two per CU) instead of
+        two launches of 240; a 'cross' layer (:174-176, the second call consumes the first call's output) writes its two results into the
+        halves of the next matrix, so no copy separates the layers."""
+        R = N * L
+        F = engine.rows_cat(f0, f1)
+        for layer, name in zip(self.layers, self.layer_names):
+            if name == 'self':
+                F = engine.loftr_layer(F, F, layer, 2 * N, L, L)
+            elif name == 'cross':
+                a, b = engine.rows_split(F, R)
+                G = torch.empty_like(F)
+                a2 = engine.loftr_layer(a, b, layer, N, L, L, out=G[:R])
+                b2 = engine.loftr_layer(b, a2, layer, N, L, L, out=G[R:])
+                F = engine.rows_join(a2, b2, G)
+            else:
+                raise KeyError
+        return engine.rows_split(F, R)
 
     def forward(self, feat0, feat1, mask0=None, mask1=None):
         assert self.d_model == feat0.size(2), "the feature number of src and transformer must be equal"

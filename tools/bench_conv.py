@@ -38,7 +38,7 @@ ONLY = os.environ.get("BC_ONLY")      # e.g. "fwd:6" = forward shape index 6 onl
 def run(tag):
     tot = 0.0
     for si, (N, H, W, Cin, Cout, C1, up) in enumerate(SHAPES):
-        if ONLY and ONLY != "fwd:%d" % si:
+        if (ONLY and ONLY != "fwd:%d" % si) or os.environ.get("BC_SKIP_CONV"):
             continue
         hs, ws = up if up else (H, W)
         c1 = C1 if C1 else Cin
@@ -57,7 +57,7 @@ def run(tag):
         print("%s fwd   M=%7d %3d->%3d%s  %.3f ms  %6.1f TFLOP/s  %6.1f GB/s" % (tag, N * H * W, Cin, Cout, " up" if up else ("  c" if x2 is not None else "   "), ms, fl / ms / 1e9, by / ms / 1e6), flush=True)
         tot += ms
     for si, (N, H, W, Cin, Cout, D1) in enumerate(DGRADS):
-        if ONLY and ONLY != "dgrad:%d" % si:
+        if (ONLY and ONLY != "dgrad:%d" % si) or os.environ.get("BC_SKIP_CONV"):
             continue
         dy = torch.randn((N, H, W, Cin), device=dev).to(tdt)
         w = torch.nn.Parameter(torch.randn((Cin, Cout, 3, 3), device=dev))      # forward weight (Cout_f = Cin here, Cin_f = Cout here)
@@ -71,6 +71,24 @@ def run(tag):
         print("%s dgrad M=%7d %3d->%3d     %.3f ms  %6.1f TFLOP/s" % (tag, N * H * W, Cin, Cout, ms, fl / ms / 1e9), flush=True)
         tot += ms
     print("%s total %.3f ms" % (tag, tot), flush=True)
+    wt = 0.0
+    for si, (N, H, W, Cin, Cout, C1, up) in enumerate(SHAPES):
+        if ONLY and ONLY != "wgrad:%d" % si:
+            continue
+        hs, ws = up if up else (H, W)
+        c1 = C1 if C1 else Cin
+        x1 = torch.randn((N, hs, ws, c1), device=dev).to(tdt)
+        x2 = torch.randn((N, hs, ws, Cin - c1), device=dev).to(tdt) if c1 < Cin else None
+        dy = torch.randn((N, H, W, Cout), device=dev).to(tdt)
+        d = _desc(dt, N, H, W, c1, Cin - c1, up is not None, hs, ws, Cout, 3, 3, 1, 1, 1, H, W, 0, 0.0, Cout)
+        ws_ = torch.empty(lib.rd_conv_wgrad_workspace_bytes(ctypes.byref(d)) // 4, dtype=torch.float32, device=dev)
+        dw = torch.empty((Cout, Cin, 3, 3), dtype=torch.float32, device=dev)
+        st = _stream(x1)
+        ms = timeit(lambda: lib.rd_conv_wgrad(ctypes.byref(d), _p(x1), _p(x2), _p(dy), _p(ws_), _p(dw), 0, st))
+        fl = 2.0 * N * H * W * Cin * Cout * 9
+        print("%s wgrad M=%7d %3d->%3d%s  %.3f ms  %6.1f TFLOP/s" % (tag, N * H * W, Cin, Cout, " up" if up else ("  c" if x2 is not None else "   "), ms, fl / ms / 1e9), flush=True)
+        wt += ms
+    print("%s wgrad total %.3f ms" % (tag, wt), flush=True)
 
 
 for mode in (sys.argv[1:] or ["0", "1"]):
