@@ -227,6 +227,22 @@ int rd_depth_quantize_u16(const float* z, uint16_t* out, int64_t n, float multip
 /* RCNet/run_rcnet_zju.py:253 np.sum(output_depth) == 0 test of the threshold-retry loop: double-precision sum of n floats */
 int rd_sum_f32(const float* x, int64_t n, double* out, void* stream);
 
+/* ---- batch augmentation on the device -- RCNet/rcnet_transforms.py:58-240 as configured by train_rcnet_zju.py:52-59 ---------------------
+   params: [B][8] floats = (do_brightness, factor, do_contrast, factor, do_saturation, factor, do_hflip, 0), drawn by the host in the
+   reference's order.  image (B,3,H,W) float 0..255.  Step 1 sums the gray values the contrast blend needs ([B][32] int64 partials, exact). */
+int rd_augment_gray_partials(const float* image, int32_t B, int32_t H, int32_t W, const float* params, int64_t* partial, void* stream);
+/* brightness -> contrast -> saturation (torchvision _blend on the int image) -> v * scale + shift (normalize_images :243-272) -> hflip;
+   out (B,H,W,3) in `dtype` */
+int rd_augment_image(const float* image, int32_t B, int32_t H, int32_t W, const float* params, const int64_t* partial, void* out_nhwc,
+                     int32_t dtype, float scale, float shift, void* stream);
+/* :163-197: horizontal flip of the ground-truth crops (B,K,1,ph,pw) (out of place) and of the boxes (B,K,4) x1' = n_width - x2 (in place,
+   may be NULL); radar points are left as they are, as the reference does */
+int rd_augment_flip_labels(const float* labels_in, float* labels_out, int32_t B, int32_t K, int32_t ph, int32_t pw, float* boxes,
+                           const float* params, float n_width, void* stream);
+/* data/datasets.py:254-272: ground-truth crops around the (padded-coordinate) radar points from the zero-padded dense map (B,1,Hp,Wp) */
+int rd_crop_patches(const float* gt_padded, const float* points, float* crops, int32_t B, int32_t K, int32_t Hp, int32_t Wp, int32_t ph,
+                    int32_t pw, void* stream);
+
 /* ---- optimizer -- RCNet/rcnet_main.py:233-238,357-359; train_zju.py:205-211,390-392 ------------------------ */
 int rd_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
                  float beta2, float eps, float weight_decay, int64_t step, float grad_scale, void* stream);

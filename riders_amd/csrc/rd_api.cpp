@@ -421,6 +421,30 @@ int rd_sum_f32(const float* x, int64_t n, double* out, void* stream) {
   return done("rd_sum_f32");
 }
 
+int rd_augment_gray_partials(const float* image, int32_t B, int32_t H, int32_t W, const float* params, int64_t* partial, void* stream) {
+  if (!image || !params || !partial || B <= 0 || H <= 0 || W <= 0) return fail("augment_gray_partials: bad args");
+  rd::launch_augment_gray_partials(image, B, H, W, params, (long long*)partial, S(stream));
+  return done("rd_augment_gray_partials");
+}
+int rd_augment_image(const float* image, int32_t B, int32_t H, int32_t W, const float* params, const int64_t* partial, void* out_nhwc, int32_t dtype,
+                     float scale, float shift, void* stream) {
+  if (!image || !params || !partial || !out_nhwc || !dt_ok(dtype) || B <= 0 || H <= 0 || W <= 0) return fail("augment_image: bad args");
+  rd::launch_augment_image(image, B, H, W, params, (const long long*)partial, out_nhwc, dtype, scale, shift, S(stream));
+  return done("rd_augment_image");
+}
+int rd_augment_flip_labels(const float* labels_in, float* labels_out, int32_t B, int32_t K, int32_t ph, int32_t pw, float* boxes, const float* params,
+                           float n_width, void* stream) {
+  if (!labels_in || !labels_out || !params || labels_in == labels_out || B <= 0 || K <= 0) return fail("augment_flip_labels: bad args");
+  rd::launch_augment_flip_labels(labels_in, labels_out, B, K, ph, pw, boxes, params, n_width, S(stream));
+  return done("rd_augment_flip_labels");
+}
+int rd_crop_patches(const float* gt_padded, const float* points, float* crops, int32_t B, int32_t K, int32_t Hp, int32_t Wp, int32_t ph, int32_t pw,
+                    void* stream) {
+  if (!gt_padded || !points || !crops || B <= 0 || K <= 0 || (ph & 1) || (pw & 1)) return fail("crop_patches: bad args");
+  rd::launch_crop_patches(gt_padded, points, crops, B, K, Hp, Wp, ph, pw, S(stream));
+  return done("rd_crop_patches");
+}
+
 int rd_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2, float eps, float wd,
                  int64_t step, float gscale, void* stream) {
   if (!p || !g || !m || !v) return fail("adam: null pointer");

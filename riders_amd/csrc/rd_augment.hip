@@ -1,0 +1,145 @@
+// RC-Net batch augmentation on the device (reference: RCNet/rcnet_transforms.py:58-240, Transforms.transform as configured by
+// train_rcnet_zju.py:52-59: brightness / contrast / saturation in [0.8, 1.2], horizontal flip, probability 1) and the ground-truth
+// crop extraction of the dataset (data/datasets.py:254-272).
+//
+// The photometric functions are torchvision.transforms.functional.adjust_{brightness,contrast,saturation} (torchvision 0.14, NOT in the
+// reference tree) applied to INT32 images -- the reference converts a 0..255 float image with images.int() (:104-107) -- i.e. the tensor
+// path  _blend(img1, img2, ratio) = (ratio * img1 + (1 - ratio) * img2).clamp(0, 255).to(int32)  (float32 arithmetic, truncation) with
+//   brightness: img2 = 0;  contrast: img2 = mean over the image of gray(img), gray = (0.2989 r + 0.587 g + 0.114 b).to(int32);
+//   saturation: img2 = gray(img) per pixel.
+// Order: brightness -> contrast -> saturation -> float -> normalise -> horizontal flip of image, ground-truth crops and boxes
+// (x1' = W - x2, x2' = W - x1); the radar points are NOT flipped (:174-197, a quirk kept as it is).
+#include "rd_common.h"
+#include "rd_kernels.h"
+
+namespace rd {
+
+// per-image parameters (floats): 0 do_brightness, 1 factor, 2 do_contrast, 3 factor, 4 do_saturation, 5 factor, 6 do_hflip, 7 unused
+static constexpr int AUGP = 8;
+static constexpr int AUG_CHUNKS = 32;
+
+__device__ __forceinline__ int aug_blend(int v, float w, float ratio) {   // torchvision _blend on an int image, one element
+  const float om = (float)(1.0 - (double)ratio);
+  float t = __fadd_rn(__fmul_rn(ratio, (float)v), __fmul_rn(om, w));
+  t = fminf(fmaxf(t, 0.f), 255.f);
+  return (int)t;
+}
+__device__ __forceinline__ int aug_gray(int r, int g, int b) {
+  return (int)__fadd_rn(__fadd_rn(__fmul_rn(0.2989f, (float)r), __fmul_rn(0.587f, (float)g)), __fmul_rn(0.114f, (float)b));
+}
+__device__ __forceinline__ void aug_brightness(const float* __restrict__ p, int (&v)[3]) {
+  if (p[0] != 0.f) {
+#pragma unroll
+    for (int c = 0; c < 3; c++) v[c] = aug_blend(v[c], 0.f, p[1]);
+  }
+}
+
+// sum over the image of gray(brightness-adjusted image): integer, so the partial sums are exact and order independent
+__global__ __launch_bounds__(256) void augment_gray_partials_kernel(const float* __restrict__ image, int HW, const float* __restrict__ params,
+                                                                    long long* __restrict__ partial) {
+  __shared__ long long sh[4];
+  const int b = blockIdx.y, chunk = blockIdx.x;
+  const float* p = params + b * AUGP;
+  const float* img = image + (int64_t)b * 3 * HW;
+  long long s = 0;
+  if (p[2] != 0.f) {
+    for (int i = chunk * 256 + threadIdx.x; i < HW; i += AUG_CHUNKS * 256) {
+      int v[3] = {(int)img[i], (int)img[HW + i], (int)img[2 * HW + i]};
+      aug_brightness(p, v);
+      s += aug_gray(v[0], v[1], v[2]);
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[b * AUG_CHUNKS + chunk] = sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+// image (B,3,H,W) float 0..255 -> out (B,H,W,3) in the activation dtype, normalised (v * scale + shift), horizontally flipped where asked
+template <typename T>
+__global__ __launch_bounds__(256) void augment_image_kernel(const float* __restrict__ image, int B, int H, int W, const float* __restrict__ params,
+                                                            const long long* __restrict__ partial, T* __restrict__ out, float scale, float shift) {
+  const int HW = H * W;
+  const int64_t total = (int64_t)B * HW;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int b = (int)(i / HW), pix = (int)(i - (int64_t)b * HW);
+    const int y = pix / W, x = pix - y * W;
+    const float* p = params + b * AUGP;
+    const float* img = image + (int64_t)b * 3 * HW;
+    int v[3] = {(int)img[pix], (int)img[HW + pix], (int)img[2 * HW + pix]};
+    aug_brightness(p, v);
+    if (p[2] != 0.f) {
+      long long s = 0;
+#pragma unroll 8
+      for (int c = 0; c < AUG_CHUNKS; c++) s += partial[b * AUG_CHUNKS + c];
+      const float mean = (float)((double)s / (double)HW);
+#pragma unroll
+      for (int c = 0; c < 3; c++) v[c] = aug_blend(v[c], mean, p[3]);
+    }
+    if (p[4] != 0.f) {
+      const float g = (float)aug_gray(v[0], v[1], v[2]);
+#pragma unroll
+      for (int c = 0; c < 3; c++) v[c] = aug_blend(v[c], g, p[5]);
+    }
+    const int xo = p[6] != 0.f ? W - 1 - x : x;
+    T* o = out + ((int64_t)b * HW + (int64_t)y * W + xo) * 3;
+#pragma unroll
+    for (int c = 0; c < 3; c++) Elem<T>::st(o + c, __fadd_rn(__fmul_rn((float)v[c], scale), shift));
+  }
+}
+
+// ground-truth crops (B, K, 1, ph, pw): flipped copy for the flagged images; boxes (B, K, 4) in place: x1' = n_width - x2, x2' = n_width - x1
+__global__ __launch_bounds__(256) void augment_flip_labels_kernel(const float* __restrict__ lin, float* __restrict__ lout, int B, int K, int ph, int pw,
+                                                                  float* __restrict__ boxes, const float* __restrict__ params, float n_width) {
+  const int64_t per = (int64_t)K * ph * pw, total = (int64_t)B * per;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int b = (int)(i / per);
+    const int x = (int)(i % pw);
+    const bool flip = params[b * AUGP + 6] != 0.f;
+    lout[i] = lin[flip ? i - x + (pw - 1 - x) : i];
+  }
+  if (boxes)
+    for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < B * K; j += gridDim.x * blockDim.x) {
+      if (params[(j / K) * AUGP + 6] != 0.f) {
+        const float x1 = boxes[j * 4 + 0], x2 = boxes[j * 4 + 2];
+        boxes[j * 4 + 0] = n_width - x2;
+        boxes[j * 4 + 2] = n_width - x1;
+      }
+    }
+}
+
+// data/datasets.py:254-272: crops[b][k] = padded_gt[b][0][int(y) - pad_y : int(y) + pad_y][int(x) - pad_x : int(x) + pad_x], (x, y) = radar point
+// in padded coordinates; the zero padding of the reference's np.pad is the caller's (gt is the padded map)
+__global__ __launch_bounds__(256) void crop_patches_kernel(const float* __restrict__ gt, const float* __restrict__ points, float* __restrict__ crops,
+                                                           int B, int K, int Hp, int Wp, int ph, int pw) {
+  const int64_t per = (int64_t)ph * pw, total = (int64_t)B * K * per;
+  const int pad_y = ph / 2, pad_x = pw / 2;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int r = (int)(i / per), o = (int)(i - (int64_t)r * per);
+    const int b = r / K, cy = o / pw, cx = o - cy * pw;
+    const int y = (int)(points[r * 3 + 1] - (float)pad_y) + cy, x = (int)(points[r * 3 + 0] - (float)pad_x) + cx;
+    crops[i] = ((unsigned)y < (unsigned)Hp && (unsigned)x < (unsigned)Wp) ? gt[((int64_t)b * Hp + y) * Wp + x] : 0.f;
+  }
+}
+
+static unsigned aug_grid(int64_t n) { return (unsigned)std::max<int64_t>(1, std::min<int64_t>(cdiv(n, 256), 4096)); }
+
+void launch_augment_gray_partials(const float* image, int B, int H, int W, const float* params, long long* partial, hipStream_t st) {
+  hipLaunchKernelGGL(augment_gray_partials_kernel, dim3(AUG_CHUNKS, B), dim3(256), 0, st, image, H * W, params, partial);
+}
+void launch_augment_image(const float* image, int B, int H, int W, const float* params, const long long* partial, void* out, int dtype, float scale,
+                          float shift, hipStream_t st) {
+  const unsigned g = aug_grid((int64_t)B * H * W);
+  if (dtype == 0) hipLaunchKernelGGL((augment_image_kernel<float>), dim3(g), dim3(256), 0, st, image, B, H, W, params, partial, (float*)out, scale, shift);
+  else hipLaunchKernelGGL((augment_image_kernel<bf16_t>), dim3(g), dim3(256), 0, st, image, B, H, W, params, partial, (bf16_t*)out, scale, shift);
+}
+void launch_augment_flip_labels(const float* lin, float* lout, int B, int K, int ph, int pw, float* boxes, const float* params, float n_width,
+                                hipStream_t st) {
+  hipLaunchKernelGGL(augment_flip_labels_kernel, dim3(aug_grid((int64_t)B * K * ph * pw)), dim3(256), 0, st, lin, lout, B, K, ph, pw, boxes, params, n_width);
+}
+void launch_crop_patches(const float* gt, const float* points, float* crops, int B, int K, int Hp, int Wp, int ph, int pw, hipStream_t st) {
+  hipLaunchKernelGGL(crop_patches_kernel, dim3(aug_grid((int64_t)B * K * ph * pw)), dim3(256), 0, st, gt, points, crops, B, K, Hp, Wp, ph, pw);
+}
+
+}  // namespace rd

@@ -149,6 +149,12 @@ void launch_boxes_to_rois(const float* boxes, float* rois, int B, int K, int fir
 void launch_depth_quantize_u16(const float* z, unsigned short* out, int64_t n, float multiplier, hipStream_t st);
 void launch_sum_f32(const float* x, int64_t n, double* out, hipStream_t st);
 
+// rd_augment.hip
+void launch_augment_gray_partials(const float* image, int B, int H, int W, const float* params, long long* partial, hipStream_t st);
+void launch_augment_image(const float* image, int B, int H, int W, const float* params, const long long* partial, void* out, int dtype, float scale, float shift, hipStream_t st);
+void launch_augment_flip_labels(const float* lin, float* lout, int B, int K, int ph, int pw, float* boxes, const float* params, float n_width, hipStream_t st);
+void launch_crop_patches(const float* gt, const float* points, float* crops, int B, int K, int Hp, int Wp, int ph, int pw, hipStream_t st);
+
 // rd_optim.hip
 void launch_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2, float eps,
                  float wd, float bc1, float bc2, float gscale, hipStream_t st);

@@ -205,8 +205,33 @@ def g_depth_png():
     save("g12_depth_png", z=z, png=raw, loaded=back.astype(np.float32), stored=stored)
 
 
+# ---------------------------------------------------------------------------------------------- G13: batch transforms
+def g_transforms():
+    """The reference's own Transforms.transform (RCNet/rcnet_transforms.py:58-240) with the ZJU training configuration
+    (train_rcnet_zju.py:52-59) on a seeded batch, torch seeded so that the draws can be repeated; torchvision's photometric functions are
+    the oracle's restatement (stub).  Stores inputs that are not regenerated by name, the outputs, and the decisions the class made."""
+    import rcnet_transforms
+    B, K, H, W, ph, pw = 4, 3, 40, 52, 12, 8
+    image = np.floor(rand_array("g13.img", (B, 3, H, W), 256.0, lo=0.0)).astype(np.float32)
+    labels = rand_array("g13.lab", (B, K, 1, ph, pw), 30.0, lo=0.0)
+    xs = np.floor(rand_array("g13.bx", (B, K), W - pw, lo=0.0)) + pw // 2
+    ys = np.floor(rand_array("g13.by", (B, K), H - ph, lo=0.0)) + ph // 2
+    boxes = np.stack([xs - pw // 2, ys - ph // 2, xs + pw // 2, ys + ph // 2], -1).astype(np.float32)
+    points = np.stack([xs, ys, rand_array("g13.z", (B, K), 50.0, lo=0.1)], -1).astype(np.float32)
+    tr = rcnet_transforms.Transforms(normalized_image_range=[0, 1], random_brightness=[0.80, 1.20], random_contrast=[0.80, 1.20],
+                                     random_saturation=[0.80, 1.20], random_noise_type='none', random_noise_spread=-1,
+                                     random_flip_type=['horizontal'])
+    torch.manual_seed(1313)
+    [img_o], [lab_o], [pts_o], [box_o] = tr.transform(images_arr=[t(image.copy())], labels_arr=[t(labels.copy())], points_arr=[t(points.copy())],
+                                                      bounding_boxes_arr=[t(boxes.copy())], random_transform_probability=1.00)
+    save("g13_transforms", image=image.astype(np.uint8), boxes=boxes, points=points, out_image=img_o.numpy(), out_labels=lab_o.numpy(),
+         out_points=pts_o.numpy(), out_boxes=box_o.numpy(), seed=np.array([1313]))
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["attention", "resnet", "decoder", "e2e", "png"]
+    which = sys.argv[1:] or ["attention", "resnet", "decoder", "e2e", "png", "transforms"]
+    if "transforms" in which:
+        g_transforms()
     if "png" in which:
         g_depth_png()
     if "attention" in which:

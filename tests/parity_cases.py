@@ -503,6 +503,50 @@ def inference_driver_case(dev):
     assert q.dtype == np.uint16 and np.array_equal(q, g12["stored"]), "uint16 * 256 encoding differs from what the reference stored"
 
 
+def transforms_case(dev):
+    """N2: device batch augmentation (riders_amd/rcnet_transforms.py) against fixture g13 -- the REFERENCE's own Transforms.transform run
+    with the ZJU training configuration.  The host draws its random decisions in the reference's order, so seeding torch like the
+    generator reproduces them: flipped samples, ground-truth crops, boxes and untouched radar points must match exactly; image values
+    within one 8-bit code / 255 on at most 0.1 % of the pixels (the contrast blend uses the image's mean gray value: exact integer sum here,
+    float32 torch.mean in the reference) and exactly elsewhere.  Also the device ground-truth crop extraction (data/datasets.py:254-272)."""
+    from riders_amd import rcnet_transforms
+    from oracle import transforms as OT
+    g = load("g13_transforms")
+    B, K, H, W, ph, pw = 4, 3, 40, 52, 12, 8
+    image = t(g["image"].astype(np.float32), dev)
+    labels = t(rand_array("g13.lab", (B, K, 1, ph, pw), 30.0, lo=0.0), dev)
+    tr = rcnet_transforms.Transforms(normalized_image_range=[0, 1], random_brightness=[0.80, 1.20], random_contrast=[0.80, 1.20],
+                                     random_saturation=[0.80, 1.20], random_noise_type='none', random_noise_spread=-1, random_flip_type=['horizontal'])
+    torch.manual_seed(int(g["seed"][0]))
+    params = tr.draw(B, 1.00)
+    assert 0 < int(params[:, 6].sum()) < B, "fixture should mix flipped and unflipped samples"
+    [img_o], [lab_o], [pts_o], [box_o] = tr.transform(images_arr=[image], labels_arr=[labels], points_arr=[t(g["points"], dev)],
+                                                      bounding_boxes_arr=[t(g["boxes"].copy(), dev)], random_transform_probability=1.00, params=params)
+    assert np.array_equal(lab_o.cpu().numpy(), g["out_labels"]), "flipped ground-truth crops"
+    assert np.array_equal(box_o.cpu().numpy(), g["out_boxes"]), "flipped boxes"
+    assert np.array_equal(pts_o.cpu().numpy(), g["out_points"]), "radar points must not move"
+    got = img_o.float().cpu().numpy()
+    diff = np.abs(got - g["out_image"]) * 255.0
+    assert diff.max() <= 1.0 + 1e-3, "image differs by more than one code: %.3f" % diff.max()
+    assert (diff > 1e-3).mean() <= 1e-3, "too many pixels differ: %.5f" % (diff > 1e-3).mean()
+    # the oracle (restated torchvision arithmetic + the reference's flip logic) agrees with the reference run exactly
+    oi, ol, ob = OT.transform(t(g["image"].astype(np.float32)), labels.cpu(), t(g["boxes"].copy()), params)
+    assert np.array_equal(oi.numpy(), g["out_image"]) and np.array_equal(ol.numpy(), g["out_labels"]) and np.array_equal(ob.numpy(), g["out_boxes"])
+    # ground-truth crops around radar points (padded coordinates), including a point whose crop leaves the map
+    gt = rand_array("g13.gt", (2, 1, 30, 44), 40.0, lo=0.0)
+    pts = np.array([[[10.0, 9.0, 5.0], [40.0, 25.0, 7.0]], [[4.0, 6.0, 2.0], [22.5, 15.9, 3.0]]], np.float32)
+    crops = rcnet_transforms.crop_patches(t(gt, dev), t(pts, dev), (12, 8)).cpu().numpy()
+    for b in range(2):
+        for k in range(2):
+            x0, y0 = int(pts[b, k, 0] - 4), int(pts[b, k, 1] - 6)
+            want = np.zeros((12, 8), np.float32)
+            for cy in range(12):
+                for cx in range(8):
+                    if 0 <= y0 + cy < 30 and 0 <= x0 + cx < 44:
+                        want[cy, cx] = gt[b, 0, y0 + cy, x0 + cx]
+            assert np.array_equal(crops[b, k, 0], want), (b, k)
+
+
 def adam_case(dev):
     from riders_amd.optim import FlatAdam
     ps = [torch.nn.Parameter(t(rand_array("ad.p%d" % i, s, 1.0), dev)) for i, s in enumerate([(7, 5), (33,), (4, 3, 3, 3)])]

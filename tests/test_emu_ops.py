@@ -152,6 +152,10 @@ def test_experimental_dma_conv_exact(emu):
     P.dma_conv_cases(emu)
 
 
+def test_batch_transforms(emu):
+    P.transforms_case(emu)
+
+
 def test_inference_driver(emu):
     P.inference_driver_case(emu)
 

@@ -89,6 +89,10 @@ def test_scatter_crops(gpu):
     P.scatter_crops_case(gpu)
 
 
+def test_batch_transforms(gpu):
+    P.transforms_case(gpu)
+
+
 def test_inference_driver(gpu):
     P.inference_driver_case(gpu)
 
