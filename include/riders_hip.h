@@ -243,6 +243,13 @@ int rd_augment_flip_labels(const float* labels_in, float* labels_out, int32_t B,
 int rd_crop_patches(const float* gt_padded, const float* points, float* crops, int32_t B, int32_t K, int32_t Hp, int32_t Wp, int32_t ph,
                     int32_t pw, void* stream);
 
+/* ---- offline projection + scatter -- data/preprocess/project_transform.py:67-97, pointcloud_project_zju.py:57-76,81-103 ------------------
+   points (n, stride >= 3) float32 xyz; t_camera_pcl, projection: 4x4 row-major float64 (device); depth_map (H,W) = max(depth, 1) of the
+   NEAREST point projecting to each pixel, 0 elsewhere (bit-exact, order independent); kept_points (n,3) = (u, v, depth) of the points
+   that pass canvas_crop and the depth range, compacted in arbitrary order, n_kept their count (both may be NULL) */
+int rd_project_scatter(const float* points, int32_t n, int32_t stride, const double* t_camera_pcl, const double* projection, int32_t H, int32_t W,
+                       double min_depth, double max_depth, float* depth_map, float* kept_points, int32_t* n_kept, void* stream);
+
 /* ---- optimizer -- RCNet/rcnet_main.py:233-238,357-359; train_zju.py:205-211,390-392 ------------------------ */
 int rd_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
                  float beta2, float eps, float weight_decay, int64_t step, float grad_scale, void* stream);

@@ -445,6 +445,15 @@ int rd_crop_patches(const float* gt_padded, const float* points, float* crops, i
   return done("rd_crop_patches");
 }
 
+int rd_project_scatter(const float* points, int32_t n, int32_t stride, const double* t_camera_pcl, const double* projection, int32_t H, int32_t W,
+                       double min_depth, double max_depth, float* depth_map, float* kept_points, int32_t* n_kept, void* stream) {
+  if (n < 0 || stride < 3 || H <= 0 || W <= 0 || !t_camera_pcl || !projection || !depth_map) return fail("project_scatter: bad args");
+  if (n > 0 && !points) return fail("project_scatter: null points");
+  if ((kept_points != nullptr) != (n_kept != nullptr)) return fail("project_scatter: kept_points and n_kept go together");
+  rd::launch_project_scatter(points, n, stride, t_camera_pcl, projection, H, W, min_depth, max_depth, depth_map, kept_points, n_kept, S(stream));
+  return done("rd_project_scatter");
+}
+
 int rd_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2, float eps, float wd,
                  int64_t step, float gscale, void* stream) {
   if (!p || !g || !m || !v) return fail("adam: null pointer");

@@ -142,4 +142,50 @@ void launch_crop_patches(const float* gt, const float* points, float* crops, int
   hipLaunchKernelGGL(crop_patches_kernel, dim3(aug_grid((int64_t)B * K * ph * pw)), dim3(256), 0, st, gt, points, crops, B, K, Hp, Wp, ph, pw);
 }
 
+// ---- offline point-cloud projection / scatter (data/preprocess/project_transform.py:67-97, pointcloud_project_zju.py:57-76,81-103) ------------
+// p_cam = T p (homogeneous, float64 as numpy computes it: the calibration matrices are float64), depth = p_cam.z, (u, v) = rint(P p_cam / w)
+// (np.round: half to even), kept if 0 < u < W, 0 < v < H, depth > 0 (canvas_crop, strict at 0) and min < depth < max (min_max_filter);
+// depth_map[v][u] = max(depth, 1) with NEARER points overwriting farther ones (the reference sorts by depth, descending, and writes in
+// that order).  "The nearest wins" is order independent: an atomic minimum on the float32 bit pattern (positive floats order like
+// unsigned integers), so the scatter is bit-exact and deterministic whatever the point order.  The map must be pre-filled with 0xFFFFFFFF;
+// pass 2 turns untouched pixels into 0.  Optionally emits the kept points (u, v, depth) compacted in input order + their count.
+__global__ __launch_bounds__(256) void project_scatter_kernel(const float* __restrict__ pts, int n, int stride, const double* __restrict__ T,
+                                                              const double* __restrict__ P, int H, int W, double dmin, double dmax,
+                                                              unsigned* __restrict__ map, float* __restrict__ kept, int* __restrict__ nkept) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) {
+    const double x = (double)pts[(int64_t)i * stride], y = (double)pts[(int64_t)i * stride + 1], z = (double)pts[(int64_t)i * stride + 2];
+    double c[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) c[r] = ((T[r * 4 + 0] * x + T[r * 4 + 1] * y) + T[r * 4 + 2] * z) + T[r * 4 + 3] * 1.0;
+    double q[3];
+#pragma unroll
+    for (int r = 0; r < 3; r++) q[r] = ((P[r * 4 + 0] * c[0] + P[r * 4 + 1] * c[1]) + P[r * 4 + 2] * c[2]) + P[r * 4 + 3] * c[3];
+    const double depth = c[2];
+    const double uf = rint(q[0] / q[2]), vf = rint(q[1] / q[2]);
+    if (!(uf > 0.0 && uf < (double)W && vf > 0.0 && vf < (double)H && depth > 0.0 && depth < dmax && depth > dmin)) continue;
+    const int u = (int)uf, v = (int)vf;
+    const float val = fmaxf((float)depth, 1.0f);
+    atomicMin(&map[v * W + u], __float_as_uint(val));
+    if (kept) {
+      const int k = atomicAdd(nkept, 1);
+      kept[k * 3 + 0] = (float)u; kept[k * 3 + 1] = (float)v; kept[k * 3 + 2] = (float)depth;
+    }
+  }
+}
+__global__ __launch_bounds__(256) void scatter_finish_kernel(unsigned* __restrict__ map, int n) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x)
+    if (map[i] == 0xFFFFFFFFu) map[i] = 0u;
+}
+__global__ __launch_bounds__(256) void fill_u32_kernel(unsigned* __restrict__ p, int n, unsigned v) {
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) p[i] = v;
+}
+void launch_project_scatter(const float* pts, int n, int stride, const double* T, const double* P, int H, int W, double dmin, double dmax, float* depth_map,
+                            float* kept, int* nkept, hipStream_t st) {
+  unsigned* map = reinterpret_cast<unsigned*>(depth_map);
+  hipLaunchKernelGGL(fill_u32_kernel, dim3(aug_grid((int64_t)H * W)), dim3(256), 0, st, map, H * W, 0xFFFFFFFFu);
+  if (nkept) hipLaunchKernelGGL(fill_u32_kernel, dim3(1), dim3(64), 0, st, reinterpret_cast<unsigned*>(nkept), 1, 0u);
+  if (n > 0) hipLaunchKernelGGL(project_scatter_kernel, dim3(aug_grid(n)), dim3(256), 0, st, pts, n, stride, T, P, H, W, dmin, dmax, map, kept, nkept);
+  hipLaunchKernelGGL(scatter_finish_kernel, dim3(aug_grid((int64_t)H * W)), dim3(256), 0, st, map, H * W);
+}
+
 }  // namespace rd

@@ -155,6 +155,8 @@ void launch_augment_image(const float* image, int B, int H, int W, const float* 
 void launch_augment_flip_labels(const float* lin, float* lout, int B, int K, int ph, int pw, float* boxes, const float* params, float n_width, hipStream_t st);
 void launch_crop_patches(const float* gt, const float* points, float* crops, int B, int K, int Hp, int Wp, int ph, int pw, hipStream_t st);
 
+void launch_project_scatter(const float* pts, int n, int stride, const double* T, const double* P, int H, int W, double dmin, double dmax, float* depth_map, float* kept, int* nkept, hipStream_t st);
+
 // rd_optim.hip
 void launch_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2, float eps,
                  float wd, float bc1, float bc2, float gscale, hipStream_t st);

@@ -228,8 +228,33 @@ def g_transforms():
          out_points=pts_o.numpy(), out_boxes=box_o.numpy(), seed=np.array([1313]))
 
 
+# ---------------------------------------------------------------------------------------------- G14: projection + scatter
+def g_projection():
+    """The reference's own project_pcl_to_image + min_max_filter (data/preprocess/project_transform.py) on a seeded point cloud with
+    KITTI-like float64 calibration matrices, followed by the scatter loop of pointcloud_project_zju.py:57-66 (depth_map[v, u] = max(depth, 1)
+    in the returned far-to-near order).  Many points share pixels, some project outside, behind the camera or out of range."""
+    sys.path.insert(0, "/root/reference/data/preprocess")
+    import project_transform as PT
+    rs = np.random.RandomState(1414)
+    n, H, W = 6000, 48, 64
+    pts = np.concatenate([rs.uniform(-12, 12, (n, 1)), rs.uniform(-4, 4, (n, 1)), rs.uniform(-5, 120, (n, 1)), rs.uniform(0, 1, (n, 2))], 1).astype(np.float32)
+    ang = 0.03
+    T = np.array([[np.cos(ang), 0, np.sin(ang), 0.1], [0, 1, 0, -0.2], [-np.sin(ang), 0, np.cos(ang), 0.3], [0, 0, 0, 1]], np.float64)
+    P = np.array([[60.0, 0, 32.0, 0], [0, 60.0, 24.0, 0], [0, 0, 1.0, 0], [0, 0, 0, 1.0]], np.float64)
+    uvs, depth = PT.project_pcl_to_image(point_cloud=pts, t_camera_pcl=T, camera_projection_matrix=P, image_shape=(H, W, 3))
+    idx = PT.min_max_filter(depth, max_value=100.0, min_value=1.5)
+    uvs, depth = uvs[idx], depth[idx]
+    depth_map = np.zeros((H, W), dtype=np.float32)
+    for i in range(len(depth)):            # pointcloud_project_zju.py:61-64
+        u, v = uvs[i]
+        depth_map[v, u] = max(depth[i], 1)
+    save("g14_projection", points=pts, T=T, P=P, depth_map=depth_map, uvs=uvs.astype(np.int32), depth=depth.astype(np.float64))
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["attention", "resnet", "decoder", "e2e", "png", "transforms"]
+    which = sys.argv[1:] or ["attention", "resnet", "decoder", "e2e", "png", "transforms", "projection"]
+    if "projection" in which:
+        g_projection()
     if "transforms" in which:
         g_transforms()
     if "png" in which:

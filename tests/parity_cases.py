@@ -547,6 +547,30 @@ def transforms_case(dev):
             assert np.array_equal(crops[b, k, 0], want), (b, k)
 
 
+def projection_case(dev):
+    """N4: device projection + scatter against fixture g14 (the REFERENCE's project_pcl_to_image / min_max_filter + its scatter loop):
+    the depth map bit for bit, the kept point set exactly (same pixels, same depths, far-to-near order)."""
+    from riders_amd import preprocess
+    g = load("g14_projection")
+    H, W = g["depth_map"].shape
+    dm, kept = preprocess.project_to_depth_map(t(g["points"], dev), g["T"], g["P"], (H, W, 3), 100.0, 1.5, return_points=True)
+    assert np.array_equal(dm.cpu().numpy(), g["depth_map"]), "depth map differs"
+    assert int((g["depth_map"] > 0).sum()) > 200 and len(g["depth"]) > int((g["depth_map"] > 0).sum()), "fixture should have pixel collisions"
+    k = kept.cpu().numpy()
+    assert k.shape[0] == g["uvs"].shape[0]
+    assert np.array_equal(np.sort(k[:, 2])[::-1], np.sort(g["depth"].astype(np.float32))[::-1])
+    got = sorted(map(tuple, np.concatenate([k[:, :2], k[:, 2:3]], 1).tolist()))
+    want = sorted(map(tuple, np.concatenate([g["uvs"].astype(np.float32), g["depth"].astype(np.float32)[:, None]], 1).tolist()))
+    assert got == want, "kept (u, v, depth) set differs"
+    assert np.all(np.diff(k[:, 2]) <= 0), "points must come back far to near"
+    # order independence: the same cloud shuffled gives the same map
+    perm = np.random.RandomState(3).permutation(g["points"].shape[0])
+    dm2 = preprocess.project_to_depth_map(t(g["points"][perm], dev), g["T"], g["P"], (H, W, 3), 100.0, 1.5)
+    assert torch.equal(dm2, dm)
+    empty = preprocess.project_to_depth_map(t(g["points"][:0], dev), g["T"], g["P"], (H, W, 3))
+    assert float(empty.abs().max()) == 0.0
+
+
 def adam_case(dev):
     from riders_amd.optim import FlatAdam
     ps = [torch.nn.Parameter(t(rand_array("ad.p%d" % i, s, 1.0), dev)) for i, s in enumerate([(7, 5), (33,), (4, 3, 3, 3)])]

@@ -156,6 +156,10 @@ def test_batch_transforms(emu):
     P.transforms_case(emu)
 
 
+def test_projection_scatter(emu):
+    P.projection_case(emu)
+
+
 def test_inference_driver(emu):
     P.inference_driver_case(emu)
 

@@ -93,6 +93,10 @@ def test_batch_transforms(gpu):
     P.transforms_case(gpu)
 
 
+def test_projection_scatter(gpu):
+    P.projection_case(gpu)
+
+
 def test_inference_driver(gpu):
     P.inference_driver_case(gpu)
 
