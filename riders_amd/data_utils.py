@@ -118,3 +118,24 @@ def save_depth(z, path, multiplier=256.0):
     """data/data_utils.py:128-143; `z` may be a numpy array or a (ROCm) tensor."""
     with open(path, "wb") as f:
         f.write(encode_png16(quantize_depth(z, multiplier)))
+
+
+# ---- stage hand-off layout (RC-Net inference -> Scale Map Learner) ------------------------------------------------------------------
+def rcnet_output_paths(output_path, radar_path):
+    """RCNet/run_rcnet_zju.py:159-171: where the quasi-dense depth / colour preview / response of one radar frame are written:
+    <output_path>/<scene>/{depth_predicted, depth_predicted_colors, response_predicted}/<file id>.png, scene = third path component from
+    the end of the radar file path."""
+    import os
+    file_id = os.path.basename(radar_path).split('.')[0]
+    save_scene = radar_path.split('/')[-3]
+    return (os.path.join(output_path, save_scene, 'depth_predicted', file_id + '.png'),
+            os.path.join(output_path, save_scene, 'depth_predicted_colors', file_id + '.png'),
+            os.path.join(output_path, save_scene, 'response_predicted', file_id + '.png'))
+
+
+def sml_rcnet_input_paths(result_root, interp, scene):
+    """train_zju.py:114-117 / val_zju.py: the SML reads the quasi-dense maps of a scene from <result_root>/<interp>/<scene>/depth_predicted,
+    sorted by file name -- i.e. `output_path` of the RC-Net stage = <result_root>/<interp>."""
+    import os
+    root = os.path.join(result_root, interp, scene, 'depth_predicted')
+    return [os.path.join(root, p) for p in sorted(os.listdir(root))]

@@ -41,3 +41,20 @@ def test_round_trip_properties():
     assert np.all(d <= z + 1e-6) and np.all(z - d < 1.0 / 256.0 + 1e-6)          # truncation: never above, less than one code below
     assert np.array_equal(d == 0, z < 1.0 / 256.0)
     assert data_utils.quantize_depth(np.array([[300.0, -2.0]], np.float32)).tolist() == [[65535, 0]]
+
+
+def test_stage_handoff_layout(tmp_path):
+    """run_rcnet_zju.py:159-171 writes where train_zju.py:114-117 reads: <result_root>/<interp>/<scene>/depth_predicted/<id>.png."""
+    import os
+    radar = ["/data/zju/scene_a/radar/000012.npy", "/data/zju/scene_a/radar/000003.npy"]
+    out_root = os.path.join(str(tmp_path), "rcnet")
+    z = np.full((4, 5), 2.5, np.float32)
+    for r in radar:
+        depth_p, color_p, resp_p = data_utils.rcnet_output_paths(out_root, r)
+        assert depth_p == os.path.join(out_root, "scene_a", "depth_predicted", os.path.basename(r)[:-4] + ".png")
+        assert os.path.dirname(color_p).endswith("depth_predicted_colors") and os.path.dirname(resp_p).endswith("response_predicted")
+        os.makedirs(os.path.dirname(depth_p), exist_ok=True)
+        data_utils.save_depth(z, depth_p)
+    got = data_utils.sml_rcnet_input_paths(str(tmp_path), "rcnet", "scene_a")
+    assert [os.path.basename(p) for p in got] == ["000003.png", "000012.png"]
+    assert np.array_equal(data_utils.load_depth(got[0]), z)
