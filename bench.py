@@ -161,6 +161,7 @@ def run_workload(kind, args, dev, world, rank, steps, warmup):
         torch.cuda.synchronize()
 
     loss = None
+    extra["loss_scale"] = args.loss_scale if args.loss_scale is not None else (16384.0 if args.dtype == "fp16" else 1.0)
     if args.eager:
         def step():
             return main_mod.train_step(model, opt, batch, cfg, reducer, **extra)
@@ -238,8 +239,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--settle-seconds", type=float, default=2.0, help="untimed replays before the timed region (clock settling)")
     ap.add_argument("--batch", type=int, default=8, help="images per GPU (BASELINE configs[1]: 8)")
-    ap.add_argument("--dtype", default=os.environ.get("RIDERS_BENCH_DTYPE", "bf16"), choices=["fp32", "bf16"],
-                    help="activation dtype (BASELINE.json configs[1] quotes bf16; fp32 is the 1e-3 parity mode)")
+    ap.add_argument("--dtype", default=os.environ.get("RIDERS_BENCH_DTYPE", "bf16"), choices=["fp32", "bf16", "fp16"],
+                    help="activation dtype (BASELINE.json configs[1] quotes bf16; fp32 is the 1e-3 parity mode; fp16 = configs[4], with --height 512 "
+                         "--width 1024, static loss scale --loss-scale)")
+    ap.add_argument("--loss-scale", type=float, default=None, help="static loss scale (default 16384 for fp16, 1 otherwise)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--height", type=int, default=256)
     ap.add_argument("--width", type=int, default=512)
@@ -276,7 +279,7 @@ def main():
                       "train imgs/sec (Scale Map Learner, MiDaS-small / EfficientNet-Lite3)",
             "value": head["value"], "unit": "imgs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": {"fp32": "f32", "bf16": "bf16"}[args.dtype], "data": "synthetic",
+            "dtype": {"fp32": "f32", "bf16": "bf16", "fp16": "f16"}[args.dtype], "data": "synthetic",
             "config": {"workload": ("RC-Net training step, batch %d/GPU, ZJU config (K=30, patch 240x100), %dx%d image, fwd+loss+bwd+Adam" if is_rc
                                     else "SML training step, batch %d/GPU, %dx%d frames, device pre-step+fwd+loss+bwd+Adam") % (
                 head["batch_per_gpu"], head["height"], head["width"]), "global_batch": head["batch_per_gpu"] * world,

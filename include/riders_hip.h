@@ -11,7 +11,7 @@
  *   - all pointers are DEVICE pointers owned by the caller (PyTorch allocates every tensor, saved-for-
  *     backward buffer and workspace); the library keeps no device memory between calls;
  *   - every entry is an asynchronous enqueue on `stream` (a hipStream_t passed as void*);
- *   - activations are NHWC ("channels_last"), dtype RD_F32 or RD_BF16; parameters, gradients of
+ *   - activations are NHWC ("channels_last"), dtype RD_F32, RD_BF16 or RD_F16; parameters, gradients of
  *     parameters, statistics and losses are always fp32 in the reference's layouts (OIHW, [out,in]);
  *   - return value: 0 = ok, negative = argument error (message via rd_last_error_string()),
  *     positive = hipError_t from the launch.  No C++ exception crosses the boundary.
@@ -25,6 +25,7 @@ extern "C" {
 
 #define RD_F32 0
 #define RD_BF16 1
+#define RD_F16 2  /* IEEE half activations (BASELINE.json configs[4]); same kernels, conversions and MFMA opcodes of the fp16 build */
 
 #define RD_ACT_NONE 0
 #define RD_ACT_RELU 1
@@ -41,7 +42,7 @@ const char* rd_last_error_string(void);
  * replaces: utils/net_utils.py:84-91 (Conv2d), :195-198 (UpConv2d), :564-569 (DecoderBlock concat),
  *           RCNet/linear_attention.py:121-131 (nn.Linear as 1x1), modules/midas/blocks.py:28-39,83-88,147,185-191 */
 typedef struct rd_conv_desc {
-  int32_t dtype;               /* RD_F32 / RD_BF16 activations                                        */
+  int32_t dtype;               /* RD_F32 / RD_BF16 / RD_F16 activations                                        */
   int32_t N, Hin, Win;         /* logical input size                                                  */
   int32_t C1, C2;              /* channels of src1 / src2 (C2 = 0: single source)                     */
   int32_t upsample, H1, W1;    /* nearest-upsample the sources from H1 x W1 to Hin x Win              */
@@ -73,6 +74,9 @@ int rd_pad_channels(const void* src, void* dst, int64_t rows, int32_t C, int32_t
 int rd_unpad_weight_grad(const float* dw_padded, float* dw, int32_t Cout, int32_t Cin, int32_t Cin_pad, int32_t taps, int32_t accumulate,
                          void* stream);
 int rd_conv_pack_weights_batch(const rd_pack_item* items, int32_t n, void* stream);
+/* the same for a table whose 16-bit items are fp16: inside the table the item dtype is 0 (fp32) or 1 (the 16-bit type), half_dtype = RD_BF16
+   (identical to the call above) or RD_F16 says which 16-bit format that is */
+int rd_conv_pack_weights_batch_half(const rd_pack_item* items, int32_t n, int32_t half_dtype, void* stream);
 /* Weight gradients of MANY 1x1 / linear layers in one launch + one ordered reduction (reference: autograd of the nn.Linear layers of
    RCNet/linear_attention.py:84-135; 96 products per RC-Net step).  gemm p: slab_p[split][Cout][C1+C2] = partial dY_p^T [X1_p | X2_p]
    over tokens [split*rows_per_split, ...); C1, C2, Cout multiples of the 16-byte vector (4 fp32 / 8 bf16), C1 % 64 == 0 when C2 > 0.  reduce q: dw_q[elems] (+)= sum of nsplit

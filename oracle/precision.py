@@ -5,11 +5,11 @@ import torch
 class _RoundBF16(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):
-        return x.to(torch.bfloat16).to(x.dtype)
+        return x.to(Precision.dtype).to(x.dtype)
 
     @staticmethod
     def backward(ctx, g):
-        return g.to(torch.bfloat16).to(g.dtype)
+        return g.to(Precision.dtype).to(g.dtype)
 
 
 class _RoundGradBF16(torch.autograd.Function):
@@ -19,7 +19,7 @@ class _RoundGradBF16(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        return g.to(torch.bfloat16).to(g.dtype)
+        return g.to(Precision.dtype).to(g.dtype)
 
 
 class Precision:
@@ -28,7 +28,8 @@ class Precision:
     and the packed weights of dense convolutions; gradients are rounded at the same tensors.  With `bf16 = False` (default) every hook
     is the identity and the oracle is the plain fp32 restatement.  Used to check the bf16 KERNELS against the same arithmetic: the
     precision loss of bf16 storage itself (BatchNorm in training mode amplifies it by |mean| / std per layer) is not a kernel property."""
-    bf16 = False
+    bf16 = False              # switch: emulate the 16-bit mode
+    dtype = torch.bfloat16    # its storage type (torch.bfloat16, or torch.float16 for the fp16 mode)
 
     @staticmethod
     def r(x):
@@ -42,4 +43,4 @@ class Precision:
 
     @staticmethod
     def w(w):
-        return w + (w.to(torch.bfloat16).to(w.dtype) - w).detach() if Precision.bf16 else w
+        return w + (w.to(Precision.dtype).to(w.dtype) - w).detach() if Precision.bf16 else w

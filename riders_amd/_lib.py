@@ -15,7 +15,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 HEADER = os.path.join(HERE, "..", "include", "riders_hip.h")
 LIB_PATH = os.environ.get("RIDERS_HIP_LIB") or os.path.join(HERE, "libriders_hip.so")   # override: A/B runs of two kernel builds (tools/)
 
-RD_F32, RD_BF16 = 0, 1
+RD_F32, RD_BF16, RD_F16 = 0, 1, 2
 ACT_NONE, ACT_RELU, ACT_LRELU, ACT_RELU6 = 0, 1, 2, 3
 
 

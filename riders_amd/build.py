@@ -21,6 +21,18 @@ def sources():
     return sorted(f for f in os.listdir(CSRC) if f.endswith(".hip") or f.endswith(".cpp"))
 
 
+def units():
+    """(source, object, extra flags): every kernel translation unit twice -- 16-bit activations = bf16 (namespace rd) and, with
+    -DRD_HALF_F16, = IEEE fp16 (namespace rd_f16, see csrc/rd_common.h); the C ABI layer (rd_api.cpp) once, it dispatches on the dtype code."""
+    out = []
+    for f in sources():
+        src = os.path.join(CSRC, f)
+        out.append((src, os.path.join(OBJ, f + ".o"), []))
+        if f.endswith(".hip"):
+            out.append((src, os.path.join(OBJ, f + ".f16.o"), ["-DRD_HALF_F16"]))
+    return out
+
+
 def _newer(a, b):
     return (not os.path.exists(b)) or os.path.getmtime(a) > os.path.getmtime(b)
 
@@ -35,27 +47,25 @@ def build(force=False, verbose=True):
     os.makedirs(OBJ, exist_ok=True)
     hm = _headers_mtime()
     jobs = []
-    for f in sources():
-        src = os.path.join(CSRC, f)
-        obj = os.path.join(OBJ, f + ".o")
+    for src, obj, extra in units():
         if force or _newer(src, obj) or hm > os.path.getmtime(obj):
-            jobs.append((src, obj))
+            jobs.append((src, obj, extra))
 
     def cc(job):
-        src, obj = job
-        cmd = [HIPCC, "-x", "hip"] + FLAGS + ["-c", src, "-o", obj]
+        src, obj, extra = job
+        cmd = [HIPCC, "-x", "hip"] + FLAGS + extra + ["-c", src, "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         return job, r
 
     if jobs:
         with ThreadPoolExecutor(max_workers=min(6, len(jobs))) as ex:
-            for (src, obj), r in ex.map(cc, jobs):
+            for (src, obj, extra), r in ex.map(cc, jobs):
                 if verbose:
-                    print("[hipcc] %s" % os.path.basename(src), flush=True)
+                    print("[hipcc] %s%s" % (os.path.basename(src), " (fp16 build)" if extra else ""), flush=True)
                 if r.returncode != 0:
                     sys.stderr.write(r.stdout + r.stderr)
                     raise RuntimeError("hipcc failed on %s" % src)
-    objs = [os.path.join(OBJ, f + ".o") for f in sources()]
+    objs = [obj for _, obj, _ in units()]
     if jobs or not os.path.exists(LIB):
         cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs
         r = subprocess.run(cmd, capture_output=True, text=True)

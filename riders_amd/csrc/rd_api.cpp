@@ -1,6 +1,10 @@
 // extern "C" surface of libriders_hip.so (see include/riders_hip.h).  Argument validation + launch only.
 #include "../../include/riders_hip.h"
 #include "rd_kernels.h"
+// the fp16 build of the same kernels (compiled with -DRD_HALF_F16, namespace rd_f16): same declarations, second namespace
+#define rd rd_f16
+#include "rd_kernels_decl.h"
+#undef rd
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
@@ -18,7 +22,10 @@ int done(const char* what) {
   return 0;
 }
 inline hipStream_t S(void* s) { return (hipStream_t)s; }
-inline bool dt_ok(int d) { return d == RD_F32 || d == RD_BF16; }
+inline bool dt_ok(int d) { return d == RD_F32 || d == RD_BF16 || d == RD_F16; }
+// Precision dispatch: RD_F16 selects the fp16 build of the kernels; inside a build the 16-bit activation type always has code 1.
+#define RD_DT(dt) ((dt) == RD_F16 ? 1 : (dt))
+#define RD_NS(dt, fn) ((dt) == RD_F16 ? rd_f16::fn : rd::fn)
 
 int check_desc(const rd_conv_desc* d) {
   if (!d) return fail("conv: null descriptor");
@@ -42,7 +49,7 @@ void fill_args(const rd_conv_desc* d, rd::ConvArgs& a) {
   a.scale_h = (float)a.H1 / (float)d->Hin; a.scale_w = (float)a.W1 / (float)d->Win;
   a.M = d->N * d->OH * d->OW;
   a.K = d->KH * d->KW * (d->C1 + d->C2);
-  a.Kpad = rd::conv_kpad(a.K, d->dtype);
+  a.Kpad = RD_NS(d->dtype, conv_kpad)(a.K, RD_DT(d->dtype));
 }
 }  // namespace
 
@@ -52,27 +59,27 @@ int rd_version(void) { return 100; }
 const char* rd_last_error_string(void) { return g_err; }
 
 int64_t rd_conv_packed_elems(int32_t rows, int32_t K, int32_t dtype) {
-  return (int64_t)rd::conv_rows_pad(rows) * rd::conv_kpad(K, dtype);
+  return (int64_t)rd::conv_rows_pad(rows) * RD_NS(dtype, conv_kpad)(K, RD_DT(dtype));
 }
 int rd_conv_pack_weights(const float* w, void* packed, int32_t Cout, int32_t Cin, int32_t KH, int32_t KW, int32_t mode,
                          int32_t dtype, void* stream) {
   if (!w || !packed) return fail("pack_weights: null pointer");
   if (!dt_ok(dtype) || (mode != 0 && mode != 1)) return fail("pack_weights: bad dtype/mode");
-  rd::launch_pack_weights(w, packed, Cout, Cin, KH, KW, mode, dtype, S(stream));
+  RD_NS(dtype, launch_pack_weights)(w, packed, Cout, Cin, KH, KW, mode, RD_DT(dtype), S(stream), 0);
   return done("rd_conv_pack_weights");
 }
 int rd_conv_pack_weights_padded(const float* w, void* packed, int32_t Cout, int32_t Cin_src, int32_t Cin, int32_t KH, int32_t KW,
                                 int32_t dtype, void* stream) {
   if (!w || !packed) return fail("pack_weights_padded: null pointer");
   if (!dt_ok(dtype) || Cin_src <= 0 || Cin < Cin_src) return fail("pack_weights_padded: bad dtype / channel counts");
-  rd::launch_pack_weights(w, packed, Cout, Cin, KH, KW, 0, dtype, S(stream), Cin_src);
+  RD_NS(dtype, launch_pack_weights)(w, packed, Cout, Cin, KH, KW, 0, RD_DT(dtype), S(stream), Cin_src);
   return done("rd_conv_pack_weights_padded");
 }
 int rd_pad_channels(const void* src, void* dst, int64_t rows, int32_t C, int32_t Cpad, int32_t dtype, void* stream) {
   if (!src || !dst) return fail("pad_channels: null pointer");
   if (!dt_ok(dtype) || C <= 0 || Cpad < C || rows < 0) return fail("pad_channels: bad arguments");
   if (rows == 0) return 0;
-  rd::launch_pad_channels(src, dst, rows, C, Cpad, dtype, S(stream));
+  RD_NS(dtype, launch_pad_channels)(src, dst, rows, C, Cpad, RD_DT(dtype), S(stream));
   return done("rd_pad_channels");
 }
 int rd_unpad_weight_grad(const float* dwp, float* dw, int32_t Cout, int32_t Cin, int32_t Cin_pad, int32_t taps, int32_t accumulate,
@@ -88,6 +95,14 @@ int rd_conv_pack_weights_batch(const rd_pack_item* items, int32_t n, void* strea
   if (n > 65535) return fail("pack_weights_batch: too many items (%d)", n);
   rd::launch_pack_weights_batch(items, n, S(stream));
   return done("rd_conv_pack_weights_batch");
+}
+int rd_conv_pack_weights_batch_half(const rd_pack_item* items, int32_t n, int32_t half_dtype, void* stream) {
+  if (n <= 0) return 0;
+  if (!items) return fail("pack_weights_batch_half: null table");
+  if (n > 65535) return fail("pack_weights_batch_half: too many items (%d)", n);
+  if (half_dtype != RD_BF16 && half_dtype != RD_F16) return fail("pack_weights_batch_half: half_dtype must be RD_BF16 or RD_F16");
+  RD_NS(half_dtype, launch_pack_weights_batch)(items, n, S(stream));
+  return done("rd_conv_pack_weights_batch_half");
 }
 int rd_linear_wgrad_batch(const rd_lwg_gemm* gemms, int32_t n_gemm, const rd_lwg_reduce* reduces, int32_t n_reduce, int32_t dtype,
                           void* stream) {
@@ -105,7 +120,7 @@ int rd_linear_wgrad_batch(const rd_lwg_gemm* gemms, int32_t n_gemm, const rd_lwg
   }
   for (int i = 0; i < n_reduce; i++)
     if (!reduces[i].slab || !reduces[i].dw || reduces[i].elems <= 0 || reduces[i].nsplit <= 0) return fail("linear_wgrad_batch: bad reduce item %d", i);
-  rd::launch_linear_wgrad_batch(reinterpret_cast<const rd::LwgGemm*>(gemms), n_gemm, reinterpret_cast<const rd::LwgReduce*>(reduces), n_reduce, dtype, S(stream));
+  RD_NS(dtype, launch_linear_wgrad_batch)(reinterpret_cast<const rd::LwgGemm*>(gemms), n_gemm, reinterpret_cast<const rd::LwgReduce*>(reduces), n_reduce, RD_DT(dtype), S(stream));
   return done("rd_linear_wgrad_batch");
 }
 int rd_loftr_layer_fwd(const void* x, const void* src, const rd_loftr_weights* w, void* out, const rd_loftr_saved* sv, int32_t N,
@@ -117,8 +132,8 @@ int rd_loftr_layer_fwd(const void* x, const void* src, const rd_loftr_weights* w
   if (N < 0 || L <= 0 || S <= 0 || L > 32 || S > 32) return fail("loftr_layer_fwd: needs 1..32 tokens per sequence (L=%d S=%d)", L, S);
   if (!w->wq || !w->wk || !w->wv || !w->wm || !w->w0 || !w->w2 || !w->g1 || !w->b1 || !w->g2 || !w->b2) return fail("loftr_layer_fwd: null weight");
   if (!sv->q || !sv->k || !sv->v || !sv->att || !sv->mpre || !sv->msg || !sv->hid || !sv->m2pre || !sv->stats) return fail("loftr_layer_fwd: null saved buffer");
-  rd::launch_loftr_layer_fwd(x, src, *reinterpret_cast<const rd::LoftrW*>(w), out, *reinterpret_cast<const rd::LoftrSaved*>(sv), N, L, S,
-                             eps_attn, eps_ln, dtype, (hipStream_t)stream);
+  RD_NS(dtype, launch_loftr_layer_fwd)(x, src, *reinterpret_cast<const rd::LoftrW*>(w), out, *reinterpret_cast<const rd::LoftrSaved*>(sv), N, L, S,
+                             eps_attn, eps_ln, RD_DT(dtype), (hipStream_t)stream);
   return done("rd_loftr_layer_fwd");
 }
 int rd_loftr_layer_bwd(const void* x, const void* src, const rd_loftr_weights* w, const rd_loftr_saved* sv, const rd_loftr_grads* g,
@@ -129,13 +144,13 @@ int rd_loftr_layer_bwd(const void* x, const void* src, const rd_loftr_weights* w
   if (!g->dout || !g->dm2pre || !g->dhid || !g->dmpre || !g->datt || !g->dq || !g->dk || !g->dv || !g->dx || (src != x && !g->dsrc))
     return fail("loftr_layer_bwd: null gradient buffer");
   if (!g->lnp1 || !g->lnp2 || !g->dg1 || !g->db1 || !g->dg2 || !g->db2) return fail("loftr_layer_bwd: null LayerNorm gradient buffer");
-  rd::launch_loftr_layer_bwd(x, src, *reinterpret_cast<const rd::LoftrW*>(w), *reinterpret_cast<const rd::LoftrSaved*>(sv),
-                             *reinterpret_cast<const rd::LoftrGrads*>(g), N, L, S, eps_attn, dtype, (hipStream_t)stream);
+  RD_NS(dtype, launch_loftr_layer_bwd)(x, src, *reinterpret_cast<const rd::LoftrW*>(w), *reinterpret_cast<const rd::LoftrSaved*>(sv),
+                             *reinterpret_cast<const rd::LoftrGrads*>(g), N, L, S, eps_attn, RD_DT(dtype), (hipStream_t)stream);
   return done("rd_loftr_layer_bwd");
 }
 int32_t rd_conv_stats_rows(const rd_conv_desc* d) {
   rd::ConvArgs a; fill_args(d, a);
-  return (int32_t)rd::conv_stats_rows(a, d->dtype);
+  return (int32_t)RD_NS(d->dtype, conv_stats_rows)(a, RD_DT(d->dtype));
 }
 
 int rd_conv_fwd(const rd_conv_desc* d, const void* src1, const void* src2, const void* w_packed, const float* bias, void* dst1,
@@ -146,7 +161,7 @@ int rd_conv_fwd(const rd_conv_desc* d, const void* src1, const void* src2, const
   if (d->D1 < d->Cout && !dst2) return fail("conv_fwd: D1 < Cout but dst2 is null");
   rd::ConvArgs a; fill_args(d, a);
   a.src1 = src1; a.src2 = src2; a.w = w_packed; a.bias = bias; a.dst1 = dst1; a.dst2 = dst2; a.stats = stats;
-  rd::launch_conv(a, d->dtype, S(stream));
+  RD_NS(d->dtype, launch_conv)(a, RD_DT(d->dtype), S(stream));
   return done("rd_conv_fwd");
 }
 static void fill_wgrad_args(const rd_conv_desc* d, rd::WgradArgs& a) {
@@ -161,7 +176,7 @@ static void fill_wgrad_args(const rd_conv_desc* d, rd::WgradArgs& a) {
 int64_t rd_conv_wgrad_workspace_bytes(const rd_conv_desc* d) {
   rd::WgradArgs a; fill_wgrad_args(d, a);
   int ns = rd::wgrad_slabs(a.M, a.K, d->Cout);
-  if (rd::wgrad3x3_tr_ok(a, d->dtype)) ns = std::max(ns, rd::wgrad3x3_tr_blocks(a));
+  if (RD_NS(d->dtype, wgrad3x3_tr_ok)(a, RD_DT(d->dtype))) ns = std::max(ns, rd::wgrad3x3_tr_blocks(a));
   return (int64_t)(ns + 1) * d->Cout * a.K * (int64_t)sizeof(float);
 }
 int rd_conv_wgrad(const rd_conv_desc* d, const void* src1, const void* src2, const void* dy, float* workspace, float* dw,
@@ -176,7 +191,7 @@ int rd_conv_wgrad(const rd_conv_desc* d, const void* src1, const void* src2, con
   a.Cout = d->Cout; a.KH = d->KH; a.KW = d->KW; a.stride = d->stride; a.pad = d->pad; a.OH = d->OH; a.OW = d->OW;
   a.scale_h = (float)a.H1 / (float)d->Hin; a.scale_w = (float)a.W1 / (float)d->Win;
   a.M = d->N * d->OH * d->OW; a.K = d->KH * d->KW * (d->C1 + d->C2);
-  rd::launch_wgrad(a, d->dtype, dw, accumulate, S(stream));
+  RD_NS(d->dtype, launch_wgrad)(a, RD_DT(d->dtype), dw, accumulate, S(stream));
   return done("rd_conv_wgrad");
 }
 
@@ -194,7 +209,7 @@ int rd_affine_act(const void* y, const float* scale, const float* shift, const v
                   int32_t C, int32_t act, float slope, int32_t dtype, void* stream) {
   if (!y || !out || !dt_ok(dtype)) return fail("affine_act: bad args");
   if (pixels * C == 0) return 0;
-  rd::launch_affine_act(y, scale, shift, residual, out, pixels, C, act, slope, dtype, S(stream));
+  RD_NS(dtype, launch_affine_act)(y, scale, shift, residual, out, pixels, C, act, slope, RD_DT(dtype), S(stream));
   return done("rd_affine_act");
 }
 int32_t rd_bn_bwd_rows(int64_t pixels, int32_t C) { return rd::bn_bwd_rows(pixels, C); }
@@ -204,9 +219,9 @@ int rd_bn_act_bwd(const void* dz, const void* z, const void* y, const float* mea
   if (!dz || !y || !mean || !rstd || !scale || !partial || !coef || !dy || !dt_ok(dtype)) return fail("bn_act_bwd: bad args");
   if (act != RD_ACT_NONE && !z) return fail("bn_act_bwd: activation backward needs z");
   int rows = rd::bn_bwd_rows(pixels, C);
-  rd::launch_bn_bwd_reduce(dz, z, y, mean, rstd, partial, pixels, C, act, slope, dtype, S(stream));
+  RD_NS(dtype, launch_bn_bwd_reduce)(dz, z, y, mean, rstd, partial, pixels, C, act, slope, RD_DT(dtype), S(stream), nullptr, nullptr);
   rd::launch_bn_bwd_finalize(partial, rows, C, (double)pixels, dgamma, dbeta, accumulate, coef, coef + C, S(stream));
-  rd::launch_bn_bwd_apply(dz, z, y, mean, rstd, scale, coef, coef + C, dy, dres, pixels, C, act, slope, dtype, S(stream));
+  RD_NS(dtype, launch_bn_bwd_apply)(dz, z, y, mean, rstd, scale, coef, coef + C, dy, dres, pixels, C, act, slope, RD_DT(dtype), S(stream), nullptr);
   return done("rd_bn_act_bwd");
 }
 int rd_bn_act_bwd_recompute(const void* dz, const void* z, const void* y, const float* mean, const float* rstd, const float* scale,
@@ -215,21 +230,21 @@ int rd_bn_act_bwd_recompute(const void* dz, const void* z, const void* y, const 
   if (!dz || !y || !mean || !rstd || !scale || !shift || !partial || !coef || !dy || !dt_ok(dtype)) return fail("bn_act_bwd_recompute: bad args");
   if (act != RD_ACT_NONE && !z && (C % (dtype == RD_F32 ? 4 : 8))) return fail("bn_act_bwd_recompute: this channel count needs z");
   int rows = rd::bn_bwd_rows(pixels, C);
-  rd::launch_bn_bwd_reduce(dz, z, y, mean, rstd, partial, pixels, C, act, slope, dtype, S(stream), scale, shift);
+  RD_NS(dtype, launch_bn_bwd_reduce)(dz, z, y, mean, rstd, partial, pixels, C, act, slope, RD_DT(dtype), S(stream), scale, shift);
   rd::launch_bn_bwd_finalize(partial, rows, C, (double)pixels, dgamma, dbeta, accumulate, coef, coef + C, S(stream));
-  rd::launch_bn_bwd_apply(dz, z, y, mean, rstd, scale, coef, coef + C, dy, dres, pixels, C, act, slope, dtype, S(stream), shift);
+  RD_NS(dtype, launch_bn_bwd_apply)(dz, z, y, mean, rstd, scale, coef, coef + C, dy, dres, pixels, C, act, slope, RD_DT(dtype), S(stream), shift);
   return done("rd_bn_act_bwd_recompute");
 }
 int rd_act_bwd(const void* dz, const void* z, void* dx, int64_t n, int32_t act, float slope, int32_t dtype, void* stream) {
   if (!dz || !z || !dx || !dt_ok(dtype)) return fail("act_bwd: bad args");
   if (n == 0) return 0;
-  rd::launch_act_bwd(dz, z, dx, n, act, slope, dtype, S(stream));
+  RD_NS(dtype, launch_act_bwd)(dz, z, dx, n, act, slope, RD_DT(dtype), S(stream));
   return done("rd_act_bwd");
 }
 int32_t rd_colsum_rows(int64_t rows, int32_t C) { return rd::colsum_rows(rows, C); }
 int rd_colsum(const void* x, float* partial, float* out, int32_t accumulate, int64_t rows, int32_t C, int32_t dtype, void* stream) {
   if (!x || !partial || !out || !dt_ok(dtype)) return fail("colsum: bad args");
-  rd::launch_colsum(x, partial, out, accumulate, rows, C, dtype, S(stream));
+  RD_NS(dtype, launch_colsum)(x, partial, out, accumulate, rows, C, RD_DT(dtype), S(stream));
   return done("rd_colsum");
 }
 
@@ -238,7 +253,7 @@ int rd_layernorm_fwd(const void* x, const float* gamma, const float* beta, const
   if (!x || !gamma || !beta || !out || !mean || !rstd || !dt_ok(dtype)) return fail("layernorm_fwd: bad args");
   if (C % 64 || C > 512) return fail("layernorm: C must be a multiple of 64 and <= 512 (got %d)", C);
   if (rows == 0) return 0;
-  rd::launch_layernorm_fwd(x, gamma, beta, residual, out, mean, rstd, rows, C, eps, dtype, S(stream));
+  RD_NS(dtype, launch_layernorm_fwd)(x, gamma, beta, residual, out, mean, rstd, rows, C, eps, RD_DT(dtype), S(stream));
   return done("rd_layernorm_fwd");
 }
 int32_t rd_layernorm_bwd_rows(int64_t rows) { return rd::layernorm_bwd_rows(rows); }
@@ -247,7 +262,7 @@ int rd_layernorm_bwd(const void* dout, const void* x, const float* gamma, const 
                      void* stream) {
   if (!dout || !x || !gamma || !mean || !rstd || !dx || !partial || !dt_ok(dtype)) return fail("layernorm_bwd: bad args");
   if (C % 64 || C > 512) return fail("layernorm: C must be a multiple of 64 and <= 512 (got %d)", C);
-  rd::launch_layernorm_bwd(dout, x, gamma, mean, rstd, dx, partial, dgamma, dbeta, accumulate, rows, C, dtype, S(stream));
+  RD_NS(dtype, launch_layernorm_bwd)(dout, x, gamma, mean, rstd, dx, partial, dgamma, dbeta, accumulate, rows, C, RD_DT(dtype), S(stream));
   return done("rd_layernorm_bwd");
 }
 
@@ -255,7 +270,7 @@ int rd_linear_attention_fwd(const void* q, const void* k, const void* v, void* o
                             int32_t ldq, int32_t ldk, int32_t ldv, int32_t ldo, float eps, int32_t dtype, void* stream) {
   if (!q || !k || !v || !out || !dt_ok(dtype)) return fail("linear_attention_fwd: bad args");
   if (L <= 0 || Sx <= 0 || L > 32 || Sx > 32) return fail("linear_attention: L,S must be in 1..32 (got %d,%d)", L, Sx);
-  rd::launch_linear_attention_fwd(q, k, v, out, N, L, Sx, H, ldq, ldk, ldv, ldo, eps, dtype, S(stream));
+  RD_NS(dtype, launch_linear_attention_fwd)(q, k, v, out, N, L, Sx, H, ldq, ldk, ldv, ldo, eps, RD_DT(dtype), S(stream));
   return done("rd_linear_attention_fwd");
 }
 int rd_linear_attention_bwd(const void* q, const void* k, const void* v, const void* dout, void* dq, void* dk, void* dv,
@@ -263,34 +278,34 @@ int rd_linear_attention_bwd(const void* q, const void* k, const void* v, const v
                             float eps, int32_t dtype, void* stream) {
   if (!q || !k || !v || !dout || !dq || !dk || !dv || !dt_ok(dtype)) return fail("linear_attention_bwd: bad args");
   if (L <= 0 || Sx <= 0 || L > 32 || Sx > 32) return fail("linear_attention: L,S must be in 1..32 (got %d,%d)", L, Sx);
-  rd::launch_linear_attention_bwd(q, k, v, dout, dq, dk, dv, N, L, Sx, H, ldq, ldk, ldv, ldo, eps, dtype, S(stream));
+  RD_NS(dtype, launch_linear_attention_bwd)(q, k, v, dout, dq, dk, dv, N, L, Sx, H, ldq, ldk, ldv, ldo, eps, RD_DT(dtype), S(stream));
   return done("rd_linear_attention_bwd");
 }
 
 int rd_maxpool_fwd(const void* x, void* out, uint8_t* arg, int32_t N, int32_t H, int32_t W, int32_t C, int32_t OH, int32_t OW,
                    int32_t k, int32_t s, int32_t p, int32_t dtype, void* stream) {
   if (!x || !out || !arg || !dt_ok(dtype) || k * k > 255) return fail("maxpool_fwd: bad args");
-  rd::launch_maxpool_fwd(x, out, arg, N, H, W, C, OH, OW, k, s, p, dtype, S(stream));
+  RD_NS(dtype, launch_maxpool_fwd)(x, out, arg, N, H, W, C, OH, OW, k, s, p, RD_DT(dtype), S(stream));
   return done("rd_maxpool_fwd");
 }
 int rd_maxpool_bwd(const void* dout, const uint8_t* arg, void* dx, int32_t N, int32_t H, int32_t W, int32_t C, int32_t OH,
                    int32_t OW, int32_t k, int32_t s, int32_t p, int32_t dtype, void* stream) {
   if (!dout || !dx || !arg || !dt_ok(dtype)) return fail("maxpool_bwd: bad args");
-  rd::launch_maxpool_bwd(dout, arg, dx, N, H, W, C, OH, OW, k, s, p, dtype, S(stream));
+  RD_NS(dtype, launch_maxpool_bwd)(dout, arg, dx, N, H, W, C, OH, OW, k, s, p, RD_DT(dtype), S(stream));
   return done("rd_maxpool_bwd");
 }
 int rd_roi_pool_fwd(const void* x, const float* rois, void* out, int32_t* argmax, int32_t R, int32_t N, int32_t H, int32_t W,
                     int32_t C, int32_t PH, int32_t PW, float scale, int32_t dtype, void* stream) {
   if (R == 0) return 0;
   if (!x || !rois || !out || !argmax || !dt_ok(dtype)) return fail("roi_pool_fwd: bad args");
-  rd::launch_roi_pool_fwd(x, rois, out, argmax, R, N, H, W, C, PH, PW, scale, dtype, S(stream));
+  RD_NS(dtype, launch_roi_pool_fwd)(x, rois, out, argmax, R, N, H, W, C, PH, PW, scale, RD_DT(dtype), S(stream));
   return done("rd_roi_pool_fwd");
 }
 int rd_roi_pool_bwd(const void* dout, const float* rois, const int32_t* argmax, float* dx, int32_t R, int32_t N, int32_t H,
                     int32_t W, int32_t C, int32_t PH, int32_t PW, int32_t dtype, void* stream) {
   if (!dx || !dt_ok(dtype)) return fail("roi_pool_bwd: bad args");
   if (R > 0 && (!dout || !rois || !argmax)) return fail("roi_pool_bwd: null pointer");
-  rd::launch_roi_pool_bwd(dout, rois, argmax, dx, R, N, H, W, C, PH, PW, dtype, S(stream));
+  RD_NS(dtype, launch_roi_pool_bwd)(dout, rois, argmax, dx, R, N, H, W, C, PH, PW, RD_DT(dtype), S(stream));
   return done("rd_roi_pool_bwd");
 }
 
@@ -300,7 +315,7 @@ int rd_roi_pool_bwd_tile(const void* dout, const float* rois, const int32_t* arg
   if (R > 0 && (!dout || !rois || !argmax)) return fail("roi_pool_bwd_tile: null pointer");
   if (C % 32) return fail("roi_pool_bwd_tile: C must be a multiple of 32");
   if (N <= 0 || H <= 0 || W <= 0 || PH <= 0 || PW <= 0 || (int64_t)H * W >= (1 << 24)) return fail("roi_pool_bwd_tile: bad sizes");
-  rd::launch_roi_pool_bwd_tile(dout, rois, argmax, dx, R, N, H, W, C, PH, PW, scale, dtype, S(stream));
+  RD_NS(dtype, launch_roi_pool_bwd_tile)(dout, rois, argmax, dx, R, N, H, W, C, PH, PW, scale, RD_DT(dtype), S(stream));
   return done("rd_roi_pool_bwd_tile");
 }
 int rd_roi_pool_bwd_gather(const void* dout, const float* rois, const int32_t* argmax, void* dx, int32_t R, int32_t N, int32_t H,
@@ -309,57 +324,57 @@ int rd_roi_pool_bwd_gather(const void* dout, const float* rois, const int32_t* a
   if (R > 0 && (!dout || !rois || !argmax)) return fail("roi_pool_bwd_gather: null pointer");
   if (C % (dtype == RD_F32 ? 4 : 8)) return fail("roi_pool_bwd_gather: C must be a multiple of the 16-byte vector");
   if (N <= 0 || H <= 0 || W <= 0 || PH <= 0 || PW <= 0) return fail("roi_pool_bwd_gather: bad sizes");
-  rd::launch_roi_pool_bwd_gather(dout, rois, argmax, dx, R, N, H, W, C, PH, PW, scale, dtype, S(stream));
+  RD_NS(dtype, launch_roi_pool_bwd_gather)(dout, rois, argmax, dx, R, N, H, W, C, PH, PW, scale, RD_DT(dtype), S(stream));
   return done("rd_roi_pool_bwd_gather");
 }
 int rd_cast(const void* src, void* dst, int64_t n, int32_t sd, int32_t dd, float scale, void* stream) {
   if (!src || !dst || !dt_ok(sd) || !dt_ok(dd)) return fail("cast: bad args");
   if (n == 0) return 0;
-  rd::launch_cast(src, dst, n, sd, dd, scale, S(stream));
+  RD_NS(((sd == RD_F16 || dd == RD_F16) ? RD_F16 : RD_F32), launch_cast)(src, dst, n, RD_DT(sd), RD_DT(dd), scale, S(stream));
   return done("rd_cast");
 }
 int rd_add(const void* a, const void* b, void* out, int64_t n, int32_t dtype, void* stream) {
   if (!a || !b || !out || !dt_ok(dtype)) return fail("add: bad args");
   if (n == 0) return 0;
-  rd::launch_add(a, b, out, n, dtype, S(stream));
+  RD_NS(dtype, launch_add)(a, b, out, n, RD_DT(dtype), S(stream));
   return done("rd_add");
 }
 int rd_nchw_to_nhwc(const void* src, void* dst, int32_t N, int32_t C, int32_t H, int32_t W, int32_t sd, int32_t dd, float scale,
                     void* stream) {
   if (!src || !dst || !dt_ok(sd) || !dt_ok(dd)) return fail("nchw_to_nhwc: bad args");
-  rd::launch_nchw_to_nhwc(src, dst, N, C, H, W, sd, dd, scale, S(stream));
+  RD_NS(((sd == RD_F16 || dd == RD_F16) ? RD_F16 : RD_F32), launch_nchw_to_nhwc)(src, dst, N, C, H, W, RD_DT(sd), RD_DT(dd), scale, S(stream));
   return done("rd_nchw_to_nhwc");
 }
 int rd_nhwc_to_nchw(const void* src, void* dst, int32_t N, int32_t C, int32_t H, int32_t W, int32_t sd, int32_t dd, void* stream) {
   if (!src || !dst || !dt_ok(sd) || !dt_ok(dd)) return fail("nhwc_to_nchw: bad args");
-  rd::launch_nhwc_to_nchw(src, dst, N, C, H, W, sd, dd, S(stream));
+  RD_NS(((sd == RD_F16 || dd == RD_F16) ? RD_F16 : RD_F32), launch_nhwc_to_nchw)(src, dst, N, C, H, W, RD_DT(sd), RD_DT(dd), S(stream));
   return done("rd_nhwc_to_nchw");
 }
 int rd_transpose_last2(const void* src, void* dst, int64_t B, int32_t R, int32_t Cc, int32_t dtype, void* stream) {
   if (!src || !dst || !dt_ok(dtype)) return fail("transpose_last2: bad args");
-  rd::launch_transpose_last2(src, dst, B, R, Cc, dtype, S(stream));
+  RD_NS(dtype, launch_transpose_last2)(src, dst, B, R, Cc, RD_DT(dtype), S(stream));
   return done("rd_transpose_last2");
 }
 int rd_concat2(const void* a, const void* b, void* out, int64_t rows, int32_t Ca, int32_t Cb, int32_t dtype, void* stream) {
   if (!a || !b || !out || !dt_ok(dtype)) return fail("concat2: bad args");
-  rd::launch_concat2(a, b, out, rows, Ca, Cb, dtype, S(stream));
+  RD_NS(dtype, launch_concat2)(a, b, out, rows, Ca, Cb, RD_DT(dtype), S(stream));
   return done("rd_concat2");
 }
 int rd_split2(const void* in, void* a, void* b, int64_t rows, int32_t Ca, int32_t Cb, int32_t dtype, void* stream) {
   if (!a || !b || !in || !dt_ok(dtype)) return fail("split2: bad args");
-  rd::launch_split2(in, a, b, rows, Ca, Cb, dtype, S(stream));
+  RD_NS(dtype, launch_split2)(in, a, b, rows, Ca, Cb, RD_DT(dtype), S(stream));
   return done("rd_split2");
 }
 int rd_upsample_nearest_fwd(const void* x, void* y, int32_t N, int32_t Hs, int32_t Ws, int32_t Hv, int32_t Wv, int32_t C,
                             int32_t dtype, void* stream) {
   if (!x || !y || !dt_ok(dtype)) return fail("upsample_nearest_fwd: bad args");
-  rd::launch_upsample_nearest_fwd(x, y, N, Hs, Ws, Hv, Wv, C, dtype, S(stream));
+  RD_NS(dtype, launch_upsample_nearest_fwd)(x, y, N, Hs, Ws, Hv, Wv, C, RD_DT(dtype), S(stream));
   return done("rd_upsample_nearest_fwd");
 }
 int rd_upsample_nearest_bwd(const void* dy, void* dx, int32_t N, int32_t Hs, int32_t Ws, int32_t Hv, int32_t Wv, int32_t C,
                             int32_t dtype, void* stream) {
   if (!dy || !dx || !dt_ok(dtype)) return fail("upsample_nearest_bwd: bad args");
-  rd::launch_upsample_nearest_bwd(dy, dx, N, Hs, Ws, Hv, Wv, C, dtype, S(stream));
+  RD_NS(dtype, launch_upsample_nearest_bwd)(dy, dx, N, Hs, Ws, Hv, Wv, C, RD_DT(dtype), S(stream));
   return done("rd_upsample_nearest_bwd");
 }
 
@@ -373,19 +388,19 @@ int32_t rd_bce_rows(int64_t n) { return rd::bce_rows(n); }
 int rd_bce_masked_fwd(const void* logits, const float* label, const float* valid, float pw, float* partial, float* loss,
                       float* sums, int64_t n, int32_t dtype, void* stream) {
   if (!logits || !label || !valid || !partial || !loss || !sums || !dt_ok(dtype)) return fail("bce_fwd: bad args");
-  rd::launch_bce_fwd(logits, label, valid, pw, partial, loss, sums, n, dtype, S(stream));
+  RD_NS(dtype, launch_bce_fwd)(logits, label, valid, pw, partial, loss, sums, n, RD_DT(dtype), S(stream));
   return done("rd_bce_masked_fwd");
 }
 int rd_bce_masked_bwd(const void* logits, const float* label, const float* valid, float pw, const float* sums, const float* dloss,
                       void* dlogits, int64_t n, int32_t dtype, void* stream) {
   if (!logits || !label || !valid || !sums || !dloss || !dlogits || !dt_ok(dtype)) return fail("bce_bwd: bad args");
-  rd::launch_bce_bwd(logits, label, valid, pw, sums, dloss, dlogits, n, dtype, S(stream));
+  RD_NS(dtype, launch_bce_bwd)(logits, label, valid, pw, sums, dloss, dlogits, n, RD_DT(dtype), S(stream));
   return done("rd_bce_masked_bwd");
 }
 int rd_sigmoid(const void* x, void* y, int64_t n, int32_t dtype, void* stream) {
   if (!x || !y || !dt_ok(dtype)) return fail("sigmoid: bad args");
   if (n == 0) return 0;
-  rd::launch_sigmoid(x, y, n, dtype, S(stream));
+  RD_NS(dtype, launch_sigmoid)(x, y, n, RD_DT(dtype), S(stream));
   return done("rd_sigmoid");
 }
 int rd_scatter_crops(const void* crops, const float* points, float* depth, float* response, int32_t Ncrop, int32_t PH, int32_t PW,
@@ -393,7 +408,7 @@ int rd_scatter_crops(const void* crops, const float* points, float* depth, float
   if (!depth || !response || !dt_ok(dtype)) return fail("scatter_crops: bad args");
   if (Ncrop > 0 && (!crops || !points)) return fail("scatter_crops: null pointer");
   if ((PH & 1) || (PW & 1)) return fail("scatter_crops: patch size must be even (reference uses patch//2 on both sides)");
-  rd::launch_scatter_crops(crops, points, depth, response, Ncrop, PH, PW, H, W, thr, dtype, S(stream));
+  RD_NS(dtype, launch_scatter_crops)(crops, points, depth, response, Ncrop, PH, PW, H, W, thr, RD_DT(dtype), S(stream));
   return done("rd_scatter_crops");
 }
 
@@ -429,7 +444,7 @@ int rd_augment_gray_partials(const float* image, int32_t B, int32_t H, int32_t W
 int rd_augment_image(const float* image, int32_t B, int32_t H, int32_t W, const float* params, const int64_t* partial, void* out_nhwc, int32_t dtype,
                      float scale, float shift, void* stream) {
   if (!image || !params || !partial || !out_nhwc || !dt_ok(dtype) || B <= 0 || H <= 0 || W <= 0) return fail("augment_image: bad args");
-  rd::launch_augment_image(image, B, H, W, params, (const long long*)partial, out_nhwc, dtype, scale, shift, S(stream));
+  RD_NS(dtype, launch_augment_image)(image, B, H, W, params, (const long long*)partial, out_nhwc, RD_DT(dtype), scale, shift, S(stream));
   return done("rd_augment_image");
 }
 int rd_augment_flip_labels(const float* labels_in, float* labels_out, int32_t B, int32_t K, int32_t ph, int32_t pw, float* boxes, const float* params,
@@ -470,46 +485,46 @@ int32_t rd_dw_rows(int64_t pixels, int32_t C) { return rd::dw_rows(pixels, C); }
 int rd_dwconv_fwd(const void* x, const float* w, void* y, int32_t N, int32_t H, int32_t W, int32_t C, int32_t OH, int32_t OW, int32_t k,
                   int32_t s, int32_t p, int32_t dtype, void* stream) {
   if (!x || !w || !y || !dt_ok(dtype) || k > 5 || k < 1) return fail("dwconv_fwd: bad args");
-  rd::launch_dwconv_fwd(x, w, y, N, H, W, C, OH, OW, k, s, p, dtype, S(stream));
+  RD_NS(dtype, launch_dwconv_fwd)(x, w, y, N, H, W, C, OH, OW, k, s, p, RD_DT(dtype), S(stream));
   return done("rd_dwconv_fwd");
 }
 int rd_dwconv_dgrad(const void* dy, const float* w, void* dx, int32_t N, int32_t H, int32_t W, int32_t C, int32_t OH, int32_t OW, int32_t k,
                     int32_t s, int32_t p, int32_t dtype, void* stream) {
   if (!dy || !w || !dx || !dt_ok(dtype) || k > 5 || k < 1) return fail("dwconv_dgrad: bad args");
-  rd::launch_dwconv_dgrad(dy, w, dx, N, H, W, C, OH, OW, k, s, p, dtype, S(stream));
+  RD_NS(dtype, launch_dwconv_dgrad)(dy, w, dx, N, H, W, C, OH, OW, k, s, p, RD_DT(dtype), S(stream));
   return done("rd_dwconv_dgrad");
 }
 int rd_dwconv_wgrad(const void* x, const void* dy, float* partial, float* dw, int32_t accumulate, int32_t N, int32_t H, int32_t W, int32_t C,
                     int32_t OH, int32_t OW, int32_t k, int32_t s, int32_t p, int32_t dtype, void* stream) {
   if (!x || !dy || !partial || !dw || !dt_ok(dtype) || k > 5 || k < 1) return fail("dwconv_wgrad: bad args");
-  rd::launch_dwconv_wgrad(x, dy, partial, dw, accumulate, N, H, W, C, OH, OW, k, s, p, dtype, S(stream));
+  RD_NS(dtype, launch_dwconv_wgrad)(x, dy, partial, dw, accumulate, N, H, W, C, OH, OW, k, s, p, RD_DT(dtype), S(stream));
   return done("rd_dwconv_wgrad");
 }
 int rd_bn_stats(const void* y, float* partial, int64_t pixels, int32_t C, int32_t dtype, void* stream) {
   if (!y || !partial || !dt_ok(dtype)) return fail("bn_stats: bad args");
-  rd::launch_bn_stats(y, partial, pixels, C, dtype, S(stream));
+  RD_NS(dtype, launch_bn_stats)(y, partial, pixels, C, RD_DT(dtype), S(stream));
   return done("rd_bn_stats");
 }
 int rd_bilinear_fwd(const void* x, void* y, int32_t N, int32_t H, int32_t W, int32_t C, int32_t OH, int32_t OW, int32_t align, int32_t dtype,
                     void* stream) {
   if (!x || !y || !dt_ok(dtype)) return fail("bilinear_fwd: bad args");
-  rd::launch_bilinear(x, y, N, H, W, C, OH, OW, align, 0, dtype, S(stream));
+  RD_NS(dtype, launch_bilinear)(x, y, N, H, W, C, OH, OW, align, 0, RD_DT(dtype), S(stream));
   return done("rd_bilinear_fwd");
 }
 int rd_bilinear_bwd(const void* dy, void* dx, int32_t N, int32_t H, int32_t W, int32_t C, int32_t OH, int32_t OW, int32_t align, int32_t dtype,
                     void* stream) {
   if (!dy || !dx || !dt_ok(dtype)) return fail("bilinear_bwd: bad args");
-  rd::launch_bilinear(dy, dx, N, H, W, C, OH, OW, align, 1, dtype, S(stream));
+  RD_NS(dtype, launch_bilinear)(dy, dx, N, H, W, C, OH, OW, align, 1, RD_DT(dtype), S(stream));
   return done("rd_bilinear_bwd");
 }
 int rd_sml_head_fwd(const void* out, const float* d, float* pred, int64_t n, float hi, float lo, int32_t dtype, void* stream) {
   if (!out || !d || !pred || !dt_ok(dtype)) return fail("sml_head_fwd: bad args");
-  rd::launch_sml_head_fwd(out, d, pred, n, hi, lo, dtype, S(stream));
+  RD_NS(dtype, launch_sml_head_fwd)(out, d, pred, n, hi, lo, RD_DT(dtype), S(stream));
   return done("rd_sml_head_fwd");
 }
 int rd_sml_head_bwd(const void* out, const float* d, const float* dpred, void* dout, int64_t n, float hi, float lo, int32_t dtype, void* stream) {
   if (!out || !d || !dpred || !dout || !dt_ok(dtype)) return fail("sml_head_bwd: bad args");
-  rd::launch_sml_head_bwd(out, d, dpred, dout, n, hi, lo, dtype, S(stream));
+  RD_NS(dtype, launch_sml_head_bwd)(out, d, dpred, dout, n, hi, lo, RD_DT(dtype), S(stream));
   return done("rd_sml_head_bwd");
 }
 int rd_reciprocal(const float* x, const float* dy, float* out, int64_t n, void* stream) {

@@ -7,6 +7,14 @@
 // array into scratch (or LDS via promote-alloca) -- seen as private_segment 48..80 bytes / +16 KB LDS on the conv kernels.
 #define RD_INLINE_LAMBDA __attribute__((always_inline))
 
+// Precision variant.  Every translation unit is compiled twice: as is (16-bit activations = bf16) and with -DRD_HALF_F16 (16-bit activations =
+// IEEE fp16: conversions and MFMA opcodes change, nothing else).  The second build lives in namespace rd_f16 (the token `rd` is renamed), so
+// both variants link into one library and rd_api.cpp picks the namespace from the dtype code (RD_BF16 / RD_F16).  The element type keeps
+// its name bf16_t in both builds: it is "the 16-bit activation type of this build".
+#ifdef RD_HALF_F16
+#define rd rd_f16
+#endif
+
 // Launch-time sized LDS (hipLaunchKernelGGL's shmem argument).  The host emulator runs blocks one after the other: a static arena of the
 // CU's full 160 KiB stands in.
 #ifdef RD_EMU
@@ -27,6 +35,24 @@ struct bf16_t { unsigned short v; };
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
 
+#ifdef RD_HALF_F16
+// ---- fp16 build: v_cvt_f32_f16 / v_cvt_f16_f32 (round to nearest even); the host emulator uses the compiler's _Float16
+__device__ __forceinline__ float bf16_to_f32(unsigned short h) {
+  _Float16 x; __builtin_memcpy(&x, &h, 2);
+  return (float)x;
+}
+__device__ __forceinline__ unsigned short f32_to_bf16(float f) {
+  const _Float16 x = (_Float16)f;
+  unsigned short h; __builtin_memcpy(&h, &x, 2);
+  return h;
+}
+__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
+  return (unsigned)f32_to_bf16(lo) | ((unsigned)f32_to_bf16(hi) << 16);
+}
+// low / high 16-bit element of a 32-bit word -> float
+__device__ __forceinline__ float half_lo_f32(unsigned w) { return bf16_to_f32((unsigned short)(w & 0xffffu)); }
+__device__ __forceinline__ float half_hi_f32(unsigned w) { return bf16_to_f32((unsigned short)(w >> 16)); }
+#else
 __device__ __forceinline__ float bf16_to_f32(unsigned short h) {
   return __uint_as_float(((unsigned)h) << 16);
 }
@@ -57,6 +83,10 @@ __device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
   return u;
 #endif
 }
+// low / high 16-bit element of a 32-bit word -> float (bf16: a shift / a mask)
+__device__ __forceinline__ float half_lo_f32(unsigned w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float half_hi_f32(unsigned w) { return __uint_as_float(w & 0xffff0000u); }
+#endif
 
 template <typename T> struct Elem;
 template <> struct Elem<float> {
@@ -79,8 +109,8 @@ __device__ __forceinline__ void ld4(const float* p, float (&o)[4]) {
 }
 __device__ __forceinline__ void ld4(const bf16_t* p, float (&o)[4]) {
   uint2 v = *reinterpret_cast<const uint2*>(p);
-  o[0] = __uint_as_float(v.x << 16); o[1] = __uint_as_float(v.x & 0xffff0000u);
-  o[2] = __uint_as_float(v.y << 16); o[3] = __uint_as_float(v.y & 0xffff0000u);
+  o[0] = half_lo_f32(v.x); o[1] = half_hi_f32(v.x);
+  o[2] = half_lo_f32(v.y); o[3] = half_hi_f32(v.y);
 }
 __device__ __forceinline__ void st4(float* p, const float (&o)[4]) {
   *reinterpret_cast<float4*>(p) = make_float4(o[0], o[1], o[2], o[3]);
@@ -97,10 +127,10 @@ __device__ __forceinline__ void ldv(const float* p, float (&o)[4]) { ld4(p, o); 
 __device__ __forceinline__ void stv(float* p, const float (&o)[4]) { st4(p, o); }
 __device__ __forceinline__ void ldv(const bf16_t* p, float (&o)[8]) {
   uint4 v = *reinterpret_cast<const uint4*>(p);
-  o[0] = __uint_as_float(v.x << 16); o[1] = __uint_as_float(v.x & 0xffff0000u);
-  o[2] = __uint_as_float(v.y << 16); o[3] = __uint_as_float(v.y & 0xffff0000u);
-  o[4] = __uint_as_float(v.z << 16); o[5] = __uint_as_float(v.z & 0xffff0000u);
-  o[6] = __uint_as_float(v.w << 16); o[7] = __uint_as_float(v.w & 0xffff0000u);
+  o[0] = half_lo_f32(v.x); o[1] = half_hi_f32(v.x);
+  o[2] = half_lo_f32(v.y); o[3] = half_hi_f32(v.y);
+  o[4] = half_lo_f32(v.z); o[5] = half_hi_f32(v.z);
+  o[6] = half_lo_f32(v.w); o[7] = half_hi_f32(v.w);
 }
 __device__ __forceinline__ void stv(bf16_t* p, const float (&o)[8]) {
   uint4 v;
@@ -122,10 +152,20 @@ __device__ __forceinline__ f32x4 mfma_16x16x4_f32(float a, float b, f32x4 c) {
 #endif
 }
 __device__ __forceinline__ f32x4 mfma_16x16x32_bf16(s16x8 a, s16x8 b, f32x4 c) {
+#ifdef RD_HALF_F16
+  typedef _Float16 rd_h8 __attribute__((ext_vector_type(8)));
+#ifdef RD_EMU
+  return emu_mfma_f32_16x16x32_f16(a, b, c);
+#else
+  rd_h8 ha, hb; __builtin_memcpy(&ha, &a, 16); __builtin_memcpy(&hb, &b, 16);
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(ha, hb, c, 0, 0, 0);     // same lane maps as the bf16 form (C/D layout is dtype independent)
+#endif
+#else
 #ifdef RD_EMU
   return emu_mfma_f32_16x16x32_bf16(a, b, c);
 #else
   return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+#endif
 #endif
 }
 
@@ -134,10 +174,20 @@ __device__ __forceinline__ f32x4 mfma_16x16x32_bf16(s16x8 a, s16x8 b, f32x4 c) {
 // in register v = 0..15.  Twice the FLOPs of 16x16x32 per instruction at the same operand bytes per lane.
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 __device__ __forceinline__ f32x16 mfma_32x32x16_bf16(s16x8 a, s16x8 b, f32x16 c) {
+#ifdef RD_HALF_F16
+  typedef _Float16 rd_h8 __attribute__((ext_vector_type(8)));
+#ifdef RD_EMU
+  return emu_mfma_f32_32x32x16_f16(a, b, c);
+#else
+  rd_h8 ha, hb; __builtin_memcpy(&ha, &a, 16); __builtin_memcpy(&hb, &b, 16);
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(ha, hb, c, 0, 0, 0);
+#endif
+#else
 #ifdef RD_EMU
   return emu_mfma_f32_32x32x16_bf16(a, b, c);
 #else
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+#endif
 #endif
 }
 

@@ -46,8 +46,8 @@ __device__ __forceinline__ void round_store4(float* d, const float (&x)[4], floa
 __device__ __forceinline__ void round_store4(bf16_t* d, const float (&x)[4], float (&xr)[4]) {
   uint2 u;
   u.x = pack_bf16x2(x[0], x[1]); u.y = pack_bf16x2(x[2], x[3]);
-  xr[0] = __uint_as_float(u.x << 16); xr[1] = __uint_as_float(u.x & 0xffff0000u);
-  xr[2] = __uint_as_float(u.y << 16); xr[3] = __uint_as_float(u.y & 0xffff0000u);
+  xr[0] = half_lo_f32(u.x); xr[1] = half_hi_f32(u.x);
+  xr[2] = half_lo_f32(u.y); xr[3] = half_hi_f32(u.y);
   *reinterpret_cast<uint2*>(d) = u;
 }
 

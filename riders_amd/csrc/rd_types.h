@@ -1,0 +1,39 @@
+// Argument structures shared by BOTH precision builds of the kernels (namespace rd = bf16 / fp32, namespace rd_f16 = fp16) and by
+// rd_api.cpp.  They live in their own namespace so that the `rd` -> `rd_f16` renaming of the fp16 build does not duplicate the types.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace rdt {
+
+struct ConvArgs {
+  const void* src1; const void* src2; const void* w; const float* bias;
+  void* dst1; void* dst2; float* stats;
+  int N, Hin, Win, C1, C2, H1, W1, Cout, KH, KW, stride, pad, dil, OH, OW, act, D1;
+  float slope, scale_h, scale_w;
+  int M, K, Kpad, ups;
+};
+
+struct WgradArgs {
+  const void* src1; const void* src2; const void* dy; float* slab;
+  int N, Hin, Win, C1, C2, H1, W1, Cout, KH, KW, stride, pad, OH, OW;
+  float scale_h, scale_w;
+  int M, K, ups, nsplit, rows_per_split;
+};
+
+struct LwgGemm { const void* x1; const void* x2; const void* dy; float* slab; int M, C1, C2, Cout, nsplit, rows_per_split; };
+
+struct LwgReduce { const float* slab; float* dw; int64_t elems; int nsplit, accumulate; };
+
+static const int LWG_MAX_ITEMS = 64, LWG_MAX_REDS = 96;   // 64 x 56 B and 96 x 32 B: both under the 4 KiB kernel-argument limit
+
+struct LoftrW { const void *wq, *wk, *wv, *wm, *w0, *w2; const float *g1, *b1, *g2, *b2; };
+
+struct LoftrSaved { void *q, *k, *v, *att, *mpre, *msg, *hid, *m2pre; float* stats; };
+
+struct LoftrGrads {
+  const void* dout; void *dm2pre, *dhid, *dmpre, *datt, *dq, *dk, *dv, *dx, *dsrc;
+  float *lnp1, *lnp2, *dg1, *db1, *dg2, *db2; int accumulate, pad_;
+};
+
+}  // namespace rdt

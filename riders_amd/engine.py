@@ -17,10 +17,10 @@ import weakref
 import torch
 
 from . import _lib
-from ._lib import ACT_LRELU, ACT_NONE, ACT_RELU, ACT_RELU6, RD_BF16, RD_F32, ConvDesc
+from ._lib import ACT_LRELU, ACT_NONE, ACT_RELU, ACT_RELU6, RD_BF16, RD_F16, RD_F32, ConvDesc
 
-_TORCH_DT = {RD_F32: torch.float32, RD_BF16: torch.bfloat16}
-_RD_DT = {torch.float32: RD_F32, torch.bfloat16: RD_BF16}
+_TORCH_DT = {RD_F32: torch.float32, RD_BF16: torch.bfloat16, RD_F16: torch.float16}
+_RD_DT = {torch.float32: RD_F32, torch.bfloat16: RD_BF16, torch.float16: RD_F16}
 
 _state = {"dtype": RD_F32, "tape": None, "defer_wgrad": True, "fused_loftr": True, "deterministic_roi_pool": False, "roi_tile_min_blocks": 256}
 
@@ -55,8 +55,10 @@ def set_defer_wgrad(flag):
 
 
 def set_compute_dtype(dt):
-    """Activation storage dtype of subsequently executed regions: 'fp32' or 'bf16' (accumulation is always fp32)."""
-    _state["dtype"] = {"fp32": RD_F32, "bf16": RD_BF16, RD_F32: RD_F32, RD_BF16: RD_BF16}[dt]
+    """Activation storage dtype of subsequently executed regions: 'fp32', 'bf16' or 'fp16' (accumulation is always fp32).
+    fp16 (BASELINE.json configs[4]) has a narrow exponent: train with a static loss scale (rcnet_main / sml_main `loss_scale`, folded back
+    into Adam's grad_scale) -- the loss is a mean over millions of pixels and its raw gradients underflow fp16."""
+    _state["dtype"] = {"fp32": RD_F32, "bf16": RD_BF16, "fp16": RD_F16, RD_F32: RD_F32, RD_BF16: RD_BF16, RD_F16: RD_F16}[dt]
 
 
 def compute_dtype():
@@ -544,11 +546,16 @@ def refresh_packed():
     if not live:
         return
     sig = tuple((w.data_ptr(), buf.data_ptr(), mode, dt, cpad) for w, buf, mode, dt, cpad in live)
+    halves = {dt for _, _, _, dt, _ in live if dt != RD_F32}
+    if len(halves) > 1:
+        raise RuntimeError("cached packed weights mix bf16 and fp16 operands: call engine.clear_caches() when switching the compute dtype")
+    half = halves.pop() if halves else RD_BF16
     if _pack_table.get("sig") != sig:
         items = (_lib.PackItem * len(live))()
         for it, (w, buf, mode, dt, cpad) in zip(items, live):
             cout, cin, kh, kw = w.shape if w.dim() == 4 else (w.shape[0], w.shape[1], 1, 1)
-            it.w, it.packed, it.Cout, it.Cin, it.KH, it.KW, it.mode, it.dtype = w.data_ptr(), buf.data_ptr(), cout, (cpad or cin), kh, kw, mode, dt
+            # inside the table the item dtype is 0 (fp32) or 1 (the 16-bit type named by `half`, rd_conv_pack_weights_batch_half)
+            it.w, it.packed, it.Cout, it.Cin, it.KH, it.KW, it.mode, it.dtype = w.data_ptr(), buf.data_ptr(), cout, (cpad or cin), kh, kw, mode, (0 if dt == RD_F32 else 1)
             it.Cin_src = cin if cpad else 0
         host = torch.frombuffer(bytearray(bytes(items)), dtype=torch.uint8)
         _pack_table["dev"] = host.to(live[0][0].device)
@@ -556,7 +563,7 @@ def refresh_packed():
         _pack_table["n"] = len(live)
         _pack_table["keep"] = [b for _, b, _, _, _ in live]
     w0 = live[0][0]
-    _chk(L().rd_conv_pack_weights_batch(_p(_pack_table["dev"]), _pack_table["n"], _stream(w0)), "rd_conv_pack_weights_batch")
+    _chk(L().rd_conv_pack_weights_batch_half(_p(_pack_table["dev"]), _pack_table["n"], half, _stream(w0)), "rd_conv_pack_weights_batch_half")
 
 
 # ------------------------------------------------------------------------------------------ conv block

@@ -57,7 +57,8 @@ class FlatAdam(object):
         self.steps = [0] * len(params)          # per-parameter step count (torch keeps `step` per parameter)
         self._touched = [False] * len(params)   # slot written by a backward kernel since zero_grad()
         self._ever = [False] * len(params)      # slot has received a gradient at least once (torch: has optimizer state)
-        self.grad_scale = 1.0
+        self.grad_scale = 1.0      # 1 / world size, set by parallel.GradientAllReducer (the all-reduce sums)
+        self.loss_scale = 1.0      # static loss scale of the fp16 mode: gradients arrive multiplied by it and are divided here
         engine.set_param_grad_allocator(self._grad_view)
 
     # kept for callers that read the global step (all parameters that train share it)
@@ -108,7 +109,7 @@ class FlatAdam(object):
         rc = engine._tb("optimizer", 28 * (end - start), lambda: engine.L().rd_adam_step(
             engine._p(self.flat_param[sl]), engine._p(self.flat_grad[sl]), engine._p(self.exp_avg[sl]), engine._p(self.exp_avg_sq[sl]), end - start,
             ctypes.c_float(g['lr']), ctypes.c_float(g['betas'][0]), ctypes.c_float(g['betas'][1]), ctypes.c_float(g['eps']),
-            ctypes.c_float(g['weight_decay']), step, ctypes.c_float(self.grad_scale), engine._stream(self.flat_param)), "adam")
+            ctypes.c_float(g['weight_decay']), step, ctypes.c_float(self.grad_scale / self.loss_scale), engine._stream(self.flat_param)), "adam")
         engine._chk(rc, "rd_adam_step")
 
     def step(self):

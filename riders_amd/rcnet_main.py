@@ -73,14 +73,20 @@ def prepare_batch(batch):
     return image, radar_point, rois, gt
 
 
-def train_step(model, optimizer, batch, cfg=ZJU_CONFIG, reducer=None):
+def scaled_backward(loss, optimizer, loss_scale):
+    """loss.backward() with the static loss scale of the fp16 mode (the seed gradient is the scale; Adam divides it out again)."""
+    optimizer.loss_scale = float(loss_scale)
+    if loss_scale == 1.0:
+        loss.backward()
+    else:
+        loss.backward(torch.full_like(loss, float(loss_scale)))
+
+
+def train_step(model, optimizer, batch, cfg=ZJU_CONFIG, reducer=None, loss_scale=1.0):
     """One optimisation step (rcnet_main.py:294-359).  Returns the loss as a device tensor (no host sync)."""
-    image, radar_point, rois, gt = prepare_batch(batch)
-    label, valid = engine.rcnet_labels(gt, radar_point, cfg['max_distance_correspondence'], cfg['set_invalid_to_negative_class'])
-    logits = model.forward(image, radar_point, rois, return_logits=True)
-    loss, _ = model.compute_loss(logits=logits, ground_truth=label, validity_map=valid, w_positive_class=cfg['w_positive_class'])
+    loss = forward_loss(model, batch, cfg)
     optimizer.zero_grad()
-    loss.backward()
+    scaled_backward(loss, optimizer, loss_scale)
     if reducer is not None:
         reducer.reduce()
     optimizer.step()
@@ -166,12 +172,12 @@ def forward_loss(model, batch, cfg=ZJU_CONFIG):
     return loss
 
 
-def compute_gradients(model, optimizer, batch, cfg=ZJU_CONFIG):
+def compute_gradients(model, optimizer, batch, cfg=ZJU_CONFIG, loss_scale=1.0):
     """Forward + loss + backward of one step (everything of rcnet_main.py:294-358 except the optimizer) through torch.autograd,
     as an unchanged training script would run it."""
     loss = forward_loss(model, batch, cfg)
     optimizer.zero_grad()
-    loss.backward()
+    scaled_backward(loss, optimizer, loss_scale)
     return loss
 
 
@@ -180,6 +186,7 @@ def staged_gradients(fwd_loss, optimizer, on_stage=None, loss_scale=1.0):
     stage mark and calls `on_stage(tag)`, which is where GraphedStep ends one hipGraph capture and begins the next.  The stage hooks
     registered with the engine (the all-reducer's) fire at the same marks."""
     optimizer.zero_grad()
+    optimizer.loss_scale = float(loss_scale)
     st = engine.StepTape()
     loss = st.forward(fwd_loss)
     st.seed(loss, loss_scale)

@@ -113,15 +113,16 @@ def forward_loss(model, batch, cfg=ZJU_SML_CONFIG, outlier=None):
     return loss
 
 
-def compute_gradients(model, optimizer, batch, cfg=ZJU_SML_CONFIG, outlier=None):
+def compute_gradients(model, optimizer, batch, cfg=ZJU_SML_CONFIG, outlier=None, loss_scale=1.0):
+    from .rcnet_main import scaled_backward
     loss = forward_loss(model, batch, cfg, outlier)
     optimizer.zero_grad()
-    loss.backward()
+    scaled_backward(loss, optimizer, loss_scale)
     return loss
 
 
-def train_step(model, optimizer, batch, cfg=ZJU_SML_CONFIG, reducer=None, outlier=None):
-    loss = compute_gradients(model, optimizer, batch, cfg, outlier)
+def train_step(model, optimizer, batch, cfg=ZJU_SML_CONFIG, reducer=None, outlier=None, loss_scale=1.0):
+    loss = compute_gradients(model, optimizer, batch, cfg, outlier, loss_scale)
     if reducer is not None:
         reducer.reduce()
     optimizer.step()

@@ -24,26 +24,27 @@ def build(verbose=False, extra=()):
     hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     hdrs += [os.path.join(HERE, "include", "hip", "hip_runtime.h"), os.path.join(ROOT, "include", "riders_hip.h")]
     hm = max(os.path.getmtime(h) for h in hdrs)
-    jobs = []
-    for f in srcs:
-        src, obj = os.path.join(CSRC, f), os.path.join(OUT, f + ".o")
-        if not os.path.exists(obj) or os.path.getmtime(obj) < max(hm, os.path.getmtime(src)):
-            jobs.append((src, obj))
+    jobs, objs = [], []
+    for f in srcs:        # every kernel unit twice: bf16 build and fp16 build (-DRD_HALF_F16, namespace rd_f16), as riders_amd/build.py
+        for suffix, flags in ((".o", []), (".f16.o", ["-DRD_HALF_F16"])) if f.endswith(".hip") else ((".o", []),):
+            src, obj = os.path.join(CSRC, f), os.path.join(OUT, f + suffix)
+            objs.append(obj)
+            if not os.path.exists(obj) or os.path.getmtime(obj) < max(hm, os.path.getmtime(src)):
+                jobs.append((src, obj, flags))
 
     def cc(job):
-        src, obj = job
-        return job, subprocess.run([CXX] + FLAGS + list(extra) + ["-c", src, "-o", obj], capture_output=True, text=True)
+        src, obj, flags = job
+        return job, subprocess.run([CXX] + FLAGS + list(extra) + flags + ["-c", src, "-o", obj], capture_output=True, text=True)
 
     if jobs:
         with ThreadPoolExecutor(max_workers=6) as ex:
-            for (src, obj), r in ex.map(cc, jobs):
+            for (src, obj, flags), r in ex.map(cc, jobs):
                 if verbose:
                     print("[emu-cc] %s" % os.path.basename(src), flush=True)
                 if r.returncode != 0:
                     sys.stderr.write(r.stdout + r.stderr)
                     raise RuntimeError("emulator build failed on %s" % src)
     if jobs or not os.path.exists(LIB):
-        objs = [os.path.join(OUT, f + ".o") for f in srcs]
         r = subprocess.run([CXX, "-shared", "-fPIC", "-o", LIB] + objs, capture_output=True, text=True)
         if r.returncode != 0:
             sys.stderr.write(r.stdout + r.stderr)

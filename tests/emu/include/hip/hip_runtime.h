@@ -329,6 +329,49 @@ static inline emu_f32x16 emu_mfma_f32_32x32x16_bf16(emu_s16x8 a, emu_s16x8 b, em
   emu::wave_sync();
   return c;
 }
+static inline float emu_f16_to_f32(unsigned short h) { _Float16 x; memcpy(&x, &h, 2); return (float)x; }
+static inline emu_f32x4 emu_mfma_f32_16x16x32_f16(emu_s16x8 a, emu_s16x8 b, emu_f32x4 c) {
+  emu::Wave& w = emu::my_wave();
+  int l = emu::lane_id();
+  memcpy(w.buf[0][l], &a, 16);
+  memcpy(w.buf[1][l], &b, 16);
+  emu::wave_sync();
+  int j = l & 15;
+  for (int r = 0; r < 4; r++) {
+    int i = (l >> 4) * 4 + r;
+    float acc = c[r];
+    for (int g = 0; g < 4; g++) {
+      unsigned short av[8], bv[8];
+      memcpy(av, w.buf[0][i + 16 * g], 16);
+      memcpy(bv, w.buf[1][j + 16 * g], 16);
+      for (int e = 0; e < 8; e++) acc += emu_f16_to_f32(av[e]) * emu_f16_to_f32(bv[e]);
+    }
+    c[r] = acc;
+  }
+  emu::wave_sync();
+  return c;
+}
+static inline emu_f32x16 emu_mfma_f32_32x32x16_f16(emu_s16x8 a, emu_s16x8 b, emu_f32x16 c) {
+  emu::Wave& w = emu::my_wave();
+  int l = emu::lane_id();
+  memcpy(w.buf[0][l], &a, 16);
+  memcpy(w.buf[1][l], &b, 16);
+  emu::wave_sync();
+  int j = l & 31;
+  for (int v = 0; v < 16; v++) {
+    int i = (v & 3) + 8 * (v >> 2) + 4 * (l >> 5);
+    float acc = c[v];
+    for (int g = 0; g < 2; g++) {
+      unsigned short av[8], bv[8];
+      memcpy(av, w.buf[0][i + 32 * g], 16);
+      memcpy(bv, w.buf[1][j + 32 * g], 16);
+      for (int e = 0; e < 8; e++) acc += emu_f16_to_f32(av[e]) * emu_f16_to_f32(bv[e]);
+    }
+    c[v] = acc;
+  }
+  emu::wave_sync();
+  return c;
+}
 // global_load_lds_dwordx4: lane l's 16 bytes land at (wave-uniform) base + 16 l; executed immediately (the model has no asynchrony)
 static inline void emu_global_load_lds16(const void* gsrc, void* lds_wave_base) {
   memcpy((char*)lds_wave_base + 16 * emu::lane_id(), gsrc, 16);

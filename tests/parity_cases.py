@@ -27,23 +27,30 @@ def q(x):
     """Test inputs / upstream gradients made bf16-representable while the bf16-mode emulation of the oracle is on (both sides then
     start from identical values; the HIP path casts its inputs to bf16 anyway)."""
     from oracle.precision import Precision
-    return x.to(torch.bfloat16).to(torch.float32) if Precision.bf16 else x
+    return x.to(Precision.dtype).to(torch.float32) if Precision.bf16 else x
 
 
 class bf16_mode:
-    """HIP path in bf16 AND the oracle rounding at the same tensors (oracle/precision.py): the comparison then isolates the kernels
-    from the precision loss of bf16 storage itself."""
+    """HIP path in a 16-bit mode ('bf16' or 'fp16') AND the oracle rounding at the same tensors (oracle/precision.py): the comparison then
+    isolates the kernels from the precision loss of 16-bit storage itself."""
+    def __init__(self, mode="bf16"):
+        self.mode = mode
+
     def __enter__(self):
         from oracle.precision import Precision
         from riders_amd import engine
-        engine.set_compute_dtype("bf16")
+        engine.clear_caches()
+        engine.set_compute_dtype(self.mode)
         Precision.bf16 = True
+        Precision.dtype = torch.float16 if self.mode == "fp16" else torch.bfloat16
 
     def __exit__(self, *a):
         from oracle.precision import Precision
         from riders_amd import engine
         engine.set_compute_dtype("fp32")
+        engine.clear_caches()
         Precision.bf16 = False
+        Precision.dtype = torch.bfloat16
 
 
 def load(name):
@@ -792,7 +799,7 @@ def rcnet_fullsize_bf16_case(dev, tol_logits=6e-2, tol_grad=0.12):
         assert err <= tol_grad and cos >= 0.99, "bf16 %s gradient: relative L2 error %.3e, cosine %.5f" % (k, err, cos)
 
 
-def bf16_exact_conv_case(dev, cin=16, cout=16, k=3, s=1, H=9, W=7, N=2, up=None, cin2=0, report=False):
+def bf16_exact_conv_case(dev, cin=16, cout=16, k=3, s=1, H=9, W=7, N=2, up=None, cin2=0, report=False, half=torch.bfloat16):
     """bf16 data path check that does not depend on rounding: with inputs / weights / upstream gradients in {-1,0,1}
     every product and partial sum is exactly representable, so the bf16 kernels must reproduce the fp32 oracle
     bit for bit (forward, data gradient, weight gradient), including the concat / upsample gather variants."""
@@ -811,14 +818,14 @@ def bf16_exact_conv_case(dev, cin=16, cout=16, k=3, s=1, H=9, W=7, N=2, up=None,
     ref = F.conv2d(xin, wr, None, stride=s, padding=k // 2)
     gy = t(rs.randint(-1, 2, tuple(ref.shape)).astype(np.float32))
     (ref * gy).sum().backward()
-    a = x1.to(dev).permute(0, 2, 3, 1).contiguous().to(torch.bfloat16)
-    b = x2.to(dev).permute(0, 2, 3, 1).contiguous().to(torch.bfloat16) if cin2 else None
+    a = x1.to(dev).permute(0, 2, 3, 1).contiguous().to(half)
+    b = x2.to(dev).permute(0, 2, 3, 1).contiguous().to(half) if cin2 else None
     tape = engine.Tape(); tape.mark(a)
     if cin2:
         tape.mark(b)
     with engine._active(tape):
         out = engine.conv_block(a, w, x2=b, stride=s, pad=k // 2, up=None if up is None else up[1])
-        tape.grads[id(out)] = gy.to(dev).permute(0, 2, 3, 1).contiguous().to(torch.bfloat16)
+        tape.grads[id(out)] = gy.to(dev).permute(0, 2, 3, 1).contiguous().to(half)
         tape.backward()
     if report:      # stress tooling: which of (forward, dgrad, wgrad) matched
         return (torch.equal(out.float().permute(0, 3, 1, 2).cpu(), ref.detach()),
@@ -887,3 +894,108 @@ def roi_pool_tile_deterministic_case(dev):
         assert torch.equal(grads[0], grads[1]) and torch.equal(grads[0], grads[2]), "parity-class roi_pool backward is not reproducible"
     finally:
         engine.set_roi_tile_min_blocks(256)
+
+
+
+def fp16_cases(dev):
+    """X1 (BASELINE.json configs[4] quotes fp16): the fp16 build of the kernels (same sources compiled with -DRD_HALF_F16: conversions and
+    MFMA opcodes differ).  (1) fp32 -> fp16 conversion is round-to-nearest-even, bit-exact against torch; (2) the data path is exact on
+    integer data for every convolution family (generic, patch, narrow persistent, 1x1 direct, stem, transpose-read and grouped weight
+    gradients, upsample / concat gathers); (3) layer- and block-level results match the oracle with the same rounding points
+    (max-norm 4e-3 = 4 fp16 ulp); (4) a small end-to-end RC-Net step against fp32: logits within 1e-2."""
+    from riders_amd import engine
+    h = torch.float16
+    g = torch.Generator().manual_seed(6)
+    bits = torch.randint(-2**31, 2**31 - 1, (1 << 15,), dtype=torch.int64, generator=g).to(torch.int32)
+    x = bits.view(torch.float32)
+    x = x[torch.isfinite(x) & (x.abs() < 65000)]
+    ties = torch.tensor([1.0 + (2 * i + 1) * 2.0 ** -11 for i in range(256)], dtype=torch.float32)
+    edge = torch.tensor([0.0, -0.0, 65504.0, -65504.0, 65519.9, 6.1e-5, 5.96e-8, 2.98e-8, 2.99e-8, 1e-9, 1.0, -1.0, 0.333333], dtype=torch.float32)
+    x = torch.cat([x, ties, -ties, edge])
+    x = x[: x.numel() - x.numel() % 8]
+    out = engine.cast(x.to(dev), torch.float16)
+    got, want = out.cpu(), x.to(torch.float16)
+    bad = (got != want).nonzero().flatten()      # value comparison: the conversion maps -0.0 to +0.0, every other bit pattern is identical
+    assert bad.numel() == 0, "fp32 -> fp16 rounding differs from round-to-nearest-even at %d values, e.g. %s -> %s (torch %s)" % (
+        bad.numel(), x[bad[:4]].tolist(), got[bad[:4]].tolist(), want[bad[:4]].tolist())
+    nz = want != 0
+    assert torch.equal(got[nz].view(torch.int16), want[nz].view(torch.int16))
+    back = engine.cast(out, torch.float32)
+    assert torch.equal(back.cpu(), x.to(torch.float16).float())
+    for c in (dict(), dict(cin=32, cout=64, k=3, s=2, H=10, W=13), dict(cin=8, cout=1, k=3, s=1, H=6, W=5),
+              dict(cin=16, cout=16, k=3, s=1, N=1, up=((4, 3), (9, 6)), cin2=8), dict(cin=3, cout=32, k=7, s=2, H=14, W=12, N=1),
+              dict(cin=128, cout=128, k=1, s=1, H=5, W=1, N=2), dict(cin=64, cout=128, k=3, s=1, H=40, W=36, N=2),
+              dict(cin=64, cout=32, k=3, s=1, H=9, W=17, N=1), dict(cin=96, cout=40, k=3, s=1, N=1, up=((5, 7), (15, 14)), cin2=32),
+              dict(cin=128, cout=256, k=1, s=1, H=24, W=21, N=1, cin2=128), dict(cin=24, cout=144, k=1, s=1, H=13, W=11, N=2)):
+        bf16_exact_conv_case(dev, half=h, **c)
+    with force_patch_conv():
+        bf16_exact_conv_case(dev, half=h, cin=64, cout=64, k=3, s=1, H=9, W=19, N=1)
+        bf16_exact_conv_case(dev, half=h, cin=16, cout=16, k=3, s=1, N=1, up=((4, 3), (9, 17)), cin2=16)
+        bf16_exact_conv_case(dev, half=h, cin=32, cout=64, k=3, s=1, H=12, W=17, N=1)
+    with bf16_mode("fp16"):
+        conv_case(dev, dict(cin=16, cout=16, k=3, s=1, H=40, W=50, N=4, bn=True), tol=4e-3)
+        conv_case(dev, dict(cin=64, cout=32, k=3, s=1, H=30, W=25, N=4, bn=True), tol=4e-3)
+        conv_case(dev, dict(cin=3, cout=32, k=7, s=2, H=40, W=36, N=2, bn=True, no_input_grad=True), tol=4e-3)
+        decoder_block_case(dev, cin=64, cskip=32, cout=32, hs=(15, 12), hv=(30, 25), N=4, tol=4e-3)
+        resnet_block_case(dev, cin=64, cout=128, stride=2, tol=4e-3)
+    engine.set_compute_dtype("fp16")
+    try:
+        linear_attention_case(dev, tol=5e-3)
+        transformer_case(dev, tol=2e-1)      # max-norm incl. weight gradients through two fused layers, no loss scale here: the bound of the bf16 mode
+        rcnet_e2e_case(dev, tol=1e-2)
+    finally:
+        engine.set_compute_dtype("fp32")
+        engine.clear_caches()
+
+
+
+def config4_case(dev):
+    """BASELINE.json configs[4] geometry: 3x512x1024 frames in fp16.  RC-Net: padded 752x1124, K = 30, patch 240x100 (B = 2 here, 8 per GPU
+    in the config); SML: 512x1024 (B = 2).  fp16 against the fp32 HIP path on identical weights / inputs: RC-Net logits within 2e-2
+    relative L2 and the loss within 1e-2; one loss-scaled training step (scale 16384, divided out by Adam) leaves every parameter finite
+    and its unscaled gradient points where the fp32 gradient points (cosine > 0.98); SML eval-mode prediction within 1e-2 relative L2."""
+    from riders_amd import engine, rcnet_main, sml_main
+    from riders_amd.optim import FlatAdam
+    cfg = rcnet_main.ZJU_CONFIG
+    batch = rcnet_main.synthetic_batch(2, 512, 1024, cfg, seed=44, device=dev)
+    res = {}
+    for mode in ("fp32", "fp16"):
+        engine.set_compute_dtype(mode); engine.clear_caches()
+        try:
+            torch.manual_seed(0)
+            model = rcnet_main.build_model(dev, cfg); model.train()
+            opt = FlatAdam(model.parameters(), lr=cfg['learning_rate'])
+            p0 = opt.flat_param.clone()
+            image, pts, rois, gt = rcnet_main.prepare_batch(batch)
+            assert tuple(image.shape[-2:]) == (752, 1124)
+            with torch.no_grad():
+                logits = model.forward(image, pts, rois).float().cpu()
+            loss = rcnet_main.train_step(model, opt, batch, cfg, loss_scale=16384.0 if mode == "fp16" else 1.0)
+            assert bool(torch.isfinite(opt.flat_param).all()) and bool(torch.isfinite(opt.flat_grad).all())
+            res[mode] = (logits, float(loss), (opt.flat_grad / opt.loss_scale).cpu())
+        finally:
+            engine.set_compute_dtype("fp32"); engine.clear_caches(); engine.set_param_grad_allocator(None)
+    (l32, loss32, d32), (l16, loss16, d16) = res["fp32"], res["fp16"]
+    close_l2(l16, l32, 2e-2, "configs[4] RC-Net logits fp16 vs fp32")
+    assert abs(loss16 - loss32) <= 1e-2 * abs(loss32), (loss16, loss32)
+    cos = float(torch.dot(d16, d32) / (d16.norm() * d32.norm()))
+    assert cos > 0.98, "fp16 gradient cosine %.4f" % cos
+    sb = sml_main.synthetic_batch(2, 512, 1024, seed=45, device=dev)
+    preds = {}
+    for mode in ("fp32", "fp16"):
+        engine.set_compute_dtype(mode); engine.clear_caches()
+        try:
+            torch.manual_seed(0)
+            m = sml_main.build_model(dev)
+            m.eval()
+            hw = sml_main.net_size(512, 1024)
+            with torch.no_grad():
+                x, d, _ = sml_main.prepare_inputs(sb[0], sb[1], sb[2], sb[5], hw)
+                preds[mode] = m.forward(x, d).float().cpu()
+            m.train()
+            opt = FlatAdam(m.parameters(), lr=1e-4)
+            loss = sml_main.train_step(m, opt, sb, outlier=sml_main.make_outlier_removal(), loss_scale=1024.0 if mode == "fp16" else 1.0)
+            assert np.isfinite(float(loss)) and bool(torch.isfinite(opt.flat_param).all())
+        finally:
+            engine.set_compute_dtype("fp32"); engine.clear_caches(); engine.set_param_grad_allocator(None)
+    close_l2(preds["fp16"], preds["fp32"], 1e-2, "configs[4] SML eval prediction fp16 vs fp32")

@@ -160,6 +160,18 @@ def test_projection_scatter(emu):
     P.projection_case(emu)
 
 
+def test_fp16_build_exact(emu):
+    """fp16 build of the kernels on the emulator (conversion + a few exact convolution families; the full list runs on the GPU)."""
+    import torch
+    h = torch.float16
+    P.bf16_exact_conv_case(emu, half=h)
+    P.bf16_exact_conv_case(emu, half=h, cin=16, cout=16, k=3, s=1, N=1, up=((4, 3), (9, 6)), cin2=8)
+    P.bf16_exact_conv_case(emu, half=h, cin=64, cout=32, k=3, s=1, H=9, W=17, N=1)
+    P.bf16_exact_conv_case(emu, half=h, cin=24, cout=144, k=1, s=1, H=13, W=11, N=2)
+    with P.bf16_mode("fp16"):
+        P.conv_case(emu, dict(cin=16, cout=16, k=3, s=1, H=12, W=10, N=2, bn=True), tol=4e-3)
+
+
 def test_inference_driver(emu):
     P.inference_driver_case(emu)
 

@@ -97,6 +97,14 @@ def test_projection_scatter(gpu):
     P.projection_case(gpu)
 
 
+def test_fp16_build(gpu):
+    P.fp16_cases(gpu)
+
+
+def test_config4_fp16_high_res(gpu):
+    P.config4_case(gpu)
+
+
 def test_inference_driver(gpu):
     P.inference_driver_case(gpu)
 

@@ -58,7 +58,7 @@ def main():
     cfgkey = "unknown"
     if line is not None:
         m = re.search(r"batch (\d+)/GPU.*?(\d+)x(\d+) (?:image|frames)", line["config"]["workload"])
-        cfgkey = "%s_b%s_%sx%s_%s" % (wl, m.group(1), m.group(2), m.group(3), {"f32": "fp32", "bf16": "bf16"}[line["dtype"]])
+        cfgkey = "%s_b%s_%sx%s_%s" % (wl, m.group(1), m.group(2), m.group(3), {"f32": "fp32", "bf16": "bf16", "f16": "fp16"}[line["dtype"]])
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     path = os.path.join(root, "profiles", "r02_traffic.json")
     db = json.load(open(path)) if os.path.exists(path) else {}
