@@ -686,7 +686,7 @@ def decoder_case(dev, tag="small", tol=TOL):
         close(p.grad, g64[k], max(4 * tol, 3 * cond(k)), "g5 grad " + k)
 
 
-def rcnet_e2e_case(dev, tol=TOL):
+def rcnet_e2e_case(dev, tol=TOL, loss_scale=1.0):
     """Full RCNetModel step vs the REFERENCE's own logits / loss / gradients (fixture g6)."""
     from riders_amd import engine
     from riders_amd.rcnet_model import RCNetModel
@@ -713,14 +713,15 @@ def rcnet_e2e_case(dev, tol=TOL):
     close(logits, g["logits"], tol, "g6 logits")
     loss, _ = m.compute_loss(logits, label, valid, 2.5)
     assert abs(float(loss) - float(g["loss"][0])) < tol * abs(float(g["loss"][0])), (float(loss), float(g["loss"][0]))
-    loss.backward()
+    loss.backward() if loss_scale == 1.0 else loss.backward(torch.full_like(loss, float(loss_scale)))   # fp16: static loss scale, divided out below
     for pref, mod in (("enc.", m.encoder), ("dec.", m.decoder)):
         for k, p in mod.named_parameters():
             if (pref + k + "|none") in g:
                 assert p.grad is None, k
                 continue
             rn = float(g[pref + k + "|norm"][0])
-            assert abs(float(p.grad.norm()) - rn) < 5 * tol * max(rn, 1e-4), (k, float(p.grad.norm()), rn)
+            gn = float(p.grad.norm()) / loss_scale
+            assert abs(gn - rn) < 5 * tol * max(rn, 1e-4), (k, gn, rn)
 
 
 def _module_grads(model):
@@ -902,7 +903,7 @@ def fp16_cases(dev):
     MFMA opcodes differ).  (1) fp32 -> fp16 conversion is round-to-nearest-even, bit-exact against torch; (2) the data path is exact on
     integer data for every convolution family (generic, patch, narrow persistent, 1x1 direct, stem, transpose-read and grouped weight
     gradients, upsample / concat gathers); (3) layer- and block-level results match the oracle with the same rounding points
-    (max-norm 4e-3 = 4 fp16 ulp); (4) a small end-to-end RC-Net step against fp32: logits within 1e-2."""
+    (max-norm 4e-3 = 4 fp16 ulp); (4) a small end-to-end RC-Net step (loss scale 4096) against the reference fixture: logits within 2e-2, gradient norms within 10 %."""
     from riders_amd import engine
     h = torch.float16
     g = torch.Generator().manual_seed(6)
@@ -942,7 +943,7 @@ def fp16_cases(dev):
     try:
         linear_attention_case(dev, tol=5e-3)
         transformer_case(dev, tol=2e-1)      # max-norm incl. weight gradients through two fused layers, no loss scale here: the bound of the bf16 mode
-        rcnet_e2e_case(dev, tol=1e-2)
+        rcnet_e2e_case(dev, tol=2e-2, loss_scale=4096.0)
     finally:
         engine.set_compute_dtype("fp32")
         engine.clear_caches()
