@@ -150,7 +150,7 @@ def run_workload(kind, args, dev, world, rank, steps, warmup):
         batch = rcnet_main.synthetic_batch(batch_n, h, w, cfg, seed=1234 + rank, device=dev)
     model.train()
     opt = FlatAdam(model.parameters(), lr=cfg['learning_rate'])
-    reducer = GradientAllReducer(opt, stages=stages) if world > 1 else None
+    reducer = GradientAllReducer(opt, stages=stages) if (world > 1 or args.force_ddp) else None
     if reducer is not None:
         reducer.broadcast_parameters(0)
 
@@ -253,6 +253,8 @@ def main():
     ap.add_argument("--sml-height", type=int, default=256)
     ap.add_argument("--sml-width", type=int, default=512)
     ap.add_argument("--eager", action="store_true", help="do not capture forward+backward into hipGraphs")
+    ap.add_argument("--force-ddp", action="store_true", help="run the N > 1 code path (RCCL process group, stage-bucketed all-reduce) on however "
+                                                              "many ranks there are, including one: a functional check of that path on a 1-GPU box")
     ap.add_argument("--detail", default=None, help="write a per-launch-shape timing table to this file")
     args = ap.parse_args()
 
@@ -263,10 +265,12 @@ def main():
         raise RuntimeError("bench.py needs a GPU: the riders_amd hot path has no CPU fallback")
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
-    if world > 1:
+    ddp = world > 1 or args.force_ddp
+    if ddp:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group(backend="nccl", device_id=dev, rank=rank, world_size=world)
 
     head = run_workload(args.workload, args, dev, world, rank, args.steps, args.warmup)
     sml = None
@@ -299,7 +303,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline and is_rc:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if ddp:
         import torch.distributed as dist
         dist.destroy_process_group()
 

@@ -112,6 +112,18 @@ __device__ __forceinline__ void ld4(const bf16_t* p, float (&o)[4]) {
   o[0] = half_lo_f32(v.x); o[1] = half_hi_f32(v.x);
   o[2] = half_lo_f32(v.y); o[3] = half_hi_f32(v.y);
 }
+// guarded forms: the address is always dereferenced (callers clamp it into the tensor) and the result is zero unless `ok` -- no branch,
+// so a group of such loads issues back to back instead of one branch + one wait each
+__device__ __forceinline__ void ld4z(const float* p, bool ok, float (&o)[4]) {
+  float4 v = *reinterpret_cast<const float4*>(p);
+  o[0] = ok ? v.x : 0.f; o[1] = ok ? v.y : 0.f; o[2] = ok ? v.z : 0.f; o[3] = ok ? v.w : 0.f;
+}
+__device__ __forceinline__ void ld4z(const bf16_t* p, bool ok, float (&o)[4]) {
+  uint2 v = *reinterpret_cast<const uint2*>(p);
+  v.x = ok ? v.x : 0u; v.y = ok ? v.y : 0u;
+  o[0] = half_lo_f32(v.x); o[1] = half_hi_f32(v.x);
+  o[2] = half_lo_f32(v.y); o[3] = half_hi_f32(v.y);
+}
 __device__ __forceinline__ void st4(float* p, const float (&o)[4]) {
   *reinterpret_cast<float4*>(p) = make_float4(o[0], o[1], o[2], o[3]);
 }

@@ -105,114 +105,55 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_kernel(const T* __restrict__
 }
 
 
-// ---- channel-vectorised depthwise kernels (C % 4 == 0): thread = (4 channels, pixel lane); the k*k x 4 weights of the
-// thread's channels live in registers, every tap is one 16-byte (fp32) / 8-byte (bf16) load ------------------------------------
-template <typename T, int K, int MODE>  // MODE 0: forward, 1: data gradient
-__global__ __launch_bounds__(256) void dwconv_vec_kernel(const T* __restrict__ src, const float* __restrict__ w, T* __restrict__ dst, int N,
-                                                         int H, int W, int C, int OH, int OW, int s, int p, int C4B, int PL, int PPB) {
-  const int t = threadIdx.x, cl = t % C4B, pl = t / C4B;
-  const int c = (blockIdx.y * C4B + cl) * 4;
-  if (c >= C) return;
-  float wr[K * K][4];
-#pragma unroll
-  for (int j = 0; j < K * K; j++)
-#pragma unroll
-    for (int e = 0; e < 4; e++) wr[j][e] = w[(c + e) * K * K + j];
-  const int DH = MODE ? H : OH, DW = MODE ? W : OW;           // destination spatial size
-  const int64_t M = (int64_t)N * DH * DW;
-  const int64_t mbeg = (int64_t)blockIdx.x * PPB, mend = mbeg + PPB < M ? mbeg + PPB : M;
-  for (int64_t m = mbeg + pl; m < mend; m += PL) {
-    int dw_ = (int)(m % DW); int64_t q = m / DW; int dh = (int)(q % DH); int n = (int)(q / DH);
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int kh = 0; kh < K; kh++) {
-      int sh;
-      if (MODE == 0) { sh = dh * s - p + kh; if ((unsigned)sh >= (unsigned)H) continue; }
-      else { int u = dh + p - kh; if (u < 0 || (u % s)) continue; sh = u / s; if (sh >= OH) continue; }
-#pragma unroll
-      for (int kw = 0; kw < K; kw++) {
-        int sw;
-        if (MODE == 0) { sw = dw_ * s - p + kw; if ((unsigned)sw >= (unsigned)W) continue; }
-        else { int u = dw_ + p - kw; if (u < 0 || (u % s)) continue; sw = u / s; if (sw >= OW) continue; }
-        const int SH = MODE ? OH : H, SW = MODE ? OW : W;
-        float v[4];
-        ld4(src + (((int64_t)n * SH + sh) * SW + sw) * C + c, v);
-#pragma unroll
-        for (int e = 0; e < 4; e++) acc[e] += v[e] * wr[kh * K + kw][e];
-      }
-    }
-    st4(dst + m * C + c, acc);
-  }
-}
-
-template <typename T, int K>
-__global__ __launch_bounds__(256) void dwconv_wgrad_vec_kernel(const T* __restrict__ x, const T* __restrict__ dy, float* __restrict__ partial,
-                                                               int N, int H, int W, int C, int OH, int OW, int s, int p, int C4B, int PL) {
-  __shared__ float red[256][4];
-  const int t = threadIdx.x, cl = t % C4B, pl = t / C4B;
-  const int c = (blockIdx.y * C4B + cl) * 4;
-  const bool cv = c < C;
-  const int64_t pixels = (int64_t)N * OH * OW;
-  const int64_t per = cdiv(pixels, gridDim.x);
-  const int64_t pbeg = (int64_t)blockIdx.x * per, pend = pbeg + per < pixels ? pbeg + per : pixels;
-  float acc[K * K][4];
-#pragma unroll
-  for (int j = 0; j < K * K; j++)
-#pragma unroll
-    for (int e = 0; e < 4; e++) acc[j][e] = 0.f;
-  if (cv) {
-    for (int64_t m = pbeg + pl; m < pend; m += PL) {
-      int ow = (int)(m % OW); int64_t q = m / OW; int oh = (int)(q % OH); int n = (int)(q / OH);
-      float g[4];
-      ld4(dy + m * C + c, g);
-#pragma unroll
-      for (int kh = 0; kh < K; kh++) {
-        int ih = oh * s - p + kh;
-        if ((unsigned)ih >= (unsigned)H) continue;
-#pragma unroll
-        for (int kw = 0; kw < K; kw++) {
-          int iw = ow * s - p + kw;
-          if ((unsigned)iw >= (unsigned)W) continue;
-          float v[4];
-          ld4(x + (((int64_t)n * H + ih) * W + iw) * C + c, v);
-#pragma unroll
-          for (int e = 0; e < 4; e++) acc[kh * K + kw][e] += g[e] * v[e];
-        }
-      }
-    }
-  }
-#pragma unroll
-  for (int j = 0; j < K * K; j++) {
-#pragma unroll
-    for (int e = 0; e < 4; e++) red[t][e] = acc[j][e];
-    __syncthreads();
-    if (pl == 0 && cv) {
-#pragma unroll
-      for (int e = 0; e < 4; e++) {
-        float sacc = 0.f;
-        for (int q = 0; q < PL; q++) sacc += red[q * C4B + cl][e];
-        partial[((int64_t)blockIdx.x * C + c + e) * (K * K) + j] = sacc;
-      }
-    }
-    __syncthreads();
-  }
-}
-
-
-// ---- stride-1 forms with a sliding register window: a thread produces DWR = 4 consecutive outputs of a row, so a filter row costs
-// DWR + K - 1 loads instead of DWR * K (5x5: 10 loads per output instead of 25; the per-tap form above is bound by L1 load issue). ----
+// ---- channel-vectorised depthwise kernels (C % 4 == 0, k in {3, 5}) ---------------------------------------------------------------------
+// thread = (quad of 4 channels, pixel lane); the k*k x 4 weights of the quad live in registers; a thread produces DWR = 4 consecutive
+// outputs of a row from a sliding register window, so a filter row costs (DWR-1)*S + K loads for DWR outputs.
+// Every load is UNCONDITIONAL (clamped address, zero selected afterwards): a bounds `if` around each load made the compiler emit one
+// branch + one s_waitcnt per load, i.e. 40 serialised memory latencies per unit; without them a row's (or a unit's) loads issue together.
+// Block geometry: QB quads x PL pixel lanes <= 256 threads with QB = ceil(C/4 / nchunk) chosen for the fewest idle threads (C/4 is
+// 36..348 in EfficientNet-Lite3: a power-of-two QB idled up to 44 % of the lanes).
 static constexpr int DWR = 4;
-template <typename T, int K, int MODE>  // MODE 0: forward, 1: data gradient (stride 1)
-__global__ __launch_bounds__(256) void dwconv_run_kernel(const T* __restrict__ src, const float* __restrict__ w, T* __restrict__ dst, int N,
-                                                         int H, int W, int C, int OH, int OW, int p, int C4B, int PL, int PPB) {
-  const int t = threadIdx.x, cl = t % C4B, pl = t / C4B;
-  const int c = (blockIdx.y * C4B + cl) * 4;
-  if (c >= C) return;
+
+// The block's weights are a contiguous run of w (QB quads x 4 channels x k*k floats): staged into LDS with coalesced 16-byte loads, then
+// each thread picks up its quad (k*k x 4 registers).  Reading them straight from global memory is a 400-byte-strided gather -- 64 cache
+// lines per instruction -- and cost more than the convolution itself on the small late-stage maps.  STR (floats per quad in LDS) keeps the
+// 16-byte LDS reads of 16 consecutive lanes on distinct banks.
+static constexpr int DW_QMAX = 64;
+template <int K> struct DwLds { static constexpr int STR = K == 5 ? 108 : 4 * K * K; };
+template <int K>
+__device__ __forceinline__ void dw_stage_weights(const float* __restrict__ w, int c0, int nq, float* lds, int cl, bool active,
+                                                 float (&wr)[K * K][4]) {
+  constexpr int QF = 4 * K * K, STR = DwLds<K>::STR;
+  const float* src = w + (int64_t)c0 * K * K;
+  if ((reinterpret_cast<uintptr_t>(src) & 15) == 0) {
+    for (int i = threadIdx.x; i < nq * (QF / 4); i += blockDim.x) {
+      const float4 v = reinterpret_cast<const float4*>(src)[i];
+      const int qd = (i * 4) / QF, off = i * 4 - qd * QF;
+      *reinterpret_cast<float4*>(lds + qd * STR + off) = v;
+    }
+  } else {
+    for (int i = threadIdx.x; i < nq * QF; i += blockDim.x) { const int qd = i / QF; lds[qd * STR + i - qd * QF] = src[i]; }
+  }
+  __syncthreads();
+  if (active) {
+#pragma unroll
+    for (int j = 0; j < K * K; j++)
+#pragma unroll
+      for (int e = 0; e < 4; e++) wr[j][e] = lds[cl * STR + e * K * K + j];
+  }
+}
+
+template <typename T, int K, int S, int MODE>  // MODE 0: forward (stride S); MODE 1: data gradient of a stride-1 layer (S == 1)
+__global__ __launch_bounds__(256) void dw_run_kernel(const T* __restrict__ src, const float* __restrict__ w, T* __restrict__ dst, int N,
+                                                     int H, int W, int C, int OH, int OW, int p, int QB, int PL, int PPB) {
+  __shared__ __attribute__((aligned(16))) float wl[DW_QMAX * DwLds<K>::STR];
+  const int t = threadIdx.x, pl = t / QB, cl = t - pl * QB;
+  const int c = (blockIdx.y * QB + cl) * 4;
+  const bool active = pl < PL && c < C;
   float wr[K * K][4];
-#pragma unroll
-  for (int j = 0; j < K * K; j++)
-#pragma unroll
-    for (int e = 0; e < 4; e++) wr[j][e] = w[(c + e) * K * K + j];
+  dw_stage_weights<K>(w, blockIdx.y * QB * 4, min(QB, C / 4 - (int)blockIdx.y * QB), wl, cl, active, wr);
+  if (!active) return;
+  constexpr int WIN = (DWR - 1) * S + K;
   const int DH = MODE ? H : OH, DW = MODE ? W : OW;           // destination size
   const int SH = MODE ? OH : H, SW = MODE ? OW : W;           // source size
   const int runs = (DW + DWR - 1) / DWR;
@@ -221,7 +162,14 @@ __global__ __launch_bounds__(256) void dwconv_run_kernel(const T* __restrict__ s
   for (int64_t m = mbeg + pl; m < mend; m += PL) {
     const int rw = (int)(m % runs); int64_t q = m / runs; const int dh = (int)(q % DH); const int n = (int)(q / DH);
     const int dw0 = rw * DWR;
-    const int cbase = MODE ? dw0 + p - (K - 1) : dw0 - p;     // source column of window slot 0
+    const int cbase = MODE ? dw0 + p - (K - 1) : dw0 * S - p;     // source column of window slot 0
+    int coff[WIN]; bool cok[WIN];
+#pragma unroll
+    for (int j = 0; j < WIN; j++) {
+      const int sw = cbase + j;
+      cok[j] = (unsigned)sw < (unsigned)SW;
+      coff[j] = (sw < 0 ? 0 : (sw >= SW ? SW - 1 : sw)) * C;
+    }
     float acc[DWR][4];
 #pragma unroll
     for (int r = 0; r < DWR; r++)
@@ -229,22 +177,18 @@ __global__ __launch_bounds__(256) void dwconv_run_kernel(const T* __restrict__ s
       for (int e = 0; e < 4; e++) acc[r][e] = 0.f;
 #pragma unroll
     for (int kh = 0; kh < K; kh++) {
-      const int sh = MODE ? dh + p - kh : dh - p + kh;
-      if ((unsigned)sh >= (unsigned)SH) continue;
-      const T* row = src + (((int64_t)n * SH + sh) * SW) * C + c;
-      float v[DWR + K - 1][4];
+      const int sh = MODE ? dh + p - kh : dh * S - p + kh;
+      const bool rok = (unsigned)sh < (unsigned)SH;
+      const T* row = src + (((int64_t)n * SH + (sh < 0 ? 0 : (sh >= SH ? SH - 1 : sh))) * SW) * C + c;
+      float v[WIN][4];
 #pragma unroll
-      for (int j = 0; j < DWR + K - 1; j++) {
-        const int sw = cbase + j;
-        if ((unsigned)sw < (unsigned)SW) ld4(row + (int64_t)sw * C, v[j]);
-        else { v[j][0] = 0.f; v[j][1] = 0.f; v[j][2] = 0.f; v[j][3] = 0.f; }
-      }
+      for (int j = 0; j < WIN; j++) ld4z(row + coff[j], rok && cok[j], v[j]);
 #pragma unroll
       for (int kw = 0; kw < K; kw++)
 #pragma unroll
         for (int r = 0; r < DWR; r++)
 #pragma unroll
-          for (int e = 0; e < 4; e++) acc[r][e] += v[MODE ? r + K - 1 - kw : r + kw][e] * wr[kh * K + kw][e];
+          for (int e = 0; e < 4; e++) acc[r][e] += v[MODE ? r + K - 1 - kw : r * S + kw][e] * wr[kh * K + kw][e];
     }
 #pragma unroll
     for (int r = 0; r < DWR; r++)
@@ -252,13 +196,81 @@ __global__ __launch_bounds__(256) void dwconv_run_kernel(const T* __restrict__ s
   }
 }
 
-template <typename T, int K>
-__global__ __launch_bounds__(256) void dwconv_wgrad_run_kernel(const T* __restrict__ x, const T* __restrict__ dy, float* __restrict__ partial,
-                                                               int N, int H, int W, int C, int OH, int OW, int p, int C4B, int PL) {
-  __shared__ float red[256][4];
-  const int t = threadIdx.x, cl = t % C4B, pl = t / C4B;
-  const int c = (blockIdx.y * C4B + cl) * 4;
-  const bool cv = c < C;
+// data gradient of a stride-2 layer: dx[ih, iw] = sum over (kh, kw) with (ih + p - kh), (iw + p - kw) even of dy[.. / 2] * w[kh, kw].
+// A run of 4 dx columns starts at a multiple of 4, so which kw pairs with which dy column is a compile-time pattern given the parity PP
+// of the pad; the row parity (ih + p) & 1 picks one of two fully unrolled bodies.
+template <typename T, int K, int PP, int PH>
+__device__ __forceinline__ void dw_dgrad2_rows(const T* __restrict__ dy, const float (&wr)[K * K][4], int n, int dh, int p, int OH, int OW, int C,
+                                               int c, const int* coff, const bool* cok, float (&acc)[DWR][4]) {
+  constexpr int NJ = (K + 2 - PP) / 2 + 1;
+#pragma unroll
+  for (int kh = PH; kh < K; kh += 2) {
+    const int oh = (dh + p - kh) >> 1;            // (dh + p - kh) is even here; negative -> negative
+    const bool rok = (unsigned)oh < (unsigned)OH;
+    const T* row = dy + (((int64_t)n * OH + (oh < 0 ? 0 : (oh >= OH ? OH - 1 : oh))) * OW) * C + c;
+    float v[NJ][4];
+#pragma unroll
+    for (int j = 0; j < NJ; j++) ld4z(row + coff[j], rok && cok[j], v[j]);
+#pragma unroll
+    for (int r = 0; r < DWR; r++)
+#pragma unroll
+      for (int j = 0; j < NJ; j++) {
+        const int kw = r + (K - 1 - PP) - 2 * j;
+        if (kw >= 0 && kw < K) {
+#pragma unroll
+          for (int e = 0; e < 4; e++) acc[r][e] += v[j][e] * wr[kh * K + kw][e];
+        }
+      }
+  }
+}
+template <typename T, int K, int PP>
+__global__ __launch_bounds__(256) void dw_dgrad2_kernel(const T* __restrict__ dy, const float* __restrict__ w, T* __restrict__ dx, int N,
+                                                        int H, int W, int C, int OH, int OW, int p, int QB, int PL, int PPB) {
+  __shared__ __attribute__((aligned(16))) float wl[DW_QMAX * DwLds<K>::STR];
+  const int t = threadIdx.x, pl = t / QB, cl = t - pl * QB;
+  const int c = (blockIdx.y * QB + cl) * 4;
+  const bool active = pl < PL && c < C;
+  float wr[K * K][4];
+  dw_stage_weights<K>(w, blockIdx.y * QB * 4, min(QB, C / 4 - (int)blockIdx.y * QB), wl, cl, active, wr);
+  if (!active) return;
+  constexpr int NJ = (K + 2 - PP) / 2 + 1;
+  const int runs = (W + DWR - 1) / DWR;
+  const int64_t M = (int64_t)N * H * runs;
+  const int64_t mbeg = (int64_t)blockIdx.x * PPB, mend = mbeg + PPB < M ? mbeg + PPB : M;
+  for (int64_t m = mbeg + pl; m < mend; m += PL) {
+    const int rw = (int)(m % runs); int64_t q = m / runs; const int dh = (int)(q % H); const int n = (int)(q / H);
+    const int iw0 = rw * DWR;
+    const int obase = (iw0 + p - K + 1 + PP) >> 1;     // first dy column that reaches this run (the numerator is even)
+    int coff[NJ]; bool cok[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; j++) {
+      const int ow = obase + j;
+      cok[j] = (unsigned)ow < (unsigned)OW;
+      coff[j] = (ow < 0 ? 0 : (ow >= OW ? OW - 1 : ow)) * C;
+    }
+    float acc[DWR][4];
+#pragma unroll
+    for (int r = 0; r < DWR; r++)
+#pragma unroll
+      for (int e = 0; e < 4; e++) acc[r][e] = 0.f;
+    if ((dh + p) & 1) dw_dgrad2_rows<T, K, PP, 1>(dy, wr, n, dh, p, OH, OW, C, c, coff, cok, acc);
+    else dw_dgrad2_rows<T, K, PP, 0>(dy, wr, n, dh, p, OH, OW, C, c, coff, cok, acc);
+#pragma unroll
+    for (int r = 0; r < DWR; r++)
+      if (iw0 + r < W) st4(dx + (((int64_t)n * H + dh) * W + iw0 + r) * C + c, acc[r]);
+  }
+}
+
+// weight gradient: thread accumulates the k*k x 4 taps of its quad over its units; the PL pixel lanes of a block are summed through LDS
+// one filter row at a time and written as partial[block][tap][C] (16-byte stores, coalesced over channels).
+template <typename T, int K, int S>
+__global__ __launch_bounds__(256) void dw_wgrad_run_kernel(const T* __restrict__ x, const T* __restrict__ dy, float* __restrict__ partial,
+                                                           int N, int H, int W, int C, int OH, int OW, int p, int QB, int PL) {
+  __shared__ float red[256][K][4];
+  const int t = threadIdx.x, pl = t / QB, cl = t - pl * QB;
+  const int c = (blockIdx.y * QB + cl) * 4;
+  const bool cv = pl < PL && c < C;
+  constexpr int WIN = (DWR - 1) * S + K;
   const int runs = (OW + DWR - 1) / DWR;
   const int64_t units = (int64_t)N * OH * runs;
   const int64_t per = cdiv(units, gridDim.x);
@@ -273,46 +285,71 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_run_kernel(const T* __restri
       const int rw = (int)(m % runs); int64_t q = m / runs; const int oh = (int)(q % OH); const int n = (int)(q / OH);
       const int ow0 = rw * DWR;
       float g[DWR][4];
+      const T* grow = dy + (((int64_t)n * OH + oh) * OW) * C + c;
 #pragma unroll
-      for (int r = 0; r < DWR; r++) {
-        if (ow0 + r < OW) ld4(dy + (((int64_t)n * OH + oh) * OW + ow0 + r) * C + c, g[r]);
-        else { g[r][0] = 0.f; g[r][1] = 0.f; g[r][2] = 0.f; g[r][3] = 0.f; }
+      for (int r = 0; r < DWR; r++) ld4z(grow + (int64_t)(ow0 + r < OW ? ow0 + r : OW - 1) * C, ow0 + r < OW, g[r]);
+      const int cbase = ow0 * S - p;
+      int coff[WIN]; bool cok[WIN];
+#pragma unroll
+      for (int j = 0; j < WIN; j++) {
+        const int iw = cbase + j;
+        cok[j] = (unsigned)iw < (unsigned)W;
+        coff[j] = (iw < 0 ? 0 : (iw >= W ? W - 1 : iw)) * C;
       }
 #pragma unroll
       for (int kh = 0; kh < K; kh++) {
-        const int ih = oh - p + kh;
-        if ((unsigned)ih >= (unsigned)H) continue;
-        const T* row = x + (((int64_t)n * H + ih) * W) * C + c;
-        float v[DWR + K - 1][4];
+        const int ih = oh * S - p + kh;
+        const bool rok = (unsigned)ih < (unsigned)H;
+        const T* row = x + (((int64_t)n * H + (ih < 0 ? 0 : (ih >= H ? H - 1 : ih))) * W) * C + c;
+        float v[WIN][4];
 #pragma unroll
-        for (int j = 0; j < DWR + K - 1; j++) {
-          const int iw = ow0 - p + j;
-          if ((unsigned)iw < (unsigned)W) ld4(row + (int64_t)iw * C, v[j]);
-          else { v[j][0] = 0.f; v[j][1] = 0.f; v[j][2] = 0.f; v[j][3] = 0.f; }
-        }
+        for (int j = 0; j < WIN; j++) ld4z(row + coff[j], rok && cok[j], v[j]);
 #pragma unroll
         for (int kw = 0; kw < K; kw++)
 #pragma unroll
           for (int r = 0; r < DWR; r++)
 #pragma unroll
-            for (int e = 0; e < 4; e++) acc[kh * K + kw][e] += g[r][e] * v[r + kw][e];
+            for (int e = 0; e < 4; e++) acc[kh * K + kw][e] += g[r][e] * v[r * S + kw][e];
       }
     }
   }
 #pragma unroll
-  for (int j = 0; j < K * K; j++) {
+  for (int kh = 0; kh < K; kh++) {
 #pragma unroll
-    for (int e = 0; e < 4; e++) red[t][e] = acc[j][e];
+    for (int kw = 0; kw < K; kw++)
+#pragma unroll
+      for (int e = 0; e < 4; e++) red[t][kw][e] = acc[kh * K + kw][e];
     __syncthreads();
     if (pl == 0 && cv) {
 #pragma unroll
-      for (int e = 0; e < 4; e++) {
-        float sacc = 0.f;
-        for (int q = 0; q < PL; q++) sacc += red[q * C4B + cl][e];
-        partial[((int64_t)blockIdx.x * C + c + e) * (K * K) + j] = sacc;
+      for (int kw = 0; kw < K; kw++) {
+        float s4[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int q = 0; q < PL; q++)
+#pragma unroll
+          for (int e = 0; e < 4; e++) s4[e] += red[q * QB + cl][kw][e];
+        st4(partial + ((int64_t)blockIdx.x * (K * K) + kh * K + kw) * C + c, s4);
       }
     }
     __syncthreads();
+  }
+}
+
+// partial[rows][taps][C] -> dw[c][tap]: 64 elements x 4 row groups per block, rows read coalesced over (tap, c)
+__global__ __launch_bounds__(256) void dw_wgrad_finalize_tc_kernel(const float* __restrict__ partial, int rows, int C, int KK, float* dw,
+                                                                   int accumulate) {
+  __shared__ double red[4][64];
+  const int e = threadIdx.x & 63, rg = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + e, CK = C * KK;
+  double a = 0.0;
+  if (i < CK)
+    for (int r = rg; r < rows; r += 4) a += partial[(int64_t)r * CK + i];
+  red[rg][e] = a;
+  __syncthreads();
+  if (rg == 0 && i < CK) {
+    a = red[0][e] + red[1][e] + red[2][e] + red[3][e];
+    const int j = i / C, c = i - j * C;
+    const int o = c * KK + j;
+    dw[o] = accumulate ? dw[o] + (float)a : (float)a;
   }
 }
 
@@ -442,35 +479,53 @@ int dw_rows(int64_t pixels, int C) {
   return (int)std::max<int64_t>(1, std::min<int64_t>(cdiv(pixels, (int64_t)g.PL * 64), 512));
 }
 
-struct VG { int C4B, PL, PPB, nchunk; };
-static VG vgeom(int C) {
-  VG g; int c4 = C / 4; int cb = 1; while (cb < c4 && cb < 64) cb <<= 1;
-  g.C4B = cb; g.PL = 256 / cb; g.PPB = g.PL * 16; g.nchunk = (int)cdiv(c4, cb);
-  return g;
+// block geometry of the quad kernels: QB quads x PL pixel lanes, nchunk blocks along the channels, fewest idle threads
+struct QG { int QB, PL, nchunk; };
+static QG qgeom(int C, int qmax) {
+  const int c4 = C / 4;
+  QG best = {1, 256, c4}; double bu = -1.0;
+  for (int nc = 1; nc <= 256; nc++) {
+    const int qb = (int)cdiv(c4, nc);
+    if (qb > qmax) continue;
+    const int pl = 256 / qb;
+    const double u = (double)c4 * pl / (256.0 * nc);
+    if (u > bu + 1e-9) { bu = u; best = {qb, pl, nc}; }
+  }
+  return best;
+}
+// units a thread works through: enough blocks to fill the chip (>= ~1024 when the layer has them), at most 8 so the k*k x 4 weight
+// registers are loaded once per several units
+static int dw_upt(int64_t units, const QG& g) {
+  const int64_t u = units * g.nchunk / ((int64_t)g.PL * 1024);
+  return (int)std::max<int64_t>(1, std::min<int64_t>(u, 8));
 }
 template <typename T, int MODE>
-static void launch_dw_vec(const void* src, const float* w, void* dst, int N, int H, int W, int C, int OH, int OW, int k, int s, int p, hipStream_t st) {
-  VG g = vgeom(C);
-  if (s == 1) {  // sliding-window form: units of DWR outputs
-    const int DH = MODE ? H : OH, DW = MODE ? W : OW;
-    int64_t units = (int64_t)N * DH * cdiv(DW, DWR);
-    const int ppb = g.PL * 4;
-    dim3 rgrid((unsigned)cdiv(units, ppb), g.nchunk);
-    if (k == 3) hipLaunchKernelGGL((dwconv_run_kernel<T, 3, MODE>), rgrid, dim3(256), 0, st, (const T*)src, w, (T*)dst, N, H, W, C, OH, OW, p, g.C4B, g.PL, ppb);
-    else hipLaunchKernelGGL((dwconv_run_kernel<T, 5, MODE>), rgrid, dim3(256), 0, st, (const T*)src, w, (T*)dst, N, H, W, C, OH, OW, p, g.C4B, g.PL, ppb);
-    return;
+static void launch_dw_quad(const void* src, const float* w, void* dst, int N, int H, int W, int C, int OH, int OW, int k, int s, int p, hipStream_t st) {
+  const QG g = qgeom(C, DW_QMAX);      // the block's weights are staged in LDS: at most DW_QMAX quads
+  const int DH = MODE ? H : OH, DW = MODE ? W : OW;
+  const int64_t units = (int64_t)N * DH * cdiv(DW, DWR);
+  const int ppb = g.PL * dw_upt(units, g);
+  const dim3 grid((unsigned)cdiv(units, ppb), g.nchunk);
+#define RD_DWQ(KERNEL) hipLaunchKernelGGL(KERNEL, grid, dim3(256), 0, st, (const T*)src, w, (T*)dst, N, H, W, C, OH, OW, p, g.QB, g.PL, ppb)
+  if (MODE == 0) {
+    if (s == 1) { if (k == 3) RD_DWQ((dw_run_kernel<T, 3, 1, 0>)); else RD_DWQ((dw_run_kernel<T, 5, 1, 0>)); }
+    else { if (k == 3) RD_DWQ((dw_run_kernel<T, 3, 2, 0>)); else RD_DWQ((dw_run_kernel<T, 5, 2, 0>)); }
+  } else if (s == 1) {
+    if (k == 3) RD_DWQ((dw_run_kernel<T, 3, 1, 1>)); else RD_DWQ((dw_run_kernel<T, 5, 1, 1>));
+  } else if (p & 1) {
+    if (k == 3) RD_DWQ((dw_dgrad2_kernel<T, 3, 1>)); else RD_DWQ((dw_dgrad2_kernel<T, 5, 1>));
+  } else {
+    if (k == 3) RD_DWQ((dw_dgrad2_kernel<T, 3, 0>)); else RD_DWQ((dw_dgrad2_kernel<T, 5, 0>));
   }
-  int64_t M = (int64_t)N * (MODE ? (int64_t)H * W : (int64_t)OH * OW);
-  dim3 grid((unsigned)cdiv(M, g.PPB), g.nchunk);
-  if (k == 3) hipLaunchKernelGGL((dwconv_vec_kernel<T, 3, MODE>), grid, dim3(256), 0, st, (const T*)src, w, (T*)dst, N, H, W, C, OH, OW, s, p, g.C4B, g.PL, g.PPB);
-  else hipLaunchKernelGGL((dwconv_vec_kernel<T, 5, MODE>), grid, dim3(256), 0, st, (const T*)src, w, (T*)dst, N, H, W, C, OH, OW, s, p, g.C4B, g.PL, g.PPB);
+#undef RD_DWQ
 }
+static bool dw_quad_ok(int C, int k, int s) { return C % 4 == 0 && (k == 3 || k == 5) && (s == 1 || s == 2); }
 
 void launch_dwconv_fwd(const void* x, const float* w, void* y, int N, int H, int W, int C, int OH, int OW, int k, int s, int p, int dtype,
                        hipStream_t st) {
-  if (C % 4 == 0 && (k == 3 || k == 5)) {
-    if (dtype == 0) launch_dw_vec<float, 0>(x, w, y, N, H, W, C, OH, OW, k, s, p, st);
-    else launch_dw_vec<bf16_t, 0>(x, w, y, N, H, W, C, OH, OW, k, s, p, st);
+  if (dw_quad_ok(C, k, s)) {
+    if (dtype == 0) launch_dw_quad<float, 0>(x, w, y, N, H, W, C, OH, OW, k, s, p, st);
+    else launch_dw_quad<bf16_t, 0>(x, w, y, N, H, W, C, OH, OW, k, s, p, st);
     return;
   }
   int64_t n = (int64_t)N * OH * OW * C;
@@ -479,9 +534,9 @@ void launch_dwconv_fwd(const void* x, const float* w, void* y, int N, int H, int
 }
 void launch_dwconv_dgrad(const void* dy, const float* w, void* dx, int N, int H, int W, int C, int OH, int OW, int k, int s, int p,
                          int dtype, hipStream_t st) {
-  if (C % 4 == 0 && (k == 3 || k == 5)) {
-    if (dtype == 0) launch_dw_vec<float, 1>(dy, w, dx, N, H, W, C, OH, OW, k, s, p, st);
-    else launch_dw_vec<bf16_t, 1>(dy, w, dx, N, H, W, C, OH, OW, k, s, p, st);
+  if (dw_quad_ok(C, k, s)) {
+    if (dtype == 0) launch_dw_quad<float, 1>(dy, w, dx, N, H, W, C, OH, OW, k, s, p, st);
+    else launch_dw_quad<bf16_t, 1>(dy, w, dx, N, H, W, C, OH, OW, k, s, p, st);
     return;
   }
   int64_t n = (int64_t)N * H * W * C;
@@ -490,23 +545,25 @@ void launch_dwconv_dgrad(const void* dy, const float* w, void* dx, int N, int H,
 }
 void launch_dwconv_wgrad(const void* x, const void* dy, float* partial, float* dw, int accumulate, int N, int H, int W, int C, int OH,
                          int OW, int k, int s, int p, int dtype, hipStream_t st) {
-  int rows = dw_rows((int64_t)N * OH * OW, C);
-  if (C % 4 == 0 && (k == 3 || k == 5)) {
-    VG v = vgeom(C);
-    dim3 vgrid(rows, v.nchunk);
-    if (s == 1) {
-#define RD_DWR(T, K) hipLaunchKernelGGL((dwconv_wgrad_run_kernel<T, K>), vgrid, dim3(256), 0, st, (const T*)x, (const T*)dy, partial, N, H, W, C, OH, OW, p, v.C4B, v.PL)
-      if (dtype == 0) { if (k == 3) RD_DWR(float, 3); else RD_DWR(float, 5); }
-      else { if (k == 3) RD_DWR(bf16_t, 3); else RD_DWR(bf16_t, 5); }
-#undef RD_DWR
-      hipLaunchKernelGGL(dwconv_wgrad_finalize_kernel, dim3(C * k * k), dim3(64), 0, st, partial, rows, C * k * k, dw, accumulate);
-      return;
+  const int rows = dw_rows((int64_t)N * OH * OW, C);      // what the caller sized `partial` for
+  if (dw_quad_ok(C, k, s)) {
+    const QG g = qgeom(C, 256);
+    const int64_t units = (int64_t)N * OH * cdiv(OW, DWR);
+    // blocks along the units: ~1024 blocks in all, >= 4 units per thread, and no more partial rows than the tensors justify
+    int64_t gx = std::min<int64_t>(1024 / g.nchunk, cdiv(units, (int64_t)g.PL * 4));
+    gx = std::min<int64_t>(gx, std::max<int64_t>(64, (int64_t)N * OH * OW / 32));
+    gx = std::max<int64_t>(1, std::min<int64_t>(gx, rows));
+    const dim3 grid((unsigned)gx, g.nchunk);
+#define RD_DWG(T, K, S) hipLaunchKernelGGL((dw_wgrad_run_kernel<T, K, S>), grid, dim3(256), 0, st, (const T*)x, (const T*)dy, partial, N, H, W, C, OH, OW, p, g.QB, g.PL)
+    if (dtype == 0) {
+      if (s == 1) { if (k == 3) RD_DWG(float, 3, 1); else RD_DWG(float, 5, 1); }
+      else { if (k == 3) RD_DWG(float, 3, 2); else RD_DWG(float, 5, 2); }
+    } else {
+      if (s == 1) { if (k == 3) RD_DWG(bf16_t, 3, 1); else RD_DWG(bf16_t, 5, 1); }
+      else { if (k == 3) RD_DWG(bf16_t, 3, 2); else RD_DWG(bf16_t, 5, 2); }
     }
-#define RD_DWV(T, K) hipLaunchKernelGGL((dwconv_wgrad_vec_kernel<T, K>), vgrid, dim3(256), 0, st, (const T*)x, (const T*)dy, partial, N, H, W, C, OH, OW, s, p, v.C4B, v.PL)
-    if (dtype == 0) { if (k == 3) RD_DWV(float, 3); else RD_DWV(float, 5); }
-    else { if (k == 3) RD_DWV(bf16_t, 3); else RD_DWV(bf16_t, 5); }
-#undef RD_DWV
-    hipLaunchKernelGGL(dwconv_wgrad_finalize_kernel, dim3(C * k * k), dim3(64), 0, st, partial, rows, C * k * k, dw, accumulate);
+#undef RD_DWG
+    hipLaunchKernelGGL(dw_wgrad_finalize_tc_kernel, dim3((unsigned)cdiv(C * k * k, 64)), dim3(256), 0, st, partial, (int)gx, C, k * k, dw, accumulate);
     return;
   }
   RG g = rgeom(C);

@@ -43,6 +43,7 @@ class GradientAllReducer(object):
         self.opt = optimizer
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.collective = dist.is_initialized()      # also with one rank: the same calls, a functional check of the path on a 1-GPU box
         self.per = max(4, (bucket_bytes // 4) & ~3)
         self.stage_ranges = {}
         covered = []
@@ -65,7 +66,8 @@ class GradientAllReducer(object):
         optimizer.grad_scale = 1.0 / self.world
         self._handles = []
         self._done = set()
-        self.log = []      # (tag, start, end) of every all-reduce issued since the last reduce(): test / debugging aid
+        self.log = []      # (tag, start, end) of every all-reduce of the current / last finished step: test / debugging aid
+        self._step_over = False
         if self.stage_ranges:
             engine.add_stage_hook(self.on_stage)
 
@@ -76,14 +78,16 @@ class GradientAllReducer(object):
         engine.remove_stage_hook(self.on_stage)
 
     def broadcast_parameters(self, src=0):
-        if self.world > 1:
+        if self.collective:
             dist.broadcast(self.opt.flat_param, src, group=self.group)
         engine.refresh_packed()     # the packed MFMA operands cached by earlier forwards follow the new values (same buffers)
 
     def _issue(self, tag, ranges):
+        if self._step_over:      # first bucket of a new step
+            self.log, self._step_over = [], False
         for s, e in self._split(ranges):
             self.log.append((tag, s, e))
-            if self.world > 1:
+            if self.collective:
                 self._handles.append(dist.all_reduce(self.opt.flat_grad[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def on_stage(self, tag):
@@ -105,6 +109,7 @@ class GradientAllReducer(object):
             h.wait()
         self._handles = []
         self._done = set()
+        self._step_over = True
 
 
 def rcnet_stages(model):

@@ -29,7 +29,7 @@ def _run_tape(dev, inputs, fn, gout):
     return out.permute(0, 3, 1, 2), [tape.grads[id(x)].permute(0, 3, 1, 2) for x in xs], tape
 
 
-def bf16_exact_dwconv_case(dev, C=48, k=5, s=1, H=11, W=14, N=2):
+def bf16_exact_dwconv_case(dev, C=48, k=5, s=1, H=11, W=14, N=2, dtype=torch.bfloat16):
     """bf16 depthwise path without rounding: inputs / weights / upstream gradients in {-1,0,1} make every product and partial sum exactly
     representable, so the bf16 depthwise forward, data gradient and weight gradient must equal the fp32 torch result bit for bit
     (EfficientNet-Lite3 blocks of the SML backbone, modules/midas/blocks.py:44-64; TF-SAME padding as the blocks use it)."""
@@ -47,11 +47,11 @@ def bf16_exact_dwconv_case(dev, C=48, k=5, s=1, H=11, W=14, N=2):
     assert tuple(ref.shape[2:]) == (oh, ow)
     gy = t(rs.randint(-1, 2, tuple(ref.shape)).astype(np.float32))
     (ref * gy).sum().backward()
-    a = _nhwc(x, dev, torch.bfloat16)
+    a = _nhwc(x, dev, dtype)
     tape = engine.Tape(); tape.mark(a)
     with engine._active(tape):
         out = engine.dwconv_block(a, w, stride=s, pad=ph, out_hw=(oh, ow))
-        tape.grads[id(out)] = _nhwc(gy, dev, torch.bfloat16)
+        tape.grads[id(out)] = _nhwc(gy, dev, dtype)
         tape.backward()
     what = "bf16 dwconv C=%d k=%d s=%d" % (C, k, s)
     assert torch.equal(out.float().permute(0, 3, 1, 2).cpu(), ref.detach()), what + ": forward"

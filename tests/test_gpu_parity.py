@@ -250,6 +250,45 @@ def test_staged_step_reports_buckets_in_backward_order(gpu):
         red.close()
 
 
+def test_step_with_rccl_collectives_matches_plain_step(gpu):
+    """The N > 1 code path on one rank (a 1-GPU box cannot run more): an RCCL process group of size 1, the stage-bucketed asynchronous
+    all-reduces issued between the replayed graphs, reduce() before Adam.  A sum over one rank is the identity, so the losses must follow
+    the plain graphed step's."""
+    import os
+    import torch
+    import torch.distributed as dist
+    from riders_amd import rcnet_main
+    from riders_amd.optim import FlatAdam
+    from riders_amd.parallel import GradientAllReducer, rcnet_stages
+    cfg = dict(rcnet_main.ZJU_CONFIG, patch_size=[64, 32], total_points_sampled=4)
+    batch = rcnet_main.synthetic_batch(2, 64, 96, cfg, seed=5, device=gpu)
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=torch.device(gpu))
+    try:
+        losses = {}
+        for mode in ("plain", "rccl"):
+            torch.manual_seed(0)
+            model = rcnet_main.build_model(gpu, cfg)
+            model.train()
+            opt = FlatAdam(model.parameters(), lr=1e-3)
+            red = GradientAllReducer(opt, stages=rcnet_stages(model)) if mode == "rccl" else None
+            try:
+                if red is not None:
+                    red.broadcast_parameters(0)
+                step = rcnet_main.GraphedTrainStep(model, opt, batch, cfg, reducer=red, warmup=1)
+                losses[mode] = [float(step()) for _ in range(3)]
+                if red is not None:
+                    assert red.collective and opt.grad_scale == 1.0
+            finally:
+                if red is not None:
+                    red.close()
+        for a, b in zip(losses["plain"], losses["rccl"]):
+            assert abs(a - b) <= 1e-3 * abs(a), losses
+    finally:
+        dist.destroy_process_group()
+
+
 def test_bf16_wgrad_transpose_read(gpu):
     """bf16 weight gradient of narrow 3x3 layers through the LDS transpose read (rd_wgrad3x3.hip), bit-exact on integer data."""
     P.bf16_exact_conv_case(gpu, cin=16, cout=1, k=3, s=1, H=9, W=20, N=1)
