@@ -264,6 +264,11 @@ int rd_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg
 int32_t rd_dw_rows(int64_t pixels, int32_t C);
 int rd_dwconv_fwd(const void* x, const float* w, void* y, int32_t N, int32_t H, int32_t W, int32_t C, int32_t OH, int32_t OW, int32_t k,
                   int32_t s, int32_t p, int32_t dtype, void* stream);
+/* forward with the following BatchNorm's batch statistics fused into the epilogue: stats [rd_dwconv_stats_rows][C][2] = (sum, sum^2) of
+ * the stored outputs, ready for rd_bn_finalize; rd_dwconv_stats_rows is 0 when the shape has no fused form (then rd_dwconv_fwd + rd_bn_stats) */
+int32_t rd_dwconv_stats_rows(int32_t N, int32_t OH, int32_t OW, int32_t C, int32_t k, int32_t s);
+int rd_dwconv_fwd_stats(const void* x, const float* w, void* y, float* stats, int32_t N, int32_t H, int32_t W, int32_t C, int32_t OH,
+                        int32_t OW, int32_t k, int32_t s, int32_t p, int32_t dtype, void* stream);
 int rd_dwconv_dgrad(const void* dy, const float* w, void* dx, int32_t N, int32_t H, int32_t W, int32_t C, int32_t OH, int32_t OW, int32_t k,
                     int32_t s, int32_t p, int32_t dtype, void* stream);
 int rd_dwconv_wgrad(const void* x, const void* dy, float* partial, float* dw, int32_t accumulate, int32_t N, int32_t H, int32_t W,

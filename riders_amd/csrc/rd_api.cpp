@@ -485,8 +485,15 @@ int32_t rd_dw_rows(int64_t pixels, int32_t C) { return rd::dw_rows(pixels, C); }
 int rd_dwconv_fwd(const void* x, const float* w, void* y, int32_t N, int32_t H, int32_t W, int32_t C, int32_t OH, int32_t OW, int32_t k,
                   int32_t s, int32_t p, int32_t dtype, void* stream) {
   if (!x || !w || !y || !dt_ok(dtype) || k > 5 || k < 1) return fail("dwconv_fwd: bad args");
-  RD_NS(dtype, launch_dwconv_fwd)(x, w, y, N, H, W, C, OH, OW, k, s, p, RD_DT(dtype), S(stream));
+  RD_NS(dtype, launch_dwconv_fwd)(x, w, y, N, H, W, C, OH, OW, k, s, p, RD_DT(dtype), S(stream), nullptr);
   return done("rd_dwconv_fwd");
+}
+int32_t rd_dwconv_stats_rows(int32_t N, int32_t OH, int32_t OW, int32_t C, int32_t k, int32_t s) { return rd::dwconv_stats_rows(N, OH, OW, C, k, s); }
+int rd_dwconv_fwd_stats(const void* x, const float* w, void* y, float* stats, int32_t N, int32_t H, int32_t W, int32_t C, int32_t OH, int32_t OW,
+                        int32_t k, int32_t s, int32_t p, int32_t dtype, void* stream) {
+  if (!x || !w || !y || !stats || !dt_ok(dtype) || rd::dwconv_stats_rows(N, OH, OW, C, k, s) <= 0) return fail("dwconv_fwd_stats: bad args");
+  RD_NS(dtype, launch_dwconv_fwd)(x, w, y, N, H, W, C, OH, OW, k, s, p, RD_DT(dtype), S(stream), stats);
+  return done("rd_dwconv_fwd_stats");
 }
 int rd_dwconv_dgrad(const void* dy, const float* w, void* dx, int32_t N, int32_t H, int32_t W, int32_t C, int32_t OH, int32_t OW, int32_t k,
                     int32_t s, int32_t p, int32_t dtype, void* stream) {

@@ -143,22 +143,34 @@ __device__ __forceinline__ void dw_stage_weights(const float* __restrict__ w, in
   }
 }
 
-template <typename T, int K, int S, int MODE>  // MODE 0: forward (stride S); MODE 1: data gradient of a stride-1 layer (S == 1)
-__global__ __launch_bounds__(256) void dw_run_kernel(const T* __restrict__ src, const float* __restrict__ w, T* __restrict__ dst, int N,
-                                                     int H, int W, int C, int OH, int OW, int p, int QB, int PL, int PPB) {
+// ST: the forward also emits BatchNorm statistics of what it stores -- stats[blockIdx.x][C][2] = (sum, sum of squares) of the block's rounded
+// outputs -- so the layer's BatchNorm needs no separate pass over y.
+template <typename T, int K, int S, int MODE, bool ST>  // MODE 0: forward (stride S); MODE 1: data gradient of a stride-1 layer (S == 1)
+// (the 5x5 stride-1 forward with statistics lands a few registers above 256 without the occupancy hint, i.e. at one wave per SIMD)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((ST && S == 1) ? 2 : 1))) void dw_run_kernel(const T* __restrict__ src, const float* __restrict__ w, T* __restrict__ dst, int N,
+                                                     int H, int W, int C, int OH, int OW, int p, int QB, int PL, int PPB,
+                                                     float* __restrict__ stats) {
   __shared__ __attribute__((aligned(16))) float wl[DW_QMAX * DwLds<K>::STR];
   const int t = threadIdx.x, pl = t / QB, cl = t - pl * QB;
   const int c = (blockIdx.y * QB + cl) * 4;
   const bool active = pl < PL && c < C;
   float wr[K * K][4];
   dw_stage_weights<K>(w, blockIdx.y * QB * 4, min(QB, C / 4 - (int)blockIdx.y * QB), wl, cl, active, wr);
-  if (!active) return;
+  if (!ST && !active) return;
+  // statistics accumulate in the thread's own LDS slot (the weights' LDS, free once every thread holds its registers): 8 more live
+  // registers across the unit loop would push the 5x5 kernels past 256 VGPRs, i.e. down to one wave per SIMD
+  float* red = wl;      // [256][8] floats <= DW_QMAX * STR
+  if (ST) {
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 8; e++) red[t * 8 + e] = 0.f;
+  }
   constexpr int WIN = (DWR - 1) * S + K;
   const int DH = MODE ? H : OH, DW = MODE ? W : OW;           // destination size
   const int SH = MODE ? OH : H, SW = MODE ? OW : W;           // source size
   const int runs = (DW + DWR - 1) / DWR;
   const int64_t M = (int64_t)N * DH * runs;
-  const int64_t mbeg = (int64_t)blockIdx.x * PPB, mend = mbeg + PPB < M ? mbeg + PPB : M;
+  const int64_t mbeg = (int64_t)blockIdx.x * PPB, mend = !active ? 0 : (mbeg + PPB < M ? mbeg + PPB : M);
   for (int64_t m = mbeg + pl; m < mend; m += PL) {
     const int rw = (int)(m % runs); int64_t q = m / runs; const int dh = (int)(q % DH); const int n = (int)(q / DH);
     const int dw0 = rw * DWR;
@@ -192,7 +204,32 @@ __global__ __launch_bounds__(256) void dw_run_kernel(const T* __restrict__ src, 
     }
 #pragma unroll
     for (int r = 0; r < DWR; r++)
-      if (dw0 + r < DW) st4(dst + (((int64_t)n * DH + dh) * DW + dw0 + r) * C + c, acc[r]);
+      if (dw0 + r < DW) {
+        st4(dst + (((int64_t)n * DH + dh) * DW + dw0 + r) * C + c, acc[r]);
+      }
+    if (ST) {
+      float u1[4] = {0.f, 0.f, 0.f, 0.f}, u2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int r = 0; r < DWR; r++)
+        if (dw0 + r < DW) {
+#pragma unroll
+          for (int e = 0; e < 4; e++) { const float v = Elem<T>::rnd(acc[r][e]); u1[e] += v; u2[e] += v * v; }
+        }
+#pragma unroll
+      for (int e = 0; e < 4; e++) { red[t * 8 + e] += u1[e]; red[t * 8 + 4 + e] += u2[e]; }
+    }
+  }
+  if (ST) {      // pixel lanes of the block summed in a fixed order
+    __syncthreads();
+    if (active && pl == 0) {
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        float a = 0.f, b = 0.f;
+        for (int q = 0; q < PL; q++) { a += red[(q * QB + cl) * 8 + e]; b += red[(q * QB + cl) * 8 + 4 + e]; }
+        stats[((int64_t)blockIdx.x * C + c + e) * 2] = a;
+        stats[((int64_t)blockIdx.x * C + c + e) * 2 + 1] = b;
+      }
+    }
   }
 }
 
@@ -499,33 +536,50 @@ static int dw_upt(int64_t units, const QG& g) {
   const int64_t u = units * g.nchunk / ((int64_t)g.PL * 1024);
   return (int)std::max<int64_t>(1, std::min<int64_t>(u, 8));
 }
+// units per block of the forward with fused statistics: as dw_upt, but never more than 1024 blocks (= statistics rows) along the units
+static int dw_stats_ppb(int64_t units, const QG& g) {
+  const int64_t upt = std::max<int64_t>(dw_upt(units, g), cdiv(units, (int64_t)g.PL * 1024));
+  return (int)(g.PL * upt);
+}
 template <typename T, int MODE>
-static void launch_dw_quad(const void* src, const float* w, void* dst, int N, int H, int W, int C, int OH, int OW, int k, int s, int p, hipStream_t st) {
+static void launch_dw_quad(const void* src, const float* w, void* dst, int N, int H, int W, int C, int OH, int OW, int k, int s, int p, hipStream_t st,
+                           float* stats = nullptr) {
   const QG g = qgeom(C, DW_QMAX);      // the block's weights are staged in LDS: at most DW_QMAX quads
   const int DH = MODE ? H : OH, DW = MODE ? W : OW;
   const int64_t units = (int64_t)N * DH * cdiv(DW, DWR);
-  const int ppb = g.PL * dw_upt(units, g);
+  const int ppb = stats ? dw_stats_ppb(units, g) : g.PL * dw_upt(units, g);
   const dim3 grid((unsigned)cdiv(units, ppb), g.nchunk);
-#define RD_DWQ(KERNEL) hipLaunchKernelGGL(KERNEL, grid, dim3(256), 0, st, (const T*)src, w, (T*)dst, N, H, W, C, OH, OW, p, g.QB, g.PL, ppb)
-  if (MODE == 0) {
-    if (s == 1) { if (k == 3) RD_DWQ((dw_run_kernel<T, 3, 1, 0>)); else RD_DWQ((dw_run_kernel<T, 5, 1, 0>)); }
-    else { if (k == 3) RD_DWQ((dw_run_kernel<T, 3, 2, 0>)); else RD_DWQ((dw_run_kernel<T, 5, 2, 0>)); }
+#define RD_DWQ(KERNEL) hipLaunchKernelGGL(KERNEL, grid, dim3(256), 0, st, (const T*)src, w, (T*)dst, N, H, W, C, OH, OW, p, g.QB, g.PL, ppb, stats)
+#define RD_DWQ2(KERNEL) hipLaunchKernelGGL(KERNEL, grid, dim3(256), 0, st, (const T*)src, w, (T*)dst, N, H, W, C, OH, OW, p, g.QB, g.PL, ppb)
+  if (MODE == 0 && stats) {
+    if (s == 1) { if (k == 3) RD_DWQ((dw_run_kernel<T, 3, 1, 0, true>)); else RD_DWQ((dw_run_kernel<T, 5, 1, 0, true>)); }
+    else { if (k == 3) RD_DWQ((dw_run_kernel<T, 3, 2, 0, true>)); else RD_DWQ((dw_run_kernel<T, 5, 2, 0, true>)); }
+  } else if (MODE == 0) {
+    if (s == 1) { if (k == 3) RD_DWQ((dw_run_kernel<T, 3, 1, 0, false>)); else RD_DWQ((dw_run_kernel<T, 5, 1, 0, false>)); }
+    else { if (k == 3) RD_DWQ((dw_run_kernel<T, 3, 2, 0, false>)); else RD_DWQ((dw_run_kernel<T, 5, 2, 0, false>)); }
   } else if (s == 1) {
-    if (k == 3) RD_DWQ((dw_run_kernel<T, 3, 1, 1>)); else RD_DWQ((dw_run_kernel<T, 5, 1, 1>));
+    if (k == 3) RD_DWQ((dw_run_kernel<T, 3, 1, 1, false>)); else RD_DWQ((dw_run_kernel<T, 5, 1, 1, false>));
   } else if (p & 1) {
-    if (k == 3) RD_DWQ((dw_dgrad2_kernel<T, 3, 1>)); else RD_DWQ((dw_dgrad2_kernel<T, 5, 1>));
+    if (k == 3) RD_DWQ2((dw_dgrad2_kernel<T, 3, 1>)); else RD_DWQ2((dw_dgrad2_kernel<T, 5, 1>));
   } else {
-    if (k == 3) RD_DWQ((dw_dgrad2_kernel<T, 3, 0>)); else RD_DWQ((dw_dgrad2_kernel<T, 5, 0>));
+    if (k == 3) RD_DWQ2((dw_dgrad2_kernel<T, 3, 0>)); else RD_DWQ2((dw_dgrad2_kernel<T, 5, 0>));
   }
 #undef RD_DWQ
+#undef RD_DWQ2
 }
 static bool dw_quad_ok(int C, int k, int s) { return C % 4 == 0 && (k == 3 || k == 5) && (s == 1 || s == 2); }
 
+int dwconv_stats_rows(int N, int OH, int OW, int C, int k, int s) {
+  if (!dw_quad_ok(C, k, s)) return 0;
+  const QG g = qgeom(C, DW_QMAX);
+  const int64_t units = (int64_t)N * OH * cdiv(OW, DWR);
+  return (int)cdiv(units, dw_stats_ppb(units, g));
+}
 void launch_dwconv_fwd(const void* x, const float* w, void* y, int N, int H, int W, int C, int OH, int OW, int k, int s, int p, int dtype,
-                       hipStream_t st) {
+                       hipStream_t st, float* stats) {
   if (dw_quad_ok(C, k, s)) {
-    if (dtype == 0) launch_dw_quad<float, 0>(x, w, y, N, H, W, C, OH, OW, k, s, p, st);
-    else launch_dw_quad<bf16_t, 0>(x, w, y, N, H, W, C, OH, OW, k, s, p, st);
+    if (dtype == 0) launch_dw_quad<float, 0>(x, w, y, N, H, W, C, OH, OW, k, s, p, st, stats);
+    else launch_dw_quad<bf16_t, 0>(x, w, y, N, H, W, C, OH, OW, k, s, p, st, stats);
     return;
   }
   int64_t n = (int64_t)N * OH * OW * C;

@@ -1271,6 +1271,9 @@ def _bn_backward(t, dz, z, y, coef, bn, act, slope, want_res):
     return dy, dres
 
 
+_DW_FUSED_STATS = os.environ.get("RD_DW_FUSED_STATS", "1") != "0"      # 0: separate rd_bn_stats pass (A/B, debugging)
+
+
 def dwconv_block(x, weight, *, stride=1, pad=0, out_hw=None, bn=None, act=ACT_NONE, slope=0.0, training=True):
     """act(BN(depthwise_conv(x))) for the EfficientNet-Lite blocks; weight (C,1,k,k) fp32."""
     lib, t, dt, st = L(), tape(), rd_of(x), _stream(x)
@@ -1278,9 +1281,15 @@ def dwconv_block(x, weight, *, stride=1, pad=0, out_hw=None, bn=None, act=ACT_NO
     k = weight.shape[-1]
     OH, OW = (int(out_hw[0]), int(out_hw[1])) if out_hw is not None else ((H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1)
     y = torch.empty((N, OH, OW, C), dtype=x.dtype, device=x.device)
-    _chk(lib.rd_dwconv_fwd(_p(x), _p(weight.detach()), _p(y), N, H, W, C, OH, OW, k, stride, pad, dt, st), "rd_dwconv_fwd")
+    stats = None
+    srows = lib.rd_dwconv_stats_rows(N, OH, OW, C, k, stride) if (_DW_FUSED_STATS and bn is not None and (training or not bn.track_running_stats)) else 0
+    if srows > 0:      # the BatchNorm statistics come out of the convolution's epilogue: no separate pass over y
+        stats = torch.empty((srows, C, 2), dtype=torch.float32, device=x.device)
+        _chk(lib.rd_dwconv_fwd_stats(_p(x), _p(weight.detach()), _p(y), _p(stats), N, H, W, C, OH, OW, k, stride, pad, dt, st), "rd_dwconv_fwd_stats")
+    else:
+        _chk(lib.rd_dwconv_fwd(_p(x), _p(weight.detach()), _p(y), N, H, W, C, OH, OW, k, stride, pad, dt, st), "rd_dwconv_fwd")
     if bn is not None:
-        z, coef, bn_train = _bn_forward(y, bn, act, slope, None, training)
+        z, coef, bn_train = _bn_forward(y, bn, act, slope, None, training, stats=stats)
     else:
         z, coef, bn_train = y, None, False
         assert act == ACT_NONE
