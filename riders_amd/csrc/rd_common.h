@@ -112,6 +112,20 @@ __device__ __forceinline__ void ld4(const bf16_t* p, float (&o)[4]) {
   o[0] = half_lo_f32(v.x); o[1] = half_hi_f32(v.x);
   o[2] = half_lo_f32(v.y); o[3] = half_hi_f32(v.y);
 }
+// occupancy hint (waves per SIMD the register allocation should leave room for); the host emulator build has no such attribute
+#ifdef RD_EMU
+#define RD_WAVES_PER_EU(n)
+#else
+#define RD_WAVES_PER_EU(n) __attribute__((amdgpu_waves_per_eu(n)))
+#endif
+// a raw 16-byte vector (kept unconverted while its load is in flight) -> VE floats; the pointer argument only selects the element type
+__device__ __forceinline__ void raw16_to_f32(const float*, const uint4& r, float (&o)[4]) {
+  o[0] = __uint_as_float(r.x); o[1] = __uint_as_float(r.y); o[2] = __uint_as_float(r.z); o[3] = __uint_as_float(r.w);
+}
+__device__ __forceinline__ void raw16_to_f32(const bf16_t*, const uint4& r, float (&o)[8]) {
+  o[0] = half_lo_f32(r.x); o[1] = half_hi_f32(r.x); o[2] = half_lo_f32(r.y); o[3] = half_hi_f32(r.y);
+  o[4] = half_lo_f32(r.z); o[5] = half_hi_f32(r.z); o[6] = half_lo_f32(r.w); o[7] = half_hi_f32(r.w);
+}
 // guarded forms: the address is always dereferenced (callers clamp it into the tensor) and the result is zero unless `ok` -- no branch,
 // so a group of such loads issues back to back instead of one branch + one wait each
 __device__ __forceinline__ void ld4z(const float* p, bool ok, float (&o)[4]) {

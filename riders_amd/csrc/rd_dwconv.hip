@@ -147,7 +147,7 @@ __device__ __forceinline__ void dw_stage_weights(const float* __restrict__ w, in
 // outputs -- so the layer's BatchNorm needs no separate pass over y.
 template <typename T, int K, int S, int MODE, bool ST>  // MODE 0: forward (stride S); MODE 1: data gradient of a stride-1 layer (S == 1)
 // (the 5x5 stride-1 forward with statistics lands a few registers above 256 without the occupancy hint, i.e. at one wave per SIMD)
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((ST && S == 1) ? 2 : 1))) void dw_run_kernel(const T* __restrict__ src, const float* __restrict__ w, T* __restrict__ dst, int N,
+__global__ __launch_bounds__(256) RD_WAVES_PER_EU((ST && S == 1) ? 2 : 1) void dw_run_kernel(const T* __restrict__ src, const float* __restrict__ w, T* __restrict__ dst, int N,
                                                      int H, int W, int C, int OH, int OW, int p, int QB, int PL, int PPB,
                                                      float* __restrict__ stats) {
   __shared__ __attribute__((aligned(16))) float wl[DW_QMAX * DwLds<K>::STR];

@@ -10,6 +10,7 @@
 #include "rd_common.h"
 #include "rd_kernels.h"
 #include <float.h>
+#include <cstdlib>
 
 namespace rd {
 
@@ -310,13 +311,165 @@ __global__ __launch_bounds__(256) void roi_pool_bwd_gather_kernel(const T* __res
   }
 }
 
+// ---- pixel-owner form of the RoI-pool backward ------------------------------------------------------------------------------------
+// As the gather kernel above: a block owns a 16 x 16 pixel tile (x 32 channels) of one image, lists the RoIs of that image whose box
+// meets the tile, and every (pixel, VE-channel group) item adds dout of the bins whose window contains the pixel and whose saved
+// arg-max names it -- registers only, no LDS accumulators, no atomics, fixed order (RoI, bin row, bin column).  What differs is where
+// the window arithmetic happens: for each listed RoI, 32 threads work out ONCE, with the forward's float expressions, which bins
+// cover each of the tile's 16 rows and 16 columns (first bin and count, windows of consecutive bins being contiguous) and leave that
+// in LDS; an item then only looks up its row and its column (one bin each in RC-Net, where the RoI has the size of its output), issues the
+// arg-max / dout requests of all its pixels together and compares.  ~45 VALU instructions per (pixel group, RoI) instead of ~400 in
+// the tile form (per-channel arg-max decode + LDS read-add-write) and ~150 in the first gather form (window loops per pixel).
+static constexpr int RPT_CC = 32;      // channels per block of the pixel-owner and tile forms
+struct RoiCand { int r; int rowc[RPB_T]; int colc[RPB_T]; };    // (first bin << 12) | count per tile row / column; 0 = none
+template <typename T>
+__global__ __launch_bounds__(256) void roi_pool_bwd_pix_kernel(const T* __restrict__ dout, const float* __restrict__ rois,
+                                                               const int* __restrict__ argmax, T* __restrict__ dx, int R, int H,
+                                                               int W, int C, int PH, int PW, float scale, int tilesW) {
+  constexpr int VE = Elem<T>::VE, GC = RPT_CC / VE;        // channel groups per block = items per thread (256 pixels x GC groups)
+  constexpr int PR = 256 / GC / RPB_T;                     // tile rows covered by one pass of the block's threads
+  __shared__ RoiGeo geo[RPB_MAXL];
+  __shared__ RoiCand cand[RPB_MAXL];
+  __shared__ int wcount[4];
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  const int b = blockIdx.y, c0 = blockIdx.z * RPT_CC;
+  const int h0 = ((int)blockIdx.x / tilesW) * RPB_T, w0 = ((int)blockIdx.x % tilesW) * RPB_T;
+  const int g = t % GC, lw = (t / GC) % RPB_T, lh0 = t / (GC * RPB_T);      // item k of the thread: pixel (lh0 + k * PR, lw), group g
+  const bool cvalid = c0 + g * VE < C && w0 + lw < W;
+  float acc[GC][VE];
+  int tgt[GC];
+#pragma unroll
+  for (int k = 0; k < GC; k++) {
+    const int h = h0 + lh0 + k * PR;
+    tgt[k] = (cvalid && h < H) ? h * W + w0 + lw : -2;     // -2 never equals a saved arg-max (>= -1)
+#pragma unroll
+    for (int e = 0; e < VE; e++) acc[k][e] = 0.f;
+  }
+  auto fetch = [&](int64_t o, int (&am)[VE], uint4& dv) RD_INLINE_LAMBDA {
+#pragma unroll
+    for (int e4 = 0; e4 < VE / 4; e4++) {
+      const int4 a4 = *reinterpret_cast<const int4*>(argmax + o + e4 * 4);
+      am[e4 * 4] = a4.x; am[e4 * 4 + 1] = a4.y; am[e4 * 4 + 2] = a4.z; am[e4 * 4 + 3] = a4.w;
+    }
+    dv = *reinterpret_cast<const uint4*>(dout + o);
+  };
+  auto take = [&](const int (&am)[VE], const uint4& raw, int target, float (&a)[VE]) RD_INLINE_LAMBDA {
+    float dv[VE];
+    raw16_to_f32(reinterpret_cast<const T*>(0), raw, dv);
+#pragma unroll
+    for (int e = 0; e < VE; e++) a[e] += am[e] == target ? dv[e] : 0.f;
+  };
+
+  for (int rbase = 0; rbase < R; rbase += 256) {
+    const int r = rbase + t;
+    bool hit = false; RoiGeo gme;
+    if (r < R) {
+      const float* roi = rois + (int64_t)r * 5;
+      const int sw = (int)roundf(roi[1] * scale), sh = (int)roundf(roi[2] * scale);
+      const int ew = (int)roundf(roi[3] * scale), eh = (int)roundf(roi[4] * scale);
+      const int rw = max(ew - sw + 1, 1), rh = max(eh - sh + 1, 1);
+      gme.r = r; gme.sh = sh; gme.sw = sw; gme.eh = sh + rh + 1; gme.ew = sw + rw + 1;
+      gme.bh = (float)rh / (float)PH; gme.bw = (float)rw / (float)PW;
+      // conservative box: windows end at ceil((p+1)*bin) <= extent + 1
+      hit = ((int)roi[0] == b) && (sh <= h0 + RPB_T - 1) && (sh + rh + 1 >= h0) && (sw <= w0 + RPB_T - 1) && (sw + rw + 1 >= w0);
+    }
+    const unsigned long long m = __ballot(hit);
+    const int before = __popcll(m & ((1ull << lane) - 1ull));
+    if (lane == 0) wcount[wv] = __popcll(m);
+    __syncthreads();
+    int woff = 0;
+    for (int q = 0; q < wv; q++) woff += wcount[q];
+    const int total = wcount[0] + wcount[1] + wcount[2] + wcount[3];
+    const int mypos = woff + before;
+    for (int cbase = 0; cbase < total; cbase += RPB_MAXL) {
+      __syncthreads();
+      if (hit && mypos >= cbase && mypos < cbase + RPB_MAXL) geo[mypos - cbase] = gme;
+      __syncthreads();
+      const int nl = min(total - cbase, RPB_MAXL);
+      // ---- which bins cover each tile row / column of each listed RoI (the forward's expressions, roi_pool_fwd_vec_kernel) ---------
+      for (int idx = t; idx < nl * 2 * RPB_T; idx += 256) {
+        const int li = idx / (2 * RPB_T), j = idx - li * 2 * RPB_T;
+        const bool rows = j < RPB_T;
+        const int pos = rows ? j : j - RPB_T;
+        const RoiGeo q = geo[li];
+        const int x = (rows ? h0 : w0) + pos, start = rows ? q.sh : q.sw, lim = rows ? H : W, P = rows ? PH : PW;
+        const float bin = rows ? q.bh : q.bw;
+        int first = 0, cnt = 0;
+        if (x < lim && x >= start - 1 && x < (rows ? q.eh : q.ew)) {
+          // p with floor(p*bin) <= d < ceil((p+1)*bin), d = x - start: p in ((d-1)/bin - 1, (d+1)/bin)
+          const float d = (float)(x - start);
+          const int p_lo = max((int)floorf((d - 1.f) / bin) - 1, 0), p_hi = min((int)ceilf((d + 1.f) / bin), P - 1);
+          for (int pp = p_lo; pp <= p_hi; pp++) {
+            int s0 = (int)floorf((float)pp * bin), e0 = (int)ceilf((float)(pp + 1) * bin);
+            s0 = min(max(s0 + start, 0), lim); e0 = min(max(e0 + start, 0), lim);
+            if (x >= s0 && x < e0) { if (cnt == 0) first = pp; cnt++; }
+          }
+        }
+        const int code = cnt ? ((first << 12) | min(cnt, 4095)) : 0;
+        if (rows) cand[li].rowc[pos] = code; else cand[li].colc[pos] = code;
+        if (j == 0) cand[li].r = q.r;
+      }
+      __syncthreads();
+      // ---- every item walks the list.  RC-Net's bins are ~1.02 pixels, so nearly every window is 2 x 2 pixels and nearly every pixel
+      // lies in 2 x 2 bins: the 2 x 2 candidate block of KB pixels is requested in one go -- UNCONDITIONALLY (a candidate that does
+      // not exist reads bin (0, 0) and is compared against a target that never matches): exec-masked or looped requests made every
+      // candidate its own memory round trip, which was most of the kernel.  Candidates beyond 2 x 2 (bins smaller than a pixel) follow
+      // in a plain loop. ----
+      constexpr int KB = 2;
+      static_assert(GC % KB == 0, "items per batch");
+      const int goff = cvalid ? c0 + g * VE : 0;
+      for (int li = 0; li < nl; li++) {
+        const int cc = cand[li].colc[lw];
+        const int rr = cand[li].r;
+        const int nc = cc & 4095, cf = cc >> 12;
+#pragma unroll
+        for (int kb = 0; kb < GC; kb += KB) {
+          int am[KB][4][VE]; uint4 dv[KB][4]; int nr[KB], rf[KB];
+#pragma unroll
+          for (int k = 0; k < KB; k++) {
+            const int rc = nc ? cand[li].rowc[lh0 + (kb + k) * PR] : 0;
+            nr[k] = tgt[kb + k] >= 0 ? (rc & 4095) : 0; rf[k] = rc >> 12;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+              const int ia = q >> 1, ib = q & 1;
+              const bool ok = ia < nr[k] && ib < nc;
+              fetch((((int64_t)rr * PH + (ok ? rf[k] + ia : 0)) * PW + (ok ? cf + ib : 0)) * C + goff, am[k][q], dv[k][q]);
+            }
+          }
+#pragma unroll
+          for (int k = 0; k < KB; k++) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+              const int ia = q >> 1, ib = q & 1;
+              take(am[k][q], dv[k][q], (ia < nr[k] && ib < nc) ? tgt[kb + k] : -2, acc[kb + k]);
+            }
+            if (nr[k] > 2 || (nc > 2 && nr[k] > 0)) {      // bins smaller than a pixel: the candidates outside the 2 x 2 block
+              for (int ia = 0; ia < nr[k]; ia++)
+                for (int ib = (ia < 2 ? 2 : 0); ib < nc; ib++) {
+                  int am1[VE]; uint4 dv1;
+                  fetch((((int64_t)rr * PH + rf[k] + ia) * PW + cf + ib) * C + goff, am1, dv1);
+                  take(am1, dv1, tgt[kb + k], acc[kb + k]);
+                }
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int k = 0; k < GC; k++) {
+    const int h = h0 + lh0 + k * PR;
+    if (tgt[k] >= 0) stv(dx + (((int64_t)b * H + h) * W + w0 + lw) * C + c0 + g * VE, acc[k]);
+  }
+}
+
 // ---- tile-accumulate form of the RoI-pool backward ---------------------------------------------------------------------------------
 // A block owns a 16 x 16 pixel tile x 32 channels of one image as fp32 accumulators in LDS.  It lists the RoIs of the image that can
 // reach the tile (as the gather kernel), and for each of them walks the sub-rectangle of bins whose windows can touch the tile:
 // (bin, VE-channel) items read arg-max and dout with 16-byte vectors and add into the LDS tile where the arg-max falls inside it
 // (ds_add_f32); bins on tile borders are scanned by both neighbours, each adds only its own pixels.  The tile is written once, in the
 // activation dtype: no global atomics (83.6 M per RC-Net step before), no zero fill, no fp32 -> bf16 cast pass.
-static constexpr int RPT_CC = 32;
 template <typename T>
 __global__ __launch_bounds__(256) void roi_pool_bwd_tile_kernel(const T* __restrict__ dout, const float* __restrict__ rois,
                                                                 const int* __restrict__ argmax, T* __restrict__ dx, int R, int H,
@@ -523,6 +676,13 @@ void launch_roi_pool_bwd_tile(const void* dout, const float* rois, const int* ar
 void launch_roi_pool_bwd_gather(const void* dout, const float* rois, const int* argmax, void* dx, int R, int N, int H, int W, int C,
                                 int PH, int PW, float scale, int dtype, hipStream_t st) {
   const int tilesH = (int)cdiv(H, RPB_T), tilesW = (int)cdiv(W, RPB_T);
+  static const bool old_form = getenv("RD_ROI_GATHER_V1") != nullptr;      // A/B: the first gather form (window loops per pixel)
+  if (!old_form && PH < (1 << 19) && PW < (1 << 19)) {
+    dim3 grid((unsigned)(tilesH * tilesW), (unsigned)N, (unsigned)cdiv(C, RPT_CC));
+    if (dtype == 0) hipLaunchKernelGGL((roi_pool_bwd_pix_kernel<float>), grid, dim3(256), 0, st, (const float*)dout, rois, argmax, (float*)dx, R, H, W, C, PH, PW, scale, tilesW);
+    else hipLaunchKernelGGL((roi_pool_bwd_pix_kernel<bf16_t>), grid, dim3(256), 0, st, (const bf16_t*)dout, rois, argmax, (bf16_t*)dx, R, H, W, C, PH, PW, scale, tilesW);
+    return;
+  }
   dim3 grid((unsigned)(tilesH * tilesW), (unsigned)N);
   if (dtype == 0) hipLaunchKernelGGL((roi_pool_bwd_gather_kernel<float>), grid, dim3(256), 0, st, (const float*)dout, rois, argmax, (float*)dx, R, H, W, C, PH, PW, scale, tilesW);
   else hipLaunchKernelGGL((roi_pool_bwd_gather_kernel<bf16_t>), grid, dim3(256), 0, st, (const bf16_t*)dout, rois, argmax, (bf16_t*)dx, R, H, W, C, PH, PW, scale, tilesW);

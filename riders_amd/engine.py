@@ -26,14 +26,15 @@ _state = {"dtype": RD_F32, "tape": None, "defer_wgrad": True, "fused_loftr": Tru
 
 
 def set_roi_tile_min_blocks(n):
-    """Smallest launch (in workgroups) for which the RoI-pool backward uses the LDS-tile kernel; smaller maps use global atomics."""
+    """Smallest launch (in workgroups) for which the RoI-pool backward uses a tiled kernel (pixel-owner gather, or LDS tile-accumulate when
+    that is preferred); smaller maps use global atomics.  n = 0 additionally prefers the LDS tile-accumulate kernel (tests)."""
     _state["roi_tile_min_blocks"] = int(n)
 
 
-
 def set_deterministic_roi_pool(flag):
-    """RoI-pool backward through the gather kernel (bit-reproducible, every gradient element written once) instead of fp32 L2
-    atomics.  Measured on RC-Net B=8: 2.1 ms vs 1.18 ms per step, so the atomic form stays the default."""
+    """RoI-pool backward through the pixel-owner gather kernel at EVERY map size (bit-reproducible: every gradient element written once, in
+    a fixed order).  By default the large maps already use it (round 2: 0.12 / 0.10 / 0.09 ms for RC-Net's three large levels against
+    0.26 / 0.19 / 0.16 ms for the LDS tile-accumulate kernel); the small ones go through fp32 L2 atomics, which is faster there."""
     _state["deterministic_roi_pool"] = bool(flag)
 
 
@@ -475,7 +476,9 @@ def as_nchw(x):
 
 # packed-weight cache: (id(param), version, mode, dtype) -> tensor
 _pack_cache = {}
-_ROI_TILE = os.environ.get("RIDERS_ROI_TILE", "1") != "0"           # A/B switch: LDS-tile RoI-pool backward vs global atomics
+# RoI-pool backward: auto = pixel-owner gather for launches of >= roi_tile_min_blocks workgroups, fp32 L2 atomics below;
+# gather / tile / atomic force one form (A/B)
+_ROI_BWD = os.environ.get("RIDERS_ROI_BWD", "auto")
 _BN_RECOMPUTE = os.environ.get("RIDERS_BN_RECOMPUTE", "1") != "0"   # A/B switch for the BatchNorm backward that does not read z
 
 
@@ -811,14 +814,17 @@ def roi_pool(x, rois, output_size, spatial_scale):
             g = t.pop_grad(out)
             if g is None:
                 return
-            if _state["deterministic_roi_pool"] and C % (16 // x.element_size()) == 0:   # gather form: fixed summation order, no atomics
+            nblk = ((H + 15) // 16) * ((W + 15) // 16) * N * ((C + 31) // 32)
+            big = nblk >= max(_state["roi_tile_min_blocks"], 1)
+            gather = _state["deterministic_roi_pool"] or _ROI_BWD == "gather" or (_ROI_BWD == "auto" and big and _state["roi_tile_min_blocks"] > 0)
+            if gather and C % (16 // x.element_size()) == 0:   # pixel-owner gather: fixed summation order, no atomics
                 dx = torch.empty_like(x)
-                _chk(lib.rd_roi_pool_bwd_gather(_p(g), _p(rois), _p(arg), _p(dx), R, N, H, W, C, PH, PW, float(spatial_scale), dt, st),
-                     "rd_roi_pool_bwd_gather")
+                _chk(_tb("roi_pool", roi_bytes, lambda: lib.rd_roi_pool_bwd_gather(_p(g), _p(rois), _p(arg), _p(dx), R, N, H, W, C, PH, PW,
+                                                                                      float(spatial_scale), dt, st),
+                         "roi_pool bwd(gather) %dx%d C=%d" % (PH, PW, C)), "rd_roi_pool_bwd_gather")
                 t.add_grad(x, dx)
                 return
-            nblk = ((H + 15) // 16) * ((W + 15) // 16) * N * (C // 32)
-            if C % 32 == 0 and H * W < (1 << 24) and _ROI_TILE and nblk >= _state["roi_tile_min_blocks"]:   # LDS tile accumulators (small maps: too few tiles)
+            if C % 32 == 0 and H * W < (1 << 24) and _ROI_BWD in ("auto", "tile") and nblk >= _state["roi_tile_min_blocks"]:   # LDS tile accumulators
                 dx = torch.empty_like(x)
                 _chk(_tb("roi_pool", roi_bytes, lambda: lib.rd_roi_pool_bwd_tile(_p(g), _p(rois), _p(arg), _p(dx), R, N, H, W, C, PH, PW,
                                                                                     float(spatial_scale), dt, st),
