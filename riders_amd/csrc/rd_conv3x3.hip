@@ -486,7 +486,9 @@ __global__ __launch_bounds__(256) void conv3x3_c1_kernel(ConvArgs a) {
       for (int kw = 0; kw < 3; kw++) {
         int ih = oh - 1 + kh, iw = ow - 1 + kw;
         bool ok = (unsigned)ih < (unsigned)a.Hin && (unsigned)iw < (unsigned)a.Win;
-        xv[kh * 3 + kw] = ok ? Elem<T>::ld(x + ((int64_t)n * a.Hin + ih) * a.Win + iw) : 0.f;
+        // unconditional load from a clamped address, zero selected afterwards: nine requests in flight instead of nine guarded round trips
+        const float xl = Elem<T>::ld(x + ((int64_t)n * a.Hin + min(max(ih, 0), a.Hin - 1)) * a.Win + min(max(iw, 0), a.Win - 1));
+        xv[kh * 3 + kw] = ok ? xl : 0.f;
       }
     T* d = (T*)a.dst1 + m * a.Cout;
     for (int c0 = 0; c0 < a.Cout; c0 += 4) {

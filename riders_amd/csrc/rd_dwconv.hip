@@ -670,20 +670,61 @@ __global__ __launch_bounds__(256) void bilinear_bwd_vec_kernel(const T* __restri
     float g[VE];
 #pragma unroll
     for (int e = 0; e < VE; e++) g[e] = 0.f;
+    // the output rows / columns that interpolate from this pixel, with their weights: ALU only, at most four each for the x2 resampling
+    int ohp[4] = {0, 0, 0, 0}, owp[4] = {0, 0, 0, 0}, nr = 0, nc = 0;
+    float whv[4] = {0.f, 0.f, 0.f, 0.f}, wwv[4] = {0.f, 0.f, 0.f, 0.f};
     for (int oh = max(ohc - rh, 0); oh <= min(ohc + rh, OH - 1); oh++) {
       int h0, h1; float lh;
       bil_src(oh, H, OH, align, h0, h1, lh);
-      float wh = (h0 == h ? 1.f - lh : 0.f) + (h1 == h ? lh : 0.f);
-      if (wh == 0.f) continue;
-      for (int ow = max(owc - rw, 0); ow <= min(owc + rw, OW - 1); ow++) {
-        int w0, w1; float lw;
-        bil_src(ow, W, OW, align, w0, w1, lw);
-        float ww = (w0 == w ? 1.f - lw : 0.f) + (w1 == w ? lw : 0.f);
-        if (ww == 0.f) continue;
-        float v[VE];
-        ldv(dy + (((int64_t)n * OH + oh) * OW + ow) * C + cv * VE, v);
+      const float wh = (h0 == h ? 1.f - lh : 0.f) + (h1 == h ? lh : 0.f);
+      if (wh != 0.f) {
 #pragma unroll
-        for (int e = 0; e < VE; e++) g[e] += wh * ww * v[e];
+        for (int j = 0; j < 4; j++) if (nr == j) { ohp[j] = oh; whv[j] = wh; }
+        nr++;
+      }
+    }
+    for (int ow = max(owc - rw, 0); ow <= min(owc + rw, OW - 1); ow++) {
+      int w0, w1; float lw;
+      bil_src(ow, W, OW, align, w0, w1, lw);
+      const float ww = (w0 == w ? 1.f - lw : 0.f) + (w1 == w ? lw : 0.f);
+      if (ww != 0.f) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) if (nc == j) { owp[j] = ow; wwv[j] = ww; }
+        nc++;
+      }
+    }
+    if (nr <= 4 && nc <= 4) {
+      // all sixteen readers requested together, unconditionally (slots beyond nr / nc point at output (0, 0) of the image with weight 0):
+      // a load inside the candidate loops is one memory round trip per reader.  Same summation order as the loops (row, then column).
+      uint4 raw[16];
+#pragma unroll
+      for (int q = 0; q < 16; q++)
+        raw[q] = *reinterpret_cast<const uint4*>(dy + (((int64_t)n * OH + ohp[q >> 2]) * OW + owp[q & 3]) * C + cv * VE);
+#pragma unroll
+      for (int q = 0; q < 16; q++) {
+        float v[VE];
+        raw16_to_f32(reinterpret_cast<const T*>(0), raw[q], v);
+        const bool ok = (q >> 2) < nr && (q & 3) < nc;
+        const float wgt = whv[q >> 2] * wwv[q & 3];
+#pragma unroll
+        for (int e = 0; e < VE; e++) g[e] += ok ? wgt * v[e] : 0.f;
+      }
+    } else {
+      for (int oh = max(ohc - rh, 0); oh <= min(ohc + rh, OH - 1); oh++) {
+        int h0, h1; float lh;
+        bil_src(oh, H, OH, align, h0, h1, lh);
+        float wh = (h0 == h ? 1.f - lh : 0.f) + (h1 == h ? lh : 0.f);
+        if (wh == 0.f) continue;
+        for (int ow = max(owc - rw, 0); ow <= min(owc + rw, OW - 1); ow++) {
+          int w0, w1; float lw;
+          bil_src(ow, W, OW, align, w0, w1, lw);
+          float ww = (w0 == w ? 1.f - lw : 0.f) + (w1 == w ? lw : 0.f);
+          if (ww == 0.f) continue;
+          float v[VE];
+          ldv(dy + (((int64_t)n * OH + oh) * OW + ow) * C + cv * VE, v);
+#pragma unroll
+          for (int e = 0; e < VE; e++) g[e] += wh * ww * v[e];
+        }
       }
     }
     stv(dx + i * VE, g);

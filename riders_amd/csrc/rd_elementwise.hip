@@ -141,15 +141,39 @@ __global__ __launch_bounds__(256) void upsample_nearest_bwd_vec_kernel(const T* 
     float g[VE];
 #pragma unroll
     for (int e = 0; e < VE; e++) g[e] = 0.f;
-    for (int hv = h0; hv <= h1; hv++) {
-      if (nearest_src(hv, sh, Hs) != h) continue;
-      for (int wv = w0; wv <= w1; wv++) {
-        if (nearest_src(wv, sw, Ws) != w) continue;
-        float v[VE];
-        ldv(dy + ((((int64_t)n * Hv + hv) * Wv + wv) * CV + cv) * VE, v);
+    // the destination rows / columns that read this source pixel are contiguous (nearest_src is monotonic): first one and count, ALU only
+    int hf = 0, nh = 0, wf = 0, nw = 0;
+    for (int hv = h0; hv <= h1; hv++)
+      if (nearest_src(hv, sh, Hs) == h) { if (nh == 0) hf = hv; nh++; }
+    for (int wv = w0; wv <= w1; wv++)
+      if (nearest_src(wv, sw, Ws) == w) { if (nw == 0) wf = wv; nw++; }
+    if (nh <= 3 && nw <= 3) {
+      // up-sampling by ~2 (RC-Net: 7x3 -> 15x6 ... 60x25 -> 120x50): at most 3 x 3 readers.  All nine are requested together,
+      // unconditionally (clamped address, masked sum) -- a load inside the candidate loop is one memory round trip per reader
+      uint4 raw[9];
 #pragma unroll
-        for (int e = 0; e < VE; e++) g[e] += v[e];
+      for (int q = 0; q < 9; q++) {
+        const int a = q / 3, bq = q - a * 3;
+        const int hv = min(hf + (a < nh ? a : 0), Hv - 1), wv = min(wf + (bq < nw ? bq : 0), Wv - 1);
+        raw[q] = *reinterpret_cast<const uint4*>(dy + ((((int64_t)n * Hv + hv) * Wv + wv) * CV + cv) * VE);
       }
+#pragma unroll
+      for (int q = 0; q < 9; q++) {
+        const int a = q / 3, bq = q - a * 3;
+        float v[VE];
+        raw16_to_f32(reinterpret_cast<const T*>(0), raw[q], v);
+        const bool ok = a < nh && bq < nw;
+#pragma unroll
+        for (int e = 0; e < VE; e++) g[e] += ok ? v[e] : 0.f;
+      }
+    } else {
+      for (int hv = hf; hv < hf + nh; hv++)
+        for (int wv = wf; wv < wf + nw; wv++) {
+          float v[VE];
+          ldv(dy + ((((int64_t)n * Hv + hv) * Wv + wv) * CV + cv) * VE, v);
+#pragma unroll
+          for (int e = 0; e < VE; e++) g[e] += v[e];
+        }
     }
     stv(dx + i * VE, g);
   }

@@ -156,8 +156,29 @@ __global__ __launch_bounds__(256) void roi_pool_fwd_vec_kernel(const T* __restri
     float best[VE]; int bi[VE];
 #pragma unroll
     for (int e = 0; e < VE; e++) { best[e] = empty ? 0.f : -FLT_MAX; bi[e] = -1; }
-    if (b >= 0 && b < N) {
-      const T* xb = x + (int64_t)b * H * W * C + g * VE;
+    const bool bok = b >= 0 && b < N;
+    const T* xb = x + (int64_t)(bok ? b : 0) * H * W * C + g * VE;
+    if (he - hs <= 2 && we - ws <= 2) {
+      // windows of at most 2 x 2 pixels (every RC-Net pooling: bins of ~1.02 pixels): the four candidates are requested together,
+      // unconditionally (clamped address, masked afterwards) -- the window loop below is one memory round trip per pixel -- and
+      // compared in the loop's order (row-major, strict >), so ties resolve identically
+      uint4 raw[4]; bool ok[4]; int idx[4];
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const int h = hs + (q >> 1), w = ws + (q & 1);
+        ok[q] = bok && h < he && w < we;
+        const int hc = min(max(h, 0), H - 1), wc = min(max(w, 0), W - 1);
+        idx[q] = h * W + w;
+        raw[q] = *reinterpret_cast<const uint4*>(xb + ((int64_t)hc * W + wc) * C);
+      }
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        float v[VE];
+        raw16_to_f32(reinterpret_cast<const T*>(0), raw[q], v);
+#pragma unroll
+        for (int e = 0; e < VE; e++) if (ok[q] && v[e] > best[e]) { best[e] = v[e]; bi[e] = idx[q]; }
+      }
+    } else if (bok) {
       for (int h = hs; h < he; h++)
         for (int w = ws; w < we; w++) {
           float v[VE];

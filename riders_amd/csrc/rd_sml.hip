@@ -27,41 +27,62 @@ __device__ __forceinline__ double block_sum_d(double v, double* sh) {
   return r;
 }
 
+// The per-sample reductions below run ONE block per sample (B <= a few dozen): the block is 1024 threads wide and every thread keeps two
+// 16-byte requests per tensor in flight -- a 256-thread block issuing one scalar load per iteration spent 512 dependent memory round trips
+// per sample (~0.3 ms per launch at 256 x 512).
+static constexpr int SML_SCAN_T = 1024;
+__device__ __forceinline__ bool sml_vec_ok(const void* a, const void* b, const void* c, int HW) {
+  return (HW & 3) == 0 && ((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(c)) & 15) == 0;
+}
+
 // ---- S1: global scale alignment --------------------------------------------------------------------------------------
 // s* = argmin_{s in [lo,hi]} sum_valid |s*p - t|, t = 1/depth on valid radar pixels.  The objective is convex piecewise
 // linear, so s* is where its slope g(s) = sum p*sign(s*p - t) changes sign: 50 bisection steps, one block per sample.
 // (scipy's bounded Brent stops within xatol = 1e-5 of the same point; with no valid pixel it returns 0.299996..., kept.)
-__global__ __launch_bounds__(256) void sml_scale_align_kernel(const float* __restrict__ mono, const float* __restrict__ sparse, int HW,
+__global__ __launch_bounds__(SML_SCAN_T) void sml_scale_align_kernel(const float* __restrict__ mono, const float* __restrict__ sparse, int HW,
                                                               float dmin, float dmax, float lo, float hi, float* __restrict__ scale,
                                                               int* __restrict__ nvalid) {
   constexpr int CAP = 4096;  // valid radar pixels kept in LDS (sparse radar: a few hundred per frame); more -> rescan global memory
-  __shared__ double sh[4];
+  __shared__ double sh[SML_SCAN_T / 64];
   __shared__ float sp[CAP], st[CAP];
   __shared__ int scount;
-  const int b = blockIdx.x;
+  const int b = blockIdx.x, T = blockDim.x;
   const float* p = mono + (int64_t)b * HW;
   const float* z = sparse + (int64_t)b * HW;
   if (threadIdx.x == 0) scount = 0;
   __syncthreads();
-  for (int i = threadIdx.x; i < HW; i += 256) {
-    float zi = z[i];
+  auto keep = [&](float zi, float pi) {
     if (zi < dmax && zi > dmin) {
       int k = atomicAdd(&scount, 1);
-      if (k < CAP) { sp[k] = p[i]; st[k] = 1.0f / zi; }
+      if (k < CAP) { sp[k] = pi; st[k] = 1.0f / zi; }
     }
+  };
+  int done = 0;
+  if (sml_vec_ok(p, z, p, HW)) {
+    const float4* z4 = reinterpret_cast<const float4*>(z);
+    const float4* p4 = reinterpret_cast<const float4*>(p);
+    const int n4 = HW >> 2;
+    for (int i = threadIdx.x; i < n4; i += 2 * T) {
+      const int i1 = i + T < n4 ? i + T : i;
+      const float4 za = z4[i], pa = p4[i], zb = z4[i1], pb = p4[i1];
+      keep(za.x, pa.x); keep(za.y, pa.y); keep(za.z, pa.z); keep(za.w, pa.w);
+      if (i + T < n4) { keep(zb.x, pb.x); keep(zb.y, pb.y); keep(zb.z, pb.z); keep(zb.w, pb.w); }
+    }
+    done = HW;
   }
+  for (int i = done + threadIdx.x; i < HW; i += T) keep(z[i], p[i]);
   __syncthreads();
   const int cnt = scount;
   const bool in_lds = cnt <= CAP;
   auto slope = [&](float s) {  // the sum is order-independent up to double rounding: compaction order does not matter
     double g = 0.0;
     if (in_lds) {
-      for (int i = threadIdx.x; i < cnt; i += 256) {
+      for (int i = threadIdx.x; i < cnt; i += T) {
         float r = s * sp[i] - st[i];
         g += r > 0.f ? (double)sp[i] : (r < 0.f ? -(double)sp[i] : 0.0);
       }
     } else {
-      for (int i = threadIdx.x; i < HW; i += 256) {
+      for (int i = threadIdx.x; i < HW; i += T) {
         float zi = z[i];
         if (zi < dmax && zi > dmin) {
           float r = s * p[i] - 1.0f / zi;
@@ -88,21 +109,34 @@ __global__ __launch_bounds__(256) void sml_scale_align_kernel(const float* __res
 // 'st' global alignment (modules/estimator.py:5-29 compute_scale_and_shift_ls, LeastSquaresEstimator :90-118): closed-form least squares
 // of scale * mono + shift against the inverse radar depth over the valid radar pixels; the 2x2 normal equations are accumulated in
 // double (the reference sums float32 arrays with numpy's pairwise fp32 sum: same quantities, ~1e-6 apart); singular -> (0, 0).
-__global__ __launch_bounds__(256) void sml_scale_shift_ls_kernel(const float* __restrict__ mono, const float* __restrict__ sparse, int HW,
+__global__ __launch_bounds__(SML_SCAN_T) void sml_scale_shift_ls_kernel(const float* __restrict__ mono, const float* __restrict__ sparse, int HW,
                                                                  float dmin, float dmax, float* __restrict__ scale,
                                                                  float* __restrict__ shift, int* __restrict__ nvalid) {
-  __shared__ double sh[4];
-  const int b = blockIdx.x;
+  __shared__ double sh[SML_SCAN_T / 64];
+  const int b = blockIdx.x, T = blockDim.x;
   const float* p = mono + (int64_t)b * HW;
   const float* z = sparse + (int64_t)b * HW;
   double a00 = 0.0, a01 = 0.0, a11 = 0.0, b0 = 0.0, b1 = 0.0;
-  for (int i = threadIdx.x; i < HW; i += 256) {
-    const float zi = z[i];
+  auto add = [&](float zi, float pf) {
     if (zi < dmax && zi > dmin) {
-      const double pi = (double)p[i], ti = (double)(1.0f / zi);
+      const double pi = (double)pf, ti = (double)(1.0f / zi);
       a00 += pi * pi; a01 += pi; a11 += 1.0; b0 += pi * ti; b1 += ti;
     }
+  };
+  int done = 0;
+  if (sml_vec_ok(p, z, p, HW)) {
+    const float4* z4 = reinterpret_cast<const float4*>(z);
+    const float4* p4 = reinterpret_cast<const float4*>(p);
+    const int n4 = HW >> 2;
+    for (int i = threadIdx.x; i < n4; i += 2 * T) {
+      const int i1 = i + T < n4 ? i + T : i;
+      const float4 za = z4[i], pa = p4[i], zb = z4[i1], pb = p4[i1];
+      add(za.x, pa.x); add(za.y, pa.y); add(za.z, pa.z); add(za.w, pa.w);
+      if (i + T < n4) { add(zb.x, pb.x); add(zb.y, pb.y); add(zb.z, pb.z); add(zb.w, pb.w); }
+    }
+    done = HW;
   }
+  for (int i = done + threadIdx.x; i < HW; i += T) add(z[i], p[i]);
   a00 = block_sum_d(a00, sh); a01 = block_sum_d(a01, sh); a11 = block_sum_d(a11, sh);
   b0 = block_sum_d(b0, sh); b1 = block_sum_d(b1, sh);
   if (threadIdx.x == 0) {
@@ -126,31 +160,50 @@ __device__ __forceinline__ float int_scale_of(float idp, float radar, float rc, 
   if (radar < dmax && radar > dmin) sc = (1.f / radar) / idp;
   return sc;
 }
-__global__ __launch_bounds__(256) void sml_scales_minmax_kernel(const float* __restrict__ mono, const float* __restrict__ sparse,
+__global__ __launch_bounds__(SML_SCAN_T) void sml_scales_minmax_kernel(const float* __restrict__ mono, const float* __restrict__ sparse,
                                                                 const float* __restrict__ rcnet, const float* __restrict__ scale,
                                                                 const float* __restrict__ shift, int HW,
                                                                 float dmin, float dmax, float hi, float lo, int use_rcnet,
                                                                 float* __restrict__ mm /* [B][3] = min, max, nvalid(radar+rcnet) */) {
-  __shared__ float smin[4], smax[4], scnt[4];
-  const int b = blockIdx.x;
+  constexpr int NW = SML_SCAN_T / 64;
+  __shared__ float smin[NW], smax[NW], scnt[NW];
+  const int b = blockIdx.x, T = blockDim.x;
   const float s = scale[b], sft = shift ? shift[b] : 0.f;
-  float mn = INFINITY, mx = -INFINITY, cn = 0.f;
-  for (int i = threadIdx.x; i < HW; i += 256) {
-    int64_t j = (int64_t)b * HW + i;
-    float rc = use_rcnet ? rcnet[j] : 0.f;
-    float v = int_scale_of(int_depth_of(s, mono[j], hi, lo, sft), sparse[j], rc, dmin, dmax, use_rcnet);
+  const float* pm = mono + (int64_t)b * HW;
+  const float* ps = sparse + (int64_t)b * HW;
+  const float* pr = use_rcnet ? rcnet + (int64_t)b * HW : pm;     // not read without use_rcnet; a valid pointer for the alignment test
+  float mn = INFINITY, mx = -INFINITY, cn = 0.f;      // min / max / an integer count in fp32: independent of the visiting order
+  auto add = [&](float m, float sp_, float rc) {
+    const float v = int_scale_of(int_depth_of(s, m, hi, lo, sft), sp_, rc, dmin, dmax, use_rcnet);
     mn = fminf(mn, v); mx = fmaxf(mx, v);
-    cn += (sparse[j] < dmax && sparse[j] > dmin) ? 1.f : 0.f;
+    cn += (sp_ < dmax && sp_ > dmin) ? 1.f : 0.f;
     cn += (use_rcnet && rc < dmax && rc > dmin) ? 1.f : 0.f;
+  };
+  int done = 0;
+  if (sml_vec_ok(pm, ps, pr, HW)) {
+    const float4* m4 = reinterpret_cast<const float4*>(pm);
+    const float4* s4 = reinterpret_cast<const float4*>(ps);
+    const float4* r4 = reinterpret_cast<const float4*>(pr);
+    const int n4 = HW >> 2;
+    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = threadIdx.x; i < n4; i += 2 * T) {
+      const int i1 = i + T < n4 ? i + T : i;
+      const float4 ma = m4[i], sa = s4[i], mb = m4[i1], sb = s4[i1];
+      const float4 ra = use_rcnet ? r4[i] : zero, rb = use_rcnet ? r4[i1] : zero;
+      add(ma.x, sa.x, ra.x); add(ma.y, sa.y, ra.y); add(ma.z, sa.z, ra.z); add(ma.w, sa.w, ra.w);
+      if (i + T < n4) { add(mb.x, sb.x, rb.x); add(mb.y, sb.y, rb.y); add(mb.z, sb.z, rb.z); add(mb.w, sb.w, rb.w); }
+    }
+    done = HW;
   }
+  for (int i = done + threadIdx.x; i < HW; i += T) add(pm[i], ps[i], use_rcnet ? pr[i] : 0.f);
   mn = wave_min(mn); mx = wave_max(mx); cn = wave_sum(cn);
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
   if (lane == 0) { smin[wv] = mn; smax[wv] = mx; scnt[wv] = cn; }
   __syncthreads();
   if (threadIdx.x == 0) {
-    mm[b * 3 + 0] = fminf(fminf(smin[0], smin[1]), fminf(smin[2], smin[3]));
-    mm[b * 3 + 1] = fmaxf(fmaxf(smax[0], smax[1]), fmaxf(smax[2], smax[3]));
-    mm[b * 3 + 2] = scnt[0] + scnt[1] + scnt[2] + scnt[3];
+    float a = smin[0], c = smax[0], n = scnt[0];
+    for (int w = 1; w < (T >> 6); w++) { a = fminf(a, smin[w]); c = fmaxf(c, smax[w]); n += scnt[w]; }
+    mm[b * 3 + 0] = a; mm[b * 3 + 1] = c; mm[b * 3 + 2] = n;
   }
 }
 // network input x (B,h,w,3) NHWC = [(int_depth-m0)/s0, (int_scales_n-m1)/s1, gray]; d (B,h,w) = int_depth;
@@ -232,12 +285,16 @@ __device__ __forceinline__ float sobel_gy(int u, int v, int fs) {
 __device__ __forceinline__ float sgn(float x) { return x > 0.f ? 1.f : (x < 0.f ? -1.f : 0.f); }
 
 // per pixel: masked L1 terms and Sobel terms; block partials[blk][8]; gfx/gfy = weights * w_{x,y} * sign(pred_{dx,dy})
+// FS: compile-time Sobel size (3 / 5 / 7; 0 = the run-time `fs_rt`): with it the tap loops unroll and their 2 * FS^2 + 9 loads -- always
+// in bounds, the indices are clamped -- issue as one batch; as run-time loops every tap was its own memory round trip.
+template <int FS>
 __global__ __launch_bounds__(256) void sml_loss_fwd_kernel(const float* __restrict__ pred, const float* __restrict__ image,
                                                            const float* __restrict__ gt_interp, const float* __restrict__ gt_sparse,
-                                                           const float* __restrict__ weights, int N, int H, int W, int fs, int mask_interp,
+                                                           const float* __restrict__ weights, int N, int H, int W, int fs_rt, int mask_interp,
                                                            float* __restrict__ gfx, float* __restrict__ gfy, double* __restrict__ partial) {
   __shared__ double sh[4];
   const int64_t total = (int64_t)N * H * W;
+  const int fs = FS ? FS : fs_rt;
   const int r = fs / 2;
   double acc[8];
   for (int j = 0; j < 8; j++) acc[j] = 0.0;
@@ -250,8 +307,10 @@ __global__ __launch_bounds__(256) void sml_loss_fwd_kernel(const float* __restri
     if (gi > 0.f) { acc[0] += fabsf(o - gi); acc[1] += 1.0; }
     if (gs > 0.f) { acc[2] += fabsf(o - gs); acc[3] += 1.0; }
     float pdx = 0.f, pdy = 0.f, idx = 0.f, idy = 0.f;
+#pragma unroll
     for (int u = 0; u < fs; u++) {
       int hh = min(max(h + u - r, 0), H - 1);
+#pragma unroll
       for (int v = 0; v < fs; v++) {
         int ww = min(max(w + v - r, 0), W - 1);
         float gx = sobel_gx(u, v, fs), gy = sobel_gy(u, v, fs);
@@ -260,8 +319,10 @@ __global__ __launch_bounds__(256) void sml_loss_fwd_kernel(const float* __restri
       }
     }
     float sdx = 0.f, sdy = 0.f;
+#pragma unroll
     for (int u = 0; u < 3; u++) {
       int hh = min(max(h + u - 1, 0), H - 1);
+#pragma unroll
       for (int v = 0; v < 3; v++) {
         int ww = min(max(w + v - 1, 0), W - 1);
         float iv = I[(int64_t)hh * W + ww];
@@ -300,12 +361,14 @@ __global__ void sml_loss_finalize_kernel(const double* __restrict__ partial, int
   info[1] = (float)sup; info[2] = (float)lid; info[3] = (float)sm; info[4] = (float)ed; info[5] = (float)a[1]; info[6] = (float)a[3];
 }
 // d loss / d pred: L1 signs + transposed Sobel through the replicate padding (gather over padded positions clamping to p)
+template <int FS>
 __global__ __launch_bounds__(256) void sml_loss_bwd_kernel(const float* __restrict__ pred, const float* __restrict__ gt_interp,
                                                            const float* __restrict__ gt_sparse, const float* __restrict__ gfx,
                                                            const float* __restrict__ gfy, const float* __restrict__ info,
-                                                           const float* __restrict__ dloss, int N, int H, int W, int fs, int mask_interp,
+                                                           const float* __restrict__ dloss, int N, int H, int W, int fs_rt, int mask_interp,
                                                            float w_lidar, float w_smooth, float* __restrict__ dpred) {
   const int64_t total = (int64_t)N * H * W;
+  const int fs = FS ? FS : fs_rt;
   const int r = fs / 2;
   const float gl = dloss[0];
   const float c_sup = 1.f / info[5], c_lid = w_lidar > 0.f ? w_lidar / info[6] : 0.f;
@@ -325,13 +388,19 @@ __global__ __launch_bounds__(256) void sml_loss_bwd_kernel(const float* __restri
       float s = 0.f;
       for (int ph = ph0; ph <= ph1; ph++)
         for (int pw = pw0; pw <= pw1; pw++)
+#pragma unroll
           for (int u = 0; u < fs; u++) {
-            int a = ph - u + r;  // output row whose tap u reads padded row ph
-            if ((unsigned)a >= (unsigned)H) continue;
+            const int a = ph - u + r;  // output row whose tap u reads padded row ph
+            const bool aok = (unsigned)a < (unsigned)H;
+            const int ac = min(max(a, 0), H - 1);
+#pragma unroll
             for (int v = 0; v < fs; v++) {
-              int b = pw - v + r;
-              if ((unsigned)b >= (unsigned)W) continue;
-              s += FX[(int64_t)a * W + b] * sobel_gx(u, v, fs) + FY[(int64_t)a * W + b] * sobel_gy(u, v, fs);
+              const int b = pw - v + r;
+              const bool ok = aok && (unsigned)b < (unsigned)W;
+              const int bc = min(max(b, 0), W - 1);
+              // unconditional loads (clamped), masked sum: the taps of a pixel are requested together
+              const float fx = FX[(int64_t)ac * W + bc], fy = FY[(int64_t)ac * W + bc];
+              s += ok ? fx * sobel_gx(u, v, fs) + fy * sobel_gy(u, v, fs) : 0.f;
             }
           }
       g += c_sm * s;
@@ -397,16 +466,16 @@ __global__ __launch_bounds__(256) void depth_metrics_kernel(const float* __restr
 // ---- launchers ---------------------------------------------------------------------------------------------------------------
 void launch_sml_scale_align(const float* mono, const float* sparse, int B, int HW, float dmin, float dmax, float lo, float hi, float* scale,
                             int* nvalid, hipStream_t st) {
-  hipLaunchKernelGGL(sml_scale_align_kernel, dim3(B), dim3(256), 0, st, mono, sparse, HW, dmin, dmax, lo, hi, scale, nvalid);
+  hipLaunchKernelGGL(sml_scale_align_kernel, dim3(B), dim3(SML_SCAN_T), 0, st, mono, sparse, HW, dmin, dmax, lo, hi, scale, nvalid);
 }
 void launch_sml_scale_shift_ls(const float* mono, const float* sparse, int B, int HW, float dmin, float dmax, float* scale, float* shift,
                                int* nvalid, hipStream_t st) {
-  hipLaunchKernelGGL(sml_scale_shift_ls_kernel, dim3(B), dim3(256), 0, st, mono, sparse, HW, dmin, dmax, scale, shift, nvalid);
+  hipLaunchKernelGGL(sml_scale_shift_ls_kernel, dim3(B), dim3(SML_SCAN_T), 0, st, mono, sparse, HW, dmin, dmax, scale, shift, nvalid);
 }
 void launch_sml_build_inputs(const float* image, const float* mono, const float* sparse, const float* rcnet, const float* scale,
                              const float* shift, float* mm, int B, int H, int W, int h, int w, float dmin, float dmax, float hi, float lo,
                              int use_rcnet, float m0, float s0, float m1, float s1, float* x, float* d, hipStream_t st) {
-  hipLaunchKernelGGL(sml_scales_minmax_kernel, dim3(B), dim3(256), 0, st, mono, sparse, rcnet, scale, shift, H * W, dmin, dmax, hi, lo, use_rcnet, mm);
+  hipLaunchKernelGGL(sml_scales_minmax_kernel, dim3(B), dim3(SML_SCAN_T), 0, st, mono, sparse, rcnet, scale, shift, H * W, dmin, dmax, hi, lo, use_rcnet, mm);
   hipLaunchKernelGGL(sml_build_inputs_kernel, dim3(ew_grid((int64_t)B * h * w)), dim3(256), 0, st, image, mono, sparse, rcnet, scale, shift, mm, B,
                      H, W, h, w, dmin, dmax, hi, lo, use_rcnet, m0, s0, m1, s1, x, d);
 }
@@ -423,14 +492,18 @@ void launch_sml_loss_fwd(const float* pred, const float* image, const float* gi,
                          float* info, hipStream_t st) {
   int64_t n = (int64_t)N * H * W;
   int rows = sml_loss_rows(n);
-  hipLaunchKernelGGL(sml_loss_fwd_kernel, dim3(rows), dim3(256), 0, st, pred, image, gi, gs, weights, N, H, W, fs, mask_interp, gfx, gfy, partial);
+#define RD_LF(F) hipLaunchKernelGGL((sml_loss_fwd_kernel<F>), dim3(rows), dim3(256), 0, st, pred, image, gi, gs, weights, N, H, W, fs, mask_interp, gfx, gfy, partial)
+  if (fs == 7) RD_LF(7); else if (fs == 5) RD_LF(5); else if (fs == 3) RD_LF(3); else RD_LF(0);
+#undef RD_LF
   hipLaunchKernelGGL(sml_loss_finalize_kernel, dim3(1), dim3(64), 0, st, partial, rows, (double)n, fs, w_lidar, w_smooth, w_edge, info);
 }
 void launch_sml_loss_bwd(const float* pred, const float* gi, const float* gs, const float* gfx, const float* gfy, const float* info,
                          const float* dloss, int N, int H, int W, int fs, int mask_interp, float w_lidar, float w_smooth, float* dpred,
                          hipStream_t st) {
-  hipLaunchKernelGGL(sml_loss_bwd_kernel, dim3(ew_grid((int64_t)N * H * W)), dim3(256), 0, st, pred, gi, gs, gfx, gfy, info, dloss, N, H, W, fs,
-                     mask_interp, w_lidar, w_smooth, dpred);
+#define RD_LB(F) hipLaunchKernelGGL((sml_loss_bwd_kernel<F>), dim3(ew_grid((int64_t)N * H * W)), dim3(256), 0, st, pred, gi, gs, gfx, gfy, info, dloss, N, H, W, fs, \
+                                    mask_interp, w_lidar, w_smooth, dpred)
+  if (fs == 7) RD_LB(7); else if (fs == 5) RD_LB(5); else if (fs == 3) RD_LB(3); else RD_LB(0);
+#undef RD_LB
 }
 void launch_bicubic(const float* x, float* y, int N, int H, int W, int OH, int OW, hipStream_t st) {
   hipLaunchKernelGGL(bicubic_kernel, dim3(ew_grid((int64_t)N * OH * OW)), dim3(256), 0, st, x, y, N, H, W, OH, OW);

@@ -12,7 +12,7 @@ import csv, glob, sys
 f = glob.glob(sys.argv[1] + "/prof/**/*kernel_stats.csv", recursive=True)[0]
 rows = list(csv.DictReader(open(f)))
 tot = sum(float(r["TotalDurationNs"]) for r in rows)
-steps = 18.0
+steps = float(max(1, sum(int(r["Calls"]) for r in rows if "sml_loss_finalize" in r["Name"])))
 print("kernel time per step: %.2f ms, launches per step: %.0f" % (tot / steps / 1e6, sum(int(r["Calls"]) for r in rows) / steps))
 for r in rows[:32]:
     print("%-86s %5d %8.1f us  %5.2f%%  %6.3f ms/step" % (r["Name"][:86], int(r["Calls"]), float(r["AverageNs"]) / 1e3, 100 * float(r["TotalDurationNs"]) / tot, float(r["TotalDurationNs"]) / steps / 1e6))
