@@ -311,22 +311,23 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
 #pragma unroll
     for (int i = 0; i < 4; i++) {
       int m = mb + pr + 8 * i;
+      // every load is unconditional (an element that does not exist reads the tensor's first element and is zeroed afterwards): guarded
+      // loads with the conversion inside the guard cost one memory round trip each, four to eight per stage
+      const bool mv = m < mend;
+      const int mm_ = mv ? m : mbeg;
+      int ow = mm_ % a.OW; int q = mm_ / a.OW; int oh = q % a.OH; int n = q / a.OH;
+      int ihb = oh * a.stride - a.pad, iwb = ow * a.stride - a.pad;
+      if (VEC) {
+        const T* p;
+        const bool ok = conv_src_ptr<T>(g, n, ihb + xkh[0], iwb + xkw[0], xci[0], p) && mv && xv[0];
+        ld4z(ok ? p : (const T*)a.src1, ok, rx[i]);
+      } else {
 #pragma unroll
-      for (int e = 0; e < 4; e++) rx[i][e] = 0.f;
-      if (m < mend) {
-        int ow = m % a.OW; int q = m / a.OW; int oh = q % a.OH; int n = q / a.OH;
-        int ihb = oh * a.stride - a.pad, iwb = ow * a.stride - a.pad;
-        if (VEC) {
-          if (xv[0]) {
-            const T* p;
-            if (conv_src_ptr<T>(g, n, ihb + xkh[0], iwb + xkw[0], xci[0], p)) ld4(p, rx[i]);
-          }
-        } else {
-#pragma unroll
-          for (int e = 0; e < 4; e++) {
-            const T* p;
-            if (xv[e] && conv_src_ptr<T>(g, n, ihb + xkh[e], iwb + xkw[e], xci[e], p)) rx[i][e] = Elem<T>::ld(p);
-          }
+        for (int e = 0; e < 4; e++) {
+          const T* p;
+          const bool ok = conv_src_ptr<T>(g, n, ihb + xkh[e], iwb + xkw[e], xci[e], p) && mv && xv[e];
+          const float v = Elem<T>::ld(ok ? p : (const T*)a.src1);
+          rx[i][e] = ok ? v : 0.f;
         }
       }
     }
@@ -335,14 +336,17 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(WgradArgs a) {
       int idx = t + 256 * i;
       int py = idx / (COT / 4), cy = (idx % (COT / 4)) * 4;
       int m = mb + py, co = c0 + cy;
+      const bool yv = idx < YV && m < mend;
+      const T* yp = (const T*)a.dy + (yv ? (int64_t)m * a.Cout + co : 0);
+      if ((a.Cout & 3) == 0) {
+        const bool ok = yv && co + 3 < a.Cout;
+        ld4z(ok ? yp : (const T*)a.dy, ok, ry[i]);
+      } else {
 #pragma unroll
-      for (int e = 0; e < 4; e++) ry[i][e] = 0.f;
-      if (idx < YV && m < mend) {
-        const T* yp = (const T*)a.dy + (int64_t)m * a.Cout + co;
-        if ((a.Cout & 3) == 0 && co + 3 < a.Cout) ld4(yp, ry[i]);
-        else {
-#pragma unroll
-          for (int e = 0; e < 4; e++) if (co + e < a.Cout) ry[i][e] = Elem<T>::ld(yp + e);
+        for (int e = 0; e < 4; e++) {
+          const bool ok = yv && co + e < a.Cout;
+          const float v = Elem<T>::ld(ok ? yp + e : (const T*)a.dy);
+          ry[i][e] = ok ? v : 0.f;
         }
       }
     }
@@ -646,24 +650,26 @@ __global__ __launch_bounds__(256) void conv_wgrad_halo_kernel(WgradArgs a, int t
     for (int it = 0; it < NX; it++) {
       int pq = xp0 + it * PLX;
       int py = pq / WT, px = pq - py * WT;
-#pragma unroll
-      for (int e = 0; e < 4; e++) fx[it][e] = 0.f;
       const T* p;
-      if (pq < HT * WT && conv_src_ptr<T>(g, n, oh0 - 1 + py, ow0 - 1 + px, xc, p)) ld4(p, fx[it]);
+      const bool ok = conv_src_ptr<T>(g, n, oh0 - 1 + py, ow0 - 1 + px, xc, p) && pq < HT * WT;
+      ld4z(ok ? p : (const T*)a.src1, ok, fx[it]);      // unconditional, masked: the tile's requests issue together
     }
 #pragma unroll
     for (int it = 0; it < NY; it++) {
       int pq = yp0 + it * PLY;
       int py = pq / TW, px = pq - py * TW;
       int oh = oh0 + py, ow = ow0 + px;
+      const bool yv = pq < TH * TW && oh < a.OH && ow < a.OW;
+      const T* yp = (const T*)a.dy + (yv ? (((int64_t)n * a.OH + oh) * a.OW + ow) * a.Cout + yc : 0);
+      if ((a.Cout & 3) == 0) {
+        const bool ok = yv && yc + 3 < a.Cout;
+        ld4z(ok ? yp : (const T*)a.dy, ok, fy[it]);
+      } else {
 #pragma unroll
-      for (int e = 0; e < 4; e++) fy[it][e] = 0.f;
-      if (pq < TH * TW && oh < a.OH && ow < a.OW) {
-        const T* yp = (const T*)a.dy + (((int64_t)n * a.OH + oh) * a.OW + ow) * a.Cout + yc;
-        if ((a.Cout & 3) == 0 && yc + 3 < a.Cout) ld4(yp, fy[it]);
-        else {
-#pragma unroll
-          for (int e = 0; e < 4; e++) if (yc + e < a.Cout) fy[it][e] = Elem<T>::ld(yp + e);
+        for (int e = 0; e < 4; e++) {
+          const bool ok = yv && yc + e < a.Cout;
+          const float v = Elem<T>::ld(ok ? yp + e : (const T*)a.dy);
+          fy[it][e] = ok ? v : 0.f;
         }
       }
     }
