@@ -254,6 +254,14 @@ int rd_crop_patches(const float* gt_padded, const float* points, float* crops, i
 int rd_project_scatter(const float* points, int32_t n, int32_t stride, const double* t_camera_pcl, const double* projection, int32_t H, int32_t W,
                        double min_depth, double max_depth, float* depth_map, float* kept_points, int32_t* n_kept, void* stream);
 
+/* ---- lidar interpolation -- data/data_utils.py:231-275 interpolate_depth, :333-367 interpolate_depth_delft (scipy LinearNDInterpolator) ----
+   barycentric evaluation of a Delaunay triangulation at every pixel: simplices (M,3) indices into the data points, whose integer pixel
+   coordinates are point_row / point_col and whose (possibly log) depths are `values` (float64, as scipy computes); out (H,W) float64 =
+   interpolated value inside the convex hull, fill_value outside; owner_workspace (H,W) int32.  The triangulation itself (Qhull) is the
+   caller's, as in the reference. */
+int rd_tri_raster(const int32_t* simplices, const int32_t* point_row, const int32_t* point_col, const double* values, int32_t n_simplices,
+                  int32_t H, int32_t W, double fill_value, int32_t* owner_workspace, double* out, void* stream);
+
 /* ---- optimizer -- RCNet/rcnet_main.py:233-238,357-359; train_zju.py:205-211,390-392 ------------------------ */
 int rd_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
                  float beta2, float eps, float weight_decay, int64_t step, float grad_scale, void* stream);

@@ -469,6 +469,14 @@ int rd_project_scatter(const float* points, int32_t n, int32_t stride, const dou
   return done("rd_project_scatter");
 }
 
+int rd_tri_raster(const int32_t* simplices, const int32_t* point_row, const int32_t* point_col, const double* values, int32_t n_simplices,
+                  int32_t H, int32_t W, double fill_value, int32_t* owner_workspace, double* out, void* stream) {
+  if (n_simplices < 0 || H <= 0 || W <= 0 || !owner_workspace || !out) return fail("tri_raster: bad args");
+  if (n_simplices > 0 && (!simplices || !point_row || !point_col || !values)) return fail("tri_raster: null pointer");
+  rd::launch_tri_raster(simplices, point_row, point_col, values, n_simplices, H, W, fill_value, owner_workspace, out, S(stream));
+  return done("rd_tri_raster");
+}
+
 int rd_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2, float eps, float wd,
                  int64_t step, float gscale, void* stream) {
   if (!p || !g || !m || !v) return fail("adam: null pointer");

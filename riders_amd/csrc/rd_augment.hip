@@ -179,6 +179,61 @@ __global__ __launch_bounds__(256) void scatter_finish_kernel(unsigned* __restric
 __global__ __launch_bounds__(256) void fill_u32_kernel(unsigned* __restrict__ p, int n, unsigned v) {
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) p[i] = v;
 }
+// ---- lidar interpolation: barycentric raster of a Delaunay triangulation (data/data_utils.py:231-275, :333-367) ----------------------
+// The reference builds scipy's LinearNDInterpolator over the valid pixels and evaluates it at every pixel.  The triangulation (Qhull) stays
+// on the host, as there; what is evaluated H*W times -- point location + barycentric weights -- runs here.  Data points AND queries are
+// integer pixel coordinates, so the edge functions are exact in int64: a pixel lies in a triangle iff its three edge functions do not
+// have opposite signs (edges and vertices included).  Pass 1: one wave per triangle walks its bounding box and claims the pixels it
+// contains with atomicMin(triangle index) -- a pixel on a shared edge belongs to the lowest-numbered triangle, so the result does not
+// depend on scheduling (the interpolant is continuous across the edge anyway).  Pass 2: every pixel evaluates its owner in double.
+__device__ __forceinline__ int64_t tri_edge(int r0, int c0, int r1, int c1, int r, int c) {
+  return (int64_t)(r1 - r0) * (c - c0) - (int64_t)(c1 - c0) * (r - r0);
+}
+__global__ __launch_bounds__(256) void tri_owner_fill_kernel(int* __restrict__ owner, int64_t n) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) owner[i] = 0x7fffffff;
+}
+__global__ __launch_bounds__(256) void tri_owner_kernel(const int* __restrict__ tri, const int* __restrict__ prow, const int* __restrict__ pcol,
+                                                        int M, int H, int W, int* __restrict__ owner) {
+  const int lane = threadIdx.x & 63;
+  for (int t = blockIdx.x * 4 + (threadIdx.x >> 6); t < M; t += gridDim.x * 4) {
+    const int a = tri[t * 3], b = tri[t * 3 + 1], c = tri[t * 3 + 2];
+    const int r0 = prow[a], c0 = pcol[a], r1 = prow[b], c1 = pcol[b], r2 = prow[c], c2 = pcol[c];
+    if (tri_edge(r0, c0, r1, c1, r2, c2) == 0) continue;                    // degenerate simplex
+    const int rlo = max(min(r0, min(r1, r2)), 0), rhi = min(max(r0, max(r1, r2)), H - 1);
+    const int clo = max(min(c0, min(c1, c2)), 0), chi = min(max(c0, max(c1, c2)), W - 1);
+    const int bw = chi - clo + 1, n = (rhi - rlo + 1) * bw;
+    for (int i = lane; i < n; i += 64) {
+      const int r = rlo + i / bw, cc = clo + i % bw;
+      const int64_t e0 = tri_edge(r1, c1, r2, c2, r, cc), e1 = tri_edge(r2, c2, r0, c0, r, cc), e2 = tri_edge(r0, c0, r1, c1, r, cc);
+      const bool neg = e0 < 0 || e1 < 0 || e2 < 0, pos = e0 > 0 || e1 > 0 || e2 > 0;
+      if (!(neg && pos)) atomicMin(&owner[(int64_t)r * W + cc], t);
+    }
+  }
+}
+__global__ __launch_bounds__(256) void tri_interp_kernel(const int* __restrict__ tri, const int* __restrict__ prow, const int* __restrict__ pcol,
+                                                         const double* __restrict__ values, const int* __restrict__ owner, int H, int W,
+                                                         double fill, double* __restrict__ out) {
+  const int64_t n = (int64_t)H * W;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+    const int t = owner[i];
+    if (t == 0x7fffffff) { out[i] = fill; continue; }
+    const int r = (int)(i / W), cc = (int)(i % W);
+    const int a = tri[t * 3], b = tri[t * 3 + 1], c = tri[t * 3 + 2];
+    const int r0 = prow[a], c0 = pcol[a], r1 = prow[b], c1 = pcol[b], r2 = prow[c], c2 = pcol[c];
+    const double area = (double)tri_edge(r0, c0, r1, c1, r2, c2);
+    const double w0 = (double)tri_edge(r1, c1, r2, c2, r, cc) / area, w1 = (double)tri_edge(r2, c2, r0, c0, r, cc) / area;
+    const double w2 = 1.0 - w0 - w1;
+    out[i] = w0 * values[a] + w1 * values[b] + w2 * values[c];
+  }
+}
+void launch_tri_raster(const int* tri, const int* prow, const int* pcol, const double* values, int M, int H, int W, double fill, int* owner,
+                       double* out, hipStream_t st) {
+  const int64_t n = (int64_t)H * W;
+  hipLaunchKernelGGL(tri_owner_fill_kernel, dim3(aug_grid(n)), dim3(256), 0, st, owner, n);
+  if (M > 0) hipLaunchKernelGGL(tri_owner_kernel, dim3((unsigned)std::min<int64_t>(cdiv(M, 4), 4096)), dim3(256), 0, st, tri, prow, pcol, M, H, W, owner);
+  hipLaunchKernelGGL(tri_interp_kernel, dim3(aug_grid(n)), dim3(256), 0, st, tri, prow, pcol, values, owner, H, W, fill, out);
+}
+
 void launch_project_scatter(const float* pts, int n, int stride, const double* T, const double* P, int H, int W, double dmin, double dmax, float* depth_map,
                             float* kept, int* nkept, hipStream_t st) {
   unsigned* map = reinterpret_cast<unsigned*>(depth_map);

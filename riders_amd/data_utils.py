@@ -139,3 +139,45 @@ def sml_rcnet_input_paths(result_root, interp, scene):
     import os
     root = os.path.join(result_root, interp, scene, 'depth_predicted')
     return [os.path.join(root, p) for p in sorted(os.listdir(root))]
+
+
+def interpolate_depth(depth_map, validity_map=None, log_space=False, device=None):
+    """Barycentric interpolation of a sparse depth map over the Delaunay triangulation of its valid pixels: same arguments and result
+    (H x W float64 numpy array) as the reference's data/data_utils.py interpolate_depth :231-275 and interpolate_depth_delft :333-367
+    (`validity_map=None` -> depth_map > 0, as the latter).  The reference hands the valid pixels to scipy's LinearNDInterpolator and
+    evaluates it at all H*W pixels on the host; here Qhull (scipy.spatial.Delaunay -- the triangulation LinearNDInterpolator builds
+    internally from the same points) stays on the host and the H*W evaluations run on the device (rd_tri_raster).  `device`: a ROCm
+    device (default: the current one); there is no host evaluation path."""
+    import torch
+    from scipy.spatial import Delaunay
+    from . import engine
+    depth_map = np.asarray(depth_map)
+    assert depth_map.ndim == 2
+    if validity_map is None:
+        validity_map = depth_map > 0.0
+    validity_map = np.asarray(validity_map)
+    assert validity_map.ndim == 2
+    rows, cols = depth_map.shape
+    data_row_idx, data_col_idx = np.where(validity_map)
+    depth_values = depth_map[data_row_idx, data_col_idx]
+    if log_space:
+        depth_values = np.log(depth_values)
+    fill = 0.0 if not log_space else float(np.log(1e-3))
+    tri = Delaunay(np.stack([data_row_idx, data_col_idx], axis=1))      # raises on fewer than 3 / collinear points, like the reference
+    dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
+    simp = torch.from_numpy(np.ascontiguousarray(tri.simplices, dtype=np.int32)).to(dev)
+    prow = torch.from_numpy(data_row_idx.astype(np.int32)).to(dev)
+    pcol = torch.from_numpy(data_col_idx.astype(np.int32)).to(dev)
+    vals = torch.from_numpy(np.ascontiguousarray(depth_values, dtype=np.float64)).to(dev)
+    owner = torch.empty((rows, cols), dtype=torch.int32, device=dev)
+    out = torch.empty((rows, cols), dtype=torch.float64, device=dev)
+    engine._chk(engine.L().rd_tri_raster(engine._p(simp), engine._p(prow), engine._p(pcol), engine._p(vals), int(simp.shape[0]), rows, cols, fill,
+                                         engine._p(owner), engine._p(out), engine._stream(out)), "rd_tri_raster")
+    Z = out.cpu().numpy()
+    if log_space:
+        Z = np.exp(Z)
+        Z[Z < 1e-1] = 0.0
+    return Z
+
+
+interpolate_depth_delft = interpolate_depth

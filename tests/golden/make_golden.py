@@ -251,8 +251,30 @@ def g_projection():
     save("g14_projection", points=pts, T=T, P=P, depth_map=depth_map, uvs=uvs.astype(np.int32), depth=depth.astype(np.float64))
 
 
+# ---------------------------------------------------------------------------------------------- G15: lidar interpolation
+def g_interpolation():
+    """The reference's own interpolate_depth (data/data_utils.py:231-275; linear and log space) and interpolate_depth_delft (:333-367,
+    validity_map=None) on a seeded sparse depth map: scattered valid pixels plus a short collinear run and a 2x2 cluster (co-circular
+    points, the case where the Delaunay triangulation is not unique)."""
+    from data import data_utils
+    H, W = 40, 56
+    z = np.zeros((H, W), np.float32)
+    rs = np.random.RandomState(1515)
+    idx = rs.choice(H * W, 90, replace=False)
+    z.flat[idx] = rs.uniform(1.5, 80.0, idx.size).astype(np.float32)
+    z[20, 10:15] = np.array([5.0, 6.0, 7.5, 9.0, 12.0], np.float32)     # collinear
+    z[30:32, 40:42] = np.array([[20.0, 21.0], [22.0, 23.5]], np.float32)  # co-circular
+    valid = (z > 0).astype(np.float32)
+    lin = data_utils.interpolate_depth(z, valid, log_space=False)
+    logz = data_utils.interpolate_depth(z, valid, log_space=True)
+    delft = data_utils.interpolate_depth_delft(z)
+    save("g15_interpolation", depth=z, linear=lin.astype(np.float64), log=logz.astype(np.float64), delft=delft.astype(np.float64))
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["attention", "resnet", "decoder", "e2e", "png", "transforms", "projection"]
+    which = sys.argv[1:] or ["attention", "resnet", "decoder", "e2e", "png", "transforms", "projection", "interpolation"]
+    if "interpolation" in which:
+        g_interpolation()
     if "projection" in which:
         g_projection()
     if "transforms" in which:

@@ -578,6 +578,35 @@ def projection_case(dev):
     assert float(empty.abs().max()) == 0.0
 
 
+def interpolation_case(dev, big=False):
+    """N4: lidar interpolation (Delaunay on the host, barycentric raster on the device) against fixture g15 (the REFERENCE's
+    interpolate_depth, linear and log space, and interpolate_depth_delft), then against the oracle on a seeded full-size map."""
+    from riders_amd import data_utils
+    from oracle import interp as OI
+    g = load("g15_interpolation")
+    z = g["depth"]
+    valid = (z > 0).astype(np.float32)
+    for key, got in (("linear", data_utils.interpolate_depth(z, valid, device=dev)),
+                     ("log", data_utils.interpolate_depth(z, valid, log_space=True, device=dev)),
+                     ("delft", data_utils.interpolate_depth_delft(z, device=dev))):
+        want = g[key]
+        assert got.shape == want.shape and got.dtype == np.float64
+        assert np.array_equal(got == 0.0, want == 0.0), key + ": hull / zero pattern differs"
+        err = np.abs(got - want).max() / np.abs(want).max()
+        assert err < 1e-9, "%s: max err %.2e" % (key, err)
+    assert np.allclose(g["linear"][z > 0], z[z > 0].astype(np.float64), rtol=1e-12, atol=0), "fixture sanity: data points reproduce themselves"
+    if big:
+        rs = np.random.RandomState(77)
+        H, W = 256, 512
+        zz = np.zeros((H, W), np.float32)
+        idx = rs.choice(H * W, 3000, replace=False)
+        zz.flat[idx] = rs.uniform(1.0, 90.0, idx.size).astype(np.float32)
+        got = data_utils.interpolate_depth(zz, (zz > 0), device=dev)
+        want = OI.interpolate_depth(zz, (zz > 0))
+        assert np.array_equal(got == 0.0, want == 0.0)
+        assert np.abs(got - want).max() / np.abs(want).max() < 1e-9
+
+
 def adam_case(dev):
     from riders_amd.optim import FlatAdam
     ps = [torch.nn.Parameter(t(rand_array("ad.p%d" % i, s, 1.0), dev)) for i, s in enumerate([(7, 5), (33,), (4, 3, 3, 3)])]

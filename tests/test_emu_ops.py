@@ -160,6 +160,10 @@ def test_projection_scatter(emu):
     P.projection_case(emu)
 
 
+def test_lidar_interpolation(emu):
+    P.interpolation_case(emu)
+
+
 def test_fp16_build_exact(emu):
     """fp16 build of the kernels on the emulator (conversion + a few exact convolution families; the full list runs on the GPU)."""
     import torch

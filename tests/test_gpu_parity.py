@@ -97,6 +97,10 @@ def test_projection_scatter(gpu):
     P.projection_case(gpu)
 
 
+def test_lidar_interpolation(gpu):
+    P.interpolation_case(gpu, big=True)
+
+
 def test_fp16_build(gpu):
     P.fp16_cases(gpu)
 

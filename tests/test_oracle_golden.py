@@ -188,3 +188,15 @@ def test_roi_pool_oracle_matches_hand_derived_kats():
             for n_, c_, k, v in c["grad_in_nonzero"]:
                 want[n_, c_, k] = v
             assert np.array_equal(xr.grad.numpy().reshape(want.shape), want), (c["name"], "scatter-add")
+
+
+def test_interpolation_oracle_matches_reference_fixture():
+    """Pins oracle/interp.py against g15 (the reference's interpolate_depth / interpolate_depth_delft run here)."""
+    from oracle import interp as OI
+    from tests.parity_cases import load
+    g = load("g15_interpolation")
+    z = g["depth"]
+    valid = (z > 0).astype(np.float32)
+    assert np.array_equal(OI.interpolate_depth(z, valid), g["linear"])
+    assert np.array_equal(OI.interpolate_depth(z, valid, log_space=True), g["log"])
+    assert np.array_equal(OI.interpolate_depth(z), g["delft"])
