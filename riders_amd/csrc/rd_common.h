@@ -112,6 +112,13 @@ __device__ __forceinline__ void ld4(const bf16_t* p, float (&o)[4]) {
   o[0] = half_lo_f32(v.x); o[1] = half_hi_f32(v.x);
   o[2] = half_lo_f32(v.y); o[3] = half_hi_f32(v.y);
 }
+// XCD-aware block order: the dispatcher places block b on XCD b % 8 (speed only, never correctness).  Giving every XCD a CONTIGUOUS range of
+// the launch's work items keeps neighbours -- which share halo rows -- behind the same 4 MiB L2 instead of fetching them once per XCD.
+// Bijective on [0, nb).
+__device__ __forceinline__ int xcd_contiguous(int bx, int nb) {
+  const int q = nb >> 3, r = nb & 7, xcd = bx & 7, idx = bx >> 3;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+}
 // occupancy hint (waves per SIMD the register allocation should leave room for); the host emulator build has no such attribute
 #ifdef RD_EMU
 #define RD_WAVES_PER_EU(n)

@@ -170,7 +170,7 @@ __global__ __launch_bounds__(256) RD_WAVES_PER_EU((ST && S == 1) ? 2 : 1) void d
   const int SH = MODE ? OH : H, SW = MODE ? OW : W;           // source size
   const int runs = (DW + DWR - 1) / DWR;
   const int64_t M = (int64_t)N * DH * runs;
-  const int64_t mbeg = (int64_t)blockIdx.x * PPB, mend = !active ? 0 : (mbeg + PPB < M ? mbeg + PPB : M);
+  const int64_t mbeg = (int64_t)xcd_contiguous(blockIdx.x, gridDim.x) * PPB, mend = !active ? 0 : (mbeg + PPB < M ? mbeg + PPB : M);
   for (int64_t m = mbeg + pl; m < mend; m += PL) {
     const int rw = (int)(m % runs); int64_t q = m / runs; const int dh = (int)(q % DH); const int n = (int)(q / DH);
     const int dw0 = rw * DWR;
@@ -273,7 +273,7 @@ __global__ __launch_bounds__(256) void dw_dgrad2_kernel(const T* __restrict__ dy
   constexpr int NJ = (K + 2 - PP) / 2 + 1;
   const int runs = (W + DWR - 1) / DWR;
   const int64_t M = (int64_t)N * H * runs;
-  const int64_t mbeg = (int64_t)blockIdx.x * PPB, mend = mbeg + PPB < M ? mbeg + PPB : M;
+  const int64_t mbeg = (int64_t)xcd_contiguous(blockIdx.x, gridDim.x) * PPB, mend = mbeg + PPB < M ? mbeg + PPB : M;
   for (int64_t m = mbeg + pl; m < mend; m += PL) {
     const int rw = (int)(m % runs); int64_t q = m / runs; const int dh = (int)(q % H); const int n = (int)(q / H);
     const int iw0 = rw * DWR;
@@ -311,7 +311,7 @@ __global__ __launch_bounds__(256) void dw_wgrad_run_kernel(const T* __restrict__
   const int runs = (OW + DWR - 1) / DWR;
   const int64_t units = (int64_t)N * OH * runs;
   const int64_t per = cdiv(units, gridDim.x);
-  const int64_t ubeg = (int64_t)blockIdx.x * per, uend = ubeg + per < units ? ubeg + per : units;
+  const int64_t ubeg = (int64_t)xcd_contiguous(blockIdx.x, gridDim.x) * per, uend = ubeg + per < units ? ubeg + per : units;
   float acc[K * K][4];
 #pragma unroll
   for (int j = 0; j < K * K; j++)

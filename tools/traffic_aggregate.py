@@ -9,6 +9,7 @@ import re
 import sys
 
 FAMILIES = [
+    ("dwconv", r"dwconv|dw_run_kernel|dw_dgrad2_kernel|dw_wgrad"),
     ("conv_gemm", r"conv3x3_patch_kernel|conv3x3_small_kernel|conv_gemm_kernel|conv1x1_direct_kernel|conv3x3_c1_kernel"),
     ("conv_wgrad", r"wgrad"),
     ("loftr_layer", r"loftr_layer"),
@@ -18,7 +19,6 @@ FAMILIES = [
     ("roi_pool", r"roi_pool"),
     ("pooling", r"maxpool"),
     ("optimizer", r"adam_kernel"),
-    ("dwconv", r"dwconv"),
 ]
 
 

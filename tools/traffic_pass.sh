@@ -10,7 +10,7 @@ root=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$root/gpurun_out/traffic_$wl; mkdir -p $out
 cd /tmp
 args="--workload $wl --eager --steps 2 --warmup 1 --settle-seconds 0 --no-cpu-baseline --no-sml $*"
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/fetch -o p -- python3 $root/bench.py $args > $out/fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/write -o p -- python3 $root/bench.py $args > $out/write.log 2>&1
+timeout 900 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $out/fetch -o p -- python3 $root/bench.py $args > $out/fetch.log 2>&1
+timeout 900 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $out/write -o p -- python3 $root/bench.py $args > $out/write.log 2>&1
 cd $root
 python3 tools/traffic_aggregate.py $wl $out 3 "$*"
