@@ -125,6 +125,14 @@ int64_t rd_conv_wgrad_workspace_bytes(const rd_conv_desc* d);
 /* dw (OIHW fp32) = or += dY^T * gather(X); deterministic two-stage reduction */
 int rd_conv_wgrad(const rd_conv_desc* d, const void* src1, const void* src2, const void* dy, float* workspace,
                   float* dw_oihw, int32_t accumulate, void* stream);
+/* The same in two steps, so that the split-K reductions of many layers can share ONE launch (30+ launches of ~9 us per RC-Net step
+ * otherwise): rd_conv_wgrad_partial writes the partial slabs into `workspace` and fills *item (host memory); rd_wgrad_reduce_batch sums
+ * the slabs of every item into its dw_oihw in the fixed order of rd_conv_wgrad (bit-identical result).  The workspaces must stay
+ * untouched until the batch has run; one weight must not appear twice in a batch. */
+typedef struct rd_wgrad_reduce_item { const float* slab; float* dw; int32_t Cout, Cin, KH, KW, nsplit, accumulate; } rd_wgrad_reduce_item;
+int rd_conv_wgrad_partial(const rd_conv_desc* d, const void* src1, const void* src2, const void* dy, float* workspace,
+                          float* dw_oihw, int32_t accumulate, rd_wgrad_reduce_item* item, void* stream);
+int rd_wgrad_reduce_batch(const rd_wgrad_reduce_item* items, int32_t n, void* stream);
 
 /* ---- BatchNorm2d (+ activation, + residual) -- utils/net_utils.py:86-91, :309-323 ----------------- */
 int rd_bn_finalize(const float* stats, int32_t rows, int32_t C, double count, const float* gamma, const float* beta,

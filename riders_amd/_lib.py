@@ -51,6 +51,11 @@ class LwgReduce(ctypes.Structure):
                 ("accumulate", ctypes.c_int32)]
 
 
+class WgradReduceItem(ctypes.Structure):
+    _fields_ = [("slab", ctypes.c_void_p), ("dw", ctypes.c_void_p), ("Cout", ctypes.c_int32), ("Cin", ctypes.c_int32),
+                ("KH", ctypes.c_int32), ("KW", ctypes.c_int32), ("nsplit", ctypes.c_int32), ("accumulate", ctypes.c_int32)]
+
+
 def _ptr_struct(names):
     return [(n, ctypes.c_void_p) for n in names]
 

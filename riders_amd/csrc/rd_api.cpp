@@ -191,8 +191,31 @@ int rd_conv_wgrad(const rd_conv_desc* d, const void* src1, const void* src2, con
   a.Cout = d->Cout; a.KH = d->KH; a.KW = d->KW; a.stride = d->stride; a.pad = d->pad; a.OH = d->OH; a.OW = d->OW;
   a.scale_h = (float)a.H1 / (float)d->Hin; a.scale_w = (float)a.W1 / (float)d->Win;
   a.M = d->N * d->OH * d->OW; a.K = d->KH * d->KW * (d->C1 + d->C2);
-  RD_NS(d->dtype, launch_wgrad)(a, RD_DT(d->dtype), dw, accumulate, S(stream));
+  RD_NS(d->dtype, launch_wgrad)(a, RD_DT(d->dtype), dw, accumulate, S(stream), nullptr);
   return done("rd_conv_wgrad");
+}
+static_assert(sizeof(rd_wgrad_reduce_item) == sizeof(rdt::WgradReduceItem), "rd_wgrad_reduce_item layout");
+int rd_conv_wgrad_partial(const rd_conv_desc* d, const void* src1, const void* src2, const void* dy, float* workspace, float* dw,
+                          int32_t accumulate, rd_wgrad_reduce_item* item, void* stream) {
+  if (int e = check_desc(d)) return e;
+  if (!src1 || !dy || !workspace || !dw || !item) return fail("conv_wgrad_partial: null pointer");
+  if (d->in_dilate != 1) return fail("conv_wgrad_partial: in_dilate must be 1");
+  rd::WgradArgs a; memset(&a, 0, sizeof(a));
+  a.src1 = src1; a.src2 = src2; a.dy = dy; a.slab = workspace;
+  a.N = d->N; a.Hin = d->Hin; a.Win = d->Win; a.C1 = d->C1; a.C2 = d->C2;
+  a.ups = d->upsample ? 1 : 0; a.H1 = a.ups ? d->H1 : d->Hin; a.W1 = a.ups ? d->W1 : d->Win;
+  a.Cout = d->Cout; a.KH = d->KH; a.KW = d->KW; a.stride = d->stride; a.pad = d->pad; a.OH = d->OH; a.OW = d->OW;
+  a.scale_h = (float)a.H1 / (float)d->Hin; a.scale_w = (float)a.W1 / (float)d->Win;
+  a.M = d->N * d->OH * d->OW; a.K = d->KH * d->KW * (d->C1 + d->C2);
+  RD_NS(d->dtype, launch_wgrad)(a, RD_DT(d->dtype), dw, accumulate, S(stream), reinterpret_cast<rdt::WgradReduceItem*>(item));
+  return done("rd_conv_wgrad_partial");
+}
+int rd_wgrad_reduce_batch(const rd_wgrad_reduce_item* items, int32_t n, void* stream) {
+  if (n < 0 || (n > 0 && !items)) return fail("wgrad_reduce_batch: bad args");
+  for (int i = 0; i < n; i++)
+    if (!items[i].slab || !items[i].dw || items[i].nsplit < 1) return fail("wgrad_reduce_batch: item not filled by rd_conv_wgrad_partial");
+  if (n) rd::launch_wgrad_reduce_batch(reinterpret_cast<const rdt::WgradReduceItem*>(items), n, S(stream));
+  return done("rd_wgrad_reduce_batch");
 }
 
 int rd_bn_finalize(const float* stats, int32_t rows, int32_t C, double count, const float* gamma, const float* beta, float eps,

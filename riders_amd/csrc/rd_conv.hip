@@ -788,15 +788,14 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 // float4 version (Cout*K a multiple of 4): thread = (float4 column ol, slab lane sl); each slab lane sums every SL-th slab with
 // 16-byte loads (a quarter of the load instructions of the scalar kernel, whose per-thread loop was the whole latency of this launch),
 // then a fixed-order LDS tree over the slab lanes.  Deterministic.
-__global__ __launch_bounds__(256) void wgrad_reduce_vec_kernel(const float* __restrict__ slab, float* __restrict__ dw, int Cout, int Cin,
-                                                                int KH, int KW, int nsplit, int accumulate, int SL) {
-  __shared__ float4 red[256];
+__device__ __forceinline__ void wgrad_reduce_vec_body(const float* __restrict__ slab, float* __restrict__ dw, int Cout, int Cin, int KH, int KW,
+                                                      int nsplit, int accumulate, int SL, int bx, int nb, float4* red) {
   const int K = KH * KW * Cin;
   const int64_t total = (int64_t)Cout * K, total4 = total >> 2;
   const int OB = 256 / SL;
   const int t = threadIdx.x, ol = t % OB, sl = t / OB;
   const float4* s4 = reinterpret_cast<const float4*>(slab);
-  for (int64_t base = (int64_t)blockIdx.x * OB; base < total4; base += (int64_t)gridDim.x * OB) {
+  for (int64_t base = (int64_t)bx * OB; base < total4; base += (int64_t)nb * OB) {
     const int64_t i4 = base + ol;
     float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
     if (i4 < total4) {
@@ -830,11 +829,27 @@ __global__ __launch_bounds__(256) void wgrad_reduce_vec_kernel(const float* __re
     __syncthreads();
   }
 }
+__global__ __launch_bounds__(256) void wgrad_reduce_vec_kernel(const float* __restrict__ slab, float* __restrict__ dw, int Cout, int Cin,
+                                                                int KH, int KW, int nsplit, int accumulate, int SL) {
+  __shared__ float4 red[256];
+  wgrad_reduce_vec_body(slab, dw, Cout, Cin, KH, KW, nsplit, accumulate, SL, blockIdx.x, gridDim.x, red);
+}
+// The slab reductions of MANY weight gradients in one launch (items by value in the kernel arguments; a block finds its item from the
+// running block counts): 30+ launches of ~9 us, each too small to fill the chip, become one per backward stage.
+__global__ __launch_bounds__(256) void wgrad_reduce_batch_kernel(WgradReduceBatch b) {
+  __shared__ float4 red[256];
+  int it = 0;
+  while (it + 1 < b.n && (int)blockIdx.x >= b.first[it + 1]) it++;
+  const WgradReduceItem& q = b.item[it];
+  wgrad_reduce_vec_body(q.slab, q.dw, q.Cout, q.Cin, q.KH, q.KW, q.nsplit, q.accumulate, b.SL[it], (int)blockIdx.x - b.first[it],
+                        b.first[it + 1] - b.first[it], red);
+}
+static int wgrad_reduce_sl(int nsplit) { int SL = 1; while (SL * 8 < nsplit && SL < 64) SL <<= 1; return SL; }   // about 8 slabs per slab lane
 
 static void launch_wgrad_reduce(const float* slab, float* dw, int Cout, int Cin, int KH, int KW, int nsplit, int accumulate, hipStream_t st) {
   int64_t total = (int64_t)Cout * KH * KW * Cin;
   if (total % 4 == 0) {
-    int SL = 1; while (SL * 8 < nsplit && SL < 64) SL <<= 1;   // about 8 slabs per slab lane
+    int SL = wgrad_reduce_sl(nsplit);
     unsigned rg = (unsigned)std::min<int64_t>(cdiv(total / 4, 256 / SL), 4096);
     hipLaunchKernelGGL(wgrad_reduce_vec_kernel, dim3(rg), dim3(256), 0, st, slab, dw, Cout, Cin, KH, KW, nsplit, accumulate, SL);
     return;
@@ -983,11 +998,33 @@ static void launch_wgrad_halo_t(const WgradArgs& a, int nblk, hipStream_t st) {
 #undef RD_HALO
 }
 
-void launch_wgrad(WgradArgs a, int dtype, float* dw, int accumulate, hipStream_t st) {
+void launch_wgrad_reduce_batch(const WgradReduceItem* items, int n, hipStream_t st) {
+  int i = 0;
+  while (i < n) {
+    WgradReduceBatch b; b.n = 0; b.first[0] = 0;
+    for (; i < n && b.n < WGRAD_BATCH_MAX; i++) {
+      const WgradReduceItem& q = items[i];
+      const int64_t total = (int64_t)q.Cout * q.KH * q.KW * q.Cin;
+      if (total % 4) { launch_wgrad_reduce(q.slab, q.dw, q.Cout, q.Cin, q.KH, q.KW, q.nsplit, q.accumulate, st); continue; }
+      const int SL = wgrad_reduce_sl(q.nsplit);
+      const int nb = (int)std::min<int64_t>(cdiv(total / 4, 256 / SL), 1024);
+      b.item[b.n] = q; b.SL[b.n] = SL; b.first[b.n + 1] = b.first[b.n] + nb; b.n++;
+    }
+    if (b.n) hipLaunchKernelGGL(wgrad_reduce_batch_kernel, dim3((unsigned)b.first[b.n]), dim3(256), 0, st, b);
+  }
+}
+
+// defer != nullptr: the partial slabs are produced, the reduction into dw is left to a later launch_wgrad_reduce_batch over *defer
+void launch_wgrad(WgradArgs a, int dtype, float* dw, int accumulate, hipStream_t st, WgradReduceItem* defer) {
   const int Cin = a.C1 + a.C2;
+  auto reduce = [&](int nsplit) {
+    if (defer) { defer->slab = a.slab; defer->dw = dw; defer->Cout = a.Cout; defer->Cin = Cin; defer->KH = a.KH; defer->KW = a.KW;
+                 defer->nsplit = nsplit; defer->accumulate = accumulate; }
+    else launch_wgrad_reduce(a.slab, dw, a.Cout, Cin, a.KH, a.KW, nsplit, accumulate, st);
+  };
   if (wgrad3x3_tr_ok(a, dtype)) {  // bf16 narrow layers: transpose-read kernel, one slab per persistent block (<= HALO_BLOCKS)
     launch_wgrad3x3_tr(a, st);
-    launch_wgrad_reduce(a.slab, dw, a.Cout, Cin, a.KH, a.KW, wgrad3x3_tr_blocks(a), accumulate, st);
+    reduce(wgrad3x3_tr_blocks(a));
     return;
   }
   if (wgrad_halo_ok(a, dtype)) {
@@ -997,7 +1034,7 @@ void launch_wgrad(WgradArgs a, int dtype, float* dw, int accumulate, hipStream_t
     int nblk = (int)std::min<int64_t>(ntiles, HALO_BLOCKS);
     if (dtype == 0) launch_wgrad_halo_t<float>(a, nblk, st);
     else launch_wgrad_halo_t<bf16_t>(a, nblk, st);
-    launch_wgrad_reduce(a.slab, dw, a.Cout, Cin, a.KH, a.KW, nblk, accumulate, st);
+    reduce(nblk);
     return;
   }
   a.nsplit = wgrad_nsplit(a.M, a.K, a.Cout);
@@ -1014,12 +1051,12 @@ void launch_wgrad(WgradArgs a, int dtype, float* dw, int accumulate, hipStream_t
     else if (cot == 32) hipLaunchKernelGGL((conv_wgrad_bf16_kernel<32>), grid, dim3(256), 0, st, a);
     else if (cot == 64) hipLaunchKernelGGL((conv_wgrad_bf16_kernel<64>), grid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL((conv_wgrad_bf16_kernel<128>), grid, dim3(256), 0, st, a);
-    launch_wgrad_reduce(a.slab, dw, a.Cout, Cin, a.KH, a.KW, a.nsplit, accumulate, st);
+    reduce(a.nsplit);
     return;
   }
   if (dtype == 0) launch_wgrad_t<float>(a, vec, st);
   else launch_wgrad_t<bf16_t>(a, vec, st);
-  launch_wgrad_reduce(a.slab, dw, a.Cout, Cin, a.KH, a.KW, a.nsplit, accumulate, st);
+  reduce(a.nsplit);
 }
 
 }  // namespace rd

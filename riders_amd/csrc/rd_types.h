@@ -25,6 +25,11 @@ struct LwgGemm { const void* x1; const void* x2; const void* dy; float* slab; in
 
 struct LwgReduce { const float* slab; float* dw; int64_t elems; int nsplit, accumulate; };
 
+// deferred split-K reduction of one convolution weight gradient (launch_wgrad with defer) and a batch of them by value in kernel arguments
+struct WgradReduceItem { const float* slab; float* dw; int Cout, Cin, KH, KW, nsplit, accumulate; };
+static const int WGRAD_BATCH_MAX = 48;      // 48 x (40 + 4 + 4) B + 8 B: under the 4 KiB kernel-argument limit
+struct WgradReduceBatch { WgradReduceItem item[WGRAD_BATCH_MAX]; int SL[WGRAD_BATCH_MAX]; int first[WGRAD_BATCH_MAX + 1]; int n; };
+
 static const int LWG_MAX_ITEMS = 64, LWG_MAX_REDS = 96;   // 64 x 56 B and 96 x 32 B: both under the 4 KiB kernel-argument limit
 
 struct LoftrW { const void *wq, *wk, *wv, *wm, *w0, *w2; const float *g1, *b1, *g2, *b2; };

@@ -162,6 +162,8 @@ class Tape:
         self.params = {}   # id(param) -> param
         self.grad_alloc = None  # optional callable(param) -> preallocated fp32 grad view (flat arena)
         self.deferred = []      # weight gradients of 1x1 / linear layers, issued as ONE grouped launch at the end of backward()
+        self.conv_reduce = []   # (rd_wgrad_reduce_item, workspace) of convolution weight gradients whose split-K slabs are written:
+        self.conv_reduce_w = set()   # ... summed by ONE rd_wgrad_reduce_batch launch per backward stage; ids of their weights
 
     def requires(self, *ts):
         return any(t is not None and id(t) in self.req for t in ts)
@@ -224,12 +226,30 @@ class Tape:
     def flush_deferred(self):
         """rd_linear_wgrad_batch over every deferred (x, dy, weight): one launch + one ordered reduction instead of two small
         latency-bound launches per layer (RC-Net's LoFTR transformer alone has 96 of them per step)."""
+        self.flush_conv_reduce()
         pending, self.deferred = self.deferred, []
         by_dt = {}
         for it in pending:                    # a tape may mix fp32 regions (RC-Net's point MLP) with bf16 ones: one batch per dtype
             by_dt.setdefault(it["x"].dtype, []).append(it)
         for items in by_dt.values():
             self._flush_items(items)
+
+    def defer_conv_reduce(self, item, ws, weight):
+        self.conv_reduce.append((item, ws))
+        self.conv_reduce_w.add(id(weight))
+        if len(self.conv_reduce) >= 48:
+            self.flush_conv_reduce()
+
+    def flush_conv_reduce(self):
+        """One launch sums the split-K slabs of every convolution weight gradient produced since the last flush (rd_wgrad_reduce_batch)."""
+        pending, self.conv_reduce, self.conv_reduce_w = self.conv_reduce, [], set()
+        if not pending:
+            return
+        arr = (_lib.WgradReduceItem * len(pending))(*[it for it, _ in pending])
+        ws0 = pending[0][1]
+        nbytes = sum(ws.numel() * 4 for _, ws in pending)
+        _chk(_tb("conv_wgrad", nbytes, lambda: L().rd_wgrad_reduce_batch(arr, len(pending), _stream(ws0)), "wgrad slab reduce batch n=%d" % len(pending)),
+             "rd_wgrad_reduce_batch")
 
     def _flush_items(self, items):
         lib = L()
@@ -717,6 +737,14 @@ def conv_block(x, weight, *, x2=None, bias=None, stride=1, pad=None, up=None, bn
                 _chk(_timed("conv_wgrad", flops, lambda: lib.rd_conv_wgrad(ctypes.byref(d), _p(x), None, _p(dy), _p(ws), _p(dwp), 0, st),
                             "wgrad " + shp, b_in + b_out + weight.numel() * 4), "rd_conv_wgrad")
                 _chk(lib.rd_unpad_weight_grad(_p(dwp), _p(dw), Cout, C1_real, cin_pad, KH * KW, acc, st), "rd_unpad_weight_grad")
+            elif _state["defer_wgrad"]:      # slabs now, their reduction with every other layer's in one launch at the next stage mark
+                if id(weight) in t.conv_reduce_w:      # a weight used twice: its two reductions must not share a launch
+                    t.flush_conv_reduce()
+                item = _lib.WgradReduceItem()
+                _chk(_timed("conv_wgrad", flops, lambda: lib.rd_conv_wgrad_partial(ctypes.byref(d), _p(x), _p(x2), _p(dy), _p(ws), _p(dw), acc,
+                                                                                      ctypes.byref(item), st),
+                            "wgrad " + shp, b_in + b_out + weight.numel() * 4), "rd_conv_wgrad_partial")
+                t.defer_conv_reduce(item, ws, weight)
             else:
                 _chk(_timed("conv_wgrad", flops, lambda: lib.rd_conv_wgrad(ctypes.byref(d), _p(x), _p(x2), _p(dy), _p(ws), _p(dw), acc, st),
                             "wgrad " + shp, b_in + b_out + weight.numel() * 4), "rd_conv_wgrad")
