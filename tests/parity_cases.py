@@ -927,6 +927,86 @@ def roi_pool_tile_deterministic_case(dev):
 
 
 
+def roi_pool_gather_rcnet_geometry_case(dev):
+    """RC-Net geometry (RoI = output size + 1 pixel: bins of ~1.02 pixels, 2 x 2-pixel windows, many overlapping RoIs) through the
+    pixel-owner gather backward: equal to the oracle in fp32, bit-identical from run to run, and EXACT in bf16 on integer-valued data
+    (every sum of a few small integers is representable, so any dropped or doubled bin shows)."""
+    from riders_amd import engine
+    rs = np.random.RandomState(19)
+    N, C, H, W, R = 2, 64, 40, 72, 40
+    PH, PW, scale = 24, 20, 0.5
+    b = rs.randint(0, N, R).astype(np.float32)
+    x1 = rs.randint(-6, 2 * W - 30, R).astype(np.float32); y1 = rs.randint(-6, 2 * H - 40, R).astype(np.float32)      # some leave the map
+    rois = np.stack([b, x1, y1, x1 + 2 * PW, y1 + 2 * PH], 1).astype(np.float32)      # scaled size = output size (+1 from the inclusive end)
+    engine.set_deterministic_roi_pool(True)
+    try:
+        for dtype, xs, ws in ((torch.float32, rs.randn(N, C, H, W), rs.randn(R, C, PH, PW)),
+                              (torch.bfloat16, rs.randint(-3, 4, (N, C, H, W)), rs.randint(-2, 3, (R, C, PH, PW)))):
+            x = t(xs.astype(np.float32)); w = t(ws.astype(np.float32))
+            xr = x.clone().requires_grad_()
+            ref = O.roi_pool(xr, t(rois), scale, (PH, PW))
+            (ref * w).sum().backward()
+            grads = []
+            for rep in range(2):
+                xd = x.to(dev).permute(0, 2, 3, 1).contiguous().to(dtype)
+                tape = engine.Tape(); tape.mark(xd)
+                with engine._active(tape):
+                    out = engine.roi_pool(xd, t(rois, dev), (PH, PW), scale)
+                    tape.grads[id(out)] = w.to(dev).permute(0, 2, 3, 1).contiguous().to(dtype)
+                    tape.backward()
+                grads.append(tape.grads[id(xd)].float().permute(0, 3, 1, 2).cpu())
+            assert torch.equal(grads[0], grads[1]), "gather backward is not reproducible"
+            if dtype == torch.float32:
+                close(grads[0], xr.grad, 1e-5, "roi_pool gather bwd (RC-Net geometry)")
+            else:
+                assert float(xr.grad.abs().max()) < 256, "fixture: sums must stay exactly representable in bf16"
+                assert torch.equal(grads[0], xr.grad), "bf16 gather backward differs on integer data"
+    finally:
+        engine.set_deterministic_roi_pool(False)
+
+
+def wgrad_reduce_batch_case(dev):
+    """rd_conv_wgrad_partial + rd_wgrad_reduce_batch against rd_conv_wgrad, bit for bit: more items than one kernel-argument batch (48),
+    an item whose Cout*K is not a multiple of 4 (scalar reduction inside the batch call), accumulate on and off; and a tape that uses one
+    weight twice (its two reductions must not share a launch)."""
+    import ctypes
+    from riders_amd import engine, _lib
+    from riders_amd.engine import _desc, _p, L, _stream
+    lib = L()
+    rs = np.random.RandomState(23)
+    shapes = [(2, 9, 7, 8, 12, 3), (1, 6, 5, 3, 5, 3), (2, 5, 5, 16, 8, 1), (1, 12, 10, 4, 4, 3)] * 13      # 52 items; (3->5, k3): 135 elements
+    items = (_lib.WgradReduceItem * len(shapes))()
+    keep, want, got = [], [], []
+    for i, (N, H, W, Cin, Cout, k) in enumerate(shapes):
+        x = t(rs.randn(N, H, W, Cin).astype(np.float32), dev); dy = t(rs.randn(N, H, W, Cout).astype(np.float32), dev)
+        d = _desc(0, N, H, W, Cin, 0, False, H, W, Cout, k, k, 1, k // 2, 1, H, W, 0, 0.0, Cout)
+        ws1 = torch.empty(lib.rd_conv_wgrad_workspace_bytes(ctypes.byref(d)) // 4, dtype=torch.float32, device=dev); ws2 = torch.empty_like(ws1)
+        acc = i % 2
+        base = t(rs.randn(Cout, Cin, k, k).astype(np.float32), dev)
+        a, b = base.clone(), base.clone()
+        assert lib.rd_conv_wgrad(ctypes.byref(d), _p(x), None, _p(dy), _p(ws1), _p(a), acc, _stream(x)) == 0
+        assert lib.rd_conv_wgrad_partial(ctypes.byref(d), _p(x), None, _p(dy), _p(ws2), _p(b), acc, ctypes.byref(items, i * ctypes.sizeof(_lib.WgradReduceItem)),
+                                         _stream(x)) == 0
+        keep += [x, dy, ws1, ws2]; want.append(a); got.append(b)
+    assert lib.rd_wgrad_reduce_batch(items, len(shapes), _stream(keep[0])) == 0
+    for i, (a, b) in enumerate(zip(want, got)):
+        assert torch.equal(a.cpu(), b.cpu()), "item %d %s differs from rd_conv_wgrad" % (i, shapes[i])
+    # one weight used by two convolutions of a tape
+    w = torch.nn.Parameter(t(rs.randn(8, 8, 3, 3).astype(np.float32), dev))
+    x1 = t(rs.randn(2, 8, 9, 7).astype(np.float32)); x2 = t(rs.randn(2, 8, 6, 11).astype(np.float32))
+    xr1, xr2, wr = x1.clone().requires_grad_(), x2.clone().requires_grad_(), w.detach().cpu().clone().requires_grad_()
+    (F.conv2d(xr1, wr, padding=1).sum() * 1.5 + (F.conv2d(xr2, wr, padding=1) ** 2).sum()).backward()
+    a1, a2 = x1.to(dev).permute(0, 2, 3, 1).contiguous(), x2.to(dev).permute(0, 2, 3, 1).contiguous()
+    tape = engine.Tape(); tape.mark(a1); tape.mark(a2)
+    with engine._active(tape):
+        o1 = engine.conv_block(a1, w, stride=1, pad=1)
+        o2 = engine.conv_block(a2, w, stride=1, pad=1)
+        tape.grads[id(o1)] = torch.full_like(o1, 1.5)
+        tape.grads[id(o2)] = 2.0 * o2.detach()
+        tape.backward()
+    close(tape.pgrads[id(w)], wr.grad, 1e-4, "weight shared by two convolutions")
+
+
 def fp16_cases(dev):
     """X1 (BASELINE.json configs[4] quotes fp16): the fp16 build of the kernels (same sources compiled with -DRD_HALF_F16: conversions and
     MFMA opcodes differ).  (1) fp32 -> fp16 conversion is round-to-nearest-even, bit-exact against torch; (2) the data path is exact on

@@ -200,3 +200,11 @@ def test_direct_pointwise_conv(emu):
         P.bf16_exact_conv_case(emu, cin=24, cout=144, k=1, s=1, H=13, W=11, N=2)                  # bf16: one k-step
         P.bf16_exact_conv_case(emu, cin=48, cout=288, k=1, s=1, H=7, W=19, N=1)                   # bf16: two k-steps, three channel blocks
         P.bf16_exact_conv_case(emu, cin=64, cout=8, k=1, s=1, H=10, W=13, N=1)
+
+
+def test_roi_pool_gather_rcnet_geometry(emu):
+    P.roi_pool_gather_rcnet_geometry_case(emu)
+
+
+def test_wgrad_reduce_batch(emu):
+    P.wgrad_reduce_batch_case(emu)

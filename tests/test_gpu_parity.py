@@ -396,3 +396,11 @@ def test_bf16_hardware_rounding_is_rne(gpu):
     out = engine.cast(xd, torch.bfloat16)
     ref = x.to(torch.bfloat16)
     assert torch.equal(out.cpu().view(torch.int16), ref.view(torch.int16)), "fp32 -> bf16 rounding differs from round-to-nearest-even"
+
+
+def test_roi_pool_gather_rcnet_geometry(gpu):
+    P.roi_pool_gather_rcnet_geometry_case(gpu)
+
+
+def test_wgrad_reduce_batch(gpu):
+    P.wgrad_reduce_batch_case(gpu)
