@@ -354,7 +354,23 @@ __global__ __launch_bounds__(256) void affine_act_gen_kernel(const T* __restrict
   float sc[VE], sh[VE];
 #pragma unroll
   for (int e = 0; e < VE; e++) { sc[e] = scale ? scale[g * VE + e] : 1.f; sh[e] = shift ? shift[g * VE + e] : 0.f; }
-  for (int64_t p = (int64_t)blockIdx.x * PPB + pl; p < pixels; p += (int64_t)gridDim.x * PPB) {
+  // two pixels per iteration: both requests are in flight before either is used (the EfficientNet maps are small enough that a wave with one
+  // outstanding 16-byte load per lane is latency-bound: waves spent half their cycles waiting, PMC round 2)
+  const int64_t step = (int64_t)gridDim.x * PPB;
+  int64_t p = (int64_t)blockIdx.x * PPB + pl;
+  for (; p + step < pixels; p += 2 * step) {
+    const int64_t o0 = p * C + g * VE, o1 = (p + step) * C + g * VE;
+    float v0[VE], v1[VE], r0[VE], r1[VE];
+    ldv(y + o0, v0); ldv(y + o1, v1);
+    if (HAS_RES) { ldv(res + o0, r0); ldv(res + o1, r1); }
+#pragma unroll
+    for (int e = 0; e < VE; e++) {
+      v0[e] = act_fwd(v0[e] * sc[e] + sh[e] + (HAS_RES ? r0[e] : 0.f), actv, slope);
+      v1[e] = act_fwd(v1[e] * sc[e] + sh[e] + (HAS_RES ? r1[e] : 0.f), actv, slope);
+    }
+    stv(out + o0, v0); stv(out + o1, v1);
+  }
+  for (; p < pixels; p += step) {
     const int64_t o = p * C + g * VE;
     float v[VE], r[VE];
     ldv(y + o, v);
@@ -383,12 +399,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_gen_kernel(const T* __restri
     const int c = g * VE + e;
     mu[e] = mean[c]; rs[e] = rstd[c]; sc[e] = scale[c]; k1[e] = c1[c]; k2[e] = c2[c]; sh[e] = RC ? shift[c] : 0.f;
   }
-  for (int64_t p = (int64_t)blockIdx.x * PPB + pl; p < pixels; p += (int64_t)gridDim.x * PPB) {
-    const int64_t o = p * C + g * VE;
-    float gg[VE], zz[VE], yy[VE], ov[VE];
-    ldv(dz + o, gg);
-    if (actv && !RC) ldv(z + o, zz);
-    ldv(y + o, yy);
+  auto one = [&](int64_t o, float (&gg)[VE], const float (&zz)[VE], const float (&yy)[VE]) RD_INLINE_LAMBDA {
+    float ov[VE];
 #pragma unroll
     for (int e = 0; e < VE; e++) {
       if (actv) gg[e] *= act_grad_from_out(RC ? yy[e] * sc[e] + sh[e] : zz[e], actv, slope);
@@ -397,6 +409,25 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_gen_kernel(const T* __restri
     }
     stv(dy + o, ov);
     if (dres) stv(dres + o, gg);
+  };
+  // two pixels per iteration, all requests issued before the first use (small maps are latency-bound otherwise)
+  const int64_t step = (int64_t)gridDim.x * PPB;
+  int64_t p = (int64_t)blockIdx.x * PPB + pl;
+  for (; p + step < pixels; p += 2 * step) {
+    const int64_t o0 = p * C + g * VE, o1 = (p + step) * C + g * VE;
+    float g0[VE], z0[VE], y0[VE], g1[VE], z1[VE], y1[VE];
+    ldv(dz + o0, g0); ldv(dz + o1, g1);
+    if (actv && !RC) { ldv(z + o0, z0); ldv(z + o1, z1); }
+    ldv(y + o0, y0); ldv(y + o1, y1);
+    one(o0, g0, z0, y0); one(o1, g1, z1, y1);
+  }
+  for (; p < pixels; p += step) {
+    const int64_t o = p * C + g * VE;
+    float gg[VE], zz[VE], yy[VE];
+    ldv(dz + o, gg);
+    if (actv && !RC) ldv(z + o, zz);
+    ldv(y + o, yy);
+    one(o, gg, zz, yy);
   }
 }
 
@@ -582,7 +613,7 @@ void launch_affine_act(const void* y, const float* scale, const float* shift, co
   }
   if (gen_ok(C, dtype)) {
     const int ppb = 256 / (C / (dtype == 0 ? 4 : 8));
-    unsigned gg = (unsigned)std::max<int64_t>(1, std::min<int64_t>(cdiv(pixels, ppb), 2048));
+    unsigned gg = (unsigned)std::max<int64_t>(1, std::min<int64_t>(cdiv(pixels, 2 * ppb), 2048));      // two pixels per thread per iteration
     act_dispatch(act, [&](auto ac) {
       constexpr int A = decltype(ac)::value;
       if (dtype == 0) { if (res) hipLaunchKernelGGL((affine_act_gen_kernel<float, A, true>), dim3(gg), dim3(256), 0, st, (const float*)y, scale, shift, (const float*)res, (float*)out, pixels, C, act, slope);
@@ -653,7 +684,7 @@ void launch_bn_bwd_apply(const void* dz, const void* z, const void* y, const flo
   }
   if (gen_ok(C, dtype)) {
     const int ppb = 256 / (C / (dtype == 0 ? 4 : 8));
-    unsigned gg = (unsigned)std::max<int64_t>(1, std::min<int64_t>(cdiv(pixels, ppb), 2048));
+    unsigned gg = (unsigned)std::max<int64_t>(1, std::min<int64_t>(cdiv(pixels, 2 * ppb), 2048));      // two pixels per thread per iteration
     act_dispatch(act, [&](auto ac) {
       constexpr int A = decltype(ac)::value; (void)A;
       if (dtype == 0) { if (shift) hipLaunchKernelGGL((bn_bwd_apply_gen_kernel<float, true, A>), dim3(gg), dim3(256), 0, st, (const float*)dz, (const float*)z, (const float*)y, mean, rstd, scale, c1, c2, shift, (float*)dy, (float*)dres, pixels, C, act, slope); else hipLaunchKernelGGL((bn_bwd_apply_gen_kernel<float, false, -1>), dim3(gg), dim3(256), 0, st, (const float*)dz, (const float*)z, (const float*)y, mean, rstd, scale, c1, c2, shift, (float*)dy, (float*)dres, pixels, C, act, slope); }
