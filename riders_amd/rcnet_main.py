@@ -202,9 +202,9 @@ def staged_gradients(fwd_loss, optimizer, on_stage=None, loss_scale=1.0):
 
 class GraphedStep(object):
     """The launch-bound part of a step (forward + loss + backward: ~1100 small kernel launches for RC-Net) captured once into
-    hipGraphs and replayed per step; the RCCL gradient all-reduce and the fused Adam launch stay eager.  The capture is SPLIT at the
-    model's stage marks: after the graph of a stage has been enqueued the all-reducer starts that stage's bucket on the communication
-    stream, so the exchange overlaps the replay of the remaining backward graphs.
+    hipGraphs and replayed per step; the RCCL gradient all-reduce and the fused Adam launch stay eager.  With an all-reducer the capture
+    is SPLIT at the model's stage marks: after the graph of a stage has been enqueued the all-reducer starts that stage's bucket on the
+    communication stream, so the exchange overlaps the replay of the remaining backward graphs.  Without one it is a single graph.
     `fwd_loss()` runs forward + loss on static device tensors and returns the loss tensor; `on_replay(n)` keeps host-side bookkeeping
     (BatchNorm num_batches_tracked counters) in step with replays; `buffers` are tensors the forward updates in place (BatchNorm running
     statistics): the warm-up passes needed before a capture are undone on them, so constructing a GraphedStep trains nothing."""
@@ -245,7 +245,8 @@ class GraphedStep(object):
                 begin()
             begin()
             try:
-                self.loss = staged_gradients(fwd_loss, optimizer, boundary, loss_scale)
+                # without an all-reducer there is nothing to interleave: one graph (each extra graph launch costs ~1 % of an RC-Net step)
+                self.loss = staged_gradients(fwd_loss, optimizer, boundary if reducer is not None else None, loss_scale)
             except BaseException:
                 state["ctx"].__exit__(None, None, None)
                 raise
