@@ -194,6 +194,12 @@ int rd_conv_wgrad(const rd_conv_desc* d, const void* src1, const void* src2, con
   RD_NS(d->dtype, launch_wgrad)(a, RD_DT(d->dtype), dw, accumulate, S(stream), nullptr);
   return done("rd_conv_wgrad");
 }
+int32_t rd_conv_wgrad_streams(const rd_conv_desc* d) {
+  if (!d || check_desc(d) || d->in_dilate != 1) return 0;
+  rd::WgradArgs a; fill_wgrad_args(d, a);
+  a.C1 = d->C1; a.C2 = d->C2; a.ups = d->upsample ? 1 : 0; a.KH = d->KH; a.KW = d->KW; a.stride = d->stride; a.Cout = d->Cout;
+  return RD_NS(d->dtype, wgrad_streams)(a) ? 1 : 0;
+}
 static_assert(sizeof(rd_wgrad_reduce_item) == sizeof(rdt::WgradReduceItem), "rd_wgrad_reduce_item layout");
 int rd_conv_wgrad_partial(const rd_conv_desc* d, const void* src1, const void* src2, const void* dy, float* workspace, float* dw,
                           int32_t accumulate, rd_wgrad_reduce_item* item, void* stream) {

@@ -998,6 +998,95 @@ static void launch_wgrad_halo_t(const WgradArgs& a, int nblk, hipStream_t st) {
 #undef RD_HALO
 }
 
+// ---- weight gradients with a handful of channels and millions of pixels (SML: the 3->3 `first` convolution and the 32->1 output head).  On the MFMA kernels they use 2-4 % of a tile (0.15-0.32 ms each for 16-32 MB of operands).  Here a thread owns a
+// pixel stride and keeps all K x G products (K = KH*KW*Cin taps, G output channels of its group) in registers: HBM-bound streaming with
+// unconditional, clamped tap loads; the block's sums go out as one slab, summed by the common reduction. ----
+template <typename T, int KH, int CIN, int G, int S>
+__global__ __launch_bounds__(256) void conv_wgrad_tiny_kernel(WgradArgs a) {
+  constexpr int K = KH * KH * CIN, VE = Elem<T>::VE;
+  __shared__ float red[4][K * G];
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  const int co0 = blockIdx.y * G;
+  const int64_t per = cdiv((int64_t)a.M, (int64_t)gridDim.x);
+  const int64_t mbeg = (int64_t)blockIdx.x * per, mend = mbeg + per < a.M ? mbeg + per : a.M;
+  const T* x = (const T*)a.src1;
+  const T* dy = (const T*)a.dy;
+  float acc[K][G];
+#pragma unroll
+  for (int k = 0; k < K; k++)
+#pragma unroll
+    for (int e = 0; e < G; e++) acc[k][e] = 0.f;
+  for (int64_t m = mbeg + t; m < mend; m += 256) {
+    const int ow = (int)(m % a.OW); const int64_t q = m / a.OW; const int oh = (int)(q % a.OH); const int n = (int)(q / a.OH);
+    float g[G];
+#pragma unroll
+    for (int e = 0; e < G; e++) {
+      const bool ok = co0 + e < a.Cout;
+      const float v = Elem<T>::ld(dy + m * a.Cout + (ok ? co0 + e : 0));
+      g[e] = ok ? v : 0.f;
+    }
+#pragma unroll
+    for (int kh = 0; kh < KH; kh++)
+#pragma unroll
+      for (int kw = 0; kw < KH; kw++) {
+        const int ih = oh * S - a.pad + kh, iw = ow * S - a.pad + kw;
+        const bool ok = (unsigned)ih < (unsigned)a.Hin && (unsigned)iw < (unsigned)a.Win;
+        const T* px = x + (((int64_t)n * a.Hin + min(max(ih, 0), a.Hin - 1)) * a.Win + min(max(iw, 0), a.Win - 1)) * CIN;
+        float xv[CIN];
+        if constexpr (CIN % VE == 0) {
+#pragma unroll
+          for (int c = 0; c < CIN; c += VE) {
+            float v[VE];
+            ldv(px + c, v);
+#pragma unroll
+            for (int e = 0; e < VE; e++) xv[c + e] = ok ? v[e] : 0.f;
+          }
+        } else {
+#pragma unroll
+          for (int c = 0; c < CIN; c++) { const float v = Elem<T>::ld(px + c); xv[c] = ok ? v : 0.f; }
+        }
+#pragma unroll
+        for (int c = 0; c < CIN; c++)
+#pragma unroll
+          for (int e = 0; e < G; e++) acc[(kh * KH + kw) * CIN + c][e] += xv[c] * g[e];
+      }
+  }
+#pragma unroll
+  for (int k = 0; k < K; k++)
+#pragma unroll
+    for (int e = 0; e < G; e++) {
+      const float v = wave_sum(acc[k][e]);
+      if (lane == 0) red[wv][k * G + e] = v;
+    }
+  __syncthreads();
+  for (int i = t; i < K * G; i += 256) {
+    const int k = i / G, e = i - k * G;
+    if (co0 + e < a.Cout)
+      a.slab[((int64_t)blockIdx.x * a.Cout + co0 + e) * K + k] = (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]);
+  }
+}
+// -> number of slabs written (0: shape not handled here)
+static bool wgrad_tiny_shape(const WgradArgs& a) {
+  const char* e = getenv("RD_WGRAD_TINY_MIN_M");      // test hook: 0 sends small cases through this kernel
+  const int min_m = e ? atoi(e) : (1 << 16);
+  if (a.ups || a.C2 || a.KH != a.KW || a.M < min_m || wgrad_slabs(a.M, a.K, a.Cout) < HALO_BLOCKS) return false;
+  // (the 3->32 stride-2 stem was tried here too, 8 groups of 4 output channels: 0.33 ms against 0.15 ms on the generic kernel -- every
+  // group re-reads the 27-tap patch -- so it stays there)
+  return (a.KH == 3 && a.C1 == 3 && a.stride == 1 && a.Cout <= 4) || (a.KH == 1 && a.C1 == 32 && a.stride == 1 && a.Cout == 1);
+}
+bool wgrad_streams(const WgradArgs& a) { return wgrad_tiny_shape(a); }
+template <typename T>
+static int launch_wgrad_tiny(const WgradArgs& a, hipStream_t st) {
+  if (!wgrad_tiny_shape(a)) return 0;
+  const int nblk = (int)std::min<int64_t>(HALO_BLOCKS, cdiv(a.M, 256 * 4));      // the workspace holds >= HALO_BLOCKS slabs for these shapes
+#define RD_TINY(KHV, CINV, GV, SV) { dim3 grid((unsigned)nblk, (unsigned)cdiv(a.Cout, GV));                                       \
+    hipLaunchKernelGGL((conv_wgrad_tiny_kernel<T, KHV, CINV, GV, SV>), grid, dim3(256), 0, st, a); return nblk; }
+  if (a.KH == 3 && a.C1 == 3 && a.stride == 1 && a.Cout <= 4) { if (a.Cout <= 3) RD_TINY(3, 3, 3, 1) else RD_TINY(3, 3, 4, 1) }
+  if (a.KH == 1 && a.C1 == 32 && a.stride == 1 && a.Cout == 1) RD_TINY(1, 32, 1, 1)
+#undef RD_TINY
+  return 0;
+}
+
 void launch_wgrad_reduce_batch(const WgradReduceItem* items, int n, hipStream_t st) {
   int i = 0;
   while (i < n) {
@@ -1022,6 +1111,10 @@ void launch_wgrad(WgradArgs a, int dtype, float* dw, int accumulate, hipStream_t
                  defer->nsplit = nsplit; defer->accumulate = accumulate; }
     else launch_wgrad_reduce(a.slab, dw, a.Cout, Cin, a.KH, a.KW, nsplit, accumulate, st);
   };
+  if (wgrad_tiny_shape(a)) {      // few channels, millions of pixels: register-accumulating streaming kernel
+    const int ns = dtype == 0 ? launch_wgrad_tiny<float>(a, st) : launch_wgrad_tiny<bf16_t>(a, st);
+    if (ns) { reduce(ns); return; }
+  }
   if (wgrad3x3_tr_ok(a, dtype)) {  // bf16 narrow layers: transpose-read kernel, one slab per persistent block (<= HALO_BLOCKS)
     launch_wgrad3x3_tr(a, st);
     reduce(wgrad3x3_tr_blocks(a));

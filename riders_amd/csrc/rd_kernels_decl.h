@@ -30,6 +30,7 @@ void launch_conv3x3_c1(const ConvArgs& a, int dtype, hipStream_t st);
 void launch_pack_weights(const float* w, void* out, int Cout, int Cin, int KH, int KW, int mode, int dtype, hipStream_t st, int CinSrc = 0);
 void launch_pack_weights_batch(const void* items, int n, hipStream_t st);
 void launch_wgrad(WgradArgs a, int dtype, float* dw, int accumulate, hipStream_t st, WgradReduceItem* defer);
+bool wgrad_streams(const WgradArgs& a);
 void launch_wgrad_reduce_batch(const WgradReduceItem* items, int n, hipStream_t st);
 
 // rd_wgrad3x3.hip

@@ -636,7 +636,7 @@ def conv_block(x, weight, *, x2=None, bias=None, stride=1, pad=None, up=None, bn
         cin_pad = (C1 + ve - 1) // ve * ve
         xp = torch.empty((N, H1, W1, cin_pad), dtype=x.dtype, device=x.device)
         _chk(lib.rd_pad_channels(_p(x), _p(xp), N * H1 * W1, C1, cin_pad, dt, st), "rd_pad_channels")
-        x, C1_real, C1 = xp, C1, cin_pad
+        x_real, x, C1_real, C1 = x, xp, C1, cin_pad
     d = _desc(dt, N, Hin, Win, C1, C2, is_up, H1, W1, Cout, KH, KW, stride, pad, 1, OH, OW, conv_act, slope, Cout)
     wp = packed_weight(weight, 0, dt, cin_pad)
     y = torch.empty((N, OH, OW, Cout), dtype=x.dtype, device=x.device)
@@ -732,7 +732,13 @@ def conv_block(x, weight, *, x2=None, bias=None, stride=1, pad=None, up=None, bn
         elif w_req:
             dw, acc = t.param_grad(weight)
             ws = torch.empty(lib.rd_conv_wgrad_workspace_bytes(ctypes.byref(d)) // 4, dtype=torch.float32, device=x.device)
-            if cin_pad:   # gradient w.r.t. the zero-padded weight, then drop the padded input channels
+            d_real = _desc(dt, N, Hin, Win, C1_real, 0, False, Hin, Win, Cout, KH, KW, stride, pad, 1, OH, OW, conv_act, slope, Cout) if cin_pad else None
+            if cin_pad and lib.rd_conv_wgrad_streams(ctypes.byref(d_real)):
+                # few channels, millions of pixels: the streaming weight-gradient kernel reads the un-padded tensor directly
+                ws = torch.empty(lib.rd_conv_wgrad_workspace_bytes(ctypes.byref(d_real)) // 4, dtype=torch.float32, device=x.device)
+                _chk(_timed("conv_wgrad", flops, lambda: lib.rd_conv_wgrad(ctypes.byref(d_real), _p(x_real), None, _p(dy), _p(ws), _p(dw), acc, st),
+                            "wgrad " + shp, b_in + b_out + weight.numel() * 4), "rd_conv_wgrad")
+            elif cin_pad:   # gradient w.r.t. the zero-padded weight, then drop the padded input channels
                 dwp = torch.empty((Cout, cin_pad, KH, KW), dtype=torch.float32, device=x.device)
                 _chk(_timed("conv_wgrad", flops, lambda: lib.rd_conv_wgrad(ctypes.byref(d), _p(x), None, _p(dy), _p(ws), _p(dwp), 0, st),
                             "wgrad " + shp, b_in + b_out + weight.numel() * 4), "rd_conv_wgrad")

@@ -142,6 +142,23 @@ class force_patch_conv:
                 os.environ[k] = v
 
 
+class force_tiny_wgrad(force_patch_conv):
+    """Send the few-channel weight gradients (3->3, 3->32 stride 2, 32->1) through the register-accumulating streaming kernel at any size."""
+    def __init__(self):
+        self.env = {"RD_WGRAD_TINY_MIN_M": "0"}
+
+
+def tiny_wgrad_cases(dev):
+    """SML's `first` 3->3 convolution (without input gradient: the padded-stem route must hand over the un-padded tensor; and with) and the
+    32->1 1x1 head, fp32 against the oracle; then bf16 on integer data, exact."""
+    with force_tiny_wgrad():
+        conv_case(dev, dict(cin=3, cout=3, k=3, s=1, H=19, W=23, N=2, bn=True, no_input_grad=True))
+        conv_case(dev, dict(cin=3, cout=4, k=3, s=1, H=11, W=9, N=2, bn=True))
+        conv_case(dev, dict(cin=32, cout=1, k=1, s=1, H=21, W=17, N=3, bn=False, act=None))
+        bf16_exact_conv_case(dev, cin=3, cout=3, k=3, s=1, H=14, W=10, N=2)
+        bf16_exact_conv_case(dev, cin=32, cout=1, k=1, s=1, H=9, W=11, N=2)
+
+
 class force_dma_conv(force_patch_conv):
     """Route eligible wide bf16 3x3 layers to the experimental LDS-DMA / 32x32x16-MFMA kernel (rd_conv3x3_dma.hip), any block count;
     `mode` selects the weight staging variant (RD_DMA_MODE)."""

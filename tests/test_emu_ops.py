@@ -208,3 +208,7 @@ def test_roi_pool_gather_rcnet_geometry(emu):
 
 def test_wgrad_reduce_batch(emu):
     P.wgrad_reduce_batch_case(emu)
+
+
+def test_streaming_weight_gradient_of_few_channel_layers(emu):
+    P.tiny_wgrad_cases(emu)

@@ -405,3 +405,7 @@ def test_roi_pool_gather_rcnet_geometry(gpu):
 
 def test_wgrad_reduce_batch(gpu):
     P.wgrad_reduce_batch_case(gpu)
+
+
+def test_streaming_weight_gradient_of_few_channel_layers(gpu):
+    P.tiny_wgrad_cases(gpu)
