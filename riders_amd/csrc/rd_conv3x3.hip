@@ -417,7 +417,6 @@ __global__ __launch_bounds__(256) void conv1x1_direct_kernel(ConvArgs a) {
   const int fr = lane & 15, fg = lane >> 4;
   const int n0 = blockIdx.y * BN;
   const int Cin = a.C1;
-  const int64_t m0 = (int64_t)blockIdx.x * 128 + wv * 32;
   uint4 wr[CT][STEPS];
   {
     const uint4* wp = reinterpret_cast<const uint4*>(a.w);
@@ -427,42 +426,70 @@ __global__ __launch_bounds__(256) void conv1x1_direct_kernel(ConvArgs a) {
 #pragma unroll
       for (int s = 0; s < STEPS; s++) { const uint4 v = wp[(int64_t)(n0 + c * 16 + fr) * kslots + s * 4 + fg]; wr[c][s] = v; }
   }
-  uint4 pf[2][STEPS];
-  int64_t mm[2]; bool mvv[2];
+  // PERSISTENT over 128-pixel tiles (blockIdx.x, + gridDim.x, ...): the weight fragments are loaded once, the BatchNorm partial sums of all
+  // the block's tiles stay in registers and go through ONE block reduction at the end, and the next tile's pixel fragments are requested
+  // before the current tile is multiplied and stored.  As one tile per block the kernel spent ~775 vector + ~200 LDS instructions per wave
+  // (16 MFMAs) almost entirely in the per-tile statistics reduction and ran at 1.0-1.1 TB/s on 0.2-GB outputs (PMC, round 2).
+  const int ntiles = (int)cdiv(a.M, 128);
+  float ssum[CT][4], ssq[CT][4];
 #pragma unroll
-  for (int pt = 0; pt < 2; pt++) {
-    mm[pt] = m0 + pt * 16 + fr;
-    mvv[pt] = mm[pt] < a.M;
+  for (int c = 0; c < CT; c++)
 #pragma unroll
-    for (int s = 0; s < STEPS; s++) {
-      uint4 v = make_uint4(0, 0, 0, 0);
-      const int ci = (s * 4 + fg) * VE;
-      if (mvv[pt] && ci < Cin) v = *reinterpret_cast<const uint4*>((const T*)a.src1 + mm[pt] * Cin + ci);
-      pf[pt][s] = v;
-    }
-  }
-  f32x4 acc[CT][2];
+    for (int r = 0; r < 4; r++) { ssum[c][r] = 0.f; ssq[c][r] = 0.f; }
+  auto fetch = [&](int tile, uint4 (&pf)[2][STEPS]) RD_INLINE_LAMBDA {
+    const int64_t m0 = (int64_t)tile * 128 + wv * 32;
 #pragma unroll
-  for (int c = 0; c < CT; c++) { acc[c][0] = f32x4{0, 0, 0, 0}; acc[c][1] = f32x4{0, 0, 0, 0}; }
+    for (int pt = 0; pt < 2; pt++) {
+      const int64_t m = m0 + pt * 16 + fr;
+      const int64_t mc = m < a.M ? m : a.M - 1;
 #pragma unroll
-  for (int s = 0; s < STEPS; s++)
-#pragma unroll
-    for (int c = 0; c < CT; c++)
-#pragma unroll
-      for (int pt = 0; pt < 2; pt++) {
-        if (sizeof(T) == 4) {
-          acc[c][pt] = mfma_16x16x4_f32(__uint_as_float(wr[c][s].x), __uint_as_float(pf[pt][s].x), acc[c][pt]);
-          acc[c][pt] = mfma_16x16x4_f32(__uint_as_float(wr[c][s].y), __uint_as_float(pf[pt][s].y), acc[c][pt]);
-          acc[c][pt] = mfma_16x16x4_f32(__uint_as_float(wr[c][s].z), __uint_as_float(pf[pt][s].z), acc[c][pt]);
-          acc[c][pt] = mfma_16x16x4_f32(__uint_as_float(wr[c][s].w), __uint_as_float(pf[pt][s].w), acc[c][pt]);
-        } else {
-          s16x8 wa, pb;
-          __builtin_memcpy(&wa, &wr[c][s], 16);
-          __builtin_memcpy(&pb, &pf[pt][s], 16);
-          acc[c][pt] = mfma_16x16x32_bf16(wa, pb, acc[c][pt]);
-        }
+      for (int s = 0; s < STEPS; s++) {
+        const int ci = (s * 4 + fg) * VE;
+        const bool ok = m < a.M && ci < Cin;
+        // unconditional load from a clamped address, zeroed afterwards (the k axis is padded to the MFMA depth with zeros)
+        const uint4 v = *reinterpret_cast<const uint4*>((const T*)a.src1 + mc * Cin + (ci < Cin ? ci : 0));
+        pf[pt][s] = ok ? v : make_uint4(0, 0, 0, 0);
       }
-  conv_epilogue<T, CT, BN, 4>(a, acc, mm, mvv, n0, 0, wv, fr, fg, t, blockIdx.x, red);
+    }
+  };
+  uint4 pa[2][STEPS], pb[2][STEPS];
+  int tile = blockIdx.x;
+  if (tile < ntiles) fetch(tile, pa);
+  while (tile < ntiles) {
+    const int nxt = tile + gridDim.x;
+    if (nxt < ntiles) fetch(nxt, pb);
+    int64_t mm[2]; bool mvv[2];
+#pragma unroll
+    for (int pt = 0; pt < 2; pt++) { mm[pt] = (int64_t)tile * 128 + wv * 32 + pt * 16 + fr; mvv[pt] = mm[pt] < a.M; }
+    f32x4 acc[CT][2];
+#pragma unroll
+    for (int c = 0; c < CT; c++) { acc[c][0] = f32x4{0, 0, 0, 0}; acc[c][1] = f32x4{0, 0, 0, 0}; }
+#pragma unroll
+    for (int s = 0; s < STEPS; s++)
+#pragma unroll
+      for (int c = 0; c < CT; c++)
+#pragma unroll
+        for (int pt = 0; pt < 2; pt++) {
+          if (sizeof(T) == 4) {
+            acc[c][pt] = mfma_16x16x4_f32(__uint_as_float(wr[c][s].x), __uint_as_float(pa[pt][s].x), acc[c][pt]);
+            acc[c][pt] = mfma_16x16x4_f32(__uint_as_float(wr[c][s].y), __uint_as_float(pa[pt][s].y), acc[c][pt]);
+            acc[c][pt] = mfma_16x16x4_f32(__uint_as_float(wr[c][s].z), __uint_as_float(pa[pt][s].z), acc[c][pt]);
+            acc[c][pt] = mfma_16x16x4_f32(__uint_as_float(wr[c][s].w), __uint_as_float(pa[pt][s].w), acc[c][pt]);
+          } else {
+            s16x8 wa, pbv;
+            __builtin_memcpy(&wa, &wr[c][s], 16);
+            __builtin_memcpy(&pbv, &pa[pt][s], 16);
+            acc[c][pt] = mfma_16x16x32_bf16(wa, pbv, acc[c][pt]);
+          }
+        }
+    conv_epilogue_store<T, CT>(a, acc, mm, mvv, n0, 0, fr, fg, ssum, ssq);
+    tile = nxt;
+#pragma unroll
+    for (int pt = 0; pt < 2; pt++)
+#pragma unroll
+      for (int s = 0; s < STEPS; s++) pa[pt][s] = pb[pt][s];
+  }
+  conv_epilogue_stats<CT, BN, 4>(a, ssum, ssq, n0, 0, wv, fr, fg, t, blockIdx.x, red);
 }
 
 // ---- single input channel (data gradient of a Cout = 1 head): direct form, one pixel per thread ---------------------------------------
@@ -597,13 +624,15 @@ bool conv1x1_direct_ok(const ConvArgs& a, int dtype) {
   return a.KH == 1 && a.KW == 1 && a.stride == 1 && a.pad == 0 && a.dil == 1 && a.C2 == 0 && !a.ups && a.OH == a.Hin && a.OW == a.Win &&
          (a.C1 % ve) == 0 && a.C1 * es <= 128 && a.M >= conv1x1_min_m();
 }
-int conv1x1_direct_rows(const ConvArgs& a) { return (int)cdiv(a.M, 128); }
+int conv1x1_direct_rows(const ConvArgs& a) { return (int)std::min<int64_t>(cdiv(a.M, 128), 1024); }   // persistent blocks = statistics rows
 void launch_conv1x1_direct(const ConvArgs& a, int dtype, hipStream_t st) {
-  const int bn = pick_bn3(a.Cout), es = dtype == 0 ? 4 : 2;
+  // at most 64 output channels per block: the persistent form keeps 2 x 4 x BN/16 statistics registers next to the accumulators and the
+  // weight fragments (BN = 128: 232-304 VGPRs, one or two waves per SIMD); the input re-read per channel block is the small operand here
+  const int bn = std::min(64, pick_bn3(a.Cout)), es = dtype == 0 ? 4 : 2;
   const int steps = a.C1 * es <= 64 ? 1 : 2;
-  dim3 grid((unsigned)cdiv(a.M, 128), (unsigned)cdiv(a.Cout, bn));
+  dim3 grid((unsigned)conv1x1_direct_rows(a), (unsigned)cdiv(a.Cout, bn));
 #define RD_P1(TT, BNV, SV) hipLaunchKernelGGL((conv1x1_direct_kernel<TT, BNV, SV>), grid, dim3(256), 0, st, a)
-#define RD_P1B(TT, SV) { if (bn == 16) RD_P1(TT, 16, SV); else if (bn == 32) RD_P1(TT, 32, SV); else if (bn == 64) RD_P1(TT, 64, SV); else RD_P1(TT, 128, SV); }
+#define RD_P1B(TT, SV) { if (bn == 16) RD_P1(TT, 16, SV); else if (bn == 32) RD_P1(TT, 32, SV); else RD_P1(TT, 64, SV); }
   if (dtype == 0) { if (steps == 1) RD_P1B(float, 1) else RD_P1B(float, 2) }
   else { if (steps == 1) RD_P1B(bf16_t, 1) else RD_P1B(bf16_t, 2) }
 #undef RD_P1B
