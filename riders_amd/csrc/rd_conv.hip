@@ -73,6 +73,8 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs a) {
 
   uint4 ra[WM]; uint4 rb[BITER];
   uint4 ra2[DEEP ? WM : 1]; uint4 rb2[DEEP ? BITER : 1];
+  uint4 ra3[DEEP ? WM : 1]; uint4 rb3[DEEP ? BITER : 1];
+  uint4 ra4[DEEP ? WM : 1]; uint4 rb4[DEEP ? BITER : 1];
 
   auto load_tile = [&](int kt, uint4 (&ra)[WM], uint4 (&rb)[BITER]) RD_INLINE_LAMBDA {
 #pragma unroll
@@ -171,22 +173,39 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs a) {
       __syncthreads();
     }
   } else {
-    auto& xa = reinterpret_cast<uint4 (&)[WM]>(ra2); auto& xb = reinterpret_cast<uint4 (&)[BITER]>(rb2);
-    load_tile(0, ra, rb);
-    store_tile(0, ra, rb);
-    if (nk > 1) load_tile(1, ra, rb);      // set A: stage 1
-    if (nk > 2) load_tile(2, xa, xb);      // set B: stage 2
+    // FOUR register sets: stages kt+1 .. kt+4 are in flight while stage kt is multiplied (two sets left every stage waiting ~half an L2
+    // round trip: the small-M / long-K launches this path serves are pure latency chains).  Stage kt sits in LDS buffer kt & 1.
+    auto& a1 = ra; auto& b1 = rb;
+    auto& a2 = reinterpret_cast<uint4 (&)[WM]>(ra2); auto& b2 = reinterpret_cast<uint4 (&)[BITER]>(rb2);
+    auto& a3 = reinterpret_cast<uint4 (&)[WM]>(ra3); auto& b3 = reinterpret_cast<uint4 (&)[BITER]>(rb3);
+    auto& a4 = reinterpret_cast<uint4 (&)[WM]>(ra4); auto& b4 = reinterpret_cast<uint4 (&)[BITER]>(rb4);
+    load_tile(0, a1, b1);
+    store_tile(0, a1, b1);
+    if (nk > 1) load_tile(1, a1, b1);
+    if (nk > 2) load_tile(2, a2, b2);
+    if (nk > 3) load_tile(3, a3, b3);
+    if (nk > 4) load_tile(4, a4, b4);
     __syncthreads();
-    for (int kt = 0; kt < nk; kt += 2) {   // stage kt sits in LDS buffer 0
+    for (int kt = 0; kt < nk; kt += 4) {
       compute(0);
-      if (kt + 1 < nk) store_tile(1, ra, rb);
+      if (kt + 1 < nk) store_tile(1, a1, b1);
       __syncthreads();
-      if (kt + 3 < nk) load_tile(kt + 3, ra, rb);
+      if (kt + 5 < nk) load_tile(kt + 5, a1, b1);
       if (kt + 1 >= nk) break;
       compute(1);
-      if (kt + 2 < nk) store_tile(0, xa, xb);
+      if (kt + 2 < nk) store_tile(0, a2, b2);
       __syncthreads();
-      if (kt + 4 < nk) load_tile(kt + 4, xa, xb);
+      if (kt + 6 < nk) load_tile(kt + 6, a2, b2);
+      if (kt + 2 >= nk) break;
+      compute(0);
+      if (kt + 3 < nk) store_tile(1, a3, b3);
+      __syncthreads();
+      if (kt + 7 < nk) load_tile(kt + 7, a3, b3);
+      if (kt + 3 >= nk) break;
+      compute(1);
+      if (kt + 4 < nk) store_tile(0, a4, b4);
+      __syncthreads();
+      if (kt + 8 < nk) load_tile(kt + 8, a4, b4);
     }
   }
 
