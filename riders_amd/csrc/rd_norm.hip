@@ -15,6 +15,18 @@
 
 namespace rd {
 
+// one channel's (a, b) partials summed over the rows by a block's 256 threads: four independent 8-byte loads in flight per thread (a plain
+// `for (r = t; r < rows; r += 256)` loop is a chain of dependent round trips: 17 us for the 13 K rows of a one-row-per-tile producer)
+__device__ __forceinline__ void bn_rows_sum(const float2* __restrict__ p2, int rows, int C, int c, int t, double& a, double& b) {
+  int r = t;
+  for (; r + 768 < rows; r += 1024) {
+    const float2 v0 = p2[(int64_t)r * C + c], v1 = p2[(int64_t)(r + 256) * C + c], v2 = p2[(int64_t)(r + 512) * C + c], v3 = p2[(int64_t)(r + 768) * C + c];
+    a += ((double)v0.x + (double)v1.x) + ((double)v2.x + (double)v3.x);
+    b += ((double)v0.y + (double)v1.y) + ((double)v2.y + (double)v3.y);
+  }
+  for (; r < rows; r += 256) { const float2 v = p2[(int64_t)r * C + c]; a += (double)v.x; b += (double)v.y; }
+}
+
 // ---- BN finalize: partial[rows][C][2] -> mean/rstd + fused scale/shift, running-stat update ----
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ partial, int rows, int C, double count,
                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -28,7 +40,7 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restric
     // float2 loads, lanes stride over the partial rows; wave shuffle + 4-entry LDS combine (fixed order, double precision)
     const float2* p2 = reinterpret_cast<const float2*>(partial);
     double a = 0.0, b = 0.0;
-    for (int r = t; r < rows; r += 256) { const float2 v = p2[(int64_t)r * C + c]; a += (double)v.x; b += (double)v.y; }
+    bn_rows_sum(p2, rows, C, c, t, a, b);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
     if ((t & 63) == 0) { s1[t >> 6] = a; s2[t >> 6] = b; }
@@ -149,7 +161,7 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __res
   const int c = blockIdx.x, t = threadIdx.x;
   const float2* p2 = reinterpret_cast<const float2*>(partial);
   double a = 0.0, b = 0.0;
-  for (int r = t; r < rows; r += 256) { const float2 v = p2[(int64_t)r * C + c]; a += (double)v.x; b += (double)v.y; }
+  bn_rows_sum(p2, rows, C, c, t, a, b);
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
   if ((t & 63) == 0) { s1[t >> 6] = a; s2[t >> 6] = b; }
