@@ -122,6 +122,11 @@ def family_roofline(timer, timed_steps, ms_per_step, dtype, traffic_key):
             roof["traffic"] = tr["bytes_per_step"] / max(row["launches_per_step"], 1e-9)
             roof["traffic_over_algorithmic"] = tr["bytes_per_step"] / max((f["bytes"] / timed_steps), 1.0)
             roof["traffic_source"] = tr.get("note", "")
+            # the counters come from separate rocprofv3 passes (they cannot be collected inside this run): say so when the kernel sources
+            # have changed since those passes
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            from traffic_aggregate import csrc_fingerprint
+            roof["traffic_stale"] = json.load(open(TRAFFIC_FILE)).get(traffic_key, {}).get("_csrc_sha1") != csrc_fingerprint(ROOT)
     except (OSError, ValueError):
         pass
     return roof

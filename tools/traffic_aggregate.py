@@ -22,6 +22,17 @@ FAMILIES = [
 ]
 
 
+def csrc_fingerprint(root):
+    """sha1 over the kernel sources (riders_amd/csrc/*.hip, *.h, *.cpp): identifies the build the counters were taken on."""
+    import hashlib
+    h = hashlib.sha1()
+    d = os.path.join(root, "riders_amd", "csrc")
+    for fn in sorted(os.listdir(d)):
+        if fn.endswith((".hip", ".h", ".cpp")):
+            h.update(fn.encode()); h.update(open(os.path.join(d, fn), "rb").read())
+    return h.hexdigest()
+
+
 def family(name):
     if "rd::" not in name:
         return None
@@ -68,10 +79,11 @@ def main():
     db[cfgkey] = {fam: dict(fetch_bytes_per_step=2.0 * fetch.get(fam, 0.0) / steps, write_bytes_per_step=write.get(fam, 0.0) / steps,
                             bytes_per_step=(2.0 * fetch.get(fam, 0.0) + write.get(fam, 0.0)) / steps, note=note)
                   for fam in sorted(set(fetch) | set(write))}
+    db[cfgkey]["_csrc_sha1"] = csrc_fingerprint(root)      # bench.py reports the figures as stale when the kernel sources have changed since
     db[cfgkey]["_kernels"] = {k: dict(fetch_bytes_per_step=2.0 * fk.get(k, 0.0) / steps, write_bytes_per_step=wk.get(k, 0.0) / steps)
                               for k in sorted(set(fk) | set(wk))}
     json.dump(db, open(path, "w"), indent=1, sort_keys=True)
-    print("traffic:", cfgkey, {k: round(v["bytes_per_step"] / 1e6, 1) for k, v in db[cfgkey].items() if k != "_kernels"}, "MB/step")
+    print("traffic:", cfgkey, {k: round(v["bytes_per_step"] / 1e6, 1) for k, v in db[cfgkey].items() if not k.startswith("_")}, "MB/step")
 
 
 if __name__ == "__main__":
