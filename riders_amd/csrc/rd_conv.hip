@@ -76,16 +76,22 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs a) {
   uint4 ra3[DEEP ? WM : 1]; uint4 rb3[DEEP ? BITER : 1];
   uint4 ra4[DEEP ? WM : 1]; uint4 rb4[DEEP ? BITER : 1];
 
+  const int nk_ = a.Kpad / BKE;      // stages; a request past the last one (issued unconditionally by the deep path) re-reads the last weights
   auto load_tile = [&](int kt, uint4 (&ra)[WM], uint4 (&rb)[BITER]) RD_INLINE_LAMBDA {
 #pragma unroll
     for (int i = 0; i < WM; i++) {
       uint4 v = make_uint4(0, 0, 0, 0);
-      if (rn[i] >= 0) {
-        if (VEC) {
-          const T* p;
-          if (kkh < a.KH && conv_src_ptr<T>(a, rn[i], rih[i] + kkh, riw[i] + kkw, kci, p))
-            v = *reinterpret_cast<const uint4*>(p);
-        } else {
+      if (VEC) {
+        // unconditional load (an element that does not exist reads the tensor's first vector and is zeroed afterwards): behind a branch
+        // the compiler cannot count the requests in flight and waits for ALL of them (vmcnt(0)) before every LDS store, which turned the
+        // multi-stage prefetch of the small-M path into one memory round trip per stage
+        const T* p;
+        const bool inb = conv_src_ptr_nb<T>(a, rn[i] >= 0 ? rn[i] : 0, rih[i] + kkh, riw[i] + kkw, kkh < a.KH ? kci : 0, p);
+        const bool ok = inb & (rn[i] >= 0) & (kkh < a.KH);
+        const uint4 lv = *reinterpret_cast<const uint4*>(p);
+        v.x = ok ? lv.x : 0u; v.y = ok ? lv.y : 0u; v.z = ok ? lv.z : 0u; v.w = ok ? lv.w : 0u;
+      } else if (rn[i] >= 0) {
+        {
           T tmp[VE];
 #pragma unroll
           for (int e = 0; e < VE; e++) {
@@ -110,7 +116,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs a) {
       int idx = t + 256 * i;
       if (BN * 8 % 256 == 0 || idx < BN * 8) {  // compile-time when the tile divides evenly: a runtime guard parks rb[] in scratch
         int row = idx >> 3, sl = idx & 7;
-        const uint4 v = wp[(int64_t)(n0 + row) * kslots + kt * 8 + sl];  // via a value: a direct global->array struct copy stays a memcpy
+        const uint4 v = wp[(int64_t)(n0 + row) * kslots + min(kt, nk_ - 1) * 8 + sl];  // via a value: a direct global->array struct copy stays a memcpy
         rb[i] = v;                                                        // through a private alloca (scratch / LDS-promoted)
       }
     }
@@ -179,33 +185,35 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs a) {
     auto& a2 = reinterpret_cast<uint4 (&)[WM]>(ra2); auto& b2 = reinterpret_cast<uint4 (&)[BITER]>(rb2);
     auto& a3 = reinterpret_cast<uint4 (&)[WM]>(ra3); auto& b3 = reinterpret_cast<uint4 (&)[BITER]>(rb3);
     auto& a4 = reinterpret_cast<uint4 (&)[WM]>(ra4); auto& b4 = reinterpret_cast<uint4 (&)[BITER]>(rb4);
+    // every load_tile below is issued UNCONDITIONALLY (stages past the end fetch clamped, unused data): only then does the compiler know
+    // how many requests are younger than the set it is about to store and waits for exactly that set
     load_tile(0, a1, b1);
     store_tile(0, a1, b1);
-    if (nk > 1) load_tile(1, a1, b1);
-    if (nk > 2) load_tile(2, a2, b2);
-    if (nk > 3) load_tile(3, a3, b3);
-    if (nk > 4) load_tile(4, a4, b4);
+    load_tile(1, a1, b1);
+    load_tile(2, a2, b2);
+    load_tile(3, a3, b3);
+    load_tile(4, a4, b4);
     __syncthreads();
     for (int kt = 0; kt < nk; kt += 4) {
       compute(0);
-      if (kt + 1 < nk) store_tile(1, a1, b1);
+      store_tile(1, a1, b1);          // stage kt + 1 (garbage past the end, never multiplied)
       __syncthreads();
-      if (kt + 5 < nk) load_tile(kt + 5, a1, b1);
+      load_tile(kt + 5, a1, b1);
       if (kt + 1 >= nk) break;
       compute(1);
-      if (kt + 2 < nk) store_tile(0, a2, b2);
+      store_tile(0, a2, b2);
       __syncthreads();
-      if (kt + 6 < nk) load_tile(kt + 6, a2, b2);
+      load_tile(kt + 6, a2, b2);
       if (kt + 2 >= nk) break;
       compute(0);
-      if (kt + 3 < nk) store_tile(1, a3, b3);
+      store_tile(1, a3, b3);
       __syncthreads();
-      if (kt + 7 < nk) load_tile(kt + 7, a3, b3);
+      load_tile(kt + 7, a3, b3);
       if (kt + 3 >= nk) break;
       compute(1);
-      if (kt + 4 < nk) store_tile(0, a4, b4);
+      store_tile(0, a4, b4);
       __syncthreads();
-      if (kt + 8 < nk) load_tile(kt + 8, a4, b4);
+      load_tile(kt + 8, a4, b4);
     }
   }
 
@@ -895,6 +903,10 @@ static void conv_tiles(int M, int Cout, int& bn, int& wm) {
   if (bn >= 32 && cdiv(M, BM) * cdiv(Cout, bn) < 384) {
     wm = 2;
     if (bn == 128 && cdiv(M, 64) * cdiv(Cout, bn) < 384) bn = 64;
+    // still fewer blocks than CUs (a few hundred rows: RC-Net's FullyConnected layers, the deep encoder stages on 8 x 16 maps): narrower
+    // channel tiles.  Such a launch is a chain of stages whose length is the MFMA work of ONE block per stage (measured: 1.1 us per fp32
+    // stage at 64 channels whatever the prefetch depth), so spreading the channels over more CUs shortens every stage.
+    if (bn == 64 && cdiv(M, 64) * cdiv(Cout, bn) < 128) bn = 32;
   }
 }
 int conv_block_pixels(int M, int Cout) { int bn, wm; conv_tiles(M, Cout, bn, wm); return 32 * wm; }

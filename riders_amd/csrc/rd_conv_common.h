@@ -32,6 +32,31 @@ __device__ __forceinline__ bool conv_src_ptr(const ConvArgs& a, int n, int ih, i
 }
 
 
+// Branch-free form of conv_src_ptr for loaders that must issue their loads unconditionally: ALWAYS yields a dereferenceable pointer (the
+// coordinates are clamped into the tensor) and returns whether the element exists.  No early returns: a load guarded by control flow is
+// sunk into the branch by the compiler, which then cannot count the requests in flight any more.
+template <typename T>
+__device__ __forceinline__ bool conv_src_ptr_nb(const ConvArgs& a, int n, int ih, int iw, int ci, const T*& p) {
+  bool ok = true;
+  if (a.dil > 1) {      // uniform
+    ok = ih >= 0 && iw >= 0 && ((ih % a.dil) | (iw % a.dil)) == 0;
+    ih = (ih < 0 ? 0 : ih) / a.dil; iw = (iw < 0 ? 0 : iw) / a.dil;
+  }
+  ok = ok & ((unsigned)ih < (unsigned)a.Hin) & ((unsigned)iw < (unsigned)a.Win);
+  ih = min(max(ih, 0), a.Hin - 1); iw = min(max(iw, 0), a.Win - 1);
+  int hs = ih, ws = iw, Hp = a.Hin, Wp = a.Win;
+  if (a.ups) {      // uniform
+    hs = min((int)floorf((float)ih * a.scale_h), a.H1 - 1);
+    ws = min((int)floorf((float)iw * a.scale_w), a.W1 - 1);
+    Hp = a.H1; Wp = a.W1;
+  }
+  const bool first = ci < a.C1;
+  const T* base = first ? (const T*)a.src1 : (const T*)a.src2;
+  const int cc = first ? ci : ci - a.C1, cw = first ? a.C1 : a.C2;
+  p = base + ((((int64_t)n * Hp + hs) * Wp + ws) * cw + cc);
+  return ok;
+}
+
 // ---- shared epilogue: bias, activation, NHWC store (dual destination), BatchNorm (sum, sum^2) partials ------------------------------
 // acc[c][pt][r] = output channel n0 + (wn*CT + c)*16 + fg*4 + r of pixel m[pt] (valid iff mv[pt]); WMV waves share the pixel axis.
 // Part 1 stores the tile and ADDS its values into the caller's per-lane statistics registers; part 2 reduces those registers over
@@ -61,6 +86,19 @@ __device__ __forceinline__ void conv_epilogue_store(const ConvArgs& a, f32x4 (&a
   const bool vec_ok = ((a.D1 & 3) == 0) && ((D2 & 3) == 0);
   const bool has_bias = a.bias != nullptr;
   const bool plain = !has_bias && a.act == ACT_NONE;
+  // the lane's bias values, fetched ONCE and unconditionally (clamped index): inside the store loop every `if (co + r < Cout) x += bias[..]`
+  // was a guarded scalar load followed by its own s_waitcnt -- up to 64 dependent memory round trips per tile on the FullyConnected layers
+  float bv[CT][4];
+  if (has_bias) {
+#pragma unroll
+    for (int c = 0; c < CT; c++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int cb = n0 + (wn * CT + c) * 16 + fg * 4 + r;
+        const float b = a.bias[cb < a.Cout ? cb : a.Cout - 1];
+        bv[c][r] = cb < a.Cout ? b : 0.f;
+      }
+  }
 #pragma unroll
   for (int pt = 0; pt < 2; pt++) {
     if (!mv[pt]) continue;
@@ -75,7 +113,7 @@ __device__ __forceinline__ void conv_epilogue_store(const ConvArgs& a, f32x4 (&a
       if (!plain) {
 #pragma unroll
         for (int r = 0; r < 4; r++) {
-          if (has_bias && co + r < a.Cout) x[r] += a.bias[co + r];
+          if (has_bias) x[r] += bv[c][r];
           x[r] = act_fwd(x[r], a.act, a.slope);
         }
       }
