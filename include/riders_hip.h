@@ -129,6 +129,9 @@ int rd_conv_wgrad(const rd_conv_desc* d, const void* src1, const void* src2, con
  * otherwise): rd_conv_wgrad_partial writes the partial slabs into `workspace` and fills *item (host memory); rd_wgrad_reduce_batch sums
  * the slabs of every item into its dw_oihw in the fixed order of rd_conv_wgrad (bit-identical result).  The workspaces must stay
  * untouched until the batch has run; one weight must not appear twice in a batch. */
+/* 1 when rd_conv_fwd runs this shape on the one-pixel-per-thread streaming kernel (a handful of channels, millions of pixels: the SML
+ * `first` 3->3 convolution, the 32->1 head and its data gradient): hand such a layer over WITHOUT zero-padded input channels */
+int32_t rd_conv_fwd_streams(const rd_conv_desc* d);
 /* 1 when rd_conv_wgrad runs this shape on the register-accumulating streaming kernel (a handful of channels, millions of pixels: the SML
  * `first` 3->3 convolution, the 32->1 head): such layers should be handed over WITHOUT zero-padded input channels */
 int32_t rd_conv_wgrad_streams(const rd_conv_desc* d);

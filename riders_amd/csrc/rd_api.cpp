@@ -153,6 +153,12 @@ int32_t rd_conv_stats_rows(const rd_conv_desc* d) {
   return (int32_t)RD_NS(d->dtype, conv_stats_rows)(a, RD_DT(d->dtype));
 }
 
+int32_t rd_conv_fwd_streams(const rd_conv_desc* d) {
+  if (!d || check_desc(d)) return 0;
+  rd::ConvArgs a; fill_args(d, a);
+  return RD_NS(d->dtype, conv_few_ok)(a) ? 1 : 0;
+}
+
 int rd_conv_fwd(const rd_conv_desc* d, const void* src1, const void* src2, const void* w_packed, const float* bias, void* dst1,
                 void* dst2, float* stats, void* stream) {
   if (int e = check_desc(d)) return e;

@@ -951,6 +951,7 @@ static bool use_conv3x3_dma(const ConvArgs& a, int dtype) {   // wide bf16 layer
   return (int64_t)conv3x3_dma_tiles(a) * cdiv(a.Cout, a.Cout <= 32 ? 32 : (a.Cout <= 64 ? 64 : 128)) >= conv3x3_min_blocks();
 }
 int conv_stats_rows(const ConvArgs& a, int dtype) {
+  if (conv_few_ok(a)) return conv_few_blocks(a);
   if (conv1x1_direct_ok(a, dtype)) return conv1x1_direct_rows(a);
   if (use_conv3x3_small(a, dtype)) return conv3x3_small_blocks(a, dtype);   // persistent blocks: one statistics row each
   if (use_conv3x3_dma(a, dtype)) return conv3x3_dma_tiles(a);
@@ -959,6 +960,7 @@ int conv_stats_rows(const ConvArgs& a, int dtype) {
 }
 
 void launch_conv(const ConvArgs& a, int dtype, hipStream_t st) {
+  if (conv_few_ok(a)) { launch_conv_few(a, dtype, st); return; }
   if (conv1x1_direct_ok(a, dtype)) { launch_conv1x1_direct(a, dtype, st); return; }
   if (conv3x3_c1_ok(a)) { launch_conv3x3_c1(a, dtype, st); return; }
   if (use_conv3x3_small(a, dtype)) { launch_conv3x3_small(a, dtype, st); return; }

@@ -639,6 +639,97 @@ void launch_conv1x1_direct(const ConvArgs& a, int dtype, hipStream_t st) {
 #undef RD_P1
 }
 
+// ---- layers with a handful of channels and millions of pixels (SML: the 3 -> 3 `first` convolution, the 32 -> 1 head and its data gradient):
+// on the MFMA kernels they fill 2-4 % of a tile and run 10-15x over their HBM time.  One output pixel per thread, weights in LDS, the
+// taps fetched with unconditional clamped loads, BatchNorm partial sums in registers with one block reduction at the end (rows = blocks).
+template <typename T, int KH, int CIN, int CO>
+__global__ __launch_bounds__(256) void conv_few_kernel(ConvArgs a) {
+  constexpr int K = KH * KH * CIN, R = KH / 2;
+  __shared__ float sw[K * CO];      // [k][cout]
+  __shared__ float red[4][CO * 2];
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  for (int i = t; i < K * CO; i += 256) {
+    const int k = i / CO, co = i - k * CO;
+    sw[i] = co < a.Cout ? Elem<T>::ld((const T*)a.w + (int64_t)co * a.Kpad + k) : 0.f;
+  }
+  __syncthreads();
+  const T* x = (const T*)a.src1;
+  float s1[CO], s2[CO];
+#pragma unroll
+  for (int c = 0; c < CO; c++) { s1[c] = 0.f; s2[c] = 0.f; }
+  float bv[CO];
+#pragma unroll
+  for (int c = 0; c < CO; c++) { const float b = a.bias ? a.bias[c < a.Cout ? c : 0] : 0.f; bv[c] = c < a.Cout ? b : 0.f; }
+  const bool vec = (a.Cout & 3) == 0;
+  for (int64_t m = (int64_t)blockIdx.x * 256 + t; m < a.M; m += (int64_t)gridDim.x * 256) {
+    const int ow = (int)(m % a.OW); const int64_t q = m / a.OW; const int oh = (int)(q % a.OH); const int n = (int)(q / a.OH);
+    float xv[K];
+#pragma unroll
+    for (int kh = 0; kh < KH; kh++)
+#pragma unroll
+      for (int kw = 0; kw < KH; kw++) {
+        const int ih = oh - R + kh, iw = ow - R + kw;
+        const bool ok = (unsigned)ih < (unsigned)a.Hin && (unsigned)iw < (unsigned)a.Win;
+        const T* px = x + (((int64_t)n * a.Hin + min(max(ih, 0), a.Hin - 1)) * a.Win + min(max(iw, 0), a.Win - 1)) * CIN;
+        if constexpr (CIN % Elem<T>::VE == 0) {
+#pragma unroll
+          for (int c = 0; c < CIN; c += Elem<T>::VE) {
+            float v[Elem<T>::VE];
+            ldv(px + c, v);
+#pragma unroll
+            for (int e = 0; e < Elem<T>::VE; e++) xv[(kh * KH + kw) * CIN + c + e] = ok ? v[e] : 0.f;
+          }
+        } else {
+#pragma unroll
+          for (int c = 0; c < CIN; c++) { const float v = Elem<T>::ld(px + c); xv[(kh * KH + kw) * CIN + c] = ok ? v : 0.f; }
+        }
+      }
+    T* d = (T*)a.dst1 + m * a.Cout;
+#pragma unroll
+    for (int c0 = 0; c0 < CO; c0 += 4) {
+      float v[4], vr[4];
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        float acc = 0.f;
+#pragma unroll
+        for (int k = 0; k < K; k++) acc += sw[k * CO + c0 + r] * xv[k];      // ascending-k order
+        v[r] = act_fwd(acc + bv[c0 + r], a.act, a.slope);
+      }
+      if (vec && c0 + 3 < a.Cout) round_store4(d + c0, v, vr);
+      else {
+#pragma unroll
+        for (int r = 0; r < 4; r++) { vr[r] = Elem<T>::rnd(v[r]); if (c0 + r < a.Cout) Elem<T>::st(d + c0 + r, vr[r]); }
+      }
+#pragma unroll
+      for (int r = 0; r < 4; r++) { s1[c0 + r] += vr[r]; s2[c0 + r] += vr[r] * vr[r]; }
+    }
+  }
+  if (!a.stats) return;
+#pragma unroll
+  for (int c = 0; c < CO; c++) {
+    const float u1 = wave_sum(s1[c]), u2 = wave_sum(s2[c]);
+    if (lane == 0) { red[wv][c * 2] = u1; red[wv][c * 2 + 1] = u2; }
+  }
+  __syncthreads();
+  for (int i = t; i < a.Cout * 2; i += 256)
+    a.stats[(int64_t)blockIdx.x * a.Cout * 2 + i] = (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]);
+}
+static int conv_few_min_m() { const char* e = getenv("RD_CONV_FEW_MIN_M"); return e ? atoi(e) : (1 << 16); }   // test hook: 0 forces the kernel
+bool conv_few_ok(const ConvArgs& a) {
+  if (a.KH != a.KW || a.stride != 1 || a.dil != 1 || a.ups || a.C2 || a.D1 != a.Cout || a.OH != a.Hin || a.OW != a.Win || a.pad != a.KH / 2) return false;
+  if (a.M < conv_few_min_m()) return false;
+  return (a.KH == 3 && a.C1 == 3 && a.Cout <= 4) || (a.KH == 1 && a.C1 == 1 && a.Cout == 32) || (a.KH == 1 && a.C1 == 32 && a.Cout <= 4);
+}
+int conv_few_blocks(const ConvArgs& a) { return (int)std::min<int64_t>(cdiv(a.M, 256 * 4), 2048); }
+void launch_conv_few(const ConvArgs& a, int dtype, hipStream_t st) {
+  const dim3 grid((unsigned)conv_few_blocks(a));
+#define RD_FEW(TT) { if (a.KH == 3) hipLaunchKernelGGL((conv_few_kernel<TT, 3, 3, 4>), grid, dim3(256), 0, st, a);       \
+                     else if (a.C1 == 1) hipLaunchKernelGGL((conv_few_kernel<TT, 1, 1, 32>), grid, dim3(256), 0, st, a);  \
+                     else hipLaunchKernelGGL((conv_few_kernel<TT, 1, 32, 4>), grid, dim3(256), 0, st, a); }
+  if (dtype == 0) RD_FEW(float) else RD_FEW(bf16_t)
+#undef RD_FEW
+}
+
 bool conv3x3_c1_ok(const ConvArgs& a) {
   return geom3x3(a) && a.C1 == 1 && a.C2 == 0 && !a.ups && !a.stats && a.D1 == a.Cout && a.Cout <= 32;
 }

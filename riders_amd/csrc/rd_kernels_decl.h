@@ -25,6 +25,9 @@ void launch_conv1x1_direct(const ConvArgs& a, int dtype, hipStream_t st);
 bool conv3x3_dma_ok(const ConvArgs& a, int dtype);
 int conv3x3_dma_tiles(const ConvArgs& a);
 void launch_conv3x3_dma(const ConvArgs& a, hipStream_t st);
+bool conv_few_ok(const ConvArgs& a);
+int conv_few_blocks(const ConvArgs& a);
+void launch_conv_few(const ConvArgs& a, int dtype, hipStream_t st);
 bool conv3x3_c1_ok(const ConvArgs& a);
 void launch_conv3x3_c1(const ConvArgs& a, int dtype, hipStream_t st);
 void launch_pack_weights(const float* w, void* out, int Cout, int Cin, int KH, int KW, int mode, int dtype, hipStream_t st, int CinSrc = 0);

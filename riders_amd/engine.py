@@ -632,7 +632,9 @@ def conv_block(x, weight, *, x2=None, bias=None, stride=1, pad=None, up=None, bn
     # the vector / MFMA-bf16 kernels instead of the scalar-gather fallbacks (7x7 stem: 0.31 + 0.52 ms per RC-Net step)
     ve = 16 // x.element_size()
     cin_pad = 0
-    if x2 is None and not is_up and C1 % ve != 0 and KH * KW >= 9 and not (t is not None and t.requires(x)):
+    if x2 is None and not is_up and C1 % ve != 0 and KH * KW >= 9 and not (t is not None and t.requires(x)) and not lib.rd_conv_fwd_streams(
+            ctypes.byref(_desc(dt, N, Hin, Win, C1, 0, False, H1, W1, Cout, KH, KW, stride, pad, 1, OH, OW, conv_act, slope, Cout))):
+        # (layers the streaming few-channel kernels take -- SML's 3 -> 3 `first` convolution -- are handed over as they are)
         cin_pad = (C1 + ve - 1) // ve * ve
         xp = torch.empty((N, H1, W1, cin_pad), dtype=x.dtype, device=x.device)
         _chk(lib.rd_pad_channels(_p(x), _p(xp), N * H1 * W1, C1, cin_pad, dt, st), "rd_pad_channels")

@@ -145,7 +145,7 @@ class force_patch_conv:
 class force_tiny_wgrad(force_patch_conv):
     """Send the few-channel weight gradients (3->3, 3->32 stride 2, 32->1) through the register-accumulating streaming kernel at any size."""
     def __init__(self):
-        self.env = {"RD_WGRAD_TINY_MIN_M": "0"}
+        self.env = {"RD_WGRAD_TINY_MIN_M": "0", "RD_CONV_FEW_MIN_M": "0"}      # ... and the few-channel forward / data-gradient kernel
 
 
 def tiny_wgrad_cases(dev):
@@ -157,6 +157,8 @@ def tiny_wgrad_cases(dev):
         conv_case(dev, dict(cin=32, cout=1, k=1, s=1, H=21, W=17, N=3, bn=False, act=None))
         bf16_exact_conv_case(dev, cin=3, cout=3, k=3, s=1, H=14, W=10, N=2)
         bf16_exact_conv_case(dev, cin=32, cout=1, k=1, s=1, H=9, W=11, N=2)
+        with bf16_mode("bf16"):      # BatchNorm statistics out of the streaming forward's epilogue, bf16 rounding points
+            conv_case(dev, dict(cin=3, cout=3, k=3, s=1, H=19, W=23, N=2, bn=True, no_input_grad=True), tol=4e-3)
 
 
 class force_dma_conv(force_patch_conv):
