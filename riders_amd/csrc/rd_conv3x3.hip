@@ -639,12 +639,13 @@ void launch_conv1x1_direct(const ConvArgs& a, int dtype, hipStream_t st) {
 #undef RD_P1
 }
 
-// ---- layers with a handful of channels and millions of pixels (SML: the 3 -> 3 `first` convolution, the 32 -> 1 head and its data gradient):
+// ---- layers with a handful of channels and millions of pixels (SML: the 3 -> 3 `first` convolution, the 32 -> 1 head and its data gradient,
+// the data gradient of the 3 -> 32 stride-2 stem):
 // on the MFMA kernels they fill 2-4 % of a tile and run 10-15x over their HBM time.  One output pixel per thread, weights in LDS, the
 // taps fetched with unconditional clamped loads, BatchNorm partial sums in registers with one block reduction at the end (rows = blocks).
-template <typename T, int KH, int CIN, int CO>
+template <typename T, int KH, int CIN, int CO, int DIL>
 __global__ __launch_bounds__(256) void conv_few_kernel(ConvArgs a) {
-  constexpr int K = KH * KH * CIN, R = KH / 2;
+  constexpr int K = KH * KH * CIN, VE = Elem<T>::VE;
   __shared__ float sw[K * CO];      // [k][cout]
   __shared__ float red[4][CO * 2];
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
@@ -663,38 +664,52 @@ __global__ __launch_bounds__(256) void conv_few_kernel(ConvArgs a) {
   const bool vec = (a.Cout & 3) == 0;
   for (int64_t m = (int64_t)blockIdx.x * 256 + t; m < a.M; m += (int64_t)gridDim.x * 256) {
     const int ow = (int)(m % a.OW); const int64_t q = m / a.OW; const int oh = (int)(q % a.OH); const int n = (int)(q / a.OH);
-    float xv[K];
+    float acc[CO];
 #pragma unroll
+    for (int c = 0; c < CO; c++) acc[c] = 0.f;
+#ifndef RD_EMU
+    // the weights are loop invariant: with many of them (288 x 4 for the stem's data gradient) the compiler hoists every LDS read out of
+    // the pixel loop into registers and spills ~900 of them (measured: 11 ms instead of ~0.05); a compiler-level memory barrier keeps the
+    // reads inside the loop
+    if constexpr (K * CO > 256) asm volatile("" ::: "memory");
+#endif
+    // taps in ascending k order; every tap's loads are unconditional (clamped address), a tap that does not exist contributes zeros.
+    // DIL = 2: the input is the stride-2 layer's output gradient, read where (oh - pad + kh, ow - pad + kw) is even (data gradient).
+    // With many weights the tap loops stay rolled (one tap's 128 LDS values at a time), otherwise the scheduler front-loads all of them.
+    constexpr int UNR = (K * CO > 256) ? 1 : KH;
+#pragma unroll UNR
     for (int kh = 0; kh < KH; kh++)
-#pragma unroll
+#pragma unroll UNR
       for (int kw = 0; kw < KH; kw++) {
-        const int ih = oh - R + kh, iw = ow - R + kw;
-        const bool ok = (unsigned)ih < (unsigned)a.Hin && (unsigned)iw < (unsigned)a.Win;
+        int ih = oh - a.pad + kh, iw = ow - a.pad + kw;
+        bool ok = ih >= 0 && iw >= 0;
+        if (DIL > 1) { ok = ok && (((ih | iw) & (DIL - 1)) == 0); ih >>= 1; iw >>= 1; }      // DIL is 1 or 2
+        ok = ok && ih < a.Hin && iw < a.Win;
         const T* px = x + (((int64_t)n * a.Hin + min(max(ih, 0), a.Hin - 1)) * a.Win + min(max(iw, 0), a.Win - 1)) * CIN;
-        if constexpr (CIN % Elem<T>::VE == 0) {
+        float xv[CIN];
+        if constexpr (CIN % VE == 0) {
 #pragma unroll
-          for (int c = 0; c < CIN; c += Elem<T>::VE) {
-            float v[Elem<T>::VE];
+          for (int c = 0; c < CIN; c += VE) {
+            float v[VE];
             ldv(px + c, v);
 #pragma unroll
-            for (int e = 0; e < Elem<T>::VE; e++) xv[(kh * KH + kw) * CIN + c + e] = ok ? v[e] : 0.f;
+            for (int e = 0; e < VE; e++) xv[c + e] = ok ? v[e] : 0.f;
           }
         } else {
 #pragma unroll
-          for (int c = 0; c < CIN; c++) { const float v = Elem<T>::ld(px + c); xv[(kh * KH + kw) * CIN + c] = ok ? v : 0.f; }
+          for (int c = 0; c < CIN; c++) { const float v = Elem<T>::ld(px + c); xv[c] = ok ? v : 0.f; }
         }
+#pragma unroll
+        for (int c = 0; c < CIN; c++)
+#pragma unroll
+          for (int co = 0; co < CO; co++) acc[co] += sw[((kh * KH + kw) * CIN + c) * CO + co] * xv[c];
       }
     T* d = (T*)a.dst1 + m * a.Cout;
 #pragma unroll
     for (int c0 = 0; c0 < CO; c0 += 4) {
       float v[4], vr[4];
 #pragma unroll
-      for (int r = 0; r < 4; r++) {
-        float acc = 0.f;
-#pragma unroll
-        for (int k = 0; k < K; k++) acc += sw[k * CO + c0 + r] * xv[k];      // ascending-k order
-        v[r] = act_fwd(acc + bv[c0 + r], a.act, a.slope);
-      }
+      for (int r = 0; r < 4; r++) v[r] = act_fwd(acc[c0 + r] + bv[c0 + r], a.act, a.slope);
       if (vec && c0 + 3 < a.Cout) round_store4(d + c0, v, vr);
       else {
 #pragma unroll
@@ -716,16 +731,19 @@ __global__ __launch_bounds__(256) void conv_few_kernel(ConvArgs a) {
 }
 static int conv_few_min_m() { const char* e = getenv("RD_CONV_FEW_MIN_M"); return e ? atoi(e) : (1 << 16); }   // test hook: 0 forces the kernel
 bool conv_few_ok(const ConvArgs& a) {
-  if (a.KH != a.KW || a.stride != 1 || a.dil != 1 || a.ups || a.C2 || a.D1 != a.Cout || a.OH != a.Hin || a.OW != a.Win || a.pad != a.KH / 2) return false;
-  if (a.M < conv_few_min_m()) return false;
+  if (a.KH != a.KW || a.stride != 1 || a.ups || a.C2 || a.D1 != a.Cout || a.M < conv_few_min_m()) return false;
+  if (a.dil == 2)      // data gradient of a stride-2 layer with 3 input channels (the 3 -> 32 stem): 32-channel dy, 3 outputs
+    return a.KH == 3 && a.C1 == 32 && a.Cout <= 4;
+  if (a.dil != 1 || a.OH != a.Hin || a.OW != a.Win || a.pad != a.KH / 2) return false;
   return (a.KH == 3 && a.C1 == 3 && a.Cout <= 4) || (a.KH == 1 && a.C1 == 1 && a.Cout == 32) || (a.KH == 1 && a.C1 == 32 && a.Cout <= 4);
 }
 int conv_few_blocks(const ConvArgs& a) { return (int)std::min<int64_t>(cdiv(a.M, 256 * 4), 2048); }
 void launch_conv_few(const ConvArgs& a, int dtype, hipStream_t st) {
   const dim3 grid((unsigned)conv_few_blocks(a));
-#define RD_FEW(TT) { if (a.KH == 3) hipLaunchKernelGGL((conv_few_kernel<TT, 3, 3, 4>), grid, dim3(256), 0, st, a);       \
-                     else if (a.C1 == 1) hipLaunchKernelGGL((conv_few_kernel<TT, 1, 1, 32>), grid, dim3(256), 0, st, a);  \
-                     else hipLaunchKernelGGL((conv_few_kernel<TT, 1, 32, 4>), grid, dim3(256), 0, st, a); }
+#define RD_FEW(TT) { if (a.dil == 2) hipLaunchKernelGGL((conv_few_kernel<TT, 3, 32, 4, 2>), grid, dim3(256), 0, st, a);        \
+                     else if (a.KH == 3) hipLaunchKernelGGL((conv_few_kernel<TT, 3, 3, 4, 1>), grid, dim3(256), 0, st, a);       \
+                     else if (a.C1 == 1) hipLaunchKernelGGL((conv_few_kernel<TT, 1, 1, 32, 1>), grid, dim3(256), 0, st, a);      \
+                     else hipLaunchKernelGGL((conv_few_kernel<TT, 1, 32, 4, 1>), grid, dim3(256), 0, st, a); }
   if (dtype == 0) RD_FEW(float) else RD_FEW(bf16_t)
 #undef RD_FEW
 }

@@ -155,6 +155,9 @@ def tiny_wgrad_cases(dev):
         conv_case(dev, dict(cin=3, cout=3, k=3, s=1, H=19, W=23, N=2, bn=True, no_input_grad=True))
         conv_case(dev, dict(cin=3, cout=4, k=3, s=1, H=11, W=9, N=2, bn=True))
         conv_case(dev, dict(cin=32, cout=1, k=1, s=1, H=21, W=17, N=3, bn=False, act=None))
+        conv_case(dev, dict(cin=3, cout=32, k=3, s=2, H=22, W=18, N=2, bn=True))      # stride-2 stem: its data gradient (dilated dy, 32 -> 3)
+        conv_case(dev, dict(cin=3, cout=32, k=3, s=2, H=21, W=17, N=1, bn=True))      # odd size
+        bf16_exact_conv_case(dev, cin=3, cout=32, k=3, s=2, H=14, W=10, N=2)
         bf16_exact_conv_case(dev, cin=3, cout=3, k=3, s=1, H=14, W=10, N=2)
         bf16_exact_conv_case(dev, cin=32, cout=1, k=1, s=1, H=9, W=11, N=2)
         with bf16_mode("bf16"):      # BatchNorm statistics out of the streaming forward's epilogue, bf16 rounding points
