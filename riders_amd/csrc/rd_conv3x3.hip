@@ -562,7 +562,11 @@ template <typename T>
 static void launch3_t(const ConvArgs& a, hipStream_t st) {
   const bool w8 = use_w8(a);
   const int tilesH = (int)cdiv(a.OH, w8 ? 16 : 8), tilesW = (int)cdiv(a.OW, w8 ? 8 : 16);
-  const int bn = pick_bn3(a.Cout);
+  // at most 64 output channels per block by default: the 128-channel tile (32 KB of double-buffered weights + the 23 KB patch) leaves two
+  // blocks per CU, the 64-channel one four -- measured 901 -> 908 img/s on the RC-Net step although every patch is staged twice as often
+  // (32-channel tiles: 884).  RD_PATCH_BN_MAX=128 restores the wide tile (A/B).
+  static const int bn_max = getenv("RD_PATCH_BN_MAX") ? atoi(getenv("RD_PATCH_BN_MAX")) : 64;
+  const int bn = std::min(bn_max, pick_bn3(a.Cout));
   dim3 grid((unsigned)(a.N * tilesH * tilesW), (unsigned)cdiv(a.Cout, bn));
 #define RD_C3(BNV)                                                                                                   \
   if (bn == BNV) {                                                                                                   \
