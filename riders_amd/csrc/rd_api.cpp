@@ -59,7 +59,7 @@ int rd_version(void) { return 100; }
 const char* rd_last_error_string(void) { return g_err; }
 
 int64_t rd_conv_packed_elems(int32_t rows, int32_t K, int32_t dtype) {
-  return (int64_t)rd::conv_rows_pad(rows) * RD_NS(dtype, conv_kpad)(K, RD_DT(dtype));
+  return RD_NS(dtype, conv_packed_elems)(rows, K, RD_DT(dtype));
 }
 int rd_conv_pack_weights(const float* w, void* packed, int32_t Cout, int32_t Cin, int32_t KH, int32_t KW, int32_t mode,
                          int32_t dtype, void* stream) {

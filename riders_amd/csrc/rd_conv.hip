@@ -227,12 +227,24 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs a) {
 // ---- weight packing -------------------------------------------------------------------------------
 // OIHW fp32 (the reference's parameter layout) -> [rows_pad][Kpad] of T with k = (kh*KW+kw)*C + c.
 // mode 0 (forward): rows = Cout, C = Cin.   mode 1 (dgrad): rows = Cin, C = Cout, taps flipped.
+// 3x3 operands whose channel axis is a whole number of 128-byte chunks carry a SECOND copy behind the row-major one, in MFMA fragment
+// order for conv3x3_frag_kernel (rd_conv3x3_frag.hip): [chunk][tap][16-row tile][k half][lane = 16 * k-group + row] x 16 bytes, so that a
+// wave's fragment of one (chunk, tap, row tile, k half) is one contiguous 1-KiB load.  rd_conv_packed_elems sizes the buffer for both.
+__host__ __device__ __forceinline__ bool pack_has_frag(int KH, int KW, int C, int dtype) { return KH == 3 && KW == 3 && (C % (dtype == 0 ? 32 : 64)) == 0; }
+template <typename T>
+__device__ __forceinline__ int64_t pack_frag_index(int row, int k, int C, int rows_pad) {
+  constexpr int VE = Elem<T>::VE, CKE = 8 * VE;
+  const int tap = k / C, c = k - tap * C;
+  const int chunk = c / CKE, kk = c - chunk * CKE, kh = kk / (4 * VE), kg = (kk % (4 * VE)) / VE, e = kk % VE;
+  return ((((int64_t)(chunk * 9 + tap) * (rows_pad >> 4) + (row >> 4)) * 2 + kh) * 64 + kg * 16 + (row & 15)) * VE + e;
+}
 template <typename T>
 __global__ void pack_weights_kernel(const float* __restrict__ w, T* __restrict__ out, int Cout, int Cin, int KH,
                                     int KW, int mode, int rows_pad, int Kpad, int CinSrc) {
   int64_t total = (int64_t)rows_pad * Kpad;
   int rows = mode ? Cin : Cout, C = mode ? Cout : Cin;
   int K = KH * KW * C;
+  const bool frag = pack_has_frag(KH, KW, C, sizeof(T) == 4 ? 0 : 1);
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     int row = (int)(i / Kpad), k = (int)(i - (int64_t)row * Kpad);
     float v = 0.f;
@@ -243,6 +255,7 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, T* __restrict__
       else v = w[(((int64_t)c * Cin + row) * KH + (KH - 1 - kh)) * KW + (KW - 1 - kw)];
     }
     Elem<T>::st(&out[i], v);
+    if (frag) Elem<T>::st(&out[total + pack_frag_index<T>(row, k, C, rows_pad)], v);    // Kpad == K here
   }
 }
 
@@ -257,6 +270,7 @@ __device__ __forceinline__ void pack_one(const PackItem& it, int bx, int nbx) {
   const int bke = sizeof(T) == 4 ? 32 : 64;
   const int Kpad = (K + bke - 1) / bke * bke;
   const int64_t total = (int64_t)rows_pad * Kpad;
+  const bool frag = pack_has_frag(it.KH, it.KW, C, sizeof(T) == 4 ? 0 : 1);
   T* out = (T*)it.out;
   for (int64_t i = (int64_t)bx * 256 + threadIdx.x; i < total; i += (int64_t)nbx * 256) {
     int row = (int)(i / Kpad), k = (int)(i - (int64_t)row * Kpad);
@@ -268,6 +282,7 @@ __device__ __forceinline__ void pack_one(const PackItem& it, int bx, int nbx) {
       else v = it.w[(((int64_t)c * it.Cin + row) * it.KH + (it.KH - 1 - kh)) * it.KW + (it.KW - 1 - kw)];
     }
     Elem<T>::st(&out[i], v);
+    if (frag) Elem<T>::st(&out[total + pack_frag_index<T>(row, k, C, rows_pad)], v);
   }
 }
 __global__ __launch_bounds__(256) void pack_weights_batch_kernel(const PackItem* __restrict__ items) {
@@ -895,6 +910,11 @@ static int pick_bn(int cout) {
 }
 int conv_rows_pad(int rows) { int bn = pick_bn(rows); return (int)cdiv(rows, bn) * bn; }
 int conv_kpad(int K, int dtype) { int bke = dtype == 0 ? 32 : 64; return (int)cdiv(K, bke) * bke; }
+// elements of a packed operand: K axes that can be 9 taps x whole 128-byte chunks leave room for the fragment-ordered copy
+int64_t conv_packed_elems(int rows, int K, int dtype) {
+  const int64_t n = (int64_t)conv_rows_pad(rows) * conv_kpad(K, dtype);
+  return (K % (9 * (dtype == 0 ? 32 : 64)) == 0) ? 2 * n : n;
+}
 
 // tile choice: small-M launches (fewer than ~1.5 blocks per CU with 128-pixel tiles) halve the pixel tile, then the channel tile
 static void conv_tiles(int M, int Cout, int& bn, int& wm) {
@@ -946,6 +966,9 @@ static bool use_conv3x3(const ConvArgs& a, int dtype) {
 static bool use_conv3x3_small(const ConvArgs& a, int dtype) {
   return conv3x3_small_ok(a, dtype) && conv3x3_tiles(a) >= conv3x3_min_blocks();
 }
+static bool use_conv3x3_frag(const ConvArgs& a, int dtype) {   // wide layers: weights in fragment order from L2, only the patch in LDS
+  return conv3x3_frag_ok(a, dtype) && conv3x3_frag_blocks(a, dtype) >= conv3x3_min_blocks();
+}
 static bool use_conv3x3_dma(const ConvArgs& a, int dtype) {   // wide bf16 layers: LDS-DMA staging + 32x32x16 MFMA (rd_conv3x3_dma.hip)
   if (!conv3x3_dma_ok(a, dtype)) return false;
   return (int64_t)conv3x3_dma_tiles(a) * cdiv(a.Cout, a.Cout <= 32 ? 32 : (a.Cout <= 64 ? 64 : 128)) >= conv3x3_min_blocks();
@@ -955,6 +978,7 @@ int conv_stats_rows(const ConvArgs& a, int dtype) {
   if (conv1x1_direct_ok(a, dtype)) return conv1x1_direct_rows(a);
   if (use_conv3x3_small(a, dtype)) return conv3x3_small_blocks(a, dtype);   // persistent blocks: one statistics row each
   if (use_conv3x3_dma(a, dtype)) return conv3x3_dma_tiles(a);
+  if (use_conv3x3_frag(a, dtype)) return conv3x3_frag_tiles(a, dtype);
   if (use_conv3x3(a, dtype)) return conv3x3_tiles(a);
   return (int)cdiv(a.M, conv_block_pixels(a.M, a.Cout));
 }
@@ -965,6 +989,7 @@ void launch_conv(const ConvArgs& a, int dtype, hipStream_t st) {
   if (conv3x3_c1_ok(a)) { launch_conv3x3_c1(a, dtype, st); return; }
   if (use_conv3x3_small(a, dtype)) { launch_conv3x3_small(a, dtype, st); return; }
   if (use_conv3x3_dma(a, dtype)) { launch_conv3x3_dma(a, st); return; }
+  if (use_conv3x3_frag(a, dtype)) { launch_conv3x3_frag(a, dtype, st); return; }
   if (use_conv3x3(a, dtype)) { launch_conv3x3(a, dtype, st); return; }
   if (dtype == 0) launch_conv_t<float>(a, st);
   else launch_conv_t<bf16_t>(a, st);

@@ -1,0 +1,349 @@
+// Register-fed 3x3 / stride-1 convolution (forward and data gradient) for gfx950: the wide layers of RC-Net (Cout > 16 with whole 128-byte
+// channel chunks; reference utils/net_utils.py:84-91,195-198,564-569) and of the SML scratch decoder (modules/midas/blocks.py:99-174).
+//
+// Why a second patch kernel.  conv3x3_patch_kernel (rd_conv3x3.hip) shares the weights of ONE tap at a time through LDS: every tap costs a
+// global -> VGPR -> LDS -> VGPR round trip behind a block barrier (9 barriers per 128-byte channel chunk, 16 MFMAs per wave between two of
+// them), its wave tile of 32 pixels x 64 channels needs 6 ds_read_b128 per 8 MFMAs, and every fragment address is XOR-swizzle arithmetic.
+// PMC (round 2): a third of the wave cycles parked at those barriers, another third stalled on issue, 26 % of the dense bf16 MFMA peak; the
+// first version of this file (weights from L2, XOR-swizzled patch) turned out VALU-bound instead: 5-8 vector instructions per MFMA, 45 % of
+// its LDS cycles bank conflicts on tiles that wrap around image rows (profiles/r03_pmc_frag_v1.txt).  Now:
+//   * only the PIXEL patch lives in LDS (staged once per chunk, nine taps walk it);
+//   * the weights never touch LDS: they are packed in MFMA FRAGMENT ORDER ([chunk][tap][16-channel tile][k half][lane] x 16 bytes, written
+//     next to the row-major operand by the pack kernels) so a wave fetches a fragment with ONE fully coalesced 1-KiB load, a tap ahead of
+//     its use, straight from L2 into the registers the MFMA reads -- no barrier inside a chunk;
+//   * a wave owns 32 output channels x (64 or 128) pixels: one ds_read_b128 feeds two MFMAs;
+//   * the patch is stored as FOUR PLANES of [pixel][32 bytes] (plane h = 16-byte channel slots 2h, 2h+1; plane stride = 32 mod 256 bytes):
+//     a fragment read of 16 consecutive patch pixels is bank-conflict free WITHOUT a swizzle (b128 lane groups mix k-groups g and g+1 of
+//     all 16 pixels: even / odd 16-byte columns of one plane, or planes h / h+1 an even number of columns apart), the staging stores of a
+//     pixel's eight slots are too, and every fragment address of the tap loop is `base register + immediate`;
+//   * narrow maps are tiled LINEARLY: the whole tensor is one strip of virtual pixels, rows of OW + 1 (one shared zero column) and one
+//     shared zero row between images; a tile is TP consecutive virtual pixels, its patch TP + 2 (OW + 1) + 2 consecutive ones, the tap
+//     offsets kh (OW + 1) + kw.  Virtual zero pixels compute and are not stored: 3-20 % of the MFMAs on the 60x25 ... 15x6 RoI maps against
+//     27-30 % with 2-D tiles, and tiles cross image borders.  Wide maps keep 2-D tiles (TP/16 rows x 16 columns);
+//   * every patch load is unconditional (clamped address, zero selected afterwards) and the next chunk's patch is requested piecewise
+//     BEHIND the fragment loads of the taps (a wave's loads return in order).
+#include "rd_conv_common.h"
+
+namespace rd {
+
+struct FragGeom {
+  int lin;        // 1: linear tiles of the virtual pixel strip; 0: 2-D tiles (TP/16 rows x 16 columns of one image)
+  int WT;         // patch row stride in pixels (2-D: 18, linear: OW + 1)
+  int tilesH, tilesW, ntiles, ncb;
+  int np;         // patch pixels
+  int ps;         // plane stride in bytes (>= 32 np, = 32 mod 256)
+  int ctall;      // 16-channel tiles in the packed operand (rows_pad / 16)
+  int wfrag;      // element offset of the fragment-ordered copy inside the packed operand (rows_pad * Kpad)
+  float rWT, rH1; // 1 / WT, 1 / (OH + 1): the strip is decoded with float reciprocals + one correction step (host: strip < 2^22 pixels)
+};
+
+constexpr int frag_pmax(int tp) { return tp <= 128 ? 256 : (tp <= 256 ? 384 : 640); }   // patch pixels a block may stage (32 / 48 / 80 KB)
+
+// x / d for 0 <= x < 2^22 (the product with the rounded reciprocal is off by less than one)
+__device__ __forceinline__ int fdiv_small(int x, int d, float rd_, int& rem) {
+  int q = (int)((float)x * rd_);
+  int r = x - q * d;
+  if (r < 0) { q--; r += d; }
+  if (r >= d) { q++; r -= d; }
+  rem = r;
+  return q;
+}
+
+// NPT 16-pixel tiles per wave, WPX x WCH waves (pixels x 32-channel groups): block tile = (16 NPT WPX) pixels x (32 WCH) channels.
+// LIN: linear tiles; MULTI: more than one channel chunk (the next chunk's patch is prefetched).
+template <typename T, int NPT, int WPX, int WCH, bool LIN, bool MULTI>
+__global__ __launch_bounds__(64 * WPX * WCH, (WPX * WCH == 8 || NPT == 8) ? 2 : 3) void conv3x3_frag_kernel(ConvArgs a, FragGeom g) {
+  constexpr int NW = WPX * WCH, NT = 64 * NW;
+  constexpr int VE = Elem<T>::VE;
+  constexpr int CKE = STAGE_BYTES / (int)sizeof(T);   // channels per chunk (128 bytes per pixel)
+  constexpr int TP = 16 * NPT * WPX, BN = 32 * WCH;
+  constexpr int PMAX = frag_pmax(TP);
+  constexpr int PIT = (PMAX * 8 + NT - 1) / NT;
+  RD_DYN_SMEM(smem);
+
+  const int t = threadIdx.x, lane = t & 63, wv = RD_WAVE_UNIFORM(t >> 6);
+  const int fr = lane & 15, fg = lane >> 4;
+  const int wpx = wv % WPX, wc = wv / WPX;
+  const int idx = xcd_contiguous((int)blockIdx.x, (int)gridDim.x);   // an XCD walks neighbouring tiles; the channel blocks of a tile sit together
+  const int cb = idx % g.ncb, tile = idx / g.ncb;
+  const int n0 = cb * BN;
+  const int Cin = a.C1 + a.C2;
+  const int nchunk = Cin / CKE;
+  const int WT = g.WT, np = g.np, PS = g.ps;
+  const int Hp = a.ups ? a.H1 : a.Hin, Wp = a.ups ? a.W1 : a.Win;
+  const int H1 = a.OH + 1;
+
+  // ---- tile origin ------------------------------------------------------------------------------------------------------------------
+  // linear: first virtual pixel of the tile (the strip starts with a zero row, which no tile computes); 2-D: image, first row, first column
+  int u0 = 0, tn = 0, toh0 = 0, tow0 = 0;
+  if (LIN) u0 = WT + tile * TP;
+  else {
+    const int tw_ = tile % g.tilesW, q_ = tile / g.tilesW, th_ = q_ % g.tilesH;
+    tn = q_ / g.tilesH; toh0 = th_ * (TP / 16); tow0 = tw_ * 16;
+  }
+  // virtual pixel -> (image, row, column) of the tensor; false for a zero row / zero column / a pixel outside the strip
+  auto strip_pixel = [&](int u, int& n, int& ih, int& iw) RD_INLINE_LAMBDA {
+    int c, hh;
+    const int vrow = fdiv_small(max(u, 0), WT, g.rWT, c);
+    n = fdiv_small(vrow, H1, g.rH1, hh);
+    ih = hh - 1; iw = c - 1;
+    return u >= 0 && c >= 1 && hh >= 1 && n < a.N;
+  };
+
+  // ---- patch staging role: slot id = t + NT i -> patch pixel id >> 3, 16-byte channel slot t & 7.  The source pixel of every slot is
+  // decoded once (-1 = zero); a chunk only picks the source tensor for its channel offset.
+  int spix[PIT];
+#pragma unroll
+  for (int i = 0; i < PIT; i++) {
+    const int pp = (t + NT * i) >> 3;
+    int n, ih, iw; bool ok;
+    if (LIN) ok = strip_pixel(u0 - WT - 1 + pp, n, ih, iw);
+    else {
+      const int py = pp / 18, px = pp - py * 18;
+      n = tn; ih = toh0 - 1 + py; iw = tow0 - 1 + px;
+      ok = (unsigned)ih < (unsigned)a.Hin && (unsigned)iw < (unsigned)a.Win;
+    }
+    int pix = -1;
+    if (ok && pp < np) {
+      int hs = ih, ws = iw;
+      if (a.ups) {  // F.interpolate(mode='nearest') source index, ATen float formula (as conv_src_ptr)
+        hs = min((int)floorf((float)ih * a.scale_h), a.H1 - 1);
+        ws = min((int)floorf((float)iw * a.scale_w), a.W1 - 1);
+      }
+      pix = (n * Hp + hs) * Wp + ws;
+    }
+    spix[i] = pix;
+  }
+  uint4 rp[PIT];
+  // one 16-byte piece of a chunk's patch: unconditional load from a clamped address, zero selected afterwards (a guarded load is one memory
+  // round trip per load).  `last`: there is no next chunk -- every lane re-reads pixel 0 (one cache line per load, nobody waits for it), so
+  // the prefetch stays branch-free and the compiler keeps COUNTING the loads in flight instead of waiting vmcnt(0) at the next join.
+  auto load_piece = [&](int chunk, int i, bool last) RD_INLINE_LAMBDA {
+    const int ci = chunk * CKE + (t & 7) * VE;
+    const bool first = ci < a.C1;
+    const T* cbp = first ? (const T*)a.src1 + ci : (const T*)a.src2 + (ci - a.C1);
+    const int cs = first ? a.C1 : a.C2;
+    const int px = last ? 0 : max(spix[i], 0);
+    const uint4 v = *reinterpret_cast<const uint4*>((last ? (const T*)a.src1 : cbp) + (int64_t)px * cs);
+    rp[i] = spix[i] < 0 ? make_uint4(0, 0, 0, 0) : v;
+  };
+  const int st_base = ((t & 7) >> 1) * PS + (t & 1) * 16 + (t >> 3) * 32;    // plane (slot >> 1), 16-byte column (slot & 1), pixel t >> 3
+  auto store_patch = [&]() RD_INLINE_LAMBDA {
+#pragma unroll
+    for (int i = 0; i < PIT; i++)
+      if (((t + NT * i) >> 3) < np) *reinterpret_cast<uint4*>(smem + st_base + i * (NT / 8) * 32) = rp[i];
+  };
+
+  // ---- this lane's output pixels (one per MFMA pixel tile): flattened output index or -1 -------------------------------------------------
+  int pm[NPT];
+#pragma unroll
+  for (int pt = 0; pt < NPT; pt++) {
+    const int q = wpx * NPT + pt;
+    if (LIN) {
+      int n, ih, iw;
+      const bool ok = strip_pixel(u0 + q * 16 + fr, n, ih, iw);
+      pm[pt] = ok ? (n * a.OH + ih) * a.OW + iw : -1;
+    } else {
+      const int oh = toh0 + q, ow = tow0 + fr;
+      pm[pt] = (oh < a.OH && ow < a.OW) ? (tn * a.OH + oh) * a.OW + ow : -1;
+    }
+  }
+  // fragment read of (pixel tile pt, tap (kr, kc), k half kh): plane kh*2 + (fg >> 1), column fg & 1, patch pixel p0 + fr + tap offset where
+  // p0 = 16 (wpx NPT + pt) [linear] or 18 (wpx NPT + pt) [2-D]: one base register per (kernel row, k half) [linear: the row stride is a
+  // run-time value] or per k half [2-D], everything else an immediate offset.
+  const int lb = (fg >> 1) * PS + (fg & 1) * 16 + (wpx * NPT * (LIN ? 16 : 18) + fr) * 32;
+  int lbase[LIN ? 3 : 1][2];
+#pragma unroll
+  for (int kr = 0; kr < (LIN ? 3 : 1); kr++)
+#pragma unroll
+    for (int kh = 0; kh < 2; kh++) lbase[kr][kh] = lb + kh * 2 * PS + kr * WT * 32;
+
+  // ---- weight fragments: [chunk][tap][16-channel tile][k half][lane], this wave's two channel tiles ------------------------------------
+  const uint4* const wfr = reinterpret_cast<const uint4*>((const T*)a.w + g.wfrag) + ((n0 >> 4) + wc * 2) * 128 + lane;
+  const int wstep = g.ctall * 128;               // uint4 per (chunk, tap)
+  auto load_w = [&](int ct, uint4 (&w)[2][2]) RD_INLINE_LAMBDA {   // ct = chunk * 9 + tap
+    const uint4* p = wfr + (int64_t)ct * wstep;
+#pragma unroll
+    for (int c = 0; c < 2; c++)
+#pragma unroll
+      for (int kh = 0; kh < 2; kh++) { const uint4 v = p[(c * 2 + kh) * 64]; w[c][kh] = v; }
+  };
+
+  f32x4 acc[2][NPT];
+#pragma unroll
+  for (int c = 0; c < 2; c++)
+#pragma unroll
+    for (int pt = 0; pt < NPT; pt++) acc[c][pt] = f32x4{0, 0, 0, 0};
+
+  // One tap: the NEXT tap's fragments are requested first (unconditionally: the last tap of the layer re-reads its own), then -- in layers
+  // with several chunks -- a couple of 16-byte pieces of the NEXT chunk's patch, then this tap's 2 x NPT fragment reads and 4 x NPT MFMAs.
+  // A wave's loads return IN ORDER, so waiting for tap t+1's fragments also waits for every piece requested before them: the pieces go
+  // BEHIND the fragment loads of their tap and get two taps of MFMA work to arrive (all of them in front of tap 0 would park every wave
+  // for one HBM round trip per chunk).  Scheduling fences keep each tap's requests at its top and its reads inside it.
+  constexpr int PPT = (PIT + 7) / 8;   // pieces per tap, taps 0..7
+  auto tap_body = [&](int chunk, int tap, uint4 (&wcur)[2][2], uint4 (&wnxt)[2][2]) RD_INLINE_LAMBDA {
+    load_w(min(chunk * 9 + tap + 1, nchunk * 9 - 1), wnxt);
+    if (MULTI && tap < 8) {
+      const bool last = chunk + 1 >= nchunk;
+#pragma unroll
+      for (int k = 0; k < PPT; k++)
+        if (tap * PPT + k < PIT) load_piece(min(chunk + 1, nchunk - 1), tap * PPT + k, last);
+    }
+    sched_fence();
+    const int kr = tap / 3, kc = tap % 3;
+#pragma unroll
+    for (int kh = 0; kh < 2; kh++) {
+      uint4 pf[NPT];
+#pragma unroll
+      for (int pt = 0; pt < NPT; pt++)
+        pf[pt] = *reinterpret_cast<const uint4*>(smem + lbase[LIN ? kr : 0][kh] + (LIN ? pt * 16 + kc : (pt + kr) * 18 + kc) * 32);
+#pragma unroll
+      for (int c = 0; c < 2; c++) {
+        const uint4 wf = wcur[c][kh];
+#pragma unroll
+        for (int pt = 0; pt < NPT; pt++) {
+          if (sizeof(T) == 4) {
+            acc[c][pt] = mfma_16x16x4_f32(__uint_as_float(wf.x), __uint_as_float(pf[pt].x), acc[c][pt]);
+            acc[c][pt] = mfma_16x16x4_f32(__uint_as_float(wf.y), __uint_as_float(pf[pt].y), acc[c][pt]);
+            acc[c][pt] = mfma_16x16x4_f32(__uint_as_float(wf.z), __uint_as_float(pf[pt].z), acc[c][pt]);
+            acc[c][pt] = mfma_16x16x4_f32(__uint_as_float(wf.w), __uint_as_float(pf[pt].w), acc[c][pt]);
+          } else {
+            s16x8 wv8, pb;
+            __builtin_memcpy(&wv8, &wf, 16);
+            __builtin_memcpy(&pb, &pf[pt], 16);
+            acc[c][pt] = mfma_16x16x32_bf16(wv8, pb, acc[c][pt]);
+          }
+        }
+      }
+    }
+    sched_fence();
+  };
+
+  uint4 wa[2][2], wb[2][2];
+#pragma unroll
+  for (int i = 0; i < PIT; i++) load_piece(0, i, false);
+  load_w(0, wa);
+  for (int chunk = 0; chunk < nchunk; chunk++) {
+    __syncthreads();            // every wave is done with the previous chunk's patch
+    store_patch();
+    __syncthreads();
+    tap_body(chunk, 0, wa, wb); tap_body(chunk, 1, wb, wa); tap_body(chunk, 2, wa, wb);
+    tap_body(chunk, 3, wb, wa); tap_body(chunk, 4, wa, wb); tap_body(chunk, 5, wb, wa);
+    tap_body(chunk, 6, wa, wb); tap_body(chunk, 7, wb, wa); tap_body(chunk, 8, wa, wb);
+    if (MULTI) {     // nine taps = an odd number of register swaps: the next chunk's first fragments landed in wb
+#pragma unroll
+      for (int c = 0; c < 2; c++)
+#pragma unroll
+        for (int kh = 0; kh < 2; kh++) wa[c][kh] = wb[c][kh];
+    }
+  }
+
+  __syncthreads();  // all waves finished reading the patch before it is reused as reduction scratch
+  float ssum[2][4], ssq[2][4];
+#pragma unroll
+  for (int c = 0; c < 2; c++)
+#pragma unroll
+    for (int r = 0; r < 4; r++) { ssum[c][r] = 0.f; ssq[c][r] = 0.f; }
+#pragma unroll
+  for (int pp = 0; pp < NPT / 2; pp++) {   // the store routine takes two pixel tiles at a time
+    int64_t mm[2]; bool mvv[2]; f32x4 a2[2][2];
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      mm[h] = pm[pp * 2 + h]; mvv[h] = pm[pp * 2 + h] >= 0;
+#pragma unroll
+      for (int c = 0; c < 2; c++) a2[c][h] = acc[c][pp * 2 + h];
+    }
+    conv_epilogue_store<T, 2>(a, a2, mm, mvv, n0, wc, fr, fg, ssum, ssq);
+  }
+  conv_epilogue_stats<2, BN, WPX, NT>(a, ssum, ssq, n0, wc, wpx, fr, fg, t, tile, reinterpret_cast<float*>(smem));
+}
+
+// ---- host side -------------------------------------------------------------------------------------------------------------------
+// block shapes (pixels x channels, waves): the table is the A/B surface of tools/bench_conv.py (RD_FRAG_V128 / _V64 / _V32)
+struct FragVariant { int tp, bn, nw; };
+static const FragVariant kFragVariants[] = {
+  {128, 128, 4},   // 0: waves 1 x 4, 128 pixels each
+  {128, 128, 8},   // 1: waves 2 x 4,  64 pixels each
+  {128,  64, 4},   // 2: waves 2 x 2,  64 pixels each
+  {256,  64, 4},   // 3: waves 2 x 2, 128 pixels each
+  {256,  64, 8},   // 4: waves 4 x 2,  64 pixels each
+  {256,  32, 4},   // 5: waves 4 x 1,  64 pixels each
+  {512,  32, 4},   // 6: waves 4 x 1, 128 pixels each
+};
+struct FragPlan { int variant, tp, bn, nw, lin, WT, tilesH, tilesW, ntiles, ncb, np, ps; };
+
+static int frag_env(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+
+static bool frag_plan(const ConvArgs& a, int dtype, FragPlan& p) {
+  const int Cin = a.C1 + a.C2;
+  const int ve = dtype == 0 ? 4 : 8, cke = dtype == 0 ? 32 : 64;
+  if (!(a.KH == 3 && a.KW == 3 && a.stride == 1 && a.pad == 1 && a.dil == 1 && a.OH == a.Hin && a.OW == a.Win)) return false;
+  if ((Cin % cke) || (a.C1 % ve) || a.Cout <= 16) return false;
+  if ((int64_t)a.N * a.Hin * a.Win >= (int64_t)1 << 31) return false;   // the kernel keeps source pixel indices in 32 bits
+  p.variant = a.Cout > 64 ? frag_env("RD_FRAG_V128", 0) : (a.Cout > 32 ? frag_env("RD_FRAG_V64", 2) : frag_env("RD_FRAG_V32", 5));
+  const FragVariant& v = kFragVariants[p.variant];
+  p.tp = v.tp; p.bn = v.bn; p.nw = v.nw;
+  p.ncb = (int)cdiv(a.Cout, p.bn);
+  // 2-D tiles of TP/16 rows x 16 columns, or linear tiles of the virtual strip (narrow maps, where 2-D tiles are mostly padding)
+  const int th = p.tp / 16;
+  const int64_t t2 = (int64_t)a.N * cdiv(a.OH, th) * cdiv(a.OW, 16);
+  const double eff2 = (double)a.M / ((double)t2 * p.tp);
+  const int64_t strip = ((int64_t)a.N * (a.OH + 1) + 1) * (a.OW + 1);       // virtual pixels incl. the first and the last zero row
+  const int64_t tl = cdiv(strip - 2 * (a.OW + 1), p.tp);
+  const double effl = (double)a.M / ((double)tl * p.tp);
+  const int npl = p.tp + 2 * (a.OW + 1) + 2;
+  const bool lin_ok = strip < ((int64_t)1 << 22) && npl <= frag_pmax(p.tp);
+  const int force_lin = frag_env("RD_FRAG_LIN", -1);   // test hook: 1 forces linear tiles where they fit, 0 forbids them
+  bool lin = lin_ok && effl > eff2;
+  if (force_lin == 0) lin = false;
+  if (force_lin == 1) lin = lin_ok;
+  p.lin = lin ? 1 : 0;
+  if (lin) { p.WT = a.OW + 1; p.tilesH = p.tilesW = 0; p.ntiles = (int)tl; p.np = npl; }
+  else { p.WT = 18; p.tilesH = (int)cdiv(a.OH, th); p.tilesW = (int)cdiv(a.OW, 16); p.ntiles = (int)t2; p.np = (th + 2) * 18; }
+  p.ps = ((p.np * 32 - 32 + 255) / 256) * 256 + 32;      // >= 32 np and = 32 (mod 256)
+  return true;
+}
+bool conv3x3_frag_ok(const ConvArgs& a, int dtype) {
+  FragPlan p;
+  return frag_env("RD_CONV3X3_FRAG", 1) && frag_plan(a, dtype, p);
+}
+int conv3x3_frag_tiles(const ConvArgs& a, int dtype) { FragPlan p; frag_plan(a, dtype, p); return p.ntiles; }
+int conv3x3_frag_blocks(const ConvArgs& a, int dtype) { FragPlan p; frag_plan(a, dtype, p); return p.ntiles * p.ncb; }
+
+template <typename T, int NPT, int WPX, int WCH>
+static void launch_frag_v(const ConvArgs& a, const FragPlan& p, const FragGeom& g, hipStream_t st) {
+  const dim3 grid((unsigned)(p.ntiles * p.ncb)), block(64 * WPX * WCH);
+  const size_t lds = (size_t)std::max(4 * p.ps, WPX * 32 * WCH * 2 * 4);
+  const bool multi = (a.C1 + a.C2) * (int)sizeof(T) > STAGE_BYTES;
+  if (p.lin) {
+    if (multi) hipLaunchKernelGGL((conv3x3_frag_kernel<T, NPT, WPX, WCH, true, true>), grid, block, lds, st, a, g);
+    else hipLaunchKernelGGL((conv3x3_frag_kernel<T, NPT, WPX, WCH, true, false>), grid, block, lds, st, a, g);
+  } else {
+    if (multi) hipLaunchKernelGGL((conv3x3_frag_kernel<T, NPT, WPX, WCH, false, true>), grid, block, lds, st, a, g);
+    else hipLaunchKernelGGL((conv3x3_frag_kernel<T, NPT, WPX, WCH, false, false>), grid, block, lds, st, a, g);
+  }
+}
+template <typename T>
+static void launch_frag_t(const ConvArgs& a, int dtype, hipStream_t st) {
+  FragPlan p; frag_plan(a, dtype, p);
+  FragGeom g;
+  g.lin = p.lin; g.WT = p.WT; g.tilesH = p.tilesH; g.tilesW = p.tilesW; g.ntiles = p.ntiles; g.ncb = p.ncb; g.np = p.np; g.ps = p.ps;
+  const int rows_pad = conv_rows_pad(a.Cout);
+  g.ctall = rows_pad / 16; g.wfrag = rows_pad * a.Kpad;
+  g.rWT = 1.0f / (float)p.WT; g.rH1 = 1.0f / (float)(a.OH + 1);
+  switch (p.variant) {
+    case 0: launch_frag_v<T, 8, 1, 4>(a, p, g, st); break;
+    case 1: launch_frag_v<T, 4, 2, 4>(a, p, g, st); break;
+    case 2: launch_frag_v<T, 4, 2, 2>(a, p, g, st); break;
+    case 3: launch_frag_v<T, 8, 2, 2>(a, p, g, st); break;
+    case 4: launch_frag_v<T, 4, 4, 2>(a, p, g, st); break;
+    case 5: launch_frag_v<T, 4, 4, 1>(a, p, g, st); break;
+    default: launch_frag_v<T, 8, 4, 1>(a, p, g, st); break;
+  }
+}
+void launch_conv3x3_frag(const ConvArgs& a, int dtype, hipStream_t st) {
+  if (dtype == 0) launch_frag_t<float>(a, dtype, st);
+  else launch_frag_t<bf16_t>(a, dtype, st);
+}
+
+}  // namespace rd

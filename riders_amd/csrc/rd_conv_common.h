@@ -132,7 +132,7 @@ __device__ __forceinline__ void conv_epilogue_store(const ConvArgs& a, f32x4 (&a
     }
   }
 }
-template <int CT, int BN, int WMV>
+template <int CT, int BN, int WMV, int NTH = 256>
 __device__ __forceinline__ void conv_epilogue_stats(const ConvArgs& a, const float (&ssum)[CT][4], const float (&ssq)[CT][4], int n0, int wn,
                                                     int wm, int fr, int fg, int t, int64_t stats_row, float* red /* >= WMV*BN*2 floats */) {
   if (!a.stats) return;  // per-block partials, combined later in a fixed order (deterministic)
@@ -150,7 +150,7 @@ __device__ __forceinline__ void conv_epilogue_stats(const ConvArgs& a, const flo
       }
     }
   __syncthreads();
-  for (int col = t; col < BN; col += 256) {
+  for (int col = t; col < BN; col += NTH) {
     int co = n0 + col;
     if (co < a.Cout) {
       float s1 = 0.f, s2 = 0.f;

@@ -6,6 +6,7 @@ using namespace rdt;
 // rd_conv.hip
 int conv_rows_pad(int rows);
 int conv_kpad(int K, int dtype);
+int64_t conv_packed_elems(int rows, int K, int dtype);
 int conv_block_pixels(int M, int Cout);
 int wgrad_nsplit(int M, int K, int Cout);
 int wgrad_slabs(int M, int K, int Cout);
@@ -21,6 +22,11 @@ int conv3x3_small_blocks(const ConvArgs& a, int dtype);
 bool conv1x1_direct_ok(const ConvArgs& a, int dtype);
 int conv1x1_direct_rows(const ConvArgs& a);
 void launch_conv1x1_direct(const ConvArgs& a, int dtype, hipStream_t st);
+// rd_conv3x3_frag.hip
+bool conv3x3_frag_ok(const ConvArgs& a, int dtype);
+int conv3x3_frag_tiles(const ConvArgs& a, int dtype);
+int conv3x3_frag_blocks(const ConvArgs& a, int dtype);
+void launch_conv3x3_frag(const ConvArgs& a, int dtype, hipStream_t st);
 // rd_conv3x3_dma.hip
 bool conv3x3_dma_ok(const ConvArgs& a, int dtype);
 int conv3x3_dma_tiles(const ConvArgs& a);

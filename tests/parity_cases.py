@@ -142,6 +142,55 @@ class force_patch_conv:
                 os.environ[k] = v
 
 
+class force_frag_conv(force_patch_conv):
+    """Route every eligible 3x3/stride-1 layer (Cout > 16, whole 128-byte channel chunks) to the register-fed kernel
+    (rd_conv3x3_frag.hip) regardless of its block count; v128 / v64 / v32 pick the block shape for > 64 / 33..64 / 17..32 output
+    channels (table kFragVariants), lin = 1 forces linear tiles wherever they fit, 0 forbids them."""
+    def __init__(self, v128=None, v64=None, v32=None, lin=None):
+        super().__init__()
+        self.env["RD_CONV3X3_FRAG"] = "1"
+        for k, v in (("RD_FRAG_V128", v128), ("RD_FRAG_V64", v64), ("RD_FRAG_V32", v32), ("RD_FRAG_LIN", lin)):
+            if v is not None:
+                self.env[k] = str(v)
+
+
+FRAG_CONV_CASES = [
+    dict(cin=32, cout=64, k=3, s=1, H=9, W=19, N=2, bn=True),                   # 2-D tiles, ragged in both axes, one chunk (fp32)
+    dict(cin=64, cout=160, k=3, s=1, H=17, W=7, N=1, bn=False, act=None),       # linear tiles on a 7-wide map, two channel blocks, two chunks; dgrad 160 -> 64: five chunks
+    dict(cin=128, cout=64, k=3, s=1, H=8, W=16, N=2, bn=True),                  # exact 2-D tile, four chunks
+    dict(cin=32, cout=128, k=3, s=1, H=5, W=6, N=7, bn=True),                   # linear tiles crossing several images (30-pixel images)
+    dict(cin=64, cout=48, k=3, s=1, H=15, W=6, N=5, bn=True),                   # RC-Net's smallest RoI map, ragged channel count
+    dict(cin=32, cout=24, k=3, s=1, H=11, W=13, N=3, bn=True),                  # 32-channel blocks
+]
+
+
+def frag_conv_cases(dev, quick=False):
+    """The register-fed 3x3 kernel in every block shape and both tile forms: fp32 against the oracle, then bf16 on integer data, exact
+    (forward + both gradients), with the up-sampling / concatenating gather and the dual-destination data gradient.  quick: the subset the
+    host emulator runs in the CPU suite; the GPU suite runs everything."""
+    if quick:
+        with force_frag_conv():
+            conv_case(dev, FRAG_CONV_CASES[0])
+            conv_case(dev, FRAG_CONV_CASES[1])
+            bf16_exact_conv_case(dev, cin=64, cout=128, k=3, s=1, N=1, up=((4, 3), (17, 6)), cin2=64)
+        with force_frag_conv(v128=1, v64=4, v32=6, lin=1):
+            conv_case(dev, FRAG_CONV_CASES[4])
+            conv_case(dev, FRAG_CONV_CASES[5])
+        return
+    for kw in (dict(), dict(v128=1, v64=3, v32=6), dict(v64=4, lin=0), dict(lin=1)):
+        with force_frag_conv(**kw):
+            for c in FRAG_CONV_CASES:
+                conv_case(dev, c)
+    for kw in (dict(), dict(v128=1, v64=3, lin=1), dict(v64=4, lin=0)):
+        with force_frag_conv(**kw):
+            bf16_exact_conv_case(dev, cin=64, cout=64, k=3, s=1, H=9, W=19, N=1)
+            bf16_exact_conv_case(dev, cin=64, cout=128, k=3, s=1, N=1, up=((4, 3), (17, 6)), cin2=64)     # concat + nearest up-sampling in the gather
+            bf16_exact_conv_case(dev, cin=128, cout=160, k=3, s=1, H=17, W=33, N=2)
+            bf16_exact_conv_case(dev, cin=192, cout=96, k=3, s=1, H=9, W=10, N=3)
+            bf16_exact_conv_case(dev, cin=64, cout=256, k=3, s=1, H=15, W=6, N=9)                          # linear tiles across images, two channel blocks
+            bf16_exact_conv_case(dev, cin=64, cout=32, k=3, s=1, H=30, W=12, N=4)
+
+
 class force_tiny_wgrad(force_patch_conv):
     """Send the few-channel weight gradients (3->3, 3->32 stride 2, 32->1) through the register-accumulating streaming kernel at any size."""
     def __init__(self):

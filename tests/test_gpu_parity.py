@@ -38,6 +38,16 @@ def test_patch_conv_decoder_and_bf16(gpu):
     P.conv_case(gpu, dict(cin=64, cout=64, k=3, s=1, H=64, W=96, N=4, bn=True))
 
 
+def test_frag_conv(gpu):
+    P.frag_conv_cases(gpu)
+    # RC-Net sizes, routed by block count (no hooks): RoI maps as pixel runs across images, encoder maps as 2-D tiles
+    P.bf16_exact_conv_case(gpu, cin=256, cout=128, k=3, s=1, H=30, W=12, N=40)
+    P.bf16_exact_conv_case(gpu, cin=128, cout=64, k=3, s=1, N=24, up=((30, 12), (60, 25)), cin2=0)
+    P.bf16_exact_conv_case(gpu, cin=64, cout=64, k=3, s=1, H=62, W=77, N=4)
+    P.conv_case(gpu, dict(cin=64, cout=64, k=3, s=1, H=64, W=96, N=4, bn=True))
+    P.conv_case(gpu, dict(cin=128, cout=128, k=3, s=1, H=15, W=6, N=60, bn=True))
+
+
 def test_experimental_dma_conv_exact(gpu):
     P.dma_conv_cases(gpu)
 
