@@ -53,7 +53,9 @@ typedef struct rd_conv_desc {
   int32_t D1;                  /* output channels [0,D1) -> dst1, [D1,Cout) -> dst2 (D1 = Cout: one)  */
 } rd_conv_desc;
 
-/* elements (of the activation dtype) in a packed weight buffer for `rows` x (KH*KW*C) */
+/* elements (of the activation dtype) in a packed weight buffer for `rows` x (KH*KW*C).  K axes that can be 9 taps x whole 128-byte channel
+ * chunks get room for a second, MFMA-fragment-ordered copy behind the row-major one (written by the pack calls for 3x3 kernels, read by the
+ * register-fed 3x3 kernel of rd_conv_fwd) */
 int64_t rd_conv_packed_elems(int32_t rows, int32_t K, int32_t dtype);
 /* OIHW fp32 -> packed; mode 0: forward operand, mode 1: data-gradient operand (transposed + flipped) */
 int rd_conv_pack_weights(const float* w_oihw, void* packed, int32_t Cout, int32_t Cin, int32_t KH, int32_t KW,
@@ -120,6 +122,11 @@ int rd_loftr_layer_bwd(const void* x, const void* src, const rd_loftr_weights* w
 int32_t rd_conv_stats_rows(const rd_conv_desc* d);
 int rd_conv_fwd(const rd_conv_desc* d, const void* src1, const void* src2, const void* w_packed, const float* bias,
                 void* dst1, void* dst2, float* stats, void* stream);
+/* Name of the kernel instantiation rd_conv_fwd / rd_conv_wgrad run this shape on, as rocprofv3's kernel trace prints it (without the
+ * `void rd::` prefix and the argument list): bench.py groups its per-launch HIP-event timings by it so that its `roofline` object describes
+ * the same kernel a `rocprofv3 --kernel-trace --stats` summary of the run ranks first.  Thread-local storage, valid until the next call. */
+const char* rd_conv_fwd_kernel_name(const rd_conv_desc* d);
+const char* rd_conv_wgrad_kernel_name(const rd_conv_desc* d);
 /* fp32 workspace bytes needed by rd_conv_wgrad */
 int64_t rd_conv_wgrad_workspace_bytes(const rd_conv_desc* d);
 /* dw (OIHW fp32) = or += dY^T * gather(X); deterministic two-stage reduction */
@@ -276,9 +283,22 @@ int rd_project_scatter(const float* points, int32_t n, int32_t stride, const dou
 int rd_tri_raster(const int32_t* simplices, const int32_t* point_row, const int32_t* point_col, const double* values, int32_t n_simplices,
                   int32_t H, int32_t W, double fill_value, int32_t* owner_workspace, double* out, void* stream);
 
+/* HOST helper (no GPU work): reverse the per-scanline PNG filters (None / Sub / Up / Average / Paeth) of an inflated 8- or 16-bit grayscale
+ * image: raw = h rows of (1 filter byte + row_bytes), bpp = bytes per pixel, out = h * row_bytes.  The depth-map reader of
+ * data/data_utils.py:94-125 (PIL there) uses it for the rows whose recurrences do not vectorise. */
+int rd_png_unfilter_host(const uint8_t* raw, int32_t h, int32_t row_bytes, int32_t bpp, uint8_t* out);
+
 /* ---- optimizer -- RCNet/rcnet_main.py:233-238,357-359; train_zju.py:205-211,390-392 ------------------------ */
 int rd_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
                  float beta2, float eps, float weight_decay, int64_t step, float grad_scale, void* stream);
+/* fp16 mode with a static loss scale (the reference trains in fp32; BASELINE configs[4] asks for fp16): an inf / NaN in the scaled gradients
+ * must not reach the moments.  rd_grad_finite_check makes flag[0] non-zero (device int32[2]) if any of the n gradients is not finite;
+ * rd_adam_step_guarded is rd_adam_step that returns at once while flag[0] is set (parameters and moments untouched);
+ * rd_adam_skip_count, called once after the step's Adam launches, moves a raised flag into the skipped-steps counter flag[1]. */
+int rd_grad_finite_check(const float* grad, int64_t n, int32_t* flag, void* stream);
+int rd_adam_step_guarded(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr, float beta1,
+                         float beta2, float eps, float weight_decay, int64_t step, float grad_scale, const int32_t* skip_flag, void* stream);
+int rd_adam_skip_count(int32_t* flag, void* stream);
 
 /* ==== Scale Map Learner (MiDaS-small) ================================================================================ */
 /* depthwise convolution of the tf_efficientnet_lite3 backbone (modules/midas/blocks.py:44-64; torch.hub, third-party):

@@ -9,6 +9,7 @@
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
+#include <stdlib.h>
 
 namespace {
 thread_local char g_err[512] = "";
@@ -169,6 +170,17 @@ int rd_conv_fwd(const rd_conv_desc* d, const void* src1, const void* src2, const
   a.src1 = src1; a.src2 = src2; a.w = w_packed; a.bias = bias; a.dst1 = dst1; a.dst2 = dst2; a.stats = stats;
   RD_NS(d->dtype, launch_conv)(a, RD_DT(d->dtype), S(stream));
   return done("rd_conv_fwd");
+}
+const char* rd_conv_fwd_kernel_name(const rd_conv_desc* d) {
+  if (!d || check_desc(d)) return "";
+  rd::ConvArgs a; fill_args(d, a);
+  return RD_NS(d->dtype, conv_kernel_name)(a, RD_DT(d->dtype));
+}
+static void fill_wgrad_args(const rd_conv_desc* d, rd::WgradArgs& a);
+const char* rd_conv_wgrad_kernel_name(const rd_conv_desc* d) {
+  if (!d || check_desc(d) || d->in_dilate != 1) return "";
+  rd::WgradArgs a; fill_wgrad_args(d, a);
+  return RD_NS(d->dtype, wgrad_kernel_name)(a, RD_DT(d->dtype));
 }
 static void fill_wgrad_args(const rd_conv_desc* d, rd::WgradArgs& a) {
   memset(&a, 0, sizeof(a));
@@ -364,6 +376,7 @@ int rd_roi_pool_bwd_gather(const void* dout, const float* rois, const int32_t* a
 }
 int rd_cast(const void* src, void* dst, int64_t n, int32_t sd, int32_t dd, float scale, void* stream) {
   if (!src || !dst || !dt_ok(sd) || !dt_ok(dd)) return fail("cast: bad args");
+  if ((sd == RD_BF16 && dd == RD_F16) || (sd == RD_F16 && dd == RD_BF16)) return fail("cast: bf16 <-> fp16 is not supported (the two 16-bit types live in separate builds): convert through fp32");
   if (n == 0) return 0;
   RD_NS(((sd == RD_F16 || dd == RD_F16) ? RD_F16 : RD_F32), launch_cast)(src, dst, n, RD_DT(sd), RD_DT(dd), scale, S(stream));
   return done("rd_cast");
@@ -377,11 +390,13 @@ int rd_add(const void* a, const void* b, void* out, int64_t n, int32_t dtype, vo
 int rd_nchw_to_nhwc(const void* src, void* dst, int32_t N, int32_t C, int32_t H, int32_t W, int32_t sd, int32_t dd, float scale,
                     void* stream) {
   if (!src || !dst || !dt_ok(sd) || !dt_ok(dd)) return fail("nchw_to_nhwc: bad args");
+  if ((sd == RD_BF16 && dd == RD_F16) || (sd == RD_F16 && dd == RD_BF16)) return fail("nchw_to_nhwc: bf16 <-> fp16 is not supported (the two 16-bit types live in separate builds): convert through fp32");
   RD_NS(((sd == RD_F16 || dd == RD_F16) ? RD_F16 : RD_F32), launch_nchw_to_nhwc)(src, dst, N, C, H, W, RD_DT(sd), RD_DT(dd), scale, S(stream));
   return done("rd_nchw_to_nhwc");
 }
 int rd_nhwc_to_nchw(const void* src, void* dst, int32_t N, int32_t C, int32_t H, int32_t W, int32_t sd, int32_t dd, void* stream) {
   if (!src || !dst || !dt_ok(sd) || !dt_ok(dd)) return fail("nhwc_to_nchw: bad args");
+  if ((sd == RD_BF16 && dd == RD_F16) || (sd == RD_F16 && dd == RD_BF16)) return fail("nhwc_to_nchw: bf16 <-> fp16 is not supported (the two 16-bit types live in separate builds): convert through fp32");
   RD_NS(((sd == RD_F16 || dd == RD_F16) ? RD_F16 : RD_F32), launch_nhwc_to_nchw)(src, dst, N, C, H, W, RD_DT(sd), RD_DT(dd), S(stream));
   return done("rd_nhwc_to_nchw");
 }
@@ -512,6 +527,33 @@ int rd_tri_raster(const int32_t* simplices, const int32_t* point_row, const int3
   return done("rd_tri_raster");
 }
 
+// PNG scanline un-filtering on the HOST (data/data_utils.py:94-125 reads the 16-bit depth maps through PIL; PIL's writer picks Sub / Up /
+// Average / Paeth per scanline, and the serial Average / Paeth recurrences cost ~0.3 s per 256x512 map as an interpreter loop).
+int rd_png_unfilter_host(const uint8_t* raw, int32_t h, int32_t row_bytes, int32_t bpp, uint8_t* out) {
+  if (!raw || !out || h < 0 || row_bytes <= 0 || bpp <= 0) return fail("png_unfilter_host: bad args");
+  for (int y = 0; y < h; y++) {
+    const uint8_t* line = raw + (size_t)y * (row_bytes + 1);
+    uint8_t* cur = out + (size_t)y * row_bytes;
+    const uint8_t* prev = y ? cur - row_bytes : nullptr;
+    const int ft = line[0];
+    line++;
+    if (ft > 4) return fail("png_unfilter_host: bad filter type %d in row %d", ft, y);
+    for (int x = 0; x < row_bytes; x++) {
+      const int a = x >= bpp ? cur[x - bpp] : 0, b = prev ? prev[x] : 0, c = (prev && x >= bpp) ? prev[x - bpp] : 0;
+      int pred = 0;
+      if (ft == 1) pred = a;
+      else if (ft == 2) pred = b;
+      else if (ft == 3) pred = (a + b) >> 1;
+      else if (ft == 4) {
+        const int p = a + b - c, pa = abs(p - a), pb = abs(p - b), pc = abs(p - c);
+        pred = (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
+      }
+      cur[x] = (uint8_t)(line[x] + pred);
+    }
+  }
+  return 0;
+}
+
 int rd_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2, float eps, float wd,
                  int64_t step, float gscale, void* stream) {
   if (!p || !g || !m || !v) return fail("adam: null pointer");
@@ -520,6 +562,25 @@ int rd_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float 
   double bc1 = 1.0 - pow((double)b1, (double)step), bc2 = 1.0 - pow((double)b2, (double)step);
   rd::launch_adam(p, g, m, v, n, lr, b1, b2, eps, wd, (float)bc1, (float)sqrt(bc2), gscale, S(stream));
   return done("rd_adam_step");
+}
+int rd_grad_finite_check(const float* g, int64_t n, int32_t* flag, void* stream) {
+  if (!g || !flag) return fail("grad_finite_check: null pointer");
+  if (n > 0) rd::launch_grad_finite(g, n, flag, S(stream));
+  return done("rd_grad_finite_check");
+}
+int rd_adam_step_guarded(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2, float eps, float wd,
+                         int64_t step, float gscale, const int32_t* skip_flag, void* stream) {
+  if (!p || !g || !m || !v || !skip_flag) return fail("adam_guarded: null pointer");
+  if (step < 1) return fail("adam_guarded: step must be >= 1");
+  if (n == 0) return 0;
+  double bc1 = 1.0 - pow((double)b1, (double)step), bc2 = 1.0 - pow((double)b2, (double)step);
+  rd::launch_adam(p, g, m, v, n, lr, b1, b2, eps, wd, (float)bc1, (float)sqrt(bc2), gscale, S(stream), skip_flag);
+  return done("rd_adam_step_guarded");
+}
+int rd_adam_skip_count(int32_t* flag, void* stream) {
+  if (!flag) return fail("adam_skip_count: null pointer");
+  rd::launch_adam_skip_count(flag, S(stream));
+  return done("rd_adam_skip_count");
 }
 
 

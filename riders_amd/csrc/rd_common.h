@@ -242,7 +242,7 @@ __device__ __forceinline__ void dma16_to_lds(const void* gsrc, void* lds_wave_ba
   const unsigned dst = (unsigned)(size_t)(__attribute__((address_space(3))) void*)lds_wave_base;
   unsigned keep;
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
+               : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory", "m0");
 #endif
 }
 // Same DMA with the source given as wave-uniform base (SGPR pair) + per-lane 32-bit byte offset: the per-lane part is a constant of the
@@ -253,7 +253,7 @@ __device__ __forceinline__ void dma16_to_lds_base(const void* gbase_uniform, uns
   emu_global_load_lds16((const char*)gbase_uniform + lane_byte_offset, lds_wave_base);
 #else
   const unsigned dst = (unsigned)(size_t)(__attribute__((address_space(3))) void*)lds_wave_base;
-  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(lane_byte_offset), "s"(gbase_uniform), "s"(dst) : "memory");
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" : : "v"(lane_byte_offset), "s"(gbase_uniform), "s"(dst) : "memory", "m0");
 #endif
 }
 __device__ __forceinline__ void dma_wait_all() {

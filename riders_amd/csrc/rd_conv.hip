@@ -995,6 +995,17 @@ void launch_conv(const ConvArgs& a, int dtype, hipStream_t st) {
   else launch_conv_t<bf16_t>(a, st);
 }
 
+// name of the kernel launch_conv picks for this shape (bench.py groups its per-launch timings by the names rocprofv3 reports)
+const char* conv_kernel_name(const ConvArgs& a, int dtype) {
+  if (conv_few_ok(a)) return "conv_few_kernel";
+  if (conv1x1_direct_ok(a, dtype)) return "conv1x1_direct_kernel";
+  if (conv3x3_c1_ok(a)) return "conv3x3_c1_kernel";
+  if (use_conv3x3_small(a, dtype)) return "conv3x3_small_kernel";
+  if (use_conv3x3_dma(a, dtype)) return "conv3x3_dma_kernel";
+  if (use_conv3x3_frag(a, dtype)) return conv3x3_frag_name(a, dtype);
+  if (use_conv3x3(a, dtype)) return "conv3x3_patch_kernel";
+  return "conv_gemm_kernel";
+}
 void launch_pack_weights(const float* w, void* out, int Cout, int Cin, int KH, int KW, int mode, int dtype,
                          hipStream_t st, int CinSrc) {
   if (CinSrc <= 0) CinSrc = Cin;
@@ -1208,6 +1219,15 @@ void launch_wgrad(WgradArgs a, int dtype, float* dw, int accumulate, hipStream_t
   if (dtype == 0) launch_wgrad_t<float>(a, vec, st);
   else launch_wgrad_t<bf16_t>(a, vec, st);
   reduce(a.nsplit);
+}
+
+const char* wgrad_kernel_name(const WgradArgs& a, int dtype) {
+  const int Cin = a.C1 + a.C2;
+  if (wgrad_tiny_shape(a)) return "conv_wgrad_tiny_kernel";
+  if (wgrad3x3_tr_ok(a, dtype)) return wgrad3x3_tr_name(a);
+  if (wgrad_halo_ok(a, dtype)) return "conv_wgrad_halo_kernel";
+  if (dtype == 1 && (Cin % 8 == 0) && (a.C1 % 8 == 0) && (a.Cout % 8 == 0)) return "conv_wgrad_bf16_kernel";
+  return "conv_wgrad_kernel";
 }
 
 }  // namespace rd

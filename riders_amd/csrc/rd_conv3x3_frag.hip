@@ -23,6 +23,7 @@
 //   * every patch load is unconditional (clamped address, zero selected afterwards) and the next chunk's patch is requested piecewise
 //     BEHIND the fragment loads of the taps (a wave's loads return in order).
 #include "rd_conv_common.h"
+#include <stdio.h>
 
 namespace rd {
 
@@ -309,6 +310,17 @@ bool conv3x3_frag_ok(const ConvArgs& a, int dtype) {
 }
 int conv3x3_frag_tiles(const ConvArgs& a, int dtype) { FragPlan p; frag_plan(a, dtype, p); return p.ntiles; }
 int conv3x3_frag_blocks(const ConvArgs& a, int dtype) { FragPlan p; frag_plan(a, dtype, p); return p.ntiles * p.ncb; }
+
+// the name rocprofv3 prints for the instantiation this shape runs on (dtype tag as in the kernel-trace CSV)
+const char* conv3x3_frag_name(const ConvArgs& a, int dtype) {
+  static thread_local char buf[96];
+  FragPlan p; frag_plan(a, dtype, p);
+  static const int npt[] = {8, 4, 4, 8, 4, 4, 8}, wpx[] = {1, 2, 2, 2, 4, 4, 4}, wch[] = {4, 4, 2, 2, 2, 1, 1};
+  const bool multi = (a.C1 + a.C2) * (dtype == 0 ? 4 : 2) > STAGE_BYTES;
+  snprintf(buf, sizeof(buf), "conv3x3_frag_kernel<%s, %d, %d, %d, %s, %s>", dtype == 0 ? "float" : "rd::bf16_t", npt[p.variant], wpx[p.variant],
+           wch[p.variant], p.lin ? "true" : "false", multi ? "true" : "false");
+  return buf;
+}
 
 template <typename T, int NPT, int WPX, int WCH>
 static void launch_frag_v(const ConvArgs& a, const FragPlan& p, const FragGeom& g, hipStream_t st) {

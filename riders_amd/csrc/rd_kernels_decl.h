@@ -12,6 +12,8 @@ int wgrad_nsplit(int M, int K, int Cout);
 int wgrad_slabs(int M, int K, int Cout);
 int conv_stats_rows(const ConvArgs& a, int dtype);
 void launch_conv(const ConvArgs& a, int dtype, hipStream_t st);
+const char* conv_kernel_name(const ConvArgs& a, int dtype);
+const char* wgrad_kernel_name(const WgradArgs& a, int dtype);
 // rd_conv3x3.hip
 bool conv3x3_ok(const ConvArgs& a, int dtype);
 int conv3x3_tiles(const ConvArgs& a);
@@ -27,6 +29,7 @@ bool conv3x3_frag_ok(const ConvArgs& a, int dtype);
 int conv3x3_frag_tiles(const ConvArgs& a, int dtype);
 int conv3x3_frag_blocks(const ConvArgs& a, int dtype);
 void launch_conv3x3_frag(const ConvArgs& a, int dtype, hipStream_t st);
+const char* conv3x3_frag_name(const ConvArgs& a, int dtype);
 // rd_conv3x3_dma.hip
 bool conv3x3_dma_ok(const ConvArgs& a, int dtype);
 int conv3x3_dma_tiles(const ConvArgs& a);
@@ -46,6 +49,7 @@ void launch_wgrad_reduce_batch(const WgradReduceItem* items, int n, hipStream_t 
 bool wgrad3x3_tr_ok(const WgradArgs& a, int dtype);
 int wgrad3x3_tr_blocks(const WgradArgs& a);
 void launch_wgrad3x3_tr(const WgradArgs& a, hipStream_t st);
+const char* wgrad3x3_tr_name(const WgradArgs& a);
 
 // rd_linear_wgrad.hip (descriptors mirror rd_lwg_gemm / rd_lwg_reduce of the C ABI; passed BY VALUE in kernel arguments)
 void launch_linear_wgrad_batch(const LwgGemm* gemms, int n_gemm, const LwgReduce* reds, int n_red, int dtype, hipStream_t st);
@@ -144,7 +148,9 @@ void launch_project_scatter(const float* pts, int n, int stride, const double* T
 
 // rd_optim.hip
 void launch_adam(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2, float eps,
-                 float wd, float bc1, float bc2, float gscale, hipStream_t st);
+                 float wd, float bc1, float bc2, float gscale, hipStream_t st, const int* skip = nullptr);
+void launch_grad_finite(const float* g, int64_t n, int* flag, hipStream_t st);
+void launch_adam_skip_count(int* flag, hipStream_t st);
 
 
 // rd_dwconv.hip

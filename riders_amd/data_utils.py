@@ -67,34 +67,15 @@ def decode_png16(data):
     if ctype != 0 or interlace != 0 or depth not in (8, 16):
         raise ValueError("unsupported PNG layout (colour type %d, bit depth %d, interlace %d)" % (ctype, depth, interlace))
     bpp = depth // 8
-    raw = np.frombuffer(zlib.decompress(b"".join(idat)), dtype=np.uint8).reshape(h, 1 + w * bpp)
+    raw = np.ascontiguousarray(np.frombuffer(zlib.decompress(b"".join(idat)), dtype=np.uint8).reshape(h, 1 + w * bpp))
     out = np.zeros((h, w * bpp), dtype=np.uint8)
-    prev = np.zeros(w * bpp, dtype=np.int32)
-    for y in range(h):          # PNG scanline filters (PIL picks them adaptively)
-        ft, line = int(raw[y, 0]), raw[y, 1:].astype(np.int32)
-        if ft == 0:
-            cur = line
-        elif ft == 2:
-            cur = (line + prev) & 255
-        else:
-            cur = np.zeros_like(line)
-            for x in range(w * bpp):
-                a = cur[x - bpp] if x >= bpp else 0
-                b = prev[x]
-                c = prev[x - bpp] if x >= bpp else 0
-                if ft == 1:
-                    pred = a
-                elif ft == 3:
-                    pred = (a + b) >> 1
-                elif ft == 4:
-                    p = a + b - c
-                    pa, pb, pc = abs(p - a), abs(p - b), abs(p - c)
-                    pred = a if (pa <= pb and pa <= pc) else (b if pb <= pc else c)
-                else:
-                    raise ValueError("bad PNG filter type %d" % ft)
-                cur[x] = (line[x] + pred) & 255
-        out[y] = cur
-        prev = cur
+    # PNG scanline filters (PIL picks them adaptively): the serial Average / Paeth recurrences run in the library's host helper
+    import ctypes
+    from . import _lib
+    lib = _lib.load() if _lib._lib is None else _lib._lib
+    rc = lib.rd_png_unfilter_host(raw.ctypes.data_as(ctypes.c_void_p), h, w * bpp, bpp, out.ctypes.data_as(ctypes.c_void_p))
+    if rc != 0:
+        raise ValueError("bad PNG filter data: %s" % lib.rd_last_error_string().decode())
     return out.view(">u2").astype(np.uint16) if depth == 16 else out
 
 

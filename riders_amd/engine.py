@@ -101,33 +101,56 @@ def rd_of(t):
 # ------------------------------------------------------------------------------------- kernel timing hook
 class KernelTimer(object):
     """Optional per-launch HIP-event timing of the GEMM-class kernels (used by bench.py for the roofline line).
-    Events are recorded on the stream the kernels are launched on (torch's current stream)."""
+    Events are recorded on the stream the kernels are launched on (torch's current stream).
 
-    def __init__(self):
-        self.records = {}  # kind -> [(start_event, end_event, algorithmic_flops)]
+    repeat > 1: a launch declared idempotent (`idem`: convolution forward / data gradient, weight-gradient slabs -- pure functions of
+    their inputs) is issued `repeat` times back to back between ONE pair of events and its duration is the elapsed time / repeat: the
+    event pair costs a few microseconds per launch, which rocprofv3's kernel durations do not contain (round 2: 27 % over on 50-us
+    launches).  Everything else is issued once."""
 
-    def run(self, kind, flops, fn, desc=None, nbytes=0.0):
+    def __init__(self, repeat=1):
+        self.records = {}  # kind -> [(start_event, end_event, algorithmic_flops, desc, bytes, kernel name, launches between the events)]
+        self.repeat = max(1, int(repeat))
+
+    def run(self, kind, flops, fn, desc=None, nbytes=0.0, kernel=None, idem=False):
         s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        n = self.repeat if idem else 1
         s.record()
         rc = fn()
+        for _ in range(n - 1):
+            fn()
         e.record()
-        self.records.setdefault(kind, []).append((s, e, flops, desc, nbytes))
+        self.records.setdefault(kind, []).append((s, e, flops, desc, nbytes, kernel, n))
         return rc
 
     def detail(self):
         """-> {(kind, desc): (launches, total ms, total flops, total algorithmic bytes)} aggregated over identical launch shapes."""
         out = {}
         for kind, recs in self.records.items():
-            for s, e, f, d, b in recs:
+            for s, e, f, d, b, _k, r in recs:
                 k = (kind, d)
                 n, ms, fl, by = out.get(k, (0, 0.0, 0.0, 0.0))
-                out[k] = (n + 1, ms + s.elapsed_time(e), fl + f, by + b)
+                out[k] = (n + 1, ms + s.elapsed_time(e) / r, fl + f, by + b)
+        return out
+
+    def by_kernel(self):
+        """-> {kernel name: dict(launches, ms, flops, bytes, shapes={desc: [launches, ms, flops, bytes]})} over the launches that carry a name."""
+        out = {}
+        for kind, recs in self.records.items():
+            for s, e, f, d, b, k, r in recs:
+                if not k:
+                    continue
+                o = out.setdefault(k, dict(launches=0, ms=0.0, flops=0.0, bytes=0.0, shapes={}))
+                ms = s.elapsed_time(e) / r
+                o["launches"] += 1; o["ms"] += ms; o["flops"] += f; o["bytes"] += b
+                sh = o["shapes"].setdefault(d, [0, 0.0, 0.0, 0.0])
+                sh[0] += 1; sh[1] += ms; sh[2] += f; sh[3] += b
         return out
 
     def summary(self):
         out = {}
         for kind, recs in self.records.items():
-            ms = sum(r[0].elapsed_time(r[1]) for r in recs)
+            ms = sum(r[0].elapsed_time(r[1]) / r[6] for r in recs)
             fl = sum(r[2] for r in recs)
             out[kind] = dict(launches=len(recs), ms=ms, flops=fl)
         return out
@@ -140,15 +163,15 @@ def set_kernel_timer(t):
     _timer["t"] = t
 
 
-def _timed(kind, flops, fn, desc=None, nbytes=0.0):
+def _timed(kind, flops, fn, desc=None, nbytes=0.0, kernel=None, idem=False):
     kt = _timer["t"]
-    return fn() if kt is None else kt.run(kind, flops, fn, desc, nbytes)
+    return fn() if kt is None else kt.run(kind, flops, fn, desc, nbytes, kernel() if callable(kernel) else kernel, idem)
 
 
-def _tb(kind, nbytes, fn, desc=None):
+def _tb(kind, nbytes, fn, desc=None, kernel=None):
     """HBM-bound launch: algorithmic bytes only (every operand moved once)."""
     kt = _timer["t"]
-    return fn() if kt is None else kt.run(kind, 0.0, fn, desc, float(nbytes))
+    return fn() if kt is None else kt.run(kind, 0.0, fn, desc, float(nbytes), kernel)
 
 
 # ------------------------------------------------------------------------------------------------- tape
@@ -654,7 +677,8 @@ def conv_block(x, weight, *, x2=None, bias=None, stride=1, pad=None, up=None, bn
     b_in = (x.numel() + (0 if x2 is None else x2.numel())) * es
     b_w, b_out = weight.numel() * es, N * OH * OW * Cout * es
     _chk(_timed("conv_gemm", flops, lambda: lib.rd_conv_fwd(ctypes.byref(d), _p(x), _p(x2), _p(wp), _p(bias_t), _p(y), None,
-                                                               _p(stats), st), "fwd " + shp, b_in + b_w + b_out), "rd_conv_fwd")
+                                                               _p(stats), st), "fwd " + shp, b_in + b_w + b_out,
+                kernel=lambda: lib.rd_conv_fwd_kernel_name(ctypes.byref(d)).decode(), idem=True), "rd_conv_fwd")
     pixels = N * OH * OW
     scale = shift = mean = rstd = None
     if use_bn:
@@ -751,7 +775,8 @@ def conv_block(x, weight, *, x2=None, bias=None, stride=1, pad=None, up=None, bn
                 item = _lib.WgradReduceItem()
                 _chk(_timed("conv_wgrad", flops, lambda: lib.rd_conv_wgrad_partial(ctypes.byref(d), _p(x), _p(x2), _p(dy), _p(ws), _p(dw), acc,
                                                                                       ctypes.byref(item), st),
-                            "wgrad " + shp, b_in + b_out + weight.numel() * 4), "rd_conv_wgrad_partial")
+                            "wgrad " + shp, b_in + b_out + weight.numel() * 4,
+                            kernel=lambda: lib.rd_conv_wgrad_kernel_name(ctypes.byref(d)).decode(), idem=True), "rd_conv_wgrad_partial")
                 t.defer_conv_reduce(item, ws, weight)
             else:
                 _chk(_timed("conv_wgrad", flops, lambda: lib.rd_conv_wgrad(ctypes.byref(d), _p(x), _p(x2), _p(dy), _p(ws), _p(dw), acc, st),
@@ -762,7 +787,8 @@ def conv_block(x, weight, *, x2=None, bias=None, stride=1, pad=None, up=None, bn
             dxv1 = torch.empty((N, Hin, Win, C1), dtype=x.dtype, device=x.device)
             dxv2 = torch.empty((N, Hin, Win, C2), dtype=x.dtype, device=x.device) if C2 else None
             _chk(_timed("conv_gemm", flops, lambda: lib.rd_conv_fwd(ctypes.byref(dd), _p(dy), None, _p(wpd), None, _p(dxv1), _p(dxv2),
-                                                                       None, st), "dgrad " + shp, b_out + b_w + N * Hin * Win * Cin * es), "rd_conv_fwd(dgrad)")
+                                                                       None, st), "dgrad " + shp, b_out + b_w + N * Hin * Win * Cin * es,
+                        kernel=lambda: lib.rd_conv_fwd_kernel_name(ctypes.byref(dd)).decode(), idem=True), "rd_conv_fwd(dgrad)")
             if is_up:
                 g1 = torch.empty_like(x)
                 _chk(_tb("elementwise", (dxv1.numel() + g1.numel()) * es,

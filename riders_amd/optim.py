@@ -59,6 +59,7 @@ class FlatAdam(object):
         self._ever = [False] * len(params)      # slot has received a gradient at least once (torch: has optimizer state)
         self.grad_scale = 1.0      # 1 / world size, set by parallel.GradientAllReducer (the all-reduce sums)
         self.loss_scale = 1.0      # static loss scale of the fp16 mode: gradients arrive multiplied by it and are divided here
+        self._overflow = None      # device int32[2] (flag, skipped steps) of the guarded fp16 step, allocated on first use
         engine.set_param_grad_allocator(self._grad_view)
 
     # kept for callers that read the global step (all parameters that train share it)
@@ -72,6 +73,21 @@ class FlatAdam(object):
             return None
         self._touched[i] = True
         return self._gviews[id(p)]
+
+    def mark_touched(self, indices):
+        """Declare these slots written since zero_grad().  A hipGraph REPLAY of the backward writes the arena without going through the
+        gradient allocator (which is what sets the flags in an eager backward): rcnet_main.GraphedStep records the slots its capture pass
+        touched and re-marks them before every step(), so `optimizer.zero_grad()` between replays -- the reference loop's habit -- cannot
+        turn the optimizer step into a silent no-op."""
+        for i in indices:
+            self._touched[i] = True
+
+    def touched_indices(self):
+        return [i for i, t in enumerate(self._touched) if t]
+
+    def skipped_steps(self):
+        """fp16 mode: optimizer steps dropped because a scaled gradient was not finite (synchronises)."""
+        return 0 if self._overflow is None else int(self._overflow[1].item())
 
     def slot_range(self, params):
         """-> sorted, merged [(start, end)] arena element ranges covering `params` (used to bucket the gradient all-reduce)."""
@@ -106,10 +122,14 @@ class FlatAdam(object):
     def _launch(self, start, end, step):
         g = self.param_groups[0]
         sl = slice(start, end)
-        rc = engine._tb("optimizer", 28 * (end - start), lambda: engine.L().rd_adam_step(
-            engine._p(self.flat_param[sl]), engine._p(self.flat_grad[sl]), engine._p(self.exp_avg[sl]), engine._p(self.exp_avg_sq[sl]), end - start,
-            ctypes.c_float(g['lr']), ctypes.c_float(g['betas'][0]), ctypes.c_float(g['betas'][1]), ctypes.c_float(g['eps']),
-            ctypes.c_float(g['weight_decay']), step, ctypes.c_float(self.grad_scale / self.loss_scale), engine._stream(self.flat_param)), "adam")
+        args = (engine._p(self.flat_param[sl]), engine._p(self.flat_grad[sl]), engine._p(self.exp_avg[sl]), engine._p(self.exp_avg_sq[sl]), end - start,
+                ctypes.c_float(g['lr']), ctypes.c_float(g['betas'][0]), ctypes.c_float(g['betas'][1]), ctypes.c_float(g['eps']),
+                ctypes.c_float(g['weight_decay']), step, ctypes.c_float(self.grad_scale / self.loss_scale))
+        st = engine._stream(self.flat_param)
+        if self._overflow is not None:
+            rc = engine._tb("optimizer", 28 * (end - start), lambda: engine.L().rd_adam_step_guarded(*args, engine._p(self._overflow), st), "adam")
+        else:
+            rc = engine._tb("optimizer", 28 * (end - start), lambda: engine.L().rd_adam_step(*args, st), "adam")
         engine._chk(rc, "rd_adam_step")
 
     def step(self):
@@ -122,6 +142,12 @@ class FlatAdam(object):
         live = [s for s, t in zip(self.steps, self._touched) if t]
         if not live:
             return
+        guarded = self.loss_scale != 1.0     # fp16 mode: a non-finite scaled gradient skips the whole update (device-side, no host sync)
+        if guarded:
+            if self._overflow is None:
+                self._overflow = torch.zeros(2, dtype=torch.int32, device=self.flat_param.device)
+            engine._chk(engine.L().rd_grad_finite_check(engine._p(self.flat_grad), self.numel, engine._p(self._overflow),
+                                                        engine._stream(self.flat_param)), "rd_grad_finite_check")
         # one launch when every slot is either written this step (all at the same step count) or has never been written (zero gradient and
         # zero moments: the update is exactly zero); otherwise one launch per run of consecutive written slots that share a step count
         uniform = len(set(live)) == 1 and all(t or not e for t, e in zip(self._touched, self._ever)) and self.param_groups[0]['weight_decay'] == 0
@@ -139,6 +165,8 @@ class FlatAdam(object):
                 end = self.offsets[j + 1] if j + 1 < n else self.numel
                 self._launch(self.offsets[i], end, self.steps[i])
                 i = j + 1
+        if guarded:
+            engine._chk(engine.L().rd_adam_skip_count(engine._p(self._overflow), engine._stream(self.flat_param)), "rd_adam_skip_count")
         engine.refresh_packed()   # one launch re-packs every cached MFMA operand of the rewritten parameters
 
     # ------------------------------------------------------------------ checkpoint interchange with torch.optim.Adam

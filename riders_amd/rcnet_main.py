@@ -251,6 +251,10 @@ class GraphedStep(object):
                 state["ctx"].__exit__(None, None, None)
                 raise
             end(None)
+            # a replay writes the gradient arena without passing the optimizer's gradient allocator: remember what the capture pass touched
+            self.touched = optimizer.touched_indices() if hasattr(optimizer, "touched_indices") else None
+            if self.touched is not None and not self.touched:
+                raise RuntimeError("GraphedStep: the captured backward wrote no parameter gradient")
         finally:
             engine._stage_hooks[:] = hooks
         if on_replay is not None:
@@ -265,6 +269,8 @@ class GraphedStep(object):
             self.on_replay(+1)
         if self.reducer is not None:
             self.reducer.reduce()
+        if self.touched is not None:      # the replay filled these slots, whatever zero_grad() calls happened since the capture
+            self.opt.mark_touched(self.touched)
         self.opt.step()
         return self.loss
 

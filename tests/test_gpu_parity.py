@@ -231,6 +231,33 @@ def test_graphed_step_matches_eager(gpu):
     assert losses["eager"][2] != losses["eager"][0]
 
 
+def test_graphed_step_survives_zero_grad_between_replays(gpu):
+    """The reference loop calls optimizer.zero_grad() before every backward (rcnet_main.py:353-359).  A replay fills the gradient arena
+    without passing the gradient allocator, so the optimizer's written-slot flags must be restored by the graphed step itself: every
+    replay has to move the parameters exactly as without the zero_grad() calls."""
+    import torch
+    from riders_amd import rcnet_main
+    from riders_amd.optim import FlatAdam
+    cfg = dict(rcnet_main.ZJU_CONFIG, patch_size=[64, 32], total_points_sampled=4)
+    batch = rcnet_main.synthetic_batch(2, 64, 96, cfg, seed=5, device=gpu)
+    finals = []
+    for zero in (False, True):
+        torch.manual_seed(0)
+        model = rcnet_main.build_model(gpu, cfg)
+        model.train()
+        opt = FlatAdam(model.parameters(), lr=1e-3)
+        step = rcnet_main.GraphedTrainStep(model, opt, batch, cfg, warmup=1)
+        p0 = opt.flat_param.clone()
+        for _ in range(3):
+            if zero:
+                opt.zero_grad()
+            step()
+        assert not torch.equal(opt.flat_param, p0) and opt.step_count == 3, zero
+        finals.append(opt.flat_param.clone())
+    rel = float((finals[0] - finals[1]).abs().max() / finals[0].abs().max())
+    assert rel <= 1e-3, rel      # only the fp32 atomic order of the small-map RoI-pool scatter differs between runs
+
+
 def test_staged_step_reports_buckets_in_backward_order(gpu):
     """Single-GPU check of the overlap plumbing (N > 1 itself cannot run on a 1-GPU box): with the all-reducer attached, a
     replayed step hands the decoder bucket over after the first graph, the transformer + point-MLP bucket after the second, and

@@ -94,6 +94,77 @@ def test_flat_adam_skips_parameters_without_gradient(emu):
     assert sorted(sd["state"]) == [0, 1] and sorted(ta.state_dict()["state"]) == [0, 1]
 
 
+def test_flat_adam_replay_marking_and_guarded_fp16_step(emu):
+    """(1) A hipGraph replay writes the gradient arena without passing the gradient allocator; with `zero_grad()` between replays (the
+    reference loop's habit) the step must still update: GraphedStep re-marks the slots its capture pass touched (`mark_touched`).
+    (2) fp16 mode (static loss scale): a non-finite scaled gradient skips the whole update on the device and is counted."""
+    from riders_amd.optim import FlatAdam
+    ours, theirs = _toy_params(), _toy_params()
+    shapes = [p.shape for p in ours]
+    fa, ta = FlatAdam(ours, lr=1e-2), torch.optim.Adam(theirs, lr=1e-2)
+    gs = _grads(0, shapes)
+    for p, g in zip(ours, gs):
+        fa._grad_view(p).copy_(g)                      # "capture pass": the backward kernels write the arena through the allocator
+    touched = fa.touched_indices()
+    assert touched == [0, 1, 2]
+    fa.zero_grad()                                     # the training loop clears the flags ...
+    before = [p.detach().clone() for p in ours]
+    fa.step()                                          # ... and without re-marking nothing is live: torch semantics, no update
+    assert all(torch.equal(p, b) for p, b in zip(ours, before))
+    fa.mark_touched(touched)                           # what GraphedStep.__call__ does after its replays
+    fa.step()
+    for q, g in zip(theirs, gs):
+        q.grad = g.clone()
+    ta.step()
+    for p, q in zip(ours, theirs):
+        close(p, q, 1e-6, "replayed step after zero_grad")
+    # (2) guarded step
+    fa.loss_scale = 1024.0
+    fa.zero_grad()
+    for p, g in zip(ours, _grads(1, shapes)):
+        fa._grad_view(p).copy_(g * 1024.0)
+    fa.flat_grad[5] = float("inf")
+    before = [p.detach().clone() for p in ours]
+    m_before = fa.exp_avg.clone()
+    fa.step()
+    assert all(torch.equal(p, b) for p, b in zip(ours, before)) and torch.equal(fa.exp_avg, m_before), "overflow must skip the update"
+    assert fa.skipped_steps() == 1
+    fa.zero_grad()
+    for p, g in zip(ours, _grads(1, shapes)):
+        fa._grad_view(p).copy_(g * 1024.0)
+    fa.step()
+    assert fa.skipped_steps() == 1 and not all(torch.equal(p, b) for p, b in zip(ours, before))
+
+
+def test_cast_rejects_mixed_half_types(emu):
+    """bf16 <-> fp16 would run as a bit copy inside one precision build (rd_api.cpp): the entry points refuse the pair."""
+    from riders_amd import engine
+    from riders_amd._lib import RD_BF16, RD_F16, RD_F32
+    lib = engine.L()
+    a, b = torch.zeros(8, dtype=torch.bfloat16), torch.zeros(8, dtype=torch.float16)
+    assert lib.rd_cast(engine._p(a), engine._p(b), 8, RD_BF16, RD_F16, 1.0, None) != 0
+    assert lib.rd_cast(engine._p(b), engine._p(a), 8, RD_F16, RD_BF16, 1.0, None) != 0
+    assert b"fp16" in lib.rd_last_error_string()
+    assert lib.rd_nchw_to_nhwc(engine._p(a), engine._p(b), 1, 2, 2, 2, RD_BF16, RD_F16, 1.0, None) != 0
+    f = torch.arange(8, dtype=torch.float32)
+    assert lib.rd_cast(engine._p(f), engine._p(b), 8, RD_F32, RD_F16, 1.0, None) == 0 and torch.equal(b.float(), f)
+
+
+def test_bench_launcher_argument_checks():
+    """bench.py --gpus N: WORLD_SIZE must equal --gpus (exit 2); without WORLD_SIZE it spawns its ranks itself and refuses when fewer
+    GPUs are visible (here: none) -- before anything touches a GPU."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=env, capture_output=True, text=True)
+    assert r.returncode == 2 and "only 0 GPU" in r.stderr
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=dict(env, WORLD_SIZE="4", RANK="0"), capture_output=True,
+                       text=True)
+    assert r.returncode == 2 and "WORLD_SIZE=4" in r.stderr
+
+
 def test_packed_operand_is_repacked_in_place(emu):
     """A weight written through torch (load_state_dict / broadcast) keeps its packed MFMA operand at the same address (captured
     hipGraphs read it) and the operand follows the new values."""

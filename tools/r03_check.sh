@@ -1,0 +1,18 @@
+#!/bin/bash
+# Round-3 check in one GPU call: (optional) GPU test suite, the bench line, rocprofv3 kernel statistics.  Output -> gpurun_out/r03_$1/
+# usage: tools/r03_check.sh <tag> [tests|notests] [extra bench flags]
+tag=${1:-a}; what=${2:-tests}; shift; shift
+out=$GRAFT_REPO_ROOT/gpurun_out/r03_$tag; mkdir -p $out
+cd $GRAFT_REPO_ROOT
+if [ "$what" = "tests" ]; then
+  timeout 1500 python -m pytest tests -q -m gpu -x > $out/gpu_tests.log 2>&1
+  tail -5 $out/gpu_tests.log
+  timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $out/smoke.log 2>&1
+  tail -1 $out/smoke.log
+fi
+timeout 900 python bench.py --gpus 1 --steps 50 --warmup 5 --no-cpu-baseline --detail $out/per_shape.txt "$@" > $out/bench.json 2> $out/bench.err
+tail -3 $out/bench.err; cut -c1-400 $out/bench.json
+export TMPDIR=/tmp; cd /tmp
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof -o rc -- python3 $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 3 --settle-seconds 0 --no-cpu-baseline --no-sml "$@" > $out/prof.log 2>&1
+find $out/prof -name "*kernel_stats.csv" -exec cp {} $out/kernel_stats.csv \;
+rm -rf $out/prof
