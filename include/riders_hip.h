@@ -283,6 +283,11 @@ int rd_project_scatter(const float* points, int32_t n, int32_t stride, const dou
 int rd_tri_raster(const int32_t* simplices, const int32_t* point_row, const int32_t* point_col, const double* values, int32_t n_simplices,
                   int32_t H, int32_t W, double fill_value, int32_t* owner_workspace, double* out, void* stream);
 
+/* modules/interpolator.py:7-18 interpolate_knots with interpolate = 'nearest' (scipy griddata -> NearestNDInterpolator): out (H,W) float64 =
+ * value of the closest of n_points knots given as integer (row, col); equidistant knots: the lowest index; no knots: fill_value.  The
+ * 'linear' method of the same function is rd_tri_raster with fill_value 1.0. */
+int rd_nearest_knot(const int32_t* point_row, const int32_t* point_col, const double* values, int32_t n_points, int32_t H, int32_t W,
+                    double fill_value, double* out, void* stream);
 /* HOST helper (no GPU work): reverse the per-scanline PNG filters (None / Sub / Up / Average / Paeth) of an inflated 8- or 16-bit grayscale
  * image: raw = h rows of (1 filter byte + row_bytes), bpp = bytes per pixel, out = h * row_bytes.  The depth-map reader of
  * data/data_utils.py:94-125 (PIL there) uses it for the rows whose recurrences do not vectorise. */

@@ -527,6 +527,13 @@ int rd_tri_raster(const int32_t* simplices, const int32_t* point_row, const int3
   return done("rd_tri_raster");
 }
 
+int rd_nearest_knot(const int32_t* point_row, const int32_t* point_col, const double* values, int32_t n_points, int32_t H, int32_t W,
+                    double fill_value, double* out, void* stream) {
+  if (n_points < 0 || H <= 0 || W <= 0 || !out) return fail("nearest_knot: bad args");
+  if (n_points > 0 && (!point_row || !point_col || !values)) return fail("nearest_knot: null pointer");
+  rd::launch_nearest_knot(point_row, point_col, values, n_points, H, W, fill_value, out, S(stream));
+  return done("rd_nearest_knot");
+}
 // PNG scanline un-filtering on the HOST (data/data_utils.py:94-125 reads the 16-bit depth maps through PIL; PIL's writer picks Sub / Up /
 // Average / Paeth per scanline, and the serial Average / Paeth recurrences cost ~0.3 s per 256x512 map as an interpreter loop).
 int rd_png_unfilter_host(const uint8_t* raw, int32_t h, int32_t row_bytes, int32_t bpp, uint8_t* out) {

@@ -234,6 +234,34 @@ void launch_tri_raster(const int* tri, const int* prow, const int* pcol, const d
   hipLaunchKernelGGL(tri_interp_kernel, dim3(aug_grid(n)), dim3(256), 0, st, tri, prow, pcol, values, owner, H, W, fill, out);
 }
 
+// ---- nearest-knot map (modules/interpolator.py:7-18 with interpolate = 'nearest': scipy griddata -> NearestNDInterpolator) ------------
+// Every pixel takes the value of the closest knot.  Knots and queries are integer pixel coordinates, so the squared distances are exact
+// integers; among equidistant knots the LOWEST index wins (scipy's cKDTree leaves ties implementation-defined; the fixture has none).
+// Brute force with the knots staged through LDS in blocks of 256: K is the number of radar / lidar returns of one frame.
+__global__ __launch_bounds__(256) void nearest_knot_kernel(const int* __restrict__ prow, const int* __restrict__ pcol, const double* __restrict__ values,
+                                                           int K, int H, int W, double fill, double* __restrict__ out) {
+  __shared__ int sr[256], sc[256];
+  const int64_t n = (int64_t)H * W;
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int r = (int)(i / W), c = (int)(i % W);
+  int64_t best = INT64_MAX; int arg = -1;
+  for (int k0 = 0; k0 < K; k0 += 256) {
+    const int kk = k0 + (int)threadIdx.x;
+    sr[threadIdx.x] = kk < K ? prow[kk] : 0; sc[threadIdx.x] = kk < K ? pcol[kk] : 0;
+    __syncthreads();
+    const int m = min(256, K - k0);
+    for (int j = 0; j < m; j++) {
+      const int64_t dr = r - sr[j], dc = c - sc[j], d2 = dr * dr + dc * dc;
+      if (d2 < best) { best = d2; arg = k0 + j; }
+    }
+    __syncthreads();
+  }
+  if (i < n) out[i] = arg >= 0 ? values[arg] : fill;
+}
+void launch_nearest_knot(const int* prow, const int* pcol, const double* values, int K, int H, int W, double fill, double* out, hipStream_t st) {
+  hipLaunchKernelGGL(nearest_knot_kernel, dim3((unsigned)cdiv((int64_t)H * W, 256)), dim3(256), 0, st, prow, pcol, values, K, H, W, fill, out);
+}
+
 void launch_project_scatter(const float* pts, int n, int stride, const double* T, const double* P, int H, int W, double dmin, double dmax, float* depth_map,
                             float* kept, int* nkept, hipStream_t st) {
   unsigned* map = reinterpret_cast<unsigned*>(depth_map);

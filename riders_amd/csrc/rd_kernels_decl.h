@@ -144,6 +144,7 @@ void launch_augment_flip_labels(const float* lin, float* lout, int B, int K, int
 void launch_crop_patches(const float* gt, const float* points, float* crops, int B, int K, int Hp, int Wp, int ph, int pw, hipStream_t st);
 
 void launch_tri_raster(const int* tri, const int* prow, const int* pcol, const double* values, int M, int H, int W, double fill, int* owner, double* out, hipStream_t st);
+void launch_nearest_knot(const int* prow, const int* pcol, const double* values, int K, int H, int W, double fill, double* out, hipStream_t st);
 void launch_project_scatter(const float* pts, int n, int stride, const double* T, const double* P, int H, int W, double dmin, double dmax, float* depth_map, float* kept, int* nkept, hipStream_t st);
 
 // rd_optim.hip

@@ -49,7 +49,8 @@ def encode_png16(q, level=6):
 
 
 def decode_png16(data):
-    """bytes of an 8/16-bit grayscale, non-interlaced PNG (what PIL writes for modes 'I' / 'I;16' / 'L') -> integer (H,W) array."""
+    """bytes of an 8/16-bit grayscale (what PIL writes for modes 'I' / 'I;16' / 'L') or 8-bit RGB / RGBA, non-interlaced PNG -> integer
+    (H,W) or (H,W,C) array."""
     if data[:8] != _SIG:
         raise ValueError("not a PNG file")
     pos, idat, hdr = 8, [], None
@@ -64,9 +65,10 @@ def decode_png16(data):
         elif tag == b"IEND":
             break
     w, h, depth, ctype, _, _, interlace = hdr
-    if ctype != 0 or interlace != 0 or depth not in (8, 16):
+    chans = {0: 1, 2: 3, 6: 4}.get(ctype)
+    if chans is None or interlace != 0 or depth not in (8, 16) or (chans > 1 and depth != 8):
         raise ValueError("unsupported PNG layout (colour type %d, bit depth %d, interlace %d)" % (ctype, depth, interlace))
-    bpp = depth // 8
+    bpp = chans * depth // 8
     raw = np.ascontiguousarray(np.frombuffer(zlib.decompress(b"".join(idat)), dtype=np.uint8).reshape(h, 1 + w * bpp))
     out = np.zeros((h, w * bpp), dtype=np.uint8)
     # PNG scanline filters (PIL picks them adaptively): the serial Average / Paeth recurrences run in the library's host helper
@@ -76,7 +78,27 @@ def decode_png16(data):
     rc = lib.rd_png_unfilter_host(raw.ctypes.data_as(ctypes.c_void_p), h, w * bpp, bpp, out.ctypes.data_as(ctypes.c_void_p))
     if rc != 0:
         raise ValueError("bad PNG filter data: %s" % lib.rd_last_error_string().decode())
+    if chans > 1:
+        return out.reshape(h, w, chans)
     return out.view(">u2").astype(np.uint16) if depth == 16 else out
+
+
+def load_image(path, normalize=False, data_format='HWC'):
+    """data/data_utils.py:59-90: an RGB image as float32 (H,W,3) or (3,H,W); 8-bit grayscale files are replicated to three channels and an
+    alpha channel is dropped, as PIL's convert('RGB') does."""
+    px = decode_png16(open(path, "rb").read())
+    if px.ndim == 2:
+        if px.dtype != np.uint8:
+            raise ValueError("16-bit grayscale images are depth maps: use load_depth")
+        px = np.repeat(px[:, :, None], 3, axis=2)
+    image = np.asarray(px[:, :, :3], np.float32)
+    if data_format == 'HWC':
+        pass
+    elif data_format == 'CHW':
+        image = np.transpose(image, (2, 0, 1))
+    else:
+        raise ValueError('Unsupported data format: {}'.format(data_format))
+    return image / 255.0 if normalize else image
 
 
 def load_depth(path, multiplier=256.0, data_format='HW'):

@@ -271,8 +271,74 @@ def g_interpolation():
     save("g15_interpolation", depth=z, linear=lin.astype(np.float64), log=logz.astype(np.float64), delft=delft.astype(np.float64))
 
 
+# ---------------------------------------------------------------------------------------------- G16: training samples (fake radar)
+def g_datasets():
+    """The reference's own RCNetTrainingDataset.__getitem__ (data/datasets.py:168-291) on files written here: an RGB frame (PIL), a radar
+    .npy and a 16-bit ground-truth PNG (the reference's save_depth).  Three seeded draws: plain radar sampling, the fake-radar branch
+    (sample_probability_of_lidar = 1: points drawn from the lidar map + noise, :214-240), and a frame with fewer points than are sampled
+    (repeat x100 branch) whose radar file is a single (3,) row."""
+    import random
+    import tempfile
+    from PIL import Image
+    from data import datasets as RD
+    from data import data_utils as RU
+    H, W, ph, pw, K = 36, 60, 12, 8, 6
+    rs = np.random.RandomState(1616)
+    img = rs.randint(0, 256, (H, W, 3)).astype(np.uint8)
+    gt = np.zeros((H, W), np.float32)
+    idx = rs.choice(H * W, 500, replace=False)
+    gt.flat[idx] = rs.uniform(0.5, 70.0, idx.size).astype(np.float32)
+    radar = np.stack([rs.uniform(0, W - 1, 11), rs.uniform(0, H - 1, 11), rs.uniform(2, 60, 11)], 1)          # float64 (x, y, depth)
+    single = radar[3].copy()
+    out = dict(image=img, radar=radar, single=single)
+    with tempfile.TemporaryDirectory() as d:
+        ip, rp, sp, gp = [os.path.join(d, n) for n in ("img.png", "radar.npy", "single.npy", "gt.png")]
+        Image.fromarray(img).save(ip)
+        np.save(rp, radar); np.save(sp, single)
+        RU.save_depth(gt, gp)
+        out["gt_png"] = np.frombuffer(open(gp, "rb").read(), dtype=np.uint8)
+        out["img_png"] = np.frombuffer(open(ip, "rb").read(), dtype=np.uint8)
+        for tag, rpath, p, seed in (("plain", rp, 0.0, 5), ("fake", rp, 1.0, 6), ("few", sp, 0.0, 7), ("fake_few", sp, 1.0, 8)):
+            ds = RD.RCNetTrainingDataset([ip], [rpath], [gp], patch_size=[ph, pw], total_points_sampled=K, sample_probability_of_lidar=p)
+            np.random.seed(seed); random.seed(seed)
+            im, pts, boxes, crops = ds[0]
+            out.update({tag + "_image": im, tag + "_points": pts, tag + "_boxes": boxes, tag + "_crops": crops, tag + "_seed": np.array([seed])})
+    out["cfg"] = np.array([ph, pw, K])
+    save("g16_datasets", **out)
+
+
+# ---------------------------------------------------------------------------------------------- G17: knot interpolation (Interpolator2D)
+def g_interpolator():
+    """The reference's own Interpolator2D (modules/interpolator.py:21-49) on a seeded inverse-depth pair: interpolated scale maps for
+    'linear' and 'nearest' (scipy griddata, fill_value 1.0).  `tie` marks the pixels with two equidistant nearest knots, the one thing
+    scipy's cKDTree leaves implementation-defined."""
+    from modules import interpolator as RI
+    H, W = 34, 46
+    rs = np.random.RandomState(1717)
+    pred_inv = rs.uniform(0.02, 0.4, (H, W)).astype(np.float32)
+    sparse_inv = np.zeros((H, W), np.float32)
+    valid = np.zeros((H, W), bool)
+    valid.flat[rs.choice(H * W, 40, replace=False)] = True
+    r, c = np.nonzero(valid)
+    qr, qc = np.mgrid[0:H, 0:W]
+    srt = np.sort((qr[..., None] - r) ** 2 + (qc[..., None] - c) ** 2, axis=-1)
+    tie = srt[..., 0] == srt[..., 1]          # pixels with two equidistant nearest knots: scipy's cKDTree leaves the pick implementation-defined
+    sparse_inv[valid] = rs.uniform(0.02, 0.4, int(valid.sum())).astype(np.float32)
+    it = RI.Interpolator2D(pred_inv=pred_inv, sparse_depth_inv=sparse_inv, valid=valid)
+    it.generate_interpolated_scale_map(interpolate_method='linear', fill_corners=False)
+    lin = it.interpolated_scale_map.copy()
+    it.generate_interpolated_scale_map(interpolate_method='nearest', fill_corners=False)
+    near = it.interpolated_scale_map.copy()
+    save("g17_interpolator", pred_inv=pred_inv, sparse_inv=sparse_inv, valid=valid, linear=lin, nearest=near, tie=tie, knot_coords=it.knot_coords,
+         knot_scales=it.knot_scales, knot_shifts=it.knot_shifts)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["attention", "resnet", "decoder", "e2e", "png", "transforms", "projection", "interpolation"]
+    which = sys.argv[1:] or ["attention", "resnet", "decoder", "e2e", "png", "transforms", "projection", "interpolation", "datasets", "interpolator"]
+    if "datasets" in which:
+        g_datasets()
+    if "interpolator" in which:
+        g_interpolator()
     if "interpolation" in which:
         g_interpolation()
     if "projection" in which:

@@ -649,6 +649,50 @@ def projection_case(dev):
     assert float(empty.abs().max()) == 0.0
 
 
+def interpolator_case(dev, big=False):
+    """X2: riders_amd.interpolator.Interpolator2D (modules/interpolator.py:7-49) against fixture g17, the REFERENCE's own class on scipy
+    griddata: 'linear' (Delaunay on the host, barycentric raster on the device, fill 1.0) to 1e-6 of the float32 map, 'nearest' exact
+    where the nearest knot is unique and one of the equidistant knots' values where it is not; then both against the oracle full-size."""
+    from riders_amd.interpolator import Interpolator2D
+    from oracle import interp as OI
+    g = load("g17_interpolator")
+    it = Interpolator2D(pred_inv=g["pred_inv"], sparse_depth_inv=g["sparse_inv"], valid=g["valid"])
+    assert np.array_equal(it.knot_coords, g["knot_coords"]) and np.array_equal(it.knot_scales, g["knot_scales"])
+    assert np.array_equal(it.knot_shifts, g["knot_shifts"]) and len(it.knot_list) == int(g["valid"].sum())
+    it.generate_interpolated_scale_map(interpolate_method='linear', fill_corners=False, device=dev)
+    lin = it.interpolated_scale_map
+    assert lin.dtype == np.float32 and np.array_equal(lin == 1.0, g["linear"] == 1.0), "fill pattern (convex hull) differs"
+    assert np.abs(lin - g["linear"]).max() <= 1e-6 * np.abs(g["linear"]).max()
+    it.generate_interpolated_scale_map(interpolate_method='nearest', fill_corners=False, device=dev)
+    near, tie = it.interpolated_scale_map, g["tie"]
+    assert np.array_equal(near[~tie], g["nearest"][~tie])
+    r, c = np.nonzero(g["valid"])
+    vals = g["knot_scales"].astype(np.float32)
+    for y, x in zip(*np.nonzero(tie)):
+        d2 = (r - y) ** 2 + (c - x) ** 2
+        assert near[y, x] in vals[d2 == d2.min()], "tie pixel took a knot that is not nearest"
+    try:
+        it.generate_interpolated_scale_map(interpolate_method='cubic', device=dev)
+        raise AssertionError("cubic must be refused")
+    except NotImplementedError:
+        pass
+    if big:
+        rs = np.random.RandomState(78)
+        H, W = 288, 384
+        pred = rs.uniform(0.02, 0.5, (H, W)).astype(np.float32)
+        valid = np.zeros((H, W), bool)
+        valid.flat[rs.choice(H * W, 1500, replace=False)] = True
+        sparse = np.where(valid, rs.uniform(0.02, 0.5, (H, W)), 0).astype(np.float32)
+        it = Interpolator2D(pred_inv=pred, sparse_depth_inv=sparse, valid=valid)
+        it.generate_interpolated_scale_map('linear', device=dev)
+        want = OI.interpolated_scale_map(pred, sparse, valid, 'linear')
+        assert np.array_equal(it.interpolated_scale_map == 1.0, want == 1.0)
+        assert np.abs(it.interpolated_scale_map - want).max() <= 1e-6 * np.abs(want).max()
+        it.generate_interpolated_scale_map('nearest', device=dev)
+        want = OI.interpolated_scale_map(pred, sparse, valid, 'nearest')
+        assert (it.interpolated_scale_map != want).mean() < 0.02      # only equidistant-knot pixels may differ
+
+
 def interpolation_case(dev, big=False):
     """N4: lidar interpolation (Delaunay on the host, barycentric raster on the device) against fixture g15 (the REFERENCE's
     interpolate_depth, linear and log space, and interpolate_depth_delft), then against the oracle on a seeded full-size map."""

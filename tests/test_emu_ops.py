@@ -166,6 +166,7 @@ def test_projection_scatter(emu):
 
 def test_lidar_interpolation(emu):
     P.interpolation_case(emu)
+    P.interpolator_case(emu)
 
 
 def test_fp16_build_exact(emu):

@@ -109,6 +109,7 @@ def test_projection_scatter(gpu):
 
 def test_lidar_interpolation(gpu):
     P.interpolation_case(gpu, big=True)
+    P.interpolator_case(gpu, big=True)
 
 
 def test_fp16_build(gpu):

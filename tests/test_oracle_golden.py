@@ -200,3 +200,51 @@ def test_interpolation_oracle_matches_reference_fixture():
     assert np.array_equal(OI.interpolate_depth(z, valid), g["linear"])
     assert np.array_equal(OI.interpolate_depth(z, valid, log_space=True), g["log"])
     assert np.array_equal(OI.interpolate_depth(z), g["delft"])
+
+
+def _g16_frames():
+    """Decode the files the reference read for g16 (an RGB frame PIL wrote, the 16-bit ground-truth PNG its save_depth wrote)."""
+    from riders_amd import data_utils
+    g = load("g16_datasets")
+    img = np.transpose(data_utils.decode_png16(g["img_png"].tobytes()).astype(np.float32), (2, 0, 1))
+    assert np.array_equal(img, np.transpose(g["image"].astype(np.float32), (2, 0, 1)))
+    gt = data_utils.decode_png16(g["gt_png"].tobytes()).astype(np.float32) / 256.0
+    gt[gt <= 0] = 0.0
+    return g, img, gt[None]
+
+
+def test_training_sample_oracle_and_product_match_reference_fixture(tmp_path):
+    """N2 (data/datasets.py:168-291, the fake-radar draw :214-240): oracle/datasets.py and riders_amd/datasets.py against g16, the
+    reference class's own outputs for four seeded frames -- exact, every array."""
+    import random
+    from oracle import datasets as OD
+    from riders_amd import datasets as PD
+    g, img, gt = _g16_frames()
+    ph, pw, K = [int(v) for v in g["cfg"]]
+    ip, gp, rp, sp = [str(tmp_path / n) for n in ("img.png", "gt.png", "radar.npy", "single.npy")]
+    open(ip, "wb").write(g["img_png"].tobytes()); open(gp, "wb").write(g["gt_png"].tobytes())
+    np.save(rp, g["radar"]); np.save(sp, g["single"])
+    for tag, radar, rpath, p in (("plain", g["radar"], rp, 0.0), ("fake", g["radar"], rp, 1.0), ("few", g["single"], sp, 0.0), ("fake_few", g["single"], sp, 1.0)):
+        seed = int(g[tag + "_seed"][0])
+        want = [g[tag + "_" + k] for k in ("image", "points", "boxes", "crops")]
+        np.random.seed(seed); random.seed(seed)
+        got_o = OD.training_sample(img, radar, gt, [ph, pw], K, p)
+        np.random.seed(seed); random.seed(seed)
+        got_p = PD.sample_training_frame(img, radar, gt, [ph, pw], K, p)
+        ds = PD.RCNetTrainingDataset([ip], [rpath], [gp], patch_size=[ph, pw], total_points_sampled=K, sample_probability_of_lidar=p)
+        np.random.seed(seed); random.seed(seed)
+        got_d = ds[0]
+        for name, got in (("oracle", got_o), ("product", got_p), ("product dataset", got_d)):
+            for w, a, k in zip(want, got, ("image", "points", "boxes", "crops")):
+                assert a.dtype == np.float32 and a.shape == w.shape and np.array_equal(a, w), (tag, name, k)
+    assert not np.array_equal(g["plain_points"], g["fake_points"])      # the fake branch really replaced the points
+
+
+def test_knot_interpolation_oracle_matches_reference_fixture():
+    """X2: oracle/interp.py interpolate_knots / interpolated_scale_map against g17 (the reference's Interpolator2D run here)."""
+    from oracle import interp as OI
+    g = load("g17_interpolator")
+    lin = OI.interpolated_scale_map(g["pred_inv"], g["sparse_inv"], g["valid"], 'linear')
+    near = OI.interpolated_scale_map(g["pred_inv"], g["sparse_inv"], g["valid"], 'nearest')
+    assert np.array_equal(lin, g["linear"]) and np.array_equal(near, g["nearest"])
+    assert float((g["linear"] == 1.0).mean()) > 0.1      # the fill value outside the convex hull is exercised
