@@ -22,6 +22,7 @@
 // one pixel -> one 16-byte (fp32) / 8-byte (bf16) NHWC store per lane per tile.
 #include "rd_conv_common.h"
 #include <type_traits>
+#include <stdio.h>
 
 namespace rd {
 
@@ -1000,11 +1001,20 @@ const char* conv_kernel_name(const ConvArgs& a, int dtype) {
   if (conv_few_ok(a)) return "conv_few_kernel";
   if (conv1x1_direct_ok(a, dtype)) return "conv1x1_direct_kernel";
   if (conv3x3_c1_ok(a)) return "conv3x3_c1_kernel";
-  if (use_conv3x3_small(a, dtype)) return "conv3x3_small_kernel";
+  if (use_conv3x3_small(a, dtype)) return conv3x3_small_name(a, dtype);
   if (use_conv3x3_dma(a, dtype)) return "conv3x3_dma_kernel";
   if (use_conv3x3_frag(a, dtype)) return conv3x3_frag_name(a, dtype);
-  if (use_conv3x3(a, dtype)) return "conv3x3_patch_kernel";
-  return "conv_gemm_kernel";
+  if (use_conv3x3(a, dtype)) return conv3x3_patch_name(a, dtype);
+  {     // the implicit-GEMM kernel's instantiation, as launch_conv_t picks it
+    static thread_local char buf[96];
+    const int ve = dtype == 0 ? 4 : 8, Cin = a.C1 + a.C2, es = dtype == 0 ? 4 : 2;
+    const bool vec = (Cin % ve == 0) && (a.C1 % ve == 0);
+    int bn, wm;
+    conv_tiles(a.M, a.Cout, bn, wm);
+    const bool deep = vec && wm == 2 && cdiv(a.M, 32 * wm) * cdiv(a.Cout, bn) <= 512 && a.Kpad / (STAGE_BYTES / es) >= 6;
+    snprintf(buf, sizeof(buf), "conv_gemm_kernel<%s, %d, %s, %d, %s>", dtype == 0 ? "float" : "rd::bf16_t", bn, vec ? "true" : "false", wm, deep ? "true" : "false");
+    return buf;
+  }
 }
 void launch_pack_weights(const float* w, void* out, int Cout, int Cin, int KH, int KW, int mode, int dtype,
                          hipStream_t st, int CinSrc) {
@@ -1226,7 +1236,11 @@ const char* wgrad_kernel_name(const WgradArgs& a, int dtype) {
   if (wgrad_tiny_shape(a)) return "conv_wgrad_tiny_kernel";
   if (wgrad3x3_tr_ok(a, dtype)) return wgrad3x3_tr_name(a);
   if (wgrad_halo_ok(a, dtype)) return "conv_wgrad_halo_kernel";
-  if (dtype == 1 && (Cin % 8 == 0) && (a.C1 % 8 == 0) && (a.Cout % 8 == 0)) return "conv_wgrad_bf16_kernel";
+  if (dtype == 1 && (Cin % 8 == 0) && (a.C1 % 8 == 0) && (a.Cout % 8 == 0)) {
+    static thread_local char buf[48];
+    snprintf(buf, sizeof(buf), "conv_wgrad_bf16_kernel<%d>", pick_bn(a.Cout));
+    return buf;
+  }
   return "conv_wgrad_kernel";
 }
 

@@ -8,6 +8,7 @@
 // MFMA roles, 16-byte XOR-swizzled LDS slots, epilogue (bias / activation / dual destination / BatchNorm partials) are the ones of
 // the implicit-GEMM kernel.  Replaces the same reference call sites (utils/net_utils.py:84-91,195-198,564-569) for k=3, s=1.
 #include "rd_conv_common.h"
+#include <stdio.h>
 
 namespace rd {
 
@@ -615,6 +616,21 @@ static void launch_small_t(const ConvArgs& a, hipStream_t st) {
   }
   RD_S3(2, 16) RD_S3(4, 16) RD_S3(8, 16) RD_S3(2, 32) RD_S3(4, 32) RD_S3(2, 64) RD_S3(4, 64)
 #undef RD_S3
+}
+// instantiation names as rocprofv3 prints them (bench.py groups launches by kernel)
+const char* conv3x3_small_name(const ConvArgs& a, int dtype) {
+  static thread_local char buf[96];
+  const int es = dtype == 0 ? 4 : 2;
+  snprintf(buf, sizeof(buf), "conv3x3_small_kernel<%s, %d, %d, %s>", dtype == 0 ? "float" : "rd::bf16_t", (a.C1 + a.C2) * es / 16, pick_bn3(a.Cout),
+           use_w8(a) ? "true" : "false");
+  return buf;
+}
+const char* conv3x3_patch_name(const ConvArgs& a, int dtype) {
+  static thread_local char buf[96];
+  static const int bn_max = getenv("RD_PATCH_BN_MAX") ? atoi(getenv("RD_PATCH_BN_MAX")) : 64;
+  snprintf(buf, sizeof(buf), "conv3x3_patch_kernel<%s, %d, %s>", dtype == 0 ? "float" : "rd::bf16_t", std::min(bn_max, pick_bn3(a.Cout)),
+           use_w8(a) ? "true" : "false");
+  return buf;
 }
 void launch_conv3x3_small(const ConvArgs& a, int dtype, hipStream_t st) {
   if (dtype == 0) launch_small_t<float>(a, st);

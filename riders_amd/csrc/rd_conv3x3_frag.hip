@@ -40,16 +40,6 @@ struct FragGeom {
 
 constexpr int frag_pmax(int tp) { return tp <= 128 ? 256 : (tp <= 256 ? 384 : 640); }   // patch pixels a block may stage (32 / 48 / 80 KB)
 
-// x / d for 0 <= x < 2^22 (the product with the rounded reciprocal is off by less than one)
-__device__ __forceinline__ int fdiv_small(int x, int d, float rd_, int& rem) {
-  int q = (int)((float)x * rd_);
-  int r = x - q * d;
-  if (r < 0) { q--; r += d; }
-  if (r >= d) { q++; r -= d; }
-  rem = r;
-  return q;
-}
-
 // NPT 16-pixel tiles per wave, WPX x WCH waves (pixels x 32-channel groups): block tile = (16 NPT WPX) pixels x (32 WCH) channels.
 // LIN: linear tiles; MULTI: more than one channel chunk (the next chunk's patch is prefetched).
 template <typename T, int NPT, int WPX, int WCH, bool LIN, bool MULTI>

@@ -12,6 +12,17 @@ static constexpr int STAGE_BYTES = 128; // K bytes per row per stage
 // ds_read_b128 fragment reads (16 rows x 4 k-groups per wave) bank-conflict free.
 __device__ __forceinline__ int lds_slot(int row, int slot) { return row * 8 + (slot ^ ((row >> 1) & 7)); }
 
+// x / d for 0 <= x < 2^22 through the rounded reciprocal (the float product is off by less than one): the linear-strip tilings of
+// rd_conv3x3_frag.hip / rd_wgrad3x3.hip decode pixel indices with it instead of ~40-instruction integer divisions
+__device__ __forceinline__ int fdiv_small(int x, int d, float rd_, int& rem) {
+  int q = (int)((float)x * rd_);
+  int r = x - q * d;
+  if (r < 0) { q--; r += d; }
+  if (r >= d) { q++; r -= d; }
+  rem = r;
+  return q;
+}
+
 template <typename T>
 __device__ __forceinline__ bool conv_src_ptr(const ConvArgs& a, int n, int ih, int iw, int ci, const T*& p) {
   if (a.dil > 1) {

@@ -20,6 +20,8 @@ int conv3x3_tiles(const ConvArgs& a);
 void launch_conv3x3(const ConvArgs& a, int dtype, hipStream_t st);
 bool conv3x3_small_ok(const ConvArgs& a, int dtype);
 void launch_conv3x3_small(const ConvArgs& a, int dtype, hipStream_t st);
+const char* conv3x3_small_name(const ConvArgs& a, int dtype);
+const char* conv3x3_patch_name(const ConvArgs& a, int dtype);
 int conv3x3_small_blocks(const ConvArgs& a, int dtype);
 bool conv1x1_direct_ok(const ConvArgs& a, int dtype);
 int conv1x1_direct_rows(const ConvArgs& a);

@@ -17,11 +17,17 @@
 
 namespace rd {
 
-// LDS layout note (measured, profiles/r01_wgrad_tr_lds_swizzle.txt): with the plain [pixel][channel] images the 32-lane transpose reads
-// of the 64-channel slices hit 2..4 bank groups (SQ_LDS_BANK_CONFLICT = 66 % of SQ_LDS_IDX_ACTIVE).  An XOR swizzle of the 16-channel tile
-// position with pixel bits 1 and 3 removed every conflict (counter = 0, LDS cycles / 3) and made the kernel SLOWER (0.210 -> 0.224 ms
-// wide, 0.102 -> 0.140 ms narrow): the per-read address arithmetic replaces immediate offsets and the kernel is issue / latency bound
-// with one wave per SIMD, not LDS bound.  The affine layout stays.
+#ifndef RD_WGRAD_DEEP_MAX
+#define RD_WGRAD_DEEP_MAX 12
+#endif
+
+// LDS layout.  Round 1 (profiles/r01_wgrad_tr_lds_swizzle.txt): with plain [pixel][channel] images the 32-lane transpose reads of the
+// 64-channel slices hit 2..4 bank groups (SQ_LDS_BANK_CONFLICT = 66 % of SQ_LDS_IDX_ACTIVE); an XOR swizzle removed every conflict and made
+// the kernel SLOWER, because per-read address arithmetic replaced immediate offsets.  Round 3: both at once -- the images are stored as
+// PLANES of 16 channels, [plane][pixel][32 bytes] (the layout of rd_conv3x3_frag.hip), and the k index of a step is mapped to pixels so
+// that the 32 lanes of one transpose read (lane groups 2g, 2g+1) cover 8 CONSECUTIVE pixels of one plane = 256 contiguous bytes = every
+// bank once; every read address stays `base + immediate`.  Plane strides are 32 or 64 bytes mod 256 so that the 8-lane groups of the
+// 16-byte staging stores are conflict free too.
 template <int CTI, int RT, int TW>
 __global__ __launch_bounds__(256, (CTI * RT <= 2) ? 4 : 2) void conv3x3_wgrad_tr_kernel(WgradArgs a, int tilesH, int tilesW, int nci) {
   typedef bf16_t T;
@@ -32,10 +38,16 @@ __global__ __launch_bounds__(256, (CTI * RT <= 2) ? 4 : 2) void conv3x3_wgrad_tr
   constexpr int XIT = (NXS + 255) / 256, YIT = (NYS + 255) / 256;
   constexpr int KSTEPS = NPY / 32;                     // 32 pixels per MFMA k-step
   constexpr int NCT = 9 * CTI, NCW = (NCT + 3) / 4;    // (tap, cin-tile) column tiles, per wave
-  constexpr int ASTEP = 32 * COP;                      // elements between k-steps in the dY tile (32 consecutive pixels)
-  constexpr int BSTEP = (32 / TW) * WT * CIN;          // ... in the patch (four rows of 8, two rows of 16 or one row of 32)
-  __shared__ uint4 sX[2][NXS];
-  __shared__ uint4 sY[2][NYS];
+  // plane strides in bytes: >= 32 bytes per pixel, = 32 (eight slots per pixel) or 64 (four) mod 256 when there is more than one plane
+  constexpr int XPSB = XS <= 2 ? NPX * 32 : ((NPX * 32 + 255) / 256) * 256 + (XS == 8 ? 32 : 64);
+  constexpr int YPSB = YS <= 2 ? NPY * 32 : ((NPY * 32 + 255) / 256) * 256 + (YS == 8 ? 32 : 64);
+  constexpr int XPS = XPSB / 2, YPS = YPSB / 2;        // ... in 16-bit elements
+  constexpr int ASTEP = 32 * 16;                       // elements between k-steps in a dY plane (32 consecutive pixels)
+  constexpr int BSTEP = (32 / TW) * WT * 16;           // ... in a patch plane (four rows of 8, two rows of 16 or one row of 32)
+  // second transpose read of a fragment: the next 16 pixels of the k-step (one row of 16 / two rows of 8 / the second half of a row of 32)
+  constexpr int A2 = (TW == 16 ? TW : (TW == 8 ? 2 * TW : 16)) * 16, B2 = (TW == 16 ? WT : (TW == 8 ? 2 * WT : 16)) * 16;
+  __shared__ __attribute__((aligned(16))) unsigned char sX[2][(XS / 2 > 0 ? XS / 2 : 1) * XPSB];
+  __shared__ __attribute__((aligned(16))) unsigned char sY[2][(YS / 2 > 0 ? YS / 2 : 1) * YPSB];
 
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
   const int fr = lane & 15, fg = lane >> 4;
@@ -50,12 +62,12 @@ __global__ __launch_bounds__(256, (CTI * RT <= 2) ? 4 : 2) void conv3x3_wgrad_tr
   const int tend = min(ntiles, (xcd + 1) * T8);
   int tile = xcd * T8 + (blockIdx.x >> 3);
 
-  // transpose-read roles.  k-step s, lane group fg: pixels (y, x0 .. x0+7) of the tile; this lane supplies pixel x0 + (fr >> 2) (+4
-  // for the second read) and channels 4*(fr & 3)..+3 of whichever 16-channel tile is being read.
-  constexpr int GPR = TW / 8;                          // lane groups (8 pixels each) per tile row
-  const int yl = fg / GPR, x0 = (fg % GPR) * 8;
-  const int aoff = ((yl * TW) + x0 + (fr >> 2)) * COP + (fr & 3) * 4;
-  const int boff = ((yl * WT) + x0 + (fr >> 2)) * CIN + (fr & 3) * 4;
+  // transpose-read roles.  A k-step is 32 pixels; one read covers 16 of them: lane group fg supplies pixels 4 fg .. 4 fg + 3 of those 16
+  // (this lane: 4 fg + (fr >> 2), channels 4 (fr & 3) .. +3 of whichever 16-channel plane is read), the second read the other 16.
+  const int j16 = fg * 4 + (fr >> 2);
+  const int yl = TW == 8 ? (j16 >> 3) : 0, xl = TW == 8 ? (j16 & 7) : j16;
+  const int aoff = (yl * TW + xl) * 16 + (fr & 3) * 4;
+  const int boff = (yl * WT + xl) * 16 + (fr & 3) * 4;
   int coloff[NCW]; bool jv[NCW]; int jk[NCW];
 #pragma unroll
   for (int j = 0; j < NCW; j++) {
@@ -63,7 +75,7 @@ __global__ __launch_bounds__(256, (CTI * RT <= 2) ? 4 : 2) void conv3x3_wgrad_tr
     jv[j] = idx < NCT;
     if (!jv[j]) idx = 0;
     const int tap = idx / CTI, ct = idx - tap * CTI;
-    coloff[j] = ((tap / 3) * WT + (tap % 3)) * CIN + ct * 16;
+    coloff[j] = ((tap / 3) * WT + (tap % 3)) * 16 + ct * XPS;
     jk[j] = tap * CinT + ci0 + ct * 16;
   }
 
@@ -148,9 +160,15 @@ __global__ __launch_bounds__(256, (CTI * RT <= 2) ? 4 : 2) void conv3x3_wgrad_tr
   };
   auto stash = [&](int buf, const uint4 (&rx)[XIT], const uint4 (&ry)[YIT]) RD_INLINE_LAMBDA {
 #pragma unroll
-    for (int i = 0; i < XIT; i++) { const int idx = t + 256 * i; if (idx < NXS) sX[buf][idx] = rx[i]; }
+    for (int i = 0; i < XIT; i++) {
+      const int idx = t + 256 * i, pp = idx / XS, sl = idx - pp * XS;
+      if (idx < NXS) *reinterpret_cast<uint4*>(&sX[buf][(sl >> 1) * XPSB + pp * 32 + (sl & 1) * 16]) = rx[i];
+    }
 #pragma unroll
-    for (int i = 0; i < YIT; i++) { const int idx = t + 256 * i; if (idx < NYS) sY[buf][idx] = ry[i]; }
+    for (int i = 0; i < YIT; i++) {
+      const int idx = t + 256 * i, pp = idx / YS, sl = idx - pp * YS;
+      if (idx < NYS) *reinterpret_cast<uint4*>(&sY[buf][(sl >> 1) * YPSB + pp * 32 + (sl & 1) * 16]) = ry[i];
+    }
   };
   auto compute = [&](int buf, auto njc) RD_INLINE_LAMBDA {
     constexpr int NJ = decltype(njc)::value;
@@ -161,13 +179,13 @@ __global__ __launch_bounds__(256, (CTI * RT <= 2) ? 4 : 2) void conv3x3_wgrad_tr
       s16x8 ya[RT];
 #pragma unroll
       for (int i = 0; i < RT; i++) {
-        uint2 lo = lds_read_tr16_b64(by + s * ASTEP + i * 16), hi = lds_read_tr16_b64(by + s * ASTEP + i * 16 + 4 * COP);
+        uint2 lo = lds_read_tr16_b64(by + s * ASTEP + i * YPS), hi = lds_read_tr16_b64(by + s * ASTEP + i * YPS + A2);
         uint4 v = make_uint4(lo.x, lo.y, hi.x, hi.y);
         __builtin_memcpy(&ya[i], &v, 16);
       }
 #pragma unroll
       for (int j = 0; j < NJ; j++) {
-        uint2 lo = lds_read_tr16_b64(bx + s * BSTEP + coloff[j]), hi = lds_read_tr16_b64(bx + s * BSTEP + coloff[j] + 4 * CIN);
+        uint2 lo = lds_read_tr16_b64(bx + s * BSTEP + coloff[j]), hi = lds_read_tr16_b64(bx + s * BSTEP + coloff[j] + B2);
         uint4 v = make_uint4(lo.x, lo.y, hi.x, hi.y);
         s16x8 xb;
         __builtin_memcpy(&xb, &v, 16);
@@ -182,8 +200,9 @@ __global__ __launch_bounds__(256, (CTI * RT <= 2) ? 4 : 2) void conv3x3_wgrad_tr
     if (jv[NCW - 1]) compute(buf, std::integral_constant<int, NCW>{});
     else compute(buf, std::integral_constant<int, NCW - 1>{});
   };
-  // prefetch distance two tiles where the register budget allows (narrow slices), one otherwise
-  constexpr bool DEEP = (XIT + YIT) <= 5;
+  // prefetch distance two tiles where the register budget allows (every variant at <= 12 staged vectors per thread since round 3:
+  // 0.831 -> 0.811 ms over the eleven wgrad shapes of tools/bench_conv.py), one otherwise
+  constexpr bool DEEP = (XIT + YIT) <= RD_WGRAD_DEEP_MAX;
   uint4 xa[XIT], ya_[YIT], xb_[DEEP ? XIT : 1], yb_[DEEP ? YIT : 1];
   int buf = 0;
   if (DEEP) {
@@ -230,6 +249,189 @@ __global__ __launch_bounds__(256, (CTI * RT <= 2) ? 4 : 2) void conv3x3_wgrad_tr
       }
 }
 
+// ---- linear tiling (narrow maps) --------------------------------------------------------------------------------------------------------
+// The RoI maps of RC-Net are 15x6 ... 120x50 pixels: 8 x 16 (8 x 8) tiles cover them 70-78 %, i.e. a quarter of the MFMA work and of the
+// staging traffic above goes to padding.  As in rd_conv3x3_frag.hip the whole tensor is treated as ONE strip of virtual pixels (rows of
+// OW + 1 with a shared zero column, a shared zero row between images): a tile is 128 consecutive virtual pixels of dY, its patch the
+// 128 + 2 (OW + 1) + 2 consecutive virtual pixels of x around them, tap (kh, kw) the offset kh (OW + 1) + kw.  Virtual zero pixels carry
+// dY = 0 and contribute nothing, tiles cross image borders, and the layout / transpose-read roles are the ones of the tiled kernel with a
+// run-time row stride (the per-wave column offsets are registers anyway).  80-97 % of the staged pixels are real.
+// MEASURED SLOWER than the tiled kernel on RC-Net's layers (0.905 vs 0.831 ms over the eleven shapes of tools/bench_conv.py) although it
+// issues 20-30 % fewer MFMAs: the kernel is bound by the issue rate of its 8-byte transpose reads and by the per-tile staging, not by
+// MFMA work, and the strip decode adds vector instructions per staged slot.  Kept opt-in (RD_WGRAD_LIN=1; =2 forces it) with its tests.
+struct LinGeom { int WT, H1, ntiles; float rWT, rH1; };
+
+template <int CTI, int RT>
+__global__ __launch_bounds__(256, (CTI * RT <= 2) ? 4 : 2) void conv3x3_wgrad_lin_kernel(WgradArgs a, LinGeom g, int nci) {
+  typedef bf16_t T;
+  constexpr int CIN = CTI * 16, COP = RT * 16;
+  constexpr int TP = 128, NPX = 240, NPY = TP;        // dY pixels per tile; patch pixels (TP + 2 WT + 2 <= 240: WT <= 55, two blocks per CU)
+  constexpr int XS = CIN / 8, YS = COP / 8;
+  constexpr int NXS = NPX * XS, NYS = NPY * YS;
+  constexpr int XIT = (NXS + 255) / 256, YIT = (NYS + 255) / 256;
+  constexpr int KSTEPS = NPY / 32;
+  constexpr int NCT = 9 * CTI, NCW = (NCT + 3) / 4;
+  constexpr int XPSB = XS <= 2 ? NPX * 32 : ((NPX * 32 + 255) / 256) * 256 + (XS == 8 ? 32 : 64);
+  constexpr int YPSB = YS <= 2 ? NPY * 32 : ((NPY * 32 + 255) / 256) * 256 + (YS == 8 ? 32 : 64);
+  constexpr int XPS = XPSB / 2, YPS = YPSB / 2;
+  constexpr int STEP = 32 * 16, R2 = 16 * 16;         // elements between k-steps / to the second transpose read (16 pixels further), both operands
+  __shared__ __attribute__((aligned(16))) unsigned char sX[2][(XS / 2 > 0 ? XS / 2 : 1) * XPSB];
+  __shared__ __attribute__((aligned(16))) unsigned char sY[2][(YS / 2 > 0 ? YS / 2 : 1) * YPSB];
+
+  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+  const int fr = lane & 15, fg = lane >> 4;
+  const int ci0 = ((int)blockIdx.y % nci) * CIN, co0 = ((int)blockIdx.y / nci) * COP;
+  const int CinT = a.C1 + a.C2;
+  const int WT = g.WT, H1 = g.H1, np = TP + 2 * WT + 2;
+
+  const int ntiles = g.ntiles;
+  const int T8 = (ntiles + 7) >> 3, G8 = gridDim.x >> 3;
+  const int xcd = blockIdx.x & 7;
+  const int tend = min(ntiles, (xcd + 1) * T8);
+  int tile = xcd * T8 + (blockIdx.x >> 3);
+
+  const int off = (fg * 4 + (fr >> 2)) * 16 + (fr & 3) * 4;      // this lane's pixel of a 16-pixel read, channels 4 (fr & 3) .. +3
+  int coloff[NCW]; bool jv[NCW]; int jk[NCW];
+#pragma unroll
+  for (int j = 0; j < NCW; j++) {
+    int idx = wv + 4 * j;
+    jv[j] = idx < NCT;
+    if (!jv[j]) idx = 0;
+    const int tap = idx / CTI, ct = idx - tap * CTI;
+    coloff[j] = ((tap / 3) * WT + (tap % 3)) * 16 + ct * XPS;
+    jk[j] = tap * CinT + ci0 + ct * 16;
+  }
+  f32x4 acc[RT][NCW];
+#pragma unroll
+  for (int i = 0; i < RT; i++)
+#pragma unroll
+    for (int j = 0; j < NCW; j++) acc[i][j] = f32x4{0, 0, 0, 0};
+
+  const bool yvec = (a.Cout & 7) == 0;
+  // slot constants: patch pixel and channel slot of this thread's x slots, tile pixel and channel slot of its dY slots
+  int xpp[XIT], xco[XIT];      // patch pixel | source-2 flag << 16 | valid << 17;  channel offset inside the source
+#pragma unroll
+  for (int i = 0; i < XIT; i++) {
+    const int idx = t + 256 * i, pp = idx / XS, sl = idx - pp * XS;
+    const int ci = ci0 + sl * 8;
+    const bool s2 = ci >= a.C1;
+    xpp[i] = pp | (s2 ? 1 << 16 : 0) | ((idx < NXS && pp < np) ? 1 << 17 : 0);
+    xco[i] = s2 ? ci - a.C1 : ci;
+  }
+  const int Hp = a.ups ? a.H1 : a.Hin, Wp = a.ups ? a.W1 : a.Win;
+  // virtual pixel -> tensor pixel (image, row, column); false for zero rows / columns and outside the strip
+  auto strip_pixel = [&](int u, int& n, int& ih, int& iw) RD_INLINE_LAMBDA {
+    int c, hh;
+    const int vrow = fdiv_small(max(u, 0), WT, g.rWT, c);
+    n = fdiv_small(vrow, H1, g.rH1, hh);
+    ih = hh - 1; iw = c - 1;
+    return u >= 0 && c >= 1 && hh >= 1 && n < a.N;
+  };
+  auto fetch = [&](int tl, uint4 (&rx)[XIT], uint4 (&ry)[YIT]) RD_INLINE_LAMBDA {
+    const int u0 = WT + tl * TP;
+#pragma unroll
+    for (int i = 0; i < XIT; i++) {
+      int n, ih, iw;
+      const bool ok = strip_pixel(u0 - WT - 1 + (xpp[i] & 0xffff), n, ih, iw) && ((xpp[i] >> 17) & 1);
+      int hs = ok ? ih : 0, ws = ok ? iw : 0;
+      if (a.ups) {  // F.interpolate(mode='nearest') source index, ATen float formula (as conv_src_ptr)
+        hs = min((int)floorf((float)hs * a.scale_h), a.H1 - 1);
+        ws = min((int)floorf((float)ws * a.scale_w), a.W1 - 1);
+      }
+      const int pix = ok ? (n * Hp + hs) * Wp + ws : 0;
+      const bool s2 = (xpp[i] >> 16) & 1;
+      const T* sb = s2 ? (const T*)a.src2 : (const T*)a.src1;
+      // unconditional load from a clamped address, zero selected afterwards
+      const uint4 v = *reinterpret_cast<const uint4*>(sb + (int64_t)pix * (s2 ? a.C2 : a.C1) + xco[i]);
+      rx[i] = ok ? v : make_uint4(0, 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < YIT; i++) {
+      const int idx = t + 256 * i, pp = idx / YS, sl = idx - pp * YS;
+      int n, oh, ow;
+      const bool ok = strip_pixel(u0 + pp, n, oh, ow) && idx < NYS && co0 + sl * 8 < a.Cout;
+      const T* p = (const T*)a.dy + (int64_t)(ok ? (n * a.OH + oh) * a.OW + ow : 0) * a.Cout + (ok ? co0 + sl * 8 : 0);
+      uint4 v;
+      if (yvec) v = *reinterpret_cast<const uint4*>(p);
+      else {  // Cout not a multiple of 8: element-wise, zero padded
+        unsigned short e[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) e[q] = (ok && co0 + sl * 8 + q < a.Cout) ? p[q].v : (unsigned short)0;
+        v.x = e[0] | ((unsigned)e[1] << 16); v.y = e[2] | ((unsigned)e[3] << 16);
+        v.z = e[4] | ((unsigned)e[5] << 16); v.w = e[6] | ((unsigned)e[7] << 16);
+      }
+      ry[i] = ok ? v : make_uint4(0, 0, 0, 0);
+    }
+  };
+  auto stash = [&](int buf, const uint4 (&rx)[XIT], const uint4 (&ry)[YIT]) RD_INLINE_LAMBDA {
+#pragma unroll
+    for (int i = 0; i < XIT; i++) {
+      const int idx = t + 256 * i, pp = idx / XS, sl = idx - pp * XS;
+      if (idx < NXS && pp < np) *reinterpret_cast<uint4*>(&sX[buf][(sl >> 1) * XPSB + pp * 32 + (sl & 1) * 16]) = rx[i];
+    }
+#pragma unroll
+    for (int i = 0; i < YIT; i++) {
+      const int idx = t + 256 * i, pp = idx / YS, sl = idx - pp * YS;
+      if (idx < NYS) *reinterpret_cast<uint4*>(&sY[buf][(sl >> 1) * YPSB + pp * 32 + (sl & 1) * 16]) = ry[i];
+    }
+  };
+  auto compute = [&](int buf, auto njc) RD_INLINE_LAMBDA {
+    constexpr int NJ = decltype(njc)::value;
+    const unsigned short* bx = reinterpret_cast<const unsigned short*>(&sX[buf][0]) + off;
+    const unsigned short* by = reinterpret_cast<const unsigned short*>(&sY[buf][0]) + off;
+#pragma unroll
+    for (int s = 0; s < KSTEPS; s++) {
+      s16x8 ya[RT];
+#pragma unroll
+      for (int i = 0; i < RT; i++) {
+        uint2 lo = lds_read_tr16_b64(by + s * STEP + i * YPS), hi = lds_read_tr16_b64(by + s * STEP + i * YPS + R2);
+        uint4 v = make_uint4(lo.x, lo.y, hi.x, hi.y);
+        __builtin_memcpy(&ya[i], &v, 16);
+      }
+#pragma unroll
+      for (int j = 0; j < NJ; j++) {
+        uint2 lo = lds_read_tr16_b64(bx + s * STEP + coloff[j]), hi = lds_read_tr16_b64(bx + s * STEP + coloff[j] + R2);
+        uint4 v = make_uint4(lo.x, lo.y, hi.x, hi.y);
+        s16x8 xb;
+        __builtin_memcpy(&xb, &v, 16);
+#pragma unroll
+        for (int i = 0; i < RT; i++) acc[i][j] = mfma_16x16x32_bf16(ya[i], xb, acc[i][j]);
+      }
+    }
+  };
+  auto tile_body = [&](int buf) RD_INLINE_LAMBDA {
+    if (jv[NCW - 1]) compute(buf, std::integral_constant<int, NCW>{});
+    else compute(buf, std::integral_constant<int, NCW - 1>{});
+  };
+
+  uint4 xa[XIT], ya_[YIT];
+  int buf = 0;
+  if (tile < tend) fetch(tile, xa, ya_);
+  while (tile < tend) {
+    stash(buf, xa, ya_);
+    __syncthreads();
+    const int next = tile + G8;
+    if (next < tend) fetch(next, xa, ya_);
+    tile_body(buf);
+    tile = next;
+    buf ^= 1;
+  }
+
+  float* slab = a.slab + (int64_t)blockIdx.x * a.Cout * a.K;
+#pragma unroll
+  for (int i = 0; i < RT; i++)
+#pragma unroll
+    for (int j = 0; j < NCW; j++)
+      if (jv[j]) {
+        const int k = jk[j] + fr;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const int co = co0 + i * 16 + fg * 4 + r;
+          if (co < a.Cout) slab[(int64_t)co * a.K + k] = acc[i][j][r];
+        }
+      }
+}
+
 // ---- host side -------------------------------------------------------------------------------------------------------------------
 // narrow layers (Cin in {16, 32, 64}, Cout <= 32): one slice.  Wide layers (Cin % 64 == 0): (Cin/64) x ceil(Cout/32) slices, used when the
 // 8 x 16 tiles cover the feature map well enough (the MFMA work is spent on whole tiles).
@@ -237,6 +439,20 @@ static bool tr_geom(const WgradArgs& a) {
   return a.KH == 3 && a.KW == 3 && a.stride == 1 && a.pad == 1 && (a.C1 % 8 == 0) && a.OH == a.Hin && a.OW == a.Win;
 }
 static bool tr_narrow(const WgradArgs& a) { const int Cin = a.C1 + a.C2; return (Cin == 16 || Cin == 32 || Cin == 64) && a.Cout <= 32; }
+// linear tiling: narrow maps (row stride OW + 1 <= 55 so that the patch of a 128-pixel tile fits 240 pixels), strip decodable by the
+// reciprocal division, and better covered than by 8 x TW tiles
+static int tr_tw(const WgradArgs& a);
+static bool tr_linear(const WgradArgs& a) {
+  static const int on = getenv("RD_WGRAD_LIN") ? atoi(getenv("RD_WGRAD_LIN")) : 0;
+  if (!on || a.OW + 1 > 55 || a.OW < 2) return false;
+  const int64_t strip = ((int64_t)a.N * (a.OH + 1) + 1) * (a.OW + 1);
+  if (strip >= ((int64_t)1 << 22)) return false;
+  const int tw = tr_tw(a);
+  const double eff2 = (double)a.OH * a.OW / (double)(cdiv(a.OH, 8) * 8 * cdiv(a.OW, tw) * tw);
+  const double effl = (double)a.M / (double)(cdiv(strip - 2 * (a.OW + 1), 128) * 128);
+  return on == 2 || effl > eff2;
+}
+static int64_t tr_lin_tiles(const WgradArgs& a) { return cdiv(((int64_t)a.N * (a.OH + 1) + 1) * (a.OW + 1) - 2 * (a.OW + 1), 128); }
 static int tr_tw(const WgradArgs& a) {    // tile width with the smallest padded area (8 x TW tiles); 32 only where the LDS budget allows
   const int Cin = a.C1 + a.C2;
   int best = 16;
@@ -252,6 +468,7 @@ bool wgrad3x3_tr_ok(const WgradArgs& a, int dtype) {
   if (tr_narrow(a)) return true;
   const int Cin = a.C1 + a.C2;
   if (Cin % 64 != 0 || a.Cout % 8 != 0) return false;
+  if (tr_linear(a)) return true;
   const int tw = tr_tw(a);
   const double eff = (double)a.OH * a.OW / (double)(cdiv(a.OH, 8) * 8 * cdiv(a.OW, tw) * tw);
   return eff >= 0.6;
@@ -260,18 +477,15 @@ static void tr_slices(const WgradArgs& a, int& cti, int& rt, int& nci, int& nco)
   const int Cin = a.C1 + a.C2;
   cti = Cin >= 64 ? 4 : Cin / 16;
   rt = a.Cout <= 16 ? 1 : 2;
-  // wide layers, 64-channel output slices (RD_WGRAD_TR_RT4, A/B): 26 instead of 22 transpose reads per k-step feed 36 instead of 18 MFMAs, and
-  // the input patch is staged for half as many slices
-  static const int rt4 = getenv("RD_WGRAD_TR_RT4") ? atoi(getenv("RD_WGRAD_TR_RT4")) : 0;
-  if (rt4 && Cin >= 64 && (Cin % 64) == 0 && a.Cout >= 64) rt = 4;
   nci = Cin >= 64 ? Cin / 64 : 1;
   nco = (int)cdiv(a.Cout, rt * 16);
 }
 int wgrad3x3_tr_blocks(const WgradArgs& a) {   // persistent blocks per slice = slabs to reduce
   int cti, rt, nci, nco;
   tr_slices(a, cti, rt, nci, nco);
-  const int tw = tr_tw(a);
-  const int64_t ntiles = (int64_t)a.N * cdiv(a.OH, 8) * cdiv(a.OW, tw);
+  const bool lin = tr_linear(a);
+  const int tw = lin ? 16 : tr_tw(a);
+  const int64_t ntiles = lin ? tr_lin_tiles(a) : (int64_t)a.N * cdiv(a.OH, 8) * cdiv(a.OW, tw);
   const char* e = getenv("RD_CONV3X3_G8");  // test hook shared with the forward kernel
   // persistent grid = resident capacity: 4 blocks per CU for the light variants, 2 where registers (launch bounds) or LDS allow only two
   // (measured: 512 instead of 1024 blocks is 8-13 % faster on the 64-channel slices and halves the slab traffic)
@@ -288,20 +502,29 @@ const char* wgrad3x3_tr_name(const WgradArgs& a) {
   static thread_local char buf[64];
   int cti, rt, nci, nco;
   tr_slices(a, cti, rt, nci, nco);
-  snprintf(buf, sizeof(buf), "conv3x3_wgrad_tr_kernel<%d, %d, %d>", cti, rt, tr_tw(a));
+  if (tr_linear(a)) snprintf(buf, sizeof(buf), "conv3x3_wgrad_lin_kernel<%d, %d>", cti, rt);
+  else snprintf(buf, sizeof(buf), "conv3x3_wgrad_tr_kernel<%d, %d, %d>", cti, rt, tr_tw(a));
   return buf;
 }
 void launch_wgrad3x3_tr(const WgradArgs& a, hipStream_t st) {
   int cti, rt, nci, nco;
   tr_slices(a, cti, rt, nci, nco);
+  const dim3 grid((unsigned)wgrad3x3_tr_blocks(a), (unsigned)(nci * nco));
+  if (tr_linear(a)) {
+    LinGeom g;
+    g.WT = a.OW + 1; g.H1 = a.OH + 1; g.ntiles = (int)tr_lin_tiles(a); g.rWT = 1.0f / (float)g.WT; g.rH1 = 1.0f / (float)g.H1;
+#define RD_TL(CTIV, RTV) if (cti == CTIV && rt == RTV) hipLaunchKernelGGL((conv3x3_wgrad_lin_kernel<CTIV, RTV>), grid, dim3(256), 0, st, a, g, nci);
+    RD_TL(1, 1) RD_TL(1, 2) RD_TL(2, 1) RD_TL(2, 2) RD_TL(4, 1) RD_TL(4, 2)
+#undef RD_TL
+    return;
+  }
   const int tw = tr_tw(a);
   const int tilesH = (int)cdiv(a.OH, 8), tilesW = (int)cdiv(a.OW, tw);
-  const dim3 grid((unsigned)wgrad3x3_tr_blocks(a), (unsigned)(nci * nco));
 #define RD_TR(CTIV, RTV, TWV) \
   if (cti == CTIV && rt == RTV && tw == TWV) hipLaunchKernelGGL((conv3x3_wgrad_tr_kernel<CTIV, RTV, TWV>), grid, dim3(256), 0, st, a, tilesH, tilesW, nci);
   RD_TR(1, 1, 8) RD_TR(1, 1, 16) RD_TR(1, 1, 32) RD_TR(1, 2, 8) RD_TR(1, 2, 16) RD_TR(1, 2, 32)
   RD_TR(2, 1, 8) RD_TR(2, 1, 16) RD_TR(2, 1, 32) RD_TR(2, 2, 8) RD_TR(2, 2, 16) RD_TR(2, 2, 32)
-  RD_TR(4, 1, 8) RD_TR(4, 1, 16) RD_TR(4, 2, 8) RD_TR(4, 2, 16) RD_TR(4, 4, 8) RD_TR(4, 4, 16)
+  RD_TR(4, 1, 8) RD_TR(4, 1, 16) RD_TR(4, 2, 8) RD_TR(4, 2, 16)
 #undef RD_TR
 }
 
