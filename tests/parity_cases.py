@@ -907,6 +907,51 @@ def rcnet_fullsize_oracle_case(dev, tol=TOL):
         assert err <= 5 * tol, "full-size %s gradient: relative L2 error %.3e" % (name, err)
 
 
+def rcnet_config3_rank_case(dev, tol=TOL):
+    """configs[3] per-rank geometry (global batch 32 on 8 GPUs = B = 4 per rank, R = 120 RoIs): fp32 logits / loss of the HIP path against
+    the oracle within 1e-3, labels exact; then the bf16 graphed training step at that size is finite and bit-reproducible."""
+    from riders_amd import engine, rcnet_main
+    from riders_amd.optim import FlatAdam
+    cfg = rcnet_main.ZJU_CONFIG
+    torch.manual_seed(0)
+    model = rcnet_main.build_model(dev, cfg)
+    model.train()
+    sd_e = leaves(model.encoder.state_dict()); sd_d = leaves(model.decoder.state_dict())
+    batch = rcnet_main.synthetic_batch(4, 256, 512, cfg, seed=78)
+    image, pts, rois, gt = rcnet_main.prepare_batch(tuple(b.to(dev) for b in batch))
+    label, valid = engine.rcnet_labels(gt, pts, 0.5)
+    with torch.no_grad():
+        logits = model.forward(image, pts, rois)
+        loss, _ = model.compute_loss(logits, label, valid, 2.5)
+        pts_c = batch[1].reshape(-1, 3); gt_c = batch[3].reshape(-1, 1, 240, 100)
+        lab_c, val_c = O.rcnet_labels(gt_c, pts_c, 0.5)
+        assert torch.equal(label.cpu(), lab_c) and torch.equal(valid.cpu(), val_c) and logits.shape[0] == 120
+        ref = O.rcnet_forward(batch[0] / 255.0, pts_c, [b for b in batch[2]], sd_e, sd_d, cfg['patch_size'], True)
+        ref_loss = O.rcnet_loss(ref, lab_c, val_c, 2.5)
+    close(logits, ref, tol, "configs[3] per-rank logits (B=4, R=120)")
+    assert abs(float(loss) - float(ref_loss)) <= tol * abs(float(ref_loss)), (float(loss), float(ref_loss))
+    engine.set_compute_dtype("bf16"); engine.clear_caches()
+    try:
+        runs = []
+        dbatch = tuple(b.to(dev) for b in batch)
+        for rep in range(2):
+            torch.manual_seed(0)
+            model = rcnet_main.build_model(dev, cfg)
+            model.train()
+            opt = FlatAdam(model.parameters(), lr=cfg['learning_rate'])
+            engine.set_deterministic_roi_pool(True)      # the small-map RoI-pool backward otherwise scatters with fp32 atomics
+            try:
+                step = rcnet_main.GraphedTrainStep(model, opt, dbatch, cfg, warmup=1)
+                ls = [float(step()) for _ in range(3)]
+            finally:
+                engine.set_deterministic_roi_pool(False)
+            assert all(np.isfinite(ls)), ls
+            runs.append((ls, opt.flat_param.clone()))
+        assert runs[0][0] == runs[1][0] and torch.equal(runs[0][1], runs[1][1]), "B=4 bf16 graphed step is not reproducible"
+    finally:
+        engine.set_compute_dtype("fp32"); engine.clear_caches()
+
+
 def rcnet_fullsize_bf16_case(dev, tol_logits=6e-2, tol_grad=0.12):
     """configs[1] exactly (B = 8, 496x612 padded, R = 240, patch 240x100): the bf16 throughput mode against the fp32 HIP path (itself
     pinned to the oracle / reference at 1e-3) on identical weights and inputs.  Stated tolerances: logits of 24 sampled RoIs within

@@ -145,6 +145,10 @@ def test_rcnet_full_size_fp32_vs_oracle(gpu):
     P.rcnet_fullsize_oracle_case(gpu)
 
 
+def test_rcnet_config3_per_rank_geometry(gpu):
+    P.rcnet_config3_rank_case(gpu)
+
+
 def test_rcnet_config1_bf16_vs_fp32(gpu):
     P.rcnet_fullsize_bf16_case(gpu)
 

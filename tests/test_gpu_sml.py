@@ -70,6 +70,14 @@ def test_sml_network_bf16(gpu):
     S.sml_net_bf16_case(gpu)
 
 
+def test_sml_config2_full_size(gpu):
+    S.sml_config2_fullsize_case(gpu)
+
+
+def test_sml_bf16_trains_like_fp32(gpu):
+    S.sml_bf16_convergence_case(gpu)
+
+
 def test_validation_chain_abs_rel(gpu):
     S.validate_chain_case(gpu)
 
