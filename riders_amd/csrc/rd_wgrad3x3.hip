@@ -28,16 +28,19 @@ namespace rd {
 // that the 32 lanes of one transpose read (lane groups 2g, 2g+1) cover 8 CONSECUTIVE pixels of one plane = 256 contiguous bytes = every
 // bank once; every read address stays `base + immediate`.  Plane strides are 32 or 64 bytes mod 256 so that the 8-lane groups of the
 // 16-byte staging stores are conflict free too.
-template <int CTI, int RT, int TW>
-__global__ __launch_bounds__(256, (CTI * RT <= 2) ? 4 : 2) void conv3x3_wgrad_tr_kernel(WgradArgs a, int tilesH, int tilesW, int nci) {
+// NWV waves per block: 4, or 8 for the wide slices (each wave then owns 4-5 instead of 9 column tiles: 40 instead of 72 accumulator
+// registers and half the staging registers -> four waves per SIMD instead of two for a kernel that is issue bound per wave)
+template <int CTI, int RT, int TW, int NWV = 4>
+__global__ __launch_bounds__(64 * NWV, NWV == 8 ? (RT >= 4 ? 2 : 4) : ((CTI * RT <= 2) ? 4 : 2)) void conv3x3_wgrad_tr_kernel(WgradArgs a, int tilesH, int tilesW, int nci) {
+  constexpr int NT = 64 * NWV;
   typedef bf16_t T;
   constexpr int CIN = CTI * 16, COP = RT * 16;
   constexpr int TH = 8, WT = TW + 2, HT = TH + 2, NPX = HT * WT, NPY = TH * TW;
   constexpr int XS = CIN / 8, YS = COP / 8;           // 16-byte slots per pixel
   constexpr int NXS = NPX * XS, NYS = NPY * YS;
-  constexpr int XIT = (NXS + 255) / 256, YIT = (NYS + 255) / 256;
+  constexpr int XIT = (NXS + NT - 1) / NT, YIT = (NYS + NT - 1) / NT;
   constexpr int KSTEPS = NPY / 32;                     // 32 pixels per MFMA k-step
-  constexpr int NCT = 9 * CTI, NCW = (NCT + 3) / 4;    // (tap, cin-tile) column tiles, per wave
+  constexpr int NCT = 9 * CTI, NCW = (NCT + NWV - 1) / NWV;    // (tap, cin-tile) column tiles, per wave
   // plane strides in bytes: >= 32 bytes per pixel, = 32 (eight slots per pixel) or 64 (four) mod 256 when there is more than one plane
   constexpr int XPSB = XS <= 2 ? NPX * 32 : ((NPX * 32 + 255) / 256) * 256 + (XS == 8 ? 32 : 64);
   constexpr int YPSB = YS <= 2 ? NPY * 32 : ((NPY * 32 + 255) / 256) * 256 + (YS == 8 ? 32 : 64);
@@ -68,15 +71,14 @@ __global__ __launch_bounds__(256, (CTI * RT <= 2) ? 4 : 2) void conv3x3_wgrad_tr
   const int yl = TW == 8 ? (j16 >> 3) : 0, xl = TW == 8 ? (j16 & 7) : j16;
   const int aoff = (yl * TW + xl) * 16 + (fr & 3) * 4;
   const int boff = (yl * WT + xl) * 16 + (fr & 3) * 4;
-  int coloff[NCW]; bool jv[NCW]; int jk[NCW];
+  int coloff[NCW]; bool jv[NCW];
 #pragma unroll
   for (int j = 0; j < NCW; j++) {
-    int idx = wv + 4 * j;
+    int idx = wv + NWV * j;
     jv[j] = idx < NCT;
     if (!jv[j]) idx = 0;
     const int tap = idx / CTI, ct = idx - tap * CTI;
     coloff[j] = ((tap / 3) * WT + (tap % 3)) * 16 + ct * XPS;
-    jk[j] = tap * CinT + ci0 + ct * 16;
   }
 
   f32x4 acc[RT][NCW];
@@ -102,7 +104,7 @@ __global__ __launch_bounds__(256, (CTI * RT <= 2) ? 4 : 2) void conv3x3_wgrad_tr
   int xpk[XIT], xco[XIT];   // (py-1 + 1) << 8 | (px-1 + 1) | source-2 flag << 16 | valid << 17;  channel offset inside the source
 #pragma unroll
   for (int i = 0; i < XIT; i++) {
-    const int idx = t + 256 * i;
+    const int idx = t + NT * i;
     const int pp = idx / XS, sl = idx - pp * XS;
     const int py = pp / WT, px = pp - py * WT;
     const int ci = ci0 + sl * 8;
@@ -113,7 +115,7 @@ __global__ __launch_bounds__(256, (CTI * RT <= 2) ? 4 : 2) void conv3x3_wgrad_tr
   int ypk[YIT];             // py << 8 | px | valid << 16 (valid = slot exists and its 8 channels start inside Cout)
 #pragma unroll
   for (int i = 0; i < YIT; i++) {
-    const int idx = t + 256 * i;
+    const int idx = t + NT * i;
     const int pp = idx / YS, sl = idx - pp * YS;
     const int py = pp / TW, px = pp - py * TW;
     ypk[i] = (py << 8) | px | ((idx < NYS && co0 + sl * 8 < a.Cout) ? 1 << 16 : 0) | (sl << 20);
@@ -161,12 +163,12 @@ __global__ __launch_bounds__(256, (CTI * RT <= 2) ? 4 : 2) void conv3x3_wgrad_tr
   auto stash = [&](int buf, const uint4 (&rx)[XIT], const uint4 (&ry)[YIT]) RD_INLINE_LAMBDA {
 #pragma unroll
     for (int i = 0; i < XIT; i++) {
-      const int idx = t + 256 * i, pp = idx / XS, sl = idx - pp * XS;
+      const int idx = t + NT * i, pp = idx / XS, sl = idx - pp * XS;
       if (idx < NXS) *reinterpret_cast<uint4*>(&sX[buf][(sl >> 1) * XPSB + pp * 32 + (sl & 1) * 16]) = rx[i];
     }
 #pragma unroll
     for (int i = 0; i < YIT; i++) {
-      const int idx = t + 256 * i, pp = idx / YS, sl = idx - pp * YS;
+      const int idx = t + NT * i, pp = idx / YS, sl = idx - pp * YS;
       if (idx < NYS) *reinterpret_cast<uint4*>(&sY[buf][(sl >> 1) * YPSB + pp * 32 + (sl & 1) * 16]) = ry[i];
     }
   };
@@ -183,15 +185,21 @@ __global__ __launch_bounds__(256, (CTI * RT <= 2) ? 4 : 2) void conv3x3_wgrad_tr
         uint4 v = make_uint4(lo.x, lo.y, hi.x, hi.y);
         __builtin_memcpy(&ya[i], &v, 16);
       }
+      // ALL fragment reads of the k-step first, then its MFMAs: left to itself the compiler issues two transpose reads, waits for them
+      // (lgkmcnt(0)) and runs two MFMAs, nine times per k-step -- one exposed LDS round trip per 32 MFMA cycles (ISA, round 3)
+      s16x8 xb[NJ];
 #pragma unroll
       for (int j = 0; j < NJ; j++) {
         uint2 lo = lds_read_tr16_b64(bx + s * BSTEP + coloff[j]), hi = lds_read_tr16_b64(bx + s * BSTEP + coloff[j] + B2);
         uint4 v = make_uint4(lo.x, lo.y, hi.x, hi.y);
-        s16x8 xb;
-        __builtin_memcpy(&xb, &v, 16);
-#pragma unroll
-        for (int i = 0; i < RT; i++) acc[i][j] = mfma_16x16x32_bf16(ya[i], xb, acc[i][j]);
+        __builtin_memcpy(&xb[j], &v, 16);
       }
+      sched_fence();
+#pragma unroll
+      for (int j = 0; j < NJ; j++)
+#pragma unroll
+        for (int i = 0; i < RT; i++) acc[i][j] = mfma_16x16x32_bf16(ya[i], xb[j], acc[i][j]);
+      sched_fence();
     }
   };
 
@@ -240,7 +248,8 @@ __global__ __launch_bounds__(256, (CTI * RT <= 2) ? 4 : 2) void conv3x3_wgrad_tr
 #pragma unroll
     for (int j = 0; j < NCW; j++)
       if (jv[j]) {
-        const int k = jk[j] + fr;
+        const int idx = wv + NWV * j, tap = idx / CTI, ct = idx - tap * CTI;
+        const int k = tap * CinT + ci0 + ct * 16 + fr;
 #pragma unroll
         for (int r = 0; r < 4; r++) {
           const int co = co0 + i * 16 + fg * 4 + r;
@@ -388,15 +397,19 @@ __global__ __launch_bounds__(256, (CTI * RT <= 2) ? 4 : 2) void conv3x3_wgrad_li
         uint4 v = make_uint4(lo.x, lo.y, hi.x, hi.y);
         __builtin_memcpy(&ya[i], &v, 16);
       }
+      s16x8 xb[NJ];      // all reads of the k-step, then its MFMAs (see the tiled kernel)
 #pragma unroll
       for (int j = 0; j < NJ; j++) {
         uint2 lo = lds_read_tr16_b64(bx + s * STEP + coloff[j]), hi = lds_read_tr16_b64(bx + s * STEP + coloff[j] + R2);
         uint4 v = make_uint4(lo.x, lo.y, hi.x, hi.y);
-        s16x8 xb;
-        __builtin_memcpy(&xb, &v, 16);
-#pragma unroll
-        for (int i = 0; i < RT; i++) acc[i][j] = mfma_16x16x32_bf16(ya[i], xb, acc[i][j]);
+        __builtin_memcpy(&xb[j], &v, 16);
       }
+      sched_fence();
+#pragma unroll
+      for (int j = 0; j < NJ; j++)
+#pragma unroll
+        for (int i = 0; i < RT; i++) acc[i][j] = mfma_16x16x32_bf16(ya[i], xb[j], acc[i][j]);
+      sched_fence();
     }
   };
   auto tile_body = [&](int buf) RD_INLINE_LAMBDA {
@@ -477,6 +490,11 @@ static void tr_slices(const WgradArgs& a, int& cti, int& rt, int& nci, int& nco)
   const int Cin = a.C1 + a.C2;
   cti = Cin >= 64 ? 4 : Cin / 16;
   rt = a.Cout <= 16 ? 1 : 2;
+  // Measured and not kept (tools/bench_conv.py, eleven RC-Net wgrad shapes, 0.773 ms with the kernel as it is): 64-channel output
+  // slices in four waves (RT = 4, 144 accumulator registers, spills) 0.938 ms; eight-wave blocks (NWV = 8, four waves per SIMD) 0.807 ms;
+  // both together 0.843 ms; linear tiling (below) 0.893 ms.  Probes: with the MFMA phase removed a launch takes 55 % of its time, with the
+  // global fetches removed 91 % -- the LDS phase (stash, barrier, 88 transpose reads and 72 MFMAs per wave and tile) is what binds,
+  // at ~620 TFLOP/s whatever the register tile.
   nci = Cin >= 64 ? Cin / 64 : 1;
   nco = (int)cdiv(a.Cout, rt * 16);
 }
