@@ -321,7 +321,7 @@ def run_workload(kind, args, dev, world, rank, steps, warmup):
                 flag = torch.tensor([1 if go else 0], dtype=torch.int32, device=dev)
                 dist.broadcast(flag, 0)
                 go = bool(flag.item())
-    timer = engine.KernelTimer(repeat=1 if args.eager else 5)
+    timer = engine.KernelTimer(repeat=1 if args.eager else args.timer_repeat)
     if args.eager:
         engine.set_kernel_timer(timer)
     barrier()
@@ -416,6 +416,8 @@ def main():
     ap.add_argument("--force-ddp", action="store_true", help="run the N > 1 code path (RCCL process group, stage-bucketed all-reduce) on however "
                                                               "many ranks there are, including one: a functional check of that path on a 1-GPU box")
     ap.add_argument("--detail", default=None, help="write a per-launch-shape timing table to this file")
+    ap.add_argument("--timer-repeat", type=int, default=5, help="idempotent launches issued this many times per HIP-event pair in the instrumented "
+                                                                "steps (1 under rocprofv3, so that its launch counts per step are the real ones)")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:

@@ -521,7 +521,7 @@ const char* wgrad3x3_tr_name(const WgradArgs& a) {
   int cti, rt, nci, nco;
   tr_slices(a, cti, rt, nci, nco);
   if (tr_linear(a)) snprintf(buf, sizeof(buf), "conv3x3_wgrad_lin_kernel<%d, %d>", cti, rt);
-  else snprintf(buf, sizeof(buf), "conv3x3_wgrad_tr_kernel<%d, %d, %d>", cti, rt, tr_tw(a));
+  else snprintf(buf, sizeof(buf), "conv3x3_wgrad_tr_kernel<%d, %d, %d, 4>", cti, rt, tr_tw(a));
   return buf;
 }
 void launch_wgrad3x3_tr(const WgradArgs& a, hipStream_t st) {

@@ -13,6 +13,6 @@ fi
 timeout 900 python bench.py --gpus 1 --steps 50 --warmup 5 --no-cpu-baseline --detail $out/per_shape.txt "$@" > $out/bench.json 2> $out/bench.err
 tail -3 $out/bench.err; cut -c1-400 $out/bench.json
 export TMPDIR=/tmp; cd /tmp
-timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof -o rc -- python3 $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 3 --settle-seconds 0 --no-cpu-baseline --no-sml "$@" > $out/prof.log 2>&1
+timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof -o rc -- python3 $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 3 --settle-seconds 0 --no-cpu-baseline --no-sml --timer-repeat 1 "$@" > $out/prof.log 2>&1
 find $out/prof -name "*kernel_stats.csv" -exec cp {} $out/kernel_stats.csv \;
 rm -rf $out/prof
