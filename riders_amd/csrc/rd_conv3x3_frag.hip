@@ -43,7 +43,7 @@ constexpr int frag_pmax(int tp) { return tp <= 128 ? 256 : (tp <= 256 ? 384 : 64
 // NPT 16-pixel tiles per wave, WPX x WCH waves (pixels x 32-channel groups): block tile = (16 NPT WPX) pixels x (32 WCH) channels.
 // LIN: linear tiles; MULTI: more than one channel chunk (the next chunk's patch is prefetched).
 template <typename T, int NPT, int WPX, int WCH, bool LIN, bool MULTI>
-__global__ __launch_bounds__(64 * WPX * WCH, (WPX * WCH == 8 || NPT == 8) ? 2 : 3) void conv3x3_frag_kernel(ConvArgs a, FragGeom g) {
+__global__ __launch_bounds__(64 * WPX * WCH, (WPX * WCH == 8 && WCH == 4) ? 4 : ((WPX * WCH == 8 || NPT == 8 || (MULTI && WCH == 1)) ? 2 : 3)) void conv3x3_frag_kernel(ConvArgs a, FragGeom g) {
   constexpr int NW = WPX * WCH, NT = 64 * NW;
   constexpr int VE = Elem<T>::VE;
   constexpr int CKE = STAGE_BYTES / (int)sizeof(T);   // channels per chunk (128 bytes per pixel)
@@ -271,7 +271,10 @@ static bool frag_plan(const ConvArgs& a, int dtype, FragPlan& p) {
   if (!(a.KH == 3 && a.KW == 3 && a.stride == 1 && a.pad == 1 && a.dil == 1 && a.OH == a.Hin && a.OW == a.Win)) return false;
   if ((Cin % cke) || (a.C1 % ve) || a.Cout <= 16) return false;
   if ((int64_t)a.N * a.Hin * a.Win >= (int64_t)1 << 31) return false;   // the kernel keeps source pixel indices in 32 bits
-  p.variant = a.Cout > 64 ? frag_env("RD_FRAG_V128", 0) : (a.Cout > 32 ? frag_env("RD_FRAG_V64", 2) : frag_env("RD_FRAG_V32", 5));
+  // > 64 channels: eight-wave blocks (4 waves per SIMD at 126 VGPRs) when there are several chunks -- 0.847 -> 0.803 ms over the
+  // seventeen RC-Net shapes of tools/bench_conv.py -- four 128-pixel waves for one-chunk layers (64 -> 128 data gradient: 0.066 vs 0.069)
+  const bool multi = Cin > cke;
+  p.variant = a.Cout > 64 ? frag_env("RD_FRAG_V128", multi ? 1 : 0) : (a.Cout > 32 ? frag_env("RD_FRAG_V64", 2) : frag_env("RD_FRAG_V32", 5));
   const FragVariant& v = kFragVariants[p.variant];
   p.tp = v.tp; p.bn = v.bn; p.nw = v.nw;
   p.ncb = (int)cdiv(a.Cout, p.bn);
