@@ -26,6 +26,7 @@ def main():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     path = os.path.join(root, "profiles", "r03_pmc_dominant.json")
     db = json.load(open(path)) if os.path.exists(path) else {}
+    db[wl] = {}
     for k, d in agg.items():
         m = {c: v[0] / v[1] for c, v in d.items()}
         n = max(v[1] for v in d.values())
@@ -37,9 +38,9 @@ def main():
             e["wait_any_frac"] = m.get("SQ_WAIT_ANY", 0.0) / m["SQ_WAVE_CYCLES"]
             e["wait_inst_frac"] = m.get("SQ_WAIT_INST_ANY", 0.0) / m["SQ_WAVE_CYCLES"]
             e["active_inst_frac"] = m.get("SQ_ACTIVE_INST_ANY", 0.0) / m["SQ_WAVE_CYCLES"]
-        db[k] = e
+        db[wl][k] = e
     json.dump(db, open(path, "w"), indent=1, sort_keys=True)
-    top = sorted(((v.get("mfma_util", 0.0), k) for k, v in db.items() if v.get("per_dispatch", {}).get("SQ_INSTS_MFMA", 0) > 0), reverse=True)[:8]
+    top = sorted(((v.get("mfma_util", 0.0), k) for k, v in db[wl].items() if v.get("per_dispatch", {}).get("SQ_INSTS_MFMA", 0) > 0), reverse=True)[:8]
     print("pmc:", [(k[:50], round(u, 3)) for u, k in top])
 
 
