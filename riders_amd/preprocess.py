@@ -3,7 +3,8 @@
 scatter at the head of the RIDERS pipeline.  One launch projects every point in float64 (as numpy does with the float64 calibration
 matrices), rounds half-to-even, applies canvas_crop and the depth range, and scatters max(depth, 1) with the NEAREST point winning a
 pixel (atomic minimum on the float bit pattern instead of the reference's sort-by-depth + sequential overwrite: same map, bit for bit).
-The barycentric lidar interpolation (data/data_utils.py:333-367, scipy Delaunay) is not built.
+The barycentric lidar interpolation that follows it (data/data_utils.py:231-275, :333-367) is riders_amd.data_utils.interpolate_depth
+(Delaunay on the host as in the reference, point location + barycentric evaluation of every pixel on the device, rd_tri_raster).
 """
 import ctypes
 
