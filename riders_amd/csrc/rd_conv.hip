@@ -968,7 +968,9 @@ static bool use_conv3x3_small(const ConvArgs& a, int dtype) {
   return conv3x3_small_ok(a, dtype) && conv3x3_tiles(a) >= conv3x3_min_blocks();
 }
 static bool use_conv3x3_frag(const ConvArgs& a, int dtype) {   // wide layers: weights in fragment order from L2, only the patch in LDS
-  return conv3x3_frag_ok(a, dtype) && conv3x3_frag_blocks(a, dtype) >= conv3x3_min_blocks();
+  // also far below one block per CU: a block's chain (patch load, 9 taps per chunk, store) is short next to the implicit-GEMM kernel's
+  // stage chain on the same shape -- deep encoder stages, 9 672 / 2 560 pixels x 128 channels: 21 -> 13 us and 15 -> 12 us per launch
+  return conv3x3_frag_ok(a, dtype) && conv3x3_frag_blocks(a, dtype) >= std::min(conv3x3_min_blocks(), 8);
 }
 static bool use_conv3x3_dma(const ConvArgs& a, int dtype) {   // wide bf16 layers: LDS-DMA staging + 32x32x16 MFMA (rd_conv3x3_dma.hip)
   if (!conv3x3_dma_ok(a, dtype)) return false;

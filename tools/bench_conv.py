@@ -13,11 +13,11 @@ SHAPES = [  # N, H, W, Cin, Cout, C1 (first-source channels of a concat input, 0
     (240, 30, 12, 256, 128, 128, None), (240, 30, 12, 256, 128, 0, (15, 6)),
     (240, 60, 25, 128, 64, 64, None), (240, 60, 25, 128, 64, 0, (30, 12)),
     (240, 120, 50, 64, 32, 32, None), (240, 120, 50, 64, 32, 0, (60, 25)),
-    (8, 124, 153, 64, 64, 0, None), (8, 62, 77, 128, 128, 0, None), (8, 31, 39, 128, 128, 0, None),
+    (8, 124, 153, 64, 64, 0, None), (8, 62, 77, 128, 128, 0, None), (8, 31, 39, 128, 128, 0, None), (8, 16, 20, 128, 128, 0, None),
 ]
 # data gradients that are convolutions with >= 64 input channels: (N, H, W, Cin = fwd Cout, Cout = fwd Cin, D1)
 DGRADS = [(240, 15, 6, 256, 384, 256), (240, 15, 6, 256, 256, 256), (240, 30, 12, 128, 256, 128), (240, 60, 25, 64, 128, 64),
-          (8, 124, 153, 64, 64, 64), (8, 62, 77, 128, 128, 128)]
+          (8, 124, 153, 64, 64, 64), (8, 62, 77, 128, 128, 128), (8, 31, 39, 128, 128, 128), (8, 16, 20, 128, 128, 128)]
 
 
 def timeit(fn, iters=20):
