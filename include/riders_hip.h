@@ -51,6 +51,9 @@ typedef struct rd_conv_desc {
   int32_t OH, OW;              /* output spatial size                                                 */
   int32_t act; float slope;    /* epilogue activation for convs without BatchNorm                     */
   int32_t D1;                  /* output channels [0,D1) -> dst1, [D1,Cout) -> dst2 (D1 = Cout: one)  */
+  int32_t out_reduce2;         /* 1: sum every 2x2 block of output pixels and store it at (OH/2) x (OW/2): the data gradient of a layer that
+                                  up-samples its input by exactly 2 (UpConv2d, utils/net_utils.py:195-198) lands at SOURCE resolution, the
+                                  full-resolution gradient is never written.  Only where rd_conv_out_reduce2_ok says so. */
 } rd_conv_desc;
 
 /* elements (of the activation dtype) in a packed weight buffer for `rows` x (KH*KW*C).  K axes that can be 9 taps x whole 128-byte channel
@@ -127,6 +130,9 @@ int rd_conv_fwd(const rd_conv_desc* d, const void* src1, const void* src2, const
  * the same kernel a `rocprofv3 --kernel-trace --stats` summary of the run ranks first.  Thread-local storage, valid until the next call. */
 const char* rd_conv_fwd_kernel_name(const rd_conv_desc* d);
 const char* rd_conv_wgrad_kernel_name(const rd_conv_desc* d);
+/* 1 when rd_conv_fwd can run this descriptor with out_reduce2 = 1 (even OH / OW, single destination, no statistics, a kernel whose
+ * epilogue can pair rows and columns in registers: the narrow-layer 3x3 kernel) */
+int32_t rd_conv_out_reduce2_ok(const rd_conv_desc* d);
 /* fp32 workspace bytes needed by rd_conv_wgrad */
 int64_t rd_conv_wgrad_workspace_bytes(const rd_conv_desc* d);
 /* dw (OIHW fp32) = or += dY^T * gather(X); deterministic two-stage reduction */

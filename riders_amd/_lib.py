@@ -31,6 +31,7 @@ class ConvDesc(ctypes.Structure):
         ("OH", ctypes.c_int32), ("OW", ctypes.c_int32),
         ("act", ctypes.c_int32), ("slope", ctypes.c_float),
         ("D1", ctypes.c_int32),
+        ("out_reduce2", ctypes.c_int32),
     ]
 
 

@@ -51,6 +51,7 @@ void fill_args(const rd_conv_desc* d, rd::ConvArgs& a) {
   a.M = d->N * d->OH * d->OW;
   a.K = d->KH * d->KW * (d->C1 + d->C2);
   a.Kpad = RD_NS(d->dtype, conv_kpad)(a.K, RD_DT(d->dtype));
+  a.pool2 = d->out_reduce2 ? 1 : 0;
 }
 }  // namespace
 
@@ -154,6 +155,14 @@ int32_t rd_conv_stats_rows(const rd_conv_desc* d) {
   return (int32_t)RD_NS(d->dtype, conv_stats_rows)(a, RD_DT(d->dtype));
 }
 
+int32_t rd_conv_out_reduce2_ok(const rd_conv_desc* d) {
+  if (!d || check_desc(d)) return 0;
+  if ((d->OH & 1) || (d->OW & 1) || d->D1 != d->Cout) return 0;
+  rd::ConvArgs a; fill_args(d, a);
+  a.pool2 = 1;
+  return RD_NS(d->dtype, conv_pool2_ok)(a, RD_DT(d->dtype)) ? 1 : 0;
+}
+
 int32_t rd_conv_fwd_streams(const rd_conv_desc* d) {
   if (!d || check_desc(d)) return 0;
   rd::ConvArgs a; fill_args(d, a);
@@ -168,6 +177,7 @@ int rd_conv_fwd(const rd_conv_desc* d, const void* src1, const void* src2, const
   if (d->D1 < d->Cout && !dst2) return fail("conv_fwd: D1 < Cout but dst2 is null");
   rd::ConvArgs a; fill_args(d, a);
   a.src1 = src1; a.src2 = src2; a.w = w_packed; a.bias = bias; a.dst1 = dst1; a.dst2 = dst2; a.stats = stats;
+  if (a.pool2 && (stats || !rd_conv_out_reduce2_ok(d))) return fail("conv_fwd: out_reduce2 is not available for this descriptor (see rd_conv_out_reduce2_ok)");
   RD_NS(d->dtype, launch_conv)(a, RD_DT(d->dtype), S(stream));
   return done("rd_conv_fwd");
 }

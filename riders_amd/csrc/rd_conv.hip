@@ -998,6 +998,11 @@ void launch_conv(const ConvArgs& a, int dtype, hipStream_t st) {
   else launch_conv_t<bf16_t>(a, st);
 }
 
+// out_reduce2 (ConvArgs::pool2): only the narrow-layer 3x3 kernel pairs rows / columns of its output tile in registers
+bool conv_pool2_ok(const ConvArgs& a, int dtype) {
+  return !conv_few_ok(a) && !conv1x1_direct_ok(a, dtype) && !conv3x3_c1_ok(a) && use_conv3x3_small(a, dtype) && !(a.OH & 1) && !(a.OW & 1) &&
+         a.D1 == a.Cout && !a.bias && a.act == ACT_NONE;
+}
 // name of the kernel launch_conv picks for this shape (bench.py groups its per-launch timings by the names rocprofv3 reports)
 const char* conv_kernel_name(const ConvArgs& a, int dtype) {
   if (conv_few_ok(a)) return "conv_few_kernel";

@@ -380,6 +380,37 @@ __global__ __launch_bounds__(256, small_min_waves(SPP, BN)) void conv3x3_small_k
         mvv[pt] = oh < a.OH && ow < a.OW;
         mm[pt] = ((int64_t)tc.n * a.OH + oh) * a.OW + ow;
       }
+      if (a.pool2) {
+        // Data gradient of a layer that up-samples its input by exactly 2 (nearest): the gradient of a source pixel is the sum of its 2x2
+        // block of output pixels.  Tiles start on even rows / columns, so the block lies inside the tile: columns are neighbouring lanes
+        // (fr ^ 1); rows are the two pixel tiles of the lane (16-wide tiles: rows 2 wv, 2 wv + 1) or lanes fr ^ 8 (8-wide tiles: a pixel
+        // tile holds two rows).  The full-resolution gradient is never written (round 2: 0.19 ms of upsample_nearest_bwd per RC-Net step
+        // reading what this kernel had just written, and 4x the store traffic here).  Summed in fp32, rounded once.
+#pragma unroll
+        for (int c = 0; c < CT; c++) {
+          if (!W8) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) acc[c][0][r] += acc[c][1][r];
+          }
+#pragma unroll
+          for (int pt = 0; pt < (W8 ? 2 : 1); pt++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+              float v = acc[c][pt][r];
+              if (W8) v += __shfl_xor(v, 8);
+              v += __shfl_xor(v, 1);
+              acc[c][pt][r] = v;
+            }
+        }
+        const int OH2 = a.OH >> 1, OW2 = a.OW >> 1;
+#pragma unroll
+        for (int pt = 0; pt < 2; pt++) {
+          const int oh = tc.th * TH + lpy[pt], ow = tc.tw * TW + lpx[pt];
+          const bool rep = !(fr & 1) && (W8 ? !(fr & 8) : pt == 0);      // the lane (and pixel tile) that holds the block's sum
+          mvv[pt] = mvv[pt] && rep;
+          mm[pt] = ((int64_t)tc.n * OH2 + (oh >> 1)) * OW2 + (ow >> 1);
+        }
+      }
       conv_epilogue_store<T, CT>(a, acc, mm, mvv, 0, 0, fr, fg, ssum, ssq);
     }
   };

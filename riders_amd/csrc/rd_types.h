@@ -12,6 +12,7 @@ struct ConvArgs {
   int N, Hin, Win, C1, C2, H1, W1, Cout, KH, KW, stride, pad, dil, OH, OW, act, D1;
   float slope, scale_h, scale_w;
   int M, K, Kpad, ups;
+  int pool2;   // data gradient of an exact 2x nearest up-sampling layer: 2x2 output blocks are summed and stored at half resolution
 };
 
 struct WgradArgs {

@@ -22,7 +22,8 @@ from ._lib import ACT_LRELU, ACT_NONE, ACT_RELU, ACT_RELU6, RD_BF16, RD_F16, RD_
 _TORCH_DT = {RD_F32: torch.float32, RD_BF16: torch.bfloat16, RD_F16: torch.float16}
 _RD_DT = {torch.float32: RD_F32, torch.bfloat16: RD_BF16, torch.float16: RD_F16}
 
-_state = {"dtype": RD_F32, "tape": None, "defer_wgrad": True, "fused_loftr": True, "deterministic_roi_pool": False, "roi_tile_min_blocks": 256}
+_state = {"dtype": RD_F32, "tape": None, "defer_wgrad": True, "fused_loftr": True, "deterministic_roi_pool": False, "roi_tile_min_blocks": 256,
+          "fuse_upsample_bwd": os.environ.get("RIDERS_FUSE_UPSAMPLE_BWD", "1") != "0"}     # A/B switch of the 2x2-summing data gradient
 
 
 def set_roi_tile_min_blocks(n):
@@ -784,6 +785,20 @@ def conv_block(x, weight, *, x2=None, bias=None, stride=1, pad=None, up=None, bn
         if need_in:
             wpd = packed_weight(weight, 1, dt)
             dd = _desc(dt, N, OH, OW, Cout, 0, False, OH, OW, Cin, KH, KW, 1, KH - 1 - pad, stride, Hin, Win, ACT_NONE, 0.0, C1)
+            # exact 2x nearest up-sampling (UpConv2d at 120x50 -> 240x100 ...): the kernel sums the 2x2 blocks of its output tile and stores the
+            # gradient at SOURCE resolution; the full-resolution tensor and the upsample_nearest_bwd pass over it disappear
+            fused_up = False
+            if is_up and C2 == 0 and (Hin, Win) == (2 * H1, 2 * W1) and _state.get("fuse_upsample_bwd", True):
+                dd.out_reduce2 = 1
+                fused_up = bool(lib.rd_conv_out_reduce2_ok(ctypes.byref(dd)))
+                dd.out_reduce2 = 1 if fused_up else 0
+            if fused_up:
+                g1 = torch.empty_like(x)
+                _chk(_timed("conv_gemm", flops, lambda: lib.rd_conv_fwd(ctypes.byref(dd), _p(dy), None, _p(wpd), None, _p(g1), None, None, st),
+                            "dgrad " + shp + " (2x2 summed)", b_out + b_w + g1.numel() * es,
+                            kernel=lambda: lib.rd_conv_fwd_kernel_name(ctypes.byref(dd)).decode(), idem=True), "rd_conv_fwd(dgrad, out_reduce2)")
+                t.add_grad(x, g1)
+                return
             dxv1 = torch.empty((N, Hin, Win, C1), dtype=x.dtype, device=x.device)
             dxv2 = torch.empty((N, Hin, Win, C2), dtype=x.dtype, device=x.device) if C2 else None
             _chk(_timed("conv_gemm", flops, lambda: lib.rd_conv_fwd(ctypes.byref(dd), _p(dy), None, _p(wpd), None, _p(dxv1), _p(dxv2),

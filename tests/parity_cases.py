@@ -164,6 +164,27 @@ FRAG_CONV_CASES = [
 ]
 
 
+def upsample_fused_dgrad_cases(dev):
+    """Data gradient of exact-2x up-sampling layers summed 2x2 inside the narrow-layer kernel (rd_conv_desc.out_reduce2): bf16 on integer
+    data exact against F.interpolate + conv2d autograd, 16-wide tiles (rows = the lane's two pixel tiles) and 8-wide tiles (rows = lanes
+    fr ^ 8), several tiles per persistent block; then a decoder block in fp32 against the oracle; then the switch off gives the same."""
+    from riders_amd import engine
+    with force_patch_conv():
+        bf16_exact_conv_case(dev, cin=16, cout=16, k=3, s=1, N=2, up=((8, 6), (16, 12)))       # 16-wide tiles
+        bf16_exact_conv_case(dev, cin=32, cout=16, k=3, s=1, N=2, up=((12, 4), (24, 8)))       # 8-wide tiles
+        bf16_exact_conv_case(dev, cin=32, cout=64, k=3, s=1, N=1, up=((9, 10), (18, 20)))      # 64 gradient channels (weights in LDS)
+        decoder_block_case(dev, cin=16, cskip=0, cout=16, hs=(5, 4), hv=(10, 8))
+    with force_patch_conv(g8=1):
+        bf16_exact_conv_case(dev, cin=16, cout=32, k=3, s=1, N=3, up=((20, 13), (40, 26)))
+    old = engine._state["fuse_upsample_bwd"]
+    engine._state["fuse_upsample_bwd"] = False
+    try:
+        with force_patch_conv():
+            bf16_exact_conv_case(dev, cin=16, cout=16, k=3, s=1, N=2, up=((8, 6), (16, 12)))
+    finally:
+        engine._state["fuse_upsample_bwd"] = old
+
+
 def frag_conv_cases(dev, quick=False):
     """The register-fed 3x3 kernel in every block shape and both tile forms: fp32 against the oracle, then bf16 on integer data, exact
     (forward + both gradients), with the up-sampling / concatenating gather and the dual-destination data gradient.  quick: the subset the

@@ -37,6 +37,10 @@ def test_patch_conv_decoder_and_bf16(emu):
         P.conv_case(emu, dict(cin=16, cout=16, k=3, s=1, H=30, W=20, N=3, bn=True))
 
 
+def test_upsample_fused_dgrad(emu):
+    P.upsample_fused_dgrad_cases(emu)
+
+
 def test_frag_conv(emu):
     P.frag_conv_cases(emu, quick=True)
 

@@ -38,6 +38,13 @@ def test_patch_conv_decoder_and_bf16(gpu):
     P.conv_case(gpu, dict(cin=64, cout=64, k=3, s=1, H=64, W=96, N=4, bn=True))
 
 
+def test_upsample_fused_dgrad(gpu):
+    P.upsample_fused_dgrad_cases(gpu)
+    # RC-Net's deconv0 / deconv1 geometry, routed by block count: 60x25 -> 120x50 (64 -> 32) and 120x50 -> 240x100 (32 -> 16), 24 RoIs
+    P.bf16_exact_conv_case(gpu, cin=32, cout=16, k=3, s=1, N=24, up=((120, 50), (240, 100)))
+    P.bf16_exact_conv_case(gpu, cin=64, cout=32, k=3, s=1, N=24, up=((60, 25), (120, 50)))
+
+
 def test_frag_conv(gpu):
     P.frag_conv_cases(gpu)
     # RC-Net sizes, routed by block count (no hooks): RoI maps as pixel runs across images, encoder maps as 2-D tiles
