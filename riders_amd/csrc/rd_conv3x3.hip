@@ -713,8 +713,16 @@ __global__ __launch_bounds__(256) void conv_few_kernel(ConvArgs a) {
 #pragma unroll
   for (int c = 0; c < CO; c++) { const float b = a.bias ? a.bias[c < a.Cout ? c : 0] : 0.f; bv[c] = c < a.Cout ? b : 0.f; }
   const bool vec = (a.Cout & 3) == 0;
-  for (int64_t m = (int64_t)blockIdx.x * 256 + t; m < a.M; m += (int64_t)gridDim.x * 256) {
-    const int ow = (int)(m % a.OW); const int64_t q = m / a.OW; const int oh = (int)(q % a.OH); const int n = (int)(q / a.OH);
+  // DIL = 2 (data gradient of a stride-2 layer): a pixel only has the taps whose row / column parity matches its own -- 1, 2, 2 or 4 of
+  // the nine.  With an even row length the 64 lanes of a wave take pixels of ONE column parity (waves 2k / 2k+1 of a block share a run of
+  // 128 pixels: even / odd columns), so a tap is valid for the whole wave or for none of it and the invalid ones are skipped by a ballot:
+  // 2.25 instead of 9 taps of 128 weight reads and FMAs per pixel (the LDS weight reads bound the kernel: 0.17 ms for a 58 MB layer).
+  const bool split = DIL > 1 && (a.OW & 1) == 0;
+  const int64_t Mr = split ? ((a.M + 127) & ~(int64_t)127) : a.M;
+  for (int64_t mm = (int64_t)blockIdx.x * 256 + t; mm < Mr; mm += (int64_t)gridDim.x * 256) {
+    const int64_t m = split ? ((mm & ~(int64_t)127) | ((mm & 63) << 1) | ((mm >> 6) & 1)) : mm;
+    const bool live = m < a.M;
+    const int ow = (int)(m % a.OW); const int64_t q = m / a.OW; const int oh = (int)(q % a.OH); const int n = live ? (int)(q / a.OH) : 0;
     float acc[CO];
 #pragma unroll
     for (int c = 0; c < CO; c++) acc[c] = 0.f;
@@ -734,8 +742,9 @@ __global__ __launch_bounds__(256) void conv_few_kernel(ConvArgs a) {
       for (int kw = 0; kw < KH; kw++) {
         int ih = oh - a.pad + kh, iw = ow - a.pad + kw;
         bool ok = ih >= 0 && iw >= 0;
-        if (DIL > 1) { ok = ok && (((ih | iw) & (DIL - 1)) == 0); ih >>= 1; iw >>= 1; }      // DIL is 1 or 2
+        if (DIL > 1) { ok = ok && live && (((ih | iw) & (DIL - 1)) == 0); ih >>= 1; iw >>= 1; }      // DIL is 1 or 2
         ok = ok && ih < a.Hin && iw < a.Win;
+        if (DIL > 1) { if (__ballot(ok) == 0ull) continue; }      // no lane of the wave has this tap
         const T* px = x + (((int64_t)n * a.Hin + min(max(ih, 0), a.Hin - 1)) * a.Win + min(max(iw, 0), a.Win - 1)) * CIN;
         float xv[CIN];
         if constexpr (CIN % VE == 0) {
@@ -755,6 +764,7 @@ __global__ __launch_bounds__(256) void conv_few_kernel(ConvArgs a) {
 #pragma unroll
           for (int co = 0; co < CO; co++) acc[co] += sw[((kh * KH + kw) * CIN + c) * CO + co] * xv[c];
       }
+    if (!live) continue;
     T* d = (T*)a.dst1 + m * a.Cout;
 #pragma unroll
     for (int c0 = 0; c0 < CO; c0 += 4) {

@@ -20,6 +20,10 @@ namespace rd {
 #ifndef RD_WGRAD_DEEP_MAX
 #define RD_WGRAD_DEEP_MAX 12
 #endif
+#ifndef RD_WGRAD_SHARE      // A/B hook: 0 = one pair of transpose reads per column tile and k-step, 1 = shared rows (TW = 16), 2 = + next k-step's reads
+                            // issued before this one's MFMAs, 3 = also for TW = 8
+#define RD_WGRAD_SHARE 2
+#endif
 
 // LDS layout.  Round 1 (profiles/r01_wgrad_tr_lds_swizzle.txt): with plain [pixel][channel] images the 32-lane transpose reads of the
 // 64-channel slices hit 2..4 bank groups (SQ_LDS_BANK_CONFLICT = 66 % of SQ_LDS_IDX_ACTIVE); an XOR swizzle removed every conflict and made
@@ -176,6 +180,78 @@ __global__ __launch_bounds__(64 * NWV, NWV == 8 ? (RT >= 4 ? 2 : 4) : ((CTI * RT
     constexpr int NJ = decltype(njc)::value;
     const unsigned short* bx = reinterpret_cast<const unsigned short*>(&sX[buf][0]) + boff;
     const unsigned short* by = reinterpret_cast<const unsigned short*>(&sY[buf][0]) + aoff;
+    // 64-channel slices in four waves: wave wv owns input-channel plane wv and ALL nine taps (column tile j is tap j).  The halves of its
+    // fragments are then shared between taps and between k-steps -- a transpose read covers one patch row (TW = 16) or one pair of rows
+    // (TW = 8) at column offset kw, and tap kh of k-step s wants rows 2s+kh, 2s+kh+1 (pairs 4s+kh, 4s+kh+2): every row / pair is read
+    // ONCE per tile and kw and kept in registers across the taps and the next k-step.  Transpose reads per wave and tile: 88 -> 46
+    // (TW = 16), 44 -> 35 (TW = 8).  Measured (tools/ab_wgrad.sh, tools/pmc_wgrad.sh; 360000 pixels 128 -> 64): SQ_INSTS_LDS -44 %,
+    // SQ_WAIT_INST_LDS -45 %, wave cycles -3.7 %, 0.090 -> 0.086 ms -- the reads were NOT what bound the kernel; TW = 8 came out 1-2 %
+    // slower (the operand copies cost more than its nine saved reads) and keeps one read pair per column tile.  A start offset between
+    // the two blocks of a CU (0.5 - 8 K cycles) changed nothing either.
+    if constexpr (CTI == 4 && NWV == 4 && NJ == 9 && (TW == 16 || (TW == 8 && RD_WGRAD_SHARE >= 3)) && RD_WGRAD_SHARE) {
+      constexpr int NP = TW == 16 ? 4 : 5, CARRY = TW == 16 ? 2 : 1, RSTEP = TW == 16 ? 2 : 4, HI = TW == 16 ? 1 : 2, NN = NP - CARRY;
+      const unsigned short* bw = bx + wv * XPS;
+      uint2 R[3][NP], Rn[3][NN];
+      s16x8 ya[RT], yn[RT];
+      auto read_a = [&](int s, s16x8 (&dst)[RT]) RD_INLINE_LAMBDA {
+#pragma unroll
+        for (int i = 0; i < RT; i++) {
+          uint2 lo = lds_read_tr16_b64(by + s * ASTEP + i * YPS), hi = lds_read_tr16_b64(by + s * ASTEP + i * YPS + A2);
+          uint4 v = make_uint4(lo.x, lo.y, hi.x, hi.y);
+          __builtin_memcpy(&dst[i], &v, 16);
+        }
+      };
+#pragma unroll
+      for (int kw = 0; kw < 3; kw++)
+#pragma unroll
+        for (int q = 0; q < NP; q++) R[kw][q] = lds_read_tr16_b64(bw + (q * WT + kw) * 16);
+      read_a(0, ya);
+      sched_fence();      // the first k-step's reads stay in front of the second's (the scheduler mixed them: lgkmcnt(2) before the first MFMA)
+#pragma unroll
+      for (int s = 0; s < KSTEPS; s++) {
+        // the NEXT k-step's reads are issued before this one's MFMAs (LDS returns in order: the wait in front of the first MFMA leaves
+        // them outstanding); with reads, wait, MFMAs per k-step every wave exposed one LDS round trip per k-step -- waves were parked
+        // at s_waitcnt / the barrier for 45 % of their cycles (profiles/r03_pmc_patch/wgrad_256to128_planes.txt)
+        if (RD_WGRAD_SHARE >= 2 && s + 1 < KSTEPS) {
+          read_a(s + 1, yn);
+#pragma unroll
+          for (int kw = 0; kw < 3; kw++)
+#pragma unroll
+            for (int q = 0; q < NN; q++) Rn[kw][q] = lds_read_tr16_b64(bw + (((s + 1) * RSTEP + CARRY + q) * WT + kw) * 16);
+        }
+        sched_fence();
+#pragma unroll
+        for (int kh = 0; kh < 3; kh++)
+#pragma unroll
+          for (int kw = 0; kw < 3; kw++) {
+            const uint4 v = make_uint4(R[kw][kh].x, R[kw][kh].y, R[kw][kh + HI].x, R[kw][kh + HI].y);
+            s16x8 xb;
+            __builtin_memcpy(&xb, &v, 16);
+#pragma unroll
+            for (int i = 0; i < RT; i++) acc[i][kh * 3 + kw] = mfma_16x16x32_bf16(ya[i], xb, acc[i][kh * 3 + kw]);
+          }
+        sched_fence();
+        if (s + 1 < KSTEPS) {
+          if (RD_WGRAD_SHARE < 2) {
+            read_a(s + 1, yn);
+#pragma unroll
+            for (int kw = 0; kw < 3; kw++)
+#pragma unroll
+              for (int q = 0; q < NN; q++) Rn[kw][q] = lds_read_tr16_b64(bw + (((s + 1) * RSTEP + CARRY + q) * WT + kw) * 16);
+          }
+#pragma unroll
+          for (int kw = 0; kw < 3; kw++) {
+#pragma unroll
+            for (int q = 0; q < CARRY; q++) R[kw][q] = R[kw][NN + q];
+#pragma unroll
+            for (int q = 0; q < NN; q++) R[kw][CARRY + q] = Rn[kw][q];
+          }
+#pragma unroll
+          for (int i = 0; i < RT; i++) ya[i] = yn[i];
+        }
+      }
+      return;
+    }
 #pragma unroll
     for (int s = 0; s < KSTEPS; s++) {
       s16x8 ya[RT];
@@ -210,7 +286,11 @@ __global__ __launch_bounds__(64 * NWV, NWV == 8 ? (RT >= 4 ? 2 : 4) : ((CTI * RT
   };
   // prefetch distance two tiles where the register budget allows (every variant at <= 12 staged vectors per thread since round 3:
   // 0.831 -> 0.811 ms over the eleven wgrad shapes of tools/bench_conv.py), one otherwise
-  constexpr bool DEEP = (XIT + YIT) <= RD_WGRAD_DEEP_MAX;
+#ifndef RD_WGRAD_DEEP16
+#define RD_WGRAD_DEEP16 0
+#endif
+  // (the pipelined fragment reads of the 64-channel / 16-wide variant need the second staging set's 32 registers: 256 + 31 spilled with both)
+  constexpr bool DEEP = (XIT + YIT) <= RD_WGRAD_DEEP_MAX && (RD_WGRAD_DEEP16 || !(CTI == 4 && NWV == 4 && TW == 16 && RD_WGRAD_SHARE >= 2));
   uint4 xa[XIT], ya_[YIT], xb_[DEEP ? XIT : 1], yb_[DEEP ? YIT : 1];
   int buf = 0;
   if (DEEP) {

@@ -400,6 +400,9 @@ def test_bn_generic_channel_counts(gpu):
     P.conv_case(gpu, dict(cin=24, cout=40, k=1, s=1, H=13, W=11, N=2, bn=True))
     P.conv_case(gpu, dict(cin=16, cout=144, k=1, s=1, H=9, W=10, N=2, bn=True))
     P.conv_case(gpu, dict(cin=8, cout=232, k=3, s=1, H=6, W=7, N=1, bn=True))
+    P.conv_case(gpu, dict(cin=8, cout=288, k=1, s=1, H=9, W=18, N=2, bn=True))     # > 256 channels: short per-block pixel ranges in the backward reduce
+    P.conv_case(gpu, dict(cin=8, cout=816, k=1, s=1, H=5, W=7, N=1, bn=True))
+    P.conv_case(gpu, dict(cin=16, cout=1392, k=1, s=1, H=9, W=18, N=4, bn=True))
 
 
 def test_stem_padded_channels(gpu):
