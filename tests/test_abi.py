@@ -27,8 +27,22 @@ def test_library_exports_every_declared_symbol():
 
 
 def test_conv_desc_matches_c_layout():
-    # 20 x 4-byte fields, no padding
-    assert ctypes.sizeof(_lib.ConvDesc) == 80
+    # 21 x 4-byte fields, no padding; the field names and order are those of the C struct in include/riders_hip.h
+    import re
+    assert ctypes.sizeof(_lib.ConvDesc) == 84
+    src = open(_lib.HEADER).read()
+    body = re.search(r"typedef struct rd_conv_desc\s*\{(.*?)\}\s*rd_conv_desc;", src, flags=re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", " ", body, flags=re.S)
+    body = re.sub(r"//[^\n]*", " ", body)
+    names = []
+    for decl in body.split(";"):
+        decl = decl.strip()
+        if not decl:
+            continue
+        ty, rest = decl.split(None, 1)
+        assert ty in ("int32_t", "float"), decl
+        names += [n.strip() for n in rest.split(",")]
+    assert names == [f[0] for f in _lib.ConvDesc._fields_], (names, [f[0] for f in _lib.ConvDesc._fields_])
 
 
 def test_product_refuses_host_tensors():
