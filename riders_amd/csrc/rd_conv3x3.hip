@@ -762,7 +762,7 @@ __global__ __launch_bounds__(256) void conv_few_kernel(ConvArgs a) {
 #pragma unroll
         for (int c = 0; c < CIN; c++)
 #pragma unroll
-          for (int co = 0; co < CO; co++) acc[co] += sw[((kh * KH + kw) * CIN + c) * CO + co] * xv[c];
+          for (int co = 0; co < CO; co++) acc[co] = fmaf(sw[((kh * KH + kw) * CIN + c) * CO + co], xv[c], acc[co]);
       }
     if (!live) continue;
     T* d = (T*)a.dst1 + m * a.Cout;

@@ -113,6 +113,9 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_kernel(const T* __restrict__
 // Block geometry: QB quads x PL pixel lanes <= 256 threads with QB = ceil(C/4 / nchunk) chosen for the fewest idle threads (C/4 is
 // 36..348 in EfficientNet-Lite3: a power-of-two QB idled up to 44 % of the lanes).
 static constexpr int DWR = 4;
+// The tap products are explicit fmaf(): the library is built with -ffp-contract=off (emulator and GPU round alike), which turned the 400
+// multiply-adds of a 5x5 unit into 208 v_pk_mul_f32 + 254 v_pk_add_f32; fused they are ~200 v_pk_fma_f32 (the host emulator's fmaf is the
+// same correctly-rounded operation).  These kernels are vector-issue bound (~750 instructions per 16 outputs at 5x5), not HBM bound.
 
 // The block's weights are a contiguous run of w (QB quads x 4 channels x k*k floats): staged into LDS with coalesced 16-byte loads, then
 // each thread picks up its quad (k*k x 4 registers).  Reading them straight from global memory is a 400-byte-strided gather -- 64 cache
@@ -200,7 +203,7 @@ __global__ __launch_bounds__(256) RD_WAVES_PER_EU((ST && S == 1) ? 2 : 1) void d
 #pragma unroll
         for (int r = 0; r < DWR; r++)
 #pragma unroll
-          for (int e = 0; e < 4; e++) acc[r][e] += v[MODE ? r + K - 1 - kw : r * S + kw][e] * wr[kh * K + kw][e];
+          for (int e = 0; e < 4; e++) acc[r][e] = fmaf(v[MODE ? r + K - 1 - kw : r * S + kw][e], wr[kh * K + kw][e], acc[r][e]);
     }
 #pragma unroll
     for (int r = 0; r < DWR; r++)
@@ -255,7 +258,7 @@ __device__ __forceinline__ void dw_dgrad2_rows(const T* __restrict__ dy, const f
         const int kw = r + (K - 1 - PP) - 2 * j;
         if (kw >= 0 && kw < K) {
 #pragma unroll
-          for (int e = 0; e < 4; e++) acc[r][e] += v[j][e] * wr[kh * K + kw][e];
+          for (int e = 0; e < 4; e++) acc[r][e] = fmaf(v[j][e], wr[kh * K + kw][e], acc[r][e]);
         }
       }
   }
@@ -346,7 +349,7 @@ __global__ __launch_bounds__(256) void dw_wgrad_run_kernel(const T* __restrict__
 #pragma unroll
           for (int r = 0; r < DWR; r++)
 #pragma unroll
-            for (int e = 0; e < 4; e++) acc[kh * K + kw][e] += g[r][e] * v[r * S + kw][e];
+            for (int e = 0; e < 4; e++) acc[kh * K + kw][e] = fmaf(g[r][e], v[r * S + kw][e], acc[kh * K + kw][e]);
       }
     }
   }
