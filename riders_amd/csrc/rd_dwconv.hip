@@ -360,13 +360,22 @@ __global__ __launch_bounds__(256) void dw_wgrad_run_kernel(const T* __restrict__
 #pragma unroll
       for (int e = 0; e < 4; e++) red[t][kw][e] = acc[kh * K + kw][e];
     __syncthreads();
-    if (pl == 0 && cv) {
-#pragma unroll
-      for (int kw = 0; kw < K; kw++) {
+    // pixel lane pl sums tap kw = pl (, pl + PL, ...) of this filter row over all lanes, four LDS reads in flight (same order of
+    // additions as one lane walking q = 0 .. PL-1).  With lane 0 alone doing all K taps one dependent read at a time this epilogue
+    // took longer than the unit loop: 25-30 of the 50 us of EVERY 5x5 layer whatever its size (probe builds: unit loop only 22-27 us,
+    // epilogue only 30-35).  Also measured and not kept: all 44 loads of a unit issued up front (0.88 -> 0.87 ms per SML step, mixed per
+    // layer), one or two units per thread instead of four (0.91 / 0.99: more blocks = more epilogues and partial rows).
+    if (cv) {
+      for (int kw = pl; kw < K; kw += PL) {
         float s4[4] = {0.f, 0.f, 0.f, 0.f};
-        for (int q = 0; q < PL; q++)
+        for (int q0 = 0; q0 < PL; q0 += 4) {
+          float4 v[4];
 #pragma unroll
-          for (int e = 0; e < 4; e++) s4[e] += red[q * QB + cl][kw][e];
+          for (int u = 0; u < 4; u++) v[u] = *reinterpret_cast<const float4*>(&red[min(q0 + u, PL - 1) * QB + cl][kw][0]);
+#pragma unroll
+          for (int u = 0; u < 4; u++)
+            if (q0 + u < PL) { s4[0] += v[u].x; s4[1] += v[u].y; s4[2] += v[u].z; s4[3] += v[u].w; }
+        }
         st4(partial + ((int64_t)blockIdx.x * (K * K) + kh * K + kw) * C + c, s4);
       }
     }
