@@ -133,6 +133,13 @@ const char* rd_conv_wgrad_kernel_name(const rd_conv_desc* d);
 /* 1 when rd_conv_fwd can run this descriptor with out_reduce2 = 1 (even OH / OW, single destination, no statistics, a kernel whose
  * epilogue can pair rows and columns in registers: the narrow-layer 3x3 kernel) */
 int32_t rd_conv_out_reduce2_ok(const rd_conv_desc* d);
+/* dst = round(conv(...) + addend): `addend` is a [N*OH*OW][Cout] tensor of the activation dtype, read once in the epilogue.  The engine's
+ * backward hands over a tensor's EARLIER gradient contribution when a second consumer's data gradient arrives (skip connections of
+ * utils/net_utils.py:564-569, residual blocks :250-330), instead of writing the second contribution and adding the two in a separate
+ * pass.  One destination (D1 == Cout), no statistics; rd_conv_add_ok = 1 where the kernel the descriptor is routed to supports it. */
+int32_t rd_conv_add_ok(const rd_conv_desc* d);
+int rd_conv_fwd_add(const rd_conv_desc* d, const void* src1, const void* src2, const void* w_packed, const float* bias, const void* addend,
+                    void* dst, void* stream);
 /* fp32 workspace bytes needed by rd_conv_wgrad */
 int64_t rd_conv_wgrad_workspace_bytes(const rd_conv_desc* d);
 /* dw (OIHW fp32) = or += dY^T * gather(X); deterministic two-stage reduction */

@@ -181,6 +181,22 @@ int rd_conv_fwd(const rd_conv_desc* d, const void* src1, const void* src2, const
   RD_NS(d->dtype, launch_conv)(a, RD_DT(d->dtype), S(stream));
   return done("rd_conv_fwd");
 }
+int32_t rd_conv_add_ok(const rd_conv_desc* d) {
+  if (!d || check_desc(d) || d->D1 != d->Cout || d->out_reduce2) return 0;
+  rd::ConvArgs a; fill_args(d, a);
+  return RD_NS(d->dtype, conv_add_ok)(a, RD_DT(d->dtype)) ? 1 : 0;
+}
+int rd_conv_fwd_add(const rd_conv_desc* d, const void* src1, const void* src2, const void* w_packed, const float* bias, const void* addend,
+                    void* dst, void* stream) {
+  if (int e = check_desc(d)) return e;
+  if (!src1 || !w_packed || !dst || !addend) return fail("conv_fwd_add: null pointer");
+  if (d->C2 > 0 && !src2) return fail("conv_fwd_add: C2 > 0 but src2 is null");
+  if (!rd_conv_add_ok(d)) return fail("conv_fwd_add: not available for this descriptor (see rd_conv_add_ok)");
+  rd::ConvArgs a; fill_args(d, a);
+  a.src1 = src1; a.src2 = src2; a.w = w_packed; a.bias = bias; a.dst1 = dst; a.dst2 = nullptr; a.stats = nullptr; a.add1 = addend;
+  RD_NS(d->dtype, launch_conv)(a, RD_DT(d->dtype), S(stream));
+  return done("rd_conv_fwd_add");
+}
 const char* rd_conv_fwd_kernel_name(const rd_conv_desc* d) {
   if (!d || check_desc(d)) return "";
   rd::ConvArgs a; fill_args(d, a);

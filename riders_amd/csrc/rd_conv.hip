@@ -1003,6 +1003,14 @@ bool conv_pool2_ok(const ConvArgs& a, int dtype) {
   return !conv_few_ok(a) && !conv1x1_direct_ok(a, dtype) && !conv3x3_c1_ok(a) && use_conv3x3_small(a, dtype) && !(a.OH & 1) && !(a.OW & 1) &&
          a.D1 == a.Cout && !a.bias && a.act == ACT_NONE;
 }
+// ConvArgs::add1: the kernels that store through conv_epilogue_store except the narrow-layer one (not the few-channel / single-channel
+// streaming kernels, not the experimental LDS-DMA kernel), one destination, no 2x2 reduction
+bool conv_add_ok(const ConvArgs& a, int dtype) {
+  if (a.D1 != a.Cout || a.pool2 || conv_few_ok(a)) return false;
+  if (conv1x1_direct_ok(a, dtype)) return true;
+  if (conv3x3_c1_ok(a) || use_conv3x3_small(a, dtype)) return false;      // (the narrow-layer variants sit at their register caps)
+  return !use_conv3x3_dma(a, dtype);
+}
 // name of the kernel launch_conv picks for this shape (bench.py groups its per-launch timings by the names rocprofv3 reports)
 const char* conv_kernel_name(const ConvArgs& a, int dtype) {
   if (conv_few_ok(a)) return "conv_few_kernel";

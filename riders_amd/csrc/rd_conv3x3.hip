@@ -411,7 +411,7 @@ __global__ __launch_bounds__(256, small_min_waves(SPP, BN)) void conv3x3_small_k
           mm[pt] = ((int64_t)tc.n * OH2 + (oh >> 1)) * OW2 + (ow >> 1);
         }
       }
-      conv_epilogue_store<T, CT>(a, acc, mm, mvv, 0, 0, fr, fg, ssum, ssq);
+      conv_epilogue_store<T, CT, false>(a, acc, mm, mvv, 0, 0, fr, fg, ssum, ssq);      // (no addend: these variants sit at their register caps)
     }
   };
 

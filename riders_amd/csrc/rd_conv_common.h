@@ -90,7 +90,7 @@ __device__ __forceinline__ void round_store4(bf16_t* d, const float (&x)[4], flo
 // The narrow RC-Net layers are VALU-bound in this routine (rocprofv3: ~380 VALU instructions per wave and 128-pixel tile, 4 cycles
 // each), so everything uniform is decided once: no bias / no activation (every BatchNorm-ed convolution) skips both per element,
 // invalid pixels skip the whole channel loop, the destination row pointers are formed once per pixel, and a value is rounded once.
-template <typename T, int CT>
+template <typename T, int CT, bool ADD = true>
 __device__ __forceinline__ void conv_epilogue_store(const ConvArgs& a, f32x4 (&acc)[CT][2], const int64_t (&m)[2], const bool (&mv)[2], int n0,
                                                     int wn, int fr, int fg, float (&ssum)[CT][4], float (&ssq)[CT][4]) {
   const int D2 = a.Cout - a.D1;
@@ -126,6 +126,16 @@ __device__ __forceinline__ void conv_epilogue_store(const ConvArgs& a, f32x4 (&a
         for (int r = 0; r < 4; r++) {
           if (has_bias) x[r] += bv[c][r];
           x[r] = act_fwd(x[r], a.act, a.slope);
+        }
+      }
+      if (ADD && a.add1) {      // the tensor's earlier gradient contribution rides along: cur + this, rounded once (no separate add pass)
+        const T* ap = (const T*)a.add1 + m[pt] * a.Cout + co;
+        if (vec_ok && co + 3 < a.Cout) { float av[4]; ld4(ap, av);
+#pragma unroll
+          for (int r = 0; r < 4; r++) x[r] += av[r];
+        } else {
+#pragma unroll
+          for (int r = 0; r < 4; r++) if (co + r < a.Cout) x[r] += Elem<T>::ld(ap + r);
         }
       }
       if (vec_ok && co + 3 < a.Cout) {

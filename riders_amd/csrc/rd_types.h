@@ -13,6 +13,7 @@ struct ConvArgs {
   float slope, scale_h, scale_w;
   int M, K, Kpad, ups;
   int pool2;   // data gradient of an exact 2x nearest up-sampling layer: 2x2 output blocks are summed and stored at half resolution
+  const void* add1;   // optional [M][Cout] tensor added to the result before rounding (a gradient's earlier contribution); D1 == Cout only
 };
 
 struct WgradArgs {

@@ -23,7 +23,8 @@ _TORCH_DT = {RD_F32: torch.float32, RD_BF16: torch.bfloat16, RD_F16: torch.float
 _RD_DT = {torch.float32: RD_F32, torch.bfloat16: RD_BF16, torch.float16: RD_F16}
 
 _state = {"dtype": RD_F32, "tape": None, "defer_wgrad": True, "fused_loftr": True, "deterministic_roi_pool": False, "roi_tile_min_blocks": 256,
-          "fuse_upsample_bwd": os.environ.get("RIDERS_FUSE_UPSAMPLE_BWD", "1") != "0"}     # A/B switch of the 2x2-summing data gradient
+          "fuse_upsample_bwd": os.environ.get("RIDERS_FUSE_UPSAMPLE_BWD", "1") != "0",     # A/B switch of the 2x2-summing data gradient
+          "fuse_grad_add": os.environ.get("RIDERS_FUSE_GRAD_ADD", "1") != "0"}     # A/B switch: second gradient contribution added in the data-gradient epilogue
 
 
 def set_roi_tile_min_blocks(n):
@@ -801,6 +802,16 @@ def conv_block(x, weight, *, x2=None, bias=None, stride=1, pad=None, up=None, bn
                 return
             dxv1 = torch.empty((N, Hin, Win, C1), dtype=x.dtype, device=x.device)
             dxv2 = torch.empty((N, Hin, Win, C2), dtype=x.dtype, device=x.device) if C2 else None
+            # x already holds a gradient contribution (a skip connection's decoder side, a residual shortcut): the kernel adds it in its
+            # epilogue and the sum replaces it -- no second tensor, no separate add pass
+            cur = t.grads.get(id(x)) if (C2 == 0 and not is_up and _state.get("fuse_grad_add", True) and id(x) in t.req) else None
+            if cur is not None and cur.shape == dxv1.shape and cur.dtype == dxv1.dtype and cur.is_contiguous() \
+                    and lib.rd_conv_add_ok(ctypes.byref(dd)):
+                _chk(_timed("conv_gemm", flops, lambda: lib.rd_conv_fwd_add(ctypes.byref(dd), _p(dy), None, _p(wpd), None, _p(cur), _p(dxv1), st),
+                            "dgrad " + shp + " (+grad)", b_out + b_w + 2 * N * Hin * Win * Cin * es,
+                            kernel=lambda: lib.rd_conv_fwd_kernel_name(ctypes.byref(dd)).decode(), idem=True), "rd_conv_fwd_add(dgrad)")
+                t.grads[id(x)] = dxv1
+                return
             _chk(_timed("conv_gemm", flops, lambda: lib.rd_conv_fwd(ctypes.byref(dd), _p(dy), None, _p(wpd), None, _p(dxv1), _p(dxv2),
                                                                        None, st), "dgrad " + shp, b_out + b_w + N * Hin * Win * Cin * es,
                         kernel=lambda: lib.rd_conv_fwd_kernel_name(ctypes.byref(dd)).decode(), idem=True), "rd_conv_fwd(dgrad)")

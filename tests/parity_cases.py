@@ -185,6 +185,59 @@ def upsample_fused_dgrad_cases(dev):
         engine._state["fuse_upsample_bwd"] = old
 
 
+def _two_consumer_case(dev, cin, cout, k, s, H, W, N, half=torch.bfloat16):
+    """x feeds TWO convolutions: its gradient is the sum of two data gradients.  bf16 on integer data, exact against autograd; returns the
+    number of `grad add` passes the engine launched (0 when the second data gradient took the first as its addend)."""
+    from riders_amd import engine
+    rs = np.random.RandomState(cin * 7 + cout * 3 + k + H)
+    w1 = torch.nn.Parameter(t(rs.randint(-1, 2, (cout, cin, k, k)).astype(np.float32), dev))
+    w2 = torch.nn.Parameter(t(rs.randint(-1, 2, (cout, cin, k, k)).astype(np.float32), dev))
+    x = t(rs.randint(-1, 2, (N, cin, H, W)).astype(np.float32))
+    xr = x.clone().requires_grad_()
+    r1 = F.conv2d(xr, w1.detach().cpu(), None, stride=s, padding=k // 2)
+    r2 = F.conv2d(xr, w2.detach().cpu(), None, stride=s, padding=k // 2)
+    g1 = t(rs.randint(-1, 2, tuple(r1.shape)).astype(np.float32)); g2 = t(rs.randint(-1, 2, tuple(r2.shape)).astype(np.float32))
+    ((r1 * g1).sum() + (r2 * g2).sum()).backward()
+    a = x.to(dev).permute(0, 2, 3, 1).contiguous().to(half)
+    lib = engine.L()
+    orig, calls = lib.rd_add, []
+    lib.rd_add = lambda *args: (calls.append(1), orig(*args))[1]      # count the separate add passes
+    try:
+        tape = engine.Tape(); tape.mark(a)
+        with engine._active(tape):
+            o1 = engine.conv_block(a, w1, stride=s, pad=k // 2)
+            o2 = engine.conv_block(a, w2, stride=s, pad=k // 2)
+            tape.grads[id(o1)] = g1.to(dev).permute(0, 2, 3, 1).contiguous().to(half)
+            tape.grads[id(o2)] = g2.to(dev).permute(0, 2, 3, 1).contiguous().to(half)
+            tape.backward()
+    finally:
+        lib.rd_add = orig
+    assert torch.equal(tape.grads[id(a)].float().permute(0, 3, 1, 2).cpu(), xr.grad), "gradient of a two-consumer tensor differs"
+    return len(calls)
+
+
+def grad_add_cases(dev):
+    """rd_conv_fwd_add: a tensor's earlier gradient contribution is the addend of the second consumer's data gradient (register-fed 3x3,
+    patch-staged 3x3, implicit GEMM with stride 2 and 1x1, direct 1x1); the narrow-layer kernel and the switch-off path keep the separate
+    add pass.  Integer data: every variant must be exact, and the add pass must be gone exactly where the kernel supports the addend."""
+    from riders_amd import engine
+    with force_frag_conv():
+        assert _two_consumer_case(dev, cin=64, cout=64, k=3, s=1, H=9, W=19, N=1) == 0
+        assert _two_consumer_case(dev, cin=128, cout=64, k=3, s=1, H=15, W=6, N=3) == 0       # linear tiles, ragged
+    with force_patch_conv():
+        assert _two_consumer_case(dev, cin=48, cout=40, k=3, s=1, H=9, W=17, N=2) == 0       # patch-staged kernel (data gradient: 48 channels)
+        assert _two_consumer_case(dev, cin=16, cout=16, k=3, s=1, H=12, W=10, N=2) == 1       # narrow-layer kernel: no addend, one add pass
+    assert _two_consumer_case(dev, cin=64, cout=128, k=3, s=2, H=10, W=14, N=2) == 0         # implicit GEMM, dilated gather
+    assert _two_consumer_case(dev, cin=136, cout=24, k=1, s=1, H=7, W=9, N=2) == 0            # implicit GEMM, 1x1
+    old = engine._state["fuse_grad_add"]
+    engine._state["fuse_grad_add"] = False
+    try:
+        with force_frag_conv():
+            assert _two_consumer_case(dev, cin=64, cout=64, k=3, s=1, H=9, W=19, N=1) == 1
+    finally:
+        engine._state["fuse_grad_add"] = old
+
+
 def frag_conv_cases(dev, quick=False):
     """The register-fed 3x3 kernel in every block shape and both tile forms: fp32 against the oracle, then bf16 on integer data, exact
     (forward + both gradients), with the up-sampling / concatenating gather and the dual-destination data gradient.  quick: the subset the

@@ -41,6 +41,10 @@ def test_upsample_fused_dgrad(emu):
     P.upsample_fused_dgrad_cases(emu)
 
 
+def test_grad_add_in_data_gradient_epilogue(emu):
+    P.grad_add_cases(emu)
+
+
 def test_frag_conv(emu):
     P.frag_conv_cases(emu, quick=True)
 

@@ -45,6 +45,10 @@ def test_upsample_fused_dgrad(gpu):
     P.bf16_exact_conv_case(gpu, cin=64, cout=32, k=3, s=1, N=24, up=((60, 25), (120, 50)))
 
 
+def test_grad_add_in_data_gradient_epilogue(gpu):
+    P.grad_add_cases(gpu)
+
+
 def test_frag_conv(gpu):
     P.frag_conv_cases(gpu)
     # RC-Net sizes, routed by block count (no hooks): RoI maps as pixel runs across images, encoder maps as 2-D tiles
