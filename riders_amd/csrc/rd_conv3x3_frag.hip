@@ -275,6 +275,9 @@ static bool frag_plan(const ConvArgs& a, int dtype, FragPlan& p) {
   // seventeen RC-Net shapes of tools/bench_conv.py -- four 128-pixel waves for one-chunk layers (64 -> 128 data gradient: 0.066 vs 0.069)
   const bool multi = Cin > cke;
   p.variant = a.Cout > 64 ? frag_env("RD_FRAG_V128", multi ? 1 : 0) : (a.Cout > 32 ? frag_env("RD_FRAG_V64", 2) : frag_env("RD_FRAG_V32", 5));
+  // fewer 128 x 128 blocks than CUs (the deep encoder stages: 76 and 20 tiles): 64-channel blocks double the grid
+  if (a.Cout > 64 && !getenv("RD_FRAG_V128") && frag_env("RD_FRAG_SPLIT", 1) &&
+      cdiv((int64_t)a.M, 128) * cdiv(a.Cout, 128) < frag_env("RD_FRAG_SPLIT_BLOCKS", 256)) p.variant = 2;
   const FragVariant& v = kFragVariants[p.variant];
   p.tp = v.tp; p.bn = v.bn; p.nw = v.nw;
   p.ncb = (int)cdiv(a.Cout, p.bn);
