@@ -233,9 +233,9 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs a) {
 // wave's fragment of one (chunk, tap, row tile, k half) is one contiguous 1-KiB load.  rd_conv_packed_elems sizes the buffer for both.
 __host__ __device__ __forceinline__ bool pack_has_frag(int KH, int KW, int C, int dtype) { return KH == 3 && KW == 3 && (C % (dtype == 0 ? 32 : 64)) == 0; }
 template <typename T>
-__device__ __forceinline__ int64_t pack_frag_index(int row, int k, int C, int rows_pad) {
+__device__ __forceinline__ int64_t pack_frag_index(int row, int k, int C, int rows_pad, int tap_ = -1, int c_ = 0) {
   constexpr int VE = Elem<T>::VE, CKE = 8 * VE;
-  const int tap = k / C, c = k - tap * C;
+  const int tap = tap_ >= 0 ? tap_ : k / C, c = tap_ >= 0 ? c_ : k - tap * C;
   const int chunk = c / CKE, kk = c - chunk * CKE, kh = kk / (4 * VE), kg = (kk % (4 * VE)) / VE, e = kk % VE;
   return ((((int64_t)(chunk * 9 + tap) * (rows_pad >> 4) + (row >> 4)) * 2 + kh) * 64 + kg * 16 + (row & 15)) * VE + e;
 }
@@ -273,17 +273,27 @@ __device__ __forceinline__ void pack_one(const PackItem& it, int bx, int nbx) {
   const int64_t total = (int64_t)rows_pad * Kpad;
   const bool frag = pack_has_frag(it.KH, it.KW, C, sizeof(T) == 4 ? 0 : 1);
   T* out = (T*)it.out;
-  for (int64_t i = (int64_t)bx * 256 + threadIdx.x; i < total; i += (int64_t)nbx * 256) {
-    int row = (int)(i / Kpad), k = (int)(i - (int64_t)row * Kpad);
+  // (row, k) advance with the element index instead of being divided out of it, and k -> (tap, channel) goes through a rounded float
+  // reciprocal (k < 2^22): 93 -> 70 us per RC-Net step.  (The SML step's 210 us are the strided OIHW reads -- one cache line per four
+  // useful bytes; a source-tiled LDS transpose was measured at 183 us there and 105-128 us on RC-Net's many small operands: not kept.)
+  const int64_t stride = (int64_t)nbx * 256;
+  const int srow = (int)(stride / Kpad), sk = (int)(stride - (int64_t)srow * Kpad);
+  const float rC = 1.0f / (float)C, rKW = 1.0f / (float)it.KW;
+  const int cs = it.CinSrc > 0 ? it.CinSrc : it.Cin;
+  int64_t i = (int64_t)bx * 256 + threadIdx.x;
+  int row = (int)(i / Kpad), k = (int)(i - (int64_t)row * Kpad);
+  for (; i < total; i += stride) {
     float v = 0.f;
+    int c, kw;
+    const int tap = fdiv_small(k, C, rC, c), kh = fdiv_small(tap, it.KW, rKW, kw);
     if (row < rows && k < K) {
-      int tap = k / C, c = k - tap * C, kh = tap / it.KW, kw = tap - kh * it.KW;
-      const int cs = it.CinSrc > 0 ? it.CinSrc : it.Cin;
       if (it.mode == 0) v = c < cs ? it.w[(((int64_t)row * cs + c) * it.KH + kh) * it.KW + kw] : 0.f;
       else v = it.w[(((int64_t)c * it.Cin + row) * it.KH + (it.KH - 1 - kh)) * it.KW + (it.KW - 1 - kw)];
     }
     Elem<T>::st(&out[i], v);
-    if (frag) Elem<T>::st(&out[total + pack_frag_index<T>(row, k, C, rows_pad)], v);
+    if (frag) Elem<T>::st(&out[total + pack_frag_index<T>(row, k, C, rows_pad, tap, c)], v);
+    row += srow; k += sk;
+    if (k >= Kpad) { k -= Kpad; row++; }
   }
 }
 __global__ __launch_bounds__(256) void pack_weights_batch_kernel(const PackItem* __restrict__ items) {

@@ -1108,12 +1108,14 @@ def pack_batch_case(dev):
     engine.clear_caches()
     rs = np.random.RandomState(7)
     ws = [torch.nn.Parameter(t(rs.randn(*shp).astype(np.float32), dev))
-          for shp in [(16, 16, 3, 3), (1, 16, 3, 3), (32, 3, 7, 7), (128, 64, 1, 1), (40, 24, 3, 3), (256, 128)]]
+          for shp in [(16, 16, 3, 3), (1, 16, 3, 3), (32, 3, 7, 7), (128, 64, 1, 1), (40, 24, 3, 3), (256, 128),
+                      (160, 128, 3, 3), (64, 64, 3, 3), (24, 40, 5, 5), (72, 136, 1, 1)]]      # fragment-ordered copies, several source tiles
     bufs = []
     for dt in (engine.RD_F32, engine.RD_BF16):
         for w in ws:
             for mode in (0, 1):
                 bufs.append(engine.packed_weight(w, mode, dt))
+        bufs.append(engine.packed_weight(ws[2], 0, dt, 8))      # 3-channel stem zero-padded to one 16-byte vector
     want = [b.clone() for b in bufs]
     for b in bufs:
         b.zero_()
