@@ -112,6 +112,9 @@ __global__ __launch_bounds__(256) void dwconv_wgrad_kernel(const T* __restrict__
 // branch + one s_waitcnt per load, i.e. 40 serialised memory latencies per unit; without them a row's (or a unit's) loads issue together.
 // Block geometry: QB quads x PL pixel lanes <= 256 threads with QB = ceil(C/4 / nchunk) chosen for the fewest idle threads (C/4 is
 // 36..348 in EfficientNet-Lite3: a power-of-two QB idled up to 44 % of the lanes).
+#ifndef RD_DW_ST_MODE      // forward statistics epilogue: 1 = every pixel lane sums one of the quad's eight statistics (0.58 -> 0.53 ms per SML step of
+#define RD_DW_ST_MODE 1    // depthwise forwards; tools/bench_dw.py with BD_STATS=1), 0 = lane 0 sums all eight serially, 2 = probe without the reduction (0.46)
+#endif
 static constexpr int DWR = 4;
 // The tap products are explicit fmaf(): the library is built with -ffp-contract=off (emulator and GPU round alike), which turned the 400
 // multiply-adds of a 5x5 unit into 208 v_pk_mul_f32 + 254 v_pk_add_f32; fused they are ~200 v_pk_fma_f32 (the host emulator's fmaf is the
@@ -224,6 +227,7 @@ __global__ __launch_bounds__(256) RD_WAVES_PER_EU((ST && S == 1) ? 2 : 1) void d
   }
   if (ST) {      // pixel lanes of the block summed in a fixed order
     __syncthreads();
+#if RD_DW_ST_MODE == 0
     if (active && pl == 0) {
 #pragma unroll
       for (int e = 0; e < 4; e++) {
@@ -233,6 +237,24 @@ __global__ __launch_bounds__(256) RD_WAVES_PER_EU((ST && S == 1) ? 2 : 1) void d
         stats[((int64_t)blockIdx.x * C + c + e) * 2 + 1] = b;
       }
     }
+#elif RD_DW_ST_MODE == 1
+    // pixel lane pl sums statistic e8 = pl (, pl + PL, ...) of its quad over all lanes, four LDS reads in flight, same order of additions
+    if (active) {
+      for (int e8 = pl; e8 < 8; e8 += PL) {
+        float a = 0.f;
+        for (int q0 = 0; q0 < PL; q0 += 4) {
+          float v[4];
+#pragma unroll
+          for (int u = 0; u < 4; u++) v[u] = red[(min(q0 + u, PL - 1) * QB + cl) * 8 + e8];
+#pragma unroll
+          for (int u = 0; u < 4; u++) if (q0 + u < PL) a += v[u];
+        }
+        stats[((int64_t)blockIdx.x * C + c + (e8 & 3)) * 2 + (e8 >> 2)] = a;
+      }
+    }
+#else
+    if (active && pl == 0 && red[t * 8] == 12345.f) stats[0] = 1.f;      // probe: no reduction
+#endif
   }
 }
 

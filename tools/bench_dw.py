@@ -63,7 +63,12 @@ for (C, k, s, H, W), mult in shapes().items():
     rows = lib.rd_dw_rows(B * OH * OW, C)
     part = torch.empty((rows, C, k * k), dtype=torch.float32, device=dev)
     st = _stream(x)
-    f = timeit(lambda: lib.rd_dwconv_fwd(_p(x), _p(w), _p(y), B, H, W, C, OH, OW, k, s, pt, dt, st))
+    srows = lib.rd_dwconv_stats_rows(B, OH, OW, C, k, s) if os.environ.get("BD_STATS") else 0      # BD_STATS=1: the forward the model runs (fused BatchNorm statistics)
+    if srows > 0:
+        stats = torch.empty((srows, C, 2), dtype=torch.float32, device=dev)
+        f = timeit(lambda: lib.rd_dwconv_fwd_stats(_p(x), _p(w), _p(y), _p(stats), B, H, W, C, OH, OW, k, s, pt, dt, st))
+    else:
+        f = timeit(lambda: lib.rd_dwconv_fwd(_p(x), _p(w), _p(y), B, H, W, C, OH, OW, k, s, pt, dt, st))
     g = timeit(lambda: lib.rd_dwconv_dgrad(_p(dy), _p(w), _p(dx), B, H, W, C, OH, OW, k, s, pt, dt, st))
     wg = timeit(lambda: lib.rd_dwconv_wgrad(_p(x), _p(dy), _p(part), _p(dw), 0, B, H, W, C, OH, OW, k, s, pt, dt, st))
     ideal = (x.numel() + y.numel()) * es / 6.0e6      # us at ~6 TB/s attainable
