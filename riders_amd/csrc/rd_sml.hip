@@ -246,8 +246,16 @@ __global__ __launch_bounds__(256) void max_partial_kernel(const float* __restric
 }
 __global__ __launch_bounds__(256) void outlier_removal_kernel(const float* __restrict__ depth, const float* __restrict__ partial, int nparts,
                                                               float* __restrict__ out, int N, int H, int W, int k, float thr) {
+  // the maximum over the partials, by the block (a max is order independent): every thread walking all <= 256 partials on its own was
+  // most of this kernel's 55 us
+  __shared__ float smx[4];
   float mx = -INFINITY;
-  for (int i = 0; i < nparts; i++) mx = fmaxf(mx, partial[i]);
+  for (int i = threadIdx.x; i < nparts; i += 256) mx = fmaxf(mx, partial[i]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+  if ((threadIdx.x & 63) == 0) smx[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(smx[0], smx[1]), fmaxf(smx[2], smx[3]));
   const float fill = 10.f * mx;
   const int r = k / 2;
   const int64_t total = (int64_t)N * H * W;
@@ -373,8 +381,47 @@ __global__ __launch_bounds__(256) void sml_loss_bwd_kernel(const float* __restri
   const float gl = dloss[0];
   const float c_sup = 1.f / info[5], c_lid = w_lidar > 0.f ? w_lidar / info[6] : 0.f;
   const float c_sm = w_smooth / ((float)total * (float)(fs * fs));
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    int w = (int)(i % W); int64_t q = i / W; int h = (int)(q % H); int n = (int)(q / H);
+  const int64_t gstride = (int64_t)gridDim.x * blockDim.x, gtid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  // Interior pixels (no padded position clamps onto them, every tap lies inside the map) take a path without clamps, masks or 64-bit
+  // index arithmetic per tap -- the same products in the same order; the 2r-wide frame goes through the general gather below, compacted
+  // into its own waves (as one loop over all pixels the general form cost 193 us per SML step: ~20 vector instructions per tap).
+  const int Hi = H - 2 * r, Wi = W - 2 * r;
+  const bool split = FS > 0 && Hi > 0 && Wi > 0 && w_smooth > 0.f;
+  if (split) {
+    const int64_t nint = (int64_t)N * Hi * Wi;
+    for (int64_t j = gtid; j < nint; j += gstride) {
+      const int wi = (int)(j % Wi); const int64_t q = j / Wi; const int hi = (int)(q % Hi); const int n = (int)(q / Hi);
+      const int64_t i = ((int64_t)n * H + hi + r) * W + wi + r;
+      float o = pred[i], gs = gt_sparse[i], gi = gt_interp[i];
+      if (mask_interp && gs > 0.f) gi = 0.f;
+      float g = 0.f;
+      if (gi > 0.f) g += c_sup * sgn(o - gi);
+      if (gs > 0.f) g += c_lid * sgn(o - gs);
+      const float* FX = gfx + i + (int64_t)r * W + r; const float* FY = gfy + i + (int64_t)r * W + r;      // tap (u, v) reads (h - u + r, w - v + r)
+      float s = 0.f;
+#pragma unroll
+      for (int u = 0; u < fs; u++) {
+        const float* rx = FX - u * W; const float* ry = FY - u * W;      // one pointer per filter row, the column is an immediate offset
+#pragma unroll
+        for (int v = 0; v < fs; v++) {
+          const float fx = rx[-v], fy = ry[-v];
+          s += fx * sobel_gx(u, v, fs) + fy * sobel_gy(u, v, fs);
+        }
+      }
+      g += c_sm * s;
+      dpred[i] = gl * g;
+    }
+  }
+  const int64_t E = split ? (int64_t)2 * r * W + (int64_t)Hi * 2 * r : (int64_t)H * W;      // frame pixels per image (all of them when not split)
+  for (int64_t e = gtid; e < (int64_t)N * E; e += gstride) {
+    int n = (int)(e / E), h, w;
+    {
+      const int64_t ei = e - (int64_t)n * E;
+      if (!split) { h = (int)(ei / W); w = (int)(ei - (int64_t)h * W); }
+      else if (ei < (int64_t)2 * r * W) { const int row = (int)(ei / W); h = row < r ? row : H - 2 * r + row; w = (int)(ei - (int64_t)row * W); }
+      else { const int64_t e2 = ei - (int64_t)2 * r * W; const int cc = (int)(e2 % (2 * r)); h = (int)(e2 / (2 * r)) + r; w = cc < r ? cc : W - 2 * r + cc; }
+    }
+    const int64_t i = ((int64_t)n * H + h) * W + w;
     float o = pred[i], gs = gt_sparse[i], gi = gt_interp[i];
     if (mask_interp && gs > 0.f) gi = 0.f;
     float g = 0.f;
