@@ -184,6 +184,12 @@ int rd_act_bwd(const void* dz, const void* z, void* dx, int64_t n, int32_t act, 
 int32_t rd_colsum_rows(int64_t rows, int32_t C);
 int rd_colsum(const void* x, float* partial, float* out, int32_t accumulate, int64_t rows, int32_t C, int32_t dtype,
               void* stream);
+/* the same in two steps for MANY layers: rd_colsum_partial writes a layer's partial rows ([rd_colsum_rows][C][2] floats); one
+ * rd_colsum_finalize_batch launch then finishes every pending bias gradient (items is a HOST array, passed by value to the kernel) with
+ * the summation order of rd_colsum.  Two items of one batch must not name the same `out`. */
+typedef struct rd_colsum_item { const float* partial; float* out; int32_t rows, C, accumulate, reserved; } rd_colsum_item;
+int rd_colsum_partial(const void* x, float* partial, int64_t rows, int32_t C, int32_t dtype, void* stream);
+int rd_colsum_finalize_batch(const rd_colsum_item* items, int32_t n, void* stream);
 
 /* ---- LayerNorm -- RCNet/linear_attention.py:106-107,125,131-133 (norm1/norm2, x + message) -------- */
 int rd_layernorm_fwd(const void* x, const float* gamma, const float* beta, const void* residual, void* out,

@@ -320,6 +320,20 @@ int rd_colsum(const void* x, float* partial, float* out, int32_t accumulate, int
   RD_NS(dtype, launch_colsum)(x, partial, out, accumulate, rows, C, RD_DT(dtype), S(stream));
   return done("rd_colsum");
 }
+static_assert(sizeof(rd_colsum_item) == sizeof(rdt::ColsumItem), "rd_colsum_item layout");
+int rd_colsum_partial(const void* x, float* partial, int64_t rows, int32_t C, int32_t dtype, void* stream) {
+  if (!x || !partial || !dt_ok(dtype)) return fail("colsum_partial: bad args");
+  RD_NS(dtype, launch_colsum)(x, partial, nullptr, 0, rows, C, RD_DT(dtype), S(stream));
+  return done("rd_colsum_partial");
+}
+int rd_colsum_finalize_batch(const rd_colsum_item* items, int32_t n, void* stream) {
+  if (n <= 0) return 0;
+  if (!items) return fail("colsum_finalize_batch: bad args");
+  for (int i = 0; i < n; i++)
+    if (!items[i].partial || !items[i].out || items[i].rows <= 0 || items[i].C <= 0) return fail("colsum_finalize_batch: bad item");
+  rd::launch_colsum_finalize_batch(reinterpret_cast<const rdt::ColsumItem*>(items), n, S(stream));
+  return done("rd_colsum_finalize_batch");
+}
 
 int rd_layernorm_fwd(const void* x, const float* gamma, const float* beta, const void* residual, void* out, float* mean,
                      float* rstd, int64_t rows, int32_t C, float eps, int32_t dtype, void* stream) {

@@ -720,6 +720,30 @@ void launch_act_bwd(const void* dz, const void* z, void* dx, int64_t n, int act,
   else hipLaunchKernelGGL((act_bwd_kernel<bf16_t>), dim3(ew_grid(n)), dim3(256), 0, st, (const bf16_t*)dz, (const bf16_t*)z, (bf16_t*)dx, n, act, slope);
 }
 
+// many bias gradients finished by ONE launch: item i sums its partial rows exactly as colsum_finalize_kernel does (lanes stride the rows,
+// double precision, xor tree).  SML's decoder has 22 biased convolutions per step: 22 finalize launches of 6 us each for a few KB of sums.
+struct ColsumBatch { ColsumItem it[COLSUM_BATCH_MAX]; };
+__global__ __launch_bounds__(64) void colsum_finalize_batch_kernel(ColsumBatch b) {
+  const ColsumItem it = b.it[blockIdx.y];
+  const int lane = threadIdx.x;
+  for (int c = blockIdx.x; c < it.C; c += gridDim.x) {
+    double a = 0.0;
+    for (int r = lane; r < it.rows; r += 64) a += it.partial[((int64_t)r * it.C + c) * 2];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) a += __shfl_xor(a, o);
+    if (lane == 0) it.out[c] = it.accumulate ? it.out[c] + (float)a : (float)a;
+  }
+}
+void launch_colsum_finalize_batch(const ColsumItem* items, int n, hipStream_t st) {
+  for (int base = 0; base < n; base += COLSUM_BATCH_MAX) {
+    const int m = std::min(COLSUM_BATCH_MAX, n - base);
+    ColsumBatch b;
+    int maxc = 1;
+    for (int i = 0; i < m; i++) { b.it[i] = items[base + i]; maxc = std::max(maxc, b.it[i].C); }
+    for (int i = m; i < COLSUM_BATCH_MAX; i++) b.it[i] = b.it[0];
+    hipLaunchKernelGGL(colsum_finalize_batch_kernel, dim3((unsigned)std::min(maxc, 512), (unsigned)m), dim3(64), 0, st, b);
+  }
+}
 void launch_colsum(const void* x, float* partial, float* out, int accumulate, int64_t rows, int C, int dtype, hipStream_t st) {
   RedGeom g = red_geom(C);
   int nr = red_rows(rows, C);
@@ -734,7 +758,7 @@ void launch_colsum(const void* x, float* partial, float* out, int accumulate, in
     hipLaunchKernelGGL((col_reduce_kernel<float, 1>), grid, dim3(256), 0, st, (const float*)x, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, partial, rows, C, g.CB, g.PL, 0, 0.f);
   else
     hipLaunchKernelGGL((col_reduce_kernel<bf16_t, 1>), grid, dim3(256), 0, st, (const bf16_t*)x, (const bf16_t*)nullptr, (const bf16_t*)nullptr, (const float*)nullptr, (const float*)nullptr, partial, rows, C, g.CB, g.PL, 0, 0.f);
-  hipLaunchKernelGGL(colsum_finalize_kernel, dim3((unsigned)C), dim3(64), 0, st, partial, nr, C, out, accumulate);
+  if (out) hipLaunchKernelGGL(colsum_finalize_kernel, dim3((unsigned)C), dim3(64), 0, st, partial, nr, C, out, accumulate);      // out == nullptr: partial rows only
 }
 
 void launch_layernorm_fwd(const void* x, const float* gamma, const float* beta, const void* res, void* out, float* mean,

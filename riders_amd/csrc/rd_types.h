@@ -32,6 +32,9 @@ struct WgradReduceItem { const float* slab; float* dw; int Cout, Cin, KH, KW, ns
 static const int WGRAD_BATCH_MAX = 48;      // 48 x (40 + 4 + 4) B + 8 B: under the 4 KiB kernel-argument limit
 struct WgradReduceBatch { WgradReduceItem item[WGRAD_BATCH_MAX]; int SL[WGRAD_BATCH_MAX]; int first[WGRAD_BATCH_MAX + 1]; int n; };
 
+struct ColsumItem { const float* partial; float* out; int rows, C, accumulate, reserved; };      // mirrors rd_colsum_item
+static const int COLSUM_BATCH_MAX = 64;      // 64 x 32 B by value in the kernel arguments
+
 static const int LWG_MAX_ITEMS = 64, LWG_MAX_REDS = 96;   // 64 x 56 B and 96 x 32 B: both under the 4 KiB kernel-argument limit
 
 struct LoftrW { const void *wq, *wk, *wv, *wm, *w0, *w2; const float *g1, *b1, *g2, *b2; };

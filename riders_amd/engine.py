@@ -189,6 +189,7 @@ class Tape:
         self.deferred = []      # weight gradients of 1x1 / linear layers, issued as ONE grouped launch at the end of backward()
         self.conv_reduce = []   # (rd_wgrad_reduce_item, workspace) of convolution weight gradients whose split-K slabs are written:
         self.conv_reduce_w = set()   # ... summed by ONE rd_wgrad_reduce_batch launch per backward stage; ids of their weights
+        self.colsum = []        # (rd_colsum_item, partial rows tensor, bias id): bias gradients finished by one launch per backward stage
 
     def requires(self, *ts):
         return any(t is not None and id(t) in self.req for t in ts)
@@ -267,6 +268,7 @@ class Tape:
 
     def flush_conv_reduce(self):
         """One launch sums the split-K slabs of every convolution weight gradient produced since the last flush (rd_wgrad_reduce_batch)."""
+        self.flush_colsum()
         pending, self.conv_reduce, self.conv_reduce_w = self.conv_reduce, [], set()
         if not pending:
             return
@@ -275,6 +277,17 @@ class Tape:
         nbytes = sum(ws.numel() * 4 for _, ws in pending)
         _chk(_tb("conv_wgrad", nbytes, lambda: L().rd_wgrad_reduce_batch(arr, len(pending), _stream(ws0)), "wgrad slab reduce batch n=%d" % len(pending)),
              "rd_wgrad_reduce_batch")
+
+    def flush_colsum(self):
+        """One launch finishes every pending bias gradient (rd_colsum_finalize_batch)."""
+        pending, self.colsum = self.colsum, []
+        if not pending:
+            return
+        arr = (_lib.ColsumItem * len(pending))(*[it for it, _, _ in pending])
+        part0 = pending[0][1]
+        _chk(_tb("elementwise", sum(p_.numel() * 4 for _, p_, _ in pending),
+                 lambda: L().rd_colsum_finalize_batch(arr, len(pending), _stream(part0)), "bias gradient finalize batch n=%d" % len(pending)),
+             "rd_colsum_finalize_batch")
 
     def _flush_items(self, items):
         lib = L()
@@ -752,7 +765,13 @@ def conv_block(x, weight, *, x2=None, bias=None, stride=1, pad=None, up=None, bn
             db, acc = t.param_grad(bias)
             rows = lib.rd_colsum_rows(pixels, Cout)
             part = torch.empty((rows, Cout, 2), dtype=torch.float32, device=x.device)
-            _chk(lib.rd_colsum(_p(dy), _p(part), _p(db), acc, pixels, Cout, dt, st), "rd_colsum")
+            if _state["defer_wgrad"]:      # partial rows now, every layer's final sums in one launch at the next stage mark
+                if any(b_ == id(bias) for _, _, b_ in t.colsum):      # a bias used twice: its two sums must not share a launch
+                    t.flush_colsum()
+                _chk(lib.rd_colsum_partial(_p(dy), _p(part), pixels, Cout, dt, st), "rd_colsum_partial")
+                t.colsum.append((_lib.ColsumItem(part.data_ptr(), db.data_ptr(), rows, Cout, acc, 0), part, id(bias)))
+            else:
+                _chk(lib.rd_colsum(_p(dy), _p(part), _p(db), acc, pixels, Cout, dt, st), "rd_colsum")
         ve = 16 // es
         if w_req and KH == 1 and KW == 1 and stride == 1 and not is_up and _state["defer_wgrad"] and C1 % ve == 0 and Cout % ve == 0 \
                 and (C2 == 0 or (C1 % 64 == 0 and C2 % ve == 0)):
