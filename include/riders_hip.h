@@ -339,6 +339,15 @@ int rd_dwconv_dgrad(const void* dy, const float* w, void* dx, int32_t N, int32_t
                     int32_t s, int32_t p, int32_t dtype, void* stream);
 int rd_dwconv_wgrad(const void* x, const void* dy, float* partial, float* dw, int32_t accumulate, int32_t N, int32_t H, int32_t W,
                     int32_t C, int32_t OH, int32_t OW, int32_t k, int32_t s, int32_t p, int32_t dtype, void* stream);
+/* the same in two steps for MANY layers (EfficientNet-Lite3 has 27 depthwise layers): rd_dwconv_wgrad_partial leaves the layer's partial
+ * rows and fills *item (item->rows = 0: the gradient was finished at once -- channel counts off the vector path); one
+ * rd_dw_wgrad_finalize_batch launch then finishes every pending item (HOST array, passed by value) with the summation order of
+ * rd_dwconv_wgrad.  Two items of one batch must not name the same dw. */
+typedef struct rd_dw_wgrad_item { const float* partial; float* dw; int32_t rows, C, KK, accumulate; } rd_dw_wgrad_item;
+int rd_dwconv_wgrad_partial(const void* x, const void* dy, float* partial, float* dw, int32_t accumulate, int32_t N, int32_t H, int32_t W,
+                            int32_t C, int32_t OH, int32_t OW, int32_t k, int32_t s, int32_t p, int32_t dtype, rd_dw_wgrad_item* item,
+                            void* stream);
+int rd_dw_wgrad_finalize_batch(const rd_dw_wgrad_item* items, int32_t n, void* stream);
 /* BatchNorm (sum, sum^2) partials [rd_dw_rows][C][2] for producers without a fused statistics epilogue */
 int rd_bn_stats(const void* y, float* partial, int64_t pixels, int32_t C, int32_t dtype, void* stream);
 /* modules/midas/blocks.py:168-170 (align_corners=1) and :187 nn.Upsample (align_corners=0) */

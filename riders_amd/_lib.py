@@ -57,6 +57,11 @@ class WgradReduceItem(ctypes.Structure):
                 ("KH", ctypes.c_int32), ("KW", ctypes.c_int32), ("nsplit", ctypes.c_int32), ("accumulate", ctypes.c_int32)]
 
 
+class DwWgradItem(ctypes.Structure):
+    _fields_ = [("partial", ctypes.c_void_p), ("dw", ctypes.c_void_p), ("rows", ctypes.c_int32), ("C", ctypes.c_int32),
+                ("KK", ctypes.c_int32), ("accumulate", ctypes.c_int32)]
+
+
 class ColsumItem(ctypes.Structure):
     _fields_ = [("partial", ctypes.c_void_p), ("out", ctypes.c_void_p), ("rows", ctypes.c_int32), ("C", ctypes.c_int32),
                 ("accumulate", ctypes.c_int32), ("reserved", ctypes.c_int32)]

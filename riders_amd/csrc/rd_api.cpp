@@ -655,8 +655,25 @@ int rd_dwconv_dgrad(const void* dy, const float* w, void* dx, int32_t N, int32_t
 int rd_dwconv_wgrad(const void* x, const void* dy, float* partial, float* dw, int32_t accumulate, int32_t N, int32_t H, int32_t W, int32_t C,
                     int32_t OH, int32_t OW, int32_t k, int32_t s, int32_t p, int32_t dtype, void* stream) {
   if (!x || !dy || !partial || !dw || !dt_ok(dtype) || k > 5 || k < 1) return fail("dwconv_wgrad: bad args");
-  RD_NS(dtype, launch_dwconv_wgrad)(x, dy, partial, dw, accumulate, N, H, W, C, OH, OW, k, s, p, RD_DT(dtype), S(stream));
+  RD_NS(dtype, launch_dwconv_wgrad)(x, dy, partial, dw, accumulate, N, H, W, C, OH, OW, k, s, p, RD_DT(dtype), S(stream), nullptr);
   return done("rd_dwconv_wgrad");
+}
+static_assert(sizeof(rd_dw_wgrad_item) == sizeof(rdt::DwWgradItem), "rd_dw_wgrad_item layout");
+int rd_dwconv_wgrad_partial(const void* x, const void* dy, float* partial, float* dw, int32_t accumulate, int32_t N, int32_t H, int32_t W,
+                            int32_t C, int32_t OH, int32_t OW, int32_t k, int32_t s, int32_t p, int32_t dtype, rd_dw_wgrad_item* item,
+                            void* stream) {
+  if (!x || !dy || !partial || !dw || !item || !dt_ok(dtype) || k > 5 || k < 1) return fail("dwconv_wgrad_partial: bad args");
+  RD_NS(dtype, launch_dwconv_wgrad)(x, dy, partial, dw, accumulate, N, H, W, C, OH, OW, k, s, p, RD_DT(dtype), S(stream),
+                                    reinterpret_cast<rdt::DwWgradItem*>(item));
+  return done("rd_dwconv_wgrad_partial");
+}
+int rd_dw_wgrad_finalize_batch(const rd_dw_wgrad_item* items, int32_t n, void* stream) {
+  if (n <= 0) return 0;
+  if (!items) return fail("dw_wgrad_finalize_batch: bad args");
+  for (int i = 0; i < n; i++)
+    if (!items[i].partial || !items[i].dw || items[i].rows <= 0 || items[i].C <= 0 || items[i].KK <= 0) return fail("dw_wgrad_finalize_batch: item not filled by rd_dwconv_wgrad_partial");
+  rd::launch_dw_wgrad_finalize_batch(reinterpret_cast<const rdt::DwWgradItem*>(items), n, S(stream));
+  return done("rd_dw_wgrad_finalize_batch");
 }
 int rd_bn_stats(const void* y, float* partial, int64_t pixels, int32_t C, int32_t dtype, void* stream) {
   if (!y || !partial || !dt_ok(dtype)) return fail("bn_stats: bad args");

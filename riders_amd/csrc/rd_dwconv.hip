@@ -631,8 +631,44 @@ void launch_dwconv_dgrad(const void* dy, const float* w, void* dx, int N, int H,
   if (dtype == 0) hipLaunchKernelGGL((dwconv_dgrad_kernel<float>), dim3(ew_grid(n)), dim3(256), 0, st, (const float*)dy, w, (float*)dx, N, H, W, C, OH, OW, k, s, p);
   else hipLaunchKernelGGL((dwconv_dgrad_kernel<bf16_t>), dim3(ew_grid(n)), dim3(256), 0, st, (const bf16_t*)dy, w, (bf16_t*)dx, N, H, W, C, OH, OW, k, s, p);
 }
+// many depthwise weight gradients finished by ONE launch (item i exactly as dw_wgrad_finalize_tc_kernel: 64 elements x 4 row groups per block)
+struct DwWgradBatch { DwWgradItem it[DW_WGRAD_BATCH_MAX]; };
+__global__ __launch_bounds__(256) void dw_wgrad_finalize_batch_kernel(DwWgradBatch b) {
+  __shared__ double red[4][64];
+  const DwWgradItem it = b.it[blockIdx.y];
+  const int e = threadIdx.x & 63, rg = threadIdx.x >> 6;
+  const int CK = it.C * it.KK;
+  for (int base = blockIdx.x * 64; base < CK; base += gridDim.x * 64) {      // (uniform per block)
+    const int i = base + e;
+    double a = 0.0;
+    if (i < CK)
+      for (int r = rg; r < it.rows; r += 4) a += it.partial[(int64_t)r * CK + i];
+    red[rg][e] = a;
+    __syncthreads();
+    if (rg == 0 && i < CK) {
+      a = red[0][e] + red[1][e] + red[2][e] + red[3][e];
+      const int j = i / it.C, c = i - j * it.C;
+      const int o = c * it.KK + j;
+      it.dw[o] = it.accumulate ? it.dw[o] + (float)a : (float)a;
+    }
+    __syncthreads();
+  }
+}
+void launch_dw_wgrad_finalize_batch(const DwWgradItem* items, int n, hipStream_t st) {
+  for (int base = 0; base < n; base += DW_WGRAD_BATCH_MAX) {
+    const int m = std::min(DW_WGRAD_BATCH_MAX, n - base);
+    DwWgradBatch b;
+    int maxg = 1;
+    for (int i = 0; i < m; i++) { b.it[i] = items[base + i]; maxg = std::max(maxg, (int)cdiv(b.it[i].C * b.it[i].KK, 64)); }
+    for (int i = m; i < DW_WGRAD_BATCH_MAX; i++) b.it[i] = b.it[0];
+    hipLaunchKernelGGL(dw_wgrad_finalize_batch_kernel, dim3((unsigned)std::min(maxg, 1024), (unsigned)m), dim3(256), 0, st, b);
+  }
+}
+// item != nullptr: the vector path leaves its partial rows and fills *item for a later launch_dw_wgrad_finalize_batch (item->rows = 0 when
+// the gradient was finished here: shapes on the scalar path)
 void launch_dwconv_wgrad(const void* x, const void* dy, float* partial, float* dw, int accumulate, int N, int H, int W, int C, int OH,
-                         int OW, int k, int s, int p, int dtype, hipStream_t st) {
+                         int OW, int k, int s, int p, int dtype, hipStream_t st, DwWgradItem* item) {
+  if (item) { item->partial = partial; item->dw = dw; item->rows = 0; item->C = C; item->KK = k * k; item->accumulate = accumulate; }
   const int rows = dw_rows((int64_t)N * OH * OW, C);      // what the caller sized `partial` for
   if (dw_quad_ok(C, k, s)) {
     const QG g = qgeom(C, 256);
@@ -651,6 +687,7 @@ void launch_dwconv_wgrad(const void* x, const void* dy, float* partial, float* d
       else { if (k == 3) RD_DWG(bf16_t, 3, 2); else RD_DWG(bf16_t, 5, 2); }
     }
 #undef RD_DWG
+    if (item) { item->rows = (int)gx; return; }
     hipLaunchKernelGGL(dw_wgrad_finalize_tc_kernel, dim3((unsigned)cdiv(C * k * k, 64)), dim3(256), 0, st, partial, (int)gx, C, k * k, dw, accumulate);
     return;
   }

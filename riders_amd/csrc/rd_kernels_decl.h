@@ -164,7 +164,8 @@ int dw_rows(int64_t pixels, int C);
 int dwconv_stats_rows(int N, int OH, int OW, int C, int k, int s);
 void launch_dwconv_fwd(const void* x, const float* w, void* y, int N, int H, int W, int C, int OH, int OW, int k, int s, int p, int dtype, hipStream_t st, float* stats);
 void launch_dwconv_dgrad(const void* dy, const float* w, void* dx, int N, int H, int W, int C, int OH, int OW, int k, int s, int p, int dtype, hipStream_t st);
-void launch_dwconv_wgrad(const void* x, const void* dy, float* partial, float* dw, int accumulate, int N, int H, int W, int C, int OH, int OW, int k, int s, int p, int dtype, hipStream_t st);
+void launch_dwconv_wgrad(const void* x, const void* dy, float* partial, float* dw, int accumulate, int N, int H, int W, int C, int OH, int OW, int k, int s, int p, int dtype, hipStream_t st, DwWgradItem* item = nullptr);
+void launch_dw_wgrad_finalize_batch(const DwWgradItem* items, int n, hipStream_t st);
 void launch_bn_stats(const void* y, float* partial, int64_t pixels, int C, int dtype, hipStream_t st);
 void launch_bilinear(const void* x, void* y, int N, int H, int W, int C, int OH, int OW, int align, int backward, int dtype, hipStream_t st);
 void launch_sml_head_fwd(const void* out, const float* d, float* pred, int64_t n, float hi, float lo, int dtype, hipStream_t st);

@@ -32,6 +32,8 @@ struct WgradReduceItem { const float* slab; float* dw; int Cout, Cin, KH, KW, ns
 static const int WGRAD_BATCH_MAX = 48;      // 48 x (40 + 4 + 4) B + 8 B: under the 4 KiB kernel-argument limit
 struct WgradReduceBatch { WgradReduceItem item[WGRAD_BATCH_MAX]; int SL[WGRAD_BATCH_MAX]; int first[WGRAD_BATCH_MAX + 1]; int n; };
 
+struct DwWgradItem { const float* partial; float* dw; int rows, C, KK, accumulate; };      // mirrors rd_dw_wgrad_item
+static const int DW_WGRAD_BATCH_MAX = 64;
 struct ColsumItem { const float* partial; float* out; int rows, C, accumulate, reserved; };      // mirrors rd_colsum_item
 static const int COLSUM_BATCH_MAX = 64;      // 64 x 32 B by value in the kernel arguments
 

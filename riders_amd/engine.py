@@ -190,6 +190,7 @@ class Tape:
         self.conv_reduce = []   # (rd_wgrad_reduce_item, workspace) of convolution weight gradients whose split-K slabs are written:
         self.conv_reduce_w = set()   # ... summed by ONE rd_wgrad_reduce_batch launch per backward stage; ids of their weights
         self.colsum = []        # (rd_colsum_item, partial rows tensor, bias id): bias gradients finished by one launch per backward stage
+        self.dw_reduce = []     # (rd_dw_wgrad_item, partial rows tensor, weight id): depthwise weight gradients, likewise
 
     def requires(self, *ts):
         return any(t is not None and id(t) in self.req for t in ts)
@@ -269,6 +270,7 @@ class Tape:
     def flush_conv_reduce(self):
         """One launch sums the split-K slabs of every convolution weight gradient produced since the last flush (rd_wgrad_reduce_batch)."""
         self.flush_colsum()
+        self.flush_dw_reduce()
         pending, self.conv_reduce, self.conv_reduce_w = self.conv_reduce, [], set()
         if not pending:
             return
@@ -277,6 +279,17 @@ class Tape:
         nbytes = sum(ws.numel() * 4 for _, ws in pending)
         _chk(_tb("conv_wgrad", nbytes, lambda: L().rd_wgrad_reduce_batch(arr, len(pending), _stream(ws0)), "wgrad slab reduce batch n=%d" % len(pending)),
              "rd_wgrad_reduce_batch")
+
+    def flush_dw_reduce(self):
+        """One launch finishes every pending depthwise weight gradient (rd_dw_wgrad_finalize_batch)."""
+        pending, self.dw_reduce = self.dw_reduce, []
+        if not pending:
+            return
+        arr = (_lib.DwWgradItem * len(pending))(*[it for it, _, _ in pending])
+        part0 = pending[0][1]
+        _chk(_tb("conv_wgrad", sum(p_.numel() * 4 for _, p_, _ in pending),
+                 lambda: L().rd_dw_wgrad_finalize_batch(arr, len(pending), _stream(part0)), "depthwise wgrad finalize batch n=%d" % len(pending)),
+             "rd_dw_wgrad_finalize_batch")
 
     def flush_colsum(self):
         """One launch finishes every pending bias gradient (rd_colsum_finalize_batch)."""
@@ -1424,7 +1437,16 @@ def dwconv_block(x, weight, *, stride=1, pad=0, out_hw=None, bn=None, act=ACT_NO
             dw, acc = t.param_grad(weight)
             rows = lib.rd_dw_rows(N * OH * OW, C)
             part = torch.empty((rows, C, k * k), dtype=torch.float32, device=x.device)
-            _chk(lib.rd_dwconv_wgrad(_p(x), _p(dy), _p(part), _p(dw), acc, N, H, W, C, OH, OW, k, stride, pad, dt, st), "rd_dwconv_wgrad")
+            if _state["defer_wgrad"]:      # partial rows now, every depthwise layer's final sums in one launch at the next stage mark
+                if any(w_ == id(weight) for _, _, w_ in t.dw_reduce):
+                    t.flush_dw_reduce()
+                item = _lib.DwWgradItem()
+                _chk(lib.rd_dwconv_wgrad_partial(_p(x), _p(dy), _p(part), _p(dw), acc, N, H, W, C, OH, OW, k, stride, pad, dt, ctypes.byref(item), st),
+                     "rd_dwconv_wgrad_partial")
+                if item.rows > 0:
+                    t.dw_reduce.append((item, part, id(weight)))
+            else:
+                _chk(lib.rd_dwconv_wgrad(_p(x), _p(dy), _p(part), _p(dw), acc, N, H, W, C, OH, OW, k, stride, pad, dt, st), "rd_dwconv_wgrad")
         if t.requires(x):
             dx = torch.empty_like(x)
             _chk(lib.rd_dwconv_dgrad(_p(dy), _p(weight.detach()), _p(dx), N, H, W, C, OH, OW, k, stride, pad, dt, st), "rd_dwconv_dgrad")
