@@ -115,8 +115,17 @@ typedef struct rd_loftr_grads {
   const void* dout;
   void *dm2pre, *dhid, *dmpre, *datt, *dq, *dk, *dv, *dx, *dsrc;
   float *lnp1, *lnp2, *dg1, *db1, *dg2, *db2;
-  int32_t accumulate, reserved;
+  int32_t accumulate;
+  int32_t defer_ln;            /* 1: leave the LayerNorm partials lnp1 / lnp2 ([N][128][2] = (dbeta, dgamma) terms per ROI) for rd_ln_grad_batch */
 } rd_loftr_grads;
+/* LayerNorm parameter gradients of many layer applications in ONE launch: an item is one (gamma, beta) pair with the partial buffers
+ * [rows][C][2] of up to four applications (the transformer applies each layer to both token streams: RCNet/linear_attention.py:159-184),
+ * added in the order given, each summed as rd_loftr_layer_bwd's own finalize does.  HOST array, passed by value. */
+typedef struct rd_ln_grad_item {
+  const float* partial[4]; float* dgamma; float* dbeta;
+  int32_t rows[4]; int32_t C, nparts, accumulate, reserved;
+} rd_ln_grad_item;
+int rd_ln_grad_batch(const rd_ln_grad_item* items, int32_t n, void* stream);
 int rd_loftr_layer_fwd(const void* x, const void* src, const rd_loftr_weights* w, void* out, const rd_loftr_saved* saved, int32_t N,
                        int32_t L, int32_t S, float eps_attn, float eps_ln, int32_t dtype, void* stream);
 int rd_loftr_layer_bwd(const void* x, const void* src, const rd_loftr_weights* w_t, const rd_loftr_saved* saved,

@@ -320,6 +320,18 @@ int rd_colsum(const void* x, float* partial, float* out, int32_t accumulate, int
   RD_NS(dtype, launch_colsum)(x, partial, out, accumulate, rows, C, RD_DT(dtype), S(stream));
   return done("rd_colsum");
 }
+static_assert(sizeof(rd_ln_grad_item) == sizeof(rdt::LnGradItem), "rd_ln_grad_item layout");
+int rd_ln_grad_batch(const rd_ln_grad_item* items, int32_t n, void* stream) {
+  if (n <= 0) return 0;
+  if (!items) return fail("ln_grad_batch: bad args");
+  for (int i = 0; i < n; i++) {
+    const rd_ln_grad_item& it = items[i];
+    if (!it.dgamma || !it.dbeta || it.C <= 0 || it.nparts < 1 || it.nparts > 4) return fail("ln_grad_batch: bad item");
+    for (int p = 0; p < it.nparts; p++) if (!it.partial[p] || it.rows[p] <= 0) return fail("ln_grad_batch: bad partial");
+  }
+  rd::launch_ln_grad_batch(reinterpret_cast<const rdt::LnGradItem*>(items), n, S(stream));
+  return done("rd_ln_grad_batch");
+}
 static_assert(sizeof(rd_colsum_item) == sizeof(rdt::ColsumItem), "rd_colsum_item layout");
 int rd_colsum_partial(const void* x, float* partial, int64_t rows, int32_t C, int32_t dtype, void* stream) {
   if (!x || !partial || !dt_ok(dtype)) return fail("colsum_partial: bad args");

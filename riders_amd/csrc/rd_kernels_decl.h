@@ -83,6 +83,7 @@ void launch_act_bwd(const void* dz, const void* z, void* dx, int64_t n, int act,
 void launch_colsum(const void* x, float* partial, float* out, int accumulate, int64_t rows, int C, int dtype, hipStream_t st);
 int colsum_rows(int64_t rows, int C);
 void launch_colsum_finalize_batch(const ColsumItem* items, int n, hipStream_t st);
+void launch_ln_grad_batch(const LnGradItem* items, int n, hipStream_t st);
 void launch_layernorm_fwd(const void* x, const float* gamma, const float* beta, const void* res, void* out, float* mean,
                           float* rstd, int64_t rows, int C, float eps, int dtype, hipStream_t st);
 int layernorm_bwd_rows(int64_t rows);

@@ -495,6 +495,7 @@ void launch_loftr_layer_bwd(const void* x, const void* src, const LoftrW& w, con
   if (dtype == 0) hipLaunchKernelGGL((loftr_layer_bwd_kernel<float>), dim3((unsigned)N), dim3(LNT), 0, st, (const float*)x, (const float*)src, w, sv, gr, L, S, eps_attn);
   else hipLaunchKernelGGL((loftr_layer_bwd_kernel<bf16_t>), dim3((unsigned)N), dim3(LNT), 0, st, (const bf16_t*)x, (const bf16_t*)src, w, sv, gr, L, S, eps_attn);
   // LayerNorm parameter gradients: ordered sum of the per-ROI partials
+  if (gr.defer_ln) return;      // the caller finishes them later (rd_ln_grad_batch: one launch for every layer application of a stage)
   launch_bn_bwd_finalize(gr.lnp1, N, LC, 1.0, gr.dg1, gr.db1, gr.accumulate, nullptr, nullptr, st);
   launch_bn_bwd_finalize(gr.lnp2, N, LC, 1.0, gr.dg2, gr.db2, gr.accumulate, nullptr, nullptr, st);
 }

@@ -720,6 +720,42 @@ void launch_act_bwd(const void* dz, const void* z, void* dx, int64_t n, int act,
   else hipLaunchKernelGGL((act_bwd_kernel<bf16_t>), dim3(ew_grid(n)), dim3(256), 0, st, (const bf16_t*)dz, (const bf16_t*)z, (bf16_t*)dx, n, act, slope);
 }
 
+// LayerNorm parameter gradients of MANY layer applications in one launch.  An item is one (gamma, beta) pair with the partial buffers of
+// all its applications since the last flush; they are added in order, each summed over its rows exactly as bn_bwd_finalize_kernel does
+// (RC-Net: 12 fused LoFTR backward launches per step, two finalize launches of 5 us behind each).
+struct LnGradBatch { LnGradItem it[LN_GRAD_BATCH_MAX]; };
+__global__ __launch_bounds__(256) void ln_grad_batch_kernel(LnGradBatch b) {
+  __shared__ double s1[4], s2[4];
+  const LnGradItem& it = b.it[blockIdx.y];
+  const int c = blockIdx.x, t = threadIdx.x;
+  if (c >= it.C) return;
+  float ga = 0.f, be = 0.f;
+  if (it.accumulate) { ga = it.dgamma[c]; be = it.dbeta[c]; }
+  for (int p = 0; p < it.nparts; p++) {
+    double a = 0.0, g = 0.0;
+    bn_rows_sum(reinterpret_cast<const float2*>(it.partial[p]), it.rows[p], it.C, c, t, a, g);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o); g += __shfl_xor(g, o); }
+    __syncthreads();
+    if ((t & 63) == 0) { s1[t >> 6] = a; s2[t >> 6] = g; }
+    __syncthreads();
+    a = (s1[0] + s1[1]) + (s1[2] + s1[3]); g = (s2[0] + s2[1]) + (s2[2] + s2[3]);
+    const bool first = p == 0 && !it.accumulate;
+    be = first ? (float)a : be + (float)a;
+    ga = first ? (float)g : ga + (float)g;
+  }
+  if (t == 0) { it.dbeta[c] = be; it.dgamma[c] = ga; }
+}
+void launch_ln_grad_batch(const LnGradItem* items, int n, hipStream_t st) {
+  for (int base = 0; base < n; base += LN_GRAD_BATCH_MAX) {
+    const int m = std::min(LN_GRAD_BATCH_MAX, n - base);
+    LnGradBatch b;
+    int maxc = 1;
+    for (int i = 0; i < m; i++) { b.it[i] = items[base + i]; maxc = std::max(maxc, b.it[i].C); }
+    for (int i = m; i < LN_GRAD_BATCH_MAX; i++) b.it[i] = b.it[0];
+    hipLaunchKernelGGL(ln_grad_batch_kernel, dim3((unsigned)maxc, (unsigned)m), dim3(256), 0, st, b);
+  }
+}
 // many bias gradients finished by ONE launch: item i sums its partial rows exactly as colsum_finalize_kernel does (lanes stride the rows,
 // double precision, xor tree).  SML's decoder has 22 biased convolutions per step: 22 finalize launches of 6 us each for a few KB of sums.
 struct ColsumBatch { ColsumItem it[COLSUM_BATCH_MAX]; };

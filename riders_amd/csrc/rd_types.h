@@ -32,6 +32,10 @@ struct WgradReduceItem { const float* slab; float* dw; int Cout, Cin, KH, KW, ns
 static const int WGRAD_BATCH_MAX = 48;      // 48 x (40 + 4 + 4) B + 8 B: under the 4 KiB kernel-argument limit
 struct WgradReduceBatch { WgradReduceItem item[WGRAD_BATCH_MAX]; int SL[WGRAD_BATCH_MAX]; int first[WGRAD_BATCH_MAX + 1]; int n; };
 
+// LayerNorm parameter gradients of one (gamma, beta) pair: up to four per-row partial buffers [rows][C][2] = (dbeta, dgamma) terms, summed
+// in order (mirrors rd_ln_grad_item)
+struct LnGradItem { const float* partial[4]; float* dgamma; float* dbeta; int rows[4]; int C, nparts, accumulate, reserved; };
+static const int LN_GRAD_BATCH_MAX = 32;
 struct DwWgradItem { const float* partial; float* dw; int rows, C, KK, accumulate; };      // mirrors rd_dw_wgrad_item
 static const int DW_WGRAD_BATCH_MAX = 64;
 struct ColsumItem { const float* partial; float* out; int rows, C, accumulate, reserved; };      // mirrors rd_colsum_item
@@ -45,7 +49,7 @@ struct LoftrSaved { void *q, *k, *v, *att, *mpre, *msg, *hid, *m2pre; float* sta
 
 struct LoftrGrads {
   const void* dout; void *dm2pre, *dhid, *dmpre, *datt, *dq, *dk, *dv, *dx, *dsrc;
-  float *lnp1, *lnp2, *dg1, *db1, *dg2, *db2; int accumulate, pad_;
+  float *lnp1, *lnp2, *dg1, *db1, *dg2, *db2; int accumulate, defer_ln;      // defer_ln = 1: leave the LayerNorm partials, no finalize launches
 };
 
 }  // namespace rdt

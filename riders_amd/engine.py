@@ -191,6 +191,7 @@ class Tape:
         self.conv_reduce_w = set()   # ... summed by ONE rd_wgrad_reduce_batch launch per backward stage; ids of their weights
         self.colsum = []        # (rd_colsum_item, partial rows tensor, bias id): bias gradients finished by one launch per backward stage
         self.dw_reduce = []     # (rd_dw_wgrad_item, partial rows tensor, weight id): depthwise weight gradients, likewise
+        self.ln_grads = {}      # id(gamma) -> dict(dg, db, acc, parts=[(partial rows tensor, rows)]): LayerNorm parameter gradients, likewise
 
     def requires(self, *ts):
         return any(t is not None and id(t) in self.req for t in ts)
@@ -271,6 +272,7 @@ class Tape:
         """One launch sums the split-K slabs of every convolution weight gradient produced since the last flush (rd_wgrad_reduce_batch)."""
         self.flush_colsum()
         self.flush_dw_reduce()
+        self.flush_ln_grads()
         pending, self.conv_reduce, self.conv_reduce_w = self.conv_reduce, [], set()
         if not pending:
             return
@@ -290,6 +292,31 @@ class Tape:
         _chk(_tb("conv_wgrad", sum(p_.numel() * 4 for _, p_, _ in pending),
                  lambda: L().rd_dw_wgrad_finalize_batch(arr, len(pending), _stream(part0)), "depthwise wgrad finalize batch n=%d" % len(pending)),
              "rd_dw_wgrad_finalize_batch")
+
+    def defer_ln_grad(self, gamma, dg, db, acc, part, rows):
+        e = self.ln_grads.get(id(gamma))
+        if e is not None and len(e["parts"]) >= 4:      # an item holds four applications of one layer
+            self.flush_ln_grads()
+            e = None
+        if e is None:
+            e = self.ln_grads[id(gamma)] = dict(dg=dg, db=db, acc=acc, parts=[])
+        e["parts"].append((part, rows))
+
+    def flush_ln_grads(self):
+        """One launch sums the LayerNorm parameter-gradient partials of every layer application since the last flush (rd_ln_grad_batch)."""
+        pending, self.ln_grads = self.ln_grads, {}
+        if not pending:
+            return
+        items = []
+        for e in pending.values():
+            it = _lib.LnGradItem()
+            for i, (part, rows) in enumerate(e["parts"]):
+                it.partial[i] = part.data_ptr(); it.rows[i] = rows
+            it.dgamma, it.dbeta, it.C, it.nparts, it.accumulate = e["dg"].data_ptr(), e["db"].data_ptr(), e["dg"].numel(), len(e["parts"]), e["acc"]
+            items.append(it)
+        arr = (_lib.LnGradItem * len(items))(*items)
+        any_part = next(iter(pending.values()))["parts"][0][0]
+        _chk(L().rd_ln_grad_batch(arr, len(items), _stream(any_part)), "rd_ln_grad_batch")
 
     def flush_colsum(self):
         """One launch finishes every pending bias gradient (rd_colsum_finalize_batch)."""
@@ -1130,9 +1157,13 @@ def loftr_layer(x, source, layer, N, L, S, out=None):
         gr.dsrc = 0 if dsrc is None else dsrc.data_ptr()
         gr.lnp1, gr.lnp2 = lnp[0].data_ptr(), lnp[1].data_ptr()
         gr.dg1, gr.db1, gr.dg2, gr.db2, gr.accumulate = dg1.data_ptr(), db1.data_ptr(), dg2.data_ptr(), db2.data_ptr(), a1
+        gr.defer_ln = 1 if _state["defer_wgrad"] else 0      # the LayerNorm partials of every application of a stage are summed by ONE launch
         wb, keepb = wstruct(1)
         _chk(_timed("loftr_layer", 2.0 * flops, lambda: lib.rd_loftr_layer_bwd(_p(x), _p(source), ctypes.byref(wb), ctypes.byref(sv), ctypes.byref(gr),
                                                                                  N, L, S, eps_a, dt, st), "bwd N=%d L=%d" % (N, L)), "rd_loftr_layer_bwd")
+        if gr.defer_ln:
+            t.defer_ln_grad(lns[0], dg1, db1, a1, lnp[0], N)
+            t.defer_ln_grad(lns[2], dg2, db2, a1, lnp[1], N)
         for w_, x1, x2, dy, M in ((ws[0], x, None, dq, ML), (ws[1], source, None, dk, MS), (ws[2], source, None, dv, MS),
                                   (ws[3], att, None, dmpre, ML), (ws[4], x, msg, dhid, ML), (ws[5], hid, None, dm2pre, ML)):
             if w_.requires_grad:
