@@ -69,10 +69,15 @@ __device__ __forceinline__ void attn_head(AttnSmem& s, const T* __restrict__ q, 
     for (int i = 0; i < NIT; i++) {
       const int idx = lane + 64 * i, rr = idx / SPR, c = (idx - rr * SPR) * VE;
       const int rl = min(rr, L - 1), rs = min(rr, S - 1);
+#if defined(RD_LOFTR_PROBE) && RD_LOFTR_PROBE == 3   // timing probe (tools/ab_loftr.sh): no staging loads, wrong results
+#pragma unroll
+      for (int e = 0; e < VE; e++) { xq[i][e] = 0.01f * (float)(lane + e); xk[i][e] = 0.02f * (float)(rl + e); xv[i][e] = 0.03f * (float)(rs + c); if (BWD) xd[i][e] = 0.01f * (float)(cc0 + e); }
+#else
       rd::ldv(q + (nn * L + rl) * ldq + cc0 + c, xq[i]);
       rd::ldv(k + (nn * S + rs) * ldk + cc0 + c, xk[i]);
       rd::ldv(v + (nn * S + rs) * ldv + cc0 + c, xv[i]);
       if (BWD) rd::ldv(dout + (nn * L + rl) * ldo + cc0 + c, xd[i]);
+#endif
     }
     sched_fence();
     after_loads();

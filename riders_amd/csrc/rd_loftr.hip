@@ -197,9 +197,13 @@ __global__ __launch_bounds__(LNT) void loftr_layer_fwd_kernel(const T* __restric
   LPROF(1)
 
   // linear attention: wave wv owns head wv (q, k, v come back from L2; the head routine stages them per head)
+#if defined(RD_LOFTR_PROBE) && RD_LOFTR_PROBE == 4
+  tok_load<T, LC, LC>(w.wm, Wm);
+#else
   attn_head<T, false>(sm.u.at[wv], (const T*)sv.q, (const T*)sv.k, (const T*)sv.v, (const T*)nullptr, (T*)sv.att, (T*)nullptr,
                       (T*)nullptr, (T*)nullptr, n, wv, true, L, S, LC, LC, LC, LC, eps_attn,
-                      [&]() RD_INLINE_LAMBDA { tok_load<T, LC, LC>(w.wm, Wm); });   // merge weights: behind the staging loads, in flight across the phase
+                      [&]() RD_INLINE_LAMBDA { tok_load<T, LC, LC>(w.wm, Wm); });
+#endif   // merge weights: behind the staging loads, in flight across the phase
   __syncthreads();
   LPROF(2)
   load_rows<T>((const T*)sv.att + xo, L, sm.bS, LDA);
@@ -412,12 +416,26 @@ __global__ __launch_bounds__(LNT) void loftr_layer_bwd_kernel(const T* __restric
       }
     };
   };
+#if defined(RD_LOFTR_PROBE) && RD_LOFTR_PROBE >= 2
+  tok_mma<T, LC, LC>(sm.bD, sm.bD, LC, LDA, Wm, [&](int ct, f32x4 (&acc)[2]) RD_INLINE_LAMBDA { if (acc[0][0] == 12345.f) sm.acc[0] = 1.f; });
+#else
   tok_mma<T, LC, LC>(sm.bD, sm.bD, LC, LDA, Wm, to_global((T*)gr.datt, xo, L));
+#endif
   __syncthreads();
   LPROF(14)
 
   // 6. attention backward (recomputes KV / P from the saved q, k, v)
-  attn_head<T, true>(sm.u.at[wv], (const T*)sv.q, (const T*)sv.k, (const T*)sv.v, (const T*)gr.datt, (T*)nullptr, (T*)gr.dq,
+#if defined(RD_LOFTR_PROBE) && RD_LOFTR_PROBE == 4
+  tok_load<T, LC, LC>(w.wq, Wq); if (EARLY) { tok_load<T, LC, LC>(w.wk, Wk); tok_load<T, LC, LC>(w.wv, Wv); }
+  if (false)
+#endif
+  attn_head<T, true>(sm.u.at[wv], (const T*)sv.q, (const T*)sv.k, (const T*)sv.v,
+#if defined(RD_LOFTR_PROBE)
+                     (const T*)gr.dout,
+#else
+                     (const T*)gr.datt,
+#endif
+                     (T*)nullptr, (T*)gr.dq,
                      (T*)gr.dk, (T*)gr.dv, n, wv, true, L, S, LC, LC, LC, LC, eps_attn,
                      [&]() RD_INLINE_LAMBDA { tok_load<T, LC, LC>(w.wq, Wq); if (EARLY) { tok_load<T, LC, LC>(w.wk, Wk); tok_load<T, LC, LC>(w.wv, Wv); } });
   __syncthreads();
