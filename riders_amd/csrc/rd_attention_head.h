@@ -153,8 +153,7 @@ __device__ __forceinline__ void attn_head(AttnSmem& s, const T* __restrict__ q, 
       int l = tI * 16 + g * 4 + e;
       float dO = s.d[l * LD + r];
       float dz = P[tI][e] * dO;
-#pragma unroll
-      for (int o = 1; o < 16; o <<= 1) dz += __shfl_xor(dz, o);
+      dz = row16_sum(dz);
       s.d[l * LD + r] = fS * Z[tI][e] * dO;
       if (r == 0) s.dden[l] = -Z[tI][e] * Z[tI][e] * fS * dz;
     }

@@ -322,6 +322,46 @@ __device__ __forceinline__ float wave_sum(float v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
   return v;
 }
+// Sums in butterfly order 1, 2, 4, 8 (row16_sum: the 16 lanes of a DPP row) then 16, 32 (wave_sum_up).  __shfl_xor is a ds_bpermute: address
+// arithmetic + an LDS-queue round trip + a wait per step; the fused LoFTR layer is vector-issue bound and spent 128 of them per backward
+// launch.  On the GPU the in-row steps are DPP operands of the adds: after the two quad steps every lane of a quad holds the quad's sum, so
+// the half-mirror / mirror lanes hold exactly what lane ^ 4 / lane ^ 8 hold; row_bcast15 / row_bcast31 then form (R0 + R1), (R2 + R3) and
+// (R2 + R3) + (R0 + R1) in row 3 -- the same two additions the xor steps 16 and 32 perform -- and lane 63 is broadcast through an SGPR.
+// The emulator build keeps the xor butterfly: bit-identical sums.  RD_DPP_SUM=0: xor butterfly on the GPU too (A/B), 1: DPP in-row only.
+#ifndef RD_DPP_SUM
+#define RD_DPP_SUM 2
+#endif
+#if RD_DPP_SUM && !defined(RD_EMU)
+template <int CTRL, int ROWS>
+__device__ __forceinline__ float dpp_f32(float v) {     // lanes outside the row mask read 0
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROWS, 0xF, false));
+}
+__device__ __forceinline__ float row16_sum(float v) {
+  v += dpp_f32<0xB1, 0xF>(v);     // quad_perm [1,0,3,2]
+  v += dpp_f32<0x4E, 0xF>(v);     // quad_perm [2,3,0,1]
+  v += dpp_f32<0x141, 0xF>(v);    // row_half_mirror
+  v += dpp_f32<0x140, 0xF>(v);    // row_mirror
+  return v;
+}
+#else
+__device__ __forceinline__ float row16_sum(float v) {
+#pragma unroll
+  for (int o = 1; o < 16; o <<= 1) v += __shfl_xor(v, o);
+  return v;
+}
+#endif
+__device__ __forceinline__ float wave_sum_up(float v) {
+  v = row16_sum(v);
+#if RD_DPP_SUM >= 2 && !defined(RD_EMU)
+  v += dpp_f32<0x142, 0xA>(v);    // row_bcast15 into rows 1 and 3
+  v += dpp_f32<0x143, 0xC>(v);    // row_bcast31 into rows 2 and 3
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+#else
+  v += __shfl_xor(v, 16);
+  v += __shfl_xor(v, 32);
+  return v;
+#endif
+}
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));

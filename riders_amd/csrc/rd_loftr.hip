@@ -236,9 +236,9 @@ __global__ __launch_bounds__(LNT) void loftr_layer_fwd_kernel(const T* __restric
         continue;
       }
       const float v0 = sm.u.fh.f[r * LF + lane], v1 = sm.u.fh.f[r * LF + 64 + lane];
-      const float mu = wave_sum(v0 + v1) / (float)LC;
+      const float mu = wave_sum_up(v0 + v1) / (float)LC;
       const float d0 = v0 - mu, d1 = v1 - mu;
-      const float var = wave_sum(d0 * d0 + d1 * d1) / (float)LC;
+      const float var = wave_sum_up(d0 * d0 + d1 * d1) / (float)LC;
       const float rs = 1.0f / sqrtf(var + eps_ln);
       float o0 = d0 * rs * gamma[0] + beta[0], o1 = d1 * rs * gamma[1] + beta[1];
       const int64_t go = xo + (int64_t)r * LC;
@@ -327,7 +327,7 @@ __global__ __launch_bounds__(LNT) void loftr_layer_bwd_kernel(const T* __restric
         ag[e] += d[e] * xh[e]; ab[e] += d[e];
         if (seed_acc) sm.acc[r * LF + c] = d[e];   // residual path: dx starts as the upstream gradient
       }
-      const float s1 = wave_sum(g[0] + g[1]) / (float)LC, s2 = wave_sum(g[0] * xh[0] + g[1] * xh[1]) / (float)LC;
+      const float s1 = wave_sum_up(g[0] + g[1]) / (float)LC, s2 = wave_sum_up(g[0] * xh[0] + g[1] * xh[1]) / (float)LC;
 #pragma unroll
       for (int e = 0; e < 2; e++) {
         const int c = e * 64 + lane;
