@@ -162,8 +162,7 @@ __device__ __forceinline__ void conv_epilogue_stats(const ConvArgs& a, const flo
 #pragma unroll
     for (int r = 0; r < 4; r++) {
       float s1 = ssum[c][r], s2 = ssq[c][r];
-#pragma unroll
-      for (int o = 1; o < 16; o <<= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+      s1 = row16_sum(s1); s2 = row16_sum(s2);   // over fr = lane & 15: DPP adds, the xor butterfly's additions (rd_common.h)
       if (fr == 0) {
         int col = (wn * CT + c) * 16 + fg * 4 + r;
         red[(wm * BN + col) * 2 + 0] = s1;
