@@ -169,6 +169,33 @@ int rd_conv_wgrad_partial(const rd_conv_desc* d, const void* src1, const void* s
                           float* dw_oihw, int32_t accumulate, rd_wgrad_reduce_item* item, void* stream);
 int rd_wgrad_reduce_batch(const rd_wgrad_reduce_item* items, int32_t n, void* stream);
 
+/* ---- fusions of the BatchNorm passes into the convolutions either side of them (round 4; utils/net_utils.py:84-91 conv -> BatchNorm2d ->
+ * activation, its autograd).  A BatchNorm-ed convolution's raw output y and its per-channel (scale, shift) -- rd_bn_finalize -- stand in
+ * for the activated tensor z = act(scale * y + shift), which is then never written:
+ *   in_*  (forward / weight gradient of the CONSUMER): src1 is y; the staging gather applies scale / shift / activation per element,
+ *         rounded to the activation dtype exactly as rd_affine_act would have stored z; padding stays zero; src2 is read as it is.
+ *   bn_*  (data gradient of the CONSUMER, i.e. the kernel that produces dz): besides storing dz into dst1 the epilogue accumulates the
+ *         BatchNorm-backward sums of the PRODUCER, (sum g, sum g * xhat) with g = dz * act'(bn_scale * y + bn_shift) and
+ *         xhat = (y - bn_mean) * bn_rstd over the stored dz, into `stats` rows of [Cout][2] floats (columns >= D1 unused): the reduce pass
+ *         of rd_bn_act_bwd_recompute disappears (rd_bn_bwd_from_partial finishes from these rows).  bn_y has dst1's layout ([pixels][D1]).
+ * Null pointers switch a part off.  rd_conv_fusion_ok / rd_conv_wgrad_fusion_ok say whether the kernel a descriptor is routed to supports
+ * the requested parts; callers fall back to the separate passes otherwise. */
+typedef struct rd_conv_fusion {
+  const float* in_scale; const float* in_shift; int32_t in_act; float in_slope;
+  const void* bn_y; const float* bn_scale; const float* bn_shift; const float* bn_mean; const float* bn_rstd; int32_t bn_act; float bn_slope;
+} rd_conv_fusion;
+int32_t rd_conv_fusion_ok(const rd_conv_desc* d, const rd_conv_fusion* f);
+/* rd_conv_fwd / rd_conv_fwd_add (addend may be NULL) with the fusions above */
+int rd_conv_fwd_fused(const rd_conv_desc* d, const rd_conv_fusion* f, const void* src1, const void* src2, const void* w_packed,
+                      const float* bias, const void* addend, void* dst1, void* dst2, float* stats, void* stream);
+int32_t rd_conv_wgrad_fusion_ok(const rd_conv_desc* d, const rd_conv_fusion* f);
+/* kernel instantiation names of the fused calls (as rd_conv_fwd_kernel_name / rd_conv_wgrad_kernel_name) */
+const char* rd_conv_fused_kernel_name(const rd_conv_desc* d, const rd_conv_fusion* f);
+const char* rd_conv_wgrad_fused_kernel_name(const rd_conv_desc* d, const rd_conv_fusion* f);
+/* rd_conv_wgrad_partial with the in_* part (src1 = the producer's raw output) */
+int rd_conv_wgrad_partial_fused(const rd_conv_desc* d, const rd_conv_fusion* f, const void* src1, const void* src2, const void* dy,
+                                float* workspace, float* dw_oihw, int32_t accumulate, rd_wgrad_reduce_item* item, void* stream);
+
 /* ---- BatchNorm2d (+ activation, + residual) -- utils/net_utils.py:86-91, :309-323 ----------------- */
 int rd_bn_finalize(const float* stats, int32_t rows, int32_t C, double count, const float* gamma, const float* beta,
                    float eps, float momentum, int32_t training, float* running_mean, float* running_var,
@@ -176,6 +203,12 @@ int rd_bn_finalize(const float* stats, int32_t rows, int32_t C, double count, co
 /* out = act(scale[c]*y + shift[c] + residual); scale/shift/residual may be NULL */
 int rd_affine_act(const void* y, const float* scale, const float* shift, const void* residual, void* out, int64_t pixels,
                   int32_t C, int32_t act, float slope, int32_t dtype, void* stream);
+/* out = act2(z + residual) with z = act1(scale[c]*y + shift[c]) rounded to the activation dtype as rd_affine_act stores it: the BatchNorm
+   apply of a residual block's second convolution fused with the block's add + activation (utils/net_utils.py:309-323); z is not written.
+   Channel counts with a 16-byte vector form only (rd_affine_act_add_ok). */
+int32_t rd_affine_act_add_ok(int32_t C, int32_t dtype);
+int rd_affine_act_add(const void* y, const float* scale, const float* shift, int32_t act1, float slope1, const void* residual, void* out,
+                      int64_t pixels, int32_t C, int32_t act2, float slope2, int32_t dtype, void* stream);
 int32_t rd_bn_bwd_rows(int64_t pixels, int32_t C);
 /* full BN(+act) backward: dy = dBN(dz * act'(z)); dres (optional) = dz * act'(z); dgamma/dbeta fp32 */
 int rd_bn_act_bwd(const void* dz, const void* z, const void* y, const float* save_mean, const float* save_rstd,

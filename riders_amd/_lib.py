@@ -35,6 +35,13 @@ class ConvDesc(ctypes.Structure):
     ]
 
 
+class ConvFusion(ctypes.Structure):
+    """rd_conv_fusion: consumer-side BatchNorm apply (in_*) and BatchNorm-backward sums in the data-gradient epilogue (bn_*)."""
+    _fields_ = [("in_scale", ctypes.c_void_p), ("in_shift", ctypes.c_void_p), ("in_act", ctypes.c_int32), ("in_slope", ctypes.c_float),
+                ("bn_y", ctypes.c_void_p), ("bn_scale", ctypes.c_void_p), ("bn_shift", ctypes.c_void_p), ("bn_mean", ctypes.c_void_p),
+                ("bn_rstd", ctypes.c_void_p), ("bn_act", ctypes.c_int32), ("bn_slope", ctypes.c_float)]
+
+
 class PackItem(ctypes.Structure):
     _fields_ = [("w", ctypes.c_void_p), ("packed", ctypes.c_void_p), ("Cout", ctypes.c_int32), ("Cin", ctypes.c_int32),
                 ("KH", ctypes.c_int32), ("KW", ctypes.c_int32), ("mode", ctypes.c_int32), ("dtype", ctypes.c_int32),

@@ -197,15 +197,63 @@ int rd_conv_fwd_add(const rd_conv_desc* d, const void* src1, const void* src2, c
   RD_NS(d->dtype, launch_conv)(a, RD_DT(d->dtype), S(stream));
   return done("rd_conv_fwd_add");
 }
+namespace {
+// fusion request -> kernel arguments; returns false when a part is asked for that the routed kernel cannot do
+bool apply_fusion(const rd_conv_desc* d, const rd_conv_fusion* f, rd::ConvArgs& a) {
+  if (!f) return true;
+  const bool want_in = f->in_scale != nullptr, want_bn = f->bn_y != nullptr;
+  if (want_in && !f->in_shift) return false;
+  if (want_bn && (!f->bn_scale || !f->bn_shift || !f->bn_mean || !f->bn_rstd)) return false;
+  if (want_in) { a.in_scale = f->in_scale; a.in_shift = f->in_shift; a.in_act = f->in_act; a.in_slope = f->in_slope; }
+  if (want_bn) { a.bn_y = f->bn_y; a.bn_scale = f->bn_scale; a.bn_shift = f->bn_shift; a.bn_mean = f->bn_mean; a.bn_rstd = f->bn_rstd;
+                 a.bn_act = f->bn_act; a.bn_slope = f->bn_slope; }
+  if (want_in && !RD_NS(d->dtype, conv_in_affine_ok)(a, RD_DT(d->dtype))) return false;
+  if (want_bn && !RD_NS(d->dtype, conv_bn_bwd_ok)(a, RD_DT(d->dtype))) return false;
+  return true;
+}
+}  // namespace
+int32_t rd_conv_fusion_ok(const rd_conv_desc* d, const rd_conv_fusion* f) {
+  if (!d || check_desc(d)) return 0;
+  rd::ConvArgs a; fill_args(d, a);
+  return apply_fusion(d, f, a) ? 1 : 0;
+}
+int rd_conv_fwd_fused(const rd_conv_desc* d, const rd_conv_fusion* f, const void* src1, const void* src2, const void* w_packed,
+                      const float* bias, const void* addend, void* dst1, void* dst2, float* stats, void* stream) {
+  if (int e = check_desc(d)) return e;
+  if (!src1 || !w_packed || !dst1) return fail("conv_fwd_fused: null pointer");
+  if (d->C2 > 0 && !src2) return fail("conv_fwd_fused: C2 > 0 but src2 is null");
+  if (d->D1 < d->Cout && !dst2) return fail("conv_fwd_fused: D1 < Cout but dst2 is null");
+  if (addend && !rd_conv_add_ok(d)) return fail("conv_fwd_fused: an addend is not available for this descriptor (see rd_conv_add_ok)");
+  rd::ConvArgs a; fill_args(d, a);
+  a.src1 = src1; a.src2 = src2; a.w = w_packed; a.bias = bias; a.dst1 = dst1; a.dst2 = dst2; a.stats = stats; a.add1 = addend;
+  if (a.pool2 && !rd_conv_out_reduce2_ok(d)) return fail("conv_fwd_fused: out_reduce2 is not available for this descriptor (see rd_conv_out_reduce2_ok)");
+  if (!apply_fusion(d, f, a)) return fail("conv_fwd_fused: the requested fusion is not available for this descriptor (see rd_conv_fusion_ok)");
+  if (a.bn_y && !stats) return fail("conv_fwd_fused: the BatchNorm-backward sums need a stats buffer");
+  if (!a.bn_y && a.pool2 && stats) return fail("conv_fwd_fused: out_reduce2 has no forward statistics");
+  RD_NS(d->dtype, launch_conv)(a, RD_DT(d->dtype), S(stream));
+  return done("rd_conv_fwd_fused");
+}
 const char* rd_conv_fwd_kernel_name(const rd_conv_desc* d) {
   if (!d || check_desc(d)) return "";
   rd::ConvArgs a; fill_args(d, a);
+  return RD_NS(d->dtype, conv_kernel_name)(a, RD_DT(d->dtype));
+}
+const char* rd_conv_fused_kernel_name(const rd_conv_desc* d, const rd_conv_fusion* f) {
+  if (!d || check_desc(d)) return "";
+  rd::ConvArgs a; fill_args(d, a);
+  if (!apply_fusion(d, f, a)) return "";
   return RD_NS(d->dtype, conv_kernel_name)(a, RD_DT(d->dtype));
 }
 static void fill_wgrad_args(const rd_conv_desc* d, rd::WgradArgs& a);
 const char* rd_conv_wgrad_kernel_name(const rd_conv_desc* d) {
   if (!d || check_desc(d) || d->in_dilate != 1) return "";
   rd::WgradArgs a; fill_wgrad_args(d, a);
+  return RD_NS(d->dtype, wgrad_kernel_name)(a, RD_DT(d->dtype));
+}
+const char* rd_conv_wgrad_fused_kernel_name(const rd_conv_desc* d, const rd_conv_fusion* f) {
+  if (!d || !rd_conv_wgrad_fusion_ok(d, f)) return "";
+  rd::WgradArgs a; fill_wgrad_args(d, a);
+  if (f && f->in_scale) { a.in_scale = f->in_scale; a.in_shift = f->in_shift; }
   return RD_NS(d->dtype, wgrad_kernel_name)(a, RD_DT(d->dtype));
 }
 static void fill_wgrad_args(const rd_conv_desc* d, rd::WgradArgs& a) {
@@ -260,6 +308,25 @@ int rd_conv_wgrad_partial(const rd_conv_desc* d, const void* src1, const void* s
   RD_NS(d->dtype, launch_wgrad)(a, RD_DT(d->dtype), dw, accumulate, S(stream), reinterpret_cast<rdt::WgradReduceItem*>(item));
   return done("rd_conv_wgrad_partial");
 }
+int32_t rd_conv_wgrad_fusion_ok(const rd_conv_desc* d, const rd_conv_fusion* f) {
+  if (!d || check_desc(d) || d->in_dilate != 1) return 0;
+  if (!f || !f->in_scale) return 1;
+  if (!f->in_shift || f->bn_y) return 0;
+  rd::WgradArgs a; fill_wgrad_args(d, a);
+  return RD_NS(d->dtype, wgrad_in_affine_ok)(a, RD_DT(d->dtype)) ? 1 : 0;
+}
+int rd_conv_wgrad_partial_fused(const rd_conv_desc* d, const rd_conv_fusion* f, const void* src1, const void* src2, const void* dy,
+                                float* workspace, float* dw, int32_t accumulate, rd_wgrad_reduce_item* item, void* stream) {
+  if (int e = check_desc(d)) return e;
+  if (!src1 || !dy || !workspace || !dw || !item) return fail("conv_wgrad_partial_fused: null pointer");
+  if (d->in_dilate != 1) return fail("conv_wgrad_partial_fused: in_dilate must be 1");
+  if (!rd_conv_wgrad_fusion_ok(d, f)) return fail("conv_wgrad_partial_fused: the requested fusion is not available for this descriptor (see rd_conv_wgrad_fusion_ok)");
+  rd::WgradArgs a; fill_wgrad_args(d, a);
+  a.src1 = src1; a.src2 = src2; a.dy = dy; a.slab = workspace;
+  if (f && f->in_scale) { a.in_scale = f->in_scale; a.in_shift = f->in_shift; a.in_act = f->in_act; a.in_slope = f->in_slope; }
+  RD_NS(d->dtype, launch_wgrad)(a, RD_DT(d->dtype), dw, accumulate, S(stream), reinterpret_cast<rdt::WgradReduceItem*>(item));
+  return done("rd_conv_wgrad_partial_fused");
+}
 int rd_wgrad_reduce_batch(const rd_wgrad_reduce_item* items, int32_t n, void* stream) {
   if (n < 0 || (n > 0 && !items)) return fail("wgrad_reduce_batch: bad args");
   for (int i = 0; i < n; i++)
@@ -284,6 +351,15 @@ int rd_affine_act(const void* y, const float* scale, const float* shift, const v
   if (pixels * C == 0) return 0;
   RD_NS(dtype, launch_affine_act)(y, scale, shift, residual, out, pixels, C, act, slope, RD_DT(dtype), S(stream));
   return done("rd_affine_act");
+}
+int32_t rd_affine_act_add_ok(int32_t C, int32_t dtype) { return dt_ok(dtype) && rd::affine_act_add_ok(C, RD_DT(dtype)) ? 1 : 0; }
+int rd_affine_act_add(const void* y, const float* scale, const float* shift, int32_t act1, float slope1, const void* residual, void* out,
+                      int64_t pixels, int32_t C, int32_t act2, float slope2, int32_t dtype, void* stream) {
+  if (!y || !scale || !shift || !residual || !out || !dt_ok(dtype)) return fail("affine_act_add: bad args");
+  if (!rd::affine_act_add_ok(C, RD_DT(dtype))) return fail("affine_act_add: channel count %d has no vector form (see rd_affine_act_add_ok)", C);
+  if (pixels * C == 0) return 0;
+  RD_NS(dtype, launch_affine_act_add)(y, scale, shift, act1, slope1, residual, out, pixels, C, act2, slope2, RD_DT(dtype), S(stream));
+  return done("rd_affine_act_add");
 }
 int32_t rd_bn_bwd_rows(int64_t pixels, int32_t C) { return rd::bn_bwd_rows(pixels, C); }
 int rd_bn_act_bwd(const void* dz, const void* z, const void* y, const float* mean, const float* rstd, const float* scale,

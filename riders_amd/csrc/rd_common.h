@@ -25,6 +25,13 @@
 #define RD_WAVE_UNIFORM(x) __builtin_amdgcn_readfirstlane(x)
 #endif
 
+// the 16-bit element type as rocprofv3's kernel trace prints it in this build's instantiation names
+#ifdef RD_HALF_F16
+#define RD_T16_NAME "rd_f16::bf16_t"
+#else
+#define RD_T16_NAME "rd::bf16_t"
+#endif
+
 namespace rd {
 
 // ---- element types -------------------------------------------------------------------------

@@ -982,15 +982,10 @@ static bool use_conv3x3_frag(const ConvArgs& a, int dtype) {   // wide layers: w
   // stage chain on the same shape -- deep encoder stages, 9 672 / 2 560 pixels x 128 channels: 21 -> 13 us and 15 -> 12 us per launch
   return conv3x3_frag_ok(a, dtype) && conv3x3_frag_blocks(a, dtype) >= std::min(conv3x3_min_blocks(), 8);
 }
-static bool use_conv3x3_dma(const ConvArgs& a, int dtype) {   // wide bf16 layers: LDS-DMA staging + 32x32x16 MFMA (rd_conv3x3_dma.hip)
-  if (!conv3x3_dma_ok(a, dtype)) return false;
-  return (int64_t)conv3x3_dma_tiles(a) * cdiv(a.Cout, a.Cout <= 32 ? 32 : (a.Cout <= 64 ? 64 : 128)) >= conv3x3_min_blocks();
-}
 int conv_stats_rows(const ConvArgs& a, int dtype) {
   if (conv_few_ok(a)) return conv_few_blocks(a);
   if (conv1x1_direct_ok(a, dtype)) return conv1x1_direct_rows(a);
   if (use_conv3x3_small(a, dtype)) return conv3x3_small_blocks(a, dtype);   // persistent blocks: one statistics row each
-  if (use_conv3x3_dma(a, dtype)) return conv3x3_dma_tiles(a);
   if (use_conv3x3_frag(a, dtype)) return conv3x3_frag_tiles(a, dtype);
   if (use_conv3x3(a, dtype)) return conv3x3_tiles(a);
   return (int)cdiv(a.M, conv_block_pixels(a.M, a.Cout));
@@ -1001,13 +996,14 @@ void launch_conv(const ConvArgs& a, int dtype, hipStream_t st) {
   if (conv1x1_direct_ok(a, dtype)) { launch_conv1x1_direct(a, dtype, st); return; }
   if (conv3x3_c1_ok(a)) { launch_conv3x3_c1(a, dtype, st); return; }
   if (use_conv3x3_small(a, dtype)) { launch_conv3x3_small(a, dtype, st); return; }
-  if (use_conv3x3_dma(a, dtype)) { launch_conv3x3_dma(a, st); return; }
   if (use_conv3x3_frag(a, dtype)) { launch_conv3x3_frag(a, dtype, st); return; }
   if (use_conv3x3(a, dtype)) { launch_conv3x3(a, dtype, st); return; }
   if (dtype == 0) launch_conv_t<float>(a, st);
   else launch_conv_t<bf16_t>(a, st);
 }
 
+static bool wgrad_tiny_shape(const WgradArgs& a);
+static bool wgrad_tiny_shape_fwd(const WgradArgs& a) { return wgrad_tiny_shape(a); }
 // out_reduce2 (ConvArgs::pool2): only the narrow-layer 3x3 kernel pairs rows / columns of its output tile in registers
 bool conv_pool2_ok(const ConvArgs& a, int dtype) {
   return !conv_few_ok(a) && !conv1x1_direct_ok(a, dtype) && !conv3x3_c1_ok(a) && use_conv3x3_small(a, dtype) && !(a.OH & 1) && !(a.OW & 1) &&
@@ -1019,15 +1015,27 @@ bool conv_add_ok(const ConvArgs& a, int dtype) {
   if (a.D1 != a.Cout || a.pool2 || conv_few_ok(a)) return false;
   if (conv1x1_direct_ok(a, dtype)) return true;
   if (conv3x3_c1_ok(a) || use_conv3x3_small(a, dtype)) return false;      // (the narrow-layer variants sit at their register caps)
-  return !use_conv3x3_dma(a, dtype);
+  return true;
 }
+// ConvArgs::in_scale (consumer-side BatchNorm apply while staging): the two 3x3 / stride-1 kernels that stage whole 16-byte channel
+// vectors of a pixel patch through registers (every 3x3 layer of RC-Net that reads a BatchNorm-ed convolution's output)
+bool conv_in_affine_ok(const ConvArgs& a, int dtype) {
+  if (conv_few_ok(a) || conv1x1_direct_ok(a, dtype) || conv3x3_c1_ok(a)) return false;
+  return use_conv3x3_small(a, dtype) || use_conv3x3_frag(a, dtype);
+}
+// ConvArgs::bn_y (BatchNorm-backward sums in the data-gradient epilogue): kernels that store through conv_epilogue_store and write
+// statistics rows; dz = the first destination
+bool conv_bn_bwd_ok(const ConvArgs& a, int dtype) {
+  (void)a; (void)dtype;
+  return false;
+}
+bool wgrad_in_affine_ok(const WgradArgs& a, int dtype) { return !wgrad_tiny_shape_fwd(a) && wgrad3x3_tr_affine_ok(a, dtype); }
 // name of the kernel launch_conv picks for this shape (bench.py groups its per-launch timings by the names rocprofv3 reports)
 const char* conv_kernel_name(const ConvArgs& a, int dtype) {
   if (conv_few_ok(a)) return "conv_few_kernel";
   if (conv1x1_direct_ok(a, dtype)) return "conv1x1_direct_kernel";
   if (conv3x3_c1_ok(a)) return "conv3x3_c1_kernel";
   if (use_conv3x3_small(a, dtype)) return conv3x3_small_name(a, dtype);
-  if (use_conv3x3_dma(a, dtype)) return "conv3x3_dma_kernel";
   if (use_conv3x3_frag(a, dtype)) return conv3x3_frag_name(a, dtype);
   if (use_conv3x3(a, dtype)) return conv3x3_patch_name(a, dtype);
   {     // the implicit-GEMM kernel's instantiation, as launch_conv_t picks it
@@ -1037,7 +1045,7 @@ const char* conv_kernel_name(const ConvArgs& a, int dtype) {
     int bn, wm;
     conv_tiles(a.M, a.Cout, bn, wm);
     const bool deep = vec && wm == 2 && cdiv(a.M, 32 * wm) * cdiv(a.Cout, bn) <= 512 && a.Kpad / (STAGE_BYTES / es) >= 6;
-    snprintf(buf, sizeof(buf), "conv_gemm_kernel<%s, %d, %s, %d, %s>", dtype == 0 ? "float" : "rd::bf16_t", bn, vec ? "true" : "false", wm, deep ? "true" : "false");
+    snprintf(buf, sizeof(buf), "conv_gemm_kernel<%s, %d, %s, %d, %s>", dtype == 0 ? "float" : RD_T16_NAME, bn, vec ? "true" : "false", wm, deep ? "true" : "false");
     return buf;
   }
 }

@@ -233,7 +233,10 @@ constexpr int small_min_waves(int spp, int bn) {
 template <int SPP>
 __device__ __forceinline__ int patch_slot(int p, int j) { return p * SPP + (j ^ ((p / (16 / SPP)) % SPP)); }
 
-template <typename T, int SPP, int BN, bool W8>
+// AFF: source 1 is a BatchNorm-ed producer's RAW output; the staging applies scale / shift + activation (ConvArgs::in_scale) on the way into
+// LDS, so the activated tensor never exists in HBM.  A thread's slots all carry the same VE channels (256 % SPP == 0): the coefficients
+// come from a block copy in LDS, padding slots stay zero (validity bits travel with each prefetched register set).
+template <typename T, int SPP, int BN, bool W8, bool AFF = false>
 __global__ __launch_bounds__(256, small_min_waves(SPP, BN)) void conv3x3_small_kernel(ConvArgs a, int tilesH, int tilesW) {
   constexpr int VE = Elem<T>::VE;
   constexpr int TW = W8 ? 8 : 16, TH = W8 ? 16 : 8;
@@ -259,6 +262,9 @@ __global__ __launch_bounds__(256, small_min_waves(SPP, BN)) void conv3x3_small_k
   // wave reads its fragments from a lane-major LDS copy ([c][s][lane], conflict free).
   constexpr bool WLDS = (CT * STEPS > 5);
   __shared__ uint4 sW[WLDS ? CT * STEPS * 64 : 1];
+  __shared__ __attribute__((aligned(16))) float sAff[AFF ? 2 * SPP * VE : 1];
+  if (AFF) affine_fill(sAff, a.in_scale, a.in_shift, 0, SPP * VE, a.C1, t, 256);
+  const bool aff_lane = AFF && (t % SPP) * VE < a.C1;
   uint4 wr[WLDS ? 1 : CT][WLDS ? 1 : STEPS];
   {
     const uint4* wp = reinterpret_cast<const uint4*>(a.w);
@@ -299,13 +305,15 @@ __global__ __launch_bounds__(256, small_min_waves(SPP, BN)) void conv3x3_small_k
     else { sbase[i] = (const T*)a.src2 + (ci - a.C1); sC[i] = a.C2; }
   }
   const int Hp = a.ups ? a.H1 : a.Hin, Wp = a.ups ? a.W1 : a.Win;
-  auto load_patch = [&](TC tc, uint4 (&rp)[PIT]) RD_INLINE_LAMBDA {
+  auto load_patch = [&](TC tc, uint4 (&rp)[PIT], unsigned& okm) RD_INLINE_LAMBDA {
     const int oh0 = tc.th * TH, ow0 = tc.tw * TW, nb = tc.n * Hp;
+    okm = 0;
 #pragma unroll
     for (int i = 0; i < PIT; i++) {
       uint4 v = make_uint4(0, 0, 0, 0);
       const int ih = oh0 + spy[i], iw = ow0 + spx[i];
       if (sok[i] && (unsigned)ih < (unsigned)a.Hin && (unsigned)iw < (unsigned)a.Win) {
+        if (AFF) okm |= 1u << i;
         int hs = ih, ws = iw;
         if (a.ups) {  // F.interpolate(mode='nearest') source index, ATen float formula (as conv_src_ptr)
           hs = min((int)floorf((float)ih * a.scale_h), a.H1 - 1);
@@ -317,11 +325,21 @@ __global__ __launch_bounds__(256, small_min_waves(SPP, BN)) void conv3x3_small_k
       rp[i] = v;
     }
   };
-  auto store_patch = [&](int buf, const uint4 (&rp)[PIT]) RD_INLINE_LAMBDA {
+  auto store_patch = [&](int buf, const uint4 (&rp)[PIT], unsigned okm) RD_INLINE_LAMBDA {
+    float sc[VE], sh[VE];
+    if (AFF) {
+#pragma unroll
+      for (int e = 0; e < VE; e++) { sc[e] = sAff[(t % SPP) * VE + e]; sh[e] = sAff[SPP * VE + (t % SPP) * VE + e]; }
+    }
 #pragma unroll
     for (int i = 0; i < PIT; i++) {
       int idx = t + 256 * i;
-      if (idx < NSLOT) { int pp = idx / SPP; sP[buf][patch_slot<SPP>(pp, idx - pp * SPP)] = rp[i]; }
+      if (idx < NSLOT) {
+        int pp = idx / SPP;
+        uint4 v = rp[i];
+        if (AFF) { const uint4 z = affine16((const T*)nullptr, v, sc, sh, a.in_act, a.in_slope); if (aff_lane && ((okm >> i) & 1u)) v = z; }
+        sP[buf][patch_slot<SPP>(pp, idx - pp * SPP)] = v;
+      }
     }
   };
   int ppix[2], lpy[2], lpx[2];
@@ -419,19 +437,21 @@ __global__ __launch_bounds__(256, small_min_waves(SPP, BN)) void conv3x3_small_k
   // shorter than the HBM latency, with distance one every block stalled on its next patch (ROI-resolution layers ran at 17-30 % of
   // the HBM roof with four blocks per CU)
   uint4 ra[PIT], rb[PIT];
+  unsigned ma = 0, mb = 0;      // validity bits of the two register sets (AFF: padding must stay zero behind the affine map)
   int t0 = tile, t1 = tile + G8;
   TC c0 = decode(t0), c1 = advance(c0);
-  if (t0 < tend) load_patch(c0, ra);
-  if (t1 < tend) load_patch(c1, rb);
+  if (t0 < tend) load_patch(c0, ra, ma);
+  if (t1 < tend) load_patch(c1, rb, mb);
+  if (AFF) __syncthreads();     // the coefficient copy is complete
   int buf = 0;
   while (t0 < tend) {
-    store_patch(buf, ra);
+    store_patch(buf, ra, ma);
     __syncthreads();
-    { const int t2 = t1 + G8; const TC c2 = advance(c1); if (t2 < tend) load_patch(c2, ra); tile_body(t0, c0, buf); t0 = t1; t1 = t2; c0 = c1; c1 = c2; buf ^= 1; }
+    { const int t2 = t1 + G8; const TC c2 = advance(c1); if (t2 < tend) load_patch(c2, ra, ma); tile_body(t0, c0, buf); t0 = t1; t1 = t2; c0 = c1; c1 = c2; buf ^= 1; }
     if (t0 >= tend) break;
-    store_patch(buf, rb);
+    store_patch(buf, rb, mb);
     __syncthreads();
-    { const int t2 = t1 + G8; const TC c2 = advance(c1); if (t2 < tend) load_patch(c2, rb); tile_body(t0, c0, buf); t0 = t1; t1 = t2; c0 = c1; c1 = c2; buf ^= 1; }
+    { const int t2 = t1 + G8; const TC c2 = advance(c1); if (t2 < tend) load_patch(c2, rb, mb); tile_body(t0, c0, buf); t0 = t1; t1 = t2; c0 = c1; c1 = c2; buf ^= 1; }
   }
   conv_epilogue_stats<CT, BN, 4>(a, ssum, ssq, 0, 0, wv, fr, fg, t, blockIdx.x, red);   // every block writes its row (zeros if it had no tile)
 }
@@ -640,9 +660,13 @@ static void launch_small_t(const ConvArgs& a, hipStream_t st) {
   const int ntiles = a.N * tilesH * tilesW;
   const int spp = (a.C1 + a.C2) * (int)sizeof(T) / 16, bn = pick_bn3(a.Cout);
   dim3 grid((unsigned)conv3x3_small_blocks(a, (int)sizeof(T) == 4 ? 0 : 1));
+  const bool aff = a.in_scale != nullptr;
 #define RD_S3(SPPV, BNV)                                                                                                  \
   if (spp == SPPV && bn == BNV) {                                                                                         \
-    if (w8) hipLaunchKernelGGL((conv3x3_small_kernel<T, SPPV, BNV, true>), grid, dim3(256), 0, st, a, tilesH, tilesW);    \
+    if (aff) {                                                                                                            \
+      if (w8) hipLaunchKernelGGL((conv3x3_small_kernel<T, SPPV, BNV, true, true>), grid, dim3(256), 0, st, a, tilesH, tilesW);   \
+      else hipLaunchKernelGGL((conv3x3_small_kernel<T, SPPV, BNV, false, true>), grid, dim3(256), 0, st, a, tilesH, tilesW);     \
+    } else if (w8) hipLaunchKernelGGL((conv3x3_small_kernel<T, SPPV, BNV, true>), grid, dim3(256), 0, st, a, tilesH, tilesW);    \
     else hipLaunchKernelGGL((conv3x3_small_kernel<T, SPPV, BNV, false>), grid, dim3(256), 0, st, a, tilesH, tilesW);      \
   }
   RD_S3(2, 16) RD_S3(4, 16) RD_S3(8, 16) RD_S3(2, 32) RD_S3(4, 32) RD_S3(2, 64) RD_S3(4, 64)
@@ -652,14 +676,14 @@ static void launch_small_t(const ConvArgs& a, hipStream_t st) {
 const char* conv3x3_small_name(const ConvArgs& a, int dtype) {
   static thread_local char buf[96];
   const int es = dtype == 0 ? 4 : 2;
-  snprintf(buf, sizeof(buf), "conv3x3_small_kernel<%s, %d, %d, %s>", dtype == 0 ? "float" : "rd::bf16_t", (a.C1 + a.C2) * es / 16, pick_bn3(a.Cout),
-           use_w8(a) ? "true" : "false");
+  snprintf(buf, sizeof(buf), "conv3x3_small_kernel<%s, %d, %d, %s, %s>", dtype == 0 ? "float" : RD_T16_NAME, (a.C1 + a.C2) * es / 16, pick_bn3(a.Cout),
+           use_w8(a) ? "true" : "false", a.in_scale ? "true" : "false");
   return buf;
 }
 const char* conv3x3_patch_name(const ConvArgs& a, int dtype) {
   static thread_local char buf[96];
   static const int bn_max = getenv("RD_PATCH_BN_MAX") ? atoi(getenv("RD_PATCH_BN_MAX")) : 64;
-  snprintf(buf, sizeof(buf), "conv3x3_patch_kernel<%s, %d, %s>", dtype == 0 ? "float" : "rd::bf16_t", std::min(bn_max, pick_bn3(a.Cout)),
+  snprintf(buf, sizeof(buf), "conv3x3_patch_kernel<%s, %d, %s>", dtype == 0 ? "float" : RD_T16_NAME, std::min(bn_max, pick_bn3(a.Cout)),
            use_w8(a) ? "true" : "false");
   return buf;
 }

@@ -36,13 +36,16 @@ struct FragGeom {
   int ctall;      // 16-channel tiles in the packed operand (rows_pad / 16)
   int wfrag;      // element offset of the fragment-ordered copy inside the packed operand (rows_pad * Kpad)
   float rWT, rH1; // 1 / WT, 1 / (OH + 1): the strip is decoded with float reciprocals + one correction step (host: strip < 2^22 pixels)
+  int aff;        // byte offset of the [2][Cin] coefficient copy of the consumer-side BatchNorm apply inside the dynamic LDS
 };
 
 constexpr int frag_pmax(int tp) { return tp <= 128 ? 256 : (tp <= 256 ? 384 : 640); }   // patch pixels a block may stage (32 / 48 / 80 KB)
 
 // NPT 16-pixel tiles per wave, WPX x WCH waves (pixels x 32-channel groups): block tile = (16 NPT WPX) pixels x (32 WCH) channels.
 // LIN: linear tiles; MULTI: more than one channel chunk (the next chunk's patch is prefetched).
-template <typename T, int NPT, int WPX, int WCH, bool LIN, bool MULTI>
+// AFF: source 1 is a BatchNorm-ed producer's RAW output; scale / shift + activation are applied while the patch is written to LDS
+// (ConvArgs::in_scale; coefficients in an LDS copy behind the planes at byte offset g.aff), padding pixels stay zero.
+template <typename T, int NPT, int WPX, int WCH, bool LIN, bool MULTI, bool AFF = false>
 __global__ __launch_bounds__(64 * WPX * WCH, (WPX * WCH == 8 && WCH == 4) ? 4 : ((WPX * WCH == 8 || NPT == 8 || (MULTI && WCH == 1)) ? 2 : 3)) void conv3x3_frag_kernel(ConvArgs a, FragGeom g) {
   constexpr int NW = WPX * WCH, NT = 64 * NW;
   constexpr int VE = Elem<T>::VE;
@@ -119,10 +122,22 @@ __global__ __launch_bounds__(64 * WPX * WCH, (WPX * WCH == 8 && WCH == 4) ? 4 : 
     rp[i] = spix[i] < 0 ? make_uint4(0, 0, 0, 0) : v;
   };
   const int st_base = ((t & 7) >> 1) * PS + (t & 1) * 16 + (t >> 3) * 32;    // plane (slot >> 1), 16-byte column (slot & 1), pixel t >> 3
-  auto store_patch = [&]() RD_INLINE_LAMBDA {
+  const float* const aff = reinterpret_cast<const float*>(smem + g.aff);
+  if (AFF) affine_fill(const_cast<float*>(aff), a.in_scale, a.in_shift, 0, Cin, a.C1, t, NT);      // visible after the first chunk's barrier
+  auto store_patch = [&](int chunk) RD_INLINE_LAMBDA {
+    float sc[VE], sh[VE];
+    const int ci = chunk * CKE + (t & 7) * VE;
+    if (AFF) {
+#pragma unroll
+      for (int e = 0; e < VE; e++) { sc[e] = aff[ci + e]; sh[e] = aff[Cin + ci + e]; }
+    }
 #pragma unroll
     for (int i = 0; i < PIT; i++)
-      if (((t + NT * i) >> 3) < np) *reinterpret_cast<uint4*>(smem + st_base + i * (NT / 8) * 32) = rp[i];
+      if (((t + NT * i) >> 3) < np) {
+        uint4 v = rp[i];
+        if (AFF) { const uint4 z = affine16((const T*)nullptr, v, sc, sh, a.in_act, a.in_slope); if (ci < a.C1 && spix[i] >= 0) v = z; }
+        *reinterpret_cast<uint4*>(smem + st_base + i * (NT / 8) * 32) = v;
+      }
   };
 
   // ---- this lane's output pixels (one per MFMA pixel tile): flattened output index or -1 -------------------------------------------------
@@ -216,7 +231,7 @@ __global__ __launch_bounds__(64 * WPX * WCH, (WPX * WCH == 8 && WCH == 4) ? 4 : 
   load_w(0, wa);
   for (int chunk = 0; chunk < nchunk; chunk++) {
     __syncthreads();            // every wave is done with the previous chunk's patch
-    store_patch();
+    store_patch(chunk);
     __syncthreads();
     tap_body(chunk, 0, wa, wb); tap_body(chunk, 1, wb, wa); tap_body(chunk, 2, wa, wb);
     tap_body(chunk, 3, wb, wa); tap_body(chunk, 4, wa, wb); tap_body(chunk, 5, wb, wa);
@@ -313,23 +328,25 @@ const char* conv3x3_frag_name(const ConvArgs& a, int dtype) {
   FragPlan p; frag_plan(a, dtype, p);
   static const int npt[] = {8, 4, 4, 8, 4, 4, 8}, wpx[] = {1, 2, 2, 2, 4, 4, 4}, wch[] = {4, 4, 2, 2, 2, 1, 1};
   const bool multi = (a.C1 + a.C2) * (dtype == 0 ? 4 : 2) > STAGE_BYTES;
-  snprintf(buf, sizeof(buf), "conv3x3_frag_kernel<%s, %d, %d, %d, %s, %s>", dtype == 0 ? "float" : "rd::bf16_t", npt[p.variant], wpx[p.variant],
-           wch[p.variant], p.lin ? "true" : "false", multi ? "true" : "false");
+  snprintf(buf, sizeof(buf), "conv3x3_frag_kernel<%s, %d, %d, %d, %s, %s, %s>", dtype == 0 ? "float" : RD_T16_NAME, npt[p.variant], wpx[p.variant],
+           wch[p.variant], p.lin ? "true" : "false", multi ? "true" : "false", a.in_scale ? "true" : "false");
   return buf;
 }
 
 template <typename T, int NPT, int WPX, int WCH>
-static void launch_frag_v(const ConvArgs& a, const FragPlan& p, const FragGeom& g, hipStream_t st) {
+static void launch_frag_v(const ConvArgs& a, const FragPlan& p, const FragGeom& g_, hipStream_t st) {
   const dim3 grid((unsigned)(p.ntiles * p.ncb)), block(64 * WPX * WCH);
-  const size_t lds = (size_t)std::max(4 * p.ps, WPX * 32 * WCH * 2 * 4);
+  const bool aff = a.in_scale != nullptr;
+  FragGeom g = g_;
+  g.aff = std::max(4 * p.ps, WPX * 32 * WCH * 2 * 4);      // coefficient copy behind the planes / the statistics scratch
+  const size_t lds = (size_t)g.aff + (aff ? (size_t)(a.C1 + a.C2) * 8 : 0);
   const bool multi = (a.C1 + a.C2) * (int)sizeof(T) > STAGE_BYTES;
-  if (p.lin) {
-    if (multi) hipLaunchKernelGGL((conv3x3_frag_kernel<T, NPT, WPX, WCH, true, true>), grid, block, lds, st, a, g);
-    else hipLaunchKernelGGL((conv3x3_frag_kernel<T, NPT, WPX, WCH, true, false>), grid, block, lds, st, a, g);
-  } else {
-    if (multi) hipLaunchKernelGGL((conv3x3_frag_kernel<T, NPT, WPX, WCH, false, true>), grid, block, lds, st, a, g);
-    else hipLaunchKernelGGL((conv3x3_frag_kernel<T, NPT, WPX, WCH, false, false>), grid, block, lds, st, a, g);
-  }
+#define RD_FR(LINV, MULTIV)                                                                                                         \
+  { if (aff) hipLaunchKernelGGL((conv3x3_frag_kernel<T, NPT, WPX, WCH, LINV, MULTIV, true>), grid, block, lds, st, a, g);          \
+    else hipLaunchKernelGGL((conv3x3_frag_kernel<T, NPT, WPX, WCH, LINV, MULTIV>), grid, block, lds, st, a, g); }
+  if (p.lin) { if (multi) RD_FR(true, true) else RD_FR(true, false) }
+  else { if (multi) RD_FR(false, true) else RD_FR(false, false) }
+#undef RD_FR
 }
 template <typename T>
 static void launch_frag_t(const ConvArgs& a, int dtype, hipStream_t st) {
@@ -338,7 +355,7 @@ static void launch_frag_t(const ConvArgs& a, int dtype, hipStream_t st) {
   g.lin = p.lin; g.WT = p.WT; g.tilesH = p.tilesH; g.tilesW = p.tilesW; g.ntiles = p.ntiles; g.ncb = p.ncb; g.np = p.np; g.ps = p.ps;
   const int rows_pad = conv_rows_pad(a.Cout);
   g.ctall = rows_pad / 16; g.wfrag = rows_pad * a.Kpad;
-  g.rWT = 1.0f / (float)p.WT; g.rH1 = 1.0f / (float)(a.OH + 1);
+  g.rWT = 1.0f / (float)p.WT; g.rH1 = 1.0f / (float)(a.OH + 1); g.aff = 0;
   switch (p.variant) {
     case 0: launch_frag_v<T, 8, 1, 4>(a, p, g, st); break;
     case 1: launch_frag_v<T, 4, 2, 4>(a, p, g, st); break;

@@ -68,6 +68,38 @@ __device__ __forceinline__ bool conv_src_ptr_nb(const ConvArgs& a, int n, int ih
   return ok;
 }
 
+// ---- consumer-side BatchNorm apply (ConvArgs::in_scale): one 16-byte vector of the producer's raw output y -> act(scale * y + shift),
+// rounded to the activation type.  The expression is rd_affine_act's (rd_norm.hip, bn_apply1): the value a consumer stages is bit for bit
+// the z that pass would have written.  sc / sh: the VE per-channel coefficients of this vector (registers or LDS).
+__device__ __forceinline__ float bn_apply1(float y, float s, float b, int act, float slope) { return act_fwd(y * s + b, act, slope); }
+__device__ __forceinline__ uint4 affine16(const float*, const uint4& r, const float* sc, const float* sh, int act, float slope) {
+  uint4 o;
+  o.x = __float_as_uint(bn_apply1(__uint_as_float(r.x), sc[0], sh[0], act, slope));
+  o.y = __float_as_uint(bn_apply1(__uint_as_float(r.y), sc[1], sh[1], act, slope));
+  o.z = __float_as_uint(bn_apply1(__uint_as_float(r.z), sc[2], sh[2], act, slope));
+  o.w = __float_as_uint(bn_apply1(__uint_as_float(r.w), sc[3], sh[3], act, slope));
+  return o;
+}
+__device__ __forceinline__ uint4 affine16(const bf16_t*, const uint4& r, const float* sc, const float* sh, int act, float slope) {
+  float v[8];
+  raw16_to_f32((const bf16_t*)nullptr, r, v);
+#pragma unroll
+  for (int e = 0; e < 8; e++) v[e] = bn_apply1(v[e], sc[e], sh[e], act, slope);
+  uint4 o;
+  o.x = pack_bf16x2(v[0], v[1]); o.y = pack_bf16x2(v[2], v[3]); o.z = pack_bf16x2(v[4], v[5]); o.w = pack_bf16x2(v[6], v[7]);
+  return o;
+}
+// the block's copy of the coefficients: aff[c] = scale, aff[Cin + c] = shift for the Cin channels [c0, c0 + Cin) of the gather's K axis;
+// channels of the second source (c >= C1) get the identity (they are never transformed, the values only keep the reads in bounds)
+__device__ __forceinline__ void affine_fill(float* aff, const float* scale, const float* shift, int c0, int Cin, int C1, int t, int nt) {
+  for (int i = t; i < Cin; i += nt) {
+    const int c = c0 + i;
+    const bool in1 = c < C1;
+    const float s = scale[in1 ? c : 0], b = shift[in1 ? c : 0];
+    aff[i] = in1 ? s : 1.f; aff[Cin + i] = in1 ? b : 0.f;
+  }
+}
+
 // ---- shared epilogue: bias, activation, NHWC store (dual destination), BatchNorm (sum, sum^2) partials ------------------------------
 // acc[c][pt][r] = output channel n0 + (wn*CT + c)*16 + fg*4 + r of pixel m[pt] (valid iff mv[pt]); WMV waves share the pixel axis.
 // Part 1 stores the tile and ADDS its values into the caller's per-lane statistics registers; part 2 reduces those registers over

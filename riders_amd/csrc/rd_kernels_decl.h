@@ -15,6 +15,9 @@ void launch_conv(const ConvArgs& a, int dtype, hipStream_t st);
 const char* conv_kernel_name(const ConvArgs& a, int dtype);
 bool conv_pool2_ok(const ConvArgs& a, int dtype);
 bool conv_add_ok(const ConvArgs& a, int dtype);
+bool conv_in_affine_ok(const ConvArgs& a, int dtype);
+bool conv_bn_bwd_ok(const ConvArgs& a, int dtype);
+bool wgrad_in_affine_ok(const WgradArgs& a, int dtype);
 const char* wgrad_kernel_name(const WgradArgs& a, int dtype);
 // rd_conv3x3.hip
 bool conv3x3_ok(const ConvArgs& a, int dtype);
@@ -34,10 +37,6 @@ int conv3x3_frag_tiles(const ConvArgs& a, int dtype);
 int conv3x3_frag_blocks(const ConvArgs& a, int dtype);
 void launch_conv3x3_frag(const ConvArgs& a, int dtype, hipStream_t st);
 const char* conv3x3_frag_name(const ConvArgs& a, int dtype);
-// rd_conv3x3_dma.hip
-bool conv3x3_dma_ok(const ConvArgs& a, int dtype);
-int conv3x3_dma_tiles(const ConvArgs& a);
-void launch_conv3x3_dma(const ConvArgs& a, hipStream_t st);
 bool conv_few_ok(const ConvArgs& a);
 int conv_few_blocks(const ConvArgs& a);
 void launch_conv_few(const ConvArgs& a, int dtype, hipStream_t st);
@@ -51,6 +50,7 @@ void launch_wgrad_reduce_batch(const WgradReduceItem* items, int n, hipStream_t 
 
 // rd_wgrad3x3.hip
 bool wgrad3x3_tr_ok(const WgradArgs& a, int dtype);
+bool wgrad3x3_tr_affine_ok(const WgradArgs& a, int dtype);
 int wgrad3x3_tr_blocks(const WgradArgs& a);
 void launch_wgrad3x3_tr(const WgradArgs& a, hipStream_t st);
 const char* wgrad3x3_tr_name(const WgradArgs& a);
@@ -70,6 +70,9 @@ void launch_bn_finalize(const float* partial, int rows, int C, double count, con
                         float* mean, float* rstd, float* scale, float* shift, hipStream_t st);
 void launch_affine_act(const void* y, const float* scale, const float* shift, const void* res, void* out, int64_t pixels,
                        int C, int act, float slope, int dtype, hipStream_t st);
+bool affine_act_add_ok(int C, int dtype);
+void launch_affine_act_add(const void* y, const float* scale, const float* shift, int act1, float slope1, const void* res, void* out,
+                           int64_t pixels, int C, int act2, float slope2, int dtype, hipStream_t st);
 int bn_bwd_rows(int64_t pixels, int C);
 void launch_bn_bwd_reduce(const void* dz, const void* z, const void* y, const float* mean, const float* rstd,
                           float* partial, int64_t pixels, int C, int act, float slope, int dtype, hipStream_t st,

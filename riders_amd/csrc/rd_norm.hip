@@ -84,7 +84,8 @@ __global__ __launch_bounds__(256) void affine_act_kernel(const T* __restrict__ y
 #pragma unroll
       for (int e = 0; e < 4; e++) {
         float s = scale ? scale[c + e] : 1.f, b = shift ? shift[c + e] : 0.f;
-        v[e] = act_fwd(v[e] * s + b + r[e], act, slope);
+        const float u = v[e] * s + b;
+        v[e] = act_fwd(res ? u + r[e] : u, act, slope);
       }
       st4(out + (i << 2), v);
     }
@@ -92,8 +93,8 @@ __global__ __launch_bounds__(256) void affine_act_kernel(const T* __restrict__ y
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += stride) {
       int c = (int)(i % C);
       float s = scale ? scale[c] : 1.f, b = shift ? shift[c] : 0.f;
-      float x = Elem<T>::ld(y + i) * s + b + (res ? Elem<T>::ld(res + i) : 0.f);
-      Elem<T>::st(out + i, act_fwd(x, act, slope));
+      const float u = Elem<T>::ld(y + i) * s + b;
+      Elem<T>::st(out + i, act_fwd(res ? u + Elem<T>::ld(res + i) : u, act, slope));
     }
   }
 }
@@ -247,7 +248,38 @@ __global__ __launch_bounds__(256) void affine_act_vec_kernel(const T* __restrict
     ldv(y + i * VE, v);
     if (HAS_RES) ldv(res + i * VE, r);
 #pragma unroll
-    for (int e = 0; e < VE; e++) v[e] = act_fwd(v[e] * sc[e] + sh[e] + (HAS_RES ? r[e] : 0.f), actv, slope);
+    for (int e = 0; e < VE; e++) {      // without a residual exactly bn_apply1 (rd_conv_common.h): consumers that apply BatchNorm while staging reproduce z bit for bit
+      const float u = v[e] * sc[e] + sh[e];
+      v[e] = act_fwd(HAS_RES ? u + r[e] : u, actv, slope);
+    }
+    stv(out + i * VE, v);
+  }
+}
+
+// out = act2(round(act1(scale * y + shift)) + res): the BatchNorm apply + activation of a residual block's second convolution
+// (utils/net_utils.py:309-321: conv2 is a conv -> BatchNorm -> act module) fused with the block's add + activation (:323).  The inner
+// value is rounded to the activation type exactly where rd_affine_act would have stored it, so the result equals the two-pass form.
+template <typename T, int ACT1, int ACT2>
+__global__ __launch_bounds__(256) void affine_act_add_vec_kernel(const T* __restrict__ y, const float* __restrict__ scale,
+                                                                 const float* __restrict__ shift, const T* __restrict__ res,
+                                                                 T* __restrict__ out, int64_t nvec, int C, int act1, float slope1, int act2, float slope2) {
+  constexpr int VE = Elem<T>::VE;
+  const int a1 = ACT1 >= 0 ? ACT1 : act1, a2 = ACT2 >= 0 ? ACT2 : act2;
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int c0 = (int)((i * VE) % C);
+  float sc[VE], sh[VE];
+#pragma unroll
+  for (int e = 0; e < VE; e++) { sc[e] = scale[c0 + e]; sh[e] = shift[c0 + e]; }
+  for (; i < nvec; i += stride) {
+    float v[VE], r[VE];
+    ldv(y + i * VE, v);
+    ldv(res + i * VE, r);
+#pragma unroll
+    for (int e = 0; e < VE; e++) {
+      const float z = Elem<T>::rnd(act_fwd(v[e] * sc[e] + sh[e], a1, slope1));
+      v[e] = act_fwd(z + r[e], a2, slope2);
+    }
     stv(out + i * VE, v);
   }
 }
@@ -380,8 +412,8 @@ __global__ __launch_bounds__(256) void affine_act_gen_kernel(const T* __restrict
     if (HAS_RES) { ldv(res + o0, r0); ldv(res + o1, r1); }
 #pragma unroll
     for (int e = 0; e < VE; e++) {
-      v0[e] = act_fwd(v0[e] * sc[e] + sh[e] + (HAS_RES ? r0[e] : 0.f), actv, slope);
-      v1[e] = act_fwd(v1[e] * sc[e] + sh[e] + (HAS_RES ? r1[e] : 0.f), actv, slope);
+      { const float u = v0[e] * sc[e] + sh[e]; v0[e] = act_fwd(HAS_RES ? u + r0[e] : u, actv, slope); }
+      { const float u = v1[e] * sc[e] + sh[e]; v1[e] = act_fwd(HAS_RES ? u + r1[e] : u, actv, slope); }
     }
     stv(out + o0, v0); stv(out + o1, v1);
   }
@@ -391,7 +423,7 @@ __global__ __launch_bounds__(256) void affine_act_gen_kernel(const T* __restrict
     ldv(y + o, v);
     if (HAS_RES) ldv(res + o, r);
 #pragma unroll
-    for (int e = 0; e < VE; e++) v[e] = act_fwd(v[e] * sc[e] + sh[e] + (HAS_RES ? r[e] : 0.f), actv, slope);
+    for (int e = 0; e < VE; e++) { const float u = v[e] * sc[e] + sh[e]; v[e] = act_fwd(HAS_RES ? u + r[e] : u, actv, slope); }
     stv(out + o, v);
   }
 }
@@ -644,6 +676,18 @@ void launch_affine_act(const void* y, const float* scale, const float* shift, co
   if (dtype == 0) { if (v4) RD_AA(float, true); else RD_AA(float, false); }
   else { if (v4) RD_AA(bf16_t, true); else RD_AA(bf16_t, false); }
 #undef RD_AA
+}
+
+bool affine_act_add_ok(int C, int dtype) { return vec_ok(C, dtype); }
+void launch_affine_act_add(const void* y, const float* scale, const float* shift, int act1, float slope1, const void* res, void* out,
+                           int64_t pixels, int C, int act2, float slope2, int dtype, hipStream_t st) {
+  const int64_t nvec = pixels * C / (dtype == 0 ? 4 : 8);
+  const unsigned gv = ew_grid(nvec);
+  act_dispatch(act1 == act2 ? act1 : -1, [&](auto ac) {      // (residual blocks use one activation for both)
+    constexpr int A = decltype(ac)::value;
+    if (dtype == 0) hipLaunchKernelGGL((affine_act_add_vec_kernel<float, A, A>), dim3(gv), dim3(256), 0, st, (const float*)y, scale, shift, (const float*)res, (float*)out, nvec, C, act1, slope1, act2, slope2);
+    else hipLaunchKernelGGL((affine_act_add_vec_kernel<bf16_t, A, A>), dim3(gv), dim3(256), 0, st, (const bf16_t*)y, scale, shift, (const bf16_t*)res, (bf16_t*)out, nvec, C, act1, slope1, act2, slope2);
+  });
 }
 
 int bn_bwd_rows(int64_t pixels, int C) { return red_rows(pixels, C); }

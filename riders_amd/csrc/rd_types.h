@@ -14,6 +14,14 @@ struct ConvArgs {
   int M, K, Kpad, ups;
   int pool2;   // data gradient of an exact 2x nearest up-sampling layer: 2x2 output blocks are summed and stored at half resolution
   const void* add1;   // optional [M][Cout] tensor added to the result before rounding (a gradient's earlier contribution); D1 == Cout only
+  // consumer-side BatchNorm apply (round 4): src1 is the PRODUCER's raw convolution output y; the staging gather computes
+  // act(in_scale[c] * y + in_shift[c]) per element (rounded to the activation type: bit-identical to rd_affine_act's z) -- the activated
+  // tensor is never written.  Padding stays zero; src2 (the skip half of a concat) is read as it is.  nullptr: src1 is read as it is.
+  const float* in_scale; const float* in_shift; int in_act; float in_slope;
+  // BatchNorm-backward statistics epilogue (round 4, data gradients): dst1 is dz of a BatchNorm-ed producer whose raw output is bn_y
+  // ([M][D1], the layout of dst1); `stats` then receives per-block (sum g, sum g * xhat) rows, g = dz * act'(bn_scale*y + bn_shift),
+  // xhat = (y - bn_mean) * bn_rstd, over the STORED (rounded) dz -- what rd_bn_act_bwd_recompute's reduce pass would compute.
+  const void* bn_y; const float *bn_scale, *bn_shift, *bn_mean, *bn_rstd; int bn_act; float bn_slope;
 };
 
 struct WgradArgs {
@@ -21,6 +29,7 @@ struct WgradArgs {
   int N, Hin, Win, C1, C2, H1, W1, Cout, KH, KW, stride, pad, OH, OW;
   float scale_h, scale_w;
   int M, K, ups, nsplit, rows_per_split;
+  const float* in_scale; const float* in_shift; int in_act; float in_slope;   // consumer-side BatchNorm apply on src1 (see ConvArgs)
 };
 
 struct LwgGemm { const void* x1; const void* x2; const void* dy; float* slab; int M, C1, C2, Cout, nsplit, rows_per_split; };

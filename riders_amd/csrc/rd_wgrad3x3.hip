@@ -34,7 +34,9 @@ namespace rd {
 // 16-byte staging stores are conflict free too.
 // NWV waves per block: 4, or 8 for the wide slices (each wave then owns 4-5 instead of 9 column tiles: 40 instead of 72 accumulator
 // registers and half the staging registers -> four waves per SIMD instead of two for a kernel that is issue bound per wave)
-template <int CTI, int RT, int TW, int NWV = 4>
+// AFF: source 1 is a BatchNorm-ed producer's RAW output; scale / shift + activation are applied when the patch is written to LDS
+// (WgradArgs::in_scale) -- the x operand of the gradient is the activated tensor the forward convolution saw, which is never stored.
+template <int CTI, int RT, int TW, int NWV = 4, bool AFF = false>
 __global__ __launch_bounds__(64 * NWV, NWV == 8 ? (RT >= 4 ? 2 : 4) : ((CTI * RT <= 2) ? 4 : 2)) void conv3x3_wgrad_tr_kernel(WgradArgs a, int tilesH, int tilesW, int nci) {
   constexpr int NT = 64 * NWV;
   typedef bf16_t T;
@@ -61,6 +63,9 @@ __global__ __launch_bounds__(64 * NWV, NWV == 8 ? (RT >= 4 ? 2 : 4) : ((CTI * RT
   // wide layers: blockIdx.y picks a (CIN input channels) x (COP output channels) slice of the gradient; every slice walks all tiles
   const int ci0 = ((int)blockIdx.y % nci) * CIN, co0 = ((int)blockIdx.y / nci) * COP;
   const int CinT = a.C1 + a.C2;
+  __shared__ __attribute__((aligned(16))) float sAff[AFF ? 2 * CIN : 1];      // (scale, shift) of this slice's input channels
+  if (AFF) affine_fill(sAff, a.in_scale, a.in_shift, ci0, CIN, a.C1, t, NT);
+  const bool aff_lane = AFF && ci0 + (t % XS) * 8 < a.C1;      // NT % XS == 0: all x slots of a thread carry the same eight channels
 
   // persistent tile walk: XCD x owns a contiguous range of tiles (halo pixels shared by neighbouring tiles stay in its L2)
   const int ntiles = a.N * tilesH * tilesW;
@@ -125,14 +130,16 @@ __global__ __launch_bounds__(64 * NWV, NWV == 8 ? (RT >= 4 ? 2 : 4) : ((CTI * RT
     ypk[i] = (py << 8) | px | ((idx < NYS && co0 + sl * 8 < a.Cout) ? 1 << 16 : 0) | (sl << 20);
   }
   const int Hp = a.ups ? a.H1 : a.Hin, Wp = a.ups ? a.W1 : a.Win;
-  auto fetch = [&](TC tc, uint4 (&rx)[XIT], uint4 (&ry)[YIT]) RD_INLINE_LAMBDA {
+  auto fetch = [&](TC tc, uint4 (&rx)[XIT], uint4 (&ry)[YIT], unsigned& okm) RD_INLINE_LAMBDA {
     const int n = tc.n;
     const int oh0 = tc.th * TH, ow0 = tc.tw * TW;
+    okm = 0;
 #pragma unroll
     for (int i = 0; i < XIT; i++) {
       uint4 v = make_uint4(0, 0, 0, 0);
       const int ih = oh0 - 1 + ((xpk[i] >> 8) & 0xff), iw = ow0 - 1 + (xpk[i] & 0xff);
       if ((xpk[i] >> 17) && (unsigned)ih < (unsigned)a.Hin && (unsigned)iw < (unsigned)a.Win) {
+        if (AFF) okm |= 1u << i;
         int hs = ih, ws = iw;
         if (a.ups) {  // F.interpolate(mode='nearest') source index, ATen float formula (as conv_src_ptr)
           hs = min((int)floorf((float)ih * a.scale_h), a.H1 - 1);
@@ -164,11 +171,20 @@ __global__ __launch_bounds__(64 * NWV, NWV == 8 ? (RT >= 4 ? 2 : 4) : ((CTI * RT
       ry[i] = v;
     }
   };
-  auto stash = [&](int buf, const uint4 (&rx)[XIT], const uint4 (&ry)[YIT]) RD_INLINE_LAMBDA {
+  auto stash = [&](int buf, const uint4 (&rx)[XIT], const uint4 (&ry)[YIT], unsigned okm) RD_INLINE_LAMBDA {
+    float sc[8], sh[8];
+    if (AFF) {
+#pragma unroll
+      for (int e = 0; e < 8; e++) { sc[e] = sAff[(t % XS) * 8 + e]; sh[e] = sAff[CIN + (t % XS) * 8 + e]; }
+    }
 #pragma unroll
     for (int i = 0; i < XIT; i++) {
       const int idx = t + NT * i, pp = idx / XS, sl = idx - pp * XS;
-      if (idx < NXS) *reinterpret_cast<uint4*>(&sX[buf][(sl >> 1) * XPSB + pp * 32 + (sl & 1) * 16]) = rx[i];
+      if (idx < NXS) {
+        uint4 v = rx[i];
+        if (AFF) { const uint4 z = affine16((const T*)nullptr, v, sc, sh, a.in_act, a.in_slope); if (aff_lane && ((okm >> i) & 1u)) v = z; }
+        *reinterpret_cast<uint4*>(&sX[buf][(sl >> 1) * XPSB + pp * 32 + (sl & 1) * 16]) = v;
+      }
     }
 #pragma unroll
     for (int i = 0; i < YIT; i++) {
@@ -293,29 +309,32 @@ __global__ __launch_bounds__(64 * NWV, NWV == 8 ? (RT >= 4 ? 2 : 4) : ((CTI * RT
   constexpr bool DEEP = (XIT + YIT) <= RD_WGRAD_DEEP_MAX && (RD_WGRAD_DEEP16 || !(CTI == 4 && NWV == 4 && TW == 16 && RD_WGRAD_SHARE >= 2));
   uint4 xa[XIT], ya_[YIT], xb_[DEEP ? XIT : 1], yb_[DEEP ? YIT : 1];
   int buf = 0;
+  unsigned ma = 0, mb = 0;      // validity bits of the staged x slots (AFF: padding stays zero behind the affine map)
   if (DEEP) {
     int t0 = tile, t1 = tile + G8;
     TC c1 = advance(decode(t0));
-    if (t0 < tend) fetch(decode(t0), xa, ya_);
-    if (t1 < tend) fetch(c1, reinterpret_cast<uint4 (&)[XIT]>(xb_), reinterpret_cast<uint4 (&)[YIT]>(yb_));
+    if (t0 < tend) fetch(decode(t0), xa, ya_, ma);
+    if (t1 < tend) fetch(c1, reinterpret_cast<uint4 (&)[XIT]>(xb_), reinterpret_cast<uint4 (&)[YIT]>(yb_), mb);
+    if (AFF) __syncthreads();      // the coefficient copy is complete
     while (t0 < tend) {
-      stash(buf, xa, ya_);
+      stash(buf, xa, ya_, ma);
       __syncthreads();
-      { const int t2 = t1 + G8; c1 = advance(c1); if (t2 < tend) fetch(c1, xa, ya_); tile_body(buf); t0 = t1; t1 = t2; buf ^= 1; }
+      { const int t2 = t1 + G8; c1 = advance(c1); if (t2 < tend) fetch(c1, xa, ya_, ma); tile_body(buf); t0 = t1; t1 = t2; buf ^= 1; }
       if (t0 >= tend) break;
-      stash(buf, reinterpret_cast<const uint4 (&)[XIT]>(xb_), reinterpret_cast<const uint4 (&)[YIT]>(yb_));
+      stash(buf, reinterpret_cast<const uint4 (&)[XIT]>(xb_), reinterpret_cast<const uint4 (&)[YIT]>(yb_), mb);
       __syncthreads();
-      { const int t2 = t1 + G8; c1 = advance(c1); if (t2 < tend) fetch(c1, reinterpret_cast<uint4 (&)[XIT]>(xb_), reinterpret_cast<uint4 (&)[YIT]>(yb_)); tile_body(buf); t0 = t1; t1 = t2; buf ^= 1; }
+      { const int t2 = t1 + G8; c1 = advance(c1); if (t2 < tend) fetch(c1, reinterpret_cast<uint4 (&)[XIT]>(xb_), reinterpret_cast<uint4 (&)[YIT]>(yb_), mb); tile_body(buf); t0 = t1; t1 = t2; buf ^= 1; }
     }
   } else {
     TC c0 = decode(tile);
-    if (tile < tend) fetch(c0, xa, ya_);
+    if (tile < tend) fetch(c0, xa, ya_, ma);
+    if (AFF) __syncthreads();      // the coefficient copy is complete
     while (tile < tend) {
-      stash(buf, xa, ya_);
+      stash(buf, xa, ya_, ma);
       __syncthreads();
       const int next = tile + G8;
       c0 = advance(c0);
-      if (next < tend) fetch(c0, xa, ya_);
+      if (next < tend) fetch(c0, xa, ya_, ma);
       tile_body(buf);
       tile = next;
       buf ^= 1;
@@ -566,6 +585,7 @@ bool wgrad3x3_tr_ok(const WgradArgs& a, int dtype) {
   const double eff = (double)a.OH * a.OW / (double)(cdiv(a.OH, 8) * 8 * cdiv(a.OW, tw) * tw);
   return eff >= 0.6;
 }
+bool wgrad3x3_tr_affine_ok(const WgradArgs& a, int dtype) { return wgrad3x3_tr_ok(a, dtype) && !tr_linear(a); }   // (the opt-in linear-tiled kernel reads src1 as it is)
 static void tr_slices(const WgradArgs& a, int& cti, int& rt, int& nci, int& nco) {
   const int Cin = a.C1 + a.C2;
   cti = Cin >= 64 ? 4 : Cin / 16;
@@ -601,7 +621,7 @@ const char* wgrad3x3_tr_name(const WgradArgs& a) {
   int cti, rt, nci, nco;
   tr_slices(a, cti, rt, nci, nco);
   if (tr_linear(a)) snprintf(buf, sizeof(buf), "conv3x3_wgrad_lin_kernel<%d, %d>", cti, rt);
-  else snprintf(buf, sizeof(buf), "conv3x3_wgrad_tr_kernel<%d, %d, %d, 4>", cti, rt, tr_tw(a));
+  else snprintf(buf, sizeof(buf), "conv3x3_wgrad_tr_kernel<%d, %d, %d, 4, %s>", cti, rt, tr_tw(a), a.in_scale ? "true" : "false");
   return buf;
 }
 void launch_wgrad3x3_tr(const WgradArgs& a, hipStream_t st) {
@@ -618,8 +638,11 @@ void launch_wgrad3x3_tr(const WgradArgs& a, hipStream_t st) {
   }
   const int tw = tr_tw(a);
   const int tilesH = (int)cdiv(a.OH, 8), tilesW = (int)cdiv(a.OW, tw);
+  const bool aff = a.in_scale != nullptr;
 #define RD_TR(CTIV, RTV, TWV) \
-  if (cti == CTIV && rt == RTV && tw == TWV) hipLaunchKernelGGL((conv3x3_wgrad_tr_kernel<CTIV, RTV, TWV>), grid, dim3(256), 0, st, a, tilesH, tilesW, nci);
+  if (cti == CTIV && rt == RTV && tw == TWV) { \
+    if (aff) hipLaunchKernelGGL((conv3x3_wgrad_tr_kernel<CTIV, RTV, TWV, 4, true>), grid, dim3(256), 0, st, a, tilesH, tilesW, nci); \
+    else hipLaunchKernelGGL((conv3x3_wgrad_tr_kernel<CTIV, RTV, TWV>), grid, dim3(256), 0, st, a, tilesH, tilesW, nci); }
   RD_TR(1, 1, 8) RD_TR(1, 1, 16) RD_TR(1, 1, 32) RD_TR(1, 2, 8) RD_TR(1, 2, 16) RD_TR(1, 2, 32)
   RD_TR(2, 1, 8) RD_TR(2, 1, 16) RD_TR(2, 1, 32) RD_TR(2, 2, 8) RD_TR(2, 2, 16) RD_TR(2, 2, 32)
   RD_TR(4, 1, 8) RD_TR(4, 1, 16) RD_TR(4, 2, 8) RD_TR(4, 2, 16)

@@ -24,7 +24,19 @@ _RD_DT = {torch.float32: RD_F32, torch.bfloat16: RD_BF16, torch.float16: RD_F16}
 
 _state = {"dtype": RD_F32, "tape": None, "defer_wgrad": True, "fused_loftr": True, "deterministic_roi_pool": False, "roi_tile_min_blocks": 256,
           "fuse_upsample_bwd": os.environ.get("RIDERS_FUSE_UPSAMPLE_BWD", "1") != "0",     # A/B switch of the 2x2-summing data gradient
-          "fuse_grad_add": os.environ.get("RIDERS_FUSE_GRAD_ADD", "1") != "0"}     # A/B switch: second gradient contribution added in the data-gradient epilogue
+          "fuse_grad_add": os.environ.get("RIDERS_FUSE_GRAD_ADD", "1") != "0",     # A/B switch: second gradient contribution added in the data-gradient epilogue
+          # A/B switch (round 4): conv -> BatchNorm -> activation outputs stay virtual (LazyAct) and the consumer applies scale / shift /
+          # activation while staging its input; 0 restores the separate rd_affine_act pass everywhere
+          "lazy_bn": os.environ.get("RIDERS_LAZY_BN", "1") != "0"}
+
+
+# how often a virtual activation was consumed in place / had to be written after all (tests assert that the fused routes are taken)
+lazy_counts = {"fwd_fused": 0, "wgrad_fused": 0, "add_fused": 0, "materialized": 0, "bn_bwd_fused": 0}
+
+
+def set_lazy_bn(flag):
+    """Consumer-side BatchNorm apply (LazyAct) on / off; results are bit-identical either way (tests compare the two)."""
+    _state["lazy_bn"] = bool(flag)
 
 
 def set_roi_tile_min_blocks(n):
@@ -667,6 +679,47 @@ def refresh_packed():
     _chk(L().rd_conv_pack_weights_batch_half(_p(_pack_table["dev"]), _pack_table["n"], half, _stream(w0)), "rd_conv_pack_weights_batch_half")
 
 
+# ------------------------------------------------------------------------------------------ virtual activations
+class LazyAct(object):
+    """z = act(scale[c] * y + shift[c]) of a BatchNorm-ed convolution that is NOT written to HBM: the raw convolution output `y`, the
+    per-channel coefficients of rd_bn_finalize and the activation code (reference: utils/net_utils.py:84-91 conv -> BatchNorm2d -> act).
+    conv_block (forward staging and weight-gradient staging of the 3x3 kernels) and add_act apply the map while they read y -- rounded
+    exactly as rd_affine_act would have stored z, so every result is bit-identical to the materialised path -- and `materialize()` writes
+    z (once) for any consumer or kernel route that cannot.  The object itself is the tape key of z: gradients are added to it and the
+    producing conv_block pops them."""
+    __slots__ = ("y", "coef", "act", "slope", "_z", "__weakref__")
+
+    def __init__(self, y, coef, act, slope):
+        self.y, self.coef, self.act, self.slope, self._z = y, coef, act, float(slope), None
+
+    shape = property(lambda self: self.y.shape)
+    dtype = property(lambda self: self.y.dtype)
+    device = property(lambda self: self.y.device)
+
+    def fusion(self):
+        f = _lib.ConvFusion()
+        f.in_scale, f.in_shift, f.in_act, f.in_slope = self.coef[0].data_ptr(), self.coef[1].data_ptr(), self.act, self.slope
+        return f
+
+    def materialize(self):
+        if self._z is None:
+            lazy_counts["materialized"] += 1
+            y = self.y
+            C = y.shape[-1]
+            z = torch.empty_like(y)
+            nb = y.numel() * y.element_size()
+            _chk(_tb("bn_apply", 2 * nb, lambda: L().rd_affine_act(_p(y), _p(self.coef[0]), _p(self.coef[1]), None, _p(z), y.numel() // C, C, self.act,
+                                                                    self.slope, rd_of(y), _stream(y)), "bn apply+act M=%d C=%d" % (y.numel() // C, C)),
+                 "rd_affine_act")
+            self._z = z
+        return self._z
+
+
+def materialize(x):
+    """LazyAct -> its activated tensor (written on first use); tensors pass through."""
+    return x.materialize() if isinstance(x, LazyAct) else x
+
+
 # ------------------------------------------------------------------------------------------ conv block
 def _desc(dt, N, Hin, Win, C1, C2, up, H1, W1, Cout, KH, KW, stride, pad, dil, OH, OW, act, slope, D1):
     d = ConvDesc()
@@ -678,15 +731,21 @@ def _desc(dt, N, Hin, Win, C1, C2, up, H1, W1, Cout, KH, KW, stride, pad, dil, O
 
 
 def conv_block(x, weight, *, x2=None, bias=None, stride=1, pad=None, up=None, bn=None, act=ACT_NONE, slope=0.2,
-               residual=None, training=True, out_hw=None):
+               residual=None, training=True, out_hw=None, lazy_out=False):
     """act(BN(conv([up(x) | up(x2)], weight) + bias) + residual) on NHWC tensors; records its own backward.
 
     x: (N,H,W,C1) [, x2: (N,H,W,C2)]; weight OIHW fp32 (nn.Linear [out,in] is treated as 1x1);
     up: (Hv, Wv) nearest-upsample target applied to the sources inside the gather;
     bn: a torch.nn.BatchNorm2d used as a parameter container (train: batch stats + running update).
+    x may be a LazyAct (the un-materialised output of a BatchNorm-ed conv_block): the kernels apply its scale / shift / activation while
+    staging; lazy_out=True returns this layer's output as a LazyAct (callers whose consumers are conv_block / add_act).
     """
     lib = L()
     t = tape()
+    xk = x                      # tape key of the first source (the LazyAct itself when the input is virtual)
+    lz = x if isinstance(x, LazyAct) else None
+    if lz is not None:
+        x = lz.y
     dt = rd_of(x)
     st = _stream(x)
     N, H1, W1, C1 = x.shape
@@ -710,7 +769,7 @@ def conv_block(x, weight, *, x2=None, bias=None, stride=1, pad=None, up=None, bn
     # the vector / MFMA-bf16 kernels instead of the scalar-gather fallbacks (7x7 stem: 0.31 + 0.52 ms per RC-Net step)
     ve = 16 // x.element_size()
     cin_pad = 0
-    if x2 is None and not is_up and C1 % ve != 0 and KH * KW >= 9 and not (t is not None and t.requires(x)) and not lib.rd_conv_fwd_streams(
+    if x2 is None and not is_up and C1 % ve != 0 and KH * KW >= 9 and not (t is not None and t.requires(xk)) and not lib.rd_conv_fwd_streams(
             ctypes.byref(_desc(dt, N, Hin, Win, C1, 0, False, H1, W1, Cout, KH, KW, stride, pad, 1, OH, OW, conv_act, slope, Cout))):
         # (layers the streaming few-channel kernels take -- SML's 3 -> 3 `first` convolution -- are handed over as they are)
         cin_pad = (C1 + ve - 1) // ve * ve
@@ -718,6 +777,12 @@ def conv_block(x, weight, *, x2=None, bias=None, stride=1, pad=None, up=None, bn
         _chk(lib.rd_pad_channels(_p(x), _p(xp), N * H1 * W1, C1, cin_pad, dt, st), "rd_pad_channels")
         x_real, x, C1_real, C1 = x, xp, C1, cin_pad
     d = _desc(dt, N, Hin, Win, C1, C2, is_up, H1, W1, Cout, KH, KW, stride, pad, 1, OH, OW, conv_act, slope, Cout)
+    fus = None
+    if lz is not None:          # virtual input: fused where the kernel this shape is routed to stages whole channel vectors, else z is written now
+        fus = lz.fusion()
+        if cin_pad or not lib.rd_conv_fusion_ok(ctypes.byref(d), ctypes.byref(fus)):
+            assert not cin_pad
+            fus, x = None, lz.materialize()
     wp = packed_weight(weight, 0, dt, cin_pad)
     y = torch.empty((N, OH, OW, Cout), dtype=x.dtype, device=x.device)
     stats = None
@@ -731,9 +796,15 @@ def conv_block(x, weight, *, x2=None, bias=None, stride=1, pad=None, up=None, bn
     es = x.element_size()   # algorithmic HBM bytes of the three convolution launches (every operand moved exactly once)
     b_in = (x.numel() + (0 if x2 is None else x2.numel())) * es
     b_w, b_out = weight.numel() * es, N * OH * OW * Cout * es
-    _chk(_timed("conv_gemm", flops, lambda: lib.rd_conv_fwd(ctypes.byref(d), _p(x), _p(x2), _p(wp), _p(bias_t), _p(y), None,
-                                                               _p(stats), st), "fwd " + shp, b_in + b_w + b_out,
-                kernel=lambda: lib.rd_conv_fwd_kernel_name(ctypes.byref(d)).decode(), idem=True), "rd_conv_fwd")
+    if fus is not None:
+        lazy_counts["fwd_fused"] += 1
+        _chk(_timed("conv_gemm", flops, lambda: lib.rd_conv_fwd_fused(ctypes.byref(d), ctypes.byref(fus), _p(x), _p(x2), _p(wp), _p(bias_t), None,
+                                                                         _p(y), None, _p(stats), st), "fwd " + shp + " (bn-in)", b_in + b_w + b_out,
+                    kernel=lambda: lib.rd_conv_fused_kernel_name(ctypes.byref(d), ctypes.byref(fus)).decode(), idem=True), "rd_conv_fwd_fused")
+    else:
+        _chk(_timed("conv_gemm", flops, lambda: lib.rd_conv_fwd(ctypes.byref(d), _p(x), _p(x2), _p(wp), _p(bias_t), _p(y), None,
+                                                                   _p(stats), st), "fwd " + shp, b_in + b_w + b_out,
+                    kernel=lambda: lib.rd_conv_fwd_kernel_name(ctypes.byref(d)).decode(), idem=True), "rd_conv_fwd")
     pixels = N * OH * OW
     scale = shift = mean = rstd = None
     if use_bn:
@@ -746,25 +817,31 @@ def conv_block(x, weight, *, x2=None, bias=None, stride=1, pad=None, up=None, bn
                                             float(bn.momentum if bn.momentum is not None else 0.1), 1 if bn_train else 0,
                                             _p(bn.running_mean), _p(bn.running_var), _p(mean), _p(rstd), _p(scale), _p(shift), st),
                  "bn finalize C=%d" % Cout), "rd_bn_finalize")
-    if use_bn or residual is not None:
+    lazy = None
+    if lazy_out and use_bn and residual is None and _state["lazy_bn"] and _BN_RECOMPUTE and Cout % ve == 0:
+        z = None
+        lazy = LazyAct(y, coef, act, slope)      # z stays virtual: the consumer applies (scale, shift, act) while it stages y
+    elif use_bn or residual is not None:
         z = torch.empty_like(y)
         _chk(_tb("bn_apply", (2 + (residual is not None)) * b_out,
                  lambda: lib.rd_affine_act(_p(y), _p(scale), _p(shift), _p(residual), _p(z), pixels, Cout, act, slope, dt, st),
                  "bn apply+act M=%d C=%d" % (pixels, Cout)), "rd_affine_act")
     else:
         z = y
+    zk = lazy if lazy is not None else z      # what the caller receives = the tape key of this layer's output
     if t is None:
-        return z
+        return zk
 
-    need_in = t.requires(x, x2)
+    need_in = t.requires(xk, x2)
     need_res = t.requires(residual)
     w_req = weight.requires_grad
     if not (need_in or need_res or w_req or (use_bn and bn.weight is not None and bn.weight.requires_grad)):
-        return z
-    t.mark(z)
+        return zk
+    t.mark(zk)
 
     def backward():
-        dz = t.pop_grad(z)
+        nonlocal x
+        dz = t.pop_grad(zk)
         if dz is None:
             return
         dres = None
@@ -813,6 +890,12 @@ def conv_block(x, weight, *, x2=None, bias=None, stride=1, pad=None, up=None, bn
             else:
                 _chk(lib.rd_colsum(_p(dy), _p(part), _p(db), acc, pixels, Cout, dt, st), "rd_colsum")
         ve = 16 // es
+        wfus = None
+        if w_req and fus is not None:       # the weight gradient's x operand is the virtual z too: fused where its kernel can, else z is written now
+            if _state["defer_wgrad"] and not (KH == 1 and KW == 1) and lib.rd_conv_wgrad_fusion_ok(ctypes.byref(d), ctypes.byref(fus)):
+                wfus = fus
+            else:
+                x = lz.materialize()
         if w_req and KH == 1 and KW == 1 and stride == 1 and not is_up and _state["defer_wgrad"] and C1 % ve == 0 and Cout % ve == 0 \
                 and (C2 == 0 or (C1 % 64 == 0 and C2 % ve == 0)):
             t.deferred.append(dict(x=x, x2=x2, dy=dy, weight=weight, M=pixels, C1=C1, C2=C2, Cin=Cin, Cout=Cout, flops=flops))
@@ -834,10 +917,17 @@ def conv_block(x, weight, *, x2=None, bias=None, stride=1, pad=None, up=None, bn
                 if id(weight) in t.conv_reduce_w:      # a weight used twice: its two reductions must not share a launch
                     t.flush_conv_reduce()
                 item = _lib.WgradReduceItem()
-                _chk(_timed("conv_wgrad", flops, lambda: lib.rd_conv_wgrad_partial(ctypes.byref(d), _p(x), _p(x2), _p(dy), _p(ws), _p(dw), acc,
-                                                                                      ctypes.byref(item), st),
-                            "wgrad " + shp, b_in + b_out + weight.numel() * 4,
-                            kernel=lambda: lib.rd_conv_wgrad_kernel_name(ctypes.byref(d)).decode(), idem=True), "rd_conv_wgrad_partial")
+                if wfus is not None:
+                    lazy_counts["wgrad_fused"] += 1
+                    _chk(_timed("conv_wgrad", flops, lambda: lib.rd_conv_wgrad_partial_fused(ctypes.byref(d), ctypes.byref(wfus), _p(x), _p(x2), _p(dy),
+                                                                                                _p(ws), _p(dw), acc, ctypes.byref(item), st),
+                                "wgrad " + shp + " (bn-in)", b_in + b_out + weight.numel() * 4,
+                                kernel=lambda: lib.rd_conv_wgrad_fused_kernel_name(ctypes.byref(d), ctypes.byref(wfus)).decode(), idem=True), "rd_conv_wgrad_partial_fused")
+                else:
+                    _chk(_timed("conv_wgrad", flops, lambda: lib.rd_conv_wgrad_partial(ctypes.byref(d), _p(x), _p(x2), _p(dy), _p(ws), _p(dw), acc,
+                                                                                          ctypes.byref(item), st),
+                                "wgrad " + shp, b_in + b_out + weight.numel() * 4,
+                                kernel=lambda: lib.rd_conv_wgrad_kernel_name(ctypes.byref(d)).decode(), idem=True), "rd_conv_wgrad_partial")
                 t.defer_conv_reduce(item, ws, weight)
             else:
                 _chk(_timed("conv_wgrad", flops, lambda: lib.rd_conv_wgrad(ctypes.byref(d), _p(x), _p(x2), _p(dy), _p(ws), _p(dw), acc, st),
@@ -857,19 +947,19 @@ def conv_block(x, weight, *, x2=None, bias=None, stride=1, pad=None, up=None, bn
                 _chk(_timed("conv_gemm", flops, lambda: lib.rd_conv_fwd(ctypes.byref(dd), _p(dy), None, _p(wpd), None, _p(g1), None, None, st),
                             "dgrad " + shp + " (2x2 summed)", b_out + b_w + g1.numel() * es,
                             kernel=lambda: lib.rd_conv_fwd_kernel_name(ctypes.byref(dd)).decode(), idem=True), "rd_conv_fwd(dgrad, out_reduce2)")
-                t.add_grad(x, g1)
+                t.add_grad(xk, g1)
                 return
             dxv1 = torch.empty((N, Hin, Win, C1), dtype=x.dtype, device=x.device)
             dxv2 = torch.empty((N, Hin, Win, C2), dtype=x.dtype, device=x.device) if C2 else None
             # x already holds a gradient contribution (a skip connection's decoder side, a residual shortcut): the kernel adds it in its
             # epilogue and the sum replaces it -- no second tensor, no separate add pass
-            cur = t.grads.get(id(x)) if (C2 == 0 and not is_up and _state.get("fuse_grad_add", True) and id(x) in t.req) else None
+            cur = t.grads.get(id(xk)) if (C2 == 0 and not is_up and _state.get("fuse_grad_add", True) and id(xk) in t.req) else None
             if cur is not None and cur.shape == dxv1.shape and cur.dtype == dxv1.dtype and cur.is_contiguous() \
                     and lib.rd_conv_add_ok(ctypes.byref(dd)):
                 _chk(_timed("conv_gemm", flops, lambda: lib.rd_conv_fwd_add(ctypes.byref(dd), _p(dy), None, _p(wpd), None, _p(cur), _p(dxv1), st),
                             "dgrad " + shp + " (+grad)", b_out + b_w + 2 * N * Hin * Win * Cin * es,
                             kernel=lambda: lib.rd_conv_fwd_kernel_name(ctypes.byref(dd)).decode(), idem=True), "rd_conv_fwd_add(dgrad)")
-                t.grads[id(x)] = dxv1
+                t.grads[id(xk)] = dxv1
                 return
             _chk(_timed("conv_gemm", flops, lambda: lib.rd_conv_fwd(ctypes.byref(dd), _p(dy), None, _p(wpd), None, _p(dxv1), _p(dxv2),
                                                                        None, st), "dgrad " + shp, b_out + b_w + N * Hin * Win * Cin * es,
@@ -887,11 +977,11 @@ def conv_block(x, weight, *, x2=None, bias=None, stride=1, pad=None, up=None, bn
                          "rd_upsample_nearest_bwd")
             else:
                 g1, g2 = dxv1, dxv2
-            t.add_grad(x, g1)
+            t.add_grad(xk, g1)
             t.add_grad(x2, g2)
 
     t.record(backward)
-    return z
+    return zk
 
 
 def linear(x, weight, *, x2=None, bias=None, act=ACT_NONE, slope=0.2):
@@ -1254,12 +1344,31 @@ def output_cast(x, dtype):
 
 def add_act(a, b, act=ACT_NONE, slope=0.2):
     """act(a + b) on same-shape NHWC tensors (ResNet block tail, utils/net_utils.py:323)."""
-    lib, t, dt, st = L(), tape(), rd_of(a), _stream(a)
-    C = a.shape[-1]
-    out = torch.empty_like(a)
-    _chk(_tb("elementwise", 3 * a.numel() * a.element_size(),
-             lambda: lib.rd_affine_act(_p(a), None, None, _p(b), _p(out), a.numel() // C, C, act, slope, dt, st), "add+act"), "rd_affine_act")
-    if t is not None and t.requires(a, b):
+    ak = a                      # tape key of the first operand (a LazyAct stays the key of its z)
+    if isinstance(a, LazyAct):  # act(act1(scale*y + shift) + b) in one pass over y and b: z is never written
+        lz = a
+        if isinstance(b, LazyAct):
+            b = b.materialize()
+        y = lz.y
+        dt, st, C = rd_of(y), _stream(y), y.shape[-1]
+        if L().rd_affine_act_add_ok(C, dt):
+            lib, t = L(), tape()
+            lazy_counts["add_fused"] += 1
+            out = torch.empty_like(y)
+            _chk(_tb("elementwise", 3 * y.numel() * y.element_size(),
+                     lambda: lib.rd_affine_act_add(_p(y), _p(lz.coef[0]), _p(lz.coef[1]), lz.act, lz.slope, _p(b), _p(out), y.numel() // C, C, act, slope,
+                                                   dt, st), "bn apply+act+add+act"), "rd_affine_act_add")
+            a = None
+        else:
+            a = lz.materialize()
+    b = materialize(b)
+    if a is not None:
+        lib, t, dt, st = L(), tape(), rd_of(a), _stream(a)
+        C = a.shape[-1]
+        out = torch.empty_like(a)
+        _chk(_tb("elementwise", 3 * a.numel() * a.element_size(),
+                 lambda: lib.rd_affine_act(_p(a), None, None, _p(b), _p(out), a.numel() // C, C, act, slope, dt, st), "add+act"), "rd_affine_act")
+    if t is not None and t.requires(ak, b):
         t.mark(out)
 
         def backward():
@@ -1271,7 +1380,7 @@ def add_act(a, b, act=ACT_NONE, slope=0.2):
                 _chk(lib.rd_act_bwd(_p(g), _p(out), _p(d), g.numel(), act, slope, dt, st), "rd_act_bwd")
             else:
                 d = g
-            t.add_grad(a, d)
+            t.add_grad(ak, d)
             t.add_grad(b, d)
         t.record(backward)
     return out

@@ -78,13 +78,15 @@ class Conv2d(torch.nn.Module, _BNCounter):
             self.batch_norm = torch.nn.BatchNorm2d(out_channels)
         self._bn_setup()
 
-    def _fwd(self, x, x2=None, up=None):
+    def _fwd(self, x, x2=None, up=None, lazy=False):
+        """lazy=True (callers whose consumer is another conv_block / add_act): the BatchNorm-ed output stays virtual (engine.LazyAct) and
+        the consumer applies scale / shift / activation while it stages the raw convolution output."""
         act, slope = _act_code(self.activation_func)
         bn = self.batch_norm if self.use_batch_norm else None
         if bn is not None and self.training:
             self._nbt_pending += 1
         return engine.conv_block(x, self.conv.weight, x2=x2, stride=self.conv.stride[0], pad=self.conv.padding[0], up=up,
-                                 bn=bn, act=act, slope=slope, training=self.training)
+                                 bn=bn, act=act, slope=slope, training=self.training, lazy_out=lazy)
 
     def forward(self, x):
         def run(x):
@@ -103,8 +105,8 @@ class UpConv2d(torch.nn.Module):
                            weight_initializer=weight_initializer, activation_func=activation_func,
                            use_batch_norm=use_batch_norm)
 
-    def _fwd(self, x, shape):
-        return self.conv._fwd(x, up=(int(shape[0]), int(shape[1])))
+    def _fwd(self, x, shape, lazy=False):
+        return self.conv._fwd(x, up=(int(shape[0]), int(shape[1])), lazy=lazy)
 
     def forward(self, x, shape):
         def run(x):
@@ -153,8 +155,8 @@ class ResNetBlock(torch.nn.Module):
                                  weight_initializer=weight_initializer, activation_func=None, use_batch_norm=False)
 
     def _fwd(self, x):
-        conv1 = self.conv1._fwd(x)
-        conv2 = self.conv2._fwd(conv1)
+        conv1 = self.conv1._fwd(x, lazy=True)       # consumed by conv2's staging
+        conv2 = self.conv2._fwd(conv1, lazy=True)   # consumed by the fused apply + add + activation below
         if tuple(x.shape[1:3]) != tuple(conv2.shape[1:3]) or x.shape[3] != conv2.shape[3]:
             X = self.projection._fwd(x)
         else:
@@ -187,15 +189,15 @@ class DecoderBlock(torch.nn.Module):
                            weight_initializer=weight_initializer, activation_func=activation_func,
                            use_batch_norm=use_batch_norm)
 
-    def _fwd(self, x, skip=None, shape=None):
+    def _fwd(self, x, skip=None, shape=None, lazy=False):
         if skip is not None:
             shape = tuple(skip.shape[1:3])
         elif shape is None:
             shape = (int(2 * x.shape[1]), int(2 * x.shape[2]))
-        deconv = self.deconv._fwd(x, shape)
+        deconv = self.deconv._fwd(x, shape, lazy=True)      # consumed by self.conv's staging
         if self.skip_channels > 0:
-            return self.conv._fwd(deconv, x2=skip)
-        return self.conv._fwd(deconv)
+            return self.conv._fwd(deconv, x2=skip, lazy=lazy)
+        return self.conv._fwd(deconv, lazy=lazy)
 
     def forward(self, x, skip=None, shape=None):
         ins = (x,) if skip is None else (x, skip)

@@ -287,29 +287,6 @@ def tiny_wgrad_cases(dev):
             conv_case(dev, dict(cin=3, cout=3, k=3, s=1, H=19, W=23, N=2, bn=True, no_input_grad=True), tol=4e-3)
 
 
-class force_dma_conv(force_patch_conv):
-    """Route eligible wide bf16 3x3 layers to the experimental LDS-DMA / 32x32x16-MFMA kernel (rd_conv3x3_dma.hip), any block count;
-    `mode` selects the weight staging variant (RD_DMA_MODE)."""
-    def __init__(self, mode=0, pbufs=None):
-        super().__init__()
-        self.env.update({"RD_CONV3X3_DMA": "1", "RD_DMA_MODE": str(mode)})
-        if pbufs is not None:
-            self.env["RD_DMA_PBUFS"] = str(pbufs)
-
-
-def dma_conv_cases(dev):
-    """Bit-exact bf16 cases of the experimental kernel: every tile configuration (32 / 64 / 128 channels, 16- and 8-wide tiles), one to
-    three chunks, upsample + concat gather, dual destination (data gradient of a concat input), every staging mode."""
-    shapes = [dict(cin=64, cout=32, k=3, s=1, H=9, W=17, N=1), dict(cin=32, cout=64, k=3, s=1, H=12, W=17, N=1),
-              dict(cin=64, cout=64, k=3, s=1, H=9, W=19, N=1), dict(cin=128, cout=128, k=3, s=1, H=8, W=16, N=2),
-              dict(cin=64, cout=128, k=3, s=1, N=1, up=((4, 3), (17, 6)), cin2=64), dict(cin=192, cout=96, k=3, s=1, H=9, W=10, N=1),
-              dict(cin=32, cout=64, k=3, s=1, N=1, up=((5, 4), (11, 9)), cin2=32)]     # concat boundary inside a chunk (per-lane source)
-    for mode, pbufs in ((0, None), (1, None), (2, 2)):
-        with force_dma_conv(mode, pbufs):
-            for c in shapes:
-                bf16_exact_conv_case(dev, **c)
-
-
 PATCH_CONV_CASES = [
     dict(cin=32, cout=32, k=3, s=1, H=9, W=19, N=2, bn=True),                  # 16x8 tiles, ragged in both axes; dgrad also patch-staged
     dict(cin=64, cout=160, k=3, s=1, H=17, W=7, N=1, bn=False, act=None),      # 8x16 tiles, two channel blocks, two chunks
@@ -389,6 +366,112 @@ def resnet_block_case(dev, cin=16, cout=32, stride=2, tol=TOL):
     (out * w.to(dev)).sum().backward()
     close(xd.grad, xr.grad, tol, "resnet block dx")
     compare_param_grads(m, sd, tol)
+
+
+# ------------------------------------------------------------------------------------- virtual BatchNorm outputs (round 4)
+def _lazy_both(build_and_run):
+    """build_and_run() -> list of tensors (outputs, input gradients, parameter gradients) of one forward + backward.  Runs it with the
+    consumer-side BatchNorm apply on and off (engine.set_lazy_bn) and asserts BIT-IDENTICAL results: the fused staging computes
+    act(scale * y + shift) with rd_affine_act's expression and rounding.  -> the counters of the fused run."""
+    from riders_amd import engine
+    res, counts = [], None
+    for flag in (True, False):
+        engine.set_lazy_bn(flag)
+        for k in engine.lazy_counts:
+            engine.lazy_counts[k] = 0
+        try:
+            res.append([r.detach().float().cpu().clone() for r in build_and_run()])
+        finally:
+            engine.set_lazy_bn(True)
+        if flag:
+            counts = dict(engine.lazy_counts)
+    assert len(res[0]) == len(res[1])
+    for i, (a, b) in enumerate(zip(*res)):
+        assert a.shape == b.shape and bool(torch.isfinite(a).all()), i
+        assert torch.equal(a, b), "lazy BatchNorm: tensor %d differs from the materialised path (max |diff| %.3e)" % (i, float((a - b).abs().max()))
+    return counts
+
+
+def _lazy_module_run(dev, make, inputs, call):
+    def run():
+        torch.manual_seed(0)
+        m = make().to(dev)
+        fill_state_dict(m, "lazy")
+        m.train()
+        xs = [x.clone().to(dev).requires_grad_() for x in inputs]
+        out = call(m, *xs)
+        w = q(t(rand_array("lazy.w", tuple(out.shape), 1.0))).to(dev)
+        (out * w).sum().backward()
+        return [out] + [x.grad for x in xs] + [p.grad for p in m.parameters() if p.grad is not None]
+    return run
+
+
+def lazy_bn_cases(dev, quick=False):
+    """Residual block and decoder block / decoder chain with their BatchNorm-ed intermediate tensors virtual (engine.LazyAct): forward
+    staging of the narrow-layer and register-fed 3x3 kernels, weight-gradient staging of the transpose-read kernel (bf16), the fused apply +
+    add + activation, the materialising fall-backs -- all bit-identical to the separate rd_affine_act pass, fp32 and bf16."""
+    from riders_amd import net_utils, networks
+    act = lambda: net_utils.activation_func('leaky_relu')
+    for mode in ("fp32", "bf16"):
+        ctx = bf16_mode("bf16") if mode == "bf16" else None
+        if ctx:
+            ctx.__enter__()
+        try:
+            cw = 64 if mode == "bf16" else 32      # one 128-byte channel chunk of the register-fed kernel
+            # residual block, both convolutions on the register-fed kernel (2-D tiles) / linear tiles; stride-2 block: conv1 on the implicit GEMM
+            with force_frag_conv(lin=0):
+                x = q(t(rand_array("lazy.rx", (2, cw, 15, 16), 1.0)))      # (tiles cover the map well enough for the transpose-read weight gradient)
+                c = _lazy_both(_lazy_module_run(dev, lambda: net_utils.ResNetBlock(cw, cw, 1, 'kaiming_uniform', act(), True), [x], lambda m, x: m(x)))
+                assert c["fwd_fused"] == 1 and c["add_fused"] == 1 and c["materialized"] == (0 if mode == "bf16" else 1), c      # fp32 weight gradient: no fused form
+                assert c["wgrad_fused"] == (1 if mode == "bf16" else 0), c
+            with force_frag_conv(lin=1):
+                x = q(t(rand_array("lazy.rx2", (3, cw // 2, 10, 12), 1.0)))
+                c = _lazy_both(_lazy_module_run(dev, lambda: net_utils.ResNetBlock(cw // 2, 2 * cw, 2, 'kaiming_uniform', act(), True), [x], lambda m, x: m(x)))
+                assert c["fwd_fused"] == 1 and c["add_fused"] == 1, c
+            # decoder block: up-sampled virtual input + real skip through the narrow-layer kernel; several tiles per persistent block
+            for g8 in ((None, 1) if not quick else (None,)):
+                with force_patch_conv(g8=g8):
+                    x = q(t(rand_array("lazy.dx", (2, 32, 7, 5), 1.0)))
+                    sk = q(t(rand_array("lazy.ds", (2, 16, 15, 11), 1.0)))
+                    c = _lazy_both(_lazy_module_run(dev, lambda: net_utils.DecoderBlock(32, 16, 16, 'kaiming_uniform', act(), True, 'up'), [x, sk], lambda m, x, s: m(x, s)))
+                    assert c["fwd_fused"] == 1, c
+                    x = q(t(rand_array("lazy.dx2", (2, 16, 8, 9), 1.0)))
+                    c = _lazy_both(_lazy_module_run(dev, lambda: net_utils.DecoderBlock(16, 0, 16, 'kaiming_uniform', act(), True, 'up'), [x], lambda m, x: m(x, shape=(16, 18))))
+                    assert c["fwd_fused"] == 1, c
+            if quick:
+                continue
+            # the whole decoder chain: every block's output virtual, consumed by the next up-convolution (exact 2x and ragged ratios) and the head
+            with force_patch_conv():
+                lat = q(t(rand_array("lazy.lat", (2, 2 * cw, 2, 1), 1.0)))
+                skips = [q(t(rand_array("lazy.sk%d" % i, (2, c_, h_, w_), 1.0))) for i, (c_, h_, w_) in
+                         enumerate(((16, 32, 16), (cw // 2, 16, 8), (cw // 2, 7, 4), (cw, 4, 2)))]
+                mk = lambda: networks.MultiScaleDecoder(2 * cw, 1, 1, [cw, cw // 2, cw // 2, 16, 16], [cw, cw // 2, cw // 2, 16, 0], 'kaiming_uniform', 'leaky_relu',
+                                                        'linear', True, 'up')
+                c = _lazy_both(_lazy_module_run(dev, mk, [lat] + skips, lambda m, x, *s: m(x, list(s), (64, 32))[-1]))
+                assert c["fwd_fused"] >= 8, c
+        finally:
+            if ctx:
+                ctx.__exit__()
+
+
+def lazy_bn_rcnet_geometry_case(dev):
+    """The decoder at RC-Net's RoI geometry (bf16, 24 RoIs, 240x100 patches: the kernels' default routing -- persistent narrow-layer blocks
+    with several tiles each, linear and 2-D tiles of the register-fed kernel, 16- and 8-wide weight-gradient tiles) and an encoder stage
+    (residual blocks at 124x153), virtual BatchNorm outputs on / off: bit-identical logits and gradients."""
+    from riders_amd import net_utils, networks
+    with bf16_mode("bf16"):
+        R = 24
+        lat = q(t(rand_array("lazyg.lat", (R, 256, 7, 3), 1.0)))
+        skips = [q(t(rand_array("lazyg.sk%d" % i, (R, c_, h_, w_), 1.0))) for i, (c_, h_, w_) in
+                 enumerate(((32, 120, 50), (64, 60, 25), (128, 30, 12), (128, 15, 6)))]
+        mk = lambda: networks.MultiScaleDecoder(256, 1, 1, [256, 128, 64, 32, 16], [128, 128, 64, 32, 0], 'kaiming_uniform', 'leaky_relu', 'linear', True, 'up')
+        c = _lazy_both(_lazy_module_run(dev, mk, [lat] + skips, lambda m, x, *s: m(x, list(s), (240, 100))[-1]))
+        assert c["fwd_fused"] == 10 and c["wgrad_fused"] >= 8, c
+        x = q(t(rand_array("lazyg.enc", (2, 64, 124, 153), 1.0)))
+        act = net_utils.activation_func('leaky_relu')
+        c = _lazy_both(_lazy_module_run(dev, lambda: torch.nn.Sequential(net_utils.ResNetBlock(64, 64, 1, 'kaiming_uniform', act, True),
+                                                                         net_utils.ResNetBlock(64, 128, 2, 'kaiming_uniform', act, True)), [x], lambda m, x: m(x)))
+        assert c["fwd_fused"] == 2 and c["add_fused"] == 2 and c["wgrad_fused"] == 2, c
 
 
 # -------------------------------------------------------------------------------------------- attention / LoFTR

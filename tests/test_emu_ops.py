@@ -45,6 +45,10 @@ def test_grad_add_in_data_gradient_epilogue(emu):
     P.grad_add_cases(emu)
 
 
+def test_lazy_batchnorm_is_bit_identical(emu):
+    P.lazy_bn_cases(emu)
+
+
 def test_frag_conv(emu):
     P.frag_conv_cases(emu, quick=True)
 
@@ -160,10 +164,6 @@ def test_stem_padded_channels(emu):
     P.conv_case(emu, dict(cin=3, cout=32, k=7, s=2, H=20, W=18, N=2, bn=True, no_input_grad=True))
     P.conv_case(emu, dict(cin=3, cout=32, k=3, s=2, H=15, W=14, N=1, bn=True, no_input_grad=True))
     P.conv_case(emu, dict(cin=5, cout=16, k=3, s=1, H=9, W=11, N=2, bn=False, act=None, no_input_grad=True))
-
-
-def test_experimental_dma_conv_exact(emu):
-    P.dma_conv_cases(emu)
 
 
 def test_batch_transforms(emu):

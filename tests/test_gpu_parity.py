@@ -59,8 +59,11 @@ def test_frag_conv(gpu):
     P.conv_case(gpu, dict(cin=128, cout=128, k=3, s=1, H=15, W=6, N=60, bn=True))
 
 
-def test_experimental_dma_conv_exact(gpu):
-    P.dma_conv_cases(gpu)
+def test_lazy_batchnorm_is_bit_identical(gpu):
+    """Consumer-side BatchNorm apply (engine.LazyAct): forward / weight-gradient staging of the 3x3 kernels and the fused apply + add +
+    activation give the bits of the separate rd_affine_act pass -- small shapes on every kernel route, then RC-Net's own layer sizes."""
+    P.lazy_bn_cases(gpu)
+    P.lazy_bn_rcnet_geometry_case(gpu)
 
 
 def test_decoder_block(gpu):
