@@ -25,18 +25,21 @@ _RD_DT = {torch.float32: RD_F32, torch.bfloat16: RD_BF16, torch.float16: RD_F16}
 _state = {"dtype": RD_F32, "tape": None, "defer_wgrad": True, "fused_loftr": True, "deterministic_roi_pool": False, "roi_tile_min_blocks": 256,
           "fuse_upsample_bwd": os.environ.get("RIDERS_FUSE_UPSAMPLE_BWD", "1") != "0",     # A/B switch of the 2x2-summing data gradient
           "fuse_grad_add": os.environ.get("RIDERS_FUSE_GRAD_ADD", "1") != "0",     # A/B switch: second gradient contribution added in the data-gradient epilogue
-          # A/B switch (round 4): conv -> BatchNorm -> activation outputs stay virtual (LazyAct) and the consumer applies scale / shift /
-          # activation while staging its input; 0 restores the separate rd_affine_act pass everywhere
-          "lazy_bn": os.environ.get("RIDERS_LAZY_BN", "1") != "0"}
+          # Round 4: conv -> BatchNorm -> activation outputs stay virtual (LazyAct) and the consumer applies scale / shift / activation while
+          # staging its input.  Level 0: never (the separate rd_affine_act pass everywhere); 1 (default): inside residual blocks (conv1 ->
+          # conv2 staging, conv2 -> fused apply + add + activation: measured faster); 2: also the decoder chain (measured SLOWER on MI355X:
+          # the 3x3 kernels are vector-issue bound and the staging arithmetic costs more than the HBM pass it replaces -- DESIGN.md)
+          "lazy_bn": int(os.environ.get("RIDERS_LAZY_BN", "1"))}
 
 
 # how often a virtual activation was consumed in place / had to be written after all (tests assert that the fused routes are taken)
 lazy_counts = {"fwd_fused": 0, "wgrad_fused": 0, "add_fused": 0, "materialized": 0, "bn_bwd_fused": 0}
 
 
-def set_lazy_bn(flag):
-    """Consumer-side BatchNorm apply (LazyAct) on / off; results are bit-identical either way (tests compare the two)."""
-    _state["lazy_bn"] = bool(flag)
+def set_lazy_bn(level):
+    """Consumer-side BatchNorm apply (LazyAct): 0 off, 1 residual blocks only (default), 2 every conv -> BatchNorm -> conv chain (True = 2).
+    Results are bit-identical at every level (tests compare them)."""
+    _state["lazy_bn"] = 2 if level is True else int(level)
 
 
 def set_roi_tile_min_blocks(n):
@@ -738,7 +741,8 @@ def conv_block(x, weight, *, x2=None, bias=None, stride=1, pad=None, up=None, bn
     up: (Hv, Wv) nearest-upsample target applied to the sources inside the gather;
     bn: a torch.nn.BatchNorm2d used as a parameter container (train: batch stats + running update).
     x may be a LazyAct (the un-materialised output of a BatchNorm-ed conv_block): the kernels apply its scale / shift / activation while
-    staging; lazy_out=True returns this layer's output as a LazyAct (callers whose consumers are conv_block / add_act).
+    staging; lazy_out = 1 / 2 returns this layer's output as a LazyAct (callers whose consumers are conv_block / add_act) when the engine's
+    lazy_bn level (set_lazy_bn) is at least that.
     """
     lib = L()
     t = tape()
@@ -818,7 +822,7 @@ def conv_block(x, weight, *, x2=None, bias=None, stride=1, pad=None, up=None, bn
                                             _p(bn.running_mean), _p(bn.running_var), _p(mean), _p(rstd), _p(scale), _p(shift), st),
                  "bn finalize C=%d" % Cout), "rd_bn_finalize")
     lazy = None
-    if lazy_out and use_bn and residual is None and _state["lazy_bn"] and _BN_RECOMPUTE and Cout % ve == 0:
+    if lazy_out and use_bn and residual is None and _state["lazy_bn"] >= int(lazy_out) and _BN_RECOMPUTE and Cout % ve == 0:
         z = None
         lazy = LazyAct(y, coef, act, slope)      # z stays virtual: the consumer applies (scale, shift, act) while it stages y
     elif use_bn or residual is not None:

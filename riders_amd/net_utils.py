@@ -78,9 +78,9 @@ class Conv2d(torch.nn.Module, _BNCounter):
             self.batch_norm = torch.nn.BatchNorm2d(out_channels)
         self._bn_setup()
 
-    def _fwd(self, x, x2=None, up=None, lazy=False):
-        """lazy=True (callers whose consumer is another conv_block / add_act): the BatchNorm-ed output stays virtual (engine.LazyAct) and
-        the consumer applies scale / shift / activation while it stages the raw convolution output."""
+    def _fwd(self, x, x2=None, up=None, lazy=0):
+        """lazy = 1 / 2 (callers whose consumer is another conv_block / add_act): at that engine.set_lazy_bn level the BatchNorm-ed output
+        stays virtual (engine.LazyAct) and the consumer applies scale / shift / activation while it stages the raw convolution output."""
         act, slope = _act_code(self.activation_func)
         bn = self.batch_norm if self.use_batch_norm else None
         if bn is not None and self.training:
@@ -105,7 +105,7 @@ class UpConv2d(torch.nn.Module):
                            weight_initializer=weight_initializer, activation_func=activation_func,
                            use_batch_norm=use_batch_norm)
 
-    def _fwd(self, x, shape, lazy=False):
+    def _fwd(self, x, shape, lazy=0):
         return self.conv._fwd(x, up=(int(shape[0]), int(shape[1])), lazy=lazy)
 
     def forward(self, x, shape):
@@ -155,8 +155,8 @@ class ResNetBlock(torch.nn.Module):
                                  weight_initializer=weight_initializer, activation_func=None, use_batch_norm=False)
 
     def _fwd(self, x):
-        conv1 = self.conv1._fwd(x, lazy=True)       # consumed by conv2's staging
-        conv2 = self.conv2._fwd(conv1, lazy=True)   # consumed by the fused apply + add + activation below
+        conv1 = self.conv1._fwd(x, lazy=1)       # consumed by conv2's staging
+        conv2 = self.conv2._fwd(conv1, lazy=1)   # consumed by the fused apply + add + activation below
         if tuple(x.shape[1:3]) != tuple(conv2.shape[1:3]) or x.shape[3] != conv2.shape[3]:
             X = self.projection._fwd(x)
         else:
@@ -189,12 +189,12 @@ class DecoderBlock(torch.nn.Module):
                            weight_initializer=weight_initializer, activation_func=activation_func,
                            use_batch_norm=use_batch_norm)
 
-    def _fwd(self, x, skip=None, shape=None, lazy=False):
+    def _fwd(self, x, skip=None, shape=None, lazy=0):
         if skip is not None:
             shape = tuple(skip.shape[1:3])
         elif shape is None:
             shape = (int(2 * x.shape[1]), int(2 * x.shape[2]))
-        deconv = self.deconv._fwd(x, shape, lazy=True)      # consumed by self.conv's staging
+        deconv = self.deconv._fwd(x, shape, lazy=2)      # consumed by self.conv's staging (level 2: slower on MI355X, see engine.set_lazy_bn)
         if self.skip_channels > 0:
             return self.conv._fwd(deconv, x2=skip, lazy=lazy)
         return self.conv._fwd(deconv, lazy=lazy)

@@ -220,16 +220,16 @@ class MultiScaleDecoder(torch.nn.Module):
                                         use_batch_norm=False)
 
     def _fwd(self, x, skips, shape=None):
-        # every block's output is consumed by the next block's up-convolution (or the output convolution): it stays virtual (engine.LazyAct)
+        # every block's output is consumed by the next block's up-convolution (or the output convolution): virtual (engine.LazyAct) at lazy_bn level 2
         n = len(skips) - 1
-        h = self.deconv4._fwd(x, skips[n], lazy=True); n -= 1
-        h = self.deconv3._fwd(h, skips[n], lazy=True); n -= 1
-        h = self.deconv2._fwd(h, skips[n], lazy=True); n -= 1
-        h = self.deconv1._fwd(h, skips[n], lazy=True); n -= 1
+        h = self.deconv4._fwd(x, skips[n], lazy=2); n -= 1
+        h = self.deconv3._fwd(h, skips[n], lazy=2); n -= 1
+        h = self.deconv2._fwd(h, skips[n], lazy=2); n -= 1
+        h = self.deconv1._fwd(h, skips[n], lazy=2); n -= 1
         if n == 0:
-            h = self.deconv0._fwd(h, skips[n], lazy=True)
+            h = self.deconv0._fwd(h, skips[n], lazy=2)
         else:
-            h = self.deconv0._fwd(h, shape=tuple(shape[-2:]), lazy=True)
+            h = self.deconv0._fwd(h, shape=tuple(shape[-2:]), lazy=2)
         return [self.output0._fwd(h)]
 
     def forward(self, x, skips, shape=None):

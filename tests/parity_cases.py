@@ -376,13 +376,13 @@ def _lazy_both(build_and_run):
     from riders_amd import engine
     res, counts = [], None
     for flag in (True, False):
-        engine.set_lazy_bn(flag)
+        engine.set_lazy_bn(2 if flag else 0)
         for k in engine.lazy_counts:
             engine.lazy_counts[k] = 0
         try:
             res.append([r.detach().float().cpu().clone() for r in build_and_run()])
         finally:
-            engine.set_lazy_bn(True)
+            engine.set_lazy_bn(1)
         if flag:
             counts = dict(engine.lazy_counts)
     assert len(res[0]) == len(res[1])

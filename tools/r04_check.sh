@@ -14,8 +14,8 @@ elif [ "$what" = "lazytests" ]; then
   tail -5 $out/gpu_tests.log
 fi
 for i in 1 2; do
-  RIDERS_LAZY_BN=0 timeout 600 python bench.py --gpus 1 --steps 50 --warmup 5 --no-cpu-baseline --no-sml "$@" 2>$out/bench_base.err | grep metric | sed 's/^/lazy0 /' | cut -c1-260
-  timeout 600 python bench.py --gpus 1 --steps 50 --warmup 5 --no-cpu-baseline --no-sml "$@" 2>$out/bench_new.err | grep metric | sed 's/^/lazy1 /' | cut -c1-260
+  RIDERS_LAZY_BN=${LZA:-0} timeout 600 python bench.py --gpus 1 --steps 50 --warmup 5 --no-cpu-baseline --no-sml "$@" 2>$out/bench_base.err | grep metric | sed 's/^/lazy0 /' | cut -c1-260
+  RIDERS_LAZY_BN=${LZB:-1} timeout 600 python bench.py --gpus 1 --steps 50 --warmup 5 --no-cpu-baseline --no-sml "$@" 2>$out/bench_new.err | grep metric | sed 's/^/lazy1 /' | cut -c1-260
 done
 timeout 900 python bench.py --gpus 1 --steps 50 --warmup 5 --no-cpu-baseline --detail $out/per_shape.txt "$@" > $out/bench.json 2> $out/bench.err
 tail -3 $out/bench.err; cut -c1-300 $out/bench.json
