@@ -46,8 +46,9 @@ import torch  # noqa: E402
 
 PEAK_HBM = 8000.0                                   # GB/s  (MI355X_MICROARCH.md)
 PEAK_MFMA = {"fp32": 157.3, "bf16": 2500.0, "fp16": 2500.0}       # TFLOP/s dense
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r03_traffic.json")   # written by tools/traffic_pass.sh (rocprofv3 --pmc passes)
-PMC_FILE = os.path.join(ROOT, "profiles", "r03_pmc_dominant.json")   # MFMA-busy / wait counters of the dominant kernel (tools/pmc_dominant.sh)
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r04_traffic.json")   # written by tools/traffic_pass.sh (rocprofv3 --pmc passes)
+PMC_FILE = os.path.join(ROOT, "profiles", "r04_pmc_dominant.json")   # MFMA-busy / wait counters of the dominant kernel (tools/pmc_dominant.sh)
+KSTATS_FILE = "profiles/r04_%s_kernel_stats.csv"                     # rocprofv3 --kernel-trace --stats summary of the same command
 RIDGE = {k: v * 1e12 / (PEAK_HBM * 1e9) for k, v in PEAK_MFMA.items()}     # FLOP/B above which the MFMA roof binds
 
 
@@ -158,7 +159,7 @@ def val_abs_rel_pair(dev):
                 sample="%d synthetic %dx%d frames, random-init weights (identical on both paths), fp32" % (B, H, W))
 
 
-def cpu_baseline(budget_s=75.0):
+def cpu_baseline(budget_s=12.0):
     """Oracle training steps with torch CPU ops on the host cores, bounded to ~budget_s seconds: thread sweep (8, 16, 32, 64) on the RC-Net
     B = 1 step, then RC-Net B = 8 and the SML step at the best thread count; imgs/s of the best configuration is `value`."""
     t_start = time.time()
@@ -214,11 +215,14 @@ def family_table(timer, timed_steps, ms_per_step, dtype):
     return table
 
 
-def kernel_roofline(timer, timed_steps, ms_per_step, dtype, traffic_key):
-    """The roofline object: the named kernel with the largest summed launch time (see the module docstring)."""
+def kernel_roofline(timer, timed_steps, ms_per_step, dtype, traffic_key, conv_only=False, with_tables=True):
+    """The roofline object: the named kernel with the largest summed launch time (see the module docstring).  conv_only: among the
+    convolution / weight-gradient kernels only (`roofline_conv`); otherwise among ALL named kernels incl. the BatchNorm passes."""
     peak_mfma = PEAK_MFMA[dtype]
     ks = timer.by_kernel()
-    fams = family_table(timer, timed_steps, ms_per_step, dtype)
+    if conv_only:
+        ks = {n: v for n, v in ks.items() if v.get("kind") in ("conv_gemm", "conv_wgrad")}
+    fams = family_table(timer, timed_steps, ms_per_step, dtype) if with_tables else None
     if not ks:
         return dict(families=fams) if fams else None
     dom = max(ks, key=lambda k: ks[k]["ms"])
@@ -237,14 +241,19 @@ def kernel_roofline(timer, timed_steps, ms_per_step, dtype, traffic_key):
                              gbs=v[3] / (v[1] * 1e-3) / 1e9 if v[1] > 0 else 0.0) for d, v in top],
                 kernels={n: dict(ms_per_step=v["ms"] / timed_steps, launches_per_step=v["launches"] / timed_steps, avg_launch_us=v["ms"] * 1e3 / v["launches"],
                                  tflops=v["flops"] / (v["ms"] * 1e-3) / 1e12 if v["ms"] > 0 else 0.0,
-                                 frac_mfma=v["flops"] / (v["ms"] * 1e-3) / 1e12 / peak_mfma if v["ms"] > 0 else 0.0)
-                         for n, v in sorted(ks.items(), key=lambda kv: -kv[1]["ms"])[:8]},
+                                 gbs=v["bytes"] / (v["ms"] * 1e-3) / 1e9 if v["ms"] > 0 else 0.0,
+                                 frac=max(v["flops"] / (v["ms"] * 1e-3) / 1e12 / peak_mfma, v["bytes"] / (v["ms"] * 1e-3) / 1e9 / PEAK_HBM) if v["ms"] > 0 else 0.0)
+                         for n, v in sorted(ks.items(), key=lambda kv: -kv[1]["ms"])[:10]} if with_tables else None,
                 families=fams,
-                note="dominant = the convolution / weight-gradient kernel instantiation with the largest summed launch time over %d instrumented eager "
+                note="dominant = the %s kernel instantiation with the largest summed launch time over %d instrumented eager "
                      "steps of the same workload right after the timed region; durations from HIP events on the launch stream, idempotent launches "
-                     "issued %dx per event pair; achieved = algorithmic FLOPs (2/MAC) or bytes (each operand once) of exactly those launches / "
-                     "their summed durations; the rocprofv3 --kernel-trace --stats summary of the same command is profiles/r03_rcnet_b8_bf16_kernel_stats.csv"
-                     % (timed_steps, timer.repeat))
+                     "issued %dx per event pair (the BatchNorm backward's reduce / finalize / apply launches are issued and timed one by one); "
+                     "achieved = algorithmic FLOPs (2/MAC) or bytes (each operand once) of exactly those launches / "
+                     "their summed durations; the rocprofv3 --kernel-trace --stats summary of the same command is %s"
+                     % ("convolution / weight-gradient" if conv_only else "named (convolution, weight-gradient, BatchNorm-pass)", timed_steps, timer.repeat,
+                        KSTATS_FILE % traffic_key))
+    if not with_tables:
+        roof.pop("kernels", None); roof.pop("families", None)
     try:    # PMC figures of the committed rocprofv3 counter passes (they cannot be collected inside this run)
         pm = json.load(open(PMC_FILE)).get(traffic_key.split("_")[0], {}).get(dom)
         if pm:
@@ -266,8 +275,11 @@ def kernel_roofline(timer, timed_steps, ms_per_step, dtype, traffic_key):
     return roof
 
 
-def run_workload(kind, args, dev, world, rank, steps, warmup):
+def run_workload(kind, args, dev, world, rank, steps, warmup, **override):
+    """override: dtype / batch / height / width / settle_seconds of a secondary leg (the fp32 parity mode, configs[4]) on a copy of args."""
     from riders_amd import engine, rcnet_main, sml_main
+    if override:
+        args = argparse.Namespace(**dict(vars(args), **override))
     from riders_amd.optim import FlatAdam
     from riders_amd.parallel import GradientAllReducer, rcnet_stages, sml_stages
     engine.set_compute_dtype(args.dtype)
@@ -358,7 +370,9 @@ def run_workload(kind, args, dev, world, rank, steps, warmup):
                launch_mode="eager" if args.eager else ("hipGraphs split at the stage marks (fwd+bwd) + eager all-reduce/Adam" if reducer is not None
                                                        else "one hipGraph (fwd+bwd) + eager Adam"))
     if rank == 0:
-        out["roofline"] = kernel_roofline(timer, timed_steps, ms, args.dtype, "%s_b%d_%dx%d_%s" % (kind, batch_n, h, w, args.dtype))
+        key = "%s_b%d_%dx%d_%s" % (kind, batch_n, h, w, args.dtype)
+        out["roofline"] = kernel_roofline(timer, timed_steps, ms, args.dtype, key)
+        out["roofline_conv"] = kernel_roofline(timer, timed_steps, ms, args.dtype, key, conv_only=True, with_tables=False)
         if args.detail:
             rows = sorted(timer.detail().items(), key=lambda kv: -kv[1][1])
             with open(args.detail if kind == "rcnet" else args.detail + ".sml", "w") as f:
@@ -372,11 +386,37 @@ def run_workload(kind, args, dev, world, rank, steps, warmup):
     return out
 
 
+def visible_gpu_count():
+    """GPUs this process may use, WITHOUT touching the HIP / HSA runtime (torch.cuda.device_count() falls back to hipGetDeviceCount on ROCm
+    builds without amdsmi, which initialises the runtime in the parent): the kfd topology lists one node per agent, GPUs are the nodes with
+    SIMDs; HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES / CUDA_VISIBLE_DEVICES narrow it.  None when the topology cannot be read."""
+    import glob
+    n = 0
+    nodes = glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties")
+    if not nodes:
+        return None
+    for p in nodes:
+        try:
+            props = dict(l.split()[:2] for l in open(p).read().splitlines() if len(l.split()) >= 2)
+        except OSError:
+            return None
+        if int(props.get("simd_count", "0")) > 0:
+            n += 1
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([x for x in v.split(",") if x.strip() != ""]))
+    return n
+
+
 def spawn_ranks(n, argv):
-    """GPU-free parent: start n rank processes (one per GPU) BEFORE anything in this process touches a GPU, relay rank 0's stdout."""
+    """GPU-free parent: start n rank processes (one per GPU) BEFORE anything in this process touches a GPU, relay rank 0's stdout; when a
+    rank exits with an error the others are terminated at once (they would sit in RCCL until its timeout) and that code is returned."""
     import socket
     import subprocess
-    have = torch.cuda.device_count()      # counts devices without initialising the runtime
+    have = visible_gpu_count()
+    if have is None:
+        have = torch.cuda.device_count()      # last resort (may initialise the runtime; starting fresh child processes afterwards is still fine)
     if have < n:
         sys.stderr.write("bench.py: --gpus %d but only %d GPU(s) visible\n" % (n, have))
         return 2
@@ -390,8 +430,19 @@ def spawn_ranks(n, argv):
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC only on this driver (RCCL across processes)
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
                                       stdout=None if r == 0 else subprocess.DEVNULL))
-    rcs = [p.wait() for p in procs]
-    return max(abs(rc) for rc in rcs)
+    worst = 0
+    while procs:
+        time.sleep(0.2)
+        for p in list(procs):
+            rc = p.poll()
+            if rc is None:
+                continue
+            procs.remove(p)
+            if rc != 0:
+                worst = max(worst, abs(rc))
+                for q_ in procs:
+                    q_.terminate()
+    return worst
 
 
 def main():
@@ -412,6 +463,7 @@ def main():
     ap.add_argument("--workload", default="rcnet", choices=["rcnet", "sml"],
                     help="headline workload: rcnet = BASELINE configs[1]; sml = configs[2] alone")
     ap.add_argument("--no-sml", action="store_true", help="skip the second (SML, configs[2]) entry of the default N = 1 run")
+    ap.add_argument("--no-legs", action="store_true", help="skip the fp32 (parity mode) and configs[4] (fp16 512x1024) entries of the default N = 1 run")
     ap.add_argument("--sml-batch", type=int, default=16)
     ap.add_argument("--sml-height", type=int, default=256)
     ap.add_argument("--sml-width", type=int, default=512)
@@ -453,8 +505,18 @@ def main():
 
     head = run_workload(args.workload, args, dev, world, rank, args.steps, args.warmup)
     sml = None
+    legs = {}
+    default_line = args.workload == "rcnet" and world == 1 and args.dtype == "bf16" and (args.height, args.width, args.batch) == (256, 512, 8) \
+        and not args.config3 and not args.force_ddp and not args.eager
     if args.workload == "rcnet" and world == 1 and not args.no_sml:
-        sml = run_workload("sml", args, dev, world, rank, args.steps, args.warmup)
+        sml = run_workload("sml", args, dev, world, rank, args.steps, args.warmup, settle_seconds=min(args.settle_seconds, 1.0))
+    if default_line and not args.no_legs:
+        # every mode that carries a claim is timed by the same run: the fp32 parity mode (north_star's 1e-3 holds for it) and BASELINE
+        # configs[4] (fp16, 512x1024, batch 8 per GPU); shorter legs, same timing method
+        sec_steps = max(1, min(args.steps, 60))
+        legs["fp32"] = run_workload("rcnet", args, dev, world, rank, sec_steps, min(args.warmup, 5), dtype="fp32", settle_seconds=min(args.settle_seconds, 1.0))
+        legs["config4"] = run_workload("rcnet", args, dev, world, rank, sec_steps, min(args.warmup, 5), dtype="fp16", height=512, width=1024,
+                                       settle_seconds=min(args.settle_seconds, 1.0))
     if rank == 0:
         is_rc = args.workload == "rcnet"
         out = {
@@ -473,17 +535,25 @@ def main():
             "world_size": world, "comm": comm,
             "allreduce": None if not ddp else "RCCL sum of the flat fp32 gradient arena in 3 stage buckets, each started when the backward "
                                               "passes its stage mark (overlaps the remaining backward graphs); 1/N folded into Adam",
-            "roofline": head["roofline"],
+            "roofline": head["roofline"], "roofline_conv": head["roofline_conv"],
         }
         if sml is not None:
             out["sml"] = {"metric": "train imgs/sec (Scale Map Learner, MiDaS-small / EfficientNet-Lite3; BASELINE configs[2])",
                           "value": sml["value"], "unit": "imgs/s", "ms_per_step": sml["ms_per_step"], "dtype": out["dtype"],
                           "config": {"workload": "SML training step, batch %d/GPU, %dx%d frames, device pre-step+fwd+loss+bwd+Adam" % (
                               sml["batch_per_gpu"], sml["height"], sml["width"])},
-                          "final_loss": sml["final_loss"], "settle_steps": sml["settle_steps"], "roofline": sml["roofline"]}
+                          "final_loss": sml["final_loss"], "settle_steps": sml["settle_steps"], "roofline": sml["roofline"],
+                          "roofline_conv": sml["roofline_conv"]}
             # BASELINE.json's metric names both stages: an image passes through an RC-Net step and an SML step
             out["chained"] = {"metric": "train imgs/sec through RC-Net then SML (per-image time = RC-Net step/8 + SML step/16)",
                               "value": 1.0 / (1.0 / head["value"] + 1.0 / sml["value"]), "unit": "imgs/s"}
+        for name, leg in legs.items():
+            out[name] = {"metric": {"fp32": "train imgs/sec (RC-Net, batch 8, 256x512, fp32: the 1e-3 parity mode)",
+                                    "config4": "train imgs/sec (RC-Net, batch 8 per GPU, 3x512x1024, fp16: BASELINE configs[4] per rank)"}[name],
+                         "value": leg["value"], "unit": "imgs/s", "ms_per_step": leg["ms_per_step"], "steps": leg["steps"],
+                         "dtype": {"fp32": "f32", "config4": "f16"}[name],
+                         "config": {"workload": "RC-Net training step, batch %d/GPU, %dx%d image, fwd+loss+bwd+Adam" % (leg["batch_per_gpu"], leg["height"], leg["width"])},
+                         "final_loss": leg["final_loss"], "roofline": leg["roofline"], "roofline_conv": leg["roofline_conv"]}
         if world == 1 and not args.no_cpu_baseline and is_rc:
             try:
                 out["val_abs_rel"] = val_abs_rel_pair(dev)

@@ -221,6 +221,15 @@ int rd_bn_act_bwd_recompute(const void* dz, const void* z, const void* y, const 
                             const float* scale, const float* shift, float* partial, float* coef, float* dgamma, float* dbeta,
                             int32_t accumulate, void* dy, void* dres, int64_t pixels, int32_t C, int32_t act, float slope,
                             int32_t dtype, void* stream);
+/* the same call restricted to some of its three launches (bit 0: reduce pass, bit 1: finalize, bit 2: apply pass; 7 = rd_bn_act_bwd_recompute):
+   bench.py times the passes one by one so that its roofline object can name the dominant KERNEL of any family */
+int rd_bn_act_bwd_recompute_phases(const void* dz, const void* z, const void* y, const float* save_mean, const float* save_rstd,
+                                   const float* scale, const float* shift, float* partial, float* coef, float* dgamma, float* dbeta,
+                                   int32_t accumulate, void* dy, void* dres, int64_t pixels, int32_t C, int32_t act, float slope,
+                                   int32_t dtype, int32_t phases, void* stream);
+/* instantiation name (as rd_conv_fwd_kernel_name) of which = 0: rd_affine_act (flag = residual given), 1: the BatchNorm-backward reduce
+   pass, 2: its apply pass (flag = recompute form) for this channel count / dtype / activation */
+const char* rd_bn_kernel_name(int32_t which, int32_t C, int32_t dtype, int32_t act, int32_t flag);
 int rd_act_bwd(const void* dz, const void* z, void* dx, int64_t n, int32_t act, float slope, int32_t dtype, void* stream);
 /* bias gradient: out[c] (+)= sum over rows of x[rows][C] */
 int32_t rd_colsum_rows(int64_t rows, int32_t C);

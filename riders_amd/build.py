@@ -13,6 +13,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "_obj")
 LIB = os.path.join(HERE, "libriders_hip.so")
+HOST_LIB = os.path.join(HERE, "libriders_host.so")     # host-only helpers (csrc/rd_host.cpp, plain g++): bound without the GPU runtime
+HOST_SRC = os.path.join(CSRC, "rd_host.cpp")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wno-unused-result"]
 
@@ -74,7 +76,20 @@ def build(force=False, verbose=True):
             raise RuntimeError("link failed")
         if verbose:
             print("[link] %s" % LIB, flush=True)
+    build_host(verbose)
     return LIB
+
+
+def build_host(verbose=False):
+    """riders_amd/libriders_host.so: the host-only part of the ABI for processes that must not initialise a GPU (data-loader workers)."""
+    if _newer(HOST_SRC, HOST_LIB):
+        r = subprocess.run([os.environ.get("CXX", "g++"), "-O2", "-shared", "-fPIC", "-o", HOST_LIB, HOST_SRC], capture_output=True, text=True)
+        if r.returncode != 0:
+            sys.stderr.write(r.stdout + r.stderr)
+            raise RuntimeError("host helper build failed")
+        if verbose:
+            print("[g++] %s" % HOST_LIB, flush=True)
+    return HOST_LIB
 
 
 if __name__ == "__main__":

@@ -373,16 +373,26 @@ int rd_bn_act_bwd(const void* dz, const void* z, const void* y, const float* mea
   RD_NS(dtype, launch_bn_bwd_apply)(dz, z, y, mean, rstd, scale, coef, coef + C, dy, dres, pixels, C, act, slope, RD_DT(dtype), S(stream), nullptr);
   return done("rd_bn_act_bwd");
 }
-int rd_bn_act_bwd_recompute(const void* dz, const void* z, const void* y, const float* mean, const float* rstd, const float* scale,
-                            const float* shift, float* partial, float* coef, float* dgamma, float* dbeta, int32_t accumulate, void* dy,
-                            void* dres, int64_t pixels, int32_t C, int32_t act, float slope, int32_t dtype, void* stream) {
+int rd_bn_act_bwd_recompute_phases(const void* dz, const void* z, const void* y, const float* mean, const float* rstd, const float* scale,
+                                   const float* shift, float* partial, float* coef, float* dgamma, float* dbeta, int32_t accumulate, void* dy,
+                                   void* dres, int64_t pixels, int32_t C, int32_t act, float slope, int32_t dtype, int32_t phases, void* stream) {
   if (!dz || !y || !mean || !rstd || !scale || !shift || !partial || !coef || !dy || !dt_ok(dtype)) return fail("bn_act_bwd_recompute: bad args");
   if (act != RD_ACT_NONE && !z && (C % (dtype == RD_F32 ? 4 : 8))) return fail("bn_act_bwd_recompute: this channel count needs z");
   int rows = rd::bn_bwd_rows(pixels, C);
-  RD_NS(dtype, launch_bn_bwd_reduce)(dz, z, y, mean, rstd, partial, pixels, C, act, slope, RD_DT(dtype), S(stream), scale, shift);
-  rd::launch_bn_bwd_finalize(partial, rows, C, (double)pixels, dgamma, dbeta, accumulate, coef, coef + C, S(stream));
-  RD_NS(dtype, launch_bn_bwd_apply)(dz, z, y, mean, rstd, scale, coef, coef + C, dy, dres, pixels, C, act, slope, RD_DT(dtype), S(stream), shift);
+  if (phases & 1) RD_NS(dtype, launch_bn_bwd_reduce)(dz, z, y, mean, rstd, partial, pixels, C, act, slope, RD_DT(dtype), S(stream), scale, shift);
+  if (phases & 2) rd::launch_bn_bwd_finalize(partial, rows, C, (double)pixels, dgamma, dbeta, accumulate, coef, coef + C, S(stream));
+  if (phases & 4) RD_NS(dtype, launch_bn_bwd_apply)(dz, z, y, mean, rstd, scale, coef, coef + C, dy, dres, pixels, C, act, slope, RD_DT(dtype), S(stream), shift);
   return done("rd_bn_act_bwd_recompute");
+}
+int rd_bn_act_bwd_recompute(const void* dz, const void* z, const void* y, const float* mean, const float* rstd, const float* scale,
+                            const float* shift, float* partial, float* coef, float* dgamma, float* dbeta, int32_t accumulate, void* dy,
+                            void* dres, int64_t pixels, int32_t C, int32_t act, float slope, int32_t dtype, void* stream) {
+  return rd_bn_act_bwd_recompute_phases(dz, z, y, mean, rstd, scale, shift, partial, coef, dgamma, dbeta, accumulate, dy, dres, pixels, C, act, slope,
+                                        dtype, 7, stream);
+}
+const char* rd_bn_kernel_name(int32_t which, int32_t C, int32_t dtype, int32_t act, int32_t flag) {
+  if (!dt_ok(dtype) || which < 0 || which > 2 || C <= 0) return "";
+  return RD_NS(dtype, bn_kernel_name)(which, C, RD_DT(dtype), act, flag);
 }
 int rd_act_bwd(const void* dz, const void* z, void* dx, int64_t n, int32_t act, float slope, int32_t dtype, void* stream) {
   if (!dz || !z || !dx || !dt_ok(dtype)) return fail("act_bwd: bad args");
@@ -662,33 +672,6 @@ int rd_nearest_knot(const int32_t* point_row, const int32_t* point_col, const do
   rd::launch_nearest_knot(point_row, point_col, values, n_points, H, W, fill_value, out, S(stream));
   return done("rd_nearest_knot");
 }
-// PNG scanline un-filtering on the HOST (data/data_utils.py:94-125 reads the 16-bit depth maps through PIL; PIL's writer picks Sub / Up /
-// Average / Paeth per scanline, and the serial Average / Paeth recurrences cost ~0.3 s per 256x512 map as an interpreter loop).
-int rd_png_unfilter_host(const uint8_t* raw, int32_t h, int32_t row_bytes, int32_t bpp, uint8_t* out) {
-  if (!raw || !out || h < 0 || row_bytes <= 0 || bpp <= 0) return fail("png_unfilter_host: bad args");
-  for (int y = 0; y < h; y++) {
-    const uint8_t* line = raw + (size_t)y * (row_bytes + 1);
-    uint8_t* cur = out + (size_t)y * row_bytes;
-    const uint8_t* prev = y ? cur - row_bytes : nullptr;
-    const int ft = line[0];
-    line++;
-    if (ft > 4) return fail("png_unfilter_host: bad filter type %d in row %d", ft, y);
-    for (int x = 0; x < row_bytes; x++) {
-      const int a = x >= bpp ? cur[x - bpp] : 0, b = prev ? prev[x] : 0, c = (prev && x >= bpp) ? prev[x - bpp] : 0;
-      int pred = 0;
-      if (ft == 1) pred = a;
-      else if (ft == 2) pred = b;
-      else if (ft == 3) pred = (a + b) >> 1;
-      else if (ft == 4) {
-        const int p = a + b - c, pa = abs(p - a), pb = abs(p - b), pc = abs(p - c);
-        pred = (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
-      }
-      cur[x] = (uint8_t)(line[x] + pred);
-    }
-  }
-  return 0;
-}
-
 int rd_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float b1, float b2, float eps, float wd,
                  int64_t step, float gscale, void* stream) {
   if (!p || !g || !m || !v) return fail("adam: null pointer");

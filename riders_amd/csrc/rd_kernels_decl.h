@@ -73,6 +73,7 @@ void launch_affine_act(const void* y, const float* scale, const float* shift, co
 bool affine_act_add_ok(int C, int dtype);
 void launch_affine_act_add(const void* y, const float* scale, const float* shift, int act1, float slope1, const void* res, void* out,
                            int64_t pixels, int C, int act2, float slope2, int dtype, hipStream_t st);
+const char* bn_kernel_name(int which, int C, int dtype, int act, int flag);
 int bn_bwd_rows(int64_t pixels, int C);
 void launch_bn_bwd_reduce(const void* dz, const void* z, const void* y, const float* mean, const float* rstd,
                           float* partial, int64_t pixels, int C, int act, float slope, int dtype, hipStream_t st,

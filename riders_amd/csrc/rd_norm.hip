@@ -12,6 +12,7 @@
 #include "rd_common.h"
 #include "rd_kernels.h"
 #include <type_traits>
+#include <stdio.h>
 
 namespace rd {
 
@@ -690,6 +691,27 @@ void launch_affine_act_add(const void* y, const float* scale, const float* shift
   });
 }
 
+// instantiation names as rocprofv3's kernel trace prints them (bench.py attributes HIP-event timings to kernels by these names):
+// which 0 = rd_affine_act (flag: residual present), 1 = BatchNorm-backward reduce, 2 = BatchNorm-backward apply (flag: recompute form)
+const char* bn_kernel_name(int which, int C, int dtype, int act, int flag) {
+  static thread_local char buf[96];
+  const char* T = dtype == 0 ? "float" : RD_T16_NAME;
+  const bool v = vec_ok(C, dtype), g = !v && gen_ok(C, dtype);
+  const char* form = v ? "vec" : "gen";
+  const int A = (act >= 0 && act <= 3) ? act : -1;
+  if (!(v || g)) flag = which == 0 ? flag : 0;
+  if (which == 0) {
+    if (v || g) snprintf(buf, sizeof(buf), "affine_act_%s_kernel<%s, %d, %s>", form, T, A, flag ? "true" : "false");
+    else snprintf(buf, sizeof(buf), "affine_act_kernel<%s, %s>", T, (C % 4 == 0) ? "true" : "false");
+  } else if (which == 1) {
+    if (v || g) { if (flag) snprintf(buf, sizeof(buf), "col_reduce_%s_kernel<%s, 0, true, %d>", form, T, A); else snprintf(buf, sizeof(buf), "col_reduce_%s_kernel<%s, 0, false, -1>", form, T); }
+    else snprintf(buf, sizeof(buf), "col_reduce_kernel<%s, 0>", T);
+  } else {
+    if (v || g) { if (flag) snprintf(buf, sizeof(buf), "bn_bwd_apply_%s_kernel<%s, true, %d>", form, T, A); else snprintf(buf, sizeof(buf), "bn_bwd_apply_%s_kernel<%s, false, -1>", form, T); }
+    else snprintf(buf, sizeof(buf), "bn_bwd_apply_kernel<%s, %s>", T, (C % 4 == 0) ? "true" : "false");
+  }
+  return buf;
+}
 int bn_bwd_rows(int64_t pixels, int C) { return red_rows(pixels, C); }
 int colsum_rows(int64_t rows, int C) { return red_rows(rows, C); }
 

@@ -6,6 +6,8 @@ Same signatures and arithmetic as the reference's data/data_utils.py load_depth 
 The quantisation runs on the device (rd_depth_quantize_u16) when `z` is a ROCm tensor, so only two bytes per pixel cross PCIe;
 the PNG container itself (zlib-compressed scanlines) is written and parsed here without PIL.
 """
+import ctypes
+import os
 import struct
 import zlib
 
@@ -48,6 +50,24 @@ def encode_png16(q, level=6):
     return _SIG + _chunk(b"IHDR", ihdr) + _chunk(b"IDAT", zlib.compress(rows.tobytes(), level)) + _chunk(b"IEND", b"")
 
 
+_host = {"lib": None}
+
+
+def _host_lib():
+    """riders_amd/libriders_host.so (csrc/rd_host.cpp built by plain g++): host-only helpers bound WITHOUT importing torch or touching the GPU
+    runtime -- this runs inside DataLoader workers (RCNetTrainingDataset.__getitem__ -> load_image / load_depth), which must not create a
+    device context and cannot re-initialise one after a fork."""
+    if _host["lib"] is None:
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libriders_host.so")
+        if not os.path.exists(path):
+            raise RuntimeError("riders_amd: %s not found; build it with `python -m riders_amd.build`" % path)
+        lib = ctypes.CDLL(path)
+        lib.rd_png_unfilter_host.restype = ctypes.c_int
+        lib.rd_png_unfilter_host.argtypes = [ctypes.c_void_p, ctypes.c_int32, ctypes.c_int32, ctypes.c_int32, ctypes.c_void_p]
+        _host["lib"] = lib
+    return _host["lib"]
+
+
 def decode_png16(data):
     """bytes of an 8/16-bit grayscale (what PIL writes for modes 'I' / 'I;16' / 'L') or 8-bit RGB / RGBA, non-interlaced PNG -> integer
     (H,W) or (H,W,C) array."""
@@ -72,12 +92,9 @@ def decode_png16(data):
     raw = np.ascontiguousarray(np.frombuffer(zlib.decompress(b"".join(idat)), dtype=np.uint8).reshape(h, 1 + w * bpp))
     out = np.zeros((h, w * bpp), dtype=np.uint8)
     # PNG scanline filters (PIL picks them adaptively): the serial Average / Paeth recurrences run in the library's host helper
-    import ctypes
-    from . import _lib
-    lib = _lib.load() if _lib._lib is None else _lib._lib
-    rc = lib.rd_png_unfilter_host(raw.ctypes.data_as(ctypes.c_void_p), h, w * bpp, bpp, out.ctypes.data_as(ctypes.c_void_p))
+    rc = _host_lib().rd_png_unfilter_host(raw.ctypes.data_as(ctypes.c_void_p), h, w * bpp, bpp, out.ctypes.data_as(ctypes.c_void_p))
     if rc != 0:
-        raise ValueError("bad PNG filter data: %s" % lib.rd_last_error_string().decode())
+        raise ValueError("bad PNG filter data (rd_png_unfilter_host returned %d)" % rc)
     if chans > 1:
         return out.reshape(h, w, chans)
     return out.view(">u2").astype(np.uint16) if depth == 16 else out

@@ -157,7 +157,7 @@ class KernelTimer(object):
             for s, e, f, d, b, k, r in recs:
                 if not k:
                     continue
-                o = out.setdefault(k, dict(launches=0, ms=0.0, flops=0.0, bytes=0.0, shapes={}))
+                o = out.setdefault(k, dict(launches=0, ms=0.0, flops=0.0, bytes=0.0, shapes={}, kind=kind))
                 ms = s.elapsed_time(e) / r
                 o["launches"] += 1; o["ms"] += ms; o["flops"] += f; o["bytes"] += b
                 sh = o["shapes"].setdefault(d, [0, 0.0, 0.0, 0.0])
@@ -188,7 +188,24 @@ def _timed(kind, flops, fn, desc=None, nbytes=0.0, kernel=None, idem=False):
 def _tb(kind, nbytes, fn, desc=None, kernel=None):
     """HBM-bound launch: algorithmic bytes only (every operand moved once)."""
     kt = _timer["t"]
-    return fn() if kt is None else kt.run(kind, 0.0, fn, desc, float(nbytes), kernel)
+    return fn() if kt is None else kt.run(kind, 0.0, fn, desc, float(nbytes), kernel() if callable(kernel) else kernel)
+
+
+def _bn_name(which, C, dt, act, flag):
+    return lambda: L().rd_bn_kernel_name(which, C, dt, act, 1 if flag else 0).decode()
+
+
+def _bn_bwd_recompute(dz, z, y, mean, rstd, scale, shift, partial, coef2, dgam, dbet, acc, dy, dres, pixels, C, act, slope, dt, st, nbytes, desc):
+    """rd_bn_act_bwd_recompute; under a kernel timer its reduce / finalize / apply launches are issued (and timed, and named) one by one so
+    that bench.py's roofline can rank the BatchNorm passes next to the convolution kernels."""
+    lib = L()
+    args = (_p(dz), _p(z), _p(y), _p(mean), _p(rstd), _p(scale), _p(shift), _p(partial), _p(coef2), _p(dgam), _p(dbet), acc, _p(dy), _p(dres), pixels, C,
+            act, slope, dt)
+    if _timer["t"] is None:
+        return lib.rd_bn_act_bwd_recompute(*args, st)
+    rc = _tb("bn_backward", 2.0 * nbytes / 3.0, lambda: lib.rd_bn_act_bwd_recompute_phases(*args, 1, st), desc + " [reduce]", kernel=_bn_name(1, C, dt, act, True))
+    rc = rc or _tb("bn_finalize", partial.numel() * 4, lambda: lib.rd_bn_act_bwd_recompute_phases(*args, 2, st), "bn bwd finalize C=%d" % C, kernel="bn_bwd_finalize_kernel")
+    return rc or _tb("bn_backward", nbytes, lambda: lib.rd_bn_act_bwd_recompute_phases(*args, 4, st), desc + " [apply]", kernel=_bn_name(2, C, dt, act, True))
 
 
 # ------------------------------------------------------------------------------------------------- tape
@@ -712,8 +729,8 @@ class LazyAct(object):
             z = torch.empty_like(y)
             nb = y.numel() * y.element_size()
             _chk(_tb("bn_apply", 2 * nb, lambda: L().rd_affine_act(_p(y), _p(self.coef[0]), _p(self.coef[1]), None, _p(z), y.numel() // C, C, self.act,
-                                                                    self.slope, rd_of(y), _stream(y)), "bn apply+act M=%d C=%d" % (y.numel() // C, C)),
-                 "rd_affine_act")
+                                                                    self.slope, rd_of(y), _stream(y)), "bn apply+act M=%d C=%d" % (y.numel() // C, C),
+                     kernel=_bn_name(0, C, rd_of(y), self.act, False)), "rd_affine_act")
             self._z = z
         return self._z
 
@@ -829,7 +846,7 @@ def conv_block(x, weight, *, x2=None, bias=None, stride=1, pad=None, up=None, bn
         z = torch.empty_like(y)
         _chk(_tb("bn_apply", (2 + (residual is not None)) * b_out,
                  lambda: lib.rd_affine_act(_p(y), _p(scale), _p(shift), _p(residual), _p(z), pixels, Cout, act, slope, dt, st),
-                 "bn apply+act M=%d C=%d" % (pixels, Cout)), "rd_affine_act")
+                 "bn apply+act M=%d C=%d" % (pixels, Cout), kernel=_bn_name(0, Cout, dt, act, residual is not None)), "rd_affine_act")
     else:
         z = y
     zk = lazy if lazy is not None else z      # what the caller receives = the tape key of this layer's output
@@ -862,10 +879,8 @@ def conv_block(x, weight, *, x2=None, bias=None, stride=1, pad=None, up=None, bn
             dres = torch.empty_like(y) if need_res else None
             if residual is None and _BN_RECOMPUTE:   # z = act(scale*y + shift): the backward recomputes the activation argument from y, z is not read
                 # algorithmic bytes: dz and y read once, dy written once (the two-pass kernels read dz and y twice)
-                _chk(_tb("bn_backward", 3 * b_out,
-                         lambda: lib.rd_bn_act_bwd_recompute(_p(dz), _p(z), _p(y), _p(mean), _p(rstd), _p(scale), _p(shift), _p(partial), _p(coef2),
-                                                             _p(dgam), _p(dbet), acc, _p(dy), _p(dres), pixels, Cout, act, slope, dt, st),
-                         "bn backward M=%d C=%d" % (pixels, Cout)), "rd_bn_act_bwd_recompute")
+                _chk(_bn_bwd_recompute(dz, z, y, mean, rstd, scale, shift, partial, coef2, dgam, dbet, acc, dy, dres, pixels, Cout, act, slope, dt, st,
+                                       3 * b_out, "bn backward M=%d C=%d" % (pixels, Cout)), "rd_bn_act_bwd_recompute")
             else:
                 _chk(_tb("bn_backward", (4 + (dres is not None)) * b_out,
                          lambda: lib.rd_bn_act_bwd(_p(dz), _p(z), _p(y), _p(mean), _p(rstd), _p(scale), _p(partial), _p(coef2), _p(dgam),
@@ -1516,7 +1531,9 @@ def _bn_forward(y, bn, act, slope, residual, training, stats=None):
                             float(bn.eps), float(bn.momentum if bn.momentum is not None else 0.1), 1 if bn_train else 0,
                             _p(bn.running_mean), _p(bn.running_var), _p(coef[2]), _p(coef[3]), _p(coef[0]), _p(coef[1]), st), "rd_bn_finalize")
     z = torch.empty_like(y)
-    _chk(lib.rd_affine_act(_p(y), _p(coef[0]), _p(coef[1]), _p(residual), _p(z), pixels, C, act, slope, dt, st), "rd_affine_act")
+    _chk(_tb("bn_apply", (2 + (residual is not None)) * y.numel() * y.element_size(),
+             lambda: lib.rd_affine_act(_p(y), _p(coef[0]), _p(coef[1]), _p(residual), _p(z), pixels, C, act, slope, dt, st),
+             "bn apply+act M=%d C=%d" % (pixels, C), kernel=_bn_name(0, C, dt, act, residual is not None)), "rd_affine_act")
     return z, coef, bn_train
 
 
@@ -1536,8 +1553,8 @@ def _bn_backward(t, dz, z, y, coef, bn, act, slope, want_res):
                                _p(dy), _p(dres), pixels, C, act, slope, dt, st), "rd_bn_act_bwd")
         return dy, dres
     # no residual on this path: the activation argument is recomputed from y (coef[0] = scale, coef[1] = shift), z is not read
-    _chk(lib.rd_bn_act_bwd_recompute(_p(dz), _p(z), _p(y), _p(coef[2]), _p(coef[3]), _p(coef[0]), _p(coef[1]), _p(partial), _p(coef2), _p(dgam),
-                                     _p(dbet), acc, _p(dy), _p(dres), pixels, C, act, slope, dt, st), "rd_bn_act_bwd_recompute")
+    _chk(_bn_bwd_recompute(dz, z, y, coef[2], coef[3], coef[0], coef[1], partial, coef2, dgam, dbet, acc, dy, dres, pixels, C, act, slope, dt, st,
+                           3 * y.numel() * y.element_size(), "bn backward M=%d C=%d" % (pixels, C)), "rd_bn_act_bwd_recompute")
     return dy, dres
 
 

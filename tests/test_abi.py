@@ -45,6 +45,39 @@ def test_conv_desc_matches_c_layout():
     assert names == [f[0] for f in _lib.ConvDesc._fields_], (names, [f[0] for f in _lib.ConvDesc._fields_])
 
 
+def test_conv_fusion_matches_c_layout():
+    """rd_conv_fusion: the ctypes mirror has the header's members in the header's order (pointers 8 bytes, two (int32, float) pairs)."""
+    import re
+    src = open(_lib.HEADER).read()
+    body = re.search(r"typedef struct rd_conv_fusion\s*\{(.*?)\}\s*rd_conv_fusion;", src, flags=re.S).group(1)
+    names = []
+    for decl in body.split(";"):
+        decl = decl.strip()
+        if decl:
+            names.append(decl.replace("*", " ").split()[-1])
+    assert names == [f[0] for f in _lib.ConvFusion._fields_], (names, [f[0] for f in _lib.ConvFusion._fields_])
+    assert ctypes.sizeof(_lib.ConvFusion) == 8 * 7 + 4 * 4
+
+
+def test_png_decode_does_not_touch_the_gpu_runtime():
+    """decode_png16 runs in DataLoader workers; it must bind only the host helper library -- neither torch nor libriders_hip.so
+    may be loaded by it (checked in a fresh interpreter)."""
+    import subprocess
+    import sys
+    code = ("import sys, numpy as np\n"
+            "from riders_amd import data_utils as D\n"
+            "z = (np.arange(12 * 20, dtype=np.float32).reshape(12, 20) % 97) / 3.0\n"
+            "png = D.encode_png16((z * 256.0).astype(np.uint16))\n"
+            "got = D.decode_png16(png)\n"
+            "assert got.shape == (12, 20) and got.dtype == np.uint16\n"
+            "assert 'torch' not in sys.modules, 'decode_png16 imported torch'\n"
+            "maps = open('/proc/self/maps').read()\n"
+            "assert 'libriders_hip.so' not in maps and 'libamdhip64' not in maps, 'decode_png16 loaded the HIP library'\n"
+            "assert 'libriders_host.so' in maps\n")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0, r.stderr[-800:]
+
+
 def test_product_refuses_host_tensors():
     import torch
     from riders_amd import engine
