@@ -177,7 +177,8 @@ int rd_conv_fwd(const rd_conv_desc* d, const void* src1, const void* src2, const
   if (d->D1 < d->Cout && !dst2) return fail("conv_fwd: D1 < Cout but dst2 is null");
   rd::ConvArgs a; fill_args(d, a);
   a.src1 = src1; a.src2 = src2; a.w = w_packed; a.bias = bias; a.dst1 = dst1; a.dst2 = dst2; a.stats = stats;
-  if (a.pool2 && (stats || !rd_conv_out_reduce2_ok(d))) return fail("conv_fwd: out_reduce2 is not available for this descriptor (see rd_conv_out_reduce2_ok)");
+  if (a.pool2 && (stats || bias || d->act != RD_ACT_NONE || !rd_conv_out_reduce2_ok(d)))      // (a bias would be added once to the 2x2 sum instead of four times)
+    return fail("conv_fwd: out_reduce2 is not available for this descriptor / with a bias or an activation (see rd_conv_out_reduce2_ok)");
   RD_NS(d->dtype, launch_conv)(a, RD_DT(d->dtype), S(stream));
   return done("rd_conv_fwd");
 }
@@ -226,7 +227,8 @@ int rd_conv_fwd_fused(const rd_conv_desc* d, const rd_conv_fusion* f, const void
   if (addend && !rd_conv_add_ok(d)) return fail("conv_fwd_fused: an addend is not available for this descriptor (see rd_conv_add_ok)");
   rd::ConvArgs a; fill_args(d, a);
   a.src1 = src1; a.src2 = src2; a.w = w_packed; a.bias = bias; a.dst1 = dst1; a.dst2 = dst2; a.stats = stats; a.add1 = addend;
-  if (a.pool2 && !rd_conv_out_reduce2_ok(d)) return fail("conv_fwd_fused: out_reduce2 is not available for this descriptor (see rd_conv_out_reduce2_ok)");
+  if (a.pool2 && (bias || d->act != RD_ACT_NONE || !rd_conv_out_reduce2_ok(d)))
+    return fail("conv_fwd_fused: out_reduce2 is not available for this descriptor / with a bias or an activation (see rd_conv_out_reduce2_ok)");
   if (!apply_fusion(d, f, a)) return fail("conv_fwd_fused: the requested fusion is not available for this descriptor (see rd_conv_fusion_ok)");
   if (a.bn_y && !stats) return fail("conv_fwd_fused: the BatchNorm-backward sums need a stats buffer");
   if (!a.bn_y && a.pool2 && stats) return fail("conv_fwd_fused: out_reduce2 has no forward statistics");

@@ -278,7 +278,13 @@ static const FragVariant kFragVariants[] = {
 };
 struct FragPlan { int variant, tp, bn, nw, lin, WT, tilesH, tilesW, ntiles, ncb, np, ps; };
 
+// A/B hooks of tools/bench_conv.py and the tests: -1 = not set.  Variant indices are validated against the block width they may be used for
+// (a 64-channel block on a <= 32-channel operand would read weight-fragment tiles past the packed rows), everything else is a plain switch.
 static int frag_env(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+static int frag_variant_env(const char* name, int dflt, int bn_want) {
+  const int v = frag_env(name, dflt);
+  return (v >= 0 && v < 7 && kFragVariants[v].bn == bn_want) ? v : dflt;
+}
 
 static bool frag_plan(const ConvArgs& a, int dtype, FragPlan& p) {
   const int Cin = a.C1 + a.C2;
@@ -289,7 +295,7 @@ static bool frag_plan(const ConvArgs& a, int dtype, FragPlan& p) {
   // > 64 channels: eight-wave blocks (4 waves per SIMD at 126 VGPRs) when there are several chunks -- 0.847 -> 0.803 ms over the
   // seventeen RC-Net shapes of tools/bench_conv.py -- four 128-pixel waves for one-chunk layers (64 -> 128 data gradient: 0.066 vs 0.069)
   const bool multi = Cin > cke;
-  p.variant = a.Cout > 64 ? frag_env("RD_FRAG_V128", multi ? 1 : 0) : (a.Cout > 32 ? frag_env("RD_FRAG_V64", 2) : frag_env("RD_FRAG_V32", 5));
+  p.variant = a.Cout > 64 ? frag_variant_env("RD_FRAG_V128", multi ? 1 : 0, 128) : (a.Cout > 32 ? frag_variant_env("RD_FRAG_V64", 2, 64) : frag_variant_env("RD_FRAG_V32", 5, 32));
   // fewer 128 x 128 blocks than CUs (the deep encoder stages: 76 and 20 tiles): 64-channel blocks double the grid
   if (a.Cout > 64 && !getenv("RD_FRAG_V128") && frag_env("RD_FRAG_SPLIT", 1) &&
       cdiv((int64_t)a.M, 128) * cdiv(a.Cout, 128) < frag_env("RD_FRAG_SPLIT_BLOCKS", 256)) p.variant = 2;

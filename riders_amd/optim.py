@@ -60,6 +60,7 @@ class FlatAdam(object):
         self.grad_scale = 1.0      # 1 / world size, set by parallel.GradientAllReducer (the all-reduce sums)
         self.loss_scale = 1.0      # static loss scale of the fp16 mode: gradients arrive multiplied by it and are divided here
         self._overflow = None      # device int32[2] (flag, skipped steps) of the guarded fp16 step, allocated on first use
+        self._skips_reconciled = 0  # skipped steps already taken back out of the host step counters (reconcile_skipped)
         engine.set_param_grad_allocator(self._grad_view)
 
     # kept for callers that read the global step (all parameters that train share it)
@@ -86,8 +87,24 @@ class FlatAdam(object):
         return [i for i, t in enumerate(self._touched) if t]
 
     def skipped_steps(self):
-        """fp16 mode: optimizer steps dropped because a scaled gradient was not finite (synchronises)."""
+        """fp16 mode: optimizer steps dropped because a scaled gradient was not finite (synchronises).  The host-side step counters (bias
+        correction) are advanced before the device decides to skip, so after k skipped steps they run k ahead of the moments until
+        `reconcile_skipped()` (called by state_dict()) takes them back -- torch's GradScaler likewise does not advance `step` on a skip."""
         return 0 if self._overflow is None else int(self._overflow[1].item())
+
+    def reconcile_skipped(self, warn_after=8):
+        """Subtract the device-side skip count from the host step counters (synchronises; the loss scale is static, so a persistent overflow
+        skips EVERY step: more than `warn_after` skips since the last call raise a warning naming the remedy).  -> skips taken back."""
+        k = self.skipped_steps()
+        new = k - self._skips_reconciled
+        if new > 0:
+            self.steps = [max(0, s - new) if e else s for s, e in zip(self.steps, self._ever)]
+            self._skips_reconciled = k
+            if new > warn_after:
+                import warnings
+                warnings.warn("FlatAdam: %d optimizer steps were skipped because the scaled fp16 gradient was not finite; lower loss_scale "
+                              "(now %g)" % (new, self.loss_scale))
+        return max(new, 0)
 
     def slot_range(self, params):
         """-> sorted, merged [(start, end)] arena element ranges covering `params` (used to bucket the gradient all-reduce)."""
@@ -174,6 +191,7 @@ class FlatAdam(object):
         """torch.optim.Adam's layout: per-parameter `step` / `exp_avg` / `exp_avg_sq` (copies sliced out of the arena) for every parameter
         that has received a gradient, and one param group listing parameter indices."""
         state = {}
+        self.reconcile_skipped()      # `step` = updates actually applied (fp16 mode: not the skipped ones)
         for i, (p, o) in enumerate(zip(self.params, self.offsets)):
             if not self._ever[i]:
                 continue

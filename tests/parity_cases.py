@@ -1428,3 +1428,73 @@ def config4_case(dev):
         finally:
             engine.set_compute_dtype("fp32"); engine.clear_caches(); engine.set_param_grad_allocator(None)
     close_l2(preds["fp16"], preds["fp32"], 1e-2, "configs[4] SML eval prediction fp16 vs fp32")
+
+
+def config4_b8_case(dev):
+    """BASELINE.json configs[4] at ITS per-rank size: batch 8 of 3x512x1024 frames (padded 752x1124, R = 240 RoIs), fp16.  (a) fp16 logits of
+    all 240 RoIs against the fp32 HIP path on identical weights / inputs (relative L2 <= 2e-2, loss within 1e-2) -- the fp32 path itself is
+    pinned to the oracle by the other cases; (b) the loss-scaled graphed fp16 training step (scale 16384 folded back by Adam) is finite,
+    skips nothing and is bit-reproducible (two runs from the same state: identical losses and parameters)."""
+    from riders_amd import engine, rcnet_main
+    from riders_amd.optim import FlatAdam
+    cfg = rcnet_main.ZJU_CONFIG
+    batch = rcnet_main.synthetic_batch(8, 512, 1024, cfg, seed=46, device=dev)
+    res = {}
+    for mode in ("fp32", "fp16"):
+        engine.set_compute_dtype(mode); engine.clear_caches()
+        try:
+            torch.manual_seed(0)
+            model = rcnet_main.build_model(dev, cfg); model.train()
+            image, pts, rois, gt = rcnet_main.prepare_batch(batch)
+            assert tuple(image.shape[-2:]) == (752, 1124) and rois.shape[0] == 240
+            label, valid = engine.rcnet_labels(gt, pts, 0.5)
+            with torch.no_grad():
+                logits = model.forward(image, pts, rois)
+                loss, _ = model.compute_loss(logits, label, valid, cfg['w_positive_class'])
+            res[mode] = (logits.float().cpu(), float(loss))
+        finally:
+            engine.set_compute_dtype("fp32"); engine.clear_caches()
+    close_l2(res["fp16"][0], res["fp32"][0], 2e-2, "configs[4] B=8 logits fp16 vs fp32")
+    assert abs(res["fp16"][1] - res["fp32"][1]) <= 1e-2 * abs(res["fp32"][1]), (res["fp16"][1], res["fp32"][1])
+    engine.set_compute_dtype("fp16"); engine.clear_caches()
+    try:
+        runs = []
+        for rep in range(2):
+            torch.manual_seed(0)
+            model = rcnet_main.build_model(dev, cfg); model.train()
+            opt = FlatAdam(model.parameters(), lr=cfg['learning_rate'])
+            engine.set_deterministic_roi_pool(True)
+            try:
+                step = rcnet_main.GraphedTrainStep(model, opt, batch, cfg, warmup=1, loss_scale=16384.0)
+                ls = [float(step()) for _ in range(3)]
+            finally:
+                engine.set_deterministic_roi_pool(False)
+            assert all(np.isfinite(ls)) and opt.skipped_steps() == 0 and bool(torch.isfinite(opt.flat_param).all()), (ls, opt.skipped_steps())
+            runs.append((ls, opt.flat_param.clone()))
+            del step
+        assert runs[0][0] == runs[1][0] and torch.equal(runs[0][1], runs[1][1]), "configs[4] B=8 fp16 graphed step is not reproducible"
+    finally:
+        engine.set_compute_dtype("fp32"); engine.clear_caches(); engine.set_param_grad_allocator(None)
+
+
+def point_mlp_case(dev, R=240, tol=TOL):
+    """R5, RCNet/networks.py:299-329: FullyConnectedEncoder 3 -> 32 -> 64 -> 128 -> 128 -> 128 -> 2688 (= 128 x 7 x 3 at the ZJU patch size),
+    bias + LeakyReLU(0.2) after EVERY layer incl. the last; raw padded-pixel coordinates (hundreds) and metres as inputs (Appendix F.3), fp32.
+    Forward, input gradient and all twelve parameter gradients against the oracle."""
+    from riders_amd import networks
+    m = networks.FullyConnectedEncoder(3, [32, 64, 128, 128, 128], 128 * 7 * 3, 'kaiming_uniform', 'leaky_relu').to(dev)
+    sd = leaves(fill_state_dict(m, "pmlp"))
+    pts = np.stack([rand_array("pmlp.x", (R,), 500.0, lo=20.0), rand_array("pmlp.y", (R,), 250.0, lo=20.0), rand_array("pmlp.z", (R,), 60.0, lo=1.0)], 1)
+    x = t(pts.astype(np.float32))
+    xr = x.clone().requires_grad_()
+    ref = O.point_mlp(xr, sd, prefix='')
+    assert ref.shape == (R, 2688)
+    w = t(rand_array("pmlp.w", tuple(ref.shape), 1.0))
+    (ref * w).sum().backward()
+    xd = x.to(dev).requires_grad_()
+    out = m(xd)
+    close(out, ref, tol, "point MLP forward")
+    assert float((out.detach() < 0).float().mean()) > 0.05, "the last layer's LeakyReLU leaves negative outputs (x 0.2), not zeros"
+    (out * w.to(dev)).sum().backward()
+    close(xd.grad, xr.grad, tol, "point MLP d points")
+    assert compare_param_grads(m, sd, tol) == 12

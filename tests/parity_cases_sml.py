@@ -440,3 +440,103 @@ def sml_net_case(dev, tol=TOL):
     m.eval()
     with torch.no_grad():
         close(m.forward(x.detach(), d), g["pred_eval"], tol, "g9 eval pred")
+
+
+def sml_fullsize_backward_case(dev, tol=TOL):
+    """the SML BACKWARD at configs[2]'s frame size (fp32, B = 2, 256x512), i.e. at the pixel counts that select
+    conv_few_kernel, the persistent conv1x1_direct, the depthwise block geometry and the frag-conv tiles of the throughput run.  Input
+    gradient and the GLOBAL relative L2 error of all parameter gradients against an fp64 run of the oracle, with the conditioning-aware bound
+    of sml_net_case (3 x the fp32 oracle's own global error, floor 2e-3); the prediction itself within 1e-3."""
+    from riders_amd.midas.midas_net_custom import MidasNet_small_videpth
+    B, H, W = 2, 256, 512
+    m = MidasNet_small_videpth(device=dev, min_pred=0.1, max_pred=255.0, in_channels=3)
+    fill_state_dict(m, "g9.sml")
+    xin = rand_array("s19.x", (B, 3, H, W), 1.0)
+    din = rand_array("s19.d", (B, 1, H, W), 0.3, lo=0.05) + np.float32(0.02)
+    win = rand_array("s19.w", (B, 1, H, W), 1.0)
+    x = t(xin, dev).requires_grad_()
+    m.train()
+    pred = m.forward(x, t(din, dev))
+    (pred * t(win, dev)).sum().backward()
+
+    def oracle_grads(dt):
+        o = OS.SMLOracle().to(dt)
+        o.load_state_dict({k: (v.to(dt) if v.is_floating_point() else v) for k, v in fill_state_dict(MidasNet_small_videpth(
+            device='cpu', min_pred=0.1, max_pred=255.0, in_channels=3), "g9.sml").items()})
+        o.train()
+        xo = t(xin).to(dt).requires_grad_()
+        po = o(xo, t(din).to(dt))
+        (po * t(win).to(dt)).sum().backward()
+        gr = {k: p.grad for k, p in o.named_parameters()}
+        gr["x"] = xo.grad
+        return po.detach(), gr
+    p64, g64 = oracle_grads(torch.float64)
+    p32, g32 = oracle_grads(torch.float32)
+    close(pred, p64, tol, "SML 256x512 fp32 train-mode pred")
+
+    def gl2(get):
+        num = den = 0.0
+        for k, ref in g64.items():
+            if ref is None:
+                continue
+            v = get(k)
+            assert v is not None, k
+            num += float((v.detach().cpu().double() - ref).pow(2).sum()); den += float(ref.pow(2).sum())
+        return (num / den) ** 0.5
+    hip = {k: p.grad for k, p in m.named_parameters()}
+    hip["x"] = x.grad
+    for k, ref in g64.items():
+        if ref is None:
+            assert hip.get(k) is None, "unexpected gradient for " + k
+    gerr, gcond = gl2(lambda k: hip[k]), gl2(lambda k: g32[k])
+    print("SML 256x512 backward: global gradient error %.3e (fp32 oracle vs fp64: %.3e)" % (gerr, gcond))
+    assert gerr <= max(2e-3, 3 * gcond), "global gradient error %.3e vs fp32-oracle %.3e" % (gerr, gcond)
+    cx = float((g32["x"].double() - g64["x"]).abs().max() / float(g64["x"].abs().max()))
+    close(x.grad, g64["x"], max(4 * tol, 3 * cx), "SML 256x512 dx")
+
+
+def sml_config3_rank_case(dev, tol=TOL):
+    """The SML's per-rank share of configs[3] (global batch 32 on 8 GPUs = B = 4 per rank, 256x512 frames): fp32 loss of the whole step's
+    forward (device pre-step -> network -> 1/pred -> outlier removal -> loss) against the oracle chain within 1e-3, then the bf16 graphed
+    training step at that size is finite and bit-reproducible."""
+    from riders_amd import engine, sml_main
+    from riders_amd.optim import FlatAdam
+    cfg = sml_main.ZJU_SML_CONFIG
+    B, H, W = 4, 256, 512
+    batch = sml_main.synthetic_batch(B, H, W, seed=33)
+    torch.manual_seed(0)
+    m = sml_main.build_model(dev, cfg)
+    fill_state_dict(m, "g9.sml")
+    m.train()
+    o = OS.SMLOracle(); o.load_state_dict({k: v.detach().cpu() for k, v in m.state_dict().items()}); o.train()
+    with torch.no_grad():
+        loss = float(sml_main.forward_loss(m, tuple(b.to(dev) for b in batch), cfg, sml_main.make_outlier_removal(cfg)))
+        image, mono, radar, gt, sparse_gt, rcnet = [b.numpy() for b in batch]
+        hw = sml_main.net_size(H, W)
+        xs, ds = [], []
+        for i in range(B):
+            xo, do, _ = OS.prestep_sample(image[i], mono[i, 0], radar[i, 0], rcnet[i, 0], hw)
+            xs.append(t(np.ascontiguousarray(xo))); ds.append(t(np.ascontiguousarray(do)))
+        xo, do = torch.stack(xs).float(), torch.stack(ds).float()
+        gi = torch.stack([t(np.ascontiguousarray(OS.nearest_resize(gt[i, 0], hw[0], hw[1]))) for i in range(B)])[:, None].float()
+        gs = torch.stack([t(np.ascontiguousarray(OS.nearest_resize(sparse_gt[i, 0], hw[0], hw[1]))) for i in range(B)])[:, None].float()
+        gi = OS.remove_outliers(gi, cfg['outlier_removal_kernel_size'], cfg['outlier_removal_threshold'])
+        ref, _ = OS.compute_loss(1.0 / do, 1.0 / o(xo, do), gi, gs, w_smoothness=cfg['w_smoothness'], sobel_filter_size=cfg['sobel_filter_size'],
+                                 w_lidar_loss=cfg['w_lidar_loss'], w_edge=cfg['w_edge'])
+    assert abs(loss - float(ref)) <= tol * abs(float(ref)), (loss, float(ref))
+    with bf16_mode():
+        runs = []
+        dbatch = tuple(b.to(dev) for b in batch)
+        for rep in range(2):
+            torch.manual_seed(0)
+            m = sml_main.build_model(dev, cfg)
+            fill_state_dict(m, "g9.sml")
+            m.train()
+            opt = FlatAdam(m.parameters(), lr=cfg['learning_rate'])
+            step = sml_main.GraphedTrainStep(m, opt, dbatch, cfg, outlier=sml_main.make_outlier_removal(cfg), warmup=1)
+            ls = [float(step()) for _ in range(3)]
+            assert all(np.isfinite(ls)), ls
+            runs.append((ls, opt.flat_param.clone()))
+            del step
+            engine.set_param_grad_allocator(None)
+        assert runs[0][0] == runs[1][0] and torch.equal(runs[0][1], runs[1][1]), "SML B=4 bf16 graphed step is not reproducible"

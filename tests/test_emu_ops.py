@@ -227,3 +227,7 @@ def test_wgrad_reduce_batch(emu):
 
 def test_streaming_weight_gradient_of_few_channel_layers(emu):
     P.tiny_wgrad_cases(emu)
+
+
+def test_point_mlp(emu):
+    P.point_mlp_case(emu, R=6)

@@ -472,3 +472,11 @@ def test_wgrad_reduce_batch(gpu):
 
 def test_streaming_weight_gradient_of_few_channel_layers(gpu):
     P.tiny_wgrad_cases(gpu)
+
+
+def test_config4_per_rank_batch(gpu):
+    P.config4_b8_case(gpu)
+
+
+def test_point_mlp(gpu):
+    P.point_mlp_case(gpu)

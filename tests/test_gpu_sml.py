@@ -100,3 +100,11 @@ def test_sml_train_step_and_validate(gpu):
     model.eval()
     r = sml_main.validate_batch(model, batch)
     assert np.isfinite(r["abs_rel"]).all() and (r["count"] > 0).all()
+
+
+def test_sml_full_size_backward(gpu):
+    S.sml_fullsize_backward_case(gpu)
+
+
+def test_sml_config3_per_rank_share(gpu):
+    S.sml_config3_rank_case(gpu)
