@@ -29,7 +29,26 @@ _state = {"dtype": RD_F32, "tape": None, "defer_wgrad": True, "fused_loftr": Tru
           # staging its input.  Level 0: never (the separate rd_affine_act pass everywhere); 1 (default): inside residual blocks (conv1 ->
           # conv2 staging, conv2 -> fused apply + add + activation: measured faster); 2: also the decoder chain (measured SLOWER on MI355X:
           # the 3x3 kernels are vector-issue bound and the staging arithmetic costs more than the HBM pass it replaces -- DESIGN.md)
-          "lazy_bn": int(os.environ.get("RIDERS_LAZY_BN", "1"))}
+          "lazy_bn": int(os.environ.get("RIDERS_LAZY_BN", "1")),
+          # Round 4: the convolution weight gradients run on a SECOND stream.  They are off the backward's critical path (dy -> data gradient
+          # -> the next layer's BatchNorm passes): forked behind the event that marks dy ready, joined before the stage's slab reduction, they
+          # overlap the HBM-bound BatchNorm passes / the data gradients of the following layers (also inside captured hipGraphs: the fork /
+          # join become graph edges).  0: everything on one stream (A/B)
+          "wgrad_stream": os.environ.get("RIDERS_WGRAD_STREAM", "1") != "0"}
+
+
+_side = {}
+
+
+def _side_stream(dev):
+    s = _side.get(dev)
+    if s is None:
+        s = _side[dev] = torch.cuda.Stream(device=dev)
+    return s
+
+
+def set_wgrad_stream(flag):
+    _state["wgrad_stream"] = bool(flag)
 
 
 # how often a virtual activation was consumed in place / had to be written after all (tests assert that the fused routes are taken)
@@ -224,6 +243,24 @@ class Tape:
         self.colsum = []        # (rd_colsum_item, partial rows tensor, bias id): bias gradients finished by one launch per backward stage
         self.dw_reduce = []     # (rd_dw_wgrad_item, partial rows tensor, weight id): depthwise weight gradients, likewise
         self.ln_grads = {}      # id(gamma) -> dict(dg, db, acc, parts=[(partial rows tensor, rows)]): LayerNorm parameter gradients, likewise
+        self.side_keep = []     # operands of weight-gradient launches in flight on the side stream (kept alive until the join)
+        self.side_dev = None    # device whose side stream has un-joined work
+
+    def fork_side(self, like, keep):
+        """-> the side stream, made to wait for everything queued so far on the current stream (the operands in `keep` are then ready and
+        are held until join_side())."""
+        dev = like.device
+        side = _side_stream(dev)
+        side.wait_event(torch.cuda.current_stream(dev).record_event())
+        self.side_keep.extend(k for k in keep if k is not None)
+        self.side_dev = dev
+        return side
+
+    def join_side(self):
+        """The current stream waits for the side stream's weight-gradient launches (before their slabs are summed / a stage ends)."""
+        if self.side_dev is not None:
+            torch.cuda.current_stream(self.side_dev).wait_stream(_side_stream(self.side_dev))
+            self.side_dev, self.side_keep = None, []
 
     def requires(self, *ts):
         return any(t is not None and id(t) in self.req for t in ts)
@@ -305,6 +342,7 @@ class Tape:
         self.flush_colsum()
         self.flush_dw_reduce()
         self.flush_ln_grads()
+        self.join_side()
         pending, self.conv_reduce, self.conv_reduce_w = self.conv_reduce, [], set()
         if not pending:
             return
@@ -936,15 +974,18 @@ def conv_block(x, weight, *, x2=None, bias=None, stride=1, pad=None, up=None, bn
                 if id(weight) in t.conv_reduce_w:      # a weight used twice: its two reductions must not share a launch
                     t.flush_conv_reduce()
                 item = _lib.WgradReduceItem()
+                st_w = st
+                if _state["wgrad_stream"] and x.is_cuda and _timer["t"] is None:      # off the critical path: second stream, joined at the slab reduction
+                    st_w = ctypes.c_void_p(t.fork_side(x, (x, x2, dy, ws, dw)).cuda_stream)
                 if wfus is not None:
                     lazy_counts["wgrad_fused"] += 1
                     _chk(_timed("conv_wgrad", flops, lambda: lib.rd_conv_wgrad_partial_fused(ctypes.byref(d), ctypes.byref(wfus), _p(x), _p(x2), _p(dy),
-                                                                                                _p(ws), _p(dw), acc, ctypes.byref(item), st),
+                                                                                                _p(ws), _p(dw), acc, ctypes.byref(item), st_w),
                                 "wgrad " + shp + " (bn-in)", b_in + b_out + weight.numel() * 4,
                                 kernel=lambda: lib.rd_conv_wgrad_fused_kernel_name(ctypes.byref(d), ctypes.byref(wfus)).decode(), idem=True), "rd_conv_wgrad_partial_fused")
                 else:
                     _chk(_timed("conv_wgrad", flops, lambda: lib.rd_conv_wgrad_partial(ctypes.byref(d), _p(x), _p(x2), _p(dy), _p(ws), _p(dw), acc,
-                                                                                          ctypes.byref(item), st),
+                                                                                          ctypes.byref(item), st_w),
                                 "wgrad " + shp, b_in + b_out + weight.numel() * 4,
                                 kernel=lambda: lib.rd_conv_wgrad_kernel_name(ctypes.byref(d)).decode(), idem=True), "rd_conv_wgrad_partial")
                 t.defer_conv_reduce(item, ws, weight)

@@ -497,8 +497,8 @@ def sml_fullsize_backward_case(dev, tol=TOL):
 
 def sml_config3_rank_case(dev, tol=TOL):
     """The SML's per-rank share of configs[3] (global batch 32 on 8 GPUs = B = 4 per rank, 256x512 frames): fp32 loss of the whole step's
-    forward (device pre-step -> network -> 1/pred -> outlier removal -> loss) against the oracle chain within 1e-3, then the bf16 graphed
-    training step at that size is finite and bit-reproducible."""
+    forward (device pre-step -> network -> 1/pred -> outlier removal -> loss) against the oracle chain within 1e-3 stage by stage, then the
+    bf16 graphed training step at that size is finite and bit-reproducible."""
     from riders_amd import engine, sml_main
     from riders_amd.optim import FlatAdam
     cfg = sml_main.ZJU_SML_CONFIG
@@ -510,7 +510,7 @@ def sml_config3_rank_case(dev, tol=TOL):
     m.train()
     o = OS.SMLOracle(); o.load_state_dict({k: v.detach().cpu() for k, v in m.state_dict().items()}); o.train()
     with torch.no_grad():
-        loss = float(sml_main.forward_loss(m, tuple(b.to(dev) for b in batch), cfg, sml_main.make_outlier_removal(cfg)))
+        dbatch = tuple(b.to(dev) for b in batch)
         image, mono, radar, gt, sparse_gt, rcnet = [b.numpy() for b in batch]
         hw = sml_main.net_size(H, W)
         xs, ds = [], []
@@ -518,15 +518,22 @@ def sml_config3_rank_case(dev, tol=TOL):
             xo, do, _ = OS.prestep_sample(image[i], mono[i, 0], radar[i, 0], rcnet[i, 0], hw)
             xs.append(t(np.ascontiguousarray(xo))); ds.append(t(np.ascontiguousarray(do)))
         xo, do = torch.stack(xs).float(), torch.stack(ds).float()
+        # stage by stage: device pre-step, network, then the loss chain evaluated on the HIP prediction (the loss is dominated by the far
+        # depths = the smallest predictions, where a prediction error of 1e-3 of max|pred| is a much larger relative error of 1/pred: the
+        # end-to-end loss of two 1e-3-close predictions differs by 3e-3 here, so the loss kernels are checked on identical predictions)
+        x, d, _ = sml_main.prepare_inputs(dbatch[0], dbatch[1], dbatch[2], dbatch[5], hw, cfg)
+        close(x, xo, tol, "SML B=4 pre-step network input"); close(d, do, tol, "SML B=4 pre-step scaffold")
+        pred = m.forward(x, d)
+        close(pred, o(xo, do), tol, "SML B=4 256x512 fp32 train-mode pred")
+        loss = float(sml_main.forward_loss(m, dbatch, cfg, sml_main.make_outlier_removal(cfg)))
         gi = torch.stack([t(np.ascontiguousarray(OS.nearest_resize(gt[i, 0], hw[0], hw[1]))) for i in range(B)])[:, None].float()
         gs = torch.stack([t(np.ascontiguousarray(OS.nearest_resize(sparse_gt[i, 0], hw[0], hw[1]))) for i in range(B)])[:, None].float()
         gi = OS.remove_outliers(gi, cfg['outlier_removal_kernel_size'], cfg['outlier_removal_threshold'])
-        ref, _ = OS.compute_loss(1.0 / do, 1.0 / o(xo, do), gi, gs, w_smoothness=cfg['w_smoothness'], sobel_filter_size=cfg['sobel_filter_size'],
+        ref, _ = OS.compute_loss(1.0 / do, 1.0 / pred.float().cpu(), gi, gs, w_smoothness=cfg['w_smoothness'], sobel_filter_size=cfg['sobel_filter_size'],
                                  w_lidar_loss=cfg['w_lidar_loss'], w_edge=cfg['w_edge'])
     assert abs(loss - float(ref)) <= tol * abs(float(ref)), (loss, float(ref))
     with bf16_mode():
         runs = []
-        dbatch = tuple(b.to(dev) for b in batch)
         for rep in range(2):
             torch.manual_seed(0)
             m = sml_main.build_model(dev, cfg)

@@ -1,27 +1,40 @@
 #!/bin/bash
-# Round-4 check in one GPU call: (optional) GPU test suite + smoke, A/B bench lines (RIDERS_LAZY_BN=0/1 ...), rocprofv3 kernel statistics.
-# Output -> gpurun_out/r04_<tag>/    usage: tools/r04_check.sh <tag> [tests|lazytests|notests] [prof|noprof] [extra bench flags]
+# Round-4 check in one GPU call: (optional) GPU test suite + smoke, A/B bench lines of one environment switch, the full bench line,
+# rocprofv3 kernel statistics of the bf16 RC-Net leg.  Output -> gpurun_out/r04_<tag>/
+# usage: [ABVAR=RIDERS_LAZY_BN A=0 B=1] tools/r04_check.sh <tag> [tests|sometests|notests] [prof|noprof] [extra bench flags]
+#   sometests: K="pytest -k expression"
 tag=${1:-a}; what=${2:-tests}; prof=${3:-prof}; shift; shift; shift
 out=$GRAFT_REPO_ROOT/gpurun_out/r04_$tag; mkdir -p $out
 cd $GRAFT_REPO_ROOT
 if [ "$what" = "tests" ]; then
   timeout 1500 python -m pytest tests -q -m gpu -x > $out/gpu_tests.log 2>&1
-  tail -5 $out/gpu_tests.log
+  grep -E "passed|failed" $out/gpu_tests.log | tail -2
   timeout 300 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $out/smoke.log 2>&1
   tail -1 $out/smoke.log
-elif [ "$what" = "lazytests" ]; then
-  timeout 900 python -m pytest tests -q -m gpu -x -k "lazy or decoder or resnet or rcnet_e2e or conv" > $out/gpu_tests.log 2>&1
-  tail -5 $out/gpu_tests.log
+elif [ "$what" = "sometests" ]; then
+  timeout 900 python -m pytest tests -q -m gpu -x -k "${K:-lazy}" > $out/gpu_tests.log 2>&1
+  grep -E "passed|failed" $out/gpu_tests.log | tail -2
 fi
-for i in 1 2; do
-  RIDERS_LAZY_BN=${LZA:-0} timeout 600 python bench.py --gpus 1 --steps 50 --warmup 5 --no-cpu-baseline --no-sml "$@" 2>$out/bench_base.err | grep metric | sed 's/^/lazy0 /' | cut -c1-260
-  RIDERS_LAZY_BN=${LZB:-1} timeout 600 python bench.py --gpus 1 --steps 50 --warmup 5 --no-cpu-baseline --no-sml "$@" 2>$out/bench_new.err | grep metric | sed 's/^/lazy1 /' | cut -c1-260
-done
+if [ -n "$ABVAR" ]; then
+  for i in 1 2; do
+    env $ABVAR=$A timeout 600 python bench.py --gpus 1 --steps 50 --warmup 5 --no-cpu-baseline --no-sml --no-legs "$@" 2>$out/bench_a.err | grep metric | sed "s/^/$ABVAR=$A /" | cut -c1-230
+    env $ABVAR=$B timeout 600 python bench.py --gpus 1 --steps 50 --warmup 5 --no-cpu-baseline --no-sml --no-legs "$@" 2>$out/bench_b.err | grep metric | sed "s/^/$ABVAR=$B /" | cut -c1-230
+  done
+  if [ -n "$ABSML" ]; then
+    env $ABVAR=$A timeout 600 python bench.py --gpus 1 --steps 30 --warmup 5 --no-cpu-baseline --workload sml "$@" 2>>$out/bench_a.err | grep metric | sed "s/^/sml $ABVAR=$A /" | cut -c1-230
+    env $ABVAR=$B timeout 600 python bench.py --gpus 1 --steps 30 --warmup 5 --no-cpu-baseline --workload sml "$@" 2>>$out/bench_b.err | grep metric | sed "s/^/sml $ABVAR=$B /" | cut -c1-230
+  fi
+fi
 timeout 900 python bench.py --gpus 1 --steps 50 --warmup 5 --no-cpu-baseline --detail $out/per_shape.txt "$@" > $out/bench.json 2> $out/bench.err
-tail -3 $out/bench.err; cut -c1-300 $out/bench.json
+tail -3 $out/bench.err | cut -c1-300; python - <<PY
+import json
+d=json.loads(open("$out/bench.json").read().strip().split("\n")[-1])
+print("rcnet %.1f img/s (%.3f ms)"%(d["value"],d["ms_per_step"]), " ".join("%s %.1f"%(k,d[k]["value"]) for k in ("sml","chained","fp32","config4") if k in d))
+print("roofline", d["roofline"]["kernel"], "%.3f"%d["roofline"]["frac"], "| conv", d["roofline_conv"]["kernel"], "%.3f"%d["roofline_conv"]["frac"])
+PY
 if [ "$prof" = "prof" ]; then
   export TMPDIR=/tmp; cd /tmp
-  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof -o rc -- python3 $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 3 --settle-seconds 0 --no-cpu-baseline --no-sml --timer-repeat 1 "$@" > $out/prof.log 2>&1
+  timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $out/prof -o rc -- python3 $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 3 --settle-seconds 0 --no-cpu-baseline --no-sml --no-legs --timer-repeat 1 "$@" > $out/prof.log 2>&1
   find $out/prof -name "*kernel_stats.csv" -exec cp {} $out/kernel_stats.csv \;
   rm -rf $out/prof
 fi
