@@ -33,8 +33,10 @@ _state = {"dtype": RD_F32, "tape": None, "defer_wgrad": True, "fused_loftr": Tru
           # Round 4: the convolution weight gradients run on a SECOND stream.  They are off the backward's critical path (dy -> data gradient
           # -> the next layer's BatchNorm passes): forked behind the event that marks dy ready, joined before the stage's slab reduction, they
           # overlap the HBM-bound BatchNorm passes / the data gradients of the following layers (also inside captured hipGraphs: the fork /
-          # join become graph edges).  0: everything on one stream (A/B)
-          "wgrad_stream": os.environ.get("RIDERS_WGRAD_STREAM", "1") != "0"}
+          # join become graph edges).  MEASURED SLOWER on MI355X / ROCm 7 (RC-Net 1005 -> 952 img/s, SML 1222 -> 1155: 38 fork / join edges per
+          # step cost more than the overlap returns -- the wide weight-gradient blocks hold 506 of a SIMD's 512 VGPRs, nothing co-schedules):
+          # default 0 = everything on one stream; 1 keeps the experiment reproducible
+          "wgrad_stream": os.environ.get("RIDERS_WGRAD_STREAM", "0") != "0"}
 
 
 _side = {}
