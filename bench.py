@@ -301,7 +301,7 @@ def run_workload(kind, args, dev, world, rank, steps, warmup, **override):
         batch = rcnet_main.synthetic_batch(batch_n, h, w, cfg, seed=1234 + rank, device=dev)
     model.train()
     opt = FlatAdam(model.parameters(), lr=cfg['learning_rate'])
-    reducer = GradientAllReducer(opt, stages=stages) if (world > 1 or args.force_ddp) else None
+    reducer = GradientAllReducer(opt, stages=stages, mode=args.allreduce) if (world > 1 or args.force_ddp) else None
     if reducer is not None:
         reducer.broadcast_parameters(0)
 
@@ -367,8 +367,10 @@ def run_workload(kind, args, dev, world, rank, steps, warmup, **override):
     ms = elapsed * 1e3 / max(steps, 1)
     out = dict(value=batch_n * world * steps / elapsed, ms_per_step=ms, steps=steps, warmup=warmup, settle_steps=settle, final_loss=final_loss,
                batch_per_gpu=batch_n, height=h, width=w,
-               launch_mode="eager" if args.eager else ("hipGraphs split at the stage marks (fwd+bwd) + eager all-reduce/Adam" if reducer is not None
-                                                       else "one hipGraph (fwd+bwd) + eager Adam"))
+               launch_mode="eager" if args.eager else (
+                   ("one hipGraph (fwd+bwd) with an external event per stage mark + eager all-reduce/Adam" if getattr(step, "stage_events", None)
+                    else "hipGraphs split at the stage marks (fwd+bwd) + eager all-reduce/Adam") if reducer is not None
+                   else "one hipGraph (fwd+bwd) + eager Adam"))
     if rank == 0:
         key = "%s_b%d_%dx%d_%s" % (kind, batch_n, h, w, args.dtype)
         out["roofline"] = kernel_roofline(timer, timed_steps, ms, args.dtype, key)
@@ -470,6 +472,8 @@ def main():
     ap.add_argument("--eager", action="store_true", help="do not capture forward+backward into hipGraphs")
     ap.add_argument("--force-ddp", action="store_true", help="run the N > 1 code path (RCCL process group, stage-bucketed all-reduce) on however "
                                                               "many ranks there are, including one: a functional check of that path on a 1-GPU box")
+    ap.add_argument("--allreduce", default="all_reduce", choices=["all_reduce", "rs_ag"],
+                    help="gradient exchange per bucket: one all-reduce (RCCL's choice: a ring on xGMI) or reduce_scatter + all_gather in place")
     ap.add_argument("--detail", default=None, help="write a per-launch-shape timing table to this file")
     ap.add_argument("--timer-repeat", type=int, default=5, help="idempotent launches issued this many times per HIP-event pair in the instrumented "
                                                                 "steps (1 under rocprofv3, so that its launch counts per step are the real ones)")
@@ -533,8 +537,8 @@ def main():
                         "BASELINE configs[1] per rank at every N (weak scaling); configs[3]'s global 32 on 8 GPUs is --config3"},
             "final_loss": head["final_loss"], "launch_mode": head["launch_mode"], "settle_steps": head["settle_steps"],
             "world_size": world, "comm": comm,
-            "allreduce": None if not ddp else "RCCL sum of the flat fp32 gradient arena in 3 stage buckets, each started when the backward "
-                                              "passes its stage mark (overlaps the remaining backward graphs); 1/N folded into Adam",
+            "allreduce": None if not ddp else "RCCL sum (%s) of the flat fp32 gradient arena in 3 stage buckets, each started when the backward "
+                                              "passes its stage mark (overlaps the remaining backward); 1/N folded into Adam" % args.allreduce,
             "roofline": head["roofline"], "roofline_conv": head["roofline_conv"],
         }
         if sml is not None:

@@ -280,6 +280,19 @@ int rd_roi_pool_bwd_tile(const void* dout, const float* rois, const int32_t* arg
 int rd_roi_pool_bwd_gather(const void* dout, const float* rois, const int32_t* argmax, void* dx, int32_t R, int32_t N, int32_t H,
                            int32_t W, int32_t C, int32_t PH, int32_t PW, float spatial_scale, int32_t dtype, void* stream);
 
+/* Compact arg-max (round 4): ONE byte per pooled element instead of the int32 pixel index -- the arg-max's offset inside its bin window,
+   (h - hs) << 4 | (w - ws), 0xFF for an empty bin (RC-Net's bins are ~1.02 pixels; the int32 was 4 of the 6 bytes per element either pass
+   moves).  C must be a multiple of the 16-byte vector.  A bin window wider or taller than 15 pixels cannot be encoded: the forward then
+   raises *overflow_flag (device int32, zero-initialised by the caller, sticky) and both backward forms write NaN gradients.
+   rd_roi_pool_bwd_u8 = the fp32 scatter form (rd_roi_pool_bwd), rd_roi_pool_bwd_gather_u8 = the pixel-owner gather (rd_roi_pool_bwd_gather). */
+int rd_roi_pool_fwd_u8(const void* x, const float* rois, void* out, uint8_t* argmax, int32_t* overflow_flag, int32_t R, int32_t N, int32_t H,
+                       int32_t W, int32_t C, int32_t PH, int32_t PW, float spatial_scale, int32_t dtype, void* stream);
+int rd_roi_pool_bwd_u8(const void* dout, const float* rois, const uint8_t* argmax, const int32_t* overflow_flag, float* dx_f32, int32_t R,
+                       int32_t N, int32_t H, int32_t W, int32_t C, int32_t PH, int32_t PW, float spatial_scale, int32_t dtype, void* stream);
+int rd_roi_pool_bwd_gather_u8(const void* dout, const float* rois, const uint8_t* argmax, const int32_t* overflow_flag, void* dx, int32_t R,
+                              int32_t N, int32_t H, int32_t W, int32_t C, int32_t PH, int32_t PW, float spatial_scale, int32_t dtype,
+                              void* stream);
+
 /* ---- layout / resampling helpers ------------------------------------------------------------------------- */
 int rd_cast(const void* src, void* dst, int64_t n, int32_t src_dtype, int32_t dst_dtype, float scale, void* stream);
 int rd_add(const void* a, const void* b, void* out, int64_t n, int32_t dtype, void* stream);

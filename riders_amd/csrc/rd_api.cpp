@@ -514,6 +514,30 @@ int rd_roi_pool_bwd_gather(const void* dout, const float* rois, const int32_t* a
   RD_NS(dtype, launch_roi_pool_bwd_gather)(dout, rois, argmax, dx, R, N, H, W, C, PH, PW, scale, RD_DT(dtype), S(stream));
   return done("rd_roi_pool_bwd_gather");
 }
+int rd_roi_pool_fwd_u8(const void* x, const float* rois, void* out, uint8_t* argmax, int32_t* overflow_flag, int32_t R, int32_t N, int32_t H,
+                       int32_t W, int32_t C, int32_t PH, int32_t PW, float scale, int32_t dtype, void* stream) {
+  if (R == 0) return 0;
+  if (!x || !rois || !out || !argmax || !overflow_flag || !dt_ok(dtype)) return fail("roi_pool_fwd_u8: bad args");
+  if (C % (dtype == RD_F32 ? 4 : 8)) return fail("roi_pool_fwd_u8: C must be a multiple of the 16-byte vector (use rd_roi_pool_fwd)");
+  RD_NS(dtype, launch_roi_pool_fwd_u8)(x, rois, out, argmax, overflow_flag, R, N, H, W, C, PH, PW, scale, RD_DT(dtype), S(stream));
+  return done("rd_roi_pool_fwd_u8");
+}
+int rd_roi_pool_bwd_u8(const void* dout, const float* rois, const uint8_t* argmax, const int32_t* overflow_flag, float* dx, int32_t R, int32_t N,
+                       int32_t H, int32_t W, int32_t C, int32_t PH, int32_t PW, float scale, int32_t dtype, void* stream) {
+  if (!dx || !overflow_flag || !dt_ok(dtype)) return fail("roi_pool_bwd_u8: bad args");
+  if (R > 0 && (!dout || !rois || !argmax)) return fail("roi_pool_bwd_u8: null pointer");
+  RD_NS(dtype, launch_roi_pool_bwd_u8)(dout, rois, argmax, overflow_flag, dx, R, N, H, W, C, PH, PW, scale, RD_DT(dtype), S(stream));
+  return done("rd_roi_pool_bwd_u8");
+}
+int rd_roi_pool_bwd_gather_u8(const void* dout, const float* rois, const uint8_t* argmax, const int32_t* overflow_flag, void* dx, int32_t R,
+                              int32_t N, int32_t H, int32_t W, int32_t C, int32_t PH, int32_t PW, float scale, int32_t dtype, void* stream) {
+  if (!dx || !overflow_flag || !dt_ok(dtype)) return fail("roi_pool_bwd_gather_u8: bad args");
+  if (R > 0 && (!dout || !rois || !argmax)) return fail("roi_pool_bwd_gather_u8: null pointer");
+  if (C % (dtype == RD_F32 ? 4 : 8)) return fail("roi_pool_bwd_gather_u8: C must be a multiple of the 16-byte vector");
+  if (N <= 0 || H <= 0 || W <= 0 || PH <= 0 || PW <= 0 || PH >= (1 << 19) || PW >= (1 << 19)) return fail("roi_pool_bwd_gather_u8: bad sizes");
+  RD_NS(dtype, launch_roi_pool_bwd_gather_u8)(dout, rois, argmax, overflow_flag, dx, R, N, H, W, C, PH, PW, scale, RD_DT(dtype), S(stream));
+  return done("rd_roi_pool_bwd_gather_u8");
+}
 int rd_cast(const void* src, void* dst, int64_t n, int32_t sd, int32_t dd, float scale, void* stream) {
   if (!src || !dst || !dt_ok(sd) || !dt_ok(dd)) return fail("cast: bad args");
   if ((sd == RD_BF16 && dd == RD_F16) || (sd == RD_F16 && dd == RD_BF16)) return fail("cast: bf16 <-> fp16 is not supported (the two 16-bit types live in separate builds): convert through fp32");

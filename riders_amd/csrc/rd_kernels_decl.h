@@ -110,6 +110,13 @@ void launch_roi_pool_bwd_tile(const void* dout, const float* rois, const int* ar
 void launch_roi_pool_bwd_gather(const void* dout, const float* rois, const int* argmax, void* dx, int R, int N, int H, int W, int C,
                                 int PH, int PW, float scale, int dtype, hipStream_t st);
 
+void launch_roi_pool_fwd_u8(const void* x, const float* rois, void* out, unsigned char* argmax, int* flag, int R, int N, int H, int W, int C,
+                            int PH, int PW, float scale, int dtype, hipStream_t st);
+void launch_roi_pool_bwd_u8(const void* dout, const float* rois, const unsigned char* argmax, const int* flag, float* dx_f32, int R, int N, int H,
+                            int W, int C, int PH, int PW, float scale, int dtype, hipStream_t st);
+void launch_roi_pool_bwd_gather_u8(const void* dout, const float* rois, const unsigned char* argmax, const int* flag, void* dx, int R, int N, int H,
+                                   int W, int C, int PH, int PW, float scale, int dtype, hipStream_t st);
+
 // rd_elementwise.hip
 void launch_pad_channels(const void* src, void* dst, int64_t rows, int C, int Cpad, int dtype, hipStream_t st);
 void launch_unpad_weight_grad(const float* dwp, float* dw, int Cout, int Cin, int CinPad, int taps, int accumulate, hipStream_t st);

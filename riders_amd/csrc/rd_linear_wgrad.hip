@@ -15,44 +15,71 @@ namespace rd {
 struct LwgBatch { LwgGemm it[LWG_MAX_ITEMS]; };
 struct LwgRedBatch { LwgReduce it[LWG_MAX_REDS]; };
 
-template <typename T>
-__global__ __launch_bounds__(256) void linear_wgrad_kernel(LwgBatch b) {
+// Block tile = (NI x 64 input channels) x (NO x 64 output channels), NI + NO <= 4 (round 4; 64 x 64 before).  The EfficientNet-Lite3 1x1 layers
+// of the SML are 24..232 channels on one side and 6x that on the other: with 64 x 64 tiles the narrow operand's token rows were staged once
+// per 64-wide tile of the wide one (x of a 24 -> 144 expansion three times, dY of a 576 -> 96 projection nine times; PMC round 3: 1.47 GB
+// fetched per launch against ~0.5 GB of operands).  A block now stages up to three tiles of the wide operand next to one of the narrow one
+// (or 2 + 2) per token stage, and every wave keeps its 32 x 32 corner of each of the NI x NO sub-tiles.
+__host__ __device__ __forceinline__ void lwg_shape(int Cin, int Cout, int& ni, int& no) {
+  const int tci = (Cin + 63) >> 6, tco = (Cout + 63) >> 6;
+  if (tci == 1) { ni = 1; no = tco < 3 ? tco : 3; }
+  else if (tco == 1) { no = 1; ni = tci < 3 ? tci : 3; }
+  else { ni = 2; no = 2; }
+}
+__host__ __device__ __forceinline__ int lwg_blocks_per_split(int Cin, int Cout) {
+  int ni, no;
+  lwg_shape(Cin, Cout, ni, no);
+  return ((((Cin + 63) >> 6) + ni - 1) / ni) * ((((Cout + 63) >> 6) + no - 1) / no);
+}
+
+template <typename T, int NI, int NO>
+__device__ __forceinline__ void lwg_body(const LwgGemm& g, uint4 (&sT)[2][4][(sizeof(T) == 2 ? 64 * 8 : 32 * 17)]) {
   constexpr bool BF = sizeof(T) == 2;
   constexpr int ST = BF ? 64 : 32;             // tokens per stage (a 64-channel row is 128 / 256 bytes)
   constexpr int RS = BF ? 8 : 17;              // 16-byte slots per LDS row (fp32 rows padded by one slot: 4 k-groups on 4 bank sets)
   constexpr int SPR = BF ? 8 : 16;             // data slots per row
   constexpr int VE = Elem<T>::VE;
-  __shared__ uint4 sX[2][ST * RS];
-  __shared__ uint4 sY[2][ST * RS];
-  const LwgGemm& g = b.it[blockIdx.y];
   const int Cin = g.C1 + g.C2;
   const int tci = (Cin + 63) >> 6, tco = (g.Cout + 63) >> 6;   // partial edge tiles: channel counts need only be multiples of VE
-  const int per = tci * tco;
+  const int gci = (tci + NI - 1) / NI, gco = (tco + NO - 1) / NO;
+  const int per = gci * gco;
   if ((int)blockIdx.x >= per * g.nsplit) return;
   const int sp = blockIdx.x / per, rem = blockIdx.x - sp * per;
-  const int co0 = (rem / tci) * 64, ci0 = (rem % tci) * 64;
+  const int co0 = (rem / gci) * 64 * NO, ci0 = (rem % gci) * 64 * NI;
   const int mbeg = sp * g.rows_per_split, mend = min(g.M, mbeg + g.rows_per_split);
-  const T* xs; int xld, xc0;   // a 64-channel tile lies in ONE source (C1 % 64 == 0 whenever C2 > 0)
-  if (ci0 < g.C1) { xs = (const T*)g.x1; xld = g.C1; xc0 = ci0; } else { xs = (const T*)g.x2; xld = g.C2; xc0 = ci0 - g.C1; }
+  const T* xs[NI]; int xld[NI], xc0[NI];   // a 64-channel tile lies in ONE source (C1 % 64 == 0 whenever C2 > 0)
+#pragma unroll
+  for (int ti = 0; ti < NI; ti++) {
+    const int c = ci0 + ti * 64;
+    if (c < g.C1 || g.C2 == 0) { xs[ti] = (const T*)g.x1; xld[ti] = g.C1; xc0[ti] = c; } else { xs[ti] = (const T*)g.x2; xld[ti] = g.C2; xc0[ti] = c - g.C1; }
+  }
   const T* ys = (const T*)g.dy;
 
   const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
   const int fr = lane & 15, fg = lane >> 4;
-  const int wr = wv >> 1, wc = wv & 1;        // wave tile: couts wr*32..+31, cins wc*32..+31
+  const int wr = wv >> 1, wc = wv & 1;        // wave tile inside every 64 x 64 sub-tile: couts wr*32..+31, cins wc*32..+31
 
-  uint4 rx[2], ry[2];
+  uint4 rx[NI][2], ry[NO][2];
   auto fetch = [&](int m0) RD_INLINE_LAMBDA {
 #pragma unroll
     for (int i = 0; i < 2; i++) {
       const int idx = t + 256 * i;             // ST * SPR = 512 slots per tile
       const int row = idx / SPR, sl = idx - row * SPR;
       const int m = m0 + row;
-      uint4 vx = make_uint4(0, 0, 0, 0), vy = vx;
-      if (m < mend) {
-        if (xc0 + sl * VE < xld) vx = *reinterpret_cast<const uint4*>(xs + (int64_t)m * xld + xc0 + sl * VE);
-        if (co0 + sl * VE < g.Cout) vy = *reinterpret_cast<const uint4*>(ys + (int64_t)m * g.Cout + co0 + sl * VE);
+      const bool mv = m < mend;
+      const int64_t mc = mv ? m : mbeg;        // unconditional loads from a clamped row, zero selected afterwards
+#pragma unroll
+      for (int ti = 0; ti < NI; ti++) {
+        const bool ok = mv && xc0[ti] + sl * VE < xld[ti];
+        const uint4 v = *reinterpret_cast<const uint4*>(xs[ti] + mc * xld[ti] + (ok ? xc0[ti] + sl * VE : 0));
+        rx[ti][i] = ok ? v : make_uint4(0, 0, 0, 0);
       }
-      rx[i] = vx; ry[i] = vy;
+#pragma unroll
+      for (int to = 0; to < NO; to++) {
+        const bool ok = mv && co0 + to * 64 + sl * VE < g.Cout;
+        const uint4 v = *reinterpret_cast<const uint4*>(ys + mc * g.Cout + (ok ? co0 + to * 64 + sl * VE : 0));
+        ry[to][i] = ok ? v : make_uint4(0, 0, 0, 0);
+      }
     }
   };
   auto stash = [&](int buf) RD_INLINE_LAMBDA {
@@ -60,16 +87,22 @@ __global__ __launch_bounds__(256) void linear_wgrad_kernel(LwgBatch b) {
     for (int i = 0; i < 2; i++) {
       const int idx = t + 256 * i;
       const int row = idx / SPR, sl = idx - row * SPR;
-      sX[buf][row * RS + sl] = rx[i];
-      sY[buf][row * RS + sl] = ry[i];
+#pragma unroll
+      for (int ti = 0; ti < NI; ti++) sT[buf][ti][row * RS + sl] = rx[ti][i];
+#pragma unroll
+      for (int to = 0; to < NO; to++) sT[buf][NI + to][row * RS + sl] = ry[to][i];
     }
   };
 
-  f32x4 acc[2][2];
+  f32x4 acc[NO][NI][2][2];
 #pragma unroll
-  for (int i = 0; i < 2; i++)
+  for (int to = 0; to < NO; to++)
 #pragma unroll
-    for (int j = 0; j < 2; j++) acc[i][j] = f32x4{0, 0, 0, 0};
+    for (int ti = 0; ti < NI; ti++)
+#pragma unroll
+      for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++) acc[to][ti][i][j] = f32x4{0, 0, 0, 0};
 
   const int nst = mend > mbeg ? (mend - mbeg + ST - 1) / ST : 0;
   if (nst > 0) fetch(mbeg);
@@ -80,60 +113,91 @@ __global__ __launch_bounds__(256) void linear_wgrad_kernel(LwgBatch b) {
     if (s + 1 < nst) fetch(mbeg + (s + 1) * ST);
     if (BF) {
       // transpose-read roles: this lane supplies token (fg*8 + (fr>>2)) (+4), channels 4*(fr&3)..+3 of the 16-channel tile being read
-      const unsigned short* bx = reinterpret_cast<const unsigned short*>(&sX[buf][0]) + (fg * 8 + (fr >> 2)) * 64 + (fr & 3) * 4;
-      const unsigned short* by = reinterpret_cast<const unsigned short*>(&sY[buf][0]) + (fg * 8 + (fr >> 2)) * 64 + (fr & 3) * 4;
+      const int lo_ = (fg * 8 + (fr >> 2)) * 64 + (fr & 3) * 4;
 #pragma unroll
       for (int ks = 0; ks < 2; ks++) {
-        s16x8 ya[2], xb[2];
+        s16x8 ya[NO][2], xb[NI][2];
 #pragma unroll
-        for (int i = 0; i < 2; i++) {
-          const int o = ks * 32 * 64 + (wr * 2 + i) * 16;
-          uint2 lo = lds_read_tr16_b64(by + o), hi = lds_read_tr16_b64(by + o + 4 * 64);
-          uint4 v = make_uint4(lo.x, lo.y, hi.x, hi.y);
-          __builtin_memcpy(&ya[i], &v, 16);
-        }
+        for (int to = 0; to < NO; to++)
 #pragma unroll
-        for (int j = 0; j < 2; j++) {
-          const int o = ks * 32 * 64 + (wc * 2 + j) * 16;
-          uint2 lo = lds_read_tr16_b64(bx + o), hi = lds_read_tr16_b64(bx + o + 4 * 64);
-          uint4 v = make_uint4(lo.x, lo.y, hi.x, hi.y);
-          __builtin_memcpy(&xb[j], &v, 16);
-        }
+          for (int i = 0; i < 2; i++) {
+            const unsigned short* by = reinterpret_cast<const unsigned short*>(&sT[buf][NI + to][0]) + lo_ + ks * 32 * 64 + (wr * 2 + i) * 16;
+            uint2 lo = lds_read_tr16_b64(by), hi = lds_read_tr16_b64(by + 4 * 64);
+            uint4 v = make_uint4(lo.x, lo.y, hi.x, hi.y);
+            __builtin_memcpy(&ya[to][i], &v, 16);
+          }
 #pragma unroll
-        for (int i = 0; i < 2; i++)
+        for (int ti = 0; ti < NI; ti++)
 #pragma unroll
-          for (int j = 0; j < 2; j++) acc[i][j] = mfma_16x16x32_bf16(ya[i], xb[j], acc[i][j]);
+          for (int j = 0; j < 2; j++) {
+            const unsigned short* bx = reinterpret_cast<const unsigned short*>(&sT[buf][ti][0]) + lo_ + ks * 32 * 64 + (wc * 2 + j) * 16;
+            uint2 lo = lds_read_tr16_b64(bx), hi = lds_read_tr16_b64(bx + 4 * 64);
+            uint4 v = make_uint4(lo.x, lo.y, hi.x, hi.y);
+            __builtin_memcpy(&xb[ti][j], &v, 16);
+          }
+#pragma unroll
+        for (int to = 0; to < NO; to++)
+#pragma unroll
+          for (int ti = 0; ti < NI; ti++)
+#pragma unroll
+            for (int i = 0; i < 2; i++)
+#pragma unroll
+              for (int j = 0; j < 2; j++) acc[to][ti][i][j] = mfma_16x16x32_bf16(ya[to][i], xb[ti][j], acc[to][ti][i][j]);
       }
     } else {
-      const float* fx = reinterpret_cast<const float*>(&sX[buf][0]);
-      const float* fy = reinterpret_cast<const float*>(&sY[buf][0]);
 #pragma unroll
       for (int ks = 0; ks < ST / 4; ks++) {
         const int row = (ks * 4 + fg) * RS * 4;
-        float ya[2], xb[2];
+        float ya[NO][2], xb[NI][2];
 #pragma unroll
-        for (int i = 0; i < 2; i++) ya[i] = fy[row + (wr * 2 + i) * 16 + fr];
+        for (int to = 0; to < NO; to++)
 #pragma unroll
-        for (int j = 0; j < 2; j++) xb[j] = fx[row + (wc * 2 + j) * 16 + fr];
+          for (int i = 0; i < 2; i++) ya[to][i] = reinterpret_cast<const float*>(&sT[buf][NI + to][0])[row + (wr * 2 + i) * 16 + fr];
 #pragma unroll
-        for (int i = 0; i < 2; i++)
+        for (int ti = 0; ti < NI; ti++)
 #pragma unroll
-          for (int j = 0; j < 2; j++) acc[i][j] = mfma_16x16x4_f32(ya[i], xb[j], acc[i][j]);
+          for (int j = 0; j < 2; j++) xb[ti][j] = reinterpret_cast<const float*>(&sT[buf][ti][0])[row + (wc * 2 + j) * 16 + fr];
+#pragma unroll
+        for (int to = 0; to < NO; to++)
+#pragma unroll
+          for (int ti = 0; ti < NI; ti++)
+#pragma unroll
+            for (int i = 0; i < 2; i++)
+#pragma unroll
+              for (int j = 0; j < 2; j++) acc[to][ti][i][j] = mfma_16x16x4_f32(ya[to][i], xb[ti][j], acc[to][ti][i][j]);
       }
     }
   }
   float* slab = g.slab + (int64_t)sp * g.Cout * Cin;
 #pragma unroll
-  for (int i = 0; i < 2; i++)
+  for (int to = 0; to < NO; to++)
 #pragma unroll
-    for (int j = 0; j < 2; j++) {
-      const int ci = ci0 + (wc * 2 + j) * 16 + fr;
+    for (int ti = 0; ti < NI; ti++)
 #pragma unroll
-      for (int r = 0; r < 4; r++) {
-        const int co = co0 + (wr * 2 + i) * 16 + fg * 4 + r;
-        if (co < g.Cout && ci < Cin) slab[(int64_t)co * Cin + ci] = acc[i][j][r];
-      }
-    }
+      for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+          const int ci = ci0 + ti * 64 + (wc * 2 + j) * 16 + fr;
+#pragma unroll
+          for (int r = 0; r < 4; r++) {
+            const int co = co0 + to * 64 + (wr * 2 + i) * 16 + fg * 4 + r;
+            if (co < g.Cout && ci < Cin) slab[(int64_t)co * Cin + ci] = acc[to][ti][i][j][r];
+          }
+        }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void linear_wgrad_kernel(LwgBatch b) {
+  __shared__ uint4 sT[2][4][(sizeof(T) == 2 ? 64 * 8 : 32 * 17)];      // [buffer][tile: NI input tiles, then NO output tiles][token row][slot]
+  const LwgGemm& g = b.it[blockIdx.y];
+  int ni, no;
+  lwg_shape(g.C1 + g.C2, g.Cout, ni, no);
+  if (ni == 1 && no == 1) lwg_body<T, 1, 1>(g, sT);
+  else if (ni == 1 && no == 2) lwg_body<T, 1, 2>(g, sT);
+  else if (ni == 1) lwg_body<T, 1, 3>(g, sT);
+  else if (no == 1 && ni == 2) lwg_body<T, 2, 1>(g, sT);
+  else if (no == 1) lwg_body<T, 3, 1>(g, sT);
+  else lwg_body<T, 2, 2>(g, sT);
 }
 
 // dw[e] (+)= sum of the item's slabs, fixed order (deterministic).  thread = (float4 column ol, slab lane sl): lane sl adds slabs sl, sl+SL, ...
@@ -193,7 +257,7 @@ void launch_linear_wgrad_batch(const LwgGemm* gemms, int n_gemm, const LwgReduce
     for (int i = 0; i < n; i++) {
       b.it[i] = gemms[base + i];
       const LwgGemm& g = b.it[i];
-      maxb = std::max(maxb, ((g.C1 + g.C2 + 63) >> 6) * ((g.Cout + 63) >> 6) * g.nsplit);
+      maxb = std::max(maxb, lwg_blocks_per_split(g.C1 + g.C2, g.Cout) * g.nsplit);
     }
     for (int i = n; i < LWG_MAX_ITEMS; i++) b.it[i] = b.it[0];
     if (dtype == 0) hipLaunchKernelGGL((linear_wgrad_kernel<float>), dim3((unsigned)maxb, (unsigned)n), dim3(256), 0, st, b);

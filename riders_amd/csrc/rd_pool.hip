@@ -168,11 +168,47 @@ __global__ __launch_bounds__(256) void roi_pool_fwd_kernel(const T* __restrict__
 }
 
 
-// 16-byte-vector form (C % VE == 0): one thread pools VE channels of a bin
-template <typename T>
+// Compact arg-max (round 4): one BYTE per pooled element instead of the int32 pixel index -- the arg-max as an offset inside its bin window,
+// (h - hs) * 16 + (w - ws), 0xFF for an empty bin.  RC-Net's bins are ~1.02 pixels (windows of 2 x 2), the int32 was 4 of the 6 bytes the
+// forward writes per element and 4 of the 6 the backward reads (83.6 M elements per step).  Windows wider or taller than 15 pixels cannot
+// be encoded: the forward then raises *flag (sticky) and the backward kernels turn the whole gradient into NaN -- loud, not silent.
+static constexpr int ROI_U8_MAXWIN = 15;
+__device__ __forceinline__ void roi_store_arg(int* p, const int (&bi)[4]) { *reinterpret_cast<int4*>(p) = make_int4(bi[0], bi[1], bi[2], bi[3]); }
+__device__ __forceinline__ void roi_store_arg(int* p, const int (&bi)[8]) {
+  *reinterpret_cast<int4*>(p) = make_int4(bi[0], bi[1], bi[2], bi[3]);
+  *reinterpret_cast<int4*>(p + 4) = make_int4(bi[4], bi[5], bi[6], bi[7]);
+}
+__device__ __forceinline__ void roi_store_arg(unsigned char* p, const int (&bi)[4]) {
+  *reinterpret_cast<unsigned*>(p) = (unsigned)(bi[0] & 255) | ((unsigned)(bi[1] & 255) << 8) | ((unsigned)(bi[2] & 255) << 16) | ((unsigned)(bi[3] & 255) << 24);
+}
+__device__ __forceinline__ void roi_store_arg(unsigned char* p, const int (&bi)[8]) {
+  uint2 v;
+  v.x = (unsigned)(bi[0] & 255) | ((unsigned)(bi[1] & 255) << 8) | ((unsigned)(bi[2] & 255) << 16) | ((unsigned)(bi[3] & 255) << 24);
+  v.y = (unsigned)(bi[4] & 255) | ((unsigned)(bi[5] & 255) << 8) | ((unsigned)(bi[6] & 255) << 16) | ((unsigned)(bi[7] & 255) << 24);
+  *reinterpret_cast<uint2*>(p) = v;
+}
+__device__ __forceinline__ void roi_load_arg(const int* p, int (&am)[4]) { const int4 a = *reinterpret_cast<const int4*>(p); am[0] = a.x; am[1] = a.y; am[2] = a.z; am[3] = a.w; }
+__device__ __forceinline__ void roi_load_arg(const int* p, int (&am)[8]) {
+  const int4 a = *reinterpret_cast<const int4*>(p), b = *reinterpret_cast<const int4*>(p + 4);
+  am[0] = a.x; am[1] = a.y; am[2] = a.z; am[3] = a.w; am[4] = b.x; am[5] = b.y; am[6] = b.z; am[7] = b.w;
+}
+__device__ __forceinline__ void roi_load_arg(const unsigned char* p, int (&am)[4]) {
+  const unsigned a = *reinterpret_cast<const unsigned*>(p);
+  am[0] = a & 255; am[1] = (a >> 8) & 255; am[2] = (a >> 16) & 255; am[3] = a >> 24;
+}
+__device__ __forceinline__ void roi_load_arg(const unsigned char* p, int (&am)[8]) {
+  const uint2 a = *reinterpret_cast<const uint2*>(p);
+  am[0] = a.x & 255; am[1] = (a.x >> 8) & 255; am[2] = (a.x >> 16) & 255; am[3] = a.x >> 24;
+  am[4] = a.y & 255; am[5] = (a.y >> 8) & 255; am[6] = (a.y >> 16) & 255; am[7] = a.y >> 24;
+}
+
+// 16-byte-vector form (C % VE == 0): one thread pools VE channels of a bin.  A = int (pixel index h * W + w, -1 = empty bin) or unsigned
+// char (compact code, above)
+template <typename T, typename A>
 __global__ __launch_bounds__(256) void roi_pool_fwd_vec_kernel(const T* __restrict__ x, const float* __restrict__ rois,
-                                                               T* __restrict__ out, int* __restrict__ argmax, int R, int N,
-                                                               int H, int W, int C, int PH, int PW, float scale) {
+                                                               T* __restrict__ out, A* __restrict__ argmax, int R, int N,
+                                                               int H, int W, int C, int PH, int PW, float scale, int* __restrict__ flag) {
+  constexpr bool U8 = sizeof(A) == 1;
   constexpr int VE = Elem<T>::VE;
   const int G = C / VE;
   const int64_t total = (int64_t)R * PH * PW * G;
@@ -193,6 +229,7 @@ __global__ __launch_bounds__(256) void roi_pool_fwd_vec_kernel(const T* __restri
     float best[VE]; int bi[VE];
 #pragma unroll
     for (int e = 0; e < VE; e++) { best[e] = empty ? 0.f : -FLT_MAX; bi[e] = -1; }
+    if (U8 && (he - hs > ROI_U8_MAXWIN || we - ws > ROI_U8_MAXWIN)) *flag = 1;      // cannot be encoded: the backward poisons the gradient
     const bool bok = b >= 0 && b < N;
     const T* xb = x + (int64_t)(bok ? b : 0) * H * W * C + g * VE;
     if (he - hs <= 2 && we - ws <= 2) {
@@ -205,7 +242,7 @@ __global__ __launch_bounds__(256) void roi_pool_fwd_vec_kernel(const T* __restri
         const int h = hs + (q >> 1), w = ws + (q & 1);
         ok[q] = bok && h < he && w < we;
         const int hc = min(max(h, 0), H - 1), wc = min(max(w, 0), W - 1);
-        idx[q] = h * W + w;
+        idx[q] = U8 ? (q >> 1) * 16 + (q & 1) : h * W + w;
         raw[q] = *reinterpret_cast<const uint4*>(xb + ((int64_t)hc * W + wc) * C);
       }
 #pragma unroll
@@ -221,13 +258,11 @@ __global__ __launch_bounds__(256) void roi_pool_fwd_vec_kernel(const T* __restri
           float v[VE];
           ldv(xb + ((int64_t)h * W + w) * C, v);
 #pragma unroll
-          for (int e = 0; e < VE; e++) if (v[e] > best[e]) { best[e] = v[e]; bi[e] = h * W + w; }
+          for (int e = 0; e < VE; e++) if (v[e] > best[e]) { best[e] = v[e]; bi[e] = U8 ? (((h - hs) & 15) << 4) | ((w - ws) & 15) : h * W + w; }
         }
     }
     stv(out + i * VE, best);
-#pragma unroll
-    for (int e4 = 0; e4 < VE / 4; e4++)
-      *reinterpret_cast<int4*>(argmax + i * VE + e4 * 4) = make_int4(bi[e4 * 4], bi[e4 * 4 + 1], bi[e4 * 4 + 2], bi[e4 * 4 + 3]);
+    roi_store_arg(argmax + i * VE, bi);      // (compact form: -1 & 255 = 0xFF = empty)
   }
 }
 
@@ -247,6 +282,31 @@ __global__ __launch_bounds__(256) void roi_pool_bwd_kernel(const T* __restrict__
   }
 }
 
+
+// the same for the compact arg-max: the window start of the element's bin is recomputed with the forward's expressions
+template <typename T>
+__global__ __launch_bounds__(256) void roi_pool_bwd_u8_kernel(const T* __restrict__ dout, const float* __restrict__ rois,
+                                                              const unsigned char* __restrict__ argmax, const int* __restrict__ flag,
+                                                              float* __restrict__ dx, int R, int N, int H, int W, int C, int PH, int PW, float scale) {
+  const int64_t total = (int64_t)R * PH * PW * C;
+  const bool poison = *flag != 0;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int a = argmax[i];
+    if (a == 255 && !poison) continue;
+    int c = (int)(i % C); int64_t q = i / C;
+    int pw = (int)(q % PW); q /= PW; int ph = (int)(q % PH); int r = (int)(q / PH);
+    const float* roi = rois + (int64_t)r * 5;
+    const int b = (int)roi[0];
+    if (b < 0 || b >= N) continue;
+    const int sw = (int)roundf(roi[1] * scale), sh = (int)roundf(roi[2] * scale);
+    const int ew = (int)roundf(roi[3] * scale), eh = (int)roundf(roi[4] * scale);
+    const int rw = max(ew - sw + 1, 1), rh = max(eh - sh + 1, 1);
+    const float bh = (float)rh / (float)PH, bw = (float)rw / (float)PW;
+    const int hs = min(max((int)floorf((float)ph * bh) + sh, 0), H), ws = min(max((int)floorf((float)pw * bw) + sw, 0), W);
+    if (poison) { atomicAdd(dx + ((int64_t)b * H * W + min(hs, H - 1) * W + min(ws, W - 1)) * C + c, __builtin_nanf("")); continue; }
+    atomicAdd(dx + ((int64_t)b * H * W + (hs + (a >> 4)) * W + ws + (a & 15)) * C + c, Elem<T>::ld(dout + i));
+  }
+}
 
 // ---- gather form of the RoI-pool backward (deterministic, no atomics, writes the activation dtype directly) ---------------------------
 // A block owns a 16 x 16 pixel tile of one image.  It first lists, in ascending r, the RoIs of that image whose (scaled) box meets the
@@ -380,10 +440,14 @@ __global__ __launch_bounds__(256) void roi_pool_bwd_gather_kernel(const T* __res
 // the tile form (per-channel arg-max decode + LDS read-add-write) and ~150 in the first gather form (window loops per pixel).
 static constexpr int RPT_CC = 32;      // channels per block of the pixel-owner and tile forms
 struct RoiCand { int r; int rowc[RPB_T]; int colc[RPB_T]; };    // (first bin << 12) | count per tile row / column; 0 = none
-template <typename T>
+// compact arg-max: offset of the tile row / column inside the window of its first and of its second covering bin (d0 | d1 << 8)
+struct RoiCandOff { int rowd[RPB_T]; int cold[RPB_T]; };
+template <typename T, typename A>
 __global__ __launch_bounds__(256) void roi_pool_bwd_pix_kernel(const T* __restrict__ dout, const float* __restrict__ rois,
-                                                               const int* __restrict__ argmax, T* __restrict__ dx, int R, int H,
-                                                               int W, int C, int PH, int PW, float scale, int tilesW) {
+                                                               const A* __restrict__ argmax, T* __restrict__ dx, int R, int H,
+                                                               int W, int C, int PH, int PW, float scale, int tilesW, const int* __restrict__ flag) {
+  constexpr bool U8 = sizeof(A) == 1;
+  __shared__ RoiCandOff coff[U8 ? RPB_MAXL : 1];
   constexpr int VE = Elem<T>::VE, GC = RPT_CC / VE;        // channel groups per block = items per thread (256 pixels x GC groups)
   constexpr int PR = 256 / GC / RPB_T;                     // tile rows covered by one pass of the block's threads
   __shared__ RoiGeo geo[RPB_MAXL];
@@ -404,11 +468,7 @@ __global__ __launch_bounds__(256) void roi_pool_bwd_pix_kernel(const T* __restri
     for (int e = 0; e < VE; e++) acc[k][e] = 0.f;
   }
   auto fetch = [&](int64_t o, int (&am)[VE], uint4& dv) RD_INLINE_LAMBDA {
-#pragma unroll
-    for (int e4 = 0; e4 < VE / 4; e4++) {
-      const int4 a4 = *reinterpret_cast<const int4*>(argmax + o + e4 * 4);
-      am[e4 * 4] = a4.x; am[e4 * 4 + 1] = a4.y; am[e4 * 4 + 2] = a4.z; am[e4 * 4 + 3] = a4.w;
-    }
+    roi_load_arg(argmax + o, am);
     dv = *reinterpret_cast<const uint4*>(dout + o);
   };
   auto take = [&](const int (&am)[VE], const uint4& raw, int target, float (&a)[VE]) RD_INLINE_LAMBDA {
@@ -466,6 +526,16 @@ __global__ __launch_bounds__(256) void roi_pool_bwd_pix_kernel(const T* __restri
         const int code = cnt ? ((first << 12) | min(cnt, 4095)) : 0;
         if (rows) cand[li].rowc[pos] = code; else cand[li].colc[pos] = code;
         if (j == 0) cand[li].r = q.r;
+        if (U8) {      // x - window start of the first and the second covering bin (what the forward encoded for this pixel)
+          int d[2];
+#pragma unroll
+          for (int k2 = 0; k2 < 2; k2++) {
+            const int s0 = min(max((int)floorf((float)(first + k2) * bin) + start, 0), lim);
+            d[k2] = (x - s0) & 255;
+          }
+          const int dcode = d[0] | (d[1] << 8);
+          if (rows) coff[li].rowd[pos] = dcode; else coff[li].cold[pos] = dcode;
+        }
       }
       __syncthreads();
       // ---- every item walks the list.  RC-Net's bins are ~1.02 pixels, so nearly every window is 2 x 2 pixels and nearly every pixel
@@ -480,13 +550,16 @@ __global__ __launch_bounds__(256) void roi_pool_bwd_pix_kernel(const T* __restri
         const int cc = cand[li].colc[lw];
         const int rr = cand[li].r;
         const int nc = cc & 4095, cf = cc >> 12;
+        const int cdw = U8 ? coff[li].cold[lw] : 0;
 #pragma unroll
         for (int kb = 0; kb < GC; kb += KB) {
           int am[KB][4][VE]; uint4 dv[KB][4]; int nr[KB], rf[KB];
+          int rdh[KB];
 #pragma unroll
           for (int k = 0; k < KB; k++) {
             const int rc = nc ? cand[li].rowc[lh0 + (kb + k) * PR] : 0;
             nr[k] = tgt[kb + k] >= 0 ? (rc & 4095) : 0; rf[k] = rc >> 12;
+            rdh[k] = U8 ? coff[li].rowd[lh0 + (kb + k) * PR] : 0;
 #pragma unroll
             for (int q = 0; q < 4; q++) {
               const int ia = q >> 1, ib = q & 1;
@@ -499,14 +572,24 @@ __global__ __launch_bounds__(256) void roi_pool_bwd_pix_kernel(const T* __restri
 #pragma unroll
             for (int q = 0; q < 4; q++) {
               const int ia = q >> 1, ib = q & 1;
-              take(am[k][q], dv[k][q], (ia < nr[k] && ib < nc) ? tgt[kb + k] : -2, acc[kb + k]);
+              // compact form: the pixel's code inside candidate bin (rf + ia, cf + ib) = (row offset << 4) | column offset
+              const int want = U8 ? ((((rdh[k] >> (8 * ia)) & 255) << 4) | ((cdw >> (8 * ib)) & 255)) : tgt[kb + k];
+              take(am[k][q], dv[k][q], (ia < nr[k] && ib < nc) ? want : -2, acc[kb + k]);
             }
             if (nr[k] > 2 || (nc > 2 && nr[k] > 0)) {      // bins smaller than a pixel: the candidates outside the 2 x 2 block
+              const RoiGeo gq = geo[li];
+              const int hh = h0 + lh0 + (kb + k) * PR, ww = w0 + lw;
               for (int ia = 0; ia < nr[k]; ia++)
                 for (int ib = (ia < 2 ? 2 : 0); ib < nc; ib++) {
                   int am1[VE]; uint4 dv1;
                   fetch((((int64_t)rr * PH + rf[k] + ia) * PW + cf + ib) * C + goff, am1, dv1);
-                  take(am1, dv1, tgt[kb + k], acc[kb + k]);
+                  int want = tgt[kb + k];
+                  if (U8) {
+                    const int hs1 = min(max((int)floorf((float)(rf[k] + ia) * gq.bh) + gq.sh, 0), H);
+                    const int ws1 = min(max((int)floorf((float)(cf + ib) * gq.bw) + gq.sw, 0), W);
+                    want = (((hh - hs1) & 15) << 4) | ((ww - ws1) & 15);
+                  }
+                  take(am1, dv1, want, acc[kb + k]);
                 }
             }
           }
@@ -515,9 +598,14 @@ __global__ __launch_bounds__(256) void roi_pool_bwd_pix_kernel(const T* __restri
     }
     __syncthreads();
   }
+  const bool poison = U8 && *flag != 0;      // a window the compact arg-max could not encode: the gradient is made visibly wrong
 #pragma unroll
   for (int k = 0; k < GC; k++) {
     const int h = h0 + lh0 + k * PR;
+    if (poison) {
+#pragma unroll
+      for (int e = 0; e < VE; e++) acc[k][e] = __builtin_nanf("");
+    }
     if (tgt[k] >= 0) stv(dx + (((int64_t)b * H + h) * W + w0 + lw) * C + c0 + g * VE, acc[k]);
   }
 }
@@ -714,8 +802,8 @@ void launch_roi_pool_fwd(const void* x, const float* rois, void* out, int* argma
   const int ve = dtype == 0 ? 4 : 8;
   if (C % ve == 0) {
     unsigned gv = ew_grid(n / ve);
-    if (dtype == 0) hipLaunchKernelGGL((roi_pool_fwd_vec_kernel<float>), dim3(gv), dim3(256), 0, st, (const float*)x, rois, (float*)out, argmax, R, N, H, W, C, PH, PW, scale);
-    else hipLaunchKernelGGL((roi_pool_fwd_vec_kernel<bf16_t>), dim3(gv), dim3(256), 0, st, (const bf16_t*)x, rois, (bf16_t*)out, argmax, R, N, H, W, C, PH, PW, scale);
+    if (dtype == 0) hipLaunchKernelGGL((roi_pool_fwd_vec_kernel<float, int>), dim3(gv), dim3(256), 0, st, (const float*)x, rois, (float*)out, argmax, R, N, H, W, C, PH, PW, scale, (int*)nullptr);
+    else hipLaunchKernelGGL((roi_pool_fwd_vec_kernel<bf16_t, int>), dim3(gv), dim3(256), 0, st, (const bf16_t*)x, rois, (bf16_t*)out, argmax, R, N, H, W, C, PH, PW, scale, (int*)nullptr);
     return;
   }
   if (dtype == 0) hipLaunchKernelGGL((roi_pool_fwd_kernel<float>), dim3(ew_grid(n)), dim3(256), 0, st, (const float*)x, rois, (float*)out, argmax, R, N, H, W, C, PH, PW, scale);
@@ -744,13 +832,39 @@ void launch_roi_pool_bwd_gather(const void* dout, const float* rois, const int* 
   static const bool old_form = getenv("RD_ROI_GATHER_V1") != nullptr;      // A/B: the first gather form (window loops per pixel)
   if (!old_form && PH < (1 << 19) && PW < (1 << 19)) {
     dim3 grid((unsigned)(tilesH * tilesW), (unsigned)N, (unsigned)cdiv(C, RPT_CC));
-    if (dtype == 0) hipLaunchKernelGGL((roi_pool_bwd_pix_kernel<float>), grid, dim3(256), 0, st, (const float*)dout, rois, argmax, (float*)dx, R, H, W, C, PH, PW, scale, tilesW);
-    else hipLaunchKernelGGL((roi_pool_bwd_pix_kernel<bf16_t>), grid, dim3(256), 0, st, (const bf16_t*)dout, rois, argmax, (bf16_t*)dx, R, H, W, C, PH, PW, scale, tilesW);
+    if (dtype == 0) hipLaunchKernelGGL((roi_pool_bwd_pix_kernel<float, int>), grid, dim3(256), 0, st, (const float*)dout, rois, argmax, (float*)dx, R, H, W, C, PH, PW, scale, tilesW, (const int*)nullptr);
+    else hipLaunchKernelGGL((roi_pool_bwd_pix_kernel<bf16_t, int>), grid, dim3(256), 0, st, (const bf16_t*)dout, rois, argmax, (bf16_t*)dx, R, H, W, C, PH, PW, scale, tilesW, (const int*)nullptr);
     return;
   }
   dim3 grid((unsigned)(tilesH * tilesW), (unsigned)N);
   if (dtype == 0) hipLaunchKernelGGL((roi_pool_bwd_gather_kernel<float>), grid, dim3(256), 0, st, (const float*)dout, rois, argmax, (float*)dx, R, H, W, C, PH, PW, scale, tilesW);
   else hipLaunchKernelGGL((roi_pool_bwd_gather_kernel<bf16_t>), grid, dim3(256), 0, st, (const bf16_t*)dout, rois, argmax, (bf16_t*)dx, R, H, W, C, PH, PW, scale, tilesW);
+}
+
+// ---- compact (one byte per element) arg-max forms: C must be a multiple of the 16-byte vector -----------------------------------------
+void launch_roi_pool_fwd_u8(const void* x, const float* rois, void* out, unsigned char* argmax, int* flag, int R, int N, int H, int W, int C,
+                            int PH, int PW, float scale, int dtype, hipStream_t st) {
+  const int64_t n = (int64_t)R * PH * PW * C;
+  if (n == 0) return;
+  const unsigned gv = ew_grid(n / (dtype == 0 ? 4 : 8));
+  if (dtype == 0) hipLaunchKernelGGL((roi_pool_fwd_vec_kernel<float, unsigned char>), dim3(gv), dim3(256), 0, st, (const float*)x, rois, (float*)out, argmax, R, N, H, W, C, PH, PW, scale, flag);
+  else hipLaunchKernelGGL((roi_pool_fwd_vec_kernel<bf16_t, unsigned char>), dim3(gv), dim3(256), 0, st, (const bf16_t*)x, rois, (bf16_t*)out, argmax, R, N, H, W, C, PH, PW, scale, flag);
+}
+void launch_roi_pool_bwd_u8(const void* dout, const float* rois, const unsigned char* argmax, const int* flag, float* dx_f32, int R, int N, int H,
+                            int W, int C, int PH, int PW, float scale, int dtype, hipStream_t st) {
+  const int64_t nz = (int64_t)N * H * W * C;
+  hipLaunchKernelGGL(zero_f32_kernel, dim3(ew_grid(nz / 4 + 1)), dim3(256), 0, st, dx_f32, nz);
+  const int64_t n = (int64_t)R * PH * PW * C;
+  if (n == 0) return;
+  if (dtype == 0) hipLaunchKernelGGL((roi_pool_bwd_u8_kernel<float>), dim3(ew_grid(n)), dim3(256), 0, st, (const float*)dout, rois, argmax, flag, dx_f32, R, N, H, W, C, PH, PW, scale);
+  else hipLaunchKernelGGL((roi_pool_bwd_u8_kernel<bf16_t>), dim3(ew_grid(n)), dim3(256), 0, st, (const bf16_t*)dout, rois, argmax, flag, dx_f32, R, N, H, W, C, PH, PW, scale);
+}
+void launch_roi_pool_bwd_gather_u8(const void* dout, const float* rois, const unsigned char* argmax, const int* flag, void* dx, int R, int N, int H,
+                                   int W, int C, int PH, int PW, float scale, int dtype, hipStream_t st) {
+  const int tilesH = (int)cdiv(H, RPB_T), tilesW = (int)cdiv(W, RPB_T);
+  dim3 grid((unsigned)(tilesH * tilesW), (unsigned)N, (unsigned)cdiv(C, RPT_CC));
+  if (dtype == 0) hipLaunchKernelGGL((roi_pool_bwd_pix_kernel<float, unsigned char>), grid, dim3(256), 0, st, (const float*)dout, rois, argmax, (float*)dx, R, H, W, C, PH, PW, scale, tilesW, flag);
+  else hipLaunchKernelGGL((roi_pool_bwd_pix_kernel<bf16_t, unsigned char>), grid, dim3(256), 0, st, (const bf16_t*)dout, rois, argmax, (bf16_t*)dx, R, H, W, C, PH, PW, scale, tilesW, flag);
 }
 
 }  // namespace rd

@@ -36,7 +36,8 @@ _state = {"dtype": RD_F32, "tape": None, "defer_wgrad": True, "fused_loftr": Tru
           # join become graph edges).  MEASURED SLOWER on MI355X / ROCm 7 (RC-Net 1005 -> 952 img/s, SML 1222 -> 1155: 38 fork / join edges per
           # step cost more than the overlap returns -- the wide weight-gradient blocks hold 506 of a SIMD's 512 VGPRs, nothing co-schedules):
           # default 0 = everything on one stream; 1 keeps the experiment reproducible
-          "wgrad_stream": os.environ.get("RIDERS_WGRAD_STREAM", "0") != "0"}
+          "wgrad_stream": os.environ.get("RIDERS_WGRAD_STREAM", "0") != "0",
+          "roi_u8": os.environ.get("RIDERS_ROI_U8", "1") != "0"}      # compact (one byte) RoI-pool arg-max; 0: int32 indices (A/B)
 
 
 _side = {}
@@ -412,7 +413,9 @@ class Tape:
             if M > 40960:
                 # enough (tile, split) blocks to fill the GPU, bounded by the slab traffic: every split writes (and the reduction
                 # re-reads) a Cout x Cin slab -- at most 512 splits and 32 MB of slabs per item
-                tiles = ((it["Cin"] + 63) // 64) * ((it["Cout"] + 63) // 64)
+                tci, tco = (it["Cin"] + 63) // 64, (it["Cout"] + 63) // 64      # blocks per split = groups of up to 3 + 1 / 2 x 2 tiles (lwg_shape, rd_linear_wgrad.hip)
+                ni, no = (1, min(tco, 3)) if tci == 1 else ((min(tci, 3), 1) if tco == 1 else (2, 2))
+                tiles = ((tci + ni - 1) // ni) * ((tco + no - 1) // no)
                 want = max(64, min(512, (1024 + tiles - 1) // tiles, (32 << 20) // (4 * it["Cin"] * it["Cout"])))
                 rps = max(128, ((M + want - 1) // want + 63) & ~63)
             else:
@@ -1093,19 +1096,64 @@ def maxpool(x, k=3, s=2, p=1):
     return out
 
 
-def roi_pool(x, rois, output_size, spatial_scale):
-    """x (N,H,W,C); rois (R,5) fp32 = (batch idx, x1, y1, x2, y2) -> (R,PH,PW,C) + int32 argmax."""
+_roi_flags = {}
+
+
+def _roi_flag(dev):
+    """Sticky device flag of the compact RoI arg-max: raised by a forward that met a bin window it cannot encode (> 15 pixels in a
+    direction); the backward kernels then write NaN gradients -- a wrong geometry cannot pass silently."""
+    f = _roi_flags.get(dev)
+    if f is None:
+        f = _roi_flags[dev] = torch.zeros(1, dtype=torch.int32, device=dev)
+    return f
+
+
+def roi_argmax(out):
+    """Arg-max of an engine.roi_pool output as int32 pixel indices h * W + w (-1 = empty bin), torchvision's convention; the compact
+    one-byte form is decoded on the host with the forward's window arithmetic (tests / debugging; the kernels never need the indices)."""
+    arg = out._rd_argmax
+    if arg.dtype == torch.int32:
+        return arg
+    import numpy as np
+    rois, (H, W, PH, PW, scale) = out._rd_roi_geom
+    a = arg.cpu().numpy().astype(np.int64)
+    r = rois.detach().cpu().numpy().astype(np.float32)
+    f32 = np.float32
+
+    def starts(lo, hi, P, lim):      # clamp(floor(p * bin) + start), all in float32 as the kernels compute it
+        s = np.round(lo * f32(scale)).astype(np.int64); e = np.round(hi * f32(scale)).astype(np.int64)
+        ext = np.maximum(e - s + 1, 1)
+        binsz = (ext.astype(np.float32) / f32(P))[:, None]
+        return np.clip(np.floor(np.arange(P, dtype=np.float32)[None, :] * binsz).astype(np.int64) + s[:, None], 0, lim)
+    hs, ws = starts(r[:, 2], r[:, 4], PH, H), starts(r[:, 1], r[:, 3], PW, W)
+    idx = (hs[:, :, None, None] + (a >> 4)) * W + ws[:, None, :, None] + (a & 15)
+    return torch.from_numpy(np.where(a == 255, -1, idx).astype(np.int32))
+
+
+def roi_pool(x, rois, output_size, spatial_scale, compact=None):
+    """x (N,H,W,C); rois (R,5) fp32 = (batch idx, x1, y1, x2, y2) -> (R,PH,PW,C); the arg-max is kept for the backward as int32 pixel indices
+    or (compact, the default where the kernels of this shape support it: round 4) as ONE BYTE per element, the arg-max's offset inside its bin
+    window -- `roi_argmax(out)` gives the indices either way."""
     lib, t, dt, st = L(), tape(), rd_of(x), _stream(x)
     N, H, W, C = x.shape
     R = rois.shape[0]
     PH, PW = int(output_size[0]), int(output_size[1])
     out = torch.empty((R, PH, PW, C), dtype=x.dtype, device=x.device)
-    arg = torch.empty((R, PH, PW, C), dtype=torch.int32, device=x.device)
-    # algorithmic bytes (SURVEY 8d): pooled values + int32 argmax written, the source map read once
-    roi_bytes = out.numel() * (x.element_size() + 4) + x.numel() * x.element_size()
-    _chk(_tb("roi_pool", roi_bytes, lambda: lib.rd_roi_pool_fwd(_p(x), _p(rois), _p(out), _p(arg), R, N, H, W, C, PH, PW, float(spatial_scale), dt, st),
-             "roi_pool fwd %dx%d C=%d" % (PH, PW, C)), "rd_roi_pool_fwd")
+    if compact is None:
+        compact = _state["roi_u8"]
+    compact = bool(compact) and C % (16 // x.element_size()) == 0 and _ROI_BWD in ("auto", "gather", "atomic") and PH < (1 << 19) and PW < (1 << 19)
+    arg = torch.empty((R, PH, PW, C), dtype=torch.uint8 if compact else torch.int32, device=x.device)
+    flag = _roi_flag(x.device) if compact else None
+    # algorithmic bytes (SURVEY 8d): pooled values + argmax written, the source map read once
+    roi_bytes = out.numel() * (x.element_size() + arg.element_size()) + x.numel() * x.element_size()
+    if compact:
+        _chk(_tb("roi_pool", roi_bytes, lambda: lib.rd_roi_pool_fwd_u8(_p(x), _p(rois), _p(out), _p(arg), _p(flag), R, N, H, W, C, PH, PW,
+                                                                        float(spatial_scale), dt, st), "roi_pool fwd %dx%d C=%d" % (PH, PW, C)), "rd_roi_pool_fwd_u8")
+    else:
+        _chk(_tb("roi_pool", roi_bytes, lambda: lib.rd_roi_pool_fwd(_p(x), _p(rois), _p(out), _p(arg), R, N, H, W, C, PH, PW, float(spatial_scale), dt, st),
+                 "roi_pool fwd %dx%d C=%d" % (PH, PW, C)), "rd_roi_pool_fwd")
     out._rd_argmax = arg
+    out._rd_roi_geom = (rois, (H, W, PH, PW, float(spatial_scale)))
     if t is not None and t.requires(x):
         t.mark(out)
 
@@ -1116,6 +1164,20 @@ def roi_pool(x, rois, output_size, spatial_scale):
             nblk = ((H + 15) // 16) * ((W + 15) // 16) * N * ((C + 31) // 32)
             big = nblk >= max(_state["roi_tile_min_blocks"], 1)
             gather = _state["deterministic_roi_pool"] or _ROI_BWD == "gather" or (_ROI_BWD == "auto" and big and _state["roi_tile_min_blocks"] > 0)
+            if compact:      # pixel-owner gather on the large maps (or everywhere when determinism is asked for), fp32 L2 atomics on the small ones
+                if gather:
+                    dx = torch.empty_like(x)
+                    _chk(_tb("roi_pool", roi_bytes, lambda: lib.rd_roi_pool_bwd_gather_u8(_p(g), _p(rois), _p(arg), _p(flag), _p(dx), R, N, H, W, C, PH, PW,
+                                                                                             float(spatial_scale), dt, st),
+                             "roi_pool bwd(gather) %dx%d C=%d" % (PH, PW, C)), "rd_roi_pool_bwd_gather_u8")
+                    t.add_grad(x, dx)
+                    return
+                dx32 = torch.empty((N, H, W, C), dtype=torch.float32, device=x.device)
+                _chk(_tb("roi_pool", roi_bytes, lambda: lib.rd_roi_pool_bwd_u8(_p(g), _p(rois), _p(arg), _p(flag), _p(dx32), R, N, H, W, C, PH, PW,
+                                                                                float(spatial_scale), dt, st),
+                         "roi_pool bwd(atomic) %dx%d C=%d" % (PH, PW, C)), "rd_roi_pool_bwd_u8")
+                t.add_grad(x, cast(dx32, x.dtype))
+                return
             if gather and C % (16 // x.element_size()) == 0:   # pixel-owner gather: fixed summation order, no atomics
                 dx = torch.empty_like(x)
                 _chk(_tb("roi_pool", roi_bytes, lambda: lib.rd_roi_pool_bwd_gather(_p(g), _p(rois), _p(arg), _p(dx), R, N, H, W, C, PH, PW,

@@ -3,9 +3,11 @@ Interpolator2D :21-49), same names, arguments and attributes.
 
 The reference evaluates scipy.interpolate.griddata at every pixel of the map (fill_value 1.0).  Here the H*W evaluations run on the
 device: 'linear' = Delaunay triangulation of the knots on the host (Qhull, as inside griddata) + point location and barycentric weights
-per pixel in rd_tri_raster (exact int64 edge functions); 'nearest' = rd_nearest_knot (exact integer distances).  'cubic'
-(Clough-Tocher) is not built: RIDERS never selects it (train_zju.py uses interp 'rcnet'; this class is not instantiated anywhere in the
-reference).  There is no host evaluation path: the functions need a ROCm device.
+per pixel in rd_tri_raster (exact int64 edge functions); 'nearest' = rd_nearest_knot (exact integer distances).  These two need a ROCm
+device.  'cubic' (Clough-Tocher: iterative global gradient estimation on the triangulation, then a C1 piecewise cubic) has NO device
+kernel: RIDERS never selects it (train_zju.py uses interp 'rcnet'; this class is not instantiated anywhere in the reference), so the method
+value is passed through to the same scipy.interpolate.griddata call the reference makes (modules/interpolator.py:10-16) -- off the hot
+path, host only, identical result by construction.
 """
 import numpy as np
 
@@ -16,6 +18,10 @@ def interpolate_knots(map_size, knot_coords, knot_values, interpolate, fill_corn
     from . import engine
     H, W = int(map_size[0]), int(map_size[1])
     knot_coords = np.asarray(knot_coords)
+    if interpolate == 'cubic':      # host, as the reference (see the module docstring): no device kernel for a method RIDERS never selects
+        from scipy.interpolate import griddata
+        grid_x, grid_y = np.mgrid[0:H, 0:W]
+        return griddata(points=knot_coords.T, values=knot_values, xi=(grid_y, grid_x), method='cubic', fill_value=1.0)
     pts = np.ascontiguousarray(knot_coords.T)                    # (K, 2) as (x, y): the `points` griddata triangulates
     vals = np.ascontiguousarray(np.asarray(knot_values), dtype=np.float64)
     dev = torch.device(device) if device is not None else torch.device("cuda", torch.cuda.current_device())
@@ -35,7 +41,7 @@ def interpolate_knots(map_size, knot_coords, knot_values, interpolate, fill_corn
         engine._chk(lib.rd_nearest_knot(engine._p(prow), engine._p(pcol), engine._p(v), int(pts.shape[0]), H, W, 1.0, engine._p(out), st),
                     "rd_nearest_knot")
     else:
-        raise NotImplementedError("interpolate=%r: only 'linear' and 'nearest' are built (see the module docstring)" % (interpolate,))
+        raise ValueError("Unknown interpolation method %r for 2 dimensional data" % (interpolate,))      # griddata's own error
     return out.cpu().numpy()
 
 

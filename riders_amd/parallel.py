@@ -39,8 +39,14 @@ class GradientAllReducer(object):
     stages: optional {tag: iterable of parameters whose gradients are final when the backward passes stage mark `tag`}.
     Without stages (or for parameters in none) the arena is reduced by `reduce()` in `bucket_bytes` slices after backward."""
 
-    def __init__(self, optimizer, bucket_bytes=32 << 20, process_group=None, stages=None):
+    def __init__(self, optimizer, bucket_bytes=32 << 20, process_group=None, stages=None, mode="all_reduce"):
+        """mode: 'all_reduce' (RCCL picks the algorithm: a ring on xGMI) or 'rs_ag' = reduce_scatter_tensor + all_gather_into_tensor in
+        place on each bucket (the two halves of a ring all-reduce issued separately: same bytes per link, but the gather half of bucket k
+        can interleave with the scatter half of bucket k+1 on the communication stream; for A/B on an 8-GPU node, NCCL/RCCL backend only)."""
+        if mode not in ("all_reduce", "rs_ag"):
+            raise ValueError("GradientAllReducer: mode must be 'all_reduce' or 'rs_ag'")
         self.opt = optimizer
+        self.mode = mode
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.collective = dist.is_initialized()      # also with one rank: the same calls, a functional check of the path on a 1-GPU box
@@ -88,7 +94,21 @@ class GradientAllReducer(object):
         for s, e in self._split(ranges):
             self.log.append((tag, s, e))
             if self.collective:
-                self._handles.append(dist.all_reduce(self.opt.flat_grad[s:e], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+                self._handles.extend(self._sum(self.opt.flat_grad[s:e]))
+
+    def _sum(self, buf):
+        """Start the sum of one arena slice across the ranks -> the async work handles."""
+        w = self.world
+        n = buf.numel() // w * w
+        if self.mode != "rs_ag" or dist.get_backend(self.group) != "nccl" or n == 0:      # (gloo has no reduce_scatter_tensor)
+            return [dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)]
+        rank = dist.get_rank(self.group)
+        body, shard = buf[:n], buf[:n].view(w, -1)[rank]      # in place: rank r's shard is the r-th piece of the bucket (NCCL's in-place convention)
+        hs = [dist.reduce_scatter_tensor(shard, body, op=dist.ReduceOp.SUM, group=self.group, async_op=True),
+              dist.all_gather_into_tensor(body, shard, group=self.group, async_op=True)]      # same communication stream: ordered behind the scatter
+        if n < buf.numel():     # the few elements that do not divide by the world size
+            hs.append(dist.all_reduce(buf[n:], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        return hs
 
     def on_stage(self, tag):
         """Stage hook (called from the backward, or by a graph-replaying driver right after the stage's graph was enqueued)."""

@@ -27,6 +27,7 @@ def emu(emu_lib_path):
     from riders_amd import _lib, engine
     _lib._install_for_tests(emu_lib_path)
     engine.clear_caches()
+    engine._roi_flags.clear()      # the compact RoI arg-max's sticky overflow flag does not travel between tests
     engine.set_compute_dtype("fp32")
     yield torch.device("cpu")
     engine.clear_caches()
@@ -42,6 +43,7 @@ def gpu():
     _lib._uninstall_for_tests()
     _lib.load()
     engine.clear_caches()
+    engine._roi_flags.clear()
     engine.set_compute_dtype("fp32")
     yield torch.device("cuda:0")
     engine.clear_caches()

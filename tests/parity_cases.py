@@ -550,12 +550,62 @@ def roi_pool_case(dev):
             out = engine.roi_pool(xd, t(rois, dev), (PH, PW), scale)
             tape.grads[id(out)] = w.to(dev).permute(0, 2, 3, 1).contiguous()
             tape.backward()
-        assert torch.equal(out._rd_argmax.permute(0, 3, 1, 2).cpu(), arg), "roi_pool argmax differs"
+        assert torch.equal(engine.roi_argmax(out).permute(0, 3, 1, 2).cpu(), arg), "roi_pool argmax differs"
         assert torch.equal(out.permute(0, 3, 1, 2).cpu(), ref.detach()), "roi_pool values differ"
         close(tape.grads[id(xd)].permute(0, 3, 1, 2), xr.grad, 1e-5, "roi_pool bwd")
 
 
-def load_roi_pool_kat():
+def roi_pool_compact_case(dev):
+    """Compact (one byte) RoI arg-max against the int32 form: pooled values, decoded arg-max and the gradient of both backward forms (fp32
+    L2 atomics, pixel-owner gather) are IDENTICAL, fp32 and bf16, windows from 1 x 1 to 12 x 11 pixels, boxes leaving the map, empty bins;
+    a window that cannot be encoded (> 15 pixels) raises the sticky flag and the gradient comes back NaN."""
+    from riders_amd import engine
+    rs = np.random.RandomState(21)
+    N, C, H, W = 2, 16, 30, 41
+    rois = np.array([[0, 0, 0, 40, 29], [1, 2.5, 3.5, 19.4, 18.6], [0, 7, 5, 7, 5], [1, -3, -2, 14, 40], [0, 39.5, 28.5, 45, 33],
+                     [1, 4, 4, 33, 22], [0, 1, 1, 37, 23], [1, 10, 8, 35.5, 29.5]], np.float32)
+    for dtype in (torch.float32, torch.bfloat16):
+        engine.set_compute_dtype("bf16" if dtype == torch.bfloat16 else "fp32")
+        try:
+            x = t(rs.randn(N, H, W, C).astype(np.float32)).to(dtype).to(dev)
+            for scale, (PH, PW) in ((1.0, (4, 5)), (0.5, (6, 7)), (1.0, (29, 40))):
+                w = t(rs.randn(rois.shape[0], PH, PW, C).astype(np.float32)).to(dtype).to(dev)
+                res = {}
+                for compact in (False, True):
+                    for det in (False, True):
+                        engine.set_deterministic_roi_pool(det)
+                        try:
+                            tape = engine.Tape(); tape.mark(x)
+                            with engine._active(tape):
+                                out = engine.roi_pool(x, t(rois, dev), (PH, PW), scale, compact=compact)
+                                tape.grads[id(out)] = w
+                                tape.backward()
+                        finally:
+                            engine.set_deterministic_roi_pool(False)
+                        assert out._rd_argmax.dtype == (torch.uint8 if compact else torch.int32)
+                        res[(compact, det)] = (out.float().cpu(), engine.roi_argmax(out).cpu(), tape.grads[id(x)].float().cpu())
+                for det in (False, True):
+                    a, b = res[(False, det)], res[(True, det)]
+                    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]), "compact RoI arg-max: pooled values / decoded arg-max differ"
+                    if det or dtype == torch.float32:      # (the atomic form's bf16 result is a cast of an fp32 sum in scatter order: compare within rounding)
+                        close(b[2], a[2], 1e-6 if det else 1e-5, "compact RoI arg-max gradient")
+                    else:
+                        close(b[2], a[2], 1e-2, "compact RoI arg-max gradient (bf16, atomic order)")
+                assert torch.equal(res[(True, True)][2], res[(False, True)][2]), "gather form: compact and int32 gradients must be bit-identical"
+            # a 41-pixel-wide bin cannot be encoded: flag, then NaN gradients
+            assert int(engine._roi_flag(x.device).cpu()) == 0
+            tape = engine.Tape(); tape.mark(x)
+            with engine._active(tape):
+                out = engine.roi_pool(x, t(rois[:1], dev), (1, 1), 1.0, compact=True)
+                tape.grads[id(out)] = torch.ones_like(out)
+                tape.backward()
+            assert int(engine._roi_flag(x.device).cpu()) == 1 and bool(torch.isnan(tape.grads[id(x)].float()).any())
+            engine._roi_flags.clear()
+        finally:
+            engine.set_compute_dtype("fp32")
+
+
+def load_roi_pool_kat():def load_roi_pool_kat():
     import json
     return json.load(open(os.path.join(G, "roi_pool_kat.json")))["cases"]
 
@@ -591,7 +641,7 @@ def roi_pool_kat_case(dev):
                     engine.set_deterministic_roi_pool(False)
                     engine.set_roi_tile_min_blocks(256)
                 what = "%s [%s, %s]" % (c["name"], str(dtype).split(".")[-1], mode)
-                assert np.array_equal(out._rd_argmax.permute(0, 3, 1, 2).cpu().numpy(), np.asarray(c["argmax"], np.int32)), what + ": argmax"
+                assert np.array_equal(engine.roi_argmax(out).permute(0, 3, 1, 2).cpu().numpy(), np.asarray(c["argmax"], np.int32)), what + ": argmax"
                 assert np.array_equal(out.float().permute(0, 3, 1, 2).cpu().numpy(), np.asarray(c["out"], np.float32)), what + ": values"
                 if "grad_out" in c:
                     want = np.zeros((N, C, H * W), np.float32)
@@ -638,7 +688,7 @@ def _roi_pool_stress(dev, R, C, H, W):
             out = engine.roi_pool(xd, t(rois, dev), (PH, PW), scale)
             tape.grads[id(out)] = w.to(dev).permute(0, 2, 3, 1).contiguous()
             tape.backward()
-        assert torch.equal(out._rd_argmax.permute(0, 3, 1, 2).cpu(), arg), "roi_pool argmax differs"
+        assert torch.equal(engine.roi_argmax(out).permute(0, 3, 1, 2).cpu(), arg), "roi_pool argmax differs"
         close(tape.grads[id(xd)].permute(0, 3, 1, 2), xr.grad, 1e-5, "roi_pool gather bwd (stress)")
 
 
@@ -828,10 +878,16 @@ def interpolator_case(dev, big=False):
     for y, x in zip(*np.nonzero(tie)):
         d2 = (r - y) ** 2 + (c - x) ** 2
         assert near[y, x] in vals[d2 == d2.min()], "tie pixel took a knot that is not nearest"
+    # 'cubic' (never selected by RIDERS) is the reference's own host call (scipy griddata, Clough-Tocher) passed through: same function, same result
+    from scipy.interpolate import griddata
+    it.generate_interpolated_scale_map(interpolate_method='cubic', device=dev)
+    gx, gy = np.mgrid[0:it.map_size[0], 0:it.map_size[1]]
+    ref_c = griddata(points=it.knot_coords.T, values=it.knot_scales, xi=(gy, gx), method='cubic', fill_value=1.0).astype(np.float32)
+    assert it.interpolated_scale_map.shape == ref_c.shape and np.array_equal(it.interpolated_scale_map, ref_c)
     try:
-        it.generate_interpolated_scale_map(interpolate_method='cubic', device=dev)
-        raise AssertionError("cubic must be refused")
-    except NotImplementedError:
+        it.generate_interpolated_scale_map(interpolate_method='quintic', device=dev)
+        raise AssertionError("an unknown method must be refused")
+    except ValueError:
         pass
     if big:
         rs = np.random.RandomState(78)

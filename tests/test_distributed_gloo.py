@@ -131,3 +131,62 @@ def test_two_training_steps_world2_match_per_shard_mean(emu_lib_path):
         engine.clear_caches()
         engine.set_param_grad_allocator(None)
         _lib._uninstall_for_tests()
+
+
+def _sml_worker(rank, world, port, outdir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import contextlib
+    import io
+    from riders_amd import sml_main
+    from riders_amd.optim import FlatAdam
+    from riders_amd.parallel import GradientAllReducer, sml_stages
+    torch.manual_seed(200 + rank)          # different initial weights per rank on purpose
+    with contextlib.redirect_stdout(io.StringIO()):
+        model = sml_main.build_model(torch.device("cpu"))      # the real MidasNet_small_videpth: its parameter list and stage split are what is tested
+    opt = FlatAdam(list(model.parameters()), lr=1e-4)
+    red = GradientAllReducer(opt, stages=sml_stages(model), bucket_bytes=4 << 20)
+    red.broadcast_parameters(0)
+    init = opt.flat_param.clone()
+    # the backward of a step, as the engine drives it: gradients land in the arena, the stage marks fire in backward order, then reduce().
+    # (The kernels themselves run in the single-process emulator / GPU tests; a whole SML step on the host emulator takes ~20 minutes.)
+    g = torch.Generator().manual_seed(300 + rank)
+    local = torch.randn(opt.numel, generator=g)
+    opt.flat_grad.copy_(local)
+    red.on_stage("scratch_done")
+    red.on_stage("layer4_done")
+    order = [t for t, _, _ in red.log]
+    red.reduce()
+    log = list(red.log)
+    summed = opt.flat_grad.clone()
+    dist.barrier()
+    dist.destroy_process_group()
+    torch.save(dict(init=init, order=order, log=log, local=local, summed=summed, scale=opt.grad_scale, numel=opt.numel), os.path.join(outdir, "r%d.pt" % rank))
+
+
+def test_sml_arena_world2_stage_buckets():
+    """The Scale Map Learner's gradient exchange on two ranks: parameters are broadcast, the scratch-decoder and layer4 buckets
+    (parallel.sml_stages on the real model) are issued from their stage marks in backward order before reduce(), every arena element is
+    reduced exactly once, and the reduced arena is the sum of the two ranks' local gradients."""
+    import tempfile
+    ctx = mp.get_context("spawn")
+    port = _free_port()
+    with tempfile.TemporaryDirectory() as outdir:
+        procs = [ctx.Process(target=_sml_worker, args=(r, 2, port, outdir)) for r in range(2)]
+        for p in procs:
+            p.start()
+        for p in procs:
+            p.join(timeout=300)
+            assert p.exitcode == 0, "worker exit code %s" % p.exitcode
+        res = [torch.load(os.path.join(outdir, "r%d.pt" % r)) for r in range(2)]
+    assert torch.equal(res[0]["init"], res[1]["init"]), "parameters not broadcast from rank 0"
+    assert sorted(set(res[0]["order"]), key=res[0]["order"].index) == ["scratch_done", "layer4_done"], res[0]["order"]
+    assert res[0]["scale"] == 0.5
+    cover = torch.zeros(res[0]["numel"], dtype=torch.int32)
+    for _, s, e in res[0]["log"]:
+        cover[s:e] += 1
+    assert bool((cover == 1).all()), "arena elements reduced %d..%d times" % (int(cover.min()), int(cover.max()))
+    tot = res[0]["local"] + res[1]["local"]
+    for r in range(2):
+        assert torch.equal(res[r]["summed"], tot), "rank %d: all-reduced arena differs from the sum of the local gradients" % r

@@ -76,6 +76,10 @@ def test_transformer(emu):
     P.transformer_case(emu)
 
 
+def test_roi_pool_compact_argmax(emu):
+    P.roi_pool_compact_case(emu)
+
+
 def test_roi_pool(emu):
     P.roi_pool_case(emu)
 
