@@ -1121,7 +1121,8 @@ def roi_argmax(out):
     f32 = np.float32
 
     def starts(lo, hi, P, lim):      # clamp(floor(p * bin) + start), all in float32 as the kernels compute it
-        s = np.round(lo * f32(scale)).astype(np.int64); e = np.round(hi * f32(scale)).astype(np.int64)
+        rnd = lambda v: (np.sign(v) * np.floor(np.abs(v) + f32(0.5))).astype(np.int64)      # roundf: halves away from zero
+        s, e = rnd(lo * f32(scale)), rnd(hi * f32(scale))
         ext = np.maximum(e - s + 1, 1)
         binsz = (ext.astype(np.float32) / f32(P))[:, None]
         return np.clip(np.floor(np.arange(P, dtype=np.float32)[None, :] * binsz).astype(np.int64) + s[:, None], 0, lim)

@@ -605,7 +605,7 @@ def roi_pool_compact_case(dev):
             engine.set_compute_dtype("fp32")
 
 
-def load_roi_pool_kat():def load_roi_pool_kat():
+def load_roi_pool_kat():
     import json
     return json.load(open(os.path.join(G, "roi_pool_kat.json")))["cases"]
 
