@@ -367,10 +367,8 @@ def run_workload(kind, args, dev, world, rank, steps, warmup, **override):
     ms = elapsed * 1e3 / max(steps, 1)
     out = dict(value=batch_n * world * steps / elapsed, ms_per_step=ms, steps=steps, warmup=warmup, settle_steps=settle, final_loss=final_loss,
                batch_per_gpu=batch_n, height=h, width=w,
-               launch_mode="eager" if args.eager else (
-                   ("one hipGraph (fwd+bwd) with an external event per stage mark + eager all-reduce/Adam" if getattr(step, "stage_events", None)
-                    else "hipGraphs split at the stage marks (fwd+bwd) + eager all-reduce/Adam") if reducer is not None
-                   else "one hipGraph (fwd+bwd) + eager Adam"))
+               launch_mode="eager" if args.eager else ("hipGraphs split at the stage marks (fwd+bwd) + eager all-reduce/Adam" if reducer is not None
+                                                       else "one hipGraph (fwd+bwd) + eager Adam"))
     if rank == 0:
         key = "%s_b%d_%dx%d_%s" % (kind, batch_n, h, w, args.dtype)
         out["roofline"] = kernel_roofline(timer, timed_steps, ms, args.dtype, key)

@@ -228,16 +228,13 @@ class GraphedStep(object):
                 for b, s_ in zip(buffers, saved):
                     b.copy_(s_)
             self.graphs, self.tags = [], []
-            self.stage_events = []      # single-graph mode with an all-reducer: (tag, external event recorded INSIDE the graph at the stage mark)
             pool = torch.cuda.graph_pool_handle()
             state = {}
-            # With an all-reducer the capture used to be SPLIT at the stage marks (3 graphs for RC-Net: measured 5 % slower than one graph at
-            # one rank before any wire time).  Now ONE graph: each stage mark records an external event inside the graph (an event-record
-            # node), and after the replay was enqueued an auxiliary stream waits for that event and starts the stage's bucket from there --
-            # torch.distributed's communication stream then waits only for the stage, not for the whole graph.  RIDERS_DDP_SPLIT_GRAPHS=1
-            # (or a torch / ROCm without external events) restores the split capture.
-            single = reducer is not None and os.environ.get("RIDERS_DDP_SPLIT_GRAPHS", "0") == "0"
-
+            # With an all-reducer the capture is SPLIT at the stage marks (one graph per stage; measured 5 % slower than one graph at one rank
+            # before any wire time).  ONE graph with an external event recorded at each mark (an event-record node the communication side could
+            # wait on) was built in round 4 and cannot run: torch-rocm 2.10 raises "External events are disallowed in rocm" for
+            # torch.cuda.Event(external=True) under capture, and an event recorded behind torch's back on a capturing stream is not something
+            # that can be validated on a 1-GPU pool (a mis-ordered wait would all-reduce unfinished gradients silently).
             def begin():
                 state["g"] = torch.cuda.CUDAGraph()
                 state["ctx"] = torch.cuda.graph(state["g"], pool=pool)
@@ -252,34 +249,14 @@ class GraphedStep(object):
                 end(tag)
                 begin()
 
-            def mark(tag):
-                ev = torch.cuda.Event(external=True)
-                ev.record()
-                self.stage_events.append((tag, ev))
-
-            def capture(on_stage):
-                begin()
-                try:
-                    self.loss = staged_gradients(fwd_loss, optimizer, on_stage, loss_scale)
-                except BaseException:
-                    state["ctx"].__exit__(None, None, None)
-                    raise
-                end(None)
-            if single:
-                try:
-                    capture(mark)
-                    self.aux = torch.cuda.Stream()
-                except Exception as ex:      # no external events in this runtime: split graphs as before
-                    import warnings
-                    warnings.warn("GraphedStep: single-graph capture with stage events failed (%r); using one graph per stage" % (ex,))
-                    self.graphs, self.tags, self.stage_events, single = [], [], [], False
-                    torch.cuda.synchronize()
-                    with torch.no_grad():
-                        for b, s_ in zip(buffers, saved):
-                            b.copy_(s_)
-            if not single:
+            begin()
+            try:
                 # without an all-reducer there is nothing to interleave: one graph (each extra graph launch costs ~1 % of an RC-Net step)
-                capture(boundary if reducer is not None else None)
+                self.loss = staged_gradients(fwd_loss, optimizer, boundary if reducer is not None else None, loss_scale)
+            except BaseException:
+                state["ctx"].__exit__(None, None, None)
+                raise
+            end(None)
             # a replay writes the gradient arena without passing the optimizer's gradient allocator: remember what the capture pass touched
             self.touched = optimizer.touched_indices() if hasattr(optimizer, "touched_indices") else None
             if self.touched is not None and not self.touched:
@@ -293,10 +270,6 @@ class GraphedStep(object):
         for g, tag in zip(self.graphs, self.tags):
             g.replay()
             if tag is not None and self.reducer is not None:
-                self.reducer.on_stage(tag)
-        for tag, ev in self.stage_events:      # single graph: the bucket of a stage starts behind the event the graph records at its mark
-            self.aux.wait_event(ev)
-            with torch.cuda.stream(self.aux):
                 self.reducer.on_stage(tag)
         if self.on_replay is not None:
             self.on_replay(+1)

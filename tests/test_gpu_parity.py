@@ -336,32 +336,28 @@ def test_step_with_rccl_collectives_matches_plain_step(gpu):
     dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=torch.device(gpu))
     try:
         losses, modes = {}, {}
-        # rccl: ONE graph with an external event per stage mark (round 4); rccl_split: one graph per stage (rounds 2-3, RIDERS_DDP_SPLIT_GRAPHS=1);
-        # rccl_rs_ag: reduce_scatter + all_gather per bucket instead of one all-reduce
-        for mode in ("plain", "rccl", "rccl_split", "rccl_rs_ag"):
+        # rccl: one graph per stage, the stage's bucket started between two replays; rccl_rs_ag: reduce_scatter + all_gather per bucket instead of
+        # one all-reduce.  (One graph with external stage events is not available: torch-rocm raises "External events are disallowed in rocm".)
+        for mode in ("plain", "rccl", "rccl_rs_ag"):
             torch.manual_seed(0)
             model = rcnet_main.build_model(gpu, cfg)
             model.train()
             opt = FlatAdam(model.parameters(), lr=1e-3)
             red = GradientAllReducer(opt, stages=rcnet_stages(model), mode="rs_ag" if mode == "rccl_rs_ag" else "all_reduce") if mode != "plain" else None
-            os.environ["RIDERS_DDP_SPLIT_GRAPHS"] = "1" if mode == "rccl_split" else "0"
             try:
                 if red is not None:
                     red.broadcast_parameters(0)
                 step = rcnet_main.GraphedTrainStep(model, opt, batch, cfg, reducer=red, warmup=1)
                 losses[mode] = [float(step()) for _ in range(3)]
-                modes[mode] = (len(step.graphs), len(step.stage_events))
+                modes[mode] = len(step.graphs)
                 if red is not None:
                     assert red.collective and opt.grad_scale == 1.0
                     assert [t for t, _, _ in red.log][:2] == ["decoder_done", "attention_done"], red.log      # the stage buckets go first, in backward order
             finally:
-                os.environ.pop("RIDERS_DDP_SPLIT_GRAPHS", None)
                 if red is not None:
                     red.close()
-        assert modes["plain"] == (1, 0) and modes["rccl_split"] == (3, 0), modes
-        assert modes["rccl"] in ((1, 2), (3, 0)), modes      # (3, 0): this runtime has no external events and the capture fell back
-        print("graphs / stage events per mode:", modes)
-        for m in ("rccl", "rccl_split", "rccl_rs_ag"):
+        assert modes == {"plain": 1, "rccl": 3, "rccl_rs_ag": 3}, modes
+        for m in ("rccl", "rccl_rs_ag"):
             for a, b in zip(losses["plain"], losses[m]):
                 assert abs(a - b) <= 1e-3 * abs(a), (m, losses)
     finally:
