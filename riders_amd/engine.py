@@ -1142,7 +1142,8 @@ def roi_pool(x, rois, output_size, spatial_scale, compact=None):
     out = torch.empty((R, PH, PW, C), dtype=x.dtype, device=x.device)
     if compact is None:
         compact = _state["roi_u8"]
-    compact = bool(compact) and C % (16 // x.element_size()) == 0 and _ROI_BWD in ("auto", "gather", "atomic") and PH < (1 << 19) and PW < (1 << 19)
+    compact = bool(compact) and C % (16 // x.element_size()) == 0 and _ROI_BWD in ("auto", "gather", "atomic") and PH < (1 << 19) and PW < (1 << 19) \
+        and _state["roi_tile_min_blocks"] > 0      # (the LDS tile-accumulate backward, an A/B form, reads int32 indices)
     arg = torch.empty((R, PH, PW, C), dtype=torch.uint8 if compact else torch.int32, device=x.device)
     flag = _roi_flag(x.device) if compact else None
     # algorithmic bytes: pooled values + argmax written, the source map read once
