@@ -510,7 +510,7 @@ int rd_roi_pool_bwd_gather(const void* dout, const float* rois, const int32_t* a
   if (!dx || !dt_ok(dtype)) return fail("roi_pool_bwd_gather: bad args");
   if (R > 0 && (!dout || !rois || !argmax)) return fail("roi_pool_bwd_gather: null pointer");
   if (C % (dtype == RD_F32 ? 4 : 8)) return fail("roi_pool_bwd_gather: C must be a multiple of the 16-byte vector");
-  if (N <= 0 || H <= 0 || W <= 0 || PH <= 0 || PW <= 0) return fail("roi_pool_bwd_gather: bad sizes");
+  if (N <= 0 || H <= 0 || W <= 0 || PH <= 0 || PW <= 0 || PH >= (1 << 19) || PW >= (1 << 19)) return fail("roi_pool_bwd_gather: bad sizes");
   RD_NS(dtype, launch_roi_pool_bwd_gather)(dout, rois, argmax, dx, R, N, H, W, C, PH, PW, scale, RD_DT(dtype), S(stream));
   return done("rd_roi_pool_bwd_gather");
 }

@@ -30,7 +30,17 @@ namespace rd {
 // WM = 2 halves the tile for small-M launches (LoFTR projections, deep encoder stages) so they spread over more CUs.
 // DEEP = two register sets, global loads issued two stages ahead: small-M launches with a long K axis (SML's 1x1 convolutions on
 // 1.7-7 K pixels with up to 1392 channels) are a chain of stages each waiting one L2 round trip (~1.3 us per stage measured).
-template <typename T, int BN, bool VEC, int WM, bool DEEP = false>
+// PAR (round 4) = the data gradient of a STRIDE-2 layer (ConvArgs::dil == 2: dY viewed as zero-dilated): an output pixel only meets the
+// taps whose parity matches its own -- (1, 2, 2, 4) of the 9 taps of a 3x3 layer for the four (row, column) parity classes, (1, 0, 0, 0)
+// for a 1x1 projection -- but a tile of consecutive pixels mixes the classes and walked all nine (4x the staging and the MFMAs: 81 us for
+// the 64 -> 128 stage against 20 us of its forward).  Here the pixel axis is ordered class by class (a block's tile lies in ONE class, the
+// grid is the sum of the classes' tiles) and the K walk visits the class's taps only; channel counts are whole stages (Cin % BKE == 0).
+__host__ __device__ __forceinline__ void par_class(int c, int OH, int OW, int N, int& ph, int& pw, int& oh2, int& ow2, int& mc) {
+  ph = c >> 1; pw = c & 1;
+  oh2 = (OH - ph + 1) >> 1; ow2 = (OW - pw + 1) >> 1;
+  mc = N * oh2 * ow2;
+}
+template <typename T, int BN, bool VEC, int WM, bool DEEP = false, bool PAR = false>
 __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs a) {
   constexpr int VE = Elem<T>::VE;
   constexpr int BKE = STAGE_BYTES / (int)sizeof(T);  // K elements per stage
@@ -50,20 +60,46 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs a) {
     const int nb = gridDim.x, q = nb >> 3, r = nb & 7, xcd = bx & 7, idx = bx >> 3;
     bx = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
-  const int m0 = bx * BMV;
+  int m0 = bx * BMV;
   const int wm = wv % WM, wn = wv / WM;
   const int n0 = blockIdx.y * BN;
   const int Cin = a.C1 + a.C2;
+  // PAR: this block's parity class, its pixel count and the class's taps kh0 + 2 i, kw0 + 2 j
+  int ph = 0, pw = 0, oh2 = 1, ow2 = 1, mcl = a.M, kh0 = 0, kw0 = 0, nkw = 1, spt = 1, npar = 0;
+  if (PAR) {
+    int c = 0, tb = bx;
+    for (; c < 4; c++) {
+      par_class(c, a.OH, a.OW, a.N, ph, pw, oh2, ow2, mcl);
+      const int tc = (mcl + BMV - 1) / BMV;
+      if (tb < tc || c == 3) break;
+      tb -= tc;
+    }
+    m0 = tb * BMV;
+    kh0 = (ph + a.pad) & 1; kw0 = (pw + a.pad) & 1;
+    const int nkh = kh0 < a.KH ? (a.KH - kh0 + 1) >> 1 : 0;
+    nkw = kw0 < a.KW ? (a.KW - kw0 + 1) >> 1 : 0;
+    spt = Cin / BKE;
+    npar = nkh * nkw * spt;
+  }
+  // pixel of local row ml (PAR: row of the class) -> image, row, column; false past the end
+  auto row_pixel = [&](int ml, int& n, int& oh, int& ow) RD_INLINE_LAMBDA {
+    if (PAR) {
+      const int c2 = ml % ow2, q = ml / ow2, r2 = q % oh2;
+      n = q / oh2; oh = 2 * r2 + ph; ow = 2 * c2 + pw;
+      return ml < mcl;
+    }
+    ow = ml % a.OW; const int q = ml / a.OW; oh = q % a.OH; n = q / a.OH;
+    return ml < a.M;
+  };
 
   // ---- per-thread staging state: slot s of rows r0+32*i --------------------------------------
   const int s = t & 7, r0 = t >> 3;
   int rn[WM], rih[WM], riw[WM];
 #pragma unroll
   for (int i = 0; i < WM; i++) {
-    int m = m0 + r0 + 32 * i;
-    if (m < a.M) {
-      int ow = m % a.OW; int q = m / a.OW; int oh = q % a.OH; rn[i] = q / a.OH;
-      rih[i] = oh * a.stride - a.pad; riw[i] = ow * a.stride - a.pad;
+    int n, oh, ow;
+    if (row_pixel(m0 + r0 + 32 * i, n, oh, ow)) {
+      rn[i] = n; rih[i] = oh * a.stride - a.pad; riw[i] = ow * a.stride - a.pad;
     } else { rn[i] = -1; rih[i] = 0; riw[i] = 0; }
   }
   // k-state of this thread's vector (VEC path): k = kt*BKE + s*VE
@@ -77,8 +113,13 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs a) {
   uint4 ra3[DEEP ? WM : 1]; uint4 rb3[DEEP ? BITER : 1];
   uint4 ra4[DEEP ? WM : 1]; uint4 rb4[DEEP ? BITER : 1];
 
-  const int nk_ = a.Kpad / BKE;      // stages; a request past the last one (issued unconditionally by the deep path) re-reads the last weights
+  const int nk_ = PAR ? npar : a.Kpad / BKE;      // stages; a request past the last one (issued unconditionally by the deep path) re-reads the last weights
   auto load_tile = [&](int kt, uint4 (&ra)[WM], uint4 (&rb)[BITER]) RD_INLINE_LAMBDA {
+    if (PAR) {      // logical stage -> (tap of the class, channel stage) -> physical stage of the packed operand
+      const int j = min(kt, nk_ - 1), tp = j / spt, js = j - tp * spt, th = tp / nkw;
+      kkh = kh0 + 2 * th; kkw = kw0 + 2 * (tp - th * nkw); kci = js * BKE + s * VE;
+      kt = (kkh * a.KW + kkw) * spt + js;
+    }
 #pragma unroll
     for (int i = 0; i < WM; i++) {
       uint4 v = make_uint4(0, 0, 0, 0);
@@ -117,11 +158,11 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs a) {
       int idx = t + 256 * i;
       if (BN * 8 % 256 == 0 || idx < BN * 8) {  // compile-time when the tile divides evenly: a runtime guard parks rb[] in scratch
         int row = idx >> 3, sl = idx & 7;
-        const uint4 v = wp[(int64_t)(n0 + row) * kslots + min(kt, nk_ - 1) * 8 + sl];  // via a value: a direct global->array struct copy stays a memcpy
+        const uint4 v = wp[(int64_t)(n0 + row) * kslots + (PAR ? kt : min(kt, nk_ - 1)) * 8 + sl];  // via a value: a direct global->array struct copy stays a memcpy
         rb[i] = v;                                                        // through a private alloca (scratch / LDS-promoted)
       }
     }
-    if (VEC) {  // advance this thread's k-state by one stage
+    if (VEC && !PAR) {  // advance this thread's k-state by one stage
       kci += BKE;
       while (kci >= Cin) { kci -= Cin; if (++kkw == a.KW) { kkw = 0; ++kkh; } }
     }
@@ -140,7 +181,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs a) {
 #pragma unroll
   for (int c = 0; c < CT; c++) { acc[c][0] = f32x4{0, 0, 0, 0}; acc[c][1] = f32x4{0, 0, 0, 0}; }
 
-  const int nk = a.Kpad / BKE;
+  const int nk = nk_;
   const int fr = lane & 15, fg = lane >> 4;
   auto compute = [&](int buf) RD_INLINE_LAMBDA {
 #pragma unroll
@@ -168,7 +209,9 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs a) {
       }
     }
   };
-  if (!DEEP) {
+  if (PAR && nk == 0) {
+    // a class without taps (the odd rows / columns of a 1x1 stride-2 projection): zeros (+ the addend) are stored below
+  } else if (!DEEP) {
     load_tile(0, ra, rb);
     store_tile(0, ra, rb);
     __syncthreads();
@@ -221,7 +264,14 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(ConvArgs a) {
   // ---- epilogue (shared): bias, activation, NHWC store (dual destination), BN statistics ----------------
   int64_t mm[2]; bool mvv[2];
 #pragma unroll
-  for (int pt = 0; pt < 2; pt++) { mm[pt] = m0 + wm * 32 + pt * 16 + fr; mvv[pt] = mm[pt] < a.M; }
+  for (int pt = 0; pt < 2; pt++) {
+    mm[pt] = m0 + wm * 32 + pt * 16 + fr; mvv[pt] = mm[pt] < a.M;
+    if (PAR) {
+      int n, oh, ow;
+      mvv[pt] = row_pixel((int)mm[pt], n, oh, ow);
+      mm[pt] = ((int64_t)n * a.OH + oh) * a.OW + ow;
+    }
+  }
   conv_epilogue<T, CT, BN, WM>(a, acc, mm, mvv, n0, wn, wm, fr, fg, t, bx, reinterpret_cast<float*>(&sA[0][0]));
 }
 
@@ -942,6 +992,22 @@ static void conv_tiles(int M, int Cout, int& bn, int& wm) {
 }
 int conv_block_pixels(int M, int Cout) { int bn, wm; conv_tiles(M, Cout, bn, wm); return 32 * wm; }
 
+// parity-class walk of a stride-2 layer's data gradient (conv_gemm_kernel PAR): whole 128-byte channel stages, one source, no statistics
+static bool conv_gemm_par(const ConvArgs& a, int dtype) {
+  const int bke = STAGE_BYTES / (dtype == 0 ? 4 : 2), Cin = a.C1 + a.C2;
+  static const bool off = getenv("RD_CONV_PAR") && atoi(getenv("RD_CONV_PAR")) == 0;      // A/B switch
+  return !off && a.dil == 2 && a.stride == 1 && !a.ups && a.C2 == 0 && Cin % bke == 0 && !a.stats && !a.pool2 && a.K == a.KH * a.KW * Cin &&
+         a.Kpad == a.K;
+}
+static bool conv_gemm_deep(const ConvArgs& a, int dtype) {
+  const int ve = dtype == 0 ? 4 : 8, Cin = a.C1 + a.C2, es = dtype == 0 ? 4 : 2;
+  const bool vec = (Cin % ve == 0) && (a.C1 % ve == 0);
+  int bn, wm;
+  conv_tiles(a.M, a.Cout, bn, wm);
+  int nk = a.Kpad / (STAGE_BYTES / es);
+  if (conv_gemm_par(a, dtype)) nk = ((a.KH + 1) / 2) * ((a.KW + 1) / 2) * (Cin / (STAGE_BYTES / es));      // the longest class
+  return vec && wm == 2 && cdiv(a.M, 32 * wm) * cdiv(a.Cout, bn) <= 512 && nk >= 6;
+}
 template <typename T>
 static void launch_conv_t(const ConvArgs& a, hipStream_t st) {
   constexpr int VE = Elem<T>::VE;
@@ -950,14 +1016,22 @@ static void launch_conv_t(const ConvArgs& a, hipStream_t st) {
   int bn, wm;
   conv_tiles(a.M, a.Cout, bn, wm);
   dim3 grid((unsigned)cdiv(a.M, 32 * wm), (unsigned)cdiv(a.Cout, bn));
+  const bool par = conv_gemm_par(a, sizeof(T) == 4 ? 0 : 1);
+  if (par) {      // the tiles of the four parity classes, one after the other
+    unsigned gx = 0;
+    for (int c = 0; c < 4; c++) { int ph, pw, oh2, ow2, mc; par_class(c, a.OH, a.OW, a.N, ph, pw, oh2, ow2, mc); gx += (unsigned)cdiv(mc, 32 * wm); }
+    grid.x = gx;
+  }
   // few blocks and a long K axis: latency-bound stage chain -> two-stage-ahead loads
-  const bool deep = vec && wm == 2 && (int64_t)grid.x * grid.y <= 512 && a.Kpad / (STAGE_BYTES / (int)sizeof(T)) >= 6;
+  const bool deep = conv_gemm_deep(a, sizeof(T) == 4 ? 0 : 1);
 #define RD_CONV_CASE(BNV, WMV)                                                                                  \
   if (bn == BNV && wm == WMV) {                                                                                  \
-    if (vec) hipLaunchKernelGGL((conv_gemm_kernel<T, BNV, true, WMV>), grid, dim3(256), 0, st, a);         \
+    if (par) hipLaunchKernelGGL((conv_gemm_kernel<T, BNV, true, WMV, false, true>), grid, dim3(256), 0, st, a);  \
+    else if (vec) hipLaunchKernelGGL((conv_gemm_kernel<T, BNV, true, WMV>), grid, dim3(256), 0, st, a);         \
     else hipLaunchKernelGGL((conv_gemm_kernel<T, BNV, false, WMV>), grid, dim3(256), 0, st, a);                 \
   }
-#define RD_CONV_DEEP(BNV) if (bn == BNV) { hipLaunchKernelGGL((conv_gemm_kernel<T, BNV, true, 2, true>), grid, dim3(256), 0, st, a); return; }
+#define RD_CONV_DEEP(BNV) if (bn == BNV) { if (par) hipLaunchKernelGGL((conv_gemm_kernel<T, BNV, true, 2, true, true>), grid, dim3(256), 0, st, a); \
+                                            else hipLaunchKernelGGL((conv_gemm_kernel<T, BNV, true, 2, true>), grid, dim3(256), 0, st, a); return; }
   if (deep) { RD_CONV_DEEP(32) RD_CONV_DEEP(64) RD_CONV_DEEP(128) }
 #undef RD_CONV_DEEP
   RD_CONV_CASE(16, 4) RD_CONV_CASE(32, 4) RD_CONV_CASE(64, 4) RD_CONV_CASE(128, 4)
@@ -991,7 +1065,74 @@ int conv_stats_rows(const ConvArgs& a, int dtype) {
   return (int)cdiv(a.M, conv_block_pixels(a.M, a.Cout));
 }
 
+// ---- skinny linear layers: few output tiles, long K axis ----------------------------------------------------------------------------
+// The point MLP's last layer (RCNet/networks.py:299-329: 128 -> 2688 over R = 240 radar points) has a data gradient of 240 x 128 outputs
+// with K = 2688: eight 64 x 64 tiles of the implicit-GEMM kernel walk 84 dependent stages each (63 us for 165 MFLOP).  Here a block owns
+// ONE 16 x 16 output tile and its eight waves split the K axis (steps of one 16-byte vector per lane, interleaved); both operands are
+// k-contiguous (activation rows, packed weight rows) and come straight from L2 into the MFMA registers; the eight partial tiles are summed
+// through LDS in wave order (fixed summation order: reproducible), bias / activation in the epilogue.
+template <typename T>
+__global__ __launch_bounds__(512) void linear_skinny_kernel(ConvArgs a) {
+  constexpr int VE = Elem<T>::VE, STEP = 4 * VE, NWV = 8;
+  __shared__ float red[NWV][64][4];
+  const int t = threadIdx.x, lane = t & 63, wv = RD_WAVE_UNIFORM(t >> 6), fr = lane & 15, fg = lane >> 4;
+  const int m0 = blockIdx.x * 16, n0 = blockIdx.y * 16;
+  const int K = a.C1, nsteps = K / STEP;
+  const T* ap = (const T*)a.src1 + (int64_t)min(m0 + fr, a.M - 1) * K + fg * VE;
+  const T* wp = (const T*)a.w + (int64_t)(n0 + fr) * a.Kpad + fg * VE;
+  f32x4 acc = {0, 0, 0, 0};
+#pragma unroll 4
+  for (int s = wv; s < nsteps; s += NWV) {
+    const uint4 av = *reinterpret_cast<const uint4*>(ap + s * STEP);
+    const uint4 wf = *reinterpret_cast<const uint4*>(wp + s * STEP);
+    if (sizeof(T) == 4) {
+      acc = mfma_16x16x4_f32(__uint_as_float(wf.x), __uint_as_float(av.x), acc);
+      acc = mfma_16x16x4_f32(__uint_as_float(wf.y), __uint_as_float(av.y), acc);
+      acc = mfma_16x16x4_f32(__uint_as_float(wf.z), __uint_as_float(av.z), acc);
+      acc = mfma_16x16x4_f32(__uint_as_float(wf.w), __uint_as_float(av.w), acc);
+    } else {
+      s16x8 wa, pb;
+      __builtin_memcpy(&wa, &wf, 16);
+      __builtin_memcpy(&pb, &av, 16);
+      acc = mfma_16x16x32_bf16(wa, pb, acc);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 4; r++) red[wv][lane][r] = acc[r];
+  __syncthreads();
+  if (wv != 0) return;
+  // this lane: output row m0 + fr, channels n0 + 4 fg .. + 3
+  const int m = m0 + fr, co = n0 + fg * 4;
+  float x[4];
+#pragma unroll
+  for (int r = 0; r < 4; r++) {
+    float v = red[0][lane][r];
+#pragma unroll
+    for (int w = 1; w < NWV; w++) v += red[w][lane][r];
+    if (a.bias && co + r < a.Cout) v += a.bias[co + r];
+    x[r] = Elem<T>::rnd(act_fwd(v, a.act, a.slope));
+  }
+  if (m >= a.M) return;
+  T* const op = (T*)a.dst1 + (int64_t)m * a.Cout + co;
+  if (co + 3 < a.Cout && a.Cout % 4 == 0) st4(op, x);
+  else {
+#pragma unroll
+    for (int r = 0; r < 4; r++) if (co + r < a.Cout) Elem<T>::st(op + r, x[r]);
+  }
+}
+static bool conv_skinny_ok(const ConvArgs& a, int dtype) {
+  const int step = dtype == 0 ? 16 : 32;
+  return a.KH == 1 && a.KW == 1 && a.stride == 1 && a.pad == 0 && a.C2 == 0 && !a.ups && !a.pool2 && a.D1 == a.Cout && a.K == a.C1 &&
+         a.C1 % step == 0 && a.C1 >= 1024 && (int64_t)a.M * a.Cout <= 64 * 1024 && !a.stats && !a.add1 && !a.in_scale && !a.bn_y;
+}
+static void launch_linear_skinny(const ConvArgs& a, int dtype, hipStream_t st) {
+  const dim3 grid((unsigned)cdiv(a.M, 16), (unsigned)cdiv(a.Cout, 16));
+  if (dtype == 0) hipLaunchKernelGGL((linear_skinny_kernel<float>), grid, dim3(512), 0, st, a);
+  else hipLaunchKernelGGL((linear_skinny_kernel<bf16_t>), grid, dim3(512), 0, st, a);
+}
+
 void launch_conv(const ConvArgs& a, int dtype, hipStream_t st) {
+  if (conv_skinny_ok(a, dtype)) { launch_linear_skinny(a, dtype, st); return; }
   if (conv_few_ok(a)) { launch_conv_few(a, dtype, st); return; }
   if (conv1x1_direct_ok(a, dtype)) { launch_conv1x1_direct(a, dtype, st); return; }
   if (conv3x3_c1_ok(a)) { launch_conv3x3_c1(a, dtype, st); return; }
@@ -1032,9 +1173,10 @@ bool conv_bn_bwd_ok(const ConvArgs& a, int dtype) {
 bool wgrad_in_affine_ok(const WgradArgs& a, int dtype) { return !wgrad_tiny_shape_fwd(a) && wgrad3x3_tr_affine_ok(a, dtype); }
 // name of the kernel launch_conv picks for this shape (bench.py groups its per-launch timings by the names rocprofv3 reports)
 const char* conv_kernel_name(const ConvArgs& a, int dtype) {
+  if (conv_skinny_ok(a, dtype)) return dtype == 0 ? "linear_skinny_kernel<float>" : "linear_skinny_kernel<" RD_T16_NAME ">";
   if (conv_few_ok(a)) return "conv_few_kernel";
   if (conv1x1_direct_ok(a, dtype)) return "conv1x1_direct_kernel";
-  if (conv3x3_c1_ok(a)) return "conv3x3_c1_kernel";
+  if (conv3x3_c1_ok(a)) return a.Cout % (dtype == 0 ? 4 : 8) == 0 ? "conv3x3_c1v_kernel" : "conv3x3_c1_kernel";
   if (use_conv3x3_small(a, dtype)) return conv3x3_small_name(a, dtype);
   if (use_conv3x3_frag(a, dtype)) return conv3x3_frag_name(a, dtype);
   if (use_conv3x3(a, dtype)) return conv3x3_patch_name(a, dtype);
@@ -1044,8 +1186,9 @@ const char* conv_kernel_name(const ConvArgs& a, int dtype) {
     const bool vec = (Cin % ve == 0) && (a.C1 % ve == 0);
     int bn, wm;
     conv_tiles(a.M, a.Cout, bn, wm);
-    const bool deep = vec && wm == 2 && cdiv(a.M, 32 * wm) * cdiv(a.Cout, bn) <= 512 && a.Kpad / (STAGE_BYTES / es) >= 6;
-    snprintf(buf, sizeof(buf), "conv_gemm_kernel<%s, %d, %s, %d, %s>", dtype == 0 ? "float" : RD_T16_NAME, bn, vec ? "true" : "false", wm, deep ? "true" : "false");
+    const bool deep = conv_gemm_deep(a, dtype), par = conv_gemm_par(a, dtype);
+    (void)es;
+    snprintf(buf, sizeof(buf), "conv_gemm_kernel<%s, %d, %s, %d, %s, %s>", dtype == 0 ? "float" : RD_T16_NAME, bn, vec ? "true" : "false", wm, deep ? "true" : "false", par ? "true" : "false");
     return buf;
   }
 }

@@ -308,126 +308,12 @@ __global__ __launch_bounds__(256) void roi_pool_bwd_u8_kernel(const T* __restric
   }
 }
 
-// ---- gather form of the RoI-pool backward (deterministic, no atomics, writes the activation dtype directly) ---------------------------
-// A block owns a 16 x 16 pixel tile of one image.  It first lists, in ascending r, the RoIs of that image whose (scaled) box meets the
-// tile (ordered wave-ballot compaction into LDS together with their bin geometry); every (pixel, VE-channel group) item then walks
-// that short list, finds the bins whose window contains the pixel (<= 2 x 2 when bins are >= 1 pixel) -- windows are recomputed with exactly the forward's
-// float expressions -- and adds dout where the saved arg-max names this pixel.  The scatter form needed 83.6 M fp32 L2 atomics per
-// RC-Net step (1.18 ms, summation order not reproducible) plus a zero fill and a cast.
+// ---- deterministic (gather) forms of the RoI-pool backward: a block owns a 16 x 16 pixel tile of one image, lists the RoIs of that image whose
+// (scaled) box meets the tile in ascending order (ordered wave-ballot compaction into LDS), and every pixel adds dout of the bins whose window
+// contains it and whose saved arg-max names it -- no atomics, fixed order.  (The first form of this, one window loop per pixel and RoI, was
+// replaced by the pixel-owner kernel below in round 2 and removed in round 4.)
 static constexpr int RPB_T = 16, RPB_MAXL = 64;
 struct RoiGeo { int r, sh, sw, eh, ew; float bh, bw; };   // eh / ew: one past the last row / column any bin window can reach
-
-template <typename T>
-__global__ __launch_bounds__(256) void roi_pool_bwd_gather_kernel(const T* __restrict__ dout, const float* __restrict__ rois,
-                                                                  const int* __restrict__ argmax, T* __restrict__ dx, int R, int H,
-                                                                  int W, int C, int PH, int PW, float scale, int tilesW) {
-  constexpr int VE = Elem<T>::VE;
-  __shared__ RoiGeo list[RPB_MAXL];
-  __shared__ int wcount[4];
-  __shared__ int nlist;
-  const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-  const int b = blockIdx.y;
-  const int h0 = ((int)blockIdx.x / tilesW) * RPB_T, w0 = ((int)blockIdx.x % tilesW) * RPB_T;
-  const int G = C / VE;
-  const int items = RPB_T * RPB_T * G;
-  float acc[4][VE];   // a thread owns items t, t+256, ... (at most 4 passes are kept in registers; more channels loop the whole walk)
-
-  for (int ibase = 0; ibase < items; ibase += 4 * 256) {
-#pragma unroll
-    for (int k = 0; k < 4; k++)
-#pragma unroll
-      for (int e = 0; e < VE; e++) acc[k][e] = 0.f;
-    for (int rbase = 0; rbase < R; rbase += 256) {
-      // ---- list the RoIs rbase..rbase+255 that touch this tile, in ascending order; chunks of RPB_MAXL -----------------------------
-      const int r = rbase + t;
-      bool hit = false; RoiGeo gme;
-      if (r < R) {
-        const float* roi = rois + (int64_t)r * 5;
-        const int sw = (int)roundf(roi[1] * scale), sh = (int)roundf(roi[2] * scale);
-        const int ew = (int)roundf(roi[3] * scale), eh = (int)roundf(roi[4] * scale);
-        const int rw = max(ew - sw + 1, 1), rh = max(eh - sh + 1, 1);
-        gme.r = r; gme.sh = sh; gme.sw = sw; gme.eh = sh + rh + 1; gme.ew = sw + rw + 1;
-        gme.bh = (float)rh / (float)PH; gme.bw = (float)rw / (float)PW;
-        // conservative box: windows end at ceil((p+1)*bin) <= extent + 1
-        hit = ((int)roi[0] == b) && (sh <= h0 + RPB_T - 1) && (sh + rh + 1 >= h0) && (sw <= w0 + RPB_T - 1) && (sw + rw + 1 >= w0);
-      }
-      const unsigned long long m = __ballot(hit);
-      const int before = __popcll(m & ((1ull << lane) - 1ull));
-      if (lane == 0) wcount[wv] = __popcll(m);
-      __syncthreads();
-      int woff = 0;
-      for (int q = 0; q < wv; q++) woff += wcount[q];
-      const int total = wcount[0] + wcount[1] + wcount[2] + wcount[3];
-      const int mypos = woff + before;
-      for (int cbase = 0; cbase < total; cbase += RPB_MAXL) {
-        __syncthreads();
-        if (hit && mypos >= cbase && mypos < cbase + RPB_MAXL) list[mypos - cbase] = gme;
-        if (t == 0) nlist = min(total - cbase, RPB_MAXL);
-        __syncthreads();
-        const int nl = nlist;
-        // ---- every item walks the list ---------------------------------------------------------------------------------------------
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-          const int item = ibase + k * 256 + t;
-          if (item >= items) continue;
-          const int g = item % G, pix = item / G;
-          const int h = h0 + pix / RPB_T, w = w0 + pix % RPB_T;
-          if (h >= H || w >= W) continue;
-          const int target = h * W + w;
-          for (int li = 0; li < nl; li++) {
-            const RoiGeo q = list[li];
-            if (h < q.sh || h >= q.eh || w < q.sw || w >= q.ew) continue;   // pixel outside this RoI: most listed RoIs only graze the tile
-            // bins whose window [floor(p*bin), ceil((p+1)*bin)) can contain the pixel: p in ((d-1)/bin - 1, (d+1)/bin), d = h - start
-            const float dh = (float)(h - q.sh), dw = (float)(w - q.sw);
-            const int ph_lo = max((int)floorf((dh - 1.f) / q.bh) - 1, 0), ph_hi = min((int)ceilf((dh + 1.f) / q.bh), PH - 1);
-            const int pw_lo = max((int)floorf((dw - 1.f) / q.bw) - 1, 0), pw_hi = min((int)ceilf((dw + 1.f) / q.bw), PW - 1);
-            // first passing bin and count per axis (windows of consecutive bins overlap by at most one pixel, so the passing bins are
-            // contiguous); pure ALU, so that the loads below run with every lane on ITS k-th bin instead of on a shared candidate
-            int pha = -1, nph = 0, pwa = -1, npw = 0;
-            for (int ph = ph_lo; ph <= ph_hi; ph++) {
-              int hs = (int)floorf((float)ph * q.bh), he = (int)ceilf((float)(ph + 1) * q.bh);
-              hs = min(max(hs + q.sh, 0), H); he = min(max(he + q.sh, 0), H);
-              if (h >= hs && h < he) { if (nph == 0) pha = ph; nph++; }
-            }
-            if (nph == 0) continue;
-            for (int pw = pw_lo; pw <= pw_hi; pw++) {
-              int ws = (int)floorf((float)pw * q.bw), we = (int)ceilf((float)(pw + 1) * q.bw);
-              ws = min(max(ws + q.sw, 0), W); we = min(max(we + q.sw, 0), W);
-              if (w >= ws && w < we) { if (npw == 0) pwa = pw; npw++; }
-            }
-            for (int ia = 0; ia < nph; ia++)
-              for (int ib = 0; ib < npw; ib++) {
-                const int64_t o = (((int64_t)q.r * PH + pha + ia) * PW + pwa + ib) * C + g * VE;
-                int am[VE];
-#pragma unroll
-                for (int e4 = 0; e4 < VE / 4; e4++) {
-                  const int4 a4 = *reinterpret_cast<const int4*>(argmax + o + e4 * 4);
-                  am[e4 * 4] = a4.x; am[e4 * 4 + 1] = a4.y; am[e4 * 4 + 2] = a4.z; am[e4 * 4 + 3] = a4.w;
-                }
-                bool any = false;
-#pragma unroll
-                for (int e = 0; e < VE; e++) any |= (am[e] == target);
-                if (!any) continue;
-                float dv[VE];
-                ldv(dout + o, dv);
-#pragma unroll
-                for (int e = 0; e < VE; e++) if (am[e] == target) acc[k][e] += dv[e];
-              }
-          }
-        }
-      }
-      __syncthreads();
-    }
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-      const int item = ibase + k * 256 + t;
-      if (item >= items) continue;
-      const int g = item % G, pix = item / G;
-      const int h = h0 + pix / RPB_T, w = w0 + pix % RPB_T;
-      if (h < H && w < W) stv(dx + (((int64_t)b * H + h) * W + w) * C + g * VE, acc[k]);
-    }
-  }
-}
 
 // ---- pixel-owner form of the RoI-pool backward ------------------------------------------------------------------------------------
 // As the gather kernel above: a block owns a 16 x 16 pixel tile (x 32 channels) of one image, lists the RoIs of that image whose box
@@ -829,16 +715,9 @@ void launch_roi_pool_bwd_tile(const void* dout, const float* rois, const int* ar
 void launch_roi_pool_bwd_gather(const void* dout, const float* rois, const int* argmax, void* dx, int R, int N, int H, int W, int C,
                                 int PH, int PW, float scale, int dtype, hipStream_t st) {
   const int tilesH = (int)cdiv(H, RPB_T), tilesW = (int)cdiv(W, RPB_T);
-  static const bool old_form = getenv("RD_ROI_GATHER_V1") != nullptr;      // A/B: the first gather form (window loops per pixel)
-  if (!old_form && PH < (1 << 19) && PW < (1 << 19)) {
-    dim3 grid((unsigned)(tilesH * tilesW), (unsigned)N, (unsigned)cdiv(C, RPT_CC));
-    if (dtype == 0) hipLaunchKernelGGL((roi_pool_bwd_pix_kernel<float, int>), grid, dim3(256), 0, st, (const float*)dout, rois, argmax, (float*)dx, R, H, W, C, PH, PW, scale, tilesW, (const int*)nullptr);
-    else hipLaunchKernelGGL((roi_pool_bwd_pix_kernel<bf16_t, int>), grid, dim3(256), 0, st, (const bf16_t*)dout, rois, argmax, (bf16_t*)dx, R, H, W, C, PH, PW, scale, tilesW, (const int*)nullptr);
-    return;
-  }
-  dim3 grid((unsigned)(tilesH * tilesW), (unsigned)N);
-  if (dtype == 0) hipLaunchKernelGGL((roi_pool_bwd_gather_kernel<float>), grid, dim3(256), 0, st, (const float*)dout, rois, argmax, (float*)dx, R, H, W, C, PH, PW, scale, tilesW);
-  else hipLaunchKernelGGL((roi_pool_bwd_gather_kernel<bf16_t>), grid, dim3(256), 0, st, (const bf16_t*)dout, rois, argmax, (bf16_t*)dx, R, H, W, C, PH, PW, scale, tilesW);
+  dim3 grid((unsigned)(tilesH * tilesW), (unsigned)N, (unsigned)cdiv(C, RPT_CC));
+  if (dtype == 0) hipLaunchKernelGGL((roi_pool_bwd_pix_kernel<float, int>), grid, dim3(256), 0, st, (const float*)dout, rois, argmax, (float*)dx, R, H, W, C, PH, PW, scale, tilesW, (const int*)nullptr);
+  else hipLaunchKernelGGL((roi_pool_bwd_pix_kernel<bf16_t, int>), grid, dim3(256), 0, st, (const bf16_t*)dout, rois, argmax, (bf16_t*)dx, R, H, W, C, PH, PW, scale, tilesW, (const int*)nullptr);
 }
 
 // ---- compact (one byte per element) arg-max forms: C must be a multiple of the 16-byte vector -----------------------------------------

@@ -24,6 +24,7 @@ _RD_DT = {torch.float32: RD_F32, torch.bfloat16: RD_BF16, torch.float16: RD_F16}
 
 _state = {"dtype": RD_F32, "tape": None, "defer_wgrad": True, "fused_loftr": True, "deterministic_roi_pool": False, "roi_tile_min_blocks": 256,
           "fuse_upsample_bwd": os.environ.get("RIDERS_FUSE_UPSAMPLE_BWD", "1") != "0",     # A/B switch of the 2x2-summing data gradient
+          "fuse_res_add": os.environ.get("RIDERS_FUSE_RES_ADD", "1") != "0",       # A/B switch: residual of a conv without BatchNorm / activation added in its epilogue
           "fuse_grad_add": os.environ.get("RIDERS_FUSE_GRAD_ADD", "1") != "0",     # A/B switch: second gradient contribution added in the data-gradient epilogue
           # Round 4: conv -> BatchNorm -> activation outputs stay virtual (LazyAct) and the consumer applies scale / shift / activation while
           # staging its input.  Level 0: never (the separate rd_affine_act pass everywhere); 1 (default): inside residual blocks (conv1 ->
@@ -860,7 +861,16 @@ def conv_block(x, weight, *, x2=None, bias=None, stride=1, pad=None, up=None, bn
     es = x.element_size()   # algorithmic HBM bytes of the three convolution launches (every operand moved exactly once)
     b_in = (x.numel() + (0 if x2 is None else x2.numel())) * es
     b_w, b_out = weight.numel() * es, N * OH * OW * Cout * es
-    if fus is not None:
+    res_fused = False
+    if (residual is not None and not use_bn and act == ACT_NONE and fus is None and residual.shape == y.shape and residual.dtype == y.dtype
+            and residual.is_contiguous() and _state.get("fuse_res_add", True) and lib.rd_conv_add_ok(ctypes.byref(d))):
+        # conv + bias + residual with no BatchNorm and no activation (the residual units of the SML decoder, modules/midas/blocks.py:99-130):
+        # the residual rides in the convolution's epilogue as its addend (rounded once) instead of a separate add pass over y
+        res_fused = True
+        _chk(_timed("conv_gemm", flops, lambda: lib.rd_conv_fwd_add(ctypes.byref(d), _p(x), _p(x2), _p(wp), _p(bias_t), _p(residual), _p(y), st),
+                    "fwd " + shp + " (+res)", b_in + b_w + 2 * b_out,
+                    kernel=lambda: lib.rd_conv_fwd_kernel_name(ctypes.byref(d)).decode(), idem=True), "rd_conv_fwd_add")
+    elif fus is not None:
         lazy_counts["fwd_fused"] += 1
         _chk(_timed("conv_gemm", flops, lambda: lib.rd_conv_fwd_fused(ctypes.byref(d), ctypes.byref(fus), _p(x), _p(x2), _p(wp), _p(bias_t), None,
                                                                          _p(y), None, _p(stats), st), "fwd " + shp + " (bn-in)", b_in + b_w + b_out,
@@ -885,6 +895,8 @@ def conv_block(x, weight, *, x2=None, bias=None, stride=1, pad=None, up=None, bn
     if lazy_out and use_bn and residual is None and _state["lazy_bn"] >= int(lazy_out) and _BN_RECOMPUTE and Cout % ve == 0:
         z = None
         lazy = LazyAct(y, coef, act, slope)      # z stays virtual: the consumer applies (scale, shift, act) while it stages y
+    elif res_fused:
+        z = y
     elif use_bn or residual is not None:
         z = torch.empty_like(y)
         _chk(_tb("bn_apply", (2 + (residual is not None)) * b_out,
