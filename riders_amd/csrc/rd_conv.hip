@@ -1176,7 +1176,7 @@ const char* conv_kernel_name(const ConvArgs& a, int dtype) {
   if (conv_skinny_ok(a, dtype)) return dtype == 0 ? "linear_skinny_kernel<float>" : "linear_skinny_kernel<" RD_T16_NAME ">";
   if (conv_few_ok(a)) return "conv_few_kernel";
   if (conv1x1_direct_ok(a, dtype)) return "conv1x1_direct_kernel";
-  if (conv3x3_c1_ok(a)) return a.Cout % (dtype == 0 ? 4 : 8) == 0 ? "conv3x3_c1v_kernel" : "conv3x3_c1_kernel";
+  if (conv3x3_c1_ok(a)) return "conv3x3_c1_kernel";
   if (use_conv3x3_small(a, dtype)) return conv3x3_small_name(a, dtype);
   if (use_conv3x3_frag(a, dtype)) return conv3x3_frag_name(a, dtype);
   if (use_conv3x3(a, dtype)) return conv3x3_patch_name(a, dtype);

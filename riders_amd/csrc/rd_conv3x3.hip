@@ -590,52 +590,6 @@ __global__ __launch_bounds__(256) void conv3x3_c1_kernel(ConvArgs a) {
   }
 }
 
-// The same layer with the output channels in whole 16-byte vectors (RC-Net's 1 -> 16 head gradient on 5.76 M pixels): Cout / VE threads
-// per pixel, each with ITS 9 x VE weights in registers and one 16-byte store -- a wave's store instruction covers 1 KiB of consecutive
-// addresses.  (One thread per pixel read every weight from LDS per use -- 144 broadcast reads per pixel -- and wrote its 32 bytes as four
-// strided 8-byte stores: 80 us for 196 MB.)  Same products in the same ascending-tap order: results are bit for bit those of the form above.
-template <typename T>
-__global__ __launch_bounds__(256) void conv3x3_c1v_kernel(ConvArgs a) {
-  constexpr int VE = Elem<T>::VE;
-  const int tpp = a.Cout / VE;
-  const int64_t total = a.M * (int64_t)tpp;
-  const T* x = (const T*)a.src1;
-  const int64_t g0 = (int64_t)blockIdx.x * 256 + threadIdx.x, gs = (int64_t)gridDim.x * 256;
-  // a thread keeps its channel group over the grid-stride loop when the stride is a multiple of the group count (the launcher makes it so)
-  const int cg = (int)(g0 % tpp), co0 = cg * VE;
-  float w[9][VE], bv[VE];
-#pragma unroll
-  for (int tp = 0; tp < 9; tp++)
-#pragma unroll
-    for (int e = 0; e < VE; e++) w[tp][e] = Elem<T>::ld((const T*)a.w + (int64_t)(co0 + e) * a.Kpad + tp);
-#pragma unroll
-  for (int e = 0; e < VE; e++) bv[e] = a.bias ? a.bias[co0 + e] : 0.f;
-  for (int64_t g = g0; g < total; g += gs) {
-    const int64_t m = g / tpp;
-    int ow = (int)(m % a.OW); int64_t q = m / a.OW; int oh = (int)(q % a.OH); int n = (int)(q / a.OH);
-    float xv[9];
-#pragma unroll
-    for (int kh = 0; kh < 3; kh++)
-#pragma unroll
-      for (int kw = 0; kw < 3; kw++) {
-        int ih = oh - 1 + kh, iw = ow - 1 + kw;
-        bool ok = (unsigned)ih < (unsigned)a.Hin && (unsigned)iw < (unsigned)a.Win;
-        const float xl = Elem<T>::ld(x + ((int64_t)n * a.Hin + min(max(ih, 0), a.Hin - 1)) * a.Win + min(max(iw, 0), a.Win - 1));
-        xv[kh * 3 + kw] = ok ? xl : 0.f;
-      }
-    float v[VE];
-#pragma unroll
-    for (int e = 0; e < VE; e++) {
-      float s_ = 0.f;
-#pragma unroll
-      for (int tp = 0; tp < 9; tp++) s_ += w[tp][e] * xv[tp];
-      if (a.bias) s_ += bv[e];
-      v[e] = act_fwd(s_, a.act, a.slope);
-    }
-    stv((T*)a.dst1 + m * a.Cout + co0, v);
-  }
-}
-
 // ---- host side -------------------------------------------------------------------------------------------------------------------
 static int pick_bn3(int cout) { return cout <= 16 ? 16 : (cout <= 32 ? 32 : (cout <= 64 ? 64 : 128)); }
 
@@ -883,16 +837,6 @@ bool conv3x3_c1_ok(const ConvArgs& a) {
   return geom3x3(a) && a.C1 == 1 && a.C2 == 0 && !a.ups && !a.stats && a.D1 == a.Cout && a.Cout <= 32;
 }
 void launch_conv3x3_c1(const ConvArgs& a, int dtype, hipStream_t st) {
-  const int ve = dtype == 0 ? 4 : 8;
-  static const bool vec_off = getenv("RD_C1_VEC") && atoi(getenv("RD_C1_VEC")) == 0;      // A/B switch
-  if (a.Cout % ve == 0 && !vec_off) {
-    const int tpp = a.Cout / ve;
-    unsigned gv = (unsigned)std::min<int64_t>(cdiv(a.M * (int64_t)tpp, 256), 256 * 32);
-    while ((gv * 256u) % (unsigned)tpp) gv++;      // grid stride = whole pixels: a thread's channel group is loop invariant
-    if (dtype == 0) hipLaunchKernelGGL((conv3x3_c1v_kernel<float>), dim3(gv), dim3(256), 0, st, a);
-    else hipLaunchKernelGGL((conv3x3_c1v_kernel<bf16_t>), dim3(gv), dim3(256), 0, st, a);
-    return;
-  }
   unsigned grid = (unsigned)std::min<int64_t>(cdiv(a.M, 256), 256 * 32);
   if (dtype == 0) hipLaunchKernelGGL((conv3x3_c1_kernel<float>), dim3(grid), dim3(256), 0, st, a);
   else hipLaunchKernelGGL((conv3x3_c1_kernel<bf16_t>), dim3(grid), dim3(256), 0, st, a);

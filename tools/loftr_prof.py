@@ -14,7 +14,7 @@ if len(sys.argv) > 1 and sys.argv[1] == "build":
     obj = os.path.join(ROOT, "tools", "ab", "rd_loftr_prof.o")
     subprocess.check_call([build.HIPCC, "-x", "hip"] + build.FLAGS + ["-DRD_LOFTR_PROF", "-I", os.path.join(ROOT, "include"), "-c",
                            os.path.join(build.CSRC, "rd_loftr.hip"), "-o", obj])
-    objs = [obj if f == "rd_loftr.hip" else os.path.join(build.OBJ, f + ".o") for f in build.sources()]
+    objs = [obj if o.endswith("rd_loftr.hip.o") else o for (_, o, _) in build.units()]      # both precision builds; the bf16 / fp32 LoFTR unit replaced
     subprocess.check_call([build.HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", PROF] + objs)
     print(PROF)
     sys.exit(0)
