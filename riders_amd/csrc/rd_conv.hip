@@ -289,6 +289,18 @@ __device__ __forceinline__ int64_t pack_frag_index(int row, int k, int C, int ro
   const int chunk = c / CKE, kk = c - chunk * CKE, kh = kk / (4 * VE), kg = (kk % (4 * VE)) / VE, e = kk % VE;
   return ((((int64_t)(chunk * 9 + tap) * (rows_pad >> 4) + (row >> 4)) * 2 + kh) * 64 + kg * 16 + (row & 15)) * VE + e;
 }
+// Linear / 1x1 operands of the fused LoFTR layer's sizes (128 or 256 channels on either side) also carry a second copy, in the fragment
+// order of its token GEMMs (rd_loftr.hip tok_load): [16-row tile][k step of 4 vectors][lane = 16 * k-group + row] x 16 bytes.  Row-major, a
+// wave's fragment load touched 16 rows x 64 bytes -- half a cache line per row, the other half wanted one k step later by which time the
+// eight waves' 256 lines had passed through a 128-line L1: probe builds (profiles/r04_microbench/loftr_weight_stream.txt) put 6 of the
+// forward's 22 us on the weight stream, and 3 of them on this access shape alone.
+__host__ __device__ __forceinline__ bool pack_has_tokfrag(int rows, int K) { return (rows == 128 || rows == 256) && (K == 128 || K == 256); }
+template <typename T>
+__device__ __forceinline__ int64_t pack_tokfrag_index(int row, int k, int K) {
+  constexpr int VE = Elem<T>::VE, SE = 4 * VE;
+  const int ks = k / SE, kk = k - ks * SE, kg = kk / VE, e = kk - kg * VE;
+  return ((((int64_t)(row >> 4) * (K / SE) + ks) * 64) + kg * 16 + (row & 15)) * VE + e;
+}
 template <typename T>
 __global__ void pack_weights_kernel(const float* __restrict__ w, T* __restrict__ out, int Cout, int Cin, int KH,
                                     int KW, int mode, int rows_pad, int Kpad, int CinSrc) {
@@ -296,6 +308,7 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, T* __restrict__
   int rows = mode ? Cin : Cout, C = mode ? Cout : Cin;
   int K = KH * KW * C;
   const bool frag = pack_has_frag(KH, KW, C, sizeof(T) == 4 ? 0 : 1);
+  const bool tokfrag = KH == 1 && KW == 1 && pack_has_tokfrag(rows, K);      // rows_pad == rows, Kpad == K at these sizes
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     int row = (int)(i / Kpad), k = (int)(i - (int64_t)row * Kpad);
     float v = 0.f;
@@ -307,6 +320,7 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, T* __restrict__
     }
     Elem<T>::st(&out[i], v);
     if (frag) Elem<T>::st(&out[total + pack_frag_index<T>(row, k, C, rows_pad)], v);    // Kpad == K here
+    if (tokfrag) Elem<T>::st(&out[total + pack_tokfrag_index<T>(row, k, K)], v);
   }
 }
 
@@ -322,6 +336,7 @@ __device__ __forceinline__ void pack_one(const PackItem& it, int bx, int nbx) {
   const int Kpad = (K + bke - 1) / bke * bke;
   const int64_t total = (int64_t)rows_pad * Kpad;
   const bool frag = pack_has_frag(it.KH, it.KW, C, sizeof(T) == 4 ? 0 : 1);
+  const bool tokfrag = it.KH == 1 && it.KW == 1 && pack_has_tokfrag(rows, K);
   T* out = (T*)it.out;
   // (row, k) advance with the element index instead of being divided out of it, and k -> (tap, channel) goes through a rounded float
   // reciprocal (k < 2^22): 93 -> 70 us per RC-Net step.  (The SML step's 210 us are the strided OIHW reads -- one cache line per four
@@ -342,6 +357,7 @@ __device__ __forceinline__ void pack_one(const PackItem& it, int bx, int nbx) {
     }
     Elem<T>::st(&out[i], v);
     if (frag) Elem<T>::st(&out[total + pack_frag_index<T>(row, k, C, rows_pad, tap, c)], v);
+    if (tokfrag) Elem<T>::st(&out[total + pack_tokfrag_index<T>(row, k, K)], v);
     row += srow; k += sk;
     if (k >= Kpad) { k -= Kpad; row++; }
   }
@@ -974,7 +990,7 @@ int conv_kpad(int K, int dtype) { int bke = dtype == 0 ? 32 : 64; return (int)cd
 // elements of a packed operand: K axes that can be 9 taps x whole 128-byte chunks leave room for the fragment-ordered copy
 int64_t conv_packed_elems(int rows, int K, int dtype) {
   const int64_t n = (int64_t)conv_rows_pad(rows) * conv_kpad(K, dtype);
-  return (K % (9 * (dtype == 0 ? 32 : 64)) == 0) ? 2 * n : n;
+  return (K % (9 * (dtype == 0 ? 32 : 64)) == 0 || pack_has_tokfrag(rows, K)) ? 2 * n : n;
 }
 
 // tile choice: small-M launches (fewer than ~1.5 blocks per CU with 128-pixel tiles) halve the pixel tile, then the channel tile

@@ -97,12 +97,22 @@ template <typename T, int K, int NO>
 __device__ __forceinline__ void tok_load(const void* wpacked, TokW<T, K, NO>& w) {
   using W = TokW<T, K, NO>;
   const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, fr = lane & 15, fg = lane >> 4;
-  w.wp = reinterpret_cast<const uint4*>(wpacked);
+  // the fragment-ordered second copy of the packed operand (pack_has_tokfrag, rd_conv.hip): behind the NO x K row-major one
+  w.wp = reinterpret_cast<const uint4*>(wpacked) + NO * W::KSL;
   if (W::HOIST) {
 #pragma unroll
     for (int ci = 0; ci < W::NCT; ci++)
 #pragma unroll
-      for (int ks = 0; ks < W::NS; ks++) { const uint4 v = w.wp[(int64_t)((wv + ci * LNW) * 16 + fr) * W::KSL + ks * 4 + fg]; w.f[ci][ks] = v; }
+      for (int ks = 0; ks < W::NS; ks++) {
+#if defined(RD_LOFTR_PROBE) && RD_LOFTR_PROBE == 5      // timing probe: every fragment from one 1-KiB region (L1 hits): what the weight streaming costs
+        const uint4 v = w.wp[fr * 4 + fg + ((ks + ci) & 1) * 64];
+#elif defined(RD_LOFTR_PROBE) && RD_LOFTR_PROBE == 7    // timing probe: the row-major copy (16 rows x 64 bytes per load instruction), as before round 4
+        const uint4 v = (w.wp - NO * W::KSL)[(int64_t)((wv + ci * LNW) * 16 + fr) * W::KSL + ks * 4 + fg];
+#else
+        const uint4 v = w.wp[((wv + ci * LNW) * W::NS + ks) * 64 + lane];      // one contiguous 1-KiB fragment per instruction
+#endif
+        w.f[ci][ks] = v;
+      }
     sched_fence();   // keep the loads here: the scheduler otherwise sinks them next to their MFMA, two at a time
   }
 }
@@ -116,7 +126,7 @@ __device__ __forceinline__ void tok_mma(const T* a0, const T* a1, int K0, int ld
     const int ct = wv + ci * LNW;
     if (!W::HOIST) {
 #pragma unroll
-      for (int ks = 0; ks < NS; ks++) { const uint4 v = w.wp[(int64_t)(ct * 16 + fr) * W::KSL + ks * 4 + fg]; w.f[0][ks] = v; }
+      for (int ks = 0; ks < NS; ks++) { const uint4 v = w.wp[(ct * NS + ks) * 64 + lane]; w.f[0][ks] = v; }
     }
     const uint4 (&wf)[NS] = w.f[W::HOIST ? ci : 0];
     f32x4 acc[2] = {f32x4{0, 0, 0, 0}, f32x4{0, 0, 0, 0}};
