@@ -38,6 +38,10 @@ _state = {"dtype": RD_F32, "tape": None, "defer_wgrad": True, "fused_loftr": Tru
           # step cost more than the overlap returns -- the wide weight-gradient blocks hold 506 of a SIMD's 512 VGPRs, nothing co-schedules):
           # default 0 = everything on one stream; 1 keeps the experiment reproducible
           "wgrad_stream": os.environ.get("RIDERS_WGRAD_STREAM", "0") != "0",
+          # engine.side_region (RoI poolings of the skip features on a second stream, next to the transformer): measured SLOWER -- 1059 / 1058
+          # img/s off, 1049 / 1049 on (one box, alternating; the two fork / join pairs per step cost more than the overlap returns, as with
+          # RIDERS_WGRAD_STREAM) -- off by default
+          "side_roi": os.environ.get("RIDERS_SIDE_ROI", "0") != "0", "side_pending": None,
           "roi_u8": os.environ.get("RIDERS_ROI_U8", "1") != "0"}      # compact (one byte) RoI-pool arg-max; 0: int32 indices (A/B)
 
 
@@ -53,6 +57,75 @@ def _side_stream(dev):
 
 def set_wgrad_stream(flag):
     _state["wgrad_stream"] = bool(flag)
+
+
+class _OnStream(object):
+    """A tape node whose backward launches go to `stream` (see side_region)."""
+
+    def __init__(self, fn, stream):
+        self.fn, self.stream = fn, stream
+        self._stage = getattr(fn, "_stage", None)
+
+    def __call__(self):
+        with torch.cuda.stream(self.stream):
+            self.fn()
+
+
+class side_region(object):
+    """with side_region(x): launches (and torch allocations) inside go to the device's SIDE stream, forked behind everything queued on the
+    current stream so far; `side_join(x)` later makes the current stream wait for them.  Work between the two on the current stream runs
+    concurrently with the region (inside a captured hipGraph: parallel branches).  The tape mirrors it: the join's backward forks the side
+    stream again, the region's backward nodes launch there, the region entry's backward joins.  RC-Net: the five RoI poolings of the skip
+    features (and their gradients) next to the latency-bound transformer launches, which hold one workgroup per CU at two waves per SIMD.
+    Plain sequential launches for host tensors, under the kernel timer, and unless RIDERS_SIDE_ROI=1 (measured slower: see _state)."""
+
+    def __init__(self, like):
+        self.on = bool(like.is_cuda and _state["side_roi"] and _timer["t"] is None and _state.get("side_pending") is None)
+        self.dev = like.device
+
+    def __enter__(self):
+        if not self.on:
+            return self
+        t = _state["tape"]
+        side = self.side = _side_stream(self.dev)
+        main = torch.cuda.current_stream(self.dev)
+        side.wait_event(main.record_event())
+        if t is not None:
+            dev = self.dev
+
+            def backward():      # (runs after the region's backward nodes) the gradients written on the side stream are complete
+                torch.cuda.current_stream(dev).wait_stream(side)
+            t.record(backward)
+            self.n0 = len(t.nodes)
+        self.ctx = torch.cuda.stream(side)
+        self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if not self.on:
+            return False
+        self.ctx.__exit__(*exc)
+        t = _state["tape"]
+        if t is not None:
+            for i in range(self.n0, len(t.nodes)):
+                t.nodes[i] = _OnStream(t.nodes[i], self.side)
+        _state["side_pending"] = self.dev
+        return False
+
+
+def side_join(like):
+    """The current stream waits for the work of the last side_region (no-op when there is none)."""
+    dev = _state.get("side_pending")
+    if dev is None:
+        return
+    _state["side_pending"] = None
+    side = _side_stream(dev)
+    torch.cuda.current_stream(dev).wait_stream(side)
+    t = _state["tape"]
+    if t is not None:
+        def backward():      # (runs BEFORE the backward of everything recorded between the region and this join) fork
+            side.wait_event(torch.cuda.current_stream(dev).record_event())
+        t.record(backward)
 
 
 # how often a virtual activation was consumed in place / had to be written after all (tests assert that the fused routes are taken)
@@ -523,6 +596,7 @@ class StepTape(object):
 def _active(t):
     prev = _state["tape"]
     _state["tape"] = t
+    _state["side_pending"] = None      # (a forward that raised between side_region and side_join must not disable the next one)
     try:
         yield t
     finally:
