@@ -441,11 +441,19 @@ __global__ __launch_bounds__(256) void roi_pool_bwd_pix_kernel(const T* __restri
         for (int kb = 0; kb < GC; kb += KB) {
           int am[KB][4][VE]; uint4 dv[KB][4]; int nr[KB], rf[KB];
           int rdh[KB];
+          bool any = false;
 #pragma unroll
           for (int k = 0; k < KB; k++) {
             const int rc = nc ? cand[li].rowc[lh0 + (kb + k) * PR] : 0;
             nr[k] = tgt[kb + k] >= 0 ? (rc & 4095) : 0; rf[k] = rc >> 12;
             rdh[k] = U8 ? coff[li].rowd[lh0 + (kb + k) * PR] : 0;
+            any = any || nr[k] > 0;
+          }
+          // a listed RoI meets the TILE, not necessarily this wave's rows (one tile row per item, all 16 columns): when no lane has a
+          // covering bin the batch's 2 x 2 x KB requests -- one memory round trip of the serial walk -- are skipped for the whole wave
+          if (__ballot(any) == 0ull) continue;
+#pragma unroll
+          for (int k = 0; k < KB; k++) {
 #pragma unroll
             for (int q = 0; q < 4; q++) {
               const int ia = q >> 1, ib = q & 1;
