@@ -28,6 +28,9 @@ __device__ __forceinline__ void bn_rows_sum(const float2* __restrict__ p2, int r
   for (; r < rows; r += 256) { const float2 v = p2[(int64_t)r * C + c]; a += (double)v.x; b += (double)v.y; }
 }
 
+// pixels per thread of the forward `*_gen` apply kernel's grid (A/B hook: RD_BN_GEN_PPT; SML step 1227-1231 img/s at 2, 1247 at 8, 1243 at 16)
+static int gen_ppt() { static const int v = getenv("RD_BN_GEN_PPT") ? std::max(2, atoi(getenv("RD_BN_GEN_PPT"))) : 8; return v; }
+
 // ---- BN finalize: partial[rows][C][2] -> mean/rstd + fused scale/shift, running-stat update ----
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ partial, int rows, int C, double count,
                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -406,6 +409,22 @@ __global__ __launch_bounds__(256) void affine_act_gen_kernel(const T* __restrict
   // outstanding 16-byte load per lane is latency-bound: waves spent half their cycles waiting, PMC round 2)
   const int64_t step = (int64_t)gridDim.x * PPB;
   int64_t p = (int64_t)blockIdx.x * PPB + pl;
+  if (!HAS_RES) {
+    // four pixels per iteration (the grid gives a thread eight): the small EfficientNet maps (2.6-41 K pixels x 288-1392 channels) are a
+    // few hundred blocks, and a thread's iterations are dependent memory round trips -- 16.8 us for 24 MB with one two-pixel iteration
+    // on 1728 blocks (whose per-thread coefficient loads outweighed the data), 10.7 with four on 432, 4-pixel batches below
+    for (; p + 3 * step < pixels; p += 4 * step) {
+      float v[4][VE];
+#pragma unroll
+      for (int q = 0; q < 4; q++) ldv(y + (p + q * step) * C + g * VE, v[q]);
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+#pragma unroll
+        for (int e = 0; e < VE; e++) { const float u = v[q][e] * sc[e] + sh[e]; v[q][e] = act_fwd(u, actv, slope); }
+        stv(out + (p + q * step) * C + g * VE, v[q]);
+      }
+    }
+  }
   for (; p + step < pixels; p += 2 * step) {
     const int64_t o0 = p * C + g * VE, o1 = (p + step) * C + g * VE;
     float v0[VE], v1[VE], r0[VE], r1[VE];
@@ -661,7 +680,7 @@ void launch_affine_act(const void* y, const float* scale, const float* shift, co
   }
   if (gen_ok(C, dtype)) {
     const int ppb = 256 / (C / (dtype == 0 ? 4 : 8));
-    unsigned gg = (unsigned)std::max<int64_t>(1, std::min<int64_t>(cdiv(pixels, 2 * ppb), 2048));      // two pixels per thread per iteration
+    unsigned gg = (unsigned)std::max<int64_t>(1, std::min<int64_t>(cdiv(pixels, gen_ppt() * ppb), 2048));      // >= two pixels per thread (one iteration of the two-pixel loop)
     act_dispatch(act, [&](auto ac) {
       constexpr int A = decltype(ac)::value;
       if (dtype == 0) { if (res) hipLaunchKernelGGL((affine_act_gen_kernel<float, A, true>), dim3(gg), dim3(256), 0, st, (const float*)y, scale, shift, (const float*)res, (float*)out, pixels, C, act, slope);
@@ -765,7 +784,7 @@ void launch_bn_bwd_apply(const void* dz, const void* z, const void* y, const flo
   }
   if (gen_ok(C, dtype)) {
     const int ppb = 256 / (C / (dtype == 0 ? 4 : 8));
-    unsigned gg = (unsigned)std::max<int64_t>(1, std::min<int64_t>(cdiv(pixels, 2 * ppb), 2048));      // two pixels per thread per iteration
+    unsigned gg = (unsigned)std::max<int64_t>(1, std::min<int64_t>(cdiv(pixels, 2 * ppb), 2048));      // two pixels per thread per iteration (4 / 8: 1244 / 1241 vs 1246 img/s on the SML step)
     act_dispatch(act, [&](auto ac) {
       constexpr int A = decltype(ac)::value; (void)A;
       if (dtype == 0) { if (shift) hipLaunchKernelGGL((bn_bwd_apply_gen_kernel<float, true, A>), dim3(gg), dim3(256), 0, st, (const float*)dz, (const float*)z, (const float*)y, mean, rstd, scale, c1, c2, shift, (float*)dy, (float*)dres, pixels, C, act, slope); else hipLaunchKernelGGL((bn_bwd_apply_gen_kernel<float, false, -1>), dim3(gg), dim3(256), 0, st, (const float*)dz, (const float*)z, (const float*)y, mean, rstd, scale, c1, c2, shift, (float*)dy, (float*)dres, pixels, C, act, slope); }
