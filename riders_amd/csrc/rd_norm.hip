@@ -247,6 +247,22 @@ __global__ __launch_bounds__(256) void affine_act_vec_kernel(const T* __restrict
   float sc[VE], sh[VE];
 #pragma unroll
   for (int e = 0; e < VE; e++) { sc[e] = scale ? scale[c0 + e] : 1.f; sh[e] = shift ? shift[c0 + e] : 0.f; }
+  // four vectors per iteration, all requests in flight before the first is used (ew_grid4 gives a thread at least four): on the 10-45 MB
+  // tensors of the encoder stages a thread had ONE vector next to 64 bytes of coefficient loads, on 2048 blocks
+  for (; i + 3 * stride < nvec; i += 4 * stride) {
+    float v[4][VE], r[HAS_RES ? 4 : 1][VE];
+#pragma unroll
+    for (int q = 0; q < 4; q++) { ldv(y + (i + q * stride) * VE, v[q]); if (HAS_RES) ldv(res + (i + q * stride) * VE, r[q]); }
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+#pragma unroll
+      for (int e = 0; e < VE; e++) {
+        const float u = v[q][e] * sc[e] + sh[e];
+        v[q][e] = act_fwd(HAS_RES ? u + r[HAS_RES ? q : 0][e] : u, actv, slope);
+      }
+      stv(out + (i + q * stride) * VE, v[q]);
+    }
+  }
   for (; i < nvec; i += stride) {
     float v[VE], r[VE];
     ldv(y + i * VE, v);
@@ -305,6 +321,26 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_vec_kernel(const T* __restri
   for (int e = 0; e < VE; e++) {
     mu[e] = mean[c0 + e]; rs[e] = rstd[c0 + e]; sc[e] = scale[c0 + e]; k1[e] = c1[c0 + e]; k2[e] = c2[c0 + e];
     sh[e] = RC ? shift[c0 + e] : 0.f;
+  }
+  for (; i + stride < nvec; i += 2 * stride) {      // two vectors per iteration (see affine_act_vec_kernel)
+    float g[2][VE], zz[2][VE], yy[2][VE], o[VE];
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+      ldv(dz + (i + q * stride) * VE, g[q]);
+      if (actv && !RC) ldv(z + (i + q * stride) * VE, zz[q]);
+      ldv(y + (i + q * stride) * VE, yy[q]);
+    }
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+#pragma unroll
+      for (int e = 0; e < VE; e++) {
+        if (actv) g[q][e] *= act_grad_from_out(RC ? yy[q][e] * sc[e] + sh[e] : zz[q][e], actv, slope);
+        float xh = (yy[q][e] - mu[e]) * rs[e];
+        o[e] = sc[e] * (g[q][e] - k1[e] - xh * k2[e]);
+      }
+      stv(dy + (i + q * stride) * VE, o);
+      if (dres) stv(dres + (i + q * stride) * VE, g[q]);
+    }
   }
   for (; i < nvec; i += stride) {
     float g[VE], zz[VE], yy[VE], o[VE];
@@ -655,6 +691,12 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
 
 // ---- launchers ---------------------------------------------------------------------------------------------
 static unsigned ew_grid(int64_t n) { return (unsigned)std::max<int64_t>(1, std::min<int64_t>(cdiv(n, 256), 2048)); }
+// grid of the apply kernels that take `per` vectors per thread and iteration (A/B hook RD_BN_VEC_PER: 1 = the one-vector grids)
+static unsigned ew_grid_per(int64_t n, int per) {
+  static const int force = getenv("RD_BN_VEC_PER") ? atoi(getenv("RD_BN_VEC_PER")) : 0;
+  if (force > 0) per = force;
+  return (unsigned)std::max<int64_t>(1, std::min<int64_t>(cdiv(n, 256 * (int64_t)per), 2048));
+}
 
 void launch_bn_finalize(const float* partial, int rows, int C, double count, const float* gamma, const float* beta,
                         float eps, float momentum, int training, float* running_mean, float* running_var, float* mean,
@@ -668,7 +710,7 @@ void launch_affine_act(const void* y, const float* scale, const float* shift, co
   int64_t total = pixels * C;
   if (vec_ok(C, dtype)) {
     const int64_t nvec = total / (dtype == 0 ? 4 : 8);
-    unsigned gv = ew_grid(nvec);
+    unsigned gv = ew_grid_per(nvec, 4);
     act_dispatch(act, [&](auto ac) {
       constexpr int A = decltype(ac)::value;
       if (dtype == 0) { if (res) hipLaunchKernelGGL((affine_act_vec_kernel<float, A, true>), dim3(gv), dim3(256), 0, st, (const float*)y, scale, shift, (const float*)res, (float*)out, nvec, C, act, slope);
@@ -774,7 +816,7 @@ void launch_bn_bwd_apply(const void* dz, const void* z, const void* y, const flo
   int64_t total = pixels * C;
   if (vec_ok(C, dtype)) {
     const int64_t nvec = total / (dtype == 0 ? 4 : 8);
-    unsigned gv = ew_grid(nvec);
+    unsigned gv = ew_grid_per(nvec, 2);
     act_dispatch(act, [&](auto ac) {
       constexpr int A = decltype(ac)::value; (void)A;
       if (dtype == 0) { if (shift) hipLaunchKernelGGL((bn_bwd_apply_vec_kernel<float, true, A>), dim3(gv), dim3(256), 0, st, (const float*)dz, (const float*)z, (const float*)y, mean, rstd, scale, c1, c2, shift, (float*)dy, (float*)dres, nvec, C, act, slope); else hipLaunchKernelGGL((bn_bwd_apply_vec_kernel<float, false, -1>), dim3(gv), dim3(256), 0, st, (const float*)dz, (const float*)z, (const float*)y, mean, rstd, scale, c1, c2, shift, (float*)dy, (float*)dres, nvec, C, act, slope); }
