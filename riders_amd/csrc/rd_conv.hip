@@ -1072,7 +1072,10 @@ static bool use_conv3x3_frag(const ConvArgs& a, int dtype) {   // wide layers: w
   // stage chain on the same shape -- deep encoder stages, 9 672 / 2 560 pixels x 128 channels: 21 -> 13 us and 15 -> 12 us per launch
   return conv3x3_frag_ok(a, dtype) && conv3x3_frag_blocks(a, dtype) >= std::min(conv3x3_min_blocks(), 8);
 }
+static bool conv_stem_ok(const ConvArgs& a, int dtype);
+static int conv_stem_blocks(const ConvArgs& a);
 int conv_stats_rows(const ConvArgs& a, int dtype) {
+  if (conv_stem_ok(a, dtype)) return conv_stem_blocks(a);
   if (conv_few_ok(a)) return conv_few_blocks(a);
   if (conv1x1_direct_ok(a, dtype)) return conv1x1_direct_rows(a);
   if (use_conv3x3_small(a, dtype)) return conv3x3_small_blocks(a, dtype);   // persistent blocks: one statistics row each
@@ -1147,8 +1150,101 @@ static void launch_linear_skinny(const ConvArgs& a, int dtype, hipStream_t st) {
   else hipLaunchKernelGGL((linear_skinny_kernel<bf16_t>), grid, dim3(512), 0, st, a);
 }
 
+// ---- image stems: ONE 16-byte channel vector per input pixel (3 channels zero-padded to 8 bf16 / 4 fp32 by the caller), <= 32 outputs ----------
+// RC-Net's 7x7 / stride-2 stem (utils/net_utils.py:29-91 via RCNet/networks.py ResNetEncoder) and the SML backbone's 3x3 / stride-2 stem on
+// 0.6 M output pixels.  On the implicit-GEMM kernel a block tile of 128 pixels x 32 channels walks K = 448 in seven LDS stages of 8 MFMAs
+// per wave behind a barrier each: 77 us for 78 MB.  Here a tap of a pixel IS one MFMA operand vector (8 channels = 16 bytes), so a lane
+// fetches its fragments straight from global memory -- lane (pixel fr, k-group fg) of k-step ks reads tap 4 ks + fg of its pixel -- with every
+// tap's request of a 16-pixel tile in flight together; the weight operand (Cout x ceil(taps / 4) k-steps) sits in LDS in fragment order for the
+// block's persistent loop.  No pixel staging, no barrier until the statistics epilogue.  Taps past KH * KW read a clamped address and meet the
+// packed operand's zero padding.
+template <typename T, int NCT, int NS>
+__global__ __launch_bounds__(256) void conv_stem_kernel(ConvArgs a, int ntile) {
+  constexpr int VE = Elem<T>::VE, SE = 4 * VE;
+  __shared__ uint4 sw[NCT * NS * 64];      // the weight operand in fragment order [channel tile][k step][lane]: one conflict-free 1-KiB read per use
+  __shared__ float red[4 * 16 * NCT * 2];
+  const int t = threadIdx.x, lane = t & 63, wv = RD_WAVE_UNIFORM(t >> 6), fr = lane & 15, fg = lane >> 4;
+  const int ntap = a.KH * a.KW;
+  for (int i = t; i < NCT * NS * 64; i += 256) {
+    const int l = i & 63, cs = i >> 6, c = cs / NS, ks = cs - c * NS;
+    sw[i] = *reinterpret_cast<const uint4*>((const T*)a.w + (int64_t)(c * 16 + (l & 15)) * a.Kpad + ks * SE + (l >> 4) * VE);
+  }
+  // this lane's taps: (kh, kw) of tap 4 ks + fg, -1 past the end
+  int tkh[NS], tkw[NS];
+#pragma unroll
+  for (int ks = 0; ks < NS; ks++) {
+    const int tap = ks * 4 + fg;
+    tkh[ks] = tap < ntap ? tap / a.KW : -1; tkw[ks] = tap < ntap ? tap - (tap / a.KW) * a.KW : 0;
+  }
+  float ssum[NCT][4], ssq[NCT][4];
+#pragma unroll
+  for (int c = 0; c < NCT; c++)
+#pragma unroll
+    for (int r = 0; r < 4; r++) { ssum[c][r] = 0.f; ssq[c][r] = 0.f; }
+  const T* const x = (const T*)a.src1;
+  __syncthreads();
+  // a wave takes 16-pixel tiles (one at a time: the 13 fragment requests of a 7x7 tile + accumulators stay under 128 registers, four waves
+  // per SIMD hide the gather's round trip; two tiles and the weights in registers were 312 registers, one wave per SIMD, and SLOWER than
+  // the implicit-GEMM kernel)
+  for (int p = (int)blockIdx.x * 4 + wv; p < ntile; p += (int)gridDim.x * 4) {
+    int64_t mm[2]; bool mvv[2];
+    mm[0] = (int64_t)p * 16 + fr; mvv[0] = mm[0] < a.M; mm[1] = 0; mvv[1] = false;
+    const int m = mvv[0] ? (int)mm[0] : 0;
+    const int ow = m % a.OW, q = m / a.OW, pn = q / a.OH;
+    const int ph = (q - pn * a.OH) * a.stride - a.pad, pw_ = ow * a.stride - a.pad;
+    uint4 xv[NS];
+#pragma unroll
+    for (int ks = 0; ks < NS; ks++) {
+      const int ih = ph + tkh[ks], iw = pw_ + tkw[ks];
+      const bool ok = mvv[0] && tkh[ks] >= 0 && (unsigned)ih < (unsigned)a.Hin && (unsigned)iw < (unsigned)a.Win;
+      const uint4 v = *reinterpret_cast<const uint4*>(x + (((int64_t)pn * a.Hin + min(max(ih, 0), a.Hin - 1)) * a.Win + min(max(iw, 0), a.Win - 1)) * VE);
+      xv[ks] = ok ? v : make_uint4(0, 0, 0, 0);      // unconditional load from a clamped address, zero selected afterwards
+    }
+    f32x4 acc[NCT][2];
+#pragma unroll
+    for (int c = 0; c < NCT; c++) { acc[c][0] = f32x4{0, 0, 0, 0}; acc[c][1] = f32x4{0, 0, 0, 0}; }
+#pragma unroll
+    for (int ks = 0; ks < NS; ks++)
+#pragma unroll
+      for (int c = 0; c < NCT; c++) {
+        const uint4 wfr = sw[(c * NS + ks) * 64 + lane];
+        if (sizeof(T) == 4) {
+          acc[c][0] = mfma_16x16x4_f32(__uint_as_float(wfr.x), __uint_as_float(xv[ks].x), acc[c][0]);
+          acc[c][0] = mfma_16x16x4_f32(__uint_as_float(wfr.y), __uint_as_float(xv[ks].y), acc[c][0]);
+          acc[c][0] = mfma_16x16x4_f32(__uint_as_float(wfr.z), __uint_as_float(xv[ks].z), acc[c][0]);
+          acc[c][0] = mfma_16x16x4_f32(__uint_as_float(wfr.w), __uint_as_float(xv[ks].w), acc[c][0]);
+        } else {
+          s16x8 wa, pb;
+          __builtin_memcpy(&wa, &wfr, 16);
+          __builtin_memcpy(&pb, &xv[ks], 16);
+          acc[c][0] = mfma_16x16x32_bf16(wa, pb, acc[c][0]);
+        }
+      }
+    conv_epilogue_store<T, NCT>(a, acc, mm, mvv, 0, 0, fr, fg, ssum, ssq);
+  }
+  conv_epilogue_stats<NCT, 16 * NCT, 4>(a, ssum, ssq, 0, 0, wv, fr, fg, t, blockIdx.x, red);
+}
+static int conv_stem_min_m() { const char* e = getenv("RD_CONV_STEM_MIN_M"); return e ? atoi(e) : 65536; }      // test hook: 0 routes small cases here
+static bool conv_stem_ok(const ConvArgs& a, int dtype) {
+  const int ve = dtype == 0 ? 4 : 8, taps = a.KH * a.KW;
+  return a.C1 == ve && a.C2 == 0 && !a.ups && a.dil == 1 && !a.pool2 && !a.in_scale && !a.bn_y && a.KH == a.KW && (taps == 9 || taps == 49) &&
+         (a.Cout == 16 || a.Cout == 32) && a.K == taps * ve && a.Kpad >= ((taps + 3) / 4) * 4 * ve && a.M >= conv_stem_min_m() &&
+         (int64_t)a.N * a.Hin * a.Win < ((int64_t)1 << 27);
+}
+static int conv_stem_blocks(const ConvArgs& a) { return (int)std::min<int64_t>(cdiv(a.M, 16 * 4), 2048); }      // persistent blocks = statistics rows
+static void launch_conv_stem(const ConvArgs& a, int dtype, hipStream_t st) {
+  const int ntile = (int)cdiv(a.M, 16), taps = a.KH * a.KW;
+  const dim3 grid((unsigned)conv_stem_blocks(a));
+#define RD_STEM(TT, NCTV, NSV) hipLaunchKernelGGL((conv_stem_kernel<TT, NCTV, NSV>), grid, dim3(256), 0, st, a, ntile)
+#define RD_STEM_T(TT) { if (a.Cout == 32) { if (taps == 49) RD_STEM(TT, 2, 13); else RD_STEM(TT, 2, 3); } else { if (taps == 49) RD_STEM(TT, 1, 13); else RD_STEM(TT, 1, 3); } }
+  if (dtype == 0) RD_STEM_T(float) else RD_STEM_T(bf16_t)
+#undef RD_STEM_T
+#undef RD_STEM
+}
+
 void launch_conv(const ConvArgs& a, int dtype, hipStream_t st) {
   if (conv_skinny_ok(a, dtype)) { launch_linear_skinny(a, dtype, st); return; }
+  if (conv_stem_ok(a, dtype)) { launch_conv_stem(a, dtype, st); return; }
   if (conv_few_ok(a)) { launch_conv_few(a, dtype, st); return; }
   if (conv1x1_direct_ok(a, dtype)) { launch_conv1x1_direct(a, dtype, st); return; }
   if (conv3x3_c1_ok(a)) { launch_conv3x3_c1(a, dtype, st); return; }
@@ -1190,6 +1286,7 @@ bool wgrad_in_affine_ok(const WgradArgs& a, int dtype) { return !wgrad_tiny_shap
 // name of the kernel launch_conv picks for this shape (bench.py groups its per-launch timings by the names rocprofv3 reports)
 const char* conv_kernel_name(const ConvArgs& a, int dtype) {
   if (conv_skinny_ok(a, dtype)) return dtype == 0 ? "linear_skinny_kernel<float>" : "linear_skinny_kernel<" RD_T16_NAME ">";
+  if (conv_stem_ok(a, dtype)) return "conv_stem_kernel";
   if (conv_few_ok(a)) return "conv_few_kernel";
   if (conv1x1_direct_ok(a, dtype)) return "conv1x1_direct_kernel";
   if (conv3x3_c1_ok(a)) return "conv3x3_c1_kernel";

@@ -908,9 +908,10 @@ def conv_block(x, weight, *, x2=None, bias=None, stride=1, pad=None, up=None, bn
     # the vector / MFMA-bf16 kernels instead of the scalar-gather fallbacks (7x7 stem: 0.31 + 0.52 ms per RC-Net step)
     ve = 16 // x.element_size()
     cin_pad = 0
-    if x2 is None and not is_up and C1 % ve != 0 and KH * KW >= 9 and not (t is not None and t.requires(xk)) and not lib.rd_conv_fwd_streams(
+    if x2 is None and not is_up and C1 % ve != 0 and KH * KW >= 9 and not lib.rd_conv_fwd_streams(
             ctypes.byref(_desc(dt, N, Hin, Win, C1, 0, False, H1, W1, Cout, KH, KW, stride, pad, 1, OH, OW, conv_act, slope, Cout))):
-        # (layers the streaming few-channel kernels take -- SML's 3 -> 3 `first` convolution -- are handed over as they are)
+        # (layers the streaming few-channel kernels take -- SML's 3 -> 3 `first` convolution -- are handed over as they are; an input that
+        # needs a gradient -- the SML backbone's stem behind `first` -- gets it from the un-padded descriptor below)
         cin_pad = (C1 + ve - 1) // ve * ve
         xp = torch.empty((N, H1, W1, cin_pad), dtype=x.dtype, device=x.device)
         _chk(lib.rd_pad_channels(_p(x), _p(xp), N * H1 * W1, C1, cin_pad, dt, st), "rd_pad_channels")
@@ -1085,7 +1086,8 @@ def conv_block(x, weight, *, x2=None, bias=None, stride=1, pad=None, up=None, bn
                             "wgrad " + shp, b_in + b_out + weight.numel() * 4), "rd_conv_wgrad")
         if need_in:
             wpd = packed_weight(weight, 1, dt)
-            dd = _desc(dt, N, OH, OW, Cout, 0, False, OH, OW, Cin, KH, KW, 1, KH - 1 - pad, stride, Hin, Win, ACT_NONE, 0.0, C1)
+            Cin_d, C1_d = (C1_real, C1_real) if cin_pad else (Cin, C1)      # the data gradient has the tensor's own channels, not the padded ones
+            dd = _desc(dt, N, OH, OW, Cout, 0, False, OH, OW, Cin_d, KH, KW, 1, KH - 1 - pad, stride, Hin, Win, ACT_NONE, 0.0, C1_d)
             # exact 2x nearest up-sampling (UpConv2d at 120x50 -> 240x100 ...): the kernel sums the 2x2 blocks of its output tile and stores the
             # gradient at SOURCE resolution; the full-resolution tensor and the upsample_nearest_bwd pass over it disappear
             fused_up = False
@@ -1100,7 +1102,7 @@ def conv_block(x, weight, *, x2=None, bias=None, stride=1, pad=None, up=None, bn
                             kernel=lambda: lib.rd_conv_fwd_kernel_name(ctypes.byref(dd)).decode(), idem=True), "rd_conv_fwd(dgrad, out_reduce2)")
                 t.add_grad(xk, g1)
                 return
-            dxv1 = torch.empty((N, Hin, Win, C1), dtype=x.dtype, device=x.device)
+            dxv1 = torch.empty((N, Hin, Win, C1_d), dtype=x.dtype, device=x.device)
             dxv2 = torch.empty((N, Hin, Win, C2), dtype=x.dtype, device=x.device) if C2 else None
             # x already holds a gradient contribution (a skip connection's decoder side, a residual shortcut): the kernel adds it in its
             # epilogue and the sum replaces it -- no second tensor, no separate add pass

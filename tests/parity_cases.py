@@ -110,6 +110,33 @@ CONV_CASES = [
 ]
 
 
+class force_stem_kernel:
+    """Route every eligible padded-stem layer to conv_stem_kernel (rd_conv.hip) regardless of its pixel count."""
+    def __enter__(self):
+        self.old = os.environ.get("RD_CONV_STEM_MIN_M")
+        os.environ["RD_CONV_STEM_MIN_M"] = "0"
+
+    def __exit__(self, *a):
+        if self.old is None:
+            del os.environ["RD_CONV_STEM_MIN_M"]
+        else:
+            os.environ["RD_CONV_STEM_MIN_M"] = self.old
+
+
+def stem_kernel_cases(dev):
+    """conv_stem_kernel (fragments straight from global memory, weights in registers): the 7x7 / stride-2 and 3x3 / stride-2 stems with a ragged
+    last tile pair, BatchNorm statistics from its epilogue, 32 and 16 outputs, activation without BatchNorm; fp32 against the oracle, bf16
+    against the oracle with the product's rounding points."""
+    with force_stem_kernel():
+        conv_case(dev, dict(cin=3, cout=32, k=7, s=2, H=20, W=18, N=2, bn=True, no_input_grad=True))
+        conv_case(dev, dict(cin=3, cout=32, k=3, s=2, H=15, W=14, N=3, bn=True, no_input_grad=True))
+        conv_case(dev, dict(cin=3, cout=16, k=3, s=1, H=9, W=11, N=2, bn=False, no_input_grad=True))
+        conv_case(dev, dict(cin=3, cout=16, k=7, s=2, H=13, W=9, N=1, bn=True, no_input_grad=True))
+        with bf16_mode():      # the oracle rounds where the product rounds (oracle/precision.py): max-norm 1e-2 = 2.5 bf16 ulp
+            conv_case(dev, dict(cin=3, cout=32, k=7, s=2, H=20, W=18, N=2, bn=True, no_input_grad=True), tol=1e-2)
+            conv_case(dev, dict(cin=3, cout=32, k=3, s=2, H=15, W=14, N=3, bn=True, no_input_grad=True), tol=1e-2)
+
+
 class force_direct_1x1:
     """Route every eligible 1x1 layer to the direct pointwise kernel regardless of its pixel count."""
     def __enter__(self):

@@ -168,6 +168,7 @@ def test_stem_padded_channels(emu):
     P.conv_case(emu, dict(cin=3, cout=32, k=7, s=2, H=20, W=18, N=2, bn=True, no_input_grad=True))
     P.conv_case(emu, dict(cin=3, cout=32, k=3, s=2, H=15, W=14, N=1, bn=True, no_input_grad=True))
     P.conv_case(emu, dict(cin=5, cout=16, k=3, s=1, H=9, W=11, N=2, bn=False, act=None, no_input_grad=True))
+    P.stem_kernel_cases(emu)
 
 
 def test_batch_transforms(emu):

@@ -490,3 +490,11 @@ def test_config4_per_rank_batch(gpu):
 
 def test_point_mlp(gpu):
     P.point_mlp_case(gpu)
+
+
+@pytest.mark.gpu
+def test_stem_kernel(gpu):
+    """conv_stem_kernel on small cases (RD_CONV_STEM_MIN_M=0) and at RC-Net's stem size through the default routing."""
+    P.stem_kernel_cases(gpu)
+    P.conv_case(gpu, dict(cin=3, cout=32, k=7, s=2, H=372, W=816, N=1, bn=True, no_input_grad=True))
+
