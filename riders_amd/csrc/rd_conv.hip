@@ -1100,7 +1100,6 @@ __global__ __launch_bounds__(512) void linear_skinny_kernel(ConvArgs a) {
   const T* ap = (const T*)a.src1 + (int64_t)min(m0 + fr, a.M - 1) * K + fg * VE;
   const T* wp = (const T*)a.w + (int64_t)(n0 + fr) * a.Kpad + fg * VE;
   f32x4 acc = {0, 0, 0, 0};
-#pragma unroll 4
   for (int s = wv; s < nsteps; s += NWV) {
     const uint4 av = *reinterpret_cast<const uint4*>(ap + s * STEP);
     const uint4 wf = *reinterpret_cast<const uint4*>(wp + s * STEP);

@@ -14,7 +14,7 @@ b.build(verbose=False)
 os.makedirs(os.path.join(ROOT, "tools", "ab"), exist_ok=True)
 objs = []
 for src, obj, extra in b.units():
-    if os.path.basename(src) == unit:
+    if os.path.basename(src) in unit.split(","):      # several translation units: comma separated
         o2 = os.path.join("/tmp", os.path.basename(obj) + "." + name + ".o")
         subprocess.run([b.HIPCC, "-x", "hip"] + b.FLAGS + extra + defs + ["-c", src, "-o", o2], check=True)
         objs.append(o2)
