@@ -110,6 +110,27 @@ CONV_CASES = [
 ]
 
 
+def stride2_dgrad_cases(dev):
+    """Data gradient of stride-2 layers ordered by pixel-parity class (conv_gemm_kernel PAR, rd_conv.hip): bf16 on integer data, bit for bit
+    against autograd -- 3x3 with one and two channel stages per tap (the two-stage form takes the deep-prefetch instantiation on few
+    pixels), odd and even map sizes (classes of different pixel counts, an empty class on a one-column map), the 1x1 projection (three of
+    its four classes have no tap and store zeros), and fp32 through the oracle comparison of conv_case."""
+    bf16_exact_conv_case(dev, cin=32, cout=64, k=3, s=2, H=10, W=13, N=2)
+    bf16_exact_conv_case(dev, cin=64, cout=128, k=3, s=2, H=13, W=10, N=2)
+    bf16_exact_conv_case(dev, cin=64, cout=128, k=3, s=2, H=9, W=1, N=1)
+    bf16_exact_conv_case(dev, cin=64, cout=128, k=1, s=2, H=9, W=8, N=2)
+    bf16_exact_conv_case(dev, cin=128, cout=128, k=1, s=2, H=7, W=5, N=1)
+    conv_case(dev, dict(cin=32, cout=64, k=3, s=2, H=11, W=8, N=2, bn=True))
+    conv_case(dev, dict(cin=64, cout=64, k=1, s=2, H=6, W=9, N=2, bn=False, act=None))
+
+
+def skinny_linear_cases(dev):
+    """linear_skinny_kernel (rd_conv.hip: few output tiles, K >= 1024 split over a block's eight waves): bf16 / fp16-build-independent integer
+    data bit for bit, ragged row and channel counts; the fp32 path is point_mlp_case's last layer."""
+    bf16_exact_conv_case(dev, cin=1024, cout=32, k=1, s=1, H=4, W=5, N=2)
+    bf16_exact_conv_case(dev, cin=1056, cout=24, k=1, s=1, H=3, W=7, N=1)
+
+
 class force_stem_kernel:
     """Route every eligible padded-stem layer to conv_stem_kernel (rd_conv.hip) regardless of its pixel count."""
     def __enter__(self):

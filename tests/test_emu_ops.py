@@ -236,3 +236,12 @@ def test_streaming_weight_gradient_of_few_channel_layers(emu):
 
 def test_point_mlp(emu):
     P.point_mlp_case(emu, R=6)
+
+
+def test_stride2_dgrad_parity_classes(emu):
+    P.stride2_dgrad_cases(emu)
+
+
+def test_skinny_linear(emu):
+    P.skinny_linear_cases(emu)
+

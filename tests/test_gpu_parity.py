@@ -498,3 +498,14 @@ def test_stem_kernel(gpu):
     P.stem_kernel_cases(gpu)
     P.conv_case(gpu, dict(cin=3, cout=32, k=7, s=2, H=372, W=816, N=1, bn=True, no_input_grad=True))
 
+
+@pytest.mark.gpu
+def test_stride2_dgrad_parity_classes(gpu):
+    P.stride2_dgrad_cases(gpu)
+    P.bf16_exact_conv_case(gpu, cin=64, cout=128, k=3, s=2, H=93, W=204, N=1)      # RC-Net's 64 -> 128 stage at one image
+
+
+@pytest.mark.gpu
+def test_skinny_linear(gpu):
+    P.skinny_linear_cases(gpu)
+
