@@ -117,6 +117,9 @@ typedef struct rd_loftr_grads {
   float *lnp1, *lnp2, *dg1, *db1, *dg2, *db2;
   int32_t accumulate;
   int32_t defer_ln;            /* 1: leave the LayerNorm partials lnp1 / lnp2 ([N][128][2] = (dbeta, dgamma) terms per ROI) for rd_ln_grad_batch */
+  int32_t dsrc_accumulate;     /* 1 (cross attention only): dsrc holds an earlier gradient contribution of `src`; the kernel stores dsrc + its own,
+                                  rounded once (the transformer's second cross call feeds the first one's output: linear_attention.py:174-176) */
+  int32_t reserved;
 } rd_loftr_grads;
 /* LayerNorm parameter gradients of many layer applications in ONE launch: an item is one (gamma, beta) pair with the partial buffers
  * [rows][C][2] of up to four applications (the transformer applies each layer to both token streams: RCNet/linear_attention.py:159-184),

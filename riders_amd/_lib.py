@@ -88,7 +88,7 @@ class LoftrSaved(ctypes.Structure):
 
 class LoftrGrads(ctypes.Structure):
     _fields_ = _ptr_struct(["dout", "dm2pre", "dhid", "dmpre", "datt", "dq", "dk", "dv", "dx", "dsrc", "lnp1", "lnp2", "dg1", "db1",
-                            "dg2", "db2"]) + [("accumulate", ctypes.c_int32), ("defer_ln", ctypes.c_int32)]
+                            "dg2", "db2"]) + [("accumulate", ctypes.c_int32), ("defer_ln", ctypes.c_int32), ("dsrc_accumulate", ctypes.c_int32), ("reserved", ctypes.c_int32)]
 
 
 class LnGradItem(ctypes.Structure):

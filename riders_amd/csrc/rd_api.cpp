@@ -145,6 +145,7 @@ int rd_loftr_layer_bwd(const void* x, const void* src, const rd_loftr_weights* w
   if (N < 0 || L <= 0 || S <= 0 || L > 32 || S > 32) return fail("loftr_layer_bwd: needs 1..32 tokens per sequence (L=%d S=%d)", L, S);
   if (!g->dout || !g->dm2pre || !g->dhid || !g->dmpre || !g->datt || !g->dq || !g->dk || !g->dv || !g->dx || (src != x && !g->dsrc))
     return fail("loftr_layer_bwd: null gradient buffer");
+  if (g->dsrc_accumulate && src == x) return fail("loftr_layer_bwd: dsrc_accumulate is for cross attention (src != x)");
   if (!g->lnp1 || !g->lnp2 || !g->dg1 || !g->db1 || !g->dg2 || !g->db2) return fail("loftr_layer_bwd: null LayerNorm gradient buffer");
   RD_NS(dtype, launch_loftr_layer_bwd)(x, src, *reinterpret_cast<const rd::LoftrW*>(w), *reinterpret_cast<const rd::LoftrSaved*>(sv),
                              *reinterpret_cast<const rd::LoftrGrads*>(g), N, L, S, eps_attn, RD_DT(dtype), (hipStream_t)stream);

@@ -505,6 +505,12 @@ __global__ __launch_bounds__(LNT) void loftr_layer_bwd_kernel(const T* __restric
     for (int idx = threadIdx.x; idx < S * (LC / 4); idx += LNT) {
       const int r = idx / (LC / 4), c4 = (idx - r * (LC / 4)) * 4;
       float v[4] = {sm.u.fh.f[r * LF + c4], sm.u.fh.f[r * LF + c4 + 1], sm.u.fh.f[r * LF + c4 + 2], sm.u.fh.f[r * LF + c4 + 3]};
+      if (gr.dsrc_accumulate) {      // the source's earlier gradient contribution rides along: sum rounded once, no separate add pass
+        float o[4];
+        ld4((const T*)gr.dsrc + so + (int64_t)r * LC + c4, o);
+#pragma unroll
+        for (int e = 0; e < 4; e++) v[e] += o[e];
+      }
       st4((T*)gr.dsrc + so + (int64_t)r * LC + c4, v);
     }
   LPROF(19)

@@ -59,6 +59,7 @@ struct LoftrSaved { void *q, *k, *v, *att, *mpre, *msg, *hid, *m2pre; float* sta
 struct LoftrGrads {
   const void* dout; void *dm2pre, *dhid, *dmpre, *datt, *dq, *dk, *dv, *dx, *dsrc;
   float *lnp1, *lnp2, *dg1, *db1, *dg2, *db2; int accumulate, defer_ln;      // defer_ln = 1: leave the LayerNorm partials, no finalize launches
+  int dsrc_accumulate, reserved;                                                    // dsrc_accumulate = 1: dsrc += (cross attention)
 };
 
 }  // namespace rdt

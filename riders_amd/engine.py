@@ -24,6 +24,7 @@ _RD_DT = {torch.float32: RD_F32, torch.bfloat16: RD_BF16, torch.float16: RD_F16}
 
 _state = {"dtype": RD_F32, "tape": None, "defer_wgrad": True, "fused_loftr": True, "deterministic_roi_pool": False, "roi_tile_min_blocks": 256,
           "fuse_upsample_bwd": os.environ.get("RIDERS_FUSE_UPSAMPLE_BWD", "1") != "0",     # A/B switch of the 2x2-summing data gradient
+          "loftr_cross_inplace": os.environ.get("RIDERS_LOFTR_CROSS_INPLACE", "1") != "0",      # A/B switch of engine.CrossGrad
           "fuse_res_add": os.environ.get("RIDERS_FUSE_RES_ADD", "1") != "0",       # A/B switch: residual of a conv without BatchNorm / activation added in its epilogue
           "fuse_grad_add": os.environ.get("RIDERS_FUSE_GRAD_ADD", "1") != "0",     # A/B switch: second gradient contribution added in the data-gradient epilogue
           # Round 4: conv -> BatchNorm -> activation outputs stay virtual (LazyAct) and the consumer applies scale / shift / activation while
@@ -1375,6 +1376,11 @@ def rows_split(x, ra):
             ga, gb = t.pop_grad(a), t.pop_grad(b)
             if ga is None and gb is None:
                 return
+            base = getattr(ga, "_base", None) if ga is not None else None
+            if base is not None and gb is not None and getattr(gb, "_base", None) is base and base.shape == x.shape and base.dtype == x.dtype \
+                    and base.is_contiguous() and ga.data_ptr() == base.data_ptr() and gb.data_ptr() == base.data_ptr() + ga.numel() * ga.element_size():
+                t.add_grad(x, base)     # the two gradients ARE the halves of one matrix (CrossGrad): no copy
+                return
             g = torch.empty_like(x)
             for src, dst in ((ga, g[:ra]), (gb, g[ra:])):
                 if src is None:
@@ -1403,7 +1409,17 @@ def rows_join(a, b, whole):
     return whole
 
 
-def loftr_layer(x, source, layer, N, L, S, out=None):
+class CrossGrad(object):
+    """Shared by the two cross-attention calls of one transformer layer (a2 = layer(a, b); b2 = layer(b, a2)) so that their backward
+    launches write the gradient of the layer's input matrix [a; b] in place: call 2 stores d b into the lower half and ADDS its source
+    gradient to a2's pending gradient (rd_loftr_grads.dsrc_accumulate); call 1 stores d a into the upper half and adds its source gradient
+    to the lower one.  Without it every cross layer costs two gradient-add passes and two row copies (16 launches per RC-Net step)."""
+
+    def __init__(self):
+        self.G = None
+
+
+def loftr_layer(x, source, layer, N, L, S, out=None, cross=None, cross_role=0):
     """Fused LoFTREncoderLayer (rd_loftr_layer_fwd / _bwd): x (N*L, 128), source (N*S, 128) token matrices -> (N*L, 128)
     (written into `out` when given: a row range of a larger token matrix).
     `layer` is the nn.Module holding q_proj / k_proj / v_proj / merge / mlp / norm1 / norm2 (reference linear_attention.py:84-135).
@@ -1453,6 +1469,17 @@ def loftr_layer(x, source, layer, N, L, S, out=None):
         dk, dv = torch.empty((MS, C), dtype=T, device=dev), torch.empty((MS, C), dtype=T, device=dev)
         dhid = torch.empty((ML, 2 * C), dtype=T, device=dev)
         dsrc = None if same else torch.empty((MS, C), dtype=T, device=dev)
+        # cross-attention pair writing the gradient of [a; b] in place (CrossGrad): role 2 = the second forward call (x = b, source = a2),
+        # whose backward runs first; role 1 = the first call (x = a, source = b)
+        in_place = 0
+        if cross is not None and not same and ML == MS and _state.get("loftr_cross_inplace", True):
+            if cross_role == 2:
+                pend = t.grads.get(id(source))
+                if pend is not None and pend.shape == (MS, C) and pend.dtype == T and pend.is_contiguous():
+                    cross.G = torch.empty((ML + MS, C), dtype=T, device=dev)
+                    dx, dsrc, in_place = cross.G[ML:], pend, 2
+            elif cross_role == 1 and cross.G is not None:
+                dx, dsrc, in_place = cross.G[:ML], cross.G[ML:], 1
         lnp = torch.empty((2, N, C, 2), dtype=torch.float32, device=dev)
         (dg1, a1), (db1, a2), (dg2, a3), (db2, a4) = [t.param_grad(p) for p in lns]
         assert a1 == a2 == a3 == a4
@@ -1462,6 +1489,7 @@ def loftr_layer(x, source, layer, N, L, S, out=None):
         gr.lnp1, gr.lnp2 = lnp[0].data_ptr(), lnp[1].data_ptr()
         gr.dg1, gr.db1, gr.dg2, gr.db2, gr.accumulate = dg1.data_ptr(), db1.data_ptr(), dg2.data_ptr(), db2.data_ptr(), a1
         gr.defer_ln = 1 if _state["defer_wgrad"] else 0      # the LayerNorm partials of every application of a stage are summed by ONE launch
+        gr.dsrc_accumulate = 1 if in_place else 0
         wb, keepb = wstruct(1)
         _chk(_timed("loftr_layer", 2.0 * flops, lambda: lib.rd_loftr_layer_bwd(_p(x), _p(source), ctypes.byref(wb), ctypes.byref(sv), ctypes.byref(gr),
                                                                                  N, L, S, eps_a, dt, st), "bwd N=%d L=%d" % (N, L)), "rd_loftr_layer_bwd")
@@ -1475,9 +1503,13 @@ def loftr_layer(x, source, layer, N, L, S, out=None):
                 c2 = 0 if x2 is None else x2.shape[1]
                 t.deferred.append(dict(x=x1, x2=x2, dy=dy, weight=w_, M=M, C1=c1, C2=c2, Cin=c1 + c2, Cout=dy.shape[1],
                                        flops=2.0 * M * (c1 + c2) * dy.shape[1]))
+        if in_place == 2:
+            return                      # d b waits in cross.G for call 1; a2's pending gradient was updated in place
         t.add_grad(x, dx)
         if not same:
-            t.add_grad(source, dsrc)
+            t.add_grad(source, dsrc)    # (in_place == 1: the two halves of cross.G, which rows_split's backward recognises as one matrix)
+        if in_place == 1:
+            cross.G = None
     t.record(backward)
     return out
 

@@ -136,8 +136,9 @@ class LocalFeatureTransformer(nn.Module):
             elif name == 'cross':
                 a, b = engine.rows_split(F, R)
                 G = torch.empty_like(F)
-                a2 = engine.loftr_layer(a, b, layer, N, L, L, out=G[:R])
-                b2 = engine.loftr_layer(b, a2, layer, N, L, L, out=G[R:])
+                cg = engine.CrossGrad()       # the pair's backward writes d [a; b] in place (no gradient-add passes, no row copies)
+                a2 = engine.loftr_layer(a, b, layer, N, L, L, out=G[:R], cross=cg, cross_role=1)
+                b2 = engine.loftr_layer(b, a2, layer, N, L, L, out=G[R:], cross=cg, cross_role=2)
                 F = engine.rows_join(a2, b2, G)
             else:
                 raise KeyError
