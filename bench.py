@@ -569,7 +569,14 @@ def main():
         print(json.dumps(out), flush=True)
     if ddp:
         import torch.distributed as dist
-        dist.destroy_process_group()
+        # the line is out; quiesce before the group goes away and never let a teardown problem turn into the run's exit code
+        try:
+            torch.cuda.synchronize()
+            dist.barrier()
+            torch.cuda.synchronize()
+            dist.destroy_process_group()
+        except Exception as ex:
+            sys.stderr.write("bench.py: process-group teardown: %r\n" % (ex,))
 
 
 if __name__ == "__main__":
