@@ -814,6 +814,31 @@ __global__ __launch_bounds__(256) void conv_few_kernel(ConvArgs a) {
   for (int i = t; i < a.Cout * 2; i += 256)
     a.stats[(int64_t)blockIdx.x * a.Cout * 2 + i] = (red[0][i] + red[1][i]) + (red[2][i] + red[3][i]);
 }
+// ---- 1 -> Cout pointwise expansion (the data gradient of a Cout = 1 head over a 1x1 kernel: SML's 32 -> 1 output convolution on 2.65 M pixels):
+// Cout / VE threads per pixel, each with its VE weights in registers and ONE 16-byte store, so that a wave's store instruction covers 1 KiB
+// of consecutive addresses.  (In conv_few_kernel a thread owned a pixel and wrote its 64 bytes as eight 8-byte stores, 64 bytes apart from
+// its neighbour's: 106 us for 170 MB.)  Same product and sum per element: results are those of conv_few_kernel bit for bit.
+template <typename T>
+__global__ __launch_bounds__(256) void pointwise_expand_kernel(ConvArgs a) {
+  constexpr int VE = Elem<T>::VE;
+  const int G = a.Cout / VE;
+  const int64_t total = (int64_t)a.M * G, stride = (int64_t)gridDim.x * 256;
+  int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int co0 = (int)(g % G) * VE;      // loop invariant: the grid stride is a multiple of G (256 % G == 0)
+  float w[VE], bv[VE];
+#pragma unroll
+  for (int e = 0; e < VE; e++) { w[e] = Elem<T>::ld((const T*)a.w + (int64_t)(co0 + e) * a.Kpad); bv[e] = a.bias ? a.bias[co0 + e] : 0.f; }
+  const T* x = (const T*)a.src1;
+  for (; g < total; g += stride) {
+    const int64_t m = g / G;
+    const float xv = Elem<T>::ld(x + m);
+    float v[VE];
+#pragma unroll
+    for (int e = 0; e < VE; e++) v[e] = act_fwd(fmaf(w[e], xv, 0.f) + bv[e], a.act, a.slope);
+    stv((T*)a.dst1 + m * a.Cout + co0, v);
+  }
+}
+
 static int conv_few_min_m() { const char* e = getenv("RD_CONV_FEW_MIN_M"); return e ? atoi(e) : (1 << 16); }   // test hook: 0 forces the kernel
 bool conv_few_ok(const ConvArgs& a) {
   if (a.KH != a.KW || a.stride != 1 || a.ups || a.C2 || a.D1 != a.Cout || a.M < conv_few_min_m()) return false;
@@ -824,6 +849,13 @@ bool conv_few_ok(const ConvArgs& a) {
 }
 int conv_few_blocks(const ConvArgs& a) { return (int)std::min<int64_t>(cdiv(a.M, 256 * 4), 2048); }
 void launch_conv_few(const ConvArgs& a, int dtype, hipStream_t st) {
+  if (a.KH == 1 && a.C1 == 1 && a.dil == 1 && !a.stats && !a.add1 && a.Cout % (dtype == 0 ? 4 : 8) == 0 && 256 % (a.Cout / (dtype == 0 ? 4 : 8)) == 0) {
+    const int G = a.Cout / (dtype == 0 ? 4 : 8);
+    const dim3 ge((unsigned)std::min<int64_t>(cdiv((int64_t)a.M * G, 256 * 4), 4096));
+    if (dtype == 0) hipLaunchKernelGGL((pointwise_expand_kernel<float>), ge, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL((pointwise_expand_kernel<bf16_t>), ge, dim3(256), 0, st, a);
+    return;
+  }
   const dim3 grid((unsigned)conv_few_blocks(a));
 #define RD_FEW(TT) { if (a.dil == 2) hipLaunchKernelGGL((conv_few_kernel<TT, 3, 32, 4, 2>), grid, dim3(256), 0, st, a);        \
                      else if (a.KH == 3) hipLaunchKernelGGL((conv_few_kernel<TT, 3, 3, 4, 1>), grid, dim3(256), 0, st, a);       \
