@@ -641,8 +641,16 @@ __global__ __launch_bounds__(256) void dw_wgrad_finalize_batch_kernel(DwWgradBat
   for (int base = blockIdx.x * 64; base < CK; base += gridDim.x * 64) {      // (uniform per block)
     const int i = base + e;
     double a = 0.0;
-    if (i < CK)
-      for (int r = rg; r < it.rows; r += 4) a += it.partial[(int64_t)r * CK + i];
+    if (i < CK) {
+      // eight rows in flight per iteration, added in row order (see colsum_finalize_batch_kernel): 58 us for 17 items before
+      for (int r = rg; r < it.rows; r += 32) {
+        float v[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) { const int rq = r + 4 * q; const float x = it.partial[(int64_t)(rq < it.rows ? rq : 0) * CK + i]; v[q] = rq < it.rows ? x : 0.f; }
+#pragma unroll
+        for (int q = 0; q < 8; q++) a += v[q];
+      }
+    }
     red[rg][e] = a;
     __syncthreads();
     if (rg == 0 && i < CK) {
