@@ -566,6 +566,11 @@ def main():
             except Exception as ex:      # never lose the bench line to the auxiliary figure
                 out["val_abs_rel"] = dict(error=repr(ex)[:300])
             out["cpu_baseline"] = cpu_baseline()
+        try:      # C-level stdout first (RCCL prints its version banner through stdio: buffered, it would land BEHIND the line at exit)
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
         print(json.dumps(out), flush=True)
     if ddp:
         import torch.distributed as dist
