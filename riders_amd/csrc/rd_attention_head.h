@@ -42,7 +42,10 @@ __device__ __forceinline__ void stage_head(const T* __restrict__ src, int64_t ro
 // dimensions ldq/ldk/ldv/ldo (global memory).  Phases are ordered by wave_sync() (no block barrier on the GPU; a block barrier under
 // the host emulator): every wave of the block must call it the same number of times, and the caller owns any block-level ordering.
 // after_loads() runs right after the staging loads are issued (a caller's prefetch for its next phase goes behind them).
-template <typename T, bool BWD, typename Hook>
+// PRE (forward only): the caller has already written the feature-mapped q, k and the scaled v of this head into s.q / s.k / s.v (rows beyond
+// L / S zero) and ordered them with a wave_sync(): no staging loads (rd_loftr.hip: the wave that owns head h is the wave whose projection
+// GEMM tile IS head h, so its accumulators go straight into its scratch).
+template <typename T, bool BWD, typename Hook, bool PRE = false>
 __device__ __forceinline__ void attn_head(AttnSmem& s, const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v,
                                           const T* __restrict__ dout, T* __restrict__ out, T* __restrict__ dq, T* __restrict__ dk,
                                           T* __restrict__ dv, int n, int h, bool active, int L, int S, int ldq, int ldk, int ldv,
@@ -54,6 +57,8 @@ __device__ __forceinline__ void attn_head(AttnSmem& s, const T* __restrict__ q, 
   const int Lp = (L + 3) & ~3, Sp = (S + 3) & ~3;
   const int lt = (L + 15) >> 4, stl = (S + 15) >> 4;  // 16-row tiles
 
+  if (PRE) { after_loads(); }
+  else {
   wave_sync();  // a previous call's reads of this wave's scratch are complete before it is restaged (back-to-back calls)
   constexpr int VE = Elem<T>::VE;
   const bool vec = L > 0 && S > 0 && (ldq % VE == 0) && (ldk % VE == 0) && (ldv % VE == 0) && (!BWD || ldo % VE == 0) &&
@@ -102,6 +107,7 @@ __device__ __forceinline__ void attn_head(AttnSmem& s, const T* __restrict__ q, 
     after_loads();
   }
   wave_sync();
+  }
 
   // KV = K^T V  (16 x 16), Ksum
   {

@@ -198,6 +198,35 @@ __global__ __launch_bounds__(LNT) void loftr_layer_fwd_kernel(const T* __restric
       }
     };
   };
+#ifndef RD_LOFTR_ATT_GLOBAL
+  // The wave that owns head h (one head per wave) is the wave whose projection tile is channels 16 h .. 16 h + 15: its q / k / v accumulators
+  // go to global memory for the backward AND, rounded the same way and feature-mapped, straight into its own attention scratch -- no store ->
+  // barrier -> L2 load round trip in front of the attention phase (RD_LOFTR_ATT_GLOBAL: the round trip, for A/B).
+  AttnSmem& as = sm.u.at[wv];
+  wave_sync();      // (a previous phase's reads of this scratch)
+  auto to_both = [&](T* base, int64_t off, int rows, float* lds, int mode, float scale) RD_INLINE_LAMBDA {
+    return [=](int ct, f32x4 (&acc)[2]) RD_INLINE_LAMBDA {
+#pragma unroll
+      for (int tt = 0; tt < 2; tt++) {
+        const int tok = tt * 16 + fr;
+        float v[4] = {acc[tt][0], acc[tt][1], acc[tt][2], acc[tt][3]};
+        if (tok < rows) st4(base + off + (int64_t)tok * LC + ct * 16 + fg * 4, v);
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const float x = Elem<T>::rnd(v[r]);      // what the stored tensor holds (and what the backward recomputes from)
+          lds[tok * LD + fg * 4 + r] = tok < rows ? (mode ? (x > 0.f ? x + 1.f : __expf(x)) : x * scale) : 0.f;
+        }
+      }
+    };
+  };
+  tok_mma<T, LC, LC>(sm.bX, sm.bX, LC, LDA, Wq, to_both((T*)sv.q, xo, L, as.q, 1, 1.f));
+  if (!EARLY) tok_load<T, LC, LC>(w.wk, Wk);
+  tok_mma<T, LC, LC>(sp, sp, LC, LDA, Wk, to_both((T*)sv.k, so, S, as.k, 1, 1.f));
+  if (!EARLY) tok_load<T, LC, LC>(w.wv, Wv);
+  tok_mma<T, LC, LC>(sp, sp, LC, LDA, Wv, to_both((T*)sv.v, so, S, as.v, 0, 1.f / (float)S));
+  wave_sync();
+  LPROF(1)
+#else
   tok_mma<T, LC, LC>(sm.bX, sm.bX, LC, LDA, Wq, to_global((T*)sv.q, xo, L, LC));
   if (!EARLY) tok_load<T, LC, LC>(w.wk, Wk);
   tok_mma<T, LC, LC>(sp, sp, LC, LDA, Wk, to_global((T*)sv.k, so, S, LC));
@@ -205,15 +234,23 @@ __global__ __launch_bounds__(LNT) void loftr_layer_fwd_kernel(const T* __restric
   tok_mma<T, LC, LC>(sp, sp, LC, LDA, Wv, to_global((T*)sv.v, so, S, LC));
   __syncthreads();
   LPROF(1)
+#endif
 
   // linear attention: wave wv owns head wv (q, k, v come back from L2; the head routine stages them per head)
 #if defined(RD_LOFTR_PROBE) && RD_LOFTR_PROBE == 4
   tok_load<T, LC, LC>(w.wm, Wm);
 #else
-  attn_head<T, false>(sm.u.at[wv], (const T*)sv.q, (const T*)sv.k, (const T*)sv.v, (const T*)nullptr, (T*)sv.att, (T*)nullptr,
-                      (T*)nullptr, (T*)nullptr, n, wv, true, L, S, LC, LC, LC, LC, eps_attn,
-                      [&]() RD_INLINE_LAMBDA { tok_load<T, LC, LC>(w.wm, Wm); });
-#endif   // merge weights: behind the staging loads, in flight across the phase
+  {
+    auto hook = [&]() RD_INLINE_LAMBDA { tok_load<T, LC, LC>(w.wm, Wm); };      // merge weights: in flight across the phase
+#ifndef RD_LOFTR_ATT_GLOBAL
+    attn_head<T, false, decltype(hook), true>(sm.u.at[wv], (const T*)sv.q, (const T*)sv.k, (const T*)sv.v, (const T*)nullptr, (T*)sv.att, (T*)nullptr,
+                                                (T*)nullptr, (T*)nullptr, n, wv, true, L, S, LC, LC, LC, LC, eps_attn, hook);
+#else
+    attn_head<T, false, decltype(hook), false>(sm.u.at[wv], (const T*)sv.q, (const T*)sv.k, (const T*)sv.v, (const T*)nullptr, (T*)sv.att, (T*)nullptr,
+                                                 (T*)nullptr, (T*)nullptr, n, wv, true, L, S, LC, LC, LC, LC, eps_attn, hook);
+#endif
+  }
+#endif
   __syncthreads();
   LPROF(2)
   load_rows<T>((const T*)sv.att + xo, L, sm.bS, LDA);
