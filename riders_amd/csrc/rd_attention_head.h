@@ -45,7 +45,8 @@ __device__ __forceinline__ void stage_head(const T* __restrict__ src, int64_t ro
 // PRE (forward only): the caller has already written the feature-mapped q, k and the scaled v of this head into s.q / s.k / s.v (rows beyond
 // L / S zero) and ordered them with a wave_sync(): no staging loads (rd_loftr.hip: the wave that owns head h is the wave whose projection
 // GEMM tile IS head h, so its accumulators go straight into its scratch).
-template <typename T, bool BWD, typename Hook, bool PRE = false>
+// PRED (backward only): s.d (the gradient of this head's attention output, rows beyond L zero) is already in place likewise.
+template <typename T, bool BWD, typename Hook, bool PRE = false, bool PRED = false>
 __device__ __forceinline__ void attn_head(AttnSmem& s, const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v,
                                           const T* __restrict__ dout, T* __restrict__ out, T* __restrict__ dq, T* __restrict__ dk,
                                           T* __restrict__ dv, int n, int h, bool active, int L, int S, int ldq, int ldk, int ldv,
@@ -59,7 +60,7 @@ __device__ __forceinline__ void attn_head(AttnSmem& s, const T* __restrict__ q, 
 
   if (PRE) { after_loads(); }
   else {
-  wave_sync();  // a previous call's reads of this wave's scratch are complete before it is restaged (back-to-back calls)
+  if (!PRED) wave_sync();  // a previous call's reads of this wave's scratch are complete before it is restaged (back-to-back calls; PRED: the caller's)
   constexpr int VE = Elem<T>::VE;
   const bool vec = L > 0 && S > 0 && (ldq % VE == 0) && (ldk % VE == 0) && (ldv % VE == 0) && (!BWD || ldo % VE == 0) &&
                    (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v | (BWD ? (uintptr_t)dout : (uintptr_t)0)) & 15) == 0;
@@ -81,7 +82,7 @@ __device__ __forceinline__ void attn_head(AttnSmem& s, const T* __restrict__ q, 
       rd::ldv(q + (nn * L + rl) * ldq + cc0 + c, xq[i]);
       rd::ldv(k + (nn * S + rs) * ldk + cc0 + c, xk[i]);
       rd::ldv(v + (nn * S + rs) * ldv + cc0 + c, xv[i]);
-      if (BWD) rd::ldv(dout + (nn * L + rl) * ldo + cc0 + c, xd[i]);
+      if (BWD && !PRED) rd::ldv(dout + (nn * L + rl) * ldo + cc0 + c, xd[i]);
 #endif
     }
     sched_fence();
@@ -96,14 +97,14 @@ __device__ __forceinline__ void attn_head(AttnSmem& s, const T* __restrict__ q, 
         s.q[rr * LD + c + e] = okq ? (a > 0.f ? a + 1.f : __expf(a)) : 0.f;
         s.k[rr * LD + c + e] = okk ? (b > 0.f ? b + 1.f : __expf(b)) : 0.f;
         s.v[rr * LD + c + e] = okk ? xv[i][e] * (1.f / fS) : 0.f;
-        if (BWD) s.d[rr * LD + c + e] = okq ? xd[i][e] * 1.f : 0.f;
+        if (BWD && !PRED) s.d[rr * LD + c + e] = okq ? xd[i][e] * 1.f : 0.f;
       }
     }
   } else {
     stage_head<T>(q, (int64_t)n * L, ldq, col0, L, s.q, 1, 1.f, active);
     stage_head<T>(k, (int64_t)n * S, ldk, col0, S, s.k, 1, 1.f, active);
     stage_head<T>(v, (int64_t)n * S, ldv, col0, S, s.v, 0, 1.f / fS, active);
-    if (BWD) stage_head<T>(dout, (int64_t)n * L, ldo, col0, L, s.d, 0, 1.f, active);
+    if (BWD && !PRED) stage_head<T>(dout, (int64_t)n * L, ldo, col0, L, s.d, 0, 1.f, active);
     after_loads();
   }
   wave_sync();

@@ -465,26 +465,48 @@ __global__ __launch_bounds__(LNT) void loftr_layer_bwd_kernel(const T* __restric
   };
 #if defined(RD_LOFTR_PROBE) && RD_LOFTR_PROBE >= 2
   tok_mma<T, LC, LC>(sm.bD, sm.bD, LC, LDA, Wm, [&](int ct, f32x4 (&acc)[2]) RD_INLINE_LAMBDA { if (acc[0][0] == 12345.f) sm.acc[0] = 1.f; });
-#else
-  tok_mma<T, LC, LC>(sm.bD, sm.bD, LC, LDA, Wm, to_global((T*)gr.datt, xo, L));
-#endif
   __syncthreads();
   LPROF(14)
+#elif !defined(RD_LOFTR_ATT_GLOBAL)
+  // as in the forward: head h's datt tile is computed by the wave that owns head h -- stored for the weight gradient and written straight into
+  // its attention scratch (rounded as stored); no barrier, the attention phase only adds its own q / k / v loads
+  wave_sync();
+  tok_mma<T, LC, LC>(sm.bD, sm.bD, LC, LDA, Wm, [&](int ct, f32x4 (&acc)[2]) RD_INLINE_LAMBDA {
+    float* const ld_ = sm.u.at[wv].d;
+#pragma unroll
+    for (int tt = 0; tt < 2; tt++) {
+      const int tok = tt * 16 + fr;
+      float v[4] = {acc[tt][0], acc[tt][1], acc[tt][2], acc[tt][3]};
+      if (tok < L) st4((T*)gr.datt + xo + (int64_t)tok * LC + ct * 16 + fg * 4, v);
+#pragma unroll
+      for (int r = 0; r < 4; r++) ld_[tok * LD + fg * 4 + r] = tok < L ? Elem<T>::rnd(v[r]) : 0.f;
+    }
+  });
+  LPROF(14)
+#else
+  tok_mma<T, LC, LC>(sm.bD, sm.bD, LC, LDA, Wm, to_global((T*)gr.datt, xo, L));
+  __syncthreads();
+  LPROF(14)
+#endif
 
   // 6. attention backward (recomputes KV / P from the saved q, k, v)
 #if defined(RD_LOFTR_PROBE) && RD_LOFTR_PROBE == 4
   tok_load<T, LC, LC>(w.wq, Wq); if (EARLY) { tok_load<T, LC, LC>(w.wk, Wk); tok_load<T, LC, LC>(w.wv, Wv); }
   if (false)
 #endif
-  attn_head<T, true>(sm.u.at[wv], (const T*)sv.q, (const T*)sv.k, (const T*)sv.v,
+  {
+    auto hookb = [&]() RD_INLINE_LAMBDA { tok_load<T, LC, LC>(w.wq, Wq); if (EARLY) { tok_load<T, LC, LC>(w.wk, Wk); tok_load<T, LC, LC>(w.wv, Wv); } };
 #if defined(RD_LOFTR_PROBE)
-                     (const T*)gr.dout,
+    attn_head<T, true, decltype(hookb), false, false>(sm.u.at[wv], (const T*)sv.q, (const T*)sv.k, (const T*)sv.v, (const T*)gr.dout, (T*)nullptr, (T*)gr.dq,
+                                                        (T*)gr.dk, (T*)gr.dv, n, wv, true, L, S, LC, LC, LC, LC, eps_attn, hookb);
+#elif !defined(RD_LOFTR_ATT_GLOBAL)
+    attn_head<T, true, decltype(hookb), false, true>(sm.u.at[wv], (const T*)sv.q, (const T*)sv.k, (const T*)sv.v, (const T*)gr.datt, (T*)nullptr, (T*)gr.dq,
+                                                       (T*)gr.dk, (T*)gr.dv, n, wv, true, L, S, LC, LC, LC, LC, eps_attn, hookb);
 #else
-                     (const T*)gr.datt,
+    attn_head<T, true, decltype(hookb), false, false>(sm.u.at[wv], (const T*)sv.q, (const T*)sv.k, (const T*)sv.v, (const T*)gr.datt, (T*)nullptr, (T*)gr.dq,
+                                                        (T*)gr.dk, (T*)gr.dv, n, wv, true, L, S, LC, LC, LC, LC, eps_attn, hookb);
 #endif
-                     (T*)nullptr, (T*)gr.dq,
-                     (T*)gr.dk, (T*)gr.dv, n, wv, true, L, S, LC, LC, LC, LC, eps_attn,
-                     [&]() RD_INLINE_LAMBDA { tok_load<T, LC, LC>(w.wq, Wq); if (EARLY) { tok_load<T, LC, LC>(w.wk, Wk); tok_load<T, LC, LC>(w.wv, Wv); } });
+  }
   __syncthreads();
   LPROF(15)
 
