@@ -50,7 +50,7 @@ template <typename T, bool BWD, typename Hook, bool PRE = false, bool PRED = fal
 __device__ __forceinline__ void attn_head(AttnSmem& s, const T* __restrict__ q, const T* __restrict__ k, const T* __restrict__ v,
                                           const T* __restrict__ dout, T* __restrict__ out, T* __restrict__ dq, T* __restrict__ dk,
                                           T* __restrict__ dv, int n, int h, bool active, int L, int S, int ldq, int ldk, int ldv,
-                                          int ldo, float eps, Hook after_loads) {
+                                          int ldo, float eps, Hook after_loads, T* lds_out = nullptr, int ldl = 0) {
   const int lane = threadIdx.x & 63;
   const int r = lane & 15, g = lane >> 4;
   const int col0 = h * 16;
@@ -146,7 +146,10 @@ __device__ __forceinline__ void attn_head(AttnSmem& s, const T* __restrict__ q, 
 #pragma unroll
       for (int e = 0; e < 4; e++) {
         int l = tI * 16 + g * 4 + e;
-        if (active && l < L) Elem<T>::st(out + ((int64_t)n * L + l) * ldo + col0 + r, P[tI][e] * Z[tI][e] * fS);
+        const float o = P[tI][e] * Z[tI][e] * fS;
+        if (active && l < L) Elem<T>::st(out + ((int64_t)n * L + l) * ldo + col0 + r, o);
+        // lds_out: the caller's [MAXR][ldl] token tile of the attention output (rows beyond L zero), so that it need not read `out` back
+        if (lds_out) Elem<T>::st(lds_out + l * ldl + col0 + r, (active && l < L) ? o : 0.f);
       }
     return;
   }

@@ -244,7 +244,7 @@ __global__ __launch_bounds__(LNT) void loftr_layer_fwd_kernel(const T* __restric
     auto hook = [&]() RD_INLINE_LAMBDA { tok_load<T, LC, LC>(w.wm, Wm); };      // merge weights: in flight across the phase
 #ifndef RD_LOFTR_ATT_GLOBAL
     attn_head<T, false, decltype(hook), true>(sm.u.at[wv], (const T*)sv.q, (const T*)sv.k, (const T*)sv.v, (const T*)nullptr, (T*)sv.att, (T*)nullptr,
-                                                (T*)nullptr, (T*)nullptr, n, wv, true, L, S, LC, LC, LC, LC, eps_attn, hook);
+                                                (T*)nullptr, (T*)nullptr, n, wv, true, L, S, LC, LC, LC, LC, eps_attn, hook, sm.bM, LDA);
 #else
     attn_head<T, false, decltype(hook), false>(sm.u.at[wv], (const T*)sv.q, (const T*)sv.k, (const T*)sv.v, (const T*)nullptr, (T*)sv.att, (T*)nullptr,
                                                  (T*)nullptr, (T*)nullptr, n, wv, true, L, S, LC, LC, LC, LC, eps_attn, hook);
@@ -253,8 +253,13 @@ __global__ __launch_bounds__(LNT) void loftr_layer_fwd_kernel(const T* __restric
 #endif
   __syncthreads();
   LPROF(2)
+#ifndef RD_LOFTR_ATT_GLOBAL
+  const T* const attT = sm.bM;      // every head wrote its 16 columns of the attention output into the (still unused) message tile
+#else
   load_rows<T>((const T*)sv.att + xo, L, sm.bS, LDA);
   __syncthreads();
+  const T* const attT = sm.bS;
+#endif
   LPROF(3)
 
   // merge projection -> fp32 scratch (values as the unfused path stores them) + saved pre-norm activation
@@ -271,7 +276,7 @@ __global__ __launch_bounds__(LNT) void loftr_layer_fwd_kernel(const T* __restric
     };
   };
   tok_load<T, LC2, LC2>(w.w0, W0);     // in flight across the merge GEMM and norm1
-  tok_mma<T, LC, LC>(sm.bS, sm.bS, LC, LDA, Wm, to_f((T*)sv.mpre, L));
+  tok_mma<T, LC, LC>(attT, attT, LC, LDA, Wm, to_f((T*)sv.mpre, L));
   __syncthreads();
   LPROF(4)
 
