@@ -275,6 +275,122 @@ def kernel_roofline(timer, timed_steps, ms_per_step, dtype, traffic_key, conv_on
     return roof
 
 
+LINE_LIMIT = 6000      # bytes of the ONE stdout line (the driver kept ~8 KB of stdout and lost the head of a 39.8-KB line)
+FLAT_ROOF_KEYS = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_over_algorithmic", "traffic_stale", "launches_per_step",
+                  "avg_launch_us", "ms_per_step", "share_of_step", "algorithmic_flops_per_launch", "algorithmic_bytes_per_launch", "mfma_util")
+
+
+def _sig(v, n=5):
+    """floats to n significant digits (the line is for a parser with a size limit, not for arithmetic)"""
+    if isinstance(v, float):
+        return float("%.*g" % (n, v)) if v == v and abs(v) != float("inf") else None
+    return v
+
+
+def flat_roofline(roof, keys=FLAT_ROOF_KEYS):
+    """the flat part of a roofline object: no kernels / families / shapes tables, no notes; `mfma_util` lifted out of the PMC block"""
+    if not roof or "kernel" not in roof:
+        return None
+    r = dict(roof)
+    if isinstance(r.get("mfma_busy"), dict):
+        r["mfma_util"] = r["mfma_busy"].get("mfma_util")
+    return {k: _sig(r[k]) for k in keys if k in r}
+
+
+def full_record(args, world, comm, ddp, head, sml, legs, cpu, val):
+    """Everything the run measured (what round 4 printed on stdout): written to the --full-json file."""
+    is_rc = args.workload == "rcnet"
+    out = {
+        "metric": "train imgs/sec (RC-Net, 256x512 thermal + 30 radar points, patch 240x100)" if is_rc else
+                  "train imgs/sec (Scale Map Learner, MiDaS-small / EfficientNet-Lite3)",
+        "value": head["value"], "unit": "imgs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": {"fp32": "f32", "bf16": "bf16", "fp16": "f16"}[args.dtype], "data": "synthetic",
+        "config": {"workload": ("RC-Net training step, batch %d/GPU, ZJU config (K=30, patch 240x100), %dx%d image, fwd+loss+bwd+Adam" if is_rc
+                                else "SML training step, batch %d/GPU, %dx%d frames, device pre-step+fwd+loss+bwd+Adam") % (
+            head["batch_per_gpu"], head["height"], head["width"]), "global_batch": head["batch_per_gpu"] * world,
+            "parallelism": "dp%d" % world,
+            "note": ("BASELINE configs[3]: global batch 32 over %d rank(s)" % world) if args.config3 else
+                    "BASELINE configs[1] per rank at every N (weak scaling); configs[3]'s global 32 on 8 GPUs is --config3"},
+        "final_loss": head["final_loss"], "launch_mode": head["launch_mode"], "settle_steps": head["settle_steps"],
+        "world_size": world, "comm": comm,
+        "allreduce": None if not ddp else "RCCL sum (%s) of the flat fp32 gradient arena in 3 stage buckets, each started when the backward "
+                                          "passes its stage mark (overlaps the remaining backward); 1/N folded into Adam" % args.allreduce,
+        "roofline": head.get("roofline"), "roofline_conv": head.get("roofline_conv"),
+    }
+    if sml is not None:
+        out["sml"] = {"metric": "train imgs/sec (Scale Map Learner, MiDaS-small / EfficientNet-Lite3; BASELINE configs[2])",
+                      "value": sml["value"], "unit": "imgs/s", "ms_per_step": sml["ms_per_step"], "dtype": out["dtype"],
+                      "config": {"workload": "SML training step, batch %d/GPU, %dx%d frames, device pre-step+fwd+loss+bwd+Adam" % (
+                          sml["batch_per_gpu"], sml["height"], sml["width"])},
+                      "final_loss": sml["final_loss"], "settle_steps": sml["settle_steps"], "roofline": sml.get("roofline"),
+                      "roofline_conv": sml.get("roofline_conv")}
+        # BASELINE.json's metric names both stages: an image passes through an RC-Net step and an SML step
+        out["chained"] = {"metric": "train imgs/sec through RC-Net then SML (per-image time = RC-Net step/8 + SML step/16)",
+                          "value": 1.0 / (1.0 / head["value"] + 1.0 / sml["value"]), "unit": "imgs/s"}
+    for name, leg in legs.items():
+        out[name] = {"metric": LEG_METRIC[name], "value": leg["value"], "unit": "imgs/s", "ms_per_step": leg["ms_per_step"], "steps": leg["steps"],
+                     "dtype": LEG_DTYPE[name],
+                     "config": {"workload": "%s training step, batch %d/GPU, %dx%d image, fwd+loss+bwd+Adam" % (
+                         "SML" if name.endswith("_sml") else "RC-Net", leg["batch_per_gpu"], leg["height"], leg["width"])},
+                     "final_loss": leg["final_loss"], "roofline": leg.get("roofline"), "roofline_conv": leg.get("roofline_conv")}
+    if val is not None:
+        out["val_abs_rel"] = val
+    if cpu is not None:
+        out["cpu_baseline"] = cpu
+    return out
+
+
+LEG_METRIC = {"fp32": "train imgs/sec (RC-Net, batch 8, 256x512, fp32: the 1e-3 parity mode)",
+              "config4": "train imgs/sec (RC-Net, batch 8 per GPU, 3x512x1024, fp16: BASELINE configs[4] per rank)",
+              "config4_sml": "train imgs/sec (Scale Map Learner, batch 8 per GPU, 512x1024, fp16: BASELINE configs[4] per rank)"}
+LEG_DTYPE = {"fp32": "f32", "config4": "f16", "config4_sml": "f16"}
+
+
+def compact_line(full):
+    """The ONE stdout line: headline fields, flat `roofline` / `roofline_conv`, `cpu_baseline` (value, unit, cores, kind, sample) and for the
+    secondary legs only value / ms_per_step / dtype / config.workload / roofline.{kernel, bound, frac}.  Always < LINE_LIMIT bytes."""
+    keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")
+    line = {k: _sig(full[k], 7) for k in keep}
+    cfg = full["config"]
+    line["config"] = {"workload": cfg["workload"], "global_batch": cfg["global_batch"], "parallelism": cfg["parallelism"]}
+    line["roofline"] = flat_roofline(full.get("roofline"))
+    line["roofline_conv"] = flat_roofline(full.get("roofline_conv"))
+    cb = full.get("cpu_baseline")
+    if cb is not None:
+        line["cpu_baseline"] = {k: _sig(cb[k]) for k in ("value", "unit", "cores", "kind", "sample", "host_cpus") if k in cb}
+    for name in ("sml", "fp32", "config4", "config4_sml"):
+        leg = full.get(name)
+        if leg is None:
+            continue
+        r = leg.get("roofline") or {}
+        line[name] = {"value": _sig(leg["value"], 7), "unit": leg.get("unit", "imgs/s"), "ms_per_step": _sig(leg["ms_per_step"], 7), "dtype": leg["dtype"],
+                      "config": {"workload": leg["config"]["workload"]},
+                      "roofline": {k: _sig(r[k]) for k in ("kernel", "bound", "frac") if k in r}}
+    if "chained" in full:
+        line["chained"] = {"value": _sig(full["chained"]["value"], 7), "unit": "imgs/s"}
+    va = full.get("val_abs_rel")
+    if isinstance(va, dict) and "hip" in va:
+        line["val_abs_rel"] = {k: _sig(va[k], 6) for k in ("hip", "oracle", "max_abs_diff")}
+    for k in ("final_loss", "launch_mode", "world_size"):
+        line[k] = _sig(full.get(k), 7)
+    if full.get("comm"):
+        line["comm"] = full["comm"]
+    return line
+
+
+def render_line(line, limit=LINE_LIMIT):
+    """json text of the compact line; should a field ever grow past the limit, optional blocks are dropped (last first) rather than the line lost"""
+    text = json.dumps(line, separators=(",", ":"))
+    for k in ("comm", "launch_mode", "val_abs_rel", "chained", "config4_sml", "config4", "fp32", "sml", "roofline_conv"):
+        if len(text) < limit:
+            break
+        line = {a: b for a, b in line.items() if a != k}
+        text = json.dumps(line, separators=(",", ":"))
+    return text
+
+
+
 def run_workload(kind, args, dev, world, rank, steps, warmup, **override):
     """override: dtype / batch / height / width / settle_seconds of a secondary leg (the fp32 parity mode, configs[4]) on a copy of args."""
     from riders_amd import engine, rcnet_main, sml_main
@@ -476,6 +592,8 @@ def main():
                                                               "many ranks there are, including one: a functional check of that path on a 1-GPU box")
     ap.add_argument("--allreduce", default="all_reduce", choices=["all_reduce", "rs_ag"],
                     help="gradient exchange per bucket: one all-reduce (RCCL's choice: a ring on xGMI) or reduce_scatter + all_gather in place")
+    ap.add_argument("--full-json", default=os.path.join(ROOT, "gpurun_out", "bench_full.json"),
+                    help="where the complete record (all tables) is written; stdout carries the compact line only")
     ap.add_argument("--detail", default=None, help="write a per-launch-shape timing table to this file")
     ap.add_argument("--timer-repeat", type=int, default=5, help="idempotent launches issued this many times per HIP-event pair in the instrumented "
                                                                 "steps (1 under rocprofv3, so that its launch counts per step are the real ones)")
@@ -524,54 +642,31 @@ def main():
         legs["config4"] = run_workload("rcnet", args, dev, world, rank, sec_steps, min(args.warmup, 5), dtype="fp16", height=512, width=1024,
                                        settle_seconds=min(args.settle_seconds, 1.0))
     if rank == 0:
-        is_rc = args.workload == "rcnet"
-        out = {
-            "metric": "train imgs/sec (RC-Net, 256x512 thermal + 30 radar points, patch 240x100)" if is_rc else
-                      "train imgs/sec (Scale Map Learner, MiDaS-small / EfficientNet-Lite3)",
-            "value": head["value"], "unit": "imgs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": {"fp32": "f32", "bf16": "bf16", "fp16": "f16"}[args.dtype], "data": "synthetic",
-            "config": {"workload": ("RC-Net training step, batch %d/GPU, ZJU config (K=30, patch 240x100), %dx%d image, fwd+loss+bwd+Adam" if is_rc
-                                    else "SML training step, batch %d/GPU, %dx%d frames, device pre-step+fwd+loss+bwd+Adam") % (
-                head["batch_per_gpu"], head["height"], head["width"]), "global_batch": head["batch_per_gpu"] * world,
-                "parallelism": "dp%d" % world,
-                "note": ("BASELINE configs[3]: global batch 32 over %d rank(s)" % world) if args.config3 else
-                        "BASELINE configs[1] per rank at every N (weak scaling); configs[3]'s global 32 on 8 GPUs is --config3"},
-            "final_loss": head["final_loss"], "launch_mode": head["launch_mode"], "settle_steps": head["settle_steps"],
-            "world_size": world, "comm": comm,
-            "allreduce": None if not ddp else "RCCL sum (%s) of the flat fp32 gradient arena in 3 stage buckets, each started when the backward "
-                                              "passes its stage mark (overlaps the remaining backward); 1/N folded into Adam" % args.allreduce,
-            "roofline": head["roofline"], "roofline_conv": head["roofline_conv"],
-        }
-        if sml is not None:
-            out["sml"] = {"metric": "train imgs/sec (Scale Map Learner, MiDaS-small / EfficientNet-Lite3; BASELINE configs[2])",
-                          "value": sml["value"], "unit": "imgs/s", "ms_per_step": sml["ms_per_step"], "dtype": out["dtype"],
-                          "config": {"workload": "SML training step, batch %d/GPU, %dx%d frames, device pre-step+fwd+loss+bwd+Adam" % (
-                              sml["batch_per_gpu"], sml["height"], sml["width"])},
-                          "final_loss": sml["final_loss"], "settle_steps": sml["settle_steps"], "roofline": sml["roofline"],
-                          "roofline_conv": sml["roofline_conv"]}
-            # BASELINE.json's metric names both stages: an image passes through an RC-Net step and an SML step
-            out["chained"] = {"metric": "train imgs/sec through RC-Net then SML (per-image time = RC-Net step/8 + SML step/16)",
-                              "value": 1.0 / (1.0 / head["value"] + 1.0 / sml["value"]), "unit": "imgs/s"}
-        for name, leg in legs.items():
-            out[name] = {"metric": {"fp32": "train imgs/sec (RC-Net, batch 8, 256x512, fp32: the 1e-3 parity mode)",
-                                    "config4": "train imgs/sec (RC-Net, batch 8 per GPU, 3x512x1024, fp16: BASELINE configs[4] per rank)"}[name],
-                         "value": leg["value"], "unit": "imgs/s", "ms_per_step": leg["ms_per_step"], "steps": leg["steps"],
-                         "dtype": {"fp32": "f32", "config4": "f16"}[name],
-                         "config": {"workload": "RC-Net training step, batch %d/GPU, %dx%d image, fwd+loss+bwd+Adam" % (leg["batch_per_gpu"], leg["height"], leg["width"])},
-                         "final_loss": leg["final_loss"], "roofline": leg["roofline"], "roofline_conv": leg["roofline_conv"]}
-        if world == 1 and not args.no_cpu_baseline and is_rc:
+        cpu = val = None
+        if world == 1 and not args.no_cpu_baseline and args.workload == "rcnet":
             try:
-                out["val_abs_rel"] = val_abs_rel_pair(dev)
+                val = val_abs_rel_pair(dev)
             except Exception as ex:      # never lose the bench line to the auxiliary figure
-                out["val_abs_rel"] = dict(error=repr(ex)[:300])
-            out["cpu_baseline"] = cpu_baseline()
+                val = dict(error=repr(ex)[:300])
+            cpu = cpu_baseline()
+        full = full_record(args, world, comm, ddp, head, sml, legs, cpu, val)
+        line = compact_line(full)
+        # the complete record (per-kernel / per-family / per-shape tables, notes, PMC blocks) goes to the --full-json file; stdout carries
+        # ONE line the driver can hold (round 4's 39.8-KB line was not parsed: BENCH_r04.json.parsed = null)
+        try:
+            os.makedirs(os.path.dirname(os.path.abspath(args.full_json)), exist_ok=True)
+            with open(args.full_json, "w") as f:
+                json.dump(full, f)
+        except OSError as ex:
+            sys.stderr.write("bench.py: could not write %s: %r\n" % (args.full_json, ex))
+        sys.stderr.write("bench.py: full record (%d bytes) -> %s\n" % (len(json.dumps(full)), args.full_json))
+        sys.stderr.flush()
         try:      # C-level stdout first (RCCL prints its version banner through stdio: buffered, it would land BEHIND the line at exit)
             import ctypes
             ctypes.CDLL(None).fflush(None)
         except Exception:
             pass
-        print(json.dumps(out), flush=True)
+        print(render_line(line), flush=True)
     if ddp:
         import torch.distributed as dist
         # the line is out; quiesce before the group goes away and never let a teardown problem turn into the run's exit code

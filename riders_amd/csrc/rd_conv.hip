@@ -1140,7 +1140,7 @@ __global__ __launch_bounds__(512) void linear_skinny_kernel(ConvArgs a) {
 }
 static bool conv_skinny_ok(const ConvArgs& a, int dtype) {
   const int step = dtype == 0 ? 16 : 32;
-  return a.KH == 1 && a.KW == 1 && a.stride == 1 && a.pad == 0 && a.C2 == 0 && !a.ups && !a.pool2 && a.D1 == a.Cout && a.K == a.C1 &&
+  return a.KH == 1 && a.KW == 1 && a.stride == 1 && a.dil == 1 && a.pad == 0 && a.C2 == 0 && !a.ups && !a.pool2 && a.D1 == a.Cout && a.K == a.C1 &&
          a.C1 % step == 0 && a.C1 >= 1024 && (int64_t)a.M * a.Cout <= 64 * 1024 && !a.stats && !a.add1 && !a.in_scale && !a.bn_y;
 }
 static void launch_linear_skinny(const ConvArgs& a, int dtype, hipStream_t st) {

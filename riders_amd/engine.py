@@ -32,101 +32,10 @@ _state = {"dtype": RD_F32, "tape": None, "defer_wgrad": True, "fused_loftr": Tru
           # conv2 staging, conv2 -> fused apply + add + activation: measured faster); 2: also the decoder chain (measured SLOWER on MI355X:
           # the 3x3 kernels are vector-issue bound and the staging arithmetic costs more than the HBM pass it replaces -- DESIGN.md)
           "lazy_bn": int(os.environ.get("RIDERS_LAZY_BN", "1")),
-          # Round 4: the convolution weight gradients run on a SECOND stream.  They are off the backward's critical path (dy -> data gradient
-          # -> the next layer's BatchNorm passes): forked behind the event that marks dy ready, joined before the stage's slab reduction, they
-          # overlap the HBM-bound BatchNorm passes / the data gradients of the following layers (also inside captured hipGraphs: the fork /
-          # join become graph edges).  MEASURED SLOWER on MI355X / ROCm 7 (RC-Net 1005 -> 952 img/s, SML 1222 -> 1155: 38 fork / join edges per
-          # step cost more than the overlap returns -- the wide weight-gradient blocks hold 506 of a SIMD's 512 VGPRs, nothing co-schedules):
-          # default 0 = everything on one stream; 1 keeps the experiment reproducible
-          "wgrad_stream": os.environ.get("RIDERS_WGRAD_STREAM", "0") != "0",
-          # engine.side_region (RoI poolings of the skip features on a second stream, next to the transformer): measured SLOWER -- 1059 / 1058
-          # img/s off, 1049 / 1049 on (one box, alternating; the two fork / join pairs per step cost more than the overlap returns, as with
-          # RIDERS_WGRAD_STREAM) -- off by default
-          "side_roi": os.environ.get("RIDERS_SIDE_ROI", "0") != "0", "side_pending": None,
+          # (round 4 measured two concurrency experiments SLOWER on MI355X / ROCm 7 and round 5 removed them from the product: convolution weight
+          # gradients on a second stream -- RC-Net 1005 -> 952 img/s, 38 fork / join edges per step -- and the skip features' RoI poolings next to
+          # the transformer -- 1059 -> 1049; DESIGN.md section 3 "Round 4")
           "roi_u8": os.environ.get("RIDERS_ROI_U8", "1") != "0"}      # compact (one byte) RoI-pool arg-max; 0: int32 indices (A/B)
-
-
-_side = {}
-
-
-def _side_stream(dev):
-    s = _side.get(dev)
-    if s is None:
-        s = _side[dev] = torch.cuda.Stream(device=dev)
-    return s
-
-
-def set_wgrad_stream(flag):
-    _state["wgrad_stream"] = bool(flag)
-
-
-class _OnStream(object):
-    """A tape node whose backward launches go to `stream` (see side_region)."""
-
-    def __init__(self, fn, stream):
-        self.fn, self.stream = fn, stream
-        self._stage = getattr(fn, "_stage", None)
-
-    def __call__(self):
-        with torch.cuda.stream(self.stream):
-            self.fn()
-
-
-class side_region(object):
-    """with side_region(x): launches (and torch allocations) inside go to the device's SIDE stream, forked behind everything queued on the
-    current stream so far; `side_join(x)` later makes the current stream wait for them.  Work between the two on the current stream runs
-    concurrently with the region (inside a captured hipGraph: parallel branches).  The tape mirrors it: the join's backward forks the side
-    stream again, the region's backward nodes launch there, the region entry's backward joins.  RC-Net: the five RoI poolings of the skip
-    features (and their gradients) next to the latency-bound transformer launches, which hold one workgroup per CU at two waves per SIMD.
-    Plain sequential launches for host tensors, under the kernel timer, and unless RIDERS_SIDE_ROI=1 (measured slower: see _state)."""
-
-    def __init__(self, like):
-        self.on = bool(like.is_cuda and _state["side_roi"] and _timer["t"] is None and _state.get("side_pending") is None)
-        self.dev = like.device
-
-    def __enter__(self):
-        if not self.on:
-            return self
-        t = _state["tape"]
-        side = self.side = _side_stream(self.dev)
-        main = torch.cuda.current_stream(self.dev)
-        side.wait_event(main.record_event())
-        if t is not None:
-            dev = self.dev
-
-            def backward():      # (runs after the region's backward nodes) the gradients written on the side stream are complete
-                torch.cuda.current_stream(dev).wait_stream(side)
-            t.record(backward)
-            self.n0 = len(t.nodes)
-        self.ctx = torch.cuda.stream(side)
-        self.ctx.__enter__()
-        return self
-
-    def __exit__(self, *exc):
-        if not self.on:
-            return False
-        self.ctx.__exit__(*exc)
-        t = _state["tape"]
-        if t is not None:
-            for i in range(self.n0, len(t.nodes)):
-                t.nodes[i] = _OnStream(t.nodes[i], self.side)
-        _state["side_pending"] = self.dev
-        return False
-
-
-def side_join(like):
-    """The current stream waits for the work of the last side_region (no-op when there is none)."""
-    dev = _state.get("side_pending")
-    if dev is None:
-        return
-    _state["side_pending"] = None
-    side = _side_stream(dev)
-    torch.cuda.current_stream(dev).wait_stream(side)
-    t = _state["tape"]
-    if t is not None:
-        def backward():      # (runs BEFORE the backward of everything recorded between the region and this join) fork
-            side.wait_event(torch.cuda.current_stream(dev).record_event())
-        t.record(backward)
 
 
 # how often a virtual activation was consumed in place / had to be written after all (tests assert that the fused routes are taken)
@@ -321,24 +230,6 @@ class Tape:
         self.colsum = []        # (rd_colsum_item, partial rows tensor, bias id): bias gradients finished by one launch per backward stage
         self.dw_reduce = []     # (rd_dw_wgrad_item, partial rows tensor, weight id): depthwise weight gradients, likewise
         self.ln_grads = {}      # id(gamma) -> dict(dg, db, acc, parts=[(partial rows tensor, rows)]): LayerNorm parameter gradients, likewise
-        self.side_keep = []     # operands of weight-gradient launches in flight on the side stream (kept alive until the join)
-        self.side_dev = None    # device whose side stream has un-joined work
-
-    def fork_side(self, like, keep):
-        """-> the side stream, made to wait for everything queued so far on the current stream (the operands in `keep` are then ready and
-        are held until join_side())."""
-        dev = like.device
-        side = _side_stream(dev)
-        side.wait_event(torch.cuda.current_stream(dev).record_event())
-        self.side_keep.extend(k for k in keep if k is not None)
-        self.side_dev = dev
-        return side
-
-    def join_side(self):
-        """The current stream waits for the side stream's weight-gradient launches (before their slabs are summed / a stage ends)."""
-        if self.side_dev is not None:
-            torch.cuda.current_stream(self.side_dev).wait_stream(_side_stream(self.side_dev))
-            self.side_dev, self.side_keep = None, []
 
     def requires(self, *ts):
         return any(t is not None and id(t) in self.req for t in ts)
@@ -420,7 +311,6 @@ class Tape:
         self.flush_colsum()
         self.flush_dw_reduce()
         self.flush_ln_grads()
-        self.join_side()
         pending, self.conv_reduce, self.conv_reduce_w = self.conv_reduce, [], set()
         if not pending:
             return
@@ -597,7 +487,6 @@ class StepTape(object):
 def _active(t):
     prev = _state["tape"]
     _state["tape"] = t
-    _state["side_pending"] = None      # (a forward that raised between side_region and side_join must not disable the next one)
     try:
         yield t
     finally:
@@ -1068,8 +957,6 @@ def conv_block(x, weight, *, x2=None, bias=None, stride=1, pad=None, up=None, bn
                     t.flush_conv_reduce()
                 item = _lib.WgradReduceItem()
                 st_w = st
-                if _state["wgrad_stream"] and x.is_cuda and _timer["t"] is None:      # off the critical path: second stream, joined at the slab reduction
-                    st_w = ctypes.c_void_p(t.fork_side(x, (x, x2, dy, ws, dw)).cuda_stream)
                 if wfus is not None:
                     lazy_counts["wgrad_fused"] += 1
                     _chk(_timed("conv_wgrad", flops, lambda: lib.rd_conv_wgrad_partial_fused(ctypes.byref(d), ctypes.byref(wfus), _p(x), _p(x2), _p(dy),
@@ -1185,16 +1072,46 @@ def maxpool(x, k=3, s=2, p=1):
     return out
 
 
-_roi_flags = {}
+_roi_flags = {}      # device -> scratch flag of forwards WITHOUT a backward (inference, validation): written by the kernel, read by nobody
+_roi_live = []       # the flags of the most recent training forwards (one per tape), kept for check_roi_overflow()
 
 
-def _roi_flag(dev):
-    """Sticky device flag of the compact RoI arg-max: raised by a forward that met a bin window it cannot encode (> 15 pixels in a
-    direction); the backward kernels then write NaN gradients -- a wrong geometry cannot pass silently."""
-    f = _roi_flags.get(dev)
-    if f is None:
-        f = _roi_flags[dev] = torch.zeros(1, dtype=torch.int32, device=dev)
+def _roi_flag(x, t):
+    """Overflow flag of the compact RoI arg-max: raised by a forward that met a bin window it cannot encode (> 15 pixels in a direction);
+    the backward kernels of THAT forward then write NaN gradients -- a wrong geometry cannot pass silently.  The flag is scoped to the
+    training forward (one zeroed word per tape, shared by its five poolings); a forward without a backward gets a per-device scratch word
+    that no backward ever reads, so an inference or validation pass can never poison a later training step."""
+    dev = x.device
+    if t is None or not t.requires(x):
+        f = _roi_flags.get(dev)
+        if f is None:
+            f = _roi_flags[dev] = torch.zeros(1, dtype=torch.int32, device=dev)
+        return f
+    f = getattr(t, "roi_flag", None)
+    if f is None or f.device != dev:
+        f = t.roi_flag = torch.zeros(1, dtype=torch.int32, device=dev)      # a fill kernel (also under graph capture: re-zeroed by every replay)
+        _roi_live.append(f)
+        del _roi_live[:-8]
     return f
+
+
+def check_roi_overflow():
+    """Host-side check of the compact RoI arg-max (synchronises): raises if one of the recent training forwards (the last eight tapes, incl. the
+    one a captured step replays) met a bin window beyond 15 pixels -- its RoI-pool gradients are NaN.  Called where the host waits anyway
+    (FlatAdam.state_dict, RCNetModel.save_model, the end of bench.py's timed region); a training loop may call it whenever it reads the loss."""
+    live = [f for f in _roi_live]
+    if not live:
+        return
+    bad = [int(v) for v in torch.stack([f.reshape(()) for f in live]).cpu().tolist()]
+    if any(bad):
+        _roi_live[:] = [f for f, b in zip(live, bad) if not b]
+        raise RuntimeError("riders_amd: roi_pool met a bin window wider than 15 pixels, which the one-byte arg-max cannot encode; the gradients of "
+                           "that step are NaN.  Use engine.set_roi_u8(False) (int32 arg-max) for this geometry.")
+
+
+def set_roi_u8(flag):
+    """Compact one-byte RoI arg-max (default) or int32 pixel indices (any geometry)."""
+    _state["roi_u8"] = bool(flag)
 
 
 def roi_argmax(out):
@@ -1234,7 +1151,7 @@ def roi_pool(x, rois, output_size, spatial_scale, compact=None):
     compact = bool(compact) and C % (16 // x.element_size()) == 0 and _ROI_BWD in ("auto", "gather", "atomic") and PH < (1 << 19) and PW < (1 << 19) \
         and _state["roi_tile_min_blocks"] > 0      # (the LDS tile-accumulate backward, an A/B form, reads int32 indices)
     arg = torch.empty((R, PH, PW, C), dtype=torch.uint8 if compact else torch.int32, device=x.device)
-    flag = _roi_flag(x.device) if compact else None
+    flag = _roi_flag(x, t) if compact else None
     # algorithmic bytes: pooled values + argmax written, the source map read once
     roi_bytes = out.numel() * (x.element_size() + arg.element_size()) + x.numel() * x.element_size()
     if compact:
@@ -1590,7 +1507,7 @@ def output_cast(x, dtype):
 
 def add_act(a, b, act=ACT_NONE, slope=0.2):
     """act(a + b) on same-shape NHWC tensors (ResNet block tail, utils/net_utils.py:323)."""
-    ak = a                      # tape key of the first operand (a LazyAct stays the key of its z)
+    ak, bk = a, b               # tape keys of the operands (a LazyAct stays the key of its z, also after it has been materialised)
     if isinstance(a, LazyAct):  # act(act1(scale*y + shift) + b) in one pass over y and b: z is never written
         lz = a
         if isinstance(b, LazyAct):
@@ -1614,7 +1531,7 @@ def add_act(a, b, act=ACT_NONE, slope=0.2):
         out = torch.empty_like(a)
         _chk(_tb("elementwise", 3 * a.numel() * a.element_size(),
                  lambda: lib.rd_affine_act(_p(a), None, None, _p(b), _p(out), a.numel() // C, C, act, slope, dt, st), "add+act"), "rd_affine_act")
-    if t is not None and t.requires(ak, b):
+    if t is not None and t.requires(ak, bk):
         t.mark(out)
 
         def backward():
@@ -1627,7 +1544,7 @@ def add_act(a, b, act=ACT_NONE, slope=0.2):
             else:
                 d = g
             t.add_grad(ak, d)
-            t.add_grad(b, d)
+            t.add_grad(bk, d)
         t.record(backward)
     return out
 

@@ -162,11 +162,8 @@ class RCNetEncoder(torch.nn.Module):
 
         latent_image, skips_image = self.encoder_image._fwd(image)
         engine.stage_mark("attention_done")   # backward: RoI pooling, point MLP and transformer gradients are final here
-        # the skip features' RoI poolings (and, on the tape, their gradients) go to the side stream: they are independent of the point MLP and
-        # the transformer, whose latency-bound launches leave most of the chip's issue slots and all of its HBM bandwidth idle
-        with engine.side_region(latent_image):
-            skips_image_pooled = [engine.roi_pool(skips_image[i], rois, skip_feature_sizes[i], skip_scales[i])
-                                  for i in range(len(skips_image))]
+        skips_image_pooled = [engine.roi_pool(skips_image[i], rois, skip_feature_sizes[i], skip_scales[i])
+                              for i in range(len(skips_image))]
         latent_image_pooled = engine.roi_pool(latent_image, rois, (latent_height, latent_width), 1 / 32.0)
 
         # point MLP stays in fp32 (raw pixel coordinates in the hundreds), output viewed (R, C, L) -> tokens (R, L, C)
@@ -179,7 +176,6 @@ class RCNetEncoder(torch.nn.Module):
         depth_tf, image_tf = self.attention._fwd(tokens_depth, tokens_image, R, L, L)
         latent = engine.concat_channels(image_tf, depth_tf)                   # cat([image_tf, depth_tf], dim=1)
         latent = engine.alias(latent, latent.view(R, latent_height, latent_width, 2 * C))
-        engine.side_join(latent)
         return latent, skips_image_pooled
 
     def forward(self, image, points, b_boxes):

@@ -191,6 +191,7 @@ class FlatAdam(object):
         """torch.optim.Adam's layout: per-parameter `step` / `exp_avg` / `exp_avg_sq` (copies sliced out of the arena) for every parameter
         that has received a gradient, and one param group listing parameter indices."""
         state = {}
+        engine.check_roi_overflow()   # (the host waits here anyway) a checkpoint must not be written from NaN-poisoned moments
         self.reconcile_skipped()      # `step` = updates actually applied (fp16 mode: not the skipped ones)
         for i, (p, o) in enumerate(zip(self.params, self.offsets)):
             if not self._ever[i]:
@@ -213,6 +214,7 @@ class FlatAdam(object):
             self.exp_avg.copy_(sd['exp_avg'])
             self.exp_avg_sq.copy_(sd['exp_avg_sq'])
             self.param_groups[0].update({k: v for k, v in sd['param_groups'][0].items() if k != 'params'})
+            self._skips_reconciled = self.skipped_steps()
             return
         groups = sd['param_groups']
         order = [i for g in groups for i in g['params']]
@@ -236,6 +238,8 @@ class FlatAdam(object):
                 self.exp_avg_sq[o:o + p.numel()].view(p.shape).copy_(st['exp_avg_sq'])
                 self.steps[pos] = int(float(st['step']))
                 self._ever[pos] = True
+        # the loaded `step` values are updates actually applied: skips counted on the device so far belong to the state that was replaced
+        self._skips_reconciled = self.skipped_steps()
         g0 = {k: v for k, v in groups[0].items() if k in ('lr', 'betas', 'eps', 'weight_decay')}
         if 'betas' in g0:
             g0['betas'] = tuple(g0['betas'])

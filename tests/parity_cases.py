@@ -640,15 +640,32 @@ def roi_pool_compact_case(dev):
                     else:
                         close(b[2], a[2], 1e-2, "compact RoI arg-max gradient (bf16, atomic order)")
                 assert torch.equal(res[(True, True)][2], res[(False, True)][2]), "gather form: compact and int32 gradients must be bit-identical"
-            # a 41-pixel-wide bin cannot be encoded: flag, then NaN gradients
-            assert int(engine._roi_flag(x.device).cpu()) == 0
+            # a 41-pixel-wide bin cannot be encoded: the flag of THAT training forward goes up, its gradients are NaN, the host check raises ...
+            engine._roi_live[:] = []
+            engine.check_roi_overflow()
+            with torch.no_grad():      # ... but an inference forward with the same geometry raises nothing that a backward will ever read
+                engine.roi_pool(x, t(rois[:1], dev), (1, 1), 1.0, compact=True)
+            assert not engine._roi_live
             tape = engine.Tape(); tape.mark(x)
             with engine._active(tape):
                 out = engine.roi_pool(x, t(rois[:1], dev), (1, 1), 1.0, compact=True)
                 tape.grads[id(out)] = torch.ones_like(out)
                 tape.backward()
-            assert int(engine._roi_flag(x.device).cpu()) == 1 and bool(torch.isnan(tape.grads[id(x)].float()).any())
-            engine._roi_flags.clear()
+            assert int(tape.roi_flag.cpu()) == 1 and bool(torch.isnan(tape.grads[id(x)].float()).any())
+            try:
+                engine.check_roi_overflow()
+                raise AssertionError("check_roi_overflow did not raise")
+            except RuntimeError as ex:
+                assert "15 pixels" in str(ex)
+            engine.check_roi_overflow()      # reported once
+            # ... and the next training forward with an encodable geometry starts from a clean flag: finite gradients
+            tape = engine.Tape(); tape.mark(x)
+            with engine._active(tape):
+                out = engine.roi_pool(x, t(rois[:1], dev), (7, 40), 1.0, compact=True)
+                tape.grads[id(out)] = torch.ones_like(out)
+                tape.backward()
+            assert int(tape.roi_flag.cpu()) == 0 and bool(torch.isfinite(tape.grads[id(x)].float()).all())
+            engine._roi_live[:] = []
         finally:
             engine.set_compute_dtype("fp32")
 

@@ -285,3 +285,65 @@ def test_stage_ranges_cover_rcnet_arena():
         red.close()
         from riders_amd import engine
         engine.set_param_grad_allocator(None)
+
+
+def test_bench_line_stays_under_the_driver_limit():
+    """the 39.8-KB stdout line was not parsed.  The compact line built from a canned kernel timer with many kernels, families and
+    launch shapes, every leg present and long notes must stay under 6000 bytes, carry the contract's fields and parse back."""
+    import argparse
+    import importlib.util
+    import json
+    import os
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    from riders_amd.engine import KernelTimer
+
+    class Ev(object):
+        def __init__(self, t):
+            self.t = t
+
+        def elapsed_time(self, other):
+            return other.t - self.t
+
+    timer = KernelTimer(repeat=5)
+    names = ["conv3x3_frag_kernel<rd::bf16_t, 4, 2, 4, true, true, false>", "conv3x3_wgrad_tr_kernel<4, 2, 16, 4, false>",
+             "bn_bwd_apply_vec_kernel<rd::bf16_t, true, 2>", "col_reduce_vec_kernel<rd::bf16_t, true, 2>"] + \
+            ["conv_gemm_kernel<rd::bf16_t, %d, true, 2, true, false>" % i for i in range(40)]
+    for i, n in enumerate(names):
+        kind = "conv_gemm" if "conv" in n and "wgrad" not in n else ("conv_wgrad" if "wgrad" in n else "bn_backward")
+        for j in range(12):
+            timer.records.setdefault(kind, []).append((Ev(0.0), Ev(0.05 + 0.001 * i + 0.0001 * j), 4e10 if "conv" in n else 0.0,
+                                                       "layer %d shape M=%d Cin=128 Cout=256 with a long description string %s" % (i, 1000 * j, "x" * 60),
+                                                       1e8, n, 5))
+    roof = bench.kernel_roofline(timer, 3, 7.4, "bf16", "rcnet_b8_256x512_bf16")
+    roof_c = bench.kernel_roofline(timer, 3, 7.4, "bf16", "rcnet_b8_256x512_bf16", conv_only=True, with_tables=False)
+    assert "kernels" in roof and "families" in roof and len(json.dumps(roof)) > 4000
+    leg = dict(value=1089.123456789, ms_per_step=7.3456789, steps=200, warmup=10, settle_steps=250, final_loss=0.69314718, batch_per_gpu=8, height=256,
+               width=512, launch_mode="one hipGraph (fwd+bwd) + eager Adam", roofline=roof, roofline_conv=roof_c)
+    args = argparse.Namespace(workload="rcnet", steps=200, warmup=10, dtype="bf16", config3=False, allreduce="all_reduce")
+    cpu = dict(value=1.61745833, unit="imgs/s", cores=16, kind="port", host_cpus=256, thread_sweep_b1={"8": 1.4, "16": 1.6, "32": 1.2},
+               sample="oracle RC-Net full step (fwd+loss+bwd+Adam), B=1 (30 ROIs, 256x512), fp32, best of 2 timed steps after 1 warm-up per thread count",
+               rcnet_b8=dict(value=1.2, unit="imgs/s", cores=16, sample="one B=8 step"), seconds=13.4)
+    val = dict(hip=0.379146, oracle=0.379123, max_abs_diff=2.7e-5, sample="2 synthetic frames")
+    full = bench.full_record(args, 1, dict(backend="nccl (RCCL)", world_size=1, rccl_version="2.26.6"), True, leg, leg,
+                             {"fp32": leg, "config4": leg, "config4_sml": leg}, cpu, val)
+    assert len(json.dumps(full)) > 15000          # the kind of record round 4 printed on stdout
+    text = bench.render_line(bench.compact_line(full))
+    assert len(text) < 6000 and "\n" not in text
+    line = json.loads(text)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+              "config", "roofline", "cpu_baseline"):
+        assert k in line, k
+    assert line["unit"] == "imgs/s" and line["config"]["workload"].startswith("RC-Net") and "model" not in line["config"]
+    r = line["roofline"]
+    for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "launches_per_step", "avg_launch_us"):
+        assert k in r, k
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and "kernels" not in r and "families" not in r and "shapes" not in r
+    assert set(line["cpu_baseline"]) >= {"value", "unit", "cores", "kind", "sample"}
+    for name in ("sml", "fp32", "config4", "config4_sml"):
+        assert set(line[name]) == {"value", "unit", "ms_per_step", "dtype", "config", "roofline"} and set(line[name]["roofline"]) <= {"kernel", "bound", "frac"}
+    # a pathological field cannot lose the line: optional blocks are dropped instead
+    big = dict(bench.compact_line(full), comm={"x": "y" * 9000})
+    assert len(bench.render_line(big)) < 6000 and "value" in json.loads(bench.render_line(big))
