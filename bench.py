@@ -314,8 +314,10 @@ def full_record(args, world, comm, ddp, head, sml, legs, cpu, val):
                     "BASELINE configs[1] per rank at every N (weak scaling); configs[3]'s global 32 on 8 GPUs is --config3"},
         "final_loss": head["final_loss"], "launch_mode": head["launch_mode"], "settle_steps": head["settle_steps"],
         "world_size": world, "comm": comm,
-        "allreduce": None if not ddp else "RCCL sum (%s) of the flat fp32 gradient arena in 3 stage buckets, each started when the backward "
-                                          "passes its stage mark (overlaps the remaining backward); 1/N folded into Adam" % args.allreduce,
+        "allreduce": None if not ddp else "RCCL sum (%s, %s) of the flat fp32 gradient arena in 3 stage buckets, each started when the backward "
+                                          "passes its stage mark (overlaps the remaining backward); 1/N folded into Adam" % (
+                                              args.allreduce, "rd_allreduce_bucket captured in the step graph" if getattr(args, "rccl_comm", None) is not None
+                                              else "torch.distributed between stage graphs"),
         "roofline": head.get("roofline"), "roofline_conv": head.get("roofline_conv"),
     }
     if sml is not None:
@@ -417,7 +419,7 @@ def run_workload(kind, args, dev, world, rank, steps, warmup, **override):
         batch = rcnet_main.synthetic_batch(batch_n, h, w, cfg, seed=1234 + rank, device=dev)
     model.train()
     opt = FlatAdam(model.parameters(), lr=cfg['learning_rate'])
-    reducer = GradientAllReducer(opt, stages=stages, mode=args.allreduce) if (world > 1 or args.force_ddp) else None
+    reducer = GradientAllReducer(opt, stages=stages, mode=args.allreduce, comm=args.rccl_comm) if (world > 1 or args.force_ddp) else None
     if reducer is not None:
         reducer.broadcast_parameters(0)
 
@@ -487,8 +489,9 @@ def run_workload(kind, args, dev, world, rank, steps, warmup, **override):
     ms = elapsed * 1e3 / max(steps, 1)
     out = dict(value=batch_n * world * steps / elapsed, ms_per_step=ms, steps=steps, warmup=warmup, settle_steps=settle, final_loss=final_loss,
                batch_per_gpu=batch_n, height=h, width=w,
-               launch_mode="eager" if args.eager else ("hipGraphs split at the stage marks (fwd+bwd) + eager all-reduce/Adam" if reducer is not None
-                                                       else "one hipGraph (fwd+bwd) + eager Adam"))
+               launch_mode="eager" if args.eager else (
+                   "one hipGraph (fwd+bwd+captured RCCL buckets) + eager Adam" if (reducer is not None and reducer.comm is not None) else
+                   "hipGraphs split at the stage marks (fwd+bwd) + eager all-reduce/Adam" if reducer is not None else "one hipGraph (fwd+bwd) + eager Adam"))
     if rank == 0:
         key = "%s_b%d_%dx%d_%s" % (kind, batch_n, h, w, args.dtype)
         out["roofline"] = kernel_roofline(timer, timed_steps, ms, args.dtype, key)
@@ -594,6 +597,9 @@ def main():
                     help="gradient exchange per bucket: one all-reduce (RCCL's choice: a ring on xGMI) or reduce_scatter + all_gather in place")
     ap.add_argument("--full-json", default=os.path.join(ROOT, "gpurun_out", "bench_full.json"),
                     help="where the complete record (all tables) is written; stdout carries the compact line only")
+    ap.add_argument("--comm", default="c_abi", choices=["c_abi", "torch"],
+                    help="gradient exchange transport for N > 1: c_abi = the library's own RCCL communicator (rd_comm_*, collectives captured into the "
+                         "step's ONE hipGraph), torch = torch.distributed's nccl(=RCCL) collectives between per-stage graphs (round 4)")
     ap.add_argument("--detail", default=None, help="write a per-launch-shape timing table to this file")
     ap.add_argument("--timer-repeat", type=int, default=5, help="idempotent launches issued this many times per HIP-event pair in the instrumented "
                                                                 "steps (1 under rocprofv3, so that its launch counts per step are the real ones)")
@@ -626,6 +632,23 @@ def main():
         dist.init_process_group(backend="nccl", device_id=dev, rank=rank, world_size=world)
         assert dist.get_world_size() == world
         comm = dict(backend="nccl (RCCL)", world_size=dist.get_world_size(), rccl_version=".".join(str(v) for v in torch.cuda.nccl.version()))
+    args.rccl_comm = None
+    if ddp and args.comm == "c_abi":
+        from riders_amd.parallel import RcclComm
+        import torch.distributed as dist
+        ok = torch.ones(1, device=dev)
+        try:
+            args.rccl_comm = RcclComm(rank, world)
+        except Exception as ex:      # e.g. no loadable librccl.so: fall back to torch.distributed's collectives on EVERY rank (decided together below)
+            sys.stderr.write("bench.py: rank %d: rd_comm_init failed (%r)\n" % (rank, ex))
+            ok.zero_()
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if float(ok.item()) < 1.0:
+            if args.rccl_comm is not None:
+                args.rccl_comm.close()
+            args.rccl_comm = None
+            sys.stderr.write("bench.py: falling back to --comm torch\n")
+        comm["transport"] = "rd_comm (C ABI, captured)" if args.rccl_comm is not None else "torch.distributed"
 
     head = run_workload(args.workload, args, dev, world, rank, args.steps, args.warmup)
     sml = None
@@ -641,6 +664,9 @@ def main():
         legs["fp32"] = run_workload("rcnet", args, dev, world, rank, sec_steps, min(args.warmup, 5), dtype="fp32", settle_seconds=min(args.settle_seconds, 1.0))
         legs["config4"] = run_workload("rcnet", args, dev, world, rank, sec_steps, min(args.warmup, 5), dtype="fp16", height=512, width=1024,
                                        settle_seconds=min(args.settle_seconds, 1.0))
+        # ... and its SML half at the same per-rank size (8 frames of 512x1024, fp16, static loss scale 1024)
+        legs["config4_sml"] = run_workload("sml", args, dev, world, rank, min(sec_steps, 30), min(args.warmup, 3), dtype="fp16", sml_batch=8, sml_height=512,
+                                           sml_width=1024, loss_scale=1024.0, settle_seconds=min(args.settle_seconds, 1.0))
     if rank == 0:
         cpu = val = None
         if world == 1 and not args.no_cpu_baseline and args.workload == "rcnet":
@@ -669,6 +695,12 @@ def main():
         print(render_line(line), flush=True)
     if ddp:
         import torch.distributed as dist
+        if args.rccl_comm is not None:
+            try:
+                torch.cuda.synchronize()
+                args.rccl_comm.close()
+            except Exception as ex:
+                sys.stderr.write("bench.py: rd_comm_destroy: %r\n" % (ex,))
         # the line is out; quiesce before the group goes away and never let a teardown problem turn into the run's exit code
         try:
             torch.cuda.synchronize()

@@ -391,6 +391,23 @@ int rd_adam_step_guarded(float* param, const float* grad, float* exp_avg, float*
                          float beta2, float eps, float weight_decay, int64_t step, float grad_scale, const int32_t* skip_flag, void* stream);
 int rd_adam_skip_count(int32_t* flag, void* stream);
 
+/* ---- gradient exchange over RCCL / xGMI -- replaces RCNet/rcnet_model.py:259-265 (torch.nn.DataParallel) -------------------------
+ * One process per GPU.  rd_comm_unique_id: rank 0 draws the 128-byte rendezvous id (ncclGetUniqueId), the caller hands it to the other
+ * ranks by any host channel; rd_comm_init: ncclCommInitRank on the CURRENT device + a library-owned communication stream.  RCCL is bound at
+ * run time (the copy already in the process, $RIDERS_RCCL_LIB, /opt/rocm/lib/librccl.so): no link-time dependency.
+ * rd_allreduce_bucket: in-place SUM of buf[0..n) (fp32) over the ranks, enqueued on the communication stream behind everything queued so
+ * far on `compute_stream` -- it returns at once and overlaps whatever the caller enqueues next; mode 0 = all-reduce (RCCL picks the
+ * algorithm), 1 = reduce-scatter + all-gather in place.  rd_comm_broadcast: buf of rank `root` to every rank, same ordering.
+ * rd_comm_join: `compute_stream` waits for everything issued since the last join.  All four are stream operations and may be captured
+ * into a hipGraph (fork / join of the communication stream become graph edges).  rd_comm_pending: collectives issued and not yet joined. */
+int rd_comm_unique_id(void* id128);
+int rd_comm_init(int32_t rank, int32_t world, const void* id128, void** comm);
+int rd_comm_destroy(void* comm);
+int rd_allreduce_bucket(void* comm, float* buf, int64_t n, int32_t mode, void* compute_stream);
+int rd_comm_broadcast(void* comm, float* buf, int64_t n, int32_t root, void* compute_stream);
+int rd_comm_join(void* comm, void* compute_stream);
+int64_t rd_comm_pending(void* comm);
+
 /* ==== Scale Map Learner (MiDaS-small) ================================================================================ */
 /* depthwise convolution of the tf_efficientnet_lite3 backbone (modules/midas/blocks.py:44-64; torch.hub, third-party):
  * w = OIHW fp32 with I = 1; p = TF-"SAME" leading pad; partial [rd_dw_rows][C][k*k] */

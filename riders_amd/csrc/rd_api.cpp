@@ -59,6 +59,7 @@ extern "C" {
 
 int rd_version(void) { return 100; }
 const char* rd_last_error_string(void) { return g_err; }
+void rd_set_last_error(const char* msg) { snprintf(g_err, sizeof(g_err), "%s", msg ? msg : ""); }      // for the library's other host units (rd_comm.cpp)
 
 int64_t rd_conv_packed_elems(int32_t rows, int32_t K, int32_t dtype) {
   return RD_NS(dtype, conv_packed_elems)(rows, K, RD_DT(dtype));

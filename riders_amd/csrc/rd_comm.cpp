@@ -1,0 +1,204 @@
+// Gradient exchange behind the C ABI (include/riders_hip.h: rd_comm_*): RCCL over xGMI, one process per GPU.
+//
+// Replaces the reference's torch.nn.DataParallel wrapping (RCNet/rcnet_model.py:259-265, val_zju.py:341: single process, weights broadcast
+// every forward, outputs gathered on GPU 0) with what a one-process-per-GPU design needs: a sum over the ranks of slices of the flat fp32
+// gradient arena, started while the backward is still running.
+//
+//   * RCCL is bound at RUN time (dlopen + dlsym): the copy already loaded into the process is preferred (a PyTorch-ROCm process carries its
+//     own librccl.so; two RCCL builds in one address space must not be mixed through the global symbol table), then $RIDERS_RCCL_LIB, then
+//     /opt/rocm/lib/librccl.so.  libriders_hip.so therefore has no link-time dependency on RCCL and single-GPU users never load it.
+//   * The communicator owns ONE side stream and two events.  rd_allreduce_bucket forks the side stream behind everything queued so far on
+//     the caller's compute stream (event record + stream wait) and enqueues the collective there; rd_comm_join makes the compute stream wait
+//     for everything issued since the last join.  Both are plain stream operations, so they are legal inside a stream capture: the fork
+//     pulls the side stream into the capture and the join merges it back -- forward + backward + every bucket's collective become ONE
+//     hipGraph (round 4 needed one graph per stage because torch.distributed's collectives cannot be captured with external events).
+//   * xGMI is point-to-point (7 links per GPU): mode 1 issues a bucket as reduce-scatter + all-gather in place (each rank owns the r-th
+//     piece; same bytes per link as a ring all-reduce, but the gather of bucket k can overlap the scatter of bucket k + 1), mode 0 leaves
+//     the algorithm to RCCL's all-reduce.
+//
+// Error convention: 0 = ok, negative = argument error, positive = hipError_t / 1000 + ncclResult_t; text in rd_last_error_string().
+#include "../../include/riders_hip.h"
+#include <hip/hip_runtime.h>      // (the host emulator's stand-in defines RD_EMU)
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+extern "C" void rd_set_last_error(const char* msg);      // rd_api.cpp: the thread-local message behind rd_last_error_string()
+
+namespace {
+int cfail(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof(buf), fmt, ap); va_end(ap);
+  rd_set_last_error(buf);
+  return code;
+}
+}  // namespace
+
+#ifdef RD_EMU
+// ---- host emulator build (tests/emu): a one-rank loop-back with the same entry points, so that the Python layer above it (bucketing, stage
+// hooks, the single-graph step) is exercised on the GPU-less build container.  Sum over one rank = identity.
+struct rd_comm_s { int rank, world; long issued, joined; };
+extern "C" {
+int rd_comm_unique_id(void* id128) { if (!id128) return cfail(-1, "comm_unique_id: null pointer"); memset(id128, 0x5a, 128); return 0; }
+int rd_comm_init(int32_t rank, int32_t world, const void* id128, void** comm) {
+  if (!id128 || !comm) return cfail(-1, "comm_init: null pointer");
+  if (world != 1 || rank != 0) return cfail(-1, "comm_init: the host emulator build has no transport (world must be 1)");
+  rd_comm_s* c = (rd_comm_s*)calloc(1, sizeof(rd_comm_s)); c->rank = 0; c->world = 1; *comm = c; return 0;
+}
+int rd_comm_destroy(void* comm) { free(comm); return 0; }
+int rd_allreduce_bucket(void* comm, float* buf, int64_t n, int32_t mode, void*) {
+  if (!comm || !buf || n < 0 || (mode != 0 && mode != 1)) return cfail(-1, "allreduce_bucket: bad arguments");
+  ((rd_comm_s*)comm)->issued++; return 0;
+}
+int rd_comm_broadcast(void* comm, float* buf, int64_t n, int32_t root, void*) {
+  if (!comm || !buf || n < 0 || root != 0) return cfail(-1, "comm_broadcast: bad arguments");
+  return 0;
+}
+int rd_comm_join(void* comm, void*) { if (!comm) return cfail(-1, "comm_join: null communicator"); rd_comm_s* c = (rd_comm_s*)comm; c->joined = c->issued; return 0; }
+int64_t rd_comm_pending(void* comm) { rd_comm_s* c = (rd_comm_s*)comm; return c ? c->issued - c->joined : -1; }
+}
+#else
+#include <dlfcn.h>
+
+namespace {
+// the slice of rccl.h this file needs (ABI-stable since NCCL 2.x): opaque communicator, 128-byte unique id, enums by value
+typedef struct ncclComm* ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+enum { ncclSuccessV = 0 };
+enum { ncclFloat32V = 7 };      // ncclDataType_t: int8 0, uint8 1, int32 2, uint32 3, int64 4, uint64 5, float16 6, float32 7
+enum { ncclSumV = 0 };          // ncclRedOp_t
+struct Rccl {
+  void* h = nullptr;
+  int (*GetUniqueId)(ncclUniqueId*) = nullptr;
+  int (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  int (*CommDestroy)(ncclComm_t) = nullptr;
+  int (*AllReduce)(const void*, void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+  int (*ReduceScatter)(const void*, void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+  int (*AllGather)(const void*, void*, size_t, int, ncclComm_t, hipStream_t) = nullptr;
+  int (*Broadcast)(const void*, void*, size_t, int, int, ncclComm_t, hipStream_t) = nullptr;
+  int (*GroupStart)() = nullptr;
+  int (*GroupEnd)() = nullptr;
+  const char* (*GetErrorString)(int) = nullptr;
+};
+Rccl g_rccl;
+
+int load_rccl() {
+  if (g_rccl.h) return 0;
+  void* h = dlopen("librccl.so", RTLD_NOW | RTLD_NOLOAD);          // the copy this process already carries (PyTorch-ROCm's)
+  if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);
+  const char* env = getenv("RIDERS_RCCL_LIB");
+  if (!h && env) h = dlopen(env, RTLD_NOW | RTLD_LOCAL);
+  if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_LOCAL);
+  if (!h) h = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_LOCAL);
+  if (!h) return cfail(-2, "rd_comm: cannot load librccl.so (%s)", dlerror());
+  Rccl r; r.h = h;
+#define RD_SYM(field, name) *(void**)(&r.field) = dlsym(h, name); if (!r.field) return cfail(-2, "rd_comm: librccl.so has no %s", name);
+  RD_SYM(GetUniqueId, "ncclGetUniqueId") RD_SYM(CommInitRank, "ncclCommInitRank") RD_SYM(CommDestroy, "ncclCommDestroy")
+  RD_SYM(AllReduce, "ncclAllReduce") RD_SYM(ReduceScatter, "ncclReduceScatter") RD_SYM(AllGather, "ncclAllGather")
+  RD_SYM(Broadcast, "ncclBroadcast") RD_SYM(GroupStart, "ncclGroupStart") RD_SYM(GroupEnd, "ncclGroupEnd") RD_SYM(GetErrorString, "ncclGetErrorString")
+#undef RD_SYM
+  g_rccl = r;
+  return 0;
+}
+int nfail(int rc, const char* what) { return cfail(1000 + rc, "%s: %s", what, g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "RCCL error"); }
+int hfail(hipError_t e, const char* what) { return cfail((int)e, "%s: %s", what, hipGetErrorString(e)); }
+#define RD_HIP(call, what) { hipError_t e_ = (call); if (e_ != hipSuccess) return hfail(e_, what); }
+#define RD_NCCL(call, what) { int rc_ = (call); if (rc_ != ncclSuccessV) return nfail(rc_, what); }
+}  // namespace
+
+struct rd_comm_s {
+  ncclComm_t comm;
+  int rank, world, device;
+  hipStream_t side;           // library-owned communication stream
+  hipEvent_t fork, join;      // compute -> side, side -> compute
+  long issued, joined;
+};
+
+extern "C" {
+
+int rd_comm_unique_id(void* id128) {
+  if (!id128) return cfail(-1, "comm_unique_id: null pointer");
+  if (int rc = load_rccl()) return rc;
+  ncclUniqueId id;
+  RD_NCCL(g_rccl.GetUniqueId(&id), "ncclGetUniqueId");
+  memcpy(id128, id.internal, 128);
+  return 0;
+}
+
+int rd_comm_init(int32_t rank, int32_t world, const void* id128, void** comm) {
+  if (!id128 || !comm) return cfail(-1, "comm_init: null pointer");
+  if (world < 1 || rank < 0 || rank >= world) return cfail(-1, "comm_init: bad rank %d / world %d", rank, world);
+  if (int rc = load_rccl()) return rc;
+  rd_comm_s* c = (rd_comm_s*)calloc(1, sizeof(rd_comm_s));
+  c->rank = rank; c->world = world;
+  RD_HIP(hipGetDevice(&c->device), "hipGetDevice");
+  ncclUniqueId id; memcpy(id.internal, id128, 128);
+  { int rc_ = g_rccl.CommInitRank(&c->comm, world, id, rank); if (rc_ != ncclSuccessV) { free(c); return nfail(rc_, "ncclCommInitRank"); } }
+  RD_HIP(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking), "hipStreamCreate");
+  RD_HIP(hipEventCreateWithFlags(&c->fork, hipEventDisableTiming), "hipEventCreate");
+  RD_HIP(hipEventCreateWithFlags(&c->join, hipEventDisableTiming), "hipEventCreate");
+  *comm = c;
+  return 0;
+}
+
+int rd_comm_destroy(void* comm) {
+  rd_comm_s* c = (rd_comm_s*)comm;
+  if (!c) return 0;
+  hipStreamSynchronize(c->side);
+  if (g_rccl.CommDestroy) g_rccl.CommDestroy(c->comm);
+  hipEventDestroy(c->fork); hipEventDestroy(c->join);
+  hipStreamDestroy(c->side);
+  free(c);
+  return 0;
+}
+
+static int fork_side(rd_comm_s* c, hipStream_t compute) {
+  RD_HIP(hipEventRecord(c->fork, compute), "hipEventRecord(fork)");
+  RD_HIP(hipStreamWaitEvent(c->side, c->fork, 0), "hipStreamWaitEvent(side)");
+  return 0;
+}
+
+int rd_allreduce_bucket(void* comm, float* buf, int64_t n, int32_t mode, void* compute_stream) {
+  rd_comm_s* c = (rd_comm_s*)comm;
+  if (!c || !buf || n < 0 || (mode != 0 && mode != 1)) return cfail(-1, "allreduce_bucket: bad arguments");
+  if (n == 0) return 0;
+  if (int rc = fork_side(c, (hipStream_t)compute_stream)) return rc;
+  const int64_t per = n / c->world, body = per * c->world;
+  if (mode == 1 && per > 0 && c->world > 1) {
+    // in place, NCCL's convention: rank r's shard is the r-th piece of the bucket
+    float* shard = buf + per * c->rank;
+    RD_NCCL(g_rccl.ReduceScatter(buf, shard, (size_t)per, ncclFloat32V, ncclSumV, c->comm, c->side), "ncclReduceScatter");
+    RD_NCCL(g_rccl.AllGather(shard, buf, (size_t)per, ncclFloat32V, c->comm, c->side), "ncclAllGather");
+    if (body < n) RD_NCCL(g_rccl.AllReduce(buf + body, buf + body, (size_t)(n - body), ncclFloat32V, ncclSumV, c->comm, c->side), "ncclAllReduce(tail)");
+  } else {
+    RD_NCCL(g_rccl.AllReduce(buf, buf, (size_t)n, ncclFloat32V, ncclSumV, c->comm, c->side), "ncclAllReduce");
+  }
+  c->issued++;
+  return 0;
+}
+
+int rd_comm_broadcast(void* comm, float* buf, int64_t n, int32_t root, void* compute_stream) {
+  rd_comm_s* c = (rd_comm_s*)comm;
+  if (!c || !buf || n < 0 || root < 0 || root >= c->world) return cfail(-1, "comm_broadcast: bad arguments");
+  if (n == 0) return 0;
+  if (int rc = fork_side(c, (hipStream_t)compute_stream)) return rc;
+  RD_NCCL(g_rccl.Broadcast(buf, buf, (size_t)n, ncclFloat32V, root, c->comm, c->side), "ncclBroadcast");
+  c->issued++;
+  return 0;
+}
+
+int rd_comm_join(void* comm, void* compute_stream) {
+  rd_comm_s* c = (rd_comm_s*)comm;
+  if (!c) return cfail(-1, "comm_join: null communicator");
+  if (c->issued == c->joined) return 0;      // nothing in flight (an event that was never recorded must not be waited on inside a capture)
+  RD_HIP(hipEventRecord(c->join, c->side), "hipEventRecord(join)");
+  RD_HIP(hipStreamWaitEvent((hipStream_t)compute_stream, c->join, 0), "hipStreamWaitEvent(compute)");
+  c->joined = c->issued;
+  return 0;
+}
+
+int64_t rd_comm_pending(void* comm) { rd_comm_s* c = (rd_comm_s*)comm; return c ? c->issued - c->joined : -1; }
+
+}  // extern "C"
+#endif

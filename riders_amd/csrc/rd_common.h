@@ -357,6 +357,17 @@ __device__ __forceinline__ float row16_sum(float v) {
   return v;
 }
 #endif
+// sum over the 32 lanes of a wave half (lanes 0-31 / 32-63): valid in the UPPER row of each half on the GPU (lanes 16-31 and 48-63: the in-row
+// sums, then row_bcast15 adds the lower row's total), in every lane of the emulator build (xor butterfly through 16); same additions
+__device__ __forceinline__ float row32_sum(float v) {
+  v = row16_sum(v);
+#if RD_DPP_SUM && !defined(RD_EMU)
+  v += dpp_f32<0x142, 0xA>(v);    // row_bcast15 into rows 1 and 3
+  return v;
+#else
+  return v + __shfl_xor(v, 16);
+#endif
+}
 __device__ __forceinline__ float wave_sum_up(float v) {
   v = row16_sum(v);
 #if RD_DPP_SUM >= 2 && !defined(RD_EMU)

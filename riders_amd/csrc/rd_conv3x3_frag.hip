@@ -264,6 +264,226 @@ __global__ __launch_bounds__(64 * WPX * WCH, (WPX * WCH == 8 && WCH == 4) ? 4 : 
   conv_epilogue_stats<2, BN, WPX, NT>(a, ssum, ssq, n0, wc, wpx, fr, fg, t, tile, reinterpret_cast<float*>(smem));
 }
 
+
+// ---- the same kernel on v_mfma_f32_32x32x16 (round 5) -------------------------------------------------------------------------------
+// One MFMA = 32 channels x 32 pixels x 16 input channels: twice the FLOPs of the 16x16x32 form at the same operand bytes per lane, half
+// the matrix instructions per FLOP, and a higher ceiling (2.38 against 2.08 PFLOP/s measured, MI355X_MICROARCH.md).  What changes:
+//   * a pixel fragment is 32 CONSECUTIVE patch pixels x one 16-byte channel slot per lane half, so the patch is stored as EIGHT planes of
+//     [pixel][16 bytes] (plane = 16-byte channel slot): the 16 lanes a ds_read_b128 serves together (MI355X_MICROARCH.md, LDS table) then
+//     cover 16 distinct 16-byte columns of one 512-byte run -- conflict free with no swizzle; the plane stride is a compile-time constant
+//     = 16 (mod 128) bytes, which also spreads the eight slots of a staged pixel (one ds_write_b128 lane group) over all 32 banks, and every
+//     fragment address is `one of three base registers + immediate`;
+//   * the weight fragment of (32-channel tile, 16-wide k-step) is read out of the EXISTING fragment-ordered operand copy
+//     ([chunk][tap][16-row tile][k half][lane] x 16 B) through a per-lane offset: lanes 0-15 / 16-31 take the tile's two 16-row halves,
+//     lanes 32-63 the next 8 input channels -- four contiguous 256-byte runs per wave load, no second packing;
+//   * a wave owns CW 32-channel tiles x NQ 32-pixel tiles (CW = 2: one pixel-fragment read feeds two MFMAs).
+// Linear tiles only (the RoI-resolution decoder layers, where this kernel's time is); bf16 / fp16 builds only.
+constexpr int frag32_ps(int pmax) { return 16 * pmax + 16; }      // plane stride in bytes: >= 16 pixels' worth, = 16 (mod 128)
+
+template <typename T, int NQ, int WPX, int WCH, int CW, bool MULTI>
+__global__ __launch_bounds__(64 * WPX * WCH, (WPX * WCH == 8) ? (CW * NQ <= 2 ? 4 : 2) : (CW * NQ <= 2 ? 4 : (CW * NQ <= 4 ? 2 : 1)))
+void conv3x3_frag32_kernel(ConvArgs a, FragGeom g) {
+  static_assert(sizeof(T) == 2, "16-bit activations only");
+  constexpr int NW = WPX * WCH, NT = 64 * NW;
+  constexpr int VE = 8, CKE = 64;                       // elements per 16-byte slot, channels per chunk
+  constexpr int TP = 32 * NQ * WPX, BN = 32 * CW * WCH;
+  constexpr int PMAX = frag_pmax(TP);
+  constexpr int PS = frag32_ps(PMAX);
+  constexpr int PIT = (PMAX * 8 + NT - 1) / NT;
+  RD_DYN_SMEM(smem);
+
+  const int t = threadIdx.x, lane = t & 63, wv = RD_WAVE_UNIFORM(t >> 6);
+  const int lp = lane & 31, lh = lane >> 5;
+  const int wpx = wv % WPX, wc = wv / WPX;
+  const int idx = xcd_contiguous((int)blockIdx.x, (int)gridDim.x);
+  const int cb = idx % g.ncb, tile = idx / g.ncb;
+  const int n0 = cb * BN;
+  const int Cin = a.C1 + a.C2;
+  const int nchunk = Cin / CKE;
+  const int WT = g.WT, np = g.np;
+  const int Hp = a.ups ? a.H1 : a.Hin, Wp = a.ups ? a.W1 : a.Win;
+  const int H1 = a.OH + 1;
+  const int u0 = WT + tile * TP;
+  auto strip_pixel = [&](int u, int& n, int& ih, int& iw) RD_INLINE_LAMBDA {
+    int c, hh;
+    const int vrow = fdiv_small(max(u, 0), WT, g.rWT, c);
+    n = fdiv_small(vrow, H1, g.rH1, hh);
+    ih = hh - 1; iw = c - 1;
+    return u >= 0 && c >= 1 && hh >= 1 && n < a.N;
+  };
+
+  // ---- patch staging: slot id = t + NT i -> patch pixel id >> 3, 16-byte channel slot t & 7 (as conv3x3_frag_kernel) ----------------------
+  int spix[PIT];
+#pragma unroll
+  for (int i = 0; i < PIT; i++) {
+    const int pp = (t + NT * i) >> 3;
+    int n, ih, iw;
+    const bool ok = strip_pixel(u0 - WT - 1 + pp, n, ih, iw);
+    int pix = -1;
+    if (ok && pp < np) {
+      int hs = ih, ws = iw;
+      if (a.ups) {
+        hs = min((int)floorf((float)ih * a.scale_h), a.H1 - 1);
+        ws = min((int)floorf((float)iw * a.scale_w), a.W1 - 1);
+      }
+      pix = (n * Hp + hs) * Wp + ws;
+    }
+    spix[i] = pix;
+  }
+  uint4 rp[PIT];
+  auto load_piece = [&](int chunk, int i, bool last) RD_INLINE_LAMBDA {
+    const int ci = chunk * CKE + (t & 7) * VE;
+    const bool first = ci < a.C1;
+    const T* cbp = first ? (const T*)a.src1 + ci : (const T*)a.src2 + (ci - a.C1);
+    const int cs = first ? a.C1 : a.C2;
+    const int px = last ? 0 : max(spix[i], 0);
+    const uint4 v = *reinterpret_cast<const uint4*>((last ? (const T*)a.src1 : cbp) + (int64_t)px * cs);
+    rp[i] = spix[i] < 0 ? make_uint4(0, 0, 0, 0) : v;
+  };
+  const int st_base = (t & 7) * PS + (t >> 3) * 16;      // plane = slot, pixel t >> 3
+  auto store_patch = [&]() RD_INLINE_LAMBDA {
+#pragma unroll
+    for (int i = 0; i < PIT; i++)
+      if (((t + NT * i) >> 3) < np) *reinterpret_cast<uint4*>(smem + st_base + i * (NT / 8) * 16) = rp[i];
+  };
+
+  // ---- this lane's output pixels (one per 32-pixel MFMA tile; both lane halves hold the same pixel, different channels) ------------------
+  int pm[NQ];
+#pragma unroll
+  for (int q = 0; q < NQ; q++) {
+    int n, ih, iw;
+    const bool ok = strip_pixel(u0 + (wpx * NQ + q) * 32 + lp, n, ih, iw);
+    pm[q] = ok ? (n * a.OH + ih) * a.OW + iw : -1;
+  }
+  // fragment read of (pixel tile q, tap (kr, kc), k-step s): plane 2 s + lh, patch pixel 32 (wpx NQ + q) + lp + kr WT + kc
+  int lbase[3];
+#pragma unroll
+  for (int kr = 0; kr < 3; kr++) lbase[kr] = lh * PS + (wpx * NQ * 32 + lp + kr * WT) * 16;
+
+  // ---- weight fragments out of the 16x16x32-ordered copy: [chunk][tap][16-row tile][k half][lane] x 16 B --------------------------------
+  // (32-row tile T, k-step s), lane l: 16-row tile 2 T + (lp >> 4), k half s >> 1, old lane ((s & 1) 2 + lh) 16 + (lp & 15)
+  const uint4* const wfr = reinterpret_cast<const uint4*>((const T*)a.w + g.wfrag) + ((n0 >> 4) + wc * CW * 2 + (lp >> 4)) * 128 + lh * 16 + (lp & 15);
+  const int wstep = g.ctall * 128;               // uint4 per (chunk, tap)
+  auto load_w = [&](int ct, uint4 (&w)[CW][4]) RD_INLINE_LAMBDA {   // ct = chunk * 9 + tap
+    const uint4* p = wfr + (int64_t)ct * wstep;
+#pragma unroll
+    for (int c = 0; c < CW; c++)
+#pragma unroll
+      for (int s_ = 0; s_ < 4; s_++) { const uint4 v = p[c * 256 + (s_ >> 1) * 64 + (s_ & 1) * 32]; w[c][s_] = v; }
+  };
+
+  f32x16 acc[CW][NQ];
+#pragma unroll
+  for (int c = 0; c < CW; c++)
+#pragma unroll
+    for (int q = 0; q < NQ; q++)
+#pragma unroll
+      for (int v = 0; v < 16; v++) acc[c][q][v] = 0.f;
+
+  constexpr int PPT = (PIT + 7) / 8;   // next-chunk patch pieces per tap, taps 0..7
+  auto tap_body = [&](int chunk, int tap, uint4 (&wcur)[CW][4], uint4 (&wnxt)[CW][4]) RD_INLINE_LAMBDA {
+    load_w(min(chunk * 9 + tap + 1, nchunk * 9 - 1), wnxt);
+    if (MULTI && tap < 8) {
+      const bool last = chunk + 1 >= nchunk;
+#pragma unroll
+      for (int k = 0; k < PPT; k++)
+        if (tap * PPT + k < PIT) load_piece(min(chunk + 1, nchunk - 1), tap * PPT + k, last);
+    }
+    sched_fence();
+    const int kr = tap / 3, kc = tap % 3;
+#pragma unroll
+    for (int s_ = 0; s_ < 4; s_++) {
+      uint4 pf[NQ];
+#pragma unroll
+      for (int q = 0; q < NQ; q++) pf[q] = *reinterpret_cast<const uint4*>(smem + lbase[kr] + s_ * 2 * PS + (q * 32 + kc) * 16);
+#pragma unroll
+      for (int c = 0; c < CW; c++) {
+        s16x8 wv8;
+        __builtin_memcpy(&wv8, &wcur[c][s_], 16);
+#pragma unroll
+        for (int q = 0; q < NQ; q++) {
+          s16x8 pb;
+          __builtin_memcpy(&pb, &pf[q], 16);
+          acc[c][q] = mfma_32x32x16_bf16(wv8, pb, acc[c][q]);
+        }
+      }
+    }
+    sched_fence();
+  };
+
+  uint4 wa[CW][4], wb[CW][4];
+#pragma unroll
+  for (int i = 0; i < PIT; i++) load_piece(0, i, false);
+  load_w(0, wa);
+  for (int chunk = 0; chunk < nchunk; chunk++) {
+    __syncthreads();
+    store_patch();
+    __syncthreads();
+    tap_body(chunk, 0, wa, wb); tap_body(chunk, 1, wb, wa); tap_body(chunk, 2, wa, wb);
+    tap_body(chunk, 3, wb, wa); tap_body(chunk, 4, wa, wb); tap_body(chunk, 5, wb, wa);
+    tap_body(chunk, 6, wa, wb); tap_body(chunk, 7, wb, wa); tap_body(chunk, 8, wa, wb);
+    if (MULTI) {
+#pragma unroll
+      for (int c = 0; c < CW; c++)
+#pragma unroll
+        for (int s_ = 0; s_ < 4; s_++) wa[c][s_] = wb[c][s_];
+    }
+  }
+
+  __syncthreads();  // all waves finished reading the patch before it is reused as reduction scratch
+  // ---- epilogue: register v of a 32x32 tile = channel (v & 3) + 8 (v >> 2) + 4 lh of pixel lp: four groups of 4 consecutive channels, 8 apart --
+  float* const red = reinterpret_cast<float*>(smem);
+#pragma unroll
+  for (int c = 0; c < CW; c++) {
+    float ssum[4][4], ssq[4][4];
+#pragma unroll
+    for (int gq = 0; gq < 4; gq++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) { ssum[gq][r] = 0.f; ssq[gq][r] = 0.f; }
+    const int cbase = n0 + (wc * CW + c) * 32 + lh * 4;
+#pragma unroll
+    for (int q0 = 0; q0 < NQ; q0 += 2) {   // the store routine takes two pixel tiles at a time
+      int64_t mm[2]; bool mvv[2]; f32x4 a2[4][2];
+#pragma unroll
+      for (int h = 0; h < 2; h++) {
+        const int q = q0 + h < NQ ? q0 + h : q0;
+        mm[h] = pm[q]; mvv[h] = (q0 + h < NQ) && pm[q] >= 0;
+#pragma unroll
+        for (int gq = 0; gq < 4; gq++)
+#pragma unroll
+          for (int r = 0; r < 4; r++) a2[gq][h][r] = acc[c][q][gq * 4 + r];
+      }
+      conv_epilogue_store_at<T, 4, true, 8>(a, a2, mm, mvv, cbase, ssum, ssq);
+    }
+    if (a.stats) {      // (sum, sum^2) over the wave's pixels: 32 pixel lanes per half, the half picks the channels
+#pragma unroll
+      for (int gq = 0; gq < 4; gq++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const float s1 = row32_sum(ssum[gq][r]), s2 = row32_sum(ssq[gq][r]);
+          if (lp == 31) {
+            const int col = (wc * CW + c) * 32 + gq * 8 + lh * 4 + r;
+            red[(wpx * BN + col) * 2 + 0] = s1;
+            red[(wpx * BN + col) * 2 + 1] = s2;
+          }
+        }
+    }
+  }
+  if (a.stats) {
+    __syncthreads();
+    for (int col = t; col < BN; col += NT) {
+      const int co = n0 + col;
+      if (co < a.Cout) {
+        float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+        for (int w = 0; w < WPX; w++) { s1 += red[(w * BN + col) * 2]; s2 += red[(w * BN + col) * 2 + 1]; }
+        a.stats[((int64_t)tile * a.Cout + co) * 2 + 0] = s1;
+        a.stats[((int64_t)tile * a.Cout + co) * 2 + 1] = s2;
+      }
+    }
+  }
+}
+
 // ---- host side -------------------------------------------------------------------------------------------------------------------
 // block shapes (pixels x channels, waves): the table is the A/B surface of tools/bench_conv.py (RD_FRAG_V128 / _V64 / _V32)
 struct FragVariant { int tp, bn, nw; };
@@ -276,7 +496,18 @@ static const FragVariant kFragVariants[] = {
   {256,  32, 4},   // 5: waves 4 x 1,  64 pixels each
   {512,  32, 4},   // 6: waves 4 x 1, 128 pixels each
 };
-struct FragPlan { int variant, tp, bn, nw, lin, WT, tilesH, tilesW, ntiles, ncb, np, ps; };
+struct FragPlan { int variant, tp, bn, nw, lin, WT, tilesH, tilesW, ntiles, ncb, np, ps, v32; };
+// 32x32x16 variants (conv3x3_frag32_kernel): pixels x channels per block, waves, (NQ, WPX, WCH, CW)
+struct Frag32Variant { int tp, bn, nw, nq, wpx, wch, cw; };
+static const Frag32Variant kFrag32Variants[] = {
+  {0, 0, 0, 0, 0, 0, 0},
+  {128, 128, 8, 2, 2, 4, 1},   // 1: eight waves of 64 pixels x 32 channels (the 16x16x32 kernel's tile)
+  {128, 128, 4, 2, 2, 2, 2},   // 2: four waves of 64 x 64: one pixel-fragment read feeds two MFMAs
+  {128, 128, 4, 4, 1, 4, 1},   // 3: four waves of 128 x 32
+  {256, 128, 4, 4, 2, 2, 2},   // 4: four waves of 128 x 64 (one block per CU)
+  {128,  64, 4, 2, 2, 2, 1},   // 5: 64-channel blocks, four waves of 64 x 32
+  {256,  64, 2, 4, 2, 1, 2},   // 6: 64-channel blocks, two waves of 128 x 64
+};
 
 // A/B hooks of tools/bench_conv.py and the tests: -1 = not set.  Variant indices are validated against the block width they may be used for
 // (a 64-channel block on a <= 32-channel operand would read weight-fragment tiles past the packed rows), everything else is a plain switch.
@@ -301,6 +532,18 @@ static bool frag_plan(const ConvArgs& a, int dtype, FragPlan& p) {
       cdiv((int64_t)a.M, 128) * cdiv(a.Cout, 128) < frag_env("RD_FRAG_SPLIT_BLOCKS", 256)) p.variant = 2;
   const FragVariant& v = kFragVariants[p.variant];
   p.tp = v.tp; p.bn = v.bn; p.nw = v.nw;
+  // the 32x32x16 form: 16-bit builds, linear tiles, no consumer-side BatchNorm apply (those shapes keep the 16x16x32 kernel)
+  p.v32 = 0;
+  if (dtype != 0 && !a.in_scale) {
+    int want = a.Cout > 64 ? frag_env("RD_FRAG32_V128", 0) : (a.Cout > 32 ? frag_env("RD_FRAG32_V64", 0) : 0);
+    if (want >= 1 && want <= 6 && kFrag32Variants[want].bn == (a.Cout > 64 ? 128 : 64)) {
+      const Frag32Variant& w32 = kFrag32Variants[want];
+      const int64_t strip32 = ((int64_t)a.N * (a.OH + 1) + 1) * (a.OW + 1);
+      if (strip32 < ((int64_t)1 << 22) && w32.tp + 2 * (a.OW + 1) + 2 <= frag_pmax(w32.tp) && frag_env("RD_FRAG_LIN", -1) != 0) {
+        p.v32 = want; p.tp = w32.tp; p.bn = w32.bn; p.nw = w32.nw;
+      }
+    }
+  }
   p.ncb = (int)cdiv(a.Cout, p.bn);
   // 2-D tiles of TP/16 rows x 16 columns, or linear tiles of the virtual strip (narrow maps, where 2-D tiles are mostly padding)
   const int th = p.tp / 16;
@@ -315,6 +558,7 @@ static bool frag_plan(const ConvArgs& a, int dtype, FragPlan& p) {
   bool lin = lin_ok && effl > eff2;
   if (force_lin == 0) lin = false;
   if (force_lin == 1) lin = lin_ok;
+  if (p.v32) lin = true;      // (checked above)
   p.lin = lin ? 1 : 0;
   if (lin) { p.WT = a.OW + 1; p.tilesH = p.tilesW = 0; p.ntiles = (int)tl; p.np = npl; }
   else { p.WT = 18; p.tilesH = (int)cdiv(a.OH, th); p.tilesW = (int)cdiv(a.OW, 16); p.ntiles = (int)t2; p.np = (th + 2) * 18; }
@@ -334,6 +578,11 @@ const char* conv3x3_frag_name(const ConvArgs& a, int dtype) {
   FragPlan p; frag_plan(a, dtype, p);
   static const int npt[] = {8, 4, 4, 8, 4, 4, 8}, wpx[] = {1, 2, 2, 2, 4, 4, 4}, wch[] = {4, 4, 2, 2, 2, 1, 1};
   const bool multi = (a.C1 + a.C2) * (dtype == 0 ? 4 : 2) > STAGE_BYTES;
+  if (p.v32) {
+    const Frag32Variant& w = kFrag32Variants[p.v32];
+    snprintf(buf, sizeof(buf), "conv3x3_frag32_kernel<%s, %d, %d, %d, %d, %s>", RD_T16_NAME, w.nq, w.wpx, w.wch, w.cw, multi ? "true" : "false");
+    return buf;
+  }
   snprintf(buf, sizeof(buf), "conv3x3_frag_kernel<%s, %d, %d, %d, %s, %s, %s>", dtype == 0 ? "float" : RD_T16_NAME, npt[p.variant], wpx[p.variant],
            wch[p.variant], p.lin ? "true" : "false", multi ? "true" : "false", a.in_scale ? "true" : "false");
   return buf;
@@ -354,6 +603,16 @@ static void launch_frag_v(const ConvArgs& a, const FragPlan& p, const FragGeom& 
   else { if (multi) RD_FR(false, true) else RD_FR(false, false) }
 #undef RD_FR
 }
+template <typename T, int NQ, int WPX, int WCH, int CW>
+static void launch_frag32_v(const ConvArgs& a, const FragPlan& p, const FragGeom& g, hipStream_t st) {
+  if constexpr (sizeof(T) == 2) {
+    const dim3 grid((unsigned)(p.ntiles * p.ncb)), block(64 * WPX * WCH);
+    const size_t lds = std::max<size_t>(8 * (size_t)frag32_ps(frag_pmax(32 * NQ * WPX)), (size_t)WPX * 32 * CW * WCH * 2 * 4);
+    const bool multi = (a.C1 + a.C2) * (int)sizeof(T) > STAGE_BYTES;
+    if (multi) hipLaunchKernelGGL((conv3x3_frag32_kernel<T, NQ, WPX, WCH, CW, true>), grid, block, lds, st, a, g);
+    else hipLaunchKernelGGL((conv3x3_frag32_kernel<T, NQ, WPX, WCH, CW, false>), grid, block, lds, st, a, g);
+  }
+}
 template <typename T>
 static void launch_frag_t(const ConvArgs& a, int dtype, hipStream_t st) {
   FragPlan p; frag_plan(a, dtype, p);
@@ -362,6 +621,15 @@ static void launch_frag_t(const ConvArgs& a, int dtype, hipStream_t st) {
   const int rows_pad = conv_rows_pad(a.Cout);
   g.ctall = rows_pad / 16; g.wfrag = rows_pad * a.Kpad;
   g.rWT = 1.0f / (float)p.WT; g.rH1 = 1.0f / (float)(a.OH + 1); g.aff = 0;
+  switch (p.v32) {
+    case 1: launch_frag32_v<T, 2, 2, 4, 1>(a, p, g, st); return;
+    case 2: launch_frag32_v<T, 2, 2, 2, 2>(a, p, g, st); return;
+    case 3: launch_frag32_v<T, 4, 1, 4, 1>(a, p, g, st); return;
+    case 4: launch_frag32_v<T, 4, 2, 2, 2>(a, p, g, st); return;
+    case 5: launch_frag32_v<T, 2, 2, 2, 1>(a, p, g, st); return;
+    case 6: launch_frag32_v<T, 4, 2, 1, 2>(a, p, g, st); return;
+    default: break;
+  }
   switch (p.variant) {
     case 0: launch_frag_v<T, 8, 1, 4>(a, p, g, st); break;
     case 1: launch_frag_v<T, 4, 2, 4>(a, p, g, st); break;

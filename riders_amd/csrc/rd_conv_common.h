@@ -122,9 +122,11 @@ __device__ __forceinline__ void round_store4(bf16_t* d, const float (&x)[4], flo
 // The narrow RC-Net layers are VALU-bound in this routine (rocprofv3: ~380 VALU instructions per wave and 128-pixel tile, 4 cycles
 // each), so everything uniform is decided once: no bias / no activation (every BatchNorm-ed convolution) skips both per element,
 // invalid pixels skip the whole channel loop, the destination row pointers are formed once per pixel, and a value is rounded once.
-template <typename T, int CT, bool ADD = true>
-__device__ __forceinline__ void conv_epilogue_store(const ConvArgs& a, f32x4 (&acc)[CT][2], const int64_t (&m)[2], const bool (&mv)[2], int n0,
-                                                    int wn, int fr, int fg, float (&ssum)[CT][4], float (&ssq)[CT][4]) {
+// General form: accumulator c of the lane holds the 4 consecutive output channels cbase + c * CSTR .. + 3 (16x16x32 tiles: cbase = n0 + (wn CT) 16
+// + 4 fg, CSTR = 16; 32x32x16 tiles: cbase = n0 + 32 (channel tile) + 4 (lane >> 5), CSTR = 8).
+template <typename T, int CT, bool ADD = true, int CSTR = 16>
+__device__ __forceinline__ void conv_epilogue_store_at(const ConvArgs& a, f32x4 (&acc)[CT][2], const int64_t (&m)[2], const bool (&mv)[2], int cbase,
+                                                       float (&ssum)[CT][4], float (&ssq)[CT][4]) {
   const int D2 = a.Cout - a.D1;
   const bool vec_ok = ((a.D1 & 3) == 0) && ((D2 & 3) == 0);
   const bool has_bias = a.bias != nullptr;
@@ -137,7 +139,7 @@ __device__ __forceinline__ void conv_epilogue_store(const ConvArgs& a, f32x4 (&a
     for (int c = 0; c < CT; c++)
 #pragma unroll
       for (int r = 0; r < 4; r++) {
-        const int cb = n0 + (wn * CT + c) * 16 + fg * 4 + r;
+        const int cb = cbase + c * CSTR + r;
         const float b = a.bias[cb < a.Cout ? cb : a.Cout - 1];
         bv[c][r] = cb < a.Cout ? b : 0.f;
       }
@@ -149,7 +151,7 @@ __device__ __forceinline__ void conv_epilogue_store(const ConvArgs& a, f32x4 (&a
     T* const p2 = (T*)a.dst2 + m[pt] * D2 - a.D1;     // indexed by the global channel (only dereferenced for co >= D1)
 #pragma unroll
     for (int c = 0; c < CT; c++) {
-      const int co = n0 + (wn * CT + c) * 16 + fg * 4;
+      const int co = cbase + c * CSTR;
       float x[4], xr[4];
 #pragma unroll
       for (int r = 0; r < 4; r++) x[r] = acc[c][pt][r];
@@ -184,6 +186,11 @@ __device__ __forceinline__ void conv_epilogue_store(const ConvArgs& a, f32x4 (&a
       for (int r = 0; r < 4; r++) { ssum[c][r] += xr[r]; ssq[c][r] += xr[r] * xr[r]; }
     }
   }
+}
+template <typename T, int CT, bool ADD = true>
+__device__ __forceinline__ void conv_epilogue_store(const ConvArgs& a, f32x4 (&acc)[CT][2], const int64_t (&m)[2], const bool (&mv)[2], int n0,
+                                                    int wn, int fr, int fg, float (&ssum)[CT][4], float (&ssq)[CT][4]) {
+  conv_epilogue_store_at<T, CT, ADD, 16>(a, acc, m, mv, n0 + wn * CT * 16 + fg * 4, ssum, ssq);
 }
 template <int CT, int BN, int WMV, int NTH = 256>
 __device__ __forceinline__ void conv_epilogue_stats(const ConvArgs& a, const float (&ssum)[CT][4], const float (&ssq)[CT][4], int n0, int wn,

@@ -96,3 +96,12 @@ class MidasNet_small_videpth(BaseModel):
             pred = self._fwd(engine.from_nchw(x), dd)
             return engine.alias(pred, pred.view(dd.shape))
         return engine.run_region(run, (x,), list(self.parameters()))
+
+
+class MidasNet_small_depth(BaseModel):
+    """modules/midas/midas_net_custom.py:136-261, model_type 'midas-small-depth' (train_zju.py:180): an alternative head the ZJU configuration
+    never selects (out of scope).  The name exists because train_zju.py:14 / val_zju.py:17 import it next to
+    MidasNet_small_videpth; constructing it says so."""
+
+    def __init__(self, *args, **kwargs):
+        raise NotImplementedError("MidasNet_small_depth ('midas-small-depth') is not on the RIDERS ZJU path; use MidasNet_small_videpth")

@@ -13,10 +13,66 @@ the work queued so far, so the exchange runs while the earlier layers are still 
 Buckets are whole stages (7-9 MB for RC-Net): xGMI is point-to-point, a ring collective is per-link bound, so few large
 messages beat many small ones.
 """
+import ctypes
+
 import torch
 import torch.distributed as dist
 
 from . import engine
+
+
+class RcclComm(object):
+    """The library's own RCCL communicator (include/riders_hip.h rd_comm_*: ncclCommInitRank on this process's device + a library-owned
+    communication stream).  The 128-byte rendezvous id is drawn by rank 0 and handed to the other ranks through `exchange(bytes or None) ->
+    bytes` -- by default a broadcast over an initialised torch.distributed group (any backend), which is used for this ONE host-side
+    exchange only; with world == 1 nothing is exchanged.  The collectives themselves never pass through torch.distributed: they are stream
+    operations of libriders_hip.so and can be captured into the step's hipGraph (rcnet_main.GraphedStep)."""
+
+    def __init__(self, rank=None, world=None, exchange=None):
+        lib = engine.L()
+        if rank is None:
+            rank = dist.get_rank() if dist.is_initialized() else 0
+        if world is None:
+            world = dist.get_world_size() if dist.is_initialized() else 1
+        self.rank, self.world = int(rank), int(world)
+        idb = ctypes.create_string_buffer(128)
+        if self.rank == 0:
+            engine._chk(lib.rd_comm_unique_id(idb), "rd_comm_unique_id")
+        if self.world > 1:
+            if exchange is None:
+                if not dist.is_initialized():
+                    raise RuntimeError("RcclComm: world > 1 needs an initialised torch.distributed group or an `exchange` callable for the rendezvous id")
+
+                def exchange(b):
+                    box = [b]
+                    dist.broadcast_object_list(box, src=0)
+                    return box[0]
+            got = exchange(bytes(idb.raw) if self.rank == 0 else None)
+            idb = ctypes.create_string_buffer(bytes(got), 128)
+        h = ctypes.c_void_p()
+        engine._chk(lib.rd_comm_init(self.rank, self.world, idb, ctypes.byref(h)), "rd_comm_init")
+        self.handle = h
+
+    def all_reduce(self, buf, mode=0):
+        """in-place fp32 sum of `buf` over the ranks on the communication stream, ordered behind the work queued on buf's current stream"""
+        assert buf.dtype == torch.float32 and buf.is_contiguous()
+        engine._chk(engine.L().rd_allreduce_bucket(self.handle, engine._p(buf), buf.numel(), int(mode), engine._stream(buf)), "rd_allreduce_bucket")
+
+    def broadcast(self, buf, root=0):
+        assert buf.dtype == torch.float32 and buf.is_contiguous()
+        engine._chk(engine.L().rd_comm_broadcast(self.handle, engine._p(buf), buf.numel(), int(root), engine._stream(buf)), "rd_comm_broadcast")
+
+    def join(self, like):
+        """the current stream of `like`'s device waits for every collective issued since the last join (the host does not block)"""
+        engine._chk(engine.L().rd_comm_join(self.handle, engine._stream(like)), "rd_comm_join")
+
+    def pending(self):
+        return int(engine.L().rd_comm_pending(self.handle))
+
+    def close(self):
+        if self.handle is not None:
+            engine.L().rd_comm_destroy(self.handle)
+            self.handle = None
 
 
 class ModuleHolder(torch.nn.Module):
@@ -39,8 +95,10 @@ class GradientAllReducer(object):
     stages: optional {tag: iterable of parameters whose gradients are final when the backward passes stage mark `tag`}.
     Without stages (or for parameters in none) the arena is reduced by `reduce()` in `bucket_bytes` slices after backward."""
 
-    def __init__(self, optimizer, bucket_bytes=32 << 20, process_group=None, stages=None, mode="all_reduce"):
-        """mode: 'all_reduce' (RCCL picks the algorithm: a ring on xGMI) or 'rs_ag' = reduce_scatter_tensor + all_gather_into_tensor in
+    def __init__(self, optimizer, bucket_bytes=32 << 20, process_group=None, stages=None, mode="all_reduce", comm=None):
+        """comm: an RcclComm -- the collectives are the library's own (rd_allreduce_bucket on its communication stream, capturable: the step is
+        ONE hipGraph); None: torch.distributed's (backend "nccl" = RCCL, or gloo in the CPU tests).
+        mode: 'all_reduce' (RCCL picks the algorithm: a ring on xGMI) or 'rs_ag' = reduce_scatter_tensor + all_gather_into_tensor in
         place on each bucket (the two halves of a ring all-reduce issued separately: same bytes per link, but the gather half of bucket k
         can interleave with the scatter half of bucket k+1 on the communication stream; for A/B on an 8-GPU node, NCCL/RCCL backend only)."""
         if mode not in ("all_reduce", "rs_ag"):
@@ -48,8 +106,12 @@ class GradientAllReducer(object):
         self.opt = optimizer
         self.mode = mode
         self.group = process_group
-        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
-        self.collective = dist.is_initialized()      # also with one rank: the same calls, a functional check of the path on a 1-GPU box
+        self.comm = comm
+        if comm is not None:
+            self.world, self.collective = comm.world, True
+        else:
+            self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+            self.collective = dist.is_initialized()      # also with one rank: the same calls, a functional check of the path on a 1-GPU box
         self.per = max(4, (bucket_bytes // 4) & ~3)
         self.stage_ranges = {}
         covered = []
@@ -84,7 +146,10 @@ class GradientAllReducer(object):
         engine.remove_stage_hook(self.on_stage)
 
     def broadcast_parameters(self, src=0):
-        if self.collective:
+        if self.comm is not None:
+            self.comm.broadcast(self.opt.flat_param, src)
+            self.comm.join(self.opt.flat_param)
+        elif self.collective:
             dist.broadcast(self.opt.flat_param, src, group=self.group)
         engine.refresh_packed()     # the packed MFMA operands cached by earlier forwards follow the new values (same buffers)
 
@@ -98,6 +163,9 @@ class GradientAllReducer(object):
 
     def _sum(self, buf):
         """Start the sum of one arena slice across the ranks -> the async work handles."""
+        if self.comm is not None:      # library-owned communication stream; ordered by rd_comm_join, no handles
+            self.comm.all_reduce(buf, 1 if self.mode == "rs_ag" else 0)
+            return []
         w = self.world
         n = buf.numel() // w * w
         if self.mode != "rs_ag" or dist.get_backend(self.group) != "nccl" or n == 0:      # (gloo has no reduce_scatter_tensor)
@@ -128,6 +196,8 @@ class GradientAllReducer(object):
         for h in self._handles:
             h.wait()
         self._handles = []
+        if self.comm is not None:
+            self.comm.join(self.opt.flat_grad)
         self._done = set()
         self._step_over = True
 

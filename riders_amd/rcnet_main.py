@@ -230,6 +230,15 @@ class GraphedStep(object):
             self.graphs, self.tags = [], []
             pool = torch.cuda.graph_pool_handle()
             state = {}
+            # The library's own collectives (parallel.RcclComm: rd_allreduce_bucket on its communication stream) are stream operations and
+            # are CAPTURED: forward + backward + every bucket's exchange + the final join are one graph, the fork / join of the communication
+            # stream are graph edges (round 5; replaces the per-stage graphs below for that transport).
+            self.captured_comm = reducer is not None and getattr(reducer, "comm", None) is not None
+            if self.captured_comm:      # RCCL sets up channels / buffers lazily on a communicator's first collective: not inside a capture
+                warm = torch.zeros(256, dtype=torch.float32, device=optimizer.flat_grad.device)
+                reducer.comm.all_reduce(warm)
+                reducer.comm.join(warm)
+                torch.cuda.synchronize()
             # With an all-reducer the capture is SPLIT at the stage marks (one graph per stage; measured 5 % slower than one graph at one rank
             # before any wire time).  ONE graph with an external event recorded at each mark (an event-record node the communication side could
             # wait on) was built in round 4 and cannot run: torch-rocm 2.10 raises "External events are disallowed in rocm" for
@@ -237,7 +246,8 @@ class GraphedStep(object):
             # that can be validated on a 1-GPU pool (a mis-ordered wait would all-reduce unfinished gradients silently).
             def begin():
                 state["g"] = torch.cuda.CUDAGraph()
-                state["ctx"] = torch.cuda.graph(state["g"], pool=pool)
+                # (thread_local: RCCL's proxy thread may touch the runtime while this thread captures)
+                state["ctx"] = torch.cuda.graph(state["g"], pool=pool, **({"capture_error_mode": "thread_local"} if self.captured_comm else {}))
                 state["ctx"].__enter__()
 
             def end(tag):
@@ -252,7 +262,11 @@ class GraphedStep(object):
             begin()
             try:
                 # without an all-reducer there is nothing to interleave: one graph (each extra graph launch costs ~1 % of an RC-Net step)
-                self.loss = staged_gradients(fwd_loss, optimizer, boundary if reducer is not None else None, loss_scale)
+                if self.captured_comm:
+                    self.loss = staged_gradients(fwd_loss, optimizer, reducer.on_stage, loss_scale)
+                    reducer.reduce()      # the remaining buckets + the join, inside the capture
+                else:
+                    self.loss = staged_gradients(fwd_loss, optimizer, boundary if reducer is not None else None, loss_scale)
             except BaseException:
                 state["ctx"].__exit__(None, None, None)
                 raise
@@ -273,7 +287,7 @@ class GraphedStep(object):
                 self.reducer.on_stage(tag)
         if self.on_replay is not None:
             self.on_replay(+1)
-        if self.reducer is not None:
+        if self.reducer is not None and not self.captured_comm:
             self.reducer.reduce()
         if self.touched is not None:      # the replay filled these slots, whatever zero_grad() calls happened since the capture
             self.opt.mark_touched(self.touched)

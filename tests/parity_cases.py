@@ -194,10 +194,12 @@ class force_frag_conv(force_patch_conv):
     """Route every eligible 3x3/stride-1 layer (Cout > 16, whole 128-byte channel chunks) to the register-fed kernel
     (rd_conv3x3_frag.hip) regardless of its block count; v128 / v64 / v32 pick the block shape for > 64 / 33..64 / 17..32 output
     channels (table kFragVariants), lin = 1 forces linear tiles wherever they fit, 0 forbids them."""
-    def __init__(self, v128=None, v64=None, v32=None, lin=None):
+    def __init__(self, v128=None, v64=None, v32=None, lin=None, m32_128=None, m32_64=None):
+        """m32_128 / m32_64: variant of the 32x32x16-MFMA form (kFrag32Variants) for > 64 / 33..64 output channels, 0 = the 16x16x32 kernel"""
         super().__init__()
         self.env["RD_CONV3X3_FRAG"] = "1"
-        for k, v in (("RD_FRAG_V128", v128), ("RD_FRAG_V64", v64), ("RD_FRAG_V32", v32), ("RD_FRAG_LIN", lin)):
+        for k, v in (("RD_FRAG_V128", v128), ("RD_FRAG_V64", v64), ("RD_FRAG_V32", v32), ("RD_FRAG_LIN", lin), ("RD_FRAG32_V128", m32_128),
+                     ("RD_FRAG32_V64", m32_64)):
             if v is not None:
                 self.env[k] = str(v)
 
@@ -284,6 +286,53 @@ def grad_add_cases(dev):
             assert _two_consumer_case(dev, cin=64, cout=64, k=3, s=1, H=9, W=19, N=1) == 1
     finally:
         engine._state["fuse_grad_add"] = old
+
+
+def _bn_conv_int(dev, cin, cout, H, W, N, half):
+    """conv -> BatchNorm (train) -> LeakyReLU on integer data in 16-bit mode: output, input gradient, weight / BatchNorm gradients, running stats"""
+    from riders_amd import engine, net_utils
+    rs = np.random.RandomState(cin * 7 + cout)
+    m = net_utils.Conv2d(cin, cout, 3, 1, 'kaiming_uniform', net_utils.activation_func('leaky_relu'), True).to(dev)
+    with torch.no_grad():
+        m.conv.weight.copy_(t(rs.randint(-1, 2, tuple(m.conv.weight.shape)).astype(np.float32)))
+        m.batch_norm.weight.copy_(t(rs.uniform(0.5, 1.5, cout).astype(np.float32)))
+        m.batch_norm.bias.copy_(t(rs.uniform(-0.5, 0.5, cout).astype(np.float32)))
+    engine.refresh_packed()
+    x = t(rs.randint(-1, 2, (N, cin, H, W)).astype(np.float32)).to(dev).requires_grad_()
+    gy = t(rs.randint(-1, 2, (N, cout, H, W)).astype(np.float32)).to(dev)
+    m.train()
+    out = m(x)
+    (out * gy).sum().backward()
+    return [out.detach().float().cpu(), x.grad.float().cpu(), m.conv.weight.grad.float().cpu(), m.batch_norm.weight.grad.float().cpu(),
+            m.batch_norm.bias.grad.float().cpu(), m.batch_norm.running_mean.cpu().clone(), m.batch_norm.running_var.cpu().clone()]
+
+
+def frag32_cases(dev, quick=False):
+    """conv3x3_frag32_kernel (v_mfma_f32_32x32x16, eight 16-byte patch planes, weight fragments re-read from the 16x16x32-ordered copy), every
+    block shape: 16-bit data path exact on integer data (forward, both data-gradient destinations, the up-sampling / concatenating gather,
+    linear tiles across images, one and several channel chunks, ragged channel counts), and conv -> BatchNorm -> LeakyReLU against the
+    16x16x32 kernel on integer data: the fused (sum, sum^2) epilogue sums exactly representable values, so everything downstream of the
+    statistics must be bit-identical between the two MFMA forms."""
+    variants128 = (2,) if quick else (1, 2, 3, 4)
+    variants64 = (5,) if quick else (5, 6)
+    with bf16_mode():
+        for v in variants128:
+            with force_frag_conv(m32_128=v, m32_64=variants64[v % len(variants64)]):
+                bf16_exact_conv_case(dev, cin=64, cout=128, k=3, s=1, N=1, up=((4, 3), (17, 6)), cin2=64)     # two chunks, concat + up-sampling; dgrad 128 -> 128 (two destinations)
+                bf16_exact_conv_case(dev, cin=64, cout=96, k=3, s=1, H=15, W=6, N=5)                           # one chunk, ragged 128-block; dgrad 96 -> 64 (64-channel block)
+                if not quick:
+                    bf16_exact_conv_case(dev, cin=128, cout=160, k=3, s=1, H=17, W=13, N=2)                    # two channel blocks, the second ragged
+                    bf16_exact_conv_case(dev, cin=192, cout=48, k=3, s=1, H=9, W=10, N=3)                      # 64-channel block, three chunks; dgrad 48 -> 192
+                    bf16_exact_conv_case(dev, cin=64, cout=256, k=3, s=1, H=15, W=6, N=9)                      # linear tiles across images
+        ref = None
+        for v128, v64 in ((0, 0),) + tuple((v, variants64[0]) for v in variants128) + ((variants128[0], variants64[-1]),):
+            with force_frag_conv(m32_128=v128, m32_64=v64, lin=1):
+                got = _bn_conv_int(dev, 64, 128, 15, 6, 3, torch.bfloat16) + _bn_conv_int(dev, 128, 64, 7, 11, 2, torch.bfloat16)
+            if ref is None:
+                ref = got
+            else:
+                for a, b, nm in zip(ref, got, ("z", "dx", "dw", "dgamma", "dbeta", "running_mean", "running_var") * 2):
+                    assert torch.equal(a, b), "32x32x16 variant (%d, %d): %s differs from the 16x16x32 kernel's" % (v128, v64, nm)
 
 
 def frag_conv_cases(dev, quick=False):

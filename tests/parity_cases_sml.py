@@ -553,3 +553,50 @@ def sml_config3_rank_case(dev, tol=TOL):
             del step
             engine.set_param_grad_allocator(None)
         assert runs[0][0] == runs[1][0] and torch.equal(runs[0][1], runs[1][1]), "SML B=4 bf16 graphed step is not reproducible"
+
+
+def sml_config4_rank_case(dev):
+    """BASELINE.json configs[4], the SML half at ITS per-rank size: batch 8 of 512x1024 frames (net input 512x1024), fp16.  (a) eval-mode
+    prediction of all 8 frames in fp16 against the fp32 HIP path on identical weights / inputs (relative L2 <= 1e-2; the fp32 path is pinned to
+    the oracle by the other cases); (b) the loss-scaled graphed fp16 training step (device pre-step + forward + loss + backward + Adam, scale
+    1024 folded back by Adam) is finite, skips nothing, and is bit-reproducible from the same state."""
+    from riders_amd import engine, sml_main
+    from riders_amd.optim import FlatAdam
+    cfg = sml_main.ZJU_SML_CONFIG
+    B, H, W = 8, 512, 1024
+    sb = sml_main.synthetic_batch(B, H, W, seed=47, device=dev)
+    hw = sml_main.net_size(H, W)
+    assert tuple(hw) == (512, 1024)
+    preds = {}
+    for mode in ("fp32", "fp16"):
+        engine.set_compute_dtype(mode); engine.clear_caches()
+        try:
+            torch.manual_seed(0)
+            m = sml_main.build_model(dev, cfg)
+            m.eval()
+            with torch.no_grad():
+                x, d, _ = sml_main.prepare_inputs(sb[0], sb[1], sb[2], sb[5], hw, cfg)
+                preds[mode] = m.forward(x, d).float().cpu()
+            del m
+        finally:
+            engine.set_compute_dtype("fp32"); engine.clear_caches()
+    assert tuple(preds["fp16"].shape) == (B, 1, 512, 1024)
+    close_l2(preds["fp16"], preds["fp32"], 1e-2, "configs[4] SML B=8 512x1024 eval prediction fp16 vs fp32")
+    engine.set_compute_dtype("fp16"); engine.clear_caches()
+    try:
+        runs = []
+        for rep in range(2):
+            torch.manual_seed(0)
+            m = sml_main.build_model(dev, cfg)
+            m.train()
+            opt = FlatAdam(m.parameters(), lr=cfg['learning_rate'])
+            step = sml_main.GraphedTrainStep(m, opt, sb, cfg, outlier=sml_main.make_outlier_removal(cfg), warmup=1, loss_scale=1024.0)
+            ls = [float(step()) for _ in range(3)]
+            assert all(np.isfinite(ls)) and opt.skipped_steps() == 0 and bool(torch.isfinite(opt.flat_param).all()), (ls, opt.skipped_steps())
+            runs.append((ls, opt.flat_param.clone()))
+            del step, opt, m
+            engine.set_param_grad_allocator(None)
+            engine.clear_caches()
+        assert runs[0][0] == runs[1][0] and torch.equal(runs[0][1], runs[1][1]), "configs[4] SML B=8 fp16 graphed step is not reproducible"
+    finally:
+        engine.set_compute_dtype("fp32"); engine.clear_caches(); engine.set_param_grad_allocator(None)

@@ -53,6 +53,10 @@ def test_frag_conv(emu):
     P.frag_conv_cases(emu, quick=True)
 
 
+def test_frag32_conv(emu):
+    P.frag32_cases(emu, quick=True)
+
+
 def test_decoder_block(emu):
     P.decoder_block_case(emu)
     P.decoder_block_case(emu, cin=16, cskip=0, cout=16, hs=(5, 4), hv=(10, 8))

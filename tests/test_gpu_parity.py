@@ -51,6 +51,10 @@ def test_grad_add_in_data_gradient_epilogue(gpu):
 
 def test_frag_conv(gpu):
     P.frag_conv_cases(gpu)
+
+
+def test_frag32_conv(gpu):
+    P.frag32_cases(gpu)
     # RC-Net sizes, routed by block count (no hooks): RoI maps as pixel runs across images, encoder maps as 2-D tiles
     P.bf16_exact_conv_case(gpu, cin=256, cout=128, k=3, s=1, H=30, W=12, N=40)
     P.bf16_exact_conv_case(gpu, cin=128, cout=64, k=3, s=1, N=24, up=((30, 12), (60, 25)), cin2=0)
@@ -338,12 +342,25 @@ def test_step_with_rccl_collectives_matches_plain_step(gpu):
         losses, modes = {}, {}
         # rccl: one graph per stage, the stage's bucket started between two replays; rccl_rs_ag: reduce_scatter + all_gather per bucket instead of
         # one all-reduce.  (One graph with external stage events is not available: torch-rocm raises "External events are disallowed in rocm".)
-        for mode in ("plain", "rccl", "rccl_rs_ag"):
+        # c_abi / c_abi_rs_ag (round 5): the library's own communicator (rd_comm_init / rd_allreduce_bucket on its communication stream): the
+        # collectives are CAPTURED, forward + backward + exchange are ONE graph
+        from riders_amd.parallel import RcclComm
+        comm = RcclComm()
+        assert comm.world == 1 and comm.pending() == 0
+        probe = torch.arange(1000, dtype=torch.float32, device=gpu)
+        for md in (0, 1):
+            comm.all_reduce(probe, md)
+        assert comm.pending() == 2
+        comm.join(probe)
+        torch.cuda.synchronize()
+        assert comm.pending() == 0 and torch.equal(probe.cpu(), torch.arange(1000, dtype=torch.float32))      # a sum over one rank
+        for mode in ("plain", "rccl", "rccl_rs_ag", "c_abi", "c_abi_rs_ag"):
             torch.manual_seed(0)
             model = rcnet_main.build_model(gpu, cfg)
             model.train()
             opt = FlatAdam(model.parameters(), lr=1e-3)
-            red = GradientAllReducer(opt, stages=rcnet_stages(model), mode="rs_ag" if mode == "rccl_rs_ag" else "all_reduce") if mode != "plain" else None
+            red = GradientAllReducer(opt, stages=rcnet_stages(model), mode="rs_ag" if mode.endswith("rs_ag") else "all_reduce",
+                                     comm=comm if mode.startswith("c_abi") else None) if mode != "plain" else None
             try:
                 if red is not None:
                     red.broadcast_parameters(0)
@@ -356,10 +373,27 @@ def test_step_with_rccl_collectives_matches_plain_step(gpu):
             finally:
                 if red is not None:
                     red.close()
-        assert modes == {"plain": 1, "rccl": 3, "rccl_rs_ag": 3}, modes
-        for m in ("rccl", "rccl_rs_ag"):
+        assert modes == {"plain": 1, "rccl": 3, "rccl_rs_ag": 3, "c_abi": 1, "c_abi_rs_ag": 1}, modes
+        for m in ("rccl", "rccl_rs_ag", "c_abi", "c_abi_rs_ag"):
             for a, b in zip(losses["plain"], losses[m]):
                 assert abs(a - b) <= 1e-3 * abs(a), (m, losses)
+        assert losses["c_abi"] == losses["plain"], losses      # same kernels, same order, an identity exchange: bit-identical
+        # the eager step (torch.autograd + stage hooks) through the same transport
+        torch.manual_seed(0)
+        model = rcnet_main.build_model(gpu, cfg)
+        model.train()
+        opt = FlatAdam(model.parameters(), lr=1e-3)
+        red = GradientAllReducer(opt, stages=rcnet_stages(model), comm=comm)
+        try:
+            red.broadcast_parameters(0)
+            eager = [float(rcnet_main.train_step(model, opt, batch, cfg, red)) for _ in range(3)]
+            assert comm.pending() == 0 and [t for t, _, _ in red.log][:2] == ["decoder_done", "attention_done"]
+        finally:
+            red.close()
+        for a, b in zip(losses["plain"], eager):
+            assert abs(a - b) <= 1e-3 * abs(a), (eager, losses)
+        torch.cuda.synchronize()
+        comm.close()
     finally:
         # quiesce before the group goes away: drop the captured graphs / reducer, drain the device and the communicator (one run in ~15 of the
         # round-4 build aborted inside destroy_process_group with the NCCL watchdog thread still polling)

@@ -108,3 +108,7 @@ def test_sml_full_size_backward(gpu):
 
 def test_sml_config3_per_rank_share(gpu):
     S.sml_config3_rank_case(gpu)
+
+
+def test_sml_config4_per_rank_batch(gpu):
+    S.sml_config4_rank_case(gpu)

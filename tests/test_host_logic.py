@@ -347,3 +347,38 @@ def test_bench_line_stays_under_the_driver_limit():
     # a pathological field cannot lose the line: optional blocks are dropped instead
     big = dict(bench.compact_line(full), comm={"x": "y" * 9000})
     assert len(bench.render_line(big)) < 6000 and "value" in json.loads(bench.render_line(big))
+
+
+def test_c_abi_comm_loopback_and_bucketing(emu):
+    """rd_comm_* through the emulator build's one-rank loop-back: RcclComm binds the entry points, GradientAllReducer(comm=...) issues the
+    stage buckets through rd_allreduce_bucket (no torch.distributed), reduce() joins, and the error convention holds (negative = argument
+    error with a message)."""
+    import ctypes
+    from riders_amd import engine
+    from riders_amd.optim import FlatAdam
+    from riders_amd.parallel import GradientAllReducer, RcclComm
+    lib = engine.L()
+    comm = RcclComm(rank=0, world=1)
+    assert comm.world == 1 and comm.pending() == 0
+    params = _toy_params()
+    opt = FlatAdam(params, lr=1e-3)
+    red = GradientAllReducer(opt, bucket_bytes=64, stages={"late": params[2:]}, comm=comm)
+    try:
+        assert red.collective and red.world == 1 and opt.grad_scale == 1.0
+        red.broadcast_parameters(0)
+        for p in params:
+            opt._grad_view(p).copy_(torch.full_like(p, 2.0))
+        red.on_stage("late")
+        n_stage = len(red.log)
+        assert n_stage >= 1 and all(t == "late" for t, _, _ in red.log) and comm.pending() == n_stage
+        red.reduce()
+        assert comm.pending() == 0 and len(red.log) == len(red.buckets)
+        assert all(bool(torch.all(opt._grad_view(p) == 2.0)) for p in params)      # a sum over one rank
+    finally:
+        red.close()
+    h = ctypes.c_void_p()
+    idb = ctypes.create_string_buffer(128)
+    assert lib.rd_comm_init(1, 2, idb, ctypes.byref(h)) < 0 and b"world" in lib.rd_last_error_string()
+    assert lib.rd_allreduce_bucket(comm.handle, None, 4, 0, None) < 0
+    assert lib.rd_allreduce_bucket(comm.handle, engine._p(opt.flat_grad), 4, 7, None) < 0 and b"allreduce_bucket" in lib.rd_last_error_string()
+    comm.close()
