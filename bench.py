@@ -345,7 +345,7 @@ def full_record(args, world, comm, ddp, head, sml, legs, cpu, val):
 
 LEG_METRIC = {"fp32": "train imgs/sec (RC-Net, batch 8, 256x512, fp32: the 1e-3 parity mode)",
               "config4": "train imgs/sec (RC-Net, batch 8 per GPU, 3x512x1024, fp16: BASELINE configs[4] per rank)",
-              "config4_sml": "train imgs/sec (Scale Map Learner, batch 8 per GPU, 512x1024, fp16: BASELINE configs[4] per rank)"}
+              "config4_sml": "train imgs/sec (Scale Map Learner, batch 8 per GPU, 512x1024 at native resolution, fp16: BASELINE configs[4] per rank)"}
 LEG_DTYPE = {"fp32": "f32", "config4": "f16", "config4_sml": "f16"}
 
 
@@ -405,7 +405,7 @@ def run_workload(kind, args, dev, world, rank, steps, warmup, **override):
     torch.manual_seed(0)  # identical initial weights on every rank
     if kind == "sml":
         batch_n, h, w = args.sml_batch, args.sml_height, args.sml_width
-        cfg = sml_main.ZJU_SML_CONFIG
+        cfg = dict(sml_main.ZJU_SML_CONFIG, net_hw=(h, w)) if getattr(args, "sml_native", False) else sml_main.ZJU_SML_CONFIG
         import contextlib
         with contextlib.redirect_stdout(sys.stderr):      # the constructor prints like the reference's; stdout carries the ONE JSON line only
             model = sml_main.build_model(dev, cfg)
@@ -435,7 +435,19 @@ def run_workload(kind, args, dev, world, rank, steps, warmup, **override):
         def step():
             return main_mod.train_step(model, opt, batch, cfg, reducer, **extra)
     else:
-        step = main_mod.GraphedTrainStep(model, opt, batch, cfg, reducer, **extra)
+        try:
+            step = main_mod.GraphedTrainStep(model, opt, batch, cfg, reducer, **extra)
+        except Exception as ex:
+            if reducer is None or reducer.comm is None:
+                raise
+            # the captured-collective step could not be built (every rank runs the same code on the same shapes, so every rank lands here):
+            # fall back to torch.distributed's collectives between per-stage graphs rather than lose the measurement
+            sys.stderr.write("bench.py: rank %d: single-graph step with captured RCCL buckets failed (%r); falling back to --comm torch\n" % (rank, ex))
+            torch.cuda.synchronize()
+            reducer.close()
+            args.rccl_comm = None
+            reducer = GradientAllReducer(opt, stages=stages, mode=args.allreduce)
+            step = main_mod.GraphedTrainStep(model, opt, batch, cfg, reducer, **extra)
     for _ in range(warmup):
         loss = step()
     settle = 0
@@ -597,6 +609,9 @@ def main():
                     help="gradient exchange per bucket: one all-reduce (RCCL's choice: a ring on xGMI) or reduce_scatter + all_gather in place")
     ap.add_argument("--full-json", default=os.path.join(ROOT, "gpurun_out", "bench_full.json"),
                     help="where the complete record (all tables) is written; stdout carries the compact line only")
+    ap.add_argument("--opts", default=os.environ.get("RIDERS_OPTS", ""),
+                    help="A/B switches, 'name=value,...': engine switches (engine.set_switch: lazy_bn, roi_u8, ...) and, prefixed rd., routing options of "
+                         "the library (rd_set_option: rd.frag_v128, rd.frag32_v128, ...); validated, unknown names fail.  Default: $RIDERS_OPTS")
     ap.add_argument("--comm", default="c_abi", choices=["c_abi", "torch"],
                     help="gradient exchange transport for N > 1: c_abi = the library's own RCCL communicator (rd_comm_*, collectives captured into the "
                          "step's ONE hipGraph), torch = torch.distributed's nccl(=RCCL) collectives between per-stage graphs (round 4)")
@@ -650,6 +665,9 @@ def main():
             sys.stderr.write("bench.py: falling back to --comm torch\n")
         comm["transport"] = "rd_comm (C ABI, captured)" if args.rccl_comm is not None else "torch.distributed"
 
+    if args.opts:
+        from riders_amd import engine
+        engine.apply_opts(args.opts)
     head = run_workload(args.workload, args, dev, world, rank, args.steps, args.warmup)
     sml = None
     legs = {}
@@ -666,7 +684,7 @@ def main():
                                        settle_seconds=min(args.settle_seconds, 1.0))
         # ... and its SML half at the same per-rank size (8 frames of 512x1024, fp16, static loss scale 1024)
         legs["config4_sml"] = run_workload("sml", args, dev, world, rank, min(sec_steps, 30), min(args.warmup, 3), dtype="fp16", sml_batch=8, sml_height=512,
-                                           sml_width=1024, loss_scale=1024.0, settle_seconds=min(args.settle_seconds, 1.0))
+                                           sml_width=1024, sml_native=True, loss_scale=1024.0, settle_seconds=min(args.settle_seconds, 1.0))
     if rank == 0:
         cpu = val = None
         if world == 1 and not args.no_cpu_baseline and args.workload == "rcnet":

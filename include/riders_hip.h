@@ -391,6 +391,13 @@ int rd_adam_step_guarded(float* param, const float* grad, float* exp_avg, float*
                          float beta2, float eps, float weight_decay, int64_t step, float grad_scale, const int32_t* skip_flag, void* stream);
 int rd_adam_skip_count(int32_t* flag, void* stream);
 
+/* ---- routing options: kernel-selection switches for tests and A/B tools (the product path reads no environment variable).  Names and
+ * ranges: kOpts in csrc/rd_api.cpp (e.g. "conv3x3_min_blocks", "frag_v128", "frag32_v128", "wgrad_tr_tw"); values are clamped; an unknown
+ * name returns -1.  rd_clear_option(NULL) / rd_clear_options() restore every default. */
+int rd_set_option(const char* name, int32_t value);
+int rd_clear_option(const char* name);
+int rd_clear_options(void);
+
 /* ---- gradient exchange over RCCL / xGMI -- replaces RCNet/rcnet_model.py:259-265 (torch.nn.DataParallel) -------------------------
  * One process per GPU.  rd_comm_unique_id: rank 0 draws the 128-byte rendezvous id (ncclGetUniqueId), the caller hands it to the other
  * ranks by any host channel; rd_comm_init: ncclCommInitRank on the CURRENT device + a library-owned communication stream.  RCCL is bound at

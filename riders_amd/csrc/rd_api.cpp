@@ -55,7 +55,40 @@ void fill_args(const rd_conv_desc* d, rd::ConvArgs& a) {
 }
 }  // namespace
 
+namespace {
+struct OptDef { const char* name; int lo, hi; };
+// index = rdt::RdOpt
+const OptDef kOpts[rdt::OPT_COUNT] = {
+  {"conv_par", 0, 1}, {"conv3x3_min_blocks", 0, 1 << 30}, {"conv_stem_min_m", 0, 1 << 30}, {"wgrad_blocks", 8, 1 << 16}, {"wgrad_tiny_min_m", 0, 1 << 30},
+  {"conv3x3_w8", 0, 1}, {"patch_bn_max", 32, 128}, {"conv3x3_g8", 1, 4096}, {"conv1x1_min_m", 0, 1 << 30}, {"conv_few_min_m", 0, 1 << 30},
+  {"frag_v128", 0, 6}, {"frag_v64", 0, 6}, {"frag_v32", 0, 6}, {"frag_split", 0, 1}, {"frag_split_blocks", 0, 1 << 30},
+  {"frag32_v128", 0, 3}, {"frag32_v64", 0, 3}, {"frag_lin", 0, 1}, {"conv3x3_frag", 0, 1}, {"bn_gen_ppt", 2, 64}, {"bn_vec_per", 0, 64},
+  {"wgrad_tr_tw", 8, 32},
+};
+int g_opt_val[rdt::OPT_COUNT];
+bool g_opt_set[rdt::OPT_COUNT];
+}  // namespace
+
 extern "C" {
+
+int rd_opt(int id, int dflt) { return (id >= 0 && id < rdt::OPT_COUNT && g_opt_set[id]) ? g_opt_val[id] : dflt; }
+int rd_opt_is_set(int id) { return id >= 0 && id < rdt::OPT_COUNT && g_opt_set[id]; }
+int rd_set_option(const char* name, int32_t value) {
+  if (!name) return fail("set_option: null name");
+  for (int i = 0; i < rdt::OPT_COUNT; i++)
+    if (!strcmp(name, kOpts[i].name)) {
+      g_opt_val[i] = value < kOpts[i].lo ? kOpts[i].lo : (value > kOpts[i].hi ? kOpts[i].hi : value);
+      g_opt_set[i] = true;
+      return 0;
+    }
+  return fail("set_option: unknown option '%s'", name);
+}
+int rd_clear_options(void) { for (int i = 0; i < rdt::OPT_COUNT; i++) g_opt_set[i] = false; return 0; }
+int rd_clear_option(const char* name) {
+  if (!name) return rd_clear_options();
+  for (int i = 0; i < rdt::OPT_COUNT; i++) if (!strcmp(name, kOpts[i].name)) { g_opt_set[i] = false; return 0; }
+  return fail("clear_option: unknown option '%s'", name);
+}
 
 int rd_version(void) { return 100; }
 const char* rd_last_error_string(void) { return g_err; }

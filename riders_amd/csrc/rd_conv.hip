@@ -1011,7 +1011,7 @@ int conv_block_pixels(int M, int Cout) { int bn, wm; conv_tiles(M, Cout, bn, wm)
 // parity-class walk of a stride-2 layer's data gradient (conv_gemm_kernel PAR): whole 128-byte channel stages, one source, no statistics
 static bool conv_gemm_par(const ConvArgs& a, int dtype) {
   const int bke = STAGE_BYTES / (dtype == 0 ? 4 : 2), Cin = a.C1 + a.C2;
-  static const bool off = getenv("RD_CONV_PAR") && atoi(getenv("RD_CONV_PAR")) == 0;      // A/B switch
+  const bool off = rd_opt(OPT_CONV_PAR, 1) == 0;      // A/B switch (rd_set_option)
   return !off && a.dil == 2 && a.stride == 1 && !a.ups && a.C2 == 0 && Cin % bke == 0 && !a.stats && !a.pool2 && a.K == a.KH * a.KW * Cin &&
          a.Kpad == a.K;
 }
@@ -1057,8 +1057,7 @@ static void launch_conv_t(const ConvArgs& a, hipStream_t st) {
 
 // 3x3/stride-1 layers with enough tiles to fill the chip go to the patch-staged kernel (rd_conv3x3.hip)
 static int conv3x3_min_blocks() {
-  const char* e = getenv("RD_CONV3X3_MIN_BLOCKS");  // test hook: 0 forces the patch kernel on small cases
-  return e ? atoi(e) : 256;
+  return rd_opt(OPT_CONV3X3_MIN_BLOCKS, 256);  // test hook (rd_set_option): 0 forces the patch kernel on small cases
 }
 static bool use_conv3x3(const ConvArgs& a, int dtype) {
   if (!conv3x3_ok(a, dtype)) return false;
@@ -1223,7 +1222,7 @@ __global__ __launch_bounds__(256) void conv_stem_kernel(ConvArgs a, int ntile) {
   }
   conv_epilogue_stats<NCT, 16 * NCT, 4>(a, ssum, ssq, 0, 0, wv, fr, fg, t, blockIdx.x, red);
 }
-static int conv_stem_min_m() { const char* e = getenv("RD_CONV_STEM_MIN_M"); return e ? atoi(e) : 65536; }      // test hook: 0 routes small cases here
+static int conv_stem_min_m() { return rd_opt(OPT_CONV_STEM_MIN_M, 65536); }      // test hook: 0 routes small cases here
 static bool conv_stem_ok(const ConvArgs& a, int dtype) {
   const int ve = dtype == 0 ? 4 : 8, taps = a.KH * a.KW;
   return a.C1 == ve && a.C2 == 0 && !a.ups && a.dil == 1 && !a.pool2 && !a.in_scale && !a.bn_y && a.KH == a.KW && (taps == 9 || taps == 49) &&
@@ -1331,7 +1330,7 @@ int wgrad_slabs(int M, int K, int Cout) {
 int wgrad_nsplit(int M, int K, int Cout) {
   int cot = pick_bn(Cout);
   int64_t tiles = cdiv(K, 128) * cdiv(Cout, cot);
-  static const int target = getenv("RD_WGRAD_BLOCKS") ? atoi(getenv("RD_WGRAD_BLOCKS")) : 1024;   // experiment hook
+  const int target = rd_opt(OPT_WGRAD_BLOCKS, 1024);   // experiment hook (rd_set_option)
   int64_t want = cdiv(target, tiles);
   int64_t maxs = cdiv(M, 64);  // at least two 32-pixel stages per split (small-M GEMMs such as the LoFTR projections need the blocks)
   int64_t s = std::max<int64_t>(1, std::min(want, maxs));
@@ -1434,8 +1433,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_tiny_kernel(WgradArgs a) {
 }
 // -> number of slabs written (0: shape not handled here)
 static bool wgrad_tiny_shape(const WgradArgs& a) {
-  const char* e = getenv("RD_WGRAD_TINY_MIN_M");      // test hook: 0 sends small cases through this kernel
-  const int min_m = e ? atoi(e) : (1 << 16);
+  const int min_m = rd_opt(OPT_WGRAD_TINY_MIN_M, 1 << 16);      // test hook (rd_set_option): 0 sends small cases through this kernel
   if (a.ups || a.C2 || a.KH != a.KW || a.M < min_m || wgrad_slabs(a.M, a.K, a.Cout) < HALO_BLOCKS) return false;
   // (the 3->32 stride-2 stem was tried here too, 8 groups of 4 output channels: 0.33 ms against 0.15 ms on the generic kernel -- every
   // group re-reads the 27-tap patch -- so it stays there)

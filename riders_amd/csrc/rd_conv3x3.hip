@@ -601,7 +601,7 @@ bool conv3x3_ok(const ConvArgs& a, int dtype) {
          (a.C1 % ve == 0);
 }
 static bool use_w8(const ConvArgs& a) {  // tile shape with the smaller padded area
-  if (const char* e = getenv("RD_CONV3X3_W8")) return atoi(e) != 0;   // experiment hook
+  if (rd_opt_is_set(OPT_CONV3X3_W8)) return rd_opt(OPT_CONV3X3_W8, 0) != 0;   // experiment hook (rd_set_option)
   int64_t a16 = cdiv(a.OH, 8) * 8 * cdiv(a.OW, 16) * 16, a8 = cdiv(a.OH, 16) * 16 * cdiv(a.OW, 8) * 8;
   return a8 < a16;
 }
@@ -617,7 +617,7 @@ static void launch3_t(const ConvArgs& a, hipStream_t st) {
   // at most 64 output channels per block by default: the 128-channel tile (32 KB of double-buffered weights + the 23 KB patch) leaves two
   // blocks per CU, the 64-channel one four -- measured 901 -> 908 img/s on the RC-Net step although every patch is staged twice as often
   // (32-channel tiles: 884).  RD_PATCH_BN_MAX=128 restores the wide tile (A/B).
-  static const int bn_max = getenv("RD_PATCH_BN_MAX") ? atoi(getenv("RD_PATCH_BN_MAX")) : 64;
+  const int bn_max = rd_opt(OPT_PATCH_BN_MAX, 64);
   const int bn = std::min(bn_max, pick_bn3(a.Cout));
   dim3 grid((unsigned)(a.N * tilesH * tilesW), (unsigned)cdiv(a.Cout, bn));
 #define RD_C3(BNV)                                                                                                   \
@@ -647,11 +647,11 @@ bool conv3x3_small_ok(const ConvArgs& a, int dtype) {
 int conv3x3_small_blocks(const ConvArgs& a, int dtype) {   // persistent blocks = BatchNorm statistics rows of this path
   const bool w8 = use_w8(a);
   const int64_t ntiles = (int64_t)a.N * cdiv(a.OH, w8 ? 16 : 8) * cdiv(a.OW, w8 ? 8 : 16);
-  const char* e = getenv("RD_CONV3X3_G8");  // test hook: few persistent blocks -> several tiles per block on small cases
+  // (test hook, rd_set_option "conv3x3_g8": few persistent blocks -> several tiles per block on small cases)
   // persistent grid = resident capacity: 8 XCDs x 32 CUs x (4 or 2 blocks per CU, see small_min_waves)
   const int cb_slots = ((a.C1 + a.C2) * (dtype == 0 ? 4 : 2)) / 16;
   const int per_cu = small_min_waves(cb_slots, pick_bn3(a.Cout));
-  return 8 * (int)std::min<int64_t>(cdiv(ntiles, 8), e ? atoi(e) : 32 * per_cu);
+  return 8 * (int)std::min<int64_t>(cdiv(ntiles, 8), rd_opt(OPT_CONV3X3_G8, 32 * per_cu));
 }
 template <typename T>
 static void launch_small_t(const ConvArgs& a, hipStream_t st) {
@@ -682,7 +682,7 @@ const char* conv3x3_small_name(const ConvArgs& a, int dtype) {
 }
 const char* conv3x3_patch_name(const ConvArgs& a, int dtype) {
   static thread_local char buf[96];
-  static const int bn_max = getenv("RD_PATCH_BN_MAX") ? atoi(getenv("RD_PATCH_BN_MAX")) : 64;
+  const int bn_max = rd_opt(OPT_PATCH_BN_MAX, 64);
   snprintf(buf, sizeof(buf), "conv3x3_patch_kernel<%s, %d, %s>", dtype == 0 ? "float" : RD_T16_NAME, std::min(bn_max, pick_bn3(a.Cout)),
            use_w8(a) ? "true" : "false");
   return buf;
@@ -692,7 +692,7 @@ void launch_conv3x3_small(const ConvArgs& a, int dtype, hipStream_t st) {
   else launch_small_t<bf16_t>(a, st);
 }
 
-static int conv1x1_min_m() { const char* e = getenv("RD_CONV1X1_MIN_M"); return e ? atoi(e) : 8192; }   // test hook: 0 forces the kernel
+static int conv1x1_min_m() { return rd_opt(OPT_CONV1X1_MIN_M, 8192); }   // test hook: 0 forces the kernel
 // 1x1 / stride 1 / single source, K within two k-steps (Cin * sizeof <= 128 bytes), Cin a multiple of the 16-byte vector
 bool conv1x1_direct_ok(const ConvArgs& a, int dtype) {
   const int es = dtype == 0 ? 4 : 2, ve = 16 / es;
@@ -839,7 +839,7 @@ __global__ __launch_bounds__(256) void pointwise_expand_kernel(ConvArgs a) {
   }
 }
 
-static int conv_few_min_m() { const char* e = getenv("RD_CONV_FEW_MIN_M"); return e ? atoi(e) : (1 << 16); }   // test hook: 0 forces the kernel
+static int conv_few_min_m() { return rd_opt(OPT_CONV_FEW_MIN_M, 1 << 16); }   // test hook: 0 forces the kernel
 bool conv_few_ok(const ConvArgs& a) {
   if (a.KH != a.KW || a.stride != 1 || a.ups || a.C2 || a.D1 != a.Cout || a.M < conv_few_min_m()) return false;
   if (a.dil == 2)      // data gradient of a stride-2 layer with 3 input channels (the 3 -> 32 stem): 32-channel dy, 3 outputs

@@ -281,7 +281,7 @@ __global__ __launch_bounds__(64 * WPX * WCH, (WPX * WCH == 8 && WCH == 4) ? 4 : 
 constexpr int frag32_ps(int pmax) { return 16 * pmax + 16; }      // plane stride in bytes: >= 16 pixels' worth, = 16 (mod 128)
 
 template <typename T, int NQ, int WPX, int WCH, int CW, bool MULTI>
-__global__ __launch_bounds__(64 * WPX * WCH, (WPX * WCH == 8) ? (CW * NQ <= 2 ? 4 : 2) : (CW * NQ <= 2 ? 4 : (CW * NQ <= 4 ? 2 : 1)))
+__global__ __launch_bounds__(64 * WPX * WCH, (WPX * WCH == 8) ? (CW * NQ <= 2 ? 4 : 2) : (CW * NQ <= 2 ? 3 : (CW * NQ <= 4 ? 2 : 1)))
 void conv3x3_frag32_kernel(ConvArgs a, FragGeom g) {
   static_assert(sizeof(T) == 2, "16-bit activations only");
   constexpr int NW = WPX * WCH, NT = 64 * NW;
@@ -502,18 +502,20 @@ struct Frag32Variant { int tp, bn, nw, nq, wpx, wch, cw; };
 static const Frag32Variant kFrag32Variants[] = {
   {0, 0, 0, 0, 0, 0, 0},
   {128, 128, 8, 2, 2, 4, 1},   // 1: eight waves of 64 pixels x 32 channels (the 16x16x32 kernel's tile)
-  {128, 128, 4, 2, 2, 2, 2},   // 2: four waves of 64 x 64: one pixel-fragment read feeds two MFMAs
-  {128, 128, 4, 4, 1, 4, 1},   // 3: four waves of 128 x 32
-  {256, 128, 4, 4, 2, 2, 2},   // 4: four waves of 128 x 64 (one block per CU)
-  {128,  64, 4, 2, 2, 2, 1},   // 5: 64-channel blocks, four waves of 64 x 32
-  {256,  64, 2, 4, 2, 1, 2},   // 6: 64-channel blocks, two waves of 128 x 64
+  {128, 128, 4, 4, 1, 4, 1},   // 2: four waves of 128 x 32
+  {128,  64, 4, 2, 2, 2, 1},   // 3: 64-channel blocks, four waves of 64 x 32
 };
+// Measured on MI355X (profiles/r05_microbench/frag32_variants.txt, RC-Net's > 64-channel decoder shapes, tools/bench_conv.py): variant 1 -- the
+// same tile, only the MFMA shape changed -- is 5 % SLOWER than the 16x16x32 kernel (0.914-0.932 vs 0.866-0.871 ms over the twelve shapes),
+// variant 2 equal within noise (0.886-0.896), wave tiles of 64 x 64 and 128 x 64 (two MFMAs per pixel-fragment read; removed again) 10-20 %
+// slower: with two or four accumulators per wave the 64-cycle latency of a 32x32x16 MFMA is exposed between dependent instructions, and
+// the kernel was not bound by matrix-instruction issue in the first place.  The default stays the 16x16x32 kernel; option frag32_v128 /
+// frag32_v64 (rd_set_option) selects these variants for A/B.
 
-// A/B hooks of tools/bench_conv.py and the tests: -1 = not set.  Variant indices are validated against the block width they may be used for
+// A/B hooks of tools/bench_conv.py and the tests (rd_set_option, never the environment).  Variant indices are validated against the block width they may be used for
 // (a 64-channel block on a <= 32-channel operand would read weight-fragment tiles past the packed rows), everything else is a plain switch.
-static int frag_env(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
-static int frag_variant_env(const char* name, int dflt, int bn_want) {
-  const int v = frag_env(name, dflt);
+static int frag_variant_opt(int id, int dflt, int bn_want) {
+  const int v = rd_opt(id, dflt);
   return (v >= 0 && v < 7 && kFragVariants[v].bn == bn_want) ? v : dflt;
 }
 
@@ -526,20 +528,20 @@ static bool frag_plan(const ConvArgs& a, int dtype, FragPlan& p) {
   // > 64 channels: eight-wave blocks (4 waves per SIMD at 126 VGPRs) when there are several chunks -- 0.847 -> 0.803 ms over the
   // seventeen RC-Net shapes of tools/bench_conv.py -- four 128-pixel waves for one-chunk layers (64 -> 128 data gradient: 0.066 vs 0.069)
   const bool multi = Cin > cke;
-  p.variant = a.Cout > 64 ? frag_variant_env("RD_FRAG_V128", multi ? 1 : 0, 128) : (a.Cout > 32 ? frag_variant_env("RD_FRAG_V64", 2, 64) : frag_variant_env("RD_FRAG_V32", 5, 32));
+  p.variant = a.Cout > 64 ? frag_variant_opt(OPT_FRAG_V128, multi ? 1 : 0, 128) : (a.Cout > 32 ? frag_variant_opt(OPT_FRAG_V64, 2, 64) : frag_variant_opt(OPT_FRAG_V32, 5, 32));
   // fewer 128 x 128 blocks than CUs (the deep encoder stages: 76 and 20 tiles): 64-channel blocks double the grid
-  if (a.Cout > 64 && !getenv("RD_FRAG_V128") && frag_env("RD_FRAG_SPLIT", 1) &&
-      cdiv((int64_t)a.M, 128) * cdiv(a.Cout, 128) < frag_env("RD_FRAG_SPLIT_BLOCKS", 256)) p.variant = 2;
+  if (a.Cout > 64 && !rd_opt_is_set(OPT_FRAG_V128) && rd_opt(OPT_FRAG_SPLIT, 1) &&
+      cdiv((int64_t)a.M, 128) * cdiv(a.Cout, 128) < rd_opt(OPT_FRAG_SPLIT_BLOCKS, 256)) p.variant = 2;
   const FragVariant& v = kFragVariants[p.variant];
   p.tp = v.tp; p.bn = v.bn; p.nw = v.nw;
   // the 32x32x16 form: 16-bit builds, linear tiles, no consumer-side BatchNorm apply (those shapes keep the 16x16x32 kernel)
   p.v32 = 0;
   if (dtype != 0 && !a.in_scale) {
-    int want = a.Cout > 64 ? frag_env("RD_FRAG32_V128", 0) : (a.Cout > 32 ? frag_env("RD_FRAG32_V64", 0) : 0);
-    if (want >= 1 && want <= 6 && kFrag32Variants[want].bn == (a.Cout > 64 ? 128 : 64)) {
+    int want = a.Cout > 64 ? rd_opt(OPT_FRAG32_V128, 0) : (a.Cout > 32 ? rd_opt(OPT_FRAG32_V64, 0) : 0);
+    if (want >= 1 && want <= 3 && kFrag32Variants[want].bn == (a.Cout > 64 ? 128 : 64)) {
       const Frag32Variant& w32 = kFrag32Variants[want];
       const int64_t strip32 = ((int64_t)a.N * (a.OH + 1) + 1) * (a.OW + 1);
-      if (strip32 < ((int64_t)1 << 22) && w32.tp + 2 * (a.OW + 1) + 2 <= frag_pmax(w32.tp) && frag_env("RD_FRAG_LIN", -1) != 0) {
+      if (strip32 < ((int64_t)1 << 22) && w32.tp + 2 * (a.OW + 1) + 2 <= frag_pmax(w32.tp) && rd_opt(OPT_FRAG_LIN, -1) != 0) {
         p.v32 = want; p.tp = w32.tp; p.bn = w32.bn; p.nw = w32.nw;
       }
     }
@@ -554,7 +556,7 @@ static bool frag_plan(const ConvArgs& a, int dtype, FragPlan& p) {
   const double effl = (double)a.M / ((double)tl * p.tp);
   const int npl = p.tp + 2 * (a.OW + 1) + 2;
   const bool lin_ok = strip < ((int64_t)1 << 22) && npl <= frag_pmax(p.tp);
-  const int force_lin = frag_env("RD_FRAG_LIN", -1);   // test hook: 1 forces linear tiles where they fit, 0 forbids them
+  const int force_lin = rd_opt(OPT_FRAG_LIN, -1);   // test hook (rd_set_option "frag_lin"): 1 forces linear tiles where they fit, 0 forbids them
   bool lin = lin_ok && effl > eff2;
   if (force_lin == 0) lin = false;
   if (force_lin == 1) lin = lin_ok;
@@ -567,7 +569,7 @@ static bool frag_plan(const ConvArgs& a, int dtype, FragPlan& p) {
 }
 bool conv3x3_frag_ok(const ConvArgs& a, int dtype) {
   FragPlan p;
-  return frag_env("RD_CONV3X3_FRAG", 1) && frag_plan(a, dtype, p);
+  return rd_opt(OPT_CONV3X3_FRAG, 1) && frag_plan(a, dtype, p);
 }
 int conv3x3_frag_tiles(const ConvArgs& a, int dtype) { FragPlan p; frag_plan(a, dtype, p); return p.ntiles; }
 int conv3x3_frag_blocks(const ConvArgs& a, int dtype) { FragPlan p; frag_plan(a, dtype, p); return p.ntiles * p.ncb; }
@@ -623,11 +625,8 @@ static void launch_frag_t(const ConvArgs& a, int dtype, hipStream_t st) {
   g.rWT = 1.0f / (float)p.WT; g.rH1 = 1.0f / (float)(a.OH + 1); g.aff = 0;
   switch (p.v32) {
     case 1: launch_frag32_v<T, 2, 2, 4, 1>(a, p, g, st); return;
-    case 2: launch_frag32_v<T, 2, 2, 2, 2>(a, p, g, st); return;
-    case 3: launch_frag32_v<T, 4, 1, 4, 1>(a, p, g, st); return;
-    case 4: launch_frag32_v<T, 4, 2, 2, 2>(a, p, g, st); return;
-    case 5: launch_frag32_v<T, 2, 2, 2, 1>(a, p, g, st); return;
-    case 6: launch_frag32_v<T, 4, 2, 1, 2>(a, p, g, st); return;
+    case 2: launch_frag32_v<T, 4, 1, 4, 1>(a, p, g, st); return;
+    case 3: launch_frag32_v<T, 2, 2, 2, 1>(a, p, g, st); return;
     default: break;
   }
   switch (p.variant) {

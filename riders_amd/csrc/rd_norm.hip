@@ -29,7 +29,7 @@ __device__ __forceinline__ void bn_rows_sum(const float2* __restrict__ p2, int r
 }
 
 // pixels per thread of the forward `*_gen` apply kernel's grid (A/B hook: RD_BN_GEN_PPT; SML step 1227-1231 img/s at 2, 1247 at 8, 1243 at 16)
-static int gen_ppt() { static const int v = getenv("RD_BN_GEN_PPT") ? std::max(2, atoi(getenv("RD_BN_GEN_PPT"))) : 8; return v; }
+static int gen_ppt() { return rd_opt(OPT_BN_GEN_PPT, 8); }
 
 // ---- BN finalize: partial[rows][C][2] -> mean/rstd + fused scale/shift, running-stat update ----
 __global__ __launch_bounds__(256) void bn_finalize_kernel(const float* __restrict__ partial, int rows, int C, double count,
@@ -714,7 +714,7 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const T* __restrict_
 static unsigned ew_grid(int64_t n) { return (unsigned)std::max<int64_t>(1, std::min<int64_t>(cdiv(n, 256), 2048)); }
 // grid of the apply kernels that take `per` vectors per thread and iteration (A/B hook RD_BN_VEC_PER: 1 = the one-vector grids)
 static unsigned ew_grid_per(int64_t n, int per) {
-  static const int force = getenv("RD_BN_VEC_PER") ? atoi(getenv("RD_BN_VEC_PER")) : 0;
+  const int force = rd_opt(OPT_BN_VEC_PER, 0);
   if (force > 0) per = force;
   return (unsigned)std::max<int64_t>(1, std::min<int64_t>(cdiv(n, 256 * (int64_t)per), 2048));
 }

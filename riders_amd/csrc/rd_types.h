@@ -62,4 +62,17 @@ struct LoftrGrads {
   int dsrc_accumulate, reserved;                                                    // dsrc_accumulate = 1: dsrc += (cross attention)
 };
 
+// ---- routing options (round 5): the kernel-selection switches that used to be read with getenv() at launch time.  One process-wide table in
+// rd_api.cpp, written ONLY through the C ABI (rd_set_option / rd_clear_options: names = the lower-case identifiers below, values clamped to
+// the ranges listed there), read by the launch code through rd_opt(): the product path consults no environment variable.  Tests use them to
+// route small cases to a particular kernel, tools/bench_*.py to A/B block shapes.
+enum RdOpt {
+  OPT_CONV_PAR, OPT_CONV3X3_MIN_BLOCKS, OPT_CONV_STEM_MIN_M, OPT_WGRAD_BLOCKS, OPT_WGRAD_TINY_MIN_M, OPT_CONV3X3_W8, OPT_PATCH_BN_MAX,
+  OPT_CONV3X3_G8, OPT_CONV1X1_MIN_M, OPT_CONV_FEW_MIN_M, OPT_FRAG_V128, OPT_FRAG_V64, OPT_FRAG_V32, OPT_FRAG_SPLIT, OPT_FRAG_SPLIT_BLOCKS,
+  OPT_FRAG32_V128, OPT_FRAG32_V64, OPT_FRAG_LIN, OPT_CONV3X3_FRAG, OPT_BN_GEN_PPT, OPT_BN_VEC_PER, OPT_WGRAD_TR_TW, OPT_COUNT
+};
+
 }  // namespace rdt
+
+extern "C" int rd_opt(int id, int dflt);      // the option's value if it has been set, else dflt
+extern "C" int rd_opt_is_set(int id);

@@ -370,7 +370,7 @@ static int tr_tw(const WgradArgs& a) {    // tile width with the smallest padded
   int64_t area = cdiv(a.OW, 16) * 16;
   if (cdiv(a.OW, 8) * 8 < area) { best = 8; area = cdiv(a.OW, 8) * 8; }
   if (Cin < 64 && cdiv(a.OW, 32) * 32 <= area) best = 32;
-  if (const char* e = getenv("RD_WGRAD_TR_TW")) { const int v = atoi(e); if (v == 8 || v == 16 || (v == 32 && Cin < 64)) best = v; }   // experiment hook
+  if (rd_opt_is_set(OPT_WGRAD_TR_TW)) { const int v = rd_opt(OPT_WGRAD_TR_TW, 16); if (v == 8 || v == 16 || (v == 32 && Cin < 64)) best = v; }   // experiment hook (rd_set_option)
   return best;
 }
 bool wgrad3x3_tr_ok(const WgradArgs& a, int dtype) {
@@ -401,14 +401,14 @@ int wgrad3x3_tr_blocks(const WgradArgs& a) {   // persistent blocks per slice = 
   tr_slices(a, cti, rt, nci, nco);
   const int tw = tr_tw(a);
   const int64_t ntiles = (int64_t)a.N * cdiv(a.OH, 8) * cdiv(a.OW, tw);
-  const char* e = getenv("RD_CONV3X3_G8");  // test hook shared with the forward kernel
+  const bool e = rd_opt_is_set(OPT_CONV3X3_G8);  // test hook shared with the forward kernel (rd_set_option "conv3x3_g8")
   // persistent grid = resident capacity: 4 blocks per CU for the light variants, 2 where registers (launch bounds) or LDS allow only two
   // (measured: 512 instead of 1024 blocks is 8-13 % faster on the 64-channel slices and halves the slab traffic)
   const int Cin = a.C1 + a.C2;
   const int lds = 2 * 16 * ((8 + 2) * (tw + 2) * (cti * 16 / 8) + 8 * tw * (rt * 16 / 8));
   const int per_cu = (cti * rt <= 2 && lds * 4 <= 160 * 1024) ? 4 : 2;
   (void)Cin;
-  int cap = e ? atoi(e) : std::max(1, 32 * per_cu / (nci * nco));
+  int cap = e ? rd_opt(OPT_CONV3X3_G8, 1) : std::max(1, 32 * per_cu / (nci * nco));
   // every block writes (and the reduction re-reads) a Cout x K slab slice: wide layers with few tiles keep >= 4 tiles per block
   if (!e && nci * nco > 1) cap = (int)std::max<int64_t>(1, std::min<int64_t>(cap, ntiles / 32));
   return 8 * (int)std::min<int64_t>(cdiv(ntiles, 8), cap);

@@ -23,19 +23,69 @@ _TORCH_DT = {RD_F32: torch.float32, RD_BF16: torch.bfloat16, RD_F16: torch.float
 _RD_DT = {torch.float32: RD_F32, torch.bfloat16: RD_BF16, torch.float16: RD_F16}
 
 _state = {"dtype": RD_F32, "tape": None, "defer_wgrad": True, "fused_loftr": True, "deterministic_roi_pool": False, "roi_tile_min_blocks": 256,
-          "fuse_upsample_bwd": os.environ.get("RIDERS_FUSE_UPSAMPLE_BWD", "1") != "0",     # A/B switch of the 2x2-summing data gradient
-          "loftr_cross_inplace": os.environ.get("RIDERS_LOFTR_CROSS_INPLACE", "1") != "0",      # A/B switch of engine.CrossGrad
-          "fuse_res_add": os.environ.get("RIDERS_FUSE_RES_ADD", "1") != "0",       # A/B switch: residual of a conv without BatchNorm / activation added in its epilogue
-          "fuse_grad_add": os.environ.get("RIDERS_FUSE_GRAD_ADD", "1") != "0",     # A/B switch: second gradient contribution added in the data-gradient epilogue
+          # A/B switches of the engine (set_switch; none of them is read from the environment by the engine itself -- tools pass RIDERS_OPTS,
+          # parsed ONCE and validated by apply_opts() below)
+          "fuse_upsample_bwd": True,       # the 2x2-summing data gradient of exact 2x up-sampling layers
+          "loftr_cross_inplace": True,     # engine.CrossGrad
+          "fuse_res_add": True,            # residual of a conv without BatchNorm / activation added in its epilogue
+          "fuse_grad_add": True,           # second gradient contribution added in the data-gradient epilogue
           # Round 4: conv -> BatchNorm -> activation outputs stay virtual (LazyAct) and the consumer applies scale / shift / activation while
           # staging its input.  Level 0: never (the separate rd_affine_act pass everywhere); 1 (default): inside residual blocks (conv1 ->
           # conv2 staging, conv2 -> fused apply + add + activation: measured faster); 2: also the decoder chain (measured SLOWER on MI355X:
           # the 3x3 kernels are vector-issue bound and the staging arithmetic costs more than the HBM pass it replaces -- DESIGN.md)
-          "lazy_bn": int(os.environ.get("RIDERS_LAZY_BN", "1")),
+          "lazy_bn": 1,
           # (round 4 measured two concurrency experiments SLOWER on MI355X / ROCm 7 and round 5 removed them from the product: convolution weight
           # gradients on a second stream -- RC-Net 1005 -> 952 img/s, 38 fork / join edges per step -- and the skip features' RoI poolings next to
           # the transformer -- 1059 -> 1049; DESIGN.md section 3 "Round 4")
-          "roi_u8": os.environ.get("RIDERS_ROI_U8", "1") != "0"}      # compact (one byte) RoI-pool arg-max; 0: int32 indices (A/B)
+          "roi_u8": True,                  # compact (one byte) RoI-pool arg-max; False: int32 indices
+          # RoI-pool backward: auto = pixel-owner gather for launches of >= roi_tile_min_blocks workgroups, fp32 L2 atomics below;
+          # gather / tile / atomic force one form
+          "roi_bwd": "auto",
+          "bn_recompute": True,            # the BatchNorm backward that does not read z
+          "dw_fused_stats": True}          # depthwise convolution with the BatchNorm statistics in its epilogue; False: separate rd_bn_stats pass
+
+_SWITCHES = {"fuse_upsample_bwd": bool, "loftr_cross_inplace": bool, "fuse_res_add": bool, "fuse_grad_add": bool, "lazy_bn": (0, 2), "roi_u8": bool,
+             "roi_bwd": ("auto", "gather", "tile", "atomic"), "bn_recompute": bool, "dw_fused_stats": bool, "roi_tile_min_blocks": (0, 1 << 30),
+             "defer_wgrad": bool, "fused_loftr": bool, "deterministic_roi_pool": bool}
+
+
+def set_switch(name, value):
+    """One validated entry point for the engine's A/B switches (tests, tools): unknown names and out-of-range values raise."""
+    kind = _SWITCHES.get(name)
+    if kind is None:
+        raise KeyError("riders_amd.engine: unknown switch %r (known: %s)" % (name, ", ".join(sorted(_SWITCHES))))
+    if kind is bool:
+        value = bool(int(value)) if not isinstance(value, bool) else value
+    elif isinstance(kind[0], int):
+        value = int(value)
+        if not kind[0] <= value <= kind[1]:
+            raise ValueError("riders_amd.engine: switch %s = %r outside [%d, %d]" % (name, value, kind[0], kind[1]))
+    elif value not in kind:
+        raise ValueError("riders_amd.engine: switch %s = %r not one of %r" % (name, value, kind))
+    _state[name] = value
+
+
+def set_option(name, value):
+    """Kernel-routing option of the library (include/riders_hip.h rd_set_option: "frag_v128", "conv3x3_min_blocks", ...); None clears it."""
+    lib = L()
+    if value is None:
+        _chk(lib.rd_clear_option(name.encode()), "rd_clear_option")
+    else:
+        _chk(lib.rd_set_option(name.encode(), int(value)), "rd_set_option")
+
+
+def apply_opts(spec):
+    """"name=value,name=value": engine switches (set_switch) and, prefixed `rd.`, library routing options (set_option).  The ONE place a
+    string from outside (tools: the RIDERS_OPTS environment variable, read by bench.py / tools/bench_*.py, never by the package) reaches them."""
+    for kv in (spec or "").split(","):
+        kv = kv.strip()
+        if not kv:
+            continue
+        k, _, v = kv.partition("=")
+        if k.startswith("rd."):
+            set_option(k[3:], None if v == "" else int(v))
+        else:
+            set_switch(k, v if k == "roi_bwd" else int(v))
 
 
 # how often a virtual activation was consumed in place / had to be written after all (tests assert that the fused routes are taken)
@@ -614,10 +664,6 @@ def as_nchw(x):
 
 # packed-weight cache: (id(param), version, mode, dtype) -> tensor
 _pack_cache = {}
-# RoI-pool backward: auto = pixel-owner gather for launches of >= roi_tile_min_blocks workgroups, fp32 L2 atomics below;
-# gather / tile / atomic force one form (A/B)
-_ROI_BWD = os.environ.get("RIDERS_ROI_BWD", "auto")
-_BN_RECOMPUTE = os.environ.get("RIDERS_BN_RECOMPUTE", "1") != "0"   # A/B switch for the BatchNorm backward that does not read z
 
 
 def packed_weight(w, mode, dt, cin_pad=0):
@@ -857,7 +903,7 @@ def conv_block(x, weight, *, x2=None, bias=None, stride=1, pad=None, up=None, bn
                                             _p(bn.running_mean), _p(bn.running_var), _p(mean), _p(rstd), _p(scale), _p(shift), st),
                  "bn finalize C=%d" % Cout), "rd_bn_finalize")
     lazy = None
-    if lazy_out and use_bn and residual is None and _state["lazy_bn"] >= int(lazy_out) and _BN_RECOMPUTE and Cout % ve == 0:
+    if lazy_out and use_bn and residual is None and _state["lazy_bn"] >= int(lazy_out) and _state["bn_recompute"] and Cout % ve == 0:
         z = None
         lazy = LazyAct(y, coef, act, slope)      # z stays virtual: the consumer applies (scale, shift, act) while it stages y
     elif res_fused:
@@ -897,7 +943,7 @@ def conv_block(x, weight, *, x2=None, bias=None, stride=1, pad=None, up=None, bn
             assert acc == acc2
             dy = torch.empty_like(y)
             dres = torch.empty_like(y) if need_res else None
-            if residual is None and _BN_RECOMPUTE:   # z = act(scale*y + shift): the backward recomputes the activation argument from y, z is not read
+            if residual is None and _state["bn_recompute"]:   # z = act(scale*y + shift): the backward recomputes the activation argument from y, z is not read
                 # algorithmic bytes: dz and y read once, dy written once (the two-pass kernels read dz and y twice)
                 _chk(_bn_bwd_recompute(dz, z, y, mean, rstd, scale, shift, partial, coef2, dgam, dbet, acc, dy, dres, pixels, Cout, act, slope, dt, st,
                                        3 * b_out, "bn backward M=%d C=%d" % (pixels, Cout)), "rd_bn_act_bwd_recompute")
@@ -1111,7 +1157,7 @@ def check_roi_overflow():
 
 def set_roi_u8(flag):
     """Compact one-byte RoI arg-max (default) or int32 pixel indices (any geometry)."""
-    _state["roi_u8"] = bool(flag)
+    set_switch("roi_u8", bool(flag))
 
 
 def roi_argmax(out):
@@ -1148,7 +1194,7 @@ def roi_pool(x, rois, output_size, spatial_scale, compact=None):
     out = torch.empty((R, PH, PW, C), dtype=x.dtype, device=x.device)
     if compact is None:
         compact = _state["roi_u8"]
-    compact = bool(compact) and C % (16 // x.element_size()) == 0 and _ROI_BWD in ("auto", "gather", "atomic") and PH < (1 << 19) and PW < (1 << 19) \
+    compact = bool(compact) and C % (16 // x.element_size()) == 0 and _state["roi_bwd"] in ("auto", "gather", "atomic") and PH < (1 << 19) and PW < (1 << 19) \
         and _state["roi_tile_min_blocks"] > 0      # (the LDS tile-accumulate backward, an A/B form, reads int32 indices)
     arg = torch.empty((R, PH, PW, C), dtype=torch.uint8 if compact else torch.int32, device=x.device)
     flag = _roi_flag(x, t) if compact else None
@@ -1171,7 +1217,7 @@ def roi_pool(x, rois, output_size, spatial_scale, compact=None):
                 return
             nblk = ((H + 15) // 16) * ((W + 15) // 16) * N * ((C + 31) // 32)
             big = nblk >= max(_state["roi_tile_min_blocks"], 1)
-            gather = _state["deterministic_roi_pool"] or _ROI_BWD == "gather" or (_ROI_BWD == "auto" and big and _state["roi_tile_min_blocks"] > 0)
+            gather = _state["deterministic_roi_pool"] or _state["roi_bwd"] == "gather" or (_state["roi_bwd"] == "auto" and big and _state["roi_tile_min_blocks"] > 0)
             if compact:      # pixel-owner gather on the large maps (or everywhere when determinism is asked for), fp32 L2 atomics on the small ones
                 if gather:
                     dx = torch.empty_like(x)
@@ -1193,7 +1239,7 @@ def roi_pool(x, rois, output_size, spatial_scale, compact=None):
                          "roi_pool bwd(gather) %dx%d C=%d" % (PH, PW, C)), "rd_roi_pool_bwd_gather")
                 t.add_grad(x, dx)
                 return
-            if C % 32 == 0 and H * W < (1 << 24) and _ROI_BWD in ("auto", "tile") and nblk >= _state["roi_tile_min_blocks"]:   # LDS tile accumulators
+            if C % 32 == 0 and H * W < (1 << 24) and _state["roi_bwd"] in ("auto", "tile") and nblk >= _state["roi_tile_min_blocks"]:   # LDS tile accumulators
                 dx = torch.empty_like(x)
                 _chk(_tb("roi_pool", roi_bytes, lambda: lib.rd_roi_pool_bwd_tile(_p(g), _p(rois), _p(arg), _p(dx), R, N, H, W, C, PH, PW,
                                                                                     float(spatial_scale), dt, st),
@@ -1692,7 +1738,7 @@ def _bn_backward(t, dz, z, y, coef, bn, act, slope, want_res):
     dbet, _ = t.param_grad(bn.bias)
     dy = torch.empty_like(y)
     dres = torch.empty_like(y) if want_res else None
-    if not _BN_RECOMPUTE:
+    if not _state["bn_recompute"]:
         _chk(lib.rd_bn_act_bwd(_p(dz), _p(z), _p(y), _p(coef[2]), _p(coef[3]), _p(coef[0]), _p(partial), _p(coef2), _p(dgam), _p(dbet), acc,
                                _p(dy), _p(dres), pixels, C, act, slope, dt, st), "rd_bn_act_bwd")
         return dy, dres
@@ -1702,7 +1748,6 @@ def _bn_backward(t, dz, z, y, coef, bn, act, slope, want_res):
     return dy, dres
 
 
-_DW_FUSED_STATS = os.environ.get("RD_DW_FUSED_STATS", "1") != "0"      # 0: separate rd_bn_stats pass (A/B, debugging)
 
 
 def dwconv_block(x, weight, *, stride=1, pad=0, out_hw=None, bn=None, act=ACT_NONE, slope=0.0, training=True):
@@ -1713,7 +1758,7 @@ def dwconv_block(x, weight, *, stride=1, pad=0, out_hw=None, bn=None, act=ACT_NO
     OH, OW = (int(out_hw[0]), int(out_hw[1])) if out_hw is not None else ((H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1)
     y = torch.empty((N, OH, OW, C), dtype=x.dtype, device=x.device)
     stats = None
-    srows = lib.rd_dwconv_stats_rows(N, OH, OW, C, k, stride) if (_DW_FUSED_STATS and bn is not None and (training or not bn.track_running_stats)) else 0
+    srows = lib.rd_dwconv_stats_rows(N, OH, OW, C, k, stride) if (_state["dw_fused_stats"] and bn is not None and (training or not bn.track_running_stats)) else 0
     if srows > 0:      # the BatchNorm statistics come out of the convolution's epilogue: no separate pass over y
         stats = torch.empty((srows, C, 2), dtype=torch.float32, device=x.device)
         _chk(lib.rd_dwconv_fwd_stats(_p(x), _p(weight.detach()), _p(y), _p(stats), N, H, W, C, OH, OW, k, stride, pad, dt, st), "rd_dwconv_fwd_stats")

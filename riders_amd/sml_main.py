@@ -96,7 +96,9 @@ def forward_loss(model, batch, cfg=ZJU_SML_CONFIG, outlier=None):
     """Pre-step + forward + loss of one SML step (train_zju.py:246-376) -> loss tensor."""
     image, mono, sparse_depth, gt, sparse_gt, rcnet = batch
     H, W = image.shape[-2:]
-    hw = net_size(H, W)
+    # network input size: the reference's transform rule (nearest resize to the multiple of 32 closest to 288, modules/midas/transforms.py:62-131
+    # through train_zju.py:164) unless cfg['net_hw'] asks for a size outright (BASELINE configs[4]: the 512x1024 frames at native resolution)
+    hw = tuple(cfg['net_hw']) if cfg.get('net_hw') else net_size(H, W)
     x, d, _ = prepare_inputs(image, mono, sparse_depth, rcnet, hw, cfg)
     gt_r, sgt_r = nearest_resize(gt, *hw), nearest_resize(sparse_gt, *hw)
     pred = model.forward(x, d)

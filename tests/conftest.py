@@ -28,8 +28,10 @@ def emu(emu_lib_path):
     _lib._install_for_tests(emu_lib_path)
     engine.clear_caches()
     engine._roi_flags.clear()      # the compact RoI arg-max's sticky overflow flag does not travel between tests
+    engine.L().rd_clear_options()  # ... nor do routing options a failed test left set
     engine.set_compute_dtype("fp32")
     yield torch.device("cpu")
+    engine.L().rd_clear_options()
     engine.clear_caches()
     _lib._uninstall_for_tests()
 
@@ -44,6 +46,8 @@ def gpu():
     _lib.load()
     engine.clear_caches()
     engine._roi_flags.clear()
+    engine.L().rd_clear_options()
     engine.set_compute_dtype("fp32")
     yield torch.device("cuda:0")
+    engine.L().rd_clear_options()
     engine.clear_caches()

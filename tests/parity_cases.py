@@ -131,17 +131,25 @@ def skinny_linear_cases(dev):
     bf16_exact_conv_case(dev, cin=1056, cout=24, k=1, s=1, H=3, W=7, N=1)
 
 
-class force_stem_kernel:
-    """Route every eligible padded-stem layer to conv_stem_kernel (rd_conv.hip) regardless of its pixel count."""
+class _force_options:
+    """Routing options of the library for the duration of a block (include/riders_hip.h rd_set_option; the kernels read no environment
+    variable): {name: value}; every option is cleared again on exit (the defaults are 'not set')."""
+    opts = {}
+
     def __enter__(self):
-        self.old = os.environ.get("RD_CONV_STEM_MIN_M")
-        os.environ["RD_CONV_STEM_MIN_M"] = "0"
+        from riders_amd import engine
+        for k, v in self.opts.items():
+            engine.set_option(k, v)
 
     def __exit__(self, *a):
-        if self.old is None:
-            del os.environ["RD_CONV_STEM_MIN_M"]
-        else:
-            os.environ["RD_CONV_STEM_MIN_M"] = self.old
+        from riders_amd import engine
+        for k in self.opts:
+            engine.set_option(k, None)
+
+
+class force_stem_kernel(_force_options):
+    """Route every eligible padded-stem layer to conv_stem_kernel (rd_conv.hip) regardless of its pixel count."""
+    opts = {"conv_stem_min_m": 0}
 
 
 def stem_kernel_cases(dev):
@@ -158,36 +166,17 @@ def stem_kernel_cases(dev):
             conv_case(dev, dict(cin=3, cout=32, k=3, s=2, H=15, W=14, N=3, bn=True, no_input_grad=True), tol=1e-2)
 
 
-class force_direct_1x1:
+class force_direct_1x1(_force_options):
     """Route every eligible 1x1 layer to the direct pointwise kernel regardless of its pixel count."""
-    def __enter__(self):
-        self.old = os.environ.get("RD_CONV1X1_MIN_M")
-        os.environ["RD_CONV1X1_MIN_M"] = "0"
-
-    def __exit__(self, *a):
-        if self.old is None:
-            del os.environ["RD_CONV1X1_MIN_M"]
-        else:
-            os.environ["RD_CONV1X1_MIN_M"] = self.old
+    opts = {"conv1x1_min_m": 0}
 
 
-class force_patch_conv:
+class force_patch_conv(_force_options):
     """Route every eligible 3x3/stride-1 layer to the patch-staged kernel (rd_conv3x3.hip) regardless of its block count."""
     def __init__(self, g8=None):
-        self.env = {"RD_CONV3X3_MIN_BLOCKS": "0"}
+        self.opts = {"conv3x3_min_blocks": 0}
         if g8 is not None:
-            self.env["RD_CONV3X3_G8"] = str(g8)     # persistent blocks per XCD of the narrow-layer kernel
-
-    def __enter__(self):
-        self.old = {k: os.environ.get(k) for k in self.env}
-        os.environ.update(self.env)
-
-    def __exit__(self, *a):
-        for k, v in self.old.items():
-            if v is None:
-                del os.environ[k]
-            else:
-                os.environ[k] = v
+            self.opts["conv3x3_g8"] = int(g8)     # persistent blocks per XCD of the narrow-layer kernel
 
 
 class force_frag_conv(force_patch_conv):
@@ -197,11 +186,10 @@ class force_frag_conv(force_patch_conv):
     def __init__(self, v128=None, v64=None, v32=None, lin=None, m32_128=None, m32_64=None):
         """m32_128 / m32_64: variant of the 32x32x16-MFMA form (kFrag32Variants) for > 64 / 33..64 output channels, 0 = the 16x16x32 kernel"""
         super().__init__()
-        self.env["RD_CONV3X3_FRAG"] = "1"
-        for k, v in (("RD_FRAG_V128", v128), ("RD_FRAG_V64", v64), ("RD_FRAG_V32", v32), ("RD_FRAG_LIN", lin), ("RD_FRAG32_V128", m32_128),
-                     ("RD_FRAG32_V64", m32_64)):
+        self.opts["conv3x3_frag"] = 1
+        for k, v in (("frag_v128", v128), ("frag_v64", v64), ("frag_v32", v32), ("frag_lin", lin), ("frag32_v128", m32_128), ("frag32_v64", m32_64)):
             if v is not None:
-                self.env[k] = str(v)
+                self.opts[k] = int(v)
 
 
 FRAG_CONV_CASES = [
@@ -227,12 +215,12 @@ def upsample_fused_dgrad_cases(dev):
     with force_patch_conv(g8=1):
         bf16_exact_conv_case(dev, cin=16, cout=32, k=3, s=1, N=3, up=((20, 13), (40, 26)))
     old = engine._state["fuse_upsample_bwd"]
-    engine._state["fuse_upsample_bwd"] = False
+    engine.set_switch("fuse_upsample_bwd", False)
     try:
         with force_patch_conv():
             bf16_exact_conv_case(dev, cin=16, cout=16, k=3, s=1, N=2, up=((8, 6), (16, 12)))
     finally:
-        engine._state["fuse_upsample_bwd"] = old
+        engine.set_switch("fuse_upsample_bwd", old)
 
 
 def _two_consumer_case(dev, cin, cout, k, s, H, W, N, half=torch.bfloat16):
@@ -280,12 +268,12 @@ def grad_add_cases(dev):
     assert _two_consumer_case(dev, cin=64, cout=128, k=3, s=2, H=10, W=14, N=2) == 0         # implicit GEMM, dilated gather
     assert _two_consumer_case(dev, cin=136, cout=24, k=1, s=1, H=7, W=9, N=2) == 0            # implicit GEMM, 1x1
     old = engine._state["fuse_grad_add"]
-    engine._state["fuse_grad_add"] = False
+    engine.set_switch("fuse_grad_add", False)
     try:
         with force_frag_conv():
             assert _two_consumer_case(dev, cin=64, cout=64, k=3, s=1, H=9, W=19, N=1) == 1
     finally:
-        engine._state["fuse_grad_add"] = old
+        engine.set_switch("fuse_grad_add", old)
 
 
 def _bn_conv_int(dev, cin, cout, H, W, N, half):
@@ -313,8 +301,8 @@ def frag32_cases(dev, quick=False):
     linear tiles across images, one and several channel chunks, ragged channel counts), and conv -> BatchNorm -> LeakyReLU against the
     16x16x32 kernel on integer data: the fused (sum, sum^2) epilogue sums exactly representable values, so everything downstream of the
     statistics must be bit-identical between the two MFMA forms."""
-    variants128 = (2,) if quick else (1, 2, 3, 4)
-    variants64 = (5,) if quick else (5, 6)
+    variants128 = (2,) if quick else (1, 2)
+    variants64 = (3,)
     with bf16_mode():
         for v in variants128:
             with force_frag_conv(m32_128=v, m32_64=variants64[v % len(variants64)]):
@@ -365,7 +353,7 @@ def frag_conv_cases(dev, quick=False):
 class force_tiny_wgrad(force_patch_conv):
     """Send the few-channel weight gradients (3->3, 3->32 stride 2, 32->1) through the register-accumulating streaming kernel at any size."""
     def __init__(self):
-        self.env = {"RD_WGRAD_TINY_MIN_M": "0", "RD_CONV_FEW_MIN_M": "0"}      # ... and the few-channel forward / data-gradient kernel
+        self.opts = {"wgrad_tiny_min_m": 0, "conv_few_min_m": 0}      # ... and the few-channel forward / data-gradient kernel
 
 
 def tiny_wgrad_cases(dev):
@@ -1232,6 +1220,45 @@ def rcnet_fullsize_oracle_case(dev, tol=TOL):
         r = torch.cat([sd[pref + k].grad.reshape(-1) for k, p in mod.named_parameters() if p.grad is not None])
         err = float((got[name] - r).norm() / r.norm())
         assert err <= 5 * tol, "full-size %s gradient: relative L2 error %.3e" % (name, err)
+
+
+def rcnet_fullsize_bf16_oracle_case(dev, tol_logits=3e-2, tol_grad=0.10):
+    """The driver-timed mode END TO END against the oracle (not against the fp32 HIP path): configs[1] geometry at full size on one image
+    (496x612 padded, R = 30 RoIs, patch 240x100), bf16 activations, with the oracle rounding at the SAME tensors (oracle/precision.py: stored
+    activations, MFMA operands, stored gradients -- bf16_mode()).  What is left between the two is summation order inside fp32 accumulators
+    and the rounding-boundary flips it causes: logits within 3e-2 of max|logit| and 2e-2 relative L2, loss within 5e-3, per-module gradient
+    vectors within 10 % relative L2 with cosine > 0.995 (measured on MI355X, round 5: printed below)."""
+    from riders_amd import engine, rcnet_main
+    cfg = rcnet_main.ZJU_CONFIG
+    batch = rcnet_main.synthetic_batch(1, 256, 512, cfg, seed=77)
+    with bf16_mode():
+        torch.manual_seed(0)
+        model = rcnet_main.build_model(dev, cfg)
+        model.train()
+        sd_e = leaves(model.encoder.state_dict()); sd_d = leaves(model.decoder.state_dict())
+        image, pts, rois, gt = rcnet_main.prepare_batch(tuple(b.to(dev) for b in batch))
+        label, valid = engine.rcnet_labels(gt, pts, 0.5)
+        logits = model.forward(image, pts, rois)
+        loss, _ = model.compute_loss(logits, label, valid, 2.5)
+        loss.backward()
+        pts_c = batch[1].reshape(-1, 3); gt_c = batch[3].reshape(-1, 1, 240, 100)
+        lab_c, val_c = O.rcnet_labels(gt_c, pts_c, 0.5)
+        ref = O.rcnet_forward(batch[0] / 255.0, pts_c, [b for b in batch[2]], sd_e, sd_d, cfg['patch_size'], True)
+        ref_loss = O.rcnet_loss(ref, lab_c, val_c, 2.5)
+        ref_loss.backward()
+        got_l, got = logits.detach().float().cpu(), _module_grads(model)
+    mx = float((got_l - ref.detach()).abs().max() / ref.detach().abs().max())
+    l2 = float((got_l - ref.detach()).norm() / ref.detach().norm())
+    print("bf16 HIP vs bf16-emulating oracle @ full size: logits max-err %.3e  L2 %.3e  loss %.6f / %.6f" % (mx, l2, float(loss), float(ref_loss)))
+    assert mx <= tol_logits and l2 <= 2e-2, (mx, l2)
+    assert abs(float(loss) - float(ref_loss)) <= 5e-3 * abs(float(ref_loss)), (float(loss), float(ref_loss))
+    for name, mod, sd, pref in (("encoder_image", model.encoder.encoder_image, sd_e, "encoder_image."), ("attention", model.encoder.attention, sd_e, "attention."),
+                                ("encoder_depth", model.encoder.encoder_depth, sd_e, "encoder_depth."), ("decoder", model.decoder, sd_d, "")):
+        r = torch.cat([sd[pref + k].grad.reshape(-1) for k, p in mod.named_parameters() if p.grad is not None]).float()
+        err = float((got[name] - r).norm() / r.norm())
+        cos = float(torch.dot(got[name], r) / (got[name].norm() * r.norm()))
+        print("bf16 HIP vs bf16-emulating oracle gradient %-14s relative L2 %.3e  cosine %.6f" % (name, err, cos))
+        assert err <= tol_grad and cos >= 0.995, "bf16 %s gradient vs the rounding oracle: relative L2 error %.3e, cosine %.5f" % (name, err, cos)
 
 
 def rcnet_config3_rank_case(dev, tol=TOL):

@@ -1,5 +1,6 @@
 """Micro-benchmark of the 3x3 convolution kernels on RC-Net's layer shapes (B = 8, R = 240 RoIs), forward and data gradient, through the C
-ABI.  A/B inside one process: RD_CONV3X3_DMA=0 routes the wide layers to the patch kernel, =1 to the LDS-DMA / 32x32x16-MFMA kernel."""
+ABI.  A/B inside one process: every argument is a mode = a list of routing options (engine.set_option / rd_set_option), e.g.
+`python tools/bench_conv.py default frag_v128=0 frag_v128=,frag32_v128=3`."""
 import ctypes, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -93,10 +94,15 @@ def run(tag):
     print("%s wgrad total %.3f ms" % (tag, wt), flush=True)
 
 
-for mode in (sys.argv[1:] or ["0", "1"]):
+for mode in (sys.argv[1:] or ["default"]):
+    # a mode is a comma-separated list of routing options of the library, "frag_v128=0,frag32_v128=3" (rd_set_option; the old RD_FRAG_V128=0
+    # spelling is accepted), "name=" clears one; anything that is not an option is only a label
     for kv in mode.split(","):
         if "=" in kv:
-            k, v = kv.split("="); os.environ[k] = v
-        else:
-            os.environ["RD_CONV3X3_DMA"] = kv
+            k, v = kv.split("=")
+            name = k[3:].lower() if k.startswith("RD_") else k
+            try:
+                engine.set_option(name, None if v == "" else int(v))
+            except (RuntimeError, ValueError):
+                pass
     run("[%s]" % mode)
