@@ -230,6 +230,12 @@ int rd_bn_act_bwd_recompute_phases(const void* dz, const void* z, const void* y,
                                    const float* scale, const float* shift, float* partial, float* coef, float* dgamma, float* dbeta,
                                    int32_t accumulate, void* dy, void* dres, int64_t pixels, int32_t C, int32_t act, float slope,
                                    int32_t dtype, int32_t phases, void* stream);
+/* The same backward when the reduce pass has already been done elsewhere: `partial` = rows x row_channels x (sum g, sum g * xhat) written by
+ * the data gradient that produced dz (rd_conv_fwd_fused with rd_conv_fusion.bn_y: the statistics rows of that launch, rd_conv_stats_rows of
+ * ITS descriptor, row_channels = its Cout >= C).  Finalize + apply only: dz and y are read once. */
+int rd_bn_act_bwd_from_partial(const void* dz, const void* y, const float* mean, const float* rstd, const float* scale, const float* shift,
+                               const float* partial, int32_t rows, int32_t row_channels, float* coef, float* dgamma, float* dbeta, int32_t accumulate,
+                               void* dy, int64_t pixels, int32_t C, int32_t act, float slope, int32_t dtype, void* stream);
 /* instantiation name (as rd_conv_fwd_kernel_name) of which = 0: rd_affine_act (flag = residual given), 1: the BatchNorm-backward reduce
    pass, 2: its apply pass (flag = recompute form) for this channel count / dtype / activation */
 const char* rd_bn_kernel_name(int32_t which, int32_t C, int32_t dtype, int32_t act, int32_t flag);

@@ -421,6 +421,16 @@ int rd_bn_act_bwd_recompute_phases(const void* dz, const void* z, const void* y,
   if (phases & 4) RD_NS(dtype, launch_bn_bwd_apply)(dz, z, y, mean, rstd, scale, coef, coef + C, dy, dres, pixels, C, act, slope, RD_DT(dtype), S(stream), shift);
   return done("rd_bn_act_bwd_recompute");
 }
+int rd_bn_act_bwd_from_partial(const void* dz, const void* y, const float* mean, const float* rstd, const float* scale, const float* shift,
+                               const float* partial, int32_t rows, int32_t row_channels, float* coef, float* dgamma, float* dbeta, int32_t accumulate,
+                               void* dy, int64_t pixels, int32_t C, int32_t act, float slope, int32_t dtype, void* stream) {
+  if (!dz || !y || !mean || !rstd || !scale || !shift || !partial || !coef || !dy || !dt_ok(dtype)) return fail("bn_act_bwd_from_partial: bad args");
+  if (rows <= 0 || row_channels < C || C <= 0) return fail("bn_act_bwd_from_partial: bad partial geometry (rows %d, row channels %d, C %d)", rows, row_channels, C);
+  if (act != RD_ACT_NONE && (C % (dtype == RD_F32 ? 4 : 8))) return fail("bn_act_bwd_from_partial: this channel count needs z");
+  rd::launch_bn_bwd_finalize(partial, rows, C, (double)pixels, dgamma, dbeta, accumulate, coef, coef + C, S(stream), row_channels);
+  RD_NS(dtype, launch_bn_bwd_apply)(dz, nullptr, y, mean, rstd, scale, coef, coef + C, dy, nullptr, pixels, C, act, slope, RD_DT(dtype), S(stream), shift);
+  return done("rd_bn_act_bwd_from_partial");
+}
 int rd_bn_act_bwd_recompute(const void* dz, const void* z, const void* y, const float* mean, const float* rstd, const float* scale,
                             const float* shift, float* partial, float* coef, float* dgamma, float* dbeta, int32_t accumulate, void* dy,
                             void* dres, int64_t pixels, int32_t C, int32_t act, float slope, int32_t dtype, void* stream) {

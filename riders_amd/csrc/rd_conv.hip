@@ -1277,8 +1277,13 @@ bool conv_in_affine_ok(const ConvArgs& a, int dtype) {
 // ConvArgs::bn_y (BatchNorm-backward sums in the data-gradient epilogue): kernels that store through conv_epilogue_store and write
 // statistics rows; dz = the first destination
 bool conv_bn_bwd_ok(const ConvArgs& a, int dtype) {
-  (void)a; (void)dtype;
-  return false;
+  // the register-fed 3x3 kernel (16x16x32 form) and the implicit-GEMM kernel: both write one statistics row per tile through
+  // conv_epilogue_stats; dz must be whole 4-channel groups of the first destination, no 2x2 reduction, no bias / activation of its own
+  if (a.pool2 || a.bias || a.act != ACT_NONE || (a.D1 & 3) || ((a.Cout - a.D1) & 3) || a.in_scale) return false;
+  if (conv_skinny_ok(a, dtype) || conv_stem_ok(a, dtype) || conv_few_ok(a) || conv1x1_direct_ok(a, dtype) || conv3x3_c1_ok(a) || use_conv3x3_small(a, dtype)) return false;
+  if (use_conv3x3_frag(a, dtype)) return !conv3x3_frag_is32(a, dtype);
+  if (use_conv3x3(a, dtype)) return false;      // (the patch-staged kernel is only a fallback since round 3)
+  return true;                                  // implicit GEMM
 }
 bool wgrad_in_affine_ok(const WgradArgs& a, int dtype) { return !wgrad_tiny_shape_fwd(a) && wgrad3x3_tr_affine_ok(a, dtype); }
 // name of the kernel launch_conv picks for this shape (bench.py groups its per-launch timings by the names rocprofv3 reports)

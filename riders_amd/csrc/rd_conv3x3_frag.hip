@@ -259,7 +259,7 @@ __global__ __launch_bounds__(64 * WPX * WCH, (WPX * WCH == 8 && WCH == 4) ? 4 : 
 #pragma unroll
       for (int c = 0; c < 2; c++) a2[c][h] = acc[c][pp * 2 + h];
     }
-    conv_epilogue_store<T, 2>(a, a2, mm, mvv, n0, wc, fr, fg, ssum, ssq);
+    conv_epilogue_store<T, 2, true, true>(a, a2, mm, mvv, n0, wc, fr, fg, ssum, ssq);
   }
   conv_epilogue_stats<2, BN, WPX, NT>(a, ssum, ssq, n0, wc, wpx, fr, fg, t, tile, reinterpret_cast<float*>(smem));
 }
@@ -571,6 +571,7 @@ bool conv3x3_frag_ok(const ConvArgs& a, int dtype) {
   FragPlan p;
   return rd_opt(OPT_CONV3X3_FRAG, 1) && frag_plan(a, dtype, p);
 }
+bool conv3x3_frag_is32(const ConvArgs& a, int dtype) { FragPlan p; return frag_plan(a, dtype, p) && p.v32 != 0; }
 int conv3x3_frag_tiles(const ConvArgs& a, int dtype) { FragPlan p; frag_plan(a, dtype, p); return p.ntiles; }
 int conv3x3_frag_blocks(const ConvArgs& a, int dtype) { FragPlan p; frag_plan(a, dtype, p); return p.ntiles * p.ncb; }
 

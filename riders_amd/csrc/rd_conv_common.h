@@ -124,7 +124,10 @@ __device__ __forceinline__ void round_store4(bf16_t* d, const float (&x)[4], flo
 // invalid pixels skip the whole channel loop, the destination row pointers are formed once per pixel, and a value is rounded once.
 // General form: accumulator c of the lane holds the 4 consecutive output channels cbase + c * CSTR .. + 3 (16x16x32 tiles: cbase = n0 + (wn CT) 16
 // + 4 fg, CSTR = 16; 32x32x16 tiles: cbase = n0 + 32 (channel tile) + 4 (lane >> 5), CSTR = 8).
-template <typename T, int CT, bool ADD = true, int CSTR = 16>
+// BNB: compile the BatchNorm-backward sums (ConvArgs::bn_y) in -- only the kernels conv_bn_bwd_ok() names pass true: in the narrow-layer
+// kernels, which sit at their register caps, the mere presence of that code cost 8-12 registers and 4-22 spilled ones (round 5, measured:
+// 0.29 ms per RC-Net step).
+template <typename T, int CT, bool ADD = true, int CSTR = 16, bool BNB = false>
 __device__ __forceinline__ void conv_epilogue_store_at(const ConvArgs& a, f32x4 (&acc)[CT][2], const int64_t (&m)[2], const bool (&mv)[2], int cbase,
                                                        float (&ssum)[CT][4], float (&ssq)[CT][4]) {
   const int D2 = a.Cout - a.D1;
@@ -182,15 +185,32 @@ __device__ __forceinline__ void conv_epilogue_store_at(const ConvArgs& a, f32x4 
           if (cc < a.Cout) Elem<T>::st((cc < a.D1 ? p1 : p2) + cc, xr[r]);
         }
       }
+      if (BNB && a.bn_y) {
+        // data gradient whose first destination is dz of a BatchNorm-ed producer (ConvArgs::bn_y = its raw output, same layout as dst1): the
+        // statistics registers collect the BatchNorm backward's sums over the STORED (rounded) dz instead -- g = dz * act'(scale y + shift),
+        // (sum g, sum g * xhat) -- with col_reduce_vec_kernel's expressions (rd_norm.hip), so the producer's backward skips its reduce pass
+        if (co + 3 < a.D1) {
+          float yy[4];
+          ld4((const T*)a.bn_y + m[pt] * a.D1 + co, yy);
 #pragma unroll
-      for (int r = 0; r < 4; r++) { ssum[c][r] += xr[r]; ssq[c][r] += xr[r] * xr[r]; }
+          for (int r = 0; r < 4; r++) {
+            const int cc = co + r;
+            float g = xr[r];
+            if (a.bn_act) g *= act_grad_from_out(yy[r] * a.bn_scale[cc] + a.bn_shift[cc], a.bn_act, a.bn_slope);
+            ssum[c][r] += g; ssq[c][r] += g * ((yy[r] - a.bn_mean[cc]) * a.bn_rstd[cc]);
+          }
+        }
+      } else {
+#pragma unroll
+        for (int r = 0; r < 4; r++) { ssum[c][r] += xr[r]; ssq[c][r] += xr[r] * xr[r]; }
+      }
     }
   }
 }
-template <typename T, int CT, bool ADD = true>
+template <typename T, int CT, bool ADD = true, bool BNB = false>
 __device__ __forceinline__ void conv_epilogue_store(const ConvArgs& a, f32x4 (&acc)[CT][2], const int64_t (&m)[2], const bool (&mv)[2], int n0,
                                                     int wn, int fr, int fg, float (&ssum)[CT][4], float (&ssq)[CT][4]) {
-  conv_epilogue_store_at<T, CT, ADD, 16>(a, acc, m, mv, n0 + wn * CT * 16 + fg * 4, ssum, ssq);
+  conv_epilogue_store_at<T, CT, ADD, 16, BNB>(a, acc, m, mv, n0 + wn * CT * 16 + fg * 4, ssum, ssq);
 }
 template <int CT, int BN, int WMV, int NTH = 256>
 __device__ __forceinline__ void conv_epilogue_stats(const ConvArgs& a, const float (&ssum)[CT][4], const float (&ssq)[CT][4], int n0, int wn,
@@ -228,7 +248,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvArgs& a, f32x4 (&acc)[CT
   for (int c = 0; c < CT; c++)
 #pragma unroll
     for (int r = 0; r < 4; r++) { ssum[c][r] = 0.f; ssq[c][r] = 0.f; }
-  conv_epilogue_store<T, CT>(a, acc, m, mv, n0, wn, fr, fg, ssum, ssq);
+  conv_epilogue_store<T, CT, true, true>(a, acc, m, mv, n0, wn, fr, fg, ssum, ssq);      // (conv_epilogue: the implicit-GEMM kernel)
   conv_epilogue_stats<CT, BN, WMV>(a, ssum, ssq, n0, wn, wm, fr, fg, t, stats_row, red);
 }
 

@@ -34,6 +34,7 @@ void launch_conv1x1_direct(const ConvArgs& a, int dtype, hipStream_t st);
 // rd_conv3x3_frag.hip
 bool conv3x3_frag_ok(const ConvArgs& a, int dtype);
 int conv3x3_frag_tiles(const ConvArgs& a, int dtype);
+bool conv3x3_frag_is32(const ConvArgs& a, int dtype);
 int conv3x3_frag_blocks(const ConvArgs& a, int dtype);
 void launch_conv3x3_frag(const ConvArgs& a, int dtype, hipStream_t st);
 const char* conv3x3_frag_name(const ConvArgs& a, int dtype);
@@ -79,7 +80,7 @@ void launch_bn_bwd_reduce(const void* dz, const void* z, const void* y, const fl
                           float* partial, int64_t pixels, int C, int act, float slope, int dtype, hipStream_t st,
                           const float* scale = nullptr, const float* shift = nullptr);
 void launch_bn_bwd_finalize(const float* partial, int rows, int C, double count, float* dgamma, float* dbeta,
-                            int accumulate, float* c1, float* c2, hipStream_t st);
+                            int accumulate, float* c1, float* c2, hipStream_t st, int row_pitch = 0);
 void launch_bn_bwd_apply(const void* dz, const void* z, const void* y, const float* mean, const float* rstd,
                          const float* scale, const float* c1, const float* c2, void* dy, void* dres, int64_t pixels,
                          int C, int act, float slope, int dtype, hipStream_t st, const float* shift = nullptr);

@@ -185,12 +185,12 @@ __global__ __launch_bounds__(256) void col_reduce_kernel(const T* __restrict__ d
 // one workgroup per channel: threads stride over the partial rows (float2 loads), wave shuffle + 4-entry LDS combine in double
 // precision (fixed order).  Four waves keep 4x the loads in flight of the one-wave version: this kernel is pure load latency.
 __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(const float* __restrict__ partial, int rows, int C, double count,
-                                                              float* dgamma, float* dbeta, int accumulate, float* c1, float* c2) {
+                                                              float* dgamma, float* dbeta, int accumulate, float* c1, float* c2, int row_pitch) {
   __shared__ double s1[4], s2[4];
   const int c = blockIdx.x, t = threadIdx.x;
   const float2* p2 = reinterpret_cast<const float2*>(partial);
   double a = 0.0, b = 0.0;
-  bn_rows_sum(p2, rows, C, c, t, a, b);
+  bn_rows_sum(p2, rows, row_pitch, c, t, a, b);      // row_pitch = channels per partial row (> C: the rows of a two-destination data gradient)
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) { a += __shfl_xor(a, o); b += __shfl_xor(b, o); }
   if ((t & 63) == 0) { s1[t >> 6] = a; s2[t >> 6] = b; }
@@ -826,8 +826,9 @@ void launch_bn_bwd_reduce(const void* dz, const void* z, const void* y, const fl
 }
 
 void launch_bn_bwd_finalize(const float* partial, int rows, int C, double count, float* dgamma, float* dbeta,
-                            int accumulate, float* c1, float* c2, hipStream_t st) {
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)C), dim3(256), 0, st, partial, rows, C, count, dgamma, dbeta, accumulate, c1, c2);
+                            int accumulate, float* c1, float* c2, hipStream_t st, int row_pitch) {
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)C), dim3(256), 0, st, partial, rows, C, count, dgamma, dbeta, accumulate, c1, c2,
+                     row_pitch > 0 ? row_pitch : C);
 }
 
 void launch_bn_bwd_apply(const void* dz, const void* z, const void* y, const float* mean, const float* rstd,
@@ -972,7 +973,7 @@ void launch_layernorm_bwd(const void* dout, const void* x, const float* gamma, c
     hipLaunchKernelGGL((layernorm_bwd_kernel<float>), dim3(nb), dim3(256), 0, st, (const float*)dout, (const float*)x, gamma, mean, rstd, (float*)dx, partial, rows, C);
   else
     hipLaunchKernelGGL((layernorm_bwd_kernel<bf16_t>), dim3(nb), dim3(256), 0, st, (const bf16_t*)dout, (const bf16_t*)x, gamma, mean, rstd, (bf16_t*)dx, partial, rows, C);
-  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)C), dim3(256), 0, st, partial, nb, C, 1.0, dgamma, dbeta, accumulate, (float*)nullptr, (float*)nullptr);
+  hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((unsigned)C), dim3(256), 0, st, partial, nb, C, 1.0, dgamma, dbeta, accumulate, (float*)nullptr, (float*)nullptr, C);
 }
 
 }  // namespace rd

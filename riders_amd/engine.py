@@ -42,10 +42,15 @@ _state = {"dtype": RD_F32, "tape": None, "defer_wgrad": True, "fused_loftr": Tru
           # gather / tile / atomic force one form
           "roi_bwd": "auto",
           "bn_recompute": True,            # the BatchNorm backward that does not read z
+          # its reduce pass inside the data-gradient epilogue that produces dz (rd_conv_fusion.bn_y; register-fed 3x3 and implicit-GEMM kernels).
+          # Built and MEASURED in round 5: 11 of RC-Net's 27 reduce launches go (bn_backward + finalize -0.13 ms per
+          # step), the data gradients that carry the sums get 0.20 ms slower (one more tensor read + ~10 vector instructions per stored
+          # element in epilogues that are already issue bound): 1021.8 -> 1007.1 img/s on one box, alternating.  Off by default.
+          "bn_bwd_fused": False,
           "dw_fused_stats": True}          # depthwise convolution with the BatchNorm statistics in its epilogue; False: separate rd_bn_stats pass
 
 _SWITCHES = {"fuse_upsample_bwd": bool, "loftr_cross_inplace": bool, "fuse_res_add": bool, "fuse_grad_add": bool, "lazy_bn": (0, 2), "roi_u8": bool,
-             "roi_bwd": ("auto", "gather", "tile", "atomic"), "bn_recompute": bool, "dw_fused_stats": bool, "roi_tile_min_blocks": (0, 1 << 30),
+             "roi_bwd": ("auto", "gather", "tile", "atomic"), "bn_recompute": bool, "bn_bwd_fused": bool, "dw_fused_stats": bool, "roi_tile_min_blocks": (0, 1 << 30),
              "defer_wgrad": bool, "fused_loftr": bool, "deterministic_roi_pool": bool}
 
 
@@ -280,6 +285,8 @@ class Tape:
         self.colsum = []        # (rd_colsum_item, partial rows tensor, bias id): bias gradients finished by one launch per backward stage
         self.dw_reduce = []     # (rd_dw_wgrad_item, partial rows tensor, weight id): depthwise weight gradients, likewise
         self.ln_grads = {}      # id(gamma) -> dict(dg, db, acc, parts=[(partial rows tensor, rows)]): LayerNorm parameter gradients, likewise
+        self.bn_src = {}        # id(output of conv -> BatchNorm -> act) -> dict(y, coef, act, slope, C, partial): lets the data gradient that
+                                # produces its dz also produce the BatchNorm backward's sums (conv_block)
 
     def requires(self, *ts):
         return any(t is not None and id(t) in self.req for t in ts)
@@ -925,25 +932,41 @@ def conv_block(x, weight, *, x2=None, bias=None, stride=1, pad=None, up=None, bn
     if not (need_in or need_res or w_req or (use_bn and bn.weight is not None and bn.weight.requires_grad)):
         return zk
     t.mark(zk)
+    if use_bn and bn_train and residual is None and _state["bn_recompute"] and _state["bn_bwd_fused"] and Cout % ve == 0:
+        t.bn_src[id(zk)] = dict(y=y, coef=coef, act=act, slope=slope, C=Cout, partial=None)
 
     def backward():
         nonlocal x
         dz = t.pop_grad(zk)
+        src = t.bn_src.pop(id(zk), None)
         if dz is None:
             return
         dres = None
         if use_bn:
             if not bn_train:
                 raise NotImplementedError("backward through eval-mode BatchNorm is not supported")
-            rows = lib.rd_bn_bwd_rows(pixels, Cout)
-            partial = torch.empty((rows, Cout, 2), dtype=torch.float32, device=x.device)
             coef2 = torch.empty((2, Cout), dtype=torch.float32, device=x.device)
             dgam, acc = t.param_grad(bn.weight)
             dbet, acc2 = t.param_grad(bn.bias)
             assert acc == acc2
             dy = torch.empty_like(y)
             dres = torch.empty_like(y) if need_res else None
-            if residual is None and _state["bn_recompute"]:   # z = act(scale*y + shift): the backward recomputes the activation argument from y, z is not read
+            part = src["partial"] if src is not None else None
+            if part is not None and part[3] is dz and not need_res:
+                # the data gradient that wrote this very dz tensor already summed (g, g * xhat) over it in its epilogue: finalize + apply only
+                lazy_counts["bn_bwd_fused"] += 1
+                _chk(_tb("bn_backward", 3 * b_out,
+                         lambda: lib.rd_bn_act_bwd_from_partial(_p(dz), _p(y), _p(mean), _p(rstd), _p(scale), _p(shift), _p(part[0]), part[1], part[2],
+                                                                _p(coef2), _p(dgam), _p(dbet), acc, _p(dy), pixels, Cout, act, slope, dt, st),
+                         "bn backward M=%d C=%d [finalize+apply, sums from the dgrad]" % (pixels, Cout), kernel=_bn_name(2, Cout, dt, act, True)),
+                     "rd_bn_act_bwd_from_partial")
+                partial = None
+            else:
+                rows = lib.rd_bn_bwd_rows(pixels, Cout)
+                partial = torch.empty((rows, Cout, 2), dtype=torch.float32, device=x.device)
+            if partial is None:
+                pass
+            elif residual is None and _state["bn_recompute"]:   # z = act(scale*y + shift): the backward recomputes the activation argument from y, z is not read
                 # algorithmic bytes: dz and y read once, dy written once (the two-pass kernels read dz and y twice)
                 _chk(_bn_bwd_recompute(dz, z, y, mean, rstd, scale, shift, partial, coef2, dgam, dbet, acc, dy, dres, pixels, Cout, act, slope, dt, st,
                                        3 * b_out, "bn backward M=%d C=%d" % (pixels, Cout)), "rd_bn_act_bwd_recompute")
@@ -1041,16 +1064,43 @@ def conv_block(x, weight, *, x2=None, bias=None, stride=1, pad=None, up=None, bn
             # x already holds a gradient contribution (a skip connection's decoder side, a residual shortcut): the kernel adds it in its
             # epilogue and the sum replaces it -- no second tensor, no separate add pass
             cur = t.grads.get(id(xk)) if (C2 == 0 and not is_up and _state.get("fuse_grad_add", True) and id(xk) in t.req) else None
-            if cur is not None and cur.shape == dxv1.shape and cur.dtype == dxv1.dtype and cur.is_contiguous() \
-                    and lib.rd_conv_add_ok(ctypes.byref(dd)):
+            if cur is not None and not (cur.shape == dxv1.shape and cur.dtype == dxv1.dtype and cur.is_contiguous() and lib.rd_conv_add_ok(ctypes.byref(dd))):
+                cur = None
+            # x is the output of conv -> BatchNorm -> act (materialised or virtual): this launch writes its dz, so its epilogue also sums the
+            # BatchNorm backward's (g, g * xhat) over what it stores -- the producer's backward then skips its reduce pass over (dz, y).  Valid
+            # only if the tensor written here is the final dz (checked by identity in the producer's backward: a later contribution makes a new one).
+            bsrc = t.bn_src.get(id(xk)) if not is_up and not cin_pad else None
+            bfus = sb = None
+            if bsrc is not None and bsrc["C"] == C1_d and id(xk) in t.req and (cur is not None or t.grads.get(id(xk)) is None):
+                bfus = _lib.ConvFusion()
+                cf = bsrc["coef"]
+                bfus.bn_y, bfus.bn_scale, bfus.bn_shift, bfus.bn_mean, bfus.bn_rstd = _p(bsrc["y"]), _p(cf[0]), _p(cf[1]), _p(cf[2]), _p(cf[3])
+                bfus.bn_act, bfus.bn_slope = bsrc["act"], bsrc["slope"]
+                if lib.rd_conv_fusion_ok(ctypes.byref(dd), ctypes.byref(bfus)):
+                    nrows = lib.rd_conv_stats_rows(ctypes.byref(dd))
+                    sb = torch.empty((nrows, Cin_d, 2), dtype=torch.float32, device=x.device)
+                else:
+                    bfus = None
+            if bfus is not None:
+                _chk(_timed("conv_gemm", flops, lambda: lib.rd_conv_fwd_fused(ctypes.byref(dd), ctypes.byref(bfus), _p(dy), None, _p(wpd), None, _p(cur),
+                                                                                 _p(dxv1), _p(dxv2), _p(sb), st),
+                            "dgrad " + shp + (" (+grad, bn sums)" if cur is not None else " (bn sums)"),
+                            b_out + b_w + (N * Hin * Win * Cin + N * Hin * Win * C1_d * (2 if cur is not None else 1)) * es,
+                            kernel=lambda: lib.rd_conv_fused_kernel_name(ctypes.byref(dd), ctypes.byref(bfus)).decode(), idem=True), "rd_conv_fwd_fused(dgrad)")
+                bsrc["partial"] = (sb, nrows, Cin_d, dxv1)
+                if cur is not None:
+                    t.grads[id(xk)] = dxv1
+                    return
+            elif cur is not None:
                 _chk(_timed("conv_gemm", flops, lambda: lib.rd_conv_fwd_add(ctypes.byref(dd), _p(dy), None, _p(wpd), None, _p(cur), _p(dxv1), st),
                             "dgrad " + shp + " (+grad)", b_out + b_w + 2 * N * Hin * Win * Cin * es,
                             kernel=lambda: lib.rd_conv_fwd_kernel_name(ctypes.byref(dd)).decode(), idem=True), "rd_conv_fwd_add(dgrad)")
                 t.grads[id(xk)] = dxv1
                 return
-            _chk(_timed("conv_gemm", flops, lambda: lib.rd_conv_fwd(ctypes.byref(dd), _p(dy), None, _p(wpd), None, _p(dxv1), _p(dxv2),
-                                                                       None, st), "dgrad " + shp, b_out + b_w + N * Hin * Win * Cin * es,
-                        kernel=lambda: lib.rd_conv_fwd_kernel_name(ctypes.byref(dd)).decode(), idem=True), "rd_conv_fwd(dgrad)")
+            else:
+                _chk(_timed("conv_gemm", flops, lambda: lib.rd_conv_fwd(ctypes.byref(dd), _p(dy), None, _p(wpd), None, _p(dxv1), _p(dxv2),
+                                                                           None, st), "dgrad " + shp, b_out + b_w + N * Hin * Win * Cin * es,
+                            kernel=lambda: lib.rd_conv_fwd_kernel_name(ctypes.byref(dd)).decode(), idem=True), "rd_conv_fwd(dgrad)")
             if is_up:
                 g1 = torch.empty_like(x)
                 _chk(_tb("elementwise", (dxv1.numel() + g1.numel()) * es,

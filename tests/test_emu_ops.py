@@ -57,6 +57,10 @@ def test_frag32_conv(emu):
     P.frag32_cases(emu, quick=True)
 
 
+def test_bn_bwd_sums_in_dgrad_epilogue(emu):
+    P.bn_bwd_fused_cases(emu, quick=True)
+
+
 def test_decoder_block(emu):
     P.decoder_block_case(emu)
     P.decoder_block_case(emu, cin=16, cskip=0, cout=16, hs=(5, 4), hv=(10, 8))

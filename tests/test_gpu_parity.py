@@ -55,6 +55,10 @@ def test_frag_conv(gpu):
 
 def test_frag32_conv(gpu):
     P.frag32_cases(gpu)
+
+
+def test_bn_bwd_sums_in_dgrad_epilogue(gpu):
+    P.bn_bwd_fused_cases(gpu)
     # RC-Net sizes, routed by block count (no hooks): RoI maps as pixel runs across images, encoder maps as 2-D tiles
     P.bf16_exact_conv_case(gpu, cin=256, cout=128, k=3, s=1, H=30, W=12, N=40)
     P.bf16_exact_conv_case(gpu, cin=128, cout=64, k=3, s=1, N=24, up=((30, 12), (60, 25)), cin2=0)

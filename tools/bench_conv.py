@@ -34,6 +34,10 @@ def timeit(fn, iters=20):
 
 
 ONLY = os.environ.get("BC_ONLY")      # e.g. "fwd:6" = forward shape index 6 only (PMC passes)
+if os.environ.get("BC_ROIS"):          # block-count quantisation study: the decoder shapes with another number of RoIs (default 240)
+    _n = int(os.environ["BC_ROIS"])
+    SHAPES = [((_n if s[0] == 240 else s[0]),) + tuple(s[1:]) for s in SHAPES]
+    DGRADS = [((_n if s[0] == 240 else s[0]),) + tuple(s[1:]) for s in DGRADS]
 
 
 def run(tag):

@@ -106,13 +106,16 @@ def child(mode, workdir):
     settings = dict(      # the kwargs literal of train_zju.py:429-487 with the paths / step counts of this run
         train_root=data_root, scenes=["scene0"], image_file="thermal_undistort", mono_pred_file="any", radar_file="radar_png", gt_file="lidar_png_int",
         sparse_gt_file="lidar_png", result_root=result_root,
-        learning_rates=[1e-4], learning_schedule=[1], batch_size=1, n_step_per_summary=10 ** 9, n_step_per_checkpoint=10 ** 9,
+        learning_rates=[1e-4], learning_schedule=[2], batch_size=2, n_step_per_summary=10 ** 9, n_step_per_checkpoint=10 ** 9,
         random_crop_size=None, input_random_filp=False, input_random_brightness=None, input_random_contrast=None, input_random_saturation=None,
         input_random_radar_noise=None,
         loss_func='l1', w_smoothness=0.2, w_weight_decay=0.0, sobel_filter_size=7, w_lidar_loss=1.5, w_edge=0.0, w_unsupervised=0.0,
         ground_truth_outlier_removal_kernel_size=3, ground_truth_outlier_removal_threshold=1.5, ground_truth_dilation_kernel_size=-1,
         restore_path=init_path, min_pred=0.1, max_pred=255.0, min_depth=0.0, max_depth=100.0, checkpoint_dirpath=ckpt, n_threads=0,
         model_type='midas-small', interp='rcnet', random_rcnet_thr=None, global_alignment='s', mono_type='inv')
+    # both frames form ONE batch and the run is two epochs = two optimisation steps: the DataLoader shuffles with a seed drawn from torch's global
+    # generator, which the two model constructors advance differently -- with one frame per step the two variants would visit the frames in
+    # different orders; the order inside a batch changes neither the BatchNorm statistics nor the loss
     losses = []
     real_print = print
 
@@ -125,7 +128,7 @@ def child(mode, workdir):
     train_zju.print = spy
     torch.manual_seed(11); np.random.seed(11); random.seed(11)
     train_zju.train(**settings)
-    final = os.path.join(ckpt, "model-2.pth")
+    final = os.path.join(ckpt, "model-2.pth")      # (train_zju.py:421: the step count at the end of training)
     sd = torch.load(final, map_location="cpu")
     init = torch.load(init_path, map_location="cpu")
     keys = [k for k in sd if sd[k].is_floating_point() and "running" not in k]
