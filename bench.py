@@ -46,9 +46,9 @@ import torch  # noqa: E402
 
 PEAK_HBM = 8000.0                                   # GB/s  (MI355X_MICROARCH.md)
 PEAK_MFMA = {"fp32": 157.3, "bf16": 2500.0, "fp16": 2500.0}       # TFLOP/s dense
-TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r04_traffic.json")   # written by tools/traffic_pass.sh (rocprofv3 --pmc passes)
-PMC_FILE = os.path.join(ROOT, "profiles", "r04_pmc_dominant.json")   # MFMA-busy / wait counters of the dominant kernel (tools/pmc_dominant.sh)
-KSTATS_FILE = "profiles/r04_%s_kernel_stats.csv"                     # rocprofv3 --kernel-trace --stats summary of the same command
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "r05_traffic.json")   # written by tools/traffic_pass.sh (rocprofv3 --pmc passes)
+PMC_FILE = os.path.join(ROOT, "profiles", "r05_pmc_dominant.json")   # MFMA-busy / wait counters of the dominant kernel (tools/pmc_dominant.sh)
+KSTATS_FILE = "profiles/r05_%s_kernel_stats.csv"                     # rocprofv3 --kernel-trace --stats summary of the same command
 RIDGE = {k: v * 1e12 / (PEAK_HBM * 1e9) for k, v in PEAK_MFMA.items()}     # FLOP/B above which the MFMA roof binds
 
 

@@ -37,6 +37,10 @@ struct FragGeom {
   int wfrag;      // element offset of the fragment-ordered copy inside the packed operand (rows_pad * Kpad)
   float rWT, rH1; // 1 / WT, 1 / (OH + 1): the strip is decoded with float reciprocals + one correction step (host: strip < 2^22 pixels)
   int aff;        // byte offset of the [2][Cin] coefficient copy of the consumer-side BatchNorm apply inside the dynamic LDS
+  int db;         // byte offset of the SECOND patch buffer (0: one buffer).  Round 5, multi-chunk layers: chunk c is staged into buffer c & 1 as
+                  // soon as a wave has finished chunk c - 1's taps, so a chunk costs ONE block barrier (store -> barrier -> taps) instead of two
+                  // (barrier -> store -> barrier -> taps): buffer c & 1 was last read during chunk c - 2, which every wave left before it
+                  // passed chunk c - 1's barrier
 };
 
 constexpr int frag_pmax(int tp) { return tp <= 128 ? 256 : (tp <= 256 ? 384 : 640); }   // patch pixels a block may stage (32 / 48 / 80 KB)
@@ -124,7 +128,7 @@ __global__ __launch_bounds__(64 * WPX * WCH, (WPX * WCH == 8 && WCH == 4) ? 4 : 
   const int st_base = ((t & 7) >> 1) * PS + (t & 1) * 16 + (t >> 3) * 32;    // plane (slot >> 1), 16-byte column (slot & 1), pixel t >> 3
   const float* const aff = reinterpret_cast<const float*>(smem + g.aff);
   if (AFF) affine_fill(const_cast<float*>(aff), a.in_scale, a.in_shift, 0, Cin, a.C1, t, NT);      // visible after the first chunk's barrier
-  auto store_patch = [&](int chunk) RD_INLINE_LAMBDA {
+  auto store_patch = [&](int chunk, int boff) RD_INLINE_LAMBDA {
     float sc[VE], sh[VE];
     const int ci = chunk * CKE + (t & 7) * VE;
     if (AFF) {
@@ -136,7 +140,7 @@ __global__ __launch_bounds__(64 * WPX * WCH, (WPX * WCH == 8 && WCH == 4) ? 4 : 
       if (((t + NT * i) >> 3) < np) {
         uint4 v = rp[i];
         if (AFF) { const uint4 z = affine16((const T*)nullptr, v, sc, sh, a.in_act, a.in_slope); if (ci < a.C1 && spix[i] >= 0) v = z; }
-        *reinterpret_cast<uint4*>(smem + st_base + i * (NT / 8) * 32) = v;
+        *reinterpret_cast<uint4*>(smem + boff + st_base + i * (NT / 8) * 32) = v;
       }
   };
 
@@ -187,6 +191,7 @@ __global__ __launch_bounds__(64 * WPX * WCH, (WPX * WCH == 8 && WCH == 4) ? 4 : 
   // BEHIND the fragment loads of their tap and get two taps of MFMA work to arrive (all of them in front of tap 0 would park every wave
   // for one HBM round trip per chunk).  Scheduling fences keep each tap's requests at its top and its reads inside it.
   constexpr int PPT = (PIT + 7) / 8;   // pieces per tap, taps 0..7
+  int boff = 0;      // byte offset of the patch buffer the current chunk reads
   auto tap_body = [&](int chunk, int tap, uint4 (&wcur)[2][2], uint4 (&wnxt)[2][2]) RD_INLINE_LAMBDA {
     load_w(min(chunk * 9 + tap + 1, nchunk * 9 - 1), wnxt);
     if (MULTI && tap < 8) {
@@ -202,7 +207,7 @@ __global__ __launch_bounds__(64 * WPX * WCH, (WPX * WCH == 8 && WCH == 4) ? 4 : 
       uint4 pf[NPT];
 #pragma unroll
       for (int pt = 0; pt < NPT; pt++)
-        pf[pt] = *reinterpret_cast<const uint4*>(smem + lbase[LIN ? kr : 0][kh] + (LIN ? pt * 16 + kc : (pt + kr) * 18 + kc) * 32);
+        pf[pt] = *reinterpret_cast<const uint4*>(smem + boff + lbase[LIN ? kr : 0][kh] + (LIN ? pt * 16 + kc : (pt + kr) * 18 + kc) * 32);
 #pragma unroll
       for (int c = 0; c < 2; c++) {
         const uint4 wf = wcur[c][kh];
@@ -230,8 +235,9 @@ __global__ __launch_bounds__(64 * WPX * WCH, (WPX * WCH == 8 && WCH == 4) ? 4 : 
   for (int i = 0; i < PIT; i++) load_piece(0, i, false);
   load_w(0, wa);
   for (int chunk = 0; chunk < nchunk; chunk++) {
-    __syncthreads();            // every wave is done with the previous chunk's patch
-    store_patch(chunk);
+    boff = (MULTI && (chunk & 1)) ? g.db : 0;
+    if (!(MULTI && g.db)) __syncthreads();            // one buffer: every wave is done with the previous chunk's patch
+    store_patch(chunk, boff);
     __syncthreads();
     tap_body(chunk, 0, wa, wb); tap_body(chunk, 1, wb, wa); tap_body(chunk, 2, wa, wb);
     tap_body(chunk, 3, wb, wa); tap_body(chunk, 4, wa, wb); tap_body(chunk, 5, wb, wa);
@@ -596,9 +602,14 @@ static void launch_frag_v(const ConvArgs& a, const FragPlan& p, const FragGeom& 
   const dim3 grid((unsigned)(p.ntiles * p.ncb)), block(64 * WPX * WCH);
   const bool aff = a.in_scale != nullptr;
   FragGeom g = g_;
-  g.aff = std::max(4 * p.ps, WPX * 32 * WCH * 2 * 4);      // coefficient copy behind the planes / the statistics scratch
-  const size_t lds = (size_t)g.aff + (aff ? (size_t)(a.C1 + a.C2) * 8 : 0);
   const bool multi = (a.C1 + a.C2) * (int)sizeof(T) > STAGE_BYTES;
+  const int one = std::max(4 * p.ps, WPX * 32 * WCH * 2 * 4);      // the planes / the statistics scratch
+  // second patch buffer of the multi-chunk layers (128-pixel tiles: two blocks of 2 x 33 KB still share a CU).  Measured (round 5,
+  // tools/r05_fragdb.sh, alternating): 0.782 against 0.784-0.785 ms over the seventeen shapes of tools/bench_conv.py, the RC-Net step
+  // 1077.6 against 1077.5 img/s -- the second barrier per chunk was not what the waves wait for.  Option frag_db, off by default.
+  g.db = (multi && one <= 36 * 1024 && rd_opt(OPT_FRAG_DB, 0)) ? one : 0;
+  g.aff = one + g.db;                                               // coefficient copy behind the buffer(s)
+  const size_t lds = (size_t)g.aff + (aff ? (size_t)(a.C1 + a.C2) * 8 : 0);
 #define RD_FR(LINV, MULTIV)                                                                                                         \
   { if (aff) hipLaunchKernelGGL((conv3x3_frag_kernel<T, NPT, WPX, WCH, LINV, MULTIV, true>), grid, block, lds, st, a, g);          \
     else hipLaunchKernelGGL((conv3x3_frag_kernel<T, NPT, WPX, WCH, LINV, MULTIV>), grid, block, lds, st, a, g); }

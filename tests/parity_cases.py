@@ -183,11 +183,12 @@ class force_frag_conv(force_patch_conv):
     """Route every eligible 3x3/stride-1 layer (Cout > 16, whole 128-byte channel chunks) to the register-fed kernel
     (rd_conv3x3_frag.hip) regardless of its block count; v128 / v64 / v32 pick the block shape for > 64 / 33..64 / 17..32 output
     channels (table kFragVariants), lin = 1 forces linear tiles wherever they fit, 0 forbids them."""
-    def __init__(self, v128=None, v64=None, v32=None, lin=None, m32_128=None, m32_64=None):
+    def __init__(self, v128=None, v64=None, v32=None, lin=None, m32_128=None, m32_64=None, db=None):
         """m32_128 / m32_64: variant of the 32x32x16-MFMA form (kFrag32Variants) for > 64 / 33..64 output channels, 0 = the 16x16x32 kernel"""
         super().__init__()
         self.opts["conv3x3_frag"] = 1
-        for k, v in (("frag_v128", v128), ("frag_v64", v64), ("frag_v32", v32), ("frag_lin", lin), ("frag32_v128", m32_128), ("frag32_v64", m32_64)):
+        for k, v in (("frag_v128", v128), ("frag_v64", v64), ("frag_v32", v32), ("frag_lin", lin), ("frag32_v128", m32_128), ("frag32_v64", m32_64),
+                     ("frag_db", db)):      # db = 1: two patch buffers in the multi-chunk layers (one barrier per chunk)
             if v is not None:
                 self.opts[k] = int(v)
 
@@ -335,12 +336,14 @@ def frag_conv_cases(dev, quick=False):
         with force_frag_conv(v128=1, v64=4, v32=6, lin=1):
             conv_case(dev, FRAG_CONV_CASES[4])
             conv_case(dev, FRAG_CONV_CASES[5])
+        with force_frag_conv(db=1):
+            bf16_exact_conv_case(dev, cin=192, cout=96, k=3, s=1, H=9, W=10, N=3)      # three chunks through both patch buffers
         return
     for kw in (dict(), dict(v128=1, v64=3, v32=6), dict(v64=4, lin=0), dict(lin=1)):
         with force_frag_conv(**kw):
             for c in FRAG_CONV_CASES:
                 conv_case(dev, c)
-    for kw in (dict(), dict(v128=1, v64=3, lin=1), dict(v64=4, lin=0)):
+    for kw in (dict(), dict(v128=1, v64=3, lin=1), dict(v64=4, lin=0), dict(db=1), dict(db=1, lin=1, v128=0)):
         with force_frag_conv(**kw):
             bf16_exact_conv_case(dev, cin=64, cout=64, k=3, s=1, H=9, W=19, N=1)
             bf16_exact_conv_case(dev, cin=64, cout=128, k=3, s=1, N=1, up=((4, 3), (17, 6)), cin2=64)     # concat + nearest up-sampling in the gather

@@ -1,4 +1,4 @@
-"""Aggregate the counter pass of tools/pmc_dominant.sh per kernel instantiation -> profiles/r04_pmc_dominant.json.
+"""Aggregate the counter pass of tools/pmc_dominant.sh per kernel instantiation -> profiles/r05_pmc_dominant.json.
 mfma_util = SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8): the fraction of the chip's matrix-pipe cycles that were busy
 while the kernel ran.  SQ_VALU_MFMA_BUSY_CYCLES counts cycles summed over the 1024 SIMDs (16 per 16x16x32 bf16 MFMA: 47.2 M for 2.95 M
 instructions); rocprofv3 reports GRBM_GUI_ACTIVE summed over the 8 XCDs (958 K for a ~50 us dispatch at ~2.3 GHz = 8 x 120 K), hence the / 8.  wait fractions are of SQ_WAVE_CYCLES (quad-cycles; WAIT_ANY = parked at s_waitcnt / barrier, WAIT_INST_ANY = issue stall)."""
@@ -24,7 +24,7 @@ def main():
             c = d.setdefault(row["Counter_Name"], [0.0, 0])
             c[0] += float(row["Counter_Value"]); c[1] += 1
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    path = os.path.join(root, "profiles", "r04_pmc_dominant.json")
+    path = os.path.join(root, "profiles", "r05_pmc_dominant.json")
     db = json.load(open(path)) if os.path.exists(path) else {}
     db[wl] = {}
     for k, d in agg.items():

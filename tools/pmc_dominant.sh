@@ -1,7 +1,7 @@
 #!/bin/bash
 # MFMA-busy / wait counters of every named kernel of the bench step on the DEFAULT build (north_star: "rocprof-reported ... MFMA utilisation"):
 # one rocprofv3 --pmc pass (SQ counters + GRBM_GUI_ACTIVE, --kernel-trace only) over 2 eager steps of the bench command, aggregated per kernel
-# instantiation into profiles/r04_pmc_dominant.json, which bench.py attaches to its `roofline` object for the dominant kernel.
+# instantiation into profiles/r05_pmc_dominant.json, which bench.py attaches to its `roofline` object for the dominant kernel.
 # Usage (GPU box, repo root):  bash tools/pmc_dominant.sh rcnet|sml
 set -u
 wl=${1:-rcnet}; shift || true

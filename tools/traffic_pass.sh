@@ -2,7 +2,7 @@
 # HBM traffic of every kernel family of the bench step from PMC counters, as MI355X_MICROARCH.md prescribes: FETCH_SIZE and WRITE_SIZE
 # in SEPARATE rocprofv3 passes (they do not fit one pass), --kernel-trace only, same command as the bench (eager launches, 3 steps).
 # Usage (on the GPU box, from the repo root):  bash tools/traffic_pass.sh rcnet|sml [extra bench args]
-# Writes gpurun_out/traffic_<workload>/{fetch,write}/*counter_collection.csv and merges the per-family bytes into profiles/r04_traffic.json.
+# Writes gpurun_out/traffic_<workload>/{fetch,write}/*counter_collection.csv and merges the per-family bytes into profiles/r05_traffic.json.
 set -u
 wl=${1:-rcnet}; shift || true
 export TMPDIR=/tmp
