@@ -63,7 +63,7 @@ const OptDef kOpts[rdt::OPT_COUNT] = {
   {"conv3x3_w8", 0, 1}, {"patch_bn_max", 32, 128}, {"conv3x3_g8", 1, 4096}, {"conv1x1_min_m", 0, 1 << 30}, {"conv_few_min_m", 0, 1 << 30},
   {"frag_v128", 0, 6}, {"frag_v64", 0, 6}, {"frag_v32", 0, 6}, {"frag_split", 0, 1}, {"frag_split_blocks", 0, 1 << 30},
   {"frag32_v128", 0, 3}, {"frag32_v64", 0, 3}, {"frag_lin", 0, 1}, {"conv3x3_frag", 0, 1}, {"bn_gen_ppt", 2, 64}, {"bn_vec_per", 0, 64},
-  {"wgrad_tr_tw", 8, 32}, {"frag_db", 0, 1},
+  {"wgrad_tr_tw", 8, 32}, {"frag_db", 0, 1}, {"wgrad_fit", 0, 1},
 };
 int g_opt_val[rdt::OPT_COUNT];
 bool g_opt_set[rdt::OPT_COUNT];
@@ -306,6 +306,11 @@ int64_t rd_conv_wgrad_workspace_bytes(const rd_conv_desc* d) {
   rd::WgradArgs a; fill_wgrad_args(d, a);
   int ns = rd::wgrad_slabs(a.M, a.K, d->Cout);
   if (RD_NS(d->dtype, wgrad3x3_tr_ok)(a, RD_DT(d->dtype))) ns = std::max(ns, rd::wgrad3x3_tr_blocks(a));
+  // the same shape with a consumer-side BatchNorm apply runs on the 8 x TW kernel even where the map-fitted one takes the plain launch
+  static const float kDummy = 0.f;
+  a.in_scale = &kDummy;
+  if (RD_NS(d->dtype, wgrad3x3_tr_ok)(a, RD_DT(d->dtype))) ns = std::max(ns, rd::wgrad3x3_tr_blocks(a));
+  a.in_scale = nullptr;
   return (int64_t)(ns + 1) * d->Cout * a.K * (int64_t)sizeof(float);
 }
 int rd_conv_wgrad(const rd_conv_desc* d, const void* src1, const void* src2, const void* dy, float* workspace, float* dw,

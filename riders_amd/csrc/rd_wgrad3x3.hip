@@ -357,6 +357,173 @@ __global__ __launch_bounds__(64 * NWV, NWV == 8 ? (RT >= 4 ? 2 : 4) : ((CTI * RT
       }
 }
 
+
+// ---- round 5: map-fitted tiles, 64 x 64 output slices, v_mfma_f32_32x32x16 (weight-gradient half) -------------------------
+// The kernel above tiles a map with 8 x 8 / 8 x 16 pixel tiles whatever its width: on RC-Net's RoI maps (15x6, 30x12, 60x25) 27-30 % of the
+// issued MFMAs multiply padding, and a 64-channel input slice is staged once per 32 output channels (PMC round 4: 36 % padded MFMAs, 1.71 x
+// the algorithmic HBM traffic).  Here
+//   * a tile is TH FULL-WIDTH rows of one map (TH chosen by the host so that TH x OW <= 128 pixels wastes the least of its last 16-pixel
+//     k-step: 15x6 -> the whole map, 90 of 96; 30x12 -> 10 rows, 120 of 128; 60x25 -> 4 rows, 100 of 112): the transpose reads take PER-LANE
+//     pixel offsets (k index -> (row, column) of the tile, worked out per k-step with a float reciprocal) instead of the immediates that
+//     need power-of-two tile widths; no column padding, the halo columns are the image border;
+//   * the MFMA is 32x32x16: A = dY^T (32 output channels x 16 pixels), B = X (16 pixels x 32 input channels), one per tap; a wave owns 32 x 32
+//     x nine taps (144 accumulator registers), the four waves of a block a 64 x 64 slice: every staged input slice feeds 64 output channels;
+//   * planes of 16 channels x [pixel][32 bytes] as above with plane strides = 128 (mod 256) bytes: the two 16-lane groups a transpose read
+//     serves together (channels 0-15 / 16-31 of the same four pixels) fall into different bank halves; staging stores go four pixels x two
+//     16-byte halves of ONE plane per 8-lane group (128 contiguous bytes).
+struct FitGeom { int TH, tilesH, npx, tpx, ks, nci; float rOW, rWT; };
+template <int NWV>
+__global__ __launch_bounds__(64 * NWV, 2) void conv3x3_wgrad_fit_kernel(WgradArgs a, FitGeom g) {
+  static_assert(NWV == 4, "four waves: (output half) x (input half)");
+  constexpr int NT = 64 * NWV;
+  typedef bf16_t T;
+  constexpr int NPXMAX = 176, TPXMAX = 128;
+  constexpr int XPSB = NPXMAX * 32 + 128, YPSB = TPXMAX * 32 + 128;      // plane strides in bytes (= 128 mod 256)
+  constexpr int XIT = (NPXMAX * 8 + NT - 1) / NT, YIT = TPXMAX * 8 / NT;
+  __shared__ __attribute__((aligned(16))) unsigned char sX[2][4 * XPSB];
+  __shared__ __attribute__((aligned(16))) unsigned char sY[2][4 * YPSB];
+
+  const int t = threadIdx.x, lane = t & 63, wv = RD_WAVE_UNIFORM(t >> 6);
+  const int hco = wv & 1, hci = wv >> 1;
+  const int ci0 = ((int)blockIdx.y % g.nci) * 64, co0 = ((int)blockIdx.y / g.nci) * 64;
+  const int CinT = a.C1 + a.C2;
+  const int OW = a.OW, WT = OW + 2, TH = g.TH;
+  const int Hp = a.ups ? a.H1 : a.Hin, Wp = a.ups ? a.W1 : a.Win;
+
+  // persistent tile walk (XCD x owns a contiguous range of tiles, as above)
+  const int ntiles = a.N * g.tilesH;
+  const int T8 = (ntiles + 7) >> 3, G8 = gridDim.x >> 3;
+  const int xcd = blockIdx.x & 7;
+  const int tend = min(ntiles, (xcd + 1) * T8);
+  int tile = xcd * T8 + (blockIdx.x >> 3);
+
+  // ---- staging roles: slot s = t + NT i -> half s & 1, pixel sub-index (s >> 1) & 3, plane (s >> 3) & 3, pixel group s >> 5 ----------------
+  int xoff[XIT], xpy[XIT], xpx[XIT];      // LDS byte offset; patch row / column (-1 based); column < 0: slot unused
+#pragma unroll
+  for (int i = 0; i < XIT; i++) {
+    const int s_ = t + NT * i, pp = (s_ >> 5) * 4 + ((s_ >> 1) & 3), pl = (s_ >> 3) & 3;
+    int px;
+    const int py = fdiv_small(min(pp, g.npx - 1), WT, g.rWT, px);
+    xoff[i] = pl * XPSB + pp * 32 + (s_ & 1) * 16;
+    xpy[i] = py - 1; xpx[i] = pp < g.npx ? px - 1 : -100;
+  }
+  int yoff[YIT], yky[YIT], ykx[YIT];
+#pragma unroll
+  for (int i = 0; i < YIT; i++) {
+    const int s_ = t + NT * i, kk = (s_ >> 5) * 4 + ((s_ >> 1) & 3), pl = (s_ >> 3) & 3;
+    int kx;
+    const int ky = fdiv_small(min(kk, g.tpx - 1), OW, g.rOW, kx);
+    yoff[i] = pl * YPSB + kk * 32 + (s_ & 1) * 16;
+    yky[i] = ky; ykx[i] = kk < g.tpx ? kx : -100;
+  }
+  const int sch = ((t >> 3) & 3) * 16 + (t & 1) * 8;      // channel offset of this thread's slots inside the 64-channel slice (same for every i: NT % 32 == 0)
+  const bool x2nd = ci0 + sch >= a.C1;                    // the slice's channels come from the second source (concat)
+  const T* const xsrc = x2nd ? (const T*)a.src2 + (ci0 + sch - a.C1) : (const T*)a.src1 + (ci0 + sch);
+  const int xcs = x2nd ? a.C2 : a.C1;
+  const bool yok = co0 + sch < a.Cout;
+  const T* const ysrc = (const T*)a.dy + co0 + (yok ? sch : 0);
+
+  auto fetch = [&](int tl, uint4 (&rx)[XIT], uint4 (&ry)[YIT]) RD_INLINE_LAMBDA {
+    const int n = tl / g.tilesH, oh0 = (tl - n * g.tilesH) * TH;
+#pragma unroll
+    for (int i = 0; i < XIT; i++) {      // unconditional loads from clamped addresses, zero selected afterwards
+      const int ih = oh0 + xpy[i], iw = xpx[i];
+      const bool ok = (unsigned)ih < (unsigned)a.Hin && (unsigned)iw < (unsigned)a.Win;
+      int hs = min(max(ih, 0), a.Hin - 1), ws = min(max(iw, 0), a.Win - 1);
+      if (a.ups) {
+        hs = min((int)floorf((float)hs * a.scale_h), a.H1 - 1);
+        ws = min((int)floorf((float)ws * a.scale_w), a.W1 - 1);
+      }
+      const uint4 v = *reinterpret_cast<const uint4*>(xsrc + (int64_t)((n * Hp + hs) * Wp + ws) * xcs);
+      rx[i] = ok ? v : make_uint4(0, 0, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < YIT; i++) {
+      const int oh = oh0 + yky[i], ow = ykx[i];
+      const bool ok = yok && ow >= 0 && oh < a.OH;
+      const uint4 v = *reinterpret_cast<const uint4*>(ysrc + (int64_t)((n * a.OH + min(oh, a.OH - 1)) * OW + max(ow, 0)) * a.Cout);
+      ry[i] = ok ? v : make_uint4(0, 0, 0, 0);
+    }
+  };
+  auto stash = [&](int buf, const uint4 (&rx)[XIT], const uint4 (&ry)[YIT]) RD_INLINE_LAMBDA {
+#pragma unroll
+    for (int i = 0; i < XIT; i++)
+      if (t + NT * i < NPXMAX * 8) *reinterpret_cast<uint4*>(&sX[buf][xoff[i]]) = rx[i];
+#pragma unroll
+    for (int i = 0; i < YIT; i++) *reinterpret_cast<uint4*>(&sY[buf][yoff[i]]) = ry[i];
+  };
+
+  // ---- transpose-read roles: 16-lane group G = lane >> 4 reads plane (G & 1) of its half, k-group G >> 1; lane m of the group supplies
+  // pixel (m >> 2) of the read's four pixels, channels 4 (m & 3) .. + 3 -------------------------------------------------------------------
+  const int G = lane >> 4, m = lane & 15;
+  const int kq = 8 * (G >> 1) + (m >> 2);                                         // this lane's pixel inside a k-step, first read (second: + 4)
+  const int abase = (2 * hco + (G & 1)) * YPSB + kq * 32 + (m & 3) * 8;
+  const int bbase = (2 * hci + (G & 1)) * XPSB + (m & 3) * 8;
+
+  f32x16 acc[9];
+#pragma unroll
+  for (int j = 0; j < 9; j++)
+#pragma unroll
+    for (int v = 0; v < 16; v++) acc[j][v] = 0.f;
+
+  auto compute = [&](int buf) RD_INLINE_LAMBDA {
+    const unsigned char* const by = &sY[buf][0] + abase;
+    const unsigned char* const bx = &sX[buf][0] + bbase;
+    for (int s_ = 0; s_ < g.ks; s_++) {
+      // patch offsets of this lane's two pixel quads: k -> (row, column) of the tile; padded k (>= TH OW) reads pixel 0 (its dY is zero)
+      int o[2];
+#pragma unroll
+      for (int r = 0; r < 2; r++) {
+        int kk = s_ * 16 + kq + 4 * r, kx;
+        kk = kk < g.tpx ? kk : 0;
+        const int ky = fdiv_small(kk, OW, g.rOW, kx);
+        o[r] = (ky * WT + kx) * 32;
+      }
+      const uint2 alo = lds_read_tr16_b64(by + s_ * 512), ahi = lds_read_tr16_b64(by + s_ * 512 + 128);
+      const uint4 av = make_uint4(alo.x, alo.y, ahi.x, ahi.y);
+      s16x8 af;
+      __builtin_memcpy(&af, &av, 16);
+#pragma unroll
+      for (int kh = 0; kh < 3; kh++)
+#pragma unroll
+        for (int kw = 0; kw < 3; kw++) {
+          const int d = (kh * WT + kw) * 32;
+          const uint2 lo = lds_read_tr16_b64(bx + o[0] + d), hi = lds_read_tr16_b64(bx + o[1] + d);
+          const uint4 bv = make_uint4(lo.x, lo.y, hi.x, hi.y);
+          s16x8 bf;
+          __builtin_memcpy(&bf, &bv, 16);
+          acc[kh * 3 + kw] = mfma_32x32x16_bf16(af, bf, acc[kh * 3 + kw]);
+        }
+    }
+  };
+
+  uint4 rx[XIT], ry[YIT];
+  int buf = 0;
+  if (tile < tend) fetch(tile, rx, ry);
+  while (tile < tend) {
+    stash(buf, rx, ry);
+    __syncthreads();
+    const int next = tile + G8;
+    if (next < tend) fetch(next, rx, ry);
+    compute(buf);
+    tile = next;
+    buf ^= 1;
+  }
+
+  // ---- slab: register v of a tap's tile = output channel (v & 3) + 8 (v >> 2) + 4 (lane >> 5), input channel lane & 31 -----------------------
+  float* slab = a.slab + (int64_t)blockIdx.x * a.Cout * a.K;
+  const int ci = ci0 + hci * 32 + (lane & 31);
+#pragma unroll
+  for (int j = 0; j < 9; j++) {
+    const int k = j * CinT + ci;
+#pragma unroll
+    for (int v = 0; v < 16; v++) {
+      const int co = co0 + hco * 32 + (v & 3) + 8 * (v >> 2) + 4 * (lane >> 5);
+      if (co < a.Cout) slab[(int64_t)co * a.K + k] = acc[j][v];
+    }
+  }
+}
+
 // ---- host side -------------------------------------------------------------------------------------------------------------------
 // narrow layers (Cin in {16, 32, 64}, Cout <= 32): one slice.  Wide layers (Cin % 64 == 0): (Cin/64) x ceil(Cout/32) slices, used when the
 // 8 x 16 tiles cover the feature map well enough (the MFMA work is spent on whole tiles).
@@ -373,7 +540,42 @@ static int tr_tw(const WgradArgs& a) {    // tile width with the smallest padded
   if (rd_opt_is_set(OPT_WGRAD_TR_TW)) { const int v = rd_opt(OPT_WGRAD_TR_TW, 16); if (v == 8 || v == 16 || (v == 32 && Cin < 64)) best = v; }   // experiment hook (rd_set_option)
   return best;
 }
+// map-fitted kernel (conv3x3_wgrad_fit_kernel): wide layers on narrow maps; option wgrad_fit: 0 never, 1 wherever it fits, unset = where its
+// tiles waste clearly less than the 8 x TW tiles above
+struct FitPlan { int TH, tilesH, npx, tpx, ks, nci, nco; double eff; };
+static bool fit_plan(const WgradArgs& a, int dtype, FitPlan& p) {
+  const int Cin = a.C1 + a.C2;
+  if (dtype != 1 || !tr_geom(a) || a.in_scale || Cin % 64 != 0 || a.Cout % 8 != 0 || a.Cout < 64 || a.OW > 56) return false;
+  if ((int64_t)a.N * a.Hin * a.Win >= (int64_t)1 << 31) return false;
+  const int force = rd_opt(OPT_WGRAD_FIT, 0);
+  if (force == 0) return false;
+  int best = 0; double beff = 0.0;
+  for (int th = 1; th <= a.OH && th * a.OW <= 128; th++) {
+    if ((th + 2) * (a.OW + 2) > 176) break;
+    const int ks = (int)cdiv(th * a.OW, 16);
+    const double eff = (double)a.OH * a.OW / ((double)cdiv(a.OH, th) * ks * 16);
+    if (eff > beff + 1e-9) { beff = eff; best = th; }
+  }
+  if (!best) return false;
+  p.TH = best; p.tilesH = (int)cdiv(a.OH, best); p.npx = (best + 2) * (a.OW + 2); p.tpx = best * a.OW; p.ks = (int)cdiv(p.tpx, 16);
+  p.nci = Cin / 64; p.nco = (int)cdiv(a.Cout, 64); p.eff = beff;
+  // Measured on MI355X (round 5, tools/r05_wgradfit.sh -> profiles/r05_microbench/wgrad_fit_ab.txt): bit-exact, and NOT faster -- 585-588 against
+  // 584-639 TFLOP/s on 86 400 pixels 256 -> 128, 387-391 against 390-428 on 21 600 pixels 384 -> 256, 644-646 against 634-688 on 360 000 pixels
+  // 128 -> 64; the RC-Net step 1037.8 against 1045.0 img/s.  A quarter fewer MFMAs and a third less staging buy nothing: at 256 registers (144 of
+  // them accumulators) the compiler has no room to run the next k-step's twenty transpose reads under this one's nine MFMAs, and a wave pays
+  // the LDS round trip per k-step.  The way on would be LDS-DMA staging (frees the 40 staging registers) + an explicit read pipeline.  Kept as
+  // option wgrad_fit = 1 (tests: wgrad_fit_cases); the default route is the 8 x TW kernel.
+  return force == 1;
+}
+static int fit_blocks(const WgradArgs& a, const FitPlan& p) {
+  const int64_t ntiles = (int64_t)a.N * p.tilesH;
+  int cap = std::max(1, 64 / (p.nci * p.nco));      // 512 resident blocks (two per CU) over the slices, in units of 8 (one per XCD)
+  if (rd_opt_is_set(OPT_CONV3X3_G8)) cap = rd_opt(OPT_CONV3X3_G8, 1);
+  else cap = (int)std::max<int64_t>(1, std::min<int64_t>(cap, ntiles / 32));      // >= 4 tiles per block: every block writes a slab slice
+  return 8 * (int)std::min<int64_t>(cdiv(ntiles, 8), cap);
+}
 bool wgrad3x3_tr_ok(const WgradArgs& a, int dtype) {
+  { FitPlan fp; if (fit_plan(a, dtype, fp)) return true; }
   if (dtype != 1 || !tr_geom(a)) return false;
   if ((int64_t)a.N * a.Hin * a.Win >= (int64_t)1 << 31) return false;   // the kernel keeps pixel indices in 32 bits
   if (tr_narrow(a)) return true;
@@ -383,7 +585,15 @@ bool wgrad3x3_tr_ok(const WgradArgs& a, int dtype) {
   const double eff = (double)a.OH * a.OW / (double)(cdiv(a.OH, 8) * 8 * cdiv(a.OW, tw) * tw);
   return eff >= 0.6;
 }
-bool wgrad3x3_tr_affine_ok(const WgradArgs& a, int dtype) { return wgrad3x3_tr_ok(a, dtype); }
+bool wgrad3x3_tr_affine_ok(const WgradArgs& a, int dtype) {      // (asked WITHOUT in_scale set: the fitted kernel has no affine form, the 8 x TW kernel must take the shape)
+  if (dtype != 1 || !tr_geom(a)) return false;
+  if ((int64_t)a.N * a.Hin * a.Win >= (int64_t)1 << 31) return false;
+  if (tr_narrow(a)) return true;
+  const int Cin = a.C1 + a.C2;
+  if (Cin % 64 != 0 || a.Cout % 8 != 0) return false;
+  const int tw = tr_tw(a);
+  return (double)a.OH * a.OW / (double)(cdiv(a.OH, 8) * 8 * cdiv(a.OW, tw) * tw) >= 0.6;
+}
 static void tr_slices(const WgradArgs& a, int& cti, int& rt, int& nci, int& nco) {
   const int Cin = a.C1 + a.C2;
   cti = Cin >= 64 ? 4 : Cin / 16;
@@ -397,6 +607,7 @@ static void tr_slices(const WgradArgs& a, int& cti, int& rt, int& nci, int& nco)
   nco = (int)cdiv(a.Cout, rt * 16);
 }
 int wgrad3x3_tr_blocks(const WgradArgs& a) {   // persistent blocks per slice = slabs to reduce
+  { FitPlan fp; if (fit_plan(a, 1, fp)) return fit_blocks(a, fp); }
   int cti, rt, nci, nco;
   tr_slices(a, cti, rt, nci, nco);
   const int tw = tr_tw(a);
@@ -415,12 +626,22 @@ int wgrad3x3_tr_blocks(const WgradArgs& a) {   // persistent blocks per slice = 
 }
 const char* wgrad3x3_tr_name(const WgradArgs& a) {
   static thread_local char buf[64];
+  { FitPlan fp; if (fit_plan(a, 1, fp)) return "conv3x3_wgrad_fit_kernel<4>"; }
   int cti, rt, nci, nco;
   tr_slices(a, cti, rt, nci, nco);
   snprintf(buf, sizeof(buf), "conv3x3_wgrad_tr_kernel<%d, %d, %d, 4, %s>", cti, rt, tr_tw(a), a.in_scale ? "true" : "false");
   return buf;
 }
 void launch_wgrad3x3_tr(const WgradArgs& a, hipStream_t st) {
+  { FitPlan fp;
+    if (fit_plan(a, 1, fp)) {
+      FitGeom g;
+      g.TH = fp.TH; g.tilesH = fp.tilesH; g.npx = fp.npx; g.tpx = fp.tpx; g.ks = fp.ks; g.nci = fp.nci;
+      g.rOW = 1.0f / (float)a.OW; g.rWT = 1.0f / (float)(a.OW + 2);
+      const dim3 grid((unsigned)fit_blocks(a, fp), (unsigned)(fp.nci * fp.nco));
+      hipLaunchKernelGGL((conv3x3_wgrad_fit_kernel<4>), grid, dim3(256), 0, st, a, g);
+      return;
+    } }
   int cti, rt, nci, nco;
   tr_slices(a, cti, rt, nci, nco);
   const dim3 grid((unsigned)wgrad3x3_tr_blocks(a), (unsigned)(nci * nco));

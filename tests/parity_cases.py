@@ -324,6 +324,36 @@ def frag32_cases(dev, quick=False):
                     assert torch.equal(a, b), "32x32x16 variant (%d, %d): %s differs from the 16x16x32 kernel's" % (v128, v64, nm)
 
 
+class force_wgrad_fit(_force_options):
+    """Route every eligible wide 3x3 weight gradient to the map-fitted 32x32x16 kernel (conv3x3_wgrad_fit_kernel), or (0) keep it off."""
+    def __init__(self, on=1, g8=None):
+        self.opts = {"wgrad_fit": int(on)}
+        if g8 is not None:
+            self.opts["conv3x3_g8"] = int(g8)      # persistent blocks per XCD: several tiles per block on small cases
+
+
+def wgrad_fit_cases(dev, quick=False):
+    """conv3x3_wgrad_fit_kernel: full-width row tiles fitted to the map (per-lane transpose-read offsets), 64 x 64 slices on 32x32x16 MFMAs --
+    16-bit data path exact on integer data against the fp32 oracle (the forward and data gradient of the same call ride along): RC-Net's RoI
+    maps 15x6 / 30x12 / 60x25 (one tile per map, ragged last tile, padded last k-step), several tiles per persistent block, the up-sampling
+    and concatenating gather (a slice straddling the two sources), an output-channel count that is not a multiple of 64."""
+    from riders_amd import engine
+    lib = engine.L()
+    with bf16_mode():
+        for g8 in ((1,) if quick else (None, 1)):
+            with force_wgrad_fit(1, g8):
+                d = engine._desc(engine.RD_BF16, 5, 15, 6, 64, 0, False, 15, 6, 64, 3, 3, 1, 1, 1, 15, 6, 0, 0.0, 64)
+                assert lib.rd_conv_wgrad_kernel_name(__import__("ctypes").byref(d)).decode().startswith("conv3x3_wgrad_fit_kernel"), "not routed to the fitted kernel"
+                bf16_exact_conv_case(dev, cin=64, cout=64, k=3, s=1, H=15, W=6, N=5)                       # one 90-pixel tile per map (96 with the padded k-step)
+                bf16_exact_conv_case(dev, cin=64, cout=128, k=3, s=1, N=2, up=((7, 3), (15, 6)), cin2=64)    # up-sampled first source + skip: the 64-channel slices sit in different sources
+                if quick:
+                    continue
+                bf16_exact_conv_case(dev, cin=128, cout=96, k=3, s=1, H=30, W=12, N=3)                     # 10-row tiles (120 of 128 pixels), second output slice half empty
+                bf16_exact_conv_case(dev, cin=128, cout=64, k=3, s=1, H=60, W=25, N=2)                     # 4-row tiles of 25 columns: 100 of 112 pixels, quads wrap around rows
+                bf16_exact_conv_case(dev, cin=32, cout=72, k=3, s=1, N=2, up=((30, 12), (60, 25)), cin2=32)  # one slice straddling both sources, ragged output channels
+                bf16_exact_conv_case(dev, cin=192, cout=256, k=3, s=1, H=7, W=5, N=9)                      # twelve slices, few tiles
+
+
 def frag_conv_cases(dev, quick=False):
     """The register-fed 3x3 kernel in every block shape and both tile forms: fp32 against the oracle, then bf16 on integer data, exact
     (forward + both gradients), with the up-sampling / concatenating gather and the dual-destination data gradient.  quick: the subset the

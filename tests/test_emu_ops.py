@@ -57,6 +57,10 @@ def test_frag32_conv(emu):
     P.frag32_cases(emu, quick=True)
 
 
+def test_wgrad_fit(emu):
+    P.wgrad_fit_cases(emu, quick=True)
+
+
 def test_bn_bwd_sums_in_dgrad_epilogue(emu):
     P.bn_bwd_fused_cases(emu, quick=True)
 
