@@ -372,14 +372,19 @@ __global__ __launch_bounds__(64 * NWV, NWV == 8 ? (RT >= 4 ? 2 : 4) : ((CTI * RT
 //     serves together (channels 0-15 / 16-31 of the same four pixels) fall into different bank halves; staging stores go four pixels x two
 //     16-byte halves of ONE plane per 8-lane group (128 contiguous bytes).
 struct FitGeom { int TH, tilesH, npx, tpx, ks, nci; float rOW, rWT; };
+__device__ __attribute__((aligned(16))) unsigned g_fit_zero[8];      // the source of every staged element that does not exist (halo, padded k, ragged channels)
+
+// Staging is LDS-DMA (global_load_lds_dwordx4, rd_common.h dma16_to_lds): a wave instruction lands 32 pixels x 32 bytes of ONE 16-channel plane
+// as a contiguous kilobyte; wave w stages plane w of both operands.  No staging registers and no ds_write pass: the 144 accumulator registers
+// leave room for the read pipeline below (the first version of this kernel staged through registers, sat at the 256-register cap and ran
+// every k-step's twenty transpose reads in front of its nine MFMAs: 585 against 584-639 TFLOP/s for the 8 x TW kernel).
 template <int NWV>
 __global__ __launch_bounds__(64 * NWV, 2) void conv3x3_wgrad_fit_kernel(WgradArgs a, FitGeom g) {
-  static_assert(NWV == 4, "four waves: (output half) x (input half)");
-  constexpr int NT = 64 * NWV;
+  static_assert(NWV == 4, "four waves: (output half) x (input half); wave w stages channel plane w");
   typedef bf16_t T;
-  constexpr int NPXMAX = 176, TPXMAX = 128;
+  constexpr int NPXMAX = 160, TPXMAX = 128;
   constexpr int XPSB = NPXMAX * 32 + 128, YPSB = TPXMAX * 32 + 128;      // plane strides in bytes (= 128 mod 256)
-  constexpr int XIT = (NPXMAX * 8 + NT - 1) / NT, YIT = TPXMAX * 8 / NT;
+  constexpr int XG = NPXMAX / 32, YG = TPXMAX / 32;                       // 32-pixel groups per plane = DMA instructions per wave and tile
   __shared__ __attribute__((aligned(16))) unsigned char sX[2][4 * XPSB];
   __shared__ __attribute__((aligned(16))) unsigned char sY[2][4 * YPSB];
 
@@ -390,67 +395,56 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv3x3_wgrad_fit_kernel(WgradArg
   const int OW = a.OW, WT = OW + 2, TH = g.TH;
   const int Hp = a.ups ? a.H1 : a.Hin, Wp = a.ups ? a.W1 : a.Win;
 
-  // persistent tile walk (XCD x owns a contiguous range of tiles, as above)
   const int ntiles = a.N * g.tilesH;
   const int T8 = (ntiles + 7) >> 3, G8 = gridDim.x >> 3;
   const int xcd = blockIdx.x & 7;
   const int tend = min(ntiles, (xcd + 1) * T8);
   int tile = xcd * T8 + (blockIdx.x >> 3);
 
-  // ---- staging roles: slot s = t + NT i -> half s & 1, pixel sub-index (s >> 1) & 3, plane (s >> 3) & 3, pixel group s >> 5 ----------------
-  int xoff[XIT], xpy[XIT], xpx[XIT];      // LDS byte offset; patch row / column (-1 based); column < 0: slot unused
-#pragma unroll
-  for (int i = 0; i < XIT; i++) {
-    const int s_ = t + NT * i, pp = (s_ >> 5) * 4 + ((s_ >> 1) & 3), pl = (s_ >> 3) & 3;
-    int px;
-    const int py = fdiv_small(min(pp, g.npx - 1), WT, g.rWT, px);
-    xoff[i] = pl * XPSB + pp * 32 + (s_ & 1) * 16;
-    xpy[i] = py - 1; xpx[i] = pp < g.npx ? px - 1 : -100;
-  }
-  int yoff[YIT], yky[YIT], ykx[YIT];
-#pragma unroll
-  for (int i = 0; i < YIT; i++) {
-    const int s_ = t + NT * i, kk = (s_ >> 5) * 4 + ((s_ >> 1) & 3), pl = (s_ >> 3) & 3;
-    int kx;
-    const int ky = fdiv_small(min(kk, g.tpx - 1), OW, g.rOW, kx);
-    yoff[i] = pl * YPSB + kk * 32 + (s_ & 1) * 16;
-    yky[i] = ky; ykx[i] = kk < g.tpx ? kx : -100;
-  }
-  const int sch = ((t >> 3) & 3) * 16 + (t & 1) * 8;      // channel offset of this thread's slots inside the 64-channel slice (same for every i: NT % 32 == 0)
-  const bool x2nd = ci0 + sch >= a.C1;                    // the slice's channels come from the second source (concat)
+  // ---- staging role of this lane: pixel (lane >> 1) of every 32-pixel group, 16-byte half lane & 1 of plane wv ------------------------------
+  const int sch = wv * 16 + (lane & 1) * 8;               // channel offset inside the 64-channel slices
+  const bool x2nd = ci0 + sch >= a.C1;                    // this lane's input channels come from the second source (concat)
   const T* const xsrc = x2nd ? (const T*)a.src2 + (ci0 + sch - a.C1) : (const T*)a.src1 + (ci0 + sch);
   const int xcs = x2nd ? a.C2 : a.C1;
   const bool yok = co0 + sch < a.Cout;
   const T* const ysrc = (const T*)a.dy + co0 + (yok ? sch : 0);
-
-  auto fetch = [&](int tl, uint4 (&rx)[XIT], uint4 (&ry)[YIT]) RD_INLINE_LAMBDA {
+  const T* const zero = reinterpret_cast<const T*>(g_fit_zero);
+  int xm[XG], ym[YG];      // patch (row + 1) << 8 | (column + 1), tile row << 8 | column; -1: the pixel does not exist in this geometry
+#pragma unroll
+  for (int i = 0; i < XG; i++) {
+    const int pp = i * 32 + (lane >> 1);
+    int px;
+    const int py = fdiv_small(min(pp, g.npx - 1), WT, g.rWT, px);
+    xm[i] = (pp < g.npx && px >= 1 && px <= OW) ? (py << 8) | px : -1;      // the halo columns are the image border: always zero
+  }
+#pragma unroll
+  for (int i = 0; i < YG; i++) {
+    const int kk = i * 32 + (lane >> 1);
+    int kx;
+    const int ky = fdiv_small(min(kk, g.tpx - 1), OW, g.rOW, kx);
+    ym[i] = (kk < g.tpx && yok) ? (ky << 8) | kx : -1;
+  }
+  auto issue = [&](int tl, int buf) RD_INLINE_LAMBDA {
     const int n = tl / g.tilesH, oh0 = (tl - n * g.tilesH) * TH;
 #pragma unroll
-    for (int i = 0; i < XIT; i++) {      // unconditional loads from clamped addresses, zero selected afterwards
-      const int ih = oh0 + xpy[i], iw = xpx[i];
-      const bool ok = (unsigned)ih < (unsigned)a.Hin && (unsigned)iw < (unsigned)a.Win;
+    for (int i = 0; i < XG; i++) {
+      const int ih = oh0 - 1 + (xm[i] >> 8), iw = (xm[i] & 0xff) - 1;
+      const bool ok = xm[i] >= 0 && (unsigned)ih < (unsigned)a.Hin;
       int hs = min(max(ih, 0), a.Hin - 1), ws = min(max(iw, 0), a.Win - 1);
       if (a.ups) {
         hs = min((int)floorf((float)hs * a.scale_h), a.H1 - 1);
         ws = min((int)floorf((float)ws * a.scale_w), a.W1 - 1);
       }
-      const uint4 v = *reinterpret_cast<const uint4*>(xsrc + (int64_t)((n * Hp + hs) * Wp + ws) * xcs);
-      rx[i] = ok ? v : make_uint4(0, 0, 0, 0);
+      const T* p = xsrc + (int64_t)((n * Hp + hs) * Wp + ws) * xcs;
+      dma16_to_lds(ok ? p : zero, &sX[buf][wv * XPSB + i * 1024]);
     }
 #pragma unroll
-    for (int i = 0; i < YIT; i++) {
-      const int oh = oh0 + yky[i], ow = ykx[i];
-      const bool ok = yok && ow >= 0 && oh < a.OH;
-      const uint4 v = *reinterpret_cast<const uint4*>(ysrc + (int64_t)((n * a.OH + min(oh, a.OH - 1)) * OW + max(ow, 0)) * a.Cout);
-      ry[i] = ok ? v : make_uint4(0, 0, 0, 0);
+    for (int i = 0; i < YG; i++) {
+      const int oh = oh0 + (ym[i] >> 8), ow = ym[i] & 0xff;
+      const bool ok = ym[i] >= 0 && oh < a.OH;
+      const T* p = ysrc + (int64_t)((n * a.OH + min(oh, a.OH - 1)) * OW + ow) * a.Cout;
+      dma16_to_lds(ok ? p : zero, &sY[buf][wv * YPSB + i * 1024]);
     }
-  };
-  auto stash = [&](int buf, const uint4 (&rx)[XIT], const uint4 (&ry)[YIT]) RD_INLINE_LAMBDA {
-#pragma unroll
-    for (int i = 0; i < XIT; i++)
-      if (t + NT * i < NPXMAX * 8) *reinterpret_cast<uint4*>(&sX[buf][xoff[i]]) = rx[i];
-#pragma unroll
-    for (int i = 0; i < YIT; i++) *reinterpret_cast<uint4*>(&sY[buf][yoff[i]]) = ry[i];
   };
 
   // ---- transpose-read roles: 16-lane group G = lane >> 4 reads plane (G & 1) of its half, k-group G >> 1; lane m of the group supplies
@@ -469,9 +463,8 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv3x3_wgrad_fit_kernel(WgradArg
   auto compute = [&](int buf) RD_INLINE_LAMBDA {
     const unsigned char* const by = &sY[buf][0] + abase;
     const unsigned char* const bx = &sX[buf][0] + bbase;
-    for (int s_ = 0; s_ < g.ks; s_++) {
-      // patch offsets of this lane's two pixel quads: k -> (row, column) of the tile; padded k (>= TH OW) reads pixel 0 (its dY is zero)
-      int o[2];
+    // patch offsets of this lane's two pixel quads of k-step s: k -> (row, column) of the tile; padded k (>= TH OW) reads pixel 0 (its dY is zero)
+    auto offs = [&](int s_, int (&o)[2]) RD_INLINE_LAMBDA {
 #pragma unroll
       for (int r = 0; r < 2; r++) {
         int kk = s_ * 16 + kq + 4 * r, kx;
@@ -479,33 +472,51 @@ __global__ __launch_bounds__(64 * NWV, 2) void conv3x3_wgrad_fit_kernel(WgradArg
         const int ky = fdiv_small(kk, OW, g.rOW, kx);
         o[r] = (ky * WT + kx) * 32;
       }
-      const uint2 alo = lds_read_tr16_b64(by + s_ * 512), ahi = lds_read_tr16_b64(by + s_ * 512 + 128);
-      const uint4 av = make_uint4(alo.x, alo.y, ahi.x, ahi.y);
-      s16x8 af;
-      __builtin_memcpy(&af, &av, 16);
+    };
+    auto read_a = [&](int s_) RD_INLINE_LAMBDA {
+      const uint2 lo = lds_read_tr16_b64(by + s_ * 512), hi = lds_read_tr16_b64(by + s_ * 512 + 128);
+      const uint4 v = make_uint4(lo.x, lo.y, hi.x, hi.y);
+      s16x8 f;
+      __builtin_memcpy(&f, &v, 16);
+      return f;
+    };
+    auto read_b = [&](const int (&o)[2], int d) RD_INLINE_LAMBDA {
+      const uint2 lo = lds_read_tr16_b64(bx + o[0] + d), hi = lds_read_tr16_b64(bx + o[1] + d);
+      const uint4 v = make_uint4(lo.x, lo.y, hi.x, hi.y);
+      s16x8 f;
+      __builtin_memcpy(&f, &v, 16);
+      return f;
+    };
+    // read pipeline: the operand of MFMA n + 1 is requested before MFMA n is issued (LDS returns in order: the wait in front of an MFMA leaves
+    // the younger request outstanding), across taps and across k-steps; the last k-step re-reads its own first operands
+    int o[2];
+    offs(0, o);
+    s16x8 a_cur = read_a(0), b_cur = read_b(o, 0);
+    for (int s_ = 0; s_ < g.ks; s_++) {
+      const int sn = s_ + 1 < g.ks ? s_ + 1 : s_;
+      int on[2];
+      offs(sn, on);
+      const s16x8 a_nxt = read_a(sn);
 #pragma unroll
-      for (int kh = 0; kh < 3; kh++)
-#pragma unroll
-        for (int kw = 0; kw < 3; kw++) {
-          const int d = (kh * WT + kw) * 32;
-          const uint2 lo = lds_read_tr16_b64(bx + o[0] + d), hi = lds_read_tr16_b64(bx + o[1] + d);
-          const uint4 bv = make_uint4(lo.x, lo.y, hi.x, hi.y);
-          s16x8 bf;
-          __builtin_memcpy(&bf, &bv, 16);
-          acc[kh * 3 + kw] = mfma_32x32x16_bf16(af, bf, acc[kh * 3 + kw]);
-        }
+      for (int tap = 0; tap < 9; tap++) {
+        const s16x8 b_nxt = tap < 8 ? read_b(o, (((tap + 1) / 3) * WT + (tap + 1) % 3) * 32) : read_b(on, 0);
+        acc[tap] = mfma_32x32x16_bf16(a_cur, b_cur, acc[tap]);
+        b_cur = b_nxt;
+      }
+      a_cur = a_nxt; o[0] = on[0]; o[1] = on[1];
     }
   };
 
-  uint4 rx[XIT], ry[YIT];
   int buf = 0;
-  if (tile < tend) fetch(tile, rx, ry);
+  if (tile < tend) issue(tile, 0);
+  dma_wait_all();
+  __syncthreads();
   while (tile < tend) {
-    stash(buf, rx, ry);
-    __syncthreads();
     const int next = tile + G8;
-    if (next < tend) fetch(next, rx, ry);
+    if (next < tend) issue(next, buf ^ 1);      // every wave left buffer buf ^ 1 before the barrier it just passed
     compute(buf);
+    dma_wait_all();
+    __syncthreads();
     tile = next;
     buf ^= 1;
   }
@@ -545,13 +556,13 @@ static int tr_tw(const WgradArgs& a) {    // tile width with the smallest padded
 struct FitPlan { int TH, tilesH, npx, tpx, ks, nci, nco; double eff; };
 static bool fit_plan(const WgradArgs& a, int dtype, FitPlan& p) {
   const int Cin = a.C1 + a.C2;
-  if (dtype != 1 || !tr_geom(a) || a.in_scale || Cin % 64 != 0 || a.Cout % 8 != 0 || a.Cout < 64 || a.OW > 56) return false;
+  if (dtype != 1 || !tr_geom(a) || a.in_scale || Cin % 64 != 0 || a.Cout % 8 != 0 || a.Cout < 64 || a.OW > 50) return false;
   if ((int64_t)a.N * a.Hin * a.Win >= (int64_t)1 << 31) return false;
   const int force = rd_opt(OPT_WGRAD_FIT, 0);
   if (force == 0) return false;
   int best = 0; double beff = 0.0;
   for (int th = 1; th <= a.OH && th * a.OW <= 128; th++) {
-    if ((th + 2) * (a.OW + 2) > 176) break;
+    if ((th + 2) * (a.OW + 2) > 160) break;
     const int ks = (int)cdiv(th * a.OW, 16);
     const double eff = (double)a.OH * a.OW / ((double)cdiv(a.OH, th) * ks * 16);
     if (eff > beff + 1e-9) { beff = eff; best = th; }
@@ -559,12 +570,16 @@ static bool fit_plan(const WgradArgs& a, int dtype, FitPlan& p) {
   if (!best) return false;
   p.TH = best; p.tilesH = (int)cdiv(a.OH, best); p.npx = (best + 2) * (a.OW + 2); p.tpx = best * a.OW; p.ks = (int)cdiv(p.tpx, 16);
   p.nci = Cin / 64; p.nco = (int)cdiv(a.Cout, 64); p.eff = beff;
-  // Measured on MI355X (round 5, tools/r05_wgradfit.sh -> profiles/r05_microbench/wgrad_fit_ab.txt): bit-exact, and NOT faster -- 585-588 against
-  // 584-639 TFLOP/s on 86 400 pixels 256 -> 128, 387-391 against 390-428 on 21 600 pixels 384 -> 256, 644-646 against 634-688 on 360 000 pixels
-  // 128 -> 64; the RC-Net step 1037.8 against 1045.0 img/s.  A quarter fewer MFMAs and a third less staging buy nothing: at 256 registers (144 of
-  // them accumulators) the compiler has no room to run the next k-step's twenty transpose reads under this one's nine MFMAs, and a wave pays
-  // the LDS round trip per k-step.  The way on would be LDS-DMA staging (frees the 40 staging registers) + an explicit read pipeline.  Kept as
-  // option wgrad_fit = 1 (tests: wgrad_fit_cases); the default route is the 8 x TW kernel.
+  // Measured on MI355X (round 5, tools/r05_wgradfit.sh -> profiles/r05_microbench/wgrad_fit_ab.txt), bit-exact in both versions:
+  //   v1 (register staging, 256 registers, every k-step's twenty transpose reads in front of its nine MFMAs): 585-588 TFLOP/s on 86 400 pixels
+  //      256 -> 128 against 584-639 for the 8 x TW kernel, the RC-Net step 1037.8 against 1045.0 img/s;
+  //   v2 (LDS-DMA staging, 206 registers, operand reads pipelined one MFMA ahead -- the ISA shows 2-5 reads outstanding at every wait):
+  //      636 / 604-620 against 587-649 / 575-630 on 86 400 pixels, 424-434 against 392-432 on 21 600 pixels 384 -> 256, 673-685 against
+  //      622-694 on 360 000 pixels 128 -> 64; the step 1077.9 against 1084.3 img/s.
+  // A quarter fewer MFMAs, a third less staging and a pipelined inner loop land where the old kernel is.  What the two have in common is the
+  // split over pixels: 512 persistent blocks each write a (64 x 576 or 32 x 576) fp32 slab slice at the same moment at the end -- 75 MB (here)
+  // / 38 MB (8 x TW kernel) per launch for 51 GFLOP (= 51 us at 1 PFLOP/s) -- and the reduction pass reads them again: at these sizes the
+  // slab traffic is a first-order term that no change inside the tile loop touches.  Kept as option wgrad_fit = 1 (tests: wgrad_fit_cases).
   return force == 1;
 }
 static int fit_blocks(const WgradArgs& a, const FitPlan& p) {
