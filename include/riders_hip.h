@@ -236,6 +236,29 @@ int rd_bn_act_bwd_recompute_phases(const void* dz, const void* z, const void* y,
 int rd_bn_act_bwd_from_partial(const void* dz, const void* y, const float* mean, const float* rstd, const float* scale, const float* shift,
                                const float* partial, int32_t rows, int32_t row_channels, float* coef, float* dgamma, float* dbeta, int32_t accumulate,
                                void* dy, int64_t pixels, int32_t C, int32_t act, float slope, int32_t dtype, void* stream);
+/* ---- Decoder head: the last decoder convolution's BatchNorm + activation fused with the one-channel 3x3 output convolution.
+ * Replaces, for RCNet/networks.py:773-779 (MultiScaleDecoder.forward: deconv0 -> output0; output0 = net_utils.Conv2d(16 -> 1, 3x3, bias=False,
+ * no BatchNorm, linear: utils/net_utils.py:50-91), the chain BatchNorm2d apply + LeakyReLU -> conv2d and its autograd backward (conv2d data +
+ * weight gradient, LeakyReLU / BatchNorm2d backward): the activated tensor and its gradient (184 MB each at 5.76 M pixels) are recomputed
+ * from the raw convolution output y instead of stored.
+ *   y (N,H,W,C) = the producer convolution's raw output; scale / shift / mean / rstd = rd_bn_finalize's outputs for it; w_head fp32 [1][C][3][3]
+ *   (rounded to the activation type inside, as the packed operand of rd_conv_fwd is); logits / dlogits (N,H,W,1) in the activation type.
+ * rd_bn_head_ok: 1 when the route handles the shape (C == 16).  Backward = rd_bn_head_bwd_reduce (partial: rd_bn_head_rows x 88 x 2 floats)
+ * followed by rd_bn_head_bwd_apply (coef: 2 x C floats of scratch; writes the BatchNorm parameter gradients, the head's weight gradient
+ * dw_head fp32 [1][C][3][3] and dy = the gradient w.r.t. y; *_accumulate: add to what the gradient buffers hold). */
+int32_t rd_bn_head_ok(int32_t N, int32_t H, int32_t W, int32_t C, int32_t dtype);
+int32_t rd_bn_head_rows(int32_t N, int32_t H, int32_t W);
+int rd_bn_head_fwd(const void* y, const float* scale, const float* shift, int32_t act, float slope, const float* w_head, void* logits, int32_t N,
+                   int32_t H, int32_t W, int32_t C, int32_t dtype, void* stream);
+int rd_bn_head_bwd_reduce(const void* dlogits, const void* y, const float* mean, const float* rstd, const float* scale, const float* shift,
+                          int32_t act, float slope, const float* w_head, float* partial, int32_t N, int32_t H, int32_t W, int32_t C, int32_t dtype,
+                          void* stream);
+int rd_bn_head_bwd_apply(const void* dlogits, const void* y, const float* mean, const float* rstd, const float* scale, const float* shift,
+                         int32_t act, float slope, const float* w_head, const float* partial, int32_t rows, float* coef, float* dgamma, float* dbeta,
+                         int32_t bn_accumulate, float* dw_head, int32_t w_accumulate, void* dy, int32_t N, int32_t H, int32_t W, int32_t C,
+                         int32_t dtype, void* stream);
+/* instantiation name (as rd_conv_fwd_kernel_name) of which = 0: forward, 1: backward reduce, 2: backward apply */
+const char* rd_bn_head_kernel_name(int32_t which, int32_t dtype, int32_t act);
 /* instantiation name (as rd_conv_fwd_kernel_name) of which = 0: rd_affine_act (flag = residual given), 1: the BatchNorm-backward reduce
    pass, 2: its apply pass (flag = recompute form) for this channel count / dtype / activation */
 const char* rd_bn_kernel_name(int32_t which, int32_t C, int32_t dtype, int32_t act, int32_t flag);

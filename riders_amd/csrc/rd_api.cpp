@@ -63,7 +63,7 @@ const OptDef kOpts[rdt::OPT_COUNT] = {
   {"conv3x3_w8", 0, 1}, {"patch_bn_max", 32, 128}, {"conv3x3_g8", 1, 4096}, {"conv1x1_min_m", 0, 1 << 30}, {"conv_few_min_m", 0, 1 << 30},
   {"frag_v128", 0, 6}, {"frag_v64", 0, 6}, {"frag_v32", 0, 6}, {"frag_split", 0, 1}, {"frag_split_blocks", 0, 1 << 30},
   {"frag32_v128", 0, 3}, {"frag32_v64", 0, 3}, {"frag_lin", 0, 1}, {"conv3x3_frag", 0, 1}, {"bn_gen_ppt", 2, 64}, {"bn_vec_per", 0, 64},
-  {"wgrad_tr_tw", 8, 32}, {"frag_db", 0, 1}, {"wgrad_fit", 0, 1},
+  {"wgrad_tr_tw", 8, 32}, {"frag_db", 0, 1}, {"wgrad_fit", 0, 1}, {"head_np", 256, 4096}, {"head_cpi", 0, 0x888},
 };
 int g_opt_val[rdt::OPT_COUNT];
 bool g_opt_set[rdt::OPT_COUNT];
@@ -441,6 +441,41 @@ int rd_bn_act_bwd_recompute(const void* dz, const void* z, const void* y, const 
                             void* dres, int64_t pixels, int32_t C, int32_t act, float slope, int32_t dtype, void* stream) {
   return rd_bn_act_bwd_recompute_phases(dz, z, y, mean, rstd, scale, shift, partial, coef, dgamma, dbeta, accumulate, dy, dres, pixels, C, act, slope,
                                         dtype, 7, stream);
+}
+/* ---- decoder head (rd_head.hip): BatchNorm + activation of the last decoder convolution fused with the one-channel 3x3 output convolution */
+int32_t rd_bn_head_ok(int32_t N, int32_t H, int32_t W, int32_t C, int32_t dtype) {
+  return dt_ok(dtype) && RD_NS(dtype, bn_head_ok)(N, H, W, C, RD_DT(dtype)) ? 1 : 0;
+}
+int32_t rd_bn_head_rows(int32_t N, int32_t H, int32_t W) { return rd::bn_head_rows(N, H, W); }
+int rd_bn_head_fwd(const void* y, const float* scale, const float* shift, int32_t act, float slope, const float* w_head, void* logits, int32_t N,
+                   int32_t H, int32_t W, int32_t C, int32_t dtype, void* stream) {
+  if (!y || !scale || !shift || !w_head || !logits || !dt_ok(dtype)) return fail("bn_head_fwd: bad args");
+  if (!rd_bn_head_ok(N, H, W, C, dtype)) return fail("bn_head_fwd: unsupported shape (N %d, %d x %d, C %d)", N, H, W, C);
+  RD_NS(dtype, launch_bn_head_fwd)(y, scale, shift, act, slope, w_head, logits, N, H, W, RD_DT(dtype), S(stream));
+  return done("rd_bn_head_fwd");
+}
+int rd_bn_head_bwd_reduce(const void* dlogits, const void* y, const float* mean, const float* rstd, const float* scale, const float* shift,
+                          int32_t act, float slope, const float* w_head, float* partial, int32_t N, int32_t H, int32_t W, int32_t C, int32_t dtype,
+                          void* stream) {
+  if (!dlogits || !y || !mean || !rstd || !scale || !shift || !w_head || !partial || !dt_ok(dtype)) return fail("bn_head_bwd_reduce: bad args");
+  if (!rd_bn_head_ok(N, H, W, C, dtype)) return fail("bn_head_bwd_reduce: unsupported shape (N %d, %d x %d, C %d)", N, H, W, C);
+  RD_NS(dtype, launch_bn_head_bwd_reduce)(dlogits, y, mean, rstd, scale, shift, act, slope, w_head, partial, N, H, W, RD_DT(dtype), S(stream));
+  return done("rd_bn_head_bwd_reduce");
+}
+int rd_bn_head_bwd_apply(const void* dlogits, const void* y, const float* mean, const float* rstd, const float* scale, const float* shift,
+                         int32_t act, float slope, const float* w_head, const float* partial, int32_t rows, float* coef, float* dgamma, float* dbeta,
+                         int32_t bn_accumulate, float* dw_head, int32_t w_accumulate, void* dy, int32_t N, int32_t H, int32_t W, int32_t C,
+                         int32_t dtype, void* stream) {
+  if (!dlogits || !y || !mean || !rstd || !scale || !shift || !w_head || !partial || !coef || !dy || !dt_ok(dtype)) return fail("bn_head_bwd_apply: bad args");
+  if (!rd_bn_head_ok(N, H, W, C, dtype)) return fail("bn_head_bwd_apply: unsupported shape (N %d, %d x %d, C %d)", N, H, W, C);
+  if (rows <= 0 || rows != rd_bn_head_rows(N, H, W)) return fail("bn_head_bwd_apply: rows %d, expected %d", rows, rd_bn_head_rows(N, H, W));
+  RD_NS(dtype, launch_bn_head_bwd_apply)(dlogits, y, mean, rstd, scale, shift, act, slope, w_head, partial, rows, coef, dgamma, dbeta, bn_accumulate,
+                                         dw_head, w_accumulate, dy, N, H, W, RD_DT(dtype), S(stream));
+  return done("rd_bn_head_bwd_apply");
+}
+const char* rd_bn_head_kernel_name(int32_t which, int32_t dtype, int32_t act) {
+  if (!dt_ok(dtype) || which < 0 || which > 2) return "";
+  return RD_NS(dtype, bn_head_kernel_name)(which, RD_DT(dtype), act);
 }
 const char* rd_bn_kernel_name(int32_t which, int32_t C, int32_t dtype, int32_t act, int32_t flag) {
   if (!dt_ok(dtype) || which < 0 || which > 2 || C <= 0) return "";

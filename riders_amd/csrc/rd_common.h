@@ -410,4 +410,16 @@ __device__ __forceinline__ float act_grad_from_out(float z, int act, float slope
 
 __host__ __device__ __forceinline__ int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
+// one channel's (a, b) partials summed over the rows by a block's 256 threads: four independent 8-byte loads in flight per thread (a plain
+// `for (r = t; r < rows; r += 256)` loop is a chain of dependent round trips: 17 us for the 13 K rows of a one-row-per-tile producer)
+__device__ __forceinline__ void bn_rows_sum(const float2* __restrict__ p2, int rows, int C, int c, int t, double& a, double& b) {
+  int r = t;
+  for (; r + 768 < rows; r += 1024) {
+    const float2 v0 = p2[(int64_t)r * C + c], v1 = p2[(int64_t)(r + 256) * C + c], v2 = p2[(int64_t)(r + 512) * C + c], v3 = p2[(int64_t)(r + 768) * C + c];
+    a += ((double)v0.x + (double)v1.x) + ((double)v2.x + (double)v3.x);
+    b += ((double)v0.y + (double)v1.y) + ((double)v2.y + (double)v3.y);
+  }
+  for (; r < rows; r += 256) { const float2 v = p2[(int64_t)r * C + c]; a += (double)v.x; b += (double)v.y; }
+}
+
 }  // namespace rd

@@ -1,0 +1,464 @@
+// Decoder head: BatchNorm + activation of the last decoder convolution fused with the 3x3 output convolution (one output channel).
+//
+// Reference: RCNet/networks.py:773-779 (MultiScaleDecoder: deconv0 -> output0), utils/net_utils.py:84-91 (conv -> BatchNorm2d -> act) and
+// :50-82 (output0 = Conv2d(n_filters[-1] = 16 -> 1, 3x3, bias=False, no BatchNorm, linear)).
+//
+// At RoI resolution (R = 240 crops of 240 x 100: 5.76 M pixels) the 16-channel tensors are 184 MB each (bf16) and every pass over one is
+// 35-100 us of HBM time.  The unfused chain moved nine of them around this one layer pair (forward: apply reads y writes a, head reads a;
+// backward: the head's data gradient writes da, its weight gradient reads a, the BatchNorm reduce reads da + y, the apply reads da + y and
+// writes dy).  The output convolution has ONE output channel: its arithmetic is 144 multiply-adds per pixel and its gradient is a
+// function of nine neighbouring dlogits (2 bytes per pixel), so everything around it can be recomputed from y instead of stored:
+//   forward   logits = conv3x3(round(act(scale y + shift)))                  reads y (+ halo rows), writes logits      (a never exists)
+//   backward  pass 1: sums of g, g xhat (BatchNorm) and of a (x) dlogits (head weight gradient), g = round(da) act'     reads y
+//             pass 2: dy = scale (g - c1 - xhat c2)                                                                     reads y, writes dy
+// with da = conv3x3^T(dlogits) recomputed in both passes (da never exists).  Every value is rounded where the unfused kernels round it
+// (a and da to the activation type, weights to the activation type), sums are fp32 in a fixed order.
+//
+// Work item = (pixel, group of CPI = 4 or 8 channels), the groups of a pixel in neighbouring lanes; the group's 9 CPI weights in registers.
+#include "rd_conv_common.h"
+#include <type_traits>
+#include <stdio.h>
+
+namespace rd {
+
+static constexpr int HC = 16;      // channels of the producer (RC-Net: n_filters[-1], rcnet_model.py:77-94)
+
+struct HeadArgs {
+  const void* y; const void* dl; const float* w;      // y (N,H,W,16); dlogits / logits (N,H,W,1); w fp32 [1][16][3][3]
+  const float *scale, *shift, *mean, *rstd, *c1, *c2;
+  void* out;                                           // forward: logits; pass 2: dy
+  float* partial;                                      // pass 1: rows x HEAD_PC x 2
+  int N, H, W, th, tw, tilesH, tilesW, act;
+  float slope;
+};
+static constexpr int HEAD_PC = HC + HC * 9 / 2;        // pairs per partial row: 16 x (sum g, sum g xhat) + the 144 weight-gradient sums
+
+// CPI consecutive channels <-> floats
+template <typename T, int CPI> struct ChanIO;
+template <> struct ChanIO<float, 8> {
+  static __device__ __forceinline__ void ld(const float* p, float (&o)[8]) {
+    float a[4], b[4]; ld4(p, a); ld4(p + 4, b);
+#pragma unroll
+    for (int e = 0; e < 4; e++) { o[e] = a[e]; o[4 + e] = b[e]; }
+  }
+  static __device__ __forceinline__ void st(float* p, const float (&o)[8]) {
+    const float a[4] = {o[0], o[1], o[2], o[3]}, b[4] = {o[4], o[5], o[6], o[7]};
+    st4(p, a); st4(p + 4, b);
+  }
+};
+template <> struct ChanIO<bf16_t, 8> {
+  static __device__ __forceinline__ void ld(const bf16_t* p, float (&o)[8]) { ldv(p, o); }
+  static __device__ __forceinline__ void st(bf16_t* p, const float (&o)[8]) { stv(p, o); }
+};
+template <typename T> struct ChanIO<T, 4> {
+  static __device__ __forceinline__ void ld(const T* p, float (&o)[4]) { ld4(p, o); }
+  static __device__ __forceinline__ void st(T* p, const float (&o)[4]) { st4(p, o); }
+};
+
+// sum over the NI = 16 / CPI neighbouring lanes that hold the channel groups of one pixel
+template <int NI>
+__device__ __forceinline__ float parts_sum(float v) {
+#if RD_DPP_SUM && !defined(RD_EMU)
+  v += dpp_f32<0xB1, 0xF>(v);                  // quad_perm [1,0,3,2]
+  if (NI == 4) v += dpp_f32<0x4E, 0xF>(v);     // quad_perm [2,3,0,1]
+#else
+  v += __shfl_xor(v, 1);
+  if (NI == 4) v += __shfl_xor(v, 2);
+#endif
+  return v;
+}
+
+struct HeadTile { int n, r0, c0; };
+// (row, column) of a thread's pixel inside a tile of width w, advanced by a constant number of pixels per iteration without a division
+struct PixWalk {
+  int r, c, dr, dc, w;
+  __device__ __forceinline__ PixWalk(int p0, int step, int width) : r(p0 / width), c(p0 - (p0 / width) * width), dr(step / width), dc(step - (step / width) * width), w(width) {}
+  __device__ __forceinline__ PixWalk next() const { PixWalk n = *this; n.r += dr; n.c += dc; if (n.c >= w) { n.c -= w; n.r++; } return n; }
+  __device__ __forceinline__ PixWalk next2() const { return next().next(); }
+};
+__device__ __forceinline__ HeadTile head_tile(const HeadArgs& a, int tile) {
+  HeadTile t;
+  const int tc = tile % a.tilesW, q = tile / a.tilesW;
+  t.c0 = tc * a.tw; t.r0 = (q % a.tilesH) * a.th; t.n = q / a.tilesH;
+  return t;
+}
+// the channel group's weights, rounded to the activation type (what the packed operand of the unfused convolution holds): wq[c][kh * 3 + kw]
+template <typename T, int CPI>
+__device__ __forceinline__ void head_weights(const float* __restrict__ w, int part, float (&wq)[CPI][9]) {
+  const float4* w4 = reinterpret_cast<const float4*>(w + part * CPI * 9);      // 36 / 72 floats (fp32 parameter storage is 16-byte aligned)
+  float f[CPI * 9];
+#pragma unroll
+  for (int i = 0; i < CPI * 9 / 4; i++) { const float4 v = w4[i]; f[i * 4] = v.x; f[i * 4 + 1] = v.y; f[i * 4 + 2] = v.z; f[i * 4 + 3] = v.w; }
+#pragma unroll
+  for (int c = 0; c < CPI; c++)
+#pragma unroll
+    for (int k = 0; k < 9; k++) wq[c][k] = Elem<T>::rnd(f[c * 9 + k]);
+}
+// dlogits of the tile + one pixel of halo -> LDS as floats (zero outside the image): sdl[(r - r0 + 1) * (tw + 2) + (c - c0 + 1)]
+template <typename T>
+__device__ __forceinline__ void stage_dl(const HeadArgs& a, const HeadTile& tl, float* sdl) {
+  const int twh = a.tw + 2, np = (a.th + 2) * twh;
+  const T* dl = (const T*)a.dl + (int64_t)tl.n * a.H * a.W;
+  for (int i = threadIdx.x; i < np; i += 256) {
+    const int lr = i / twh, lc = i - lr * twh;
+    const int r = tl.r0 - 1 + lr, c = tl.c0 - 1 + lc;
+    const bool ok = (unsigned)r < (unsigned)a.H && (unsigned)c < (unsigned)a.W;
+    const float v = Elem<T>::ld(dl + (int64_t)min(max(r, 0), a.H - 1) * a.W + min(max(c, 0), a.W - 1));
+    sdl[i] = ok ? v : 0.f;
+  }
+}
+// da[c] = sum over the data gradient's taps tp = (kh', kw') ascending of w[c][2 - kh'][2 - kw'] * dlogits[q + (kh' - 1, kw' - 1)] (the order of
+// conv3x3_c1_kernel, rd_conv3x3.hip, the kernel this replaces; fused multiply-adds here: the library is built with -ffp-contract=off and the 288
+// multiply-adds per pixel of the two backward passes are what bounds them); e[tp] = that neighbour's dlogit
+__device__ __forceinline__ void head_neighbours(const float* sdl, int twh, int pr, int pc, float (&e)[9]) {
+#pragma unroll
+  for (int kh = 0; kh < 3; kh++)
+#pragma unroll
+    for (int kw = 0; kw < 3; kw++) e[kh * 3 + kw] = sdl[(pr + kh) * twh + pc + kw];
+}
+template <typename T, int CPI>
+__device__ __forceinline__ void head_dgrad(const float (&wq)[CPI][9], const float (&e)[9], float (&da)[CPI]) {
+#pragma unroll
+  for (int c = 0; c < CPI; c++) {
+    float s = 0.f;
+#pragma unroll
+    for (int tp = 0; tp < 9; tp++) s = fmaf(wq[c][8 - tp], e[tp], s);
+    da[c] = Elem<T>::rnd(s);      // the unfused path stores da in the activation type
+  }
+}
+
+// ---- forward -----------------------------------------------------------------------------------------------------------------------
+// phase 1: every pixel of the tile + halo: a = round(act(scale y + shift)) (zero outside the image: the convolution pads a, not y), its nine
+// per-tap dot products over the 16 channels -> LDS; phase 2: an output pixel sums the nine taps of its neighbours.
+template <typename T, int ACT, int CPI>
+__global__ __launch_bounds__(256) RD_WAVES_PER_EU(4) void bn_head_fwd_kernel(HeadArgs a) {
+  constexpr int NI = HC / CPI;
+  RD_DYN_SMEM(smem);
+  float* tp = reinterpret_cast<float*>(smem);      // [np][9]
+  const int actv = ACT >= 0 ? ACT : a.act;
+  const int t = threadIdx.x, part = t % NI;
+  const HeadTile tl = head_tile(a, xcd_contiguous(blockIdx.x, gridDim.x));
+  const int twh = a.tw + 2, np = (a.th + 2) * twh;
+  float wq[CPI][9], sc[CPI], sh[CPI];
+  head_weights<T, CPI>(a.w, part, wq);
+#pragma unroll
+  for (int c = 0; c < CPI; c++) { sc[c] = a.scale[part * CPI + c]; sh[c] = a.shift[part * CPI + c]; }
+  const T* yb = (const T*)a.y + (int64_t)tl.n * a.H * a.W * HC + part * CPI;
+  auto pix = [&](const PixWalk& q, bool& ok) RD_INLINE_LAMBDA -> const T* {
+    const int r = tl.r0 - 1 + q.r, c = tl.c0 - 1 + q.c;
+    ok = q.r < a.th + 2 && (unsigned)r < (unsigned)a.H && (unsigned)c < (unsigned)a.W;
+    return yb + ((int64_t)min(max(r, 0), a.H - 1) * a.W + min(max(c, 0), a.W - 1)) * HC;
+  };
+  auto taps = [&](const PixWalk& q, bool ok, const float (&yy)[CPI]) RD_INLINE_LAMBDA {
+    float av[CPI];
+#pragma unroll
+    for (int c = 0; c < CPI; c++) av[c] = ok ? Elem<T>::rnd(act_fwd(yy[c] * sc[c] + sh[c], actv, a.slope)) : 0.f;
+    float d[9];
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+      float s = 0.f;
+#pragma unroll
+      for (int c = 0; c < CPI; c++) s = fmaf(wq[c][k], av[c], s);
+      d[k] = parts_sum<NI>(s);
+    }
+    if (q.r < a.th + 2) {      // the lanes of a pixel share the nine stores
+      const int p = q.r * twh + q.c;
+#pragma unroll
+      for (int k = 0; k < 9; k++)
+        if (k % NI == part) tp[p * 9 + k] = d[k];
+    }
+  };
+  // whole waves run every iteration (parts_sum needs all lanes of a pixel): the trip count is the block's, not the thread's
+  const int nit = (np * NI + 255) >> 8;
+  PixWalk q0(t / NI, 256 / NI, twh), q1 = q0.next();
+  int it = 0;
+  for (; it + 1 < nit; it += 2) {
+    bool ok0, ok1; float y0[CPI], y1[CPI];
+    const T* p0 = pix(q0, ok0); const T* p1 = pix(q1, ok1);
+    ChanIO<T, CPI>::ld(p0, y0); ChanIO<T, CPI>::ld(p1, y1);
+    taps(q0, ok0, y0); taps(q1, ok1, y1);
+    q0 = q0.next2(); q1 = q1.next2();
+  }
+  if (it < nit) {
+    bool ok0; float y0[CPI];
+    ChanIO<T, CPI>::ld(pix(q0, ok0), y0);
+    taps(q0, ok0, y0);
+  }
+  __syncthreads();
+  T* out = (T*)a.out + (int64_t)tl.n * a.H * a.W;
+  const int npx = a.th * a.tw;
+  for (int o = t; o < npx; o += 256) {
+    const int pr = o / a.tw, pc = o - pr * a.tw;
+    const int r = tl.r0 + pr, c = tl.c0 + pc;
+    if (r < a.H && c < a.W) {
+      float s = 0.f;
+#pragma unroll
+      for (int kh = 0; kh < 3; kh++)
+#pragma unroll
+        for (int kw = 0; kw < 3; kw++) s += tp[((pr + kh) * twh + pc + kw) * 9 + kh * 3 + kw];
+      Elem<T>::st(out + (int64_t)r * a.W + c, s);
+    }
+  }
+}
+
+// ---- backward, pass 1: BatchNorm sums + head weight gradient ------------------------------------------------------------------------------
+// persistent blocks (block b owns tiles b, b + grid, ...), sums of all its tiles in registers, one partial row per block
+template <typename T, int ACT, int CPI>
+__global__ __launch_bounds__(256) void bn_head_bwd_reduce_kernel(HeadArgs a, int ntiles) {
+  constexpr int NI = HC / CPI, PQ = CPI * 11;      // per channel group: CPI x (sum g, sum g xhat) + CPI x 9 weight-gradient sums
+  RD_DYN_SMEM(smem);
+  float* sdl = reinterpret_cast<float*>(smem);
+  const int actv = ACT >= 0 ? ACT : a.act;
+  const int t = threadIdx.x, part = t % NI, lane = t & 63, wv = t >> 6;
+  const int twh = a.tw + 2;
+  float wq[CPI][9], sc[CPI], sh[CPI], mu[CPI], rs[CPI];
+  head_weights<T, CPI>(a.w, part, wq);
+#pragma unroll
+  for (int c = 0; c < CPI; c++) {
+    const int cc = part * CPI + c;
+    sc[c] = a.scale[cc]; sh[c] = a.shift[cc]; mu[c] = a.mean[cc]; rs[c] = a.rstd[cc];
+  }
+  float sa[CPI], sb[CPI], wacc[CPI][9];
+#pragma unroll
+  for (int c = 0; c < CPI; c++) {
+    sa[c] = 0.f; sb[c] = 0.f;
+#pragma unroll
+    for (int k = 0; k < 9; k++) wacc[c][k] = 0.f;
+  }
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const HeadTile tl = head_tile(a, tile);
+    __syncthreads();      // the previous tile's readers
+    stage_dl<T>(a, tl, sdl);
+    __syncthreads();
+    const T* yb = (const T*)a.y + (int64_t)tl.n * a.H * a.W * HC + part * CPI;
+    auto item = [&](const PixWalk& q, const float (&yy)[CPI], bool ok) RD_INLINE_LAMBDA {
+      float e[9], da[CPI];
+      head_neighbours(sdl, twh, q.r, q.c, e);
+      head_dgrad<T, CPI>(wq, e, da);
+#pragma unroll
+      for (int c = 0; c < CPI; c++) {
+        const float u = yy[c] * sc[c] + sh[c];
+        const float av = ok ? Elem<T>::rnd(act_fwd(u, actv, a.slope)) : 0.f;
+        float g = ok ? da[c] : 0.f;
+        if (actv) g *= act_grad_from_out(u, actv, a.slope);
+        sa[c] += g; sb[c] += g * ((yy[c] - mu[c]) * rs[c]);
+        // dw[c][kh][kw] = sum_q a[q][c] * dlogits[q - (kh - 1, kw - 1)] = a * e[8 - (kh * 3 + kw)]
+#pragma unroll
+        for (int k = 0; k < 9; k++) wacc[c][k] = fmaf(av, e[8 - k], wacc[c][k]);
+      }
+    };
+    auto addr = [&](const PixWalk& q, bool& ok) RD_INLINE_LAMBDA -> const T* {
+      const int r = tl.r0 + q.r, c = tl.c0 + q.c;
+      ok = r < a.H && c < a.W;
+      return yb + ((int64_t)min(r, a.H - 1) * a.W + min(c, a.W - 1)) * HC;
+    };
+    PixWalk q0(t / NI, 256 / NI, a.tw), q1 = q0.next();
+    for (; q1.r < a.th; q0 = q0.next2(), q1 = q1.next2()) {
+      bool ok0, ok1; float y0[CPI], y1[CPI];
+      const T* p0 = addr(q0, ok0); const T* p1 = addr(q1, ok1);
+      ChanIO<T, CPI>::ld(p0, y0); ChanIO<T, CPI>::ld(p1, y1);
+      item(q0, y0, ok0); item(q1, y1, ok1);
+    }
+    if (q0.r < a.th) {
+      bool ok0; float y0[CPI];
+      ChanIO<T, CPI>::ld(addr(q0, ok0), y0);
+      item(q0, y0, ok0);
+    }
+  }
+  // block reduction: lanes of the same channel group (xor NI .. 32, fixed tree), then the four waves through LDS in wave order
+  __syncthreads();
+  float* red = sdl;      // [4 waves][NI groups][PQ]
+  auto lanes = [&](float v) RD_INLINE_LAMBDA {
+#pragma unroll
+    for (int o = NI; o < 64; o <<= 1) v += __shfl_xor(v, o);
+    return v;
+  };
+#pragma unroll
+  for (int c = 0; c < CPI; c++) {
+    const float x0 = lanes(sa[c]), x1 = lanes(sb[c]);
+    if (lane < NI) { red[(wv * NI + part) * PQ + c * 2] = x0; red[(wv * NI + part) * PQ + c * 2 + 1] = x1; }
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+      const float x = lanes(wacc[c][k]);
+      if (lane < NI) red[(wv * NI + part) * PQ + 2 * CPI + c * 9 + k] = x;
+    }
+  }
+  __syncthreads();
+  // partial row: pairs [0, 16) = (sum g, sum g xhat) of channel c; pairs [16, 88) = the weight-gradient sums dw[c * 9 + k], two per pair
+  float* row = a.partial + (int64_t)blockIdx.x * HEAD_PC * 2;
+  for (int j = t; j < NI * PQ; j += 256) {
+    const int h = j / PQ, q = j - h * PQ;
+    const float v = (red[(0 * NI + h) * PQ + q] + red[(1 * NI + h) * PQ + q]) + (red[(2 * NI + h) * PQ + q] + red[(3 * NI + h) * PQ + q]);
+    if (q < 2 * CPI) row[(h * CPI + (q >> 1)) * 2 + (q & 1)] = v;
+    else row[HC * 2 + h * CPI * 9 + (q - 2 * CPI)] = v;
+  }
+}
+
+// partial rows -> BatchNorm coefficients + parameter gradients (blocks [0, 16): exactly bn_bwd_finalize_kernel) and the head's weight gradient
+// (blocks [16, 88): two of its 144 sums each); fixed order, double precision
+__global__ __launch_bounds__(256) void bn_head_finalize_kernel(const float* __restrict__ partial, int rows, double count, float* dgamma, float* dbeta,
+                                                               int bn_acc, float* c1, float* c2, float* dw, int w_acc) {
+  __shared__ double s1[4], s2[4];
+  const int c = blockIdx.x, t = threadIdx.x;
+  double x = 0.0, y = 0.0;
+  bn_rows_sum(reinterpret_cast<const float2*>(partial), rows, HEAD_PC, c, t, x, y);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { x += __shfl_xor(x, o); y += __shfl_xor(y, o); }
+  if ((t & 63) == 0) { s1[t >> 6] = x; s2[t >> 6] = y; }
+  __syncthreads();
+  if (t == 0) {
+    x = (s1[0] + s1[1]) + (s1[2] + s1[3]); y = (s2[0] + s2[1]) + (s2[2] + s2[3]);
+    if (c < HC) {
+      if (dbeta) dbeta[c] = bn_acc ? dbeta[c] + (float)x : (float)x;
+      if (dgamma) dgamma[c] = bn_acc ? dgamma[c] + (float)y : (float)y;
+      c1[c] = (float)(x / count); c2[c] = (float)(y / count);
+    } else if (dw) {
+      const int j = (c - HC) * 2;
+      dw[j] = w_acc ? dw[j] + (float)x : (float)x;
+      dw[j + 1] = w_acc ? dw[j + 1] + (float)y : (float)y;
+    }
+  }
+}
+
+// ---- backward, pass 2: dy = scale (g - c1 - xhat c2), g = round(conv3x3^T(dlogits)) act'(scale y + shift) ------------------------------------
+template <typename T, int ACT, int CPI>
+__global__ __launch_bounds__(256) void bn_head_bwd_apply_kernel(HeadArgs a) {
+  constexpr int NI = HC / CPI;
+  RD_DYN_SMEM(smem);
+  float* sdl = reinterpret_cast<float*>(smem);
+  const int actv = ACT >= 0 ? ACT : a.act;
+  const int t = threadIdx.x, part = t % NI;
+  const int twh = a.tw + 2;
+  const HeadTile tl = head_tile(a, xcd_contiguous(blockIdx.x, gridDim.x));
+  float wq[CPI][9], sc[CPI], sh[CPI], mu[CPI], rs[CPI], k1[CPI], k2[CPI];
+  head_weights<T, CPI>(a.w, part, wq);
+#pragma unroll
+  for (int c = 0; c < CPI; c++) {
+    const int cc = part * CPI + c;
+    sc[c] = a.scale[cc]; sh[c] = a.shift[cc]; mu[c] = a.mean[cc]; rs[c] = a.rstd[cc]; k1[c] = a.c1[cc]; k2[c] = a.c2[cc];
+  }
+  stage_dl<T>(a, tl, sdl);
+  __syncthreads();
+  const int64_t ib = (int64_t)tl.n * a.H * a.W * HC + part * CPI;
+  const T* yb = (const T*)a.y + ib;
+  T* ob = (T*)a.out + ib;
+  // dy = scale (g - c1 - (y - mean) rstd c2) = fma(B, y, fma(scale, g, A)): two fused multiply-adds per element (this pass is as close to its
+  // vector-issue time as to its HBM time)
+  float cA[CPI], cB[CPI];
+#pragma unroll
+  for (int c = 0; c < CPI; c++) { cB[c] = -(sc[c] * rs[c] * k2[c]); cA[c] = sc[c] * (rs[c] * k2[c] * mu[c] - k1[c]); }
+  auto off = [&](const PixWalk& q, bool& ok) RD_INLINE_LAMBDA -> int64_t {
+    const int r = tl.r0 + q.r, c = tl.c0 + q.c;
+    ok = r < a.H && c < a.W;
+    return ((int64_t)min(r, a.H - 1) * a.W + min(c, a.W - 1)) * HC;
+  };
+  auto item = [&](const PixWalk& q, int64_t o, const float (&yy)[CPI], bool ok) RD_INLINE_LAMBDA {
+    float e[9], da[CPI], dy[CPI];
+    head_neighbours(sdl, twh, q.r, q.c, e);
+    head_dgrad<T, CPI>(wq, e, da);
+#pragma unroll
+    for (int c = 0; c < CPI; c++) {
+      float g = da[c];
+      if (actv) g *= act_grad_from_out(yy[c] * sc[c] + sh[c], actv, a.slope);
+      dy[c] = fmaf(cB[c], yy[c], fmaf(sc[c], g, cA[c]));
+    }
+    if (ok) ChanIO<T, CPI>::st(ob + o, dy);
+  };
+  PixWalk q0(t / NI, 256 / NI, a.tw), q1 = q0.next();
+  for (; q1.r < a.th; q0 = q0.next2(), q1 = q1.next2()) {
+    bool ok0, ok1; float y0[CPI], y1[CPI];
+    const int64_t o0 = off(q0, ok0), o1 = off(q1, ok1);
+    ChanIO<T, CPI>::ld(yb + o0, y0); ChanIO<T, CPI>::ld(yb + o1, y1);
+    item(q0, o0, y0, ok0); item(q1, o1, y1, ok1);
+  }
+  if (q0.r < a.th) {
+    bool ok0; float y0[CPI];
+    const int64_t o0 = off(q0, ok0);
+    ChanIO<T, CPI>::ld(yb + o0, y0);
+    item(q0, o0, y0, ok0);
+  }
+}
+
+// ---- host side ---------------------------------------------------------------------------------------------------------------------
+struct HeadPlan { int th, tw, tilesH, tilesW; };
+static HeadPlan head_plan(int H, int W, int max_np) {
+  HeadPlan p;
+  p.tilesW = W <= 160 ? 1 : (int)cdiv(W, 128);
+  p.tw = (int)cdiv(W, p.tilesW);
+  int th = std::max(1, std::min(H, max_np / (p.tw + 2) - 2));
+  p.tilesH = (int)cdiv(H, th);
+  p.th = (int)cdiv(H, p.tilesH);
+  return p;
+}
+bool bn_head_ok(int N, int H, int W, int C, int dtype) {
+  (void)dtype;
+  return C == HC && N > 0 && H > 0 && W > 0 && (int64_t)N * H * W < ((int64_t)1 << 31) / HC;
+}
+static int head_fwd_np() { return rd_opt(OPT_HEAD_NP, 1360); }     // pixels (tile + halo) of a forward tile: 36 bytes of LDS each
+static int head_bwd_np() { return 2048; }
+static int head_cpi(int which) { return ((rd_opt(OPT_HEAD_CPI, 0x444) >> (4 * which)) & 15) == 8 ? 8 : 4; }      // channels per work item of kernel `which`
+static HeadArgs head_args(const HeadPlan& p, int N, int H, int W, int act, float slope) {
+  HeadArgs a = {};
+  a.N = N; a.H = H; a.W = W; a.th = p.th; a.tw = p.tw; a.tilesH = p.tilesH; a.tilesW = p.tilesW; a.act = act; a.slope = slope;
+  return a;
+}
+int bn_head_rows(int N, int H, int W) {
+  const HeadPlan p = head_plan(H, W, head_bwd_np());
+  return (int)std::min<int64_t>((int64_t)N * p.tilesH * p.tilesW, 1024);
+}
+// (activation, channels per item) -> compile-time
+template <typename F> static void head_dispatch(int act, int cpi, F f) {
+  if (act == ACT_LRELU) { if (cpi == 8) f(std::integral_constant<int, ACT_LRELU>(), std::integral_constant<int, 8>()); else f(std::integral_constant<int, ACT_LRELU>(), std::integral_constant<int, 4>()); }
+  else { if (cpi == 8) f(std::integral_constant<int, -1>(), std::integral_constant<int, 8>()); else f(std::integral_constant<int, -1>(), std::integral_constant<int, 4>()); }
+}
+void launch_bn_head_fwd(const void* y, const float* scale, const float* shift, int act, float slope, const float* w, void* logits, int N, int H, int W,
+                        int dtype, hipStream_t st) {
+  const HeadPlan p = head_plan(H, W, head_fwd_np());
+  HeadArgs a = head_args(p, N, H, W, act, slope);
+  a.y = y; a.scale = scale; a.shift = shift; a.w = w; a.out = logits;
+  const unsigned grid = (unsigned)(N * p.tilesH * p.tilesW);
+  const size_t lds = (size_t)(p.th + 2) * (p.tw + 2) * 9 * sizeof(float);
+  head_dispatch(act, head_cpi(0), [&](auto ac, auto cp) {
+    constexpr int A = decltype(ac)::value, CPI = decltype(cp)::value;
+    if (dtype == 0) hipLaunchKernelGGL((bn_head_fwd_kernel<float, A, CPI>), dim3(grid), dim3(256), lds, st, a);
+    else hipLaunchKernelGGL((bn_head_fwd_kernel<bf16_t, A, CPI>), dim3(grid), dim3(256), lds, st, a);
+  });
+}
+void launch_bn_head_bwd_reduce(const void* dl, const void* y, const float* mean, const float* rstd, const float* scale, const float* shift, int act,
+                               float slope, const float* w, float* partial, int N, int H, int W, int dtype, hipStream_t st) {
+  const HeadPlan p = head_plan(H, W, head_bwd_np());
+  HeadArgs a = head_args(p, N, H, W, act, slope);
+  a.y = y; a.dl = dl; a.scale = scale; a.shift = shift; a.mean = mean; a.rstd = rstd; a.w = w; a.partial = partial;
+  const int ntiles = N * p.tilesH * p.tilesW;
+  const unsigned grid = (unsigned)bn_head_rows(N, H, W);
+  const size_t lds = std::max((size_t)(p.th + 2) * (p.tw + 2), (size_t)4 * HC * 11) * sizeof(float);
+  head_dispatch(act, head_cpi(1), [&](auto ac, auto cp) {
+    constexpr int A = decltype(ac)::value, CPI = decltype(cp)::value;
+    if (dtype == 0) hipLaunchKernelGGL((bn_head_bwd_reduce_kernel<float, A, CPI>), dim3(grid), dim3(256), lds, st, a, ntiles);
+    else hipLaunchKernelGGL((bn_head_bwd_reduce_kernel<bf16_t, A, CPI>), dim3(grid), dim3(256), lds, st, a, ntiles);
+  });
+}
+void launch_bn_head_bwd_apply(const void* dl, const void* y, const float* mean, const float* rstd, const float* scale, const float* shift, int act,
+                              float slope, const float* w, const float* partial, int rows, float* coef, float* dgamma, float* dbeta, int bn_acc,
+                              float* dw, int w_acc, void* dy, int N, int H, int W, int dtype, hipStream_t st) {
+  hipLaunchKernelGGL(bn_head_finalize_kernel, dim3(HEAD_PC), dim3(256), 0, st, partial, rows, (double)N * H * W, dgamma, dbeta, bn_acc, coef, coef + HC, dw,
+                     w_acc);
+  const HeadPlan p = head_plan(H, W, head_bwd_np());
+  HeadArgs a = head_args(p, N, H, W, act, slope);
+  a.y = y; a.dl = dl; a.scale = scale; a.shift = shift; a.mean = mean; a.rstd = rstd; a.w = w; a.c1 = coef; a.c2 = coef + HC; a.out = dy;
+  const unsigned grid = (unsigned)(N * p.tilesH * p.tilesW);
+  const size_t lds = (size_t)(p.th + 2) * (p.tw + 2) * sizeof(float);
+  head_dispatch(act, head_cpi(2), [&](auto ac, auto cp) {
+    constexpr int A = decltype(ac)::value, CPI = decltype(cp)::value;
+    if (dtype == 0) hipLaunchKernelGGL((bn_head_bwd_apply_kernel<float, A, CPI>), dim3(grid), dim3(256), lds, st, a);
+    else hipLaunchKernelGGL((bn_head_bwd_apply_kernel<bf16_t, A, CPI>), dim3(grid), dim3(256), lds, st, a);
+  });
+}
+const char* bn_head_kernel_name(int which, int dtype, int act) {
+  static thread_local char buf[96];
+  static const char* const names[3] = {"bn_head_fwd_kernel", "bn_head_bwd_reduce_kernel", "bn_head_bwd_apply_kernel"};
+  snprintf(buf, sizeof(buf), "%s<%s, %d, %d>", names[which], dtype == 0 ? "float" : RD_T16_NAME, act == ACT_LRELU ? ACT_LRELU : -1, head_cpi(which));
+  return buf;
+}
+
+}  // namespace rd

@@ -96,6 +96,18 @@ void launch_layernorm_bwd(const void* dout, const void* x, const float* gamma, c
                           void* dx, float* partial, float* dgamma, float* dbeta, int accumulate, int64_t rows, int C,
                           int dtype, hipStream_t st);
 
+// rd_head.hip (decoder head: BatchNorm + activation of the last decoder convolution fused with the one-channel 3x3 output convolution)
+bool bn_head_ok(int N, int H, int W, int C, int dtype);
+int bn_head_rows(int N, int H, int W);
+void launch_bn_head_fwd(const void* y, const float* scale, const float* shift, int act, float slope, const float* w, void* logits, int N, int H, int W,
+                        int dtype, hipStream_t st);
+void launch_bn_head_bwd_reduce(const void* dl, const void* y, const float* mean, const float* rstd, const float* scale, const float* shift, int act,
+                               float slope, const float* w, float* partial, int N, int H, int W, int dtype, hipStream_t st);
+void launch_bn_head_bwd_apply(const void* dl, const void* y, const float* mean, const float* rstd, const float* scale, const float* shift, int act,
+                              float slope, const float* w, const float* partial, int rows, float* coef, float* dgamma, float* dbeta, int bn_acc,
+                              float* dw, int w_acc, void* dy, int N, int H, int W, int dtype, hipStream_t st);
+const char* bn_head_kernel_name(int which, int dtype, int act);
+
 // rd_pool.hip
 void launch_maxpool_fwd(const void* x, void* out, unsigned char* arg, int N, int H, int W, int C, int OH, int OW, int k,
                         int s, int p, int dtype, hipStream_t st);

@@ -34,6 +34,7 @@ _state = {"dtype": RD_F32, "tape": None, "defer_wgrad": True, "fused_loftr": Tru
           # conv2 staging, conv2 -> fused apply + add + activation: measured faster); 2: also the decoder chain (measured SLOWER on MI355X:
           # the 3x3 kernels are vector-issue bound and the staging arithmetic costs more than the HBM pass it replaces -- DESIGN.md)
           "lazy_bn": 1,
+          "bn_head": True,    # conv -> BatchNorm -> act -> one-channel 3x3 output convolution: the fused decoder-head kernels (rd_bn_head_*)
           # (round 4 measured two concurrency experiments SLOWER on MI355X / ROCm 7 and round 5 removed them from the product: convolution weight
           # gradients on a second stream -- RC-Net 1005 -> 952 img/s, 38 fork / join edges per step -- and the skip features' RoI poolings next to
           # the transformer -- 1059 -> 1049; DESIGN.md section 3 "Round 4")
@@ -49,7 +50,7 @@ _state = {"dtype": RD_F32, "tape": None, "defer_wgrad": True, "fused_loftr": Tru
           "bn_bwd_fused": False,
           "dw_fused_stats": True}          # depthwise convolution with the BatchNorm statistics in its epilogue; False: separate rd_bn_stats pass
 
-_SWITCHES = {"fuse_upsample_bwd": bool, "loftr_cross_inplace": bool, "fuse_res_add": bool, "fuse_grad_add": bool, "lazy_bn": (0, 2), "roi_u8": bool,
+_SWITCHES = {"fuse_upsample_bwd": bool, "loftr_cross_inplace": bool, "fuse_res_add": bool, "fuse_grad_add": bool, "lazy_bn": (0, 2), "bn_head": bool, "roi_u8": bool,
              "roi_bwd": ("auto", "gather", "tile", "atomic"), "bn_recompute": bool, "bn_bwd_fused": bool, "dw_fused_stats": bool, "roi_tile_min_blocks": (0, 1 << 30),
              "defer_wgrad": bool, "fused_loftr": bool, "deterministic_roi_pool": bool}
 
@@ -94,7 +95,13 @@ def apply_opts(spec):
 
 
 # how often a virtual activation was consumed in place / had to be written after all (tests assert that the fused routes are taken)
-lazy_counts = {"fwd_fused": 0, "wgrad_fused": 0, "add_fused": 0, "materialized": 0, "bn_bwd_fused": 0}
+lazy_counts = {"fwd_fused": 0, "wgrad_fused": 0, "add_fused": 0, "materialized": 0, "bn_bwd_fused": 0, "head_fused": 0, "head_unfused_bwd": 0}
+
+
+def head_route(C):
+    """True when a conv -> BatchNorm -> act layer with C output channels whose only consumer is a one-channel 3x3 output convolution should
+    hand that consumer a LazyAct (conv_block then takes the fused decoder-head kernels, rd_bn_head_*)."""
+    return bool(_state["bn_head"] and _state["lazy_bn"] >= 1 and _state["bn_recompute"] and C == 16)
 
 
 def set_lazy_bn(level):
@@ -302,6 +309,10 @@ class Tape:
         if t is None or g is None or id(t) not in self.req:
             return
         cur = self.grads.get(id(t))
+        if cur is not None and isinstance(g, HeadGrad):      # a virtual gradient meets another contribution: written out the unfused way
+            g = g.materialize(self)
+        if isinstance(cur, HeadGrad):
+            cur = cur.materialize(self)
         if cur is None:
             self.grads[id(t)] = g
         else:  # never in place: gradient tensors may be shared with other consumers
@@ -796,6 +807,39 @@ class LazyAct(object):
         return self._z
 
 
+class HeadGrad(object):
+    """The gradient of a LazyAct whose consumer is the one-channel 3x3 output convolution (conv_block's head route): dlogits + the head's
+    weight stand in for the 16-channel tensor, which the producer's backward never needs in HBM (rd_bn_head_bwd_reduce / _apply recompute it
+    from the nine neighbouring dlogits of a pixel).  materialize(): the unfused backward of the head convolution, for a producer that
+    cannot take the virtual form."""
+    __slots__ = ("lz", "dl", "weight", "w_req", "geom", "flops", "shp")
+
+    def __init__(self, lz, dl, weight, w_req, geom, flops, shp):
+        self.lz, self.dl, self.weight, self.w_req, self.geom, self.flops, self.shp = lz, dl, weight, w_req, geom, flops, shp
+
+    def materialize(self, t):
+        lib = L()
+        lazy_counts["head_unfused_bwd"] += 1
+        N, H, W, C, dt = self.geom
+        dl, st = self.dl, _stream(self.dl)
+        if self.w_req:
+            a = self.lz.materialize()
+            d = _desc(dt, N, H, W, C, 0, False, H, W, 1, 3, 3, 1, 1, 1, H, W, ACT_NONE, 0.0, 1)
+            dw, acc = t.param_grad(self.weight)
+            ws = torch.empty(lib.rd_conv_wgrad_workspace_bytes(ctypes.byref(d)) // 4, dtype=torch.float32, device=dl.device)
+            _chk(_timed("conv_wgrad", self.flops, lambda: lib.rd_conv_wgrad(ctypes.byref(d), _p(a), None, _p(dl), _p(ws), _p(dw), acc, st), "wgrad " + self.shp),
+                 "rd_conv_wgrad")
+        dd = _desc(dt, N, H, W, 1, 0, False, H, W, C, 3, 3, 1, 1, 1, H, W, ACT_NONE, 0.0, C)
+        da = torch.empty((N, H, W, C), dtype=dl.dtype, device=dl.device)
+        _chk(_timed("conv_gemm", self.flops, lambda: lib.rd_conv_fwd(ctypes.byref(dd), _p(dl), None, _p(packed_weight(self.weight, 1, dt)), None, _p(da), None,
+                                                                        None, st), "dgrad " + self.shp), "rd_conv_fwd(dgrad)")
+        return da
+
+
+def _head_name(which, dt, act):
+    return lambda: L().rd_bn_head_kernel_name(which, dt, act).decode()
+
+
 def materialize(x):
     """LazyAct -> its activated tensor (written on first use); tensors pass through."""
     return x.materialize() if isinstance(x, LazyAct) else x
@@ -809,6 +853,37 @@ def _desc(dt, N, Hin, Win, C1, C2, up, H1, W1, Cout, KH, KW, stride, pad, dil, O
     d.Cout, d.KH, d.KW, d.stride, d.pad, d.in_dilate = Cout, KH, KW, stride, pad, dil
     d.OH, d.OW, d.act, d.slope, d.D1 = OH, OW, act, slope, D1
     return d
+
+
+def _conv_head(lz, xk, weight, N, H, W, C, dt, st):
+    """conv_block's head route: logits = conv3x3(act(BN(y))) with one output channel, straight from the producer's raw output y
+    (rd_bn_head_fwd: the activated tensor is never written); the backward hands the producer a HeadGrad instead of a tensor."""
+    lib = L()
+    t = tape()
+    y = lz.y
+    es = y.element_size()
+    logits = torch.empty((N, H, W, 1), dtype=y.dtype, device=y.device)
+    flops = 2.0 * N * H * W * 9 * C
+    shp = "M=%d Cin=%d Cout=1 k=3 s=1" % (N * H * W, C)
+    lazy_counts["head_fused"] += 1
+    w32 = weight.detach()
+    _chk(_timed("conv_gemm", flops, lambda: lib.rd_bn_head_fwd(_p(y), _p(lz.coef[0]), _p(lz.coef[1]), lz.act, lz.slope, _p(w32), _p(logits), N, H, W, C, dt, st),
+                "fwd " + shp + " (bn+head)", y.numel() * es + N * H * W * es, kernel=_head_name(0, dt, lz.act), idem=True), "rd_bn_head_fwd")
+    if t is None:
+        return logits
+    w_req = weight.requires_grad
+    t.mark(logits)
+
+    def backward():
+        dl = t.pop_grad(logits)
+        if dl is None:
+            return
+        if not dl.is_contiguous():
+            dl = dl.contiguous()
+        t.add_grad(xk, HeadGrad(lz, dl, weight, w_req, (N, H, W, C, dt), flops, shp))
+
+    t.record(backward)
+    return logits
 
 
 def conv_block(x, weight, *, x2=None, bias=None, stride=1, pad=None, up=None, bn=None, act=ACT_NONE, slope=0.2,
@@ -859,6 +934,11 @@ def conv_block(x, weight, *, x2=None, bias=None, stride=1, pad=None, up=None, bn
         xp = torch.empty((N, H1, W1, cin_pad), dtype=x.dtype, device=x.device)
         _chk(lib.rd_pad_channels(_p(x), _p(xp), N * H1 * W1, C1, cin_pad, dt, st), "rd_pad_channels")
         x_real, x, C1_real, C1 = x, xp, C1, cin_pad
+    if (lz is not None and _state["bn_head"] and lz._z is None and KH == 3 and KW == 3 and stride == 1 and pad == 1 and Cout == 1 and x2 is None
+            and not is_up and bias is None and not use_bn and residual is None and act == ACT_NONE and out_hw is None and not cin_pad
+            and weight.dtype == torch.float32 and weight.is_contiguous() and (t is None or t.requires(xk))
+            and lib.rd_bn_head_ok(N, H1, W1, C1, dt)):
+        return _conv_head(lz, xk, weight, N, H1, W1, C1, dt, st)
     d = _desc(dt, N, Hin, Win, C1, C2, is_up, H1, W1, Cout, KH, KW, stride, pad, 1, OH, OW, conv_act, slope, Cout)
     fus = None
     if lz is not None:          # virtual input: fused where the kernel this shape is routed to stages whole channel vectors, else z is written now
@@ -952,7 +1032,25 @@ def conv_block(x, weight, *, x2=None, bias=None, stride=1, pad=None, up=None, bn
             dy = torch.empty_like(y)
             dres = torch.empty_like(y) if need_res else None
             part = src["partial"] if src is not None else None
-            if part is not None and part[3] is dz and not need_res:
+            if isinstance(dz, HeadGrad) and (need_res or not _state["bn_recompute"]):
+                dz = dz.materialize(t)
+            if isinstance(dz, HeadGrad):
+                # this layer's output feeds the one-channel output convolution and nothing else: its gradient is a function of the nine
+                # neighbouring dlogits, recomputed inside the two passes of the BatchNorm backward (pass 1 also sums the head's weight gradient)
+                hg, w_h = dz, dz.weight
+                hrows = lib.rd_bn_head_rows(N, OH, OW)
+                hpart = torch.empty((hrows, 88, 2), dtype=torch.float32, device=x.device)
+                hargs = (_p(hg.dl), _p(y), _p(mean), _p(rstd), _p(scale), _p(shift), act, slope, _p(w_h.detach()))
+                _chk(_timed("bn_backward", 2 * hg.flops, lambda: lib.rd_bn_head_bwd_reduce(*hargs, _p(hpart), N, OH, OW, Cout, dt, st),
+                            "bn+head backward M=%d C=%d [sums + head wgrad]" % (pixels, Cout), b_out + 2 * pixels * es, kernel=_head_name(1, dt, act), idem=True),
+                     "rd_bn_head_bwd_reduce")
+                dwh, acch = t.param_grad(w_h) if hg.w_req else (None, 0)
+                _chk(_timed("bn_backward", hg.flops, lambda: lib.rd_bn_head_bwd_apply(*hargs, _p(hpart), hrows, _p(coef2), _p(dgam), _p(dbet), acc, _p(dwh), acch,
+                                                                                       _p(dy), N, OH, OW, Cout, dt, st),
+                            "bn+head backward M=%d C=%d [apply + head dgrad]" % (pixels, Cout), 2 * b_out + 2 * pixels * es, kernel=_head_name(2, dt, act)),
+                     "rd_bn_head_bwd_apply")
+                partial = None
+            elif part is not None and part[3] is dz and not need_res:
                 # the data gradient that wrote this very dz tensor already summed (g, g * xhat) over it in its epilogue: finalize + apply only
                 lazy_counts["bn_bwd_fused"] += 1
                 _chk(_tb("bn_backward", 3 * b_out,
@@ -976,6 +1074,8 @@ def conv_block(x, weight, *, x2=None, bias=None, stride=1, pad=None, up=None, bn
                                                    _p(dbet), acc, _p(dy), _p(dres), pixels, Cout, act, slope, dt, st),
                          "bn backward(res) M=%d C=%d" % (pixels, Cout)), "rd_bn_act_bwd")
         else:
+            if isinstance(dz, HeadGrad):
+                dz = dz.materialize(t)
             eff_act = act
             if eff_act != ACT_NONE:
                 dy = torch.empty_like(y)

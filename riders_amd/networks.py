@@ -226,10 +226,12 @@ class MultiScaleDecoder(torch.nn.Module):
         h = self.deconv3._fwd(h, skips[n], lazy=2); n -= 1
         h = self.deconv2._fwd(h, skips[n], lazy=2); n -= 1
         h = self.deconv1._fwd(h, skips[n], lazy=2); n -= 1
+        # deconv0's output feeds the one-channel output convolution only: virtual at level 1 when the fused head kernels take the pair (engine bn_head)
+        lz0 = 1 if engine.head_route(self.output0.conv.in_channels) else 2
         if n == 0:
-            h = self.deconv0._fwd(h, skips[n], lazy=2)
+            h = self.deconv0._fwd(h, skips[n], lazy=lz0)
         else:
-            h = self.deconv0._fwd(h, shape=tuple(shape[-2:]), lazy=2)
+            h = self.deconv0._fwd(h, shape=tuple(shape[-2:]), lazy=lz0)
         return [self.output0._fwd(h)]
 
     def forward(self, x, skips, shape=None):

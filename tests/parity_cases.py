@@ -495,12 +495,14 @@ def _lazy_both(build_and_run):
     res, counts = [], None
     for flag in (True, False):
         engine.set_lazy_bn(2 if flag else 0)
+        engine.set_switch("bn_head", False)      # (the fused decoder head rounds / sums differently: bn_head_cases compares it with a tolerance)
         for k in engine.lazy_counts:
             engine.lazy_counts[k] = 0
         try:
             res.append([r.detach().float().cpu().clone() for r in build_and_run()])
         finally:
             engine.set_lazy_bn(1)
+            engine.set_switch("bn_head", True)
         if flag:
             counts = dict(engine.lazy_counts)
     assert len(res[0]) == len(res[1])
@@ -612,6 +614,81 @@ def bn_bwd_fused_cases(dev, quick=False):
                     assert torch.equal(res[True][0], res[False][0]), "forward output changed"
                     for a, b in zip(res[True][1:], res[False][1:]):
                         close(a, b, 1e-5 if mode == "fp32" else 2e-2, "BatchNorm backward sums from the data-gradient epilogue (%s)" % mode)
+        finally:
+            if ctx:
+                ctx.__exit__()
+
+
+class force_head(_force_options):
+    """Tile size (pixels incl. halo of a forward tile) and channels per work item (one nibble per kernel: forward, backward sums, backward
+    apply) of the fused decoder-head kernels (rd_head.hip)."""
+    def __init__(self, np_=None, cpi=None):
+        self.opts = {}
+        if np_ is not None:
+            self.opts["head_np"] = np_
+        if cpi is not None:
+            self.opts["head_cpi"] = cpi
+
+
+def bn_head_cases(dev, quick=False):
+    """conv -> BatchNorm -> LeakyReLU -> one-channel 3x3 output convolution through the fused decoder-head kernels (rd_bn_head_fwd /
+    _bwd_reduce / _bwd_apply: the activated 16-channel tensor and its gradient are recomputed from the raw convolution output, never
+    stored) against the unfused chain (engine switch bn_head off): logits, input gradient and every parameter gradient (first convolution,
+    BatchNorm gamma / beta, head weight) within 1e-5 (fp32) / 2e-2 of max (bf16: other summation orders, dy rounded once) -- several tiles
+    per image with halo rows, two column tiles, ragged edges, 4 and 8 channels per work item, and the fall-back when the virtual gradient
+    meets a second consumer's (both orders).  The fused route IS taken (engine.lazy_counts)."""
+    from riders_amd import engine, net_utils
+
+    class Pair(torch.nn.Module):
+        def __init__(self, cin, second=0):
+            super().__init__()
+            self.c1 = net_utils.Conv2d(cin, 16, 3, 1, 'kaiming_uniform', net_utils.activation_func('leaky_relu'), True)
+            self.out = net_utils.Conv2d(16, 1, 3, 1, 'kaiming_uniform', net_utils.activation_func('linear'), False)
+            self.second = second
+            if second:
+                self.c2 = net_utils.Conv2d(16, 8, 3, 1, 'kaiming_uniform', net_utils.activation_func('linear'), False)
+
+        def forward(self, x):
+            def run(x):
+                h = self.c1._fwd(engine.from_nchw(x), lazy=1 if engine.head_route(16) else 0)
+                if self.second == 1:
+                    o2 = self.c2._fwd(h)
+                o = self.out._fwd(h)
+                if self.second == 2:
+                    o2 = self.c2._fwd(h)
+                outs = (o, o2) if self.second else (o,)
+                return tuple(engine.to_nchw_out(v, x.dtype) for v in outs)
+            outs = engine.run_region(run, (x,), list(self.parameters()))
+            return outs[0] if not self.second else outs[0] + outs[1].sum(1, keepdim=True)
+
+    for mode in ("fp32", "bf16"):
+        ctx = bf16_mode("bf16") if mode == "bf16" else None
+        if ctx:
+            ctx.__enter__()
+        try:
+            cases = [((3, 16, 37, 23), dict(np_=256), 0), ((2, 32, 5, 170), dict(), 0)]
+            if not quick:
+                cases += [((2, 16, 37, 23), dict(np_=256, cpi=0x888), 0), ((2, 16, 20, 9), dict(), 1), ((2, 16, 20, 9), dict(), 2)]
+            elif mode == "bf16":
+                cases += [((1, 16, 12, 9), dict(cpi=0x888), 0), ((1, 16, 9, 7), dict(), 1)]
+            for shape, kw, second in cases:
+                with force_head(**kw):
+                    run = _lazy_module_run(dev, lambda: Pair(shape[1], second), [q(t(rand_array("head.x", shape, 1.0)))], lambda m, x: m(x))
+                    res = {}
+                    for on in (False, True):
+                        engine.set_switch("bn_head", on)
+                        try:
+                            for k in engine.lazy_counts:
+                                engine.lazy_counts[k] = 0
+                            res[on] = [None if v is None else v.detach().float().cpu() for v in run()]
+                            c = dict(engine.lazy_counts)
+                        finally:
+                            engine.set_switch("bn_head", True)
+                        assert c["head_fused"] == (1 if on else 0) and c["head_unfused_bwd"] == (1 if on and second else 0), (mode, shape, on, c)
+                    assert len(res[True]) == len(res[False])
+                    for i, (a, b) in enumerate(zip(res[True], res[False])):
+                        assert bool(torch.isfinite(a).all())
+                        close(a, b, 1e-5 if mode == "fp32" else 2e-2, "fused decoder head, tensor %d (%s, %s)" % (i, mode, shape))
         finally:
             if ctx:
                 ctx.__exit__()

@@ -61,6 +61,10 @@ def test_wgrad_fit(emu):
     P.wgrad_fit_cases(emu, quick=True)
 
 
+def test_bn_head_fused(emu):
+    P.bn_head_cases(emu, quick=True)
+
+
 def test_bn_bwd_sums_in_dgrad_epilogue(emu):
     P.bn_bwd_fused_cases(emu, quick=True)
 

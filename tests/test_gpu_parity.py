@@ -61,6 +61,10 @@ def test_wgrad_fit(gpu):
     P.wgrad_fit_cases(gpu)
 
 
+def test_bn_head_fused(gpu):
+    P.bn_head_cases(gpu)
+
+
 def test_bn_bwd_sums_in_dgrad_epilogue(gpu):
     P.bn_bwd_fused_cases(gpu)
     # RC-Net sizes, routed by block count (no hooks): RoI maps as pixel runs across images, encoder maps as 2-D tiles
