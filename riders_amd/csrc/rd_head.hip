@@ -33,27 +33,55 @@ struct HeadArgs {
 };
 static constexpr int HEAD_PC = HC + HC * 9 / 2;        // pairs per partial row: 16 x (sum g, sum g xhat) + the 144 weight-gradient sums
 
-// CPI consecutive channels <-> floats
+// CPI consecutive channels: raw registers (kept unconverted while the load is in flight) <-> floats
 template <typename T, int CPI> struct ChanIO;
+template <> struct ChanIO<bf16_t, 8> {
+  typedef uint4 Raw;
+  static __device__ __forceinline__ Raw ldraw(const bf16_t* p) { return *reinterpret_cast<const uint4*>(p); }
+  static __device__ __forceinline__ void cvt(const Raw& r, float (&o)[8]) { raw16_to_f32((const bf16_t*)nullptr, r, o); }
+  static __device__ __forceinline__ void st(bf16_t* p, const float (&o)[8]) { stv(p, o); }
+};
+template <> struct ChanIO<bf16_t, 4> {
+  typedef uint2 Raw;
+  static __device__ __forceinline__ Raw ldraw(const bf16_t* p) { return *reinterpret_cast<const uint2*>(p); }
+  static __device__ __forceinline__ void cvt(const Raw& r, float (&o)[4]) { o[0] = half_lo_f32(r.x); o[1] = half_hi_f32(r.x); o[2] = half_lo_f32(r.y); o[3] = half_hi_f32(r.y); }
+  static __device__ __forceinline__ void st(bf16_t* p, const float (&o)[4]) { st4(p, o); }
+};
+template <> struct ChanIO<float, 4> {
+  typedef float4 Raw;
+  static __device__ __forceinline__ Raw ldraw(const float* p) { return *reinterpret_cast<const float4*>(p); }
+  static __device__ __forceinline__ void cvt(const Raw& r, float (&o)[4]) { o[0] = r.x; o[1] = r.y; o[2] = r.z; o[3] = r.w; }
+  static __device__ __forceinline__ void st(float* p, const float (&o)[4]) { st4(p, o); }
+};
 template <> struct ChanIO<float, 8> {
-  static __device__ __forceinline__ void ld(const float* p, float (&o)[8]) {
-    float a[4], b[4]; ld4(p, a); ld4(p + 4, b);
-#pragma unroll
-    for (int e = 0; e < 4; e++) { o[e] = a[e]; o[4 + e] = b[e]; }
-  }
+  struct Raw { float4 a, b; };
+  static __device__ __forceinline__ Raw ldraw(const float* p) { Raw r; r.a = *reinterpret_cast<const float4*>(p); r.b = *reinterpret_cast<const float4*>(p + 4); return r; }
+  static __device__ __forceinline__ void cvt(const Raw& r, float (&o)[8]) { o[0] = r.a.x; o[1] = r.a.y; o[2] = r.a.z; o[3] = r.a.w; o[4] = r.b.x; o[5] = r.b.y; o[6] = r.b.z; o[7] = r.b.w; }
   static __device__ __forceinline__ void st(float* p, const float (&o)[8]) {
     const float a[4] = {o[0], o[1], o[2], o[3]}, b[4] = {o[4], o[5], o[6], o[7]};
     st4(p, a); st4(p + 4, b);
   }
 };
-template <> struct ChanIO<bf16_t, 8> {
-  static __device__ __forceinline__ void ld(const bf16_t* p, float (&o)[8]) { ldv(p, o); }
-  static __device__ __forceinline__ void st(bf16_t* p, const float (&o)[8]) { stv(p, o); }
-};
-template <typename T> struct ChanIO<T, 4> {
-  static __device__ __forceinline__ void ld(const T* p, float (&o)[4]) { ld4(p, o); }
-  static __device__ __forceinline__ void st(T* p, const float (&o)[4]) { st4(p, o); }
-};
+// explicit packed fp32 pairs (v_pk_fma_f32): the compiler pairs the straight multiply-add chains by itself, not the broadcast forms
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+
+// two values rounded to the activation type and back (one v_cvt_pk + two unpacks for the 16-bit types)
+template <typename T> __device__ __forceinline__ void rnd2(float& a, float& b);
+template <> __device__ __forceinline__ void rnd2<float>(float&, float&) {}
+template <> __device__ __forceinline__ void rnd2<bf16_t>(float& a, float& b) { const unsigned w = pack_bf16x2(a, b); a = half_lo_f32(w); b = half_hi_f32(w); }
+
+// activation of the producer, branch-free in the LeakyReLU instantiation: max(u, slope u) = (u > 0 ? u : slope u) bit for bit when
+// 0 <= slope <= 1 (the launcher instantiates ACT = LRELU only then)
+template <int ACT> __device__ __forceinline__ float head_act(float u, int act, float slope) {
+  if (ACT == ACT_LRELU) return fmaxf(u, u * slope);
+  return act_fwd(u, act, slope);
+}
+// g = da * act'(u)
+template <int ACT> __device__ __forceinline__ float head_act_bwd(float da, float u, int act, float slope) {
+  if (ACT == ACT_LRELU) return u > 0.f ? da : da * slope;
+  return act ? da * act_grad_from_out(u, act, slope) : da;
+}
 
 // sum over the NI = 16 / CPI neighbouring lanes that hold the channel groups of one pixel
 template <int NI>
@@ -72,9 +100,9 @@ struct HeadTile { int n, r0, c0; };
 // (row, column) of a thread's pixel inside a tile of width w, advanced by a constant number of pixels per iteration without a division
 struct PixWalk {
   int r, c, dr, dc, w;
+  __device__ __forceinline__ PixWalk() {}
   __device__ __forceinline__ PixWalk(int p0, int step, int width) : r(p0 / width), c(p0 - (p0 / width) * width), dr(step / width), dc(step - (step / width) * width), w(width) {}
-  __device__ __forceinline__ PixWalk next() const { PixWalk n = *this; n.r += dr; n.c += dc; if (n.c >= w) { n.c -= w; n.r++; } return n; }
-  __device__ __forceinline__ PixWalk next2() const { return next().next(); }
+  __device__ __forceinline__ void advance() { r += dr; c += dc; if (c >= w) { c -= w; r++; } }
 };
 __device__ __forceinline__ HeadTile head_tile(const HeadArgs& a, int tile) {
   HeadTile t;
@@ -109,7 +137,7 @@ __device__ __forceinline__ void stage_dl(const HeadArgs& a, const HeadTile& tl, 
 }
 // da[c] = sum over the data gradient's taps tp = (kh', kw') ascending of w[c][2 - kh'][2 - kw'] * dlogits[q + (kh' - 1, kw' - 1)] (the order of
 // conv3x3_c1_kernel, rd_conv3x3.hip, the kernel this replaces; fused multiply-adds here: the library is built with -ffp-contract=off and the 288
-// multiply-adds per pixel of the two backward passes are what bounds them); e[tp] = that neighbour's dlogit
+// multiply-adds per pixel of the two backward passes are what they issue most); e[tp] = that neighbour's dlogit
 __device__ __forceinline__ void head_neighbours(const float* sdl, int twh, int pr, int pc, float (&e)[9]) {
 #pragma unroll
   for (int kh = 0; kh < 3; kh++)
@@ -123,7 +151,27 @@ __device__ __forceinline__ void head_dgrad(const float (&wq)[CPI][9], const floa
     float s = 0.f;
 #pragma unroll
     for (int tp = 0; tp < 9; tp++) s = fmaf(wq[c][8 - tp], e[tp], s);
-    da[c] = Elem<T>::rnd(s);      // the unfused path stores da in the activation type
+    da[c] = s;
+  }
+#pragma unroll
+  for (int c = 0; c < CPI; c += 2) rnd2<T>(da[c], da[c + 1]);      // the unfused path stores da in the activation type
+}
+
+// A thread's items, U at a time, the raw loads of the next U in flight while the current U are computed.  load(q) must be safe for any q
+// (it clamps its address); item(q, raw) is called for the valid ones.
+template <int U, typename Raw, typename LoadF, typename ItemF>
+__device__ __forceinline__ void head_stream(int p0, int step, int width, int rows, LoadF load, ItemF item) {
+  PixWalk q[U]; Raw r[U];
+#pragma unroll
+  for (int j = 0; j < U; j++) { q[j] = PixWalk(p0 + j * step, U * step, width); r[j] = load(q[j]); }
+  while (q[0].r < rows) {
+    PixWalk qc[U]; Raw rc[U];
+#pragma unroll
+    for (int j = 0; j < U; j++) { qc[j] = q[j]; rc[j] = r[j]; q[j].advance(); r[j] = load(q[j]); }
+    sched_fence();
+#pragma unroll
+    for (int j = 0; j < U; j++)
+      if (qc[j].r < rows) item(qc[j], rc[j]);
   }
 }
 
@@ -131,28 +179,30 @@ __device__ __forceinline__ void head_dgrad(const float (&wq)[CPI][9], const floa
 // phase 1: every pixel of the tile + halo: a = round(act(scale y + shift)) (zero outside the image: the convolution pads a, not y), its nine
 // per-tap dot products over the 16 channels -> LDS; phase 2: an output pixel sums the nine taps of its neighbours.
 template <typename T, int ACT, int CPI>
-__global__ __launch_bounds__(256) RD_WAVES_PER_EU(4) void bn_head_fwd_kernel(HeadArgs a) {
-  constexpr int NI = HC / CPI;
+__global__ __launch_bounds__(256) RD_WAVES_PER_EU(CPI == 8 ? 3 : 4) void bn_head_fwd_kernel(HeadArgs a) {
+  constexpr int NI = HC / CPI, U = 2;
+  typedef typename ChanIO<T, CPI>::Raw Raw;
   RD_DYN_SMEM(smem);
   float* tp = reinterpret_cast<float*>(smem);      // [np][9]
-  const int actv = ACT >= 0 ? ACT : a.act;
   const int t = threadIdx.x, part = t % NI;
   const HeadTile tl = head_tile(a, xcd_contiguous(blockIdx.x, gridDim.x));
-  const int twh = a.tw + 2, np = (a.th + 2) * twh;
+  const int twh = a.tw + 2, thh = a.th + 2, np = thh * twh;
   float wq[CPI][9], sc[CPI], sh[CPI];
   head_weights<T, CPI>(a.w, part, wq);
 #pragma unroll
   for (int c = 0; c < CPI; c++) { sc[c] = a.scale[part * CPI + c]; sh[c] = a.shift[part * CPI + c]; }
   const T* yb = (const T*)a.y + (int64_t)tl.n * a.H * a.W * HC + part * CPI;
-  auto pix = [&](const PixWalk& q, bool& ok) RD_INLINE_LAMBDA -> const T* {
-    const int r = tl.r0 - 1 + q.r, c = tl.c0 - 1 + q.c;
-    ok = q.r < a.th + 2 && (unsigned)r < (unsigned)a.H && (unsigned)c < (unsigned)a.W;
-    return yb + ((int64_t)min(max(r, 0), a.H - 1) * a.W + min(max(c, 0), a.W - 1)) * HC;
+  auto load = [&](const PixWalk& q) RD_INLINE_LAMBDA {
+    const int r = min(max(tl.r0 - 1 + q.r, 0), a.H - 1), c = min(max(tl.c0 - 1 + q.c, 0), a.W - 1);
+    return ChanIO<T, CPI>::ldraw(yb + (r * a.W + c) * HC);
   };
-  auto taps = [&](const PixWalk& q, bool ok, const float (&yy)[CPI]) RD_INLINE_LAMBDA {
+  auto taps = [&](const PixWalk& q, const Raw& raw) RD_INLINE_LAMBDA {
     float av[CPI];
+    ChanIO<T, CPI>::cvt(raw, av);
 #pragma unroll
-    for (int c = 0; c < CPI; c++) av[c] = ok ? Elem<T>::rnd(act_fwd(yy[c] * sc[c] + sh[c], actv, a.slope)) : 0.f;
+    for (int c = 0; c < CPI; c++) av[c] = head_act<ACT>(av[c] * sc[c] + sh[c], a.act, a.slope);
+#pragma unroll
+    for (int c = 0; c < CPI; c += 2) rnd2<T>(av[c], av[c + 1]);
     float d[9];
 #pragma unroll
     for (int k = 0; k < 9; k++) {
@@ -161,28 +211,34 @@ __global__ __launch_bounds__(256) RD_WAVES_PER_EU(4) void bn_head_fwd_kernel(Hea
       for (int c = 0; c < CPI; c++) s = fmaf(wq[c][k], av[c], s);
       d[k] = parts_sum<NI>(s);
     }
-    if (q.r < a.th + 2) {      // the lanes of a pixel share the nine stores
+    if (q.r < thh) {      // the lanes of a pixel share the nine stores; a pixel outside the image is padding of the convolution's input: zero
+      const bool ok = (unsigned)(tl.r0 - 1 + q.r) < (unsigned)a.H && (unsigned)(tl.c0 - 1 + q.c) < (unsigned)a.W;
       const int p = q.r * twh + q.c;
 #pragma unroll
-      for (int k = 0; k < 9; k++)
-        if (k % NI == part) tp[p * 9 + k] = d[k];
+      for (int j = 0; j * NI < 9; j++) {      // lane `part` stores taps part, part + NI, ...: its value picked by selects (no store under a branch per tap)
+        float v = d[j * NI];
+#pragma unroll
+        for (int pp = 1; pp < NI; pp++)
+          if (j * NI + pp < 9) v = part == pp ? d[j * NI + pp] : v;
+        if ((j + 1) * NI <= 9 || j * NI + part < 9) tp[p * 9 + j * NI + part] = ok ? v : 0.f;
+      }
     }
   };
   // whole waves run every iteration (parts_sum needs all lanes of a pixel): the trip count is the block's, not the thread's
-  const int nit = (np * NI + 255) >> 8;
-  PixWalk q0(t / NI, 256 / NI, twh), q1 = q0.next();
-  int it = 0;
-  for (; it + 1 < nit; it += 2) {
-    bool ok0, ok1; float y0[CPI], y1[CPI];
-    const T* p0 = pix(q0, ok0); const T* p1 = pix(q1, ok1);
-    ChanIO<T, CPI>::ld(p0, y0); ChanIO<T, CPI>::ld(p1, y1);
-    taps(q0, ok0, y0); taps(q1, ok1, y1);
-    q0 = q0.next2(); q1 = q1.next2();
-  }
-  if (it < nit) {
-    bool ok0; float y0[CPI];
-    ChanIO<T, CPI>::ld(pix(q0, ok0), y0);
-    taps(q0, ok0, y0);
+  {
+    const int step = 256 / NI, nit = (np * NI + 255) >> 8;
+    PixWalk q[U]; Raw r[U];
+#pragma unroll
+    for (int j = 0; j < U; j++) { q[j] = PixWalk(t / NI + j * step, U * step, twh); r[j] = load(q[j]); }
+    for (int it = 0; it < nit; it += U) {
+      PixWalk qc[U]; Raw rc[U];
+#pragma unroll
+      for (int j = 0; j < U; j++) { qc[j] = q[j]; rc[j] = r[j]; q[j].advance(); r[j] = load(q[j]); }
+      sched_fence();
+#pragma unroll
+      for (int j = 0; j < U; j++)
+        if (it + j < nit) taps(qc[j], rc[j]);
+    }
   }
   __syncthreads();
   T* out = (T*)a.out + (int64_t)tl.n * a.H * a.W;
@@ -206,9 +262,9 @@ __global__ __launch_bounds__(256) RD_WAVES_PER_EU(4) void bn_head_fwd_kernel(Hea
 template <typename T, int ACT, int CPI>
 __global__ __launch_bounds__(256) void bn_head_bwd_reduce_kernel(HeadArgs a, int ntiles) {
   constexpr int NI = HC / CPI, PQ = CPI * 11;      // per channel group: CPI x (sum g, sum g xhat) + CPI x 9 weight-gradient sums
+  typedef typename ChanIO<T, CPI>::Raw Raw;
   RD_DYN_SMEM(smem);
   float* sdl = reinterpret_cast<float*>(smem);
-  const int actv = ACT >= 0 ? ACT : a.act;
   const int t = threadIdx.x, part = t % NI, lane = t & 63, wv = t >> 6;
   const int twh = a.tw + 2;
   float wq[CPI][9], sc[CPI], sh[CPI], mu[CPI], rs[CPI];
@@ -218,12 +274,13 @@ __global__ __launch_bounds__(256) void bn_head_bwd_reduce_kernel(HeadArgs a, int
     const int cc = part * CPI + c;
     sc[c] = a.scale[cc]; sh[c] = a.shift[cc]; mu[c] = a.mean[cc]; rs[c] = a.rstd[cc];
   }
-  float sa[CPI], sb[CPI], wacc[CPI][9];
+  float sa[CPI], sb[CPI], nmr[CPI];
+  f32x2 wacc[CPI][5];      // the nine weight-gradient sums of a channel as pairs (k, k + 1); the tenth slot stays zero
 #pragma unroll
   for (int c = 0; c < CPI; c++) {
-    sa[c] = 0.f; sb[c] = 0.f;
+    sa[c] = 0.f; sb[c] = 0.f; nmr[c] = -(mu[c] * rs[c]);
 #pragma unroll
-    for (int k = 0; k < 9; k++) wacc[c][k] = 0.f;
+    for (int k = 0; k < 5; k++) wacc[c][k] = f32x2{0.f, 0.f};
   }
   for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const HeadTile tl = head_tile(a, tile);
@@ -231,39 +288,40 @@ __global__ __launch_bounds__(256) void bn_head_bwd_reduce_kernel(HeadArgs a, int
     stage_dl<T>(a, tl, sdl);
     __syncthreads();
     const T* yb = (const T*)a.y + (int64_t)tl.n * a.H * a.W * HC + part * CPI;
-    auto item = [&](const PixWalk& q, const float (&yy)[CPI], bool ok) RD_INLINE_LAMBDA {
-      float e[9], da[CPI];
+    const bool ragged = tl.r0 + a.th > a.H || tl.c0 + a.tw > a.W;      // (block uniform) a last tile with pixels outside the image
+    auto load = [&](const PixWalk& q) RD_INLINE_LAMBDA {
+      const int r = min(tl.r0 + q.r, a.H - 1), c = min(tl.c0 + q.c, a.W - 1);
+      return ChanIO<T, CPI>::ldraw(yb + (r * a.W + c) * HC);
+    };
+    auto item = [&](const PixWalk& q, const Raw& raw) RD_INLINE_LAMBDA {
+      float yy[CPI], e[9], da[CPI], av[CPI];
+      ChanIO<T, CPI>::cvt(raw, yy);
       head_neighbours(sdl, twh, q.r, q.c, e);
+      if (ragged) {      // a pixel outside the image contributes nothing
+        const bool ok = tl.r0 + q.r < a.H && tl.c0 + q.c < a.W;
+#pragma unroll
+        for (int k = 0; k < 9; k++) e[k] = ok ? e[k] : 0.f;
+      }
       head_dgrad<T, CPI>(wq, e, da);
 #pragma unroll
       for (int c = 0; c < CPI; c++) {
         const float u = yy[c] * sc[c] + sh[c];
-        const float av = ok ? Elem<T>::rnd(act_fwd(u, actv, a.slope)) : 0.f;
-        float g = ok ? da[c] : 0.f;
-        if (actv) g *= act_grad_from_out(u, actv, a.slope);
-        sa[c] += g; sb[c] += g * ((yy[c] - mu[c]) * rs[c]);
-        // dw[c][kh][kw] = sum_q a[q][c] * dlogits[q - (kh - 1, kw - 1)] = a * e[8 - (kh * 3 + kw)]
+        av[c] = head_act<ACT>(u, a.act, a.slope);
+        const float g = head_act_bwd<ACT>(da[c], u, a.act, a.slope);
+        sa[c] += g; sb[c] = fmaf(g, fmaf(yy[c], rs[c], nmr[c]), sb[c]);      // xhat = (y - mean) rstd
+      }
 #pragma unroll
-        for (int k = 0; k < 9; k++) wacc[c][k] = fmaf(av, e[8 - k], wacc[c][k]);
+      for (int c = 0; c < CPI; c += 2) rnd2<T>(av[c], av[c + 1]);
+      // dw[c][kh][kw] = sum_q a[q][c] * dlogits[q - (kh - 1, kw - 1)] = a * e[8 - (kh * 3 + kw)]
+      const f32x2 er[5] = {f32x2{e[8], e[7]}, f32x2{e[6], e[5]}, f32x2{e[4], e[3]}, f32x2{e[2], e[1]}, f32x2{e[0], 0.f}};
+#pragma unroll
+      for (int c = 0; c < CPI; c++) {
+        const f32x2 a2 = {av[c], av[c]};
+#pragma unroll
+        for (int k = 0; k < 5; k++) wacc[c][k] = fma2(a2, er[k], wacc[c][k]);
       }
     };
-    auto addr = [&](const PixWalk& q, bool& ok) RD_INLINE_LAMBDA -> const T* {
-      const int r = tl.r0 + q.r, c = tl.c0 + q.c;
-      ok = r < a.H && c < a.W;
-      return yb + ((int64_t)min(r, a.H - 1) * a.W + min(c, a.W - 1)) * HC;
-    };
-    PixWalk q0(t / NI, 256 / NI, a.tw), q1 = q0.next();
-    for (; q1.r < a.th; q0 = q0.next2(), q1 = q1.next2()) {
-      bool ok0, ok1; float y0[CPI], y1[CPI];
-      const T* p0 = addr(q0, ok0); const T* p1 = addr(q1, ok1);
-      ChanIO<T, CPI>::ld(p0, y0); ChanIO<T, CPI>::ld(p1, y1);
-      item(q0, y0, ok0); item(q1, y1, ok1);
-    }
-    if (q0.r < a.th) {
-      bool ok0; float y0[CPI];
-      ChanIO<T, CPI>::ld(addr(q0, ok0), y0);
-      item(q0, y0, ok0);
-    }
+    head_stream<2, Raw>(t / NI, 256 / NI, a.tw, a.th, load, item);
   }
   // block reduction: lanes of the same channel group (xor NI .. 32, fixed tree), then the four waves through LDS in wave order
   __syncthreads();
@@ -279,7 +337,7 @@ __global__ __launch_bounds__(256) void bn_head_bwd_reduce_kernel(HeadArgs a, int
     if (lane < NI) { red[(wv * NI + part) * PQ + c * 2] = x0; red[(wv * NI + part) * PQ + c * 2 + 1] = x1; }
 #pragma unroll
     for (int k = 0; k < 9; k++) {
-      const float x = lanes(wacc[c][k]);
+      const float x = lanes(wacc[c][k >> 1][k & 1]);
       if (lane < NI) red[(wv * NI + part) * PQ + 2 * CPI + c * 9 + k] = x;
     }
   }
@@ -324,59 +382,45 @@ __global__ __launch_bounds__(256) void bn_head_finalize_kernel(const float* __re
 template <typename T, int ACT, int CPI>
 __global__ __launch_bounds__(256) void bn_head_bwd_apply_kernel(HeadArgs a) {
   constexpr int NI = HC / CPI;
+  typedef typename ChanIO<T, CPI>::Raw Raw;
   RD_DYN_SMEM(smem);
   float* sdl = reinterpret_cast<float*>(smem);
-  const int actv = ACT >= 0 ? ACT : a.act;
   const int t = threadIdx.x, part = t % NI;
   const int twh = a.tw + 2;
   const HeadTile tl = head_tile(a, xcd_contiguous(blockIdx.x, gridDim.x));
-  float wq[CPI][9], sc[CPI], sh[CPI], mu[CPI], rs[CPI], k1[CPI], k2[CPI];
+  float wq[CPI][9], sc[CPI], sh[CPI], cA[CPI], cB[CPI];
   head_weights<T, CPI>(a.w, part, wq);
+  // dy = scale (g - c1 - (y - mean) rstd c2) = fma(B, y, fma(scale, g, A)): two fused multiply-adds per element
 #pragma unroll
   for (int c = 0; c < CPI; c++) {
     const int cc = part * CPI + c;
-    sc[c] = a.scale[cc]; sh[c] = a.shift[cc]; mu[c] = a.mean[cc]; rs[c] = a.rstd[cc]; k1[c] = a.c1[cc]; k2[c] = a.c2[cc];
+    sc[c] = a.scale[cc]; sh[c] = a.shift[cc];
+    const float rk = a.rstd[cc] * a.c2[cc];
+    cB[c] = -(sc[c] * rk); cA[c] = sc[c] * (rk * a.mean[cc] - a.c1[cc]);
   }
   stage_dl<T>(a, tl, sdl);
   __syncthreads();
   const int64_t ib = (int64_t)tl.n * a.H * a.W * HC + part * CPI;
   const T* yb = (const T*)a.y + ib;
   T* ob = (T*)a.out + ib;
-  // dy = scale (g - c1 - (y - mean) rstd c2) = fma(B, y, fma(scale, g, A)): two fused multiply-adds per element (this pass is as close to its
-  // vector-issue time as to its HBM time)
-  float cA[CPI], cB[CPI];
-#pragma unroll
-  for (int c = 0; c < CPI; c++) { cB[c] = -(sc[c] * rs[c] * k2[c]); cA[c] = sc[c] * (rs[c] * k2[c] * mu[c] - k1[c]); }
-  auto off = [&](const PixWalk& q, bool& ok) RD_INLINE_LAMBDA -> int64_t {
-    const int r = tl.r0 + q.r, c = tl.c0 + q.c;
-    ok = r < a.H && c < a.W;
-    return ((int64_t)min(r, a.H - 1) * a.W + min(c, a.W - 1)) * HC;
+  auto load = [&](const PixWalk& q) RD_INLINE_LAMBDA {
+    const int r = min(tl.r0 + q.r, a.H - 1), c = min(tl.c0 + q.c, a.W - 1);
+    return ChanIO<T, CPI>::ldraw(yb + (r * a.W + c) * HC);
   };
-  auto item = [&](const PixWalk& q, int64_t o, const float (&yy)[CPI], bool ok) RD_INLINE_LAMBDA {
-    float e[9], da[CPI], dy[CPI];
+  auto item = [&](const PixWalk& q, const Raw& raw) RD_INLINE_LAMBDA {
+    float yy[CPI], e[9], da[CPI], dy[CPI];
+    ChanIO<T, CPI>::cvt(raw, yy);
     head_neighbours(sdl, twh, q.r, q.c, e);
     head_dgrad<T, CPI>(wq, e, da);
 #pragma unroll
     for (int c = 0; c < CPI; c++) {
-      float g = da[c];
-      if (actv) g *= act_grad_from_out(yy[c] * sc[c] + sh[c], actv, a.slope);
+      const float g = head_act_bwd<ACT>(da[c], yy[c] * sc[c] + sh[c], a.act, a.slope);
       dy[c] = fmaf(cB[c], yy[c], fmaf(sc[c], g, cA[c]));
     }
-    if (ok) ChanIO<T, CPI>::st(ob + o, dy);
+    const int r = tl.r0 + q.r, c = tl.c0 + q.c;
+    if (r < a.H && c < a.W) ChanIO<T, CPI>::st(ob + (r * a.W + c) * HC, dy);
   };
-  PixWalk q0(t / NI, 256 / NI, a.tw), q1 = q0.next();
-  for (; q1.r < a.th; q0 = q0.next2(), q1 = q1.next2()) {
-    bool ok0, ok1; float y0[CPI], y1[CPI];
-    const int64_t o0 = off(q0, ok0), o1 = off(q1, ok1);
-    ChanIO<T, CPI>::ld(yb + o0, y0); ChanIO<T, CPI>::ld(yb + o1, y1);
-    item(q0, o0, y0, ok0); item(q1, o1, y1, ok1);
-  }
-  if (q0.r < a.th) {
-    bool ok0; float y0[CPI];
-    const int64_t o0 = off(q0, ok0);
-    ChanIO<T, CPI>::ld(yb + o0, y0);
-    item(q0, o0, y0, ok0);
-  }
+  head_stream<4, Raw>(t / NI, 256 / NI, a.tw, a.th, load, item);
 }
 
 // ---- host side ---------------------------------------------------------------------------------------------------------------------
@@ -394,9 +438,9 @@ bool bn_head_ok(int N, int H, int W, int C, int dtype) {
   (void)dtype;
   return C == HC && N > 0 && H > 0 && W > 0 && (int64_t)N * H * W < ((int64_t)1 << 31) / HC;
 }
-static int head_fwd_np() { return rd_opt(OPT_HEAD_NP, 1360); }     // pixels (tile + halo) of a forward tile: 36 bytes of LDS each
+static int head_fwd_np() { return std::min(rd_opt(OPT_HEAD_NP, 1360), 1800); }     // pixels (tile + halo) of a forward tile: 36 bytes of LDS each (<= 64 KiB per block)
 static int head_bwd_np() { return 2048; }
-static int head_cpi(int which) { return ((rd_opt(OPT_HEAD_CPI, 0x444) >> (4 * which)) & 15) == 8 ? 8 : 4; }      // channels per work item of kernel `which`
+static int head_cpi(int which) { return ((rd_opt(OPT_HEAD_CPI, 0x448) >> (4 * which)) & 15) == 8 ? 8 : 4; }      // channels per work item of kernel `which`
 static HeadArgs head_args(const HeadPlan& p, int N, int H, int W, int act, float slope) {
   HeadArgs a = {};
   a.N = N; a.H = H; a.W = W; a.th = p.th; a.tw = p.tw; a.tilesH = p.tilesH; a.tilesW = p.tilesW; a.act = act; a.slope = slope;
@@ -407,8 +451,8 @@ int bn_head_rows(int N, int H, int W) {
   return (int)std::min<int64_t>((int64_t)N * p.tilesH * p.tilesW, 1024);
 }
 // (activation, channels per item) -> compile-time
-template <typename F> static void head_dispatch(int act, int cpi, F f) {
-  if (act == ACT_LRELU) { if (cpi == 8) f(std::integral_constant<int, ACT_LRELU>(), std::integral_constant<int, 8>()); else f(std::integral_constant<int, ACT_LRELU>(), std::integral_constant<int, 4>()); }
+template <typename F> static void head_dispatch(int act, float slope, int cpi, F f) {
+  if (act == ACT_LRELU && slope >= 0.f && slope <= 1.f) { if (cpi == 8) f(std::integral_constant<int, ACT_LRELU>(), std::integral_constant<int, 8>()); else f(std::integral_constant<int, ACT_LRELU>(), std::integral_constant<int, 4>()); }
   else { if (cpi == 8) f(std::integral_constant<int, -1>(), std::integral_constant<int, 8>()); else f(std::integral_constant<int, -1>(), std::integral_constant<int, 4>()); }
 }
 void launch_bn_head_fwd(const void* y, const float* scale, const float* shift, int act, float slope, const float* w, void* logits, int N, int H, int W,
@@ -418,7 +462,7 @@ void launch_bn_head_fwd(const void* y, const float* scale, const float* shift, i
   a.y = y; a.scale = scale; a.shift = shift; a.w = w; a.out = logits;
   const unsigned grid = (unsigned)(N * p.tilesH * p.tilesW);
   const size_t lds = (size_t)(p.th + 2) * (p.tw + 2) * 9 * sizeof(float);
-  head_dispatch(act, head_cpi(0), [&](auto ac, auto cp) {
+  head_dispatch(act, slope, head_cpi(0), [&](auto ac, auto cp) {
     constexpr int A = decltype(ac)::value, CPI = decltype(cp)::value;
     if (dtype == 0) hipLaunchKernelGGL((bn_head_fwd_kernel<float, A, CPI>), dim3(grid), dim3(256), lds, st, a);
     else hipLaunchKernelGGL((bn_head_fwd_kernel<bf16_t, A, CPI>), dim3(grid), dim3(256), lds, st, a);
@@ -432,7 +476,7 @@ void launch_bn_head_bwd_reduce(const void* dl, const void* y, const float* mean,
   const int ntiles = N * p.tilesH * p.tilesW;
   const unsigned grid = (unsigned)bn_head_rows(N, H, W);
   const size_t lds = std::max((size_t)(p.th + 2) * (p.tw + 2), (size_t)4 * HC * 11) * sizeof(float);
-  head_dispatch(act, head_cpi(1), [&](auto ac, auto cp) {
+  head_dispatch(act, slope, head_cpi(1), [&](auto ac, auto cp) {
     constexpr int A = decltype(ac)::value, CPI = decltype(cp)::value;
     if (dtype == 0) hipLaunchKernelGGL((bn_head_bwd_reduce_kernel<float, A, CPI>), dim3(grid), dim3(256), lds, st, a, ntiles);
     else hipLaunchKernelGGL((bn_head_bwd_reduce_kernel<bf16_t, A, CPI>), dim3(grid), dim3(256), lds, st, a, ntiles);
@@ -448,7 +492,7 @@ void launch_bn_head_bwd_apply(const void* dl, const void* y, const float* mean, 
   a.y = y; a.dl = dl; a.scale = scale; a.shift = shift; a.mean = mean; a.rstd = rstd; a.w = w; a.c1 = coef; a.c2 = coef + HC; a.out = dy;
   const unsigned grid = (unsigned)(N * p.tilesH * p.tilesW);
   const size_t lds = (size_t)(p.th + 2) * (p.tw + 2) * sizeof(float);
-  head_dispatch(act, head_cpi(2), [&](auto ac, auto cp) {
+  head_dispatch(act, slope, head_cpi(2), [&](auto ac, auto cp) {
     constexpr int A = decltype(ac)::value, CPI = decltype(cp)::value;
     if (dtype == 0) hipLaunchKernelGGL((bn_head_bwd_apply_kernel<float, A, CPI>), dim3(grid), dim3(256), lds, st, a);
     else hipLaunchKernelGGL((bn_head_bwd_apply_kernel<bf16_t, A, CPI>), dim3(grid), dim3(256), lds, st, a);

@@ -28,12 +28,14 @@ def timeit(fn, it=30):
 
 
 def main():
-    R, H, W = [int(v) for v in (sys.argv[1:4] + ["240", "240", "100"][len(sys.argv) - 1:])]
+    quick = "quick" in sys.argv      # one option set, bf16 only (the PMC passes)
+    argv = [v for v in sys.argv[1:] if v != "quick"]
+    R, H, W = [int(v) for v in (argv[:3] + ["240", "240", "100"][len(argv):])]
     lib = _lib.load()
     dev = torch.device("cuda:0")
     C = 16
     st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-    for dt_name, tdt, dt in (("bf16", torch.bfloat16, 1), ("fp32", torch.float32, 0)):
+    for dt_name, tdt, dt in (("bf16", torch.bfloat16, 1), ("fp32", torch.float32, 0))[:1 if quick else 2]:
         torch.manual_seed(0)
         y = torch.randn(R, H, W, C, device=dev).to(tdt)
         dl = (torch.randn(R, H, W, 1, device=dev) * 1e-3).to(tdt)
@@ -50,7 +52,8 @@ def main():
         px = R * H * W * y.element_size()
         print("%s  R=%d %dx%d  tensor %.1f MB  (HBM time at 5 TB/s: fwd %.0f us, sums %.0f us, apply %.0f us)" %
               (dt_name, R, H, W, nb / 1e6, (nb + px) / 5e6, (nb + px) / 5e6, (2 * nb + px) / 5e6))
-        for np_, cpi in ((1360, 0x444), (1024, 0x444), (2048, 0x444), (700, 0x444), (1360, 0x888), (1024, 0x888)):
+        sets = ((1360, 0x444), (1024, 0x444), (1800, 0x444), (700, 0x444), (1360, 0x888), (1024, 0x888))
+        for np_, cpi in (sets[1:2] if quick else sets):
             engine.set_option("head_np", np_)
             engine.set_option("head_cpi", cpi)
             f = timeit(lambda: lib.rd_bn_head_fwd(p(y), p(coef[0]), p(coef[1]), 2, 0.2, p(w), p(logits), R, H, W, C, dt, st))
