@@ -77,6 +77,10 @@ template <int ACT> __device__ __forceinline__ float head_act(float u, int act, f
   if (ACT == ACT_LRELU) return fmaxf(u, u * slope);
   return act_fwd(u, act, slope);
 }
+template <int ACT> __device__ __forceinline__ f32x2 head_act(f32x2 u, int act, float slope) {
+  if (ACT == ACT_LRELU) { const f32x2 v = u * f32x2{slope, slope}; return f32x2{fmaxf(u.x, v.x), fmaxf(u.y, v.y)}; }
+  return f32x2{act_fwd(u.x, act, slope), act_fwd(u.y, act, slope)};
+}
 // g = da * act'(u)
 template <int ACT> __device__ __forceinline__ float head_act_bwd(float da, float u, int act, float slope) {
   if (ACT == ACT_LRELU) return u > 0.f ? da : da * slope;
@@ -147,14 +151,13 @@ __device__ __forceinline__ void head_neighbours(const float* sdl, int twh, int p
 template <typename T, int CPI>
 __device__ __forceinline__ void head_dgrad(const float (&wq)[CPI][9], const float (&e)[9], float (&da)[CPI]) {
 #pragma unroll
-  for (int c = 0; c < CPI; c++) {
-    float s = 0.f;
+  for (int c = 0; c < CPI; c += 2) {      // two channels per packed multiply-add, taps in ascending order
+    f32x2 s = {0.f, 0.f};
 #pragma unroll
-    for (int tp = 0; tp < 9; tp++) s = fmaf(wq[c][8 - tp], e[tp], s);
-    da[c] = s;
+    for (int tp = 0; tp < 9; tp++) s = fma2(f32x2{wq[c][8 - tp], wq[c + 1][8 - tp]}, f32x2{e[tp], e[tp]}, s);
+    da[c] = s.x; da[c + 1] = s.y;
+    rnd2<T>(da[c], da[c + 1]);      // the unfused path stores da in the activation type
   }
-#pragma unroll
-  for (int c = 0; c < CPI; c += 2) rnd2<T>(da[c], da[c + 1]);      // the unfused path stores da in the activation type
 }
 
 // A thread's items, U at a time, the raw loads of the next U in flight while the current U are computed.  load(q) must be safe for any q
@@ -200,17 +203,23 @@ __global__ __launch_bounds__(256) RD_WAVES_PER_EU(CPI == 8 ? 3 : 4) void bn_head
     float av[CPI];
     ChanIO<T, CPI>::cvt(raw, av);
 #pragma unroll
-    for (int c = 0; c < CPI; c++) av[c] = head_act<ACT>(av[c] * sc[c] + sh[c], a.act, a.slope);
+    for (int c = 0; c < CPI; c += 2) {
+      const f32x2 u = f32x2{av[c], av[c + 1]} * f32x2{sc[c], sc[c + 1]} + f32x2{sh[c], sh[c + 1]};
+      const f32x2 z = head_act<ACT>(u, a.act, a.slope);
+      av[c] = z.x; av[c + 1] = z.y;
+      rnd2<T>(av[c], av[c + 1]);
+    }
+    f32x2 d2[5] = {f32x2{0.f, 0.f}, f32x2{0.f, 0.f}, f32x2{0.f, 0.f}, f32x2{0.f, 0.f}, f32x2{0.f, 0.f}};      // taps (0,1) (2,3) (4,5) (6,7) (8,-)
 #pragma unroll
-    for (int c = 0; c < CPI; c += 2) rnd2<T>(av[c], av[c + 1]);
+    for (int c = 0; c < CPI; c++) {
+      const f32x2 a2 = {av[c], av[c]};
+#pragma unroll
+      for (int j = 0; j < 4; j++) d2[j] = fma2(f32x2{wq[c][2 * j], wq[c][2 * j + 1]}, a2, d2[j]);
+      d2[4].x = fmaf(wq[c][8], av[c], d2[4].x);
+    }
     float d[9];
 #pragma unroll
-    for (int k = 0; k < 9; k++) {
-      float s = 0.f;
-#pragma unroll
-      for (int c = 0; c < CPI; c++) s = fmaf(wq[c][k], av[c], s);
-      d[k] = parts_sum<NI>(s);
-    }
+    for (int k = 0; k < 9; k++) d[k] = parts_sum<NI>(d2[k >> 1][k & 1]);
     if (q.r < thh) {      // the lanes of a pixel share the nine stores; a pixel outside the image is padding of the convolution's input: zero
       const bool ok = (unsigned)(tl.r0 - 1 + q.r) < (unsigned)a.H && (unsigned)(tl.c0 - 1 + q.c) < (unsigned)a.W;
       const int p = q.r * twh + q.c;
@@ -304,14 +313,17 @@ __global__ __launch_bounds__(256) void bn_head_bwd_reduce_kernel(HeadArgs a, int
       }
       head_dgrad<T, CPI>(wq, e, da);
 #pragma unroll
-      for (int c = 0; c < CPI; c++) {
-        const float u = yy[c] * sc[c] + sh[c];
-        av[c] = head_act<ACT>(u, a.act, a.slope);
-        const float g = head_act_bwd<ACT>(da[c], u, a.act, a.slope);
-        sa[c] += g; sb[c] = fmaf(g, fmaf(yy[c], rs[c], nmr[c]), sb[c]);      // xhat = (y - mean) rstd
+      for (int c = 0; c < CPI; c += 2) {
+        const f32x2 y2 = {yy[c], yy[c + 1]};
+        const f32x2 u = y2 * f32x2{sc[c], sc[c + 1]} + f32x2{sh[c], sh[c + 1]};
+        const f32x2 z = head_act<ACT>(u, a.act, a.slope);
+        av[c] = z.x; av[c + 1] = z.y;
+        rnd2<T>(av[c], av[c + 1]);
+        const f32x2 g = {head_act_bwd<ACT>(da[c], u.x, a.act, a.slope), head_act_bwd<ACT>(da[c + 1], u.y, a.act, a.slope)};
+        const f32x2 xh = fma2(y2, f32x2{rs[c], rs[c + 1]}, f32x2{nmr[c], nmr[c + 1]});      // xhat = (y - mean) rstd
+        const f32x2 s1 = f32x2{sa[c], sa[c + 1]} + g, s2 = fma2(g, xh, f32x2{sb[c], sb[c + 1]});
+        sa[c] = s1.x; sa[c + 1] = s1.y; sb[c] = s2.x; sb[c + 1] = s2.y;
       }
-#pragma unroll
-      for (int c = 0; c < CPI; c += 2) rnd2<T>(av[c], av[c + 1]);
       // dw[c][kh][kw] = sum_q a[q][c] * dlogits[q - (kh - 1, kw - 1)] = a * e[8 - (kh * 3 + kw)]
       const f32x2 er[5] = {f32x2{e[8], e[7]}, f32x2{e[6], e[5]}, f32x2{e[4], e[3]}, f32x2{e[2], e[1]}, f32x2{e[0], 0.f}};
 #pragma unroll
@@ -413,9 +425,12 @@ __global__ __launch_bounds__(256) void bn_head_bwd_apply_kernel(HeadArgs a) {
     head_neighbours(sdl, twh, q.r, q.c, e);
     head_dgrad<T, CPI>(wq, e, da);
 #pragma unroll
-    for (int c = 0; c < CPI; c++) {
-      const float g = head_act_bwd<ACT>(da[c], yy[c] * sc[c] + sh[c], a.act, a.slope);
-      dy[c] = fmaf(cB[c], yy[c], fmaf(sc[c], g, cA[c]));
+    for (int c = 0; c < CPI; c += 2) {
+      const f32x2 y2 = {yy[c], yy[c + 1]}, s2 = {sc[c], sc[c + 1]};
+      const f32x2 u = y2 * s2 + f32x2{sh[c], sh[c + 1]};
+      const f32x2 g = {head_act_bwd<ACT>(da[c], u.x, a.act, a.slope), head_act_bwd<ACT>(da[c + 1], u.y, a.act, a.slope)};
+      const f32x2 o = fma2(f32x2{cB[c], cB[c + 1]}, y2, fma2(s2, g, f32x2{cA[c], cA[c + 1]}));
+      dy[c] = o.x; dy[c + 1] = o.y;
     }
     const int r = tl.r0 + q.r, c = tl.c0 + q.c;
     if (r < a.H && c < a.W) ChanIO<T, CPI>::st(ob + (r * a.W + c) * HC, dy);
