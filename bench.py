@@ -275,9 +275,83 @@ def kernel_roofline(timer, timed_steps, ms_per_step, dtype, traffic_key, conv_on
     return roof
 
 
+def live_traffic(args, kernels, budget_s=100.0):
+    """HBM bytes per launch of the named kernels, measured by THIS run: two rocprofv3 counter passes (FETCH_SIZE, WRITE_SIZE: separate passes,
+    --kernel-trace only, as MI355X_MICROARCH.md prescribes) of the same workload as child processes (3 eager steps each), parsed with the
+    units / gfx950 correction of tools/traffic_aggregate.py.  -> {kernel: bytes per launch} or None (no rocprofv3, a child failed or ran out of
+    its time budget: the committed profile values stay).  Children only -- this process holds the GPU and never replaces itself."""
+    import shutil
+    import signal
+    import subprocess
+    import tempfile
+    if shutil.which("rocprofv3") is None:
+        return None
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from traffic_aggregate import kernel_key
+    out = tempfile.mkdtemp(prefix="riders_live_traffic_", dir="/tmp")
+    base = ["python3", os.path.abspath(__file__), "--workload", "rcnet", "--eager", "--steps", "2", "--warmup", "1", "--settle-seconds", "0", "--no-cpu-baseline",
+            "--no-sml", "--no-legs", "--no-live-traffic", "--batch", str(args.batch), "--dtype", args.dtype, "--height", str(args.height), "--width", str(args.width),
+            "--full-json", os.path.join(out, "child_full.json")]
+    if args.opts:
+        base += ["--opts", args.opts]
+    per = {}
+    try:
+        for ctr, scale in (("FETCH_SIZE", 2.0 * 1024.0), ("WRITE_SIZE", 1024.0)):      # KB; gfx950: wide streaming reads tallied at half their size
+            d = os.path.join(out, ctr)
+            cmd = ["rocprofv3", "--pmc", ctr, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "p", "--"] + base
+            pr = subprocess.Popen(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
+            try:
+                rc = pr.wait(timeout=budget_s)
+            except subprocess.TimeoutExpired:
+                os.killpg(pr.pid, signal.SIGKILL)
+                pr.wait()
+                return None
+            if rc != 0:
+                return None
+            import csv
+            import glob
+            found = False
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f, newline="")):
+                    if row["Counter_Name"] != ctr or "rd" not in row["Kernel_Name"]:
+                        continue
+                    k = kernel_key(row["Kernel_Name"])
+                    if k in kernels:
+                        e = per.setdefault(k, {}).setdefault(ctr, [0.0, 0])
+                        e[0] += float(row["Counter_Value"]) * scale; e[1] += 1
+                        found = True
+            if not found:
+                return None
+    except Exception as ex:      # never lose the bench line to an auxiliary measurement
+        sys.stderr.write("bench.py: live traffic pass failed (%r)\n" % (ex,))
+        return None
+    finally:
+        shutil.rmtree(out, ignore_errors=True)
+    res = {}
+    for k, v in per.items():
+        if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
+            res[k] = dict(bytes_per_launch=v["FETCH_SIZE"][0] / v["FETCH_SIZE"][1] + v["WRITE_SIZE"][0] / v["WRITE_SIZE"][1], dispatches=v["FETCH_SIZE"][1])
+    return res or None
+
+
+def apply_live_traffic(roof, live):
+    """overwrite a roofline object's `traffic` (committed counter file) with this run's own counter passes"""
+    if not roof or not live or roof.get("kernel") not in live:
+        return
+    t = live[roof["kernel"]]
+    if roof.get("traffic") is not None:
+        roof["traffic_committed"] = roof["traffic"]
+    roof["traffic"] = t["bytes_per_launch"]
+    roof["traffic_over_algorithmic"] = t["bytes_per_launch"] / max(roof.get("algorithmic_bytes_per_launch", 0.0), 1.0)
+    roof["traffic_source"] = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (--kernel-trace only) of the same workload, started as child processes by THIS "
+                              "bench run after its timed regions: mean over %d dispatches; FETCH_SIZE doubled (gfx950)" % t["dispatches"])
+    roof["traffic_stale"] = False
+    roof["traffic_live"] = True
+
+
 LINE_LIMIT = 6000      # bytes of the ONE stdout line (VERDICT r04: the driver kept ~8 KB of stdout and lost the head of a 39.8-KB line)
 FLAT_ROOF_KEYS = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_over_algorithmic", "traffic_stale", "launches_per_step",
-                  "avg_launch_us", "ms_per_step", "share_of_step", "algorithmic_flops_per_launch", "algorithmic_bytes_per_launch", "mfma_util")
+                  "avg_launch_us", "ms_per_step", "share_of_step", "algorithmic_flops_per_launch", "algorithmic_bytes_per_launch", "mfma_util", "traffic_live")
 
 
 def _sig(v, n=5):
@@ -615,6 +689,8 @@ def main():
     ap.add_argument("--comm", default="c_abi", choices=["c_abi", "torch"],
                     help="gradient exchange transport for N > 1: c_abi = the library's own RCCL communicator (rd_comm_*, collectives captured into the "
                          "step's ONE hipGraph), torch = torch.distributed's nccl(=RCCL) collectives between per-stage graphs (round 4)")
+    ap.add_argument("--no-live-traffic", action="store_true", help="do not start the two rocprofv3 counter passes (FETCH_SIZE / WRITE_SIZE children, ~1 min) "
+                    "that measure roofline.traffic inside the default N = 1 run; the committed profiles/r05_traffic.json values are reported instead")
     ap.add_argument("--detail", default=None, help="write a per-launch-shape timing table to this file")
     ap.add_argument("--timer-repeat", type=int, default=5, help="idempotent launches issued this many times per HIP-event pair in the instrumented "
                                                                 "steps (1 under rocprofv3, so that its launch counts per step are the real ones)")
@@ -687,6 +763,11 @@ def main():
                                            sml_width=1024, sml_native=True, loss_scale=1024.0, settle_seconds=min(args.settle_seconds, 1.0))
     if rank == 0:
         cpu = val = None
+        if default_line and not args.no_live_traffic:
+            roofs = [head.get("roofline"), head.get("roofline_conv")]
+            live = live_traffic(args, set(r["kernel"] for r in roofs if r and r.get("kernel")))
+            for r in roofs:
+                apply_live_traffic(r, live)
         if world == 1 and not args.no_cpu_baseline and args.workload == "rcnet":
             try:
                 val = val_abs_rel_pair(dev)

@@ -10,12 +10,12 @@ import sys
 
 FAMILIES = [
     ("dwconv", r"dwconv|dw_run_kernel|dw_dgrad2_kernel|dw_wgrad"),
-    ("conv_gemm", r"conv3x3_frag_kernel|conv3x3_patch_kernel|conv3x3_small_kernel|conv_gemm_kernel|conv1x1_direct_kernel|conv3x3_c1_kernel|conv_few_kernel"),
+    ("bn_finalize", r"bn_finalize|bn_bwd_finalize|bn_head_finalize"),
+    ("conv_gemm", r"conv3x3_frag_kernel|conv3x3_patch_kernel|conv3x3_small_kernel|conv_gemm_kernel|conv1x1_direct_kernel|conv3x3_c1_kernel|conv_few_kernel|bn_head_fwd_kernel"),
     ("conv_wgrad", r"wgrad"),
     ("loftr_layer", r"loftr_layer"),
     ("bn_apply", r"affine_act"),
-    ("bn_backward", r"col_reduce|bn_bwd"),
-    ("bn_finalize", r"bn_finalize"),
+    ("bn_backward", r"col_reduce|bn_bwd|bn_head_bwd"),
     ("roi_pool", r"roi_pool"),
     ("pooling", r"maxpool"),
     ("optimizer", r"adam_kernel"),
