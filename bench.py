@@ -276,10 +276,13 @@ def kernel_roofline(timer, timed_steps, ms_per_step, dtype, traffic_key, conv_on
 
 
 def live_traffic(args, kernels, budget_s=100.0):
-    """HBM bytes per launch of the named kernels, measured by THIS run: two rocprofv3 counter passes (FETCH_SIZE, WRITE_SIZE: separate passes,
-    --kernel-trace only, as MI355X_MICROARCH.md prescribes) of the same workload as child processes (3 eager steps each), parsed with the
-    units / gfx950 correction of tools/traffic_aggregate.py.  -> {kernel: bytes per launch} or None (no rocprofv3, a child failed or ran out of
-    its time budget: the committed profile values stay).  Children only -- this process holds the GPU and never replaces itself."""
+    """HBM bytes per launch and matrix-pipe busy fraction of the named kernels, measured by THIS run: three rocprofv3 counter passes (FETCH_SIZE;
+    WRITE_SIZE; SQ_VALU_MFMA_BUSY_CYCLES + GRBM_GUI_ACTIVE -- separate passes, --kernel-trace only, as MI355X_MICROARCH.md prescribes) of the same
+    workload as child processes (3 eager steps each), parsed with the units / gfx950 correction of tools/traffic_aggregate.py and the
+    normalisation of tools/pmc_dominant.py.  -> {kernel: dict(bytes_per_launch, dispatches[, mfma_util])} or None (no rocprofv3, a child failed
+    or ran out of its time budget: the committed profile values stay).  Children only -- this process holds the GPU and never replaces itself."""
+    import csv
+    import glob
     import shutil
     import signal
     import subprocess
@@ -296,41 +299,42 @@ def live_traffic(args, kernels, budget_s=100.0):
         base += ["--opts", args.opts]
     per = {}
     try:
-        for ctr, scale in (("FETCH_SIZE", 2.0 * 1024.0), ("WRITE_SIZE", 1024.0)):      # KB; gfx950: wide streaming reads tallied at half their size
-            d = os.path.join(out, ctr)
-            cmd = ["rocprofv3", "--pmc", ctr, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "p", "--"] + base
+        for n, ctrs in enumerate((("FETCH_SIZE",), ("WRITE_SIZE",), ("SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE"))):
+            d = os.path.join(out, "pass%d" % n)
+            cmd = ["rocprofv3", "--pmc"] + list(ctrs) + ["--kernel-trace", "--output-format", "csv", "-d", d, "-o", "p", "--"] + base
             pr = subprocess.Popen(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
             try:
                 rc = pr.wait(timeout=budget_s)
             except subprocess.TimeoutExpired:
                 os.killpg(pr.pid, signal.SIGKILL)
                 pr.wait()
-                return None
-            if rc != 0:
-                return None
-            import csv
-            import glob
+                rc = -1
             found = False
-            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
-                for row in csv.DictReader(open(f, newline="")):
-                    if row["Counter_Name"] != ctr or "rd" not in row["Kernel_Name"]:
-                        continue
-                    k = kernel_key(row["Kernel_Name"])
-                    if k in kernels:
-                        e = per.setdefault(k, {}).setdefault(ctr, [0.0, 0])
-                        e[0] += float(row["Counter_Value"]) * scale; e[1] += 1
-                        found = True
-            if not found:
+            if rc == 0:
+                for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                    for row in csv.DictReader(open(f, newline="")):
+                        if row["Counter_Name"] not in ctrs or "rd" not in row["Kernel_Name"]:
+                            continue
+                        k = kernel_key(row["Kernel_Name"])
+                        if k in kernels:
+                            e = per.setdefault(k, {}).setdefault(row["Counter_Name"], [0.0, 0])
+                            e[0] += float(row["Counter_Value"]); e[1] += 1
+                            found = True
+            if not found and n < 2:      # the traffic passes are the point; the matrix-pipe pass is an extra
                 return None
     except Exception as ex:      # never lose the bench line to an auxiliary measurement
-        sys.stderr.write("bench.py: live traffic pass failed (%r)\n" % (ex,))
+        sys.stderr.write("bench.py: live counter pass failed (%r)\n" % (ex,))
         return None
     finally:
         shutil.rmtree(out, ignore_errors=True)
     res = {}
     for k, v in per.items():
         if "FETCH_SIZE" in v and "WRITE_SIZE" in v:
-            res[k] = dict(bytes_per_launch=v["FETCH_SIZE"][0] / v["FETCH_SIZE"][1] + v["WRITE_SIZE"][0] / v["WRITE_SIZE"][1], dispatches=v["FETCH_SIZE"][1])
+            m = {c: x[0] / x[1] for c, x in v.items()}
+            # KB; gfx950: wide streaming reads are tallied at half their size (MI355X_MICROARCH.md, HBM section)
+            res[k] = dict(bytes_per_launch=m["FETCH_SIZE"] * 2.0 * 1024.0 + m["WRITE_SIZE"] * 1024.0, dispatches=v["FETCH_SIZE"][1])
+            if m.get("GRBM_GUI_ACTIVE"):      # busy cycles summed over the 1024 SIMDs / (1024 x the dispatch's cycles; GRBM_GUI_ACTIVE is summed over 8 XCDs)
+                res[k]["mfma_util"] = m.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0) / (1024.0 * m["GRBM_GUI_ACTIVE"] / 8.0)
     return res or None
 
 
@@ -347,6 +351,13 @@ def apply_live_traffic(roof, live):
                               "bench run after its timed regions: mean over %d dispatches; FETCH_SIZE doubled (gfx950)" % t["dispatches"])
     roof["traffic_stale"] = False
     roof["traffic_live"] = True
+    if "mfma_util" in t:
+        mb = dict(roof.get("mfma_busy") or {})
+        if "mfma_util" in mb:
+            mb["mfma_util_committed"] = mb["mfma_util"]
+        mb["mfma_util"] = t["mfma_util"]
+        mb["mfma_util_source"] = "live: SQ_VALU_MFMA_BUSY_CYCLES / (1024 x GRBM_GUI_ACTIVE / 8) of this run's own counter pass"
+        roof["mfma_busy"] = mb
 
 
 LINE_LIMIT = 6000      # bytes of the ONE stdout line (the driver kept ~8 KB of stdout and lost the head of a 39.8-KB line)
