@@ -54,13 +54,20 @@ typedef struct rd_conv_desc {
   int32_t out_reduce2;         /* 1: sum every 2x2 block of output pixels and store it at (OH/2) x (OW/2): the data gradient of a layer that
                                   up-samples its input by exactly 2 (UpConv2d, utils/net_utils.py:195-198) lands at SOURCE resolution, the
                                   full-resolution gradient is never written.  Only where rd_conv_out_reduce2_ok says so. */
+  int32_t out_d2s;             /* 1: the forward of an exact-2x nearest up-sampling 3x3 layer (UpConv2d, utils/net_utils.py:195-198) computed ON THE
+                                  SOURCE: the descriptor is the 3x3 / stride-1 convolution of the H1 x W1 source with Cout = 4 x D1 output channels
+                                  = (parity class (a, b), channel) and weights packed with mode 2 (per-class 2x2 effective kernels); channel
+                                  tile (a, b) of source pixel (i, j) is stored as pixel (2 i + a, 2 j + b) of the (2 OH) x (2 OW) x D1 output
+                                  (depth to space), and the structurally zero (tap, class) blocks are skipped.  Statistics rows: Cout columns =
+                                  4 rows of D1.  Only where rd_conv_up2_ok says so. */
 } rd_conv_desc;
 
 /* elements (of the activation dtype) in a packed weight buffer for `rows` x (KH*KW*C).  K axes that can be 9 taps x whole 128-byte channel
  * chunks get room for a second, MFMA-fragment-ordered copy behind the row-major one (written by the pack calls for 3x3 kernels, read by the
  * register-fed 3x3 kernel of rd_conv_fwd) */
 int64_t rd_conv_packed_elems(int32_t rows, int32_t K, int32_t dtype);
-/* OIHW fp32 -> packed; mode 0: forward operand, mode 1: data-gradient operand (transposed + flipped) */
+/* OIHW fp32 -> packed; mode 0: forward operand, mode 1: data-gradient operand (transposed + flipped), mode 2 (3x3 only): forward operand of the
+ * exact-2x up-sampling layer on its source (rd_conv_desc.out_d2s): 4 Cout rows = (parity class, channel), each class's taps pre-summed */
 int rd_conv_pack_weights(const float* w_oihw, void* packed, int32_t Cout, int32_t Cin, int32_t KH, int32_t KW,
                          int32_t mode, int32_t dtype, void* stream);
 /* The same re-layout for MANY weights in one launch (after an optimizer step every cached operand of every conv / linear
@@ -145,6 +152,8 @@ const char* rd_conv_wgrad_kernel_name(const rd_conv_desc* d);
 /* 1 when rd_conv_fwd can run this descriptor with out_reduce2 = 1 (even OH / OW, single destination, no statistics, a kernel whose
  * epilogue can pair rows and columns in registers: the narrow-layer 3x3 kernel) */
 int32_t rd_conv_out_reduce2_ok(const rd_conv_desc* d);
+/* 1 when rd_conv_fwd can run this descriptor with out_d2s = 1 (3x3 / stride 1 / pad 1 on the source, Cout = 4 x D1, a kernel that implements it) */
+int32_t rd_conv_up2_ok(const rd_conv_desc* d);
 /* dst = round(conv(...) + addend): `addend` is a [N*OH*OW][Cout] tensor of the activation dtype, read once in the epilogue.  The engine's
  * backward hands over a tensor's EARLIER gradient contribution when a second consumer's data gradient arrives (skip connections of
  * utils/net_utils.py:564-569, residual blocks :250-330), instead of writing the second contribution and adding the two in a separate

@@ -32,6 +32,7 @@ class ConvDesc(ctypes.Structure):
         ("act", ctypes.c_int32), ("slope", ctypes.c_float),
         ("D1", ctypes.c_int32),
         ("out_reduce2", ctypes.c_int32),
+        ("out_d2s", ctypes.c_int32),
     ]
 
 

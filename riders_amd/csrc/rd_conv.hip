@@ -301,11 +301,26 @@ __device__ __forceinline__ int64_t pack_tokfrag_index(int row, int k, int K) {
   const int ks = k / SE, kk = k - ks * SE, kg = kk / VE, e = kk - kg * VE;
   return ((((int64_t)(row >> 4) * (K / SE) + ks) * 64) + kg * 16 + (row & 15)) * VE + e;
 }
+// mode 2 (forward operand of an exact-2x nearest up-sampling 3x3 layer computed ON THE SOURCE, ConvArgs::d2s): row = (class (a, b), co) of 4 Cout rows,
+// k = (source tap (kh', kw'), ci).  Output pixel (2 i + a, 2 j + b) reads source pixel (i + floor((a + kh - 1) / 2), ...) through tap kh, so source tap
+// kh' collects a = 0: kh' = 0 <- {0}, kh' = 1 <- {1, 2};  a = 1: kh' = 1 <- {0, 1}, kh' = 2 <- {2}  (columns likewise with b): the class's 2x2
+// effective kernel, zero elsewhere.  Summed in fp32 in ascending (kh, kw) order, rounded once when stored.
+__device__ __forceinline__ float pack_up2_value(const float* __restrict__ w, int Cout, int Cin, int row, int c, int khs, int kws) {
+  const int cls = row / Cout, co = row - cls * Cout, a = cls >> 1, b = cls & 1;
+  const int h0 = a == 0 ? (khs == 0 ? 0 : (khs == 1 ? 1 : 3)) : (khs == 0 ? 3 : (khs == 1 ? 0 : 2));      // first original tap row (3: none)
+  const int h1 = a == 0 ? (khs == 0 ? 0 : (khs == 1 ? 2 : -1)) : (khs == 0 ? -1 : (khs == 1 ? 1 : 2));    // last
+  const int w0 = b == 0 ? (kws == 0 ? 0 : (kws == 1 ? 1 : 3)) : (kws == 0 ? 3 : (kws == 1 ? 0 : 2));
+  const int w1 = b == 0 ? (kws == 0 ? 0 : (kws == 1 ? 2 : -1)) : (kws == 0 ? -1 : (kws == 1 ? 1 : 2));
+  float v = 0.f;
+  for (int kh = h0; kh <= h1; kh++)
+    for (int kw = w0; kw <= w1; kw++) v += w[(((int64_t)co * Cin + c) * 3 + kh) * 3 + kw];
+  return v;
+}
 template <typename T>
 __global__ void pack_weights_kernel(const float* __restrict__ w, T* __restrict__ out, int Cout, int Cin, int KH,
                                     int KW, int mode, int rows_pad, int Kpad, int CinSrc) {
   int64_t total = (int64_t)rows_pad * Kpad;
-  int rows = mode ? Cin : Cout, C = mode ? Cout : Cin;
+  int rows = mode == 2 ? 4 * Cout : (mode ? Cin : Cout), C = mode == 1 ? Cout : Cin;
   int K = KH * KW * C;
   const bool frag = pack_has_frag(KH, KW, C, sizeof(T) == 4 ? 0 : 1);
   const bool tokfrag = KH == 1 && KW == 1 && pack_has_tokfrag(rows, K);      // rows_pad == rows, Kpad == K at these sizes
@@ -316,6 +331,7 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, T* __restrict__
       int tap = k / C, c = k - tap * C, kh = tap / KW, kw = tap - kh * KW;
       // CinSrc < Cin: the packed layout carries zero-padded input channels (3-channel stems run on the 16-byte-vector paths)
       if (mode == 0) v = c < CinSrc ? w[(((int64_t)row * CinSrc + c) * KH + kh) * KW + kw] : 0.f;
+      else if (mode == 2) v = pack_up2_value(w, Cout, Cin, row, c, kh, kw);
       else v = w[(((int64_t)c * Cin + row) * KH + (KH - 1 - kh)) * KW + (KW - 1 - kw)];
     }
     Elem<T>::st(&out[i], v);
@@ -328,7 +344,7 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, T* __restrict__
 struct PackItem { const float* w; void* out; int Cout, Cin, KH, KW, mode, dtype, CinSrc, pad_; };
 template <typename T>
 __device__ __forceinline__ void pack_one(const PackItem& it, int bx, int nbx) {
-  const int rows = it.mode ? it.Cin : it.Cout, C = it.mode ? it.Cout : it.Cin;
+  const int rows = it.mode == 2 ? 4 * it.Cout : (it.mode ? it.Cin : it.Cout), C = it.mode == 1 ? it.Cout : it.Cin;
   const int K = it.KH * it.KW * C;
   const int bn = rows <= 16 ? 16 : (rows <= 32 ? 32 : (rows <= 64 ? 64 : 128));
   const int rows_pad = (rows + bn - 1) / bn * bn;
@@ -353,6 +369,7 @@ __device__ __forceinline__ void pack_one(const PackItem& it, int bx, int nbx) {
     const int tap = fdiv_small(k, C, rC, c), kh = fdiv_small(tap, it.KW, rKW, kw);
     if (row < rows && k < K) {
       if (it.mode == 0) v = c < cs ? it.w[(((int64_t)row * cs + c) * it.KH + kh) * it.KW + kw] : 0.f;
+      else if (it.mode == 2) v = pack_up2_value(it.w, it.Cout, it.Cin, row, c, kh, kw);
       else v = it.w[(((int64_t)c * it.Cin + row) * it.KH + (it.KH - 1 - kh)) * it.KW + (it.KW - 1 - kw)];
     }
     Elem<T>::st(&out[i], v);
@@ -1074,6 +1091,7 @@ static bool use_conv3x3_frag(const ConvArgs& a, int dtype) {   // wide layers: w
 static bool conv_stem_ok(const ConvArgs& a, int dtype);
 static int conv_stem_blocks(const ConvArgs& a);
 int conv_stats_rows(const ConvArgs& a, int dtype) {
+  if (a.d2s) return conv3x3_small_blocks(a, dtype);
   if (conv_stem_ok(a, dtype)) return conv_stem_blocks(a);
   if (conv_few_ok(a)) return conv_few_blocks(a);
   if (conv1x1_direct_ok(a, dtype)) return conv1x1_direct_rows(a);
@@ -1241,6 +1259,7 @@ static void launch_conv_stem(const ConvArgs& a, int dtype, hipStream_t st) {
 }
 
 void launch_conv(const ConvArgs& a, int dtype, hipStream_t st) {
+  if (a.d2s) { launch_conv3x3_small(a, dtype, st); return; }      // (rd_api.cpp checked conv_d2s_ok)
   if (conv_skinny_ok(a, dtype)) { launch_linear_skinny(a, dtype, st); return; }
   if (conv_stem_ok(a, dtype)) { launch_conv_stem(a, dtype, st); return; }
   if (conv_few_ok(a)) { launch_conv_few(a, dtype, st); return; }
@@ -1259,6 +1278,11 @@ static bool wgrad_tiny_shape_fwd(const WgradArgs& a) { return wgrad_tiny_shape(a
 bool conv_pool2_ok(const ConvArgs& a, int dtype) {
   return !conv_few_ok(a) && !conv1x1_direct_ok(a, dtype) && !conv3x3_c1_ok(a) && use_conv3x3_small(a, dtype) && !(a.OH & 1) && !(a.OW & 1) &&
          a.D1 == a.Cout && !a.bias && a.act == ACT_NONE;
+}
+// out_d2s (ConvArgs::d2s): the narrow-layer 3x3 kernel's D2S instantiation -- 16-bit activations, 64-byte source pixels (32 channels), 4 x 16 output channels
+bool conv_d2s_ok(const ConvArgs& a, int dtype) {
+  return dtype != 0 && a.C2 == 0 && a.C1 == 32 && a.Cout == 64 && a.D1 == 16 && !a.ups && !a.pool2 && !a.bias && a.act == ACT_NONE && !a.in_scale && !a.add1 &&
+         conv3x3_small_ok(a, dtype);      // (launch_conv sends a d2s descriptor straight to that kernel, whatever its tile count)
 }
 // ConvArgs::add1: the kernels that store through conv_epilogue_store except the narrow-layer one (not the few-channel / single-channel
 // streaming kernels, not the experimental LDS-DMA kernel), one destination, no 2x2 reduction
@@ -1293,7 +1317,7 @@ const char* conv_kernel_name(const ConvArgs& a, int dtype) {
   if (conv_few_ok(a)) return "conv_few_kernel";
   if (conv1x1_direct_ok(a, dtype)) return "conv1x1_direct_kernel";
   if (conv3x3_c1_ok(a)) return "conv3x3_c1_kernel";
-  if (use_conv3x3_small(a, dtype)) return conv3x3_small_name(a, dtype);
+  if (a.d2s || use_conv3x3_small(a, dtype)) return conv3x3_small_name(a, dtype);
   if (use_conv3x3_frag(a, dtype)) return conv3x3_frag_name(a, dtype);
   if (use_conv3x3(a, dtype)) return conv3x3_patch_name(a, dtype);
   {     // the implicit-GEMM kernel's instantiation, as launch_conv_t picks it
@@ -1311,7 +1335,7 @@ const char* conv_kernel_name(const ConvArgs& a, int dtype) {
 void launch_pack_weights(const float* w, void* out, int Cout, int Cin, int KH, int KW, int mode, int dtype,
                          hipStream_t st, int CinSrc) {
   if (CinSrc <= 0) CinSrc = Cin;
-  int rows = mode ? Cin : Cout, C = mode ? Cout : Cin;
+  int rows = mode == 2 ? 4 * Cout : (mode ? Cin : Cout), C = mode == 1 ? Cout : Cin;
   int rows_pad = conv_rows_pad(rows), Kpad = conv_kpad(KH * KW * C, dtype);
   int64_t total = (int64_t)rows_pad * Kpad;
   unsigned grid = (unsigned)std::min<int64_t>(cdiv(total, 256), 4096);

@@ -236,8 +236,24 @@ __device__ __forceinline__ int patch_slot(int p, int j) { return p * SPP + (j ^ 
 // AFF: source 1 is a BatchNorm-ed producer's RAW output; the staging applies scale / shift + activation (ConvArgs::in_scale) on the way into
 // LDS, so the activated tensor never exists in HBM.  A thread's slots all carry the same VE channels (256 % SPP == 0): the coefficients
 // come from a block copy in LDS, padding slots stay zero (validity bits travel with each prefetched register set).
-template <typename T, int SPP, int BN, bool W8, bool AFF = false>
-__global__ __launch_bounds__(256, small_min_waves(SPP, BN)) void conv3x3_small_kernel(ConvArgs a, int tilesH, int tilesW) {
+// D2S (SPP = 4, BN = 64 only): the forward of an exact-2x up-sampling layer on its SOURCE (ConvArgs::d2s).  The four 16-channel output tiles are
+// the four parity classes (a, b) of the 2x2 block of output pixels a source pixel expands to; tap (kh', kw') feeds class (a, b) only if
+// kh' - a and kw' - b are 0 or 1 (the class's 2x2 effective kernel, pack mode 2), so 16 of the 36 (tap, class) MFMA pairs remain; every class
+// tile is stored at its own output pixel (depth to space), statistics per (class, channel) column.
+constexpr bool d2s_used(int c, int s) { return ((s / 3) - (c >> 1) == 0 || (s / 3) - (c >> 1) == 1) && ((s % 3) - (c & 1) == 0 || (s % 3) - (c & 1) == 1); }
+constexpr int d2s_slot(int c, int s) {      // rank of (class tile c, tap s) among the 16 used pairs, class-major: only those fragments are kept in LDS
+  int n = 0;
+  for (int cc = 0; cc < 4; cc++)
+    for (int ss = 0; ss < 9; ss++) {
+      if (cc == c && ss == s) return n;
+      if (d2s_used(cc, ss)) n++;
+    }
+  return n;
+}
+constexpr int small_min_waves_d2s() { return (2 * 180 * 4 * 16 + 16 * 1024 + 4 * 64 * 8) * 3 <= 160 * 1024 ? 3 : 2; }
+template <typename T, int SPP, int BN, bool W8, bool AFF = false, bool D2S = false>
+__global__ __launch_bounds__(256, D2S ? small_min_waves_d2s() : small_min_waves(SPP, BN)) void conv3x3_small_kernel(ConvArgs a, int tilesH, int tilesW) {
+  static_assert(!D2S || (SPP == 4 && BN == 64 && !AFF), "D2S: 64-byte pixels, four class tiles");
   constexpr int VE = Elem<T>::VE;
   constexpr int TW = W8 ? 8 : 16, TH = W8 ? 16 : 8;
   constexpr int WT = TW + 2, HT = TH + 2, NP = HT * WT;
@@ -261,7 +277,7 @@ __global__ __launch_bounds__(256, small_min_waves(SPP, BN)) void conv3x3_small_k
   // VGPRs cost a wave of occupancy (these kernels are latency bound: 2 -> 3 -> 4 waves per SIMD each measured faster): there every
   // wave reads its fragments from a lane-major LDS copy ([c][s][lane], conflict free).
   constexpr bool WLDS = (CT * STEPS > 5);
-  __shared__ uint4 sW[WLDS ? CT * STEPS * 64 : 1];
+  __shared__ uint4 sW[WLDS ? (D2S ? 16 : CT * STEPS) * 64 : 1];
   __shared__ __attribute__((aligned(16))) float sAff[AFF ? 2 * SPP * VE : 1];
   if (AFF) affine_fill(sAff, a.in_scale, a.in_shift, 0, SPP * VE, a.C1, t, 256);
   const bool aff_lane = AFF && (t % SPP) * VE < a.C1;
@@ -273,8 +289,9 @@ __global__ __launch_bounds__(256, small_min_waves(SPP, BN)) void conv3x3_small_k
     for (int c = 0; c < CT; c++)
 #pragma unroll
       for (int s = 0; s < STEPS; s++) {
+        if (D2S && !d2s_used(c, s)) continue;
         const uint4 v = wp[(int64_t)(c * 16 + fr) * kslots + s * 4 + fg];
-        if (WLDS) { if (wv == 0) sW[(c * STEPS + s) * 64 + lane] = v; }
+        if (WLDS) { if (wv == 0) sW[(D2S ? d2s_slot(c, s) : c * STEPS + s) * 64 + lane] = v; }
         else wr[WLDS ? 0 : c][WLDS ? 0 : s] = v;
       }
   }
@@ -373,7 +390,8 @@ __global__ __launch_bounds__(256, small_min_waves(SPP, BN)) void conv3x3_small_k
       for (int pt = 0; pt < 2; pt++) pf[pt] = sP[buf][patch_slot<SPP>(ppix[pt] + toff, j)];
 #pragma unroll
       for (int c = 0; c < CT; c++) {
-        const uint4 wf = WLDS ? sW[(c * STEPS + s) * 64 + lane] : wr[WLDS ? 0 : c][WLDS ? 0 : s];
+        if (D2S && !d2s_used(c, s)) continue;      // structurally zero block
+        const uint4 wf = WLDS ? sW[(D2S ? d2s_slot(c, s) : c * STEPS + s) * 64 + lane] : wr[WLDS ? 0 : c][WLDS ? 0 : s];
 #pragma unroll
         for (int pt = 0; pt < 2; pt++) {
           if (sizeof(T) == 4) {
@@ -429,6 +447,20 @@ __global__ __launch_bounds__(256, small_min_waves(SPP, BN)) void conv3x3_small_k
           mm[pt] = ((int64_t)tc.n * OH2 + (oh >> 1)) * OW2 + (ow >> 1);
         }
       }
+      if (D2S) {
+        // class tile c = (a, b) of source pixel (oh, ow) -> output pixel (2 oh + a, 2 ow + b) of the (2 OH) x (2 OW) x D1 tensor
+#pragma unroll
+        for (int c = 0; c < CT; c++) {
+          int64_t mc[2];
+#pragma unroll
+          for (int pt = 0; pt < 2; pt++) {
+            const int oh = tc.th * TH + lpy[pt], ow = tc.tw * TW + lpx[pt];
+            mc[pt] = ((int64_t)tc.n * 2 * a.OH + 2 * oh + (c >> 1)) * (2 * a.OW) + 2 * ow + (c & 1);
+          }
+          conv_epilogue_store_at<T, 1, false>(a, *reinterpret_cast<f32x4 (*)[1][2]>(&acc[c]), mc, mvv, fg * 4, *reinterpret_cast<float (*)[1][4]>(&ssum[c]),
+                                              *reinterpret_cast<float (*)[1][4]>(&ssq[c]));
+        }
+      } else
       conv_epilogue_store<T, CT, false>(a, acc, mm, mvv, 0, 0, fr, fg, ssum, ssq);      // (no addend: these variants sit at their register caps)
     }
   };
@@ -650,7 +682,7 @@ int conv3x3_small_blocks(const ConvArgs& a, int dtype) {   // persistent blocks 
   // (test hook, rd_set_option "conv3x3_g8": few persistent blocks -> several tiles per block on small cases)
   // persistent grid = resident capacity: 8 XCDs x 32 CUs x (4 or 2 blocks per CU, see small_min_waves)
   const int cb_slots = ((a.C1 + a.C2) * (dtype == 0 ? 4 : 2)) / 16;
-  const int per_cu = small_min_waves(cb_slots, pick_bn3(a.Cout));
+  const int per_cu = a.d2s ? small_min_waves_d2s() : small_min_waves(cb_slots, pick_bn3(a.Cout));
   return 8 * (int)std::min<int64_t>(cdiv(ntiles, 8), rd_opt(OPT_CONV3X3_G8, 32 * per_cu));
 }
 template <typename T>
@@ -661,6 +693,13 @@ static void launch_small_t(const ConvArgs& a, hipStream_t st) {
   const int spp = (a.C1 + a.C2) * (int)sizeof(T) / 16, bn = pick_bn3(a.Cout);
   dim3 grid((unsigned)conv3x3_small_blocks(a, (int)sizeof(T) == 4 ? 0 : 1));
   const bool aff = a.in_scale != nullptr;
+  if (a.d2s) {      // conv_d2s_ok: 64-byte pixels, 4 x 16 output channels
+    if (sizeof(T) == 2) {
+      if (w8) hipLaunchKernelGGL((conv3x3_small_kernel<bf16_t, 4, 64, true, false, true>), grid, dim3(256), 0, st, a, tilesH, tilesW);
+      else hipLaunchKernelGGL((conv3x3_small_kernel<bf16_t, 4, 64, false, false, true>), grid, dim3(256), 0, st, a, tilesH, tilesW);
+    }
+    return;
+  }
 #define RD_S3(SPPV, BNV)                                                                                                  \
   if (spp == SPPV && bn == BNV) {                                                                                         \
     if (aff) {                                                                                                            \
@@ -676,6 +715,8 @@ static void launch_small_t(const ConvArgs& a, hipStream_t st) {
 const char* conv3x3_small_name(const ConvArgs& a, int dtype) {
   static thread_local char buf[96];
   const int es = dtype == 0 ? 4 : 2;
+  if (a.d2s) snprintf(buf, sizeof(buf), "conv3x3_small_kernel<%s, 4, 64, %s, false, true>", RD_T16_NAME, use_w8(a) ? "true" : "false");
+  else
   snprintf(buf, sizeof(buf), "conv3x3_small_kernel<%s, %d, %d, %s, %s>", dtype == 0 ? "float" : RD_T16_NAME, (a.C1 + a.C2) * es / 16, pick_bn3(a.Cout),
            use_w8(a) ? "true" : "false", a.in_scale ? "true" : "false");
   return buf;

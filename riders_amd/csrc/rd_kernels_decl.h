@@ -14,6 +14,7 @@ int conv_stats_rows(const ConvArgs& a, int dtype);
 void launch_conv(const ConvArgs& a, int dtype, hipStream_t st);
 const char* conv_kernel_name(const ConvArgs& a, int dtype);
 bool conv_pool2_ok(const ConvArgs& a, int dtype);
+bool conv_d2s_ok(const ConvArgs& a, int dtype);
 bool conv_add_ok(const ConvArgs& a, int dtype);
 bool conv_in_affine_ok(const ConvArgs& a, int dtype);
 bool conv_bn_bwd_ok(const ConvArgs& a, int dtype);

@@ -34,6 +34,7 @@ _state = {"dtype": RD_F32, "tape": None, "defer_wgrad": True, "fused_loftr": Tru
           # conv2 staging, conv2 -> fused apply + add + activation: measured faster); 2: also the decoder chain (measured SLOWER on MI355X:
           # the 3x3 kernels are vector-issue bound and the staging arithmetic costs more than the HBM pass it replaces -- DESIGN.md)
           "lazy_bn": 1,
+          "up2_on_source": True,   # forward of an exact-2x UpConv2d as a 3x3 convolution of the SOURCE with per-parity-class pre-summed weights (rd_conv_desc.out_d2s)
           "bn_head": True,    # conv -> BatchNorm -> act -> one-channel 3x3 output convolution: the fused decoder-head kernels (rd_bn_head_*)
           # (round 4 measured two concurrency experiments SLOWER on MI355X / ROCm 7 and round 5 removed them from the product: convolution weight
           # gradients on a second stream -- RC-Net 1005 -> 952 img/s, 38 fork / join edges per step -- and the skip features' RoI poolings next to
@@ -50,7 +51,7 @@ _state = {"dtype": RD_F32, "tape": None, "defer_wgrad": True, "fused_loftr": Tru
           "bn_bwd_fused": False,
           "dw_fused_stats": True}          # depthwise convolution with the BatchNorm statistics in its epilogue; False: separate rd_bn_stats pass
 
-_SWITCHES = {"fuse_upsample_bwd": bool, "loftr_cross_inplace": bool, "fuse_res_add": bool, "fuse_grad_add": bool, "lazy_bn": (0, 2), "bn_head": bool, "roi_u8": bool,
+_SWITCHES = {"fuse_upsample_bwd": bool, "loftr_cross_inplace": bool, "fuse_res_add": bool, "fuse_grad_add": bool, "lazy_bn": (0, 2), "bn_head": bool, "up2_on_source": bool, "roi_u8": bool,
              "roi_bwd": ("auto", "gather", "tile", "atomic"), "bn_recompute": bool, "bn_bwd_fused": bool, "dw_fused_stats": bool, "roi_tile_min_blocks": (0, 1 << 30),
              "defer_wgrad": bool, "fused_loftr": bool, "deterministic_roi_pool": bool}
 
@@ -95,7 +96,7 @@ def apply_opts(spec):
 
 
 # how often a virtual activation was consumed in place / had to be written after all (tests assert that the fused routes are taken)
-lazy_counts = {"fwd_fused": 0, "wgrad_fused": 0, "add_fused": 0, "materialized": 0, "bn_bwd_fused": 0, "head_fused": 0, "head_unfused_bwd": 0}
+lazy_counts = {"fwd_fused": 0, "wgrad_fused": 0, "add_fused": 0, "materialized": 0, "bn_bwd_fused": 0, "head_fused": 0, "head_unfused_bwd": 0, "up2_fwd": 0}
 
 
 def head_route(C):
@@ -707,7 +708,7 @@ def packed_weight(w, mode, dt, cin_pad=0):
         assert mode == 0 and cin_pad >= cin
         n = L().rd_conv_packed_elems(cout, kh * kw * cin_pad, dt)
     else:
-        rows, c = (cin, cout) if mode else (cout, cin)
+        rows, c = (4 * cout, cin) if mode == 2 else ((cin, cout) if mode else (cout, cin))
         n = L().rd_conv_packed_elems(rows, kh * kw * c, dt)
     buf = hit[1] if (hit is not None and hit[1].numel() == n and hit[1].device == w.device) else torch.empty(n, dtype=_TORCH_DT[dt], device=w.device)
     if cin_pad:
@@ -946,13 +947,27 @@ def conv_block(x, weight, *, x2=None, bias=None, stride=1, pad=None, up=None, bn
         if cin_pad or not lib.rd_conv_fusion_ok(ctypes.byref(d), ctypes.byref(fus)):
             assert not cin_pad
             fus, x = None, lz.materialize()
-    wp = packed_weight(weight, 0, dt, cin_pad)
+    # exact-2x nearest up-sampling + 3x3 (UpConv2d at 15x6 -> 30x12 ... 120x50 -> 240x100): per output parity class (a, b) it is a 2x2 convolution of
+    # the SOURCE with pre-summed taps.  Where the library has that form (rd_conv_up2_ok) the forward runs at source resolution with 4 Cout output
+    # channels = (class, channel), skips the structurally zero (tap, class) blocks and stores depth-to-space: 2.25 x fewer MACs, a quarter of the
+    # staged pixels.  The backward keeps the virtual-resolution form (same function; the pre-summed weights are rounded once more in bf16).
+    d_up2 = None
+    if (is_up and C2 == 0 and (Hin, Win) == (2 * H1, 2 * W1) and KH == 3 and KW == 3 and stride == 1 and pad == 1 and conv_act == ACT_NONE and bias is None and lz is None
+            and not cin_pad and out_hw is None and residual is None and _state["up2_on_source"]):
+        d_up2 = _desc(dt, N, H1, W1, C1, 0, False, H1, W1, 4 * Cout, 3, 3, 1, 1, 1, H1, W1, ACT_NONE, slope, Cout)
+        d_up2.out_d2s = 1
+        if not lib.rd_conv_up2_ok(ctypes.byref(d_up2)):
+            d_up2 = None
+    wp = packed_weight(weight, 2 if d_up2 is not None else 0, dt, cin_pad)
     y = torch.empty((N, OH, OW, Cout), dtype=x.dtype, device=x.device)
     stats = None
     bn_train = use_bn and (training or not bn.track_running_stats)
     if bn_train:
-        rows = lib.rd_conv_stats_rows(ctypes.byref(d))
-        stats = torch.empty((rows, Cout, 2), dtype=torch.float32, device=x.device)
+        if d_up2 is not None:      # rows of 4 Cout columns = four rows of Cout
+            stats = torch.empty((4 * lib.rd_conv_stats_rows(ctypes.byref(d_up2)), Cout, 2), dtype=torch.float32, device=x.device)
+        else:
+            rows = lib.rd_conv_stats_rows(ctypes.byref(d))
+            stats = torch.empty((rows, Cout, 2), dtype=torch.float32, device=x.device)
     flops = 2.0 * N * OH * OW * Cout * KH * KW * Cin  # algorithmic (2 FLOP per MAC), same count for dgrad / wgrad
     shp = "M=%d Cin=%d Cout=%d k=%d s=%d%s" % (N * OH * OW, Cin, Cout, KH, stride, " up" if is_up else "")
     bias_t = bias.detach() if bias is not None else None
@@ -968,6 +983,11 @@ def conv_block(x, weight, *, x2=None, bias=None, stride=1, pad=None, up=None, bn
         _chk(_timed("conv_gemm", flops, lambda: lib.rd_conv_fwd_add(ctypes.byref(d), _p(x), _p(x2), _p(wp), _p(bias_t), _p(residual), _p(y), st),
                     "fwd " + shp + " (+res)", b_in + b_w + 2 * b_out,
                     kernel=lambda: lib.rd_conv_fwd_kernel_name(ctypes.byref(d)).decode(), idem=True), "rd_conv_fwd_add")
+    elif d_up2 is not None:
+        lazy_counts["up2_fwd"] += 1
+        _chk(_timed("conv_gemm", flops * 4.0 / 9.0, lambda: lib.rd_conv_fwd(ctypes.byref(d_up2), _p(x), None, _p(wp), None, _p(y), None, _p(stats), st),
+                    "fwd " + shp + " (on source)", b_in + b_w + b_out,
+                    kernel=lambda: lib.rd_conv_fwd_kernel_name(ctypes.byref(d_up2)).decode(), idem=True), "rd_conv_fwd(up2)")
     elif fus is not None:
         lazy_counts["fwd_fused"] += 1
         _chk(_timed("conv_gemm", flops, lambda: lib.rd_conv_fwd_fused(ctypes.byref(d), ctypes.byref(fus), _p(x), _p(x2), _p(wp), _p(bias_t), None,

@@ -496,6 +496,7 @@ def _lazy_both(build_and_run):
     for flag in (True, False):
         engine.set_lazy_bn(2 if flag else 0)
         engine.set_switch("bn_head", False)      # (the fused decoder head rounds / sums differently: bn_head_cases compares it with a tolerance)
+        engine.set_switch("up2_on_source", False)      # (taken only for a plain-tensor input: the two levels would run different forwards; up2_cases)
         for k in engine.lazy_counts:
             engine.lazy_counts[k] = 0
         try:
@@ -503,6 +504,7 @@ def _lazy_both(build_and_run):
         finally:
             engine.set_lazy_bn(1)
             engine.set_switch("bn_head", True)
+            engine.set_switch("up2_on_source", True)
         if flag:
             counts = dict(engine.lazy_counts)
     assert len(res[0]) == len(res[1])
@@ -694,6 +696,45 @@ def bn_head_cases(dev, quick=False):
         finally:
             if ctx:
                 ctx.__exit__()
+
+
+def up2_cases(dev, quick=False):
+    """The forward of an exact-2x up-sampling 3x3 layer computed on its SOURCE (rd_conv_desc.out_d2s, pack mode 2: per parity class a 2x2
+    effective kernel of pre-summed taps, structurally zero (tap, class) blocks skipped, depth-to-space store): (1) integer data in {-1, 0, 1} --
+    every product, partial sum and pre-summed weight is exactly representable, so the route must reproduce the fp32 oracle bit for bit (forward;
+    the unchanged backward with it), ragged and multi-tile maps; (2) UpConv2d with BatchNorm on random data, route on against route off:
+    outputs within 2e-2 of max and 5e-3 in relative L2 (the pre-summed weights are rounded to bf16 once more; BatchNorm statistics rows fold
+    four classes); the gradients behind BatchNorm + LeakyReLU within 6e-2 in relative L2 (measured 0.6-3 %: a 0.3 % change of the outputs flips
+    the LeakyReLU slope of ~0.25 % of the elements, each flip is 0.8 of that element's gradient); and the route IS taken."""
+    from riders_amd import engine, net_utils
+    for k in engine.lazy_counts:
+        engine.lazy_counts[k] = 0
+    bf16_exact_conv_case(dev, cin=32, cout=16, k=3, s=1, N=2, up=((5, 4), (10, 8)))
+    bf16_exact_conv_case(dev, cin=32, cout=16, k=3, s=1, N=3, up=((9, 17), (18, 34)))
+    assert engine.lazy_counts["up2_fwd"] == 2, engine.lazy_counts
+    bf16_exact_conv_case(dev, cin=32, cout=16, k=3, s=1, N=2, up=((5, 4), (11, 8)))      # not an exact 2x: the virtual-resolution gather
+    assert engine.lazy_counts["up2_fwd"] == 2, engine.lazy_counts
+    with bf16_mode("bf16"):
+        shapes = [(2, 32, 7, 9)] if quick else [(2, 32, 7, 9), (3, 32, 24, 10)]
+        for shape in shapes:
+            hv = (2 * shape[2], 2 * shape[3])
+            run = _lazy_module_run(dev, lambda: net_utils.UpConv2d(32, 16, 3, 'kaiming_uniform', net_utils.activation_func('leaky_relu'), True),
+                                   [q(t(rand_array("up2.x", shape, 1.0)))], lambda m, x: m(x, hv))
+            res = {}
+            for on in (False, True):
+                engine.set_switch("up2_on_source", on)
+                try:
+                    for k in engine.lazy_counts:
+                        engine.lazy_counts[k] = 0
+                    res[on] = [v.detach().float().cpu() for v in run()]
+                    n = engine.lazy_counts["up2_fwd"]
+                finally:
+                    engine.set_switch("up2_on_source", True)
+                assert n == (1 if on else 0), (shape, on, n)
+            close(res[True][0], res[False][0], 2e-2, "up-convolution on its source, output %s" % (shape,))
+            close_l2(res[True][0], res[False][0], 5e-3, "up-convolution on its source, output %s" % (shape,))
+            for i, (a, b) in enumerate(zip(res[True][1:], res[False][1:])):      # gradients behind BatchNorm + LeakyReLU: single mask flips dominate a max-norm
+                close_l2(a, b, 6e-2, "up-convolution on its source, gradient %d %s" % (i, shape))
 
 
 def lazy_bn_rcnet_geometry_case(dev):
@@ -1563,6 +1604,8 @@ def pack_batch_case(dev):
             for mode in (0, 1):
                 bufs.append(engine.packed_weight(w, mode, dt))
         bufs.append(engine.packed_weight(ws[2], 0, dt, 8))      # 3-channel stem zero-padded to one 16-byte vector
+        bufs.append(engine.packed_weight(ws[0], 2, dt))         # exact-2x up-convolution on its source: four parity classes of pre-summed taps
+        bufs.append(engine.packed_weight(ws[7], 2, dt))
     want = [b.clone() for b in bufs]
     for b in bufs:
         b.zero_()

@@ -61,6 +61,10 @@ def test_wgrad_fit(emu):
     P.wgrad_fit_cases(emu, quick=True)
 
 
+def test_up2_on_source(emu):
+    P.up2_cases(emu, quick=True)
+
+
 def test_bn_head_fused(emu):
     P.bn_head_cases(emu, quick=True)
 

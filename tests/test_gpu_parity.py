@@ -61,6 +61,10 @@ def test_wgrad_fit(gpu):
     P.wgrad_fit_cases(gpu)
 
 
+def test_up2_on_source(gpu):
+    P.up2_cases(gpu)
+
+
 def test_bn_head_fused(gpu):
     P.bn_head_cases(gpu)
 
