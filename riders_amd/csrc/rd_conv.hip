@@ -1090,8 +1090,9 @@ static bool use_conv3x3_frag(const ConvArgs& a, int dtype) {   // wide layers: w
 }
 static bool conv_stem_ok(const ConvArgs& a, int dtype);
 static int conv_stem_blocks(const ConvArgs& a);
+static bool conv_d2s_small(const ConvArgs& a, int dtype);
 int conv_stats_rows(const ConvArgs& a, int dtype) {
-  if (a.d2s) return conv3x3_small_blocks(a, dtype);
+  if (a.d2s) return conv_d2s_small(a, dtype) ? conv3x3_small_blocks(a, dtype) : conv3x3_frag_tiles(a, dtype);
   if (conv_stem_ok(a, dtype)) return conv_stem_blocks(a);
   if (conv_few_ok(a)) return conv_few_blocks(a);
   if (conv1x1_direct_ok(a, dtype)) return conv1x1_direct_rows(a);
@@ -1259,7 +1260,7 @@ static void launch_conv_stem(const ConvArgs& a, int dtype, hipStream_t st) {
 }
 
 void launch_conv(const ConvArgs& a, int dtype, hipStream_t st) {
-  if (a.d2s) { launch_conv3x3_small(a, dtype, st); return; }      // (rd_api.cpp checked conv_d2s_ok)
+  if (a.d2s) { if (conv_d2s_small(a, dtype)) launch_conv3x3_small(a, dtype, st); else launch_conv3x3_frag(a, dtype, st); return; }      // (rd_api.cpp checked conv_d2s_ok)
   if (conv_skinny_ok(a, dtype)) { launch_linear_skinny(a, dtype, st); return; }
   if (conv_stem_ok(a, dtype)) { launch_conv_stem(a, dtype, st); return; }
   if (conv_few_ok(a)) { launch_conv_few(a, dtype, st); return; }
@@ -1279,10 +1280,14 @@ bool conv_pool2_ok(const ConvArgs& a, int dtype) {
   return !conv_few_ok(a) && !conv1x1_direct_ok(a, dtype) && !conv3x3_c1_ok(a) && use_conv3x3_small(a, dtype) && !(a.OH & 1) && !(a.OW & 1) &&
          a.D1 == a.Cout && !a.bias && a.act == ACT_NONE;
 }
-// out_d2s (ConvArgs::d2s): the narrow-layer 3x3 kernel's D2S instantiation -- 16-bit activations, 64-byte source pixels (32 channels), 4 x 16 output channels
+// out_d2s (ConvArgs::d2s): the narrow-layer 3x3 kernel's D2S instantiation -- 16-bit activations, 64-byte source pixels (32 channels), 4 x 16 output
+// channels -- or the register-fed kernel's (whole 128-byte channel chunks, D1 a multiple of 32)
+static bool conv_d2s_small(const ConvArgs& a, int dtype) {
+  return dtype != 0 && a.C2 == 0 && a.C1 == 32 && a.Cout == 64 && a.D1 == 16 && conv3x3_small_ok(a, dtype);
+}
 bool conv_d2s_ok(const ConvArgs& a, int dtype) {
-  return dtype != 0 && a.C2 == 0 && a.C1 == 32 && a.Cout == 64 && a.D1 == 16 && !a.ups && !a.pool2 && !a.bias && a.act == ACT_NONE && !a.in_scale && !a.add1 &&
-         conv3x3_small_ok(a, dtype);      // (launch_conv sends a d2s descriptor straight to that kernel, whatever its tile count)
+  if (a.ups || a.pool2 || a.bias || a.act != ACT_NONE || a.in_scale || a.add1 || a.Cout != 4 * a.D1) return false;
+  return conv_d2s_small(a, dtype) || conv3x3_frag_d2s_ok(a, dtype);      // (launch_conv sends a d2s descriptor straight to that kernel, whatever its tile count)
 }
 // ConvArgs::add1: the kernels that store through conv_epilogue_store except the narrow-layer one (not the few-channel / single-channel
 // streaming kernels, not the experimental LDS-DMA kernel), one destination, no 2x2 reduction
@@ -1317,7 +1322,8 @@ const char* conv_kernel_name(const ConvArgs& a, int dtype) {
   if (conv_few_ok(a)) return "conv_few_kernel";
   if (conv1x1_direct_ok(a, dtype)) return "conv1x1_direct_kernel";
   if (conv3x3_c1_ok(a)) return "conv3x3_c1_kernel";
-  if (a.d2s || use_conv3x3_small(a, dtype)) return conv3x3_small_name(a, dtype);
+  if (a.d2s) return conv_d2s_small(a, dtype) ? conv3x3_small_name(a, dtype) : conv3x3_frag_name(a, dtype);
+  if (use_conv3x3_small(a, dtype)) return conv3x3_small_name(a, dtype);
   if (use_conv3x3_frag(a, dtype)) return conv3x3_frag_name(a, dtype);
   if (use_conv3x3(a, dtype)) return conv3x3_patch_name(a, dtype);
   {     // the implicit-GEMM kernel's instantiation, as launch_conv_t picks it

@@ -49,8 +49,12 @@ constexpr int frag_pmax(int tp) { return tp <= 128 ? 256 : (tp <= 256 ? 384 : 64
 // LIN: linear tiles; MULTI: more than one channel chunk (the next chunk's patch is prefetched).
 // AFF: source 1 is a BatchNorm-ed producer's RAW output; scale / shift + activation are applied while the patch is written to LDS
 // (ConvArgs::in_scale; coefficients in an LDS copy behind the planes at byte offset g.aff), padding pixels stay zero.
-template <typename T, int NPT, int WPX, int WCH, bool LIN, bool MULTI, bool AFF = false>
+// D2S: the forward of an exact-2x up-sampling layer on its SOURCE (ConvArgs::d2s, pack mode 2; see conv3x3_small_kernel): the wave's 32 output
+// channels belong to ONE parity class (a, b) (D1 % 32 == 0), so the wave runs only that class's four taps (a + {0, 1}, b + {0, 1}) per chunk -- their
+// fragments alone are fetched -- and stores its tile at output pixel (2 i + a, 2 j + b), channels relative to the class.
+template <typename T, int NPT, int WPX, int WCH, bool LIN, bool MULTI, bool AFF = false, bool D2S = false>
 __global__ __launch_bounds__(64 * WPX * WCH, (WPX * WCH == 8 && WCH == 4) ? 4 : ((WPX * WCH == 8 || NPT == 8 || (MULTI && WCH == 1)) ? 2 : 3)) void conv3x3_frag_kernel(ConvArgs a, FragGeom g) {
+  static_assert(!D2S || !AFF, "D2S has no consumer-side BatchNorm apply");
   constexpr int NW = WPX * WCH, NT = 64 * NW;
   constexpr int VE = Elem<T>::VE;
   constexpr int CKE = STAGE_BYTES / (int)sizeof(T);   // channels per chunk (128 bytes per pixel)
@@ -70,6 +74,8 @@ __global__ __launch_bounds__(64 * WPX * WCH, (WPX * WCH == 8 && WCH == 4) ? 4 : 
   const int WT = g.WT, np = g.np, PS = g.ps;
   const int Hp = a.ups ? a.H1 : a.Hin, Wp = a.ups ? a.W1 : a.Win;
   const int H1 = a.OH + 1;
+  int ca = 0, cb2 = 0, cls0 = 0;      // D2S: the wave's parity class (row, column) and its first channel
+  if (D2S) { const int cls = RD_WAVE_UNIFORM((n0 + wc * 32) / a.D1); ca = cls >> 1; cb2 = cls & 1; cls0 = cls * a.D1; }
 
   // ---- tile origin ------------------------------------------------------------------------------------------------------------------
   // linear: first virtual pixel of the tile (the strip starts with a zero row, which no tile computes); 2-D: image, first row, first column
@@ -152,10 +158,10 @@ __global__ __launch_bounds__(64 * WPX * WCH, (WPX * WCH == 8 && WCH == 4) ? 4 : 
     if (LIN) {
       int n, ih, iw;
       const bool ok = strip_pixel(u0 + q * 16 + fr, n, ih, iw);
-      pm[pt] = ok ? (n * a.OH + ih) * a.OW + iw : -1;
+      pm[pt] = ok ? (D2S ? (n * 2 * a.OH + 2 * ih + ca) * (2 * a.OW) + 2 * iw + cb2 : (n * a.OH + ih) * a.OW + iw) : -1;
     } else {
       const int oh = toh0 + q, ow = tow0 + fr;
-      pm[pt] = (oh < a.OH && ow < a.OW) ? (tn * a.OH + oh) * a.OW + ow : -1;
+      pm[pt] = (oh < a.OH && ow < a.OW) ? (D2S ? (tn * 2 * a.OH + 2 * oh + ca) * (2 * a.OW) + 2 * ow + cb2 : (tn * a.OH + oh) * a.OW + ow) : -1;
     }
   }
   // fragment read of (pixel tile pt, tap (kr, kc), k half kh): plane kh*2 + (fg >> 1), column fg & 1, patch pixel p0 + fr + tap offset where
@@ -191,23 +197,28 @@ __global__ __launch_bounds__(64 * WPX * WCH, (WPX * WCH == 8 && WCH == 4) ? 4 : 
   // BEHIND the fragment loads of their tap and get two taps of MFMA work to arrive (all of them in front of tap 0 would park every wave
   // for one HBM round trip per chunk).  Scheduling fences keep each tap's requests at its top and its reads inside it.
   constexpr int PPT = (PIT + 7) / 8;   // pieces per tap, taps 0..7
+  constexpr int PPT4 = (PIT + 3) / 4;  // D2S: four taps per chunk
   int boff = 0;      // byte offset of the patch buffer the current chunk reads
-  auto tap_body = [&](int chunk, int tap, uint4 (&wcur)[2][2], uint4 (&wnxt)[2][2]) RD_INLINE_LAMBDA {
-    load_w(min(chunk * 9 + tap + 1, nchunk * 9 - 1), wnxt);
-    if (MULTI && tap < 8) {
-      const bool last = chunk + 1 >= nchunk;
+  // tap: this tap (a compile-time constant at the nine call sites of the plain kernel, a wave-uniform value in D2S); ct_next: the fragment set
+  // (chunk * 9 + tap) to request for the next tap_body; pieces [p0, p1) of chunk_next's patch ride behind it
+  auto tap_body = [&](int tap, int ct_next, int chunk_next, int p0, int p1, uint4 (&wcur)[2][2], uint4 (&wnxt)[2][2]) RD_INLINE_LAMBDA {
+    load_w(ct_next, wnxt);
+    if (MULTI) {
+      const bool last = chunk_next >= nchunk;
 #pragma unroll
-      for (int k = 0; k < PPT; k++)
-        if (tap * PPT + k < PIT) load_piece(min(chunk + 1, nchunk - 1), tap * PPT + k, last);
+      for (int k = 0; k < (D2S ? PPT4 : PPT); k++)
+        if (p0 + k < p1 && p0 + k < PIT) load_piece(min(chunk_next, nchunk - 1), p0 + k, last);
     }
     sched_fence();
-    const int kr = tap / 3, kc = tap % 3;
+    const int kr = tap / 3, kc = tap - kr * 3;
+    const int toff = D2S ? (kr * (LIN ? WT : 18) + kc) * 32 : 0;      // (run-time tap: one scalar offset instead of immediates)
 #pragma unroll
     for (int kh = 0; kh < 2; kh++) {
       uint4 pf[NPT];
 #pragma unroll
       for (int pt = 0; pt < NPT; pt++)
-        pf[pt] = *reinterpret_cast<const uint4*>(smem + boff + lbase[LIN ? kr : 0][kh] + (LIN ? pt * 16 + kc : (pt + kr) * 18 + kc) * 32);
+        pf[pt] = D2S ? *reinterpret_cast<const uint4*>(smem + boff + lb + kh * 2 * PS + toff + (LIN ? pt * 16 : pt * 18) * 32)
+                     : *reinterpret_cast<const uint4*>(smem + boff + lbase[LIN ? kr : 0][kh] + (LIN ? pt * 16 + kc : (pt + kr) * 18 + kc) * 32);
 #pragma unroll
       for (int c = 0; c < 2; c++) {
         const uint4 wf = wcur[c][kh];
@@ -229,19 +240,30 @@ __global__ __launch_bounds__(64 * WPX * WCH, (WPX * WCH == 8 && WCH == 4) ? 4 : 
     }
     sched_fence();
   };
+  // plain kernel: tap t requests tap t + 1's fragments (the layer's last tap re-reads its own) and, for t < 8, its share of the next chunk's patch
+#define RD_TAP(chunk, t, wc_, wn_) tap_body(t, min((chunk) * 9 + (t) + 1, nchunk * 9 - 1), (chunk) + 1, (t) * PPT, (t) < 8 ? (t) * PPT + PPT : (t) * PPT, wc_, wn_)
+  auto d2s_tap = [&](int i) RD_INLINE_LAMBDA { return (ca + (i >> 1)) * 3 + cb2 + (i & 1); };      // the class's i-th tap
 
   uint4 wa[2][2], wb[2][2];
 #pragma unroll
   for (int i = 0; i < PIT; i++) load_piece(0, i, false);
-  load_w(0, wa);
+  load_w(D2S ? d2s_tap(0) : 0, wa);
   for (int chunk = 0; chunk < nchunk; chunk++) {
     boff = (MULTI && (chunk & 1)) ? g.db : 0;
     if (!(MULTI && g.db)) __syncthreads();            // one buffer: every wave is done with the previous chunk's patch
     store_patch(chunk, boff);
     __syncthreads();
-    tap_body(chunk, 0, wa, wb); tap_body(chunk, 1, wb, wa); tap_body(chunk, 2, wa, wb);
-    tap_body(chunk, 3, wb, wa); tap_body(chunk, 4, wa, wb); tap_body(chunk, 5, wb, wa);
-    tap_body(chunk, 6, wa, wb); tap_body(chunk, 7, wb, wa); tap_body(chunk, 8, wa, wb);
+    if (D2S) {      // four taps: an even number of register swaps, the next chunk's first fragments land in wa
+      const int cn = min(chunk + 1, nchunk - 1);
+      tap_body(d2s_tap(0), chunk * 9 + d2s_tap(1), chunk + 1, 0, PPT4, wa, wb);
+      tap_body(d2s_tap(1), chunk * 9 + d2s_tap(2), chunk + 1, PPT4, 2 * PPT4, wb, wa);
+      tap_body(d2s_tap(2), chunk * 9 + d2s_tap(3), chunk + 1, 2 * PPT4, 3 * PPT4, wa, wb);
+      tap_body(d2s_tap(3), cn * 9 + d2s_tap(0), chunk + 1, 3 * PPT4, 4 * PPT4, wb, wa);
+      continue;
+    }
+    RD_TAP(chunk, 0, wa, wb); RD_TAP(chunk, 1, wb, wa); RD_TAP(chunk, 2, wa, wb);
+    RD_TAP(chunk, 3, wb, wa); RD_TAP(chunk, 4, wa, wb); RD_TAP(chunk, 5, wb, wa);
+    RD_TAP(chunk, 6, wa, wb); RD_TAP(chunk, 7, wb, wa); RD_TAP(chunk, 8, wa, wb);
     if (MULTI) {     // nine taps = an odd number of register swaps: the next chunk's first fragments landed in wb
 #pragma unroll
       for (int c = 0; c < 2; c++)
@@ -249,6 +271,7 @@ __global__ __launch_bounds__(64 * WPX * WCH, (WPX * WCH == 8 && WCH == 4) ? 4 : 
         for (int kh = 0; kh < 2; kh++) wa[c][kh] = wb[c][kh];
     }
   }
+#undef RD_TAP
 
   __syncthreads();  // all waves finished reading the patch before it is reused as reduction scratch
   float ssum[2][4], ssq[2][4];
@@ -265,7 +288,8 @@ __global__ __launch_bounds__(64 * WPX * WCH, (WPX * WCH == 8 && WCH == 4) ? 4 : 
 #pragma unroll
       for (int c = 0; c < 2; c++) a2[c][h] = acc[c][pp * 2 + h];
     }
-    conv_epilogue_store<T, 2, true, true>(a, a2, mm, mvv, n0, wc, fr, fg, ssum, ssq);
+    if (D2S) conv_epilogue_store_at<T, 2, false, 16, false>(a, a2, mm, mvv, n0 + wc * 32 - cls0 + fg * 4, ssum, ssq);      // channels relative to the class
+    else conv_epilogue_store<T, 2, true, true>(a, a2, mm, mvv, n0, wc, fr, fg, ssum, ssq);
   }
   conv_epilogue_stats<2, BN, WPX, NT>(a, ssum, ssq, n0, wc, wpx, fr, fg, t, tile, reinterpret_cast<float*>(smem));
 }
@@ -577,6 +601,12 @@ bool conv3x3_frag_ok(const ConvArgs& a, int dtype) {
   FragPlan p;
   return rd_opt(OPT_CONV3X3_FRAG, 1) && frag_plan(a, dtype, p);
 }
+// ConvArgs::d2s on this kernel: 16-bit builds, whole 32-channel wave tiles inside one parity class, the block shapes the D2S instantiations exist for
+bool conv3x3_frag_d2s_ok(const ConvArgs& a, int dtype) {
+  FragPlan p;
+  return dtype != 0 && a.C2 == 0 && !a.ups && !a.in_scale && a.Cout == 4 * a.D1 && (a.D1 % 32) == 0 && rd_opt(OPT_CONV3X3_FRAG, 1) && frag_plan(a, dtype, p) &&
+         p.v32 == 0 && p.variant <= 2;
+}
 bool conv3x3_frag_is32(const ConvArgs& a, int dtype) { FragPlan p; return frag_plan(a, dtype, p) && p.v32 != 0; }
 int conv3x3_frag_tiles(const ConvArgs& a, int dtype) { FragPlan p; frag_plan(a, dtype, p); return p.ntiles; }
 int conv3x3_frag_blocks(const ConvArgs& a, int dtype) { FragPlan p; frag_plan(a, dtype, p); return p.ntiles * p.ncb; }
@@ -592,6 +622,9 @@ const char* conv3x3_frag_name(const ConvArgs& a, int dtype) {
     snprintf(buf, sizeof(buf), "conv3x3_frag32_kernel<%s, %d, %d, %d, %d, %s>", RD_T16_NAME, w.nq, w.wpx, w.wch, w.cw, multi ? "true" : "false");
     return buf;
   }
+  if (a.d2s) snprintf(buf, sizeof(buf), "conv3x3_frag_kernel<%s, %d, %d, %d, %s, %s, false, true>", RD_T16_NAME, npt[p.variant], wpx[p.variant], wch[p.variant],
+                      p.lin ? "true" : "false", multi ? "true" : "false");
+  else
   snprintf(buf, sizeof(buf), "conv3x3_frag_kernel<%s, %d, %d, %d, %s, %s, %s>", dtype == 0 ? "float" : RD_T16_NAME, npt[p.variant], wpx[p.variant],
            wch[p.variant], p.lin ? "true" : "false", multi ? "true" : "false", a.in_scale ? "true" : "false");
   return buf;
@@ -613,6 +646,15 @@ static void launch_frag_v(const ConvArgs& a, const FragPlan& p, const FragGeom& 
 #define RD_FR(LINV, MULTIV)                                                                                                         \
   { if (aff) hipLaunchKernelGGL((conv3x3_frag_kernel<T, NPT, WPX, WCH, LINV, MULTIV, true>), grid, block, lds, st, a, g);          \
     else hipLaunchKernelGGL((conv3x3_frag_kernel<T, NPT, WPX, WCH, LINV, MULTIV>), grid, block, lds, st, a, g); }
+  if (a.d2s) {      // conv3x3_frag_d2s_ok: 16-bit, the > 64-channel block shapes (variants 0-2), no consumer-side BatchNorm apply
+    if constexpr (sizeof(T) == 2 && WCH >= 2 && NPT * WPX == 8) {
+#define RD_FRD(LINV, MULTIV) hipLaunchKernelGGL((conv3x3_frag_kernel<T, NPT, WPX, WCH, LINV, MULTIV, false, true>), grid, block, lds, st, a, g);
+      if (p.lin) { if (multi) RD_FRD(true, true) else RD_FRD(true, false) }
+      else { if (multi) RD_FRD(false, true) else RD_FRD(false, false) }
+#undef RD_FRD
+    }
+    return;
+  }
   if (p.lin) { if (multi) RD_FR(true, true) else RD_FR(true, false) }
   else { if (multi) RD_FR(false, true) else RD_FR(false, false) }
 #undef RD_FR

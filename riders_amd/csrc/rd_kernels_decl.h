@@ -36,6 +36,7 @@ void launch_conv1x1_direct(const ConvArgs& a, int dtype, hipStream_t st);
 bool conv3x3_frag_ok(const ConvArgs& a, int dtype);
 int conv3x3_frag_tiles(const ConvArgs& a, int dtype);
 bool conv3x3_frag_is32(const ConvArgs& a, int dtype);
+bool conv3x3_frag_d2s_ok(const ConvArgs& a, int dtype);
 int conv3x3_frag_blocks(const ConvArgs& a, int dtype);
 void launch_conv3x3_frag(const ConvArgs& a, int dtype, hipStream_t st);
 const char* conv3x3_frag_name(const ConvArgs& a, int dtype);

@@ -714,6 +714,18 @@ def up2_cases(dev, quick=False):
     assert engine.lazy_counts["up2_fwd"] == 2, engine.lazy_counts
     bf16_exact_conv_case(dev, cin=32, cout=16, k=3, s=1, N=2, up=((5, 4), (11, 8)))      # not an exact 2x: the virtual-resolution gather
     assert engine.lazy_counts["up2_fwd"] == 2, engine.lazy_counts
+    # the register-fed kernel's D2S instantiations: one chunk / several chunks, 2-D and linear tiles, 128- and 64-channel blocks
+    n0 = engine.lazy_counts["up2_fwd"]
+    for lin in (0, 1):
+        with force_frag_conv(lin=lin):
+            bf16_exact_conv_case(dev, cin=64, cout=32, k=3, s=1, N=2, up=((9, 7), (18, 14)))
+            if not quick or lin:
+                bf16_exact_conv_case(dev, cin=128, cout=64, k=3, s=1, N=2, up=((6, 5), (12, 10)))
+    if not quick:
+        with force_frag_conv(lin=1):
+            bf16_exact_conv_case(dev, cin=128, cout=32, k=3, s=1, N=3, up=((15, 6), (30, 12)))
+            bf16_exact_conv_case(dev, cin=256, cout=128, k=3, s=1, N=1, up=((7, 3), (14, 6)))
+    assert engine.lazy_counts["up2_fwd"] - n0 == (3 if quick else 6), engine.lazy_counts
     with bf16_mode("bf16"):
         shapes = [(2, 32, 7, 9)] if quick else [(2, 32, 7, 9), (3, 32, 24, 10)]
         for shape in shapes:
