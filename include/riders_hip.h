@@ -60,6 +60,10 @@ typedef struct rd_conv_desc {
                                   tile (a, b) of source pixel (i, j) is stored as pixel (2 i + a, 2 j + b) of the (2 OH) x (2 OW) x D1 output
                                   (depth to space), and the structurally zero (tap, class) blocks are skipped.  Statistics rows: Cout columns =
                                   4 rows of D1.  Only where rd_conv_up2_ok says so. */
+  int32_t in_s2d;              /* 1: the data gradient of the same layer on the source: src1 is the (2 Hin) x (2 Win) x (C1 / 4) gradient of the
+                                  layer's output, read as an Hin x Win x C1 tensor of (parity class, channel) channels (space to depth); weights
+                                  packed with mode 3; the structurally zero (tap, class) blocks of the K axis are skipped.  The result is the
+                                  gradient at SOURCE resolution (no 2x2 reduction pass).  Only where rd_conv_up2_dgrad_ok says so. */
 } rd_conv_desc;
 
 /* elements (of the activation dtype) in a packed weight buffer for `rows` x (KH*KW*C).  K axes that can be 9 taps x whole 128-byte channel
@@ -67,7 +71,8 @@ typedef struct rd_conv_desc {
  * register-fed 3x3 kernel of rd_conv_fwd) */
 int64_t rd_conv_packed_elems(int32_t rows, int32_t K, int32_t dtype);
 /* OIHW fp32 -> packed; mode 0: forward operand, mode 1: data-gradient operand (transposed + flipped), mode 2 (3x3 only): forward operand of the
- * exact-2x up-sampling layer on its source (rd_conv_desc.out_d2s): 4 Cout rows = (parity class, channel), each class's taps pre-summed */
+ * exact-2x up-sampling layer on its source (rd_conv_desc.out_d2s): 4 Cout rows = (parity class, channel), each class's taps pre-summed;
+ * mode 3 (3x3 only): its data-gradient operand (rd_conv_desc.in_s2d): Cin rows x 9 taps x 4 Cout (class, channel) columns, transposed + flipped */
 int rd_conv_pack_weights(const float* w_oihw, void* packed, int32_t Cout, int32_t Cin, int32_t KH, int32_t KW,
                          int32_t mode, int32_t dtype, void* stream);
 /* The same re-layout for MANY weights in one launch (after an optimizer step every cached operand of every conv / linear
@@ -154,6 +159,8 @@ const char* rd_conv_wgrad_kernel_name(const rd_conv_desc* d);
 int32_t rd_conv_out_reduce2_ok(const rd_conv_desc* d);
 /* 1 when rd_conv_fwd can run this descriptor with out_d2s = 1 (3x3 / stride 1 / pad 1 on the source, Cout = 4 x D1, a kernel that implements it) */
 int32_t rd_conv_up2_ok(const rd_conv_desc* d);
+/* 1 when rd_conv_fwd can run this descriptor with in_s2d = 1 (3x3 / stride 1 / pad 1 at source resolution, C1 = 4 x the layer's output channels, C2 = 0) */
+int32_t rd_conv_up2_dgrad_ok(const rd_conv_desc* d);
 /* dst = round(conv(...) + addend): `addend` is a [N*OH*OW][Cout] tensor of the activation dtype, read once in the epilogue.  The engine's
  * backward hands over a tensor's EARLIER gradient contribution when a second consumer's data gradient arrives (skip connections of
  * utils/net_utils.py:564-569, residual blocks :250-330), instead of writing the second contribution and adding the two in a separate

@@ -33,6 +33,7 @@ class ConvDesc(ctypes.Structure):
         ("D1", ctypes.c_int32),
         ("out_reduce2", ctypes.c_int32),
         ("out_d2s", ctypes.c_int32),
+        ("in_s2d", ctypes.c_int32),
     ]
 
 

@@ -37,6 +37,7 @@ int check_desc(const rd_conv_desc* d) {
   if (d->upsample && (d->H1 <= 0 || d->W1 <= 0)) return fail("conv: upsample needs H1/W1");
   if (d->D1 <= 0 || d->D1 > d->Cout) return fail("conv: bad D1");
   if (d->out_d2s && (d->Cout != 4 * d->D1 || d->out_reduce2 || d->upsample)) return fail("conv: out_d2s needs Cout = 4 x D1, no upsample flag, no out_reduce2");
+  if (d->in_s2d && ((d->C1 & 3) || d->C2 || d->upsample || d->out_d2s || d->out_reduce2)) return fail("conv: in_s2d needs C1 = 4 x channels, one source, no upsample / out_d2s / out_reduce2");
   if ((int64_t)d->N * d->OH * d->OW >= (int64_t)1 << 31) return fail("conv: too many output pixels");
   return 0;
 }
@@ -54,6 +55,7 @@ void fill_args(const rd_conv_desc* d, rd::ConvArgs& a) {
   a.Kpad = RD_NS(d->dtype, conv_kpad)(a.K, RD_DT(d->dtype));
   a.pool2 = d->out_reduce2 ? 1 : 0;
   a.d2s = d->out_d2s ? 1 : 0;
+  a.s2d = d->in_s2d ? 1 : 0;
 }
 }  // namespace
 
@@ -102,7 +104,7 @@ int64_t rd_conv_packed_elems(int32_t rows, int32_t K, int32_t dtype) {
 int rd_conv_pack_weights(const float* w, void* packed, int32_t Cout, int32_t Cin, int32_t KH, int32_t KW, int32_t mode,
                          int32_t dtype, void* stream) {
   if (!w || !packed) return fail("pack_weights: null pointer");
-  if (!dt_ok(dtype) || mode < 0 || mode > 2 || (mode == 2 && (KH != 3 || KW != 3))) return fail("pack_weights: bad dtype/mode");
+  if (!dt_ok(dtype) || mode < 0 || mode > 3 || (mode >= 2 && (KH != 3 || KW != 3))) return fail("pack_weights: bad dtype/mode");
   RD_NS(dtype, launch_pack_weights)(w, packed, Cout, Cin, KH, KW, mode, RD_DT(dtype), S(stream), 0);
   return done("rd_conv_pack_weights");
 }
@@ -207,6 +209,13 @@ int32_t rd_conv_up2_ok(const rd_conv_desc* d) {
   return RD_NS(d->dtype, conv_d2s_ok)(a, RD_DT(d->dtype)) ? 1 : 0;
 }
 
+int32_t rd_conv_up2_dgrad_ok(const rd_conv_desc* d) {
+  if (!d || check_desc(d) || (d->C1 & 3) || d->C2 || d->upsample || d->out_d2s || d->out_reduce2 || d->D1 != d->Cout) return 0;
+  rd::ConvArgs a; fill_args(d, a);
+  a.s2d = 1;
+  return RD_NS(d->dtype, conv_s2d_ok)(a, RD_DT(d->dtype)) ? 1 : 0;
+}
+
 int32_t rd_conv_fwd_streams(const rd_conv_desc* d) {
   if (!d || check_desc(d)) return 0;
   rd::ConvArgs a; fill_args(d, a);
@@ -221,6 +230,8 @@ int rd_conv_fwd(const rd_conv_desc* d, const void* src1, const void* src2, const
   if (d->D1 < d->Cout && !dst2 && !d->out_d2s) return fail("conv_fwd: D1 < Cout but dst2 is null");
   rd::ConvArgs a; fill_args(d, a);
   a.src1 = src1; a.src2 = src2; a.w = w_packed; a.bias = bias; a.dst1 = dst1; a.dst2 = dst2; a.stats = stats;
+  if (a.s2d && (dst2 || bias || stats || d->act != RD_ACT_NONE || !rd_conv_up2_dgrad_ok(d)))
+    return fail("conv_fwd: in_s2d is not available for this descriptor / with a bias, an activation, statistics or a second destination (see rd_conv_up2_dgrad_ok)");
   if (a.d2s && (dst2 || bias || d->act != RD_ACT_NONE || !rd_conv_up2_ok(d)))
     return fail("conv_fwd: out_d2s is not available for this descriptor / with a bias, an activation or a second destination (see rd_conv_up2_ok)");
   if (a.pool2 && (stats || bias || d->act != RD_ACT_NONE || !rd_conv_out_reduce2_ok(d)))      // (a bias would be added once to the 2x2 sum instead of four times)
@@ -229,7 +240,7 @@ int rd_conv_fwd(const rd_conv_desc* d, const void* src1, const void* src2, const
   return done("rd_conv_fwd");
 }
 int32_t rd_conv_add_ok(const rd_conv_desc* d) {
-  if (!d || check_desc(d) || d->D1 != d->Cout || d->out_reduce2 || d->out_d2s) return 0;
+  if (!d || check_desc(d) || d->D1 != d->Cout || d->out_reduce2 || d->out_d2s || d->in_s2d) return 0;
   rd::ConvArgs a; fill_args(d, a);
   return RD_NS(d->dtype, conv_add_ok)(a, RD_DT(d->dtype)) ? 1 : 0;
 }
@@ -269,7 +280,7 @@ int rd_conv_fwd_fused(const rd_conv_desc* d, const rd_conv_fusion* f, const void
   if (int e = check_desc(d)) return e;
   if (!src1 || !w_packed || !dst1) return fail("conv_fwd_fused: null pointer");
   if (d->C2 > 0 && !src2) return fail("conv_fwd_fused: C2 > 0 but src2 is null");
-  if (d->out_d2s) return fail("conv_fwd_fused: out_d2s has no fused form");
+  if (d->out_d2s || d->in_s2d) return fail("conv_fwd_fused: out_d2s / in_s2d have no fused form");
   if (d->D1 < d->Cout && !dst2) return fail("conv_fwd_fused: D1 < Cout but dst2 is null");
   if (addend && !rd_conv_add_ok(d)) return fail("conv_fwd_fused: an addend is not available for this descriptor (see rd_conv_add_ok)");
   rd::ConvArgs a; fill_args(d, a);

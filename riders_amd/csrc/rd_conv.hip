@@ -320,7 +320,7 @@ template <typename T>
 __global__ void pack_weights_kernel(const float* __restrict__ w, T* __restrict__ out, int Cout, int Cin, int KH,
                                     int KW, int mode, int rows_pad, int Kpad, int CinSrc) {
   int64_t total = (int64_t)rows_pad * Kpad;
-  int rows = mode == 2 ? 4 * Cout : (mode ? Cin : Cout), C = mode == 1 ? Cout : Cin;
+  int rows = mode == 2 ? 4 * Cout : (mode ? Cin : Cout), C = mode == 3 ? 4 * Cout : (mode == 1 ? Cout : Cin);
   int K = KH * KW * C;
   const bool frag = pack_has_frag(KH, KW, C, sizeof(T) == 4 ? 0 : 1);
   const bool tokfrag = KH == 1 && KW == 1 && pack_has_tokfrag(rows, K);      // rows_pad == rows, Kpad == K at these sizes
@@ -332,6 +332,7 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, T* __restrict__
       // CinSrc < Cin: the packed layout carries zero-padded input channels (3-channel stems run on the 16-byte-vector paths)
       if (mode == 0) v = c < CinSrc ? w[(((int64_t)row * CinSrc + c) * KH + kh) * KW + kw] : 0.f;
       else if (mode == 2) v = pack_up2_value(w, Cout, Cin, row, c, kh, kw);
+      else if (mode == 3) v = pack_up2_value(w, Cout, Cin, c, row, 2 - kh, 2 - kw);      // (class, channel) column c of the flipped tap, input channel = row
       else v = w[(((int64_t)c * Cin + row) * KH + (KH - 1 - kh)) * KW + (KW - 1 - kw)];
     }
     Elem<T>::st(&out[i], v);
@@ -344,7 +345,7 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, T* __restrict__
 struct PackItem { const float* w; void* out; int Cout, Cin, KH, KW, mode, dtype, CinSrc, pad_; };
 template <typename T>
 __device__ __forceinline__ void pack_one(const PackItem& it, int bx, int nbx) {
-  const int rows = it.mode == 2 ? 4 * it.Cout : (it.mode ? it.Cin : it.Cout), C = it.mode == 1 ? it.Cout : it.Cin;
+  const int rows = it.mode == 2 ? 4 * it.Cout : (it.mode ? it.Cin : it.Cout), C = it.mode == 3 ? 4 * it.Cout : (it.mode == 1 ? it.Cout : it.Cin);
   const int K = it.KH * it.KW * C;
   const int bn = rows <= 16 ? 16 : (rows <= 32 ? 32 : (rows <= 64 ? 64 : 128));
   const int rows_pad = (rows + bn - 1) / bn * bn;
@@ -370,6 +371,7 @@ __device__ __forceinline__ void pack_one(const PackItem& it, int bx, int nbx) {
     if (row < rows && k < K) {
       if (it.mode == 0) v = c < cs ? it.w[(((int64_t)row * cs + c) * it.KH + kh) * it.KW + kw] : 0.f;
       else if (it.mode == 2) v = pack_up2_value(it.w, it.Cout, it.Cin, row, c, kh, kw);
+      else if (it.mode == 3) v = pack_up2_value(it.w, it.Cout, it.Cin, c, row, 2 - kh, 2 - kw);
       else v = it.w[(((int64_t)c * it.Cin + row) * it.KH + (it.KH - 1 - kh)) * it.KW + (it.KW - 1 - kw)];
     }
     Elem<T>::st(&out[i], v);
@@ -1260,6 +1262,7 @@ static void launch_conv_stem(const ConvArgs& a, int dtype, hipStream_t st) {
 }
 
 void launch_conv(const ConvArgs& a, int dtype, hipStream_t st) {
+  if (a.s2d) { launch_conv3x3_frag(a, dtype, st); return; }      // (rd_api.cpp checked conv_s2d_ok)
   if (a.d2s) { if (conv_d2s_small(a, dtype)) launch_conv3x3_small(a, dtype, st); else launch_conv3x3_frag(a, dtype, st); return; }      // (rd_api.cpp checked conv_d2s_ok)
   if (conv_skinny_ok(a, dtype)) { launch_linear_skinny(a, dtype, st); return; }
   if (conv_stem_ok(a, dtype)) { launch_conv_stem(a, dtype, st); return; }
@@ -1288,6 +1291,11 @@ static bool conv_d2s_small(const ConvArgs& a, int dtype) {
 bool conv_d2s_ok(const ConvArgs& a, int dtype) {
   if (a.ups || a.pool2 || a.bias || a.act != ACT_NONE || a.in_scale || a.add1 || a.Cout != 4 * a.D1) return false;
   return conv_d2s_small(a, dtype) || conv3x3_frag_d2s_ok(a, dtype);      // (launch_conv sends a d2s descriptor straight to that kernel, whatever its tile count)
+}
+// in_s2d (ConvArgs::s2d): the register-fed kernel's S2D instantiations
+bool conv_s2d_ok(const ConvArgs& a, int dtype) {
+  if (a.ups || a.pool2 || a.d2s || a.bias || a.act != ACT_NONE || a.in_scale || a.add1 || a.C2 || a.D1 != a.Cout || a.stats) return false;
+  return conv3x3_frag_s2d_ok(a, dtype);
 }
 // ConvArgs::add1: the kernels that store through conv_epilogue_store except the narrow-layer one (not the few-channel / single-channel
 // streaming kernels, not the experimental LDS-DMA kernel), one destination, no 2x2 reduction
@@ -1322,6 +1330,7 @@ const char* conv_kernel_name(const ConvArgs& a, int dtype) {
   if (conv_few_ok(a)) return "conv_few_kernel";
   if (conv1x1_direct_ok(a, dtype)) return "conv1x1_direct_kernel";
   if (conv3x3_c1_ok(a)) return "conv3x3_c1_kernel";
+  if (a.s2d) return conv3x3_frag_name(a, dtype);
   if (a.d2s) return conv_d2s_small(a, dtype) ? conv3x3_small_name(a, dtype) : conv3x3_frag_name(a, dtype);
   if (use_conv3x3_small(a, dtype)) return conv3x3_small_name(a, dtype);
   if (use_conv3x3_frag(a, dtype)) return conv3x3_frag_name(a, dtype);
@@ -1341,7 +1350,7 @@ const char* conv_kernel_name(const ConvArgs& a, int dtype) {
 void launch_pack_weights(const float* w, void* out, int Cout, int Cin, int KH, int KW, int mode, int dtype,
                          hipStream_t st, int CinSrc) {
   if (CinSrc <= 0) CinSrc = Cin;
-  int rows = mode == 2 ? 4 * Cout : (mode ? Cin : Cout), C = mode == 1 ? Cout : Cin;
+  int rows = mode == 2 ? 4 * Cout : (mode ? Cin : Cout), C = mode == 3 ? 4 * Cout : (mode == 1 ? Cout : Cin);
   int rows_pad = conv_rows_pad(rows), Kpad = conv_kpad(KH * KW * C, dtype);
   int64_t total = (int64_t)rows_pad * Kpad;
   unsigned grid = (unsigned)std::min<int64_t>(cdiv(total, 256), 4096);

@@ -52,9 +52,13 @@ constexpr int frag_pmax(int tp) { return tp <= 128 ? 256 : (tp <= 256 ? 384 : 64
 // D2S: the forward of an exact-2x up-sampling layer on its SOURCE (ConvArgs::d2s, pack mode 2; see conv3x3_small_kernel): the wave's 32 output
 // channels belong to ONE parity class (a, b) (D1 % 32 == 0), so the wave runs only that class's four taps (a + {0, 1}, b + {0, 1}) per chunk -- their
 // fragments alone are fetched -- and stores its tile at output pixel (2 i + a, 2 j + b), channels relative to the class.
-template <typename T, int NPT, int WPX, int WCH, bool LIN, bool MULTI, bool AFF = false, bool D2S = false>
+// S2D: the data gradient of the same layer on the source (ConvArgs::s2d, pack mode 3): src1 is the layer's output gradient at (2 Hin) x (2 Win) x Cr,
+// staged as Hin x Win x 4 Cr = (parity class, channel) channels (space to depth: a 16-byte slot's class picks one of the pixel's 2x2 block); the
+// 32-channel k-halves whose classes do not use a tap are skipped (class (a, b) uses the flipped taps kr in {1 - a, 2 - a}, kc in {1 - b, 2 - b}).
+template <typename T, int NPT, int WPX, int WCH, bool LIN, bool MULTI, bool AFF = false, bool D2S = false, bool S2D = false>
 __global__ __launch_bounds__(64 * WPX * WCH, (WPX * WCH == 8 && WCH == 4) ? 4 : ((WPX * WCH == 8 || NPT == 8 || (MULTI && WCH == 1)) ? 2 : 3)) void conv3x3_frag_kernel(ConvArgs a, FragGeom g) {
   static_assert(!D2S || !AFF, "D2S has no consumer-side BatchNorm apply");
+  static_assert(!S2D || (!AFF && !D2S && sizeof(T) == 2), "S2D: 16-bit activations, plain source");
   constexpr int NW = WPX * WCH, NT = 64 * NW;
   constexpr int VE = Elem<T>::VE;
   constexpr int CKE = STAGE_BYTES / (int)sizeof(T);   // channels per chunk (128 bytes per pixel)
@@ -114,7 +118,7 @@ __global__ __launch_bounds__(64 * WPX * WCH, (WPX * WCH == 8 && WCH == 4) ? 4 : 
         hs = min((int)floorf((float)ih * a.scale_h), a.H1 - 1);
         ws = min((int)floorf((float)iw * a.scale_w), a.W1 - 1);
       }
-      pix = (n * Hp + hs) * Wp + ws;
+      pix = S2D ? (n * 2 * Hp + 2 * hs) * (2 * Wp) + 2 * ws : (n * Hp + hs) * Wp + ws;      // S2D: pixel (2 i, 2 j) of the (2 H) x (2 W) tensor
     }
     spix[i] = pix;
   }
@@ -128,7 +132,12 @@ __global__ __launch_bounds__(64 * WPX * WCH, (WPX * WCH == 8 && WCH == 4) ? 4 : 
     const T* cbp = first ? (const T*)a.src1 + ci : (const T*)a.src2 + (ci - a.C1);
     const int cs = first ? a.C1 : a.C2;
     const int px = last ? 0 : max(spix[i], 0);
-    const uint4 v = *reinterpret_cast<const uint4*>((last ? (const T*)a.src1 : cbp) + (int64_t)px * cs);
+    uint4 v;
+    if (S2D) {      // channel slot ci = (class, channel): the class selects the pixel of the 2x2 block, the tensor has cr = C1 / 4 channels
+      const int cr = a.C1 >> 2, cls = ci / cr, co = ci - cls * cr;
+      v = *reinterpret_cast<const uint4*>((const T*)a.src1 + (last ? 0 : (int64_t)(px + (cls >> 1) * 2 * Wp + (cls & 1)) * cr + co));
+    } else
+    v = *reinterpret_cast<const uint4*>((last ? (const T*)a.src1 : cbp) + (int64_t)px * cs);
     rp[i] = spix[i] < 0 ? make_uint4(0, 0, 0, 0) : v;
   };
   const int st_base = ((t & 7) >> 1) * PS + (t & 1) * 16 + (t >> 3) * 32;    // plane (slot >> 1), 16-byte column (slot & 1), pixel t >> 3
@@ -201,6 +210,16 @@ __global__ __launch_bounds__(64 * WPX * WCH, (WPX * WCH == 8 && WCH == 4) ? 4 : 
   int boff = 0;      // byte offset of the patch buffer the current chunk reads
   // tap: this tap (a compile-time constant at the nine call sites of the plain kernel, a wave-uniform value in D2S); ct_next: the fragment set
   // (chunk * 9 + tap) to request for the next tap_body; pieces [p0, p1) of chunk_next's patch ride behind it
+  // S2D: does k-half kh (32 channels from chunk * 64 + 32 kh) of this chunk hold a class that uses flipped tap (kr, kc)?  (block uniform)
+  auto s2d_used = [&](int chunk, int kh, int kr, int kc) RD_INLINE_LAMBDA {
+    const int cr = a.C1 >> 2, k0 = chunk * CKE + kh * (CKE / 2), c0 = k0 / cr, c1 = (k0 + CKE / 2 - 1) / cr;
+    bool u = false;
+    for (int c = c0; c <= c1; c++) {
+      const int ca_ = c >> 1, cb_ = c & 1;
+      u = u || ((kr == 1 - ca_ || kr == 2 - ca_) && (kc == 1 - cb_ || kc == 2 - cb_));
+    }
+    return u;
+  };
   auto tap_body = [&](int tap, int ct_next, int chunk_next, int p0, int p1, uint4 (&wcur)[2][2], uint4 (&wnxt)[2][2]) RD_INLINE_LAMBDA {
     load_w(ct_next, wnxt);
     if (MULTI) {
@@ -214,6 +233,7 @@ __global__ __launch_bounds__(64 * WPX * WCH, (WPX * WCH == 8 && WCH == 4) ? 4 : 
     const int toff = D2S ? (kr * (LIN ? WT : 18) + kc) * 32 : 0;      // (run-time tap: one scalar offset instead of immediates)
 #pragma unroll
     for (int kh = 0; kh < 2; kh++) {
+      if (S2D && !s2d_used(chunk_next - 1, kh, kr, kc)) continue;      // structurally zero block of the K axis
       uint4 pf[NPT];
 #pragma unroll
       for (int pt = 0; pt < NPT; pt++)
@@ -607,6 +627,11 @@ bool conv3x3_frag_d2s_ok(const ConvArgs& a, int dtype) {
   return dtype != 0 && a.C2 == 0 && !a.ups && !a.in_scale && a.Cout == 4 * a.D1 && (a.D1 % 32) == 0 && rd_opt(OPT_CONV3X3_FRAG, 1) && frag_plan(a, dtype, p) &&
          p.v32 == 0 && p.variant <= 2;
 }
+// ConvArgs::s2d on this kernel: 16-bit builds, whole 128-byte chunks of the 4 Cr (class, channel) axis, classes of 16 channels or more
+bool conv3x3_frag_s2d_ok(const ConvArgs& a, int dtype) {
+  FragPlan p;
+  return dtype != 0 && a.C2 == 0 && !a.ups && !a.in_scale && (a.C1 & 3) == 0 && ((a.C1 >> 2) % 16) == 0 && rd_opt(OPT_CONV3X3_FRAG, 1) && frag_plan(a, dtype, p) && p.v32 == 0;
+}
 bool conv3x3_frag_is32(const ConvArgs& a, int dtype) { FragPlan p; return frag_plan(a, dtype, p) && p.v32 != 0; }
 int conv3x3_frag_tiles(const ConvArgs& a, int dtype) { FragPlan p; frag_plan(a, dtype, p); return p.ntiles; }
 int conv3x3_frag_blocks(const ConvArgs& a, int dtype) { FragPlan p; frag_plan(a, dtype, p); return p.ntiles * p.ncb; }
@@ -622,7 +647,9 @@ const char* conv3x3_frag_name(const ConvArgs& a, int dtype) {
     snprintf(buf, sizeof(buf), "conv3x3_frag32_kernel<%s, %d, %d, %d, %d, %s>", RD_T16_NAME, w.nq, w.wpx, w.wch, w.cw, multi ? "true" : "false");
     return buf;
   }
-  if (a.d2s) snprintf(buf, sizeof(buf), "conv3x3_frag_kernel<%s, %d, %d, %d, %s, %s, false, true>", RD_T16_NAME, npt[p.variant], wpx[p.variant], wch[p.variant],
+  if (a.s2d) snprintf(buf, sizeof(buf), "conv3x3_frag_kernel<%s, %d, %d, %d, %s, %s, false, false, true>", RD_T16_NAME, npt[p.variant], wpx[p.variant], wch[p.variant],
+                      p.lin ? "true" : "false", multi ? "true" : "false");
+  else if (a.d2s) snprintf(buf, sizeof(buf), "conv3x3_frag_kernel<%s, %d, %d, %d, %s, %s, false, true>", RD_T16_NAME, npt[p.variant], wpx[p.variant], wch[p.variant],
                       p.lin ? "true" : "false", multi ? "true" : "false");
   else
   snprintf(buf, sizeof(buf), "conv3x3_frag_kernel<%s, %d, %d, %d, %s, %s, %s>", dtype == 0 ? "float" : RD_T16_NAME, npt[p.variant], wpx[p.variant],
@@ -646,6 +673,15 @@ static void launch_frag_v(const ConvArgs& a, const FragPlan& p, const FragGeom& 
 #define RD_FR(LINV, MULTIV)                                                                                                         \
   { if (aff) hipLaunchKernelGGL((conv3x3_frag_kernel<T, NPT, WPX, WCH, LINV, MULTIV, true>), grid, block, lds, st, a, g);          \
     else hipLaunchKernelGGL((conv3x3_frag_kernel<T, NPT, WPX, WCH, LINV, MULTIV>), grid, block, lds, st, a, g); }
+  if (a.s2d) {      // conv3x3_frag_s2d_ok: 16-bit, plain source
+    if constexpr (sizeof(T) == 2) {
+#define RD_FRS(LINV, MULTIV) hipLaunchKernelGGL((conv3x3_frag_kernel<T, NPT, WPX, WCH, LINV, MULTIV, false, false, true>), grid, block, lds, st, a, g);
+      if (p.lin) { if (multi) RD_FRS(true, true) else RD_FRS(true, false) }
+      else { if (multi) RD_FRS(false, true) else RD_FRS(false, false) }
+#undef RD_FRS
+    }
+    return;
+  }
   if (a.d2s) {      // conv3x3_frag_d2s_ok: 16-bit, the > 64-channel block shapes (variants 0-2), no consumer-side BatchNorm apply
     if constexpr (sizeof(T) == 2 && WCH >= 2 && NPT * WPX == 8) {
 #define RD_FRD(LINV, MULTIV) hipLaunchKernelGGL((conv3x3_frag_kernel<T, NPT, WPX, WCH, LINV, MULTIV, false, true>), grid, block, lds, st, a, g);

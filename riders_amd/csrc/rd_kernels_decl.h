@@ -15,6 +15,7 @@ void launch_conv(const ConvArgs& a, int dtype, hipStream_t st);
 const char* conv_kernel_name(const ConvArgs& a, int dtype);
 bool conv_pool2_ok(const ConvArgs& a, int dtype);
 bool conv_d2s_ok(const ConvArgs& a, int dtype);
+bool conv_s2d_ok(const ConvArgs& a, int dtype);
 bool conv_add_ok(const ConvArgs& a, int dtype);
 bool conv_in_affine_ok(const ConvArgs& a, int dtype);
 bool conv_bn_bwd_ok(const ConvArgs& a, int dtype);
@@ -37,6 +38,7 @@ bool conv3x3_frag_ok(const ConvArgs& a, int dtype);
 int conv3x3_frag_tiles(const ConvArgs& a, int dtype);
 bool conv3x3_frag_is32(const ConvArgs& a, int dtype);
 bool conv3x3_frag_d2s_ok(const ConvArgs& a, int dtype);
+bool conv3x3_frag_s2d_ok(const ConvArgs& a, int dtype);
 int conv3x3_frag_blocks(const ConvArgs& a, int dtype);
 void launch_conv3x3_frag(const ConvArgs& a, int dtype, hipStream_t st);
 const char* conv3x3_frag_name(const ConvArgs& a, int dtype);

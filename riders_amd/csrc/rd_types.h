@@ -12,6 +12,7 @@ struct ConvArgs {
   int N, Hin, Win, C1, C2, H1, W1, Cout, KH, KW, stride, pad, dil, OH, OW, act, D1;
   float slope, scale_h, scale_w;
   int M, K, Kpad, ups;
+  int s2d;     // data gradient of the same layer on the source: src1 is read space-to-depth, C1 = 4 classes x (C1 / 4) channels (rd_conv_desc.in_s2d)
   int d2s;     // forward of an exact 2x nearest up-sampling 3x3 layer computed on the source: Cout = 4 classes x D1 channels, depth-to-space store (rd_conv_desc.out_d2s)
   int pool2;   // data gradient of an exact 2x nearest up-sampling layer: 2x2 output blocks are summed and stored at half resolution
   const void* add1;   // optional [M][Cout] tensor added to the result before rounding (a gradient's earlier contribution); D1 == Cout only

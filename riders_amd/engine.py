@@ -34,6 +34,7 @@ _state = {"dtype": RD_F32, "tape": None, "defer_wgrad": True, "fused_loftr": Tru
           # conv2 staging, conv2 -> fused apply + add + activation: measured faster); 2: also the decoder chain (measured SLOWER on MI355X:
           # the 3x3 kernels are vector-issue bound and the staging arithmetic costs more than the HBM pass it replaces -- DESIGN.md)
           "lazy_bn": 1,
+          "up2_dgrad": True,       # ... and its data gradient at source resolution from the space-to-depth view of dy (rd_conv_desc.in_s2d)
           "up2_on_source": True,   # forward of an exact-2x UpConv2d as a 3x3 convolution of the SOURCE with per-parity-class pre-summed weights (rd_conv_desc.out_d2s)
           "bn_head": True,    # conv -> BatchNorm -> act -> one-channel 3x3 output convolution: the fused decoder-head kernels (rd_bn_head_*)
           # (round 4 measured two concurrency experiments SLOWER on MI355X / ROCm 7 and round 5 removed them from the product: convolution weight
@@ -51,7 +52,7 @@ _state = {"dtype": RD_F32, "tape": None, "defer_wgrad": True, "fused_loftr": Tru
           "bn_bwd_fused": False,
           "dw_fused_stats": True}          # depthwise convolution with the BatchNorm statistics in its epilogue; False: separate rd_bn_stats pass
 
-_SWITCHES = {"fuse_upsample_bwd": bool, "loftr_cross_inplace": bool, "fuse_res_add": bool, "fuse_grad_add": bool, "lazy_bn": (0, 2), "bn_head": bool, "up2_on_source": bool, "roi_u8": bool,
+_SWITCHES = {"fuse_upsample_bwd": bool, "loftr_cross_inplace": bool, "fuse_res_add": bool, "fuse_grad_add": bool, "lazy_bn": (0, 2), "bn_head": bool, "up2_on_source": bool, "up2_dgrad": bool, "roi_u8": bool,
              "roi_bwd": ("auto", "gather", "tile", "atomic"), "bn_recompute": bool, "bn_bwd_fused": bool, "dw_fused_stats": bool, "roi_tile_min_blocks": (0, 1 << 30),
              "defer_wgrad": bool, "fused_loftr": bool, "deterministic_roi_pool": bool}
 
@@ -96,7 +97,7 @@ def apply_opts(spec):
 
 
 # how often a virtual activation was consumed in place / had to be written after all (tests assert that the fused routes are taken)
-lazy_counts = {"fwd_fused": 0, "wgrad_fused": 0, "add_fused": 0, "materialized": 0, "bn_bwd_fused": 0, "head_fused": 0, "head_unfused_bwd": 0, "up2_fwd": 0}
+lazy_counts = {"fwd_fused": 0, "wgrad_fused": 0, "add_fused": 0, "materialized": 0, "bn_bwd_fused": 0, "head_fused": 0, "head_unfused_bwd": 0, "up2_fwd": 0, "up2_dgrad": 0}
 
 
 def head_route(C):
@@ -708,7 +709,7 @@ def packed_weight(w, mode, dt, cin_pad=0):
         assert mode == 0 and cin_pad >= cin
         n = L().rd_conv_packed_elems(cout, kh * kw * cin_pad, dt)
     else:
-        rows, c = (4 * cout, cin) if mode == 2 else ((cin, cout) if mode else (cout, cin))
+        rows, c = (4 * cout, cin) if mode == 2 else ((cin, 4 * cout) if mode == 3 else ((cin, cout) if mode else (cout, cin)))
         n = L().rd_conv_packed_elems(rows, kh * kw * c, dt)
     buf = hit[1] if (hit is not None and hit[1].numel() == n and hit[1].device == w.device) else torch.empty(n, dtype=_TORCH_DT[dt], device=w.device)
     if cin_pad:
@@ -1167,6 +1168,21 @@ def conv_block(x, weight, *, x2=None, bias=None, stride=1, pad=None, up=None, bn
             dd = _desc(dt, N, OH, OW, Cout, 0, False, OH, OW, Cin_d, KH, KW, 1, KH - 1 - pad, stride, Hin, Win, ACT_NONE, 0.0, C1_d)
             # exact 2x nearest up-sampling (UpConv2d at 120x50 -> 240x100 ...): the kernel sums the 2x2 blocks of its output tile and stores the
             # gradient at SOURCE resolution; the full-resolution tensor and the upsample_nearest_bwd pass over it disappear
+            if (is_up and C2 == 0 and (Hin, Win) == (2 * H1, 2 * W1) and KH == 3 and KW == 3 and stride == 1 and pad == 1 and not cin_pad
+                    and _state["up2_dgrad"]):
+                # the data gradient of the exact-2x layer ON ITS SOURCE: a 3x3 convolution of dy viewed space-to-depth (4 Cout (class, channel) channels
+                # per source pixel) with the transposed per-class kernels; structurally zero K blocks skipped; no 2x2 reduction pass
+                dd2 = _desc(dt, N, H1, W1, 4 * Cout, 0, False, H1, W1, C1, 3, 3, 1, 1, 1, H1, W1, ACT_NONE, 0.0, C1)
+                dd2.in_s2d = 1
+                if lib.rd_conv_up2_dgrad_ok(ctypes.byref(dd2)):
+                    lazy_counts["up2_dgrad"] += 1
+                    g1 = torch.empty_like(x)
+                    wp3 = packed_weight(weight, 3, dt)
+                    _chk(_timed("conv_gemm", flops * 4.0 / 9.0, lambda: lib.rd_conv_fwd(ctypes.byref(dd2), _p(dy), None, _p(wp3), None, _p(g1), None, None, st),
+                                "dgrad " + shp + " (on source)", b_out + b_w + g1.numel() * es,
+                                kernel=lambda: lib.rd_conv_fwd_kernel_name(ctypes.byref(dd2)).decode(), idem=True), "rd_conv_fwd(dgrad, in_s2d)")
+                    t.add_grad(xk, g1)
+                    return
             fused_up = False
             if is_up and C2 == 0 and (Hin, Win) == (2 * H1, 2 * W1) and _state.get("fuse_upsample_bwd", True):
                 dd.out_reduce2 = 1

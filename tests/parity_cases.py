@@ -726,6 +726,7 @@ def up2_cases(dev, quick=False):
             bf16_exact_conv_case(dev, cin=128, cout=32, k=3, s=1, N=3, up=((15, 6), (30, 12)))
             bf16_exact_conv_case(dev, cin=256, cout=128, k=3, s=1, N=1, up=((7, 3), (14, 6)))
     assert engine.lazy_counts["up2_fwd"] - n0 == (3 if quick else 6), engine.lazy_counts
+    assert engine.lazy_counts["up2_dgrad"] == engine.lazy_counts["up2_fwd"], engine.lazy_counts      # every one of them also ran its data gradient on the source
     with bf16_mode("bf16"):
         shapes = [(2, 32, 7, 9)] if quick else [(2, 32, 7, 9), (3, 32, 24, 10)]
         for shape in shapes:
@@ -735,6 +736,7 @@ def up2_cases(dev, quick=False):
             res = {}
             for on in (False, True):
                 engine.set_switch("up2_on_source", on)
+                engine.set_switch("up2_dgrad", on)
                 try:
                     for k in engine.lazy_counts:
                         engine.lazy_counts[k] = 0
@@ -742,6 +744,7 @@ def up2_cases(dev, quick=False):
                     n = engine.lazy_counts["up2_fwd"]
                 finally:
                     engine.set_switch("up2_on_source", True)
+                    engine.set_switch("up2_dgrad", True)
                 assert n == (1 if on else 0), (shape, on, n)
             close(res[True][0], res[False][0], 2e-2, "up-convolution on its source, output %s" % (shape,))
             close_l2(res[True][0], res[False][0], 5e-3, "up-convolution on its source, output %s" % (shape,))
@@ -1618,6 +1621,8 @@ def pack_batch_case(dev):
         bufs.append(engine.packed_weight(ws[2], 0, dt, 8))      # 3-channel stem zero-padded to one 16-byte vector
         bufs.append(engine.packed_weight(ws[0], 2, dt))         # exact-2x up-convolution on its source: four parity classes of pre-summed taps
         bufs.append(engine.packed_weight(ws[7], 2, dt))
+        bufs.append(engine.packed_weight(ws[0], 3, dt))         # ... and its data-gradient operand
+        bufs.append(engine.packed_weight(ws[7], 3, dt))
     want = [b.clone() for b in bufs]
     for b in bufs:
         b.zero_()
