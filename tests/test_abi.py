@@ -27,9 +27,9 @@ def test_library_exports_every_declared_symbol():
 
 
 def test_conv_desc_matches_c_layout():
-    # 21 x 4-byte fields, no padding; the field names and order are those of the C struct in include/riders_hip.h
+    # 23 x 4-byte fields, no padding; the field names and order are those of the C struct in include/riders_hip.h
     import re
-    assert ctypes.sizeof(_lib.ConvDesc) == 84
+    assert ctypes.sizeof(_lib.ConvDesc) == 92
     src = open(_lib.HEADER).read()
     body = re.search(r"typedef struct rd_conv_desc\s*\{(.*?)\}\s*rd_conv_desc;", src, flags=re.S).group(1)
     body = re.sub(r"/\*.*?\*/", " ", body, flags=re.S)
