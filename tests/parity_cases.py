@@ -1484,6 +1484,59 @@ def rcnet_fullsize_bf16_oracle_case(dev, tol_logits=8e-2, tol_grad=0.30):
     assert not bad, "bf16 HIP path vs the bf16-emulating oracle: " + "; ".join(bad)
 
 
+def rcnet_round5_routes_case(dev, tol_logits=3e-2, tol_l2=2e-2, tol_grad=0.10, min_cos=0.995):
+    """Round 5's structural routes END TO END on the driver-timed mode: configs[1] geometry at full size on one image (R = 30 RoIs), bf16, the fused
+    decoder head (bn_head) and the exact-2x up-convolutions on their source (up2_on_source, up2_dgrad) all ON against all OFF -- the same
+    model, batch and seed.  What differs between the two: fp32 summation orders, dy of the head's BatchNorm from two fused multiply-adds, the
+    pre-summed up-convolution weights rounded to bf16 once more, and the rounding-boundary / LeakyReLU-slope flips these cause downstream.
+    Measured on MI355X (printed by the test): logits max-norm 1.5e-2, relative L2 1.1e-2; gradients: decoder 0.44 % relative L2 (cosine 0.99999),
+    image encoder 2.9 %, transformer 5.4 % (0.9987), point MLP 5.1 % (0.9988) -- a quarter of what separates either from the rounding-point oracle
+    (rcnet_fullsize_bf16_oracle_case).  Bounds: logits 3e-2 of max and 2e-2 relative L2, loss 2e-3, per-module gradient vectors 10 % relative L2
+    with cosine > 0.995; and every route IS taken in the ON run (engine.lazy_counts)."""
+    from riders_amd import engine, rcnet_main
+    cfg = rcnet_main.ZJU_CONFIG
+    batch = rcnet_main.synthetic_batch(1, 256, 512, cfg, seed=79)
+    res = {}
+    with bf16_mode():
+        for on in (False, True):
+            for sw in ("bn_head", "up2_on_source", "up2_dgrad"):
+                engine.set_switch(sw, on)
+            try:
+                for k in engine.lazy_counts:
+                    engine.lazy_counts[k] = 0
+                torch.manual_seed(0)
+                model = rcnet_main.build_model(dev, cfg)
+                model.train()
+                image, pts, rois, gt = rcnet_main.prepare_batch(tuple(b.to(dev) for b in batch))
+                label, valid = engine.rcnet_labels(gt, pts, 0.5)
+                logits = model.forward(image, pts, rois)
+                loss, _ = model.compute_loss(logits, label, valid, 2.5)
+                loss.backward()
+                res[on] = (logits.detach().float().cpu(), float(loss), _module_grads(model), dict(engine.lazy_counts))
+            finally:
+                for sw in ("bn_head", "up2_on_source", "up2_dgrad"):
+                    engine.set_switch(sw, True)
+    c = res[True][3]
+    assert c["head_fused"] == 1 and c["up2_fwd"] == 3 and c["up2_dgrad"] == 3 and c["head_unfused_bwd"] == 0, c      # deconv0, deconv1, deconv3 are exact 2x
+    c = res[False][3]
+    assert c["head_fused"] == 0 and c["up2_fwd"] == 0 and c["up2_dgrad"] == 0, c
+    a, b = res[True][0], res[False][0]
+    mx, l2 = float((a - b).abs().max() / b.abs().max()), float((a - b).norm() / b.norm())
+    print("round-5 routes on vs off @ full size (bf16): logits max-err %.3e  L2 %.3e  loss %.6f / %.6f" % (mx, l2, res[True][1], res[False][1]))
+    bad = []
+    if not (mx <= tol_logits and l2 <= tol_l2):
+        bad.append("logits max %.3e L2 %.3e" % (mx, l2))
+    if not abs(res[True][1] - res[False][1]) <= 2e-3 * abs(res[False][1]):
+        bad.append("loss %.6f vs %.6f" % (res[True][1], res[False][1]))
+    for name in res[True][2]:
+        g, r = res[True][2][name], res[False][2][name]
+        err, cos = float((g - r).norm() / r.norm()), float(torch.dot(g, r) / (g.norm() * r.norm()))
+        print("round-5 routes on vs off gradient %-14s relative L2 %.3e  cosine %.6f" % (name, err, cos))
+        if not (err <= tol_grad and cos >= min_cos):
+            bad.append("%s gradient: relative L2 %.3e, cosine %.5f" % (name, err, cos))
+    assert not bad, "round-5 routes on vs off: " + "; ".join(bad)
+
+
 def rcnet_config3_rank_case(dev, tol=TOL):
     """configs[3] per-rank geometry (global batch 32 on 8 GPUs = B = 4 per rank, R = 120 RoIs): fp32 logits / loss of the HIP path against
     the oracle within 1e-3, labels exact; then the bf16 graphed training step at that size is finite and bit-reproducible."""

@@ -191,6 +191,10 @@ def test_rcnet_config1_bf16_vs_fp32(gpu):
     P.rcnet_fullsize_bf16_case(gpu)
 
 
+def test_rcnet_round5_routes_on_vs_off(gpu):
+    P.rcnet_round5_routes_case(gpu)
+
+
 def test_rcnet_full_size_bf16_vs_rounding_oracle(gpu):
     P.rcnet_fullsize_bf16_oracle_case(gpu)
 
