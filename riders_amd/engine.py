@@ -34,6 +34,7 @@ _state = {"dtype": RD_F32, "tape": None, "defer_wgrad": True, "fused_loftr": Tru
           # conv2 staging, conv2 -> fused apply + add + activation: measured faster); 2: also the decoder chain (measured SLOWER on MI355X:
           # the 3x3 kernels are vector-issue bound and the staging arithmetic costs more than the HBM pass it replaces -- DESIGN.md)
           "lazy_bn": 1,
+          "fusion_conv_first": True,   # SML FeatureFusionBlock: the 1x1 out_conv before the bilinear x2 (they commute; a quarter of the pixels)
           "up2_dgrad": True,       # ... and its data gradient at source resolution from the space-to-depth view of dy (rd_conv_desc.in_s2d)
           "up2_on_source": True,   # forward of an exact-2x UpConv2d as a 3x3 convolution of the SOURCE with per-parity-class pre-summed weights (rd_conv_desc.out_d2s)
           "bn_head": True,    # conv -> BatchNorm -> act -> one-channel 3x3 output convolution: the fused decoder-head kernels (rd_bn_head_*)
@@ -52,7 +53,7 @@ _state = {"dtype": RD_F32, "tape": None, "defer_wgrad": True, "fused_loftr": Tru
           "bn_bwd_fused": False,
           "dw_fused_stats": True}          # depthwise convolution with the BatchNorm statistics in its epilogue; False: separate rd_bn_stats pass
 
-_SWITCHES = {"fuse_upsample_bwd": bool, "loftr_cross_inplace": bool, "fuse_res_add": bool, "fuse_grad_add": bool, "lazy_bn": (0, 2), "bn_head": bool, "up2_on_source": bool, "up2_dgrad": bool, "roi_u8": bool,
+_SWITCHES = {"fuse_upsample_bwd": bool, "loftr_cross_inplace": bool, "fuse_res_add": bool, "fuse_grad_add": bool, "lazy_bn": (0, 2), "bn_head": bool, "up2_on_source": bool, "up2_dgrad": bool, "fusion_conv_first": bool, "roi_u8": bool,
              "roi_bwd": ("auto", "gather", "tile", "atomic"), "bn_recompute": bool, "bn_bwd_fused": bool, "dw_fused_stats": bool, "roi_tile_min_blocks": (0, 1 << 30),
              "defer_wgrad": bool, "fused_loftr": bool, "deterministic_roi_pool": bool}
 
@@ -104,6 +105,11 @@ def head_route(C):
     """True when a conv -> BatchNorm -> act layer with C output channels whose only consumer is a one-channel 3x3 output convolution should
     hand that consumer a LazyAct (conv_block then takes the fused decoder-head kernels, rd_bn_head_*)."""
     return bool(_state["bn_head"] and _state["lazy_bn"] >= 1 and _state["bn_recompute"] and C == 16)
+
+
+def switch(name):
+    """current value of an engine switch (set_switch)"""
+    return _state[name]
 
 
 def set_lazy_bn(level):

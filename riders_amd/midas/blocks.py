@@ -64,6 +64,13 @@ class FeatureFusionBlock_custom(nn.Module):
             res = self.resConfUnit1._fwd(xs[1])
             output = engine.add_act(output, res, ACT_NONE)
         output = self.resConfUnit2._fwd(output)
+        if engine.switch("fusion_conv_first"):
+            # modules/midas/blocks.py:168-172 up-samples (bilinear x2) and then applies the 1x1 out_conv.  Both are linear and the interpolation
+            # weights of a pixel sum to 1, so they commute exactly (bias included): the convolution runs on a quarter of the pixels and the
+            # interpolation on out_features (= features / 2 when expand) channels.  Same function; in bf16 the rounding points move (the
+            # convolution's output is rounded before the interpolation instead of after).
+            output = engine.conv_block(output, self.out_conv.weight, bias=self.out_conv.bias, pad=0)
+            return engine.bilinear2x(output, self.align_corners)
         output = engine.bilinear2x(output, self.align_corners)
         return engine.conv_block(output, self.out_conv.weight, bias=self.out_conv.bias, pad=0)
 
