@@ -712,6 +712,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # stdout carries ONE line: whatever a library writes to file descriptor 1 during the run (RCCL's five-line version banner at the first
+    # communicator) goes to stderr; the descriptor is restored right in front of the final print
+    sys.stdout.flush()
+    stdout_fd = os.dup(1)
+    os.dup2(2, 1)
     if world != args.gpus:
         sys.stderr.write("bench.py: --gpus %d but WORLD_SIZE=%d: start it as `python bench.py --gpus N` (it spawns its ranks) or under "
                          "torch.distributed.run with --nproc-per-node equal to --gpus\n" % (args.gpus, world))
@@ -797,12 +802,15 @@ def main():
             sys.stderr.write("bench.py: could not write %s: %r\n" % (args.full_json, ex))
         sys.stderr.write("bench.py: full record (%d bytes) -> %s\n" % (len(json.dumps(full)), args.full_json))
         sys.stderr.flush()
-        try:      # C-level stdout first (RCCL prints its version banner through stdio: buffered, it would land BEHIND the line at exit)
+        try:      # C-level stdout first (RCCL prints its version banner through stdio: buffered, it would otherwise land behind the line at exit)
             import ctypes
             ctypes.CDLL(None).fflush(None)
         except Exception:
             pass
+        sys.stdout.flush()
+        os.dup2(stdout_fd, 1)
         print(render_line(line), flush=True)
+        os.dup2(2, 1)      # (communicator teardown may print again)
     if ddp:
         import torch.distributed as dist
         if args.rccl_comm is not None:
