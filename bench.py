@@ -275,7 +275,7 @@ def kernel_roofline(timer, timed_steps, ms_per_step, dtype, traffic_key, conv_on
     return roof
 
 
-def live_traffic(args, kernels, budget_s=100.0):
+def live_traffic(args, kernels, budget_s=45.0):
     """HBM bytes per launch and matrix-pipe busy fraction of the named kernels, measured by THIS run: three rocprofv3 counter passes (FETCH_SIZE;
     WRITE_SIZE; SQ_VALU_MFMA_BUSY_CYCLES + GRBM_GUI_ACTIVE -- separate passes, --kernel-trace only, as MI355X_MICROARCH.md prescribes) of the same
     workload as child processes (3 eager steps each), parsed with the units / gfx950 correction of tools/traffic_aggregate.py and the
@@ -310,6 +310,8 @@ def live_traffic(args, kernels, budget_s=100.0):
                 pr.wait()
                 rc = -1
             found = False
+            if rc != 0 and n < 2:      # a failed / timed-out traffic pass: do not spend another budget on the next one
+                return None
             if rc == 0:
                 for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
                     for row in csv.DictReader(open(f, newline="")):
