@@ -275,6 +275,29 @@ def kernel_roofline(timer, timed_steps, ms_per_step, dtype, traffic_key, conv_on
     return roof
 
 
+_PROFILER_VARS = ("ROCP_TOOL_LIBRARIES", "ROCPROFILER_LIBRARY", "ROCPROF_", "ROCPROFILER_", "ROCP_", "HSA_TOOLS_LIB", "ROCTX_")
+
+
+def under_profiler(env=None):
+    """True when this process was started by rocprofv3 / rocprof (their tool library is preloaded or named in the environment)."""
+    env = os.environ if env is None else env
+    if any(("rocprof" in v.lower() or "roctracer" in v.lower()) for v in (env.get("LD_PRELOAD", ""), env.get("HSA_TOOLS_LIB", ""))):
+        return True
+    return any(k.startswith(_PROFILER_VARS) for k in env)
+
+
+def clean_profiler_env(env):
+    """a copy of `env` without any profiler's variables (children that run their OWN rocprofv3 must not inherit an outer one's)"""
+    out = {k: v for k, v in env.items() if not k.startswith(_PROFILER_VARS)}
+    if "LD_PRELOAD" in out:
+        keep = [x for x in out["LD_PRELOAD"].replace(":", " ").split() if "rocprof" not in x.lower() and "roctracer" not in x.lower()]
+        if keep:
+            out["LD_PRELOAD"] = ":".join(keep)
+        else:
+            del out["LD_PRELOAD"]
+    return out
+
+
 def live_traffic(args, kernels, budget_s=45.0):
     """HBM bytes per launch and matrix-pipe busy fraction of the named kernels, measured by THIS run: three rocprofv3 counter passes (FETCH_SIZE;
     WRITE_SIZE; SQ_VALU_MFMA_BUSY_CYCLES + GRBM_GUI_ACTIVE -- separate passes, --kernel-trace only, as MI355X_MICROARCH.md prescribes) of the same
@@ -289,6 +312,9 @@ def live_traffic(args, kernels, budget_s=45.0):
     import tempfile
     if shutil.which("rocprofv3") is None:
         return None
+    if under_profiler():      # this run is itself being profiled: a counter pass started from here would be a profiler inside a profiler
+        sys.stderr.write("bench.py: running under a profiler -- the live counter passes are skipped\n")
+        return None
     sys.path.insert(0, os.path.join(ROOT, "tools"))
     from traffic_aggregate import kernel_key
     out = tempfile.mkdtemp(prefix="riders_live_traffic_", dir="/tmp")
@@ -302,7 +328,8 @@ def live_traffic(args, kernels, budget_s=45.0):
         for n, ctrs in enumerate((("FETCH_SIZE",), ("WRITE_SIZE",), ("SQ_VALU_MFMA_BUSY_CYCLES", "GRBM_GUI_ACTIVE"))):
             d = os.path.join(out, "pass%d" % n)
             cmd = ["rocprofv3", "--pmc"] + list(ctrs) + ["--kernel-trace", "--output-format", "csv", "-d", d, "-o", "p", "--"] + base
-            pr = subprocess.Popen(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
+            pr = subprocess.Popen(cmd, cwd="/tmp", env=dict(clean_profiler_env(os.environ), TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
+                                  start_new_session=True)
             try:
                 rc = pr.wait(timeout=budget_s)
             except subprocess.TimeoutExpired:
@@ -564,6 +591,7 @@ def run_workload(kind, args, dev, world, rank, steps, warmup, **override):
     elapsed = time.perf_counter() - t0
     engine.set_kernel_timer(None)
     final_loss = float(loss.detach()) if loss is not None else float('nan')
+    engine.check_roi_overflow()      # raises if a timed step met a RoI geometry the one-byte arg-max cannot encode (its gradients would be NaN)
     timed_steps = steps
     if not args.eager:
         # per-kernel HIP-event timing cannot run inside graph replays: the same step is re-run eagerly (same kernels,

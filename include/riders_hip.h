@@ -451,7 +451,10 @@ int rd_clear_options(void);
  * far on `compute_stream` -- it returns at once and overlaps whatever the caller enqueues next; mode 0 = all-reduce (RCCL picks the
  * algorithm), 1 = reduce-scatter + all-gather in place.  rd_comm_broadcast: buf of rank `root` to every rank, same ordering.
  * rd_comm_join: `compute_stream` waits for everything issued since the last join.  All four are stream operations and may be captured
- * into a hipGraph (fork / join of the communication stream become graph edges).  rd_comm_pending: collectives issued and not yet joined. */
+ * into a hipGraph (fork / join of the communication stream become graph edges).  rd_comm_pending: collectives issued and not yet joined.
+ * rd_comm_available: 0 when an RCCL build can be bound (a copy already mapped into the process is the only candidate then -- two RCCL builds
+ * are never mixed); every rank calls it and the ranks agree on the result BEFORE rd_comm_init, which blocks until all of them have entered. */
+int rd_comm_available(void);
 int rd_comm_unique_id(void* id128);
 int rd_comm_init(int32_t rank, int32_t world, const void* id128, void** comm);
 int rd_comm_destroy(void* comm);

@@ -39,18 +39,20 @@ def _newer(a, b):
     return (not os.path.exists(b)) or os.path.getmtime(a) > os.path.getmtime(b)
 
 
-def _headers_mtime():
+def _headers_mtime(src=None):
+    """newest header a source depends on: the kernel units (.hip) include csrc/*.h only; the public header include/riders_hip.h is included
+    by the C ABI layer (rd_api.cpp, rd_comm.cpp, rd_host.cpp), so a new entry point does not recompile every kernel twice"""
     hs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
-    hs.append(os.path.join(HERE, "..", "include", "riders_hip.h"))
+    if src is None or src.endswith(".cpp"):
+        hs.append(os.path.join(HERE, "..", "include", "riders_hip.h"))
     return max(os.path.getmtime(h) for h in hs)
 
 
 def build(force=False, verbose=True):
     os.makedirs(OBJ, exist_ok=True)
-    hm = _headers_mtime()
     jobs = []
     for src, obj, extra in units():
-        if force or _newer(src, obj) or hm > os.path.getmtime(obj):
+        if force or _newer(src, obj) or _headers_mtime(src) > os.path.getmtime(obj):
             jobs.append((src, obj, extra))
 
     def cc(job):

@@ -497,6 +497,37 @@ def tape():
     return _state["tape"]
 
 
+# ------------------------------------------------------------------------------------------ debug taps
+_taps = {"on": False, "fwd": {}, "grad": {}}
+
+
+def taps_enable(flag=True):
+    """Debug / parity tooling (tools/grad_localise.py, tests): while on, `tap(name, t)` keeps a float copy of the tape tensor `t` and of the
+    gradient the backward has accumulated for it when it reaches that point.  Off (the default) a tap is one dict lookup and records nothing."""
+    _taps["on"] = bool(flag)
+    _taps["fwd"], _taps["grad"] = {}, {}
+
+
+def taps():
+    return _taps["fwd"], _taps["grad"]
+
+
+def tap(name, x):
+    """Call right after `x` was produced (so that every consumer has contributed before the tap's backward node runs).  No-op unless taps_enable()."""
+    if not _taps["on"]:
+        return x
+    t = tape()
+    if not isinstance(x, LazyAct):      # (a virtual activation is not written for a tap: that would change the route under test)
+        _taps["fwd"][name] = x.detach().float().cpu()
+    if t is not None and id(x) in t.req:
+        def backward():
+            g = t.grads.get(id(x))
+            if torch.is_tensor(g):
+                _taps["grad"][name] = g.detach().float().cpu()
+        t.record(backward)
+    return x
+
+
 # ------------------------------------------------------------------------------------------ stage marks
 _stage_hooks = []
 
@@ -1206,6 +1237,8 @@ def conv_block(x, weight, *, x2=None, bias=None, stride=1, pad=None, up=None, bn
             # x already holds a gradient contribution (a skip connection's decoder side, a residual shortcut): the kernel adds it in its
             # epilogue and the sum replaces it -- no second tensor, no separate add pass
             cur = t.grads.get(id(xk)) if (C2 == 0 and not is_up and _state.get("fuse_grad_add", True) and id(xk) in t.req) else None
+            if isinstance(cur, HeadGrad):      # the one-channel head was this tensor's other consumer: its virtual gradient is written out first
+                cur = t.grads[id(xk)] = cur.materialize(t)
             if cur is not None and not (cur.shape == dxv1.shape and cur.dtype == dxv1.dtype and cur.is_contiguous() and lib.rd_conv_add_ok(ctypes.byref(dd))):
                 cur = None
             # x is the output of conv -> BatchNorm -> act (materialised or virtual): this launch writes its dz, so its epilogue also sums the
@@ -1213,6 +1246,8 @@ def conv_block(x, weight, *, x2=None, bias=None, stride=1, pad=None, up=None, bn
             # only if the tensor written here is the final dz (checked by identity in the producer's backward: a later contribution makes a new one).
             bsrc = t.bn_src.get(id(xk)) if not is_up and not cin_pad else None
             bfus = sb = None
+            if isinstance(t.grads.get(id(xk)), HeadGrad):
+                bsrc = None
             if bsrc is not None and bsrc["C"] == C1_d and id(xk) in t.req and (cur is not None or t.grads.get(id(xk)) is None):
                 bfus = _lib.ConvFusion()
                 cf = bsrc["coef"]

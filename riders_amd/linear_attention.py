@@ -129,17 +129,17 @@ class LocalFeatureTransformer(nn.Module):
         two launches of 240; a 'cross' layer (:174-176, the second call consumes the first call's output) writes its two results into the
         halves of the next matrix, so no copy separates the layers."""
         R = N * L
-        F = engine.rows_cat(f0, f1)
-        for layer, name in zip(self.layers, self.layer_names):
+        F = engine.tap("tf.in", engine.rows_cat(f0, f1))
+        for li, (layer, name) in enumerate(zip(self.layers, self.layer_names)):
             if name == 'self':
-                F = engine.loftr_layer(F, F, layer, 2 * N, L, L)
+                F = engine.tap("tf.layer%d" % li, engine.loftr_layer(F, F, layer, 2 * N, L, L))
             elif name == 'cross':
                 a, b = engine.rows_split(F, R)
                 G = torch.empty_like(F)
                 cg = engine.CrossGrad()       # the pair's backward writes d [a; b] in place (no gradient-add passes, no row copies)
                 a2 = engine.loftr_layer(a, b, layer, N, L, L, out=G[:R], cross=cg, cross_role=1)
                 b2 = engine.loftr_layer(b, a2, layer, N, L, L, out=G[R:], cross=cg, cross_role=2)
-                F = engine.rows_join(a2, b2, G)
+                F = engine.tap("tf.layer%d" % li, engine.rows_join(a2, b2, G))
             else:
                 raise KeyError
         return engine.rows_split(F, R)

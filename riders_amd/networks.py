@@ -161,13 +161,20 @@ class RCNetEncoder(torch.nn.Module):
         L = latent_height * latent_width
 
         latent_image, skips_image = self.encoder_image._fwd(image)
+        engine.tap("enc.latent_image", latent_image)
+        for i, s_ in enumerate(skips_image):
+            engine.tap("enc.skip%d" % i, s_)
         engine.stage_mark("attention_done")   # backward: RoI pooling, point MLP and transformer gradients are final here
         skips_image_pooled = [engine.roi_pool(skips_image[i], rois, skip_feature_sizes[i], skip_scales[i])
                               for i in range(len(skips_image))]
         latent_image_pooled = engine.roi_pool(latent_image, rois, (latent_height, latent_width), 1 / 32.0)
+        engine.tap("enc.latent_pooled", latent_image_pooled)
+        for i, s_ in enumerate(skips_image_pooled):
+            engine.tap("enc.skip%d_pooled" % i, s_)
 
         # point MLP stays in fp32 (raw pixel coordinates in the hundreds), output viewed (R, C, L) -> tokens (R, L, C)
         latent_depth = self.encoder_depth._fwd(points)
+        engine.tap("enc.mlp_out", latent_depth)
         tokens_depth = engine.transpose_last2(latent_depth, R, C, L)          # (R, L, C)
         tokens_depth = engine.alias(tokens_depth, tokens_depth.view(R * L, C))
         tokens_depth = engine.input_cast(tokens_depth)
@@ -175,6 +182,7 @@ class RCNetEncoder(torch.nn.Module):
 
         depth_tf, image_tf = self.attention._fwd(tokens_depth, tokens_image, R, L, L)
         latent = engine.concat_channels(image_tf, depth_tf)                   # cat([image_tf, depth_tf], dim=1)
+        engine.tap("enc.latent", latent)
         latent = engine.alias(latent, latent.view(R, latent_height, latent_width, 2 * C))
         return latent, skips_image_pooled
 
@@ -222,10 +230,10 @@ class MultiScaleDecoder(torch.nn.Module):
     def _fwd(self, x, skips, shape=None):
         # every block's output is consumed by the next block's up-convolution (or the output convolution): virtual (engine.LazyAct) at lazy_bn level 2
         n = len(skips) - 1
-        h = self.deconv4._fwd(x, skips[n], lazy=2); n -= 1
-        h = self.deconv3._fwd(h, skips[n], lazy=2); n -= 1
-        h = self.deconv2._fwd(h, skips[n], lazy=2); n -= 1
-        h = self.deconv1._fwd(h, skips[n], lazy=2); n -= 1
+        h = engine.tap("dec.deconv4", self.deconv4._fwd(x, skips[n], lazy=2)); n -= 1
+        h = engine.tap("dec.deconv3", self.deconv3._fwd(h, skips[n], lazy=2)); n -= 1
+        h = engine.tap("dec.deconv2", self.deconv2._fwd(h, skips[n], lazy=2)); n -= 1
+        h = engine.tap("dec.deconv1", self.deconv1._fwd(h, skips[n], lazy=2)); n -= 1
         # deconv0's output feeds the one-channel output convolution only: virtual at level 1 when the fused head kernels take the pair (engine bn_head)
         lz0 = 1 if engine.head_route(self.output0.conv.in_channels) else 2
         if n == 0:

@@ -28,27 +28,49 @@ class RcclComm(object):
     exchange only; with world == 1 nothing is exchanged.  The collectives themselves never pass through torch.distributed: they are stream
     operations of libriders_hip.so and can be captured into the step's hipGraph (rcnet_main.GraphedStep)."""
 
-    def __init__(self, rank=None, world=None, exchange=None):
+    def __init__(self, rank=None, world=None, exchange=None, agree=None):
+        """exchange(bytes or None) -> bytes or None: hands rank 0's rendezvous id to every rank (default: torch.distributed broadcast);
+        agree(bool) -> bool: True iff EVERY rank passed True (default: a MIN all-reduce on the host side of torch.distributed).
+        The ranks fail TOGETHER: a rank that cannot bind RCCL, or a rank 0 that cannot draw an id, still takes part in both exchanges, so no
+        peer is left waiting in a broadcast or inside ncclCommInitRank (which blocks until every rank has entered it)."""
         lib = engine.L()
         if rank is None:
             rank = dist.get_rank() if dist.is_initialized() else 0
         if world is None:
             world = dist.get_world_size() if dist.is_initialized() else 1
         self.rank, self.world = int(rank), int(world)
+        self.handle = None
         idb = ctypes.create_string_buffer(128)
-        if self.rank == 0:
-            engine._chk(lib.rd_comm_unique_id(idb), "rd_comm_unique_id")
+        err = None
+        ok = lib.rd_comm_available() == 0
+        if not ok:
+            err = "rank %d: %s" % (self.rank, (lib.rd_last_error_string() or b"RCCL cannot be bound").decode(errors="replace"))
+        if self.rank == 0 and ok:
+            if lib.rd_comm_unique_id(idb) != 0:
+                ok, err = False, "rank 0: %s" % (lib.rd_last_error_string() or b"rd_comm_unique_id failed").decode(errors="replace")
         if self.world > 1:
-            if exchange is None:
+            if exchange is None or agree is None:
                 if not dist.is_initialized():
-                    raise RuntimeError("RcclComm: world > 1 needs an initialised torch.distributed group or an `exchange` callable for the rendezvous id")
-
+                    raise RuntimeError("RcclComm: world > 1 needs an initialised torch.distributed group or `exchange` / `agree` callables for the rendezvous")
+            if exchange is None:
                 def exchange(b):
                     box = [b]
                     dist.broadcast_object_list(box, src=0)
                     return box[0]
-            got = exchange(bytes(idb.raw) if self.rank == 0 else None)
-            idb = ctypes.create_string_buffer(bytes(got), 128)
+            if agree is None:
+                def agree(flag):
+                    votes = [None] * self.world
+                    dist.all_gather_object(votes, bool(flag))
+                    return all(votes)
+            got = exchange((bytes(idb.raw) if ok else None) if self.rank == 0 else None)      # None = rank 0 could not draw an id
+            if got is None:
+                ok, err = False, err or "rank 0 could not create the rendezvous id"
+            else:
+                idb = ctypes.create_string_buffer(bytes(got), 128)
+            if not agree(ok):
+                raise RuntimeError("RcclComm: not every rank can create the communicator (%s)" % (err or "another rank failed"))
+        elif not ok:
+            raise RuntimeError("RcclComm: " + err)
         h = ctypes.c_void_p()
         engine._chk(lib.rd_comm_init(self.rank, self.world, idb, ctypes.byref(h)), "rd_comm_init")
         self.handle = h

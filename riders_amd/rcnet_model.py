@@ -94,6 +94,7 @@ class RCNetModel(object):
 
     # -- reference: rcnet_model.py:211-257 (same checkpoint dict keys) --------------------------------------
     def save_model(self, checkpoint_path, step, optimizer):
+        engine.check_roi_overflow()      # the host waits here anyway: a geometry the one-byte RoI arg-max cannot encode raises instead of saving NaNs
         checkpoint = {}
         checkpoint['train_step'] = step
         checkpoint['radarnet_optimizer_state_dict'] = optimizer.state_dict()

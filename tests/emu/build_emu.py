@@ -22,14 +22,15 @@ def build(verbose=False, extra=()):
     os.makedirs(OUT, exist_ok=True)
     srcs = sorted(f for f in os.listdir(CSRC) if f.endswith(".hip") or f.endswith(".cpp"))
     hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
-    hdrs += [os.path.join(HERE, "include", "hip", "hip_runtime.h"), os.path.join(ROOT, "include", "riders_hip.h")]
-    hm = max(os.path.getmtime(h) for h in hdrs)
+    hdrs += [os.path.join(HERE, "include", "hip", "hip_runtime.h")]
+    hm_k = max(os.path.getmtime(h) for h in hdrs)      # kernel units include csrc/*.h + the emulator's runtime header ...
+    hm_api = max(hm_k, os.path.getmtime(os.path.join(ROOT, "include", "riders_hip.h")))      # ... only the C ABI layer (.cpp) the public header
     jobs, objs = [], []
     for f in srcs:        # every kernel unit twice: bf16 build and fp16 build (-DRD_HALF_F16, namespace rd_f16), as riders_amd/build.py
         for suffix, flags in ((".o", []), (".f16.o", ["-DRD_HALF_F16"])) if f.endswith(".hip") else ((".o", []),):
             src, obj = os.path.join(CSRC, f), os.path.join(OUT, f + suffix)
             objs.append(obj)
-            if not os.path.exists(obj) or os.path.getmtime(obj) < max(hm, os.path.getmtime(src)):
+            if not os.path.exists(obj) or os.path.getmtime(obj) < max(hm_api if f.endswith(".cpp") else hm_k, os.path.getmtime(src)):
                 jobs.append((src, obj, flags))
 
     def cc(job):

@@ -52,20 +52,24 @@ def test_arena_allreduce_world2():
     assert res[0][4] > 1
 
 
-def _ddp_worker(rank, world, port, outdir, emu_lib):
+def _ddp_worker(rank, world, port, outdir, emu_lib, transport="gloo"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from riders_amd import _lib, engine, rcnet_main
     from riders_amd.optim import FlatAdam
-    from riders_amd.parallel import GradientAllReducer
+    from riders_amd.parallel import GradientAllReducer, RcclComm
     from tests.test_host_logic import _TwoStage, _toy_batch, _toy_loss
     _lib._install_for_tests(emu_lib)      # TEST INFRA: host build of the kernel sources (no GPU in this container)
     engine.set_compute_dtype("fp32")
     torch.manual_seed(100 + rank)          # different initial weights per rank on purpose: broadcast must fix it
     model = _TwoStage(); model.train()
     opt = FlatAdam(list(model.parameters()), lr=1e-2)
-    red = GradientAllReducer(opt, stages={"head_done": list(model.head.parameters()) + list(model.out.parameters())})
+    # transport "c_abi" / "c_abi_rs_ag": the gradients travel through rd_comm_* (csrc/rd_comm.cpp; here its emulator build's shared-memory
+    # transport, one process per rank as on the GPUs) -- torch.distributed (gloo) only carries the 128-byte rendezvous id and the vote
+    comm = RcclComm(rank, world) if transport != "gloo" else None
+    red = GradientAllReducer(opt, stages={"head_done": list(model.head.parameters()) + list(model.out.parameters())}, comm=comm,
+                             mode="rs_ag" if transport.endswith("rs_ag") else "all_reduce", bucket_bytes=(1 << 10) if comm is not None else (32 << 20))
     red.broadcast_parameters(0)
     init = opt.flat_param.clone()
     grads, order = [], []
@@ -77,21 +81,30 @@ def _ddp_worker(rank, world, port, outdir, emu_lib):
         red.log = []
         grads.append(opt.flat_grad.clone() * opt.grad_scale)
         opt.step()
+    if comm is not None:
+        assert comm.pending() == 0
+        comm.close()
     dist.barrier()
     dist.destroy_process_group()
     torch.save(dict(rank=rank, init=init, grads=grads, final=opt.flat_param.clone(), order=order), os.path.join(outdir, "r%d.pt" % rank))
 
 
-def test_two_training_steps_world2_match_per_shard_mean(emu_lib_path):
+import pytest  # noqa: E402
+
+
+@pytest.mark.parametrize("transport", ["gloo", "c_abi", "c_abi_rs_ag"])
+def test_two_training_steps_world2_match_per_shard_mean(emu_lib_path, transport):
     """SURVEY 8(e) semantics: every rank runs the full step on its own shard (per-rank BatchNorm statistics, per-rank loss
     normaliser), the stage-bucketed all-reduce averages the gradients, Adam applies the average.  Two steps on two ranks must equal a
     single process that evaluates both shards on the same weights and applies the mean gradient; the head bucket is issued at its
-    stage mark, i.e. before the body's backward has run."""
+    stage mark, i.e. before the body's backward has run.  Transports: torch.distributed's gloo all-reduce, and the library's own
+    communicator behind the C ABI (parallel.RcclComm -> rd_comm_init / rd_allreduce_bucket / rd_comm_broadcast / rd_comm_join) in both bucket
+    modes -- on this GPU-less container through the emulator build's shared-memory transport, two PROCESSES as on the GPUs."""
     import tempfile
     ctx = mp.get_context("spawn")
     port = _free_port()
     with tempfile.TemporaryDirectory() as outdir:
-        procs = [ctx.Process(target=_ddp_worker, args=(r, 2, port, outdir, emu_lib_path)) for r in range(2)]
+        procs = [ctx.Process(target=_ddp_worker, args=(r, 2, port, outdir, emu_lib_path, transport)) for r in range(2)]
         for p in procs:
             p.start()
         for p in procs:
@@ -100,7 +113,7 @@ def test_two_training_steps_world2_match_per_shard_mean(emu_lib_path):
         res = [torch.load(os.path.join(outdir, "r%d.pt" % r)) for r in range(2)]
     assert torch.equal(res[0]["init"], res[1]["init"]), "parameters not broadcast from rank 0"
     assert torch.equal(res[0]["final"], res[1]["final"]), "ranks diverged"
-    assert res[0]["order"] == [["head_done"], ["head_done"]], res[0]["order"]     # bucket started from the stage mark, before reduce()
+    assert all(o and set(o) == {"head_done"} for o in res[0]["order"]), res[0]["order"]     # bucket(s) started from the stage mark, before reduce()
     for s in range(2):
         assert torch.equal(res[0]["grads"][s], res[1]["grads"][s])
     # single-process reference: same initial weights, per-shard gradients on identical weights, mean, Adam
@@ -190,3 +203,64 @@ def test_sml_arena_world2_stage_buckets():
     tot = res[0]["local"] + res[1]["local"]
     for r in range(2):
         assert torch.equal(res[r]["summed"], tot), "rank %d: all-reduced arena differs from the sum of the local gradients" % r
+
+
+def _rendezvous_worker(rank, world, port, outdir, emu_lib):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from riders_amd import _lib
+    from riders_amd.parallel import RcclComm
+    _lib._install_for_tests(emu_lib)
+    lib = _lib.load()
+    real = lib.rd_comm_unique_id
+    out = {}
+    # (1) rank 0 cannot draw an id: every rank raises, nobody is left in the broadcast
+    if rank == 0:
+        lib.rd_comm_unique_id = lambda buf: -2
+    try:
+        RcclComm(rank, world)
+        out["id_failure"] = "no error"
+    except RuntimeError as ex:
+        out["id_failure"] = str(ex)
+    lib.rd_comm_unique_id = real
+    # (2) rank 1 cannot bind the transport: every rank raises BEFORE rd_comm_init (which would block the others)
+    avail = lib.rd_comm_available
+    if rank == 1:
+        lib.rd_comm_available = lambda: -2
+    try:
+        RcclComm(rank, world)
+        out["bind_failure"] = "no error"
+    except RuntimeError as ex:
+        out["bind_failure"] = str(ex)
+    lib.rd_comm_available = avail
+    # (3) and afterwards the same ranks still build a working communicator
+    c = RcclComm(rank, world)
+    buf = torch.full((5,), float(rank + 1))
+    c.all_reduce(buf)
+    c.join(buf)
+    out["sum"] = buf.tolist()
+    c.close()
+    dist.barrier()
+    dist.destroy_process_group()
+    torch.save(out, os.path.join(outdir, "r%d.pt" % rank))
+
+
+def test_comm_rendezvous_fails_on_every_rank_together(emu_lib_path):
+    """a rank that fails before the rendezvous must not leave its peers blocked -- rank 0 failing to draw the id, or any rank
+    failing to bind the transport, raises on EVERY rank (after the id exchange / the vote), and a later attempt still works."""
+    import tempfile
+    ctx = mp.get_context("spawn")
+    port = _free_port()
+    with tempfile.TemporaryDirectory() as outdir:
+        procs = [ctx.Process(target=_rendezvous_worker, args=(r, 2, port, outdir, emu_lib_path)) for r in range(2)]
+        for p in procs:
+            p.start()
+        for p in procs:
+            p.join(timeout=300)
+            assert p.exitcode == 0, "worker exit code %s" % p.exitcode
+        res = [torch.load(os.path.join(outdir, "r%d.pt" % r)) for r in range(2)]
+    for r in range(2):
+        assert "not every rank" in res[r]["id_failure"], res[r]
+        assert "not every rank" in res[r]["bind_failure"], res[r]
+        assert res[r]["sum"] == [3.0] * 5, res[r]

@@ -378,7 +378,9 @@ def test_c_abi_comm_loopback_and_bucketing(emu):
         red.close()
     h = ctypes.c_void_p()
     idb = ctypes.create_string_buffer(128)
-    assert lib.rd_comm_init(1, 2, idb, ctypes.byref(h)) < 0 and b"world" in lib.rd_last_error_string()
+    assert lib.rd_comm_init(2, 2, idb, ctypes.byref(h)) < 0 and b"world" in lib.rd_last_error_string()      # rank outside the world
+    assert lib.rd_comm_init(1, 2, idb, ctypes.byref(h)) < 0      # an id that rd_comm_unique_id never drew
+    assert lib.rd_comm_available() == 0
     assert lib.rd_allreduce_bucket(comm.handle, None, 4, 0, None) < 0
     assert lib.rd_allreduce_bucket(comm.handle, engine._p(opt.flat_grad), 4, 7, None) < 0 and b"allreduce_bucket" in lib.rd_last_error_string()
     comm.close()
