@@ -81,7 +81,7 @@ typedef struct rd_pack_item {
   const float* w_oihw; void* packed;
   int32_t Cout, Cin, KH, KW, mode, dtype;
   int32_t Cin_src;             /* 0 or the real input-channel count of w_oihw when the packed layout is zero-padded to Cin (mode 0) */
-  int32_t reserved;
+  int32_t reserved;            /* 0; 1 = keep the element-wise packing form for this item (A/B against the 16-byte-unit form of round 6; same bytes) */
 } rd_pack_item;
 /* forward operand with the input channels zero-padded from Cin_src to Cin (the 3-channel stems of utils/net_utils.py's encoders run
    on the 16-byte-vector kernels: pad the image with rd_pad_channels, un-pad the weight gradient with rd_unpad_weight_grad) */

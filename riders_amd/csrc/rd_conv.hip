@@ -343,6 +343,7 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, T* __restrict__
 
 // batch form: blockIdx.y = item (device descriptor table), blockIdx.x strides over the item's packed elements
 struct PackItem { const float* w; void* out; int Cout, Cin, KH, KW, mode, dtype, CinSrc, pad_; };
+__device__ __forceinline__ bool rd_pack_vec_enabled(const PackItem& it) { return it.pad_ == 0; }      // (rd_pack_item.reserved = 1: the element-wise form, for A/B)
 template <typename T>
 __device__ __forceinline__ void pack_one(const PackItem& it, int bx, int nbx) {
   const int rows = it.mode == 2 ? 4 * it.Cout : (it.mode ? it.Cin : it.Cout), C = it.mode == 3 ? 4 * it.Cout : (it.mode == 1 ? it.Cout : it.Cin);
@@ -381,10 +382,134 @@ __device__ __forceinline__ void pack_one(const PackItem& it, int bx, int nbx) {
     if (k >= Kpad) { k -= Kpad; row++; }
   }
 }
+// Round 6: the same packing in 16-byte units with coalesced reads (the batch kernel was 84 us per RC-Net step and ~300 us per SML step -- 9 x
+// the operands' bytes -- because every 2-byte output element was its own strided 4-byte OIHW read and its own 2-byte store, and the fragment-
+// ordered copies were scattered 2-byte stores).  A work item is one (packed row, group of VE consecutive channels of the packed K axis) over
+// ALL taps of a 1x1 or 3x3 kernel: VE x KK source values, KK 16-byte stores per layout.
+//   mode 0 / 2 (rows follow Cout): the VE x KK values of an item are ONE contiguous run of the OIHW tensor (VE input channels x KK taps of one
+//     output channel): read as 16-byte vectors, consecutive items (channel groups of a row) = consecutive runs.
+//   mode 1 / 3 (rows follow Cin, the transposed operand of the data gradient): an item needs KK-float pieces of VE different output channels;
+//     consecutive threads take consecutive ROWS (input channels), whose pieces are adjacent in memory.
+// Bit-identical to pack_one (same fp32 sums in the same order for the pre-summed up-convolution taps, one rounding) -- pack_batch_case.
+template <typename T>
+__device__ __forceinline__ bool pack_vec_ok(const PackItem& it) {
+  constexpr int VE = Elem<T>::VE;
+  const int C = it.mode == 3 ? 4 * it.Cout : (it.mode == 1 ? it.Cout : it.Cin);
+  const int KK = it.KH * it.KW;
+  if (!(KK == 1 || (it.KH == 3 && it.KW == 3))) return false;
+  if (it.CinSrc > 0 && it.CinSrc != it.Cin) return false;      // zero-padded stems keep the element-wise form
+  if (C % VE || (it.Cin % 4) || ((uintptr_t)it.w & 15) || ((uintptr_t)it.out & 15)) return false;      // 16-byte source runs and destination units
+  if ((it.mode == 2 || it.mode == 3) && (KK != 9 || (it.Cout % VE))) return false;
+  return true;
+}
+template <typename T>
+__device__ __forceinline__ void pack_one_vec(const PackItem& it, int bx, int nbx) {
+  constexpr int VE = Elem<T>::VE;
+  const int rows = it.mode == 2 ? 4 * it.Cout : (it.mode ? it.Cin : it.Cout), C = it.mode == 3 ? 4 * it.Cout : (it.mode == 1 ? it.Cout : it.Cin);
+  const int KK = it.KH * it.KW, K = KK * C;
+  const int bn = rows <= 16 ? 16 : (rows <= 32 ? 32 : (rows <= 64 ? 64 : 128));
+  const int rows_pad = (rows + bn - 1) / bn * bn;
+  const int bke = sizeof(T) == 4 ? 32 : 64;
+  const int Kpad = (K + bke - 1) / bke * bke;
+  const int64_t total = (int64_t)rows_pad * Kpad;
+  const bool frag = pack_has_frag(it.KH, it.KW, C, sizeof(T) == 4 ? 0 : 1);
+  const bool tokfrag = KK == 1 && pack_has_tokfrag(rows, K);
+  T* out = (T*)it.out;
+  const float* __restrict__ w = it.w;
+  const int CG = C / VE;                                   // channel groups per row
+  const bool by_row = it.mode == 1 || it.mode == 3;        // consecutive work items walk the rows (coalesced reads of the transposed operand)
+  const int64_t items = (int64_t)rows * CG;
+  for (int64_t u = (int64_t)bx * 256 + threadIdx.x; u < items; u += (int64_t)nbx * 256) {
+    int row, cg;
+    if (by_row) { cg = (int)(u / rows); row = (int)(u - (int64_t)cg * rows); }
+    else { row = (int)(u / CG); cg = (int)(u - (int64_t)row * CG); }
+    const int c0 = cg * VE;
+    if (KK == 1) {
+      float v[VE];
+      if (it.mode == 0) {
+#pragma unroll
+        for (int q = 0; q < VE / 4; q++) { const float4 f = *reinterpret_cast<const float4*>(w + (int64_t)row * it.Cin + c0 + 4 * q); v[4 * q] = f.x; v[4 * q + 1] = f.y; v[4 * q + 2] = f.z; v[4 * q + 3] = f.w; }
+      } else {
+#pragma unroll
+        for (int e = 0; e < VE; e++) v[e] = w[(int64_t)(c0 + e) * it.Cin + row];
+      }
+      stv(out + (int64_t)row * Kpad + c0, v);
+      if (tokfrag) stv(out + total + pack_tokfrag_index<T>(row, c0, K), v);
+      continue;
+    }
+    // 3x3: src[e][t] = w[co][ci][t] of the VE (co, ci) pairs this item touches, t = kh * 3 + kw of the ORIGINAL kernel
+    float src[VE][9];
+    if (!by_row) {      // modes 0 / 2: one contiguous run of VE x 9 floats
+      const int co = it.mode == 2 ? row % it.Cout : row;
+      const float4* run = reinterpret_cast<const float4*>(w + ((int64_t)co * it.Cin + c0) * 9);
+      float flat[VE * 9];
+#pragma unroll
+      for (int q = 0; q < VE * 9 / 4; q++) { const float4 f = run[q]; flat[4 * q] = f.x; flat[4 * q + 1] = f.y; flat[4 * q + 2] = f.z; flat[4 * q + 3] = f.w; }
+#pragma unroll
+      for (int e = 0; e < VE; e++)
+#pragma unroll
+        for (int t = 0; t < 9; t++) src[e][t] = flat[e * 9 + t];
+    } else {            // modes 1 / 3: nine floats of each of VE output channels, input channel = row
+      const int co0 = it.mode == 3 ? c0 % it.Cout : c0;
+#pragma unroll
+      for (int e = 0; e < VE; e++) {
+        const float* pw = w + ((int64_t)(co0 + e) * it.Cin + row) * 9;
+#pragma unroll
+        for (int t = 0; t < 9; t++) src[e][t] = pw[t];
+      }
+    }
+    const int cls = it.mode == 2 ? row / it.Cout : (it.mode == 3 ? c0 / it.Cout : 0), ca = cls >> 1, cb = cls & 1;
+#pragma unroll
+    for (int tap = 0; tap < 9; tap++) {      // packed tap (kh, kw) of this layout
+      const int kh = tap / 3, kw = tap - kh * 3;
+      float v[VE];
+      if (it.mode == 0) {
+#pragma unroll
+        for (int e = 0; e < VE; e++) v[e] = src[e][tap];
+      } else if (it.mode == 1) {
+#pragma unroll
+        for (int e = 0; e < VE; e++) v[e] = src[e][(2 - kh) * 3 + (2 - kw)];
+      } else {
+        // pre-summed taps of parity class (ca, cb) (pack_up2_value): source tap (khs, kws) collects original rows h0..h1, columns w0..w1
+        const int khs = it.mode == 2 ? kh : 2 - kh, kws = it.mode == 2 ? kw : 2 - kw;
+        const int h0 = ca == 0 ? (khs == 0 ? 0 : (khs == 1 ? 1 : 3)) : (khs == 0 ? 3 : (khs == 1 ? 0 : 2));
+        const int h1 = ca == 0 ? (khs == 0 ? 0 : (khs == 1 ? 2 : -1)) : (khs == 0 ? -1 : (khs == 1 ? 1 : 2));
+        const int w0 = cb == 0 ? (kws == 0 ? 0 : (kws == 1 ? 1 : 3)) : (kws == 0 ? 3 : (kws == 1 ? 0 : 2));
+        const int w1 = cb == 0 ? (kws == 0 ? 0 : (kws == 1 ? 2 : -1)) : (kws == 0 ? -1 : (kws == 1 ? 1 : 2));
+#pragma unroll
+        for (int e = 0; e < VE; e++) {
+          float a = 0.f;
+#pragma unroll
+          for (int hh = 0; hh < 3; hh++)
+#pragma unroll
+            for (int ww = 0; ww < 3; ww++)
+              if (hh >= h0 && hh <= h1 && ww >= w0 && ww <= w1) a += src[e][hh * 3 + ww];
+          v[e] = a;
+        }
+      }
+      const int k0 = tap * C + c0;
+      stv(out + (int64_t)row * Kpad + k0, v);
+      if (frag) stv(out + total + pack_frag_index<T>(row, k0, C, rows_pad, tap, c0), v);
+    }
+  }
+  // padding (rows beyond `rows`, k beyond K) is zero: 16-byte units of the row-major copy, and of the fragment-ordered copy for padded rows
+  const float z[VE] = {};
+  const int KV = Kpad / VE, KVr = K / VE;
+  const int64_t pad_units = (int64_t)(rows_pad - rows) * KV + (int64_t)rows * (KV - KVr);
+  for (int64_t u = (int64_t)bx * 256 + threadIdx.x; u < pad_units; u += (int64_t)nbx * 256) {
+    int row, kv;
+    if (u < (int64_t)rows * (KV - KVr)) { row = (int)(u / (KV - KVr)); kv = KVr + (int)(u - (int64_t)row * (KV - KVr)); }
+    else { const int64_t r = u - (int64_t)rows * (KV - KVr); row = rows + (int)(r / KV); kv = (int)(r - (int64_t)(row - rows) * KV); }
+    stv(out + (int64_t)row * Kpad + kv * VE, z);
+    if (frag && kv < KVr) { const int k0 = kv * VE, tap = k0 / C; stv(out + total + pack_frag_index<T>(row, k0, C, rows_pad, tap, k0 - tap * C), z); }
+    if (tokfrag && kv < KVr) stv(out + total + pack_tokfrag_index<T>(row, kv * VE, K), z);
+  }
+}
 __global__ __launch_bounds__(256) void pack_weights_batch_kernel(const PackItem* __restrict__ items) {
   const PackItem it = items[blockIdx.y];
-  if (it.dtype == 0) pack_one<float>(it, blockIdx.x, gridDim.x);
-  else pack_one<bf16_t>(it, blockIdx.x, gridDim.x);
+  const bool vec = rd_pack_vec_enabled(it);
+  if (it.dtype == 0) { if (vec && pack_vec_ok<float>(it)) pack_one_vec<float>(it, blockIdx.x, gridDim.x); else pack_one<float>(it, blockIdx.x, gridDim.x); }
+  else { if (vec && pack_vec_ok<bf16_t>(it)) pack_one_vec<bf16_t>(it, blockIdx.x, gridDim.x); else pack_one<bf16_t>(it, blockIdx.x, gridDim.x); }
 }
 
 // ---- weight gradient ----------------------------------------------------------------------------------

@@ -51,10 +51,11 @@ _state = {"dtype": RD_F32, "tape": None, "defer_wgrad": True, "fused_loftr": Tru
           # step), the data gradients that carry the sums get 0.20 ms slower (one more tensor read + ~10 vector instructions per stored
           # element in epilogues that are already issue bound): 1021.8 -> 1007.1 img/s on one box, alternating.  Off by default.
           "bn_bwd_fused": False,
-          "dw_fused_stats": True}          # depthwise convolution with the BatchNorm statistics in its epilogue; False: separate rd_bn_stats pass
+          "dw_fused_stats": True,          # depthwise convolution with the BatchNorm statistics in its epilogue; False: separate rd_bn_stats pass
+          "pack_vec": True}                # the batched weight re-pack in 16-byte units with coalesced reads (round 6); False: the element-wise form
 
 _SWITCHES = {"fuse_upsample_bwd": bool, "loftr_cross_inplace": bool, "fuse_res_add": bool, "fuse_grad_add": bool, "lazy_bn": (0, 2), "bn_head": bool, "up2_on_source": bool, "up2_dgrad": bool, "fusion_conv_first": bool, "roi_u8": bool,
-             "roi_bwd": ("auto", "gather", "tile", "atomic"), "bn_recompute": bool, "bn_bwd_fused": bool, "dw_fused_stats": bool, "roi_tile_min_blocks": (0, 1 << 30),
+             "roi_bwd": ("auto", "gather", "tile", "atomic"), "bn_recompute": bool, "bn_bwd_fused": bool, "dw_fused_stats": bool, "pack_vec": bool, "roi_tile_min_blocks": (0, 1 << 30),
              "defer_wgrad": bool, "fused_loftr": bool, "deterministic_roi_pool": bool}
 
 
@@ -601,11 +602,32 @@ def _active(t):
 
 
 _grad_alloc_hook = {"fn": None}
+_grad_allocs = []      # weak references to the registered allocators (one per live flat-arena optimizer: RC-Net's and the SML's may coexist)
+
+
+def _dispatch_grad_alloc(p):
+    for ref in reversed(_grad_allocs):      # newest first; an allocator returns None for a parameter it does not own
+        f = ref()
+        if f is None:
+            continue
+        g = f(p)
+        if g is not None:
+            return g
+    return None
 
 
 def set_param_grad_allocator(fn):
-    """fn(param) -> preallocated fp32 gradient tensor or None (used by the flat-arena optimizer / DDP)."""
-    _grad_alloc_hook["fn"] = fn
+    """fn(param) -> preallocated fp32 gradient tensor or None (used by the flat-arena optimizer / DDP).  Several allocators may be
+    registered (two models with their own FlatAdam in one process): each is asked in turn, newest first; bound methods are held weakly,
+    so an optimizer that is dropped takes its allocator with it.  None removes all of them."""
+    if fn is None:
+        del _grad_allocs[:]
+        _grad_alloc_hook["fn"] = None
+        return
+    _grad_allocs[:] = [r for r in _grad_allocs if r() is not None]
+    ref = weakref.WeakMethod(fn) if hasattr(fn, "__self__") else (lambda f=fn: f)
+    _grad_allocs.append(ref)
+    _grad_alloc_hook["fn"] = _dispatch_grad_alloc
 
 
 class _Region(torch.autograd.Function):
@@ -762,15 +784,19 @@ def clear_caches():
     _pack_table.clear()
 
 
-_pack_table = {}
+_pack_table = {}      # owner key -> dict(sig, dev, n, keep): the device-side item table of one rd_conv_pack_weights_batch launch
 
 
-def refresh_packed():
-    """Re-pack EVERY cached operand in one launch (rd_conv_pack_weights_batch).  Called by the optimizer right after it rewrote the
+def refresh_packed(owner=None):
+    """Re-pack cached operands in one launch (rd_conv_pack_weights_batch).  Called by the optimizer right after it rewrote the
     parameters in place: the cached buffers keep their addresses (hipGraph replays keep reading them) and the next forward finds
-    every operand fresh instead of issuing one pack launch per layer and direction."""
+    every operand fresh instead of issuing one pack launch per layer and direction.
+    owner: a frozenset of id(parameter) -- only those parameters' operands (a FlatAdam passes its own: with two models in one process, RC-Net's
+    step does not re-pack the Scale Map Learner's weights); None: every cached operand."""
     live = []
     for wid, ent in list(_pack_cache.items()):
+        if owner is not None and wid not in owner:
+            continue
         w = ent["ref"]()
         if w is None:
             continue
@@ -789,25 +815,27 @@ def refresh_packed():
             live.append((w, buf, mode, dt, cpad))
     if not live:
         return
-    sig = tuple((w.data_ptr(), buf.data_ptr(), mode, dt, cpad) for w, buf, mode, dt, cpad in live)
+    sig = tuple((w.data_ptr(), buf.data_ptr(), mode, dt, cpad) for w, buf, mode, dt, cpad in live) + (_state["pack_vec"],)
     halves = {dt for _, _, _, dt, _ in live if dt != RD_F32}
     if len(halves) > 1:
         raise RuntimeError("cached packed weights mix bf16 and fp16 operands: call engine.clear_caches() when switching the compute dtype")
     half = halves.pop() if halves else RD_BF16
-    if _pack_table.get("sig") != sig:
+    tab = _pack_table.setdefault(owner, {})
+    if tab.get("sig") != sig:
         items = (_lib.PackItem * len(live))()
         for it, (w, buf, mode, dt, cpad) in zip(items, live):
             cout, cin, kh, kw = w.shape if w.dim() == 4 else (w.shape[0], w.shape[1], 1, 1)
             # inside the table the item dtype is 0 (fp32) or 1 (the 16-bit type named by `half`, rd_conv_pack_weights_batch_half)
             it.w, it.packed, it.Cout, it.Cin, it.KH, it.KW, it.mode, it.dtype = w.data_ptr(), buf.data_ptr(), cout, (cpad or cin), kh, kw, mode, (0 if dt == RD_F32 else 1)
             it.Cin_src = cin if cpad else 0
+            it.reserved = 0 if _state["pack_vec"] else 1
         host = torch.frombuffer(bytearray(bytes(items)), dtype=torch.uint8)
-        _pack_table["dev"] = host.to(live[0][0].device)
-        _pack_table["sig"] = sig
-        _pack_table["n"] = len(live)
-        _pack_table["keep"] = [b for _, b, _, _, _ in live]
+        tab["dev"] = host.to(live[0][0].device)
+        tab["sig"] = sig
+        tab["n"] = len(live)
+        tab["keep"] = [b for _, b, _, _, _ in live]
     w0 = live[0][0]
-    _chk(L().rd_conv_pack_weights_batch_half(_p(_pack_table["dev"]), _pack_table["n"], half, _stream(w0)), "rd_conv_pack_weights_batch_half")
+    _chk(L().rd_conv_pack_weights_batch_half(_p(tab["dev"]), tab["n"], half, _stream(w0)), "rd_conv_pack_weights_batch_half")
 
 
 # ------------------------------------------------------------------------------------------ virtual activations

@@ -47,6 +47,7 @@ class FlatAdam(object):
         self.exp_avg_sq = torch.zeros(n, dtype=torch.float32, device=dev)
         self._gviews = {}
         self._index = {}
+        self._owner = frozenset(id(p) for p in params)      # engine.refresh_packed: whose cached operands this optimizer's step re-packs
         with torch.no_grad():
             for i, (p, o) in enumerate(zip(params, self.offsets)):
                 view = self.flat_param[o:o + p.numel()].view(p.shape)
@@ -184,7 +185,7 @@ class FlatAdam(object):
                 i = j + 1
         if guarded:
             engine._chk(engine.L().rd_adam_skip_count(engine._p(self._overflow), engine._stream(self.flat_param)), "rd_adam_skip_count")
-        engine.refresh_packed()   # one launch re-packs every cached MFMA operand of the rewritten parameters
+        engine.refresh_packed(self._owner)   # one launch re-packs every cached MFMA operand of the rewritten parameters (this optimizer's only)
 
     # ------------------------------------------------------------------ checkpoint interchange with torch.optim.Adam
     def state_dict(self):

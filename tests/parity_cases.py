@@ -1403,25 +1403,27 @@ def _module_grads(model):
     return {k: torch.cat([p.grad.detach().float().reshape(-1) for p in m.parameters() if p.grad is not None]).cpu() for k, m in groups.items()}
 
 
-def rcnet_fullsize_oracle_case(dev, tol=TOL):
+def rcnet_fullsize_oracle_case(dev, tol=TOL, cfg=None, images=1, hw=(256, 512), seed=77):
     """configs[1] geometry at full size on ONE image: 3x256x512 thermal edge-padded to 496x612, K = 30 radar points, patch 240x100
     (R = 30 RoIs; every launch geometry of the B = 8 step except the batch factor) -- fp32 HIP path vs the oracle: logits and loss
-    within 1e-3, labels exact, per-module gradient vectors within 5e-3 relative L2."""
+    within 1e-3, labels exact, per-module gradient vectors within 5e-3 relative L2.  cfg / images / hw: another geometry (rcnet_ntu_geometry_case)."""
     from riders_amd import engine, rcnet_main
-    cfg = rcnet_main.ZJU_CONFIG
+    cfg = cfg or rcnet_main.ZJU_CONFIG
+    ph, pw = cfg['patch_size']
     torch.manual_seed(0)
     model = rcnet_main.build_model(dev, cfg)
     model.train()
     sd_e = leaves(model.encoder.state_dict()); sd_d = leaves(model.decoder.state_dict())
-    batch = rcnet_main.synthetic_batch(1, 256, 512, cfg, seed=77)
+    batch = rcnet_main.synthetic_batch(images, hw[0], hw[1], cfg, seed=seed)
     image, pts, rois, gt = rcnet_main.prepare_batch(tuple(b.to(dev) for b in batch))
     label, valid = engine.rcnet_labels(gt, pts, 0.5)
     logits = model.forward(image, pts, rois)
     loss, _ = model.compute_loss(logits, label, valid, 2.5)
     loss.backward()
-    pts_c = batch[1].reshape(-1, 3); gt_c = batch[3].reshape(-1, 1, 240, 100)
+    pts_c = batch[1].reshape(-1, 3); gt_c = batch[3].reshape(-1, 1, ph, pw)
     lab_c, val_c = O.rcnet_labels(gt_c, pts_c, 0.5)
     assert torch.equal(label.cpu(), lab_c) and torch.equal(valid.cpu(), val_c)
+    assert logits.shape == (images * cfg['total_points_sampled'], 1, ph, pw)
     ref = O.rcnet_forward(batch[0] / 255.0, pts_c, [b for b in batch[2]], sd_e, sd_d, cfg['patch_size'], True)
     ref_loss = O.rcnet_loss(ref, lab_c, val_c, 2.5)
     ref_loss.backward()
@@ -1617,6 +1619,164 @@ def rcnet_fullsize_bf16_case(dev, tol_logits=6e-2, tol_grad=0.12):
         cos = float(torch.dot(g16[k], g32[k]) / (g16[k].norm() * g32[k].norm()))
         print("bf16 vs fp32 gradient %-14s relative L2 %.3e  cosine %.6f" % (k, err, cos))
         assert err <= tol_grad and cos >= 0.99, "bf16 %s gradient: relative L2 error %.3e, cosine %.5f" % (k, err, cos)
+
+
+def rcnet_ntu_geometry_case(dev, tol=TOL):
+    """Nothing is specialised to the ZJU shapes: the reference's OTHER RC-Net configuration (RCNet/train_rcnet_ntu.py:28-30: patch 150x50, K = 40
+    points per image) at B = 4 (R = 160 RoIs) on 192x320 frames, fp32 HIP path vs the oracle -- logits and loss within 1e-3, labels exact,
+    per-module gradients within 5e-3.  What changes against ZJU: the latent is 4x1 (L = 4 tokens, point MLP output 512), the pooled skips are
+    75x25 / 37x12 / 18x6 / 9x3, only two of the five up-convolutions are exact 2x (18x6 from 9x3, 150x50 from 75x25), RoI windows of 3 pixels."""
+    from riders_amd import engine, rcnet_main
+    cfg = dict(rcnet_main.ZJU_CONFIG, patch_size=[150, 50], total_points_sampled=40)
+    for k in engine.lazy_counts:
+        engine.lazy_counts[k] = 0
+    rcnet_fullsize_oracle_case(dev, tol, cfg=cfg, images=4, hw=(192, 320), seed=81)
+    c = engine.lazy_counts
+    assert c["head_fused"] == 1 and c["head_unfused_bwd"] == 0, c      # the fused decoder head takes this geometry too (the on-source up-convolutions are 16-bit routes)
+
+
+def rcnet_bf16_convergence_case(dev, steps=150):
+    """VERDICT r05 missing #3: does the driver-timed precision TRAIN like fp32?  The protocol of parity_cases_sml.sml_bf16_convergence_case on
+    RC-Net: `steps` optimisation steps (RCNet/rcnet_main.py:272-359: labels, forward, masked BCE, backward, Adam lr 2e-4) on one synthetic batch
+    (2 frames of 128x256, K = 30, patch 240x100: R = 60 RoIs) from identical weights in fp32 and bf16, plus an fp32 run whose initial weights
+    are perturbed by 1e-6 relative -- the yardstick for what "the same training run" means in fp32 itself.  Why this and not a tighter
+    gradient bound: tools/grad_localise.py (profiles/r06_grad_localise.txt) shows that the per-step gradient difference between bf16 and
+    fp32 is NOT accumulated rounding on the small latent tensors -- the activation gradient is already 16 % (relative L2) apart two layers
+    below the loss, where the parameter gradient of the same layers agrees to 0.5 %: a 2-3 % forward deviation flips the LeakyReLU slope
+    (1 <-> 0.2) of the ~2 % of the elements that sit next to zero, which is a 0.8 |g| error on those elements = sqrt(0.02 * 0.64) ~ 11 % in
+    L2, noise-like, averaged away by the millions of pixels behind a decoder weight and only by 5 040 token rows behind a transformer
+    weight.  It is a property of training this network in ANY 16-bit activation format; what has to hold is that the optimisation
+    trajectory is the same.  Bands (printed with the measurement): first loss within 1 %; both runs fall below 0.75 x their first loss; the
+    10-step window medians from step 10 within max(2 %, 3 x the fp32 self-sensitivity) of the fp32 curve; the final eval-mode loss (running
+    statistics, the same batch) within max(3 %, 3 x the self-sensitivity)."""
+    from riders_amd import engine, rcnet_main
+    from riders_amd.optim import FlatAdam
+    cfg = rcnet_main.ZJU_CONFIG
+    batch_cpu = rcnet_main.synthetic_batch(2, 128, 256, cfg, seed=91)
+    curves, evals = {}, {}
+    for mode in ("fp32", "bf16", "fp32 perturbed"):
+        engine.set_compute_dtype(mode[:4]); engine.clear_caches()
+        try:
+            torch.manual_seed(0)
+            m = rcnet_main.build_model(dev, cfg)
+            m.train()
+            opt = FlatAdam(m.parameters(), lr=cfg['learning_rate'])
+            if mode.endswith("perturbed"):
+                with torch.no_grad():
+                    opt.flat_param.mul_(1.0 + 1e-6)
+                engine.refresh_packed()
+            batch = tuple(b.to(dev) for b in batch_cpu)
+            engine.set_deterministic_roi_pool(True)      # (the small maps' RoI-pool backward otherwise scatters with fp32 atomics: run-to-run noise)
+            try:
+                curves[mode] = np.array([float(rcnet_main.train_step(m, opt, batch, cfg)) for _ in range(steps)])
+            finally:
+                engine.set_deterministic_roi_pool(False)
+            m.eval()
+            with torch.no_grad():
+                evals[mode] = float(rcnet_main.forward_loss(m, batch, cfg))
+            engine.check_roi_overflow()
+        finally:
+            engine.set_compute_dtype("fp32"); engine.clear_caches(); engine.set_param_grad_allocator(None)
+    f, b, p = curves["fp32"], curves["bf16"], curves["fp32 perturbed"]
+    assert np.all(np.isfinite(b)) and np.all(np.isfinite(f)) and np.all(np.isfinite(p))
+
+    def medians(c):
+        return np.array([np.median(c[i:i + 10]) for i in range(10, steps - 9, 10)])
+    mf, mb, mp = medians(f), medians(b), medians(p)
+    dev_b, dev_p = np.abs(mb - mf) / mf, np.abs(mp - mf) / mf
+    ev_b, ev_p = abs(evals["bf16"] - evals["fp32"]) / evals["fp32"], abs(evals["fp32 perturbed"] - evals["fp32"]) / evals["fp32"]
+    print("RC-Net convergence: loss[0] %.5f / %.5f (fp32 / bf16), loss[-1] %.5f / %.5f, 10-step medians from step 10: max |bf16 - fp32| / fp32 %.4f, fp32 "
+          "self-sensitivity (1e-6 weight perturbation) %.4f, eval-mode loss %.5f / %.5f (bf16 off by %.4f, perturbed fp32 by %.4f)" % (
+              f[0], b[0], f[-1], b[-1], dev_b.max(), dev_p.max(), evals["fp32"], evals["bf16"], ev_b, ev_p))
+    assert abs(b[0] - f[0]) <= 0.01 * f[0], (b[0], f[0])
+    assert f[-1] < 0.75 * f[0] and b[-1] < 0.75 * b[0], (f[0], f[-1], b[0], b[-1])
+    assert dev_b.max() <= max(0.02, 3.0 * dev_p.max()), (dev_b.max(), dev_p.max())
+    assert ev_b <= max(0.03, 3.0 * ev_p), (evals, ev_b, ev_p)
+
+
+def integration_aliasing_case(dev, tol=TOL):
+    """INTEGRATION.md section 1, executed against libriders_hip.so with no reference file in sight: the aliasing block makes the reference's
+    top-level module names resolve to riders_amd's modules; a training loop written the way RCNet/rcnet_main.py:272-359 writes it (imports
+    by those names, label build with torch ops, model.forward / compute_loss, optimizer.zero_grad, loss.backward, torch.optim.Adam.step,
+    loss.item) then runs two steps on synthetic tensors, and its per-step losses are compared with the oracle trained the same way."""
+    import importlib
+    import sys
+    import riders_amd.linear_attention
+    import riders_amd.net_utils
+    import riders_amd.networks
+    import riders_amd.rcnet_model
+    from riders_amd import rcnet_main
+    saved = {k: sys.modules.get(k) for k in ("networks", "linear_attention", "rcnet_model", "utils", "utils.net_utils")}
+    try:
+        # ---- the block of INTEGRATION.md section 1 (sitecustomize.py or the top of RCNet/train_rcnet_zju.py)
+        sys.modules['networks'] = riders_amd.networks                 # RCNet/rcnet_model.py:3
+        sys.modules['linear_attention'] = riders_amd.linear_attention  # RCNet/networks.py:4
+        sys.modules['rcnet_model'] = riders_amd.rcnet_model            # RCNet/rcnet_main.py:7
+        if 'utils' not in sys.modules:      # (the reference's `utils` package is not on this box: a stand-in module object carries the alias)
+            import types
+            sys.modules['utils'] = types.ModuleType('utils')
+        sys.modules['utils'].net_utils = riders_amd.net_utils           # RCNet/networks.py:2
+        sys.modules['utils.net_utils'] = riders_amd.net_utils
+        # ---- from here on: what the unchanged script does (RCNet/rcnet_main.py:7, :178-238, :272-359)
+        RCNetModel = importlib.import_module('rcnet_model').RCNetModel
+        cfg = dict(rcnet_main.ZJU_CONFIG, patch_size=[64, 32], total_points_sampled=4)
+        torch.manual_seed(3)
+        model = RCNetModel(input_channels_image=3, input_channels_depth=3, input_patch_size_image=cfg['patch_size'], encoder_type=cfg['encoder_type'],
+                           n_filters_encoder_image=cfg['n_filters_encoder_image'], n_neurons_encoder_depth=cfg['n_neurons_encoder_depth'],
+                           decoder_type=cfg['decoder_type'], n_filters_decoder=cfg['n_filters_decoder'], weight_initializer=cfg['weight_initializer'],
+                           activation_func=cfg['activation_func'], device=dev)
+        assert type(model.encoder).__module__ == "riders_amd.networks"
+        model.train()
+        sd_e = leaves(model.encoder.state_dict()); sd_d = leaves(model.decoder.state_dict())
+        optimizer = torch.optim.Adam([{'params': model.parameters(), 'weight_decay': 0.0}], lr=cfg['learning_rate'])
+        batch = rcnet_main.synthetic_batch(2, 64, 96, cfg, seed=17)
+        image, radar_points, bounding_boxes_list, ground_truth = [t_.to(dev) for t_ in batch]
+        image = image / 255.0                                           # rcnet_transforms.py:258-261
+        B, K = radar_points.shape[:2]
+        radar_points = radar_points.view(B * K, 3)                      # rcnet_main.py:300-306
+        ground_truth = ground_truth.view(B * K, 1, *cfg['patch_size'])
+        bounding_boxes_list = [bounding_boxes_list[b] for b in range(B)]     # rcnet_main.py:338-340: a python list of B (K, 4) tensors
+        losses = []
+        for _ in range(2):
+            # label / validity build with torch ops, as rcnet_main.py:308-332 has it
+            z = radar_points[:, 2].view(-1, 1, 1, 1)
+            validity_map = torch.where(ground_truth > 0, torch.ones_like(ground_truth), torch.zeros_like(ground_truth))
+            label = torch.where((torch.abs(ground_truth - z) < cfg['max_distance_correspondence']) & (ground_truth > 0),
+                                torch.ones_like(ground_truth), torch.zeros_like(ground_truth))
+            logits = model.forward(image=image, point=radar_points, bounding_boxes=bounding_boxes_list, return_logits=True)
+            loss, loss_info = model.compute_loss(logits=logits, ground_truth=label, validity_map=validity_map, w_positive_class=cfg['w_positive_class'])
+            optimizer.zero_grad()
+            loss.backward()
+            optimizer.step()
+            losses.append(loss.item())
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
+    # the oracle trained the same way (CPU): same initial weights, same batch, Adam with torch's defaults
+    params = [v for d in (sd_e, sd_d) for v in d.values() if v.requires_grad]
+    state = [(torch.zeros_like(v), torch.zeros_like(v)) for v in params]
+    pts_c = batch[1].reshape(-1, 3); gt_c = batch[3].reshape(-1, 1, *cfg['patch_size'])
+    lab_c, val_c = O.rcnet_labels(gt_c, pts_c, cfg['max_distance_correspondence'])
+    ref = []
+    for step in range(2):
+        for v in params:
+            v.grad = None
+        lg = O.rcnet_forward(batch[0] / 255.0, pts_c, [b for b in batch[2]], sd_e, sd_d, cfg['patch_size'], True)
+        l_ = O.rcnet_loss(lg, lab_c, val_c, cfg['w_positive_class'])
+        l_.backward()
+        ref.append(float(l_))
+        with torch.no_grad():
+            for v, (m1, m2) in zip(params, state):
+                if v.grad is not None:
+                    pn, a, b_ = O.adam_step(v, v.grad, m1, m2, step + 1, cfg['learning_rate'])
+                    v.copy_(pn); m1.copy_(a); m2.copy_(b_)
+    print("aliased unchanged-caller loop vs oracle: losses %s / %s" % (losses, ref))
+    for a, b_ in zip(losses, ref):
+        assert abs(a - b_) <= tol * abs(b_), (losses, ref)
+    assert losses[1] != losses[0]
 
 
 def bf16_exact_conv_case(dev, cin=16, cout=16, k=3, s=1, H=9, W=7, N=2, up=None, cin2=0, report=False, half=torch.bfloat16):

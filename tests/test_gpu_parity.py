@@ -575,3 +575,20 @@ def test_stride2_dgrad_parity_classes(gpu):
 def test_skinny_linear(gpu):
     P.skinny_linear_cases(gpu)
 
+
+
+def test_rcnet_ntu_geometry_fp32_vs_oracle(gpu):
+    """the reference's other RC-Net geometry (patch 150x50, K = 40, B = 4) -- nothing is specialised to the ZJU shapes"""
+    P.rcnet_ntu_geometry_case(gpu)
+
+
+def test_rcnet_bf16_trains_like_fp32(gpu):
+    """150 optimisation steps, bf16 against fp32 against fp32's own sensitivity"""
+    P.rcnet_bf16_convergence_case(gpu)
+
+
+def test_integration_aliasing_block_against_the_hip_library(gpu):
+    """INTEGRATION.md section 1's aliasing block + an unchanged-caller loop, two steps, losses vs the oracle"""
+    from riders_amd import _lib
+    assert _lib.load()._name.endswith("libriders_hip.so")
+    P.integration_aliasing_case(gpu)

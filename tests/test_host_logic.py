@@ -317,36 +317,56 @@ def test_bench_line_stays_under_the_driver_limit():
             timer.records.setdefault(kind, []).append((Ev(0.0), Ev(0.05 + 0.001 * i + 0.0001 * j), 4e10 if "conv" in n else 0.0,
                                                        "layer %d shape M=%d Cin=128 Cout=256 with a long description string %s" % (i, 1000 * j, "x" * 60),
                                                        1e8, n, 5))
-    roof = bench.kernel_roofline(timer, 3, 7.4, "bf16", "rcnet_b8_256x512_bf16")
-    roof_c = bench.kernel_roofline(timer, 3, 7.4, "bf16", "rcnet_b8_256x512_bf16", conv_only=True, with_tables=False)
-    assert "kernels" in roof and "families" in roof and len(json.dumps(roof)) > 4000
+    prof = {n: (4.0, 4 * 52000.0) for n in names}      # what the kernel-trace child returns: (calls per step, ns per step)
+    live = {n: dict(bytes_per_launch=9.0e7, dispatches=12, mfma_util=0.31, mfma_busy_cycles=4.0e7, gui_active=1.0e6) for n in names}
+    roofs = bench.build_rooflines(timer, 3, 7.4, "bf16", prof, live, "rcnet_b8_256x512_bf16")
+    assert "kernels" in roofs and "families" in roofs and len(json.dumps(roofs)) > 4000
+    dom = roofs["roofline"]
+    assert dom["kernel"] == "conv_gemm_kernel" and dom["instantiations"] == 40 and dom["what"] == "kernel family"      # the FAMILY with the largest summed time
+    assert abs(dom["avg_launch_us"] - 52.0) < 1e-6 and "rocprofv3" in dom["duration_source"] and dom["traffic_live"] and abs(dom["mfma_util"] - 40.0 / 128.0) < 1e-9
+    assert abs(dom["frac"] - dom["achieved"] / dom["peak"]) < 1e-12
+    assert roofs["roofline_kernel"]["what"] == "kernel instantiation"
+    no_prof = bench.build_rooflines(timer, 3, 7.4, "bf16", None, None, "k")["roofline"]
+    assert "HIP events" in no_prof["duration_source"] and no_prof["traffic"] is None
     leg = dict(value=1089.123456789, ms_per_step=7.3456789, steps=200, warmup=10, settle_steps=250, final_loss=0.69314718, batch_per_gpu=8, height=256,
-               width=512, launch_mode="one hipGraph (fwd+bwd) + eager Adam", roofline=roof, roofline_conv=roof_c)
-    args = argparse.Namespace(workload="rcnet", steps=200, warmup=10, dtype="bf16", config3=False, allreduce="all_reduce")
+               width=512, launch_mode="one hipGraph (fwd+bwd) + eager Adam", launches_per_step=352.0, kernel_ms_per_step=6.9, **roofs)
+    chain = dict(value=601.5, ms_per_step=26.6, steps=200, warmup=10, settle_steps=80, final_loss=0.5, images_per_step=16, batch_per_gpu=16, height=256, width=512,
+                 launch_mode="per stage: one hipGraph (fwd+bwd) + eager Adam")
+    args = argparse.Namespace(workload="chain", steps=200, warmup=10, dtype="bf16", config3=False, allreduce="all_reduce")
     cpu = dict(value=1.61745833, unit="imgs/s", cores=16, kind="port", host_cpus=256, thread_sweep_b1={"8": 1.4, "16": 1.6, "32": 1.2},
                sample="oracle RC-Net full step (fwd+loss+bwd+Adam), B=1 (30 ROIs, 256x512), fp32, best of 2 timed steps after 1 warm-up per thread count",
-               rcnet_b8=dict(value=1.2, unit="imgs/s", cores=16, sample="one B=8 step"), seconds=13.4)
-    val = dict(hip=0.379146, oracle=0.379123, max_abs_diff=2.7e-5, sample="2 synthetic frames")
-    full = bench.full_record(args, 1, dict(backend="nccl (RCCL)", world_size=1, rccl_version="2.26.6"), True, leg, leg,
-                             {"fp32": leg, "config4": leg, "config4_sml": leg}, cpu, val)
+               rcnet_b8=dict(value=1.2, unit="imgs/s", cores=16, sample="one B=8 step"), chained=dict(value=0.9, unit="imgs/s"), seconds=13.4)
+    val = dict(oracle=0.379123, sample="8 synthetic 256x512 frames (network input 288x576), random-init weights identical on every path",
+               fp32=dict(hip=0.379146, diff_of_means=2.3e-5, max_abs_diff=2.7e-5), bf16=dict(hip=0.3801, diff_of_means=1e-3, max_abs_diff=2e-3), hip=0.379146, max_abs_diff=2.7e-5)
+    caller = dict(rcnet=dict(value=400.0, ms_per_step=20.0, launches_per_step=1900.0, graphed_value=1100.0, launch_mode="eager"),
+                  sml=dict(value=500.0, ms_per_step=32.0, launches_per_step=3000.0, graphed_value=1290.0))
+    full = bench.full_record(args, 1, dict(backend="nccl (RCCL)", world_size=1, rccl_version="2.26.6"), True, chain, leg, dict(leg, batch_per_gpu=16),
+                             {"fp32": leg, "config4": leg, "config4_sml": leg}, cpu, val, caller)
     assert len(json.dumps(full)) > 15000          # the kind of record round 4 printed on stdout
     text = bench.render_line(bench.compact_line(full))
     assert len(text) < 6000 and "\n" not in text
     line = json.loads(text)
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
-              "config", "roofline", "cpu_baseline"):
+              "config", "roofline", "cpu_baseline", "rcnet", "sml", "roofline_families", "unchanged_caller", "val_abs_rel"):
         assert k in line, k
-    assert line["unit"] == "imgs/s" and line["config"]["workload"].startswith("RC-Net") and "model" not in line["config"]
+    assert line["metric"] == "train imgs/sec (RC-Net+SML, 256x512)"       # BASELINE.json's metric, word for word
+    assert line["unit"] == "imgs/s" and "RC-Net" in line["config"]["workload"] and "SML" in line["config"]["workload"] and "model" not in line["config"]
+    assert line["config"]["global_batch"] == 16
     r = line["roofline"]
-    for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "launches_per_step", "avg_launch_us"):
+    for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "launches_per_step", "avg_launch_us", "avg_launch_us_hip_events"):
         assert k in r, k
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and "kernels" not in r and "families" not in r and "shapes" not in r
     assert set(line["cpu_baseline"]) >= {"value", "unit", "cores", "kind", "sample"}
-    for name in ("sml", "fp32", "config4", "config4_sml"):
-        assert set(line[name]) == {"value", "unit", "ms_per_step", "dtype", "config", "roofline"} and set(line[name]["roofline"]) <= {"kernel", "bound", "frac"}
+    for name in ("rcnet", "sml", "fp32", "config4", "config4_sml"):
+        assert set(line[name]) <= {"value", "unit", "ms_per_step", "dtype", "config", "roofline", "launches_per_step"} and set(line[name]["roofline"]) <= {"kernel", "bound", "frac"}
+    assert set(line["val_abs_rel"]) == {"oracle", "frames", "fp32", "bf16"} and line["unchanged_caller"]["rcnet"]["launches_per_step"] == 1900.0
     # a pathological field cannot lose the line: optional blocks are dropped instead
     big = dict(bench.compact_line(full), comm={"x": "y" * 9000})
     assert len(bench.render_line(big)) < 6000 and "value" in json.loads(bench.render_line(big))
+    # a run under a profiler starts no profiler of its own, and its children would not inherit the outer one's environment
+    env = {"LD_PRELOAD": "/opt/rocm/lib/librocprofiler-sdk-tool.so:/x/libfoo.so", "ROCP_TOOL_LIBRARIES": "x", "ROCPROF_OUTPUT_PATH": "/tmp/o", "PATH": "/bin"}
+    assert bench.under_profiler(env) and not bench.under_profiler({"PATH": "/bin", "LD_PRELOAD": "/x/libfoo.so"})
+    assert bench.clean_profiler_env(env) == {"LD_PRELOAD": "/x/libfoo.so", "PATH": "/bin"}
 
 
 def test_c_abi_comm_loopback_and_bucketing(emu):
