@@ -94,6 +94,10 @@ int rd_conv_pack_weights_batch(const rd_pack_item* items, int32_t n, void* strea
 /* the same for a table whose 16-bit items are fp16: inside the table the item dtype is 0 (fp32) or 1 (the 16-bit type), half_dtype = RD_BF16
    (identical to the call above) or RD_F16 says which 16-bit format that is */
 int rd_conv_pack_weights_batch_half(const rd_pack_item* items, int32_t n, int32_t half_dtype, void* stream);
+/* the same with a caller-built block map (DEVICE array of `blocks` int32[4] = (item index, block of the item, blocks of the item, 0); every item needs
+   at least one block): the launch has exactly the blocks the operands need instead of 256 per item -- RC-Net's ~320 small operands made the
+   fixed grid a launch bound by block dispatch (riders_amd.engine.refresh_packed sizes an item at one thread per 16-byte unit group) */
+int rd_conv_pack_weights_batch_map(const rd_pack_item* items, int32_t n, int32_t half_dtype, const int32_t* block_map, int32_t blocks, void* stream);
 /* Weight gradients of MANY 1x1 / linear layers in one launch + one ordered reduction (reference: autograd of the nn.Linear layers of
    RCNet/linear_attention.py:84-135; 96 products per RC-Net step).  gemm p: slab_p[split][Cout][C1+C2] = partial dY_p^T [X1_p | X2_p]
    over tokens [split*rows_per_split, ...); C1, C2, Cout multiples of the 16-byte vector (4 fp32 / 8 bf16), C1 % 64 == 0 when C2 > 0.  reduce q: dw_q[elems] (+)= sum of nsplit

@@ -10,6 +10,9 @@
 #include <stdio.h>
 #include <string.h>
 #include <stdlib.h>
+// (declared here rather than in rd_kernels_decl.h, which every kernel unit includes)
+namespace rd { void launch_pack_weights_batch_map(const void* items, int n, const void* map, int blocks, hipStream_t st); }
+namespace rd_f16 { void launch_pack_weights_batch_map(const void* items, int n, const void* map, int blocks, hipStream_t st); }
 
 namespace {
 thread_local char g_err[512] = "";
@@ -143,6 +146,13 @@ int rd_conv_pack_weights_batch_half(const rd_pack_item* items, int32_t n, int32_
   if (half_dtype != RD_BF16 && half_dtype != RD_F16) return fail("pack_weights_batch_half: half_dtype must be RD_BF16 or RD_F16");
   RD_NS(half_dtype, launch_pack_weights_batch)(items, n, S(stream));
   return done("rd_conv_pack_weights_batch_half");
+}
+int rd_conv_pack_weights_batch_map(const rd_pack_item* items, int32_t n, int32_t half_dtype, const int32_t* block_map, int32_t blocks, void* stream) {
+  if (n <= 0 || blocks <= 0) return 0;
+  if (!items || !block_map) return fail("pack_weights_batch_map: null table");
+  if (half_dtype != RD_BF16 && half_dtype != RD_F16) return fail("pack_weights_batch_map: half_dtype must be RD_BF16 or RD_F16");
+  RD_NS(half_dtype, launch_pack_weights_batch_map)(items, n, block_map, blocks, S(stream));
+  return done("rd_conv_pack_weights_batch_map");
 }
 int rd_linear_wgrad_batch(const rd_lwg_gemm* gemms, int32_t n_gemm, const rd_lwg_reduce* reduces, int32_t n_reduce, int32_t dtype,
                           void* stream) {

@@ -417,12 +417,19 @@ __device__ __forceinline__ void pack_one_vec(const PackItem& it, int bx, int nbx
   T* out = (T*)it.out;
   const float* __restrict__ w = it.w;
   const int CG = C / VE;                                   // channel groups per row
-  const bool by_row = it.mode == 1 || it.mode == 3;        // consecutive work items walk the rows (coalesced reads of the transposed operand)
-  const int64_t items = (int64_t)rows * CG;
+  const bool by_row = it.mode == 1 || it.mode == 3;        // source rows follow Cin (the transposed operand)
+  // A wave owns a tile of 8 rows x 8 channel groups, lane = 8 * group + row: the row-major stores of one tap are 8 rows x 128 contiguous bytes,
+  // the fragment-ordered stores 8 groups x 128 contiguous bytes (16 consecutive rows of a k-group are adjacent there), the source reads are
+  // 8 adjacent runs (modes 0 / 2: 8 x VE x KK floats of one output channel; modes 1 / 3: KK floats of 8 adjacent input channels).  Whole
+  // 128-byte lines in every store is what matters: with scattered 16-byte stores the launch was SLOWER than the element-wise form on
+  // RC-Net's many small operands (104 vs 84 us; profiles/r06_microbench/pack_vec.txt).
+  const int tiles_c = (CG + 7) >> 3, tiles_r = (rows + 7) >> 3;
+  const int64_t items = (int64_t)tiles_r * tiles_c * 64;
   for (int64_t u = (int64_t)bx * 256 + threadIdx.x; u < items; u += (int64_t)nbx * 256) {
-    int row, cg;
-    if (by_row) { cg = (int)(u / rows); row = (int)(u - (int64_t)cg * rows); }
-    else { row = (int)(u / CG); cg = (int)(u - (int64_t)row * CG); }
+    const int64_t tile = u >> 6;
+    const int ln = (int)(u & 63), tr = (int)(tile / tiles_c), tc = (int)(tile - (int64_t)tr * tiles_c);
+    const int row = tr * 8 + (ln & 7), cg = tc * 8 + (ln >> 3);
+    if (row >= rows || cg >= CG) continue;
     const int c0 = cg * VE;
     if (KK == 1) {
       float v[VE];
@@ -1483,6 +1490,20 @@ void launch_pack_weights(const float* w, void* out, int Cout, int Cin, int KH, i
     hipLaunchKernelGGL((pack_weights_kernel<float>), dim3(grid), dim3(256), 0, st, w, (float*)out, Cout, Cin, KH, KW, mode, rows_pad, Kpad, CinSrc);
   else
     hipLaunchKernelGGL((pack_weights_kernel<bf16_t>), dim3(grid), dim3(256), 0, st, w, (bf16_t*)out, Cout, Cin, KH, KW, mode, rows_pad, Kpad, CinSrc);
+}
+
+// the same with a block map (round 6): block b works on item map[b].x as block map[b].y of map[b].z -- the grid is the SUM of what the items
+// need instead of 256 x n blocks of which 97 % exit at once (RC-Net: ~320 operands, 82 K blocks, a launch bound by block dispatch)
+__global__ __launch_bounds__(256) void pack_weights_batch_map_kernel(const PackItem* __restrict__ items, const int4* __restrict__ map) {
+  const int4 m = map[blockIdx.x];
+  const PackItem it = items[m.x];
+  const bool vec = rd_pack_vec_enabled(it);
+  if (it.dtype == 0) { if (vec && pack_vec_ok<float>(it)) pack_one_vec<float>(it, m.y, m.z); else pack_one<float>(it, m.y, m.z); }
+  else { if (vec && pack_vec_ok<bf16_t>(it)) pack_one_vec<bf16_t>(it, m.y, m.z); else pack_one<bf16_t>(it, m.y, m.z); }
+}
+void launch_pack_weights_batch_map(const void* items, int n, const void* map, int blocks, hipStream_t st) {
+  (void)n;
+  hipLaunchKernelGGL(pack_weights_batch_map_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const PackItem*)items, (const int4*)map);
 }
 
 void launch_pack_weights_batch(const void* items, int n, hipStream_t st) {

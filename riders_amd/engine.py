@@ -52,10 +52,11 @@ _state = {"dtype": RD_F32, "tape": None, "defer_wgrad": True, "fused_loftr": Tru
           # element in epilogues that are already issue bound): 1021.8 -> 1007.1 img/s on one box, alternating.  Off by default.
           "bn_bwd_fused": False,
           "dw_fused_stats": True,          # depthwise convolution with the BatchNorm statistics in its epilogue; False: separate rd_bn_stats pass
-          "pack_vec": True}                # the batched weight re-pack in 16-byte units with coalesced reads (round 6); False: the element-wise form
+          "pack_vec": True,                # the batched weight re-pack in 16-byte units with coalesced reads (round 6); False: the element-wise form
+          "pack_map": True}                # ... launched with a block map (the blocks the operands need); False: 256 blocks per operand
 
 _SWITCHES = {"fuse_upsample_bwd": bool, "loftr_cross_inplace": bool, "fuse_res_add": bool, "fuse_grad_add": bool, "lazy_bn": (0, 2), "bn_head": bool, "up2_on_source": bool, "up2_dgrad": bool, "fusion_conv_first": bool, "roi_u8": bool,
-             "roi_bwd": ("auto", "gather", "tile", "atomic"), "bn_recompute": bool, "bn_bwd_fused": bool, "dw_fused_stats": bool, "pack_vec": bool, "roi_tile_min_blocks": (0, 1 << 30),
+             "roi_bwd": ("auto", "gather", "tile", "atomic"), "bn_recompute": bool, "bn_bwd_fused": bool, "dw_fused_stats": bool, "pack_vec": bool, "pack_map": bool, "roi_tile_min_blocks": (0, 1 << 30),
              "defer_wgrad": bool, "fused_loftr": bool, "deterministic_roi_pool": bool}
 
 
@@ -815,7 +816,7 @@ def refresh_packed(owner=None):
             live.append((w, buf, mode, dt, cpad))
     if not live:
         return
-    sig = tuple((w.data_ptr(), buf.data_ptr(), mode, dt, cpad) for w, buf, mode, dt, cpad in live) + (_state["pack_vec"],)
+    sig = tuple((w.data_ptr(), buf.data_ptr(), mode, dt, cpad) for w, buf, mode, dt, cpad in live) + (_state["pack_vec"], _state["pack_map"])
     halves = {dt for _, _, _, dt, _ in live if dt != RD_F32}
     if len(halves) > 1:
         raise RuntimeError("cached packed weights mix bf16 and fp16 operands: call engine.clear_caches() when switching the compute dtype")
@@ -834,8 +835,40 @@ def refresh_packed(owner=None):
         tab["sig"] = sig
         tab["n"] = len(live)
         tab["keep"] = [b for _, b, _, _, _ in live]
+        # block map: block -> (item, block of the item, blocks of the item): the launch has the blocks the operands need, not 256 per item
+        bmap = []
+        for i, (w, buf, mode, dt, cpad) in enumerate(live):
+            nb = _pack_blocks(w, mode, dt, cpad)
+            bmap += [(i, b, nb, 0) for b in range(nb)]
+        tab["map"] = torch.tensor(bmap, dtype=torch.int32).to(live[0][0].device)
+        tab["blocks"] = len(bmap)
     w0 = live[0][0]
-    _chk(L().rd_conv_pack_weights_batch_half(_p(tab["dev"]), tab["n"], half, _stream(w0)), "rd_conv_pack_weights_batch_half")
+    if _state["pack_map"]:
+        _chk(L().rd_conv_pack_weights_batch_map(_p(tab["dev"]), tab["n"], half, _p(tab["map"]), tab["blocks"], _stream(w0)), "rd_conv_pack_weights_batch_map")
+    else:
+        _chk(L().rd_conv_pack_weights_batch_half(_p(tab["dev"]), tab["n"], half, _stream(w0)), "rd_conv_pack_weights_batch_half")
+
+
+def _pack_blocks(w, mode, dt, cpad):
+    """256-thread blocks one packed operand gets in the batched re-pack: one thread per work item of the 16-byte-unit form (a tile of 8 rows x 8
+    channel groups per wave; csrc/rd_conv.hip pack_one_vec) or per element of the element-wise form; 1 .. 256.  Sizing only: the kernel's loops
+    cover an operand with any number of blocks."""
+    cout, cin, kh, kw = w.shape if w.dim() == 4 else (w.shape[0], w.shape[1], 1, 1)
+    if cpad:
+        cin = cpad
+    ve = 4 if dt == RD_F32 else 8
+    rows = 4 * cout if mode == 2 else (cin if mode else cout)
+    C = 4 * cout if mode == 3 else (cout if mode == 1 else cin)
+    kk = kh * kw
+    vec = _state["pack_vec"] and (kk == 1 or (kh == 3 and kw == 3)) and not cpad and C % ve == 0 and cin % 4 == 0 and (mode not in (2, 3) or (kk == 9 and cout % ve == 0))
+    if vec:
+        work = ((rows + 7) // 8) * ((C // ve + 7) // 8) * 64
+    else:
+        bn = 16 if rows <= 16 else (32 if rows <= 32 else (64 if rows <= 64 else 128))
+        bke = 32 if dt == RD_F32 else 64
+        work = ((rows + bn - 1) // bn * bn) * ((kk * C + bke - 1) // bke * bke)
+        work = (work + 3) // 4      # the element-wise form strides: four elements per thread
+    return max(1, min(256, (work + 255) // 256))
 
 
 # ------------------------------------------------------------------------------------------ virtual activations
