@@ -1471,7 +1471,7 @@ def roi_argmax(out):
     return torch.from_numpy(np.where(a == 255, -1, idx).astype(np.int32))
 
 
-def roi_pool(x, rois, output_size, spatial_scale, compact=None):
+def roi_pool(x, rois, output_size, spatial_scale, compact=None, out=None):
     """x (N,H,W,C); rois (R,5) fp32 = (batch idx, x1, y1, x2, y2) -> (R,PH,PW,C); the arg-max is kept for the backward as int32 pixel indices
     or (compact, the default where the kernels of this shape support it: round 4) as ONE BYTE per element, the arg-max's offset inside its bin
     window -- `roi_argmax(out)` gives the indices either way."""
@@ -1479,7 +1479,10 @@ def roi_pool(x, rois, output_size, spatial_scale, compact=None):
     N, H, W, C = x.shape
     R = rois.shape[0]
     PH, PW = int(output_size[0]), int(output_size[1])
-    out = torch.empty((R, PH, PW, C), dtype=x.dtype, device=x.device)
+    if out is None:
+        out = torch.empty((R, PH, PW, C), dtype=x.dtype, device=x.device)
+    else:      # written in place, e.g. into its half of the transformer's token matrix (no copy behind the pooling)
+        assert tuple(out.shape) == (R, PH, PW, C) and out.dtype == x.dtype and out.is_contiguous()
     if compact is None:
         compact = _state["roi_u8"]
     compact = bool(compact) and C % (16 // x.element_size()) == 0 and _state["roi_bwd"] in ("auto", "gather", "atomic") and PH < (1 << 19) and PW < (1 << 19) \
@@ -1595,12 +1598,31 @@ def linear_attention(q, k, v, N, Lq, S, H, eps=1e-6):
     return out
 
 
+def _common_base(a, b):
+    """the contiguous 2-D matrix whose two row ranges a and b are (in either order), or None"""
+    base = getattr(a, "_base", None)
+    if base is None or base is not getattr(b, "_base", None) or base.dim() != 2 or a.dim() != 2 or b.dim() != 2:
+        return None
+    if not (base.is_contiguous() and a.is_contiguous() and b.is_contiguous() and a.dtype == b.dtype == base.dtype):
+        return None
+    if a.shape[1] != base.shape[1] or b.shape[1] != base.shape[1] or a.shape[0] + b.shape[0] != base.shape[0]:
+        return None
+    es, p0 = base.element_size(), base.data_ptr()
+    lo, hi = (a, b) if a.data_ptr() <= b.data_ptr() else (b, a)
+    if lo.data_ptr() != p0 or hi.data_ptr() != p0 + lo.numel() * es:
+        return None
+    return base
+
+
 def rows_cat(a, b):
     """(Ra, C), (Rb, C) -> one (Ra + Rb, C) token matrix (copy).  The LoFTR transformer keeps both token streams in ONE buffer so that a
     'self' layer -- the same weights on both streams, no interaction (RCNet/linear_attention.py:171-173) -- is one launch over all
     2 N sequences instead of two launches of N workgroups each on a 256-CU chip."""
     t = tape()
     ra, rb = a.shape[0], b.shape[0]
+    base = _common_base(a, b)
+    if base is not None and a.data_ptr() == base.data_ptr():      # a and b ARE the two row ranges of one matrix (their producers wrote in place)
+        return rows_join(a, b, base)
     out = torch.empty((ra + rb, a.shape[1]), dtype=a.dtype, device=a.device)
     for src, dst in ((a, out[:ra]), (b, out[ra:])):
         _chk(L_().rd_cast(_p(src), _p(dst), src.numel(), rd_of(src), rd_of(dst), 1.0, _stream(src)), "rd_cast")
@@ -1798,7 +1820,13 @@ def concat_channels(a, b):
             g = t.pop_grad(out)
             if g is None:
                 return
-            ga, gb = torch.empty_like(a), torch.empty_like(b)
+            base = _common_base(a, b) if a.dim() == 2 else None
+            if base is not None:      # a and b are the halves of one token matrix: so are their gradients (rows_split's backward then needs no copy)
+                Gm = torch.empty_like(base)
+                ra_ = a.shape[0]
+                ga, gb = (Gm[:ra_], Gm[ra_:]) if a.data_ptr() == base.data_ptr() else (Gm[b.shape[0]:], Gm[:b.shape[0]])
+            else:
+                ga, gb = torch.empty_like(a), torch.empty_like(b)
             _chk(lib.rd_split2(_p(g), _p(ga), _p(gb), rows, Ca, Cb, dt, st), "rd_split2")
             t.add_grad(a, ga)
             t.add_grad(b, gb)
@@ -1806,10 +1834,14 @@ def concat_channels(a, b):
     return out
 
 
-def input_cast(x, scale=1.0):
-    """Region input (fp32) -> activation dtype; gradient flows back as fp32."""
+def input_cast(x, scale=1.0, out=None):
+    """Region input (fp32) -> activation dtype; gradient flows back as fp32.  out: written there (a row range of a larger token matrix)."""
     t = tape()
-    out = to_act(x, scale)
+    if out is not None:
+        assert out.shape == x.shape and out.is_contiguous() and x.is_contiguous()
+        _chk(L().rd_cast(_p(x), _p(out), x.numel(), rd_of(x), rd_of(out), float(scale), _stream(x)), "rd_cast")
+    else:
+        out = to_act(x, scale)
     if out is x:
         return x
     if t is not None and t.requires(x):

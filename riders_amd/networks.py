@@ -167,7 +167,12 @@ class RCNetEncoder(torch.nn.Module):
         engine.stage_mark("attention_done")   # backward: RoI pooling, point MLP and transformer gradients are final here
         skips_image_pooled = [engine.roi_pool(skips_image[i], rois, skip_feature_sizes[i], skip_scales[i])
                               for i in range(len(skips_image))]
-        latent_image_pooled = engine.roi_pool(latent_image, rois, (latent_height, latent_width), 1 / 32.0)
+        # the transformer keeps both token streams in ONE (2 R L, C) matrix: the pooled latent and the cast point-MLP tokens are written
+        # straight into its two halves (engine.rows_cat then has nothing to copy)
+        merged = engine.fused_loftr() and latent_image.shape[3] == C and latent_image.dtype == engine.act_dtype()
+        tok = torch.empty((2 * R * L, C), dtype=latent_image.dtype, device=latent_image.device) if merged else None
+        latent_image_pooled = engine.roi_pool(latent_image, rois, (latent_height, latent_width), 1 / 32.0,
+                                              out=None if tok is None else tok[R * L:].view(R, latent_height, latent_width, C))
         engine.tap("enc.latent_pooled", latent_image_pooled)
         for i, s_ in enumerate(skips_image_pooled):
             engine.tap("enc.skip%d_pooled" % i, s_)
@@ -177,7 +182,7 @@ class RCNetEncoder(torch.nn.Module):
         engine.tap("enc.mlp_out", latent_depth)
         tokens_depth = engine.transpose_last2(latent_depth, R, C, L)          # (R, L, C)
         tokens_depth = engine.alias(tokens_depth, tokens_depth.view(R * L, C))
-        tokens_depth = engine.input_cast(tokens_depth)
+        tokens_depth = engine.input_cast(tokens_depth, out=None if tok is None else tok[:R * L])
         tokens_image = engine.alias(latent_image_pooled, latent_image_pooled.view(R * L, C))
 
         depth_tf, image_tf = self.attention._fwd(tokens_depth, tokens_image, R, L, L)

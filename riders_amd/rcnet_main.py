@@ -284,6 +284,20 @@ class GraphedStep(object):
         if on_replay is not None:
             on_replay(-(warmup + 1))  # neither the warm-up passes (undone) nor the capture pass (not executed) were training steps
 
+    def load_batch(self, batch):
+        """Copy a new batch into the static tensors the captured step reads (same shapes / dtypes; device-to-device or host-to-device copies on the
+        current stream, ordered before the next replay).  This is the one line a training loop adds in front of `step()` when it feeds real data:
+        `step.load_batch(next(loader)); loss = step()`."""
+        static = getattr(self, "static_batch", None)
+        if static is None:
+            raise RuntimeError("this GraphedStep was built from a closure, not from a batch: there are no static input tensors to load into")
+        if len(static) != len(batch):
+            raise ValueError("load_batch: %d tensors, the captured step reads %d" % (len(batch), len(static)))
+        for dst, src in zip(static, batch):
+            if tuple(dst.shape) != tuple(src.shape):
+                raise ValueError("load_batch: shape %s does not match the captured %s (a hipGraph replays fixed shapes)" % (tuple(src.shape), tuple(dst.shape)))
+            dst.copy_(src, non_blocking=True)
+
     def __call__(self):
         for g, tag in zip(self.graphs, self.tags):
             g.replay()
@@ -311,4 +325,5 @@ class GraphedTrainStep(GraphedStep):
                 if m.training:
                     m._nbt_pending += delta
         buffers = [b for net in nets for b in net.buffers() if b.is_floating_point()]
+        self.static_batch = tuple(batch)
         super().__init__(lambda: forward_loss(model, batch, cfg), optimizer, reducer, warmup, bump, buffers, loss_scale)

@@ -175,4 +175,6 @@ class GraphedTrainStep(object):
                 model._first_pending += delta
                 model.pretrained.layer1._stem_pending = getattr(model.pretrained.layer1, "_stem_pending", 0) + delta
         buffers = [b for b in model.buffers() if b.is_floating_point()]
-        return GraphedStep(lambda: forward_loss(model, batch, cfg, outlier), optimizer, reducer, warmup, bump, buffers, loss_scale)
+        step = GraphedStep(lambda: forward_loss(model, batch, cfg, outlier), optimizer, reducer, warmup, bump, buffers, loss_scale)
+        step.static_batch = tuple(batch)      # GraphedStep.load_batch(new_batch) copies a new batch into these before a replay
+        return step

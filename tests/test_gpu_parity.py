@@ -592,3 +592,39 @@ def test_integration_aliasing_block_against_the_hip_library(gpu):
     from riders_amd import _lib
     assert _lib.load()._name.endswith("libriders_hip.so")
     P.integration_aliasing_case(gpu)
+
+
+def test_graphed_step_load_batch_feeds_new_data(gpu):
+    """a loop over real data puts `step.load_batch(batch)` in front of the replay.  Two different batches through ONE
+    captured step must give the losses of the eager step on those batches (same weights trajectory), and a wrong shape is refused."""
+    import pytest as _pt
+    import torch
+    from riders_amd import engine, rcnet_main
+    from riders_amd.optim import FlatAdam
+    cfg = dict(rcnet_main.ZJU_CONFIG, patch_size=[64, 32], total_points_sampled=4)
+    batches = [rcnet_main.synthetic_batch(2, 64, 96, cfg, seed=s_, device=gpu) for s_ in (5, 6, 7)]
+    losses = {}
+    for mode in ("eager", "graph"):
+        torch.manual_seed(0)
+        model = rcnet_main.build_model(gpu, cfg)
+        model.train()
+        opt = FlatAdam(model.parameters(), lr=1e-3)
+        engine.set_deterministic_roi_pool(True)
+        try:
+            if mode == "eager":
+                losses[mode] = [float(rcnet_main.train_step(model, opt, b, cfg)) for b in batches]
+            else:
+                static = tuple(t_.clone() for t_ in batches[0])
+                step = rcnet_main.GraphedTrainStep(model, opt, static, cfg, warmup=1)
+                out = []
+                for b in batches:
+                    step.load_batch(b)
+                    out.append(float(step()))
+                losses[mode] = out
+                with _pt.raises(ValueError):
+                    step.load_batch(tuple(t_[:1] for t_ in b))
+        finally:
+            engine.set_deterministic_roi_pool(False)
+    for a, b in zip(losses["eager"], losses["graph"]):
+        assert abs(a - b) <= 1e-4 * abs(a), losses
+    assert len(set(losses["graph"])) == 3
