@@ -174,6 +174,14 @@ int rd_conv_fwd_add(const rd_conv_desc* d, const void* src1, const void* src2, c
                     void* dst, void* stream);
 /* fp32 workspace bytes needed by rd_conv_wgrad */
 int64_t rd_conv_wgrad_workspace_bytes(const rd_conv_desc* d);
+/* One sizing entry for the caller-owned buffers of a convolution layer (SURVEY 8b `rd_workspace_bytes(op, shape...)`; -1 = bad descriptor / op):
+   the weight-gradient slabs, the forward's BatchNorm statistics rows ([rd_conv_stats_rows][Cout][2] floats), the packed forward operand and the
+   packed data-gradient operand (bytes in the descriptor's dtype, incl. the fragment-ordered second copies). */
+#define RD_WS_CONV_WGRAD 0
+#define RD_WS_CONV_STATS 1
+#define RD_WS_CONV_PACKED 2
+#define RD_WS_CONV_PACKED_DGRAD 3
+int64_t rd_workspace_bytes(int32_t op, const rd_conv_desc* d);
 /* dw (OIHW fp32) = or += dY^T * gather(X); deterministic two-stage reduction */
 int rd_conv_wgrad(const rd_conv_desc* d, const void* src1, const void* src2, const void* dy, float* workspace,
                   float* dw_oihw, int32_t accumulate, void* stream);

@@ -346,6 +346,18 @@ int64_t rd_conv_wgrad_workspace_bytes(const rd_conv_desc* d) {
   a.in_scale = nullptr;
   return (int64_t)(ns + 1) * d->Cout * a.K * (int64_t)sizeof(float);
 }
+int64_t rd_workspace_bytes(int32_t op, const rd_conv_desc* d) {
+  // SURVEY 8(b)'s one sizing entry for the caller-owned buffers of a convolution layer (the per-op helpers stay: this dispatches to them)
+  if (!d || check_desc(d)) return -1;
+  const int es = d->dtype == RD_F32 ? 4 : 2;
+  switch (op) {
+    case RD_WS_CONV_WGRAD: return rd_conv_wgrad_workspace_bytes(d);
+    case RD_WS_CONV_STATS: return (int64_t)rd_conv_stats_rows(d) * d->Cout * 2 * (int64_t)sizeof(float);
+    case RD_WS_CONV_PACKED: return rd_conv_packed_elems(d->Cout, d->KH * d->KW * (d->C1 + d->C2), d->dtype) * es;
+    case RD_WS_CONV_PACKED_DGRAD: return rd_conv_packed_elems(d->C1 + d->C2, d->KH * d->KW * d->Cout, d->dtype) * es;
+    default: fail("workspace_bytes: unknown op %d", op); return -1;
+  }
+}
 int rd_conv_wgrad(const rd_conv_desc* d, const void* src1, const void* src2, const void* dy, float* workspace, float* dw,
                   int32_t accumulate, void* stream) {
   if (int e = check_desc(d)) return e;

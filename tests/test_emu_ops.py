@@ -265,3 +265,18 @@ def test_stride2_dgrad_parity_classes(emu):
 def test_skinny_linear(emu):
     P.skinny_linear_cases(emu)
 
+
+
+def test_workspace_bytes_dispatch(emu):
+    """rd_workspace_bytes(op, desc): one sizing entry over the per-op helpers; unknown op / bad descriptor -> -1."""
+    import ctypes
+    from riders_amd import engine
+    lib = engine.L()
+    d = engine._desc(engine.RD_BF16, 2, 24, 16, 64, 0, False, 24, 16, 128, 3, 3, 1, 1, 1, 24, 16, engine.ACT_NONE, 0.2, 128)
+    ref = ctypes.byref(d)
+    assert lib.rd_workspace_bytes(0, ref) == lib.rd_conv_wgrad_workspace_bytes(ref) > 0
+    assert lib.rd_workspace_bytes(1, ref) == lib.rd_conv_stats_rows(ref) * 128 * 2 * 4
+    assert lib.rd_workspace_bytes(2, ref) == lib.rd_conv_packed_elems(128, 9 * 64, engine.RD_BF16) * 2
+    assert lib.rd_workspace_bytes(3, ref) == lib.rd_conv_packed_elems(64, 9 * 128, engine.RD_BF16) * 2
+    assert lib.rd_workspace_bytes(9, ref) == -1 and b"workspace_bytes" in lib.rd_last_error_string()
+    assert lib.rd_workspace_bytes(0, None) == -1
