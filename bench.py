@@ -27,7 +27,9 @@ Rank 0 prints ONE JSON line (< 6 KB; everything else goes to --full-json), inclu
   "roofline_families": the same figures for the largest families (MFMA-bound convolutions, weight gradients, HBM-bound BatchNorm passes).
   "cpu_baseline":  the oracle (PyTorch-CPU restatement of the reference path, kind "port") timed on this box's host cores on a bounded sample.
   "unchanged_caller": the path an unmodified training script takes (RCNetModel.forward -> compute_loss -> loss.backward() ->
-                   torch.optim.Adam.step() -> loss.item(), eager; the SML twin) next to the graphed step: value, ms_per_step, launches per step.
+                   torch.optim.Adam.step() -> loss.item(); the SML twin): `value` with the forward region captured and replayed inside that loop
+                   (engine.set_autograph, one line of INTEGRATION.md's aliasing block), `eager_value` with plain eager launches, next to the
+                   fully captured step (`graphed_value`); launches per step from marker-cut kernel traces.
   "val_abs_rel":   the validation chain's abs-rel on 8 synthetic 256x512 frames: HIP fp32, HIP bf16 and the oracle on identical weights.
 """
 import argparse
@@ -351,6 +353,8 @@ def _child_base(args, workload, outdir, steps=2, warmup=1, eager=True, settle=0.
             "--full-json", os.path.join(outdir, "child_full.json")]
     if eager:
         base.append("--eager")
+    if getattr(args, "autograph", False):
+        base.append("--autograph")
     if args.opts:
         base += ["--opts", args.opts]
     return base
@@ -617,7 +621,8 @@ def compact_line(full):
             line[name]["launches_per_step"] = _sig(leg["launches_per_step"], 5)
     uc = full.get("unchanged_caller")
     if uc:
-        line["unchanged_caller"] = {k: {a: _sig(v[a], 6) for a in ("value", "ms_per_step", "launches_per_step", "graphed_value") if v.get(a) is not None}
+        line["unchanged_caller"] = {k: {a: _sig(v[a], 6) for a in ("value", "ms_per_step", "launches_per_step", "eager_value", "eager_ms_per_step", "eager_launches_per_step",
+                                                                      "graphed_value") if v.get(a) is not None}
                                     for k, v in uc.items() if isinstance(v, dict)}
     va = full.get("val_abs_rel")
     if isinstance(va, dict) and "oracle" in va:
@@ -876,15 +881,18 @@ def run_chain(args, dev, world, rank, steps, warmup):
         engine.set_param_grad_allocator(None)
 
 
-def run_unchanged_caller(kind, args, dev, steps, warmup=3):
+def run_unchanged_caller(kind, args, dev, steps, warmup=3, autograph=False):
     """The path the reference's unmodified training loop takes through the aliased modules: per step the label build /
     device pre-step, model.forward, compute_loss, optimizer.zero_grad(), loss.backward() through torch.autograd (the engine's region is ONE
     autograd node), torch.optim.Adam.step() and loss.item() -- eager launches, no flat arena, no captured graph
-    (RCNet/rcnet_main.py:342-359, train_zju.py:353-392).  -> dict(value, ms_per_step, ...)"""
+    (RCNet/rcnet_main.py:342-359, train_zju.py:353-392).  autograph: with engine.set_autograph(True) -- one more line in INTEGRATION.md's aliasing
+    block, none in the script -- the model's forward region is captured on its second call and replayed from then on (forward and backward
+    hipGraphs inside the SAME torch.autograd / torch.optim.Adam loop).  -> dict(value, ms_per_step, ...)"""
     from riders_amd import engine, rcnet_main, sml_main
     engine.set_compute_dtype(args.dtype)
     engine.clear_caches()
     engine.set_param_grad_allocator(None)
+    engine.set_autograph(bool(autograph))
     torch.manual_seed(0)
     if kind == "sml":
         import contextlib
@@ -925,9 +933,12 @@ def run_unchanged_caller(kind, args, dev, steps, warmup=3):
         else:
             elapsed, _ = timed(step, steps, 1, dev)
         return dict(value=n * steps / elapsed, ms_per_step=elapsed * 1e3 / steps, steps=steps, warmup=warmup, settle_steps=0, final_loss=last[0], batch_per_gpu=n,
-                    height=h, width=w, launch_mode="eager through torch.autograd, torch.optim.Adam, loss.item() per step")
+                    height=h, width=w, autograph=engine.autograph_stats() if autograph else None,
+                    launch_mode=("torch.autograd + torch.optim.Adam + loss.item() per step; the model's forward region captured and replayed (engine.set_autograph)"
+                                 if autograph else "eager through torch.autograd, torch.optim.Adam, loss.item() per step"))
     finally:
         del opt, model
+        engine.set_autograph(False)
         engine.clear_caches()
         torch.cuda.empty_cache()
 
@@ -1032,6 +1043,7 @@ def main():
                     "measure roofline.traffic inside the default N = 1 run")
     ap.add_argument("--no-children", action="store_true", help="start no profiler child at all (kernel trace, counter passes): durations then come from HIP events "
                     "only.  Pass it in every command that is itself run under rocprofv3 (it is also detected)")
+    ap.add_argument("--autograph", action="store_true", help="(caller_* workloads) engine.set_autograph(True): the forward region is captured and replayed inside the unchanged loop")
     ap.add_argument("--step-markers", action="store_true", help="(profiler children) bracket every timed step with torch.cuda._sleep(1) so that a kernel trace can be cut per step")
     ap.add_argument("--save-kstats", default=None, help="directory that receives the kernel-trace child's *_kernel_stats.csv (the summary committed under profiles/)")
     ap.add_argument("--detail", default=None, help="write a per-launch-shape timing table to this file")
@@ -1094,7 +1106,7 @@ def main():
     if args.workload == "chain":
         head, rc, sml = run_chain(args, dev, world, rank, args.steps, args.warmup)
     elif args.workload.startswith("caller"):
-        head = run_unchanged_caller("sml" if args.workload.endswith("sml") else "rcnet", args, dev, args.steps, min(args.warmup, 3))
+        head = run_unchanged_caller("sml" if args.workload.endswith("sml") else "rcnet", args, dev, args.steps, min(args.warmup, 3), autograph=args.autograph)
     else:
         head = run_workload(args.workload, args, dev, world, rank, args.steps, args.warmup, prof_children=(world == 1 and not args.no_children and not args.eager))
     default_line = args.workload == "chain" and world == 1 and args.dtype == "bf16" and (args.height, args.width, args.batch) == (256, 512, 8) \
@@ -1119,12 +1131,16 @@ def main():
         caller = {}
         for kind, graphed in (("rcnet", rc), ("sml", sml)):
             try:
-                c = run_unchanged_caller(kind, args, dev, max(5, min(args.steps, 30)))
+                nst = max(5, min(args.steps, 30))
+                c = run_unchanged_caller(kind, args, dev, nst, autograph=True)      # the aliasing block's setting: regions captured on their second call
+                ce = run_unchanged_caller(kind, args, dev, nst, autograph=False)    # plain eager launches
+                c["eager_value"], c["eager_ms_per_step"] = ce["value"], ce["ms_per_step"]
                 c["graphed_value"] = graphed["value"]
                 if not args.no_children:
-                    tr = kernel_trace_child(args, "caller_" + kind, steps=8)
-                    if tr is not None:
-                        c["launches_per_step"], c["kernel_ms_per_step"] = tr["launches_per_step"], tr["kernel_ms_per_step"]
+                    for tag, ag in (("", True), ("eager_", False)):
+                        tr = kernel_trace_child(argparse.Namespace(**dict(vars(args), autograph=ag)), "caller_" + kind, steps=8)
+                        if tr is not None:
+                            c[tag + "launches_per_step"], c[tag + "kernel_ms_per_step"] = tr["launches_per_step"], tr["kernel_ms_per_step"]
                 caller[kind] = c
             except Exception as ex:      # never lose the bench line to an auxiliary leg
                 caller[kind] = dict(error=repr(ex)[:300])

@@ -15,6 +15,7 @@ import ctypes
 import weakref
 
 import torch
+import torch.distributed
 
 from . import _lib
 from ._lib import ACT_LRELU, ACT_NONE, ACT_RELU, ACT_RELU6, RD_BF16, RD_F16, RD_F32, ConvDesc
@@ -689,15 +690,206 @@ def _match_layout(g, like):
     return out
 
 
-def run_region(runner, inputs, params):
-    """Run `runner(*inputs)` as one autograd node, or inline when a tape is already active / grad is off."""
+def run_region(runner, inputs, params, graph_key=None, on_replay=None):
+    """Run `runner(*inputs)` as one autograd node, or inline when a tape is already active / grad is off.
+    graph_key (hashable) names the launch sequence this call produces -- the module, its training flags, anything besides the input
+    shapes that changes what is launched.  With engine.set_autograph(True) a region that is called again with the same key and input
+    geometry is CAPTURED (forward and backward hipGraphs) and from then on replayed: this is how an unchanged training script -- eager
+    torch.autograd, torch.optim.Adam -- gets the captured step's launch cost (see _graphed_region).  on_replay(): host-side bookkeeping a
+    replay must repeat (BatchNorm num_batches_tracked counters)."""
     if _state["tape"] is not None:
         return runner(*inputs)
     if not torch.is_grad_enabled():
         with _active(None):
             return runner(*inputs)
     params = [p for p in params if p.requires_grad]
+    if _autograph["on"] and graph_key is not None and _timer["t"] is None and not _stage_hooks and not _taps["on"]:
+        out = _graphed_region(runner, inputs, params, graph_key, on_replay)
+        if out is not _NOT_GRAPHED:
+            return out
     return _Region.apply(runner, len(inputs), *inputs, *params)
+
+
+# ------------------------------------------------------------------------------- captured regions (unchanged callers)
+# The reference's training scripts drive the modules through torch.autograd: model.forward(...) -> compute_loss -> loss.backward() ->
+# torch.optim.Adam.step() (RCNet/rcnet_main.py:342-359, train_zju.py:353-392).  Eagerly that is ~520 launches per RC-Net step issued from
+# Python, and the host cannot issue them as fast as the GPU runs them (bench.py `unchanged_caller`: 434-712 img/s by box against
+# 1090-1133 for the captured step).  rcnet_main.GraphedTrainStep needs the loop to change; this does not: a region whose key and input
+# geometry repeat is captured ONCE -- its forward into one hipGraph, its whole backward (tape.backward() seeded with a static output
+# gradient) into a second one sharing the pool -- and every later call copies the inputs into the static tensors, replays, and hands
+# autograd the static outputs; the node's backward copies the output gradient in, replays, and deposits the static parameter gradients
+# on .grad.  Same kernels, same order, same results as the eager region (tests compare them).  The first call with a key runs eagerly
+# (one-off shapes never pay for a capture, packed operands and allocator are warm), the second captures.  As with
+# torch.cuda.make_graphed_callables the outputs of a call are overwritten by the next call with the same key.
+_autograph = {"on": False, "entries": {}, "max_entries": 4, "captured": 0, "replayed": 0, "eager": 0, "seen": {}}
+_NOT_GRAPHED = object()
+
+
+def set_autograph(flag, max_entries=4):
+    """Capture and replay repeated autograd regions (default off).  INTEGRATION.md section 1: the aliasing block switches it on."""
+    _autograph["on"] = bool(flag)
+    _autograph["max_entries"] = int(max_entries)
+    if not flag:
+        clear_autograph()
+
+
+def clear_autograph():
+    _autograph["entries"].clear()
+    _autograph["seen"].clear()
+
+
+def autograph_stats():
+    return {k: _autograph[k] for k in ("captured", "replayed", "eager")}
+
+
+class _GraphEntry(object):
+    __slots__ = ("g_f", "g_b", "static_in", "outs", "single", "static_gout", "gin", "pgrads", "params", "owner", "versions", "on_replay", "tape", "uses",
+                 "flat_sg", "flat_pub", "pub", "offsets", "mine", "foreign")
+
+
+def _geometry(x):
+    return None if x is None else (tuple(x.shape), x.dtype, tuple(x.stride()), bool(x.requires_grad), x.device.index)
+
+
+def _graphed_region(runner, inputs, params, graph_key, on_replay):
+    if not all(x is None or (torch.is_tensor(x) and x.is_cuda) for x in inputs) or not params:
+        return _NOT_GRAPHED
+    key = (graph_key, _state["dtype"], tuple(_geometry(x) for x in inputs), tuple(id(p) for p in params))
+    ag = _autograph
+    e = ag["entries"].get(key)
+    fresh = False
+    if e is None:
+        n = ag["seen"].get(key, 0)
+        ag["seen"][key] = n + 1
+        if n == 0:                    # first sight of this geometry: eager (and everything it allocates lazily is then in place)
+            ag["eager"] += 1
+            if len(ag["seen"]) > 64:
+                ag["seen"].clear()
+            return _NOT_GRAPHED
+        e = _capture_region(runner, inputs, params, on_replay)
+        while len(ag["entries"]) >= max(1, ag["max_entries"]):      # least recently used entry goes (its graphs and activations with it)
+            victim = min(ag["entries"], key=lambda k: ag["entries"][k].uses)
+            del ag["entries"][victim]
+        ag["entries"][key] = e
+        ag["captured"] += 1
+        fresh = True
+    ag["replayed"] += 1
+    e.uses = ag["replayed"]
+    return _GraphedRegion.apply(e, fresh, len(inputs), *inputs, *params)
+
+
+def _capture_region(runner, inputs, params, on_replay):
+    e = _GraphEntry()
+    e.on_replay, e.params, e.uses = on_replay, {id(p): p for p in params}, 0
+    e.owner = frozenset(id(p) for p in params)
+    refresh_packed(e.owner)          # nothing is stale inside the capture: no pack launch gets recorded (and re-run by every replay)
+    e.versions = sum(p._version for p in params)
+    relaxed = torch.distributed.is_available() and torch.distributed.is_initialized()
+    kw = {"capture_error_mode": "thread_local"} if relaxed else {}
+    pool = torch.cuda.graph_pool_handle()
+    hook = _grad_alloc_hook["fn"]
+    # static parameter gradients: ONE flat fp32 buffer allocated before the capture (16-byte aligned slots, like the flat-arena optimizer's), and a
+    # second one of the same layout that the caller sees on .grad -- publishing a backward is one device copy (or one add when the caller did
+    # not clear the gradients), not one tensor operation per parameter
+    offs, n = {}, 0
+    for p_ in params:
+        offs[id(p_)] = n
+        n += (p_.numel() + 3) // 4 * 4
+    e.flat_sg = torch.zeros(n, dtype=torch.float32, device=params[0].device)
+    e.flat_pub = torch.zeros(n, dtype=torch.float32, device=params[0].device)
+    e.pub = {id(p_): e.flat_pub[offs[id(p_)]:offs[id(p_)] + p_.numel()].view(p_.shape) for p_ in params}
+    e.offsets = offs
+
+    def alloc(p):      # a flat-arena optimizer's slot if there is one, else this entry's static slot
+        g = hook(p) if hook is not None else None
+        if g is None:
+            o = offs[id(p)]
+            g = e.flat_sg[o:o + p.numel()].view(p.shape)
+        return g
+    with torch.no_grad():
+        e.static_in = [None if x is None else x.detach().clone() for x in inputs]
+        t = Tape()
+        t.grad_alloc = alloc
+        for x, s_ in zip(inputs, e.static_in):
+            if x is not None and x.requires_grad:
+                t.mark(s_)
+        torch.cuda.synchronize()
+        e.g_f = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(e.g_f, pool=pool, **kw):
+            with _active(t):
+                outs = runner(*e.static_in)
+        e.single = not isinstance(outs, (tuple, list))
+        e.outs = (outs,) if e.single else tuple(outs)
+        e.static_gout = [torch.zeros_like(o) if id(o) in t.req else None for o in e.outs]
+        e.g_b = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(e.g_b, pool=pool, **kw):
+            for o, g in zip(e.outs, e.static_gout):
+                if g is not None:
+                    t.grads[id(o)] = g
+            with _active(t):
+                t.backward()
+            e.gin = [t.grads.get(id(s_)) if s_ is not None else None for s_ in e.static_in]
+        e.pgrads = dict(t.pgrads)
+        e.mine = [pid for pid, sg in e.pgrads.items() if sg.data_ptr() == e.flat_sg.data_ptr() + 4 * offs[pid]]      # written into this entry's flat buffer
+        e.foreign = [pid for pid in e.pgrads if pid not in set(e.mine)]
+        t.pgrads, t.grads = {}, {}
+        e.tape = t        # (keeps the RoI overflow flag and anything else the tape owns alive with the graphs)
+    return e
+
+
+class _GraphedRegion(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, e, fresh, n_in, *tensors):
+        for s_, x in zip(e.static_in, tensors[:n_in]):
+            if s_ is not None and x.data_ptr() != s_.data_ptr():
+                s_.copy_(x, non_blocking=True)
+        if not fresh:
+            v = sum(p._version for p in e.params.values())
+            if v != e.versions:       # an optimizer rewrote the parameters through torch since the last replay: ONE launch re-packs this region's operands
+                refresh_packed(e.owner)
+                e.versions = v
+            if e.on_replay is not None:
+                e.on_replay()
+        e.g_f.replay()
+        ctx.e = e
+        ctx.set_materialize_grads(False)
+        outs = tuple(o.detach() for o in e.outs)
+        return outs[0] if e.single else outs
+
+    @staticmethod
+    def backward(ctx, *gouts):
+        e = ctx.e
+        for sg, g in zip(e.static_gout, gouts):
+            if sg is None:
+                continue
+            if g is None:
+                sg.zero_()
+            else:
+                sg.copy_(g, non_blocking=True)
+        e.g_b.replay()
+        # publish: the caller's .grad tensors are views of e.flat_pub.  Cleared gradients (zero_grad(set_to_none), the reference loop's habit) ->
+        # one copy of the whole static buffer; gradients still in place from the previous backward -> one add (torch's accumulation semantics);
+        # anything else the caller put on .grad is added to parameter by parameter.
+        mine = e.mine
+        state = [e.params[pid].grad for pid in mine]
+        if all(g is None for g in state):
+            e.flat_pub.copy_(e.flat_sg, non_blocking=True)
+            for pid in mine:
+                e.params[pid].grad = e.pub[pid]
+        elif all(g is not None and g.data_ptr() == e.pub[pid].data_ptr() for g, pid in zip(state, mine)):
+            e.flat_pub.add_(e.flat_sg)
+        else:
+            for g, pid in zip(state, mine):
+                p = e.params[pid]
+                p.grad = e.pgrads[pid].clone() if g is None else g + e.pgrads[pid]
+        for pid in e.foreign:      # slots of a flat-arena optimizer: written in place by the replay, as in the eager region
+            p, sg = e.params[pid], e.pgrads[pid]
+            if p.grad is None or p.grad.data_ptr() == sg.data_ptr():
+                p.grad = sg
+            else:
+                p.grad = p.grad + sg
+        n_in = len(e.static_in)
+        return (None, None, None) + tuple(e.gin) + (None,) * (len(ctx.needs_input_grad) - 3 - n_in)
 
 
 # --------------------------------------------------------------------------------------- small helpers

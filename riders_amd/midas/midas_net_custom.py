@@ -92,10 +92,22 @@ class MidasNet_small_videpth(BaseModel):
     def forward(self, x, d):
         dd = d if d.is_contiguous() else d.contiguous()   # (B,1,H,W): C == 1, NCHW == NHWC in memory
 
-        def run(x):
+        def run(x, dd):
             pred = self._fwd(engine.from_nchw(x), dd)
             return engine.alias(pred, pred.view(dd.shape))
-        return engine.run_region(run, (x,), list(self.parameters()))
+        # (d is a region INPUT: a captured region -- engine.set_autograph -- reads it from a static tensor)
+        return engine.run_region(run, (x, dd), list(self.parameters()), graph_key=("MidasNet_small_videpth.forward", id(self), self.training),
+                                 on_replay=self._bn_replay)
+
+    def _bn_replay(self):
+        """host-side bookkeeping of one replayed forward: the num_batches_tracked counters this module's _fwd bumps"""
+        from .efficientnet_lite3 import _Counted
+        if self.training:
+            for m in self.modules():
+                if isinstance(m, _Counted):
+                    m._pending += 1
+            self._first_pending += 1
+            self.pretrained.layer1._stem_pending = getattr(self.pretrained.layer1, "_stem_pending", 0) + 1
 
 
 class MidasNet_small_depth(BaseModel):

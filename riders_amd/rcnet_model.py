@@ -50,14 +50,16 @@ class RCNetModel(object):
         rois = networks.boxes_to_rois(bounding_boxes)
         shape = self.input_patch_size_image
 
-        def run(image, point):
+        def run(image, point, rois):
             pts = point if point.is_contiguous() else point.contiguous()
             latent, skips = enc._fwd(engine.from_nchw(image), pts, rois)
             engine.stage_mark("decoder_done")     # backward: every decoder gradient is final here (parallel.GradientAllReducer)
             logits = dec._fwd(latent, skips, shape)[-1]
             return engine.to_nchw_out(logits, torch.float32)
         params = list(enc.parameters()) + list(dec.parameters())
-        logits = engine.run_region(run, (image, point), params)
+        # (the RoI rows are a region INPUT: a captured region -- engine.set_autograph -- reads them from a static tensor)
+        logits = engine.run_region(run, (image, point, rois), params, graph_key=("RCNetModel.forward", id(enc), id(dec), enc.training, dec.training, tuple(shape)),
+                                   on_replay=self._bn_replay)
         if return_logits:
             return logits
         lg = logits.contiguous()
@@ -76,6 +78,13 @@ class RCNetModel(object):
     @staticmethod
     def _unwrap(m):
         return m.module if hasattr(m, 'module') else m
+
+    def _bn_replay(self):
+        """host-side bookkeeping of one replayed forward: the BatchNorm layers' num_batches_tracked counters (net_utils._BNCounter)"""
+        for net in (self._unwrap(self.encoder), self._unwrap(self.decoder)):
+            for m in net.modules():
+                if getattr(m, 'use_batch_norm', False) and hasattr(m, '_nbt_pending') and m.training:
+                    m._nbt_pending += 1
 
     def parameters(self):
         return list(self.encoder.parameters()) + list(self.decoder.parameters())

@@ -628,3 +628,89 @@ def test_graphed_step_load_batch_feeds_new_data(gpu):
     for a, b in zip(losses["eager"], losses["graph"]):
         assert abs(a - b) <= 1e-4 * abs(a), losses
     assert len(set(losses["graph"])) == 3
+
+
+def _unchanged_loop(model_step, steps):
+    return [model_step(i) for i in range(steps)]
+
+
+def test_autograph_rcnet_unchanged_loop_matches_eager(gpu):
+    """engine.set_autograph(True): the unchanged-caller loop (torch.autograd + torch.optim.Adam + loss.item(), RCNet/rcnet_main.py:342-359) with the
+    model's forward region captured on its second call and replayed afterwards must reproduce the eager loop: same losses, same parameters,
+    same BatchNorm buffers / counters -- over batches that CHANGE between steps -- and gradient accumulation without zero_grad keeps torch's
+    semantics.  The region is captured once and replayed."""
+    import torch
+    from riders_amd import engine, rcnet_main
+    cfg = dict(rcnet_main.ZJU_CONFIG, patch_size=[64, 32], total_points_sampled=4)
+    batches = [rcnet_main.synthetic_batch(2, 64, 96, cfg, seed=20 + i, device=gpu) for i in range(5)]
+    res = {}
+    for mode in ("eager", "autograph"):
+        engine.set_autograph(mode == "autograph")
+        engine.set_deterministic_roi_pool(True)
+        try:
+            torch.manual_seed(0)
+            model = rcnet_main.build_model(gpu, cfg)
+            model.train()
+            opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+            losses = []
+            for i, b in enumerate(batches):
+                loss = rcnet_main.forward_loss(model, b, cfg)
+                if i != 3:                      # step 3 accumulates on top of step 2's gradients (no zero_grad)
+                    opt.zero_grad()
+                loss.backward()
+                opt.step()
+                losses.append(loss.item())
+            sd = {k: v.detach().clone() for k, v in list(model.encoder.state_dict().items()) + list(model.decoder.state_dict().items())}
+            res[mode] = (losses, sd, engine.autograph_stats() if mode == "autograph" else None)
+        finally:
+            engine.set_autograph(False)
+            engine.set_deterministic_roi_pool(False)
+    (le, sde, _), (la, sda, st) = res["eager"], res["autograph"]
+    assert st["captured"] - 0 >= 1 and st["replayed"] >= 4, st
+    for a, b in zip(le, la):
+        assert abs(a - b) <= 1e-5 * abs(a), (le, la)
+    for k in sde:
+        if sde[k].is_floating_point():
+            d = float((sde[k] - sda[k]).abs().max()), float(sde[k].abs().max())
+            assert d[0] <= 1e-4 * max(d[1], 1e-3), (k, d)
+        else:
+            assert torch.equal(sde[k], sda[k]), k      # num_batches_tracked
+
+
+def test_autograph_sml_unchanged_loop_matches_eager(gpu):
+    """the same for the Scale Map Learner's loop (train_zju.py:353-392): pre-step, model.forward captured / replayed, compute_loss, torch.optim.Adam"""
+    import contextlib
+    import io
+    import torch
+    from riders_amd import engine, sml_main
+    batches = [sml_main.synthetic_batch(2, 64, 96, seed=40 + i, device=gpu) for i in range(4)]
+    res = {}
+    for mode in ("eager", "autograph"):
+        engine.set_autograph(mode == "autograph")
+        try:
+            torch.manual_seed(0)
+            with contextlib.redirect_stdout(io.StringIO()):
+                model = sml_main.build_model(gpu)
+            model.train()
+            opt = torch.optim.Adam(model.parameters(), lr=1e-4)
+            orr = sml_main.make_outlier_removal()
+            losses = []
+            for b in batches:
+                loss = sml_main.forward_loss(model, b, outlier=orr)
+                opt.zero_grad()
+                loss.backward()
+                opt.step()
+                losses.append(loss.item())
+            res[mode] = (losses, {k: v.detach().clone() for k, v in model.state_dict().items()}, engine.autograph_stats())
+        finally:
+            engine.set_autograph(False)
+    (le, sde, _), (la, sda, st) = res["eager"], res["autograph"]
+    assert st["captured"] >= 1 and st["replayed"] >= 3, st
+    for a, b in zip(le, la):
+        assert abs(a - b) <= 1e-5 * abs(a), (le, la)
+    for k in sde:
+        if sde[k].is_floating_point():
+            d = float((sde[k] - sda[k]).abs().max()), float(sde[k].abs().max())
+            assert d[0] <= 1e-4 * max(d[1], 1e-3), (k, d)
+        else:
+            assert torch.equal(sde[k], sda[k]), k

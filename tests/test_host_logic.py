@@ -338,7 +338,8 @@ def test_bench_line_stays_under_the_driver_limit():
                rcnet_b8=dict(value=1.2, unit="imgs/s", cores=16, sample="one B=8 step"), chained=dict(value=0.9, unit="imgs/s"), seconds=13.4)
     val = dict(oracle=0.379123, sample="8 synthetic 256x512 frames (network input 288x576), random-init weights identical on every path",
                fp32=dict(hip=0.379146, diff_of_means=2.3e-5, max_abs_diff=2.7e-5), bf16=dict(hip=0.3801, diff_of_means=1e-3, max_abs_diff=2e-3), hip=0.379146, max_abs_diff=2.7e-5)
-    caller = dict(rcnet=dict(value=400.0, ms_per_step=20.0, launches_per_step=1900.0, graphed_value=1100.0, launch_mode="eager"),
+    caller = dict(rcnet=dict(value=400.0, ms_per_step=20.0, launches_per_step=1900.0, graphed_value=1100.0, launch_mode="eager", eager_value=350.0, eager_ms_per_step=23.0,
+                             eager_launches_per_step=2100.0),
                   sml=dict(value=500.0, ms_per_step=32.0, launches_per_step=3000.0, graphed_value=1290.0))
     full = bench.full_record(args, 1, dict(backend="nccl (RCCL)", world_size=1, rccl_version="2.26.6"), True, chain, leg, dict(leg, batch_per_gpu=16),
                              {"fp32": leg, "config4": leg, "config4_sml": leg}, cpu, val, caller)
