@@ -292,10 +292,16 @@ def build_rooflines(timer, timed_steps, ms_per_step, dtype, prof=None, live=None
     if not fam:
         return dict(roofline=None, families=family_table(timer, timed_steps, ms_per_step, dtype))
     prof_f, live_f = {}, {}
+    # (only the instantiations whose algorithmic work the engine tallied: a template's other uses -- e.g. col_reduce_vec_kernel<.., 1, ..> as the
+    # bias column sum -- carry time but no tallied work and would dilute the family)
     for n, (calls, ns) in (prof or {}).items():
+        if n not in inst:
+            continue
         e = prof_f.setdefault(family_of(n), dict(calls_per_step=0.0, ns_per_step=0.0))
         e["calls_per_step"] += calls; e["ns_per_step"] += ns
     for n, t in (live or {}).items():
+        if n not in inst:
+            continue
         e = live_f.setdefault(family_of(n), dict(bytes=0.0, dispatches=0, busy=0.0, act=0.0))
         e["bytes"] += t["bytes_per_launch"] * t["dispatches"]; e["dispatches"] += t["dispatches"]
         if "mfma_busy_cycles" in t:
@@ -307,6 +313,7 @@ def build_rooflines(timer, timed_steps, ms_per_step, dtype, prof=None, live=None
     entries = {}
     for name, w in fam.items():
         entries[name] = roofline_entry(name, w, dtype, ms_per_step, prof_f.get(name), live_f.get(name))
+        entries[name]["instantiation_names"] = sorted(n for n in inst if family_of(n) == name)
     order = sorted(entries, key=lambda k: -entries[k]["ms_per_step"])
     dom = entries[order[0]]
     dom["note"] = ("dominant = the kernel family (all instantiations of one template) with the largest summed launch time per RC-Net / SML step; the rocprofv3 "

@@ -647,12 +647,15 @@ const char* conv3x3_frag_name(const ConvArgs& a, int dtype) {
     snprintf(buf, sizeof(buf), "conv3x3_frag32_kernel<%s, %d, %d, %d, %d, %s>", RD_T16_NAME, w.nq, w.wpx, w.wch, w.cw, multi ? "true" : "false");
     return buf;
   }
+  // all nine template arguments, as rocprofv3 prints an instantiation (LIN, MULTI, AFF, D2S, S2D): bench.py matches its per-launch tallies to the
+  // kernel trace by this exact string (until round 6 the D2S / S2D defaults were left out and the register-fed family never matched)
+  const char* T16 = dtype == 0 ? "float" : RD_T16_NAME;
   if (a.s2d) snprintf(buf, sizeof(buf), "conv3x3_frag_kernel<%s, %d, %d, %d, %s, %s, false, false, true>", RD_T16_NAME, npt[p.variant], wpx[p.variant], wch[p.variant],
                       p.lin ? "true" : "false", multi ? "true" : "false");
-  else if (a.d2s) snprintf(buf, sizeof(buf), "conv3x3_frag_kernel<%s, %d, %d, %d, %s, %s, false, true>", RD_T16_NAME, npt[p.variant], wpx[p.variant], wch[p.variant],
+  else if (a.d2s) snprintf(buf, sizeof(buf), "conv3x3_frag_kernel<%s, %d, %d, %d, %s, %s, false, true, false>", RD_T16_NAME, npt[p.variant], wpx[p.variant], wch[p.variant],
                       p.lin ? "true" : "false", multi ? "true" : "false");
   else
-  snprintf(buf, sizeof(buf), "conv3x3_frag_kernel<%s, %d, %d, %d, %s, %s, %s>", dtype == 0 ? "float" : RD_T16_NAME, npt[p.variant], wpx[p.variant],
+  snprintf(buf, sizeof(buf), "conv3x3_frag_kernel<%s, %d, %d, %d, %s, %s, %s, false, false>", T16, npt[p.variant], wpx[p.variant],
            wch[p.variant], p.lin ? "true" : "false", multi ? "true" : "false", a.in_scale ? "true" : "false");
   return buf;
 }

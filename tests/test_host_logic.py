@@ -405,3 +405,33 @@ def test_c_abi_comm_loopback_and_bucketing(emu):
     assert lib.rd_allreduce_bucket(comm.handle, None, 4, 0, None) < 0
     assert lib.rd_allreduce_bucket(comm.handle, engine._p(opt.flat_grad), 4, 7, None) < 0 and b"allreduce_bucket" in lib.rd_last_error_string()
     comm.close()
+
+
+def test_committed_bench_line_is_reproducible_from_the_committed_kernel_trace():
+    """the line's roofline.frac must follow from profiles/.  The committed line (profiles/r06_bench_default.json) and the committed
+    rocprofv3 --kernel-trace --stats summary of the same run's child (profiles/r06_rcnet_b8_256x512_bf16_kernel_stats.csv): for each listed family
+    frac == algorithmic work per launch / the CSV's average duration of that family / the roof, within 2 %."""
+    import csv
+    import json
+    import os
+    import sys
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    sys.path.insert(0, os.path.join(root, "tools"))
+    from traffic_aggregate import kernel_key
+    line = json.loads(open(os.path.join(root, "profiles", "r06_bench_default.json")).read().strip().split("\n")[-1])
+    full = json.load(open(os.path.join(root, "profiles", "r06_bench_default_full.json")))
+    rows = list(csv.DictReader(open(os.path.join(root, "profiles", "r06_rcnet_b8_256x512_bf16_kernel_stats.csv"))))
+    assert line["metric"] == "train imgs/sec (RC-Net+SML, 256x512)" and line["config"]["global_batch"] == 16
+    checked = 0
+    for fam in full["roofline_families"][:4]:
+        names = set(fam["instantiation_names"])      # the instantiations whose work the engine tallied (bench.py build_rooflines)
+        sel = [r for r in rows if kernel_key(r["Name"]) in names]
+        assert {kernel_key(r["Name"]) for r in sel} == names, ("the library names an instantiation the trace does not have", names - {kernel_key(r["Name"]) for r in sel})
+        calls, ns = sum(int(r["Calls"]) for r in sel), sum(float(r["TotalDurationNs"]) for r in sel)
+        assert calls > 0, fam["kernel"]
+        avg_s = ns / calls * 1e-9
+        work = fam["algorithmic_flops_per_launch"] if fam["bound"] == "mfma" else fam["algorithmic_bytes_per_launch"]
+        frac = work / avg_s / (1e12 if fam["bound"] == "mfma" else 1e9) / fam["peak"]
+        assert abs(frac - fam["frac"]) <= 0.02 * fam["frac"], (fam["kernel"], frac, fam["frac"])
+        checked += 1
+    assert checked == 4 and abs(line["roofline"]["frac"] - full["roofline_families"][0]["frac"]) < 1e-4
