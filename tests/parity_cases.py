@@ -1584,10 +1584,17 @@ def rcnet_config3_rank_case(dev, tol=TOL):
         engine.set_compute_dtype("fp32"); engine.clear_caches()
 
 
-def rcnet_fullsize_bf16_case(dev, tol_logits=6e-2, tol_grad=0.12):
+def rcnet_fullsize_bf16_case(dev, tol_logits=5e-2, tol_grad=0.12):
     """configs[1] exactly (B = 8, 496x612 padded, R = 240, patch 240x100): the bf16 throughput mode against the fp32 HIP path (itself
     pinned to the oracle / reference at 1e-3) on identical weights and inputs.  Stated tolerances: logits of 24 sampled RoIs within
-    6e-2 of max|logit| (max-norm over 576 000 values; their relative L2 error within 4e-2), loss within 1e-2 relative, per-module gradient vectors within 8 % relative L2 and cosine > 0.995."""
+    5e-2 of max|logit| (max-norm over 576 000 values, measured 4.65e-2; their relative L2 error within 4e-2, measured 3.0e-2), loss within 1e-2
+    relative, per-module gradient vectors within 12 % relative L2 and cosine > 0.99 (measured: decoder 0.48 %, image encoder 5.8 %, point MLP 9.6 %,
+    transformer 10.9 %).  Round 6 localised where the gradient distance comes from (tools/grad_localise.py, profiles/r06_grad_localise.txt): it is
+    NOT accumulated rounding on the latent path -- the activation gradient is already 16 % away two layers below the loss and stays at 23-25 %
+    through the whole transformer; a 2-3 % forward deviation flips LeakyReLU slopes (1 <-> 0.2) on ~2 % of the elements, and a weight gradient
+    averages that noise over the pixels behind it (5.76 M for the decoder, 5 040 rows for the transformer).  The fp32 path with only its operands
+    rounded to bf16 ONCE moves the same parameter gradients by 0.39 / 3.8 / 9.1 / 7.3 %: the bounds here are 1.2-1.5 x the network's own
+    sensitivity and cannot be tightened by any storage format of the small tensors; rcnet_bf16_convergence_case checks what matters instead."""
     from riders_amd import engine, rcnet_main
     cfg = rcnet_main.ZJU_CONFIG
     batch = rcnet_main.synthetic_batch(8, 256, 512, cfg, seed=1234, device=dev)

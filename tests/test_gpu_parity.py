@@ -714,3 +714,41 @@ def test_autograph_sml_unchanged_loop_matches_eager(gpu):
             assert d[0] <= 1e-4 * max(d[1], 1e-3), (k, d)
         else:
             assert torch.equal(sde[k], sda[k]), k
+
+
+def test_autograph_other_shapes_and_eval_take_the_right_path(gpu):
+    """A captured region must not be replayed for anything it was not captured for: a batch of another size runs eagerly (and is captured on its
+    own second call), a validation forward under no_grad in between is eager and sees the trained BatchNorm statistics, and going back to the
+    first geometry replays its entry again.  Losses against the all-eager loop."""
+    import torch
+    from riders_amd import engine, rcnet_main
+    cfg = dict(rcnet_main.ZJU_CONFIG, patch_size=[64, 32], total_points_sampled=4)
+    sizes = [2, 2, 2, 1, 1, 2, 1, 2]
+    batches = [rcnet_main.synthetic_batch(b, 64, 96, cfg, seed=60 + i, device=gpu) for i, b in enumerate(sizes)]
+    res = {}
+    for mode in ("eager", "autograph"):
+        engine.set_autograph(mode == "autograph")
+        engine.set_deterministic_roi_pool(True)
+        try:
+            torch.manual_seed(0)
+            model = rcnet_main.build_model(gpu, cfg)
+            model.train()
+            opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+            out = []
+            for i, b in enumerate(batches):
+                loss = rcnet_main.forward_loss(model, b, cfg)
+                opt.zero_grad(); loss.backward(); opt.step()
+                out.append(loss.item())
+                if i == 4:      # a validation pass in the middle of training
+                    model.eval()
+                    with torch.no_grad():
+                        out.append(float(rcnet_main.forward_loss(model, batches[0], cfg)))
+                    model.train()
+            res[mode] = (out, engine.autograph_stats())
+        finally:
+            engine.set_autograph(False)
+            engine.set_deterministic_roi_pool(False)
+    (le, _), (la, st) = res["eager"], res["autograph"]
+    for a, b in zip(le, la):
+        assert abs(a - b) <= 1e-5 * abs(a), (le, la)
+    assert st["captured"] >= 2 and st["eager"] >= 2, st      # two geometries, each: first call eager, second captured
