@@ -39,13 +39,33 @@ def _newer(a, b):
     return (not os.path.exists(b)) or os.path.getmtime(a) > os.path.getmtime(b)
 
 
+_INC = None
+
+
+def _local_includes(path, seen):
+    """the csrc/*.h files `path` includes, transitively (#include "x.h" only: system and ROCm headers do not change between builds)"""
+    import re
+    try:
+        text = open(path).read()
+    except OSError:
+        return
+    for name in re.findall(r'#\s*include\s+"([^"]+)"', text):
+        h = os.path.normpath(os.path.join(os.path.dirname(path), name))
+        if os.path.exists(h) and h not in seen:
+            seen.add(h)
+            _local_includes(h, seen)
+
+
 def _headers_mtime(src=None):
-    """newest header a source depends on: the kernel units (.hip) include csrc/*.h only; the public header include/riders_hip.h is included
-    by the C ABI layer (rd_api.cpp, rd_comm.cpp, rd_host.cpp), so a new entry point does not recompile every kernel twice"""
-    hs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
-    if src is None or src.endswith(".cpp"):
-        hs.append(os.path.join(HERE, "..", "include", "riders_hip.h"))
-    return max(os.path.getmtime(h) for h in hs)
+    """newest header `src` depends on: the headers it includes, transitively (a change in rd_attention_head.h recompiles the two units that
+    include it, not all twenty-five; the public header include/riders_hip.h reaches the C ABI layer only)"""
+    if src is None:
+        hs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [os.path.join(HERE, "..", "include", "riders_hip.h")]
+    else:
+        seen = set()
+        _local_includes(src, seen)
+        hs = list(seen)
+    return max([os.path.getmtime(h) for h in hs] or [0.0])
 
 
 def build(force=False, verbose=True):

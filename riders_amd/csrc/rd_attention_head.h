@@ -16,6 +16,20 @@ __device__ __forceinline__ f32x4 wave_mm(const float* a, int ai, int ak, const f
   return acc;
 }
 
+// the same with the contraction length fixed at compile time: fully unrolled, so that all LDS operand reads of the chain are issued before the
+// first MFMA waits for one (the rolled loop was read -> wait -> MFMA per step of four: ~160 cycles per step).  Rows beyond the sequence are
+// zero in every scratch tile, so contracting over all MAXR rows adds exact zeros: bit-identical to the rolled loop over the padded length.
+template <int K>
+__device__ __forceinline__ f32x4 wave_mm_k(const float* a, int ai, int ak, const float* b, int bk, int bj, f32x4 acc) {
+  const int lane = threadIdx.x & 63, r = lane & 15, g = lane >> 4;
+  float av[K / 4], bv[K / 4];
+#pragma unroll
+  for (int i = 0; i < K / 4; i++) { av[i] = a[r * ai + (4 * i + g) * ak]; bv[i] = b[(4 * i + g) * bk + r * bj]; }
+#pragma unroll
+  for (int i = 0; i < K / 4; i++) acc = mfma_16x16x4_f32(av[i], bv[i], acc);
+  return acc;
+}
+
 struct AttnSmem {
   float q[MAXR * LD], k[MAXR * LD], v[MAXR * LD], d[MAXR * LD];
   float kv[16 * LD], dkv[16 * LD];
@@ -113,12 +127,16 @@ __device__ __forceinline__ void attn_head(AttnSmem& s, const T* __restrict__ q, 
   // KV = K^T V  (16 x 16), Ksum
   {
     f32x4 acc = f32x4{0, 0, 0, 0};
-    acc = wave_mm(s.k, 1, LD, s.v, LD, 1, Sp, acc);
+    acc = wave_mm_k<MAXR>(s.k, 1, LD, s.v, LD, 1, acc);
 #pragma unroll
     for (int e = 0; e < 4; e++) s.kv[(g * 4 + e) * LD + r] = acc[e];
-    if (lane < 16) {
+    if (lane < 16) {      // (rows >= S are zero: the sum over all MAXR rows in ascending order is the sum over S; unrolled, the reads are in flight together)
+      float kx[MAXR];
+#pragma unroll
+      for (int ss = 0; ss < MAXR; ss++) kx[ss] = s.k[ss * LD + lane];
       float t = 0.f;
-      for (int ss = 0; ss < S; ss++) t += s.k[ss * LD + lane];
+#pragma unroll
+      for (int ss = 0; ss < MAXR; ss++) t += kx[ss];
       s.ksum[lane] = t;
     }
   }
@@ -135,7 +153,7 @@ __device__ __forceinline__ void attn_head(AttnSmem& s, const T* __restrict__ q, 
 #pragma unroll
   for (int tI = 0; tI < 2; tI++) {
     P[tI] = f32x4{0, 0, 0, 0};
-    if (tI < lt) P[tI] = wave_mm(s.q + tI * 16 * LD, LD, 1, s.kv, LD, 1, 16, P[tI]);
+    if (tI < lt) P[tI] = wave_mm_k<16>(s.q + tI * 16 * LD, LD, 1, s.kv, LD, 1, P[tI]);
 #pragma unroll
     for (int e = 0; e < 4; e++) Z[tI][e] = s.zinv[tI * 16 + g * 4 + e];
   }
@@ -174,7 +192,7 @@ __device__ __forceinline__ void attn_head(AttnSmem& s, const T* __restrict__ q, 
   for (int tI = 0; tI < 2; tI++) {
     if (tI < lt) {
       f32x4 a = f32x4{0, 0, 0, 0};
-      a = wave_mm(s.d + tI * 16 * LD, LD, 1, s.kv, 1, LD, 16, a);
+      a = wave_mm_k<16>(s.d + tI * 16 * LD, LD, 1, s.kv, 1, LD, a);
 #pragma unroll
       for (int e = 0; e < 4; e++) {
         int l = tI * 16 + g * 4 + e;
@@ -187,12 +205,16 @@ __device__ __forceinline__ void attn_head(AttnSmem& s, const T* __restrict__ q, 
   // dKV = Q^T dP (16 x 16), dKsum = sum_l dden[l] Q[l,:]
   {
     f32x4 a = f32x4{0, 0, 0, 0};
-    a = wave_mm(s.q, 1, LD, s.d, LD, 1, Lp, a);
+    a = wave_mm_k<MAXR>(s.q, 1, LD, s.d, LD, 1, a);
 #pragma unroll
     for (int e = 0; e < 4; e++) s.dkv[(g * 4 + e) * LD + r] = a[e];
-    if (lane < 16) {
+    if (lane < 16) {      // (q rows >= L are zero: their products are exact zeros)
+      float dx[MAXR], qx[MAXR];
+#pragma unroll
+      for (int l = 0; l < MAXR; l++) { dx[l] = s.dden[l]; qx[l] = s.q[l * LD + lane]; }
       float t = 0.f;
-      for (int l = 0; l < L; l++) t += s.dden[l] * s.q[l * LD + lane];
+#pragma unroll
+      for (int l = 0; l < MAXR; l++) t += (l < L ? dx[l] : 0.f) * qx[l];
       s.dksum[lane] = t;
     }
   }
@@ -202,8 +224,8 @@ __device__ __forceinline__ void attn_head(AttnSmem& s, const T* __restrict__ q, 
   for (int tI = 0; tI < 2; tI++) {
     if (tI < stl) {
       f32x4 a = f32x4{0, 0, 0, 0}, b = f32x4{0, 0, 0, 0};
-      a = wave_mm(s.v + tI * 16 * LD, LD, 1, s.dkv, 1, LD, 16, a);
-      b = wave_mm(s.k + tI * 16 * LD, LD, 1, s.dkv, LD, 1, 16, b);
+      a = wave_mm_k<16>(s.v + tI * 16 * LD, LD, 1, s.dkv, 1, LD, a);
+      b = wave_mm_k<16>(s.k + tI * 16 * LD, LD, 1, s.dkv, LD, 1, b);
 #pragma unroll
       for (int e = 0; e < 4; e++) {
         int ss = tI * 16 + g * 4 + e;

@@ -837,12 +837,35 @@ def _capture_region(runner, inputs, params, on_replay):
     return e
 
 
+def _dense(t):
+    """non-overlapping and dense: the strides are a permutation of a contiguous layout (contiguous, channels_last, permuted views of either)"""
+    n = 1
+    for size, stride in sorted(((sz, st) for sz, st in zip(t.shape, t.stride()) if sz != 1), key=lambda p: p[1]):
+        if stride != n:
+            return False
+        n *= size
+    return True
+
+
+def dev_copy(dst, src):
+    """dst <- src on the current stream with a KERNEL (rd_cast) where the two tensors have the same dense layout and a dtype the library knows;
+    torch's copy_ otherwise.  Used for everything that is copied right in front of a hipGraph replay: torch's contiguous same-dtype copy is a
+    hipMemcpyAsync, and on this ROCm a memory node / copy next to graph kernels has been seen mis-ordered once already (the
+    hipMemsetAsync finding; round 6: gradients cloned right before a backward replay came out corrupted) -- kernel -> graph ordering is the
+    path every captured step has exercised since round 1."""
+    if (dst.dtype == src.dtype and dst.dtype in _RD_DT and dst.shape == src.shape and dst.stride() == src.stride() and src.is_cuda and dst.is_cuda
+            and dst.numel() > 0 and _dense(dst)):
+        _chk(L().rd_cast(_p(src), _p(dst), src.numel(), rd_of(src), rd_of(dst), 1.0, _stream(src)), "rd_cast")
+    else:
+        dst.copy_(src, non_blocking=True)
+
+
 class _GraphedRegion(torch.autograd.Function):
     @staticmethod
     def forward(ctx, e, fresh, n_in, *tensors):
         for s_, x in zip(e.static_in, tensors[:n_in]):
             if s_ is not None and x.data_ptr() != s_.data_ptr():
-                s_.copy_(x, non_blocking=True)
+                dev_copy(s_, x)
         if not fresh:
             v = sum(p._version for p in e.params.values())
             if v != e.versions:       # an optimizer rewrote the parameters through torch since the last replay: ONE launch re-packs this region's operands
@@ -865,7 +888,7 @@ class _GraphedRegion(torch.autograd.Function):
             if g is None:
                 sg.zero_()
             else:
-                sg.copy_(g, non_blocking=True)
+                dev_copy(sg, g)
         e.g_b.replay()
         # publish: the caller's .grad tensors are views of e.flat_pub.  Cleared gradients (zero_grad(set_to_none), the reference loop's habit) ->
         # one copy of the whole static buffer; gradients still in place from the previous backward -> one add (torch's accumulation semantics);
@@ -873,7 +896,7 @@ class _GraphedRegion(torch.autograd.Function):
         mine = e.mine
         state = [e.params[pid].grad for pid in mine]
         if all(g is None for g in state):
-            e.flat_pub.copy_(e.flat_sg, non_blocking=True)
+            dev_copy(e.flat_pub, e.flat_sg)
             for pid in mine:
                 e.params[pid].grad = e.pub[pid]
         elif all(g is not None and g.data_ptr() == e.pub[pid].data_ptr() for g, pid in zip(state, mine)):

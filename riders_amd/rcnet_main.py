@@ -296,7 +296,10 @@ class GraphedStep(object):
         for dst, src in zip(static, batch):
             if tuple(dst.shape) != tuple(src.shape):
                 raise ValueError("load_batch: shape %s does not match the captured %s (a hipGraph replays fixed shapes)" % (tuple(src.shape), tuple(dst.shape)))
-            dst.copy_(src, non_blocking=True)
+            if src.is_cuda:
+                engine.dev_copy(dst, src)      # a kernel, not a hipMemcpyAsync, in front of the replay (engine.dev_copy)
+            else:
+                dst.copy_(src, non_blocking=True)
 
     def __call__(self):
         for g, tag in zip(self.graphs, self.tags):

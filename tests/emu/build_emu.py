@@ -21,16 +21,19 @@ FLAGS = ["-x", "c++", "-std=c++17", "-O1", "-fPIC", "-ffp-contract=off", "-I", o
 def build(verbose=False, extra=()):
     os.makedirs(OUT, exist_ok=True)
     srcs = sorted(f for f in os.listdir(CSRC) if f.endswith(".hip") or f.endswith(".cpp"))
-    hdrs = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
-    hdrs += [os.path.join(HERE, "include", "hip", "hip_runtime.h")]
-    hm_k = max(os.path.getmtime(h) for h in hdrs)      # kernel units include csrc/*.h + the emulator's runtime header ...
-    hm_api = max(hm_k, os.path.getmtime(os.path.join(ROOT, "include", "riders_hip.h")))      # ... only the C ABI layer (.cpp) the public header
+    sys.path.insert(0, ROOT)
+    from riders_amd.build import _local_includes      # "which csrc headers does this unit include, transitively"
+    emu_rt = os.path.getmtime(os.path.join(HERE, "include", "hip", "hip_runtime.h"))
     jobs, objs = [], []
     for f in srcs:        # every kernel unit twice: bf16 build and fp16 build (-DRD_HALF_F16, namespace rd_f16), as riders_amd/build.py
+        src = os.path.join(CSRC, f)
+        seen = set()
+        _local_includes(src, seen)
+        newest = max([os.path.getmtime(src), emu_rt] + [os.path.getmtime(h) for h in seen])
         for suffix, flags in ((".o", []), (".f16.o", ["-DRD_HALF_F16"])) if f.endswith(".hip") else ((".o", []),):
-            src, obj = os.path.join(CSRC, f), os.path.join(OUT, f + suffix)
+            obj = os.path.join(OUT, f + suffix)
             objs.append(obj)
-            if not os.path.exists(obj) or os.path.getmtime(obj) < max(hm_api if f.endswith(".cpp") else hm_k, os.path.getmtime(src)):
+            if not os.path.exists(obj) or os.path.getmtime(obj) < newest:
                 jobs.append((src, obj, flags))
 
     def cc(job):
