@@ -536,6 +536,15 @@ int rd_sml_loss_fwd(const float* pred, const float* image, const float* gt_inter
 int rd_sml_loss_bwd(const float* pred, const float* gt_interp, const float* gt_sparse, const float* gfx, const float* gfy, const float* info,
                     const float* dloss, int32_t N, int32_t H, int32_t W, int32_t filter_size, float w_lidar, float w_smooth, float* dpred,
                     void* stream);
+/* the same for the reference's other supervised terms (utils/loss.py:55-100): loss_kind 0 = 'l1', 1 = 'l2' (mse), 2 = 'smoothl1' (beta 1); with
+   w_edge > 0 (needs w_smooth > 0) the saved gradient fields gfx / gfy also carry the edge-matching term (utils/loss.py:241-249), so the backward
+   below differentiates it too.  rd_sml_loss_fwd / _bwd are loss_kind 0. */
+int rd_sml_loss_fwd_kind(const float* pred, const float* image, const float* gt_interp, const float* gt_sparse, const float* weights, int32_t N,
+                         int32_t H, int32_t W, int32_t filter_size, int32_t loss_kind, float w_lidar, float w_smooth, float w_edge, float* gfx,
+                         float* gfy, double* partial, float* info, void* stream);
+int rd_sml_loss_bwd_kind(const float* pred, const float* gt_interp, const float* gt_sparse, const float* gfx, const float* gfy, const float* info,
+                         const float* dloss, int32_t N, int32_t H, int32_t W, int32_t filter_size, int32_t loss_kind, float w_lidar, float w_smooth,
+                         float* dpred, void* stream);
 /* val_zju.py:200-206 bicubic (A=-0.75, align_corners=False); :212-231 + utils/eval_utils.py metric sums, res = doubles [N][8] */
 int rd_bicubic_resize(const float* x, float* y, int32_t N, int32_t H, int32_t W, int32_t OH, int32_t OW, void* stream);
 int rd_depth_metrics(const float* out, const float* gt, int32_t N, int32_t HW, float min_depth, float max_depth, double* res, void* stream);

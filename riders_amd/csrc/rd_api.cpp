@@ -976,6 +976,23 @@ int rd_sml_loss_bwd(const float* pred, const float* gi, const float* gs, const f
   rd::launch_sml_loss_bwd(pred, gi, gs, gfx, gfy, info, dloss, N, H, W, fs, w_lidar > 0.f ? 1 : 0, w_lidar, w_smooth, dpred, S(stream));
   return done("rd_sml_loss_bwd");
 }
+int rd_sml_loss_fwd_kind(const float* pred, const float* image, const float* gi, const float* gs, const float* weights, int32_t N, int32_t H, int32_t W,
+                         int32_t fs, int32_t loss_kind, float w_lidar, float w_smooth, float w_edge, float* gfx, float* gfy, double* partial, float* info,
+                         void* stream) {
+  if (!pred || !image || !gi || !gs || !gfx || !gfy || !partial || !info) return fail("sml_loss_fwd: null pointer");
+  if (fs < 3 || fs > 9 || !(fs & 1)) return fail("sml_loss: filter size must be odd in 3..9");
+  if (loss_kind < 0 || loss_kind > 2) return fail("sml_loss: loss_kind must be 0 ('l1'), 1 ('l2') or 2 ('smoothl1')");
+  if (w_edge > 0.f && !(w_smooth > 0.f)) return fail("sml_loss: w_edge > 0 needs w_smoothness > 0 (the gradient fields are stored per unit of w_smoothness)");
+  rd::launch_sml_loss_fwd(pred, image, gi, gs, weights, N, H, W, fs, (w_lidar > 0.f ? 1 : 0) | (loss_kind << 1), w_lidar, w_smooth, w_edge, gfx, gfy, partial, info, S(stream));
+  return done("rd_sml_loss_fwd_kind");
+}
+int rd_sml_loss_bwd_kind(const float* pred, const float* gi, const float* gs, const float* gfx, const float* gfy, const float* info, const float* dloss,
+                         int32_t N, int32_t H, int32_t W, int32_t fs, int32_t loss_kind, float w_lidar, float w_smooth, float* dpred, void* stream) {
+  if (!pred || !gi || !gs || !gfx || !gfy || !info || !dloss || !dpred) return fail("sml_loss_bwd: null pointer");
+  if (loss_kind < 0 || loss_kind > 2) return fail("sml_loss: loss_kind must be 0 ('l1'), 1 ('l2') or 2 ('smoothl1')");
+  rd::launch_sml_loss_bwd(pred, gi, gs, gfx, gfy, info, dloss, N, H, W, fs, (w_lidar > 0.f ? 1 : 0) | (loss_kind << 1), w_lidar, w_smooth, dpred, S(stream));
+  return done("rd_sml_loss_bwd_kind");
+}
 int rd_bicubic_resize(const float* x, float* y, int32_t N, int32_t H, int32_t W, int32_t OH, int32_t OW, void* stream) {
   if (!x || !y) return fail("bicubic_resize: null pointer");
   rd::launch_bicubic(x, y, N, H, W, OH, OW, S(stream));

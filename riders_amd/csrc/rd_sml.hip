@@ -295,11 +295,22 @@ __device__ __forceinline__ float sgn(float x) { return x > 0.f ? 1.f : (x < 0.f 
 // per pixel: masked L1 terms and Sobel terms; block partials[blk][8]; gfx/gfy = weights * w_{x,y} * sign(pred_{dx,dy})
 // FS: compile-time Sobel size (3 / 5 / 7; 0 = the run-time `fs_rt`): with it the tap loops unroll and their 2 * FS^2 + 9 loads -- always
 // in bounds, the indices are clamped -- issue as one batch; as run-time loops every tap was its own memory round trip.
+// supervised term of one pixel and its derivative: 'l1' |d|, 'l2' d^2 (F.mse_loss), 'smoothl1' 0.5 d^2 below 1, |d| - 0.5 above (F.smooth_l1_loss, beta 1)
+__device__ __forceinline__ float sml_loss_term(float d, int kind) {
+  const float a = fabsf(d);
+  return kind == 0 ? a : (kind == 1 ? d * d : (a < 1.f ? 0.5f * d * d : a - 0.5f));
+}
+__device__ __forceinline__ float sml_loss_dterm(float d, int kind) {
+  return kind == 0 ? sgn(d) : (kind == 1 ? 2.f * d : (fabsf(d) < 1.f ? d : sgn(d)));
+}
 template <int FS>
 __global__ __launch_bounds__(256) void sml_loss_fwd_kernel(const float* __restrict__ pred, const float* __restrict__ image,
                                                            const float* __restrict__ gt_interp, const float* __restrict__ gt_sparse,
-                                                           const float* __restrict__ weights, int N, int H, int W, int fs_rt, int mask_interp,
-                                                           float* __restrict__ gfx, float* __restrict__ gfy, double* __restrict__ partial) {
+                                                           const float* __restrict__ weights, int N, int H, int W, int fs_rt, int flags,
+                                                           float edge_ratio, float* __restrict__ gfx, float* __restrict__ gfy, double* __restrict__ partial) {
+  // flags: bit 0 = mask the interpolated ground truth where sparse lidar exists (loss.py:26-33); bits 1-2 = loss_func 0 'l1', 1 'l2', 2 'smoothl1'
+  // (utils/loss.py:55-100).  edge_ratio = w_edge / w_smoothness: the gradient fields then carry the edge-matching term too (loss.py:241-249).
+  const int mask_interp = flags & 1, kind = (flags >> 1) & 3;
   __shared__ double sh[4];
   const int64_t total = (int64_t)N * H * W;
   const int fs = FS ? FS : fs_rt;
@@ -312,8 +323,8 @@ __global__ __launch_bounds__(256) void sml_loss_fwd_kernel(const float* __restri
     float o = P[(int64_t)h * W + w];
     float gs = gt_sparse[i], gi = gt_interp[i];
     if (mask_interp && gs > 0.f) gi = 0.f;
-    if (gi > 0.f) { acc[0] += fabsf(o - gi); acc[1] += 1.0; }
-    if (gs > 0.f) { acc[2] += fabsf(o - gs); acc[3] += 1.0; }
+    if (gi > 0.f) { acc[0] += sml_loss_term(o - gi, kind); acc[1] += 1.0; }
+    if (gs > 0.f) { acc[2] += sml_loss_term(o - gs, kind); acc[3] += 1.0; }
     float pdx = 0.f, pdy = 0.f, idx = 0.f, idy = 0.f;
 #pragma unroll
     for (int u = 0; u < fs; u++) {
@@ -341,7 +352,12 @@ __global__ __launch_bounds__(256) void sml_loss_fwd_kernel(const float* __restri
     float wx = wt * __expf(-fabsf(sdy)), wy = wt * __expf(-fabsf(sdx));  // x-term weighted by the image's y-gradient (loss.py:235-239)
     acc[4] += wx * fabsf(pdx); acc[5] += wy * fabsf(pdy);
     acc[6] += wt * fabsf(fabsf(pdx) - fabsf(idx)); acc[7] += wt * fabsf(fabsf(pdy) - fabsf(idy));
-    gfx[i] = wx * sgn(pdx); gfy[i] = wy * sgn(pdy);
+    float fx = wx * sgn(pdx), fy = wy * sgn(pdy);
+    if (edge_ratio != 0.f) {      // d | |p'| - |i'| | / d p' = sgn(|p'| - |i'|) sgn(p'), weighted like the loss term
+      fx += edge_ratio * wt * sgn(fabsf(pdx) - fabsf(idx)) * sgn(pdx);
+      fy += edge_ratio * wt * sgn(fabsf(pdy) - fabsf(idy)) * sgn(pdy);
+    }
+    gfx[i] = fx; gfy[i] = fy;
   }
   for (int j = 0; j < 8; j++) {
     double s = block_sum_d(acc[j], sh);
@@ -373,8 +389,9 @@ template <int FS>
 __global__ __launch_bounds__(256) void sml_loss_bwd_kernel(const float* __restrict__ pred, const float* __restrict__ gt_interp,
                                                            const float* __restrict__ gt_sparse, const float* __restrict__ gfx,
                                                            const float* __restrict__ gfy, const float* __restrict__ info,
-                                                           const float* __restrict__ dloss, int N, int H, int W, int fs_rt, int mask_interp,
+                                                           const float* __restrict__ dloss, int N, int H, int W, int fs_rt, int flags,
                                                            float w_lidar, float w_smooth, float* __restrict__ dpred) {
+  const int mask_interp = flags & 1, kind = (flags >> 1) & 3;
   const int64_t total = (int64_t)N * H * W;
   const int fs = FS ? FS : fs_rt;
   const int r = fs / 2;
@@ -395,8 +412,8 @@ __global__ __launch_bounds__(256) void sml_loss_bwd_kernel(const float* __restri
       float o = pred[i], gs = gt_sparse[i], gi = gt_interp[i];
       if (mask_interp && gs > 0.f) gi = 0.f;
       float g = 0.f;
-      if (gi > 0.f) g += c_sup * sgn(o - gi);
-      if (gs > 0.f) g += c_lid * sgn(o - gs);
+      if (gi > 0.f) g += c_sup * sml_loss_dterm(o - gi, kind);
+      if (gs > 0.f) g += c_lid * sml_loss_dterm(o - gs, kind);
       const float* FX = gfx + i + (int64_t)r * W + r; const float* FY = gfy + i + (int64_t)r * W + r;      // tap (u, v) reads (h - u + r, w - v + r)
       float s = 0.f;
 #pragma unroll
@@ -425,8 +442,8 @@ __global__ __launch_bounds__(256) void sml_loss_bwd_kernel(const float* __restri
     float o = pred[i], gs = gt_sparse[i], gi = gt_interp[i];
     if (mask_interp && gs > 0.f) gi = 0.f;
     float g = 0.f;
-    if (gi > 0.f) g += c_sup * sgn(o - gi);
-    if (gs > 0.f) g += c_lid * sgn(o - gs);
+    if (gi > 0.f) g += c_sup * sml_loss_dterm(o - gi, kind);
+    if (gs > 0.f) g += c_lid * sml_loss_dterm(o - gs, kind);
     if (w_smooth > 0.f) {
       // padded rows that clamp onto h: h itself, plus -r..-1 when h == 0, plus H..H+r-1 when h == H-1 (same for columns)
       int ph0 = h == 0 ? -r : h, ph1 = h == H - 1 ? H - 1 + r : h;
@@ -539,7 +556,8 @@ void launch_sml_loss_fwd(const float* pred, const float* image, const float* gi,
                          float* info, hipStream_t st) {
   int64_t n = (int64_t)N * H * W;
   int rows = sml_loss_rows(n);
-#define RD_LF(F) hipLaunchKernelGGL((sml_loss_fwd_kernel<F>), dim3(rows), dim3(256), 0, st, pred, image, gi, gs, weights, N, H, W, fs, mask_interp, gfx, gfy, partial)
+  const float edge_ratio = (w_edge > 0.f && w_smooth > 0.f) ? w_edge / w_smooth : 0.f;      // (mask_interp carries the loss kind in bits 1-2: rd_sml_loss_fwd_kind)
+#define RD_LF(F) hipLaunchKernelGGL((sml_loss_fwd_kernel<F>), dim3(rows), dim3(256), 0, st, pred, image, gi, gs, weights, N, H, W, fs, mask_interp, edge_ratio, gfx, gfy, partial)
   if (fs == 7) RD_LF(7); else if (fs == 5) RD_LF(5); else if (fs == 3) RD_LF(3); else RD_LF(0);
 #undef RD_LF
   hipLaunchKernelGGL(sml_loss_finalize_kernel, dim3(1), dim3(64), 0, st, partial, rows, (double)n, fs, w_lidar, w_smooth, w_edge, info);

@@ -2421,8 +2421,9 @@ def reciprocal(x):
     return out
 
 
-def sml_loss(pred, image, gt_interp, gt_sparse, weights, w_lidar, w_smooth, w_edge, filter_size):
-    """utils/loss.py compute_loss ('l1') on (N,1,H,W) fp32 contiguous tensors -> (info[7] tensor)."""
+def sml_loss(pred, image, gt_interp, gt_sparse, weights, w_lidar, w_smooth, w_edge, filter_size, loss_kind=0):
+    """utils/loss.py compute_loss on (N,1,H,W) fp32 contiguous tensors -> (info[7] tensor).  loss_kind 0 'l1', 1 'l2', 2 'smoothl1' (:55-100);
+    w_edge > 0 adds the edge-matching term (:241-249) to the loss AND to the saved gradient fields (needs w_smooth > 0)."""
     lib, t, st = L(), tape(), _stream(pred)
     N, _, H, W = pred.shape
     n = pred.numel()
@@ -2430,12 +2431,10 @@ def sml_loss(pred, image, gt_interp, gt_sparse, weights, w_lidar, w_smooth, w_ed
     partial = torch.empty((rows, 8), dtype=torch.float64, device=pred.device)
     gfx, gfy = torch.empty_like(pred), torch.empty_like(pred)
     info = torch.empty(7, dtype=torch.float32, device=pred.device)
-    _chk(lib.rd_sml_loss_fwd(_p(pred), _p(image), _p(gt_interp), _p(gt_sparse), _p(weights), N, H, W, filter_size, w_lidar, w_smooth, w_edge,
-                             _p(gfx), _p(gfy), _p(partial), _p(info), st), "rd_sml_loss_fwd")
+    _chk(lib.rd_sml_loss_fwd_kind(_p(pred), _p(image), _p(gt_interp), _p(gt_sparse), _p(weights), N, H, W, filter_size, int(loss_kind), w_lidar, w_smooth,
+                                  w_edge, _p(gfx), _p(gfy), _p(partial), _p(info), st), "rd_sml_loss_fwd_kind")
     loss = info[0]
     if t is not None and t.requires(pred):
-        if w_edge > 0:
-            raise NotImplementedError("w_edge > 0 has no backward kernel (train_zju.py:466 uses w_edge = 0)")
         t.mark(loss)
 
         def backward():
@@ -2443,8 +2442,8 @@ def sml_loss(pred, image, gt_interp, gt_sparse, weights, w_lidar, w_smooth, w_ed
             if g is None:
                 return
             dp = torch.empty_like(pred)
-            _chk(lib.rd_sml_loss_bwd(_p(pred), _p(gt_interp), _p(gt_sparse), _p(gfx), _p(gfy), _p(info), _p(g), N, H, W, filter_size, w_lidar,
-                                     w_smooth, _p(dp), st), "rd_sml_loss_bwd")
+            _chk(lib.rd_sml_loss_bwd_kind(_p(pred), _p(gt_interp), _p(gt_sparse), _p(gfx), _p(gfy), _p(info), _p(g), N, H, W, filter_size, int(loss_kind),
+                                          w_lidar, w_smooth, _p(dp), st), "rd_sml_loss_bwd_kind")
             t.add_grad(pred, dp)
         t.record(backward)
     return loss, info

@@ -131,6 +131,19 @@ def loss_case(dev, tol=1e-4):
             assert abs(a - float(b)) <= tol * max(abs(float(b)), 1e-3), (fs, nm, a, float(b))
         loss.backward()
         close(pred.grad, g["dpred"], 10 * tol, "sml loss dpred fs=%d" % fs)
+    # round 6: loss_func 'l2' / 'smoothl1' and w_edge > 0 against the reference's own values and gradients (fixtures g7_loss_l2 / _smoothl1 / _edge / _smoothl1_edge)
+    near = (np.where(gi > 0, gi, np.where(gs > 0, gs, 10.0)) + rand_array("g7.near", (N, 1, H, W), 2.0)).astype(np.float32)
+    for tag, lf, we in (("l2", "l2", 0.0), ("smoothl1", "smoothl1", 0.0), ("edge", "l1", 0.35), ("smoothl1_edge", "smoothl1", 0.5)):
+        g = load("g7_loss_" + tag)
+        pred = t(near, dev).requires_grad_()
+        loss, info = compute_loss(image=image, output_depth=pred, gt_interp=t(gi, dev), gt_sparse=t(gs, dev), loss_func=lf, w_smoothness=0.2,
+                                  sobel_filter_size=5, validity_map_loss_smoothness=torch.ones_like(image), w_lidar_loss=1.5, w_edge=we,
+                                  invalid_map_gt=None, w_unsupervised=0.0)
+        got = [float(info[k]) for k in ('loss', 'loss_supervised', 'loss_lidar', 'loss_smoothness', 'loss_edge')]
+        for a, b, nm in zip(got, g["loss"], ('loss', 'sup', 'lidar', 'smooth', 'edge')):
+            assert abs(a - float(b)) <= tol * max(abs(float(b)), 1e-3), (tag, nm, a, float(b))
+        loss.backward()
+        close(pred.grad, g["dpred"], 10 * tol, "sml loss dpred " + tag)
     g = load("g7_outlier")
     gt = rand_array("g7.or", (N, 1, H, W), 40.0, lo=0.0); gt[rand_array("g7.orm", gt.shape, 1.0, lo=0.0) < 0.5] = 0
     assert np.array_equal(OutlierRemoval(3, 1.5).remove_outliers(t(gt, dev)).cpu().numpy(), g["out"])

@@ -20,6 +20,16 @@ def test_g7_loss_and_outlier():
         assert np.allclose(got, g["loss"], rtol=1e-5, atol=1e-6), (got, g["loss"])
         loss.backward()
         close(pred.grad, g["dpred"], 1e-5)
+    # round 6: 'l2' / 'smoothl1' and the edge-matching term (utils/loss.py:72-100, :241-249), fixtures from the reference's compute_loss
+    near = (np.where(gi > 0, gi, np.where(gs > 0, gs, 10.0)) + rand_array("g7.near", (N, 1, H, W), 2.0)).astype(np.float32)
+    for tag, lf, we in (("l2", "l2", 0.0), ("smoothl1", "smoothl1", 0.0), ("edge", "l1", 0.35), ("smoothl1_edge", "smoothl1", 0.5)):
+        g = load("g7_loss_" + tag)
+        pred = t(near).requires_grad_()
+        loss, info = OS.compute_loss(image, pred, t(gi), t(gs), 0.2, 5, None, 1.5, we, lf)
+        got = [float(info[k]) for k in ('loss', 'loss_supervised', 'loss_lidar', 'loss_smoothness', 'loss_edge')]
+        assert np.allclose(got, g["loss"], rtol=1e-5, atol=1e-6), (tag, got, g["loss"])
+        loss.backward()
+        close(pred.grad, g["dpred"], 1e-5)
     g = load("g7_outlier")
     gt = rand_array("g7.or", (N, 1, H, W), 40.0, lo=0.0); gt[rand_array("g7.orm", gt.shape, 1.0, lo=0.0) < 0.5] = 0
     assert np.array_equal(OS.remove_outliers(t(gt), 3, 1.5).numpy(), g["out"])
