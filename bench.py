@@ -367,9 +367,24 @@ def _child_base(args, workload, outdir, steps=2, warmup=1, eager=True, settle=0.
     return base
 
 
+CHILD_BUDGET = {"left": 300.0}      # seconds all profiler children of one run may take together (normally ~50 s); beyond it the rest are skipped
+
+
 def _run_child(cmd, budget_s):
     import signal
     import subprocess
+    budget_s = min(budget_s, CHILD_BUDGET["left"])
+    if budget_s < 20.0:
+        sys.stderr.write("bench.py: the profiler children's time budget is spent -- skipping one\n")
+        return -2
+    t0 = time.time()
+    try:
+        return _run_child_inner(cmd, budget_s, signal, subprocess)
+    finally:
+        CHILD_BUDGET["left"] -= time.time() - t0
+
+
+def _run_child_inner(cmd, budget_s, signal, subprocess):
     pr = subprocess.Popen(cmd, cwd="/tmp", env=dict(clean_profiler_env(os.environ), TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
                           start_new_session=True)
     try:
@@ -819,10 +834,11 @@ def measure_leg(L, steps, warmup, settle_seconds, world, rank, dev, prof_childre
     ms = elapsed * 1e3 / max(steps, 1)
     out = dict(value=L.batch_n * world * steps / elapsed, ms_per_step=ms, steps=steps, warmup=warmup, settle_steps=nset, final_loss=final_loss,
                batch_per_gpu=L.batch_n, height=L.h, width=L.w, launch_mode=L.launch_mode)
+    tsteps = steps
+    if timer is None and not args.step_markers:
+        # EVERY rank runs the instrumented eager steps: with a reducer they contain collectives (a rank-0-only pass would wait for its peers forever)
+        timer, tsteps = instrument(L)
     if rank == 0 and not args.step_markers:
-        tsteps = steps
-        if timer is None:
-            timer, tsteps = instrument(L)
         key = "%s_b%d_%dx%d_%s" % (L.kind, L.batch_n, L.h, L.w, args.dtype)
         prof = live = None
         if prof_children:
@@ -982,7 +998,7 @@ def spawn_ranks(n, argv):
     have = visible_gpu_count()
     if have is None:
         have = torch.cuda.device_count()      # last resort (may initialise the runtime; starting fresh child processes afterwards is still fine)
-    if have < n:
+    if have < n and "--share-gpu" not in argv:
         sys.stderr.write("bench.py: --gpus %d but only %d GPU(s) visible\n" % (n, have))
         return 2
     with socket.socket() as sk:
@@ -1046,6 +1062,9 @@ def main():
     ap.add_argument("--comm", default="c_abi", choices=["c_abi", "torch"],
                     help="gradient exchange transport for N > 1: c_abi = the library's own RCCL communicator (rd_comm_*, collectives captured into the "
                          "step's ONE hipGraph), torch = torch.distributed's nccl(=RCCL) collectives between per-stage graphs (round 4)")
+    ap.add_argument("--pg-backend", default="nccl", choices=["nccl", "gloo"], help="torch.distributed backend; gloo (with --share-gpu) lets the N > 1 CONTROL FLOW -- "
+                    "chain loop, settle broadcast, barriers, bucketed reducers, max over ranks -- run on a one-GPU box (collectives through the host; forces --comm torch)")
+    ap.add_argument("--share-gpu", action="store_true", help="every rank uses cuda:0 (control-flow check of the N > 1 path on a one-GPU box; never a measurement)")
     ap.add_argument("--no-live-traffic", action="store_true", help="do not start the rocprofv3 counter passes (FETCH_SIZE / WRITE_SIZE / MFMA-busy children) that "
                     "measure roofline.traffic inside the default N = 1 run")
     ap.add_argument("--no-children", action="store_true", help="start no profiler child at all (kernel trace, counter passes): durations then come from HIP events "
@@ -1080,8 +1099,10 @@ def main():
         args.sml_batch = CHAIN_RC_STEPS * args.batch
     if not torch.cuda.is_available():
         raise RuntimeError("bench.py needs a GPU: the riders_amd hot path has no CPU fallback")
-    dev = torch.device("cuda", local_rank)
+    dev = torch.device("cuda", 0 if args.share_gpu else local_rank)
     torch.cuda.set_device(dev)
+    if args.pg_backend == "gloo":
+        args.comm = "torch"
     if under_profiler():
         args.no_children = True
     ddp = world > 1 or args.force_ddp
@@ -1090,9 +1111,13 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group(backend="nccl", device_id=dev, rank=rank, world_size=world)
+        if args.pg_backend == "gloo":
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group(backend="nccl", device_id=dev, rank=rank, world_size=world)
         assert dist.get_world_size() == world
-        comm = dict(backend="nccl (RCCL)", world_size=dist.get_world_size(), rccl_version=".".join(str(v) for v in torch.cuda.nccl.version()))
+        comm = dict(backend="nccl (RCCL)" if args.pg_backend == "nccl" else "gloo (control-flow check, not a measurement)", world_size=dist.get_world_size(),
+                    rccl_version=".".join(str(v) for v in torch.cuda.nccl.version()))
     args.rccl_comm = None
     if ddp and args.comm == "c_abi":
         from riders_amd.parallel import RcclComm
