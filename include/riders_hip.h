@@ -396,10 +396,10 @@ int rd_depth_quantize_u16(const float* z, uint16_t* out, int64_t n, float multip
 int rd_sum_f32(const float* x, int64_t n, double* out, void* stream);
 
 /* ---- batch augmentation on the device -- RCNet/rcnet_transforms.py:58-240 as configured by train_rcnet_zju.py:52-59 ---------------------
-   params: [B][8] floats = (do_brightness, factor, do_contrast, factor, do_saturation, factor, do_hflip, 0), drawn by the host in the
+   params: [B][8] floats = (do_brightness, factor, do_contrast, factor, do_saturation, factor, do_hflip, do_vflip), drawn by the host in the
    reference's order.  image (B,3,H,W) float 0..255.  Step 1 sums the gray values the contrast blend needs ([B][32] int64 partials, exact). */
 int rd_augment_gray_partials(const float* image, int32_t B, int32_t H, int32_t W, const float* params, int64_t* partial, void* stream);
-/* brightness -> contrast -> saturation (torchvision _blend on the int image) -> v * scale + shift (normalize_images :243-272) -> hflip;
+/* brightness -> contrast -> saturation (torchvision _blend on the int image) -> v * scale + shift (normalize_images :243-272) -> hflip -> vflip;
    out (B,H,W,3) in `dtype` */
 int rd_augment_image(const float* image, int32_t B, int32_t H, int32_t W, const float* params, const int64_t* partial, void* out_nhwc,
                      int32_t dtype, float scale, float shift, void* stream);
@@ -407,6 +407,10 @@ int rd_augment_image(const float* image, int32_t B, int32_t H, int32_t W, const 
    may be NULL); radar points are left as they are, as the reference does */
 int rd_augment_flip_labels(const float* labels_in, float* labels_out, int32_t B, int32_t K, int32_t ph, int32_t pw, float* boxes,
                            const float* params, float n_width, void* stream);
+/* :199-217: the vertical flip (params column 7) of image and crops rides in rd_augment_image / rd_augment_flip_labels; the reference's box
+   update for a vertically flipped sample is boxes[b][1][:] = n_height - boxes[b][3][:], boxes[b][3][:] = n_height - old boxes[b][1][:]
+   (rows 1 and 3 of the sample, not y1 / y2 of each box -- kept as written), in place, after the horizontal update; K >= 4 */
+int rd_augment_vflip_boxes(float* boxes, int32_t B, int32_t K, const float* params, float n_height, void* stream);
 /* data/datasets.py:254-272: ground-truth crops around the (padded-coordinate) radar points from the zero-padded dense map (B,1,Hp,Wp) */
 int rd_crop_patches(const float* gt_padded, const float* points, float* crops, int32_t B, int32_t K, int32_t Hp, int32_t Wp, int32_t ph,
                     int32_t pw, void* stream);

@@ -11,6 +11,7 @@
 #include <string.h>
 #include <stdlib.h>
 // (declared here rather than in rd_kernels_decl.h, which every kernel unit includes)
+namespace rd { void launch_augment_vflip_boxes(float* boxes, int B, int K, const float* params, float n_height, hipStream_t st); }
 namespace rd { void launch_pack_weights_batch_map(const void* items, int n, const void* map, int blocks, hipStream_t st); }
 namespace rd_f16 { void launch_pack_weights_batch_map(const void* items, int n, const void* map, int blocks, hipStream_t st); }
 
@@ -796,6 +797,12 @@ int rd_augment_flip_labels(const float* labels_in, float* labels_out, int32_t B,
   if (!labels_in || !labels_out || !params || labels_in == labels_out || B <= 0 || K <= 0) return fail("augment_flip_labels: bad args");
   rd::launch_augment_flip_labels(labels_in, labels_out, B, K, ph, pw, boxes, params, n_width, S(stream));
   return done("rd_augment_flip_labels");
+}
+int rd_augment_vflip_boxes(float* boxes, int32_t B, int32_t K, const float* params, float n_height, void* stream) {
+  if (!boxes || !params || B <= 0) return fail("augment_vflip_boxes: bad args");
+  if (K < 4) return fail("augment_vflip_boxes: the reference indexes boxes 1 and 3 of each sample (rcnet_transforms.py:213-217): K >= 4");
+  rd::launch_augment_vflip_boxes(boxes, B, K, params, n_height, S(stream));
+  return done("rd_augment_vflip_boxes");
 }
 int rd_crop_patches(const float* gt_padded, const float* points, float* crops, int32_t B, int32_t K, int32_t Hp, int32_t Wp, int32_t ph, int32_t pw,
                     void* stream) {

@@ -7,14 +7,16 @@
 // path  _blend(img1, img2, ratio) = (ratio * img1 + (1 - ratio) * img2).clamp(0, 255).to(int32)  (float32 arithmetic, truncation) with
 //   brightness: img2 = 0;  contrast: img2 = mean over the image of gray(img), gray = (0.2989 r + 0.587 g + 0.114 b).to(int32);
 //   saturation: img2 = gray(img) per pixel.
-// Order: brightness -> contrast -> saturation -> float -> normalise -> horizontal flip of image, ground-truth crops and boxes
-// (x1' = W - x2, x2' = W - x1); the radar points are NOT flipped (:174-197, a quirk kept as it is).
+// Order: brightness -> contrast -> saturation -> float -> normalise -> [point noise, host-drawn, rd_add] -> horizontal flip of image,
+// ground-truth crops and boxes (x1' = W - x2, x2' = W - x1) -> vertical flip of image and crops (:199-217); the radar points are NOT
+// flipped (:174-197), and the vertical flip's box update indexes bounding_boxes[b, 1] and [b, 3] -- BOXES 1 and 3 of the sample, all four
+// coordinates -- rather than y1 / y2 of every box (:213-217): both quirks are kept as they are.
 #include "rd_common.h"
 #include "rd_kernels.h"
 
 namespace rd {
 
-// per-image parameters (floats): 0 do_brightness, 1 factor, 2 do_contrast, 3 factor, 4 do_saturation, 5 factor, 6 do_hflip, 7 unused
+// per-image parameters (floats): 0 do_brightness, 1 factor, 2 do_contrast, 3 factor, 4 do_saturation, 5 factor, 6 do_hflip, 7 do_vflip
 static constexpr int AUGP = 8;
 static constexpr int AUG_CHUNKS = 32;
 
@@ -83,7 +85,8 @@ __global__ __launch_bounds__(256) void augment_image_kernel(const float* __restr
       for (int c = 0; c < 3; c++) v[c] = aug_blend(v[c], g, p[5]);
     }
     const int xo = p[6] != 0.f ? W - 1 - x : x;
-    T* o = out + ((int64_t)b * HW + (int64_t)y * W + xo) * 3;
+    const int yo = p[7] != 0.f ? H - 1 - y : y;
+    T* o = out + ((int64_t)b * HW + (int64_t)yo * W + xo) * 3;
 #pragma unroll
     for (int c = 0; c < 3; c++) Elem<T>::st(o + c, __fadd_rn(__fmul_rn((float)v[c], scale), shift));
   }
@@ -95,9 +98,11 @@ __global__ __launch_bounds__(256) void augment_flip_labels_kernel(const float* _
   const int64_t per = (int64_t)K * ph * pw, total = (int64_t)B * per;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int b = (int)(i / per);
-    const int x = (int)(i % pw);
-    const bool flip = params[b * AUGP + 6] != 0.f;
-    lout[i] = lin[flip ? i - x + (pw - 1 - x) : i];
+    const int x = (int)(i % pw), y = (int)((i / pw) % ph);
+    int64_t src = i;
+    if (params[b * AUGP + 6] != 0.f) src += (pw - 1 - x) - x;
+    if (params[b * AUGP + 7] != 0.f) src += (int64_t)((ph - 1 - y) - y) * pw;
+    lout[i] = lin[src];
   }
   if (boxes)
     for (int j = blockIdx.x * blockDim.x + threadIdx.x; j < B * K; j += gridDim.x * blockDim.x) {
@@ -107,6 +112,20 @@ __global__ __launch_bounds__(256) void augment_flip_labels_kernel(const float* _
         boxes[j * 4 + 2] = n_width - x1;
       }
     }
+}
+
+// :213-217 as written: for a vertically flipped sample, boxes[b][1][:] <- n_height - boxes[b][3][:] and boxes[b][3][:] <- n_height - (old) boxes[b][1][:]
+// (runs after the horizontal update, as in the reference: a separate launch, the rows were written by other threads)
+__global__ __launch_bounds__(64) void augment_vflip_boxes_kernel(float* __restrict__ boxes, int B, int K, const float* __restrict__ params, float n_height) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;      // (sample, coordinate)
+  if (j >= B * 4) return;
+  const int b = j >> 2, c = j & 3;
+  if (params[b * AUGP + 7] == 0.f) return;
+  float* r1 = boxes + ((int64_t)b * K + 1) * 4 + c;
+  float* r3 = boxes + ((int64_t)b * K + 3) * 4 + c;
+  const float t = *r1;
+  *r1 = n_height - *r3;
+  *r3 = n_height - t;
 }
 
 // data/datasets.py:254-272: crops[b][k] = padded_gt[b][0][int(y) - pad_y : int(y) + pad_y][int(x) - pad_x : int(x) + pad_x], (x, y) = radar point
@@ -137,6 +156,9 @@ void launch_augment_image(const float* image, int B, int H, int W, const float* 
 void launch_augment_flip_labels(const float* lin, float* lout, int B, int K, int ph, int pw, float* boxes, const float* params, float n_width,
                                 hipStream_t st) {
   hipLaunchKernelGGL(augment_flip_labels_kernel, dim3(aug_grid((int64_t)B * K * ph * pw)), dim3(256), 0, st, lin, lout, B, K, ph, pw, boxes, params, n_width);
+}
+void launch_augment_vflip_boxes(float* boxes, int B, int K, const float* params, float n_height, hipStream_t st) {
+  hipLaunchKernelGGL(augment_vflip_boxes_kernel, dim3(cdiv(B * 4, 64)), dim3(64), 0, st, boxes, B, K, params, n_height);
 }
 void launch_crop_patches(const float* gt, const float* points, float* crops, int B, int K, int Hp, int Wp, int ph, int pw, hipStream_t st) {
   hipLaunchKernelGGL(crop_patches_kernel, dim3(aug_grid((int64_t)B * K * ph * pw)), dim3(256), 0, st, gt, points, crops, B, K, Hp, Wp, ph, pw);

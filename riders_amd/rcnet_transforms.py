@@ -1,9 +1,10 @@
 """RC-Net batch transforms on MI355X; same class, constructor and transform() signature as the reference's RCNet/rcnet_transforms.py
 (Transforms :5, transform :58).  The random decisions are drawn on the host in the reference's order -- do_random_transform, then per
-enabled augmentation a coin and a value, then the flip coin (:99-165) -- so a run seeded like a CPU run of the reference makes the same
-decisions; the image arithmetic, the flip of image / ground-truth crops / boxes and the normalisation are three HIP launches
-(rd_augment_gray_partials, rd_augment_image, rd_augment_flip_labels) instead of per-sample Python loops.
-Not on the RIDERS path (train_rcnet_zju.py:57-59) and not built: point noise, vertical flip.
+enabled augmentation a coin and a value, the point-noise coin followed by one randn / rand draw per flagged sample and tensor, the
+horizontal and the vertical flip coin (:99-217) -- so a run seeded like a CPU run of the reference makes the same decisions; the image
+arithmetic, the flips of image / ground-truth crops / boxes and the normalisation are three HIP launches (rd_augment_gray_partials,
+rd_augment_image, rd_augment_flip_labels; + rd_augment_vflip_boxes, + one rd_add per noisy point tensor) instead of per-sample Python loops.
+train_rcnet_zju.py:57-59 itself runs without point noise and with the horizontal flip only.
 """
 import torch
 
@@ -21,15 +22,17 @@ class Transforms(object):
         self.do_random_saturation = True if -1 not in random_saturation else False
         self.random_saturation = random_saturation
         self.do_random_noise = True if (random_noise_type != 'none' and random_noise_spread > -1) else False
-        if self.do_random_noise:
-            raise NotImplementedError("radar point noise is not used by train_rcnet_zju.py (:57-58)")
+        self.random_noise_type = random_noise_type
+        self.random_noise_spread = random_noise_spread
         self.do_random_horizontal_flip = True if 'horizontal' in random_flip_type else False
         self.do_random_vertical_flip = True if 'vertical' in random_flip_type else False
-        if self.do_random_vertical_flip:
-            raise NotImplementedError("vertical flip is not used by train_rcnet_zju.py (:59)")
+        self.noise = []
 
-    def draw(self, n_batch, random_transform_probability):
-        """(n_batch, 8) float32 parameter rows, random numbers drawn exactly as transform() :99-165 draws them."""
+    def draw(self, n_batch, random_transform_probability, points_shapes=()):
+        """(n_batch, 8) float32 parameter rows, random numbers drawn exactly as transform() :99-217 draws them.  With point noise enabled,
+        `points_shapes` (the shapes of the tensors of points_arr) is needed: add_noise :398-432 draws one randn / rand of the sample's shape
+        per flagged sample, tensor by tensor, between the saturation draws and the flip coins; the scaled noise (zeros for the samples
+        left alone) is left in self.noise, one host tensor per entry of points_arr."""
         p = torch.zeros((n_batch, 8), dtype=torch.float32)
         do = torch.rand(n_batch) <= random_transform_probability
         for col, enabled, rng in ((0, self.do_random_brightness, self.random_brightness), (2, self.do_random_contrast, self.random_contrast),
@@ -40,11 +43,28 @@ class Transforms(object):
                 lo, hi = rng
                 p[:, col] = flag.float()
                 p[:, col + 1] = (hi - lo) * values + lo
+        self.noise = []
+        if self.do_random_noise:
+            flag = torch.logical_and(do, torch.rand(n_batch) <= 0.50)
+            for shape in points_shapes:
+                noise = torch.zeros(tuple(shape), dtype=torch.float32)
+                for b in range(n_batch):
+                    if flag[b]:
+                        if self.random_noise_type == 'gaussian':
+                            noise[b] = self.random_noise_spread * torch.randn(*shape[1:])
+                        elif self.random_noise_type == 'uniform':
+                            noise[b] = self.random_noise_spread * (torch.rand(*shape[1:]) - 0.5)
+                        else:
+                            raise ValueError('Unsupported noise type: {}'.format(self.random_noise_type))
+                self.noise.append(noise if bool(flag.any()) else None)
         if self.do_random_horizontal_flip:
             p[:, 6] = torch.logical_and(do, torch.rand(n_batch) <= 0.50).float()
+        if self.do_random_vertical_flip:
+            p[:, 7] = torch.logical_and(do, torch.rand(n_batch) <= 0.50).float()
         return p
 
-    def transform(self, images_arr, labels_arr=[], points_arr=[], bounding_boxes_arr=[], random_transform_probability=0.00, params=None):
+    def transform(self, images_arr, labels_arr=[], points_arr=[], bounding_boxes_arr=[], random_transform_probability=0.00, params=None, noise=None):
+        """`params` / `noise`: decisions drawn earlier by draw() (tests; a loader thread drawing ahead of the step); default: drawn here."""
         if len(images_arr) != 1 or len(labels_arr) > 1 or len(bounding_boxes_arr) > 1:
             raise NotImplementedError("the RIDERS loops pass one image / label / box tensor (rcnet_main.py:285-290, run_rcnet_zju.py:236-240)")
         image = images_arr[0]
@@ -54,7 +74,12 @@ class Transforms(object):
         dev = image.device
         lib, p_, st = engine.L(), engine._p, engine._stream(image)
         if params is None:
-            params = self.draw(B, random_transform_probability)
+            params = self.draw(B, random_transform_probability, [tuple(pt.shape) for pt in points_arr])
+            noise = self.noise
+        elif noise is None:
+            noise = [None] * len(points_arr)
+        if self.do_random_noise and len(noise) != len(points_arr):
+            raise ValueError("draw() was given %d point shapes, transform() %d point tensors" % (len(noise), len(points_arr)))
         pd = params.to(dev, non_blocking=True)
         img = image if (image.dtype == torch.float32 and image.is_contiguous()) else image.float().contiguous()
         rng = list(self.normalized_image_range)
@@ -72,10 +97,13 @@ class Transforms(object):
         engine._chk(lib.rd_augment_image(p_(img), B, H, W, p_(pd), p_(partial), p_(out), engine.rd_of(out), scale, shift, st), "rd_augment_image")
         outputs = [[out.permute(0, 3, 1, 2)]]      # logical NCHW, channels_last: what the network's first layer consumes without a copy
         boxes = None
+        flips = self.do_random_horizontal_flip or self.do_random_vertical_flip
         if len(bounding_boxes_arr) > 0:
             boxes = bounding_boxes_arr[0]
             if not (boxes.dtype == torch.float32 and boxes.is_contiguous()):
                 boxes = boxes.float().contiguous()
+            if self.do_random_vertical_flip and boxes.shape[1] < 4:
+                raise IndexError("the vertical flip indexes boxes 1 and 3 of each sample (rcnet_transforms.py:213-217): %d boxes" % boxes.shape[1])
         if len(labels_arr) > 0:
             lab = labels_arr[0]
             lab = lab if (lab.dtype == torch.float32 and lab.is_contiguous()) else lab.float().contiguous()
@@ -84,11 +112,23 @@ class Transforms(object):
             lout = torch.empty_like(lab)
             engine._chk(lib.rd_augment_flip_labels(p_(lab), p_(lout), B, K, ph, pw, p_(boxes) if (boxes is not None and self.do_random_horizontal_flip) else None,
                                                    p_(pd), float(W), st), "rd_augment_flip_labels")
+            if boxes is not None and self.do_random_vertical_flip:
+                engine._chk(lib.rd_augment_vflip_boxes(p_(boxes), B, boxes.shape[1], p_(pd), float(H), st), "rd_augment_vflip_boxes")
             outputs.append([lout])
-        elif boxes is not None and self.do_random_horizontal_flip:
+        elif boxes is not None and flips:
             raise NotImplementedError("boxes are flipped together with the ground-truth crops")
         if len(points_arr) > 0:
-            outputs.append(list(points_arr))      # radar points are NOT flipped (rcnet_transforms.py:174-197)
+            pts_out = []
+            for i, pt in enumerate(points_arr):      # radar points get the noise and are NOT flipped (rcnet_transforms.py:157-166, :174-217)
+                nz = noise[i] if self.do_random_noise else None
+                if nz is not None:
+                    src = pt if (pt.dtype == torch.float32 and pt.is_contiguous()) else pt.float().contiguous()
+                    nd = nz.to(dev, non_blocking=True)
+                    res = torch.empty_like(src)
+                    engine._chk(lib.rd_add(p_(src), p_(nd), p_(res), src.numel(), engine.RD_F32, st), "rd_add")
+                    pt = res
+                pts_out.append(pt)
+            outputs.append(pts_out)
         if boxes is not None:
             outputs.append([boxes])
         return outputs[0] if len(outputs) == 1 else outputs

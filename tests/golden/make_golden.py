@@ -228,6 +228,31 @@ def g_transforms():
          out_points=pts_o.numpy(), out_boxes=box_o.numpy(), seed=np.array([1313]))
 
 
+def g_transforms_all():
+    """G13b: the same class with EVERY augmentation it has switched on -- gaussian point noise (:157-166, add_noise :398-432) and both flips
+    (:168-217, including the vertical flip's box update that indexes boxes 1 and 3 of the sample) -- K = 5 boxes per sample so that the
+    reference's own indexing is in range."""
+    import rcnet_transforms
+    B, K, H, W, ph, pw = 6, 5, 40, 52, 12, 8
+    image = np.floor(rand_array("g13b.img", (B, 3, H, W), 256.0, lo=0.0)).astype(np.float32)
+    labels = rand_array("g13b.lab", (B, K, 1, ph, pw), 30.0, lo=0.0)
+    xs = np.floor(rand_array("g13b.bx", (B, K), W - pw, lo=0.0)) + pw // 2
+    ys = np.floor(rand_array("g13b.by", (B, K), H - ph, lo=0.0)) + ph // 2
+    boxes = np.stack([xs - pw // 2, ys - ph // 2, xs + pw // 2, ys + ph // 2], -1).astype(np.float32)
+    points = np.stack([xs, ys, rand_array("g13b.z", (B, K), 50.0, lo=0.1)], -1).astype(np.float32)
+    out = {}
+    for tag, kind, spread, seed in (("gauss", "gaussian", 0.75, 1314), ("unif", "uniform", 2.0, 1316)):
+        tr = rcnet_transforms.Transforms(normalized_image_range=[0, 1], random_brightness=[0.80, 1.20], random_contrast=[0.80, 1.20],
+                                         random_saturation=[0.80, 1.20], random_noise_type=kind, random_noise_spread=spread,
+                                         random_flip_type=['horizontal', 'vertical'])
+        torch.manual_seed(seed)
+        [img_o], [lab_o], [pts_o], [box_o] = tr.transform(images_arr=[t(image.copy())], labels_arr=[t(labels.copy())], points_arr=[t(points.copy())],
+                                                          bounding_boxes_arr=[t(boxes.copy())], random_transform_probability=1.00)
+        out.update({tag + "_out_image": img_o.numpy(), tag + "_out_labels": lab_o.numpy(), tag + "_out_points": pts_o.numpy(),
+                    tag + "_out_boxes": box_o.numpy(), tag + "_seed": np.array([seed]), tag + "_spread": np.array([spread], np.float32)})
+    save("g13b_transforms_all", image=image.astype(np.uint8), boxes=boxes, points=points, **out)
+
+
 # ---------------------------------------------------------------------------------------------- G14: projection + scatter
 def g_projection():
     """The reference's own project_pcl_to_image + min_max_filter (data/preprocess/project_transform.py) on a seeded point cloud with
@@ -345,6 +370,8 @@ if __name__ == "__main__":
         g_projection()
     if "transforms" in which:
         g_transforms()
+    if "transforms_all" in which or "transforms" in which:
+        g_transforms_all()
     if "png" in which:
         g_depth_png()
     if "attention" in which:

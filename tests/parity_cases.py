@@ -1147,6 +1147,54 @@ def transforms_case(dev):
             assert np.array_equal(crops[b, k, 0], want), (b, k)
 
 
+def transforms_all_case(dev):
+    """N2, the options train_rcnet_zju.py leaves off: fixture g13b is the REFERENCE's Transforms.transform with gaussian / uniform point
+    noise and both flips on (K = 5 boxes: the vertical flip's box update indexes boxes 1 and 3 of the sample, rcnet_transforms.py:213-217).
+    Seeded like the generator the host makes the same draws: crops, boxes and the noisy points must match exactly, the image as in
+    transforms_case; fewer than four boxes raise, as the reference's indexing does."""
+    from riders_amd import rcnet_transforms
+    from oracle import transforms as OT
+    g = load("g13b_transforms_all")
+    B, K, H, W, ph, pw = 6, 5, 40, 52, 12, 8
+    image = t(g["image"].astype(np.float32), dev)
+    labels = t(rand_array("g13b.lab", (B, K, 1, ph, pw), 30.0, lo=0.0), dev)
+    seen = np.zeros(4, np.int64)
+    for tag, kind in (("gauss", "gaussian"), ("unif", "uniform")):
+        tr = rcnet_transforms.Transforms(normalized_image_range=[0, 1], random_brightness=[0.80, 1.20], random_contrast=[0.80, 1.20],
+                                         random_saturation=[0.80, 1.20], random_noise_type=kind, random_noise_spread=float(g[tag + "_spread"][0]),
+                                         random_flip_type=['horizontal', 'vertical'])
+        torch.manual_seed(int(g[tag + "_seed"][0]))
+        params = tr.draw(B, 1.00, [(B, K, 3)])
+        noise = tr.noise
+        for b in range(B):
+            seen[int(params[b, 6]) + 2 * int(params[b, 7])] += 1
+        assert noise[0] is not None and 0 < int((noise[0].abs().sum(dim=(1, 2)) > 0).sum()) < B, "fixture should mix noisy and clean samples"
+        [img_o], [lab_o], [pts_o], [box_o] = tr.transform(images_arr=[image], labels_arr=[labels], points_arr=[t(g["points"], dev)],
+                                                          bounding_boxes_arr=[t(g["boxes"].copy(), dev)], random_transform_probability=1.00,
+                                                          params=params, noise=noise)
+        assert np.array_equal(lab_o.cpu().numpy(), g[tag + "_out_labels"]), tag + ": flipped ground-truth crops"
+        assert np.array_equal(box_o.cpu().numpy(), g[tag + "_out_boxes"]), tag + ": boxes"
+        assert np.array_equal(pts_o.cpu().numpy(), g[tag + "_out_points"]), tag + ": noisy radar points"
+        diff = np.abs(img_o.float().cpu().numpy() - g[tag + "_out_image"]) * 255.0
+        assert diff.max() <= 1.0 + 1e-3, "image differs by more than one code: %.3f" % diff.max()
+        assert (diff > 1e-3).mean() <= 1e-3, "too many pixels differ: %.5f" % (diff > 1e-3).mean()
+        oi, ol, ob, op = OT.transform(t(g["image"].astype(np.float32)), labels.cpu(), t(g["boxes"].copy()), params, points=t(g["points"]), noise=noise[0])
+        assert np.array_equal(oi.numpy(), g[tag + "_out_image"]) and np.array_equal(ol.numpy(), g[tag + "_out_labels"])
+        assert np.array_equal(ob.numpy(), g[tag + "_out_boxes"]) and np.array_equal(op.numpy(), g[tag + "_out_points"])
+        # the same seed through transform() itself (no params handed in) makes the same draws
+        torch.manual_seed(int(g[tag + "_seed"][0]))
+        outs = tr.transform(images_arr=[image], labels_arr=[labels], points_arr=[t(g["points"], dev)], bounding_boxes_arr=[t(g["boxes"].copy(), dev)],
+                            random_transform_probability=1.00)
+        assert np.array_equal(outs[2][0].cpu().numpy(), g[tag + "_out_points"]) and np.array_equal(outs[3][0].cpu().numpy(), g[tag + "_out_boxes"])
+    assert (seen > 0).sum() >= 3, "fixture should mix the flip combinations: %s" % seen
+    tr = rcnet_transforms.Transforms(normalized_image_range=[0, 1], random_flip_type=['vertical'])
+    try:
+        tr.transform(images_arr=[image], labels_arr=[labels[:, :3].contiguous()], bounding_boxes_arr=[t(g["boxes"][:, :3].copy(), dev)], random_transform_probability=1.0)
+        raise AssertionError("three boxes per sample must raise (the reference's bounding_boxes[b, 3])")
+    except IndexError:
+        pass
+
+
 def projection_case(dev):
     """N4: device projection + scatter against fixture g14 (the REFERENCE's project_pcl_to_image / min_max_filter + its scatter loop):
     the depth map bit for bit, the kept point set exactly (same pixels, same depths, far-to-near order)."""

@@ -195,6 +195,10 @@ def test_batch_transforms(emu):
     P.transforms_case(emu)
 
 
+def test_batch_transforms_noise_and_both_flips(emu):
+    P.transforms_all_case(emu)
+
+
 def test_projection_scatter(emu):
     P.projection_case(emu)
 

@@ -141,6 +141,10 @@ def test_batch_transforms(gpu):
     P.transforms_case(gpu)
 
 
+def test_batch_transforms_noise_and_both_flips(gpu):
+    P.transforms_all_case(gpu)
+
+
 def test_projection_scatter(gpu):
     P.projection_case(gpu)
 
