@@ -71,7 +71,7 @@ const OptDef kOpts[rdt::OPT_COUNT] = {
   {"conv3x3_w8", 0, 1}, {"patch_bn_max", 32, 128}, {"conv3x3_g8", 1, 4096}, {"conv1x1_min_m", 0, 1 << 30}, {"conv_few_min_m", 0, 1 << 30},
   {"frag_v128", 0, 6}, {"frag_v64", 0, 6}, {"frag_v32", 0, 6}, {"frag_split", 0, 1}, {"frag_split_blocks", 0, 1 << 30},
   {"frag32_v128", 0, 3}, {"frag32_v64", 0, 3}, {"frag_lin", 0, 1}, {"conv3x3_frag", 0, 1}, {"bn_gen_ppt", 2, 64}, {"bn_vec_per", 0, 64},
-  {"wgrad_tr_tw", 8, 32}, {"frag_db", 0, 1}, {"wgrad_fit", 0, 1}, {"head_np", 256, 1800}, {"head_cpi", 0, 0x888},
+  {"wgrad_tr_tw", 8, 32}, {"frag_db", 0, 1}, {"wgrad_fit", 0, 1}, {"head_np", 256, 1800}, {"head_cpi", 0, 0x888}, {"pw_min_m", 0, 1 << 30}, {"pw_ks", 0, 8},
 };
 int g_opt_val[rdt::OPT_COUNT];
 bool g_opt_set[rdt::OPT_COUNT];

@@ -1224,12 +1224,23 @@ static bool use_conv3x3_frag(const ConvArgs& a, int dtype) {   // wide layers: w
 }
 static bool conv_stem_ok(const ConvArgs& a, int dtype);
 static int conv_stem_blocks(const ConvArgs& a);
+// rd_conv_pw.hip: pointwise layers on a few thousand pixels
+bool conv_pw_shape(const ConvArgs& a, int dtype);
+bool conv_pw_ok(const ConvArgs& a, int dtype);
+int conv_pw_rows(const ConvArgs& a);
+const char* conv_pw_name(const ConvArgs& a, int dtype);
+void launch_conv_pw(const ConvArgs& a, int dtype, hipStream_t st);
+static bool conv_skinny_ok(const ConvArgs& a, int dtype);
+static bool conv_pw_route(const ConvArgs& a, int dtype) {      // as launch_conv orders its routes
+  return !conv_skinny_ok(a, dtype) && !conv_stem_ok(a, dtype) && !conv_few_ok(a) && !conv1x1_direct_ok(a, dtype) && conv_pw_ok(a, dtype);
+}
 static bool conv_d2s_small(const ConvArgs& a, int dtype);
 int conv_stats_rows(const ConvArgs& a, int dtype) {
   if (a.d2s) return conv_d2s_small(a, dtype) ? conv3x3_small_blocks(a, dtype) : conv3x3_frag_tiles(a, dtype);
   if (conv_stem_ok(a, dtype)) return conv_stem_blocks(a);
   if (conv_few_ok(a)) return conv_few_blocks(a);
   if (conv1x1_direct_ok(a, dtype)) return conv1x1_direct_rows(a);
+  if (conv_pw_route(a, dtype)) return conv_pw_rows(a);
   if (use_conv3x3_small(a, dtype)) return conv3x3_small_blocks(a, dtype);   // persistent blocks: one statistics row each
   if (use_conv3x3_frag(a, dtype)) return conv3x3_frag_tiles(a, dtype);
   if (use_conv3x3(a, dtype)) return conv3x3_tiles(a);
@@ -1400,6 +1411,7 @@ void launch_conv(const ConvArgs& a, int dtype, hipStream_t st) {
   if (conv_stem_ok(a, dtype)) { launch_conv_stem(a, dtype, st); return; }
   if (conv_few_ok(a)) { launch_conv_few(a, dtype, st); return; }
   if (conv1x1_direct_ok(a, dtype)) { launch_conv1x1_direct(a, dtype, st); return; }
+  if (conv_pw_ok(a, dtype)) { launch_conv_pw(a, dtype, st); return; }
   if (conv3x3_c1_ok(a)) { launch_conv3x3_c1(a, dtype, st); return; }
   if (use_conv3x3_small(a, dtype)) { launch_conv3x3_small(a, dtype, st); return; }
   if (use_conv3x3_frag(a, dtype)) { launch_conv3x3_frag(a, dtype, st); return; }
@@ -1450,6 +1462,7 @@ bool conv_bn_bwd_ok(const ConvArgs& a, int dtype) {
   // conv_epilogue_stats; dz must be whole 4-channel groups of the first destination, no 2x2 reduction, no bias / activation of its own
   if (a.pool2 || a.bias || a.act != ACT_NONE || (a.D1 & 3) || ((a.Cout - a.D1) & 3) || a.in_scale) return false;
   if (conv_skinny_ok(a, dtype) || conv_stem_ok(a, dtype) || conv_few_ok(a) || conv1x1_direct_ok(a, dtype) || conv3x3_c1_ok(a) || use_conv3x3_small(a, dtype)) return false;
+  if (conv_pw_shape(a, dtype)) return false;      // (its epilogue takes the forward statistics only)
   if (use_conv3x3_frag(a, dtype)) return !conv3x3_frag_is32(a, dtype);
   if (use_conv3x3(a, dtype)) return false;      // (the patch-staged kernel is only a fallback since round 3)
   return true;                                  // implicit GEMM
@@ -1461,6 +1474,7 @@ const char* conv_kernel_name(const ConvArgs& a, int dtype) {
   if (conv_stem_ok(a, dtype)) return "conv_stem_kernel";
   if (conv_few_ok(a)) return "conv_few_kernel";
   if (conv1x1_direct_ok(a, dtype)) return "conv1x1_direct_kernel";
+  if (conv_pw_ok(a, dtype)) return conv_pw_name(a, dtype);
   if (conv3x3_c1_ok(a)) return "conv3x3_c1_kernel";
   if (a.s2d) return conv3x3_frag_name(a, dtype);
   if (a.d2s) return conv_d2s_small(a, dtype) ? conv3x3_small_name(a, dtype) : conv3x3_frag_name(a, dtype);

@@ -1905,6 +1905,81 @@ def pack_batch_case(dev):
     engine.clear_caches()
 
 
+def pw_gemm_cases(dev):
+    """rd_conv_pw.hip (pointwise layers on a few thousand pixels): every block shape (K split over 8 / 4 waves, four channel tiles per block),
+    pixel counts / channel counts / K lengths that are not whole tiles or chunks, bias + activation, the addend, the BatchNorm statistics
+    rows -- through the C ABI (rd_conv_fwd / rd_conv_fwd_add) in fp32 and the 16-bit mode, against a float64 product of the same (rounded)
+    operands: fp32 within 1e-5 of the row scale, 16-bit within one rounding of the exact value; the statistics rows must sum to the
+    column sums of what was STORED (1e-5); the result must not depend on the block shape beyond the fp32 summation order; and the kernel
+    the library names for the shape is this one."""
+    import ctypes
+    from riders_amd import engine
+    lib = engine.L()
+    lib.rd_conv_fwd_kernel_name.restype = ctypes.c_char_p
+    rs = np.random.RandomState(11)
+    shapes = [(2, 9, 7, 136, 72), (1, 8, 8, 64, 64), (2, 5, 13, 200, 40), (1, 11, 6, 24, 264), (1, 7, 9, 520, 96)]      # N, H, W, Cin, Cout
+    try:
+        engine.set_option("pw_min_m", 0)
+        for dt, tdt, tol in ((engine.RD_F32, torch.float32, 1e-5), (engine.RD_BF16, torch.bfloat16, 2.0 ** -8)):
+            for (N, H, W, Cin, Cout) in shapes:
+                M = N * H * W
+                x = t(rs.randn(N, H, W, Cin).astype(np.float32), dev).to(tdt)
+                add = t(rs.randn(N, H, W, Cout).astype(np.float32), dev).to(tdt)
+                w = torch.nn.Parameter(t((rs.randn(Cout, Cin, 1, 1) / np.sqrt(Cin)).astype(np.float32), dev))
+                bias = t(rs.randn(Cout).astype(np.float32), dev)
+                wp = engine.packed_weight(w, 0, dt)
+                wq = w.detach().reshape(Cout, Cin).to(tdt).double().cpu()
+                exact = x.reshape(M, Cin).double().cpu() @ wq.t()
+                outs = []
+                for ks in (8, 4, 1):
+                    engine.set_option("pw_ks", ks)
+                    for variant in ("stats", "bias_act", "addend"):
+                        act = engine.ACT_LRELU if variant == "bias_act" else engine.ACT_NONE
+                        d = engine._desc(dt, N, H, W, Cin, 0, False, H, W, Cout, 1, 1, 1, 0, 1, H, W, act, 0.2, Cout)
+                        name = lib.rd_conv_fwd_kernel_name(ctypes.byref(d)).decode()
+                        assert name.startswith("pw_gemm_kernel<") and name.endswith("%d, %d>" % (ks, 4 if ks == 1 else 1)), name
+                        y = torch.full((N, H, W, Cout), float("nan"), dtype=tdt, device=x.device)
+                        st = engine._stream(x)
+                        want = exact
+                        if variant == "stats":
+                            rows = lib.rd_conv_stats_rows(ctypes.byref(d))
+                            assert rows == (M + 63) // 64
+                            stats = torch.full((rows, Cout, 2), float("nan"), dtype=torch.float32, device=x.device)
+                            engine._chk(lib.rd_conv_fwd(ctypes.byref(d), engine._p(x), None, engine._p(wp), None, engine._p(y), None, engine._p(stats), st), "rd_conv_fwd")
+                            yd = y.reshape(M, Cout).double().cpu()
+                            got = stats.double().cpu().sum(0)
+                            scale = max(1.0, float(yd.abs().sum(0).max()))
+                            assert float((got[:, 0] - yd.sum(0)).abs().max()) <= 1e-5 * scale, "statistics: sum"
+                            assert float((got[:, 1] - (yd * yd).sum(0)).abs().max()) <= 1e-5 * max(1.0, float((yd * yd).sum(0).max())), "statistics: sum of squares"
+                        elif variant == "bias_act":
+                            engine._chk(lib.rd_conv_fwd(ctypes.byref(d), engine._p(x), None, engine._p(wp), engine._p(bias), engine._p(y), None, None, st), "rd_conv_fwd")
+                            want = exact + bias.double().cpu()
+                            want = torch.where(want > 0, want, 0.2 * want)
+                        else:
+                            assert lib.rd_conv_add_ok(ctypes.byref(d)) == 1
+                            engine._chk(lib.rd_conv_fwd_add(ctypes.byref(d), engine._p(x), None, engine._p(wp), None, engine._p(add), engine._p(y), st), "rd_conv_fwd_add")
+                            want = exact + add.reshape(M, Cout).double().cpu()
+                        yd = y.reshape(M, Cout).double().cpu()
+                        assert bool(torch.isfinite(yd).all()), "%s: unwritten outputs" % variant
+                        err = float(((yd - want).abs() / (want.abs() + 1.0)).max())
+                        assert err <= tol, "pw_gemm %s ks=%d %s M=%d %d->%d: %.3e" % (tdt, ks, variant, M, Cin, Cout, err)
+                        outs.append((variant, yd))
+                for v in ("stats", "bias_act", "addend"):      # the block shapes agree up to the fp32 summation order (and one 16-bit rounding of it)
+                    ys = [o for (vv, o) in outs if vv == v]
+                    assert float((ys[0] - ys[1]).abs().max()) <= 4 * tol * float(ys[0].abs().max()) and float((ys[0] - ys[2]).abs().max()) <= 4 * tol * float(ys[0].abs().max())
+        # default routing: the long-K projections of the /32 stage only (where it was measured to win)
+        engine.set_option("pw_min_m", None); engine.set_option("pw_ks", None)
+        d = engine._desc(engine.RD_BF16, 2, 9, 7, 136, 0, False, 9, 7, 72, 1, 1, 1, 0, 1, 9, 7, 0, 0.0, 72)
+        assert not lib.rd_conv_fwd_kernel_name(ctypes.byref(d)).decode().startswith("pw_gemm")
+        d = engine._desc(engine.RD_BF16, 16, 9, 18, 1392, 0, False, 9, 18, 232, 1, 1, 1, 0, 1, 9, 18, 0, 0.0, 232)
+        assert lib.rd_conv_fwd_kernel_name(ctypes.byref(d)).decode() == "pw_gemm_kernel<rd::bf16_t, 4, 1>"
+        d = engine._desc(engine.RD_BF16, 16, 18, 36, 136, 0, False, 18, 36, 816, 1, 1, 1, 0, 1, 18, 36, 0, 0.0, 816)
+        assert not lib.rd_conv_fwd_kernel_name(ctypes.byref(d)).decode().startswith("pw_gemm")
+    finally:
+        engine.set_option("pw_min_m", None); engine.set_option("pw_ks", None)
+        engine.clear_caches()
+
+
 def roi_pool_tile_deterministic_case(dev):
     """RC-Net geometry (bins a little larger than a pixel, many overlapping RoIs): the LDS-tile backward takes its atomic-free
     parity-class path -- same result as the oracle and bit-identical from run to run."""

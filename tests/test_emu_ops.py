@@ -284,3 +284,7 @@ def test_workspace_bytes_dispatch(emu):
     assert lib.rd_workspace_bytes(3, ref) == lib.rd_conv_packed_elems(64, 9 * 128, engine.RD_BF16) * 2
     assert lib.rd_workspace_bytes(9, ref) == -1 and b"workspace_bytes" in lib.rd_last_error_string()
     assert lib.rd_workspace_bytes(0, None) == -1
+
+
+def test_pointwise_gemm_kernel(emu):
+    P.pw_gemm_cases(emu)

@@ -756,3 +756,7 @@ def test_autograph_other_shapes_and_eval_take_the_right_path(gpu):
     for a, b in zip(le, la):
         assert abs(a - b) <= 1e-5 * abs(a), (le, la)
     assert st["captured"] >= 2 and st["eager"] >= 2, st      # two geometries, each: first call eager, second captured
+
+
+def test_pointwise_gemm_kernel(gpu):
+    P.pw_gemm_cases(gpu)
