@@ -231,6 +231,18 @@ int rd_conv_wgrad_partial_fused(const rd_conv_desc* d, const rd_conv_fusion* f, 
 int rd_bn_finalize(const float* stats, int32_t rows, int32_t C, double count, const float* gamma, const float* beta,
                    float eps, float momentum, int32_t training, float* running_mean, float* running_var,
                    float* save_mean, float* save_rstd, float* scale, float* shift, void* stream);
+/* Wide layers on small maps in ONE launch per direction (csrc/rd_bn_slab.hip: a workgroup owns one 16-byte channel vector of every pixel, so the
+ * batch statistics it needs are its own).  rd_bn_slab_ok = 1 for <= 2 816 pixels and >= 64 channel vectors (512 channels of the 16-bit types).
+ * rd_bn_finalize_apply = rd_bn_finalize (training mode, from the producer's statistics rows) + rd_affine_act without residual;
+ * rd_bn_act_bwd_slab = rd_bn_act_bwd_recompute without dres: no partial rows, no coefficient buffer.  Same arithmetic; the statistics are
+ * summed in another (fixed) order.  rd_bn_slab_kernel_name: which 0 = forward, 1 = backward, as rd_conv_fwd_kernel_name. */
+int32_t rd_bn_slab_ok(int64_t pixels, int32_t C, int32_t dtype);
+int rd_bn_finalize_apply(const float* stats, int32_t rows, const void* y, const float* gamma, const float* beta, float eps, float momentum,
+                         float* running_mean, float* running_var, float* save_mean, float* save_rstd, float* scale, float* shift, void* out,
+                         int64_t pixels, int32_t C, int32_t act, float slope, int32_t dtype, void* stream);
+int rd_bn_act_bwd_slab(const void* dz, const void* y, const float* mean, const float* rstd, const float* scale, const float* shift, float* dgamma,
+                       float* dbeta, int32_t accumulate, void* dy, int64_t pixels, int32_t C, int32_t act, float slope, int32_t dtype, void* stream);
+const char* rd_bn_slab_kernel_name(int32_t which, int64_t pixels, int32_t dtype, int32_t act);
 /* out = act(scale[c]*y + shift[c] + residual); scale/shift/residual may be NULL */
 int rd_affine_act(const void* y, const float* scale, const float* shift, const void* residual, void* out, int64_t pixels,
                   int32_t C, int32_t act, float slope, int32_t dtype, void* stream);

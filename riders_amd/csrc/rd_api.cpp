@@ -11,6 +11,17 @@
 #include <string.h>
 #include <stdlib.h>
 // (declared here rather than in rd_kernels_decl.h, which every kernel unit includes)
+#define RD_SLAB_DECL(NS) namespace NS { \
+  bool bn_slab_ok(int64_t pixels, int C, int dtype); \
+  void launch_bn_bwd_slab(const void* dz, const void* y, const float* mean, const float* rstd, const float* scale, const float* shift, float* dgamma, float* dbeta, \
+                          int accumulate, void* dy, int64_t pixels, int C, int act, float slope, int dtype, hipStream_t st); \
+  void launch_bn_fwd_slab(const float* stats, int rows, const void* y, const float* gamma, const float* beta, float eps, float momentum, float* running_mean, \
+                          float* running_var, float* mean, float* rstd, float* scale, float* shift, void* out, int64_t pixels, int C, int act, float slope, int dtype, \
+                          hipStream_t st); \
+  const char* bn_slab_kernel_name(int which, int64_t pixels, int dtype, int act); }
+RD_SLAB_DECL(rd)
+RD_SLAB_DECL(rd_f16)
+#undef RD_SLAB_DECL
 namespace rd { void launch_augment_vflip_boxes(float* boxes, int B, int K, const float* params, float n_height, hipStream_t st); }
 namespace rd { void launch_pack_weights_batch_map(const void* items, int n, const void* map, int blocks, hipStream_t st); }
 namespace rd_f16 { void launch_pack_weights_batch_map(const void* items, int n, const void* map, int blocks, hipStream_t st); }
@@ -71,7 +82,7 @@ const OptDef kOpts[rdt::OPT_COUNT] = {
   {"conv3x3_w8", 0, 1}, {"patch_bn_max", 32, 128}, {"conv3x3_g8", 1, 4096}, {"conv1x1_min_m", 0, 1 << 30}, {"conv_few_min_m", 0, 1 << 30},
   {"frag_v128", 0, 6}, {"frag_v64", 0, 6}, {"frag_v32", 0, 6}, {"frag_split", 0, 1}, {"frag_split_blocks", 0, 1 << 30},
   {"frag32_v128", 0, 3}, {"frag32_v64", 0, 3}, {"frag_lin", 0, 1}, {"conv3x3_frag", 0, 1}, {"bn_gen_ppt", 2, 64}, {"bn_vec_per", 0, 64},
-  {"wgrad_tr_tw", 8, 32}, {"frag_db", 0, 1}, {"wgrad_fit", 0, 1}, {"head_np", 256, 1800}, {"head_cpi", 0, 0x888}, {"pw_min_m", 0, 1 << 30}, {"pw_ks", 0, 8},
+  {"wgrad_tr_tw", 8, 32}, {"frag_db", 0, 1}, {"wgrad_fit", 0, 1}, {"head_np", 256, 1800}, {"head_cpi", 0, 0x888}, {"pw_min_m", 0, 1 << 30}, {"pw_ks", 0, 8}, {"bn_slab", 0, 2},
 };
 int g_opt_val[rdt::OPT_COUNT];
 bool g_opt_set[rdt::OPT_COUNT];
@@ -448,6 +459,27 @@ int rd_affine_act_add(const void* y, const float* scale, const float* shift, int
   if (pixels * C == 0) return 0;
   RD_NS(dtype, launch_affine_act_add)(y, scale, shift, act1, slope1, residual, out, pixels, C, act2, slope2, RD_DT(dtype), S(stream));
   return done("rd_affine_act_add");
+}
+int32_t rd_bn_slab_ok(int64_t pixels, int32_t C, int32_t dtype) { return dt_ok(dtype) && rd::bn_slab_ok(pixels, C, RD_DT(dtype)) ? 1 : 0; }
+int rd_bn_finalize_apply(const float* stats, int32_t rows, const void* y, const float* gamma, const float* beta, float eps, float momentum,
+                         float* running_mean, float* running_var, float* save_mean, float* save_rstd, float* scale, float* shift, void* out, int64_t pixels,
+                         int32_t C, int32_t act, float slope, int32_t dtype, void* stream) {
+  if (!stats || rows <= 0 || !y || !scale || !shift || !out || !dt_ok(dtype)) return fail("bn_finalize_apply: bad args");
+  if (!rd::bn_slab_ok(pixels, C, RD_DT(dtype))) return fail("bn_finalize_apply: %lld pixels x %d channels has no one-launch form (see rd_bn_slab_ok)", (long long)pixels, C);
+  RD_NS(dtype, launch_bn_fwd_slab)(stats, rows, y, gamma, beta, eps, momentum, running_mean, running_var, save_mean, save_rstd, scale, shift, out, pixels, C, act, slope,
+                                   RD_DT(dtype), S(stream));
+  return done("rd_bn_finalize_apply");
+}
+int rd_bn_act_bwd_slab(const void* dz, const void* y, const float* mean, const float* rstd, const float* scale, const float* shift, float* dgamma, float* dbeta,
+                       int32_t accumulate, void* dy, int64_t pixels, int32_t C, int32_t act, float slope, int32_t dtype, void* stream) {
+  if (!dz || !y || !mean || !rstd || !scale || !shift || !dy || !dt_ok(dtype)) return fail("bn_act_bwd_slab: bad args");
+  if (!rd::bn_slab_ok(pixels, C, RD_DT(dtype))) return fail("bn_act_bwd_slab: %lld pixels x %d channels has no one-launch form (see rd_bn_slab_ok)", (long long)pixels, C);
+  RD_NS(dtype, launch_bn_bwd_slab)(dz, y, mean, rstd, scale, shift, dgamma, dbeta, accumulate, dy, pixels, C, act, slope, RD_DT(dtype), S(stream));
+  return done("rd_bn_act_bwd_slab");
+}
+const char* rd_bn_slab_kernel_name(int32_t which, int64_t pixels, int32_t dtype, int32_t act) {
+  if (!dt_ok(dtype) || which < 0 || which > 1) return "";
+  return RD_NS(dtype, bn_slab_kernel_name)(which, pixels, RD_DT(dtype), act);
 }
 int32_t rd_bn_bwd_rows(int64_t pixels, int32_t C) { return rd::bn_bwd_rows(pixels, C); }
 int rd_bn_act_bwd(const void* dz, const void* z, const void* y, const float* mean, const float* rstd, const float* scale,

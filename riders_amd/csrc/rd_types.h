@@ -71,7 +71,7 @@ struct LoftrGrads {
 enum RdOpt {
   OPT_CONV_PAR, OPT_CONV3X3_MIN_BLOCKS, OPT_CONV_STEM_MIN_M, OPT_WGRAD_BLOCKS, OPT_WGRAD_TINY_MIN_M, OPT_CONV3X3_W8, OPT_PATCH_BN_MAX,
   OPT_CONV3X3_G8, OPT_CONV1X1_MIN_M, OPT_CONV_FEW_MIN_M, OPT_FRAG_V128, OPT_FRAG_V64, OPT_FRAG_V32, OPT_FRAG_SPLIT, OPT_FRAG_SPLIT_BLOCKS,
-  OPT_FRAG32_V128, OPT_FRAG32_V64, OPT_FRAG_LIN, OPT_CONV3X3_FRAG, OPT_BN_GEN_PPT, OPT_BN_VEC_PER, OPT_WGRAD_TR_TW, OPT_FRAG_DB, OPT_WGRAD_FIT, OPT_HEAD_NP, OPT_HEAD_CPI, OPT_PW_MIN_M, OPT_PW_KS, OPT_COUNT
+  OPT_FRAG32_V128, OPT_FRAG32_V64, OPT_FRAG_LIN, OPT_CONV3X3_FRAG, OPT_BN_GEN_PPT, OPT_BN_VEC_PER, OPT_WGRAD_TR_TW, OPT_FRAG_DB, OPT_WGRAD_FIT, OPT_HEAD_NP, OPT_HEAD_CPI, OPT_PW_MIN_M, OPT_PW_KS, OPT_BN_SLAB, OPT_COUNT
 };
 
 }  // namespace rdt

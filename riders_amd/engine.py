@@ -274,10 +274,25 @@ def _bn_name(which, C, dt, act, flag):
     return lambda: L().rd_bn_kernel_name(which, C, dt, act, 1 if flag else 0).decode()
 
 
+def _bn_finalize_apply(stats, y, bn, coef, z, pixels, C, act, slope, dt, st):
+    """rd_bn_finalize_apply: coef rows = (scale, shift, mean, rstd) as rd_bn_finalize fills them"""
+    lib = L()
+    return _tb("bn_apply", 2 * y.numel() * y.element_size() + stats.numel() * 4,
+               lambda: lib.rd_bn_finalize_apply(_p(stats), stats.shape[0], _p(y), _p(bn.weight.detach() if bn.weight is not None else None),
+                                                _p(bn.bias.detach() if bn.bias is not None else None), float(bn.eps),
+                                                float(bn.momentum if bn.momentum is not None else 0.1), _p(bn.running_mean), _p(bn.running_var),
+                                                _p(coef[2]), _p(coef[3]), _p(coef[0]), _p(coef[1]), _p(z), pixels, C, act, slope, dt, st),
+               "bn finalize+apply+act M=%d C=%d [one launch]" % (pixels, C), kernel=lambda: lib.rd_bn_slab_kernel_name(0, pixels, dt, act).decode())
+
+
 def _bn_bwd_recompute(dz, z, y, mean, rstd, scale, shift, partial, coef2, dgam, dbet, acc, dy, dres, pixels, C, act, slope, dt, st, nbytes, desc):
     """rd_bn_act_bwd_recompute; under a kernel timer its reduce / finalize / apply launches are issued (and timed, and named) one by one so
     that bench.py's roofline can rank the BatchNorm passes next to the convolution kernels."""
     lib = L()
+    if dres is None and lib.rd_bn_slab_ok(pixels, C, dt):      # wide layer on a small map: reduce + finalize + apply in one launch (rd_bn_slab.hip)
+        return _tb("bn_backward", nbytes, lambda: lib.rd_bn_act_bwd_slab(_p(dz), _p(y), _p(mean), _p(rstd), _p(scale), _p(shift), _p(dgam), _p(dbet), acc, _p(dy),
+                                                                       pixels, C, act, slope, dt, st),
+                   desc + " [one launch]", kernel=lambda: lib.rd_bn_slab_kernel_name(1, pixels, dt, act).decode())
     args = (_p(dz), _p(z), _p(y), _p(mean), _p(rstd), _p(scale), _p(shift), _p(partial), _p(coef2), _p(dgam), _p(dbet), acc, _p(dy), _p(dres), pixels, C,
             act, slope, dt)
     if _timer["t"] is None:
@@ -1313,9 +1328,15 @@ def conv_block(x, weight, *, x2=None, bias=None, stride=1, pad=None, up=None, bn
                     kernel=lambda: lib.rd_conv_fwd_kernel_name(ctypes.byref(d)).decode(), idem=True), "rd_conv_fwd")
     pixels = N * OH * OW
     scale = shift = mean = rstd = None
+    slab = bool(use_bn and bn_train and stats is not None and residual is None and not res_fused and lib.rd_bn_slab_ok(pixels, Cout, dt)
+                and not (lazy_out and _state["lazy_bn"] >= int(lazy_out) and _state["bn_recompute"] and Cout % ve == 0))
     if use_bn:
         coef = torch.empty((4, Cout), dtype=torch.float32, device=x.device)
         scale, shift, mean, rstd = coef[0], coef[1], coef[2], coef[3]
+    if slab:      # wide layer on a small map: finalize + apply in one launch (rd_bn_slab.hip)
+        z = torch.empty_like(y)
+        _chk(_bn_finalize_apply(stats, y, bn, coef, z, pixels, Cout, act, slope, dt, st), "rd_bn_finalize_apply")
+    elif use_bn:
         _chk(_tb("bn_finalize", 0 if stats is None else stats.numel() * 4,
                  lambda: lib.rd_bn_finalize(_p(stats), 0 if stats is None else stats.shape[0], Cout, float(pixels),
                                             _p(bn.weight.detach() if bn.weight is not None else None),
@@ -1329,6 +1350,8 @@ def conv_block(x, weight, *, x2=None, bias=None, stride=1, pad=None, up=None, bn
         lazy = LazyAct(y, coef, act, slope)      # z stays virtual: the consumer applies (scale, shift, act) while it stages y
     elif res_fused:
         z = y
+    elif slab:
+        pass
     elif use_bn or residual is not None:
         z = torch.empty_like(y)
         _chk(_tb("bn_apply", (2 + (residual is not None)) * b_out,
@@ -2252,6 +2275,10 @@ def _bn_forward(y, bn, act, slope, residual, training, stats=None):
         stats = torch.empty((rows, C, 2), dtype=torch.float32, device=y.device)
         _chk(lib.rd_bn_stats(_p(y), _p(stats), pixels, C, dt, st), "rd_bn_stats")
     coef = torch.empty((4, C), dtype=torch.float32, device=y.device)
+    if bn_train and residual is None and lib.rd_bn_slab_ok(pixels, C, dt):
+        z = torch.empty_like(y)
+        _chk(_bn_finalize_apply(stats, y, bn, coef, z, pixels, C, act, slope, dt, st), "rd_bn_finalize_apply")
+        return z, coef, bn_train
     _chk(lib.rd_bn_finalize(_p(stats), 0 if stats is None else stats.shape[0], C, float(pixels), _p(bn.weight.detach()), _p(bn.bias.detach()),
                             float(bn.eps), float(bn.momentum if bn.momentum is not None else 0.1), 1 if bn_train else 0,
                             _p(bn.running_mean), _p(bn.running_var), _p(coef[2]), _p(coef[3]), _p(coef[0]), _p(coef[1]), st), "rd_bn_finalize")

@@ -632,6 +632,89 @@ class force_head(_force_options):
             self.opts["head_cpi"] = cpi
 
 
+def bn_slab_cases(dev):
+    """rd_bn_slab.hip (wide BatchNorm layers on small maps, one launch per direction) through the C ABI against the general three-step path of
+    the same library on the same tensors -- rd_bn_finalize + rd_affine_act, rd_bn_act_bwd_recompute -- and, for the statistics, against a
+    float64 sum: both register-set sizes (<= 11 / 22 pixels per thread), pixel counts that are not multiples of 256, channel counts
+    that are not whole lines, no activation / ReLU6 / LeakyReLU, accumulate on and off, fp32 and the 16-bit mode.  fp32: coefficients 2e-6,
+    outputs 1e-5 / gradients 2e-4 of the tensor's scale (other summation order); 16-bit: within one rounding."""
+    from riders_amd import engine
+    lib = engine.L()
+    rs = np.random.RandomState(31)
+    eps, mom = 1e-5, 0.1
+    try:
+        engine.set_option("bn_slab", 2)
+        cases = [(700, 24, engine.ACT_RELU6), (2592, 40, engine.ACT_RELU6), (5000, 16, engine.ACT_NONE), (5632, 8, engine.ACT_LRELU), (257, 136, engine.ACT_RELU6)]
+        for dt, tdt, tol_o, tol_g in ((engine.RD_F32, torch.float32, 1e-5, 2e-4), (engine.RD_BF16, torch.bfloat16, 2.0 ** -7, 2e-2)):
+            for pixels, C, act in cases:
+                assert lib.rd_bn_slab_ok(pixels, C, dt) == 1
+                y = t((rs.randn(pixels, C) * 1.5 + 0.3).astype(np.float32), dev).to(tdt)
+                dz = t(rs.randn(pixels, C).astype(np.float32), dev).to(tdt)
+                gamma, beta = t(rs.rand(C).astype(np.float32) + 0.5, dev), t(rs.randn(C).astype(np.float32), dev)
+                # statistics rows as a convolution epilogue would have written them: (sum, sum^2) of y over rows of 64 pixels
+                yd = y.double().cpu().numpy()
+                rows = (pixels + 63) // 64
+                st_np = np.zeros((rows, C, 2), np.float32)
+                for r in range(rows):
+                    blk = yd[r * 64:(r + 1) * 64]
+                    st_np[r, :, 0] = blk.sum(0); st_np[r, :, 1] = (blk * blk).sum(0)
+                stats = t(st_np, dev)
+                st = engine._stream(y)
+                res = {}
+                for which in ("general", "slab"):
+                    coef = torch.full((4, C), float("nan"), dtype=torch.float32, device=y.device)
+                    rm, rv = torch.full((C,), 0.25, dtype=torch.float32, device=y.device), torch.full((C,), 1.5, dtype=torch.float32, device=y.device)
+                    z = torch.full((pixels, C), float("nan"), dtype=tdt, device=y.device)
+                    if which == "slab":
+                        engine._chk(lib.rd_bn_finalize_apply(engine._p(stats), rows, engine._p(y), engine._p(gamma), engine._p(beta), eps, mom, engine._p(rm), engine._p(rv),
+                                                             engine._p(coef[2]), engine._p(coef[3]), engine._p(coef[0]), engine._p(coef[1]), engine._p(z), pixels, C, act, 0.2, dt, st),
+                                    "rd_bn_finalize_apply")
+                    else:
+                        engine._chk(lib.rd_bn_finalize(engine._p(stats), rows, C, float(pixels), engine._p(gamma), engine._p(beta), eps, mom, 1, engine._p(rm), engine._p(rv),
+                                                       engine._p(coef[2]), engine._p(coef[3]), engine._p(coef[0]), engine._p(coef[1]), st), "rd_bn_finalize")
+                        engine._chk(lib.rd_affine_act(engine._p(y), engine._p(coef[0]), engine._p(coef[1]), None, engine._p(z), pixels, C, act, 0.2, dt, st), "rd_affine_act")
+                    res[which] = dict(coef=coef.cpu(), rm=rm.cpu(), rv=rv.cpu(), z=z.float().cpu())
+                tot = st_np.astype(np.float64).sum(0)
+                m = tot[:, 0] / pixels
+                v = np.maximum(tot[:, 1] / pixels - m * m, 0.0)
+                assert np.abs(res["slab"]["coef"][2].double().numpy() - m).max() <= 2e-6 * max(1.0, np.abs(m).max()), "slab mean"
+                assert np.abs(res["slab"]["coef"][3].double().numpy() - 1.0 / np.sqrt(v + eps)).max() <= 2e-6 * (1.0 / np.sqrt(v + eps)).max(), "slab rstd"
+                for k in ("coef", "rm", "rv"):
+                    a_, b_ = res["general"][k], res["slab"][k]
+                    assert bool(torch.isfinite(b_).all()) and float((a_ - b_).abs().max()) <= 2e-6 * max(1.0, float(a_.abs().max())), "bn slab fwd %s pixels=%d C=%d" % (k, pixels, C)
+                a_, b_ = res["general"]["z"], res["slab"]["z"]
+                assert bool(torch.isfinite(b_).all()) and float((a_ - b_).abs().max()) <= tol_o * max(1.0, float(a_.abs().max())), "bn slab fwd z pixels=%d C=%d: %.3e" % (pixels, C, float((a_ - b_).abs().max()))
+                # backward from the general path's coefficients
+                coef = res["general"]["coef"].to(y.device)
+                for acc in (0, 1):
+                    out = {}
+                    for which in ("general", "slab"):
+                        dg, db = torch.full((C,), 2.0, dtype=torch.float32, device=y.device), torch.full((C,), -3.0, dtype=torch.float32, device=y.device)
+                        dy = torch.full((pixels, C), float("nan"), dtype=tdt, device=y.device)
+                        if which == "slab":
+                            engine._chk(lib.rd_bn_act_bwd_slab(engine._p(dz), engine._p(y), engine._p(coef[2]), engine._p(coef[3]), engine._p(coef[0]), engine._p(coef[1]), engine._p(dg),
+                                                               engine._p(db), acc, engine._p(dy), pixels, C, act, 0.2, dt, st), "rd_bn_act_bwd_slab")
+                        else:
+                            prow = lib.rd_bn_bwd_rows(pixels, C)
+                            partial = torch.empty((prow, C, 2), dtype=torch.float32, device=y.device)
+                            coef2 = torch.empty((2, C), dtype=torch.float32, device=y.device)
+                            engine._chk(lib.rd_bn_act_bwd_recompute(engine._p(dz), None, engine._p(y), engine._p(coef[2]), engine._p(coef[3]), engine._p(coef[0]), engine._p(coef[1]),
+                                                                    engine._p(partial), engine._p(coef2), engine._p(dg), engine._p(db), acc, engine._p(dy), None, pixels, C, act, 0.2, dt, st),
+                                        "rd_bn_act_bwd_recompute")
+                        out[which] = (dy.float().cpu(), dg.cpu(), db.cpu())
+                    for (a_, b_), nm in zip(zip(out["general"], out["slab"]), ("dy", "dgamma", "dbeta")):
+                        assert bool(torch.isfinite(b_).all()) and float((a_ - b_).abs().max()) <= tol_g * max(1.0, float(a_.abs().max())), \
+                            "bn slab bwd %s pixels=%d C=%d acc=%d: %.3e of %.3e" % (nm, pixels, C, acc, float((a_ - b_).abs().max()), float(a_.abs().max()))
+        # default routing: wide layers on small maps only
+        engine.set_option("bn_slab", None)
+        assert lib.rd_bn_slab_ok(2592, 1392, engine.RD_BF16) == 1 and lib.rd_bn_slab_ok(2816, 512, engine.RD_BF16) == 1
+        assert lib.rd_bn_slab_ok(10368, 576, engine.RD_BF16) == 0 and lib.rd_bn_slab_ok(2592, 136, engine.RD_BF16) == 0 and lib.rd_bn_slab_ok(41472, 1392, engine.RD_BF16) == 0 and lib.rd_bn_slab_ok(2592, 1390, engine.RD_BF16) == 0
+        engine.set_option("bn_slab", 0)
+        assert lib.rd_bn_slab_ok(2592, 1392, engine.RD_BF16) == 0
+    finally:
+        engine.set_option("bn_slab", None)
+
+
 def bn_head_cases(dev, quick=False):
     """conv -> BatchNorm -> LeakyReLU -> one-channel 3x3 output convolution through the fused decoder-head kernels (rd_bn_head_fwd /
     _bwd_reduce / _bwd_apply: the activated 16-channel tensor and its gradient are recomputed from the raw convolution output, never

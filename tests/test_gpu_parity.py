@@ -760,3 +760,7 @@ def test_autograph_other_shapes_and_eval_take_the_right_path(gpu):
 
 def test_pointwise_gemm_kernel(gpu):
     P.pw_gemm_cases(gpu)
+
+
+def test_bn_one_launch_wide_layers(gpu):
+    P.bn_slab_cases(gpu)
