@@ -1988,7 +1988,7 @@ def pack_batch_case(dev):
     engine.clear_caches()
 
 
-def pw_gemm_cases(dev):
+def pw_gemm_cases(dev, quick=False):
     """rd_conv_pw.hip (pointwise layers on a few thousand pixels): every block shape (K split over 8 / 4 waves, four channel tiles per block),
     pixel counts / channel counts / K lengths that are not whole tiles or chunks, bias + activation, the addend, the BatchNorm statistics
     rows -- through the C ABI (rd_conv_fwd / rd_conv_fwd_add) in fp32 and the 16-bit mode, against a float64 product of the same (rounded)
@@ -2001,6 +2001,8 @@ def pw_gemm_cases(dev):
     lib.rd_conv_fwd_kernel_name.restype = ctypes.c_char_p
     rs = np.random.RandomState(11)
     shapes = [(2, 9, 7, 136, 72), (1, 8, 8, 64, 64), (2, 5, 13, 200, 40), (1, 11, 6, 24, 264), (1, 7, 9, 520, 96)]      # N, H, W, Cin, Cout
+    if quick:      # (the emulator build: three shapes cover ragged M / N / K and the long K axis)
+        shapes = [shapes[0], shapes[3], shapes[4]]
     try:
         engine.set_option("pw_min_m", 0)
         for dt, tdt, tol in ((engine.RD_F32, torch.float32, 1e-5), (engine.RD_BF16, torch.bfloat16, 2.0 ** -8)):

@@ -287,7 +287,7 @@ def test_workspace_bytes_dispatch(emu):
 
 
 def test_pointwise_gemm_kernel(emu):
-    P.pw_gemm_cases(emu)
+    P.pw_gemm_cases(emu, quick=True)
 
 
 def test_bn_one_launch_wide_layers(emu):
