@@ -1129,6 +1129,16 @@ def labels_loss_case(dev, tol=1e-4):
     assert abs(float(loss) - float(ref)) < tol * abs(float(ref))
     (loss * 1.7).backward()
     close(xd.grad, xr.grad, tol, "bce grad")
+    # a batch without a single valid pixel: the reference divides by sum(validity_map) = 0 (RCNet/rcnet_model.py:158-159) -- NaN loss, NaN gradient; same here
+    v0 = torch.zeros_like(vr)
+    x0 = logits.detach().clone().requires_grad_()
+    r0 = O.rcnet_loss(x0, lr, v0, 2.5)
+    r0.backward()
+    xd0 = logits.detach().clone().to(dev).requires_grad_()
+    l0, _ = RCNetModel.compute_loss(model, xd0, ld, v0.to(dev), 2.5)
+    l0.backward()
+    assert bool(torch.isnan(r0)) and bool(torch.isnan(l0.detach().cpu())), "loss without valid pixels"
+    assert bool(torch.isnan(x0.grad).all()) and bool(torch.isnan(xd0.grad.cpu()).all()), "gradient without valid pixels"
 
 
 def scatter_crops_case(dev):
