@@ -144,6 +144,23 @@ def loss_case(dev, tol=1e-4):
             assert abs(a - float(b)) <= tol * max(abs(float(b)), 1e-3), (tag, nm, a, float(b))
         loss.backward()
         close(pred.grad, g["dpred"], 10 * tol, "sml loss dpred " + tag)
+    # empty masks: the reference takes l1_loss over ZERO selected elements (utils/loss.py:56-63) -- a NaN term, a NaN total, and no gradient from that
+    # term (the smoothness gradient still flows): same here, with and without any ground truth
+    for gi_, gs_ in ((gi, np.zeros_like(gs)), (np.zeros_like(gi), np.zeros_like(gs))):
+        pred = t(rand_array("g7.pred", (N, 1, H, W), 20.0, lo=0.05), dev).requires_grad_()
+        loss, info = compute_loss(image=image, output_depth=pred, gt_interp=t(gi_, dev), gt_sparse=t(gs_, dev), loss_func='l1', w_smoothness=0.2,
+                                  sobel_filter_size=7, validity_map_loss_smoothness=torch.ones_like(image), w_lidar_loss=1.5, w_edge=0.0,
+                                  invalid_map_gt=None, w_unsupervised=0.0)
+        loss.backward()
+        pr = t(rand_array("g7.pred", (N, 1, H, W), 20.0, lo=0.05)).requires_grad_()
+        lo, io = OS.compute_loss(image.cpu(), pr, t(gi_), t(gs_), 0.2, 7, torch.ones_like(image).cpu(), 1.5, 0.0, 'l1')
+        lo.backward()
+        assert bool(torch.isnan(lo)) and bool(torch.isnan(loss.detach().cpu())), "total with an empty mask"
+        for k in ('loss_supervised', 'loss_lidar', 'loss_smoothness'):
+            a, b = float(info[k]), float(io[k])
+            assert (np.isnan(a) and np.isnan(b)) or abs(a - b) <= tol * max(abs(b), 1e-3), (k, a, b)
+        assert not bool(torch.isnan(pred.grad).any()) and not bool(torch.isnan(pr.grad).any())
+        close(pred.grad, pr.grad, 10 * tol, "sml loss dpred with an empty mask")
     g = load("g7_outlier")
     gt = rand_array("g7.or", (N, 1, H, W), 40.0, lo=0.0); gt[rand_array("g7.orm", gt.shape, 1.0, lo=0.0) < 0.5] = 0
     assert np.array_equal(OutlierRemoval(3, 1.5).remove_outliers(t(gt, dev)).cpu().numpy(), g["out"])
