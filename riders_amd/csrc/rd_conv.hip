@@ -1148,7 +1148,10 @@ int64_t conv_packed_elems(int rows, int K, int dtype) {
 static void conv_tiles(int M, int Cout, int& bn, int& wm) {
   bn = pick_bn(Cout);
   wm = 4;
-  if (bn >= 32 && cdiv(M, BM) * cdiv(Cout, bn) < 384) {
+  // (round 6: outputs of >= 768 channels halve the pixel tile up to 768 blocks -- the SML's 136 -> 816 expansions and the data gradients of its
+  // 816 -> 136 projections on 10 368 pixels are 567 blocks of 128 x 128 and ran 22.3 / 25.9 us (plain / with statistics) against 17.5 / 19.6 on
+  // 64-pixel tiles; the narrower layers of that stage lose 0.7 us with them: tools/bench_pw.py, profiles/r06_microbench/pw_tiles.txt)
+  if (bn >= 32 && cdiv(M, BM) * cdiv(Cout, bn) < (Cout >= 768 ? 768 : 384)) {
     wm = 2;
     if (bn == 128 && cdiv(M, 64) * cdiv(Cout, bn) < 384) bn = 64;
     // still fewer blocks than CUs (a few hundred rows: RC-Net's FullyConnected layers, the deep encoder stages on 8 x 16 maps): narrower
