@@ -681,8 +681,10 @@ void launch_dwconv_wgrad(const void* x, const void* dy, float* partial, float* d
   if (dw_quad_ok(C, k, s)) {
     const QG g = qgeom(C, 256);
     const int64_t units = (int64_t)N * OH * cdiv(OW, DWR);
-    // blocks along the units: ~1024 blocks in all, >= 4 units per thread, and no more partial rows than the tensors justify
-    int64_t gx = std::min<int64_t>(1024 / g.nchunk, cdiv(units, (int64_t)g.PL * 4));
+    // blocks along the units: ~512 blocks in all, >= 3 units per thread, and no more partial rows than the tensors justify (round 6, swept in
+    // the captured SML step on one box, two alternating rounds: 1024 / 4 -- the values since round 3 -- 12.02 ms, 768 / 3 11.95, 512 / 3 11.89,
+    // 448 / 3 12.00, 256 / 4 12.10: every block ends in the K-row LDS epilogue and writes a partial row the finalize launch re-reads)
+    int64_t gx = std::min<int64_t>(512 / g.nchunk, cdiv(units, (int64_t)g.PL * 3));
     gx = std::min<int64_t>(gx, std::max<int64_t>(64, (int64_t)N * OH * OW / 32));
     gx = std::max<int64_t>(1, std::min<int64_t>(gx, rows));
     const dim3 grid((unsigned)gx, g.nchunk);
