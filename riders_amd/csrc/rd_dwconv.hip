@@ -564,11 +564,13 @@ static QG qgeom(int C, int qmax) {
   }
   return best;
 }
-// units a thread works through: enough blocks to fill the chip (>= ~1024 when the layer has them), at most 8 so the k*k x 4 weight
-// registers are loaded once per several units
+// units a thread works through.  ONE (round 6): rounds 2-5 gave a thread up to 8 (>= ~1024 blocks per launch) so that its k*k x 4 weight registers
+// were loaded once per several units; swept in the captured SML step on one box (two alternating rounds): 1024 blocks / <= 8 units 11.90 ms,
+// 2048 / 8 11.85, 1024 / 4 11.85, 4096 / 4 11.82, one unit per thread 11.80 -- the units of a thread are a serial chain of load round trips,
+// and more blocks hide them better than fewer weight loads pay
 static int dw_upt(int64_t units, const QG& g) {
-  const int64_t u = units * g.nchunk / ((int64_t)g.PL * 1024);
-  return (int)std::max<int64_t>(1, std::min<int64_t>(u, 8));
+  (void)units; (void)g;
+  return 1;
 }
 // units per block of the forward with fused statistics: as dw_upt, but never more than 1024 blocks (= statistics rows) along the units
 static int dw_stats_ppb(int64_t units, const QG& g) {
