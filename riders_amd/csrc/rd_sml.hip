@@ -99,6 +99,7 @@ __global__ __launch_bounds__(SML_SCAN_T) void sml_scale_align_kernel(const float
   else {
     for (int it = 0; it < 50; it++) {
       float m = 0.5f * (a + c);
+      if (m == a || m == c) break;      // a and c are neighbouring floats: the remaining steps would change nothing (same result, ~25 block sums less)
       if (slope(m) < 0.0) a = m; else c = m;
     }
     res = c;
