@@ -1144,16 +1144,18 @@ int64_t conv_packed_elems(int rows, int K, int dtype) {
   return (K % (9 * (dtype == 0 ? 32 : 64)) == 0 || pack_has_tokfrag(rows, K)) ? 2 * n : n;
 }
 
-// tile choice: small-M launches (fewer than ~1.5 blocks per CU with 128-pixel tiles) halve the pixel tile, then the channel tile
+// tile choice: small-M launches (fewer than ~2 blocks per CU with 128-pixel tiles) halve the pixel tile, then the channel tile
 static void conv_tiles(int M, int Cout, int& bn, int& wm) {
   bn = pick_bn(Cout);
   wm = 4;
   // (round 6: outputs of >= 768 channels halve the pixel tile up to 768 blocks -- the SML's 136 -> 816 expansions and the data gradients of its
   // 816 -> 136 projections on 10 368 pixels are 567 blocks of 128 x 128 and ran 22.3 / 25.9 us (plain / with statistics) against 17.5 / 19.6 on
   // 64-pixel tiles; the narrower layers of that stage lose 0.7 us with them: tools/bench_pw.py, profiles/r06_microbench/pw_tiles.txt)
-  if (bn >= 32 && cdiv(M, BM) * cdiv(Cout, bn) < (Cout >= 768 ? 768 : 384)) {
+  // (... and the general limits 384 -> 512 blocks, both of them: swept in the captured steps, three alternating rounds on one box -- SML 11.77 -> 11.68 ms,
+  // RC-Net unchanged at 7.08; 768 for the second one costs RC-Net 0.01 ms)
+  if (bn >= 32 && cdiv(M, BM) * cdiv(Cout, bn) < (Cout >= 768 ? 768 : 512)) {
     wm = 2;
-    if (bn == 128 && cdiv(M, 64) * cdiv(Cout, bn) < 384) bn = 64;
+    if (bn == 128 && cdiv(M, 64) * cdiv(Cout, bn) < 512) bn = 64;
     // still fewer blocks than CUs (a few hundred rows: RC-Net's FullyConnected layers, the deep encoder stages on 8 x 16 maps): narrower
     // channel tiles.  Such a launch is a chain of stages whose length is the MFMA work of ONE block per stage (measured: 1.1 us per fp32
     // stage at 64 channels whatever the prefetch depth), so spreading the channels over more CUs shortens every stage.
